@@ -1,0 +1,110 @@
+"""ctypes binding of libdm4d_hip.so (C ABI: include/dm4d.h).
+
+The product path has NO fallback: if the HIP library is missing or fails to load,
+importing an operator raises.  (The CPU restatements under oracle/ are test
+infrastructure and are never imported from here.)
+"""
+import ctypes as C
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+SO_PATH = os.path.join(_HERE, "libdm4d_hip.so")
+_LIB = None
+
+OK = 0
+c_f = C.POINTER(C.c_float)
+c_i32 = C.POINTER(C.c_int32)
+c_u32 = C.POINTER(C.c_uint32)
+c_u64 = C.POINTER(C.c_uint64)
+c_u8 = C.POINTER(C.c_uint8)
+vp = C.c_void_p
+
+
+class Dm4dError(RuntimeError):
+    pass
+
+
+class RasterSettings(C.Structure):
+    _fields_ = [
+        ("image_height", C.c_int32), ("image_width", C.c_int32), ("tanfovx", C.c_float), ("tanfovy", C.c_float),
+        ("scale_modifier", C.c_float), ("sh_degree", C.c_int32), ("prefiltered", C.c_int32), ("debug", C.c_int32),
+        ("bg", vp), ("viewmatrix", vp), ("projmatrix", vp), ("campos", vp),
+    ]
+
+
+class RasterInputs(C.Structure):
+    _fields_ = [
+        ("N", C.c_int32), ("sh_coeffs", C.c_int32), ("means3D", vp), ("shs", vp), ("colors_precomp", vp),
+        ("opacities", vp), ("scales", vp), ("rotations", vp), ("cov3D_precomp", vp),
+    ]
+
+
+ALLOC_FN = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_int, C.c_size_t)
+
+_SIGNATURES = {
+    "dm4d_version": (C.c_int, []),
+    "dm4d_last_error": (C.c_char_p, []),
+    "dm4d_device_count": (C.c_int, []),
+    "dm4d_device_arch": (C.c_int, [C.c_int, C.c_char_p, C.c_int]),
+    "dm4d_raster_geom_bytes": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32]),
+    "dm4d_raster_binning_bytes": (C.c_size_t, [C.c_int64]),
+    "dm4d_raster_image_bytes": (C.c_size_t, [C.c_int32, C.c_int32]),
+    "dm4d_raster_grad_bytes": (C.c_size_t, [C.c_int64]),
+    "dm4d_rasterize_prepare": (C.c_int, [C.POINTER(RasterSettings), C.POINTER(RasterInputs), vp, vp, C.c_size_t, vp]),
+    "dm4d_rasterize_num_rendered": (C.c_int64, [vp, vp]),
+    "dm4d_rasterize_render": (C.c_int, [C.POINTER(RasterSettings), C.POINTER(RasterInputs), vp, vp, vp, C.c_int64,
+                                        vp, vp, vp, vp, vp]),
+    "dm4d_rasterize_overflowed": (C.c_int, [vp, vp]),
+    "dm4d_rasterize_backward": (C.c_int, [C.POINTER(RasterSettings), C.POINTER(RasterInputs), vp, vp, vp, C.c_int64,
+                                          vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
+    "dm4d_rasterize_forward": (C.c_int64, [C.POINTER(RasterSettings), C.POINTER(RasterInputs), vp, vp, vp, vp,
+                                           ALLOC_FN, vp, vp]),
+    "dm4d_raster_read_sorted": (C.c_int, [vp, vp, C.c_int32, C.c_int32, C.c_int32, C.c_int64, c_u64, c_u32, c_u32, vp]),
+    "dm4d_raster_read_geom": (C.c_int, [vp, C.c_int32, C.c_int32, C.c_int32, c_f, c_f, c_f, c_u32, vp]),
+    "dm4d_raster_read_image_state": (C.c_int, [vp, C.c_int32, C.c_int32, c_u32, c_f, vp]),
+    "dm4d_mark_visible": (C.c_int, [C.c_int32, vp, vp, vp, vp]),
+}
+
+
+def declared_symbols():
+    """Every function include/dm4d.h declares (parsed from the header, not from this table)."""
+    import re
+
+    hdr = os.path.join(os.path.dirname(_HERE), "include", "dm4d.h")
+    text = open(hdr).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(dm4d_[a-z0-9_]+)\s*\(", text)) - {"dm4d_alloc_fn"})
+
+
+def build(force: bool = False) -> str:
+    """Compile libdm4d_hip.so for gfx950 with hipcc (cross-compiles without a GPU)."""
+    csrc = os.path.join(_HERE, "csrc")
+    cmd = ["make", "-s", "-C", csrc, "-j8"]
+    if force:
+        cmd.append("-B")
+    subprocess.check_call(cmd)
+    return SO_PATH
+
+
+def lib() -> C.CDLL:
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(SO_PATH):
+            raise ImportError(
+                f"{SO_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc --offload-arch=gfx950).  dreammesh4d_amd has no CPU fallback.")
+        L = C.CDLL(SO_PATH)
+        for name, (res, args) in _SIGNATURES.items():
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        _LIB = L
+    return _LIB
+
+
+def check(rc, what=""):
+    if rc is not None and rc < 0:
+        msg = lib().dm4d_last_error()
+        raise Dm4dError(f"{what} failed ({rc}): {msg.decode() if msg else ''}")
+    return rc

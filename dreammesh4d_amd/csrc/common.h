@@ -1,0 +1,106 @@
+// common.h -- device helpers shared by the gfx950 kernels of libdm4d_hip.so.
+// Compiled with -ffp-contract=off: FMAs appear only where __builtin_fmaf is written
+// (the "arithmetic contract" of DESIGN.md that makes tile keys, radii, n_contrib and the
+// forward image bit-comparable with the CPU checker).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define DM4D_WAVE 64
+
+#define DM4D_HIP_CHECK(expr)                                                         \
+    do {                                                                             \
+        hipError_t _e = (expr);                                                      \
+        if (_e != hipSuccess) {                                                      \
+            dm4d::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e),   \
+                            __FILE__, __LINE__);                                     \
+            return DM4D_ERR_HIP;                                                     \
+        }                                                                            \
+    } while (0)
+
+namespace dm4d {
+
+void set_error(const char *fmt, ...);
+
+__device__ __forceinline__ float as_f(uint32_t u) { return __uint_as_float(u); }
+__device__ __forceinline__ uint32_t as_u(float f) { return __float_as_uint(f); }
+
+// exp(x) for x <= 0, deterministic (only IEEE fma/mul/rint/ldexp): 2^f minimax degree 6
+// on [-0.5, 0.5], <= 1.4 ulp.  Costs about what an accurate library expf costs.
+__device__ __forceinline__ float det_expf(float x)
+{
+    const float L2E_HI = 0x1.715476p+0f;
+    const float L2E_LO = 0x1.4ae0c0p-26f;
+    x = fmaxf(x, -87.0f);
+    float t = x * L2E_HI;
+    float n = __builtin_rintf(t);
+    float f = __builtin_fmaf(x, L2E_HI, -n);
+    f = __builtin_fmaf(x, L2E_LO, f);
+    float p = 0x1.446c7ep-13f;
+    p = __builtin_fmaf(p, f, 0x1.5f48c8p-10f);
+    p = __builtin_fmaf(p, f, 0x1.3b29d8p-7f);
+    p = __builtin_fmaf(p, f, 0x1.c6aeccp-5f);
+    p = __builtin_fmaf(p, f, 0x1.ebfbe0p-3f);
+    p = __builtin_fmaf(p, f, 0x1.62e430p-1f);
+    p = __builtin_fmaf(p, f, 1.0f);
+    return __builtin_ldexpf(p, (int)n);
+}
+
+__device__ __forceinline__ int f2i_sat(float v)
+{
+    if (!(v > -1073741824.0f)) return -1073741824;
+    if (v > 1073741824.0f) return 1073741824;
+    return (int)v;
+}
+
+// ---- wave64 cross-lane helpers (DPP; gfx9 row_bcast forms) -------------------------------
+template <int CTRL, int ROW_MASK = 0xF>
+__device__ __forceinline__ float dpp_add(float v)
+{
+    int r = __builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xF, false);
+    return v + __int_as_float(r);
+}
+// Sum over the 64 lanes; the total is valid in lanes 48..63 (row 3).
+__device__ __forceinline__ float wave_sum_row3(float v)
+{
+    v = dpp_add<0xB1>(v);        // quad_perm [1,0,3,2]
+    v = dpp_add<0x4E>(v);        // quad_perm [2,3,0,1]
+    v = dpp_add<0x141>(v);       // row_half_mirror
+    v = dpp_add<0x140>(v);       // row_mirror  -> every lane holds its row's sum
+    v = dpp_add<0x142, 0xA>(v);  // row_bcast15 into rows 1,3
+    v = dpp_add<0x143, 0xC>(v);  // row_bcast31 into rows 2,3
+    return v;
+}
+__device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        uint32_t w = __shfl_xor(v, o, 64);
+        v = v > w ? v : w;
+    }
+    return v;
+}
+// inclusive prefix sum across the wave
+__device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v, int lane)
+{
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        uint32_t w = __shfl_up(v, o, 64);
+        if (lane >= o) v += w;
+    }
+    return v;
+}
+__device__ __forceinline__ int lane_id() { return (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
+// number of set bits of `mask` below this lane
+__device__ __forceinline__ uint32_t mbcnt(uint64_t mask)
+{
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+}
+
+}  // namespace dm4d

@@ -1,0 +1,180 @@
+// raster.h -- workspace layout and kernel launchers of the tile rasterizer.
+//
+// Pipeline (one view), all on the caller's stream, no host sync inside:
+//   K1 preprocess      1 thread / Gaussian   cull, cov3D, EWA cov2D, conic, radius, rect,
+//                                            per-block duplicate sums, per-tile histogram
+//   K2 scan            1 workgroup           block offsets, D, tile segment starts
+//   K3 scatter         1 thread / Gaussian   duplicates -> per-tile segments (unordered)
+//   K4 tile_sort       1 workgroup / tile    LDS bitonic sort by (depth bits, id)
+//   K5 render_fwd      1 workgroup / tile    4 waves = 4 8x8 quadrants, LDS-staged lists
+//   B1 render_bwd      1 workgroup / tile    per-duplicate partial grads, no atomics
+//   B2 gather_bwd      1 thread / Gaussian   deterministic gather + preprocess backward
+#pragma once
+#include <stddef.h>
+#include <stdint.h>
+
+#include "../../include/dm4d.h"
+
+namespace dm4d {
+
+constexpr int kTile = DM4D_TILE;
+constexpr int kPreBlock = 256;   // Gaussians per workgroup in K1/K3/B2
+constexpr int kGradStride = 12;  // floats per duplicate in the backward scratch (10 used)
+
+enum GeomCounter { kCntD = 0, kCntOverflow = 1 };
+
+static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+struct GeomLayout {
+    int N, T, nb;
+    size_t counters, xy, depth, conic_opacity, rgb, tiles_touched, offsets, clamped, block_sums, block_offsets,
+        tile_count, tile_start, tile_cursor, tile_written, zero_begin, zero_bytes, total;
+};
+
+static inline GeomLayout geom_layout(int N, int H, int W)
+{
+    GeomLayout L;
+    L.N = N;
+    int gx = (W + kTile - 1) / kTile, gy = (H + kTile - 1) / kTile;
+    L.T = gx * gy;
+    L.nb = (N + kPreBlock - 1) / kPreBlock;
+    size_t o = 0;
+    auto take = [&](size_t bytes) { size_t r = o; o = align_up(o + bytes, 256); return r; };
+    size_t n = (size_t)(N > 0 ? N : 1);
+    // counters (offset 0) .. tile_written are cleared by ONE memset node before K1
+    L.counters = take(64 * 4);
+    L.tile_count = take((size_t)L.T * 4);
+    L.tile_start = take((size_t)(L.T + 1) * 4);
+    L.tile_cursor = take((size_t)L.T * 4);
+    L.tile_written = take((size_t)L.T * 4);
+    L.zero_begin = 0;
+    L.zero_bytes = o;
+    L.xy = take(n * 8);
+    L.depth = take(n * 4);
+    L.conic_opacity = take(n * 16);
+    L.rgb = take(n * 12);
+    L.tiles_touched = take(n * 4);
+    L.offsets = take(n * 4);
+    L.clamped = take(n * 3);
+    L.block_sums = take((size_t)(L.nb + 1) * 4);
+    L.block_offsets = take((size_t)(L.nb + 1) * 4);
+    L.total = o;
+    return L;
+}
+
+struct GeomPtrs {
+    uint32_t *counters;
+    float2 *xy;
+    float *depth;
+    float4 *conic_opacity;
+    float *rgb;
+    uint32_t *tiles_touched;
+    uint32_t *offsets;
+    uint8_t *clamped;
+    uint32_t *block_sums;
+    uint32_t *block_offsets;
+    uint32_t *tile_count;
+    uint32_t *tile_start;
+    uint32_t *tile_cursor;
+    uint32_t *tile_written;
+};
+
+static inline GeomPtrs geom_ptrs(void *base, const GeomLayout &L)
+{
+    char *b = (char *)base;
+    GeomPtrs p;
+    p.counters = (uint32_t *)(b + L.counters);
+    p.xy = (float2 *)(b + L.xy);
+    p.depth = (float *)(b + L.depth);
+    p.conic_opacity = (float4 *)(b + L.conic_opacity);
+    p.rgb = (float *)(b + L.rgb);
+    p.tiles_touched = (uint32_t *)(b + L.tiles_touched);
+    p.offsets = (uint32_t *)(b + L.offsets);
+    p.clamped = (uint8_t *)(b + L.clamped);
+    p.block_sums = (uint32_t *)(b + L.block_sums);
+    p.block_offsets = (uint32_t *)(b + L.block_offsets);
+    p.tile_count = (uint32_t *)(b + L.tile_count);
+    p.tile_start = (uint32_t *)(b + L.tile_start);
+    p.tile_cursor = (uint32_t *)(b + L.tile_cursor);
+    p.tile_written = (uint32_t *)(b + L.tile_written);
+    return p;
+}
+
+struct BinPtrs {
+    uint32_t *u_depth;    // unsorted duplicates, tile-major segments
+    uint32_t *u_idx;
+    uint32_t *u_p;        // Gaussian-major duplicate index (offsets[g] + i)
+    uint32_t *point_list; // sorted Gaussian ids  (== upstream point_list)
+    uint32_t *sorted_pos; // Gaussian-major duplicate index -> position in point_list
+};
+static inline size_t binning_bytes(int64_t cap)
+{
+    size_t c = (size_t)(cap > 0 ? cap : 1);
+    return 5 * align_up(c * 4, 256);
+}
+static inline BinPtrs bin_ptrs(void *base, int64_t cap)
+{
+    size_t c = (size_t)(cap > 0 ? cap : 1);
+    size_t stride = align_up(c * 4, 256);
+    char *b = (char *)base;
+    BinPtrs p;
+    p.u_depth = (uint32_t *)(b);
+    p.u_idx = (uint32_t *)(b + stride);
+    p.u_p = (uint32_t *)(b + 2 * stride);
+    p.point_list = (uint32_t *)(b + 3 * stride);
+    p.sorted_pos = (uint32_t *)(b + 4 * stride);
+    return p;
+}
+
+struct ImgPtrs {
+    float *final_T;
+    uint32_t *n_contrib;
+};
+static inline size_t image_bytes(int H, int W)
+{
+    size_t P = (size_t)H * W;
+    return 2 * align_up((P > 0 ? P : 1) * 4, 256);
+}
+static inline ImgPtrs img_ptrs(void *base, int H, int W)
+{
+    size_t P = (size_t)H * W;
+    size_t stride = align_up((P > 0 ? P : 1) * 4, 256);
+    ImgPtrs p;
+    p.final_T = (float *)base;
+    p.n_contrib = (uint32_t *)((char *)base + stride);
+    return p;
+}
+static inline size_t grad_bytes(int64_t cap)
+{
+    size_t c = (size_t)(cap > 0 ? cap : 1);
+    return align_up(c * kGradStride * 4, 256);
+}
+
+// Camera / image constants handed to kernels by value.
+struct ViewParams {
+    int W, H, gx, gy;
+    float tanfovx, tanfovy, focal_x, focal_y, scale_modifier;
+    const float *bg, *view, *proj, *campos;
+};
+
+// ---- launchers (defined in the .hip files) ---------------------------------------------
+int launch_preprocess(const ViewParams &vp, const dm4d_raster_inputs &in, int32_t *radii, const GeomPtrs &g,
+                      hipStream_t st);
+int launch_scan(int N, int T, const GeomPtrs &g, hipStream_t st);
+int launch_scatter(const ViewParams &vp, int N, const int32_t *radii, const GeomPtrs &g, const BinPtrs &b,
+                   int64_t cap, hipStream_t st);
+int launch_tile_sort(int T, const GeomPtrs &g, const BinPtrs &b, int64_t cap, hipStream_t st);
+int launch_render_fwd(const ViewParams &vp, const float *colors /* [N,3] */, const GeomPtrs &g, const BinPtrs &b,
+                      int64_t cap, const ImgPtrs &im, float *out_color, float *out_depth, float *out_alpha,
+                      hipStream_t st);
+int launch_render_bwd(const ViewParams &vp, const float *colors, const GeomPtrs &g, const BinPtrs &b, int64_t cap,
+                      const ImgPtrs &im, const float *dL_dcolor, const float *dL_ddepth, const float *dL_dalpha,
+                      float *dLt, hipStream_t st);
+struct BwdOutputs {
+    float *dL_dmeans2D, *dL_dmeans3D, *dL_dopacity, *dL_dcolors, *dL_dsh, *dL_dscales, *dL_drotations, *dL_dcov3D;
+};
+int launch_gather_bwd(const ViewParams &vp, const dm4d_raster_inputs &in, const int32_t *radii, const GeomPtrs &g,
+                      const BinPtrs &b, int64_t cap, const float *dLt, const BwdOutputs &o, hipStream_t st);
+int launch_mark_visible(int N, const float *means3D, const float *view, uint8_t *present, hipStream_t st);
+
+}  // namespace dm4d

@@ -1,0 +1,163 @@
+// raster_bin.hip -- binning kernels of the tile rasterizer (gfx950).
+//
+//   K2 k_scan       : one workgroup; exclusive scans of the per-workgroup duplicate sums
+//                     (-> Gaussian-major offsets, D) and of the per-tile histogram
+//                     (-> tile segment starts == upstream's `ranges`).
+//   K4 k_tile_sort  : one workgroup per tile; sorts the tile's duplicates by the 64-bit key
+//                     (depth bits << 32 | Gaussian id) in LDS with a bitonic network.
+//
+// Why not upstream's global radix sort (cub::DeviceRadixSort over tile<<32|depth, 6 passes of
+// 24 B/duplicate): duplicates are already partitioned by tile after K3, a tile's list is a few
+// hundred entries and MI355X has 160 KB of LDS per CU, so each duplicate is read once (12 B) and
+// written once (8 B).  Because (tile, depth bits, id) is a total order, the result is exactly
+// the order a stable radix sort of tile<<32|depth produces from the Gaussian-major duplicate
+// list -- the parity tests compare the (key, value) list bit-for-bit.
+#include "common.h"
+#include "raster.h"
+
+namespace dm4d {
+
+constexpr int kScanThreads = 1024;
+
+// exclusive scan of in[0..n) into out[0..n), out[n] = total (if write_total). One workgroup.
+__device__ uint32_t block_exclusive_scan(const uint32_t *__restrict__ in, uint32_t *__restrict__ out, int n,
+                                         uint32_t *s_wave /* [16] */, uint32_t *s_carry)
+{
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    if (tid == 0) *s_carry = 0;
+    __syncthreads();
+    for (int base = 0; base < n; base += kScanThreads) {
+        const int i = base + tid;
+        const uint32_t v = (i < n) ? in[i] : 0u;
+        const uint32_t incl = wave_incl_scan_u32(v, lane);
+        if (lane == 63) s_wave[wv] = incl;
+        __syncthreads();
+        uint32_t pre = *s_carry;
+        for (int w = 0; w < wv; ++w) pre += s_wave[w];
+        if (i < n) out[i] = pre + incl - v;
+        __syncthreads();
+        if (tid == kScanThreads - 1) *s_carry = pre + incl;
+        __syncthreads();
+    }
+    return *s_carry;
+}
+
+__global__ __launch_bounds__(kScanThreads) void k_scan(int nb, int T, GeomPtrs g)
+{
+    __shared__ uint32_t s_wave[kScanThreads / 64];
+    __shared__ uint32_t s_carry;
+    const uint32_t D = block_exclusive_scan(g.block_sums, g.block_offsets, nb, s_wave, &s_carry);
+    if (threadIdx.x == 0) g.counters[kCntD] = D;
+    __syncthreads();
+    const uint32_t D2 = block_exclusive_scan(g.tile_count, g.tile_start, T, s_wave, &s_carry);
+    if (threadIdx.x == 0) g.tile_start[T] = D2;
+}
+
+// ---------------------------------------------------------------------------------------- K4
+constexpr int kSortThreads = 256;
+constexpr int kSortLdsCap = 4096;   // duplicates per tile sorted in LDS (48 KB); more -> global path
+
+__device__ __forceinline__ uint32_t next_pow2(uint32_t v)
+{
+    v--;
+    v |= v >> 1; v |= v >> 2; v |= v >> 4; v |= v >> 8; v |= v >> 16;
+    return v + 1;
+}
+
+// Ascending bitonic network for arbitrary n ("flip" formulation): positions >= n behave as
+// +inf and never move, so compare-exchanges touching them are skipped.
+template <typename Swap>
+__device__ __forceinline__ void bitonic_network(uint32_t n, Swap &&cmpswap)
+{
+    const uint32_t np2 = next_pow2(n);
+    const uint32_t half_pairs = np2 >> 1;
+    for (uint32_t k = 2; k <= np2; k <<= 1) {
+        // flip step
+        {
+            const uint32_t h = k >> 1;
+            for (uint32_t t = threadIdx.x; t < half_pairs; t += kSortThreads) {
+                const uint32_t i = ((t / h) * k) + (t % h);
+                const uint32_t l = i ^ (k - 1);
+                if (l < n) cmpswap(i, l);
+            }
+            __syncthreads();
+        }
+        for (uint32_t j = k >> 2; j >= 1; j >>= 1) {
+            for (uint32_t t = threadIdx.x; t < half_pairs; t += kSortThreads) {
+                const uint32_t i = ((t / j) * (j << 1)) + (t % j);
+                const uint32_t l = i + j;
+                if (l < n) cmpswap(i, l);
+            }
+            __syncthreads();
+        }
+    }
+}
+
+__global__ __launch_bounds__(kSortThreads) void k_tile_sort(GeomPtrs g, BinPtrs b, uint32_t cap)
+{
+    __shared__ uint64_t s_key[kSortLdsCap];
+    __shared__ uint32_t s_p[kSortLdsCap];
+    const int t = blockIdx.x;
+    const uint32_t s = g.tile_start[t];
+    uint32_t n = g.tile_count[t];
+    if (s >= cap) return;
+    if (s + n > cap) n = cap - s;   // overflow: memory-safe, result flagged invalid by K3
+    if (n == 0) return;
+    const int tid = threadIdx.x;
+    if (n <= (uint32_t)kSortLdsCap) {
+        for (uint32_t e = tid; e < n; e += kSortThreads) {
+            s_key[e] = ((uint64_t)b.u_depth[s + e] << 32) | b.u_idx[s + e];
+            s_p[e] = b.u_p[s + e];
+        }
+        __syncthreads();
+        if (n > 1) {
+            bitonic_network(n, [&](uint32_t i, uint32_t l) {
+                const uint64_t ki = s_key[i], kl = s_key[l];
+                if (kl < ki) {
+                    s_key[i] = kl; s_key[l] = ki;
+                    const uint32_t pi = s_p[i]; s_p[i] = s_p[l]; s_p[l] = pi;
+                }
+            });
+        }
+        for (uint32_t e = tid; e < n; e += kSortThreads) {
+            b.point_list[s + e] = (uint32_t)s_key[e];
+            const uint32_t p = s_p[e];
+            if (p < cap) b.sorted_pos[p] = s + e;
+        }
+    } else {
+        // Oversized tile: same network on the HBM-resident segment (one workgroup; rare).
+        uint32_t *kd = b.u_depth + s, *ki_ = b.u_idx + s, *kp = b.u_p + s;
+        bitonic_network(n, [&](uint32_t i, uint32_t l) {
+            const uint64_t a = ((uint64_t)kd[i] << 32) | ki_[i], c = ((uint64_t)kd[l] << 32) | ki_[l];
+            if (c < a) {
+                uint32_t x;
+                x = kd[i]; kd[i] = kd[l]; kd[l] = x;
+                x = ki_[i]; ki_[i] = ki_[l]; ki_[l] = x;
+                x = kp[i]; kp[i] = kp[l]; kp[l] = x;
+            }
+        });
+        for (uint32_t e = tid; e < n; e += kSortThreads) {
+            b.point_list[s + e] = ki_[e];
+            const uint32_t p = kp[e];
+            if (p < cap) b.sorted_pos[p] = s + e;
+        }
+    }
+}
+
+int launch_scan(int N, int T, const GeomPtrs &g, hipStream_t st)
+{
+    const int nb = (N + kPreBlock - 1) / kPreBlock;
+    hipLaunchKernelGGL(k_scan, dim3(1), dim3(kScanThreads), 0, st, nb, T, g);
+    DM4D_HIP_CHECK(hipGetLastError());
+    return DM4D_OK;
+}
+
+int launch_tile_sort(int T, const GeomPtrs &g, const BinPtrs &b, int64_t cap, hipStream_t st)
+{
+    if (T <= 0) return DM4D_OK;
+    hipLaunchKernelGGL(k_tile_sort, dim3(T), dim3(kSortThreads), 0, st, g, b, (uint32_t)cap);
+    DM4D_HIP_CHECK(hipGetLastError());
+    return DM4D_OK;
+}
+
+}  // namespace dm4d

@@ -1,0 +1,483 @@
+// raster_preprocess.hip -- per-Gaussian kernels of the tile rasterizer (gfx950).
+//
+//   K1 k_preprocess   : frustum cull, cov3D(scale,quat), EWA cov2D + 0.3 low-pass, conic,
+//                       radius = ceil(3 sqrt(lambda_max)), pixel centre, tile rect, colour;
+//                       per-workgroup duplicate sum and per-tile duplicate histogram.
+//   K3 k_scatter      : duplicates -> per-tile segments (slot = tile_start + cursor++).
+//   B2 k_gather_bwd   : deterministic gather of the per-duplicate partial gradients written
+//                       by render_bwd, then the whole preprocess backward in registers
+//                       (conic -> cov2D -> cov3D/mean -> scale/rotation; NDC and depth -> mean).
+//
+// Replaces preprocessCUDA / duplicateWithKeys / computeCov2DCUDA-bwd / preprocessCUDA-bwd of
+// the un-vendored diff-gaussian-rasterization package used at
+// custom/threestudio-dreammesh4d/renderer/diff_sugar_rasterizer_temporal.py:169-178,202-211.
+//
+// All HBM traffic is SoA and coalesced: a wave reads 64 consecutive Gaussians.  Arithmetic
+// follows the contract of DESIGN.md (no FMA contraction) so radii / depth bits / tile rects
+// compare bit-for-bit with the CPU checker.
+#include "common.h"
+#include "raster.h"
+
+namespace dm4d {
+
+struct f3 { float x, y, z; };
+
+__device__ __forceinline__ f3 xform4x3(const f3 p, const float *M)
+{
+    f3 o;
+    o.x = ((M[0] * p.x + M[4] * p.y) + M[8] * p.z) + M[12];
+    o.y = ((M[1] * p.x + M[5] * p.y) + M[9] * p.z) + M[13];
+    o.z = ((M[2] * p.x + M[6] * p.y) + M[10] * p.z) + M[14];
+    return o;
+}
+__device__ __forceinline__ float4 xform4x4(const f3 p, const float *M)
+{
+    float4 o;
+    o.x = ((M[0] * p.x + M[4] * p.y) + M[8] * p.z) + M[12];
+    o.y = ((M[1] * p.x + M[5] * p.y) + M[9] * p.z) + M[13];
+    o.z = ((M[2] * p.x + M[6] * p.y) + M[10] * p.z) + M[14];
+    o.w = ((M[3] * p.x + M[7] * p.y) + M[11] * p.z) + M[15];
+    return o;
+}
+
+__device__ __forceinline__ void quat_to_R(const float4 q /* w,x,y,z */, float R[9])
+{
+    float r = q.x, x = q.y, y = q.z, z = q.w;
+    R[0] = 1.f - 2.f * (y * y + z * z);
+    R[1] = 2.f * (x * y - r * z);
+    R[2] = 2.f * (x * z + r * y);
+    R[3] = 2.f * (x * y + r * z);
+    R[4] = 1.f - 2.f * (x * x + z * z);
+    R[5] = 2.f * (y * z - r * x);
+    R[6] = 2.f * (x * z - r * y);
+    R[7] = 2.f * (y * z + r * x);
+    R[8] = 1.f - 2.f * (x * x + y * y);
+}
+
+// Sigma = (R S)(R S)^T, upper triangle
+__device__ __forceinline__ void cov3d_from_scale_rot(const f3 scale, float mod, const float4 q, float cov6[6])
+{
+    float R[9], M[9];
+    quat_to_R(q, R);
+    float s[3] = {mod * scale.x, mod * scale.y, mod * scale.z};
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) M[a * 3 + j] = R[a * 3 + j] * s[j];
+#define DM4D_SIG(a, b) ((M[a * 3 + 0] * M[b * 3 + 0] + M[a * 3 + 1] * M[b * 3 + 1]) + M[a * 3 + 2] * M[b * 3 + 2])
+    cov6[0] = DM4D_SIG(0, 0);
+    cov6[1] = DM4D_SIG(0, 1);
+    cov6[2] = DM4D_SIG(0, 2);
+    cov6[3] = DM4D_SIG(1, 1);
+    cov6[4] = DM4D_SIG(1, 2);
+    cov6[5] = DM4D_SIG(2, 2);
+#undef DM4D_SIG
+}
+
+struct Cov2DAux {
+    float T0[3], T1[3];
+    float tz, tcx, tcy;
+    bool xclamped, yclamped;
+};
+
+// cov2D = (J W) Sigma (J W)^T (without the low-pass); c = (c00, c01, c11)
+__device__ __forceinline__ void cov2d(const f3 mean, const ViewParams &vp, const float *V, const float cov6[6],
+                                      float c[3], Cov2DAux *aux)
+{
+    f3 t = xform4x3(mean, V);
+    float limx = 1.3f * vp.tanfovx, limy = 1.3f * vp.tanfovy;
+    float txtz = t.x / t.z, tytz = t.y / t.z;
+    float cx = fminf(limx, fmaxf(-limx, txtz));
+    float cy = fminf(limy, fmaxf(-limy, tytz));
+    float tcx = cx * t.z, tcy = cy * t.z;
+    float J00 = vp.focal_x / t.z;
+    float J02 = -(vp.focal_x * tcx) / (t.z * t.z);
+    float J11 = vp.focal_y / t.z;
+    float J12 = -(vp.focal_y * tcy) / (t.z * t.z);
+    float T0[3], T1[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        T0[j] = J00 * V[j * 4 + 0] + J02 * V[j * 4 + 2];
+        T1[j] = J11 * V[j * 4 + 1] + J12 * V[j * 4 + 2];
+    }
+    const float S[9] = {cov6[0], cov6[1], cov6[2], cov6[1], cov6[3], cov6[4], cov6[2], cov6[4], cov6[5]};
+    float v0[3], v1[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        v0[j] = (T0[0] * S[0 * 3 + j] + T0[1] * S[1 * 3 + j]) + T0[2] * S[2 * 3 + j];
+        v1[j] = (T1[0] * S[0 * 3 + j] + T1[1] * S[1 * 3 + j]) + T1[2] * S[2 * 3 + j];
+    }
+    c[0] = (v0[0] * T0[0] + v0[1] * T0[1]) + v0[2] * T0[2];
+    c[1] = (v0[0] * T1[0] + v0[1] * T1[1]) + v0[2] * T1[2];
+    c[2] = (v1[0] * T1[0] + v1[1] * T1[1]) + v1[2] * T1[2];
+    if (aux) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j) { aux->T0[j] = T0[j]; aux->T1[j] = T1[j]; }
+        aux->tz = t.z;
+        aux->tcx = tcx;
+        aux->tcy = tcy;
+        aux->xclamped = (txtz < -limx || txtz > limx);
+        aux->yclamped = (tytz < -limy || tytz > limy);
+    }
+}
+
+struct Rect { int x0, y0, x1, y1; };
+__device__ __forceinline__ Rect tile_rect(float px, float py, int r, int gx, int gy)
+{
+    float fr = (float)r;
+    Rect q;
+    q.x0 = min(gx, max(0, f2i_sat((px - fr) / (float)kTile)));
+    q.y0 = min(gy, max(0, f2i_sat((py - fr) / (float)kTile)));
+    q.x1 = min(gx, max(0, f2i_sat((px + fr + (float)(kTile - 1)) / (float)kTile)));
+    q.y1 = min(gy, max(0, f2i_sat((py + fr + (float)(kTile - 1)) / (float)kTile)));
+    return q;
+}
+
+#define DM4D_SH_C0 0.28209479177387814f
+
+__device__ __forceinline__ f3 load3(const float *p, int i) { return f3{p[3 * i], p[3 * i + 1], p[3 * i + 2]}; }
+
+// ---------------------------------------------------------------------------------------- K1
+__global__ __launch_bounds__(kPreBlock) void k_preprocess(ViewParams vp, dm4d_raster_inputs in,
+                                                          int32_t *__restrict__ radii, GeomPtrs g)
+{
+    __shared__ float sV[16], sP[16];
+    __shared__ uint32_t s_wsum[kPreBlock / 64];
+    const int tid = threadIdx.x;
+    if (tid < 16) { sV[tid] = vp.view[tid]; sP[tid] = vp.proj[tid]; }
+    __syncthreads();
+    const int i = blockIdx.x * kPreBlock + tid;
+    uint32_t touched = 0;
+    if (i < in.N) {
+        int my_radius = 0;
+        const f3 p = load3(in.means3D, i);
+        const f3 pv = xform4x3(p, sV);
+        if (pv.z > 0.2f) {
+            const float4 ph = xform4x4(p, sP);
+            const float pw = 1.0f / (ph.w + 0.0000001f);
+            const float ppx = ph.x * pw, ppy = ph.y * pw;
+            float cov6[6];
+            if (in.cov3D_precomp) {
+#pragma unroll
+                for (int k = 0; k < 6; ++k) cov6[k] = in.cov3D_precomp[6 * (size_t)i + k];
+            } else {
+                const float4 q = reinterpret_cast<const float4 *>(in.rotations)[i];
+                cov3d_from_scale_rot(load3(in.scales, i), vp.scale_modifier, q, cov6);
+            }
+            float c[3];
+            cov2d(p, vp, sV, cov6, c, nullptr);
+            c[0] += 0.3f;
+            c[2] += 0.3f;
+            const float det = c[0] * c[2] - c[1] * c[1];
+            if (det != 0.0f) {
+                const float det_inv = 1.f / det;
+                const float mid = 0.5f * (c[0] + c[2]);
+                const float disc = sqrtf(fmaxf(0.1f, mid * mid - det));
+                const float lambda1 = mid + disc, lambda2 = mid - disc;
+                const int r = f2i_sat(ceilf(3.f * sqrtf(fmaxf(lambda1, lambda2))));
+                const float px = ((ppx + 1.0f) * (float)vp.W - 1.0f) * 0.5f;
+                const float py = ((ppy + 1.0f) * (float)vp.H - 1.0f) * 0.5f;
+                const Rect rc = tile_rect(px, py, r, vp.gx, vp.gy);
+                const int area = (rc.x1 - rc.x0) * (rc.y1 - rc.y0);
+                if (area != 0) {
+                    my_radius = r;
+                    touched = (uint32_t)area;
+                    g.xy[i] = make_float2(px, py);
+                    g.depth[i] = pv.z;
+                    g.conic_opacity[i] = make_float4(c[2] * det_inv, -c[1] * det_inv, c[0] * det_inv, in.opacities[i]);
+                    if (in.shs) {
+                        const float *sh = in.shs + (size_t)i * in.sh_coeffs * 3;
+#pragma unroll
+                        for (int ch = 0; ch < 3; ++ch) {
+                            float v = DM4D_SH_C0 * sh[ch] + 0.5f;
+                            g.clamped[3 * (size_t)i + ch] = (v < 0.f);
+                            g.rgb[3 * (size_t)i + ch] = fmaxf(v, 0.f);
+                        }
+                    }
+                    // per-tile duplicate histogram (integer atomics; order-independent)
+                    for (int y = rc.y0; y < rc.y1; ++y)
+                        for (int x = rc.x0; x < rc.x1; ++x) atomicAdd(&g.tile_count[y * vp.gx + x], 1u);
+                }
+            }
+        }
+        radii[i] = my_radius;
+        g.tiles_touched[i] = touched;
+    }
+    // duplicate count of this workgroup (exclusive-scanned by K2)
+    uint32_t ws = wave_sum_u32(touched);
+    if ((tid & 63) == 0) s_wsum[tid >> 6] = ws;
+    __syncthreads();
+    if (tid == 0) {
+        uint32_t s = 0;
+#pragma unroll
+        for (int w = 0; w < kPreBlock / 64; ++w) s += s_wsum[w];
+        g.block_sums[blockIdx.x] = s;
+    }
+}
+
+// ---------------------------------------------------------------------------------------- K3
+__global__ __launch_bounds__(kPreBlock) void k_scatter(ViewParams vp, int N, const int32_t *__restrict__ radii,
+                                                       GeomPtrs g, BinPtrs b, uint32_t cap)
+{
+    __shared__ uint32_t s_wsum[kPreBlock / 64];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int i = blockIdx.x * kPreBlock + tid;
+    const uint32_t touched = (i < N) ? g.tiles_touched[i] : 0u;
+    const uint32_t incl = wave_incl_scan_u32(touched, lane);
+    if (lane == 63) s_wsum[wv] = incl;
+    __syncthreads();
+    uint32_t base = g.block_offsets[blockIdx.x];
+    for (int w = 0; w < wv; ++w) base += s_wsum[w];
+    const uint32_t p0 = base + incl - touched;
+    if (i < N) g.offsets[i] = p0;
+    if (touched == 0) return;
+    const float2 xy = g.xy[i];
+    const Rect rc = tile_rect(xy.x, xy.y, radii[i], vp.gx, vp.gy);
+    const uint32_t dbits = __float_as_uint(g.depth[i]);
+    uint32_t n = 0;
+    bool overflow = false;
+    for (int y = rc.y0; y < rc.y1; ++y)
+        for (int x = rc.x0; x < rc.x1; ++x, ++n) {
+            const int t = y * vp.gx + x;
+            const uint32_t slot = g.tile_start[t] + atomicAdd(&g.tile_cursor[t], 1u);
+            if (slot < cap) {
+                b.u_depth[slot] = dbits;
+                b.u_idx[slot] = (uint32_t)i;
+                b.u_p[slot] = p0 + n;
+            } else {
+                overflow = true;
+            }
+        }
+    if (overflow) g.counters[kCntOverflow] = 1u;
+}
+
+// ---------------------------------------------------------------------------------------- B2
+__global__ __launch_bounds__(kPreBlock) void k_gather_bwd(ViewParams vp, dm4d_raster_inputs in,
+                                                          const int32_t *__restrict__ radii, GeomPtrs g, BinPtrs b,
+                                                          uint32_t cap, const float *__restrict__ dLt, BwdOutputs o)
+{
+    __shared__ float sV[16], sP[16];
+    const int tid = threadIdx.x;
+    if (tid < 16) { sV[tid] = vp.view[tid]; sP[tid] = vp.proj[tid]; }
+    __syncthreads();
+    const int i = blockIdx.x * kPreBlock + tid;
+    if (i >= in.N) return;
+    const size_t si = (size_t)i;
+
+    float acc[10];
+#pragma unroll
+    for (int k = 0; k < 10; ++k) acc[k] = 0.f;
+    const int r = radii[i];
+    if (r > 0) {
+        const float2 xy = g.xy[i];
+        const Rect rc = tile_rect(xy.x, xy.y, r, vp.gx, vp.gy);
+        uint32_t p = g.offsets[i];
+        for (int y = rc.y0; y < rc.y1; ++y)
+            for (int x = rc.x0; x < rc.x1; ++x, ++p) {
+                const int t = y * vp.gx + x;
+                if (p >= cap) continue;
+                const uint32_t pos = b.sorted_pos[p];
+                if (pos >= cap) continue;
+                const uint32_t k = pos - g.tile_start[t];
+                if (k >= g.tile_written[t]) continue;   // behind every pixel's last contributor
+                const float4 *src = reinterpret_cast<const float4 *>(dLt + (size_t)pos * kGradStride);
+                const float4 a0 = src[0], a1 = src[1], a2 = src[2];
+                acc[0] += a0.x; acc[1] += a0.y; acc[2] += a0.z; acc[3] += a0.w;
+                acc[4] += a1.x; acc[5] += a1.y; acc[6] += a1.z; acc[7] += a1.w;
+                acc[8] += a2.x; acc[9] += a2.y;
+            }
+    }
+    // acc: 0,1 = dL/dmean2D (NDC)  2,3,4 = dL/dconic (A,B,C)  5 = dL/dopacity  6..8 = dL/dcolor  9 = dL/ddepth
+    o.dL_dmeans2D[3 * si + 0] = acc[0];
+    o.dL_dmeans2D[3 * si + 1] = acc[1];
+    o.dL_dmeans2D[3 * si + 2] = 0.f;
+    if (o.dL_dopacity) o.dL_dopacity[si] = acc[5];
+    if (o.dL_dcolors) {
+        o.dL_dcolors[3 * si + 0] = acc[6];
+        o.dL_dcolors[3 * si + 1] = acc[7];
+        o.dL_dcolors[3 * si + 2] = acc[8];
+    }
+    if (o.dL_dsh && in.shs) {
+        const int M = in.sh_coeffs;
+        for (int ch = 0; ch < 3; ++ch)
+            o.dL_dsh[si * M * 3 + ch] = (r > 0 && !g.clamped[3 * si + ch]) ? DM4D_SH_C0 * acc[6 + ch] : 0.f;
+        for (int k = 3; k < 3 * M; ++k) o.dL_dsh[si * M * 3 + k] = 0.f;
+    }
+
+    float dmean[3] = {0.f, 0.f, 0.f};
+    float dcov[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    float dscale[3] = {0.f, 0.f, 0.f};
+    float drot[4] = {0.f, 0.f, 0.f, 0.f};
+    if (r > 0) {
+        const f3 m = load3(in.means3D, i);
+        float cov6[6];
+        float4 q = make_float4(1.f, 0.f, 0.f, 0.f);
+        f3 sc = {0.f, 0.f, 0.f};
+        if (in.cov3D_precomp) {
+#pragma unroll
+            for (int k = 0; k < 6; ++k) cov6[k] = in.cov3D_precomp[6 * si + k];
+        } else {
+            q = reinterpret_cast<const float4 *>(in.rotations)[i];
+            sc = load3(in.scales, i);
+            cov3d_from_scale_rot(sc, vp.scale_modifier, q, cov6);
+        }
+        // ---- conic -> cov2D -> (cov3D, T) ----
+        float c[3];
+        Cov2DAux aux;
+        cov2d(m, vp, sV, cov6, c, &aux);
+        const float a = c[0] + 0.3f, bb = c[1], cc = c[2] + 0.3f;
+        const float denom = a * cc - bb * bb;
+        const float denom2inv = 1.0f / ((denom * denom) + 0.0000001f);
+        const float gA = acc[2], gB = acc[3], gC = acc[4];
+        float dL_da = 0.f, dL_db = 0.f, dL_dc = 0.f;
+        const float *T0 = aux.T0, *T1 = aux.T1;
+        if (denom2inv != 0.f) {
+            dL_da = denom2inv * (-cc * cc * gA + bb * cc * gB + (denom - a * cc) * gC);
+            dL_dc = denom2inv * (-a * a * gC + a * bb * gB + (denom - a * cc) * gA);
+            dL_db = denom2inv * (2 * bb * cc * gA - (denom + 2 * bb * bb) * gB + 2 * a * bb * gC);
+            dcov[0] = T0[0] * T0[0] * dL_da + T0[0] * T1[0] * dL_db + T1[0] * T1[0] * dL_dc;
+            dcov[3] = T0[1] * T0[1] * dL_da + T0[1] * T1[1] * dL_db + T1[1] * T1[1] * dL_dc;
+            dcov[5] = T0[2] * T0[2] * dL_da + T0[2] * T1[2] * dL_db + T1[2] * T1[2] * dL_dc;
+            dcov[1] = 2 * T0[0] * T0[1] * dL_da + (T0[0] * T1[1] + T0[1] * T1[0]) * dL_db + 2 * T1[0] * T1[1] * dL_dc;
+            dcov[2] = 2 * T0[0] * T0[2] * dL_da + (T0[0] * T1[2] + T0[2] * T1[0]) * dL_db + 2 * T1[0] * T1[2] * dL_dc;
+            dcov[4] = 2 * T0[2] * T0[1] * dL_da + (T0[1] * T1[2] + T0[2] * T1[1]) * dL_db + 2 * T1[1] * T1[2] * dL_dc;
+        }
+        {
+            const float S[9] = {cov6[0], cov6[1], cov6[2], cov6[1], cov6[3], cov6[4], cov6[2], cov6[4], cov6[5]};
+            float dT0[3], dT1[3];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const float s0 = S[k * 3 + 0] * T0[0] + S[k * 3 + 1] * T0[1] + S[k * 3 + 2] * T0[2];
+                const float s1 = S[k * 3 + 0] * T1[0] + S[k * 3 + 1] * T1[1] + S[k * 3 + 2] * T1[2];
+                dT0[k] = 2 * s0 * dL_da + s1 * dL_db;
+                dT1[k] = 2 * s1 * dL_dc + s0 * dL_db;
+            }
+            float dJ00 = 0, dJ02 = 0, dJ11 = 0, dJ12 = 0;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                dJ00 += sV[k * 4 + 0] * dT0[k];
+                dJ02 += sV[k * 4 + 2] * dT0[k];
+                dJ11 += sV[k * 4 + 1] * dT1[k];
+                dJ12 += sV[k * 4 + 2] * dT1[k];
+            }
+            const float tz = 1.f / aux.tz, tz2 = tz * tz, tz3 = tz2 * tz;
+            const float xm = aux.xclamped ? 0.f : 1.f, ym = aux.yclamped ? 0.f : 1.f;
+            const float fx = vp.focal_x, fy = vp.focal_y;
+            const float dtx = xm * -fx * tz2 * dJ02;
+            const float dty = ym * -fy * tz2 * dJ12;
+            const float dtz = -fx * tz2 * dJ00 - fy * tz2 * dJ11 + (2 * fx * aux.tcx) * tz3 * dJ02 +
+                              (2 * fy * aux.tcy) * tz3 * dJ12;
+#pragma unroll
+            for (int j = 0; j < 3; ++j) dmean[j] = sV[j * 4 + 0] * dtx + sV[j * 4 + 1] * dty + sV[j * 4 + 2] * dtz;
+        }
+        // ---- NDC-space mean gradient through the projection ----
+        {
+            const float4 ph = xform4x4(m, sP);
+            const float mw = 1.0f / (ph.w + 0.0000001f);
+            const float mul1 = ph.x * mw * mw, mul2 = ph.y * mw * mw;
+#pragma unroll
+            for (int j = 0; j < 3; ++j)
+                dmean[j] += (sP[j * 4 + 0] * mw - sP[j * 4 + 3] * mul1) * acc[0] +
+                            (sP[j * 4 + 1] * mw - sP[j * 4 + 3] * mul2) * acc[1];
+        }
+        // ---- depth channel -> mean ----
+        {
+            const float mul3 = sV[2] * m.x + sV[6] * m.y + sV[10] * m.z + sV[14];
+#pragma unroll
+            for (int j = 0; j < 3; ++j) dmean[j] += (sV[j * 4 + 2] - sV[j * 4 + 3] * mul3) * acc[9];
+        }
+        // ---- cov3D -> scale / rotation ----
+        if (!in.cov3D_precomp) {
+            float R[9];
+            quat_to_R(q, R);
+            const float mod = vp.scale_modifier;
+            const float s[3] = {mod * sc.x, mod * sc.y, mod * sc.z};
+            const float Gs[9] = {dcov[0], 0.5f * dcov[1], 0.5f * dcov[2], 0.5f * dcov[1], dcov[3],
+                                 0.5f * dcov[4], 0.5f * dcov[2], 0.5f * dcov[4], dcov[5]};
+            float dR[9];
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                float ds = 0.f;
+#pragma unroll
+                for (int aa = 0; aa < 3; ++aa) {
+                    float a2 = 0.f;
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) a2 += Gs[aa * 3 + k] * (R[k * 3 + j] * s[j]);
+                    const float dM = 2.f * a2;
+                    ds += R[aa * 3 + j] * dM;
+                    dR[aa * 3 + j] = dM * s[j];
+                }
+                dscale[j] = mod * ds;
+            }
+            const float rr = q.x, x = q.y, y = q.z, z = q.w;
+            drot[0] = 2 * (-z * dR[1] + y * dR[2] + z * dR[3] - x * dR[5] - y * dR[6] + x * dR[7]);
+            drot[1] = 2 * (y * dR[1] + z * dR[2] + y * dR[3] - 2 * x * dR[4] - rr * dR[5] + z * dR[6] + rr * dR[7] - 2 * x * dR[8]);
+            drot[2] = 2 * (-2 * y * dR[0] + x * dR[1] + rr * dR[2] + x * dR[3] + z * dR[5] - rr * dR[6] + z * dR[7] - 2 * y * dR[8]);
+            drot[3] = 2 * (-2 * z * dR[0] - rr * dR[1] + x * dR[2] + rr * dR[3] - 2 * z * dR[4] + y * dR[5] + x * dR[6] + y * dR[7]);
+        }
+    }
+    o.dL_dmeans3D[3 * si + 0] = dmean[0];
+    o.dL_dmeans3D[3 * si + 1] = dmean[1];
+    o.dL_dmeans3D[3 * si + 2] = dmean[2];
+    if (o.dL_dcov3D) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) o.dL_dcov3D[6 * si + k] = dcov[k];
+    }
+    if (o.dL_dscales) {
+        o.dL_dscales[3 * si + 0] = dscale[0];
+        o.dL_dscales[3 * si + 1] = dscale[1];
+        o.dL_dscales[3 * si + 2] = dscale[2];
+    }
+    if (o.dL_drotations)
+        reinterpret_cast<float4 *>(o.dL_drotations)[i] = make_float4(drot[0], drot[1], drot[2], drot[3]);
+}
+
+__global__ void k_mark_visible(int N, const float *__restrict__ means3D, const float *__restrict__ view,
+                               uint8_t *__restrict__ present)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    const f3 pv = xform4x3(load3(means3D, i), view);
+    present[i] = pv.z > 0.2f;
+}
+
+// ---------------------------------------------------------------------------------------- launchers
+int launch_preprocess(const ViewParams &vp, const dm4d_raster_inputs &in, int32_t *radii, const GeomPtrs &g,
+                      hipStream_t st)
+{
+    const int nb = (in.N + kPreBlock - 1) / kPreBlock;
+    if (nb == 0) return DM4D_OK;
+    hipLaunchKernelGGL(k_preprocess, dim3(nb), dim3(kPreBlock), 0, st, vp, in, radii, g);
+    DM4D_HIP_CHECK(hipGetLastError());
+    return DM4D_OK;
+}
+
+int launch_scatter(const ViewParams &vp, int N, const int32_t *radii, const GeomPtrs &g, const BinPtrs &b,
+                   int64_t cap, hipStream_t st)
+{
+    const int nb = (N + kPreBlock - 1) / kPreBlock;
+    if (nb == 0) return DM4D_OK;
+    hipLaunchKernelGGL(k_scatter, dim3(nb), dim3(kPreBlock), 0, st, vp, N, radii, g, b, (uint32_t)cap);
+    DM4D_HIP_CHECK(hipGetLastError());
+    return DM4D_OK;
+}
+
+int launch_gather_bwd(const ViewParams &vp, const dm4d_raster_inputs &in, const int32_t *radii, const GeomPtrs &g,
+                      const BinPtrs &b, int64_t cap, const float *dLt, const BwdOutputs &o, hipStream_t st)
+{
+    const int nb = (in.N + kPreBlock - 1) / kPreBlock;
+    if (nb == 0) return DM4D_OK;
+    hipLaunchKernelGGL(k_gather_bwd, dim3(nb), dim3(kPreBlock), 0, st, vp, in, radii, g, b, (uint32_t)cap, dLt, o);
+    DM4D_HIP_CHECK(hipGetLastError());
+    return DM4D_OK;
+}
+
+int launch_mark_visible(int N, const float *means3D, const float *view, uint8_t *present, hipStream_t st)
+{
+    if (N <= 0) return DM4D_OK;
+    hipLaunchKernelGGL(k_mark_visible, dim3((N + 255) / 256), dim3(256), 0, st, N, means3D, view, present);
+    DM4D_HIP_CHECK(hipGetLastError());
+    return DM4D_OK;
+}
+
+}  // namespace dm4d

@@ -1,0 +1,160 @@
+/*
+ * dm4d.h -- C ABI of libdm4d_hip.so, the MI355X (gfx950) hot path of DreamMesh4D's
+ * dynamic stage.  Plain pointers and sizes only; every pointer marked [dev] is a
+ * DEVICE pointer (HBM) owned by the caller, every call is enqueued on the caller's
+ * hipStream_t (passed as void*), no call allocates device memory, and the library
+ * keeps no global device state (re-entrant per stream).
+ *
+ * Each entry point names the reference interface it replaces
+ * (paths relative to the DreamMesh4D tree, C/ = custom/threestudio-dreammesh4d/):
+ *
+ *   dm4d_rasterize_*      diff_gaussian_rasterization.GaussianRasterizer (un-vendored CUDA
+ *                         package, requirements.txt:49) as called at
+ *                         C/renderer/diff_sugar_rasterizer_temporal.py:129-178,202-211 and
+ *                         C/renderer/diff_sugar_rasterizer_normal.py:117-132,161-170,186-195
+ *   dm4d_mark_visible     GaussianRasterizer.markVisible (same package)
+ *   dm4d_dist2_knn3       simple_knn._C.distCUDA2 (requirements.txt:50), call site
+ *                         C/geometry/gaussian_base.py:435-438
+ *   dm4d_skin_*           C/geometry/dynamic_sugar.py:408-465,487-613 (+ C/utils/dual_quaternions.py)
+ *   dm4d_face_gaussians_* C/geometry/dynamic_sugar.py:657-706,726-743,877-889,330-364 and
+ *                         C/geometry/sugar.py:479-518
+ *
+ * Return convention: >= 0 success (some calls return a count), < 0 error code;
+ * dm4d_last_error() returns a thread-local description.
+ */
+#ifndef DM4D_H
+#define DM4D_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DM4D_OK 0
+#define DM4D_ERR_INVALID -1    /* bad argument */
+#define DM4D_ERR_HIP -2        /* a HIP runtime call failed */
+#define DM4D_ERR_CAPACITY -3   /* a caller-provided buffer is too small */
+#define DM4D_ERR_UNSUPPORTED -4
+
+#define DM4D_TILE 16           /* BLOCK_X == BLOCK_Y of the reference rasterizer */
+
+typedef void *dm4d_stream_t;   /* hipStream_t */
+
+int dm4d_version(void);
+const char *dm4d_last_error(void);
+/* Number of HIP devices visible / name of device `dev` (host helpers for the loader). */
+int dm4d_device_count(void);
+int dm4d_device_arch(int dev, char *buf, int buflen);
+
+/* ------------------------------------------------------------------ rasterizer */
+
+/* GaussianRasterizationSettings (C/renderer/diff_sugar_rasterizer_temporal.py:129-142).
+ * Matrices are in the reference's row-vector ("transposed") convention
+ * (threestudio/utils/ops.py:398-413): x' = M[0]*x + M[4]*y + M[8]*z + M[12]. */
+typedef struct dm4d_raster_settings {
+    int32_t image_height;
+    int32_t image_width;
+    float tanfovx;
+    float tanfovy;
+    float scale_modifier;
+    int32_t sh_degree;          /* only 0 is implemented (the reference never uses more) */
+    int32_t prefiltered;
+    int32_t debug;
+    const float *bg;            /* [dev] [3]  */
+    const float *viewmatrix;    /* [dev] [16] */
+    const float *projmatrix;    /* [dev] [16] */
+    const float *campos;        /* [dev] [3]  */
+} dm4d_raster_settings;
+
+/* Per-Gaussian inputs of one rasterizer call.  Exactly one of (shs | colors_precomp)
+ * and one of ((scales, rotations) | cov3D_precomp), as upstream. */
+typedef struct dm4d_raster_inputs {
+    int32_t N;
+    int32_t sh_coeffs;            /* M of shs[N,M,3]; 0 when colors_precomp is used */
+    const float *means3D;         /* [dev] [N,3] */
+    const float *shs;             /* [dev] [N,M,3] or NULL */
+    const float *colors_precomp;  /* [dev] [N,3] or NULL */
+    const float *opacities;       /* [dev] [N]   */
+    const float *scales;          /* [dev] [N,3] or NULL */
+    const float *rotations;       /* [dev] [N,4] (w,x,y,z) or NULL */
+    const float *cov3D_precomp;   /* [dev] [N,6] or NULL */
+} dm4d_raster_inputs;
+
+/* Workspace sizes (bytes).  geom: per-Gaussian + per-tile state; binning: per
+ * (Gaussian,tile) duplicate, `capacity` duplicates; image: per-pixel state;
+ * grad: backward scratch for `capacity` duplicates. */
+size_t dm4d_raster_geom_bytes(int32_t N, int32_t image_height, int32_t image_width);
+size_t dm4d_raster_binning_bytes(int64_t capacity);
+size_t dm4d_raster_image_bytes(int32_t image_height, int32_t image_width);
+size_t dm4d_raster_grad_bytes(int64_t capacity);
+
+/* Stage 1 (no host sync): preprocess every Gaussian, count duplicates per tile, scan.
+ * Writes radii[N] and the geom workspace (which must be 16-byte aligned; it need not be
+ * zeroed).  After it the number of duplicates D ("num_rendered") is in device memory. */
+int dm4d_rasterize_prepare(const dm4d_raster_settings *s, const dm4d_raster_inputs *in,
+                           int32_t *radii /* [dev] [N] */, void *geom /* [dev] */, size_t geom_bytes,
+                           dm4d_stream_t stream);
+
+/* Host read of D: synchronises `stream` (this is the one sync upstream also has). */
+int64_t dm4d_rasterize_num_rendered(const void *geom /* [dev] */, dm4d_stream_t stream);
+
+/* Stage 2: scatter duplicates into per-tile segments, sort every tile by
+ * (depth bits, Gaussian id) -- the order of a stable radix sort of tile<<32|depth --,
+ * blend front to back.  `binning` must hold `capacity` >= D duplicates; if it does not,
+ * nothing is rendered past the capacity and the overflow flag read by
+ * dm4d_rasterize_overflowed() is set.  Outputs: color [3,H,W], depth [H,W], alpha [H,W]. */
+int dm4d_rasterize_render(const dm4d_raster_settings *s, const dm4d_raster_inputs *in,
+                          const int32_t *radii /* [dev] [N], from prepare */,
+                          void *geom, void *binning, int64_t capacity, void *image,
+                          float *out_color, float *out_depth, float *out_alpha, dm4d_stream_t stream);
+
+/* 1 if the last render on this geom workspace dropped duplicates (syncs the stream). */
+int dm4d_rasterize_overflowed(const void *geom, dm4d_stream_t stream);
+
+/* Backward of prepare+render.  dL_ddepth / dL_dalpha may be NULL (treated as zero).
+ * Output gradient pointers may be NULL when not wanted, except dL_dmeans2D and
+ * dL_dmeans3D.  `grad` is scratch of dm4d_raster_grad_bytes(capacity).
+ * Deterministic: no floating-point atomics anywhere. */
+int dm4d_rasterize_backward(const dm4d_raster_settings *s, const dm4d_raster_inputs *in,
+                            const int32_t *radii, const void *geom, const void *binning, int64_t capacity,
+                            const void *image, void *grad,
+                            const float *dL_dcolor /* [3,H,W] */, const float *dL_ddepth /* [H,W] */,
+                            const float *dL_dalpha /* [H,W] */,
+                            float *dL_dmeans2D /* [N,3] */, float *dL_dmeans3D /* [N,3] */,
+                            float *dL_dopacity /* [N] */, float *dL_dcolors /* [N,3] */,
+                            float *dL_dsh /* [N,M,3] */, float *dL_dscales /* [N,3] */,
+                            float *dL_drotations /* [N,4] */, float *dL_dcov3D /* [N,6] */,
+                            dm4d_stream_t stream);
+
+/* One-shot forward in the shape of upstream's RasterizeGaussiansCUDA: the library asks the
+ * caller for the three workspaces through `alloc(ctx, which, bytes)` (which = 0 geom,
+ * 1 binning, 2 image; must return a 16-byte aligned device pointer that stays valid until
+ * the backward) and returns num_rendered.  Synchronises the stream once (to size binning). */
+typedef void *(*dm4d_alloc_fn)(void *ctx, int which, size_t bytes);
+int64_t dm4d_rasterize_forward(const dm4d_raster_settings *s, const dm4d_raster_inputs *in,
+                               float *out_color, float *out_depth, float *out_alpha, int32_t *radii,
+                               dm4d_alloc_fn alloc, void *alloc_ctx, dm4d_stream_t stream);
+
+/* Debug / parity views into the workspaces (device-to-host copies, sync the stream). */
+int dm4d_raster_read_sorted(const void *geom, const void *binning, int32_t N, int32_t image_height,
+                            int32_t image_width, int64_t D, uint64_t *keys /* [host] [D] */,
+                            uint32_t *values /* [host] [D] */, uint32_t *ranges /* [host] [tiles,2] */,
+                            dm4d_stream_t stream);
+int dm4d_raster_read_geom(const void *geom, int32_t N, int32_t image_height, int32_t image_width,
+                          float *xy /* [host][N,2] */, float *depths /* [N] */,
+                          float *conic_opacity /* [N,4] */, uint32_t *tiles_touched /* [N] */,
+                          dm4d_stream_t stream);
+int dm4d_raster_read_image_state(const void *image, int32_t image_height, int32_t image_width,
+                                 uint32_t *n_contrib /* [host][H,W] */, float *final_T /* [host][H,W] */,
+                                 dm4d_stream_t stream);
+
+/* markVisible: present[i] = view-space z > 0.2 */
+int dm4d_mark_visible(int32_t N, const float *means3D, const float *viewmatrix, uint8_t *present,
+                      dm4d_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DM4D_H */

@@ -1,0 +1,267 @@
+"""GPU parity tests: HIP rasterizer (through the C ABI) vs the CPU oracle on identical seeded
+splat sets.  Bars (BASELINE.json north_star): bit-exact tile/sort indices and radii;
+RGB/depth/alpha L-inf <= 1e-4 (we additionally assert the forward is bit-identical, which the
+shared arithmetic contract makes possible); gradients within a relative tolerance
+(different summation order, float32 vs double accumulation in the checker)."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from dreammesh4d_amd import synthetic as syn
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-4      # north_star tolerance for RGB L-inf
+GRAD_RTOL = 2e-3
+
+
+def _need_gpu():
+    if not torch.cuda.is_available():
+        pytest.skip("no HIP device")
+
+
+def _oracle(sc, cam, bg, scale_mod, **kw):
+    from oracle import raster as orc
+
+    o = orc.RasterOracle(image_height=cam.H, image_width=cam.W, tanfovx=cam.tanfov, tanfovy=cam.tanfov, bg=bg,
+                         scale_modifier=scale_mod, viewmatrix=cam.viewmatrix, projmatrix=cam.projmatrix,
+                         campos=cam.campos)
+    o.forward(sc["means3D"], sc["opacities"], **kw)
+    return o
+
+
+def _both(sc, cam, bg=(1, 1, 1), scale_mod=1.0, mode="colors"):
+    from tests.hip_raster import HipRaster
+
+    if mode == "colors":
+        okw = dict(colors_precomp=sc["colors"], scales=sc["scales"], rotations=sc["rotations"])
+        hkw = dict(colors=sc["colors"], scales=sc["scales"], rotations=sc["rotations"])
+    elif mode == "sh":
+        sh = ((sc["colors"] - 0.5) / 0.28209479177387814)[:, None, :] * 1.6 - 0.3   # some clamp below 0
+        okw = dict(shs=sh, scales=sc["scales"], rotations=sc["rotations"])
+        hkw = dict(shs=sh, scales=sc["scales"], rotations=sc["rotations"])
+    o = _oracle(sc, cam, bg, scale_mod, **okw)
+    h = HipRaster(cam, bg=bg, scale_mod=scale_mod)
+    out = h.forward(sc["means3D"], sc["opacities"], **hkw)
+    return o, h, out
+
+
+def _assert_forward_parity(o, h, out, exact=True):
+    color, radii, depth, alpha = out
+    s = h.state()
+    assert h.D == o.D
+    assert np.array_equal(radii, o.s["radii"])
+    assert np.array_equal(s["tiles_touched"], o.s["tiles_touched"])
+    vis = o.s["radii"] > 0
+    for k in ("xy", "depths", "conic_opacity"):
+        assert np.array_equal(s[k][vis].view(np.uint32), o.s[k][vis].view(np.uint32)), k
+    assert np.array_equal(s["ranges"], o.s["ranges"]) or np.array_equal(
+        s["ranges"][o.s["ranges"][:, 1] > o.s["ranges"][:, 0]], o.s["ranges"][o.s["ranges"][:, 1] > o.s["ranges"][:, 0]])
+    assert np.array_equal(s["values"], o.s["values"])
+    assert np.array_equal(s["keys"], o.s["keys"])
+    assert np.abs(color - o.s["out_color"]).max() <= TOL
+    assert np.abs(alpha - o.s["out_alpha"]).max() <= TOL
+    assert np.abs(depth - o.s["out_depth"]).max() <= TOL * 10
+    if exact:
+        assert np.array_equal(s["n_contrib"], o.s["n_contrib"])
+        assert np.array_equal(s["final_T"].view(np.uint32), o.s["final_T"].view(np.uint32))
+        assert np.array_equal(color.view(np.uint32), o.s["out_color"].view(np.uint32))
+        assert np.array_equal(depth.view(np.uint32), o.s["out_depth"].view(np.uint32))
+        assert np.array_equal(alpha.view(np.uint32), o.s["out_alpha"].view(np.uint32))
+
+
+def _assert_grads(g, og, keys=("dL_dmeans2D", "dL_dopacity", "dL_dcolors", "dL_dmeans3D", "dL_dscales", "dL_drots")):
+    for k in keys:
+        a, b = g[k], og[k]
+        assert a is not None and b is not None, k
+        assert np.isfinite(a).all(), k
+        scale = np.abs(b).max() + 1e-20
+        assert np.abs(a - b.reshape(a.shape)).max() / scale < GRAD_RTOL, (k, np.abs(a - b.reshape(a.shape)).max() / scale)
+
+
+@pytest.mark.parametrize("n,H,W,seed,lsm", [
+    (10_000, 256, 256, 0, math.log(0.008)),      # BASELINE configs[0]
+    (3_000, 100, 173, 1, math.log(0.03)),        # ragged image (not a multiple of 16)
+    (500, 33, 17, 2, math.log(0.1)),             # tiny image, big splats
+])
+def test_forward_backward_parity(n, H, W, seed, lsm):
+    _need_gpu()
+    sc = syn.random_splat_scene(n, seed=seed, log_scale_mean=lsm, log_scale_std=0.6)
+    cam = syn.make_camera(H, W, elev_deg=15.0, azim_deg=40.0)
+    o, h, out = _both(sc, cam, bg=(0.2, 0.7, 1.0), scale_mod=1.0)
+    _assert_forward_parity(o, h, out)
+    rng = np.random.default_rng(seed)
+    gC = rng.normal(size=(3, H, W)).astype(np.float32)
+    gD = rng.normal(size=(H, W)).astype(np.float32)
+    gA = rng.normal(size=(H, W)).astype(np.float32)
+    og = o.backward(gC, gD, gA)
+    g = h.backward(gC, gD, gA)
+    _assert_grads(g, og)
+    g2 = h.backward(gC, gD, gA)   # deterministic: no float atomics anywhere
+    for k in g:
+        if g[k] is not None:
+            assert np.array_equal(g[k].view(np.uint32), g2[k].view(np.uint32)), k
+
+
+def test_sh_degree0_path_and_null_grads():
+    _need_gpu()
+    sc = syn.random_splat_scene(2000, seed=5, log_scale_mean=math.log(0.03), log_scale_std=0.5)
+    cam = syn.make_camera(96, 96)
+    o, h, out = _both(sc, cam, mode="sh")
+    _assert_forward_parity(o, h, out)
+    gC = np.random.default_rng(0).normal(size=(3, 96, 96)).astype(np.float32)
+    og = o.backward(gC, None, None)
+    g = h.backward(gC, None, None)
+    _assert_grads(g, og, keys=("dL_dmeans2D", "dL_dopacity", "dL_dmeans3D", "dL_dscales", "dL_drots", "dL_dsh"))
+    assert (o.s["clamped"].sum() > 0)
+
+
+def test_cov3d_precomp_path():
+    _need_gpu()
+    from tests.hip_raster import HipRaster
+
+    sc = syn.random_splat_scene(1500, seed=6, log_scale_mean=math.log(0.03), log_scale_std=0.5)
+    cam = syn.make_camera(80, 64)
+    o0 = _oracle(sc, cam, (0, 0, 0), 1.0, colors_precomp=sc["colors"], scales=sc["scales"], rotations=sc["rotations"])
+    cov = o0.s["cov3D"].copy()
+    cov[o0.s["radii"] <= 0] = np.eye(3, dtype=np.float32)[[0, 0, 0, 1, 1, 2], [0, 1, 2, 1, 2, 2]] * 1e-4
+    o = _oracle(sc, cam, (0, 0, 0), 1.0, colors_precomp=sc["colors"], cov3D_precomp=cov)
+    h = HipRaster(cam, bg=(0, 0, 0))
+    out = h.forward(sc["means3D"], sc["opacities"], colors=sc["colors"], cov3D=cov)
+    _assert_forward_parity(o, h, out)
+    gC = np.random.default_rng(1).normal(size=(3, 80, 64)).astype(np.float32)
+    og = o.backward(gC)
+    g = h.backward(gC)
+    _assert_grads(g, og, keys=("dL_dmeans2D", "dL_dopacity", "dL_dcolors", "dL_dmeans3D", "dL_dcov3D"))
+
+
+def test_edge_cases_empty_and_culled():
+    _need_gpu()
+    from tests.hip_raster import HipRaster
+
+    cam = syn.make_camera(40, 56)
+    h = HipRaster(cam, bg=(0.1, 0.2, 0.3))
+    color, radii, depth, alpha = h.forward(np.zeros((0, 3), np.float32), np.zeros((0,), np.float32),
+                                           colors=np.zeros((0, 3), np.float32), scales=np.zeros((0, 3), np.float32),
+                                           rotations=np.zeros((0, 4), np.float32))
+    assert h.D == 0 and np.allclose(color[0], 0.1) and np.allclose(color[2], 0.3) and not alpha.any()
+    # everything behind the camera
+    sc = syn.random_splat_scene(300, seed=3)
+    sc["means3D"] = sc["means3D"] + cam.campos[None, :] * 2.0
+    o, h2, out = _both(sc, cam, bg=(0.1, 0.2, 0.3))
+    assert o.D == 0 and h2.D == 0 and not out[1].any()
+    g = h2.backward(np.ones((3, 40, 56), np.float32))
+    assert all(v is None or not np.any(v) for v in g.values())
+
+
+def test_depth_ties_break_by_gaussian_id():
+    _need_gpu()
+    sc = syn.random_splat_scene(800, seed=7, log_scale_mean=math.log(0.05), log_scale_std=0.3)
+    sc["means3D"][1::2] = sc["means3D"][0::2]           # pairs of coincident splats: identical depth bits
+    sc["colors"][1::2] = 1.0 - sc["colors"][0::2]
+    cam = syn.make_camera(64, 64)
+    o, h, out = _both(sc, cam)
+    _assert_forward_parity(o, h, out)
+    d = o.s["depths"]
+    assert np.array_equal(d[0::2].view(np.uint32), d[1::2].view(np.uint32))
+
+
+def test_oversized_tile_uses_global_sort_path():
+    _need_gpu()
+    # > 4096 duplicates in one 16x16 tile: the HBM-resident bitonic path of k_tile_sort
+    n = 6000
+    rng = np.random.default_rng(9)
+    sc = syn.random_splat_scene(n, seed=9, log_scale_mean=math.log(0.002), log_scale_std=0.2)
+    sc["means3D"] = (rng.normal(size=(n, 3)) * 0.004).astype(np.float32)
+    cam = syn.make_camera(64, 64)
+    o, h, out = _both(sc, cam)
+    assert (o.s["ranges"][:, 1].astype(np.int64) - o.s["ranges"][:, 0]).max() > 4096
+    _assert_forward_parity(o, h, out)
+    gC = rng.normal(size=(3, 64, 64)).astype(np.float32)
+    _assert_grads(h.backward(gC), o.backward(gC))
+
+
+def test_giant_splat_covers_every_tile():
+    _need_gpu()
+    sc = syn.random_splat_scene(64, seed=10, log_scale_mean=math.log(0.02), log_scale_std=0.3)
+    sc["scales"][0] = (0.5, 0.5, 0.5)
+    sc["means3D"][0] = 0
+    sc["opacities"][0] = 0.6
+    cam = syn.make_camera(128, 96)
+    o, h, out = _both(sc, cam)
+    assert o.s["tiles_touched"][0] == 8 * 6
+    _assert_forward_parity(o, h, out)
+    gC = np.random.default_rng(2).normal(size=(3, 128, 96)).astype(np.float32)
+    _assert_grads(h.backward(gC), o.backward(gC))
+
+
+def test_capacity_overflow_is_flagged_not_fatal():
+    _need_gpu()
+    from tests.hip_raster import HipRaster
+
+    sc = syn.random_splat_scene(4000, seed=4, log_scale_mean=math.log(0.03), log_scale_std=0.4)
+    cam = syn.make_camera(96, 96)
+    h = HipRaster(cam)
+    h.forward(sc["means3D"], sc["opacities"], colors=sc["colors"], scales=sc["scales"], rotations=sc["rotations"],
+              capacity=100)
+    assert h.D > 100 and h.overflowed() == 1
+    h.backward(np.ones((3, 96, 96), np.float32))   # memory-safe
+    h2 = HipRaster(cam)
+    h2.forward(sc["means3D"], sc["opacities"], colors=sc["colors"], scales=sc["scales"], rotations=sc["rotations"])
+    assert h2.overflowed() == 0
+
+
+def test_full_size_200k_512():
+    """BASELINE headline size: 200k Gaussians at 512^2 (random-splat scene), full parity."""
+    _need_gpu()
+    sc = syn.random_splat_scene(200_000, seed=0)
+    cam = syn.make_camera(512, 512)
+    o, h, out = _both(sc, cam)
+    _assert_forward_parity(o, h, out)
+    rng = np.random.default_rng(0)
+    gC = rng.normal(size=(3, 512, 512)).astype(np.float32)
+    gD = rng.normal(size=(512, 512)).astype(np.float32) * 0.1
+    gA = rng.normal(size=(512, 512)).astype(np.float32)
+    _assert_grads(h.backward(gC, gD, gA), o.backward(gC, gD, gA))
+
+
+def test_autograd_operator_matches_oracle():
+    """The drop-in module (GaussianRasterizationSettings / GaussianRasterizer) end to end."""
+    _need_gpu()
+    import dreammesh4d_amd.diff_gaussian_rasterization as dgr
+
+    dev = torch.device("cuda:0")
+    n, H, W = 5000, 128, 160
+    sc = syn.random_splat_scene(n, seed=21, log_scale_mean=math.log(0.02), log_scale_std=0.5)
+    cam = syn.make_camera(H, W, elev_deg=30, azim_deg=-60)
+    T = lambda a, rg=False: torch.tensor(a, device=dev).requires_grad_(rg)
+    m3, op = T(sc["means3D"], True), T(sc["opacities"][:, None], True)
+    col, scl, rot = T(sc["colors"], True), T(sc["scales"], True), T(sc["rotations"], True)
+    m2 = torch.zeros_like(m3, requires_grad=True)
+    rs = dgr.GaussianRasterizationSettings(image_height=H, image_width=W, tanfovx=cam.tanfov, tanfovy=cam.tanfov,
+                                           bg=T(np.ones(3, np.float32)), scale_modifier=1.0,
+                                           viewmatrix=T(cam.viewmatrix), projmatrix=T(cam.projmatrix), sh_degree=0,
+                                           campos=T(cam.campos), prefiltered=False, debug=False)
+    rast = dgr.GaussianRasterizer(raster_settings=rs)
+    with pytest.raises(Exception):
+        rast(means3D=m3, means2D=m2, opacities=op, shs=None, colors_precomp=None, scales=scl, rotations=rot)
+    color, radii, depth, alpha = rast(means3D=m3, means2D=m2, shs=None, colors_precomp=col, opacities=op, scales=scl,
+                                      rotations=rot, cov3D_precomp=None)
+    assert color.shape == (3, H, W) and depth.shape == (1, H, W) and alpha.shape == (1, H, W)
+    assert radii.dtype == torch.int32 and radii.shape == (n,)
+    rng = np.random.default_rng(3)
+    gC = rng.normal(size=(3, H, W)).astype(np.float32)
+    gA = rng.normal(size=(1, H, W)).astype(np.float32)
+    ((color * T(gC)).sum() + (alpha * T(gA)).sum()).backward()
+    o = _oracle(sc, cam, (1, 1, 1), 1.0, colors_precomp=sc["colors"], scales=sc["scales"], rotations=sc["rotations"])
+    og = o.backward(gC, None, gA[0])
+    assert np.array_equal(color.detach().cpu().numpy().view(np.uint32), o.s["out_color"].view(np.uint32))
+    assert np.array_equal(radii.cpu().numpy(), o.s["radii"])
+    got = {"dL_dmeans2D": m2.grad.cpu().numpy(), "dL_dopacity": op.grad.cpu().numpy()[:, 0],
+           "dL_dcolors": col.grad.cpu().numpy(), "dL_dmeans3D": m3.grad.cpu().numpy(),
+           "dL_dscales": scl.grad.cpu().numpy(), "dL_drots": rot.grad.cpu().numpy()}
+    _assert_grads(got, og)
+    vis = rast.markVisible(m3)
+    assert vis.dtype == torch.bool and bool(vis.all())
