@@ -24,6 +24,10 @@ static int check_settings(const dm4d_raster_settings *s, const dm4d_raster_input
 {
     if (!s || !in) { set_error("null settings/inputs"); return DM4D_ERR_INVALID; }
     if (s->image_height <= 0 || s->image_width <= 0) { set_error("bad image size %dx%d", s->image_height, s->image_width); return DM4D_ERR_INVALID; }
+    if ((int64_t)((s->image_height + kTile - 1) / kTile) * ((s->image_width + kTile - 1) / kTile) > kMaxTiles) {
+        set_error("image %dx%d has more than %d tiles", s->image_height, s->image_width, kMaxTiles);
+        return DM4D_ERR_UNSUPPORTED;
+    }
     if (in->N < 0) { set_error("negative N"); return DM4D_ERR_INVALID; }
     if (!s->bg || !s->viewmatrix || !s->projmatrix) { set_error("bg/viewmatrix/projmatrix must be device pointers"); return DM4D_ERR_INVALID; }
     if (in->N > 0) {
@@ -107,7 +111,7 @@ int dm4d_rasterize_prepare(const dm4d_raster_settings *s, const dm4d_raster_inpu
     DM4D_HIP_CHECK(hipMemsetAsync((char *)geom + L.zero_begin, 0, L.zero_bytes, st));
     rc = launch_preprocess(vp, *in, radii, g, st);
     if (rc) return rc;
-    return launch_scan(in->N, L.T, g, st);
+    return launch_colscan(in->N, L.T, g, st);
 }
 
 int64_t dm4d_rasterize_num_rendered(const void *geom, dm4d_stream_t stream)

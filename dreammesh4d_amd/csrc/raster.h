@@ -1,10 +1,11 @@
 // raster.h -- workspace layout and kernel launchers of the tile rasterizer.
 //
 // Pipeline (one view), all on the caller's stream, no host sync inside:
-//   K1 preprocess      1 thread / Gaussian   cull, cov3D, EWA cov2D, conic, radius, rect,
-//                                            per-block duplicate sums, per-tile histogram
-//   K2 scan            1 workgroup           block offsets, D, tile segment starts
-//   K3 scatter         1 thread / Gaussian   duplicates -> per-tile segments (unordered)
+//   K1 preprocess      1024 Gaussians / WG   cull, cov3D, EWA cov2D, conic, radius, rect;
+//                                            per-WG tile histogram in LDS -> dense hist[WG][tile]
+//   K2 colscan         1 thread / tile       exclusive scan of hist over WGs, tile counts
+//   K3 scatter         1024 Gaussians / WG   duplicates -> per-tile segments via LDS cursors
+//                                            (no global atomics anywhere in binning)
 //   K4 tile_sort       1 workgroup / tile    LDS bitonic sort by (depth bits, id)
 //   K5 render_fwd      1 workgroup / tile    4 waves = 4 8x8 quadrants, LDS-staged lists
 //   B1 render_bwd      1 workgroup / tile    per-duplicate partial grads, no atomics
@@ -18,7 +19,10 @@
 namespace dm4d {
 
 constexpr int kTile = DM4D_TILE;
-constexpr int kPreBlock = 256;   // Gaussians per workgroup in K1/K3/B2
+constexpr int kPreThreads = 256; // threads per workgroup in K1/K3/B2
+constexpr int kPreItems = 4;     // Gaussians per thread in K1/K3
+constexpr int kPreBlock = kPreThreads * kPreItems;   // Gaussians per workgroup in K1/K3
+constexpr int kMaxTiles = 36864; // tile histogram lives in LDS (4 B/tile of the 160 KB): <= 3072x3072 px
 constexpr int kGradStride = 12;  // floats per duplicate in the backward scratch (10 used)
 
 enum GeomCounter { kCntD = 0, kCntOverflow = 1 };
@@ -27,8 +31,8 @@ static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; 
 
 struct GeomLayout {
     int N, T, nb;
-    size_t counters, xy, depth, conic_opacity, rgb, tiles_touched, offsets, clamped, block_sums, block_offsets,
-        tile_count, tile_start, tile_cursor, tile_written, zero_begin, zero_bytes, total;
+    size_t counters, xy, depth, conic_opacity, rgb, tiles_touched, offsets, clamped, block_sums, hist,
+        tile_count, tile_start, tile_written, zero_begin, zero_bytes, total;
 };
 
 static inline GeomLayout geom_layout(int N, int H, int W)
@@ -41,14 +45,13 @@ static inline GeomLayout geom_layout(int N, int H, int W)
     size_t o = 0;
     auto take = [&](size_t bytes) { size_t r = o; o = align_up(o + bytes, 256); return r; };
     size_t n = (size_t)(N > 0 ? N : 1);
-    // counters (offset 0) .. tile_written are cleared by ONE memset node before K1
+    // counters (offset 0) are cleared by one small memset node before K1
     L.counters = take(64 * 4);
-    L.tile_count = take((size_t)L.T * 4);
-    L.tile_start = take((size_t)(L.T + 1) * 4);
-    L.tile_cursor = take((size_t)L.T * 4);
-    L.tile_written = take((size_t)L.T * 4);
     L.zero_begin = 0;
     L.zero_bytes = o;
+    L.tile_count = take((size_t)L.T * 4);
+    L.tile_start = take((size_t)(L.T + 1) * 4);
+    L.tile_written = take((size_t)L.T * 4);
     L.xy = take(n * 8);
     L.depth = take(n * 4);
     L.conic_opacity = take(n * 16);
@@ -57,7 +60,7 @@ static inline GeomLayout geom_layout(int N, int H, int W)
     L.offsets = take(n * 4);
     L.clamped = take(n * 3);
     L.block_sums = take((size_t)(L.nb + 1) * 4);
-    L.block_offsets = take((size_t)(L.nb + 1) * 4);
+    L.hist = take((size_t)(L.nb > 0 ? L.nb : 1) * L.T * 4);
     L.total = o;
     return L;
 }
@@ -72,10 +75,9 @@ struct GeomPtrs {
     uint32_t *offsets;
     uint8_t *clamped;
     uint32_t *block_sums;
-    uint32_t *block_offsets;
+    uint32_t *hist;        // [nb][T] per-WG tile histogram, exclusive-scanned over WGs in place by K2
     uint32_t *tile_count;
     uint32_t *tile_start;
-    uint32_t *tile_cursor;
     uint32_t *tile_written;
 };
 
@@ -92,10 +94,9 @@ static inline GeomPtrs geom_ptrs(void *base, const GeomLayout &L)
     p.offsets = (uint32_t *)(b + L.offsets);
     p.clamped = (uint8_t *)(b + L.clamped);
     p.block_sums = (uint32_t *)(b + L.block_sums);
-    p.block_offsets = (uint32_t *)(b + L.block_offsets);
+    p.hist = (uint32_t *)(b + L.hist);
     p.tile_count = (uint32_t *)(b + L.tile_count);
     p.tile_start = (uint32_t *)(b + L.tile_start);
-    p.tile_cursor = (uint32_t *)(b + L.tile_cursor);
     p.tile_written = (uint32_t *)(b + L.tile_written);
     return p;
 }
@@ -160,7 +161,7 @@ struct ViewParams {
 // ---- launchers (defined in the .hip files) ---------------------------------------------
 int launch_preprocess(const ViewParams &vp, const dm4d_raster_inputs &in, int32_t *radii, const GeomPtrs &g,
                       hipStream_t st);
-int launch_scan(int N, int T, const GeomPtrs &g, hipStream_t st);
+int launch_colscan(int N, int T, const GeomPtrs &g, hipStream_t st);
 int launch_scatter(const ViewParams &vp, int N, const int32_t *radii, const GeomPtrs &g, const BinPtrs &b,
                    int64_t cap, hipStream_t st);
 int launch_tile_sort(int T, const GeomPtrs &g, const BinPtrs &b, int64_t cap, hipStream_t st);

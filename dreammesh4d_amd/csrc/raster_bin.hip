@@ -1,8 +1,8 @@
 // raster_bin.hip -- binning kernels of the tile rasterizer (gfx950).
 //
-//   K2 k_scan       : one workgroup; exclusive scans of the per-workgroup duplicate sums
-//                     (-> Gaussian-major offsets, D) and of the per-tile histogram
-//                     (-> tile segment starts == upstream's `ranges`).
+//   K2 k_colscan    : per-tile exclusive scan of the dense per-workgroup tile histogram written
+//                     by K1 (-> per-(workgroup, tile) slot bases, tile counts); the tile segment
+//                     starts (== upstream's `ranges`) follow from a scan K3 does in LDS.
 //   K4 k_tile_sort  : one workgroup per tile; sorts the tile's duplicates by the 64-bit key
 //                     (depth bits << 32 | Gaussian id) in LDS with a bitonic network.
 //
@@ -17,40 +17,33 @@
 
 namespace dm4d {
 
-constexpr int kScanThreads = 1024;
-
-// exclusive scan of in[0..n) into out[0..n), out[n] = total (if write_total). One workgroup.
-__device__ uint32_t block_exclusive_scan(const uint32_t *__restrict__ in, uint32_t *__restrict__ out, int n,
-                                         uint32_t *s_wave /* [16] */, uint32_t *s_carry)
+// ---------------------------------------------------------------------------------------- K2
+// hist[w][t] (duplicates of workgroup w in tile t) -> exclusive scan over w in place, and
+// tile_count[t] = column total.  One thread per tile; consecutive threads read consecutive
+// tiles of one histogram row, so every step is a coalesced row access; 8 rows in flight.
+constexpr int kColThreads = 64;
+__global__ __launch_bounds__(kColThreads) void k_colscan(int nb, int T, GeomPtrs g)
 {
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    if (tid == 0) *s_carry = 0;
-    __syncthreads();
-    for (int base = 0; base < n; base += kScanThreads) {
-        const int i = base + tid;
-        const uint32_t v = (i < n) ? in[i] : 0u;
-        const uint32_t incl = wave_incl_scan_u32(v, lane);
-        if (lane == 63) s_wave[wv] = incl;
-        __syncthreads();
-        uint32_t pre = *s_carry;
-        for (int w = 0; w < wv; ++w) pre += s_wave[w];
-        if (i < n) out[i] = pre + incl - v;
-        __syncthreads();
-        if (tid == kScanThreads - 1) *s_carry = pre + incl;
-        __syncthreads();
+    const int t = blockIdx.x * kColThreads + threadIdx.x;
+    if (t >= T) return;
+    uint32_t run = 0;
+    int w = 0;
+    for (; w + 8 <= nb; w += 8) {
+        uint32_t v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = g.hist[(size_t)(w + k) * T + t];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            g.hist[(size_t)(w + k) * T + t] = run;
+            run += v[k];
+        }
     }
-    return *s_carry;
-}
-
-__global__ __launch_bounds__(kScanThreads) void k_scan(int nb, int T, GeomPtrs g)
-{
-    __shared__ uint32_t s_wave[kScanThreads / 64];
-    __shared__ uint32_t s_carry;
-    const uint32_t D = block_exclusive_scan(g.block_sums, g.block_offsets, nb, s_wave, &s_carry);
-    if (threadIdx.x == 0) g.counters[kCntD] = D;
-    __syncthreads();
-    const uint32_t D2 = block_exclusive_scan(g.tile_count, g.tile_start, T, s_wave, &s_carry);
-    if (threadIdx.x == 0) g.tile_start[T] = D2;
+    for (; w < nb; ++w) {
+        const uint32_t v = g.hist[(size_t)w * T + t];
+        g.hist[(size_t)w * T + t] = run;
+        run += v;
+    }
+    g.tile_count[t] = run;
 }
 
 // ---------------------------------------------------------------------------------------- K4
@@ -144,10 +137,11 @@ __global__ __launch_bounds__(kSortThreads) void k_tile_sort(GeomPtrs g, BinPtrs 
     }
 }
 
-int launch_scan(int N, int T, const GeomPtrs &g, hipStream_t st)
+int launch_colscan(int N, int T, const GeomPtrs &g, hipStream_t st)
 {
     const int nb = (N + kPreBlock - 1) / kPreBlock;
-    hipLaunchKernelGGL(k_scan, dim3(1), dim3(kScanThreads), 0, st, nb, T, g);
+    if (T <= 0) return DM4D_OK;
+    hipLaunchKernelGGL(k_colscan, dim3((T + kColThreads - 1) / kColThreads), dim3(kColThreads), 0, st, nb, T, g);
     DM4D_HIP_CHECK(hipGetLastError());
     return DM4D_OK;
 }

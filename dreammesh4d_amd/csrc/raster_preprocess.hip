@@ -138,17 +138,26 @@ __device__ __forceinline__ Rect tile_rect(float px, float py, int r, int gx, int
 __device__ __forceinline__ f3 load3(const float *p, int i) { return f3{p[3 * i], p[3 * i + 1], p[3 * i + 2]}; }
 
 // ---------------------------------------------------------------------------------------- K1
-__global__ __launch_bounds__(kPreBlock) void k_preprocess(ViewParams vp, dm4d_raster_inputs in,
-                                                          int32_t *__restrict__ radii, GeomPtrs g)
+// One workgroup = kPreBlock (1024) consecutive Gaussians, 4 per thread (coalesced: a wave reads
+// 64 consecutive Gaussians per step).  The per-tile duplicate histogram of the workgroup is
+// accumulated with LDS atomics and written densely to hist[WG][tile]; K2 turns it into
+// per-(WG, tile) bases.  No global atomics except one add per workgroup for D.
+__global__ __launch_bounds__(kPreThreads) void k_preprocess(ViewParams vp, dm4d_raster_inputs in,
+                                                            int32_t *__restrict__ radii, GeomPtrs g, int T)
 {
+    extern __shared__ __attribute__((aligned(16))) uint32_t s_hist[];   // [T]
     __shared__ float sV[16], sP[16];
-    __shared__ uint32_t s_wsum[kPreBlock / 64];
+    __shared__ uint32_t s_wsum[kPreThreads / 64];
     const int tid = threadIdx.x;
     if (tid < 16) { sV[tid] = vp.view[tid]; sP[tid] = vp.proj[tid]; }
+    for (int t = tid; t < T; t += kPreThreads) s_hist[t] = 0u;
     __syncthreads();
-    const int i = blockIdx.x * kPreBlock + tid;
-    uint32_t touched = 0;
-    if (i < in.N) {
+    uint32_t touched_sum = 0;
+#pragma unroll 1
+    for (int it = 0; it < kPreItems; ++it) {
+        const int i = blockIdx.x * kPreBlock + it * kPreThreads + tid;
+        if (i >= in.N) break;
+        uint32_t touched = 0;
         int my_radius = 0;
         const f3 p = load3(in.means3D, i);
         const f3 pv = xform4x3(p, sV);
@@ -194,65 +203,115 @@ __global__ __launch_bounds__(kPreBlock) void k_preprocess(ViewParams vp, dm4d_ra
                             g.rgb[3 * (size_t)i + ch] = fmaxf(v, 0.f);
                         }
                     }
-                    // per-tile duplicate histogram (integer atomics; order-independent)
                     for (int y = rc.y0; y < rc.y1; ++y)
-                        for (int x = rc.x0; x < rc.x1; ++x) atomicAdd(&g.tile_count[y * vp.gx + x], 1u);
+                        for (int x = rc.x0; x < rc.x1; ++x) atomicAdd(&s_hist[y * vp.gx + x], 1u);   // LDS
                 }
             }
         }
         radii[i] = my_radius;
         g.tiles_touched[i] = touched;
+        touched_sum += touched;
     }
-    // duplicate count of this workgroup (exclusive-scanned by K2)
-    uint32_t ws = wave_sum_u32(touched);
+    const uint32_t ws = wave_sum_u32(touched_sum);
     if ((tid & 63) == 0) s_wsum[tid >> 6] = ws;
     __syncthreads();
+    uint32_t *row = g.hist + (size_t)blockIdx.x * T;
+    for (int t = tid; t < T; t += kPreThreads) row[t] = s_hist[t];
     if (tid == 0) {
         uint32_t s = 0;
 #pragma unroll
-        for (int w = 0; w < kPreBlock / 64; ++w) s += s_wsum[w];
+        for (int w = 0; w < kPreThreads / 64; ++w) s += s_wsum[w];
         g.block_sums[blockIdx.x] = s;
+        if (s) atomicAdd(&g.counters[kCntD], s);   // one integer atomic per workgroup
     }
 }
 
 // ---------------------------------------------------------------------------------------- K3
-__global__ __launch_bounds__(kPreBlock) void k_scatter(ViewParams vp, int N, const int32_t *__restrict__ radii,
-                                                       GeomPtrs g, BinPtrs b, uint32_t cap)
+// Same 1024-Gaussian workgroups as K1.  LDS holds cursor[t] = tile_start[t] + (duplicates of
+// earlier workgroups in tile t); every duplicate takes its slot with one LDS atomic.
+__device__ __forceinline__ uint32_t block_excl_scan_256(uint32_t v, uint32_t *s_w /* [4] */, uint32_t *total)
 {
-    __shared__ uint32_t s_wsum[kPreBlock / 64];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int i = blockIdx.x * kPreBlock + tid;
-    const uint32_t touched = (i < N) ? g.tiles_touched[i] : 0u;
-    const uint32_t incl = wave_incl_scan_u32(touched, lane);
-    if (lane == 63) s_wsum[wv] = incl;
+    const uint32_t incl = wave_incl_scan_u32(v, lane);
     __syncthreads();
-    uint32_t base = g.block_offsets[blockIdx.x];
-    for (int w = 0; w < wv; ++w) base += s_wsum[w];
-    const uint32_t p0 = base + incl - touched;
-    if (i < N) g.offsets[i] = p0;
-    if (touched == 0) return;
-    const float2 xy = g.xy[i];
-    const Rect rc = tile_rect(xy.x, xy.y, radii[i], vp.gx, vp.gy);
-    const uint32_t dbits = __float_as_uint(g.depth[i]);
-    uint32_t n = 0;
-    bool overflow = false;
-    for (int y = rc.y0; y < rc.y1; ++y)
-        for (int x = rc.x0; x < rc.x1; ++x, ++n) {
-            const int t = y * vp.gx + x;
-            const uint32_t slot = g.tile_start[t] + atomicAdd(&g.tile_cursor[t], 1u);
-            if (slot < cap) {
-                b.u_depth[slot] = dbits;
-                b.u_idx[slot] = (uint32_t)i;
-                b.u_p[slot] = p0 + n;
-            } else {
-                overflow = true;
-            }
+    if (lane == 63) s_w[wv] = incl;
+    __syncthreads();
+    uint32_t pre = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < kPreThreads / 64; ++w) {
+        const uint32_t x = s_w[w];
+        if (w < wv) pre += x;
+        tot += x;
+    }
+    *total = tot;
+    return pre + incl - v;
+}
+
+__global__ __launch_bounds__(kPreThreads) void k_scatter(ViewParams vp, int N, int T, int nb,
+                                                         const int32_t *__restrict__ radii, GeomPtrs g, BinPtrs b,
+                                                         uint32_t cap)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t s_cursor[];   // [T]
+    __shared__ uint32_t s_w[kPreThreads / 64];
+    const int tid = threadIdx.x;
+    // tile_start = exclusive scan of tile_count (each workgroup redoes this small scan in LDS;
+    // workgroup 0 publishes it for the later kernels)
+    {
+        const int per = (T + kPreThreads - 1) / kPreThreads;
+        const int t0 = tid * per, t1 = min(T, t0 + per);
+        uint32_t loc = 0;
+        for (int t = t0; t < t1; ++t) loc += g.tile_count[t];
+        uint32_t total;
+        uint32_t run = block_excl_scan_256(loc, s_w, &total);
+        const uint32_t *row = g.hist + (size_t)blockIdx.x * T;
+        for (int t = t0; t < t1; ++t) {
+            if (blockIdx.x == 0) g.tile_start[t] = run;
+            s_cursor[t] = run + row[t];
+            run += g.tile_count[t];
         }
+        if (blockIdx.x == 0 && tid == 0) g.tile_start[T] = total;
+    }
+    // Gaussian-major duplicate offset of this workgroup = sum of earlier workgroups' duplicates
+    uint32_t carry;
+    {
+        uint32_t loc = 0;
+        for (int w = tid; w < (int)blockIdx.x; w += kPreThreads) loc += g.block_sums[w];
+        uint32_t total;
+        block_excl_scan_256(loc, s_w, &total);
+        carry = total;
+    }
+    __syncthreads();
+    bool overflow = false;
+#pragma unroll 1
+    for (int it = 0; it < kPreItems; ++it) {
+        const int i = blockIdx.x * kPreBlock + it * kPreThreads + tid;
+        const uint32_t touched = (i < N) ? g.tiles_touched[i] : 0u;
+        uint32_t total;
+        const uint32_t p0 = carry + block_excl_scan_256(touched, s_w, &total);
+        carry += total;
+        if (i < N) g.offsets[i] = p0;
+        if (touched == 0) continue;
+        const float2 xy = g.xy[i];
+        const Rect rc = tile_rect(xy.x, xy.y, radii[i], vp.gx, vp.gy);
+        const uint32_t dbits = __float_as_uint(g.depth[i]);
+        uint32_t n = 0;
+        for (int y = rc.y0; y < rc.y1; ++y)
+            for (int x = rc.x0; x < rc.x1; ++x, ++n) {
+                const uint32_t slot = atomicAdd(&s_cursor[y * vp.gx + x], 1u);   // LDS
+                if (slot < cap) {
+                    b.u_depth[slot] = dbits;
+                    b.u_idx[slot] = (uint32_t)i;
+                    b.u_p[slot] = p0 + n;
+                } else {
+                    overflow = true;
+                }
+            }
+    }
     if (overflow) g.counters[kCntOverflow] = 1u;
 }
 
 // ---------------------------------------------------------------------------------------- B2
-__global__ __launch_bounds__(kPreBlock) void k_gather_bwd(ViewParams vp, dm4d_raster_inputs in,
+__global__ __launch_bounds__(kPreThreads) void k_gather_bwd(ViewParams vp, dm4d_raster_inputs in,
                                                           const int32_t *__restrict__ radii, GeomPtrs g, BinPtrs b,
                                                           uint32_t cap, const float *__restrict__ dLt, BwdOutputs o)
 {
@@ -260,7 +319,7 @@ __global__ __launch_bounds__(kPreBlock) void k_gather_bwd(ViewParams vp, dm4d_ra
     const int tid = threadIdx.x;
     if (tid < 16) { sV[tid] = vp.view[tid]; sP[tid] = vp.proj[tid]; }
     __syncthreads();
-    const int i = blockIdx.x * kPreBlock + tid;
+    const int i = blockIdx.x * kPreThreads + tid;
     if (i >= in.N) return;
     const size_t si = (size_t)i;
 
@@ -447,7 +506,10 @@ int launch_preprocess(const ViewParams &vp, const dm4d_raster_inputs &in, int32_
 {
     const int nb = (in.N + kPreBlock - 1) / kPreBlock;
     if (nb == 0) return DM4D_OK;
-    hipLaunchKernelGGL(k_preprocess, dim3(nb), dim3(kPreBlock), 0, st, vp, in, radii, g);
+    const int T = vp.gx * vp.gy;
+    if ((size_t)T * 4 > 32768)
+        DM4D_HIP_CHECK(hipFuncSetAttribute((const void *)k_preprocess, hipFuncAttributeMaxDynamicSharedMemorySize, T * 4));
+    hipLaunchKernelGGL(k_preprocess, dim3(nb), dim3(kPreThreads), (size_t)T * 4, st, vp, in, radii, g, T);
     DM4D_HIP_CHECK(hipGetLastError());
     return DM4D_OK;
 }
@@ -455,9 +517,13 @@ int launch_preprocess(const ViewParams &vp, const dm4d_raster_inputs &in, int32_
 int launch_scatter(const ViewParams &vp, int N, const int32_t *radii, const GeomPtrs &g, const BinPtrs &b,
                    int64_t cap, hipStream_t st)
 {
+    // always launched (even with N == 0): workgroup 0 publishes tile_start for the render kernels
     const int nb = (N + kPreBlock - 1) / kPreBlock;
-    if (nb == 0) return DM4D_OK;
-    hipLaunchKernelGGL(k_scatter, dim3(nb), dim3(kPreBlock), 0, st, vp, N, radii, g, b, (uint32_t)cap);
+    const int T = vp.gx * vp.gy;
+    if ((size_t)T * 4 > 32768)
+        DM4D_HIP_CHECK(hipFuncSetAttribute((const void *)k_scatter, hipFuncAttributeMaxDynamicSharedMemorySize, T * 4));
+    hipLaunchKernelGGL(k_scatter, dim3(nb > 0 ? nb : 1), dim3(kPreThreads), (size_t)T * 4, st, vp, N, T, nb, radii, g,
+                       b, (uint32_t)cap);
     DM4D_HIP_CHECK(hipGetLastError());
     return DM4D_OK;
 }
@@ -465,9 +531,9 @@ int launch_scatter(const ViewParams &vp, int N, const int32_t *radii, const Geom
 int launch_gather_bwd(const ViewParams &vp, const dm4d_raster_inputs &in, const int32_t *radii, const GeomPtrs &g,
                       const BinPtrs &b, int64_t cap, const float *dLt, const BwdOutputs &o, hipStream_t st)
 {
-    const int nb = (in.N + kPreBlock - 1) / kPreBlock;
+    const int nb = (in.N + kPreThreads - 1) / kPreThreads;
     if (nb == 0) return DM4D_OK;
-    hipLaunchKernelGGL(k_gather_bwd, dim3(nb), dim3(kPreBlock), 0, st, vp, in, radii, g, b, (uint32_t)cap, dLt, o);
+    hipLaunchKernelGGL(k_gather_bwd, dim3(nb), dim3(kPreThreads), 0, st, vp, in, radii, g, b, (uint32_t)cap, dLt, o);
     DM4D_HIP_CHECK(hipGetLastError());
     return DM4D_OK;
 }
