@@ -46,6 +46,8 @@ _SIGNATURES = {
     "dm4d_version": (C.c_int, []),
     "dm4d_last_error": (C.c_char_p, []),
     "dm4d_device_count": (C.c_int, []),
+    "dm4d_profile_enable": (None, [C.c_uint]),
+    "dm4d_profile_collect": (C.c_int64, [C.c_int, C.POINTER(C.c_double)]),
     "dm4d_device_arch": (C.c_int, [C.c_int, C.c_char_p, C.c_int]),
     "dm4d_raster_geom_bytes": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32]),
     "dm4d_raster_binning_bytes": (C.c_size_t, [C.c_int64]),

@@ -20,6 +20,27 @@ void set_error(const char *fmt, ...)
     va_end(ap);
 }
 
+// ---- per-kernel HIP-event timing (off by default) ----------------------------------------
+struct ProfPair { hipEvent_t a, b; int id; };
+static unsigned g_prof_mask = 0;
+static std::vector<ProfPair> g_prof_pairs;
+
+ProfScope::ProfScope(int id_, hipStream_t st_) : id(id_), st(st_), slot(nullptr)
+{
+    if (!(g_prof_mask & (1u << id))) return;
+    ProfPair p;
+    p.id = id;
+    if (hipEventCreate(&p.a) != hipSuccess || hipEventCreate(&p.b) != hipSuccess) return;
+    (void)hipEventRecord(p.a, st);
+    g_prof_pairs.push_back(p);
+    slot = (void *)(uintptr_t)g_prof_pairs.size();
+}
+ProfScope::~ProfScope()
+{
+    if (!slot) return;
+    (void)hipEventRecord(g_prof_pairs[(size_t)(uintptr_t)slot - 1].b, st);
+}
+
 static int check_settings(const dm4d_raster_settings *s, const dm4d_raster_inputs *in)
 {
     if (!s || !in) { set_error("null settings/inputs"); return DM4D_ERR_INVALID; }
@@ -76,6 +97,28 @@ extern "C" {
 
 int dm4d_version(void) { return 100; }
 const char *dm4d_last_error(void) { return g_err; }
+
+void dm4d_profile_enable(unsigned kernel_mask) { g_prof_mask = kernel_mask; }
+
+/* Sums the recorded intervals of kernel `kernel_id` (synchronises the events), frees them.
+ * Returns the number of launches; *total_ms receives their summed duration. */
+int64_t dm4d_profile_collect(int kernel_id, double *total_ms)
+{
+    double tot = 0.0;
+    int64_t n = 0;
+    std::vector<ProfPair> keep;
+    for (auto &p : g_prof_pairs) {
+        if (p.id != kernel_id) { keep.push_back(p); continue; }
+        float ms = 0.f;
+        (void)hipEventSynchronize(p.b);
+        if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) { tot += ms; ++n; }
+        (void)hipEventDestroy(p.a);
+        (void)hipEventDestroy(p.b);
+    }
+    g_prof_pairs.swap(keep);
+    if (total_ms) *total_ms = tot;
+    return n;
+}
 
 int dm4d_device_count(void)
 {

@@ -22,6 +22,17 @@ namespace dm4d {
 
 void set_error(const char *fmt, ...);
 
+// Optional per-kernel timing with HIP events on the launch stream (bench.py's roofline leg).
+enum KernelId { kKPreprocess = 0, kKColscan, kKScatter, kKTileSort, kKRenderFwd, kKRenderBwd, kKGatherBwd,
+                kKSkinFwd, kKSkinBwd, kKFaceFwd, kKFaceBwd, kKKnn, kKernelCount };
+struct ProfScope {
+    int id;
+    hipStream_t st;
+    void *slot;
+    ProfScope(int id, hipStream_t st);
+    ~ProfScope();
+};
+
 __device__ __forceinline__ float as_f(uint32_t u) { return __uint_as_float(u); }
 __device__ __forceinline__ uint32_t as_u(float f) { return __float_as_uint(f); }
 

@@ -141,6 +141,7 @@ int launch_colscan(int N, int T, const GeomPtrs &g, hipStream_t st)
 {
     const int nb = (N + kPreBlock - 1) / kPreBlock;
     if (T <= 0) return DM4D_OK;
+    ProfScope prof_(kKColscan, st);
     hipLaunchKernelGGL(k_colscan, dim3((T + kColThreads - 1) / kColThreads), dim3(kColThreads), 0, st, nb, T, g);
     DM4D_HIP_CHECK(hipGetLastError());
     return DM4D_OK;
@@ -149,6 +150,7 @@ int launch_colscan(int N, int T, const GeomPtrs &g, hipStream_t st)
 int launch_tile_sort(int T, const GeomPtrs &g, const BinPtrs &b, int64_t cap, hipStream_t st)
 {
     if (T <= 0) return DM4D_OK;
+    ProfScope prof_(kKTileSort, st);
     hipLaunchKernelGGL(k_tile_sort, dim3(T), dim3(kSortThreads), 0, st, g, b, (uint32_t)cap);
     DM4D_HIP_CHECK(hipGetLastError());
     return DM4D_OK;

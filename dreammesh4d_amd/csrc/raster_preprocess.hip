@@ -509,6 +509,7 @@ int launch_preprocess(const ViewParams &vp, const dm4d_raster_inputs &in, int32_
     const int T = vp.gx * vp.gy;
     if ((size_t)T * 4 > 32768)
         DM4D_HIP_CHECK(hipFuncSetAttribute((const void *)k_preprocess, hipFuncAttributeMaxDynamicSharedMemorySize, T * 4));
+    ProfScope prof_(kKPreprocess, st);
     hipLaunchKernelGGL(k_preprocess, dim3(nb), dim3(kPreThreads), (size_t)T * 4, st, vp, in, radii, g, T);
     DM4D_HIP_CHECK(hipGetLastError());
     return DM4D_OK;
@@ -522,6 +523,7 @@ int launch_scatter(const ViewParams &vp, int N, const int32_t *radii, const Geom
     const int T = vp.gx * vp.gy;
     if ((size_t)T * 4 > 32768)
         DM4D_HIP_CHECK(hipFuncSetAttribute((const void *)k_scatter, hipFuncAttributeMaxDynamicSharedMemorySize, T * 4));
+    ProfScope prof_(kKScatter, st);
     hipLaunchKernelGGL(k_scatter, dim3(nb > 0 ? nb : 1), dim3(kPreThreads), (size_t)T * 4, st, vp, N, T, nb, radii, g,
                        b, (uint32_t)cap);
     DM4D_HIP_CHECK(hipGetLastError());
@@ -533,6 +535,7 @@ int launch_gather_bwd(const ViewParams &vp, const dm4d_raster_inputs &in, const 
 {
     const int nb = (in.N + kPreThreads - 1) / kPreThreads;
     if (nb == 0) return DM4D_OK;
+    ProfScope prof_(kKGatherBwd, st);
     hipLaunchKernelGGL(k_gather_bwd, dim3(nb), dim3(kPreThreads), 0, st, vp, in, radii, g, b, (uint32_t)cap, dLt, o);
     DM4D_HIP_CHECK(hipGetLastError());
     return DM4D_OK;

@@ -287,6 +287,7 @@ int launch_render_fwd(const ViewParams &vp, const float *colors, const GeomPtrs 
 {
     const int T = vp.gx * vp.gy;
     if (T <= 0) return DM4D_OK;
+    ProfScope prof_(kKRenderFwd, st);
     hipLaunchKernelGGL(k_render_fwd, dim3(T), dim3(kRenderThreads), 0, st, vp, colors, g, b, (uint32_t)cap, im,
                        out_color, out_depth, out_alpha);
     DM4D_HIP_CHECK(hipGetLastError());
@@ -299,6 +300,7 @@ int launch_render_bwd(const ViewParams &vp, const float *colors, const GeomPtrs 
 {
     const int T = vp.gx * vp.gy;
     if (T <= 0) return DM4D_OK;
+    ProfScope prof_(kKRenderBwd, st);
     hipLaunchKernelGGL(k_render_bwd, dim3(T), dim3(kRenderThreads), 0, st, vp, colors, g, b, (uint32_t)cap, im,
                        dL_dcolor, dL_ddepth, dL_dalpha, dLt);
     DM4D_HIP_CHECK(hipGetLastError());

@@ -48,6 +48,13 @@ const char *dm4d_last_error(void);
 int dm4d_device_count(void);
 int dm4d_device_arch(int dev, char *buf, int buflen);
 
+/* Per-kernel timing with HIP events recorded on the launch stream (used by bench.py for the
+ * roofline of the dominant kernel).  kernel ids: 0 preprocess, 1 colscan, 2 scatter,
+ * 3 tile_sort, 4 render_fwd, 5 render_bwd, 6 gather_bwd, 7 skin_fwd, 8 skin_bwd, 9 face_fwd,
+ * 10 face_bwd, 11 knn.  Process-global debug facility; off by default. */
+void dm4d_profile_enable(unsigned kernel_mask);
+int64_t dm4d_profile_collect(int kernel_id, double *total_ms);
+
 /* ------------------------------------------------------------------ rasterizer */
 
 /* GaussianRasterizationSettings (C/renderer/diff_sugar_rasterizer_temporal.py:129-142).

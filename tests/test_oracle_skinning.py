@@ -1,0 +1,138 @@
+"""Pins oracle/skinning.py by closed-form identities (CPU only).  pypose / pytorch3d are not
+available, so their conventions are "parity unpinned"; these identities are what any correct
+implementation of the reference math must satisfy."""
+import math
+
+import numpy as np
+import torch
+
+from dreammesh4d_amd import synthetic as syn
+from oracle import skinning as sk
+
+torch.manual_seed(0)
+D = torch.float64
+
+
+def _scene(n_faces=400, M=60, K=4):
+    sc = syn.mesh_bound_scene(n_faces, n_nodes=M, k=K, seed=1)
+    t = lambda a, dt=D: torch.tensor(a, dtype=dt)
+    w = t(sc["nbr_w"])
+    w = w / w.sum(dim=1, keepdim=True)          # exact row-normalisation in float64
+    return sc, t(sc["verts"]), torch.tensor(sc["faces"]), torch.tensor(sc["nbr_idx"]), w
+
+
+def _rand_unit_quat(n):
+    q = torch.randn(n, 4, dtype=D)
+    q = q / q.norm(dim=-1, keepdim=True)
+    return torch.where(q[:, 3:] < 0, -q, q)
+
+
+def test_log_exp_round_trip_and_matrix():
+    q = _rand_unit_quat(500)
+    r = sk.so3_log(q)
+    assert torch.allclose(sk.so3_exp(r), q, atol=1e-12)
+    R = sk.quat_matrix(q)
+    assert torch.allclose(R @ R.transpose(1, 2), torch.eye(3, dtype=D).expand(500, 3, 3), atol=1e-12)
+    assert torch.allclose(torch.linalg.det(R), torch.ones(500, dtype=D), atol=1e-12)
+    x, y, z, w = q.unbind(-1)
+    R_std = torch.stack([1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y),
+                         2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x),
+                         2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)], -1).reshape(-1, 3, 3)
+    assert torch.allclose(R, R_std, atol=1e-12)
+    # tiny-angle branches
+    tiny = torch.tensor([[1e-12, 0, 0, 1.0], [0, 0, 0, 1.0]], dtype=D)
+    assert torch.allclose(sk.so3_log(tiny), torch.tensor([[2e-12, 0, 0], [0, 0, 0]], dtype=D), atol=1e-20)
+    assert torch.allclose(sk.so3_exp(torch.zeros(1, 3, dtype=D)), torch.tensor([[0, 0, 0, 1.0]], dtype=D))
+    # Hamilton product composes rotations: R(a*b) = R(a) R(b)
+    a, b = _rand_unit_quat(50), _rand_unit_quat(50)
+    assert torch.allclose(sk.quat_matrix(sk.quat_mul(a, b)), sk.quat_matrix(a) @ sk.quat_matrix(b), atol=1e-12)
+
+
+def test_strain_matrix_layout():
+    s = torch.tensor([[0.1, 0.2, 0.3, 0.4, 0.5, 0.6]], dtype=D)
+    want = torch.tensor([[[1.1, 0.4, 0.5], [0.4, 1.2, 0.6], [0.5, 0.6, 1.3]]], dtype=D)
+    assert torch.allclose(sk.strain_to_matrix(s), want)
+
+
+def test_identity_deformation_is_static_geometry():
+    sc, verts, faces, idx, w = _scene()
+    M = sc["nodes"].shape[0]
+    z = lambda *s: torch.zeros(*s, dtype=D)
+    trans, rot, S, op = sk.node_attributes(z(M, 3), z(M, 4), z(M, 6), z(M, 1))
+    for method in ("lbs", "dqs", "hybrid"):
+        xyz, vrot = sk.skin_vertices(verts, idx, w, trans, rot, S, op, method)
+        assert torch.allclose(xyz, verts, atol=1e-12), method
+        assert torch.allclose(vrot, torch.tensor([0, 0, 0, 1.0], dtype=D).expand_as(vrot), atol=1e-12)
+    qs = sk.static_quaternions(verts, faces, torch.tensor(sc["complex"], dtype=D))
+    means, q, normals = sk.face_gaussians(xyz, vrot, faces, qs)
+    fv = verts[faces]
+    bary = sk.bary_table(6, D)
+    assert torch.allclose(means, (fv[:, None] * bary[None, :, :, None]).sum(-2).reshape(-1, 3), atol=1e-12)
+    assert torch.allclose(q, qs, atol=1e-12)
+    assert torch.allclose(normals, sk.face_normals(verts, faces).repeat_interleave(6, 0), atol=1e-9)
+    # first axis of the static frame is the face normal, and the frame is right-handed & orthonormal
+    Rs = sk.quat_matrix(qs[:, [1, 2, 3, 0]])
+    assert torch.allclose(Rs[:, :, 0], normals, atol=1e-9)
+    assert torch.allclose(torch.linalg.det(Rs), torch.ones(len(Rs), dtype=D), atol=1e-9)
+
+
+def test_single_rigid_motion_all_methods_agree():
+    sc, verts, faces, idx, w = _scene()
+    M = sc["nodes"].shape[0]
+    q0 = _rand_unit_quat(1)
+    t0 = torch.tensor([[0.05, -0.1, 0.2]], dtype=D)
+    ident = torch.tensor([[0, 0, 0, 1.0]], dtype=D)
+    dr = (q0 - ident).expand(M, 4).clone()          # node_attributes adds the identity and normalises
+    trans, rot, S, op = sk.node_attributes(t0.expand(M, 3).clone(), dr, torch.zeros(M, 6, dtype=D),
+                                           torch.randn(M, 1, dtype=D))
+    R0 = sk.quat_matrix(q0)[0]
+    want = verts @ R0.T + t0
+    for method in ("lbs", "dqs", "hybrid"):
+        xyz, vrot = sk.skin_vertices(verts, idx, w, trans, rot, S, op, method)
+        assert torch.allclose(xyz, want, atol=1e-10), method
+        assert torch.allclose(vrot, q0.expand_as(vrot), atol=1e-10)
+    qs = sk.static_quaternions(verts, faces, torch.tensor(sc["complex"], dtype=D))
+    means, q, normals = sk.face_gaussians(xyz, vrot, faces, qs)
+    m_static, _, n_static = sk.face_gaussians(verts, ident.expand(len(verts), 4), faces, qs)
+    assert torch.allclose(means, m_static @ R0.T + t0, atol=1e-10)
+    assert torch.allclose(normals, n_static @ R0.T, atol=1e-9)
+    Rq = sk.quat_matrix(q[:, [1, 2, 3, 0]])
+    assert torch.allclose(Rq, R0[None] @ sk.quat_matrix(qs[:, [1, 2, 3, 0]]), atol=1e-9)
+
+
+def test_hybrid_weight_and_static_attributes():
+    sc, verts, faces, idx, w = _scene()
+    M = sc["nodes"].shape[0]
+    g = torch.Generator().manual_seed(3)
+    dx = 0.05 * torch.randn(M, 3, dtype=D, generator=g)
+    dr = 0.1 * torch.randn(M, 4, dtype=D, generator=g)
+    ds = 0.05 * torch.randn(M, 6, dtype=D, generator=g)
+    do = torch.randn(M, 1, dtype=D, generator=g)
+    trans, rot, S, op = sk.node_attributes(dx, dr, ds, do)
+    x_l, _ = sk.skin_vertices(verts, idx, w, trans, rot, S, op, "lbs")
+    x_d, _ = sk.skin_vertices(verts, idx, w, trans, rot, S, op, "dqs")
+    x_h, _ = sk.skin_vertices(verts, idx, w, trans, rot, S, op, "hybrid")
+    eta = torch.clamp((w[..., None] * op[idx]).sum(1) + 0.4, max=1.0)
+    assert torch.allclose(x_h, eta * x_l + (1 - eta) * x_d, atol=1e-12)
+    assert (eta < 1).any() and (eta == 1).any()
+    assert not torch.allclose(x_l, x_d, atol=1e-4)
+    scales, opac, rgb = sk.static_attributes(torch.tensor(sc["log_scales"], dtype=D), torch.tensor(sc["densities"], dtype=D),
+                                             torch.tensor(sc["sh_dc"], dtype=D), 3.8e-6)
+    assert scales.shape == (sc["n_gaussians"], 3) and torch.all(scales[:, 0] == 3.8e-6)
+    assert torch.allclose(rgb, torch.tensor(sc["sh_dc"], dtype=D).view(-1, 3) * 0.28209479177387814 + 0.5)
+    assert opac.min() > 0 and opac.max() < 1
+
+
+def test_uv_sphere_face_counts():
+    for f in (8334, 16667, 33334):
+        v, fc = syn.uv_sphere(f)
+        assert abs(len(fc) - f) <= 0.02 * f and len(fc) % 2 == 0
+        assert fc.max() == len(v) - 1 and fc.min() == 0
+        # closed manifold: every edge shared by exactly two faces
+        e = np.sort(np.concatenate([fc[:, [0, 1]], fc[:, [1, 2]], fc[:, [2, 0]]]), axis=1)
+        _, cnt = np.unique(e, axis=0, return_counts=True)
+        assert np.all(cnt == 2)
+        # outward orientation
+        fv = v[fc]
+        n = np.cross(fv[:, 1] - fv[:, 0], fv[:, 2] - fv[:, 0])
+        assert np.all((n * fv.mean(1)).sum(1) > 0)
