@@ -34,6 +34,10 @@ class GaussianRasterizationSettings(NamedTuple):
     debug: bool
 
 
+# diagnostics for bench.py: num_rendered (duplicate count D) of the most recent forward calls
+LAST_NUM_RENDERED = []
+
+
 def _f32(t, device):
     return t.detach().to(device=device, dtype=torch.float32).contiguous()
 
@@ -115,6 +119,8 @@ class _RasterizeGaussians(torch.autograd.Function):
                                                depth.data_ptr(), alpha.data_ptr(), st), "dm4d_rasterize_render")
         ctx.call = call
         ctx.num_rendered = int(D)
+        LAST_NUM_RENDERED.append(int(D))
+        del LAST_NUM_RENDERED[:-64]
         ctx.shapes = (means3D.shape, means2D.shape, sh.shape, colors_precomp.shape, opacities.shape, scales.shape,
                       rotations.shape, cov3Ds_precomp.shape)
         ctx.save_for_backward(radii, geom, binning, image)
