@@ -35,7 +35,7 @@ class RasterSettings(C.Structure):
 
 class RasterInputs(C.Structure):
     _fields_ = [
-        ("N", C.c_int32), ("sh_coeffs", C.c_int32), ("means3D", vp), ("shs", vp), ("colors_precomp", vp),
+        ("N", C.c_int32), ("sh_coeffs", C.c_int32), ("n_channels", C.c_int32), ("means3D", vp), ("shs", vp), ("colors_precomp", vp),
         ("opacities", vp), ("scales", vp), ("rotations", vp), ("cov3D_precomp", vp),
     ]
 
@@ -52,7 +52,8 @@ _SIGNATURES = {
     "dm4d_raster_geom_bytes": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32]),
     "dm4d_raster_binning_bytes": (C.c_size_t, [C.c_int64]),
     "dm4d_raster_image_bytes": (C.c_size_t, [C.c_int32, C.c_int32]),
-    "dm4d_raster_grad_bytes": (C.c_size_t, [C.c_int64]),
+    "dm4d_raster_grad_bytes": (C.c_size_t, [C.c_int64, C.c_int32]),
+    "dm4d_selftest_wave_reduce": (C.c_int, [vp, vp, vp]),
     "dm4d_rasterize_prepare": (C.c_int, [C.POINTER(RasterSettings), C.POINTER(RasterInputs), vp, vp, C.c_size_t, vp]),
     "dm4d_rasterize_num_rendered": (C.c_int64, [vp, vp]),
     "dm4d_rasterize_render": (C.c_int, [C.POINTER(RasterSettings), C.POINTER(RasterInputs), vp, vp, vp, C.c_int64,

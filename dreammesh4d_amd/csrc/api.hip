@@ -62,6 +62,11 @@ static int check_settings(const dm4d_raster_settings *s, const dm4d_raster_input
             set_error("Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!");
             return DM4D_ERR_INVALID;
         }
+        if (in->n_channels != 0 && in->n_channels != 3 && in->n_channels != 6) {
+            set_error("n_channels must be 3 or 6 (got %d)", in->n_channels);
+            return DM4D_ERR_INVALID;
+        }
+        if (in->n_channels == 6 && in->shs) { set_error("6 channels need colors_precomp"); return DM4D_ERR_INVALID; }
         if (in->shs && (s->sh_degree != 0 || in->sh_coeffs < 1)) {
             set_error("sh_degree %d with %d coefficients is not supported (only degree 0)", s->sh_degree, in->sh_coeffs);
             return DM4D_ERR_UNSUPPORTED;
@@ -70,9 +75,10 @@ static int check_settings(const dm4d_raster_settings *s, const dm4d_raster_input
     return DM4D_OK;
 }
 
-static ViewParams view_params(const dm4d_raster_settings *s)
+static ViewParams view_params(const dm4d_raster_settings *s, const dm4d_raster_inputs *in)
 {
     ViewParams vp;
+    vp.C = (in && in->n_channels > 3) ? 6 : 3;
     vp.W = s->image_width;
     vp.H = s->image_height;
     vp.gx = (vp.W + kTile - 1) / kTile;
@@ -138,7 +144,7 @@ int dm4d_device_arch(int dev, char *buf, int buflen)
 size_t dm4d_raster_geom_bytes(int32_t N, int32_t H, int32_t W) { return geom_layout(N, H, W).total; }
 size_t dm4d_raster_binning_bytes(int64_t capacity) { return binning_bytes(capacity); }
 size_t dm4d_raster_image_bytes(int32_t H, int32_t W) { return image_bytes(H, W); }
-size_t dm4d_raster_grad_bytes(int64_t capacity) { return grad_bytes(capacity); }
+size_t dm4d_raster_grad_bytes(int64_t capacity, int32_t n_channels) { return grad_bytes(capacity, n_channels > 3 ? 6 : 3); }
 
 int dm4d_rasterize_prepare(const dm4d_raster_settings *s, const dm4d_raster_inputs *in, int32_t *radii, void *geom,
                            size_t geom_bytes_, dm4d_stream_t stream)
@@ -150,7 +156,7 @@ int dm4d_rasterize_prepare(const dm4d_raster_settings *s, const dm4d_raster_inpu
     if (in->N > 0 && !radii) { set_error("radii missing"); return DM4D_ERR_INVALID; }
     hipStream_t st = (hipStream_t)stream;
     const GeomPtrs g = geom_ptrs(geom, L);
-    const ViewParams vp = view_params(s);
+    const ViewParams vp = view_params(s, in);
     DM4D_HIP_CHECK(hipMemsetAsync((char *)geom + L.zero_begin, 0, L.zero_bytes, st));
     rc = launch_preprocess(vp, *in, radii, g, st);
     if (rc) return rc;
@@ -190,11 +196,11 @@ int dm4d_rasterize_render(const dm4d_raster_settings *s, const dm4d_raster_input
     const GeomPtrs g = geom_ptrs(geom, L);
     const BinPtrs b = bin_ptrs(binning, capacity);
     const ImgPtrs im = img_ptrs(image, s->image_height, s->image_width);
-    const ViewParams vp = view_params(s);
+    const ViewParams vp = view_params(s, in);
     const float *colors = in->colors_precomp ? in->colors_precomp : g.rgb;
     rc = launch_scatter(vp, in->N, radii, g, b, capacity, st);
     if (rc) return rc;
-    rc = launch_tile_sort(L.T, g, b, capacity, st);
+    rc = launch_tile_sort(vp, g, b, capacity, st);
     if (rc) return rc;
     return launch_render_fwd(vp, colors, g, b, capacity, im, out_color, out_depth, out_alpha, st);
 }
@@ -215,7 +221,7 @@ int dm4d_rasterize_backward(const dm4d_raster_settings *s, const dm4d_raster_inp
     const GeomPtrs g = geom_ptrs(const_cast<void *>(geom), L);
     const BinPtrs b = bin_ptrs(const_cast<void *>(binning), capacity);
     const ImgPtrs im = img_ptrs(const_cast<void *>(image), s->image_height, s->image_width);
-    const ViewParams vp = view_params(s);
+    const ViewParams vp = view_params(s, in);
     const float *colors = in->colors_precomp ? in->colors_precomp : g.rgb;
     rc = launch_render_bwd(vp, colors, g, b, capacity, im, dL_dcolor, dL_ddepth, dL_dalpha, (float *)grad, st);
     if (rc) return rc;
@@ -293,6 +299,13 @@ int dm4d_raster_read_image_state(const void *image, int32_t H, int32_t W, uint32
     DM4D_HIP_CHECK(hipMemcpyAsync(n_contrib, im.n_contrib, P * 4, hipMemcpyDeviceToHost, st));
     DM4D_HIP_CHECK(hipStreamSynchronize(st));
     return DM4D_OK;
+}
+
+/* Self-test of the packed wave reduction: in [16][64] floats, out [16] sums (device pointers). */
+int dm4d_selftest_wave_reduce(const float *in, float *out, dm4d_stream_t stream)
+{
+    if (!in || !out) { set_error("null"); return DM4D_ERR_INVALID; }
+    return launch_selftest_reduce(in, out, (hipStream_t)stream);
 }
 
 int dm4d_mark_visible(int32_t N, const float *means3D, const float *viewmatrix, uint8_t *present, dm4d_stream_t stream)

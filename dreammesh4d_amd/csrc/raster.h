@@ -6,9 +6,10 @@
 //   K2 colscan         1 thread / tile       exclusive scan of hist over WGs, tile counts
 //   K3 scatter         1024 Gaussians / WG   duplicates -> per-tile segments via LDS cursors
 //                                            (no global atomics anywhere in binning)
-//   K4 tile_sort       1 workgroup / tile    LDS bitonic sort by (depth bits, id)
-//   K5 render_fwd      1 workgroup / tile    4 waves = 4 8x8 quadrants, LDS-staged lists
-//   B1 render_bwd      1 workgroup / tile    per-duplicate partial grads, no atomics
+//   K4 tile_sort       1 workgroup / tile    LDS bitonic sort by (depth bits, id); then the
+//                                            tile's list is split into four 8x8-quadrant lists
+//   K5 render_fwd      1 WAVE / quadrant     own depth-sorted list, no barriers, early exit
+//   B1 render_bwd      1 WAVE / quadrant     per-(duplicate, quadrant) partial grads, no atomics
 //   B2 gather_bwd      1 thread / Gaussian   deterministic gather + preprocess backward
 #pragma once
 #include <stddef.h>
@@ -23,7 +24,14 @@ constexpr int kPreThreads = 256; // threads per workgroup in K1/K3/B2
 constexpr int kPreItems = 4;     // Gaussians per thread in K1/K3
 constexpr int kPreBlock = kPreThreads * kPreItems;   // Gaussians per workgroup in K1/K3
 constexpr int kMaxTiles = 36864; // tile histogram lives in LDS (4 B/tile of the 160 KB): <= 3072x3072 px
-constexpr int kGradStride = 12;  // floats per duplicate in the backward scratch (10 used)
+constexpr int kMaxChannels = 6;  // colour channels blended per pass: 3 (drop-in operator) or 6 (RGB + normal)
+// floats per (duplicate, quadrant) record of the backward scratch: 2 mean + 3 conic + opacity + depth + C colours
+#ifdef __HIPCC__
+#define DM4D_HD __host__ __device__
+#else
+#define DM4D_HD
+#endif
+DM4D_HD static inline int grad_stride(int C) { return C <= 3 ? 12 : 16; }
 
 enum GeomCounter { kCntD = 0, kCntOverflow = 1 };
 
@@ -32,7 +40,7 @@ static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; 
 struct GeomLayout {
     int N, T, nb;
     size_t counters, xy, depth, conic_opacity, rgb, tiles_touched, offsets, clamped, block_sums, hist,
-        tile_count, tile_start, tile_written, zero_begin, zero_bytes, total;
+        tile_count, tile_start, qcount, qdone, qkmax, zero_begin, zero_bytes, total;
 };
 
 static inline GeomLayout geom_layout(int N, int H, int W)
@@ -51,7 +59,9 @@ static inline GeomLayout geom_layout(int N, int H, int W)
     L.zero_bytes = o;
     L.tile_count = take((size_t)L.T * 4);
     L.tile_start = take((size_t)(L.T + 1) * 4);
-    L.tile_written = take((size_t)L.T * 4);
+    L.qcount = take((size_t)L.T * 16);   // entries of each quadrant list            [T][4]
+    L.qdone = take((size_t)L.T * 16);    // entries the forward consumed               [T][4]
+    L.qkmax = take((size_t)L.T * 16);    // tile-list position bound of those entries  [T][4]
     L.xy = take(n * 8);
     L.depth = take(n * 4);
     L.conic_opacity = take(n * 16);
@@ -78,7 +88,9 @@ struct GeomPtrs {
     uint32_t *hist;        // [nb][T] per-WG tile histogram, exclusive-scanned over WGs in place by K2
     uint32_t *tile_count;
     uint32_t *tile_start;
-    uint32_t *tile_written;
+    uint32_t *qcount;
+    uint32_t *qdone;
+    uint32_t *qkmax;
 };
 
 static inline GeomPtrs geom_ptrs(void *base, const GeomLayout &L)
@@ -97,7 +109,9 @@ static inline GeomPtrs geom_ptrs(void *base, const GeomLayout &L)
     p.hist = (uint32_t *)(b + L.hist);
     p.tile_count = (uint32_t *)(b + L.tile_count);
     p.tile_start = (uint32_t *)(b + L.tile_start);
-    p.tile_written = (uint32_t *)(b + L.tile_written);
+    p.qcount = (uint32_t *)(b + L.qcount);
+    p.qdone = (uint32_t *)(b + L.qdone);
+    p.qkmax = (uint32_t *)(b + L.qkmax);
     return p;
 }
 
@@ -107,11 +121,14 @@ struct BinPtrs {
     uint32_t *u_p;        // Gaussian-major duplicate index (offsets[g] + i)
     uint32_t *point_list; // sorted Gaussian ids  (== upstream point_list)
     uint32_t *sorted_pos; // Gaussian-major duplicate index -> position in point_list
+    uint2 *qlist;         // [4][cap] quadrant lists: (Gaussian id, position k in the tile list),
+                          // quadrant q of tile t at qlist[q*cap + tile_start[t] ...]
+    size_t cap;
 };
 static inline size_t binning_bytes(int64_t cap)
 {
     size_t c = (size_t)(cap > 0 ? cap : 1);
-    return 5 * align_up(c * 4, 256);
+    return 5 * align_up(c * 4, 256) + align_up(c * 32, 256);
 }
 static inline BinPtrs bin_ptrs(void *base, int64_t cap)
 {
@@ -124,6 +141,8 @@ static inline BinPtrs bin_ptrs(void *base, int64_t cap)
     p.u_p = (uint32_t *)(b + 2 * stride);
     p.point_list = (uint32_t *)(b + 3 * stride);
     p.sorted_pos = (uint32_t *)(b + 4 * stride);
+    p.qlist = (uint2 *)(b + 5 * stride);
+    p.cap = c;
     return p;
 }
 
@@ -145,18 +164,43 @@ static inline ImgPtrs img_ptrs(void *base, int H, int W)
     p.n_contrib = (uint32_t *)((char *)base + stride);
     return p;
 }
-static inline size_t grad_bytes(int64_t cap)
+static inline size_t grad_bytes(int64_t cap, int C)
 {
     size_t c = (size_t)(cap > 0 ? cap : 1);
-    return align_up(c * kGradStride * 4, 256);
+    return align_up(4 * c * grad_stride(C) * 4, 256);   // 4 quadrant slices
 }
 
 // Camera / image constants handed to kernels by value.
 struct ViewParams {
-    int W, H, gx, gy;
+    int W, H, gx, gy, C;   // C = colour channels (3 or 6)
     float tanfovx, tanfovy, focal_x, focal_y, scale_modifier;
     const float *bg, *view, *proj, *campos;
 };
+
+#ifdef __HIPCC__
+// 4-bit mask of the 8x8 quadrants of the tile with origin (ox, oy) that the alpha >= 1/255
+// support of a splat can reach: exact axis-aligned bound of the ellipse
+// { d : 1/2 d^T A d <= ln(255 o) }, inflated by margins that cover the rounding of log/sqrt/div.
+// Conservative, so culled (splat, pixel) pairs are exactly ones the reference `continue`s on.
+// Used by K4 (to build the quadrant lists) and recomputed by B2 (to find the written records):
+// both run the SAME device code on the SAME inputs, so the masks agree bit-for-bit.
+__device__ __forceinline__ uint32_t quadrant_mask(float x, float y, float ca, float cb, float cc, float o, float ox,
+                                                  float oy)
+{
+    if (o < 1.0f / 255.0f) return 0u;   // alpha <= opacity < 1/255 for every pixel
+    const float tau = __logf(255.0f * o) * 1.001f + 0.01f;
+    const float det = ca * cc - cb * cb;
+    const float hx = sqrtf(2.0f * tau * cc / det) * 1.0001f + 0.02f;
+    const float hy = sqrtf(2.0f * tau * ca / det) * 1.0001f + 0.02f;
+    if (!(det > 0.f) || !(hx == hx) || !(hy == hy)) return 0xFu;
+    const bool x0 = (x + hx >= ox) && (x - hx <= ox + 7.0f);
+    const bool x1 = (x + hx >= ox + 8.0f) && (x - hx <= ox + 15.0f);
+    const bool y0 = (y + hy >= oy) && (y - hy <= oy + 7.0f);
+    const bool y1 = (y + hy >= oy + 8.0f) && (y - hy <= oy + 15.0f);
+    return (uint32_t)(x0 && y0) | ((uint32_t)(x1 && y0) << 1) | ((uint32_t)(x0 && y1) << 2) |
+           ((uint32_t)(x1 && y1) << 3);
+}
+#endif
 
 // ---- launchers (defined in the .hip files) ---------------------------------------------
 int launch_preprocess(const ViewParams &vp, const dm4d_raster_inputs &in, int32_t *radii, const GeomPtrs &g,
@@ -164,8 +208,8 @@ int launch_preprocess(const ViewParams &vp, const dm4d_raster_inputs &in, int32_
 int launch_colscan(int N, int T, const GeomPtrs &g, hipStream_t st);
 int launch_scatter(const ViewParams &vp, int N, const int32_t *radii, const GeomPtrs &g, const BinPtrs &b,
                    int64_t cap, hipStream_t st);
-int launch_tile_sort(int T, const GeomPtrs &g, const BinPtrs &b, int64_t cap, hipStream_t st);
-int launch_render_fwd(const ViewParams &vp, const float *colors /* [N,3] */, const GeomPtrs &g, const BinPtrs &b,
+int launch_tile_sort(const ViewParams &vp, const GeomPtrs &g, const BinPtrs &b, int64_t cap, hipStream_t st);
+int launch_render_fwd(const ViewParams &vp, const float *colors /* [N,C] */, const GeomPtrs &g, const BinPtrs &b,
                       int64_t cap, const ImgPtrs &im, float *out_color, float *out_depth, float *out_alpha,
                       hipStream_t st);
 int launch_render_bwd(const ViewParams &vp, const float *colors, const GeomPtrs &g, const BinPtrs &b, int64_t cap,
@@ -177,5 +221,6 @@ struct BwdOutputs {
 int launch_gather_bwd(const ViewParams &vp, const dm4d_raster_inputs &in, const int32_t *radii, const GeomPtrs &g,
                       const BinPtrs &b, int64_t cap, const float *dLt, const BwdOutputs &o, hipStream_t st);
 int launch_mark_visible(int N, const float *means3D, const float *view, uint8_t *present, hipStream_t st);
+int launch_selftest_reduce(const float *in, float *out, hipStream_t st);
 
 }  // namespace dm4d

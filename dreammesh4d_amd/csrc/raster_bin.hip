@@ -86,17 +86,68 @@ __device__ __forceinline__ void bitonic_network(uint32_t n, Swap &&cmpswap)
     }
 }
 
-__global__ __launch_bounds__(kSortThreads) void k_tile_sort(GeomPtrs g, BinPtrs b, uint32_t cap)
+// Split the sorted tile list into the four quadrant lists (stable compaction by quadrant_mask).
+template <typename GidAt>
+__device__ __forceinline__ void build_quadrant_lists(const ViewParams &vp, int tile, uint32_t s, uint32_t n,
+                                                     const GeomPtrs &g, const BinPtrs &b, uint32_t cap, GidAt &&gid_at)
+{
+    __shared__ uint32_t s_qbase[4];
+    __shared__ uint32_t s_wq[kSortThreads / 64][4];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const float ox = (float)((tile % vp.gx) * kTile), oy = (float)((tile / vp.gx) * kTile);
+    if (tid < 4) s_qbase[tid] = 0u;
+    __syncthreads();
+    for (uint32_t e0 = 0; e0 < n; e0 += kSortThreads) {
+        const uint32_t e = e0 + tid;
+        uint32_t m = 0u, gid = 0u;
+        if (e < n) {
+            gid = gid_at(e);
+            const float2 xy = g.xy[gid];
+            const float4 co = g.conic_opacity[gid];
+            m = quadrant_mask(xy.x, xy.y, co.x, co.y, co.z, co.w, ox, oy);
+        }
+        uint64_t bal[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) bal[q] = __ballot((m >> q) & 1u);
+        if (lane == 0) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) s_wq[wv][q] = (uint32_t)__popcll(bal[q]);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            if ((m >> q) & 1u) {
+                uint32_t pos = s_qbase[q] + mbcnt(bal[q]);
+                for (int w = 0; w < wv; ++w) pos += s_wq[w][q];
+                if (s + pos < cap) b.qlist[(size_t)q * b.cap + s + pos] = make_uint2(gid, e);
+            }
+        }
+        __syncthreads();
+        if (tid < 4) {
+            uint32_t add = 0;
+#pragma unroll
+            for (int w = 0; w < kSortThreads / 64; ++w) add += s_wq[w][tid];
+            s_qbase[tid] += add;
+        }
+        __syncthreads();
+    }
+    if (tid < 4) g.qcount[tile * 4 + tid] = s_qbase[tid];
+}
+
+__global__ __launch_bounds__(kSortThreads) void k_tile_sort(ViewParams vp, GeomPtrs g, BinPtrs b, uint32_t cap)
 {
     __shared__ uint64_t s_key[kSortLdsCap];
     __shared__ uint32_t s_p[kSortLdsCap];
     const int t = blockIdx.x;
+    const int tid = threadIdx.x;
     const uint32_t s = g.tile_start[t];
     uint32_t n = g.tile_count[t];
-    if (s >= cap) return;
-    if (s + n > cap) n = cap - s;   // overflow: memory-safe, result flagged invalid by K3
-    if (n == 0) return;
-    const int tid = threadIdx.x;
+    if (s >= cap) n = 0;
+    else if (s + n > cap) n = cap - s;   // overflow: memory-safe, result flagged invalid by K3
+    if (n == 0) {
+        if (tid < 4) g.qcount[t * 4 + tid] = 0u;
+        return;
+    }
     if (n <= (uint32_t)kSortLdsCap) {
         for (uint32_t e = tid; e < n; e += kSortThreads) {
             s_key[e] = ((uint64_t)b.u_depth[s + e] << 32) | b.u_idx[s + e];
@@ -117,6 +168,7 @@ __global__ __launch_bounds__(kSortThreads) void k_tile_sort(GeomPtrs g, BinPtrs 
             const uint32_t p = s_p[e];
             if (p < cap) b.sorted_pos[p] = s + e;
         }
+        build_quadrant_lists(vp, t, s, n, g, b, cap, [&](uint32_t e) { return (uint32_t)s_key[e]; });
     } else {
         // Oversized tile: same network on the HBM-resident segment (one workgroup; rare).
         uint32_t *kd = b.u_depth + s, *ki_ = b.u_idx + s, *kp = b.u_p + s;
@@ -134,6 +186,7 @@ __global__ __launch_bounds__(kSortThreads) void k_tile_sort(GeomPtrs g, BinPtrs 
             const uint32_t p = kp[e];
             if (p < cap) b.sorted_pos[p] = s + e;
         }
+        build_quadrant_lists(vp, t, s, n, g, b, cap, [&](uint32_t e) { return ki_[e]; });
     }
 }
 
@@ -147,11 +200,12 @@ int launch_colscan(int N, int T, const GeomPtrs &g, hipStream_t st)
     return DM4D_OK;
 }
 
-int launch_tile_sort(int T, const GeomPtrs &g, const BinPtrs &b, int64_t cap, hipStream_t st)
+int launch_tile_sort(const ViewParams &vp, const GeomPtrs &g, const BinPtrs &b, int64_t cap, hipStream_t st)
 {
+    const int T = vp.gx * vp.gy;
     if (T <= 0) return DM4D_OK;
     ProfScope prof_(kKTileSort, st);
-    hipLaunchKernelGGL(k_tile_sort, dim3(T), dim3(kSortThreads), 0, st, g, b, (uint32_t)cap);
+    hipLaunchKernelGGL(k_tile_sort, dim3(T), dim3(kSortThreads), 0, st, vp, g, b, (uint32_t)cap);
     DM4D_HIP_CHECK(hipGetLastError());
     return DM4D_OK;
 }

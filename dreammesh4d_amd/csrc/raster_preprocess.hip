@@ -323,12 +323,16 @@ __global__ __launch_bounds__(kPreThreads) void k_gather_bwd(ViewParams vp, dm4d_
     if (i >= in.N) return;
     const size_t si = (size_t)i;
 
-    float acc[10];
+    // acc: 0,1 dL/dmean2D (NDC) | 2,3,4 dL/dconic (A,B,C) | 5 dL/dopacity | 6 dL/ddepth | 7.. dL/dcolour
+    float acc[7 + kMaxChannels];
 #pragma unroll
-    for (int k = 0; k < 10; ++k) acc[k] = 0.f;
+    for (int k = 0; k < 7 + kMaxChannels; ++k) acc[k] = 0.f;
     const int r = radii[i];
+    const int C = vp.C;
     if (r > 0) {
+        const int GS = grad_stride(C);
         const float2 xy = g.xy[i];
+        const float4 co = g.conic_opacity[i];
         const Rect rc = tile_rect(xy.x, xy.y, r, vp.gx, vp.gy);
         uint32_t p = g.offsets[i];
         for (int y = rc.y0; y < rc.y1; ++y)
@@ -338,28 +342,34 @@ __global__ __launch_bounds__(kPreThreads) void k_gather_bwd(ViewParams vp, dm4d_
                 const uint32_t pos = b.sorted_pos[p];
                 if (pos >= cap) continue;
                 const uint32_t k = pos - g.tile_start[t];
-                if (k >= g.tile_written[t]) continue;   // behind every pixel's last contributor
-                const float4 *src = reinterpret_cast<const float4 *>(dLt + (size_t)pos * kGradStride);
-                const float4 a0 = src[0], a1 = src[1], a2 = src[2];
-                acc[0] += a0.x; acc[1] += a0.y; acc[2] += a0.z; acc[3] += a0.w;
-                acc[4] += a1.x; acc[5] += a1.y; acc[6] += a1.z; acc[7] += a1.w;
-                acc[8] += a2.x; acc[9] += a2.y;
+                // the same mask K4 used to build the quadrant lists (same code, same inputs)
+                const uint32_t m = quadrant_mask(xy.x, xy.y, co.x, co.y, co.z, co.w, (float)(x * kTile), (float)(y * kTile));
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    if (!((m >> q) & 1u) || k >= g.qkmax[t * 4 + q]) continue;   // record not written
+                    const float4 *src = reinterpret_cast<const float4 *>(dLt + ((size_t)q * b.cap + pos) * GS);
+                    const float4 a0 = src[0], a1 = src[1], a2 = src[2];
+                    acc[0] += a0.x; acc[1] += a0.y; acc[2] += a0.z; acc[3] += a0.w;
+                    acc[4] += a1.x; acc[5] += a1.y; acc[6] += a1.z; acc[7] += a1.w;
+                    acc[8] += a2.x; acc[9] += a2.y;
+                    if (C > 3) {
+                        const float4 a3 = src[3];
+                        acc[10] += a2.z; acc[11] += a2.w; acc[12] += a3.x;
+                    }
+                }
             }
     }
-    // acc: 0,1 = dL/dmean2D (NDC)  2,3,4 = dL/dconic (A,B,C)  5 = dL/dopacity  6..8 = dL/dcolor  9 = dL/ddepth
     o.dL_dmeans2D[3 * si + 0] = acc[0];
     o.dL_dmeans2D[3 * si + 1] = acc[1];
     o.dL_dmeans2D[3 * si + 2] = 0.f;
     if (o.dL_dopacity) o.dL_dopacity[si] = acc[5];
     if (o.dL_dcolors) {
-        o.dL_dcolors[3 * si + 0] = acc[6];
-        o.dL_dcolors[3 * si + 1] = acc[7];
-        o.dL_dcolors[3 * si + 2] = acc[8];
+        for (int ch = 0; ch < C; ++ch) o.dL_dcolors[(size_t)C * si + ch] = acc[7 + ch];
     }
     if (o.dL_dsh && in.shs) {
         const int M = in.sh_coeffs;
         for (int ch = 0; ch < 3; ++ch)
-            o.dL_dsh[si * M * 3 + ch] = (r > 0 && !g.clamped[3 * si + ch]) ? DM4D_SH_C0 * acc[6 + ch] : 0.f;
+            o.dL_dsh[si * M * 3 + ch] = (r > 0 && !g.clamped[3 * si + ch]) ? DM4D_SH_C0 * acc[7 + ch] : 0.f;
         for (int k = 3; k < 3 * M; ++k) o.dL_dsh[si * M * 3 + k] = 0.f;
     }
 
@@ -443,7 +453,7 @@ __global__ __launch_bounds__(kPreThreads) void k_gather_bwd(ViewParams vp, dm4d_
         {
             const float mul3 = sV[2] * m.x + sV[6] * m.y + sV[10] * m.z + sV[14];
 #pragma unroll
-            for (int j = 0; j < 3; ++j) dmean[j] += (sV[j * 4 + 2] - sV[j * 4 + 3] * mul3) * acc[9];
+            for (int j = 0; j < 3; ++j) dmean[j] += (sV[j * 4 + 2] - sV[j * 4 + 3] * mul3) * acc[6];
         }
         // ---- cov3D -> scale / rotation ----
         if (!in.cov3D_precomp) {

@@ -1,226 +1,260 @@
 // raster_render.hip -- alpha-compositing kernels of the tile rasterizer (gfx950, wave64).
 //
-// One workgroup per 16x16 tile (the reference's BLOCK_X x BLOCK_Y, so tile lists, n_contrib
-// and final_T keep their upstream meaning), 4 waves, and each WAVE owns one 8x8 pixel
-// quadrant.  The tile's depth-sorted list is staged through LDS 256 entries at a time with
-// coalesced gathers; while staging, each entry gets a 4-bit quadrant mask from the exact
-// axis-aligned bound of its alpha >= 1/255 ellipse, and every wave compacts the staged chunk
-// to the entries that can touch ITS quadrant (ballot + mbcnt).  Mesh-bound splats are ~1 px
-// wide, so this removes about half of the per-pixel evaluations the reference performs, without
-// changing a single result: culled (entry, pixel) pairs are exactly ones upstream `continue`s on.
+// Execution unit = ONE WAVE per 8x8-pixel quadrant of a 16x16 tile.  Tiles stay 16x16 (the
+// reference's BLOCK_X x BLOCK_Y) so tile lists, keys, n_contrib and final_T keep their
+// upstream meaning, but K4 splits every tile's depth-sorted list into four quadrant lists using
+// the exact bound of each splat's alpha >= 1/255 ellipse (quadrant_mask, raster.h).  A
+// mesh-bound splat is ~1 px wide, so a quadrant list holds under half of its tile's list, and
+// culled (splat, pixel) pairs are exactly ones the reference `continue`s on: results are
+// unchanged.  One wave per workgroup means no barriers at all, 4x more independent work items
+// than tiles for the 256 CUs to balance, and early exit at 8x8 granularity.
 //
-// Forward  (K5): front-to-back blend, early exit per wave (ballot) and per tile.
-// Backward (B1): back-to-front; the per-(entry, wave) sums over 64 pixels are reduced with DPP
-//                row operations, combined across the 4 waves in fixed order in LDS and written
-//                ONCE per duplicate to a scratch array -- no floating-point atomics, so the
-//                gradients are bit-reproducible run to run.  B2 (raster_preprocess.hip)
-//                gathers them per Gaussian.
+// Forward  (K5): 64 list entries at a time are gathered by the 64 lanes (coalesced list read,
+//                L2-resident attribute gathers), double-buffered through wave-private LDS; every
+//                lane then walks the chunk with broadcast LDS reads.  Front-to-back blend;
+//                the wave stops when all 64 pixels are saturated (ballot).
+// Backward (B1): back-to-front over the entries the forward consumed.  The 64-pixel sums of the
+//                10 (13 with 6 colour channels) per-entry gradients use a packed butterfly:
+//                v_permlane32_swap and v_permlane16_swap fold 4 values into one register before
+//                the in-row DPP steps (28 instead of 60 cross-lane instructions), and one
+//                store writes the whole record.  Records are indexed by (quadrant, tile-list
+//                position): no floating-point atomics, gradients are bit-reproducible.
+//
+// blockIdx -> (tile, quadrant) keeps the 4 quadrants of a tile on ONE XCD (blocks are dispatched
+// round-robin over the 8 XCDs), so the attribute gathers of neighbouring quadrants share an L2.
 //
 // Replaces renderCUDA fwd/bwd of the un-vendored diff-gaussian-rasterization (ashawkey fork:
 // extra depth and alpha channels) used at
 // custom/threestudio-dreammesh4d/renderer/diff_sugar_rasterizer_temporal.py:169-178,202-211.
+// C = 6 blends the RGB pass and the normal pass of one view together (same geometry, :202-211).
 #include "common.h"
 #include "raster.h"
 
 namespace dm4d {
 
-constexpr int kChunk = 256;
-constexpr int kRenderThreads = 256;
+typedef unsigned int u2v __attribute__((ext_vector_type(2)));
 
-struct Staged {
-    float4 a;  // x, y, conic.x, conic.y
-    float4 b;  // conic.z, opacity, depth, -
-    float4 c;  // r, g, b, -
-};
+template <int C> struct StagedN { static constexpr int kVec = (C <= 3) ? 3 : 4; };
 
-// 4-bit mask of the 8x8 quadrants of tile (ox, oy) that the alpha >= 1/255 support of the
-// splat can reach.  Conservative (margins cover the rounding of log/sqrt/div).
-__device__ __forceinline__ uint32_t quadrant_mask(float x, float y, float ca, float cb, float cc, float o, float ox,
-                                                  float oy)
+// gather one list entry: a = (x, y, conic.x, conic.y)  b = (conic.z, opacity, depth, k bits)
+//                        c = colours 0..3               d = colours 4..5
+template <int C>
+__device__ __forceinline__ void gather_entry(const uint2 qe, const GeomPtrs &g, const float *__restrict__ colors,
+                                             float4 (&r)[4])
 {
-    if (o < 1.0f / 255.0f) return 0u;   // alpha <= opacity < 1/255 for every pixel
-    const float tau = __logf(255.0f * o) * 1.001f + 0.01f;
-    const float det = ca * cc - cb * cb;
-    const float hx = sqrtf(2.0f * tau * cc / det) * 1.0001f + 0.02f;
-    const float hy = sqrtf(2.0f * tau * ca / det) * 1.0001f + 0.02f;
-    if (!(det > 0.f) || !(hx == hx) || !(hy == hy)) return 0xFu;
-    const bool x0 = (x + hx >= ox) && (x - hx <= ox + 7.0f);
-    const bool x1 = (x + hx >= ox + 8.0f) && (x - hx <= ox + 15.0f);
-    const bool y0 = (y + hy >= oy) && (y - hy <= oy + 7.0f);
-    const bool y1 = (y + hy >= oy + 8.0f) && (y - hy <= oy + 15.0f);
-    return (uint32_t)(x0 && y0) | ((uint32_t)(x1 && y0) << 1) | ((uint32_t)(x0 && y1) << 2) |
-           ((uint32_t)(x1 && y1) << 3);
-}
-
-__device__ __forceinline__ void stage_entry(Staged *s_e, uint32_t *s_mask, int j, uint32_t gid, const GeomPtrs &g,
-                                            const float *__restrict__ colors, float ox, float oy)
-{
+    const uint32_t gid = qe.x;
     const float2 xy = g.xy[gid];
     const float4 co = g.conic_opacity[gid];
     const float dep = g.depth[gid];
-    const float *c = colors + 3 * (size_t)gid;
-    s_e[j].a = make_float4(xy.x, xy.y, co.x, co.y);
-    s_e[j].b = make_float4(co.z, co.w, dep, 0.f);
-    s_e[j].c = make_float4(c[0], c[1], c[2], 0.f);
-    s_mask[j] = quadrant_mask(xy.x, xy.y, co.x, co.y, co.z, co.w, ox, oy);
+    const float *c = colors + (size_t)C * gid;
+    r[0] = make_float4(xy.x, xy.y, co.x, co.y);
+    r[1] = make_float4(co.z, co.w, dep, __uint_as_float(qe.y));
+    if (C <= 3) {
+        r[2] = make_float4(c[0], c[1], c[2], 0.f);
+    } else {
+        const float2 c01 = *reinterpret_cast<const float2 *>(c);
+        const float2 c23 = *reinterpret_cast<const float2 *>(c + 2);
+        const float2 c45 = *reinterpret_cast<const float2 *>(c + 4);
+        r[2] = make_float4(c01.x, c01.y, c23.x, c23.y);
+        r[3] = make_float4(c45.x, c45.y, 0.f, 0.f);
+    }
 }
 
-// compaction of the staged chunk to this wave's quadrant; returns the count
-__device__ __forceinline__ uint32_t compact_for_wave(const uint32_t *s_mask, uint16_t *wlist, int cnt, int wv, int lane)
+__device__ __forceinline__ void block_to_quadrant(int b, int &tile, int &q)
 {
-    uint32_t wcnt = 0;
-#pragma unroll
-    for (int it = 0; it < kChunk / 64; ++it) {
-        const int j = it * 64 + lane;
-        const bool m = (j < cnt) && ((s_mask[j] >> wv) & 1u);
-        const uint64_t bal = __ballot(m);
-        if (m) wlist[wcnt + mbcnt(bal)] = (uint16_t)j;
-        wcnt += (uint32_t)__popcll(bal);
-    }
-    return wcnt;
+    const int xcd = b & 7, r = b >> 3;
+    q = r & 3;
+    tile = (r >> 2) * 8 + xcd;
 }
 
 // ---------------------------------------------------------------------------------------- K5
-__global__ __launch_bounds__(kRenderThreads) void k_render_fwd(ViewParams vp, const float *__restrict__ colors,
-                                                               GeomPtrs g, BinPtrs b, uint32_t cap, ImgPtrs im,
-                                                               float *__restrict__ out_color,
-                                                               float *__restrict__ out_depth,
-                                                               float *__restrict__ out_alpha)
+template <int C>
+__global__ __launch_bounds__(64) void k_render_fwd(ViewParams vp, const float *__restrict__ colors, GeomPtrs g,
+                                                   BinPtrs b, uint32_t cap, ImgPtrs im, float *__restrict__ out_color,
+                                                   float *__restrict__ out_depth, float *__restrict__ out_alpha, int T)
 {
-    __shared__ Staged s_e[kChunk];
-    __shared__ uint32_t s_mask[kChunk];
-    __shared__ uint16_t s_wlist[kRenderThreads / 64][kChunk];
-
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int tile = blockIdx.x;
+    constexpr int NV = StagedN<C>::kVec;
+    __shared__ float4 s_e[2][64][NV];
+    int tile, q;
+    block_to_quadrant(blockIdx.x, tile, q);
+    if (tile >= T) return;
+    const int lane = threadIdx.x;
     const int tx = tile % vp.gx, ty = tile / vp.gx;
-    const int px = tx * kTile + (wv & 1) * 8 + (lane & 7);
-    const int py = ty * kTile + (wv >> 1) * 8 + (lane >> 3);
+    const int px = tx * kTile + (q & 1) * 8 + (lane & 7);
+    const int py = ty * kTile + (q >> 1) * 8 + (lane >> 3);
     const bool inside = px < vp.W && py < vp.H;
     const float pxf = (float)px, pyf = (float)py;
-    const float ox = (float)(tx * kTile), oy = (float)(ty * kTile);
 
     const uint32_t s = g.tile_start[tile];
-    uint32_t n = g.tile_count[tile];
-    if (s >= cap) n = 0;
-    else if (s + n > cap) n = cap - s;
+    const uint32_t nq = (s < cap) ? g.qcount[tile * 4 + q] : 0u;
+    const uint2 *__restrict__ list = b.qlist + (size_t)q * b.cap + s;
 
-    float T = 1.0f, C0 = 0.f, C1 = 0.f, C2 = 0.f, D = 0.f, Wt = 0.f;
-    uint32_t last = 0;
+    float T_ = 1.0f, D = 0.f, Wt = 0.f;
+    float Cacc[C];
+#pragma unroll
+    for (int ch = 0; ch < C; ++ch) Cacc[ch] = 0.f;
+    uint32_t last = 0, lastj = 0;
     bool done = !inside;
 
-    for (uint32_t c0 = 0; c0 < n; c0 += kChunk) {
-        if (__syncthreads_count(done) == kRenderThreads) break;
-        const int cnt = (int)min((uint32_t)kChunk, n - c0);
-        if (tid < cnt) stage_entry(s_e, s_mask, tid, b.point_list[s + c0 + tid], g, colors, ox, oy);
-        __syncthreads();
-        const uint32_t wcnt = compact_for_wave(s_mask, s_wlist[wv], cnt, wv, lane);
-        for (uint32_t t = 0; t < wcnt; ++t) {
-            if (__ballot(!done) == 0) break;
-            const int j = s_wlist[wv][t];
-            const float4 ea = s_e[j].a, eb = s_e[j].b, ec = s_e[j].c;
+    float4 r[4];
+    if ((uint32_t)lane < nq) gather_entry<C>(list[lane], g, colors, r);
+    int buf = 0;
+    for (uint32_t c0 = 0; c0 < nq; c0 += 64, buf ^= 1) {
+        const int cnt = (int)min(64u, nq - c0);
+        if (lane < cnt) {
+#pragma unroll
+            for (int v = 0; v < NV; ++v) s_e[buf][lane][v] = r[v];
+        }
+        if (c0 + 64 + (uint32_t)lane < nq) gather_entry<C>(list[c0 + 64 + lane], g, colors, r);   // prefetch
+        __builtin_amdgcn_wave_barrier();
+        bool all_done = false;
+        for (int t = 0; t < cnt; ++t) {
+            if (__ballot(!done) == 0) { all_done = true; break; }
+            const float4 ea = s_e[buf][t][0], eb = s_e[buf][t][1];
             if (!done) {
                 const float dx = ea.x - pxf, dy = ea.y - pyf;
                 const float power = -0.5f * ((ea.z * dx) * dx + (eb.x * dy) * dy) - (ea.w * dx) * dy;
                 if (power <= 0.0f) {
                     const float alpha = fminf(0.99f, eb.y * det_expf(power));
                     if (alpha >= 1.0f / 255.0f) {
-                        const float test_T = T * (1.0f - alpha);
+                        const float test_T = T_ * (1.0f - alpha);
                         if (test_T < 0.0001f) {
                             done = true;
                         } else {
-                            const float w = alpha * T;
-                            C0 = __builtin_fmaf(ec.x, w, C0);
-                            C1 = __builtin_fmaf(ec.y, w, C1);
-                            C2 = __builtin_fmaf(ec.z, w, C2);
+                            const float w = alpha * T_;
+                            const float4 ec = s_e[buf][t][2];
+                            Cacc[0] = __builtin_fmaf(ec.x, w, Cacc[0]);
+                            Cacc[1] = __builtin_fmaf(ec.y, w, Cacc[1]);
+                            Cacc[2] = __builtin_fmaf(ec.z, w, Cacc[2]);
+                            if (C > 3) {
+                                const float4 ed = s_e[buf][t][NV - 1];
+                                Cacc[3] = __builtin_fmaf(ec.w, w, Cacc[3]);
+                                Cacc[C > 4 ? 4 : 0] = __builtin_fmaf(ed.x, w, Cacc[C > 4 ? 4 : 0]);
+                                Cacc[C > 5 ? 5 : 0] = __builtin_fmaf(ed.y, w, Cacc[C > 5 ? 5 : 0]);
+                            }
                             D = __builtin_fmaf(eb.z, w, D);
                             Wt = Wt + w;
-                            T = test_T;
-                            last = c0 + (uint32_t)j + 1u;
+                            T_ = test_T;
+                            last = __float_as_uint(eb.w) + 1u;
+                            lastj = c0 + (uint32_t)t + 1u;
                         }
                     }
                 }
             }
         }
+        if (all_done) break;
     }
     if (inside) {
         const size_t P = (size_t)vp.H * vp.W;
         const size_t pid = (size_t)py * vp.W + px;
-        im.final_T[pid] = T;
+        im.final_T[pid] = T_;
         im.n_contrib[pid] = last;
-        out_color[pid] = __builtin_fmaf(T, vp.bg[0], C0);
-        out_color[P + pid] = __builtin_fmaf(T, vp.bg[1], C1);
-        out_color[2 * P + pid] = __builtin_fmaf(T, vp.bg[2], C2);
+#pragma unroll
+        for (int ch = 0; ch < C; ++ch) out_color[ch * P + pid] = __builtin_fmaf(T_, vp.bg[ch], Cacc[ch]);
         out_depth[pid] = D;
         out_alpha[pid] = Wt;
+    }
+    const uint32_t wj = wave_max_u32(lastj), wk = wave_max_u32(last);
+    if (lane == 0) {
+        g.qdone[tile * 4 + q] = wj;
+        g.qkmax[tile * 4 + q] = wk;
     }
 }
 
 // ---------------------------------------------------------------------------------------- B1
-__global__ __launch_bounds__(kRenderThreads) void k_render_bwd(ViewParams vp, const float *__restrict__ colors,
-                                                               GeomPtrs g, BinPtrs b, uint32_t cap, ImgPtrs im,
-                                                               const float *__restrict__ dL_dcolor,
-                                                               const float *__restrict__ dL_ddepth,
-                                                               const float *__restrict__ dL_dalpha,
-                                                               float *__restrict__ dLt)
+// Packed 64-lane sums of NV (12 or 16) per-lane values.  After it, register out[r], lanes of row
+// rho (lane >> 4) all hold the total of value 4r + {0,2,1,3}[rho].
+template <int NV>
+__device__ __forceinline__ void wave_reduce_packed(const float (&v)[NV], float (&out)[NV / 4])
 {
-    __shared__ Staged s_e[kChunk];
-    __shared__ uint32_t s_mask[kChunk];
-    __shared__ uint16_t s_wlist[kRenderThreads / 64][kChunk];
-    __shared__ float4 s_acc[kRenderThreads / 64][kChunk][kGradStride / 4];
-    __shared__ uint32_t s_wmax[kRenderThreads / 64];
+    float p[NV / 2];
+#pragma unroll
+    for (int m = 0; m < NV / 2; ++m) {
+        const u2v x = __builtin_amdgcn_permlane32_swap(__float_as_uint(v[2 * m]), __float_as_uint(v[2 * m + 1]), false, false);
+        p[m] = __uint_as_float(x.x) + __uint_as_float(x.y);
+    }
+#pragma unroll
+    for (int r = 0; r < NV / 4; ++r) {
+        const u2v x = __builtin_amdgcn_permlane16_swap(__float_as_uint(p[2 * r]), __float_as_uint(p[2 * r + 1]), false, false);
+        float o = __uint_as_float(x.x) + __uint_as_float(x.y);
+        o = dpp_add<0xB1>(o);    // quad_perm [1,0,3,2]
+        o = dpp_add<0x4E>(o);    // quad_perm [2,3,0,1]
+        o = dpp_add<0x141>(o);   // row_half_mirror
+        o = dpp_add<0x140>(o);   // row_mirror
+        out[r] = o;
+    }
+}
 
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int tile = blockIdx.x;
+template <int C>
+__global__ __launch_bounds__(64) void k_render_bwd(ViewParams vp, const float *__restrict__ colors, GeomPtrs g,
+                                                   BinPtrs b, uint32_t cap, ImgPtrs im,
+                                                   const float *__restrict__ dL_dcolor,
+                                                   const float *__restrict__ dL_ddepth,
+                                                   const float *__restrict__ dL_dalpha, float *__restrict__ dLq, int T)
+{
+    constexpr int NV = StagedN<C>::kVec;
+    constexpr int GS = (C <= 3) ? 12 : 16;   // == grad_stride(C)
+    __shared__ float4 s_e[2][64][NV];
+    int tile, q;
+    block_to_quadrant(blockIdx.x, tile, q);
+    if (tile >= T) return;
+    const int lane = threadIdx.x;
     const int tx = tile % vp.gx, ty = tile / vp.gx;
-    const int px = tx * kTile + (wv & 1) * 8 + (lane & 7);
-    const int py = ty * kTile + (wv >> 1) * 8 + (lane >> 3);
+    const int px = tx * kTile + (q & 1) * 8 + (lane & 7);
+    const int py = ty * kTile + (q >> 1) * 8 + (lane >> 3);
     const bool inside = px < vp.W && py < vp.H;
     const float pxf = (float)px, pyf = (float)py;
-    const float ox = (float)(tx * kTile), oy = (float)(ty * kTile);
 
     const uint32_t s = g.tile_start[tile];
-    uint32_t n = g.tile_count[tile];
-    if (s >= cap) n = 0;
-    else if (s + n > cap) n = cap - s;
+    const uint32_t nd = (s < cap) ? g.qdone[tile * 4 + q] : 0u;
+    if (nd == 0) return;
+    const uint2 *__restrict__ list = b.qlist + (size_t)q * b.cap + s;
+    float *__restrict__ rec_base = dLq + ((size_t)q * b.cap + s) * GS;
 
     const size_t P = (size_t)vp.H * vp.W;
     const size_t pid = (size_t)py * vp.W + px;
-    float T_final = 0.f, gC0 = 0.f, gC1 = 0.f, gC2 = 0.f, gD = 0.f, gA = 0.f;
+    float T_final = 0.f, gD = 0.f, gA = 0.f;
+    float gCol[C];
+#pragma unroll
+    for (int ch = 0; ch < C; ++ch) gCol[ch] = 0.f;
     uint32_t last = 0;
     if (inside) {
         T_final = im.final_T[pid];
         last = im.n_contrib[pid];
-        gC0 = dL_dcolor[pid];
-        gC1 = dL_dcolor[P + pid];
-        gC2 = dL_dcolor[2 * P + pid];
+#pragma unroll
+        for (int ch = 0; ch < C; ++ch) gCol[ch] = dL_dcolor[ch * P + pid];
         if (dL_ddepth) gD = dL_ddepth[pid];
         if (dL_dalpha) gA = dL_dalpha[pid];
     }
-    if (last > n) last = n;
-    const float bgdot = (vp.bg[0] * gC0 + vp.bg[1] * gC1) + vp.bg[2] * gC2;
+    float bgdot = 0.f;
+#pragma unroll
+    for (int ch = 0; ch < C; ++ch) bgdot += vp.bg[ch] * gCol[ch];
     const float Tb = T_final * bgdot;
-    float T = T_final, S = 0.f;
+    float T_ = T_final, S = 0.f;
     const float half_W = 0.5f * (float)vp.W, half_H = 0.5f * (float)vp.H;
+    // which value this lane stores: register (lane & 15), memory slot 4*(lane&15) + {0,2,1,3}[row]
+    const int my_reg = lane & 15, row = lane >> 4;
+    const int my_slot = 4 * my_reg + ((row == 1) ? 2 : (row == 2) ? 1 : row);
 
-    const uint32_t wmax = wave_max_u32(last);
-    if (lane == 0) s_wmax[wv] = wmax;
-    __syncthreads();
-    const uint32_t bmax = max(max(s_wmax[0], s_wmax[1]), max(s_wmax[2], s_wmax[3]));
-    const uint32_t n_written = min(n, (bmax + kChunk - 1) / kChunk * kChunk);
-    if (tid == 0) g.tile_written[tile] = n_written;
-
-    for (int c0 = (int)((n_written + kChunk - 1) / kChunk) * kChunk - kChunk; c0 >= 0; c0 -= kChunk) {
-        const int cnt = (int)min((uint32_t)kChunk, n_written - (uint32_t)c0);
-        if (tid < cnt) stage_entry(s_e, s_mask, tid, b.point_list[s + c0 + tid], g, colors, ox, oy);
-        __syncthreads();
-        const uint32_t wcnt = compact_for_wave(s_mask, s_wlist[wv], cnt, wv, lane);
-        for (int t = (int)wcnt - 1; t >= 0; --t) {
-            const int j = s_wlist[wv][t];
-            const uint32_t k = (uint32_t)c0 + (uint32_t)j;
-            if (k >= wmax) continue;   // wave-uniform: behind every pixel's last contributor
-            const float4 ea = s_e[j].a, eb = s_e[j].b, ec = s_e[j].c;
-            float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f, v4 = 0.f, v5 = 0.f, v6 = 0.f, v7 = 0.f, v8 = 0.f, v9 = 0.f;
+    const int c_last = (int)((nd - 1) / 64) * 64;
+    float4 r[4];
+    if ((uint32_t)(c_last + lane) < nd) gather_entry<C>(list[c_last + lane], g, colors, r);
+    int buf = 0;
+    for (int c0 = c_last; c0 >= 0; c0 -= 64, buf ^= 1) {
+        const int cnt = (int)min(64u, nd - (uint32_t)c0);
+        if (lane < cnt) {
+#pragma unroll
+            for (int v = 0; v < NV; ++v) s_e[buf][lane][v] = r[v];
+        }
+        if (c0 >= 64) gather_entry<C>(list[c0 - 64 + lane], g, colors, r);   // prefetch the chunk in front
+        __builtin_amdgcn_wave_barrier();
+        for (int t = cnt - 1; t >= 0; --t) {
+            const float4 ea = s_e[buf][t][0], eb = s_e[buf][t][1];
+            const uint32_t k = __float_as_uint(eb.w);
+            float v[GS];
+#pragma unroll
+            for (int i = 0; i < GS; ++i) v[i] = 0.f;
+            bool contrib = false;
             if (k < last) {
                 const float dx = ea.x - pxf, dy = ea.y - pyf;
                 const float power = -0.5f * ((ea.z * dx) * dx + (eb.x * dy) * dy) - (ea.w * dx) * dy;
@@ -228,81 +262,121 @@ __global__ __launch_bounds__(kRenderThreads) void k_render_bwd(ViewParams vp, co
                     const float G = det_expf(power);
                     const float alpha = fminf(0.99f, eb.y * G);
                     if (alpha >= 1.0f / 255.0f) {
+                        contrib = true;
+                        const float4 ec = s_e[buf][t][2];
+                        float col[C];
+                        col[0] = ec.x; col[1] = ec.y; col[2] = ec.z;
+                        if (C > 3) {
+                            const float4 ed = s_e[buf][t][NV - 1];
+                            col[3] = ec.w;
+                            col[C > 4 ? 4 : 0] = ed.x;
+                            col[C > 5 ? 5 : 0] = ed.y;
+                        }
                         const float om = 1.f - alpha;
-                        T = T / om;
-                        const float w = alpha * T;
-                        const float V = ((gA + ec.x * gC0) + (ec.y * gC1 + ec.z * gC2)) + eb.z * gD;
-                        const float dL_da = T * V - (S + Tb) / om;
+                        T_ = T_ / om;
+                        const float w = alpha * T_;
+                        float V = gA + eb.z * gD;
+#pragma unroll
+                        for (int ch = 0; ch < C; ++ch) V = __builtin_fmaf(col[ch], gCol[ch], V);
+                        const float dL_da = T_ * V - (S + Tb) / om;
                         S = __builtin_fmaf(V, w, S);
-                        v6 = w * gC0;
-                        v7 = w * gC1;
-                        v8 = w * gC2;
-                        v9 = w * gD;
-                        v5 = G * dL_da;
                         const float dL_dG = eb.y * dL_da;
                         const float gdx = G * dx, gdy = G * dy;
-                        v0 = dL_dG * (-gdx * ea.z - gdy * ea.w) * half_W;
-                        v1 = dL_dG * (-gdy * eb.x - gdx * ea.w) * half_H;
-                        v2 = -0.5f * gdx * dx * dL_dG;
-                        v3 = -gdx * dy * dL_dG;
-                        v4 = -0.5f * gdy * dy * dL_dG;
+                        v[0] = dL_dG * (-gdx * ea.z - gdy * ea.w) * half_W;
+                        v[1] = dL_dG * (-gdy * eb.x - gdx * ea.w) * half_H;
+                        v[2] = -0.5f * gdx * dx * dL_dG;
+                        v[3] = -gdx * dy * dL_dG;
+                        v[4] = -0.5f * gdy * dy * dL_dG;
+                        v[5] = G * dL_da;
+                        v[6] = w * gD;
+#pragma unroll
+                        for (int ch = 0; ch < C; ++ch) v[7 + ch] = w * gCol[ch];
                     }
                 }
             }
-            v0 = wave_sum_row3(v0); v1 = wave_sum_row3(v1); v2 = wave_sum_row3(v2); v3 = wave_sum_row3(v3);
-            v4 = wave_sum_row3(v4); v5 = wave_sum_row3(v5); v6 = wave_sum_row3(v6); v7 = wave_sum_row3(v7);
-            v8 = wave_sum_row3(v8); v9 = wave_sum_row3(v9);
-            if (lane == 63) {
-                s_acc[wv][j][0] = make_float4(v0, v1, v2, v3);
-                s_acc[wv][j][1] = make_float4(v4, v5, v6, v7);
-                s_acc[wv][j][2] = make_float4(v8, v9, 0.f, 0.f);
-            }
-        }
-        __syncthreads();
-        if (tid < cnt) {
-            const uint32_t k = (uint32_t)c0 + (uint32_t)tid;
-            const uint32_t m = s_mask[tid];
-            float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0, r2 = r0;
+            float out[GS / 4];
+            if (__ballot(contrib) != 0) {
+                wave_reduce_packed<GS>(v, out);
+            } else {
 #pragma unroll
-            for (int w = 0; w < kRenderThreads / 64; ++w) {
-                if (((m >> w) & 1u) && k < s_wmax[w]) {
-                    const float4 a0 = s_acc[w][tid][0], a1 = s_acc[w][tid][1], a2 = s_acc[w][tid][2];
-                    r0.x += a0.x; r0.y += a0.y; r0.z += a0.z; r0.w += a0.w;
-                    r1.x += a1.x; r1.y += a1.y; r1.z += a1.z; r1.w += a1.w;
-                    r2.x += a2.x; r2.y += a2.y;
-                }
+                for (int i = 0; i < GS / 4; ++i) out[i] = 0.f;
             }
-            float4 *dst = reinterpret_cast<float4 *>(dLt + (size_t)(s + k) * kGradStride);
-            dst[0] = r0;
-            dst[1] = r1;
-            dst[2] = r2;
+            if (my_reg < GS / 4) {
+                float val = out[0];
+#pragma unroll
+                for (int i = 1; i < GS / 4; ++i) val = (my_reg == i) ? out[i] : val;
+                rec_base[(size_t)k * GS + my_slot] = val;
+            }
         }
-        __syncthreads();
     }
 }
 
 // ---------------------------------------------------------------------------------------- launchers
+template <int C>
+static int launch_fwd_t(const ViewParams &vp, const float *colors, const GeomPtrs &g, const BinPtrs &b, int64_t cap,
+                        const ImgPtrs &im, float *out_color, float *out_depth, float *out_alpha, hipStream_t st)
+{
+    const int T = vp.gx * vp.gy;
+    const int blocks = ((T + 7) / 8) * 8 * 4;
+    ProfScope prof_(kKRenderFwd, st);
+    hipLaunchKernelGGL(k_render_fwd<C>, dim3(blocks), dim3(64), 0, st, vp, colors, g, b, (uint32_t)cap, im, out_color,
+                       out_depth, out_alpha, T);
+    DM4D_HIP_CHECK(hipGetLastError());
+    return DM4D_OK;
+}
+
 int launch_render_fwd(const ViewParams &vp, const float *colors, const GeomPtrs &g, const BinPtrs &b, int64_t cap,
                       const ImgPtrs &im, float *out_color, float *out_depth, float *out_alpha, hipStream_t st)
 {
+    if (vp.gx * vp.gy <= 0) return DM4D_OK;
+    return vp.C <= 3 ? launch_fwd_t<3>(vp, colors, g, b, cap, im, out_color, out_depth, out_alpha, st)
+                     : launch_fwd_t<6>(vp, colors, g, b, cap, im, out_color, out_depth, out_alpha, st);
+}
+
+template <int C>
+static int launch_bwd_t(const ViewParams &vp, const float *colors, const GeomPtrs &g, const BinPtrs &b, int64_t cap,
+                        const ImgPtrs &im, const float *dL_dcolor, const float *dL_ddepth, const float *dL_dalpha,
+                        float *dLq, hipStream_t st)
+{
     const int T = vp.gx * vp.gy;
-    if (T <= 0) return DM4D_OK;
-    ProfScope prof_(kKRenderFwd, st);
-    hipLaunchKernelGGL(k_render_fwd, dim3(T), dim3(kRenderThreads), 0, st, vp, colors, g, b, (uint32_t)cap, im,
-                       out_color, out_depth, out_alpha);
+    const int blocks = ((T + 7) / 8) * 8 * 4;
+    ProfScope prof_(kKRenderBwd, st);
+    hipLaunchKernelGGL(k_render_bwd<C>, dim3(blocks), dim3(64), 0, st, vp, colors, g, b, (uint32_t)cap, im, dL_dcolor,
+                       dL_ddepth, dL_dalpha, dLq, T);
     DM4D_HIP_CHECK(hipGetLastError());
     return DM4D_OK;
 }
 
 int launch_render_bwd(const ViewParams &vp, const float *colors, const GeomPtrs &g, const BinPtrs &b, int64_t cap,
                       const ImgPtrs &im, const float *dL_dcolor, const float *dL_ddepth, const float *dL_dalpha,
-                      float *dLt, hipStream_t st)
+                      float *dLq, hipStream_t st)
 {
-    const int T = vp.gx * vp.gy;
-    if (T <= 0) return DM4D_OK;
-    ProfScope prof_(kKRenderBwd, st);
-    hipLaunchKernelGGL(k_render_bwd, dim3(T), dim3(kRenderThreads), 0, st, vp, colors, g, b, (uint32_t)cap, im,
-                       dL_dcolor, dL_ddepth, dL_dalpha, dLt);
+    if (vp.gx * vp.gy <= 0) return DM4D_OK;
+    return vp.C <= 3 ? launch_bwd_t<3>(vp, colors, g, b, cap, im, dL_dcolor, dL_ddepth, dL_dalpha, dLq, st)
+                     : launch_bwd_t<6>(vp, colors, g, b, cap, im, dL_dcolor, dL_ddepth, dL_dalpha, dLq, st);
+}
+
+// ---- self-test of the packed reduction (exported through dm4d_selftest_wave_reduce) ----------
+__global__ void k_selftest_reduce(const float *__restrict__ in /* [16][64] */, float *__restrict__ out /* [16] */)
+{
+    const int lane = threadIdx.x;
+    float v[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) v[i] = in[i * 64 + lane];
+    float o[4];
+    wave_reduce_packed<16>(v, o);
+    const int my_reg = lane & 15, row = lane >> 4;
+    const int my_slot = 4 * my_reg + ((row == 1) ? 2 : (row == 2) ? 1 : row);
+    if (my_reg < 4) {
+        float val = o[0];
+#pragma unroll
+        for (int i = 1; i < 4; ++i) val = (my_reg == i) ? o[i] : val;
+        out[my_slot] = val;
+    }
+}
+int launch_selftest_reduce(const float *in, float *out, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_selftest_reduce, dim3(1), dim3(64), 0, st, in, out);
     DM4D_HIP_CHECK(hipGetLastError());
     return DM4D_OK;
 }

@@ -78,7 +78,7 @@ class _Call:
                                             float(rs.scale_modifier), int(rs.sh_degree), int(bool(rs.prefiltered)),
                                             int(bool(rs.debug)), _ptr(keep["bg"]), _ptr(keep["view"]),
                                             _ptr(keep["proj"]), _ptr(keep["campos"]))
-        self.inputs = _lib.RasterInputs(self.N, self.M, _ptr(keep["means3D"]), _ptr(keep["sh"]), _ptr(keep["col"]),
+        self.inputs = _lib.RasterInputs(self.N, self.M, 3, _ptr(keep["means3D"]), _ptr(keep["sh"]), _ptr(keep["col"]),
                                         _ptr(keep["opac"]), _ptr(keep["scales"]), _ptr(keep["rots"]),
                                         _ptr(keep["cov"]))
 
@@ -149,7 +149,7 @@ class _RasterizeGaussians(torch.autograd.Function):
             d_sc = torch.empty(N, 3, **f) if has_sr else None
             d_rot = torch.empty(N, 4, **f) if has_sr else None
             d_cov = torch.empty(N, 6, **f) if not has_sr else None
-            grad = _bytes(L.dm4d_raster_grad_bytes(D), dev)
+            grad = _bytes(L.dm4d_raster_grad_bytes(D, 3), dev)
             _lib.check(L.dm4d_rasterize_backward(
                 call.settings, call.inputs, _ptr(radii), geom.data_ptr(), binning.data_ptr(), D, image.data_ptr(),
                 grad.data_ptr(), g_color.data_ptr(), _ptr(g_depth), _ptr(g_alpha), _ptr(d_m2), _ptr(d_m3),

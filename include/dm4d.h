@@ -80,9 +80,13 @@ typedef struct dm4d_raster_settings {
 typedef struct dm4d_raster_inputs {
     int32_t N;
     int32_t sh_coeffs;            /* M of shs[N,M,3]; 0 when colors_precomp is used */
+    int32_t n_channels;           /* colour channels C of colors_precomp: 3 (0 means 3) or 6.  C = 6 blends the
+                                     RGB pass and the normal pass of one view together (identical geometry,
+                                     C/renderer/diff_sugar_rasterizer_temporal.py:169-178 + 202-211): colours are
+                                     [N,6], out_color / dL_dcolor [6,H,W], dL_dcolors [N,6]. */
     const float *means3D;         /* [dev] [N,3] */
     const float *shs;             /* [dev] [N,M,3] or NULL */
-    const float *colors_precomp;  /* [dev] [N,3] or NULL */
+    const float *colors_precomp;  /* [dev] [N,C] or NULL */
     const float *opacities;       /* [dev] [N]   */
     const float *scales;          /* [dev] [N,3] or NULL */
     const float *rotations;       /* [dev] [N,4] (w,x,y,z) or NULL */
@@ -95,7 +99,7 @@ typedef struct dm4d_raster_inputs {
 size_t dm4d_raster_geom_bytes(int32_t N, int32_t image_height, int32_t image_width);
 size_t dm4d_raster_binning_bytes(int64_t capacity);
 size_t dm4d_raster_image_bytes(int32_t image_height, int32_t image_width);
-size_t dm4d_raster_grad_bytes(int64_t capacity);
+size_t dm4d_raster_grad_bytes(int64_t capacity, int32_t n_channels);
 
 /* Stage 1 (no host sync): preprocess every Gaussian, count duplicates per tile, scan.
  * Writes radii[N] and the geom workspace (which must be 16-byte aligned; it need not be
@@ -111,7 +115,7 @@ int64_t dm4d_rasterize_num_rendered(const void *geom /* [dev] */, dm4d_stream_t 
  * (depth bits, Gaussian id) -- the order of a stable radix sort of tile<<32|depth --,
  * blend front to back.  `binning` must hold `capacity` >= D duplicates; if it does not,
  * nothing is rendered past the capacity and the overflow flag read by
- * dm4d_rasterize_overflowed() is set.  Outputs: color [3,H,W], depth [H,W], alpha [H,W]. */
+ * dm4d_rasterize_overflowed() is set.  Outputs: color [C,H,W], depth [H,W], alpha [H,W]. */
 int dm4d_rasterize_render(const dm4d_raster_settings *s, const dm4d_raster_inputs *in,
                           const int32_t *radii /* [dev] [N], from prepare */,
                           void *geom, void *binning, int64_t capacity, void *image,
@@ -127,10 +131,10 @@ int dm4d_rasterize_overflowed(const void *geom, dm4d_stream_t stream);
 int dm4d_rasterize_backward(const dm4d_raster_settings *s, const dm4d_raster_inputs *in,
                             const int32_t *radii, const void *geom, const void *binning, int64_t capacity,
                             const void *image, void *grad,
-                            const float *dL_dcolor /* [3,H,W] */, const float *dL_ddepth /* [H,W] */,
+                            const float *dL_dcolor /* [C,H,W] */, const float *dL_ddepth /* [H,W] */,
                             const float *dL_dalpha /* [H,W] */,
                             float *dL_dmeans2D /* [N,3] */, float *dL_dmeans3D /* [N,3] */,
-                            float *dL_dopacity /* [N] */, float *dL_dcolors /* [N,3] */,
+                            float *dL_dopacity /* [N] */, float *dL_dcolors /* [N,C] */,
                             float *dL_dsh /* [N,M,3] */, float *dL_dscales /* [N,3] */,
                             float *dL_drotations /* [N,4] */, float *dL_dcov3D /* [N,6] */,
                             dm4d_stream_t stream);
@@ -156,6 +160,10 @@ int dm4d_raster_read_geom(const void *geom, int32_t N, int32_t image_height, int
 int dm4d_raster_read_image_state(const void *image, int32_t image_height, int32_t image_width,
                                  uint32_t *n_contrib /* [host][H,W] */, float *final_T /* [host][H,W] */,
                                  dm4d_stream_t stream);
+
+/* Self-test of the packed 64-lane reduction used by the backward blend kernel:
+ * in [16][64] floats, out [16] (device pointers); out[i] = sum_l in[i][l]. */
+int dm4d_selftest_wave_reduce(const float *in, float *out, dm4d_stream_t stream);
 
 /* markVisible: present[i] = view-space z > 0.2 */
 int dm4d_mark_visible(int32_t N, const float *means3D, const float *viewmatrix, uint8_t *present,

@@ -27,15 +27,16 @@ class HipRaster:
         t = lambda a: None if a is None else torch.tensor(np.asarray(a, np.float32), device=dev).contiguous()
         self.t = dict(m=t(means3D), o=t(opacities), c=t(colors), sh=t(shs), s=t(scales), r=t(rotations), cov=t(cov3D))
         N = self.N = int(self.t["m"].shape[0])
+        self.C = 3 if colors is None else int(np.asarray(colors).shape[-1])
         H, W = cam.H, cam.W
         M = 0 if shs is None else int(self.t["sh"].shape[1])
         self.settings = _lib.RasterSettings(H, W, cam.tanfov, cam.tanfov, self.scale_mod, 0, 0, 0, _p(self.bg),
                                             _p(self.view), _p(self.proj), _p(self.campos))
-        self.inputs = _lib.RasterInputs(N, M, _p(self.t["m"]) if N else None, _p(self.t["sh"]), _p(self.t["c"]),
+        self.inputs = _lib.RasterInputs(N, M, self.C, _p(self.t["m"]) if N else None, _p(self.t["sh"]), _p(self.t["c"]),
                                         _p(self.t["o"]) if N else None, _p(self.t["s"]), _p(self.t["r"]),
                                         _p(self.t["cov"]))
         st = torch.cuda.current_stream(dev).cuda_stream
-        self.color = torch.empty(3, H, W, device=dev)
+        self.color = torch.empty(self.C, H, W, device=dev)
         self.depth = torch.empty(H, W, device=dev)
         self.alpha = torch.empty(H, W, device=dev)
         self.radii = torch.empty(max(N, 1), dtype=torch.int32, device=dev)
@@ -84,10 +85,10 @@ class HipRaster:
         z = lambda *s: torch.full(s, float("nan"), device=dev)
         has_sr = self.t["s"] is not None
         M = 0 if self.t["sh"] is None else int(self.t["sh"].shape[1])
-        o = {"dL_dmeans2D": z(N, 3), "dL_dmeans3D": z(N, 3), "dL_dopacity": z(N), "dL_dcolors": z(N, 3),
+        o = {"dL_dmeans2D": z(N, 3), "dL_dmeans3D": z(N, 3), "dL_dopacity": z(N), "dL_dcolors": z(N, self.C),
              "dL_dsh": z(N, M, 3) if M else None, "dL_dscales": z(N, 3) if has_sr else None,
              "dL_drots": z(N, 4) if has_sr else None, "dL_dcov3D": z(N, 6)}
-        grad = torch.empty(L.dm4d_raster_grad_bytes(self.cap), dtype=torch.uint8, device=dev)
+        grad = torch.empty(L.dm4d_raster_grad_bytes(self.cap, self.C), dtype=torch.uint8, device=dev)
         st = torch.cuda.current_stream(dev).cuda_stream
         _lib.check(L.dm4d_rasterize_backward(self.settings, self.inputs, _p(self.radii), _p(self.geom),
                                              _p(self.binning), self.cap, _p(self.image), _p(grad), _p(gC), _p(gD),

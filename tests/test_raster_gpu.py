@@ -265,3 +265,53 @@ def test_autograd_operator_matches_oracle():
     _assert_grads(got, og)
     vis = rast.markVisible(m3)
     assert vis.dtype == torch.bool and bool(vis.all())
+
+
+def test_packed_wave_reduction_selftest():
+    _need_gpu()
+    from dreammesh4d_amd import _lib
+
+    L = _lib.lib()
+    dev = torch.device("cuda:0")
+    x = torch.randn(16, 64, device=dev)
+    out = torch.zeros(16, device=dev)
+    _lib.check(L.dm4d_selftest_wave_reduce(x.data_ptr(), out.data_ptr(), torch.cuda.current_stream(dev).cuda_stream))
+    torch.cuda.synchronize()
+    want = x.double().sum(dim=1)
+    assert torch.allclose(out.double(), want, atol=1e-4), (out, want)
+
+
+def test_fused_six_channel_pass_equals_two_passes():
+    """C = 6 (RGB + normal in one pass) must equal the reference's two passes: same image planes,
+    summed geometry gradients, per-pass colour gradients."""
+    _need_gpu()
+    from tests.hip_raster import HipRaster
+
+    n, H, W = 20_000, 200, 264
+    sc = syn.random_splat_scene(n, seed=31, log_scale_mean=math.log(0.012), log_scale_std=0.5)
+    rng = np.random.default_rng(31)
+    nrm = rng.normal(size=(n, 3)).astype(np.float32)
+    nrm /= np.linalg.norm(nrm, axis=1, keepdims=True)
+    cam = syn.make_camera(H, W, elev_deg=25, azim_deg=100)
+    bg = (1.0, 1.0, 1.0)
+    o1 = _oracle(sc, cam, bg, 1.0, colors_precomp=sc["colors"], scales=sc["scales"], rotations=sc["rotations"])
+    o2 = _oracle(sc, cam, bg, 1.0, colors_precomp=nrm, scales=sc["scales"], rotations=sc["rotations"])
+    h = HipRaster(cam, bg=(1, 1, 1, 1, 1, 1))
+    col6 = np.concatenate([sc["colors"], nrm], axis=1)
+    color, radii, depth, alpha = h.forward(sc["means3D"], sc["opacities"], colors=col6, scales=sc["scales"],
+                                           rotations=sc["rotations"])
+    assert np.array_equal(color[:3].view(np.uint32), o1.s["out_color"].view(np.uint32))
+    assert np.array_equal(color[3:].view(np.uint32), o2.s["out_color"].view(np.uint32))
+    assert np.array_equal(depth.view(np.uint32), o1.s["out_depth"].view(np.uint32))
+    assert np.array_equal(alpha.view(np.uint32), o1.s["out_alpha"].view(np.uint32))
+    assert np.array_equal(radii, o1.s["radii"])
+    gC = rng.normal(size=(3, H, W)).astype(np.float32)
+    gN = rng.normal(size=(3, H, W)).astype(np.float32)
+    gD = rng.normal(size=(H, W)).astype(np.float32) * 0.1
+    gA = rng.normal(size=(H, W)).astype(np.float32)
+    g1, g2 = o1.backward(gC, gD, gA), o2.backward(gN, None, None)
+    g = h.backward(np.concatenate([gC, gN]), gD, gA)
+    summed = {k: g1[k] + g2[k] for k in ("dL_dmeans2D", "dL_dopacity", "dL_dmeans3D", "dL_dscales", "dL_drots")}
+    _assert_grads(g, summed, keys=tuple(summed))
+    _assert_grads({"a": g["dL_dcolors"][:, :3], "b": g["dL_dcolors"][:, 3:]},
+                  {"a": g1["dL_dcolors"], "b": g2["dL_dcolors"]}, keys=("a", "b"))
