@@ -1,0 +1,548 @@
+// skinning.hip -- sparse-control skinning of mesh vertices and the face -> Gaussian transform
+// (gfx950).  Replaces, per (frame, view) unit, the pypose / pytorch3d / fancy-index graph of
+//   custom/threestudio-dreammesh4d/geometry/dynamic_sugar.py:408-465  (node attributes)
+//   .../dynamic_sugar.py:487-613   (_get_timed_vertex_attributes_from_dg: LBS / DQS / hybrid,
+//                                   vertex rotation Exp(sum_k w_k Log q_k))
+//   .../utils/dual_quaternions.py:94-131,184-197,224-231
+//   .../dynamic_sugar.py:657-676,726-743,877-889 (Gaussian means, fused rotations)
+//   .../dynamic_sugar.py:330-364   (deformed face normals, one per Gaussian)
+// which materialises [V,K,3,3] tensors, two bmm's and ~40 elementwise launches per call, with
+// SIX kernels: forward = 1 thread/vertex + 1 thread/Gaussian; backward = gather formulations
+// over static adjacency (face->corner records -> vertex, vertex->neighbour records -> node), so
+// there are no atomics and the gradients are bit-reproducible.
+//
+// Everything is HBM-bound gather work on a few hundred KB: vertex and node tables stay in L2.
+// Gradients are the exact (Euclidean) derivatives of the forward (DESIGN.md "gradient convention").
+#include "common.h"
+#include "raster.h"
+
+namespace dm4d {
+
+struct q4 { float x, y, z, w; };   // (x, y, z, w) storage, as pypose SO3
+struct v3 { float x, y, z; };
+
+__device__ __forceinline__ v3 mk3(float x, float y, float z) { return v3{x, y, z}; }
+__device__ __forceinline__ v3 operator+(v3 a, v3 b) { return v3{a.x + b.x, a.y + b.y, a.z + b.z}; }
+__device__ __forceinline__ v3 operator-(v3 a, v3 b) { return v3{a.x - b.x, a.y - b.y, a.z - b.z}; }
+__device__ __forceinline__ v3 operator*(float s, v3 a) { return v3{s * a.x, s * a.y, s * a.z}; }
+__device__ __forceinline__ float dot(v3 a, v3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+__device__ __forceinline__ v3 cross(v3 a, v3 b) { return v3{a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
+__device__ __forceinline__ v3 ld3(const float *p, size_t i) { return v3{p[3 * i], p[3 * i + 1], p[3 * i + 2]}; }
+__device__ __forceinline__ void st3(float *p, size_t i, v3 a) { p[3 * i] = a.x; p[3 * i + 1] = a.y; p[3 * i + 2] = a.z; }
+__device__ __forceinline__ q4 ldq(const float *p, size_t i) { const float4 t = reinterpret_cast<const float4 *>(p)[i]; return q4{t.x, t.y, t.z, t.w}; }
+__device__ __forceinline__ v3 qv(q4 q) { return v3{q.x, q.y, q.z}; }
+__device__ __forceinline__ float qdot(q4 a, q4 b) { return a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w; }
+__device__ __forceinline__ q4 qscale(float s, q4 a) { return q4{s * a.x, s * a.y, s * a.z, s * a.w}; }
+__device__ __forceinline__ q4 qadd(q4 a, q4 b) { return q4{a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w}; }
+__device__ __forceinline__ q4 qconj(q4 a) { return q4{-a.x, -a.y, -a.z, a.w}; }
+// Hamilton product
+__device__ __forceinline__ q4 qmul(q4 a, q4 b)
+{
+    return q4{a.w * b.x + a.x * b.w + a.y * b.z - a.z * b.y, a.w * b.y - a.x * b.z + a.y * b.w + a.z * b.x,
+              a.w * b.z + a.x * b.y - a.y * b.x + a.z * b.w, a.w * b.w - a.x * b.x - a.y * b.y - a.z * b.z};
+}
+// R(q) p = p + 2 w (v x p) + 2 v x (v x p)   (pypose SO3 Act)
+__device__ __forceinline__ v3 qact(q4 q, v3 p)
+{
+    const v3 v = qv(q);
+    const v3 uv = 2.f * cross(v, p);
+    return p + q.w * uv + cross(v, uv);
+}
+// gradient of h . qact(q, y) w.r.t. q (as a free 4-vector) and y
+__device__ __forceinline__ q4 qact_grad_q(q4 q, v3 y, v3 h)
+{
+    const v3 v = qv(q);
+    const v3 gv = (2.f * q.w) * cross(y, h) + 2.f * (dot(v, y) * h + dot(h, v) * y - (2.f * dot(h, y)) * v);
+    return q4{gv.x, gv.y, gv.z, 2.f * dot(h, cross(v, y))};
+}
+__device__ __forceinline__ v3 qact_grad_p(q4 q, v3 h)   // R(q)^T h for unit q; exact transpose in general
+{
+    // d/dp [p + 2w (v x p) + 2 v x (v x p)]^T h = h - 2w (v x h) + 2 v x (v x h)
+    const v3 v = qv(q);
+    const v3 uv = 2.f * cross(v, h);
+    return h - q.w * uv + cross(v, uv);
+}
+
+constexpr float kEps = 1.1920928955078125e-07f;   // float32 eps: pypose's series/generic branch threshold
+
+// SO3 Log (quaternion -> rotation vector): 2 atan(|v|/w)/|v| * v
+__device__ __forceinline__ v3 so3_log(q4 q)
+{
+    const v3 v = qv(q);
+    const float u = sqrtf(dot(v, v));
+    const float f = (u < kEps) ? (2.f / q.w - (2.f / 3.f) * u * u / (q.w * q.w * q.w)) : 2.f * atanf(u / q.w) / u;
+    return f * v;
+}
+// given g = dL/dLog, returns dL/dq (free 4-vector)
+__device__ __forceinline__ q4 so3_log_grad(q4 q, v3 g)
+{
+    const v3 v = qv(q);
+    const float u2 = dot(v, v), u = sqrtf(u2), w = q.w;
+    float f, dfu_over_u;
+    if (u < 1e-4f) {
+        f = 2.f / w - (2.f / 3.f) * u2 / (w * w * w);
+        dfu_over_u = -4.f / (3.f * w * w * w);
+    } else {
+        const float at = atanf(u / w);
+        f = 2.f * at / u;
+        dfu_over_u = 2.f * (w * u / (u2 + w * w) - at) / (u2 * u);
+    }
+    const float vg = dot(v, g);
+    const v3 gv = f * g + (dfu_over_u * vg) * v;
+    return q4{gv.x, gv.y, gv.z, -2.f / (u2 + w * w) * vg};
+}
+// so3 Exp (rotation vector -> quaternion)
+__device__ __forceinline__ q4 so3_exp(v3 r)
+{
+    const float t2 = dot(r, r), t = sqrtf(t2);
+    float a, c;
+    if (t < kEps) { a = 0.5f - t2 / 48.f + t2 * t2 / 3840.f; c = 1.f - t2 / 8.f + t2 * t2 / 384.f; }
+    else { a = sinf(0.5f * t) / t; c = cosf(0.5f * t); }
+    return q4{a * r.x, a * r.y, a * r.z, c};
+}
+// given g = dL/dq (4-vector) at q = Exp(r), returns dL/dr
+__device__ __forceinline__ v3 so3_exp_grad(v3 r, q4 g)
+{
+    const float t2 = dot(r, r), t = sqrtf(t2);
+    float a, da_over_t;
+    if (t < 1e-3f) { a = 0.5f - t2 / 48.f; da_over_t = -1.f / 24.f + t2 / 960.f; }
+    else {
+        const float s = sinf(0.5f * t), c = cosf(0.5f * t);
+        a = s / t;
+        da_over_t = (0.5f * t * c - s) / (t2 * t);
+    }
+    const v3 gx = qv(g);
+    return a * gx + (da_over_t * dot(r, gx) - 0.5f * a * g.w) * r;
+}
+
+// ---- node attributes from the raw deformation-network outputs --------------------------------
+struct NodeAttr { q4 q; float pn; v3 t; float S[9]; float o; };
+__device__ __forceinline__ NodeAttr node_attr(int m, const float *dx, const float *dr, const float *ds, const float *dop)
+{
+    NodeAttr a;
+    a.t = ld3(dx, m);
+    const q4 p = ldq(dr, m);
+    const q4 pp = q4{p.x, p.y, p.z, p.w + 1.f};            // + identity (dynamic_sugar.py:449-451)
+    a.pn = fmaxf(sqrtf(qdot(pp, pp)), 1e-12f);             // F.normalize eps
+    a.q = qscale(1.f / a.pn, pp);
+    if (ds) {
+        const float *s = ds + 6 * (size_t)m;
+        a.S[0] = 1.f + s[0]; a.S[1] = s[3]; a.S[2] = s[4];
+        a.S[3] = s[3]; a.S[4] = 1.f + s[1]; a.S[5] = s[5];
+        a.S[6] = s[4]; a.S[7] = s[5]; a.S[8] = 1.f + s[2];
+    } else {
+        a.S[0] = a.S[4] = a.S[8] = 1.f;
+        a.S[1] = a.S[2] = a.S[3] = a.S[5] = a.S[6] = a.S[7] = 0.f;
+    }
+    a.o = dop ? 1.f / (1.f + __expf(-dop[m])) : 0.f;
+    return a;
+}
+
+constexpr int kSkinThreads = 256;
+enum { kLbs = 0, kDqs = 1, kHybrid = 2 };
+constexpr int kMaxK = 8;
+constexpr int kNodeRec = 14;   // dx3 dr4 ds6 do1
+
+struct SkinArgs {
+    int method, V, M, K;
+    const float *verts; const int32_t *nbr_idx; const float *nbr_w;
+    const float *dx, *dr, *ds, *dop;
+};
+
+// ---------------------------------------------------------------------------------------- forward
+__global__ __launch_bounds__(kSkinThreads) void k_skin_fwd(SkinArgs a, float *__restrict__ out_xyz,
+                                                           float *__restrict__ out_rot)
+{
+    const int v = blockIdx.x * kSkinThreads + threadIdx.x;
+    if (v >= a.V) return;
+    const v3 p = ld3(a.verts, v);
+    v3 x_lbs = mk3(0, 0, 0), rho = mk3(0, 0, 0);
+    q4 br = q4{0, 0, 0, 0}, bd = q4{0, 0, 0, 0};
+    float eta = 0.f;
+    for (int k = 0; k < a.K; ++k) {
+        const int m = a.nbr_idx[(size_t)v * a.K + k];
+        const float w = a.nbr_w[(size_t)v * a.K + k];
+        const NodeAttr n = node_attr(m, a.dx, a.dr, a.ds, a.dop);
+        if (a.method != kDqs) {
+            const v3 y = mk3(n.S[0] * p.x + n.S[1] * p.y + n.S[2] * p.z, n.S[3] * p.x + n.S[4] * p.y + n.S[5] * p.z,
+                             n.S[6] * p.x + n.S[7] * p.y + n.S[8] * p.z);
+            x_lbs = x_lbs + w * (qact(n.q, y) + n.t);
+        }
+        if (a.method != kLbs) {
+            const float qn = sqrtf(qdot(n.q, n.q));
+            const q4 qr = qscale(1.f / qn, n.q);
+            const q4 d = qmul(q4{0.5f * n.t.x, 0.5f * n.t.y, 0.5f * n.t.z, 0.f}, qr);
+            br = qadd(br, qscale(w, qr));
+            bd = qadd(bd, qscale(w, d));
+        }
+        eta += w * n.o;
+        rho = rho + w * so3_log(n.q);
+    }
+    v3 x;
+    if (a.method == kLbs) {
+        x = x_lbs;
+    } else {
+        const float nn = sqrtf(qdot(br, br));
+        const q4 rh = qscale(1.f / nn, br), dh = qscale(1.f / nn, bd);
+        const q4 trq = qmul(qscale(2.f, dh), qconj(rh));
+        const v3 x_dqs = qact(rh, p) + qv(trq);
+        if (a.method == kDqs) x = x_dqs;
+        else {
+            const float e = fminf(eta + 0.4f, 1.0f);
+            x = e * x_lbs + (1.f - e) * x_dqs;
+        }
+    }
+    st3(out_xyz, v, x);
+    const q4 vr = so3_exp(rho);
+    reinterpret_cast<float4 *>(out_rot)[v] = make_float4(vr.x, vr.y, vr.z, vr.w);
+}
+
+// ---------------------------------------------------------------------------------------- backward 1
+// per vertex: gradients w.r.t. the raw outputs of its K neighbour nodes -> rec[v][k][14]
+__global__ __launch_bounds__(kSkinThreads) void k_skin_bwd_vertex(SkinArgs a, const float *__restrict__ g_xyz,
+                                                                  const float *__restrict__ g_rot,
+                                                                  float *__restrict__ rec)
+{
+    const int v = blockIdx.x * kSkinThreads + threadIdx.x;
+    if (v >= a.V) return;
+    const v3 p = ld3(a.verts, v);
+    const v3 gx = g_xyz ? ld3(g_xyz, v) : mk3(0, 0, 0);
+    const q4 gq = g_rot ? ldq(g_rot, v) : q4{0, 0, 0, 0};
+    // ---- recompute the forward blend state ----
+    v3 x_lbs = mk3(0, 0, 0), rho = mk3(0, 0, 0);
+    q4 br = q4{0, 0, 0, 0}, bd = q4{0, 0, 0, 0};
+    float eta_raw = 0.f;
+    for (int k = 0; k < a.K; ++k) {
+        const int m = a.nbr_idx[(size_t)v * a.K + k];
+        const float w = a.nbr_w[(size_t)v * a.K + k];
+        const NodeAttr n = node_attr(m, a.dx, a.dr, a.ds, a.dop);
+        if (a.method != kDqs) {
+            const v3 y = mk3(n.S[0] * p.x + n.S[1] * p.y + n.S[2] * p.z, n.S[3] * p.x + n.S[4] * p.y + n.S[5] * p.z,
+                             n.S[6] * p.x + n.S[7] * p.y + n.S[8] * p.z);
+            x_lbs = x_lbs + w * (qact(n.q, y) + n.t);
+        }
+        if (a.method != kLbs) {
+            const float qn = sqrtf(qdot(n.q, n.q));
+            const q4 qr = qscale(1.f / qn, n.q);
+            br = qadd(br, qscale(w, qr));
+            bd = qadd(bd, qscale(w, qmul(q4{0.5f * n.t.x, 0.5f * n.t.y, 0.5f * n.t.z, 0.f}, qr)));
+        }
+        eta_raw += w * n.o;
+        rho = rho + w * so3_log(n.q);
+    }
+    // ---- gradients of the blended quantities ----
+    float eta = 1.f, g_eta = 0.f;
+    v3 g_lbs = gx, g_dqs = mk3(0, 0, 0);
+    q4 g_br = q4{0, 0, 0, 0}, g_bd = q4{0, 0, 0, 0};
+    if (a.method != kLbs) {
+        const float nn = sqrtf(qdot(br, br));
+        const q4 rh = qscale(1.f / nn, br), dh = qscale(1.f / nn, bd);
+        if (a.method == kDqs) { g_dqs = gx; g_lbs = mk3(0, 0, 0); }
+        else {
+            const v3 x_dqs = qact(rh, p) + qv(qmul(qscale(2.f, dh), qconj(rh)));
+            eta = fminf(eta_raw + 0.4f, 1.0f);
+            g_lbs = eta * gx;
+            g_dqs = (1.f - eta) * gx;
+            g_eta = (eta_raw + 0.4f < 1.0f) ? dot(gx, x_lbs - x_dqs) : 0.f;
+        }
+        // x_dqs = R(rh) p + (2 dh * conj(rh)).xyz
+        q4 g_rh = qact_grad_q(rh, p, g_dqs);
+        const q4 G = q4{g_dqs.x, g_dqs.y, g_dqs.z, 0.f};
+        const q4 g_dh = qscale(2.f, qmul(G, rh));                    // dL/da = G * conj(b), b = conj(rh)
+        const q4 g_b = qmul(qconj(qscale(2.f, dh)), G);              // dL/db = conj(a) * G
+        g_rh = qadd(g_rh, q4{-g_b.x, -g_b.y, -g_b.z, g_b.w});
+        g_bd = qscale(1.f / nn, g_dh);
+        g_br = qadd(qscale(1.f / nn, g_rh), qscale(-(qdot(g_rh, rh) + qdot(g_dh, dh)) / nn, rh));
+    }
+    const v3 g_rho = so3_exp_grad(rho, gq);
+    // ---- per-neighbour gradients ----
+    for (int k = 0; k < a.K; ++k) {
+        const int m = a.nbr_idx[(size_t)v * a.K + k];
+        const float w = a.nbr_w[(size_t)v * a.K + k];
+        const NodeAttr n = node_attr(m, a.dx, a.dr, a.ds, a.dop);
+        v3 g_t = mk3(0, 0, 0);
+        q4 g_q = so3_log_grad(n.q, w * g_rho);
+        float g_S[6] = {0, 0, 0, 0, 0, 0};
+        if (a.method != kDqs) {
+            const v3 h = w * g_lbs;
+            const v3 y = mk3(n.S[0] * p.x + n.S[1] * p.y + n.S[2] * p.z, n.S[3] * p.x + n.S[4] * p.y + n.S[5] * p.z,
+                             n.S[6] * p.x + n.S[7] * p.y + n.S[8] * p.z);
+            g_t = g_t + h;
+            g_q = qadd(g_q, qact_grad_q(n.q, y, h));
+            const v3 gy = qact_grad_p(n.q, h);
+            g_S[0] = gy.x * p.x; g_S[1] = gy.y * p.y; g_S[2] = gy.z * p.z;
+            g_S[3] = gy.x * p.y + gy.y * p.x;
+            g_S[4] = gy.x * p.z + gy.z * p.x;
+            g_S[5] = gy.y * p.z + gy.z * p.y;
+        }
+        if (a.method != kLbs) {
+            const float qn = sqrtf(qdot(n.q, n.q));
+            const q4 qr = qscale(1.f / qn, n.q);
+            const q4 av = q4{0.5f * n.t.x, 0.5f * n.t.y, 0.5f * n.t.z, 0.f};
+            const q4 g_d = qscale(w, g_bd);
+            const q4 g_a = qmul(g_d, qconj(qr));
+            g_t = g_t + 0.5f * qv(g_a);
+            q4 g_qr = qadd(qmul(qconj(av), g_d), qscale(w, g_br));
+            g_q = qadd(g_q, qscale(1.f / qn, qadd(g_qr, qscale(-qdot(g_qr, qr), qr))));
+        }
+        // through q = pp / |pp|
+        const q4 g_p = qscale(1.f / n.pn, qadd(g_q, qscale(-qdot(g_q, n.q), n.q)));
+        const float g_o = w * g_eta;
+        float *r = rec + ((size_t)v * a.K + k) * kNodeRec;
+        r[0] = g_t.x; r[1] = g_t.y; r[2] = g_t.z;
+        r[3] = g_p.x; r[4] = g_p.y; r[5] = g_p.z; r[6] = g_p.w;
+        r[7] = g_S[0]; r[8] = g_S[1]; r[9] = g_S[2]; r[10] = g_S[3]; r[11] = g_S[4]; r[12] = g_S[5];
+        r[13] = g_o * n.o * (1.f - n.o);
+    }
+}
+
+// ---------------------------------------------------------------------------------------- backward 2
+// per node: fixed-order sum of the records of every (vertex, k) that references it (static CSR)
+__global__ __launch_bounds__(64) void k_skin_bwd_node(int M, const int32_t *__restrict__ csr_off,
+                                                      const int32_t *__restrict__ csr_item,
+                                                      const float *__restrict__ rec, float *__restrict__ g_dx,
+                                                      float *__restrict__ g_dr, float *__restrict__ g_ds,
+                                                      float *__restrict__ g_do)
+{
+    const int m = blockIdx.x * 64 + threadIdx.x;
+    if (m >= M) return;
+    float acc[kNodeRec];
+#pragma unroll
+    for (int i = 0; i < kNodeRec; ++i) acc[i] = 0.f;
+    for (int e = csr_off[m]; e < csr_off[m + 1]; ++e) {
+        const float *r = rec + (size_t)csr_item[e] * kNodeRec;
+#pragma unroll
+        for (int i = 0; i < kNodeRec; ++i) acc[i] += r[i];
+    }
+    if (g_dx) { g_dx[3 * m] = acc[0]; g_dx[3 * m + 1] = acc[1]; g_dx[3 * m + 2] = acc[2]; }
+    if (g_dr) { g_dr[4 * m] = acc[3]; g_dr[4 * m + 1] = acc[4]; g_dr[4 * m + 2] = acc[5]; g_dr[4 * m + 3] = acc[6]; }
+    if (g_ds) { for (int i = 0; i < 6; ++i) g_ds[6 * m + i] = acc[7 + i]; }
+    if (g_do) g_do[m] = acc[13];
+}
+
+// ---------------------------------------------------------------------------------------- face -> Gaussians
+constexpr int kMaxPerFace = 6;
+__constant__ float c_bary[4][kMaxPerFace][3] = {
+    {{1.f / 3, 1.f / 3, 1.f / 3}},
+    {{1.f / 2, 1.f / 4, 1.f / 4}, {1.f / 4, 1.f / 2, 1.f / 4}, {1.f / 4, 1.f / 4, 1.f / 2}},
+    {{1.f / 3, 1.f / 3, 1.f / 3}, {2.f / 3, 1.f / 6, 1.f / 6}, {1.f / 6, 2.f / 3, 1.f / 6}, {1.f / 6, 1.f / 6, 2.f / 3}},
+    {{2.f / 3, 1.f / 6, 1.f / 6}, {1.f / 6, 2.f / 3, 1.f / 6}, {1.f / 6, 1.f / 6, 2.f / 3},
+     {1.f / 6, 5.f / 12, 5.f / 12}, {5.f / 12, 1.f / 6, 5.f / 12}, {5.f / 12, 5.f / 12, 1.f / 6}}};   // sugar.py:235-276
+__device__ __forceinline__ int bary_row(int G) { return G == 1 ? 0 : G == 3 ? 1 : G == 4 ? 2 : 3; }
+
+__global__ __launch_bounds__(kSkinThreads) void k_face_fwd(int F, int G, const int32_t *__restrict__ faces,
+                                                           const float *__restrict__ vxyz,
+                                                           const float *__restrict__ vrot,
+                                                           const float *__restrict__ q_static /* [N,4] wxyz */,
+                                                           float *__restrict__ means, float *__restrict__ rots,
+                                                           float *__restrict__ normals)
+{
+    const int i = blockIdx.x * kSkinThreads + threadIdx.x;
+    if (i >= F * G) return;
+    const int f = i / G, s = i - f * G;
+    const int i0 = faces[3 * f], i1 = faces[3 * f + 1], i2 = faces[3 * f + 2];
+    const float *b = c_bary[bary_row(G)][s];
+    const v3 x0 = ld3(vxyz, i0), x1 = ld3(vxyz, i1), x2 = ld3(vxyz, i2);
+    st3(means, i, (b[0] * x0 + b[1] * x1) + b[2] * x2);
+    const v3 r = (b[0] * so3_log(ldq(vrot, i0)) + b[1] * so3_log(ldq(vrot, i1))) + b[2] * so3_log(ldq(vrot, i2));
+    const q4 qd = so3_exp(r);
+    const float4 qs = reinterpret_cast<const float4 *>(q_static)[i];          // w,x,y,z
+    const q4 Q = qmul(qd, q4{qs.y, qs.z, qs.w, qs.x});
+    const float inv = 1.f / fmaxf(sqrtf(qdot(Q, Q)), 1e-12f);
+    reinterpret_cast<float4 *>(rots)[i] = make_float4(Q.w * inv, Q.x * inv, Q.y * inv, Q.z * inv);
+    if (normals) {
+        const v3 c = cross(x1 - x0, x2 - x0);
+        st3(normals, i, (1.f / fmaxf(sqrtf(dot(c, c)), 1e-12f)) * c);
+    }
+}
+
+constexpr int kCornerRec = 6;   // dL/dx (3) + dL/d(rotation-vector blend) (3) per face corner
+__global__ __launch_bounds__(kSkinThreads) void k_face_bwd_face(int F, int G, const int32_t *__restrict__ faces,
+                                                                const float *__restrict__ vxyz,
+                                                                const float *__restrict__ vrot,
+                                                                const float *__restrict__ q_static,
+                                                                const float *__restrict__ g_means,
+                                                                const float *__restrict__ g_rots,
+                                                                const float *__restrict__ g_normals,
+                                                                float *__restrict__ rec /* [F][3][6] */)
+{
+    const int f = blockIdx.x * kSkinThreads + threadIdx.x;
+    if (f >= F) return;
+    const int i0 = faces[3 * f], i1 = faces[3 * f + 1], i2 = faces[3 * f + 2];
+    const v3 x0 = ld3(vxyz, i0), x1 = ld3(vxyz, i1), x2 = ld3(vxyz, i2);
+    const v3 L0 = so3_log(ldq(vrot, i0)), L1 = so3_log(ldq(vrot, i1)), L2 = so3_log(ldq(vrot, i2));
+    v3 X[3] = {mk3(0, 0, 0), mk3(0, 0, 0), mk3(0, 0, 0)}, R[3] = {mk3(0, 0, 0), mk3(0, 0, 0), mk3(0, 0, 0)};
+    v3 gn = mk3(0, 0, 0);
+    for (int s = 0; s < G; ++s) {
+        const size_t i = (size_t)f * G + s;
+        const float *b = c_bary[bary_row(G)][s];
+        if (g_means) {
+            const v3 gm = ld3(g_means, i);
+            X[0] = X[0] + b[0] * gm; X[1] = X[1] + b[1] * gm; X[2] = X[2] + b[2] * gm;
+        }
+        if (g_rots) {
+            const v3 r = (b[0] * L0 + b[1] * L1) + b[2] * L2;
+            const q4 qd = so3_exp(r);
+            const float4 qs4 = reinterpret_cast<const float4 *>(q_static)[i];
+            const q4 qs = q4{qs4.y, qs4.z, qs4.w, qs4.x};
+            const q4 Q = qmul(qd, qs);
+            const float nq = fmaxf(sqrtf(qdot(Q, Q)), 1e-12f);
+            const q4 out = qscale(1.f / nq, Q);
+            const float4 go4 = reinterpret_cast<const float4 *>(g_rots)[i];      // grads in w,x,y,z order
+            const q4 go = q4{go4.y, go4.z, go4.w, go4.x};
+            const q4 gQ = qscale(1.f / nq, qadd(go, qscale(-qdot(go, out), out)));
+            const q4 gqd = qmul(gQ, qconj(qs));
+            const v3 gr = so3_exp_grad(r, gqd);
+            R[0] = R[0] + b[0] * gr; R[1] = R[1] + b[1] * gr; R[2] = R[2] + b[2] * gr;
+        }
+        if (g_normals) gn = gn + ld3(g_normals, i);
+    }
+    if (g_normals) {
+        const v3 e1 = x1 - x0, e2 = x2 - x0, c = cross(e1, e2);
+        const float cn = fmaxf(sqrtf(dot(c, c)), 1e-12f);
+        const v3 n = (1.f / cn) * c;
+        const v3 gc = (1.f / cn) * (gn - dot(gn, n) * n);
+        const v3 ge1 = cross(e2, gc), ge2 = cross(gc, e1);
+        X[1] = X[1] + ge1;
+        X[2] = X[2] + ge2;
+        X[0] = X[0] - (ge1 + ge2);
+    }
+    float *o = rec + (size_t)f * 3 * kCornerRec;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        o[j * kCornerRec + 0] = X[j].x; o[j * kCornerRec + 1] = X[j].y; o[j * kCornerRec + 2] = X[j].z;
+        o[j * kCornerRec + 3] = R[j].x; o[j * kCornerRec + 4] = R[j].y; o[j * kCornerRec + 5] = R[j].z;
+    }
+}
+
+// per vertex: fixed-order sum over incident face corners (static CSR), then Log backward
+__global__ __launch_bounds__(kSkinThreads) void k_face_bwd_vertex(int V, const int32_t *__restrict__ csr_off,
+                                                                  const int32_t *__restrict__ csr_item /* 3f+j */,
+                                                                  const float *__restrict__ vrot,
+                                                                  const float *__restrict__ rec,
+                                                                  float *__restrict__ g_vxyz, float *__restrict__ g_vrot)
+{
+    const int v = blockIdx.x * kSkinThreads + threadIdx.x;
+    if (v >= V) return;
+    v3 X = mk3(0, 0, 0), R = mk3(0, 0, 0);
+    for (int e = csr_off[v]; e < csr_off[v + 1]; ++e) {
+        const float *r = rec + (size_t)csr_item[e] * kCornerRec;
+        X = X + mk3(r[0], r[1], r[2]);
+        R = R + mk3(r[3], r[4], r[5]);
+    }
+    st3(g_vxyz, v, X);
+    const q4 g = so3_log_grad(ldq(vrot, v), R);
+    reinterpret_cast<float4 *>(g_vrot)[v] = make_float4(g.x, g.y, g.z, g.w);
+}
+
+}  // namespace dm4d
+
+using namespace dm4d;
+
+static int skin_check(int method, int V, int M, int K, const void *verts, const void *idx, const void *w, const void *dx,
+                      const void *dr, const void *ds, const void *dop)
+{
+    if (method < 0 || method > 2) { set_error("method must be 0 (lbs), 1 (dqs) or 2 (hybrid)"); return DM4D_ERR_INVALID; }
+    if (V < 0 || M <= 0 || K <= 0 || K > kMaxK) { set_error("bad V/M/K (%d/%d/%d)", V, M, K); return DM4D_ERR_INVALID; }
+    if (V > 0 && (!verts || !idx || !w || !dx || !dr)) { set_error("null input"); return DM4D_ERR_INVALID; }
+    if (method != kDqs && !ds) { set_error("lbs/hybrid need the strain output ds"); return DM4D_ERR_INVALID; }
+    if (method == kHybrid && !dop) { set_error("hybrid needs the opacity output"); return DM4D_ERR_INVALID; }
+    return DM4D_OK;
+}
+
+extern "C" {
+
+int dm4d_skin_vertices_forward(int32_t method, int32_t V, int32_t M, int32_t K, const float *verts,
+                               const int32_t *nbr_idx, const float *nbr_w, const float *dx, const float *dr,
+                               const float *ds, const float *d_opacity, float *out_xyz, float *out_rot,
+                               dm4d_stream_t stream)
+{
+    int rc = skin_check(method, V, M, K, verts, nbr_idx, nbr_w, dx, dr, ds, d_opacity);
+    if (rc) return rc;
+    if (V == 0) return DM4D_OK;
+    if (!out_xyz || !out_rot) { set_error("null output"); return DM4D_ERR_INVALID; }
+    hipStream_t st = (hipStream_t)stream;
+    SkinArgs a{method, V, M, K, verts, nbr_idx, nbr_w, dx, dr, method == kDqs ? nullptr : ds,
+               method == kHybrid ? d_opacity : nullptr};
+    ProfScope prof_(kKSkinFwd, st);
+    hipLaunchKernelGGL(k_skin_fwd, dim3((V + kSkinThreads - 1) / kSkinThreads), dim3(kSkinThreads), 0, st, a, out_xyz, out_rot);
+    DM4D_HIP_CHECK(hipGetLastError());
+    return DM4D_OK;
+}
+
+size_t dm4d_skin_scratch_bytes(int32_t V, int32_t K) { return (size_t)(V > 0 ? V : 1) * K * kNodeRec * 4; }
+
+int dm4d_skin_vertices_backward(int32_t method, int32_t V, int32_t M, int32_t K, const float *verts,
+                                const int32_t *nbr_idx, const float *nbr_w, const float *dx, const float *dr,
+                                const float *ds, const float *d_opacity, const float *dL_dxyz, const float *dL_drot,
+                                const int32_t *node_csr_offsets, const int32_t *node_csr_items, void *scratch,
+                                float *dL_ddx, float *dL_ddr, float *dL_dds, float *dL_ddo, dm4d_stream_t stream)
+{
+    int rc = skin_check(method, V, M, K, verts, nbr_idx, nbr_w, dx, dr, ds, d_opacity);
+    if (rc) return rc;
+    if (!node_csr_offsets || !node_csr_items || !scratch) { set_error("null csr/scratch"); return DM4D_ERR_INVALID; }
+    hipStream_t st = (hipStream_t)stream;
+    SkinArgs a{method, V, M, K, verts, nbr_idx, nbr_w, dx, dr, method == kDqs ? nullptr : ds,
+               method == kHybrid ? d_opacity : nullptr};
+    ProfScope prof_(kKSkinBwd, st);
+    if (V > 0) {
+        hipLaunchKernelGGL(k_skin_bwd_vertex, dim3((V + kSkinThreads - 1) / kSkinThreads), dim3(kSkinThreads), 0, st, a,
+                           dL_dxyz, dL_drot, (float *)scratch);
+        DM4D_HIP_CHECK(hipGetLastError());
+    }
+    hipLaunchKernelGGL(k_skin_bwd_node, dim3((M + 63) / 64), dim3(64), 0, st, M, node_csr_offsets, node_csr_items,
+                       (const float *)scratch, dL_ddx, dL_ddr, dL_dds, dL_ddo);
+    DM4D_HIP_CHECK(hipGetLastError());
+    return DM4D_OK;
+}
+
+static int face_check(int F, int G, const void *faces, const void *vxyz, const void *vrot, const void *qs)
+{
+    if (F < 0 || !(G == 1 || G == 3 || G == 4 || G == 6)) { set_error("bad F/G (%d/%d); G must be 1, 3, 4 or 6", F, G); return DM4D_ERR_INVALID; }
+    if (F > 0 && (!faces || !vxyz || !vrot || !qs)) { set_error("null input"); return DM4D_ERR_INVALID; }
+    return DM4D_OK;
+}
+
+int dm4d_face_gaussians_forward(int32_t F, int32_t G, const int32_t *faces, const float *vxyz, const float *vrot,
+                                const float *q_static_wxyz, float *means, float *rotations_wxyz, float *normals,
+                                dm4d_stream_t stream)
+{
+    int rc = face_check(F, G, faces, vxyz, vrot, q_static_wxyz);
+    if (rc) return rc;
+    if (F == 0) return DM4D_OK;
+    if (!means || !rotations_wxyz) { set_error("null output"); return DM4D_ERR_INVALID; }
+    hipStream_t st = (hipStream_t)stream;
+    ProfScope prof_(kKFaceFwd, st);
+    hipLaunchKernelGGL(k_face_fwd, dim3((F * G + kSkinThreads - 1) / kSkinThreads), dim3(kSkinThreads), 0, st, F, G, faces,
+                       vxyz, vrot, q_static_wxyz, means, rotations_wxyz, normals);
+    DM4D_HIP_CHECK(hipGetLastError());
+    return DM4D_OK;
+}
+
+size_t dm4d_face_scratch_bytes(int32_t F) { return (size_t)(F > 0 ? F : 1) * 3 * kCornerRec * 4; }
+
+int dm4d_face_gaussians_backward(int32_t F, int32_t G, int32_t V, const int32_t *faces, const float *vxyz,
+                                 const float *vrot, const float *q_static_wxyz, const float *dL_dmeans,
+                                 const float *dL_drotations_wxyz, const float *dL_dnormals,
+                                 const int32_t *vert_csr_offsets, const int32_t *vert_csr_items, void *scratch,
+                                 float *dL_dvxyz, float *dL_dvrot, dm4d_stream_t stream)
+{
+    int rc = face_check(F, G, faces, vxyz, vrot, q_static_wxyz);
+    if (rc) return rc;
+    if (V < 0 || !vert_csr_offsets || !vert_csr_items || !scratch || !dL_dvxyz || !dL_dvrot) { set_error("null csr/scratch/output"); return DM4D_ERR_INVALID; }
+    hipStream_t st = (hipStream_t)stream;
+    ProfScope prof_(kKFaceBwd, st);
+    if (F > 0) {
+        hipLaunchKernelGGL(k_face_bwd_face, dim3((F + kSkinThreads - 1) / kSkinThreads), dim3(kSkinThreads), 0, st, F, G, faces,
+                           vxyz, vrot, q_static_wxyz, dL_dmeans, dL_drotations_wxyz, dL_dnormals, (float *)scratch);
+        DM4D_HIP_CHECK(hipGetLastError());
+    }
+    if (V > 0) {
+        hipLaunchKernelGGL(k_face_bwd_vertex, dim3((V + kSkinThreads - 1) / kSkinThreads), dim3(kSkinThreads), 0, st, V,
+                           vert_csr_offsets, vert_csr_items, vrot, (const float *)scratch, dL_dvxyz, dL_dvrot);
+        DM4D_HIP_CHECK(hipGetLastError());
+    }
+    return DM4D_OK;
+}
+
+}  // extern "C"

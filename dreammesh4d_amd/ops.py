@@ -1,0 +1,174 @@
+"""Autograd front-ends of the HIP skinning / face->Gaussian kernels (C ABI: include/dm4d.h).
+
+Host-side mirror of the reference's geometry math for one timestamp:
+
+* ``skin_vertices``   <->  DynamicSuGaRModel._get_timed_dg_attributes +
+                           _get_timed_vertex_attributes_from_dg
+                           (custom/threestudio-dreammesh4d/geometry/dynamic_sugar.py:408-465,487-613)
+* ``face_gaussians``  <->  get_timed_gs_attributes / _get_gs_xyz_from_vertex / fuse_rotations /
+                           get_timed_gs_normals (.../dynamic_sugar.py:657-676,726-743,877-889,330-364)
+
+No CPU fallback: tensors must live on a HIP device.
+"""
+import numpy as np
+import torch
+
+from . import _lib
+
+METHODS = {"lbs": 0, "dqs": 1, "hybrid": 2}
+
+
+def _p(t):
+    return None if t is None else t.data_ptr()
+
+
+def _st(dev):
+    return torch.cuda.current_stream(dev).cuda_stream
+
+
+def _f32(t):
+    return None if t is None else t.detach().to(torch.float32).contiguous()
+
+
+def _csr(keys: np.ndarray, n_keys: int):
+    """items sorted by key (stable) + offsets; the static adjacency the backward gathers over."""
+    keys = np.asarray(keys).reshape(-1)
+    order = np.argsort(keys, kind="stable").astype(np.int32)
+    off = np.zeros(n_keys + 1, np.int64)
+    np.cumsum(np.bincount(keys, minlength=n_keys), out=off[1:])
+    return off.astype(np.int32), order
+
+
+class DeformGraph:
+    """Static skinning tables: vertices, K nearest graph nodes per vertex and their weights
+    (dynamic_sugar.py:745-861 builds them once, on the CPU)."""
+
+    def __init__(self, verts, nbr_idx, nbr_w, n_nodes, device):
+        dev = torch.device(device)
+        if dev.type != "cuda":
+            raise RuntimeError("dreammesh4d_amd.ops: HIP device required (no CPU path)")
+        self.device = dev
+        idx = np.asarray(nbr_idx.cpu() if torch.is_tensor(nbr_idx) else nbr_idx).astype(np.int64)
+        self.V, self.K = idx.shape
+        self.M = int(n_nodes)
+        if idx.size and (idx.min() < 0 or idx.max() >= self.M):
+            raise ValueError("neighbour index out of range")
+        self.verts = torch.as_tensor(np.asarray(verts.cpu() if torch.is_tensor(verts) else verts), dtype=torch.float32).to(dev).contiguous()
+        self.nbr_idx = torch.as_tensor(idx.astype(np.int32)).to(dev).contiguous()
+        self.nbr_w = torch.as_tensor(np.asarray(nbr_w.cpu() if torch.is_tensor(nbr_w) else nbr_w), dtype=torch.float32).to(dev).contiguous()
+        off, items = _csr(idx, self.M)
+        self.csr_off = torch.as_tensor(off).to(dev)
+        self.csr_items = torch.as_tensor(items).to(dev)
+
+
+class MeshTopology:
+    """Static faces + vertex->corner adjacency for the face->Gaussian backward."""
+
+    def __init__(self, faces, n_verts, n_per_face, device):
+        dev = torch.device(device)
+        f = np.asarray(faces.cpu() if torch.is_tensor(faces) else faces).astype(np.int64)
+        self.F, self.V, self.G = int(f.shape[0]), int(n_verts), int(n_per_face)
+        if self.G not in (1, 3, 4, 6):
+            raise ValueError("n_gaussians_per_surface_triangle must be 1, 3, 4 or 6")
+        self.device = dev
+        self.faces = torch.as_tensor(f.astype(np.int32)).to(dev).contiguous()
+        off, items = _csr(f, self.V)
+        self.csr_off = torch.as_tensor(off).to(dev)
+        self.csr_items = torch.as_tensor(items).to(dev)
+
+
+class _SkinVertices(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, graph, method, dx, dr, ds, do):
+        L = _lib.lib()
+        g = graph
+        dev = g.device
+        dx_, dr_, ds_, do_ = _f32(dx), _f32(dr), _f32(ds), _f32(do)
+        xyz = torch.empty(g.V, 3, dtype=torch.float32, device=dev)
+        rot = torch.empty(g.V, 4, dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            _lib.check(L.dm4d_skin_vertices_forward(method, g.V, g.M, g.K, _p(g.verts), _p(g.nbr_idx), _p(g.nbr_w),
+                                                    _p(dx_), _p(dr_), _p(ds_), _p(do_), _p(xyz), _p(rot), _st(dev)),
+                       "dm4d_skin_vertices_forward")
+        ctx.graph, ctx.method = g, method
+        ctx.save_for_backward(dx_, dr_, *( [ds_] if ds_ is not None else []), *([do_] if do_ is not None else []))
+        ctx.has = (ds_ is not None, do_ is not None)
+        ctx.shapes = (dx.shape, dr.shape, None if ds is None else ds.shape, None if do is None else do.shape)
+        return xyz, rot
+
+    @staticmethod
+    def backward(ctx, g_xyz, g_rot):
+        L = _lib.lib()
+        g, method = ctx.graph, ctx.method
+        dev = g.device
+        saved = list(ctx.saved_tensors)
+        dx_, dr_ = saved[0], saved[1]
+        ds_ = saved[2] if ctx.has[0] else None
+        do_ = saved[2 + int(ctx.has[0])] if ctx.has[1] else None
+        f = dict(dtype=torch.float32, device=dev)
+        o_dx, o_dr = torch.empty(g.M, 3, **f), torch.empty(g.M, 4, **f)
+        o_ds = torch.empty(g.M, 6, **f) if ds_ is not None else None
+        o_do = torch.empty(g.M, **f) if do_ is not None else None
+        scratch = torch.empty(L.dm4d_skin_scratch_bytes(g.V, g.K), dtype=torch.uint8, device=dev)
+        gx, gr = _f32(g_xyz), _f32(g_rot)
+        with torch.cuda.device(dev):
+            _lib.check(L.dm4d_skin_vertices_backward(method, g.V, g.M, g.K, _p(g.verts), _p(g.nbr_idx), _p(g.nbr_w),
+                                                     _p(dx_), _p(dr_), _p(ds_), _p(do_), _p(gx), _p(gr),
+                                                     _p(g.csr_off), _p(g.csr_items), _p(scratch), _p(o_dx), _p(o_dr),
+                                                     _p(o_ds), _p(o_do), _st(dev)), "dm4d_skin_vertices_backward")
+        s = ctx.shapes
+        return (None, None, o_dx.reshape(s[0]), o_dr.reshape(s[1]), None if o_ds is None else o_ds.reshape(s[2]),
+                None if o_do is None else o_do.reshape(s[3]))
+
+
+def skin_vertices(graph: DeformGraph, dx, dr, ds=None, d_opacity=None, method="hybrid"):
+    """Raw deformation-network outputs for one timestamp -> (vertex xyz [V,3], vertex rotation [V,4] xyzw)."""
+    m = METHODS[method]
+    if m != 1 and ds is None:
+        raise ValueError("lbs / hybrid skinning needs the strain head output")
+    if m == 2 and d_opacity is None:
+        raise ValueError("hybrid skinning needs the opacity head output")
+    return _SkinVertices.apply(graph, m, dx, dr, ds if m != 1 else None, d_opacity if m == 2 else None)
+
+
+class _FaceGaussians(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, topo, vxyz, vrot, q_static, want_normals):
+        L = _lib.lib()
+        t = topo
+        dev = t.device
+        vx, vr, qs = _f32(vxyz), _f32(vrot), _f32(q_static)
+        N = t.F * t.G
+        f = dict(dtype=torch.float32, device=dev)
+        means, rots = torch.empty(N, 3, **f), torch.empty(N, 4, **f)
+        normals = torch.empty(N, 3, **f) if want_normals else None
+        with torch.cuda.device(dev):
+            _lib.check(L.dm4d_face_gaussians_forward(t.F, t.G, _p(t.faces), _p(vx), _p(vr), _p(qs), _p(means), _p(rots),
+                                                     _p(normals), _st(dev)), "dm4d_face_gaussians_forward")
+        ctx.topo = t
+        ctx.save_for_backward(vx, vr, qs)
+        if normals is None:
+            normals = torch.empty(0, **f)
+        return means, rots, normals
+
+    @staticmethod
+    def backward(ctx, g_means, g_rots, g_normals):
+        L = _lib.lib()
+        t = ctx.topo
+        dev = t.device
+        vx, vr, qs = ctx.saved_tensors
+        f = dict(dtype=torch.float32, device=dev)
+        o_x, o_r = torch.empty(t.V, 3, **f), torch.empty(t.V, 4, **f)
+        scratch = torch.empty(L.dm4d_face_scratch_bytes(t.F), dtype=torch.uint8, device=dev)
+        gm, gr = _f32(g_means), _f32(g_rots)
+        gn = _f32(g_normals) if g_normals is not None and g_normals.numel() else None
+        with torch.cuda.device(dev):
+            _lib.check(L.dm4d_face_gaussians_backward(t.F, t.G, t.V, _p(t.faces), _p(vx), _p(vr), _p(qs), _p(gm), _p(gr),
+                                                      _p(gn), _p(t.csr_off), _p(t.csr_items), _p(scratch), _p(o_x),
+                                                      _p(o_r), _st(dev)), "dm4d_face_gaussians_backward")
+        return None, o_x, o_r, None, None
+
+
+def face_gaussians(topo: MeshTopology, vxyz, vrot, q_static_wxyz, want_normals=True):
+    """Deformed vertices -> (means [N,3], rotations [N,4] wxyz, normals [N,3] or empty)."""
+    return _FaceGaussians.apply(topo, vxyz, vrot, q_static_wxyz, bool(want_normals))

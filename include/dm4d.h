@@ -169,6 +169,48 @@ int dm4d_selftest_wave_reduce(const float *in, float *out, dm4d_stream_t stream)
 int dm4d_mark_visible(int32_t N, const float *means3D, const float *viewmatrix, uint8_t *present,
                       dm4d_stream_t stream);
 
+/* ------------------------------------------------------------------ skinning / face -> Gaussians */
+
+/* Sparse-control skinning of the V mesh vertices by M deformation-graph nodes, K neighbours each
+ * (C/geometry/dynamic_sugar.py:408-465 node attributes, :487-613 vertex skinning;
+ * C/utils/dual_quaternions.py:94-131,184-197,224-231).  method: 0 = "lbs", 1 = "dqs", 2 = "hybrid"
+ * (C/configs/sugar_dynamic_dg.yaml:86).  Inputs are the RAW outputs of the deformation network for
+ * one timestamp: dx [M,3] translation, dr [M,4] rotation delta (x,y,z,w; the kernel adds the identity
+ * and normalises), ds [M,6] strain (lbs/hybrid), d_opacity [M] logit (hybrid).  nbr_idx [V,K] int32,
+ * nbr_w [V,K] row-normalised.  Outputs: xyz [V,3], rot [V,4] (x,y,z,w unit quaternion =
+ * Exp(sum_k w_k Log q_k)). */
+int dm4d_skin_vertices_forward(int32_t method, int32_t V, int32_t M, int32_t K, const float *verts,
+                               const int32_t *nbr_idx, const float *nbr_w, const float *dx, const float *dr,
+                               const float *ds, const float *d_opacity, float *out_xyz, float *out_rot,
+                               dm4d_stream_t stream);
+size_t dm4d_skin_scratch_bytes(int32_t V, int32_t K);
+/* Backward.  node_csr_* is the static inverse of nbr_idx: node m is referenced by the items
+ * node_csr_items[node_csr_offsets[m] .. node_csr_offsets[m+1]) where item = v*K + k.
+ * dL_dxyz / dL_drot may be NULL (zero).  Output pointers may be NULL when not wanted.
+ * Deterministic (gather formulation, no atomics). */
+int dm4d_skin_vertices_backward(int32_t method, int32_t V, int32_t M, int32_t K, const float *verts,
+                                const int32_t *nbr_idx, const float *nbr_w, const float *dx, const float *dr,
+                                const float *ds, const float *d_opacity, const float *dL_dxyz, const float *dL_drot,
+                                const int32_t *node_csr_offsets, const int32_t *node_csr_items, void *scratch,
+                                float *dL_ddx, float *dL_ddr, float *dL_dds, float *dL_ddo, dm4d_stream_t stream);
+
+/* Mesh-bound Gaussians of a deformed mesh: F faces x G Gaussians (G in {1,3,4,6}, barycentric tables of
+ * C/geometry/sugar.py:235-276), face-major order.  means = sum_j b_gj x_j (C/geometry/dynamic_sugar.py:726-743);
+ * rotation = normalize(Exp(sum_j b_gj Log q_j) (x) q_static) in (w,x,y,z) order (:669-676,877-889);
+ * normals (optional) = unit face normal of the deformed mesh repeated per Gaussian (:330-364). */
+int dm4d_face_gaussians_forward(int32_t F, int32_t G, const int32_t *faces, const float *vxyz, const float *vrot,
+                                const float *q_static_wxyz, float *means, float *rotations_wxyz, float *normals,
+                                dm4d_stream_t stream);
+size_t dm4d_face_scratch_bytes(int32_t F);
+/* Backward.  vert_csr_*: vertex v is corner (item % 3) of face (item / 3) for the items
+ * vert_csr_items[vert_csr_offsets[v] .. vert_csr_offsets[v+1]).  Any of the three upstream gradients
+ * may be NULL.  Outputs dL_dvxyz [V,3], dL_dvrot [V,4] (x,y,z,w). */
+int dm4d_face_gaussians_backward(int32_t F, int32_t G, int32_t V, const int32_t *faces, const float *vxyz,
+                                 const float *vrot, const float *q_static_wxyz, const float *dL_dmeans,
+                                 const float *dL_drotations_wxyz, const float *dL_dnormals,
+                                 const int32_t *vert_csr_offsets, const int32_t *vert_csr_items, void *scratch,
+                                 float *dL_dvxyz, float *dL_dvrot, dm4d_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -25,14 +25,15 @@ def test_workspace_size_queries_are_monotone_and_aligned():
     assert 0 < a < b and a % 256 == 0 and b % 256 == 0
     assert L.dm4d_raster_binning_bytes(0) > 0
     assert L.dm4d_raster_binning_bytes(10) <= L.dm4d_raster_binning_bytes(1_000_000)
-    assert L.dm4d_raster_grad_bytes(1_000_000) >= 1_000_000 * 40
+    assert L.dm4d_raster_grad_bytes(1_000_000, 3) >= 1_000_000 * 40
+    assert L.dm4d_raster_grad_bytes(1_000_000, 6) > L.dm4d_raster_grad_bytes(1_000_000, 3)
     assert L.dm4d_raster_image_bytes(512, 512) >= 512 * 512 * 8
 
 
 def test_argument_validation_without_a_device():
     L = _lib.lib()
     s = _lib.RasterSettings(0, 0, 1.0, 1.0, 1.0, 0, 0, 0, None, None, None, None)
-    i = _lib.RasterInputs(0, 0, None, None, None, None, None, None, None)
+    i = _lib.RasterInputs(0, 0, 3, None, None, None, None, None, None, None)
     rc = L.dm4d_rasterize_prepare(ctypes.byref(s), ctypes.byref(i), None, None, 0, None)
     assert rc == -1 and b"image size" in L.dm4d_last_error()
     with pytest.raises(_lib.Dm4dError):
