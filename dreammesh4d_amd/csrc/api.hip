@@ -75,24 +75,32 @@ static int check_settings(const dm4d_raster_settings *s, const dm4d_raster_input
     return DM4D_OK;
 }
 
-static ViewParams view_params(const dm4d_raster_settings *s, const dm4d_raster_inputs *in)
+// single-view call -> batch of one
+static BatchDesc single_view_batch(const dm4d_raster_settings *s, const dm4d_raster_inputs *in)
 {
-    ViewParams vp;
-    vp.C = (in && in->n_channels > 3) ? 6 : 3;
-    vp.W = s->image_width;
-    vp.H = s->image_height;
-    vp.gx = (vp.W + kTile - 1) / kTile;
-    vp.gy = (vp.H + kTile - 1) / kTile;
-    vp.tanfovx = s->tanfovx;
-    vp.tanfovy = s->tanfovy;
-    vp.focal_y = (float)vp.H / (2.0f * s->tanfovy);
-    vp.focal_x = (float)vp.W / (2.0f * s->tanfovx);
-    vp.scale_modifier = s->scale_modifier;
-    vp.bg = s->bg;
-    vp.view = s->viewmatrix;
-    vp.proj = s->projmatrix;
-    vp.campos = s->campos;
-    return vp;
+    BatchDesc d;
+    memset(&d, 0, sizeof(d));
+    d.B = 1;
+    d.N = in->N;
+    d.C = in->n_channels > 3 ? 6 : 3;
+    d.W = s->image_width;
+    d.H = s->image_height;
+    d.sh_coeffs = in->sh_coeffs;
+    d.tanfovx = s->tanfovx;
+    d.tanfovy = s->tanfovy;
+    d.scale_modifier = s->scale_modifier;
+    d.bg = s->bg;
+    d.view = s->viewmatrix;
+    d.proj = s->projmatrix;
+    d.campos = s->campos;
+    d.means3D = in->means3D;
+    d.rotations = in->rotations;
+    d.scales = in->scales;
+    d.opacities = in->opacities;
+    d.colors = in->colors_precomp;
+    d.shs = in->shs;
+    d.cov3D = in->cov3D_precomp;
+    return d;
 }
 
 }  // namespace dm4d
@@ -155,12 +163,13 @@ int dm4d_rasterize_prepare(const dm4d_raster_settings *s, const dm4d_raster_inpu
     if (!geom || geom_bytes_ < L.total) { set_error("geom workspace too small (%zu < %zu)", geom_bytes_, L.total); return DM4D_ERR_CAPACITY; }
     if (in->N > 0 && !radii) { set_error("radii missing"); return DM4D_ERR_INVALID; }
     hipStream_t st = (hipStream_t)stream;
-    const GeomPtrs g = geom_ptrs(geom, L);
-    const ViewParams vp = view_params(s, in);
+    BatchDesc d = single_view_batch(s, in);
+    d.radii = radii;
+    d.geom = (char *)geom;
     DM4D_HIP_CHECK(hipMemsetAsync((char *)geom + L.zero_begin, 0, L.zero_bytes, st));
-    rc = launch_preprocess(vp, *in, radii, g, st);
+    rc = launch_preprocess(d, st);
     if (rc) return rc;
-    return launch_colscan(in->N, L.T, g, st);
+    return launch_colscan(d, st);
 }
 
 int64_t dm4d_rasterize_num_rendered(const void *geom, dm4d_stream_t stream)
@@ -192,17 +201,20 @@ int dm4d_rasterize_render(const dm4d_raster_settings *s, const dm4d_raster_input
     if (!geom || !binning || !image || !out_color || !out_depth || !out_alpha || (in->N > 0 && !radii)) { set_error("null workspace/output"); return DM4D_ERR_INVALID; }
     if (capacity < 0 || capacity > 0xFFFFFFF0ll) { set_error("capacity out of range"); return DM4D_ERR_INVALID; }
     hipStream_t st = (hipStream_t)stream;
-    const GeomLayout L = geom_layout(in->N, s->image_height, s->image_width);
-    const GeomPtrs g = geom_ptrs(geom, L);
-    const BinPtrs b = bin_ptrs(binning, capacity);
-    const ImgPtrs im = img_ptrs(image, s->image_height, s->image_width);
-    const ViewParams vp = view_params(s, in);
-    const float *colors = in->colors_precomp ? in->colors_precomp : g.rgb;
-    rc = launch_scatter(vp, in->N, radii, g, b, capacity, st);
+    BatchDesc d = single_view_batch(s, in);
+    d.radii = const_cast<int32_t *>(radii);
+    d.geom = (char *)geom;
+    d.binning = (char *)binning;
+    d.cap = (uint32_t)capacity;
+    d.image = (char *)image;
+    d.out_color = out_color;
+    d.out_depth = out_depth;
+    d.out_alpha = out_alpha;
+    rc = launch_scatter(d, st);
     if (rc) return rc;
-    rc = launch_tile_sort(vp, g, b, capacity, st);
+    rc = launch_tile_sort(d, st);
     if (rc) return rc;
-    return launch_render_fwd(vp, colors, g, b, capacity, im, out_color, out_depth, out_alpha, st);
+    return launch_render_fwd(d, st);
 }
 
 int dm4d_rasterize_backward(const dm4d_raster_settings *s, const dm4d_raster_inputs *in, const int32_t *radii,
@@ -217,16 +229,20 @@ int dm4d_rasterize_backward(const dm4d_raster_settings *s, const dm4d_raster_inp
     if (!geom || !binning || !image || !grad || !dL_dcolor) { set_error("null workspace/grad input"); return DM4D_ERR_INVALID; }
     if (in->N > 0 && (!dL_dmeans2D || !dL_dmeans3D || !radii)) { set_error("dL_dmeans2D/dL_dmeans3D/radii required"); return DM4D_ERR_INVALID; }
     hipStream_t st = (hipStream_t)stream;
-    const GeomLayout L = geom_layout(in->N, s->image_height, s->image_width);
-    const GeomPtrs g = geom_ptrs(const_cast<void *>(geom), L);
-    const BinPtrs b = bin_ptrs(const_cast<void *>(binning), capacity);
-    const ImgPtrs im = img_ptrs(const_cast<void *>(image), s->image_height, s->image_width);
-    const ViewParams vp = view_params(s, in);
-    const float *colors = in->colors_precomp ? in->colors_precomp : g.rgb;
-    rc = launch_render_bwd(vp, colors, g, b, capacity, im, dL_dcolor, dL_ddepth, dL_dalpha, (float *)grad, st);
+    BatchDesc d = single_view_batch(s, in);
+    d.radii = const_cast<int32_t *>(radii);
+    d.geom = (char *)const_cast<void *>(geom);
+    d.binning = (char *)const_cast<void *>(binning);
+    d.cap = (uint32_t)capacity;
+    d.image = (char *)const_cast<void *>(image);
+    d.dL_dcolor = dL_dcolor;
+    d.dL_ddepth = dL_ddepth;
+    d.dL_dalpha = dL_dalpha;
+    d.dLq = (float *)grad;
+    d.o = BwdOutputs{dL_dmeans2D, dL_dmeans3D, dL_dopacity, dL_dcolors, dL_dsh, dL_dscales, dL_drotations, dL_dcov3D};
+    rc = launch_render_bwd(d, st);
     if (rc) return rc;
-    BwdOutputs o{dL_dmeans2D, dL_dmeans3D, dL_dopacity, dL_dcolors, dL_dsh, dL_dscales, dL_drotations, dL_dcov3D};
-    return launch_gather_bwd(vp, *in, radii, g, b, capacity, (const float *)grad, o, st);
+    return launch_gather_bwd(d, st);
 }
 
 int64_t dm4d_rasterize_forward(const dm4d_raster_settings *s, const dm4d_raster_inputs *in, float *out_color,

@@ -17,6 +17,12 @@
 
 #include "../../include/dm4d.h"
 
+#ifdef __HIPCC__
+#define DM4D_HD __host__ __device__
+#else
+#define DM4D_HD
+#endif
+
 namespace dm4d {
 
 constexpr int kTile = DM4D_TILE;
@@ -26,16 +32,11 @@ constexpr int kPreBlock = kPreThreads * kPreItems;   // Gaussians per workgroup 
 constexpr int kMaxTiles = 36864; // tile histogram lives in LDS (4 B/tile of the 160 KB): <= 3072x3072 px
 constexpr int kMaxChannels = 6;  // colour channels blended per pass: 3 (drop-in operator) or 6 (RGB + normal)
 // floats per (duplicate, quadrant) record of the backward scratch: 2 mean + 3 conic + opacity + depth + C colours
-#ifdef __HIPCC__
-#define DM4D_HD __host__ __device__
-#else
-#define DM4D_HD
-#endif
 DM4D_HD static inline int grad_stride(int C) { return C <= 3 ? 12 : 16; }
 
 enum GeomCounter { kCntD = 0, kCntOverflow = 1 };
 
-static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+DM4D_HD static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 struct GeomLayout {
     int N, T, nb;
@@ -43,7 +44,9 @@ struct GeomLayout {
         tile_count, tile_start, qcount, qdone, qkmax, zero_begin, zero_bytes, total;
 };
 
-static inline GeomLayout geom_layout(int N, int H, int W)
+DM4D_HD static inline size_t take_(size_t &o, size_t bytes) { size_t r = o; o = align_up(o + bytes, 256); return r; }
+
+DM4D_HD static inline GeomLayout geom_layout(int N, int H, int W)
 {
     GeomLayout L;
     L.N = N;
@@ -51,26 +54,25 @@ static inline GeomLayout geom_layout(int N, int H, int W)
     L.T = gx * gy;
     L.nb = (N + kPreBlock - 1) / kPreBlock;
     size_t o = 0;
-    auto take = [&](size_t bytes) { size_t r = o; o = align_up(o + bytes, 256); return r; };
     size_t n = (size_t)(N > 0 ? N : 1);
     // counters (offset 0) are cleared by one small memset node before K1
-    L.counters = take(64 * 4);
+    L.counters = take_(o, 64 * 4);
     L.zero_begin = 0;
     L.zero_bytes = o;
-    L.tile_count = take((size_t)L.T * 4);
-    L.tile_start = take((size_t)(L.T + 1) * 4);
-    L.qcount = take((size_t)L.T * 16);   // entries of each quadrant list            [T][4]
-    L.qdone = take((size_t)L.T * 16);    // entries the forward consumed               [T][4]
-    L.qkmax = take((size_t)L.T * 16);    // tile-list position bound of those entries  [T][4]
-    L.xy = take(n * 8);
-    L.depth = take(n * 4);
-    L.conic_opacity = take(n * 16);
-    L.rgb = take(n * 12);
-    L.tiles_touched = take(n * 4);
-    L.offsets = take(n * 4);
-    L.clamped = take(n * 3);
-    L.block_sums = take((size_t)(L.nb + 1) * 4);
-    L.hist = take((size_t)(L.nb > 0 ? L.nb : 1) * L.T * 4);
+    L.tile_count = take_(o, (size_t)L.T * 4);
+    L.tile_start = take_(o, (size_t)(L.T + 1) * 4);
+    L.qcount = take_(o, (size_t)L.T * 16);   // entries of each quadrant list            [T][4]
+    L.qdone = take_(o, (size_t)L.T * 16);    // entries the forward consumed               [T][4]
+    L.qkmax = take_(o, (size_t)L.T * 16);    // tile-list position bound of those entries  [T][4]
+    L.xy = take_(o, n * 8);
+    L.depth = take_(o, n * 4);
+    L.conic_opacity = take_(o, n * 16);
+    L.rgb = take_(o, n * 12);
+    L.tiles_touched = take_(o, n * 4);
+    L.offsets = take_(o, n * 4);
+    L.clamped = take_(o, n * 3);
+    L.block_sums = take_(o, (size_t)(L.nb + 1) * 4);
+    L.hist = take_(o, (size_t)(L.nb > 0 ? L.nb : 1) * L.T * 4);
     L.total = o;
     return L;
 }
@@ -93,7 +95,7 @@ struct GeomPtrs {
     uint32_t *qkmax;
 };
 
-static inline GeomPtrs geom_ptrs(void *base, const GeomLayout &L)
+DM4D_HD static inline GeomPtrs geom_ptrs(void *base, const GeomLayout &L)
 {
     char *b = (char *)base;
     GeomPtrs p;
@@ -125,12 +127,12 @@ struct BinPtrs {
                           // quadrant q of tile t at qlist[q*cap + tile_start[t] ...]
     size_t cap;
 };
-static inline size_t binning_bytes(int64_t cap)
+DM4D_HD static inline size_t binning_bytes(int64_t cap)
 {
     size_t c = (size_t)(cap > 0 ? cap : 1);
     return 5 * align_up(c * 4, 256) + align_up(c * 32, 256);
 }
-static inline BinPtrs bin_ptrs(void *base, int64_t cap)
+DM4D_HD static inline BinPtrs bin_ptrs(void *base, int64_t cap)
 {
     size_t c = (size_t)(cap > 0 ? cap : 1);
     size_t stride = align_up(c * 4, 256);
@@ -150,12 +152,12 @@ struct ImgPtrs {
     float *final_T;
     uint32_t *n_contrib;
 };
-static inline size_t image_bytes(int H, int W)
+DM4D_HD static inline size_t image_bytes(int H, int W)
 {
     size_t P = (size_t)H * W;
     return 2 * align_up((P > 0 ? P : 1) * 4, 256);
 }
-static inline ImgPtrs img_ptrs(void *base, int H, int W)
+DM4D_HD static inline ImgPtrs img_ptrs(void *base, int H, int W)
 {
     size_t P = (size_t)H * W;
     size_t stride = align_up((P > 0 ? P : 1) * 4, 256);
@@ -164,7 +166,7 @@ static inline ImgPtrs img_ptrs(void *base, int H, int W)
     p.n_contrib = (uint32_t *)((char *)base + stride);
     return p;
 }
-static inline size_t grad_bytes(int64_t cap, int C)
+DM4D_HD static inline size_t grad_bytes(int64_t cap, int C)
 {
     size_t c = (size_t)(cap > 0 ? cap : 1);
     return align_up(4 * c * grad_stride(C) * 4, 256);   // 4 quadrant slices
@@ -202,24 +204,110 @@ __device__ __forceinline__ uint32_t quadrant_mask(float x, float y, float ca, fl
 }
 #endif
 
-// ---- launchers (defined in the .hip files) ---------------------------------------------
-int launch_preprocess(const ViewParams &vp, const dm4d_raster_inputs &in, int32_t *radii, const GeomPtrs &g,
-                      hipStream_t st);
-int launch_colscan(int N, int T, const GeomPtrs &g, hipStream_t st);
-int launch_scatter(const ViewParams &vp, int N, const int32_t *radii, const GeomPtrs &g, const BinPtrs &b,
-                   int64_t cap, hipStream_t st);
-int launch_tile_sort(const ViewParams &vp, const GeomPtrs &g, const BinPtrs &b, int64_t cap, hipStream_t st);
-int launch_render_fwd(const ViewParams &vp, const float *colors /* [N,C] */, const GeomPtrs &g, const BinPtrs &b,
-                      int64_t cap, const ImgPtrs &im, float *out_color, float *out_depth, float *out_alpha,
-                      hipStream_t st);
-int launch_render_bwd(const ViewParams &vp, const float *colors, const GeomPtrs &g, const BinPtrs &b, int64_t cap,
-                      const ImgPtrs &im, const float *dL_dcolor, const float *dL_ddepth, const float *dL_dalpha,
-                      float *dLt, hipStream_t st);
 struct BwdOutputs {
     float *dL_dmeans2D, *dL_dmeans3D, *dL_dopacity, *dL_dcolors, *dL_dsh, *dL_dscales, *dL_drotations, *dL_dcov3D;
 };
-int launch_gather_bwd(const ViewParams &vp, const dm4d_raster_inputs &in, const int32_t *radii, const GeomPtrs &g,
-                      const BinPtrs &b, int64_t cap, const float *dLt, const BwdOutputs &o, hipStream_t st);
+
+// A batch of B views that share N, the image size, the intrinsics and (optionally, stride 0) some
+// inputs.  Every per-view quantity is `base + b * stride`; kernels use blockIdx.y as the view index,
+// so ONE launch covers the whole batch (>> 256 workgroups keep all 8 XCDs busy and average out the
+// per-tile load imbalance of a single small image).  The single-view C API is the B = 1 case.
+struct BatchDesc {
+    int B, N, C, W, H, sh_coeffs;
+    float tanfovx, tanfovy, scale_modifier;
+    const float *bg;
+    const float *view, *proj, *campos; size_t cam_stride, campos_stride;
+    const float *means3D; size_t means_stride;
+    const float *rotations; size_t rot_stride;
+    const float *scales; size_t scale_stride;
+    const float *opacities; size_t opac_stride;
+    const float *colors; size_t color_stride;
+    const float *shs; size_t sh_stride;
+    const float *cov3D; size_t cov_stride;
+    int32_t *radii; size_t radii_stride;
+    char *geom; size_t geom_stride;
+    char *binning; size_t bin_stride; uint32_t cap;
+    char *image; size_t img_stride;
+    float *out_color, *out_depth, *out_alpha;
+    const float *dL_dcolor, *dL_ddepth, *dL_dalpha;
+    float *dLq; size_t dlq_stride;
+    BwdOutputs o;          // per-view stride of each = N * width
+};
+
+struct ViewCtx {
+    ViewParams vp;
+    dm4d_raster_inputs in;
+    int32_t *radii;
+    GeomPtrs g;
+    BinPtrs b;
+    ImgPtrs im;
+    float *out_color, *out_depth, *out_alpha;
+    const float *dL_dcolor, *dL_ddepth, *dL_dalpha;
+    float *dLq;
+    BwdOutputs o;
+    const float *colors;   // colours actually blended ([N,C]): colors_precomp or the SH-evaluated rgb
+    int T;
+    uint32_t cap;
+};
+
+DM4D_HD static inline ViewCtx resolve(const BatchDesc &d, int b)
+{
+    ViewCtx c;
+    const size_t sb = (size_t)b, N = (size_t)d.N, P = (size_t)d.H * d.W;
+    c.vp.W = d.W; c.vp.H = d.H; c.vp.C = d.C;
+    c.vp.gx = (d.W + kTile - 1) / kTile;
+    c.vp.gy = (d.H + kTile - 1) / kTile;
+    c.vp.tanfovx = d.tanfovx; c.vp.tanfovy = d.tanfovy;
+    c.vp.focal_y = (float)d.H / (2.0f * d.tanfovy);
+    c.vp.focal_x = (float)d.W / (2.0f * d.tanfovx);
+    c.vp.scale_modifier = d.scale_modifier;
+    c.vp.bg = d.bg;
+    c.vp.view = d.view + sb * d.cam_stride;
+    c.vp.proj = d.proj + sb * d.cam_stride;
+    c.vp.campos = d.campos ? d.campos + sb * d.campos_stride : nullptr;
+    c.T = c.vp.gx * c.vp.gy;
+    c.in.N = d.N; c.in.sh_coeffs = d.sh_coeffs; c.in.n_channels = d.C;
+    c.in.means3D = d.means3D ? d.means3D + sb * d.means_stride : nullptr;
+    c.in.rotations = d.rotations ? d.rotations + sb * d.rot_stride : nullptr;
+    c.in.scales = d.scales ? d.scales + sb * d.scale_stride : nullptr;
+    c.in.opacities = d.opacities ? d.opacities + sb * d.opac_stride : nullptr;
+    c.in.colors_precomp = d.colors ? d.colors + sb * d.color_stride : nullptr;
+    c.in.shs = d.shs ? d.shs + sb * d.sh_stride : nullptr;
+    c.in.cov3D_precomp = d.cov3D ? d.cov3D + sb * d.cov_stride : nullptr;
+    c.radii = d.radii ? d.radii + sb * d.radii_stride : nullptr;
+    const GeomLayout L = geom_layout(d.N, d.H, d.W);
+    c.g = geom_ptrs(d.geom + sb * d.geom_stride, L);
+    c.b = bin_ptrs(d.binning ? d.binning + sb * d.bin_stride : nullptr, d.cap);
+    c.im = img_ptrs(d.image ? d.image + sb * d.img_stride : nullptr, d.H, d.W);
+    c.cap = d.cap;
+    c.colors = c.in.colors_precomp ? c.in.colors_precomp : c.g.rgb;
+    c.out_color = d.out_color ? d.out_color + sb * d.C * P : nullptr;
+    c.out_depth = d.out_depth ? d.out_depth + sb * P : nullptr;
+    c.out_alpha = d.out_alpha ? d.out_alpha + sb * P : nullptr;
+    c.dL_dcolor = d.dL_dcolor ? d.dL_dcolor + sb * d.C * P : nullptr;
+    c.dL_ddepth = d.dL_ddepth ? d.dL_ddepth + sb * P : nullptr;
+    c.dL_dalpha = d.dL_dalpha ? d.dL_dalpha + sb * P : nullptr;
+    c.dLq = d.dLq ? d.dLq + sb * d.dlq_stride : nullptr;
+    c.o.dL_dmeans2D = d.o.dL_dmeans2D ? d.o.dL_dmeans2D + sb * N * 3 : nullptr;
+    c.o.dL_dmeans3D = d.o.dL_dmeans3D ? d.o.dL_dmeans3D + sb * N * 3 : nullptr;
+    c.o.dL_dopacity = d.o.dL_dopacity ? d.o.dL_dopacity + sb * N : nullptr;
+    c.o.dL_dcolors = d.o.dL_dcolors ? d.o.dL_dcolors + sb * N * d.C : nullptr;
+    c.o.dL_dsh = d.o.dL_dsh ? d.o.dL_dsh + sb * N * d.sh_coeffs * 3 : nullptr;
+    c.o.dL_dscales = d.o.dL_dscales ? d.o.dL_dscales + sb * N * 3 : nullptr;
+    c.o.dL_drotations = d.o.dL_drotations ? d.o.dL_drotations + sb * N * 4 : nullptr;
+    c.o.dL_dcov3D = d.o.dL_dcov3D ? d.o.dL_dcov3D + sb * N * 6 : nullptr;
+    return c;
+}
+
+// ---- launchers (defined in the .hip files); every launch covers the d.B views of the batch ----
+int launch_preprocess(const BatchDesc &d, hipStream_t st);
+int launch_colscan(const BatchDesc &d, hipStream_t st);
+int launch_scatter(const BatchDesc &d, hipStream_t st);
+int launch_tile_sort(const BatchDesc &d, hipStream_t st);
+int launch_render_fwd(const BatchDesc &d, hipStream_t st);
+int launch_render_bwd(const BatchDesc &d, hipStream_t st);
+int launch_gather_bwd(const BatchDesc &d, hipStream_t st);
+int launch_zero_counters(const BatchDesc &d, hipStream_t st);
 int launch_mark_visible(int N, const float *means3D, const float *view, uint8_t *present, hipStream_t st);
 int launch_selftest_reduce(const float *in, float *out, hipStream_t st);
 

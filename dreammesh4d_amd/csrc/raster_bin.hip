@@ -22,8 +22,11 @@ namespace dm4d {
 // tile_count[t] = column total.  One thread per tile; consecutive threads read consecutive
 // tiles of one histogram row, so every step is a coalesced row access; 8 rows in flight.
 constexpr int kColThreads = 64;
-__global__ __launch_bounds__(kColThreads) void k_colscan(int nb, int T, GeomPtrs g)
+__global__ __launch_bounds__(kColThreads) void k_colscan(BatchDesc d)
 {
+    const ViewCtx c = resolve(d, blockIdx.y);
+    const GeomPtrs &g = c.g;
+    const int T = c.T, nb = (c.in.N + kPreBlock - 1) / kPreBlock;
     const int t = blockIdx.x * kColThreads + threadIdx.x;
     if (t >= T) return;
     uint32_t run = 0;
@@ -134,8 +137,13 @@ __device__ __forceinline__ void build_quadrant_lists(const ViewParams &vp, int t
     if (tid < 4) g.qcount[tile * 4 + tid] = s_qbase[tid];
 }
 
-__global__ __launch_bounds__(kSortThreads) void k_tile_sort(ViewParams vp, GeomPtrs g, BinPtrs b, uint32_t cap)
+__global__ __launch_bounds__(kSortThreads) void k_tile_sort(BatchDesc d)
 {
+    const ViewCtx c = resolve(d, blockIdx.y);
+    const ViewParams &vp = c.vp;
+    const GeomPtrs &g = c.g;
+    const BinPtrs &b = c.b;
+    const uint32_t cap = c.cap;
     __shared__ uint64_t s_key[kSortLdsCap];
     __shared__ uint32_t s_p[kSortLdsCap];
     const int t = blockIdx.x;
@@ -190,22 +198,22 @@ __global__ __launch_bounds__(kSortThreads) void k_tile_sort(ViewParams vp, GeomP
     }
 }
 
-int launch_colscan(int N, int T, const GeomPtrs &g, hipStream_t st)
+int launch_colscan(const BatchDesc &d, hipStream_t st)
 {
-    const int nb = (N + kPreBlock - 1) / kPreBlock;
+    const int T = ((d.W + kTile - 1) / kTile) * ((d.H + kTile - 1) / kTile);
     if (T <= 0) return DM4D_OK;
     ProfScope prof_(kKColscan, st);
-    hipLaunchKernelGGL(k_colscan, dim3((T + kColThreads - 1) / kColThreads), dim3(kColThreads), 0, st, nb, T, g);
+    hipLaunchKernelGGL(k_colscan, dim3((T + kColThreads - 1) / kColThreads, d.B), dim3(kColThreads), 0, st, d);
     DM4D_HIP_CHECK(hipGetLastError());
     return DM4D_OK;
 }
 
-int launch_tile_sort(const ViewParams &vp, const GeomPtrs &g, const BinPtrs &b, int64_t cap, hipStream_t st)
+int launch_tile_sort(const BatchDesc &d, hipStream_t st)
 {
-    const int T = vp.gx * vp.gy;
+    const int T = ((d.W + kTile - 1) / kTile) * ((d.H + kTile - 1) / kTile);
     if (T <= 0) return DM4D_OK;
     ProfScope prof_(kKTileSort, st);
-    hipLaunchKernelGGL(k_tile_sort, dim3(T), dim3(kSortThreads), 0, st, vp, g, b, (uint32_t)cap);
+    hipLaunchKernelGGL(k_tile_sort, dim3(T, d.B), dim3(kSortThreads), 0, st, d);
     DM4D_HIP_CHECK(hipGetLastError());
     return DM4D_OK;
 }

@@ -142,10 +142,15 @@ __device__ __forceinline__ f3 load3(const float *p, int i) { return f3{p[3 * i],
 // 64 consecutive Gaussians per step).  The per-tile duplicate histogram of the workgroup is
 // accumulated with LDS atomics and written densely to hist[WG][tile]; K2 turns it into
 // per-(WG, tile) bases.  No global atomics except one add per workgroup for D.
-__global__ __launch_bounds__(kPreThreads) void k_preprocess(ViewParams vp, dm4d_raster_inputs in,
-                                                            int32_t *__restrict__ radii, GeomPtrs g, int T)
+__global__ __launch_bounds__(kPreThreads) void k_preprocess(BatchDesc d)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t s_hist[];   // [T]
+    const ViewCtx c = resolve(d, blockIdx.y);
+    const ViewParams &vp = c.vp;
+    const dm4d_raster_inputs &in = c.in;
+    int32_t *__restrict__ radii = c.radii;
+    const GeomPtrs &g = c.g;
+    const int T = c.T;
     __shared__ float sV[16], sP[16];
     __shared__ uint32_t s_wsum[kPreThreads / 64];
     const int tid = threadIdx.x;
@@ -247,11 +252,16 @@ __device__ __forceinline__ uint32_t block_excl_scan_256(uint32_t v, uint32_t *s_
     return pre + incl - v;
 }
 
-__global__ __launch_bounds__(kPreThreads) void k_scatter(ViewParams vp, int N, int T, int nb,
-                                                         const int32_t *__restrict__ radii, GeomPtrs g, BinPtrs b,
-                                                         uint32_t cap)
+__global__ __launch_bounds__(kPreThreads) void k_scatter(BatchDesc d)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t s_cursor[];   // [T]
+    const ViewCtx c = resolve(d, blockIdx.y);
+    const ViewParams &vp = c.vp;
+    const int N = c.in.N, T = c.T;
+    const int32_t *__restrict__ radii = c.radii;
+    const GeomPtrs &g = c.g;
+    const BinPtrs &b = c.b;
+    const uint32_t cap = c.cap;
     __shared__ uint32_t s_w[kPreThreads / 64];
     const int tid = threadIdx.x;
     // tile_start = exclusive scan of tile_count (each workgroup redoes this small scan in LDS;
@@ -311,10 +321,17 @@ __global__ __launch_bounds__(kPreThreads) void k_scatter(ViewParams vp, int N, i
 }
 
 // ---------------------------------------------------------------------------------------- B2
-__global__ __launch_bounds__(kPreThreads) void k_gather_bwd(ViewParams vp, dm4d_raster_inputs in,
-                                                          const int32_t *__restrict__ radii, GeomPtrs g, BinPtrs b,
-                                                          uint32_t cap, const float *__restrict__ dLt, BwdOutputs o)
+__global__ __launch_bounds__(kPreThreads) void k_gather_bwd(BatchDesc d)
 {
+    const ViewCtx c = resolve(d, blockIdx.y);
+    const ViewParams &vp = c.vp;
+    const dm4d_raster_inputs &in = c.in;
+    const int32_t *__restrict__ radii = c.radii;
+    const GeomPtrs &g = c.g;
+    const BinPtrs &b = c.b;
+    const uint32_t cap = c.cap;
+    const float *__restrict__ dLt = c.dLq;
+    const BwdOutputs &o = c.o;
     __shared__ float sV[16], sP[16];
     const int tid = threadIdx.x;
     if (tid < 16) { sV[tid] = vp.view[tid]; sP[tid] = vp.proj[tid]; }
@@ -511,42 +528,51 @@ __global__ void k_mark_visible(int N, const float *__restrict__ means3D, const f
 }
 
 // ---------------------------------------------------------------------------------------- launchers
-int launch_preprocess(const ViewParams &vp, const dm4d_raster_inputs &in, int32_t *radii, const GeomPtrs &g,
-                      hipStream_t st)
+__global__ void k_zero_counters(BatchDesc d)
 {
-    const int nb = (in.N + kPreBlock - 1) / kPreBlock;
+    const int b = blockIdx.x;
+    if (threadIdx.x < 64) reinterpret_cast<uint32_t *>(d.geom + (size_t)b * d.geom_stride)[threadIdx.x] = 0u;
+}
+
+int launch_zero_counters(const BatchDesc &d, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_zero_counters, dim3(d.B), dim3(64), 0, st, d);
+    DM4D_HIP_CHECK(hipGetLastError());
+    return DM4D_OK;
+}
+
+int launch_preprocess(const BatchDesc &d, hipStream_t st)
+{
+    const int nb = (d.N + kPreBlock - 1) / kPreBlock;
     if (nb == 0) return DM4D_OK;
-    const int T = vp.gx * vp.gy;
+    const int T = ((d.W + kTile - 1) / kTile) * ((d.H + kTile - 1) / kTile);
     if ((size_t)T * 4 > 32768)
         DM4D_HIP_CHECK(hipFuncSetAttribute((const void *)k_preprocess, hipFuncAttributeMaxDynamicSharedMemorySize, T * 4));
     ProfScope prof_(kKPreprocess, st);
-    hipLaunchKernelGGL(k_preprocess, dim3(nb), dim3(kPreThreads), (size_t)T * 4, st, vp, in, radii, g, T);
+    hipLaunchKernelGGL(k_preprocess, dim3(nb, d.B), dim3(kPreThreads), (size_t)T * 4, st, d);
     DM4D_HIP_CHECK(hipGetLastError());
     return DM4D_OK;
 }
 
-int launch_scatter(const ViewParams &vp, int N, const int32_t *radii, const GeomPtrs &g, const BinPtrs &b,
-                   int64_t cap, hipStream_t st)
+int launch_scatter(const BatchDesc &d, hipStream_t st)
 {
     // always launched (even with N == 0): workgroup 0 publishes tile_start for the render kernels
-    const int nb = (N + kPreBlock - 1) / kPreBlock;
-    const int T = vp.gx * vp.gy;
+    const int nb = (d.N + kPreBlock - 1) / kPreBlock;
+    const int T = ((d.W + kTile - 1) / kTile) * ((d.H + kTile - 1) / kTile);
     if ((size_t)T * 4 > 32768)
         DM4D_HIP_CHECK(hipFuncSetAttribute((const void *)k_scatter, hipFuncAttributeMaxDynamicSharedMemorySize, T * 4));
     ProfScope prof_(kKScatter, st);
-    hipLaunchKernelGGL(k_scatter, dim3(nb > 0 ? nb : 1), dim3(kPreThreads), (size_t)T * 4, st, vp, N, T, nb, radii, g,
-                       b, (uint32_t)cap);
+    hipLaunchKernelGGL(k_scatter, dim3(nb > 0 ? nb : 1, d.B), dim3(kPreThreads), (size_t)T * 4, st, d);
     DM4D_HIP_CHECK(hipGetLastError());
     return DM4D_OK;
 }
 
-int launch_gather_bwd(const ViewParams &vp, const dm4d_raster_inputs &in, const int32_t *radii, const GeomPtrs &g,
-                      const BinPtrs &b, int64_t cap, const float *dLt, const BwdOutputs &o, hipStream_t st)
+int launch_gather_bwd(const BatchDesc &d, hipStream_t st)
 {
-    const int nb = (in.N + kPreThreads - 1) / kPreThreads;
+    const int nb = (d.N + kPreThreads - 1) / kPreThreads;
     if (nb == 0) return DM4D_OK;
     ProfScope prof_(kKGatherBwd, st);
-    hipLaunchKernelGGL(k_gather_bwd, dim3(nb), dim3(kPreThreads), 0, st, vp, in, radii, g, b, (uint32_t)cap, dLt, o);
+    hipLaunchKernelGGL(k_gather_bwd, dim3(nb, d.B), dim3(kPreThreads), 0, st, d);
     DM4D_HIP_CHECK(hipGetLastError());
     return DM4D_OK;
 }

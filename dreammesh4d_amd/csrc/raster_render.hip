@@ -69,12 +69,20 @@ __device__ __forceinline__ void block_to_quadrant(int b, int &tile, int &q)
 
 // ---------------------------------------------------------------------------------------- K5
 template <int C>
-__global__ __launch_bounds__(64) void k_render_fwd(ViewParams vp, const float *__restrict__ colors, GeomPtrs g,
-                                                   BinPtrs b, uint32_t cap, ImgPtrs im, float *__restrict__ out_color,
-                                                   float *__restrict__ out_depth, float *__restrict__ out_alpha, int T)
+__global__ __launch_bounds__(64) void k_render_fwd(BatchDesc d)
 {
     constexpr int NV = StagedN<C>::kVec;
     __shared__ float4 s_e[2][64][NV];
+    const ViewCtx c = resolve(d, blockIdx.y);
+    const ViewParams &vp = c.vp;
+    const float *__restrict__ colors = c.colors;
+    const GeomPtrs &g = c.g;
+    const BinPtrs &b = c.b;
+    const uint32_t cap = c.cap;
+    const ImgPtrs &im = c.im;
+    float *__restrict__ out_color = c.out_color, *__restrict__ out_depth = c.out_depth,
+                       *__restrict__ out_alpha = c.out_alpha;
+    const int T = c.T;
     int tile, q;
     block_to_quadrant(blockIdx.x, tile, q);
     if (tile >= T) return;
@@ -186,15 +194,22 @@ __device__ __forceinline__ void wave_reduce_packed(const float (&v)[NV], float (
 }
 
 template <int C>
-__global__ __launch_bounds__(64) void k_render_bwd(ViewParams vp, const float *__restrict__ colors, GeomPtrs g,
-                                                   BinPtrs b, uint32_t cap, ImgPtrs im,
-                                                   const float *__restrict__ dL_dcolor,
-                                                   const float *__restrict__ dL_ddepth,
-                                                   const float *__restrict__ dL_dalpha, float *__restrict__ dLq, int T)
+__global__ __launch_bounds__(64) void k_render_bwd(BatchDesc d)
 {
     constexpr int NV = StagedN<C>::kVec;
     constexpr int GS = (C <= 3) ? 12 : 16;   // == grad_stride(C)
     __shared__ float4 s_e[2][64][NV];
+    const ViewCtx c = resolve(d, blockIdx.y);
+    const ViewParams &vp = c.vp;
+    const float *__restrict__ colors = c.colors;
+    const GeomPtrs &g = c.g;
+    const BinPtrs &b = c.b;
+    const uint32_t cap = c.cap;
+    const ImgPtrs &im = c.im;
+    const float *__restrict__ dL_dcolor = c.dL_dcolor, *__restrict__ dL_ddepth = c.dL_ddepth,
+                             *__restrict__ dL_dalpha = c.dL_dalpha;
+    float *__restrict__ dLq = c.dLq;
+    const int T = c.T;
     int tile, q;
     block_to_quadrant(blockIdx.x, tile, q);
     if (tile >= T) return;
@@ -312,48 +327,28 @@ __global__ __launch_bounds__(64) void k_render_bwd(ViewParams vp, const float *_
 }
 
 // ---------------------------------------------------------------------------------------- launchers
-template <int C>
-static int launch_fwd_t(const ViewParams &vp, const float *colors, const GeomPtrs &g, const BinPtrs &b, int64_t cap,
-                        const ImgPtrs &im, float *out_color, float *out_depth, float *out_alpha, hipStream_t st)
+int launch_render_fwd(const BatchDesc &d, hipStream_t st)
 {
-    const int T = vp.gx * vp.gy;
+    const int T = ((d.W + kTile - 1) / kTile) * ((d.H + kTile - 1) / kTile);
+    if (T <= 0) return DM4D_OK;
     const int blocks = ((T + 7) / 8) * 8 * 4;
     ProfScope prof_(kKRenderFwd, st);
-    hipLaunchKernelGGL(k_render_fwd<C>, dim3(blocks), dim3(64), 0, st, vp, colors, g, b, (uint32_t)cap, im, out_color,
-                       out_depth, out_alpha, T);
+    if (d.C <= 3) hipLaunchKernelGGL(k_render_fwd<3>, dim3(blocks, d.B), dim3(64), 0, st, d);
+    else hipLaunchKernelGGL(k_render_fwd<6>, dim3(blocks, d.B), dim3(64), 0, st, d);
     DM4D_HIP_CHECK(hipGetLastError());
     return DM4D_OK;
 }
 
-int launch_render_fwd(const ViewParams &vp, const float *colors, const GeomPtrs &g, const BinPtrs &b, int64_t cap,
-                      const ImgPtrs &im, float *out_color, float *out_depth, float *out_alpha, hipStream_t st)
+int launch_render_bwd(const BatchDesc &d, hipStream_t st)
 {
-    if (vp.gx * vp.gy <= 0) return DM4D_OK;
-    return vp.C <= 3 ? launch_fwd_t<3>(vp, colors, g, b, cap, im, out_color, out_depth, out_alpha, st)
-                     : launch_fwd_t<6>(vp, colors, g, b, cap, im, out_color, out_depth, out_alpha, st);
-}
-
-template <int C>
-static int launch_bwd_t(const ViewParams &vp, const float *colors, const GeomPtrs &g, const BinPtrs &b, int64_t cap,
-                        const ImgPtrs &im, const float *dL_dcolor, const float *dL_ddepth, const float *dL_dalpha,
-                        float *dLq, hipStream_t st)
-{
-    const int T = vp.gx * vp.gy;
+    const int T = ((d.W + kTile - 1) / kTile) * ((d.H + kTile - 1) / kTile);
+    if (T <= 0) return DM4D_OK;
     const int blocks = ((T + 7) / 8) * 8 * 4;
     ProfScope prof_(kKRenderBwd, st);
-    hipLaunchKernelGGL(k_render_bwd<C>, dim3(blocks), dim3(64), 0, st, vp, colors, g, b, (uint32_t)cap, im, dL_dcolor,
-                       dL_ddepth, dL_dalpha, dLq, T);
+    if (d.C <= 3) hipLaunchKernelGGL(k_render_bwd<3>, dim3(blocks, d.B), dim3(64), 0, st, d);
+    else hipLaunchKernelGGL(k_render_bwd<6>, dim3(blocks, d.B), dim3(64), 0, st, d);
     DM4D_HIP_CHECK(hipGetLastError());
     return DM4D_OK;
-}
-
-int launch_render_bwd(const ViewParams &vp, const float *colors, const GeomPtrs &g, const BinPtrs &b, int64_t cap,
-                      const ImgPtrs &im, const float *dL_dcolor, const float *dL_ddepth, const float *dL_dalpha,
-                      float *dLq, hipStream_t st)
-{
-    if (vp.gx * vp.gy <= 0) return DM4D_OK;
-    return vp.C <= 3 ? launch_bwd_t<3>(vp, colors, g, b, cap, im, dL_dcolor, dL_ddepth, dL_dalpha, dLq, st)
-                     : launch_bwd_t<6>(vp, colors, g, b, cap, im, dL_dcolor, dL_ddepth, dL_dalpha, dLq, st);
 }
 
 // ---- self-test of the packed reduction (exported through dm4d_selftest_wave_reduce) ----------
