@@ -40,6 +40,25 @@ class RasterInputs(C.Structure):
     ]
 
 
+class ViewsStruct(C.Structure):
+    """dm4d_views (include/dm4d.h)."""
+    _fields_ = [(n, C.c_int32) for n in ("B", "N", "F", "G", "V", "M", "K", "method", "image_height", "image_width")] + \
+               [(n, C.c_float) for n in ("tanfovx", "tanfovy", "scale_modifier")] + [("capacity", C.c_int64)] + \
+               [(n, vp) for n in ("bg", "viewmatrix", "projmatrix", "verts", "nbr_idx", "nbr_w", "dx", "dr", "ds",
+                                  "d_opacity", "faces", "q_static", "scales", "opacities", "rgb", "vxyz", "vrot",
+                                  "means3D", "rotations", "colors", "radii", "out_color", "out_depth", "out_alpha",
+                                  "geom", "binning", "image")]
+
+
+class ViewsGrads(C.Structure):
+    """dm4d_views_grads (include/dm4d.h)."""
+    _fields_ = [(n, vp) for n in ("dL_dcolor", "dL_ddepth", "dL_dalpha", "dL_dvxyz_ext", "dL_dvrot_ext",
+                                  "node_csr_offsets", "node_csr_items", "vert_csr_offsets", "vert_csr_items",
+                                  "grad_scratch", "skin_scratch", "face_scratch", "dL_dmeans2D", "dL_dmeans3D",
+                                  "dL_drotations", "dL_dcolors", "dL_dopacity", "dL_dscales", "dL_dvxyz", "dL_dvrot",
+                                  "dL_ddx", "dL_ddr", "dL_dds", "dL_ddo")]
+
+
 ALLOC_FN = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_int, C.c_size_t)
 
 _SIGNATURES = {
@@ -73,6 +92,15 @@ _SIGNATURES = {
     "dm4d_face_gaussians_forward": (C.c_int, [C.c_int32] * 2 + [vp] * 8),
     "dm4d_face_scratch_bytes": (C.c_size_t, [C.c_int32]),
     "dm4d_face_gaussians_backward": (C.c_int, [C.c_int32] * 3 + [vp] * 13),
+    "dm4d_views_geom_bytes": (C.c_size_t, [C.c_int32] * 4),
+    "dm4d_views_binning_bytes": (C.c_size_t, [C.c_int32, C.c_int64]),
+    "dm4d_views_image_bytes": (C.c_size_t, [C.c_int32] * 3),
+    "dm4d_views_grad_bytes": (C.c_size_t, [C.c_int32, C.c_int64]),
+    "dm4d_views_skin_scratch_bytes": (C.c_size_t, [C.c_int32] * 3),
+    "dm4d_views_face_scratch_bytes": (C.c_size_t, [C.c_int32] * 2),
+    "dm4d_views_forward": (C.c_int, [C.POINTER(ViewsStruct), vp]),
+    "dm4d_views_backward": (C.c_int, [C.POINTER(ViewsStruct), C.POINTER(ViewsGrads), vp]),
+    "dm4d_views_counters": (C.c_int, [C.POINTER(ViewsStruct), C.POINTER(C.c_int64), C.POINTER(C.c_int32), vp]),
 }
 
 

@@ -146,15 +146,28 @@ constexpr int kNodeRec = 14;   // dx3 dr4 ds6 do1
 struct SkinArgs {
     int method, V, M, K;
     const float *verts; const int32_t *nbr_idx; const float *nbr_w;
-    const float *dx, *dr, *ds, *dop;
+    const float *dx, *dr, *ds, *dop;     // [B][M][3|4|6|1]: blockIdx.y selects the view
 };
+// per-view slices of the batched node tables
+__device__ __forceinline__ SkinArgs skin_view(SkinArgs a, int b)
+{
+    const size_t o = (size_t)b * a.M;
+    a.dx += o * 3;
+    a.dr += o * 4;
+    if (a.ds) a.ds += o * 6;
+    if (a.dop) a.dop += o;
+    return a;
+}
 
 // ---------------------------------------------------------------------------------------- forward
-__global__ __launch_bounds__(kSkinThreads) void k_skin_fwd(SkinArgs a, float *__restrict__ out_xyz,
+__global__ __launch_bounds__(kSkinThreads) void k_skin_fwd(SkinArgs a0, float *__restrict__ out_xyz,
                                                            float *__restrict__ out_rot)
 {
     const int v = blockIdx.x * kSkinThreads + threadIdx.x;
-    if (v >= a.V) return;
+    if (v >= a0.V) return;
+    const SkinArgs a = skin_view(a0, blockIdx.y);
+    out_xyz += (size_t)blockIdx.y * a.V * 3;
+    out_rot += (size_t)blockIdx.y * a.V * 4;
     const v3 p = ld3(a.verts, v);
     v3 x_lbs = mk3(0, 0, 0), rho = mk3(0, 0, 0);
     q4 br = q4{0, 0, 0, 0}, bd = q4{0, 0, 0, 0};
@@ -199,12 +212,16 @@ __global__ __launch_bounds__(kSkinThreads) void k_skin_fwd(SkinArgs a, float *__
 
 // ---------------------------------------------------------------------------------------- backward 1
 // per vertex: gradients w.r.t. the raw outputs of its K neighbour nodes -> rec[v][k][14]
-__global__ __launch_bounds__(kSkinThreads) void k_skin_bwd_vertex(SkinArgs a, const float *__restrict__ g_xyz,
+__global__ __launch_bounds__(kSkinThreads) void k_skin_bwd_vertex(SkinArgs a0, const float *__restrict__ g_xyz,
                                                                   const float *__restrict__ g_rot,
                                                                   float *__restrict__ rec)
 {
     const int v = blockIdx.x * kSkinThreads + threadIdx.x;
-    if (v >= a.V) return;
+    if (v >= a0.V) return;
+    const SkinArgs a = skin_view(a0, blockIdx.y);
+    if (g_xyz) g_xyz += (size_t)blockIdx.y * a.V * 3;
+    if (g_rot) g_rot += (size_t)blockIdx.y * a.V * 4;
+    rec += (size_t)blockIdx.y * a.V * a.K * kNodeRec;
     const v3 p = ld3(a.verts, v);
     const v3 gx = g_xyz ? ld3(g_xyz, v) : mk3(0, 0, 0);
     const q4 gq = g_rot ? ldq(g_rot, v) : q4{0, 0, 0, 0};
@@ -302,10 +319,18 @@ __global__ __launch_bounds__(64) void k_skin_bwd_node(int M, const int32_t *__re
                                                       const int32_t *__restrict__ csr_item,
                                                       const float *__restrict__ rec, float *__restrict__ g_dx,
                                                       float *__restrict__ g_dr, float *__restrict__ g_ds,
-                                                      float *__restrict__ g_do)
+                                                      float *__restrict__ g_do, size_t rec_view_stride)
 {
     const int m = blockIdx.x * 64 + threadIdx.x;
     if (m >= M) return;
+    {
+        const size_t bv = blockIdx.y, o = bv * M;
+        rec += bv * rec_view_stride;
+        if (g_dx) g_dx += o * 3;
+        if (g_dr) g_dr += o * 4;
+        if (g_ds) g_ds += o * 6;
+        if (g_do) g_do += o;
+    }
     float acc[kNodeRec];
 #pragma unroll
     for (int i = 0; i < kNodeRec; ++i) acc[i] = 0.f;
@@ -330,15 +355,27 @@ __constant__ float c_bary[4][kMaxPerFace][3] = {
      {1.f / 6, 5.f / 12, 5.f / 12}, {5.f / 12, 1.f / 6, 5.f / 12}, {5.f / 12, 5.f / 12, 1.f / 6}}};   // sugar.py:235-276
 __device__ __forceinline__ int bary_row(int G) { return G == 1 ? 0 : G == 3 ? 1 : G == 4 ? 2 : 3; }
 
-__global__ __launch_bounds__(kSkinThreads) void k_face_fwd(int F, int G, const int32_t *__restrict__ faces,
+// normals are written at normals[i * nstride + 0..2] (nstride 3, or 6 when they are the second half of a
+// fused [N,6] colour buffer whose first half receives `rgb`)
+__global__ __launch_bounds__(kSkinThreads) void k_face_fwd(int F, int G, int V, const int32_t *__restrict__ faces,
                                                            const float *__restrict__ vxyz,
                                                            const float *__restrict__ vrot,
                                                            const float *__restrict__ q_static /* [N,4] wxyz */,
                                                            float *__restrict__ means, float *__restrict__ rots,
-                                                           float *__restrict__ normals)
+                                                           float *__restrict__ normals, int nstride,
+                                                           const float *__restrict__ rgb, float *__restrict__ colors6)
 {
     const int i = blockIdx.x * kSkinThreads + threadIdx.x;
     if (i >= F * G) return;
+    {
+        const size_t bv = blockIdx.y, n = (size_t)F * G;
+        vxyz += bv * V * 3;
+        vrot += bv * V * 4;
+        means += bv * n * 3;
+        rots += bv * n * 4;
+        if (normals) normals += bv * n * nstride;
+        if (colors6) colors6 += bv * n * 6;
+    }
     const int f = i / G, s = i - f * G;
     const int i0 = faces[3 * f], i1 = faces[3 * f + 1], i2 = faces[3 * f + 2];
     const float *b = c_bary[bary_row(G)][s];
@@ -352,22 +389,37 @@ __global__ __launch_bounds__(kSkinThreads) void k_face_fwd(int F, int G, const i
     reinterpret_cast<float4 *>(rots)[i] = make_float4(Q.w * inv, Q.x * inv, Q.y * inv, Q.z * inv);
     if (normals) {
         const v3 c = cross(x1 - x0, x2 - x0);
-        st3(normals, i, (1.f / fmaxf(sqrtf(dot(c, c)), 1e-12f)) * c);
+        const v3 nn = (1.f / fmaxf(sqrtf(dot(c, c)), 1e-12f)) * c;
+        float *o = normals + (size_t)i * nstride;
+        o[0] = nn.x; o[1] = nn.y; o[2] = nn.z;
+    }
+    if (colors6) {
+        float *o = colors6 + (size_t)i * 6;
+        o[0] = rgb[3 * i]; o[1] = rgb[3 * i + 1]; o[2] = rgb[3 * i + 2];
     }
 }
 
 constexpr int kCornerRec = 6;   // dL/dx (3) + dL/d(rotation-vector blend) (3) per face corner
-__global__ __launch_bounds__(kSkinThreads) void k_face_bwd_face(int F, int G, const int32_t *__restrict__ faces,
+__global__ __launch_bounds__(kSkinThreads) void k_face_bwd_face(int F, int G, int V, const int32_t *__restrict__ faces,
                                                                 const float *__restrict__ vxyz,
                                                                 const float *__restrict__ vrot,
                                                                 const float *__restrict__ q_static,
                                                                 const float *__restrict__ g_means,
                                                                 const float *__restrict__ g_rots,
-                                                                const float *__restrict__ g_normals,
+                                                                const float *__restrict__ g_normals, int nstride,
                                                                 float *__restrict__ rec /* [F][3][6] */)
 {
     const int f = blockIdx.x * kSkinThreads + threadIdx.x;
     if (f >= F) return;
+    {
+        const size_t bv = blockIdx.y, n = (size_t)F * G;
+        vxyz += bv * V * 3;
+        vrot += bv * V * 4;
+        if (g_means) g_means += bv * n * 3;
+        if (g_rots) g_rots += bv * n * 4;
+        if (g_normals) g_normals += bv * n * nstride;
+        rec += bv * F * 3 * kCornerRec;
+    }
     const int i0 = faces[3 * f], i1 = faces[3 * f + 1], i2 = faces[3 * f + 2];
     const v3 x0 = ld3(vxyz, i0), x1 = ld3(vxyz, i1), x2 = ld3(vxyz, i2);
     const v3 L0 = so3_log(ldq(vrot, i0)), L1 = so3_log(ldq(vrot, i1)), L2 = so3_log(ldq(vrot, i2));
@@ -395,7 +447,7 @@ __global__ __launch_bounds__(kSkinThreads) void k_face_bwd_face(int F, int G, co
             const v3 gr = so3_exp_grad(r, gqd);
             R[0] = R[0] + b[0] * gr; R[1] = R[1] + b[1] * gr; R[2] = R[2] + b[2] * gr;
         }
-        if (g_normals) gn = gn + ld3(g_normals, i);
+        if (g_normals) { const float *pn = g_normals + i * nstride; gn = gn + mk3(pn[0], pn[1], pn[2]); }
     }
     if (g_normals) {
         const v3 e1 = x1 - x0, e2 = x2 - x0, c = cross(e1, e2);
@@ -416,22 +468,35 @@ __global__ __launch_bounds__(kSkinThreads) void k_face_bwd_face(int F, int G, co
 }
 
 // per vertex: fixed-order sum over incident face corners (static CSR), then Log backward
-__global__ __launch_bounds__(kSkinThreads) void k_face_bwd_vertex(int V, const int32_t *__restrict__ csr_off,
+// ext_*: optional extra upstream gradients on the deformed vertices (mesh regularisers), added here
+__global__ __launch_bounds__(kSkinThreads) void k_face_bwd_vertex(int V, int F, const int32_t *__restrict__ csr_off,
                                                                   const int32_t *__restrict__ csr_item /* 3f+j */,
                                                                   const float *__restrict__ vrot,
                                                                   const float *__restrict__ rec,
+                                                                  const float *__restrict__ ext_xyz,
+                                                                  const float *__restrict__ ext_rot,
                                                                   float *__restrict__ g_vxyz, float *__restrict__ g_vrot)
 {
     const int v = blockIdx.x * kSkinThreads + threadIdx.x;
     if (v >= V) return;
-    v3 X = mk3(0, 0, 0), R = mk3(0, 0, 0);
+    {
+        const size_t bv = blockIdx.y;
+        vrot += bv * V * 4;
+        rec += bv * F * 3 * kCornerRec;
+        g_vxyz += bv * V * 3;
+        g_vrot += bv * V * 4;
+        if (ext_xyz) ext_xyz += bv * V * 3;
+        if (ext_rot) ext_rot += bv * V * 4;
+    }
+    v3 X = ext_xyz ? ld3(ext_xyz, v) : mk3(0, 0, 0), R = mk3(0, 0, 0);
     for (int e = csr_off[v]; e < csr_off[v + 1]; ++e) {
         const float *r = rec + (size_t)csr_item[e] * kCornerRec;
         X = X + mk3(r[0], r[1], r[2]);
         R = R + mk3(r[3], r[4], r[5]);
     }
     st3(g_vxyz, v, X);
-    const q4 g = so3_log_grad(ldq(vrot, v), R);
+    q4 g = so3_log_grad(ldq(vrot, v), R);
+    if (ext_rot) g = qadd(g, ldq(ext_rot, v));
     reinterpret_cast<float4 *>(g_vrot)[v] = make_float4(g.x, g.y, g.z, g.w);
 }
 
@@ -439,8 +504,73 @@ __global__ __launch_bounds__(kSkinThreads) void k_face_bwd_vertex(int V, const i
 
 using namespace dm4d;
 
-static int skin_check(int method, int V, int M, int K, const void *verts, const void *idx, const void *w, const void *dx,
-                      const void *dr, const void *ds, const void *dop)
+namespace dm4d {
+
+int skin_forward_launch(int B, int method, int V, int M, int K, const float *verts, const int32_t *idx, const float *w,
+                        const float *dx, const float *dr, const float *ds, const float *dop, float *out_xyz,
+                        float *out_rot, hipStream_t st)
+{
+    if (V <= 0 || B <= 0) return DM4D_OK;
+    SkinArgs a{method, V, M, K, verts, idx, w, dx, dr, method == kDqs ? nullptr : ds, method == kHybrid ? dop : nullptr};
+    ProfScope prof_(kKSkinFwd, st);
+    hipLaunchKernelGGL(k_skin_fwd, dim3((V + kSkinThreads - 1) / kSkinThreads, B), dim3(kSkinThreads), 0, st, a, out_xyz, out_rot);
+    DM4D_HIP_CHECK(hipGetLastError());
+    return DM4D_OK;
+}
+
+int skin_backward_launch(int B, int method, int V, int M, int K, const float *verts, const int32_t *idx, const float *w,
+                         const float *dx, const float *dr, const float *ds, const float *dop, const float *g_xyz,
+                         const float *g_rot, const int32_t *csr_off, const int32_t *csr_items, float *scratch,
+                         float *o_dx, float *o_dr, float *o_ds, float *o_do, hipStream_t st)
+{
+    if (B <= 0) return DM4D_OK;
+    SkinArgs a{method, V, M, K, verts, idx, w, dx, dr, method == kDqs ? nullptr : ds, method == kHybrid ? dop : nullptr};
+    ProfScope prof_(kKSkinBwd, st);
+    if (V > 0) {
+        hipLaunchKernelGGL(k_skin_bwd_vertex, dim3((V + kSkinThreads - 1) / kSkinThreads, B), dim3(kSkinThreads), 0, st, a,
+                           g_xyz, g_rot, scratch);
+        DM4D_HIP_CHECK(hipGetLastError());
+    }
+    hipLaunchKernelGGL(k_skin_bwd_node, dim3((M + 63) / 64, B), dim3(64), 0, st, M, csr_off, csr_items,
+                       (const float *)scratch, o_dx, o_dr, o_ds, o_do, (size_t)V * K * kNodeRec);
+    DM4D_HIP_CHECK(hipGetLastError());
+    return DM4D_OK;
+}
+
+int face_forward_launch(int B, int F, int G, int V, const int32_t *faces, const float *vxyz, const float *vrot,
+                        const float *qs, float *means, float *rots, float *normals, int nstride, const float *rgb,
+                        float *colors6, hipStream_t st)
+{
+    if (F <= 0 || B <= 0) return DM4D_OK;
+    ProfScope prof_(kKFaceFwd, st);
+    hipLaunchKernelGGL(k_face_fwd, dim3((F * G + kSkinThreads - 1) / kSkinThreads, B), dim3(kSkinThreads), 0, st, F, G, V,
+                       faces, vxyz, vrot, qs, means, rots, normals, nstride, rgb, colors6);
+    DM4D_HIP_CHECK(hipGetLastError());
+    return DM4D_OK;
+}
+
+int face_backward_launch(int B, int F, int G, int V, const int32_t *faces, const float *vxyz, const float *vrot,
+                         const float *qs, const float *g_means, const float *g_rots, const float *g_normals, int nstride,
+                         const int32_t *csr_off, const int32_t *csr_items, float *scratch, const float *ext_xyz,
+                         const float *ext_rot, float *o_vxyz, float *o_vrot, hipStream_t st)
+{
+    if (B <= 0) return DM4D_OK;
+    ProfScope prof_(kKFaceBwd, st);
+    if (F > 0) {
+        hipLaunchKernelGGL(k_face_bwd_face, dim3((F + kSkinThreads - 1) / kSkinThreads, B), dim3(kSkinThreads), 0, st, F, G,
+                           V, faces, vxyz, vrot, qs, g_means, g_rots, g_normals, nstride, scratch);
+        DM4D_HIP_CHECK(hipGetLastError());
+    }
+    if (V > 0) {
+        hipLaunchKernelGGL(k_face_bwd_vertex, dim3((V + kSkinThreads - 1) / kSkinThreads, B), dim3(kSkinThreads), 0, st, V,
+                           F, csr_off, csr_items, vrot, (const float *)scratch, ext_xyz, ext_rot, o_vxyz, o_vrot);
+        DM4D_HIP_CHECK(hipGetLastError());
+    }
+    return DM4D_OK;
+}
+
+int skin_check(int method, int V, int M, int K, const void *verts, const void *idx, const void *w, const void *dx,
+               const void *dr, const void *ds, const void *dop)
 {
     if (method < 0 || method > 2) { set_error("method must be 0 (lbs), 1 (dqs) or 2 (hybrid)"); return DM4D_ERR_INVALID; }
     if (V < 0 || M <= 0 || K <= 0 || K > kMaxK) { set_error("bad V/M/K (%d/%d/%d)", V, M, K); return DM4D_ERR_INVALID; }
@@ -449,6 +579,17 @@ static int skin_check(int method, int V, int M, int K, const void *verts, const 
     if (method == kHybrid && !dop) { set_error("hybrid needs the opacity output"); return DM4D_ERR_INVALID; }
     return DM4D_OK;
 }
+
+int face_check(int F, int G, const void *faces, const void *vxyz, const void *vrot, const void *qs)
+{
+    if (F < 0 || !(G == 1 || G == 3 || G == 4 || G == 6)) { set_error("bad F/G (%d/%d); G must be 1, 3, 4 or 6", F, G); return DM4D_ERR_INVALID; }
+    if (F > 0 && (!faces || !vxyz || !vrot || !qs)) { set_error("null input"); return DM4D_ERR_INVALID; }
+    return DM4D_OK;
+}
+
+}  // namespace dm4d
+
+using namespace dm4d;
 
 extern "C" {
 
@@ -461,13 +602,8 @@ int dm4d_skin_vertices_forward(int32_t method, int32_t V, int32_t M, int32_t K, 
     if (rc) return rc;
     if (V == 0) return DM4D_OK;
     if (!out_xyz || !out_rot) { set_error("null output"); return DM4D_ERR_INVALID; }
-    hipStream_t st = (hipStream_t)stream;
-    SkinArgs a{method, V, M, K, verts, nbr_idx, nbr_w, dx, dr, method == kDqs ? nullptr : ds,
-               method == kHybrid ? d_opacity : nullptr};
-    ProfScope prof_(kKSkinFwd, st);
-    hipLaunchKernelGGL(k_skin_fwd, dim3((V + kSkinThreads - 1) / kSkinThreads), dim3(kSkinThreads), 0, st, a, out_xyz, out_rot);
-    DM4D_HIP_CHECK(hipGetLastError());
-    return DM4D_OK;
+    return skin_forward_launch(1, method, V, M, K, verts, nbr_idx, nbr_w, dx, dr, ds, d_opacity, out_xyz, out_rot,
+                               (hipStream_t)stream);
 }
 
 size_t dm4d_skin_scratch_bytes(int32_t V, int32_t K) { return (size_t)(V > 0 ? V : 1) * K * kNodeRec * 4; }
@@ -481,26 +617,9 @@ int dm4d_skin_vertices_backward(int32_t method, int32_t V, int32_t M, int32_t K,
     int rc = skin_check(method, V, M, K, verts, nbr_idx, nbr_w, dx, dr, ds, d_opacity);
     if (rc) return rc;
     if (!node_csr_offsets || !node_csr_items || !scratch) { set_error("null csr/scratch"); return DM4D_ERR_INVALID; }
-    hipStream_t st = (hipStream_t)stream;
-    SkinArgs a{method, V, M, K, verts, nbr_idx, nbr_w, dx, dr, method == kDqs ? nullptr : ds,
-               method == kHybrid ? d_opacity : nullptr};
-    ProfScope prof_(kKSkinBwd, st);
-    if (V > 0) {
-        hipLaunchKernelGGL(k_skin_bwd_vertex, dim3((V + kSkinThreads - 1) / kSkinThreads), dim3(kSkinThreads), 0, st, a,
-                           dL_dxyz, dL_drot, (float *)scratch);
-        DM4D_HIP_CHECK(hipGetLastError());
-    }
-    hipLaunchKernelGGL(k_skin_bwd_node, dim3((M + 63) / 64), dim3(64), 0, st, M, node_csr_offsets, node_csr_items,
-                       (const float *)scratch, dL_ddx, dL_ddr, dL_dds, dL_ddo);
-    DM4D_HIP_CHECK(hipGetLastError());
-    return DM4D_OK;
-}
-
-static int face_check(int F, int G, const void *faces, const void *vxyz, const void *vrot, const void *qs)
-{
-    if (F < 0 || !(G == 1 || G == 3 || G == 4 || G == 6)) { set_error("bad F/G (%d/%d); G must be 1, 3, 4 or 6", F, G); return DM4D_ERR_INVALID; }
-    if (F > 0 && (!faces || !vxyz || !vrot || !qs)) { set_error("null input"); return DM4D_ERR_INVALID; }
-    return DM4D_OK;
+    return skin_backward_launch(1, method, V, M, K, verts, nbr_idx, nbr_w, dx, dr, ds, d_opacity, dL_dxyz, dL_drot,
+                                node_csr_offsets, node_csr_items, (float *)scratch, dL_ddx, dL_ddr, dL_dds, dL_ddo,
+                                (hipStream_t)stream);
 }
 
 int dm4d_face_gaussians_forward(int32_t F, int32_t G, const int32_t *faces, const float *vxyz, const float *vrot,
@@ -511,12 +630,8 @@ int dm4d_face_gaussians_forward(int32_t F, int32_t G, const int32_t *faces, cons
     if (rc) return rc;
     if (F == 0) return DM4D_OK;
     if (!means || !rotations_wxyz) { set_error("null output"); return DM4D_ERR_INVALID; }
-    hipStream_t st = (hipStream_t)stream;
-    ProfScope prof_(kKFaceFwd, st);
-    hipLaunchKernelGGL(k_face_fwd, dim3((F * G + kSkinThreads - 1) / kSkinThreads), dim3(kSkinThreads), 0, st, F, G, faces,
-                       vxyz, vrot, q_static_wxyz, means, rotations_wxyz, normals);
-    DM4D_HIP_CHECK(hipGetLastError());
-    return DM4D_OK;
+    return face_forward_launch(1, F, G, 0, faces, vxyz, vrot, q_static_wxyz, means, rotations_wxyz, normals, 3, nullptr,
+                               nullptr, (hipStream_t)stream);
 }
 
 size_t dm4d_face_scratch_bytes(int32_t F) { return (size_t)(F > 0 ? F : 1) * 3 * kCornerRec * 4; }
@@ -530,19 +645,9 @@ int dm4d_face_gaussians_backward(int32_t F, int32_t G, int32_t V, const int32_t 
     int rc = face_check(F, G, faces, vxyz, vrot, q_static_wxyz);
     if (rc) return rc;
     if (V < 0 || !vert_csr_offsets || !vert_csr_items || !scratch || !dL_dvxyz || !dL_dvrot) { set_error("null csr/scratch/output"); return DM4D_ERR_INVALID; }
-    hipStream_t st = (hipStream_t)stream;
-    ProfScope prof_(kKFaceBwd, st);
-    if (F > 0) {
-        hipLaunchKernelGGL(k_face_bwd_face, dim3((F + kSkinThreads - 1) / kSkinThreads), dim3(kSkinThreads), 0, st, F, G, faces,
-                           vxyz, vrot, q_static_wxyz, dL_dmeans, dL_drotations_wxyz, dL_dnormals, (float *)scratch);
-        DM4D_HIP_CHECK(hipGetLastError());
-    }
-    if (V > 0) {
-        hipLaunchKernelGGL(k_face_bwd_vertex, dim3((V + kSkinThreads - 1) / kSkinThreads), dim3(kSkinThreads), 0, st, V,
-                           vert_csr_offsets, vert_csr_items, vrot, (const float *)scratch, dL_dvxyz, dL_dvrot);
-        DM4D_HIP_CHECK(hipGetLastError());
-    }
-    return DM4D_OK;
+    return face_backward_launch(1, F, G, V, faces, vxyz, vrot, q_static_wxyz, dL_dmeans, dL_drotations_wxyz, dL_dnormals,
+                                3, vert_csr_offsets, vert_csr_items, (float *)scratch, nullptr, nullptr, dL_dvxyz,
+                                dL_dvrot, (hipStream_t)stream);
 }
 
 }  // extern "C"

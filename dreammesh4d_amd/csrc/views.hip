@@ -1,0 +1,160 @@
+// views.hip -- the whole per-view hot path for a BATCH of (frame, view) units in 8 + 6 launches:
+//
+//   forward : skin vertices -> face->Gaussians (+ normals into the fused colour buffer) -> zero
+//             counters -> preprocess -> colscan -> scatter -> tile sort -> blend (6 channels)
+//   backward: blend bwd -> gather + preprocess bwd -> face bwd (faces, vertices) -> skin bwd
+//             (vertices, nodes)
+//
+// Every launch covers all B views (grid.y = view), there is NO host synchronisation (the duplicate
+// lists use a caller-chosen capacity; overflow raises a flag the host reads lazily), and the
+// RGB pass and the normal pass of the reference's renderer
+// (custom/threestudio-dreammesh4d/renderer/diff_sugar_rasterizer_temporal.py:161-217) share one
+// binning and one blend.  This is what custom/.../renderer/gaussian_batch_renderer.py:21-76 does with a
+// Python loop over views and two rasterizer calls (two host syncs) per view.
+#include <string.h>
+#include <vector>
+#include "common.h"
+#include "raster.h"
+
+namespace dm4d {
+int skin_forward_launch(int B, int method, int V, int M, int K, const float *verts, const int32_t *idx, const float *w,
+                        const float *dx, const float *dr, const float *ds, const float *dop, float *out_xyz,
+                        float *out_rot, hipStream_t st);
+int skin_backward_launch(int B, int method, int V, int M, int K, const float *verts, const int32_t *idx, const float *w,
+                         const float *dx, const float *dr, const float *ds, const float *dop, const float *g_xyz,
+                         const float *g_rot, const int32_t *csr_off, const int32_t *csr_items, float *scratch,
+                         float *o_dx, float *o_dr, float *o_ds, float *o_do, hipStream_t st);
+int face_forward_launch(int B, int F, int G, int V, const int32_t *faces, const float *vxyz, const float *vrot,
+                        const float *qs, float *means, float *rots, float *normals, int nstride, const float *rgb,
+                        float *colors6, hipStream_t st);
+int face_backward_launch(int B, int F, int G, int V, const int32_t *faces, const float *vxyz, const float *vrot,
+                         const float *qs, const float *g_means, const float *g_rots, const float *g_normals, int nstride,
+                         const int32_t *csr_off, const int32_t *csr_items, float *scratch, const float *ext_xyz,
+                         const float *ext_rot, float *o_vxyz, float *o_vrot, hipStream_t st);
+int skin_check(int method, int V, int M, int K, const void *verts, const void *idx, const void *w, const void *dx,
+               const void *dr, const void *ds, const void *dop);
+int face_check(int F, int G, const void *faces, const void *vxyz, const void *vrot, const void *qs);
+
+static int views_check(const dm4d_views *v)
+{
+    if (!v) { set_error("null views"); return DM4D_ERR_INVALID; }
+    if (v->B <= 0 || v->B > 65535) { set_error("bad batch size %d", v->B); return DM4D_ERR_INVALID; }
+    if (v->N != v->F * v->G) { set_error("N (%d) != F*G (%d*%d)", v->N, v->F, v->G); return DM4D_ERR_INVALID; }
+    if (v->image_height <= 0 || v->image_width <= 0) { set_error("bad image size"); return DM4D_ERR_INVALID; }
+    if ((int64_t)((v->image_height + kTile - 1) / kTile) * ((v->image_width + kTile - 1) / kTile) > kMaxTiles) {
+        set_error("image has more than %d tiles", kMaxTiles);
+        return DM4D_ERR_UNSUPPORTED;
+    }
+    if (v->capacity <= 0 || v->capacity > 0xFFFFFFF0ll) { set_error("capacity out of range"); return DM4D_ERR_INVALID; }
+    if (!v->bg || !v->viewmatrix || !v->projmatrix || !v->q_static || !v->scales || !v->opacities || !v->rgb ||
+        !v->vxyz || !v->vrot || !v->means3D || !v->rotations || !v->colors || !v->radii || !v->geom || !v->binning ||
+        !v->image) {
+        set_error("null tensor in dm4d_views");
+        return DM4D_ERR_INVALID;
+    }
+    int rc = skin_check(v->method, v->V, v->M, v->K, v->verts, v->nbr_idx, v->nbr_w, v->dx, v->dr, v->ds, v->d_opacity);
+    if (rc) return rc;
+    return face_check(v->F, v->G, v->faces, v->vxyz, v->vrot, v->q_static);
+}
+
+static BatchDesc views_batch(const dm4d_views *v)
+{
+    BatchDesc d;
+    memset(&d, 0, sizeof(d));
+    d.B = v->B; d.N = v->N; d.C = 6; d.W = v->image_width; d.H = v->image_height;
+    d.tanfovx = v->tanfovx; d.tanfovy = v->tanfovy; d.scale_modifier = v->scale_modifier;
+    d.bg = v->bg;
+    d.view = v->viewmatrix; d.proj = v->projmatrix; d.cam_stride = 16;
+    d.means3D = v->means3D; d.means_stride = (size_t)v->N * 3;
+    d.rotations = v->rotations; d.rot_stride = (size_t)v->N * 4;
+    d.colors = v->colors; d.color_stride = (size_t)v->N * 6;
+    d.scales = v->scales; d.scale_stride = 0;
+    d.opacities = v->opacities; d.opac_stride = 0;
+    d.radii = v->radii; d.radii_stride = (size_t)v->N;
+    d.geom = (char *)v->geom; d.geom_stride = geom_layout(v->N, v->image_height, v->image_width).total;
+    d.binning = (char *)v->binning; d.bin_stride = binning_bytes(v->capacity); d.cap = (uint32_t)v->capacity;
+    d.image = (char *)v->image; d.img_stride = image_bytes(v->image_height, v->image_width);
+    d.out_color = v->out_color; d.out_depth = v->out_depth; d.out_alpha = v->out_alpha;
+    return d;
+}
+
+}  // namespace dm4d
+
+using namespace dm4d;
+
+extern "C" {
+
+size_t dm4d_views_geom_bytes(int32_t B, int32_t N, int32_t H, int32_t W) { return (size_t)B * geom_layout(N, H, W).total; }
+size_t dm4d_views_binning_bytes(int32_t B, int64_t capacity) { return (size_t)B * binning_bytes(capacity); }
+size_t dm4d_views_image_bytes(int32_t B, int32_t H, int32_t W) { return (size_t)B * image_bytes(H, W); }
+size_t dm4d_views_grad_bytes(int32_t B, int64_t capacity) { return (size_t)B * grad_bytes(capacity, 6); }
+size_t dm4d_views_skin_scratch_bytes(int32_t B, int32_t V, int32_t K) { return (size_t)B * dm4d_skin_scratch_bytes(V, K); }
+size_t dm4d_views_face_scratch_bytes(int32_t B, int32_t F) { return (size_t)B * dm4d_face_scratch_bytes(F); }
+
+int dm4d_views_forward(const dm4d_views *v, dm4d_stream_t stream)
+{
+    int rc = views_check(v);
+    if (rc) return rc;
+    if (!v->out_color || !v->out_depth || !v->out_alpha) { set_error("null output image"); return DM4D_ERR_INVALID; }
+    hipStream_t st = (hipStream_t)stream;
+    rc = skin_forward_launch(v->B, v->method, v->V, v->M, v->K, v->verts, v->nbr_idx, v->nbr_w, v->dx, v->dr, v->ds,
+                             v->d_opacity, v->vxyz, v->vrot, st);
+    if (rc) return rc;
+    rc = face_forward_launch(v->B, v->F, v->G, v->V, v->faces, v->vxyz, v->vrot, v->q_static, v->means3D, v->rotations,
+                             v->colors + 3, 6, v->rgb, v->colors, st);
+    if (rc) return rc;
+    const BatchDesc d = views_batch(v);
+    if ((rc = launch_zero_counters(d, st))) return rc;
+    if ((rc = launch_preprocess(d, st))) return rc;
+    if ((rc = launch_colscan(d, st))) return rc;
+    if ((rc = launch_scatter(d, st))) return rc;
+    if ((rc = launch_tile_sort(d, st))) return rc;
+    return launch_render_fwd(d, st);
+}
+
+int dm4d_views_backward(const dm4d_views *v, const dm4d_views_grads *gr, dm4d_stream_t stream)
+{
+    int rc = views_check(v);
+    if (rc) return rc;
+    if (!gr || !gr->dL_dcolor || !gr->grad_scratch || !gr->skin_scratch || !gr->face_scratch || !gr->node_csr_offsets ||
+        !gr->node_csr_items || !gr->vert_csr_offsets || !gr->vert_csr_items || !gr->dL_dmeans2D || !gr->dL_dmeans3D ||
+        !gr->dL_drotations || !gr->dL_dcolors || !gr->dL_dvxyz || !gr->dL_dvrot || !gr->dL_ddx || !gr->dL_ddr) {
+        set_error("null tensor in dm4d_views_grads");
+        return DM4D_ERR_INVALID;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    BatchDesc d = views_batch(v);
+    d.dL_dcolor = gr->dL_dcolor; d.dL_ddepth = gr->dL_ddepth; d.dL_dalpha = gr->dL_dalpha;
+    d.dLq = (float *)gr->grad_scratch; d.dlq_stride = grad_bytes(v->capacity, 6) / 4;
+    d.o = BwdOutputs{gr->dL_dmeans2D, gr->dL_dmeans3D, gr->dL_dopacity, gr->dL_dcolors, nullptr, gr->dL_dscales,
+                     gr->dL_drotations, nullptr};
+    if ((rc = launch_render_bwd(d, st))) return rc;
+    if ((rc = launch_gather_bwd(d, st))) return rc;
+    rc = face_backward_launch(v->B, v->F, v->G, v->V, v->faces, v->vxyz, v->vrot, v->q_static, gr->dL_dmeans3D,
+                              gr->dL_drotations, gr->dL_dcolors + 3, 6, gr->vert_csr_offsets, gr->vert_csr_items,
+                              (float *)gr->face_scratch, gr->dL_dvxyz_ext, gr->dL_dvrot_ext, gr->dL_dvxyz, gr->dL_dvrot,
+                              st);
+    if (rc) return rc;
+    return skin_backward_launch(v->B, v->method, v->V, v->M, v->K, v->verts, v->nbr_idx, v->nbr_w, v->dx, v->dr, v->ds,
+                                v->d_opacity, gr->dL_dvxyz, gr->dL_dvrot, gr->node_csr_offsets, gr->node_csr_items,
+                                (float *)gr->skin_scratch, gr->dL_ddx, gr->dL_ddr, gr->dL_dds, gr->dL_ddo, st);
+}
+
+/* out[b] = {num_rendered, overflow flag} per view (synchronises the stream). */
+int dm4d_views_counters(const dm4d_views *v, int64_t *num_rendered, int32_t *overflowed, dm4d_stream_t stream)
+{
+    if (!v || !v->geom) { set_error("null views"); return DM4D_ERR_INVALID; }
+    hipStream_t st = (hipStream_t)stream;
+    const size_t stride = geom_layout(v->N, v->image_height, v->image_width).total;
+    std::vector<uint32_t> tmp((size_t)v->B * 2);
+    for (int b = 0; b < v->B; ++b)
+        DM4D_HIP_CHECK(hipMemcpyAsync(&tmp[2 * b], (const char *)v->geom + b * stride, 8, hipMemcpyDeviceToHost, st));
+    DM4D_HIP_CHECK(hipStreamSynchronize(st));
+    for (int b = 0; b < v->B; ++b) {
+        if (num_rendered) num_rendered[b] = tmp[2 * b + kCntD];
+        if (overflowed) overflowed[b] = tmp[2 * b + kCntOverflow] ? 1 : 0;
+    }
+    return DM4D_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,151 @@
+"""Batched (frame, view) renderer: the fast path of the hot loop.
+
+One ``render_views`` call = ``GaussianBatchRenderer.batch_forward`` of the reference
+(custom/threestudio-dreammesh4d/renderer/gaussian_batch_renderer.py:9-122) for a whole batch:
+for every view, sparse-control skinning at the view's timestamp, face->Gaussian transform, and the
+RGB + normal rasterizer passes of ``DiffGaussian.forward``
+(.../renderer/diff_sugar_rasterizer_temporal.py:161-217) -- as ONE C call (8 kernel launches that
+each cover all views, no host sync), and one C call for the backward.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+from .ops import METHODS, DeformGraph, MeshTopology
+
+vp = C.c_void_p
+
+
+ViewsStruct, ViewsGrads = _lib.ViewsStruct, _lib.ViewsGrads
+
+
+def _p(t):
+    return None if t is None else t.data_ptr()
+
+
+def _f32(t):
+    return None if t is None else t.detach().to(torch.float32).contiguous()
+
+
+class ViewRenderer:
+    """Static scene description + capacity policy for ``render_views``."""
+
+    def __init__(self, graph: DeformGraph, topo: MeshTopology, image_height, image_width, tanfov, method="hybrid",
+                 scale_modifier=1.0, capacity_factor=6.0):
+        assert graph.device == topo.device and graph.V == topo.V
+        self.graph, self.topo = graph, topo
+        self.device = graph.device
+        self.H, self.W = int(image_height), int(image_width)
+        self.tanfov = float(tanfov)
+        self.method = METHODS[method]
+        self.scale_modifier = float(scale_modifier)
+        self.N = topo.F * topo.G
+        self.capacity = max(int(capacity_factor * self.N), 1 << 16)
+        self.last = None   # (ViewsStruct, keep-alive) of the most recent forward, for check()
+
+    def check(self):
+        """Host check of the duplicate-list capacity (syncs).  Returns num_rendered per view; raises on overflow
+        after doubling the capacity for subsequent calls."""
+        if self.last is None:
+            return None
+        L = _lib.lib()
+        vs, _ = self.last
+        B = vs.B
+        nr = (C.c_int64 * B)()
+        ov = (C.c_int32 * B)()
+        with torch.cuda.device(self.device):
+            _lib.check(L.dm4d_views_counters(C.byref(vs), nr, ov, torch.cuda.current_stream(self.device).cuda_stream),
+                       "dm4d_views_counters")
+        nr = list(nr)
+        if any(ov):
+            self.capacity = int(max(nr) * 1.5) + 1024
+            raise _lib.Dm4dError(f"duplicate list overflow: num_rendered {max(nr)} > capacity; "
+                                 f"capacity raised to {self.capacity}, re-run the step")
+        return nr
+
+
+class _RenderViews(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, r, dx, dr, ds, do, q_static, scales, opacities, rgb, viewmats, projmats, bg6, ext_hook):
+        L = _lib.lib()
+        g, t, dev = r.graph, r.topo, r.device
+        B = int(viewmats.shape[0])
+        N, H, W = r.N, r.H, r.W
+        f = dict(dtype=torch.float32, device=dev)
+        keep = dict(dx=_f32(dx), dr=_f32(dr), ds=_f32(ds), do=_f32(do), qs=_f32(q_static), sc=_f32(scales),
+                    op=_f32(opacities).reshape(-1), rgb=_f32(rgb), vm=_f32(viewmats).reshape(B, 16),
+                    pm=_f32(projmats).reshape(B, 16), bg=_f32(bg6).reshape(6))
+        for k, want in (("dx", (B, g.M, 3)), ("dr", (B, g.M, 4))):
+            if tuple(keep[k].shape) != want:
+                raise ValueError(f"{k} must be {want}, got {tuple(keep[k].shape)}")
+        out = dict(vxyz=torch.empty(B, g.V, 3, **f), vrot=torch.empty(B, g.V, 4, **f), means=torch.empty(B, N, 3, **f),
+                   rots=torch.empty(B, N, 4, **f), colors=torch.empty(B, N, 6, **f),
+                   radii=torch.empty(B, N, dtype=torch.int32, device=dev), color=torch.empty(B, 6, H, W, **f),
+                   depth=torch.empty(B, 1, H, W, **f), alpha=torch.empty(B, 1, H, W, **f))
+        cap = r.capacity
+        ws = dict(geom=torch.empty(L.dm4d_views_geom_bytes(B, N, H, W), dtype=torch.uint8, device=dev),
+                  binning=torch.empty(L.dm4d_views_binning_bytes(B, cap), dtype=torch.uint8, device=dev),
+                  image=torch.empty(L.dm4d_views_image_bytes(B, H, W), dtype=torch.uint8, device=dev))
+        vs = ViewsStruct(B, N, t.F, t.G, g.V, g.M, g.K, r.method, H, W, r.tanfov, r.tanfov, r.scale_modifier, cap,
+                         _p(keep["bg"]), _p(keep["vm"]), _p(keep["pm"]), _p(g.verts), _p(g.nbr_idx), _p(g.nbr_w),
+                         _p(keep["dx"]), _p(keep["dr"]), _p(keep["ds"]), _p(keep["do"]), _p(t.faces), _p(keep["qs"]),
+                         _p(keep["sc"]), _p(keep["op"]), _p(keep["rgb"]), _p(out["vxyz"]), _p(out["vrot"]),
+                         _p(out["means"]), _p(out["rots"]), _p(out["colors"]), _p(out["radii"]), _p(out["color"]),
+                         _p(out["depth"]), _p(out["alpha"]), _p(ws["geom"]), _p(ws["binning"]), _p(ws["image"]))
+        with torch.cuda.device(dev):
+            _lib.check(L.dm4d_views_forward(C.byref(vs), torch.cuda.current_stream(dev).cuda_stream),
+                       "dm4d_views_forward")
+        ctx.r, ctx.vs, ctx.keep, ctx.out, ctx.ws = r, vs, keep, out, ws
+        ctx.shapes = (dx.shape, dr.shape, None if ds is None else ds.shape, None if do is None else do.shape,
+                      scales.shape, opacities.shape, rgb.shape)
+        ctx.need_static = any(x.requires_grad for x in (scales, opacities, rgb))
+        r.last = (vs, (keep, out, ws))
+        ctx.mark_non_differentiable(out["radii"])
+        return out["color"], out["depth"], out["alpha"], out["radii"], out["vxyz"], out["vrot"]
+
+    @staticmethod
+    def backward(ctx, g_color, g_depth, g_alpha, _g_radii, g_vxyz, g_vrot):
+        L = _lib.lib()
+        r, vs, out = ctx.r, ctx.vs, ctx.out
+        g, t, dev = r.graph, r.topo, r.device
+        B, N, H, W = vs.B, r.N, r.H, r.W
+        f = dict(dtype=torch.float32, device=dev)
+        gc = _f32(g_color) if g_color is not None else torch.zeros(B, 6, H, W, **f)
+        gd, ga = _f32(g_depth), _f32(g_alpha)
+        gx, gr_ = _f32(g_vxyz), _f32(g_vrot)
+        o = dict(m2=torch.empty(B, N, 3, **f), m3=torch.empty(B, N, 3, **f), rot=torch.empty(B, N, 4, **f),
+                 col=torch.empty(B, N, 6, **f), op=torch.empty(B, N, **f) if ctx.need_static else None,
+                 sc=torch.empty(B, N, 3, **f) if ctx.need_static else None, vx=torch.empty(B, g.V, 3, **f),
+                 vr=torch.empty(B, g.V, 4, **f), dx=torch.empty(B, g.M, 3, **f), dr=torch.empty(B, g.M, 4, **f),
+                 ds=torch.empty(B, g.M, 6, **f) if ctx.keep["ds"] is not None else None,
+                 do=torch.empty(B, g.M, **f) if ctx.keep["do"] is not None else None)
+        scr = dict(grad=torch.empty(L.dm4d_views_grad_bytes(B, vs.capacity), dtype=torch.uint8, device=dev),
+                   skin=torch.empty(L.dm4d_views_skin_scratch_bytes(B, g.V, g.K), dtype=torch.uint8, device=dev),
+                   face=torch.empty(L.dm4d_views_face_scratch_bytes(B, t.F), dtype=torch.uint8, device=dev))
+        gs = ViewsGrads(_p(gc), _p(gd), _p(ga), _p(gx), _p(gr_), _p(g.csr_off), _p(g.csr_items), _p(t.csr_off),
+                        _p(t.csr_items), _p(scr["grad"]), _p(scr["skin"]), _p(scr["face"]), _p(o["m2"]), _p(o["m3"]),
+                        _p(o["rot"]), _p(o["col"]), _p(o["op"]), _p(o["sc"]), _p(o["vx"]), _p(o["vr"]), _p(o["dx"]),
+                        _p(o["dr"]), _p(o["ds"]), _p(o["do"]))
+        with torch.cuda.device(dev):
+            _lib.check(L.dm4d_views_backward(C.byref(vs), C.byref(gs), torch.cuda.current_stream(dev).cuda_stream),
+                       "dm4d_views_backward")
+        s = ctx.shapes
+        r.last_grads = o   # per-view gradients (means2D etc.) for callers that want them
+        g_sc = o["sc"].sum(0).reshape(s[4]) if ctx.need_static else None
+        g_op = o["op"].sum(0).reshape(s[5]) if ctx.need_static else None
+        g_rgb = o["col"][:, :, :3].sum(0).reshape(s[6]) if ctx.need_static else None
+        return (None, o["dx"].reshape(s[0]), o["dr"].reshape(s[1]), None if o["ds"] is None else o["ds"].reshape(s[2]),
+                None if o["do"] is None else o["do"].reshape(s[3]), None, g_sc, g_op, g_rgb, None, None, None, None)
+
+
+def render_views(renderer: ViewRenderer, dx, dr, ds, d_opacity, q_static, scales, opacities, rgb, viewmats, projmats,
+                 bg6):
+    """Returns dict: color [B,6,H,W] (RGB | normal), depth [B,1,H,W], alpha [B,1,H,W], radii [B,N] int32,
+    vxyz [B,V,3], vrot [B,V,4]."""
+    m = renderer.method
+    color, depth, alpha, radii, vxyz, vrot = _RenderViews.apply(
+        renderer, dx, dr, ds if m != 1 else None, d_opacity if m == 2 else None, q_static, scales, opacities, rgb,
+        viewmats, projmats, bg6, None)
+    return {"color": color, "depth": depth, "alpha": alpha, "radii": radii, "vxyz": vxyz, "vrot": vrot}

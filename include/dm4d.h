@@ -211,6 +211,61 @@ int dm4d_face_gaussians_backward(int32_t F, int32_t G, int32_t V, const int32_t 
                                  const int32_t *vert_csr_offsets, const int32_t *vert_csr_items, void *scratch,
                                  float *dL_dvxyz, float *dL_dvrot, dm4d_stream_t stream);
 
+/* ------------------------------------------------------------------ batched views (the fast path) */
+
+/* The whole per-view hot path for B (frame, view) units of one scene in 8 launches forward /
+ * 6 backward, every launch covering all views (grid.y = view), with no host synchronisation:
+ * skinning -> face->Gaussians -> fused 6-channel rasterisation (RGB + normal pass of
+ * C/renderer/diff_sugar_rasterizer_temporal.py:161-217 share one binning and one blend).
+ * Replaces the per-view Python loop of C/renderer/gaussian_batch_renderer.py:21-76 and its
+ * 2 rasterizer calls (2 host syncs) per view.  All tensors are caller-allocated device memory. */
+typedef struct dm4d_views {
+    int32_t B, N, F, G, V, M, K, method;      /* N = F*G Gaussians; method as dm4d_skin_vertices_forward */
+    int32_t image_height, image_width;
+    float tanfovx, tanfovy, scale_modifier;
+    int64_t capacity;                          /* duplicates per view the binning workspace can hold */
+    const float *bg;                           /* [6]   */
+    const float *viewmatrix, *projmatrix;      /* [B,16] each, row-vector convention */
+    const float *verts;                        /* [V,3] static vertices */
+    const int32_t *nbr_idx;                    /* [V,K] */
+    const float *nbr_w;                        /* [V,K] */
+    const float *dx, *dr, *ds, *d_opacity;     /* [B,M,3] [B,M,4] [B,M,6] [B,M] raw deformation-net outputs */
+    const int32_t *faces;                      /* [F,3] */
+    const float *q_static;                     /* [N,4] (w,x,y,z) */
+    const float *scales, *opacities, *rgb;     /* [N,3] [N] [N,3] (shared by all views) */
+    /* outputs */
+    float *vxyz, *vrot;                        /* [B,V,3] [B,V,4] deformed vertices */
+    float *means3D, *rotations, *colors;       /* [B,N,3] [B,N,4] [B,N,6] (colors = rgb | normal) */
+    int32_t *radii;                            /* [B,N] */
+    float *out_color, *out_depth, *out_alpha;  /* [B,6,H,W] [B,H,W] [B,H,W] */
+    /* workspaces (dm4d_views_*_bytes) */
+    void *geom, *binning, *image;
+} dm4d_views;
+
+typedef struct dm4d_views_grads {
+    const float *dL_dcolor, *dL_ddepth, *dL_dalpha;     /* [B,6,H,W] [B,H,W] [B,H,W]; depth/alpha may be NULL */
+    const float *dL_dvxyz_ext, *dL_dvrot_ext;           /* optional extra grads on the deformed vertices */
+    const int32_t *node_csr_offsets, *node_csr_items;   /* as dm4d_skin_vertices_backward */
+    const int32_t *vert_csr_offsets, *vert_csr_items;   /* as dm4d_face_gaussians_backward */
+    void *grad_scratch, *skin_scratch, *face_scratch;   /* dm4d_views_{grad,skin_scratch,face_scratch}_bytes */
+    /* outputs (per view; the caller reduces the static ones over B) */
+    float *dL_dmeans2D, *dL_dmeans3D, *dL_drotations;   /* [B,N,3] [B,N,3] [B,N,4] */
+    float *dL_dcolors, *dL_dopacity, *dL_dscales;       /* [B,N,6] [B,N] [B,N,3]; opacity/scales may be NULL */
+    float *dL_dvxyz, *dL_dvrot;                         /* [B,V,3] [B,V,4] */
+    float *dL_ddx, *dL_ddr, *dL_dds, *dL_ddo;           /* [B,M,3] [B,M,4] [B,M,6] [B,M] */
+} dm4d_views_grads;
+
+size_t dm4d_views_geom_bytes(int32_t B, int32_t N, int32_t image_height, int32_t image_width);
+size_t dm4d_views_binning_bytes(int32_t B, int64_t capacity);
+size_t dm4d_views_image_bytes(int32_t B, int32_t image_height, int32_t image_width);
+size_t dm4d_views_grad_bytes(int32_t B, int64_t capacity);
+size_t dm4d_views_skin_scratch_bytes(int32_t B, int32_t V, int32_t K);
+size_t dm4d_views_face_scratch_bytes(int32_t B, int32_t F);
+int dm4d_views_forward(const dm4d_views *v, dm4d_stream_t stream);
+int dm4d_views_backward(const dm4d_views *v, const dm4d_views_grads *g, dm4d_stream_t stream);
+/* num_rendered[b], overflowed[b] of the last forward (host arrays of B; synchronises the stream). */
+int dm4d_views_counters(const dm4d_views *v, int64_t *num_rendered, int32_t *overflowed, dm4d_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif
