@@ -3,12 +3,14 @@
 
 Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N > 1 launched with
 torch.distributed.run, one rank per GPU.  A "step" = every rank renders VIEWS_PER_STEP
-(frame, view) units -- each unit is the reference's per-view work: RGB rasterizer pass +
-normal rasterizer pass, forward and backward
-(custom/threestudio-dreammesh4d/renderer/diff_sugar_rasterizer_temporal.py:169-178,202-211) --
-then the ranks all-reduce the parameter-gradient buffer (the one exchange step of the path,
-SURVEY.md section 8e).  Units are independent, so ranks shard them with no other collective:
-per-GPU work is fixed ("weak" scaling) and `value` = units of all ranks / wall time.
+(frame, view) units of the sugar_dynamic_dg scene -- each unit is the reference's per-view work:
+sparse-control skinning of the mesh at the frame's timestamp, face->Gaussian transform
+(custom/threestudio-dreammesh4d/geometry/dynamic_sugar.py:487-613,657-706), RGB rasterizer pass
++ normal rasterizer pass (.../renderer/diff_sugar_rasterizer_temporal.py:169-178,202-211),
+forward and backward -- then the ranks all-reduce the parameter-gradient buffer (the one
+exchange step of the path).  Units are independent, so ranks shard the
+frames with no other collective: per-GPU work is fixed ("weak" scaling) and
+`value` = units of all ranks / wall time.
 
 Inputs are synthetic and seeded (dreammesh4d_amd/synthetic.py), resident in HBM before the
 timed region.  Rank 0 prints ONE JSON line.
@@ -27,9 +29,12 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-N_GAUSS = 200_000
+N_FACES = 33_334        # configs[3]: 33,334 faces x 6 Gaussians/face = ~200k mesh-bound Gaussians
+N_NODES, K_NBR = 1000, 4
+N_FRAMES = 32
 H = W = 512
-VIEWS_PER_STEP = 8      # the reference's per-rank iteration: 4 frames x (1 SDS view + 1 ref view)
+FRAMES_PER_STEP, VIEWS_PER_FRAME = 4, 2     # the reference's per-rank iteration: 4 frames x (1 SDS + 1 ref view)
+VIEWS_PER_STEP = FRAMES_PER_STEP * VIEWS_PER_FRAME
 K_RENDER_BWD = 5        # kernel id of the dominant kernel (include/dm4d.h)
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8 TB/s peak
 
@@ -44,40 +49,60 @@ def parse():
     return ap.parse_args()
 
 
-def build_workload(dev, rank):
-    from dreammesh4d_amd import synthetic as syn
-    import dreammesh4d_amd.diff_gaussian_rasterization as dgr
+class Workload:
+    """Seeded mesh-bound scene (dreammesh4d_amd/synthetic.py) resident in HBM; this rank's (frame, view)
+    units per step.  The per-frame node outputs stand in for the HexPlane+MLP of
+    geometry/deformation.py (they are the trainable leaves whose gradients are all-reduced)."""
 
-    sc = syn.random_splat_scene(N_GAUSS, seed=0)
-    rng = np.random.default_rng(1)
-    nrm = rng.normal(size=(N_GAUSS, 3))
-    nrm = (nrm / np.linalg.norm(nrm, axis=1, keepdims=True)).astype(np.float32)
-    T = lambda a, rg=False: torch.tensor(a, device=dev).requires_grad_(rg)
-    P = {"means3D": T(sc["means3D"], True), "opac": T(sc["opacities"][:, None], True), "colors": T(sc["colors"], True),
-         "scales": T(sc["scales"], True), "rots": T(sc["rotations"], True), "normals": T(nrm, True)}
-    # cameras: this rank's (frame, view) units; azimuths differ per rank like per-rank seeds in the reference
-    cams = []
-    for v in range(VIEWS_PER_STEP):
-        az = -180.0 + 360.0 * ((rank * VIEWS_PER_STEP + v) * 0.61803398875 % 1.0)
-        el = -10.0 + 90.0 * ((rank * VIEWS_PER_STEP + v) * 0.41421356237 % 1.0)
-        cam = syn.make_camera(H, W, elev_deg=el, azim_deg=az)
-        rs = dgr.GaussianRasterizationSettings(H, W, cam.tanfov, cam.tanfov, T(np.ones(3, np.float32)), 1.0,
-                                               T(cam.viewmatrix), T(cam.projmatrix), 0, T(cam.campos), False, False)
-        cams.append((cam, dgr.GaussianRasterizer(rs)))
-    g = torch.Generator(device="cpu").manual_seed(2)
-    grads = {"rgb": torch.randn(3, H, W, generator=g).to(dev), "alpha": torch.randn(1, H, W, generator=g).to(dev),
-             "depth": (0.1 * torch.randn(1, H, W, generator=g)).to(dev), "normal": torch.randn(3, H, W, generator=g).to(dev)}
-    return sc, nrm, P, cams, grads
+    def __init__(self, dev, rank, world):
+        from dreammesh4d_amd import geometry as geo, ops, synthetic as syn, views
 
+        self.dev = dev
+        sc = self.sc = syn.mesh_bound_scene(N_FACES, n_nodes=N_NODES, k=K_NBR, seed=0)
+        T = lambda a: torch.tensor(a, device=dev)
+        self.graph = ops.DeformGraph(sc["verts"], sc["nbr_idx"], sc["nbr_w"], N_NODES, dev)
+        self.topo = ops.MeshTopology(sc["faces"], len(sc["verts"]), 6, dev)
+        verts, faces = T(sc["verts"]), T(sc["faces"])
+        self.qs = geo.quaternions(verts, faces, T(sc["complex"]), 6)
+        self.scales = geo.scaling(T(sc["log_scales"]), syn.THICKNESS)
+        self.opac = geo.strengths(T(sc["densities"]))
+        self.rgb = geo.points_rgb(T(sc["sh_dc"]))
+        self.N = self.topo.F * 6
+        self.ts, self.motion = syn.node_motion(N_NODES, N_FRAMES, seed=0)
+        # trainable leaves: raw node outputs of every frame [L, M, .]
+        self.P = {k: torch.stack([T(m[k]) for m in self.motion]).requires_grad_(True)
+                  for k in ("trans", "d_rot", "strain", "d_opacity")}
+        # rank r renders frames {4r .. 4r+3} (mod L), VIEWS_PER_FRAME cameras each (SURVEY.md section 8e)
+        self.frames = [(FRAMES_PER_STEP * rank + i) % N_FRAMES for i in range(FRAMES_PER_STEP)]
+        self.cams, self.unit_frames = [], []
+        for fi, fr in enumerate(self.frames):
+            for v in range(VIEWS_PER_FRAME):
+                u = (rank * VIEWS_PER_STEP + fi * VIEWS_PER_FRAME + v)
+                az = -180.0 + 360.0 * (u * 0.61803398875 % 1.0)
+                el = -10.0 + 90.0 * (u * 0.41421356237 % 1.0)
+                self.cams.append(syn.make_camera(H, W, elev_deg=el, azim_deg=az))
+                self.unit_frames.append(fr)
+        self.vm = torch.stack([T(c.viewmatrix) for c in self.cams])
+        self.pm = torch.stack([T(c.projmatrix) for c in self.cams])
+        self.fidx = torch.tensor(self.unit_frames, device=dev)
+        self.bg6 = torch.ones(6, device=dev)
+        self.renderer = views.ViewRenderer(self.graph, self.topo, H, W, self.cams[0].tanfov, method="hybrid")
+        g = torch.Generator(device="cpu").manual_seed(2)
+        B = VIEWS_PER_STEP
+        self.gC = torch.randn(B, 6, H, W, generator=g).to(dev)
+        self.gD = (0.1 * torch.randn(B, 1, H, W, generator=g)).to(dev)
+        self.gA = torch.randn(B, 1, H, W, generator=g).to(dev)
+        self.render_views = views.render_views
 
-def render_unit(P, rast, grads):
-    """One (frame, view) unit: RGB pass + normal pass, forward and backward."""
-    m2 = torch.zeros_like(P["means3D"], requires_grad=True)
-    color, radii, depth, alpha = rast(means3D=P["means3D"], means2D=m2, opacities=P["opac"],
-                                      colors_precomp=P["colors"], scales=P["scales"], rotations=P["rots"])
-    normal, _, _, _ = rast(means3D=P["means3D"], means2D=torch.zeros_like(m2), opacities=P["opac"],
-                           colors_precomp=P["normals"], scales=P["scales"], rotations=P["rots"])
-    torch.autograd.backward([color, depth, alpha, normal], [grads["rgb"], grads["depth"], grads["alpha"], grads["normal"]])
+    def step(self):
+        P = self.P
+        for p in P.values():
+            p.grad = None
+        out = self.render_views(self.renderer, P["trans"][self.fidx], P["d_rot"][self.fidx], P["strain"][self.fidx],
+                                P["d_opacity"][self.fidx].squeeze(-1), self.qs, self.scales, self.opac, self.rgb, self.vm,
+                                self.pm, self.bg6)
+        torch.autograd.backward([out["color"], out["depth"], out["alpha"]], [self.gC, self.gD, self.gA])
+        return out
 
 
 def main():
@@ -94,19 +119,16 @@ def main():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", device_id=dev)
     from dreammesh4d_amd import _lib
-    import dreammesh4d_amd.diff_gaussian_rasterization as dgr
     L = _lib.lib()
 
-    sc, nrm, P, cams, grads = build_workload(dev, rank)
-    params = list(P.values())
+    wl = Workload(dev, rank, world)
+    params = list(wl.P.values())
+    flat = torch.zeros(sum(p.numel() for p in params), device=dev) if world > 1 else None
 
     def step():
-        for p in params:
-            p.grad = None
-        for _, rast in cams:
-            render_unit(P, rast, grads)
-        if world > 1:
-            flat = torch.cat([p.grad.reshape(-1) for p in params])
+        wl.step()
+        if world > 1:   # the one exchange step of the path: data-parallel gradient all-reduce (mean)
+            torch.cat([p.grad.reshape(-1) for p in params], out=flat)
             dist.all_reduce(flat)
             flat.mul_(1.0 / world)
 
@@ -118,14 +140,15 @@ def main():
     for _ in range(args.warmup):
         step()
     sync()
+    D_views = wl.renderer.check()      # also validates the duplicate-list capacity
     L.dm4d_profile_enable(1 << K_RENDER_BWD)
-    dgr.LAST_NUM_RENDERED.clear()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     sync()
     elapsed = time.perf_counter() - t0
     L.dm4d_profile_enable(0)
+    wl.renderer.check()
     if world > 1:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -134,62 +157,86 @@ def main():
     import ctypes
     tot_ms = ctypes.c_double(0.0)
     n_launch = L.dm4d_profile_collect(K_RENDER_BWD, ctypes.byref(tot_ms))
-    D_mean = float(np.mean(dgr.LAST_NUM_RENDERED)) if dgr.LAST_NUM_RENDERED else 0.0
+    D_mean = float(np.mean(D_views))
 
     if rank == 0:
         units = world * VIEWS_PER_STEP * args.steps
         value = units / elapsed
-        # dominant kernel: render_bwd.  Algorithmic bytes per launch (render-bwd row):
-        # 48 B per duplicate (id + attributes) + 40 B per pixel (grads, state, colour) + 44 B per Gaussian (grads)
-        alg_bytes = 48.0 * D_mean + 40.0 * H * W + 44.0 * N_GAUSS
+        N = wl.N
+        # Dominant kernel: k_render_bwd<6>, ONE launch per step covering the 8 views of the batch with the RGB
+        # and the normal pass fused.  Algorithmic bytes per launch (render-bwd row of
+        # B_b, credited per reference pass): views x 2 passes x (48 B/duplicate + 40 B/pixel + 44 B/Gaussian).
+        alg_bytes = VIEWS_PER_STEP * 2.0 * (48.0 * D_mean + 40.0 * H * W + 44.0 * N)
         avg_s = (tot_ms.value / max(n_launch, 1)) * 1e-3
         achieved = alg_bytes / avg_s / 1e9 if avg_s > 0 else 0.0
+        # whole-view algorithmic bytes: B_view = 2 (B_f + B_b) + B_skin
+        V = len(wl.sc["verts"])
+        b_view = 2 * ((104 * N + 84 * D_mean + 28 * H * W) + (228 * N + 48 * D_mean + 40 * H * W)) + 40 * V + 28 * N + 12288 * N_NODES
         out = {
             "metric": "rendered views/sec (fwd+bwd, 512^2, 200k Gaussians)",
             "value": round(value, 3), "unit": "views/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "random-splat scene, 200k Gaussians, 512x512, per view: RGB pass + normal pass "
-                                   "fwd+bwd through the drop-in GaussianRasterizer (1 host sync per pass, as upstream)",
-                       "views_per_step_per_gpu": VIEWS_PER_STEP, "mean_duplicates_D": round(D_mean),
-                       "parallelism": f"dp{world} (units sharded, 1 grad all-reduce/step)" if world > 1 else "single GPU"},
-            "roofline": {"bound": "hbm", "kernel": "k_render_bwd", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
+            "config": {"workload": f"sugar_dynamic_dg (configs[3] per-GPU share): mesh-bound {N} Gaussians "
+                                   f"({wl.topo.F} faces x 6), {N_NODES} graph nodes K={K_NBR} hybrid LBS/DQS skinning, "
+                                   f"512x512; per view: skinning + face->Gaussian + RGB pass + normal pass, fwd+bwd",
+                       "views_per_step_per_gpu": VIEWS_PER_STEP, "frames_per_step_per_gpu": FRAMES_PER_STEP,
+                       "mean_duplicates_D": round(D_mean), "whole_view_frac_of_hbm_roofline":
+                           round(value / world * b_view / (HBM_PEAK_GBS * 1e9), 5),
+                       "parallelism": f"dp{world} (frames sharded, 1 grad all-reduce/step)" if world > 1 else "single GPU"},
+            "roofline": {"bound": "hbm", "kernel": "k_render_bwd<6> (batched over the step's views)",
+                         "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
                          "alg_bytes_per_launch": round(alg_bytes), "avg_launch_us": round(avg_s * 1e6, 2),
                          "launches_timed": int(n_launch)},
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(sc, nrm, cams, grads, args.cpu_baseline_views)
+            out["cpu_baseline"] = cpu_baseline(wl, args.cpu_baseline_views)
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
 
 
-def cpu_baseline(sc, nrm, cams, grads, n_views):
-    """The oracle (CPU restatement of the reference algorithm, OpenMP over tiles / Gaussians) timed on
-    this box's host cores on a bounded sample: the first `n_views` units of the same workload."""
-    from oracle import raster as orc
+def cpu_baseline(wl, n_views):
+    """The oracle (CPU restatement of the reference algorithm: PyTorch-CPU skinning, C/OpenMP rasterizer)
+    timed on this box's host cores on a bounded sample: the first `n_views` units of the same workload."""
+    from oracle import raster as orc, skinning as sk
 
-    gC, gA = grads["rgb"].cpu().numpy(), grads["alpha"].cpu().numpy()[0]
-    gD, gN = grads["depth"].cpu().numpy()[0], grads["normal"].cpu().numpy()
+    torch.set_num_threads(os.cpu_count())
+    sc = wl.sc
+    t = lambda a: torch.tensor(np.asarray(a))
+    verts, faces, idx, w = t(sc["verts"]), t(sc["faces"]), t(sc["nbr_idx"]), t(sc["nbr_w"])
+    qs = sk.static_quaternions(verts.double(), faces, t(sc["complex"]).double()).float()
+    scales, opac, rgb = sk.static_attributes(t(sc["log_scales"]), t(sc["densities"]), t(sc["sh_dc"]), 3.8e-6)
+    gC, gD, gA = wl.gC.cpu().numpy(), wl.gD.cpu().numpy(), wl.gA.cpu().numpy()
 
-    def unit(cam):
-        for colors, g_c, g_d, g_a in ((sc["colors"], gC, gD, gA), (nrm, gN, None, None)):
+    def unit(u):
+        cam, m = wl.cams[u], wl.motion[wl.unit_frames[u]]
+        leaves = [t(m[k]).requires_grad_(True) for k in ("trans", "d_rot", "strain", "d_opacity")]
+        trans, q, S, op = sk.node_attributes(*leaves)
+        xyz, vrot = sk.skin_vertices(verts, idx, w, trans, q, S, op, "hybrid")
+        means, rots, normals = sk.face_gaussians(xyz, vrot, faces, qs)
+        g_means, g_rots, g_nrm = 0, 0, None
+        for colors, g_c, g_d, g_a in ((rgb.numpy(), gC[u, :3], gD[u, 0], gA[u, 0]), (normals.detach().numpy(), gC[u, 3:], None, None)):
             o = orc.RasterOracle(image_height=H, image_width=W, tanfovx=cam.tanfov, tanfovy=cam.tanfov, bg=(1, 1, 1),
                                  scale_modifier=1.0, viewmatrix=cam.viewmatrix, projmatrix=cam.projmatrix,
                                  campos=cam.campos)
-            o.forward(sc["means3D"], sc["opacities"], colors_precomp=colors, scales=sc["scales"],
-                      rotations=sc["rotations"])
-            o.backward(g_c, g_d, g_a)
+            o.forward(means.detach().numpy(), opac.view(-1).numpy(), colors_precomp=colors, scales=scales.numpy(),
+                      rotations=rots.detach().numpy())
+            g = o.backward(g_c, g_d, g_a)
+            g_means = g_means + g["dL_dmeans3D"]
+            g_rots = g_rots + g["dL_drots"]
+            g_nrm = g["dL_dcolors"]
+        torch.autograd.backward([means, rots, normals], [t(g_means), t(g_rots), t(g_nrm)])
 
-    unit(cams[0][0])  # warm-up (page-in, thread pool)
+    unit(0)  # warm-up (page-in, thread pools)
     t0 = time.perf_counter()
     for v in range(n_views):
-        unit(cams[v % len(cams)][0])
+        unit(v % len(wl.cams))
     dt = time.perf_counter() - t0
     return {"value": round(n_views / dt, 4), "unit": "views/s", "cores": os.cpu_count(), "kind": "port",
-            "sample": f"{n_views} of the same (frame, view) units (RGB+normal pass fwd+bwd), C oracle with OpenMP "
-                      f"over tiles/Gaussians, {os.cpu_count()} host threads"}
+            "sample": f"{n_views} of the same (frame, view) units (skinning + face->Gaussian in PyTorch-CPU, RGB + "
+                      f"normal pass fwd+bwd in the C/OpenMP oracle), {os.cpu_count()} host threads"}
 
 
 if __name__ == "__main__":

@@ -115,42 +115,36 @@ __global__ __launch_bounds__(64) void k_render_fwd(BatchDesc d)
         }
         if (c0 + 64 + (uint32_t)lane < nq) gather_entry<C>(list[c0 + 64 + lane], g, colors, r);   // prefetch
         __builtin_amdgcn_wave_barrier();
-        bool all_done = false;
-        for (int t = 0; t < cnt; ++t) {
-            if (__ballot(!done) == 0) { all_done = true; break; }
-            const float4 ea = s_e[buf][t][0], eb = s_e[buf][t][1];
-            if (!done) {
-                const float dx = ea.x - pxf, dy = ea.y - pyf;
-                const float power = -0.5f * ((ea.z * dx) * dx + (eb.x * dy) * dy) - (ea.w * dx) * dy;
-                if (power <= 0.0f) {
-                    const float alpha = fminf(0.99f, eb.y * det_expf(power));
-                    if (alpha >= 1.0f / 255.0f) {
-                        const float test_T = T_ * (1.0f - alpha);
-                        if (test_T < 0.0001f) {
-                            done = true;
-                        } else {
-                            const float w = alpha * T_;
-                            const float4 ec = s_e[buf][t][2];
-                            Cacc[0] = __builtin_fmaf(ec.x, w, Cacc[0]);
-                            Cacc[1] = __builtin_fmaf(ec.y, w, Cacc[1]);
-                            Cacc[2] = __builtin_fmaf(ec.z, w, Cacc[2]);
-                            if (C > 3) {
-                                const float4 ed = s_e[buf][t][NV - 1];
-                                Cacc[3] = __builtin_fmaf(ec.w, w, Cacc[3]);
-                                Cacc[C > 4 ? 4 : 0] = __builtin_fmaf(ed.x, w, Cacc[C > 4 ? 4 : 0]);
-                                Cacc[C > 5 ? 5 : 0] = __builtin_fmaf(ed.y, w, Cacc[C > 5 ? 5 : 0]);
-                            }
-                            D = __builtin_fmaf(eb.z, w, D);
-                            Wt = Wt + w;
-                            T_ = test_T;
-                            last = __float_as_uint(eb.w) + 1u;
-                            lastj = c0 + (uint32_t)t + 1u;
-                        }
-                    }
-                }
+        if (__ballot(!done) == 0) break;   // every pixel of the quadrant is saturated
+        int t = 0;
+        do {
+            // Branch-free body (selects, not exec-mask branches): lanes that do not take the entry
+            // blend with weight 0, which leaves their accumulators bit-identical.
+            const float4 ea = s_e[buf][t][0], eb = s_e[buf][t][1], ec = s_e[buf][t][2];
+            const float dx = ea.x - pxf, dy = ea.y - pyf;
+            const float power = -0.5f * ((ea.z * dx) * dx + (eb.x * dy) * dy) - (ea.w * dx) * dy;
+            const float alpha = fminf(0.99f, eb.y * det_expf(power));
+            const float test_T = T_ * (1.0f - alpha);
+            const bool valid = (!done) & (power <= 0.0f) & (alpha >= 1.0f / 255.0f);
+            const bool stop = valid & (test_T < 0.0001f);
+            const bool contrib = valid & (!stop);
+            const float w = contrib ? alpha * T_ : 0.f;
+            Cacc[0] = __builtin_fmaf(ec.x, w, Cacc[0]);
+            Cacc[1] = __builtin_fmaf(ec.y, w, Cacc[1]);
+            Cacc[2] = __builtin_fmaf(ec.z, w, Cacc[2]);
+            if (C > 3) {
+                const float4 ed = s_e[buf][t][NV - 1];
+                Cacc[3] = __builtin_fmaf(ec.w, w, Cacc[3]);
+                Cacc[C > 4 ? 4 : 0] = __builtin_fmaf(ed.x, w, Cacc[C > 4 ? 4 : 0]);
+                Cacc[C > 5 ? 5 : 0] = __builtin_fmaf(ed.y, w, Cacc[C > 5 ? 5 : 0]);
             }
-        }
-        if (all_done) break;
+            D = __builtin_fmaf(eb.z, w, D);
+            Wt = Wt + w;
+            T_ = contrib ? test_T : T_;
+            last = contrib ? __float_as_uint(eb.w) + 1u : last;
+            lastj = contrib ? c0 + (uint32_t)t + 1u : lastj;
+            done = done | stop;
+        } while (++t < cnt && __ballot(!done) != 0);
     }
     if (inside) {
         const size_t P = (size_t)vp.H * vp.W;
@@ -266,49 +260,45 @@ __global__ __launch_bounds__(64) void k_render_bwd(BatchDesc d)
         for (int t = cnt - 1; t >= 0; --t) {
             const float4 ea = s_e[buf][t][0], eb = s_e[buf][t][1];
             const uint32_t k = __float_as_uint(eb.w);
-            float v[GS];
-#pragma unroll
-            for (int i = 0; i < GS; ++i) v[i] = 0.f;
-            bool contrib = false;
-            if (k < last) {
-                const float dx = ea.x - pxf, dy = ea.y - pyf;
-                const float power = -0.5f * ((ea.z * dx) * dx + (eb.x * dy) * dy) - (ea.w * dx) * dy;
-                if (power <= 0.0f) {
-                    const float G = det_expf(power);
-                    const float alpha = fminf(0.99f, eb.y * G);
-                    if (alpha >= 1.0f / 255.0f) {
-                        contrib = true;
-                        const float4 ec = s_e[buf][t][2];
-                        float col[C];
-                        col[0] = ec.x; col[1] = ec.y; col[2] = ec.z;
-                        if (C > 3) {
-                            const float4 ed = s_e[buf][t][NV - 1];
-                            col[3] = ec.w;
-                            col[C > 4 ? 4 : 0] = ed.x;
-                            col[C > 5 ? 5 : 0] = ed.y;
-                        }
-                        const float om = 1.f - alpha;
-                        T_ = T_ / om;
-                        const float w = alpha * T_;
-                        float V = gA + eb.z * gD;
-#pragma unroll
-                        for (int ch = 0; ch < C; ++ch) V = __builtin_fmaf(col[ch], gCol[ch], V);
-                        const float dL_da = T_ * V - (S + Tb) / om;
-                        S = __builtin_fmaf(V, w, S);
-                        const float dL_dG = eb.y * dL_da;
-                        const float gdx = G * dx, gdy = G * dy;
-                        v[0] = dL_dG * (-gdx * ea.z - gdy * ea.w) * half_W;
-                        v[1] = dL_dG * (-gdy * eb.x - gdx * ea.w) * half_H;
-                        v[2] = -0.5f * gdx * dx * dL_dG;
-                        v[3] = -gdx * dy * dL_dG;
-                        v[4] = -0.5f * gdy * dy * dL_dG;
-                        v[5] = G * dL_da;
-                        v[6] = w * gD;
-#pragma unroll
-                        for (int ch = 0; ch < C; ++ch) v[7 + ch] = w * gCol[ch];
-                    }
-                }
+            // Branch-free: lanes that do not take the entry contribute exact zeros.
+            const float dx = ea.x - pxf, dy = ea.y - pyf;
+            const float power = -0.5f * ((ea.z * dx) * dx + (eb.x * dy) * dy) - (ea.w * dx) * dy;
+            const float Gr = det_expf(power);
+            const float alpha = fminf(0.99f, eb.y * Gr);
+            const bool contrib = (k < last) & (power <= 0.0f) & (alpha >= 1.0f / 255.0f);
+            const float4 ec = s_e[buf][t][2];
+            float col[C];
+            col[0] = ec.x; col[1] = ec.y; col[2] = ec.z;
+            if (C > 3) {
+                const float4 ed = s_e[buf][t][NV - 1];
+                col[3] = ec.w;
+                col[C > 4 ? 4 : 0] = ed.x;
+                col[C > 5 ? 5 : 0] = ed.y;
             }
+            const float G = contrib ? Gr : 0.f;
+            const float inv_om = __builtin_amdgcn_rcpf(1.f - alpha);
+            const float Tn = T_ * inv_om;
+            T_ = contrib ? Tn : T_;
+            const float w = contrib ? alpha * Tn : 0.f;
+            float V = gA + eb.z * gD;
+#pragma unroll
+            for (int ch = 0; ch < C; ++ch) V = __builtin_fmaf(col[ch], gCol[ch], V);
+            const float dL_da = contrib ? (Tn * V - (S + Tb) * inv_om) : 0.f;
+            S = __builtin_fmaf(V, w, S);
+            const float dL_dG = eb.y * dL_da;
+            const float gdx = G * dx, gdy = G * dy;
+            float v[GS];
+            v[0] = dL_dG * (-gdx * ea.z - gdy * ea.w) * half_W;
+            v[1] = dL_dG * (-gdy * eb.x - gdx * ea.w) * half_H;
+            v[2] = -0.5f * gdx * dx * dL_dG;
+            v[3] = -gdx * dy * dL_dG;
+            v[4] = -0.5f * gdy * dy * dL_dG;
+            v[5] = G * dL_da;
+            v[6] = w * gD;
+#pragma unroll
+            for (int ch = 0; ch < C; ++ch) v[7 + ch] = w * gCol[ch];
+#pragma unroll
+            for (int i = 7 + C; i < GS; ++i) v[i] = 0.f;
             float out[GS / 4];
             if (__ballot(contrib) != 0) {
                 wave_reduce_packed<GS>(v, out);

@@ -321,7 +321,9 @@ __global__ __launch_bounds__(64) void k_skin_bwd_node(int M, const int32_t *__re
                                                       float *__restrict__ g_dr, float *__restrict__ g_ds,
                                                       float *__restrict__ g_do, size_t rec_view_stride)
 {
-    const int m = blockIdx.x * 64 + threadIdx.x;
+    // one WAVE per node: lanes stride over the node's (vertex, k) records, then a fixed-order
+    // butterfly sums the 64 partials (deterministic)
+    const int m = blockIdx.x, lane = threadIdx.x;
     if (m >= M) return;
     {
         const size_t bv = blockIdx.y, o = bv * M;
@@ -334,11 +336,17 @@ __global__ __launch_bounds__(64) void k_skin_bwd_node(int M, const int32_t *__re
     float acc[kNodeRec];
 #pragma unroll
     for (int i = 0; i < kNodeRec; ++i) acc[i] = 0.f;
-    for (int e = csr_off[m]; e < csr_off[m + 1]; ++e) {
+    for (int e = csr_off[m] + lane; e < csr_off[m + 1]; e += 64) {
         const float *r = rec + (size_t)csr_item[e] * kNodeRec;
 #pragma unroll
         for (int i = 0; i < kNodeRec; ++i) acc[i] += r[i];
     }
+#pragma unroll
+    for (int i = 0; i < kNodeRec; ++i) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) acc[i] += __shfl_xor(acc[i], o, 64);
+    }
+    if (lane != 0) return;
     if (g_dx) { g_dx[3 * m] = acc[0]; g_dx[3 * m + 1] = acc[1]; g_dx[3 * m + 2] = acc[2]; }
     if (g_dr) { g_dr[4 * m] = acc[3]; g_dr[4 * m + 1] = acc[4]; g_dr[4 * m + 2] = acc[5]; g_dr[4 * m + 3] = acc[6]; }
     if (g_ds) { for (int i = 0; i < 6; ++i) g_ds[6 * m + i] = acc[7 + i]; }
@@ -531,7 +539,7 @@ int skin_backward_launch(int B, int method, int V, int M, int K, const float *ve
                            g_xyz, g_rot, scratch);
         DM4D_HIP_CHECK(hipGetLastError());
     }
-    hipLaunchKernelGGL(k_skin_bwd_node, dim3((M + 63) / 64, B), dim3(64), 0, st, M, csr_off, csr_items,
+    hipLaunchKernelGGL(k_skin_bwd_node, dim3(M, B), dim3(64), 0, st, M, csr_off, csr_items,
                        (const float *)scratch, o_dx, o_dr, o_ds, o_do, (size_t)V * K * kNodeRec);
     DM4D_HIP_CHECK(hipGetLastError());
     return DM4D_OK;

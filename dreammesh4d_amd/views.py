@@ -44,6 +44,36 @@ class ViewRenderer:
         self.N = topo.F * topo.G
         self.capacity = max(int(capacity_factor * self.N), 1 << 16)
         self.last = None   # (ViewsStruct, keep-alive) of the most recent forward, for check()
+        self._ws_pool = []     # recycled (geom, binning, image) workspace sets, keyed by (B, capacity)
+        self._scratch = {}     # persistent backward scratch, keyed by (B, capacity)
+
+    def _take_ws(self, B):
+        L = _lib.lib()
+        key = (B, self.capacity)
+        for i, (k, ws) in enumerate(self._ws_pool):
+            if k == key:
+                del self._ws_pool[i]
+                return ws
+        dev, N, H, W = self.device, self.N, self.H, self.W
+        return dict(key=key,
+                    geom=torch.empty(L.dm4d_views_geom_bytes(B, N, H, W), dtype=torch.uint8, device=dev),
+                    binning=torch.empty(L.dm4d_views_binning_bytes(B, self.capacity), dtype=torch.uint8, device=dev),
+                    image=torch.empty(L.dm4d_views_image_bytes(B, H, W), dtype=torch.uint8, device=dev))
+
+    def _give_ws(self, ws):
+        if len(self._ws_pool) < 4:
+            self._ws_pool.append((ws["key"], ws))
+
+    def _bwd_scratch(self, B, capacity):
+        L = _lib.lib()
+        key = (B, capacity)
+        if key not in self._scratch:
+            g, t, dev = self.graph, self.topo, self.device
+            self._scratch = {key: dict(
+                grad=torch.empty(L.dm4d_views_grad_bytes(B, capacity), dtype=torch.uint8, device=dev),
+                skin=torch.empty(L.dm4d_views_skin_scratch_bytes(B, g.V, g.K), dtype=torch.uint8, device=dev),
+                face=torch.empty(L.dm4d_views_face_scratch_bytes(B, t.F), dtype=torch.uint8, device=dev))}
+        return self._scratch[key]
 
     def check(self):
         """Host check of the duplicate-list capacity (syncs).  Returns num_rendered per view; raises on overflow
@@ -85,9 +115,7 @@ class _RenderViews(torch.autograd.Function):
                    radii=torch.empty(B, N, dtype=torch.int32, device=dev), color=torch.empty(B, 6, H, W, **f),
                    depth=torch.empty(B, 1, H, W, **f), alpha=torch.empty(B, 1, H, W, **f))
         cap = r.capacity
-        ws = dict(geom=torch.empty(L.dm4d_views_geom_bytes(B, N, H, W), dtype=torch.uint8, device=dev),
-                  binning=torch.empty(L.dm4d_views_binning_bytes(B, cap), dtype=torch.uint8, device=dev),
-                  image=torch.empty(L.dm4d_views_image_bytes(B, H, W), dtype=torch.uint8, device=dev))
+        ws = r._take_ws(B)
         vs = ViewsStruct(B, N, t.F, t.G, g.V, g.M, g.K, r.method, H, W, r.tanfov, r.tanfov, r.scale_modifier, cap,
                          _p(keep["bg"]), _p(keep["vm"]), _p(keep["pm"]), _p(g.verts), _p(g.nbr_idx), _p(g.nbr_w),
                          _p(keep["dx"]), _p(keep["dr"]), _p(keep["ds"]), _p(keep["do"]), _p(t.faces), _p(keep["qs"]),
@@ -121,9 +149,7 @@ class _RenderViews(torch.autograd.Function):
                  vr=torch.empty(B, g.V, 4, **f), dx=torch.empty(B, g.M, 3, **f), dr=torch.empty(B, g.M, 4, **f),
                  ds=torch.empty(B, g.M, 6, **f) if ctx.keep["ds"] is not None else None,
                  do=torch.empty(B, g.M, **f) if ctx.keep["do"] is not None else None)
-        scr = dict(grad=torch.empty(L.dm4d_views_grad_bytes(B, vs.capacity), dtype=torch.uint8, device=dev),
-                   skin=torch.empty(L.dm4d_views_skin_scratch_bytes(B, g.V, g.K), dtype=torch.uint8, device=dev),
-                   face=torch.empty(L.dm4d_views_face_scratch_bytes(B, t.F), dtype=torch.uint8, device=dev))
+        scr = r._bwd_scratch(B, vs.capacity)
         gs = ViewsGrads(_p(gc), _p(gd), _p(ga), _p(gx), _p(gr_), _p(g.csr_off), _p(g.csr_items), _p(t.csr_off),
                         _p(t.csr_items), _p(scr["grad"]), _p(scr["skin"]), _p(scr["face"]), _p(o["m2"]), _p(o["m3"]),
                         _p(o["rot"]), _p(o["col"]), _p(o["op"]), _p(o["sc"]), _p(o["vx"]), _p(o["vr"]), _p(o["dx"]),
@@ -132,6 +158,8 @@ class _RenderViews(torch.autograd.Function):
             _lib.check(L.dm4d_views_backward(C.byref(vs), C.byref(gs), torch.cuda.current_stream(dev).cuda_stream),
                        "dm4d_views_backward")
         s = ctx.shapes
+        r._give_ws(ctx.ws)   # stream-ordered reuse by the next forward is safe
+        ctx.ws = None
         r.last_grads = o   # per-view gradients (means2D etc.) for callers that want them
         g_sc = o["sc"].sum(0).reshape(s[4]) if ctx.need_static else None
         g_op = o["op"].sum(0).reshape(s[5]) if ctx.need_static else None
