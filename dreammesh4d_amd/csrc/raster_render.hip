@@ -72,7 +72,9 @@ template <int C>
 __global__ __launch_bounds__(64) void k_render_fwd(BatchDesc d)
 {
     constexpr int NV = StagedN<C>::kVec;
-    __shared__ float4 s_e[2][64][NV];
+    // one wave-private staging buffer: the next chunk waits in registers (prefetched during the
+    // blend loop) and is written after the loop -- same wave, program order, no hazard
+    __shared__ float4 s_e[64][NV];
     const ViewCtx c = resolve(d, blockIdx.y);
     const ViewParams &vp = c.vp;
     const float *__restrict__ colors = c.colors;
@@ -106,12 +108,12 @@ __global__ __launch_bounds__(64) void k_render_fwd(BatchDesc d)
 
     float4 r[4];
     if ((uint32_t)lane < nq) gather_entry<C>(list[lane], g, colors, r);
-    int buf = 0;
-    for (uint32_t c0 = 0; c0 < nq; c0 += 64, buf ^= 1) {
+    for (uint32_t c0 = 0; c0 < nq; c0 += 64) {
         const int cnt = (int)min(64u, nq - c0);
+        __builtin_amdgcn_wave_barrier();
         if (lane < cnt) {
 #pragma unroll
-            for (int v = 0; v < NV; ++v) s_e[buf][lane][v] = r[v];
+            for (int v = 0; v < NV; ++v) s_e[lane][v] = r[v];
         }
         if (c0 + 64 + (uint32_t)lane < nq) gather_entry<C>(list[c0 + 64 + lane], g, colors, r);   // prefetch
         __builtin_amdgcn_wave_barrier();
@@ -120,7 +122,7 @@ __global__ __launch_bounds__(64) void k_render_fwd(BatchDesc d)
         do {
             // Branch-free body (selects, not exec-mask branches): lanes that do not take the entry
             // blend with weight 0, which leaves their accumulators bit-identical.
-            const float4 ea = s_e[buf][t][0], eb = s_e[buf][t][1], ec = s_e[buf][t][2];
+            const float4 ea = s_e[t][0], eb = s_e[t][1], ec = s_e[t][2];
             const float dx = ea.x - pxf, dy = ea.y - pyf;
             const float power = -0.5f * ((ea.z * dx) * dx + (eb.x * dy) * dy) - (ea.w * dx) * dy;
             const float alpha = fminf(0.99f, eb.y * det_expf(power));
@@ -133,7 +135,7 @@ __global__ __launch_bounds__(64) void k_render_fwd(BatchDesc d)
             Cacc[1] = __builtin_fmaf(ec.y, w, Cacc[1]);
             Cacc[2] = __builtin_fmaf(ec.z, w, Cacc[2]);
             if (C > 3) {
-                const float4 ed = s_e[buf][t][NV - 1];
+                const float4 ed = s_e[t][NV - 1];
                 Cacc[3] = __builtin_fmaf(ec.w, w, Cacc[3]);
                 Cacc[C > 4 ? 4 : 0] = __builtin_fmaf(ed.x, w, Cacc[C > 4 ? 4 : 0]);
                 Cacc[C > 5 ? 5 : 0] = __builtin_fmaf(ed.y, w, Cacc[C > 5 ? 5 : 0]);
@@ -192,7 +194,7 @@ __global__ __launch_bounds__(64) void k_render_bwd(BatchDesc d)
 {
     constexpr int NV = StagedN<C>::kVec;
     constexpr int GS = (C <= 3) ? 12 : 16;   // == grad_stride(C)
-    __shared__ float4 s_e[2][64][NV];
+    __shared__ float4 s_e[64][NV];
     const ViewCtx c = resolve(d, blockIdx.y);
     const ViewParams &vp = c.vp;
     const float *__restrict__ colors = c.colors;
@@ -248,17 +250,17 @@ __global__ __launch_bounds__(64) void k_render_bwd(BatchDesc d)
     const int c_last = (int)((nd - 1) / 64) * 64;
     float4 r[4];
     if ((uint32_t)(c_last + lane) < nd) gather_entry<C>(list[c_last + lane], g, colors, r);
-    int buf = 0;
-    for (int c0 = c_last; c0 >= 0; c0 -= 64, buf ^= 1) {
+    for (int c0 = c_last; c0 >= 0; c0 -= 64) {
         const int cnt = (int)min(64u, nd - (uint32_t)c0);
+        __builtin_amdgcn_wave_barrier();
         if (lane < cnt) {
 #pragma unroll
-            for (int v = 0; v < NV; ++v) s_e[buf][lane][v] = r[v];
+            for (int v = 0; v < NV; ++v) s_e[lane][v] = r[v];
         }
         if (c0 >= 64) gather_entry<C>(list[c0 - 64 + lane], g, colors, r);   // prefetch the chunk in front
         __builtin_amdgcn_wave_barrier();
         for (int t = cnt - 1; t >= 0; --t) {
-            const float4 ea = s_e[buf][t][0], eb = s_e[buf][t][1];
+            const float4 ea = s_e[t][0], eb = s_e[t][1];
             const uint32_t k = __float_as_uint(eb.w);
             // Branch-free: lanes that do not take the entry contribute exact zeros.
             const float dx = ea.x - pxf, dy = ea.y - pyf;
@@ -266,11 +268,11 @@ __global__ __launch_bounds__(64) void k_render_bwd(BatchDesc d)
             const float Gr = det_expf(power);
             const float alpha = fminf(0.99f, eb.y * Gr);
             const bool contrib = (k < last) & (power <= 0.0f) & (alpha >= 1.0f / 255.0f);
-            const float4 ec = s_e[buf][t][2];
+            const float4 ec = s_e[t][2];
             float col[C];
             col[0] = ec.x; col[1] = ec.y; col[2] = ec.z;
             if (C > 3) {
-                const float4 ed = s_e[buf][t][NV - 1];
+                const float4 ed = s_e[t][NV - 1];
                 col[3] = ec.w;
                 col[C > 4 ? 4 : 0] = ed.x;
                 col[C > 5 ? 5 : 0] = ed.y;
