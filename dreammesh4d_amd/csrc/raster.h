@@ -120,7 +120,6 @@ DM4D_HD static inline GeomPtrs geom_ptrs(void *base, const GeomLayout &L)
 struct BinPtrs {
     uint32_t *u_depth;    // unsorted duplicates, tile-major segments
     uint32_t *u_idx;
-    uint32_t *u_p;        // Gaussian-major duplicate index (offsets[g] + i)
     uint32_t *point_list; // sorted Gaussian ids  (== upstream point_list)
     uint32_t *sorted_pos; // Gaussian-major duplicate index -> position in point_list
     uint2 *qlist;         // [4][cap] quadrant lists: (Gaussian id, position k in the tile list),
@@ -130,7 +129,7 @@ struct BinPtrs {
 DM4D_HD static inline size_t binning_bytes(int64_t cap)
 {
     size_t c = (size_t)(cap > 0 ? cap : 1);
-    return 5 * align_up(c * 4, 256) + align_up(c * 32, 256);
+    return 4 * align_up(c * 4, 256) + align_up(c * 32, 256);
 }
 DM4D_HD static inline BinPtrs bin_ptrs(void *base, int64_t cap)
 {
@@ -140,10 +139,9 @@ DM4D_HD static inline BinPtrs bin_ptrs(void *base, int64_t cap)
     BinPtrs p;
     p.u_depth = (uint32_t *)(b);
     p.u_idx = (uint32_t *)(b + stride);
-    p.u_p = (uint32_t *)(b + 2 * stride);
-    p.point_list = (uint32_t *)(b + 3 * stride);
-    p.sorted_pos = (uint32_t *)(b + 4 * stride);
-    p.qlist = (uint2 *)(b + 5 * stride);
+    p.point_list = (uint32_t *)(b + 2 * stride);
+    p.sorted_pos = (uint32_t *)(b + 3 * stride);
+    p.qlist = (uint2 *)(b + 4 * stride);
     p.cap = c;
     return p;
 }

@@ -50,8 +50,23 @@ __global__ __launch_bounds__(kColThreads) void k_colscan(BatchDesc d)
 }
 
 // ---------------------------------------------------------------------------------------- K4
+// Per-tile sort by the 64-bit key (depth bits << 32 | Gaussian id) == the order a stable radix sort
+// of tile<<32|depth produces from the Gaussian-major duplicate list.
+//
+// Fast path (n <= kSortLdsCap, everything in LDS): ADAPTIVE DEPTH-BUCKET COUNTING SORT.
+//   1. min / max of the tile's depths                      (block reduction)
+//   2. bucket = monotone quantisation of the depth into kBins buckets, LDS histogram, scan
+//   3. scatter keys bucket-major (slot order inside a bucket is arbitrary)
+//   4. rank inside the bucket by the full 64-bit key (buckets hold a handful of entries; in the
+//      degenerate all-equal-depth case this degrades to an O(n^2/256) rank sort, still exact)
+// The result is fully determined by the keys (a total order), so it is deterministic although the
+// scatter uses LDS atomics.  O(n) work and 6 barriers instead of the O(n log^2 n) / 55-barrier
+// bitonic network this replaced.
+// Slow path (n > kSortLdsCap): bitonic network on the HBM-resident segment, one workgroup.
 constexpr int kSortThreads = 256;
-constexpr int kSortLdsCap = 4096;   // duplicates per tile sorted in LDS (48 KB); more -> global path
+constexpr int kSortLdsCap = 2048;
+constexpr int kSortPerThread = kSortLdsCap / kSortThreads;
+constexpr int kBins = 1024;
 
 __device__ __forceinline__ uint32_t next_pow2(uint32_t v)
 {
@@ -68,7 +83,6 @@ __device__ __forceinline__ void bitonic_network(uint32_t n, Swap &&cmpswap)
     const uint32_t np2 = next_pow2(n);
     const uint32_t half_pairs = np2 >> 1;
     for (uint32_t k = 2; k <= np2; k <<= 1) {
-        // flip step
         {
             const uint32_t h = k >> 1;
             for (uint32_t t = threadIdx.x; t < half_pairs; t += kSortThreads) {
@@ -89,15 +103,31 @@ __device__ __forceinline__ void bitonic_network(uint32_t n, Swap &&cmpswap)
     }
 }
 
-// Split the sorted tile list into the four quadrant lists (stable compaction by quadrant_mask).
+// Gaussian-major duplicate index of (gid, tile): offsets[gid] + position of the tile in gid's rect
+__device__ __forceinline__ uint32_t dup_index(const ViewCtx &c, uint32_t gid, int tx, int ty)
+{
+    const float2 xy = c.g.xy[gid];
+    const float fr = (float)c.radii[gid];
+    const int gx = c.vp.gx;
+    const int x0 = min(gx, max(0, f2i_sat((xy.x - fr) / (float)kTile)));
+    const int y0 = min(c.vp.gy, max(0, f2i_sat((xy.y - fr) / (float)kTile)));
+    const int x1 = min(gx, max(0, f2i_sat((xy.x + fr + (float)(kTile - 1)) / (float)kTile)));
+    return c.g.offsets[gid] + (uint32_t)((ty - y0) * (x1 - x0) + (tx - x0));
+}
+
+// Split the sorted tile list into the four quadrant lists (stable compaction by quadrant_mask) and
+// record where every duplicate landed (sorted_pos).
 template <typename GidAt>
-__device__ __forceinline__ void build_quadrant_lists(const ViewParams &vp, int tile, uint32_t s, uint32_t n,
-                                                     const GeomPtrs &g, const BinPtrs &b, uint32_t cap, GidAt &&gid_at)
+__device__ __forceinline__ void finish_tile(const ViewCtx &c, int tile, uint32_t s, uint32_t n, GidAt &&gid_at)
 {
     __shared__ uint32_t s_qbase[4];
     __shared__ uint32_t s_wq[kSortThreads / 64][4];
+    const GeomPtrs &g = c.g;
+    const BinPtrs &b = c.b;
+    const uint32_t cap = c.cap;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const float ox = (float)((tile % vp.gx) * kTile), oy = (float)((tile / vp.gx) * kTile);
+    const int tx = tile % c.vp.gx, ty = tile / c.vp.gx;
+    const float ox = (float)(tx * kTile), oy = (float)(ty * kTile);
     if (tid < 4) s_qbase[tid] = 0u;
     __syncthreads();
     for (uint32_t e0 = 0; e0 < n; e0 += kSortThreads) {
@@ -105,6 +135,9 @@ __device__ __forceinline__ void build_quadrant_lists(const ViewParams &vp, int t
         uint32_t m = 0u, gid = 0u;
         if (e < n) {
             gid = gid_at(e);
+            b.point_list[s + e] = gid;
+            const uint32_t p = dup_index(c, gid, tx, ty);
+            if (p < cap) b.sorted_pos[p] = s + e;
             const float2 xy = g.xy[gid];
             const float4 co = g.conic_opacity[gid];
             m = quadrant_mask(xy.x, xy.y, co.x, co.y, co.z, co.w, ox, oy);
@@ -139,15 +172,17 @@ __device__ __forceinline__ void build_quadrant_lists(const ViewParams &vp, int t
 
 __global__ __launch_bounds__(kSortThreads) void k_tile_sort(BatchDesc d)
 {
+    __shared__ uint64_t s_a[kSortLdsCap];      // sorted keys
+    __shared__ uint64_t s_b[kSortLdsCap];      // bucket-major keys
+    __shared__ uint32_t s_bin[kBins + 1];      // histogram -> bucket ends
+    __shared__ uint32_t s_cur[kBins];          // bucket starts / scatter cursors
+    __shared__ uint32_t s_red[2 * (kSortThreads / 64)];
     const ViewCtx c = resolve(d, blockIdx.y);
-    const ViewParams &vp = c.vp;
     const GeomPtrs &g = c.g;
     const BinPtrs &b = c.b;
     const uint32_t cap = c.cap;
-    __shared__ uint64_t s_key[kSortLdsCap];
-    __shared__ uint32_t s_p[kSortLdsCap];
     const int t = blockIdx.x;
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const uint32_t s = g.tile_start[t];
     uint32_t n = g.tile_count[t];
     if (s >= cap) n = 0;
@@ -157,44 +192,96 @@ __global__ __launch_bounds__(kSortThreads) void k_tile_sort(BatchDesc d)
         return;
     }
     if (n <= (uint32_t)kSortLdsCap) {
-        for (uint32_t e = tid; e < n; e += kSortThreads) {
-            s_key[e] = ((uint64_t)b.u_depth[s + e] << 32) | b.u_idx[s + e];
-            s_p[e] = b.u_p[s + e];
+        // ---- load, min / max depth ----
+        uint64_t key[kSortPerThread];
+        uint32_t dmin = 0xFFFFFFFFu, dmax = 0u;
+#pragma unroll
+        for (int r = 0; r < kSortPerThread; ++r) {
+            const uint32_t e = r * kSortThreads + tid;
+            key[r] = ~0ull;
+            if (e < n) {
+                const uint32_t dz = b.u_depth[s + e];
+                key[r] = ((uint64_t)dz << 32) | b.u_idx[s + e];
+                dmin = min(dmin, dz);
+                dmax = max(dmax, dz);
+            }
+        }
+        for (int o = 32; o > 0; o >>= 1) {
+            dmin = min(dmin, (uint32_t)__shfl_xor((int)dmin, o, 64));
+            dmax = max(dmax, (uint32_t)__shfl_xor((int)dmax, o, 64));
+        }
+        if (lane == 0) { s_red[wv] = dmin; s_red[4 + wv] = dmax; }
+        for (int i = tid; i <= kBins; i += kSortThreads) s_bin[i] = 0u;
+        __syncthreads();
+        dmin = min(min(s_red[0], s_red[1]), min(s_red[2], s_red[3]));
+        dmax = max(max(s_red[4], s_red[5]), max(s_red[6], s_red[7]));
+        // depths are positive floats (> 0.2), so the bit patterns order like the values
+        const float zmin = __uint_as_float(dmin), zspan = __uint_as_float(dmax) - zmin;
+        const float scale = (zspan > 0.f && zspan < 3.0e38f) ? (float)kBins / zspan : 0.f;
+        uint32_t bin[kSortPerThread];
+#pragma unroll
+        for (int r = 0; r < kSortPerThread; ++r) {
+            const uint32_t e = r * kSortThreads + tid;
+            bin[r] = 0u;
+            if (e < n) {
+                const float z = __uint_as_float((uint32_t)(key[r] >> 32));
+                bin[r] = min((uint32_t)(kBins - 1), (uint32_t)max(0, f2i_sat((z - zmin) * scale)));
+                atomicAdd(&s_bin[bin[r] + 1], 1u);
+            }
         }
         __syncthreads();
-        if (n > 1) {
-            bitonic_network(n, [&](uint32_t i, uint32_t l) {
-                const uint64_t ki = s_key[i], kl = s_key[l];
-                if (kl < ki) {
-                    s_key[i] = kl; s_key[l] = ki;
-                    const uint32_t pi = s_p[i]; s_p[i] = s_p[l]; s_p[l] = pi;
-                }
-            });
+        // ---- exclusive scan of the kBins counts (kBins / 256 per thread) ----
+        {
+            constexpr int per = kBins / kSortThreads;
+            uint32_t loc[per], sum = 0;
+#pragma unroll
+            for (int i = 0; i < per; ++i) { loc[i] = s_bin[1 + tid * per + i]; sum += loc[i]; }
+            const uint32_t incl = wave_incl_scan_u32(sum, lane);
+            __syncthreads();
+            if (lane == 63) s_red[wv] = incl;
+            __syncthreads();
+            uint32_t run = incl - sum;
+            for (int w = 0; w < wv; ++w) run += s_red[w];
+#pragma unroll
+            for (int i = 0; i < per; ++i) {
+                s_cur[tid * per + i] = run;      // start of bucket tid*per+i
+                run += loc[i];
+                s_bin[1 + tid * per + i] = run;  // end of that bucket == start of the next
+            }
         }
-        for (uint32_t e = tid; e < n; e += kSortThreads) {
-            b.point_list[s + e] = (uint32_t)s_key[e];
-            const uint32_t p = s_p[e];
-            if (p < cap) b.sorted_pos[p] = s + e;
+        __syncthreads();
+        // ---- bucket-major scatter ----
+#pragma unroll
+        for (int r = 0; r < kSortPerThread; ++r) {
+            const uint32_t e = r * kSortThreads + tid;
+            if (e < n) s_b[atomicAdd(&s_cur[bin[r]], 1u)] = key[r];
         }
-        build_quadrant_lists(vp, t, s, n, g, b, cap, [&](uint32_t e) { return (uint32_t)s_key[e]; });
+        __syncthreads();
+        // ---- rank inside the bucket by the full key, write the sorted keys ----
+#pragma unroll
+        for (int r = 0; r < kSortPerThread; ++r) {
+            const uint32_t e = r * kSortThreads + tid;
+            if (e < n) {
+                const uint32_t lo = s_bin[bin[r]], hi = s_bin[bin[r] + 1];
+                uint32_t rank = 0;
+                for (uint32_t j = lo; j < hi; ++j) rank += (s_b[j] < key[r]) ? 1u : 0u;
+                s_a[lo + rank] = key[r];
+            }
+        }
+        __syncthreads();
+        finish_tile(c, t, s, n, [&](uint32_t e) { return (uint32_t)s_a[e]; });
     } else {
-        // Oversized tile: same network on the HBM-resident segment (one workgroup; rare).
-        uint32_t *kd = b.u_depth + s, *ki_ = b.u_idx + s, *kp = b.u_p + s;
+        // Oversized tile: bitonic network on the HBM-resident segment (one workgroup; rare).
+        uint32_t *kd = b.u_depth + s, *ki_ = b.u_idx + s;
         bitonic_network(n, [&](uint32_t i, uint32_t l) {
-            const uint64_t a = ((uint64_t)kd[i] << 32) | ki_[i], c = ((uint64_t)kd[l] << 32) | ki_[l];
-            if (c < a) {
+            const uint64_t a = ((uint64_t)kd[i] << 32) | ki_[i], cc = ((uint64_t)kd[l] << 32) | ki_[l];
+            if (cc < a) {
                 uint32_t x;
                 x = kd[i]; kd[i] = kd[l]; kd[l] = x;
                 x = ki_[i]; ki_[i] = ki_[l]; ki_[l] = x;
-                x = kp[i]; kp[i] = kp[l]; kp[l] = x;
             }
         });
-        for (uint32_t e = tid; e < n; e += kSortThreads) {
-            b.point_list[s + e] = ki_[e];
-            const uint32_t p = kp[e];
-            if (p < cap) b.sorted_pos[p] = s + e;
-        }
-        build_quadrant_lists(vp, t, s, n, g, b, cap, [&](uint32_t e) { return ki_[e]; });
+        finish_tile(c, t, s, n, [&](uint32_t e) { return ki_[e]; });
     }
 }
 

@@ -311,7 +311,6 @@ __global__ __launch_bounds__(kPreThreads) void k_scatter(BatchDesc d)
                 if (slot < cap) {
                     b.u_depth[slot] = dbits;
                     b.u_idx[slot] = (uint32_t)i;
-                    b.u_p[slot] = p0 + n;
                 } else {
                     overflow = true;
                 }
