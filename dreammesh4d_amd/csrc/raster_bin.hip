@@ -4,7 +4,8 @@
 //                     by K1 (-> per-(workgroup, tile) slot bases, tile counts); the tile segment
 //                     starts (== upstream's `ranges`) follow from a scan K3 does in LDS.
 //   K4 k_tile_sort  : one workgroup per tile; sorts the tile's duplicates by the 64-bit key
-//                     (depth bits << 32 | Gaussian id) in LDS with a bitonic network.
+//                     (depth bits << 32 | Gaussian id) with a depth-bucket counting sort in LDS, then
+//                     splits the sorted list into the four 8x8-quadrant lists.
 //
 // Why not upstream's global radix sort (cub::DeviceRadixSort over tile<<32|depth, 6 passes of
 // 24 B/duplicate): duplicates are already partitioned by tile after K3, a tile's list is a few
@@ -62,46 +63,12 @@ __global__ __launch_bounds__(kColThreads) void k_colscan(BatchDesc d)
 // The result is fully determined by the keys (a total order), so it is deterministic although the
 // scatter uses LDS atomics.  O(n) work and 6 barriers instead of the O(n log^2 n) / 55-barrier
 // bitonic network this replaced.
-// Slow path (n > kSortLdsCap): bitonic network on the HBM-resident segment, one workgroup.
+// Large tiles (n > kSortLdsCap): the same algorithm with the keys resident in HBM/L2 (the bucket-major
+// copy borrows the tile's quadrant-0 list segment, which is only written afterwards).
 constexpr int kSortThreads = 256;
 constexpr int kSortLdsCap = 2048;
 constexpr int kSortPerThread = kSortLdsCap / kSortThreads;
 constexpr int kBins = 1024;
-
-__device__ __forceinline__ uint32_t next_pow2(uint32_t v)
-{
-    v--;
-    v |= v >> 1; v |= v >> 2; v |= v >> 4; v |= v >> 8; v |= v >> 16;
-    return v + 1;
-}
-
-// Ascending bitonic network for arbitrary n ("flip" formulation): positions >= n behave as
-// +inf and never move, so compare-exchanges touching them are skipped.
-template <typename Swap>
-__device__ __forceinline__ void bitonic_network(uint32_t n, Swap &&cmpswap)
-{
-    const uint32_t np2 = next_pow2(n);
-    const uint32_t half_pairs = np2 >> 1;
-    for (uint32_t k = 2; k <= np2; k <<= 1) {
-        {
-            const uint32_t h = k >> 1;
-            for (uint32_t t = threadIdx.x; t < half_pairs; t += kSortThreads) {
-                const uint32_t i = ((t / h) * k) + (t % h);
-                const uint32_t l = i ^ (k - 1);
-                if (l < n) cmpswap(i, l);
-            }
-            __syncthreads();
-        }
-        for (uint32_t j = k >> 2; j >= 1; j >>= 1) {
-            for (uint32_t t = threadIdx.x; t < half_pairs; t += kSortThreads) {
-                const uint32_t i = ((t / j) * (j << 1)) + (t % j);
-                const uint32_t l = i + j;
-                if (l < n) cmpswap(i, l);
-            }
-            __syncthreads();
-        }
-    }
-}
 
 // Gaussian-major duplicate index of (gid, tile): offsets[gid] + position of the tile in gid's rect
 __device__ __forceinline__ uint32_t dup_index(const ViewCtx &c, uint32_t gid, int tx, int ty)
@@ -271,16 +238,67 @@ __global__ __launch_bounds__(kSortThreads) void k_tile_sort(BatchDesc d)
         __syncthreads();
         finish_tile(c, t, s, n, [&](uint32_t e) { return (uint32_t)s_a[e]; });
     } else {
-        // Oversized tile: bitonic network on the HBM-resident segment (one workgroup; rare).
+        // ---- large tile: the same bucket sort with the keys resident in HBM (L2) ----
+        // temp (bucket-major keys) lives in the tile's own quadrant-0 list segment, which
+        // finish_tile() only writes afterwards; the sorted keys go back in place.
         uint32_t *kd = b.u_depth + s, *ki_ = b.u_idx + s;
-        bitonic_network(n, [&](uint32_t i, uint32_t l) {
-            const uint64_t a = ((uint64_t)kd[i] << 32) | ki_[i], cc = ((uint64_t)kd[l] << 32) | ki_[l];
-            if (cc < a) {
-                uint32_t x;
-                x = kd[i]; kd[i] = kd[l]; kd[l] = x;
-                x = ki_[i]; ki_[i] = ki_[l]; ki_[l] = x;
+        uint64_t *tmp = reinterpret_cast<uint64_t *>(b.qlist + s);
+        uint32_t dmin = 0xFFFFFFFFu, dmax = 0u;
+        for (uint32_t e = tid; e < n; e += kSortThreads) {
+            const uint32_t dz = kd[e];
+            dmin = min(dmin, dz);
+            dmax = max(dmax, dz);
+        }
+        for (int o = 32; o > 0; o >>= 1) {
+            dmin = min(dmin, (uint32_t)__shfl_xor((int)dmin, o, 64));
+            dmax = max(dmax, (uint32_t)__shfl_xor((int)dmax, o, 64));
+        }
+        if (lane == 0) { s_red[wv] = dmin; s_red[4 + wv] = dmax; }
+        for (int i = tid; i <= kBins; i += kSortThreads) s_bin[i] = 0u;
+        __syncthreads();
+        dmin = min(min(s_red[0], s_red[1]), min(s_red[2], s_red[3]));
+        dmax = max(max(s_red[4], s_red[5]), max(s_red[6], s_red[7]));
+        const float zmin = __uint_as_float(dmin), zspan = __uint_as_float(dmax) - zmin;
+        const float scale = (zspan > 0.f && zspan < 3.0e38f) ? (float)kBins / zspan : 0.f;
+        auto bin_of = [&](uint32_t dz) {
+            return min((uint32_t)(kBins - 1), (uint32_t)max(0, f2i_sat((__uint_as_float(dz) - zmin) * scale)));
+        };
+        for (uint32_t e = tid; e < n; e += kSortThreads) atomicAdd(&s_bin[bin_of(kd[e]) + 1], 1u);
+        __syncthreads();
+        {
+            constexpr int per = kBins / kSortThreads;
+            uint32_t loc[per], sum = 0;
+#pragma unroll
+            for (int i = 0; i < per; ++i) { loc[i] = s_bin[1 + tid * per + i]; sum += loc[i]; }
+            const uint32_t incl = wave_incl_scan_u32(sum, lane);
+            __syncthreads();
+            if (lane == 63) s_red[wv] = incl;
+            __syncthreads();
+            uint32_t run = incl - sum;
+            for (int w = 0; w < wv; ++w) run += s_red[w];
+#pragma unroll
+            for (int i = 0; i < per; ++i) {
+                s_cur[tid * per + i] = run;
+                run += loc[i];
+                s_bin[1 + tid * per + i] = run;
             }
-        });
+        }
+        __syncthreads();
+        for (uint32_t e = tid; e < n; e += kSortThreads) {
+            const uint32_t dz = kd[e];
+            tmp[atomicAdd(&s_cur[bin_of(dz)], 1u)] = ((uint64_t)dz << 32) | ki_[e];
+        }
+        __syncthreads();   // workgroup-scope: tmp writes visible to the whole workgroup
+        for (uint32_t e = tid; e < n; e += kSortThreads) {
+            const uint64_t k = tmp[e];
+            const uint32_t bn = bin_of((uint32_t)(k >> 32));
+            const uint32_t lo = s_bin[bn], hi = s_bin[bn + 1];
+            uint32_t rank = 0;
+            for (uint32_t j = lo; j < hi; ++j) rank += (tmp[j] < k) ? 1u : 0u;
+            kd[lo + rank] = (uint32_t)(k >> 32);
+            ki_[lo + rank] = (uint32_t)k;
+        }
+        __syncthreads();
         finish_tile(c, t, s, n, [&](uint32_t e) { return ki_[e]; });
     }
 }
