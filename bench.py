@@ -22,6 +22,8 @@ import os
 import sys
 import time
 
+os.environ.setdefault("OMP_WAIT_POLICY", "PASSIVE")   # two OpenMP runtimes (torch, oracle) must not spin against each other
+
 import numpy as np
 import torch
 
@@ -202,7 +204,7 @@ def cpu_baseline(wl, n_views):
     timed on this box's host cores on a bounded sample: the first `n_views` units of the same workload."""
     from oracle import raster as orc, skinning as sk
 
-    torch.set_num_threads(os.cpu_count())
+    torch.set_num_threads(min(16, os.cpu_count()))   # skinning tensors are small; more threads only contend
     sc = wl.sc
     t = lambda a: torch.tensor(np.asarray(a))
     verts, faces, idx, w = t(sc["verts"]), t(sc["faces"]), t(sc["nbr_idx"]), t(sc["nbr_w"])
@@ -235,8 +237,9 @@ def cpu_baseline(wl, n_views):
         unit(v % len(wl.cams))
     dt = time.perf_counter() - t0
     return {"value": round(n_views / dt, 4), "unit": "views/s", "cores": os.cpu_count(), "kind": "port",
-            "sample": f"{n_views} of the same (frame, view) units (skinning + face->Gaussian in PyTorch-CPU, RGB + "
-                      f"normal pass fwd+bwd in the C/OpenMP oracle), {os.cpu_count()} host threads"}
+            "sample": f"{n_views} of the same (frame, view) units (skinning + face->Gaussian in PyTorch-CPU on "
+                      f"{min(16, os.cpu_count())} threads, RGB + normal pass fwd+bwd in the C/OpenMP oracle on "
+                      f"{os.cpu_count()} threads)"}
 
 
 if __name__ == "__main__":

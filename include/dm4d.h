@@ -169,6 +169,12 @@ int dm4d_selftest_wave_reduce(const float *in, float *out, dm4d_stream_t stream)
 int dm4d_mark_visible(int32_t N, const float *means3D, const float *viewmatrix, uint8_t *present,
                       dm4d_stream_t stream);
 
+/* ------------------------------------------------------------------ simple-knn */
+
+/* simple_knn._C.distCUDA2 (C/geometry/gaussian_base.py:435-438): out[i] = mean of the squared distances
+ * from point i to its 3 nearest OTHER points (self excluded by index).  points [N,3], out [N]. */
+int dm4d_dist2_knn3(int32_t N, const float *points, float *out, dm4d_stream_t stream);
+
 /* ------------------------------------------------------------------ skinning / face -> Gaussians */
 
 /* Sparse-control skinning of the V mesh vertices by M deformation-graph nodes, K neighbours each
