@@ -53,8 +53,9 @@ def parse():
 
 class Workload:
     """Seeded mesh-bound scene (dreammesh4d_amd/synthetic.py) resident in HBM; this rank's (frame, view)
-    units per step.  The per-frame node outputs stand in for the HexPlane+MLP of
-    geometry/deformation.py (they are the trainable leaves whose gradients are all-reduced)."""
+    units per step.  Node outputs come from the HexPlane+MLP deformation network
+    (dreammesh4d_amd/deformation.py, 35.76 M parameters -- the trainable state whose 143 MB of gradients
+    are all-reduced), with its zero-initialised heads perturbed (seeded) so the mesh actually moves."""
 
     def __init__(self, dev, rank, world):
         from dreammesh4d_amd import geometry as geo, ops, synthetic as syn, views
@@ -70,10 +71,16 @@ class Workload:
         self.opac = geo.strengths(T(sc["densities"]))
         self.rgb = geo.points_rgb(T(sc["sh_dc"]))
         self.N = self.topo.F * 6
-        self.ts, self.motion = syn.node_motion(N_NODES, N_FRAMES, seed=0)
-        # trainable leaves: raw node outputs of every frame [L, M, .]
-        self.P = {k: torch.stack([T(m[k]) for m in self.motion]).requires_grad_(True)
-                  for k in ("trans", "d_rot", "strain", "d_opacity")}
+        from dreammesh4d_amd.deformation import DeformationNetwork
+        torch.manual_seed(0)
+        self.net = DeformationNetwork(no_ds=False, no_dr=False, no_do=False).to(dev)     # hybrid: all four heads
+        g0 = torch.Generator(device="cpu").manual_seed(11)
+        with torch.no_grad():
+            for name, p in self.net.named_parameters():
+                if "_deform" in name:
+                    p.add_((0.02 * torch.randn(p.shape, generator=g0)).to(dev))
+        self.nodes = T(sc["nodes"])
+        self.timestamps = torch.linspace(0, 1, N_FRAMES + 2)[1:-1].to(dev)            # data/temporal_image.py:155-158
         # rank r renders frames {4r .. 4r+3} (mod L), VIEWS_PER_FRAME cameras each
         self.frames = [(FRAMES_PER_STEP * rank + i) % N_FRAMES for i in range(FRAMES_PER_STEP)]
         self.cams, self.unit_frames = [], []
@@ -86,7 +93,8 @@ class Workload:
                 self.unit_frames.append(fr)
         self.vm = torch.stack([T(c.viewmatrix) for c in self.cams])
         self.pm = torch.stack([T(c.projmatrix) for c in self.cams])
-        self.fidx = torch.tensor(self.unit_frames, device=dev)
+        self.fidx = torch.tensor([self.frames.index(f) for f in self.unit_frames], device=dev)   # unit -> row of this step's frames
+        self.frame_t = self.timestamps[torch.tensor(self.frames, device=dev)]
         self.bg6 = torch.ones(6, device=dev)
         self.renderer = views.ViewRenderer(self.graph, self.topo, H, W, self.cams[0].tanfov, method="hybrid")
         g = torch.Generator(device="cpu").manual_seed(2)
@@ -97,12 +105,12 @@ class Workload:
         self.render_views = views.render_views
 
     def step(self):
-        P = self.P
-        for p in P.values():
-            p.grad = None
-        out = self.render_views(self.renderer, P["trans"][self.fidx], P["d_rot"][self.fidx], P["strain"][self.fidx],
-                                P["d_opacity"][self.fidx].squeeze(-1), self.qs, self.scales, self.opac, self.rgb, self.vm,
-                                self.pm, self.bg6)
+        self.net.zero_grad(set_to_none=True)
+        # node attributes once per distinct timestamp of the step (cached per step in the reference,
+        # dynamic_sugar.py:367-405), then broadcast to the views of that frame
+        dx, dr, ds, do = self.net.node_outputs(self.nodes, self.frame_t)
+        out = self.render_views(self.renderer, dx[self.fidx], dr[self.fidx], ds[self.fidx], do[self.fidx], self.qs,
+                                self.scales, self.opac, self.rgb, self.vm, self.pm, self.bg6)
         torch.autograd.backward([out["color"], out["depth"], out["alpha"]], [self.gC, self.gD, self.gA])
         return out
 
@@ -123,16 +131,13 @@ def main():
     from dreammesh4d_amd import _lib
     L = _lib.lib()
 
+    from dreammesh4d_amd.distributed import GradAllReducer
     wl = Workload(dev, rank, world)
-    params = list(wl.P.values())
-    flat = torch.zeros(sum(p.numel() for p in params), device=dev) if world > 1 else None
+    reducer = GradAllReducer(wl.net.parameters())     # 35.76 M floats = 143 MB, one message
 
     def step():
         wl.step()
-        if world > 1:   # the one exchange step of the path: data-parallel gradient all-reduce (mean)
-            torch.cat([p.grad.reshape(-1) for p in params], out=flat)
-            dist.all_reduce(flat)
-            flat.mul_(1.0 / world)
+        reducer()       # the one exchange step of the path: data-parallel gradient all-reduce (no-op for 1 GPU)
 
     def sync():
         torch.cuda.synchronize(dev)
@@ -183,7 +188,8 @@ def main():
                                    f"({wl.topo.F} faces x 6), {N_NODES} graph nodes K={K_NBR} hybrid LBS/DQS skinning, "
                                    f"512x512; per view: skinning + face->Gaussian + RGB pass + normal pass, fwd+bwd",
                        "views_per_step_per_gpu": VIEWS_PER_STEP, "frames_per_step_per_gpu": FRAMES_PER_STEP,
-                       "mean_duplicates_D": round(D_mean), "whole_view_frac_of_hbm_roofline":
+                       "mean_duplicates_D": round(D_mean), "allreduce_bytes_per_step": reducer.nbytes if world > 1 else 0,
+                       "whole_view_frac_of_hbm_roofline":
                            round(value / world * b_view / (HBM_PEAK_GBS * 1e9), 5),
                        "parallelism": f"dp{world} (frames sharded, 1 grad all-reduce/step)" if world > 1 else "single GPU"},
             "roofline": {"bound": "hbm", "kernel": "k_render_bwd<6> (batched over the step's views)",
@@ -212,9 +218,13 @@ def cpu_baseline(wl, n_views):
     scales, opac, rgb = sk.static_attributes(t(sc["log_scales"]), t(sc["densities"]), t(sc["sh_dc"]), 3.8e-6)
     gC, gD, gA = wl.gC.cpu().numpy(), wl.gD.cpu().numpy(), wl.gA.cpu().numpy()
 
+    with torch.no_grad():
+        raw = [x.detach().cpu() for x in wl.net.node_outputs(wl.nodes, wl.frame_t)]
+
     def unit(u):
-        cam, m = wl.cams[u], wl.motion[wl.unit_frames[u]]
-        leaves = [t(m[k]).requires_grad_(True) for k in ("trans", "d_rot", "strain", "d_opacity")]
+        cam, f = wl.cams[u], int(wl.fidx[u])
+        leaves = [raw[0][f].clone().requires_grad_(True), raw[1][f].clone().requires_grad_(True),
+                  raw[2][f].clone().requires_grad_(True), raw[3][f].clone().unsqueeze(-1).requires_grad_(True)]
         trans, q, S, op = sk.node_attributes(*leaves)
         xyz, vrot = sk.skin_vertices(verts, idx, w, trans, q, S, op, "hybrid")
         means, rots, normals = sk.face_gaussians(xyz, vrot, faces, qs)
@@ -237,7 +247,7 @@ def cpu_baseline(wl, n_views):
         unit(v % len(wl.cams))
     dt = time.perf_counter() - t0
     return {"value": round(n_views / dt, 4), "unit": "views/s", "cores": os.cpu_count(), "kind": "port",
-            "sample": f"{n_views} of the same (frame, view) units (skinning + face->Gaussian in PyTorch-CPU on "
+            "sample": f"{n_views} of the same (frame, view) units, HexPlane query excluded (skinning + face->Gaussian in PyTorch-CPU on "
                       f"{min(16, os.cpu_count())} threads, RGB + normal pass fwd+bwd in the C/OpenMP oracle on "
                       f"{os.cpu_count()} threads)"}
 

@@ -1,0 +1,150 @@
+"""HexPlane + MLP deformation network of the dynamic stage.
+
+Host-side mirror (PyTorch ops, any device) of
+custom/threestudio-dreammesh4d/geometry/deformation.py: `DeformationNetwork` ->
+`Deformation` -> `HexPlaneField` (:177-248), queried through `forward_dynamic_delta`
+(:430-436,538-539) by `DynamicSuGaRModel._get_timed_dg_attributes`
+(geometry/dynamic_sugar.py:420-431) on the ~1000 deformation-graph nodes.
+
+Module / parameter names follow the reference so its checkpoints load with
+`load_state_dict` (README.md:88: the dynamic stage starts from a static-stage ckpt and saves its own):
+    timenet.{0,2}.*                                       (constructed, optimised, never used: :489-493)
+    deformation_net.grid.aabb, deformation_net.grid.grids.<scale>.<plane>
+    deformation_net.feature_out.0.*
+    deformation_net.{pos,scales,rotations,opacity}_deform.feature_out.{0.main_stream,1}.*
+Parity is pinned by tests/golden/deformation_small.npz (outputs + parameter gradients computed by the
+reference file itself; generator: tests/golden/make_golden.py).
+
+35,755,892 parameters at the shipped configuration (resolution [64,64,64,25], multires [1,2,4,8]):
+143 MB of float32 gradients per iteration -- the payload of the data-parallel all-reduce.
+"""
+import itertools
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+PLANE_AXES = list(itertools.combinations(range(4), 2))   # (x,y) (x,z) (x,t) (y,z) (y,t) (z,t)
+
+
+class HexPlaneField(nn.Module):
+    def __init__(self, bounds=1.0, resolution=(64, 64, 64, 25), multires=(1, 2, 4, 8), channels=32):
+        super().__init__()
+        # note the order: [[+b],[−b]] -- normalisation maps x to −x/b (deformation.py:186-188)
+        self.aabb = nn.Parameter(torch.tensor([[bounds] * 3, [-bounds] * 3], dtype=torch.float32), requires_grad=False)
+        self.grids = nn.ModuleList()
+        for mult in multires:
+            reso = [int(r) * int(mult) for r in resolution[:3]] + [int(resolution[3])]
+            planes = nn.ParameterList()
+            for a0, a1 in PLANE_AXES:
+                p = nn.Parameter(torch.empty(1, channels, reso[a1], reso[a0]))
+                if 3 in (a0, a1):
+                    nn.init.ones_(p)                      # time planes start at 1 (:132-133)
+                else:
+                    nn.init.uniform_(p, a=0.1, b=0.5)
+                planes.append(p)
+            self.grids.append(planes)
+        self.feat_dim = channels * len(multires)
+
+    def forward(self, pts, t):
+        """pts [P,3], t [P,1] in [-1,1] -> features [P, channels * n_scales]."""
+        lo, hi = self.aabb[0], self.aabb[1]
+        x = (pts - lo) * (2.0 / (hi - lo)) - 1.0
+        x4 = torch.cat([x, t], dim=-1)                    # [P,4]
+        feats = []
+        for planes in self.grids:
+            acc = None
+            for plane, (a0, a1) in zip(planes, PLANE_AXES):
+                uv = x4[:, [a0, a1]].view(1, 1, -1, 2)    # grid_sample: (x=width=a0, y=height=a1)
+                s = F.grid_sample(plane, uv, mode="bilinear", padding_mode="border", align_corners=True)
+                s = s.view(plane.shape[1], -1).t()        # [P, channels]
+                acc = s if acc is None else acc * s
+            feats.append(acc)
+        return torch.cat(feats, dim=-1)
+
+
+class _LinearRes(nn.Module):
+    def __init__(self, width):
+        super().__init__()
+        self.main_stream = nn.Linear(width, width)
+
+    def forward(self, x):
+        x = F.relu(x)
+        return x + self.main_stream(x)
+
+
+class _Head(nn.Module):
+    """relu -> residual linear -> linear, zero-initialised (deformation.py:285-305,507-512)."""
+
+    def __init__(self, width, out_dim):
+        super().__init__()
+        self.feature_out = nn.Sequential(_LinearRes(width), nn.Linear(width, out_dim))
+
+    def zero_(self):
+        for m in self.feature_out.modules():
+            if isinstance(m, nn.Linear):
+                nn.init.zeros_(m.weight)
+                nn.init.zeros_(m.bias)
+
+    def forward(self, h):
+        return self.feature_out(h)
+
+
+class _Deformation(nn.Module):
+    def __init__(self, width, grid, no_ds, no_dr, no_do):
+        super().__init__()
+        self.grid = grid
+        self.feature_out = nn.Sequential(nn.Linear(grid.feat_dim, width))   # defor_depth == 1
+        self.pos_deform = _Head(width, 3)
+        self.scales_deform = _Head(width, 6)
+        self.rotations_deform = _Head(width, 4)
+        self.opacity_deform = _Head(width, 1)
+        self.no_ds, self.no_dr, self.no_do = no_ds, no_dr, no_do
+
+    def forward_dynamic_delta(self, pts, t):
+        h = self.feature_out(self.grid(pts[:, :3], t[:, :1])).float()
+        dx = self.pos_deform(h)
+        ds = None if self.no_ds else self.scales_deform(h)
+        dr = None if self.no_dr else self.rotations_deform(h)
+        do = None if self.no_do else self.opacity_deform(h)
+        return dx, dr, ds, do
+
+
+class DeformationNetwork(nn.Module):
+    def __init__(self, net_width=64, bounds=1.0, resolution=(64, 64, 64, 25), multires=(1, 2, 4, 8),
+                 no_ds=False, no_dr=False, no_do=True, timebase_pe=4, posebase_pe=10, scale_rotation_pe=2,
+                 opacity_pe=2, timenet_width=64, timenet_output=32):
+        super().__init__()
+        self.timenet = nn.Sequential(nn.Linear(2 * timebase_pe + 1, timenet_width), nn.ReLU(),
+                                     nn.Linear(timenet_width, timenet_output))
+        self.deformation_net = _Deformation(net_width, HexPlaneField(bounds, resolution, multires), no_ds, no_dr, no_do)
+        for name, n in (("time_poc", timebase_pe), ("pos_poc", posebase_pe), ("rotation_scaling_poc", scale_rotation_pe),
+                        ("opacity_poc", opacity_pe)):
+            self.register_buffer(name, torch.tensor([2.0 ** i for i in range(n)]))
+        for m in self.modules():
+            if isinstance(m, nn.Linear):
+                nn.init.xavier_uniform_(m.weight, gain=1)       # biases keep PyTorch's default (:557-565)
+        for head in (self.deformation_net.pos_deform, self.deformation_net.scales_deform,
+                     self.deformation_net.rotations_deform, self.deformation_net.opacity_deform):
+            head.zero_()
+
+    def forward_dynamic_delta(self, point, times_sel):
+        """(pts [P,3], t [P,1] = 2*timestamp-1) -> (dx [P,3], dr [P,4] | None, ds [P,6] | None, do [P,1] | None)."""
+        return self.deformation_net.forward_dynamic_delta(point, times_sel)
+
+    def node_outputs(self, nodes, timestamps):
+        """All B timestamps in one batched query: nodes [M,3], timestamps [B] in (0,1) ->
+        dx [B,M,3], dr [B,M,4], ds [B,M,6] | None, do [B,M] | None  (dynamic_sugar.py:420-431, ts*2-1)."""
+        B, M = int(timestamps.shape[0]), int(nodes.shape[0])
+        pts = nodes.unsqueeze(0).expand(B, M, 3).reshape(-1, 3)
+        t = (timestamps.view(B, 1, 1).expand(B, M, 1).reshape(-1, 1)) * 2.0 - 1.0
+        dx, dr, ds, do = self.forward_dynamic_delta(pts, t)
+        r = lambda x, k: None if x is None else x.view(B, M, k)
+        do = None if do is None else do.view(B, M)
+        return r(dx, 3), r(dr, 4), r(ds, 6), do
+
+    def get_mlp_parameters(self):
+        return [p for n, p in self.named_parameters() if "grid" not in n]
+
+    def get_grid_parameters(self):
+        return list(self.deformation_net.grid.parameters())

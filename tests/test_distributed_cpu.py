@@ -1,0 +1,61 @@
+"""world_size-2 gloo tests (CPU) of the N > 1 path: frame sharding and the single gradient all-reduce."""
+import os
+import socket
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from dreammesh4d_amd import distributed as D
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Linear(4, 3), torch.nn.Linear(3, 2))
+    unused = torch.nn.Parameter(torch.ones(5))            # trainable but never used (like the reference's timenet)
+    params = list(net.parameters()) + [unused]
+    red = D.GradAllReducer(params)
+    x = torch.full((2, 4), float(rank + 1))
+    net(x).sum().backward()
+    local = [None if p.grad is None else p.grad.clone() for p in params]
+    red()
+    out[rank] = {"grads": [p.grad.clone() for p in params], "local": local, "nbytes": red.nbytes,
+                 "frames": D.shard_frames(32, rank, world, 4, iteration=1)}
+    dist.destroy_process_group()
+
+
+def test_grad_allreduce_and_frame_sharding_world2():
+    world = 2
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    a, b = out[0], out[1]
+    for ga, gb, la, lb in zip(a["grads"], b["grads"], a["local"], b["local"]):
+        assert torch.equal(ga, gb)                                        # identical after the exchange
+        la = torch.zeros_like(ga) if la is None else la
+        lb = torch.zeros_like(ga) if lb is None else lb
+        assert torch.allclose(ga, 0.5 * (la + lb))                        # mean over ranks; missing grads count as zeros
+    assert not a["grads"][-1].any()                                       # the unused parameter got a zero gradient
+    assert a["nbytes"] == sum(g.numel() for g in a["grads"]) * 4
+    assert set(a["frames"]).isdisjoint(b["frames"]) and len(a["frames"]) == 4
+
+
+def test_shard_frames_covers_the_timeline():
+    seen = set()
+    for r in range(8):
+        f = D.shard_frames(32, r, 8, 4, iteration=0)
+        assert len(f) == 4 and seen.isdisjoint(f)
+        seen.update(f)
+    assert seen == set(range(32))
+    assert D.shard_frames(32, 0, 1, 4, iteration=3) == [12, 13, 14, 15]
+    assert D.world() == 1 and D.rank() == 0
