@@ -179,6 +179,15 @@ def main():
         # whole-view algorithmic bytes: B_view = 2 (B_f + B_b) + B_skin
         V = len(wl.sc["verts"])
         b_view = 2 * ((104 * N + 84 * D_mean + 28 * H * W) + (228 * N + 48 * D_mean + 40 * H * W)) + 40 * V + 28 * N + 12288 * N_NODES
+        # HBM traffic of the dominant kernel per launch from the committed PMC passes of this same workload
+        # (profiles/r01_pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs, FETCH_SIZE x2
+        # per MI355X_MICROARCH.md's gfx950 correction).  The workload is seeded, so it is launch-invariant.
+        traffic = None
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
+            traffic = round(pmc["dm4d::k_render_bwd<6>"]["bytes_corrected"])
+        except Exception:
+            pass
         out = {
             "metric": "rendered views/sec (fwd+bwd, 512^2, 200k Gaussians)",
             "value": round(value, 3), "unit": "views/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -194,7 +203,7 @@ def main():
                        "parallelism": f"dp{world} (frames sharded, 1 grad all-reduce/step)" if world > 1 else "single GPU"},
             "roofline": {"bound": "hbm", "kernel": "k_render_bwd<6> (batched over the step's views)",
                          "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                          "alg_bytes_per_launch": round(alg_bytes), "avg_launch_us": round(avg_s * 1e6, 2),
                          "launches_timed": int(n_launch)},
         }
