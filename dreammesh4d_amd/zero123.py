@@ -1,0 +1,437 @@
+"""Zero123 SDS gradient step of the dynamic stage.
+
+Host-side mirror of
+  custom/threestudio-dreammesh4d/guidance/temporal_stable_zero123_guidance.py:228-236 (encode_images),
+  :250-297 (get_cond), :299-374 (__call__: the SDS step), :376-386 (update_step)
+  threestudio/models/guidance/stable_zero123_guidance.py:277-... (static twin, no frame_indices)
+and of the pieces of the vendored LDM they call:
+  extern/ldm_zero123/modules/diffusionmodules/openaimodel.py:429-842 (UNetModel, in 8 / out 4 channels,
+      model_channels 320, mult (1,2,4,4), attention at ds 1,2,4, 8 heads, context 768),
+  extern/ldm_zero123/modules/attention.py:150-190 (CrossAttention), :193-... (BasicTransformerBlock, SpatialTransformer),
+  extern/ldm_zero123/modules/diffusionmodules/model.py (AutoencoderKL Encoder, ch 128, mult (1,2,4,4)),
+  extern/ldm_zero123/models/diffusion/ddpm.py:653 (cc_projection), :1953-1956 (hybrid conditioning).
+
+This is where MFMA belongs on this path: dense conv / GEMM through PyTorch-ROCm (MIOpen / hipBLASLt), fp16
+weights, attention through F.scaled_dot_product_attention instead of einsum + softmax.  No hand kernel.
+
+Module and parameter names follow the LDM checkpoint layout (`model.diffusion_model.*`,
+`first_stage_model.encoder.*`, `first_stage_model.quant_conv.*`, `cc_projection.*`) so
+`stable_zero123.ckpt` loads with `load_zero123_state_dict` (weights are not in the reference tree,
+load/zero123/download.sh).  Architecture parity is pinned by tests/golden/zero123_small.npz: a
+reduced-width UNet and encoder of the REFERENCE code, filled by a name-seeded recipe both sides share.
+"""
+import math
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+
+# ----------------------------------------------------------------------------- building blocks
+class GroupNorm32(nn.GroupNorm):
+    """GroupNorm evaluated in fp32 (extern/ldm_zero123/modules/diffusionmodules/util.py:242-244)."""
+
+    def forward(self, x):
+        return super().forward(x.float()).type(x.dtype)
+
+
+def timestep_embedding(t, dim, max_period=10000):
+    half = dim // 2
+    freqs = torch.exp(-math.log(max_period) * torch.arange(half, dtype=torch.float32, device=t.device) / half)
+    args = t[:, None].float() * freqs[None]
+    emb = torch.cat([torch.cos(args), torch.sin(args)], dim=-1)
+    if dim % 2:
+        emb = torch.cat([emb, torch.zeros_like(emb[:, :1])], dim=-1)
+    return emb
+
+
+class Upsample(nn.Module):
+    def __init__(self, ch):
+        super().__init__()
+        self.conv = nn.Conv2d(ch, ch, 3, padding=1)
+
+    def forward(self, x):
+        return self.conv(F.interpolate(x, scale_factor=2, mode="nearest"))
+
+
+class Downsample(nn.Module):
+    def __init__(self, ch):
+        super().__init__()
+        self.op = nn.Conv2d(ch, ch, 3, stride=2, padding=1)
+
+    def forward(self, x):
+        return self.op(x)
+
+
+class ResBlock(nn.Module):
+    def __init__(self, ch, emb_ch, out_ch):
+        super().__init__()
+        self.in_layers = nn.Sequential(GroupNorm32(32, ch), nn.SiLU(), nn.Conv2d(ch, out_ch, 3, padding=1))
+        self.emb_layers = nn.Sequential(nn.SiLU(), nn.Linear(emb_ch, out_ch))
+        self.out_layers = nn.Sequential(GroupNorm32(32, out_ch), nn.SiLU(), nn.Dropout(0.0),
+                                        nn.Conv2d(out_ch, out_ch, 3, padding=1))
+        nn.init.zeros_(self.out_layers[3].weight)
+        nn.init.zeros_(self.out_layers[3].bias)
+        self.skip_connection = nn.Identity() if ch == out_ch else nn.Conv2d(ch, out_ch, 1)
+
+    def forward(self, x, emb):
+        h = self.in_layers(x)
+        h = h + self.emb_layers(emb).type(h.dtype)[:, :, None, None]
+        return self.skip_connection(x) + self.out_layers(h)
+
+
+class CrossAttention(nn.Module):
+    def __init__(self, query_dim, context_dim, heads, dim_head):
+        super().__init__()
+        inner = heads * dim_head
+        context_dim = query_dim if context_dim is None else context_dim
+        self.heads = heads
+        self.to_q = nn.Linear(query_dim, inner, bias=False)
+        self.to_k = nn.Linear(context_dim, inner, bias=False)
+        self.to_v = nn.Linear(context_dim, inner, bias=False)
+        self.to_out = nn.Sequential(nn.Linear(inner, query_dim), nn.Dropout(0.0))
+
+    def forward(self, x, context=None):
+        ctx = x if context is None else context
+        B, L, _ = x.shape
+        h = self.heads
+        q = self.to_q(x).view(B, L, h, -1).transpose(1, 2)
+        k = self.to_k(ctx).view(B, ctx.shape[1], h, -1).transpose(1, 2)
+        v = self.to_v(ctx).view(B, ctx.shape[1], h, -1).transpose(1, 2)
+        o = F.scaled_dot_product_attention(q, k, v)           # softmax(q k^T / sqrt(d)) v
+        return self.to_out(o.transpose(1, 2).reshape(B, L, -1))
+
+
+class GEGLU(nn.Module):
+    def __init__(self, dim_in, dim_out):
+        super().__init__()
+        self.proj = nn.Linear(dim_in, dim_out * 2)
+
+    def forward(self, x):
+        x, gate = self.proj(x).chunk(2, dim=-1)
+        return x * F.gelu(gate)
+
+
+class FeedForward(nn.Module):
+    def __init__(self, dim, mult=4):
+        super().__init__()
+        self.net = nn.Sequential(GEGLU(dim, dim * mult), nn.Dropout(0.0), nn.Linear(dim * mult, dim))
+
+    def forward(self, x):
+        return self.net(x)
+
+
+class BasicTransformerBlock(nn.Module):
+    def __init__(self, dim, heads, dim_head, context_dim):
+        super().__init__()
+        self.attn1 = CrossAttention(dim, None, heads, dim_head)
+        self.ff = FeedForward(dim)
+        self.attn2 = CrossAttention(dim, context_dim, heads, dim_head)
+        self.norm1, self.norm2, self.norm3 = nn.LayerNorm(dim), nn.LayerNorm(dim), nn.LayerNorm(dim)
+
+    def forward(self, x, context):
+        x = self.attn1(self.norm1(x)) + x
+        x = self.attn2(self.norm2(x), context) + x
+        return self.ff(self.norm3(x)) + x
+
+
+class SpatialTransformer(nn.Module):
+    def __init__(self, ch, heads, dim_head, context_dim, depth=1):
+        super().__init__()
+        inner = heads * dim_head
+        self.norm = nn.GroupNorm(32, ch, eps=1e-6, affine=True)
+        self.proj_in = nn.Conv2d(ch, inner, 1)
+        self.transformer_blocks = nn.ModuleList([BasicTransformerBlock(inner, heads, dim_head, context_dim)
+                                                 for _ in range(depth)])
+        self.proj_out = nn.Conv2d(inner, ch, 1)
+        nn.init.zeros_(self.proj_out.weight)
+        nn.init.zeros_(self.proj_out.bias)
+
+    def forward(self, x, context):
+        B, Cc, Hh, Ww = x.shape
+        h = self.proj_in(self.norm(x))
+        h = h.flatten(2).transpose(1, 2)                      # b (h w) c
+        for blk in self.transformer_blocks:
+            h = blk(h, context)
+        h = h.transpose(1, 2).reshape(B, -1, Hh, Ww)
+        return self.proj_out(h) + x
+
+
+class _Seq(nn.Sequential):
+    """TimestepEmbedSequential: routes emb to ResBlocks and context to SpatialTransformers."""
+
+    def forward(self, x, emb, context):
+        for layer in self:
+            if isinstance(layer, ResBlock):
+                x = layer(x, emb)
+            elif isinstance(layer, SpatialTransformer):
+                x = layer(x, context)
+            else:
+                x = layer(x)
+        return x
+
+
+class UNetModel(nn.Module):
+    def __init__(self, in_channels=8, out_channels=4, model_channels=320, attention_resolutions=(4, 2, 1),
+                 num_res_blocks=2, channel_mult=(1, 2, 4, 4), num_heads=8, context_dim=768, transformer_depth=1):
+        super().__init__()
+        self.model_channels = model_channels
+        emb = model_channels * 4
+        self.time_embed = nn.Sequential(nn.Linear(model_channels, emb), nn.SiLU(), nn.Linear(emb, emb))
+        att = lambda ch: SpatialTransformer(ch, num_heads, ch // num_heads, context_dim, transformer_depth)
+        self.input_blocks = nn.ModuleList([_Seq(nn.Conv2d(in_channels, model_channels, 3, padding=1))])
+        chans, ch, ds = [model_channels], model_channels, 1
+        for level, mult in enumerate(channel_mult):
+            for _ in range(num_res_blocks):
+                layers = [ResBlock(ch, emb, mult * model_channels)]
+                ch = mult * model_channels
+                if ds in attention_resolutions:
+                    layers.append(att(ch))
+                self.input_blocks.append(_Seq(*layers))
+                chans.append(ch)
+            if level != len(channel_mult) - 1:
+                self.input_blocks.append(_Seq(Downsample(ch)))
+                chans.append(ch)
+                ds *= 2
+        self.middle_block = _Seq(ResBlock(ch, emb, ch), att(ch), ResBlock(ch, emb, ch))
+        self.output_blocks = nn.ModuleList()
+        for level, mult in list(enumerate(channel_mult))[::-1]:
+            for i in range(num_res_blocks + 1):
+                layers = [ResBlock(ch + chans.pop(), emb, model_channels * mult)]
+                ch = model_channels * mult
+                if ds in attention_resolutions:
+                    layers.append(att(ch))
+                if level and i == num_res_blocks:
+                    layers.append(Upsample(ch))
+                    ds //= 2
+                self.output_blocks.append(_Seq(*layers))
+        self.out = nn.Sequential(GroupNorm32(32, ch), nn.SiLU(), nn.Conv2d(model_channels, out_channels, 3, padding=1))
+        nn.init.zeros_(self.out[2].weight)
+        nn.init.zeros_(self.out[2].bias)
+
+    def forward(self, x, timesteps, context):
+        emb = self.time_embed(timestep_embedding(timesteps, self.model_channels).type(x.dtype))
+        hs, h = [], x
+        for m in self.input_blocks:
+            h = m(h, emb, context)
+            hs.append(h)
+        h = self.middle_block(h, emb, context)
+        for m in self.output_blocks:
+            h = m(torch.cat([h, hs.pop()], dim=1), emb, context)
+        return self.out(h.type(x.dtype))
+
+
+# ----------------------------------------------------------------------------- VAE encoder
+class _VaeRes(nn.Module):
+    def __init__(self, cin, cout):
+        super().__init__()
+        self.norm1 = nn.GroupNorm(32, cin, eps=1e-6)
+        self.conv1 = nn.Conv2d(cin, cout, 3, padding=1)
+        self.norm2 = nn.GroupNorm(32, cout, eps=1e-6)
+        self.dropout = nn.Dropout(0.0)
+        self.conv2 = nn.Conv2d(cout, cout, 3, padding=1)
+        if cin != cout:
+            self.nin_shortcut = nn.Conv2d(cin, cout, 1)
+
+    def forward(self, x):
+        h = self.conv1(F.silu(self.norm1(x)))
+        h = self.conv2(self.dropout(F.silu(self.norm2(h))))
+        return (self.nin_shortcut(x) if hasattr(self, "nin_shortcut") else x) + h
+
+
+class _VaeAttn(nn.Module):
+    def __init__(self, ch):
+        super().__init__()
+        self.norm = nn.GroupNorm(32, ch, eps=1e-6)
+        self.q, self.k, self.v, self.proj_out = (nn.Conv2d(ch, ch, 1) for _ in range(4))
+
+    def forward(self, x):
+        B, Cc, Hh, Ww = x.shape
+        h = self.norm(x)
+        q, k, v = (f(h).flatten(2).transpose(1, 2)[:, None] for f in (self.q, self.k, self.v))   # b 1 (hw) c
+        o = F.scaled_dot_product_attention(q, k, v)[:, 0].transpose(1, 2).reshape(B, Cc, Hh, Ww)
+        return x + self.proj_out(o)
+
+
+class _VaeDown(nn.Module):
+    def __init__(self, ch):
+        super().__init__()
+        self.conv = nn.Conv2d(ch, ch, 3, stride=2, padding=0)
+
+    def forward(self, x):
+        return self.conv(F.pad(x, (0, 1, 0, 1)))
+
+
+class _Level(nn.Module):
+    pass
+
+
+class VaeEncoder(nn.Module):
+    def __init__(self, ch=128, ch_mult=(1, 2, 4, 4), num_res_blocks=2, in_channels=3, z_channels=4):
+        super().__init__()
+        self.conv_in = nn.Conv2d(in_channels, ch, 3, padding=1)
+        self.down = nn.ModuleList()
+        cin = ch
+        for i, m in enumerate(ch_mult):
+            lvl = _Level()
+            lvl.block = nn.ModuleList()
+            lvl.attn = nn.ModuleList()
+            for _ in range(num_res_blocks):
+                lvl.block.append(_VaeRes(cin, ch * m))
+                cin = ch * m
+            if i != len(ch_mult) - 1:
+                lvl.downsample = _VaeDown(cin)
+            self.down.append(lvl)
+        self.mid = _Level()
+        self.mid.block_1 = _VaeRes(cin, cin)
+        self.mid.attn_1 = _VaeAttn(cin)
+        self.mid.block_2 = _VaeRes(cin, cin)
+        self.norm_out = nn.GroupNorm(32, cin, eps=1e-6)
+        self.conv_out = nn.Conv2d(cin, 2 * z_channels, 3, padding=1)
+
+    def forward(self, x):
+        h = self.conv_in(x)
+        for lvl in self.down:
+            for b in lvl.block:
+                h = b(h)
+            if hasattr(lvl, "downsample"):
+                h = lvl.downsample(h)
+        h = self.mid.block_2(self.mid.attn_1(self.mid.block_1(h)))
+        return self.conv_out(F.silu(self.norm_out(h)))
+
+
+class FirstStage(nn.Module):
+    """`first_stage_model` restricted to what the SDS step needs: encoder + quant_conv."""
+
+    def __init__(self, **kw):
+        super().__init__()
+        self.encoder = VaeEncoder(**kw)
+        z = kw.get("z_channels", 4)
+        self.quant_conv = nn.Conv2d(2 * z, 2 * z, 1)
+
+    def encode_moments(self, x):
+        return self.quant_conv(self.encoder(x))
+
+
+class _DiffusionWrapper(nn.Module):
+    def __init__(self, unet):
+        super().__init__()
+        self.diffusion_model = unet
+
+
+class Zero123(nn.Module):
+    """LatentDiffusion (hybrid conditioning) reduced to the inference surface the guidance uses."""
+
+    def __init__(self, unet_kwargs=None, vae_kwargs=None, scale_factor=0.18215, timesteps=1000, linear_start=0.00085,
+                 linear_end=0.0120):
+        super().__init__()
+        uk = dict(unet_kwargs or {})
+        self.model = _DiffusionWrapper(UNetModel(**uk))
+        self.first_stage_model = FirstStage(**dict(vae_kwargs or {}))
+        ctx = uk.get("context_dim", 768)
+        self.cc_projection = nn.Linear(ctx + 4, ctx)
+        nn.init.eye_(self.cc_projection.weight[:ctx, :ctx])
+        nn.init.zeros_(self.cc_projection.bias)
+        self.scale_factor = scale_factor
+        betas = torch.linspace(linear_start ** 0.5, linear_end ** 0.5, timesteps, dtype=torch.float64) ** 2
+        self.register_buffer("alphas_cumprod", torch.cumprod(1.0 - betas, dim=0).float(), persistent=False)
+
+    def apply_model(self, x_noisy, t, cond):
+        """hybrid conditioning (ddpm.py:1953-1956): concat c_concat on channels, cross-attend to c_crossattn."""
+        xc = torch.cat([x_noisy] + cond["c_concat"], dim=1)
+        cc = torch.cat(cond["c_crossattn"], dim=1)
+        return self.model.diffusion_model(xc, t, context=cc)
+
+    def encode_first_stage_sample(self, x, noise=None):
+        mean, logvar = self.first_stage_model.encode_moments(x).chunk(2, dim=1)
+        logvar = logvar.clamp(-30.0, 20.0)
+        if noise is None:
+            noise = torch.randn(mean.shape).to(mean)      # the reference samples this on the CPU (distributions.py:37-41)
+        return self.scale_factor * (mean + torch.exp(0.5 * logvar) * noise)
+
+
+def load_zero123_state_dict(model: Zero123, sd):
+    """Load an LDM Zero123 checkpoint state dict (keys `model.diffusion_model.*`, `first_stage_model.*`,
+    `cc_projection.*`), ignoring what the SDS step never uses (decoder, CLIP, EMA, schedule buffers)."""
+    own = model.state_dict()
+    take = {k: v for k, v in sd.items() if k in own and tuple(v.shape) == tuple(own[k].shape)}
+    missing = [k for k in own if k not in take]
+    model.load_state_dict(take, strict=False)
+    return missing
+
+
+# ----------------------------------------------------------------------------- guidance
+class TemporalStableZero123Guidance(nn.Module):
+    """`temporal-stable-zero123-guidance`.  `__call__(rgb[B,H,W,3], elevation, azimuth, camera_distances,
+    frame_indices, rgb_as_latents=False) -> {"loss_sds", "grad_norm", "min_step", "max_step"}`."""
+
+    def __init__(self, model: Zero123, c_crossattn, c_concat, cond_elevation_deg=0.0, cond_azimuth_deg=0.0,
+                 guidance_scale=3.0, min_step_percent=0.02, max_step_percent=0.98, grad_clip=None,
+                 half_precision_weights=True):
+        super().__init__()
+        self.weights_dtype = torch.float16 if half_precision_weights else torch.float32
+        self.model = model.to(self.weights_dtype)
+        for p in self.model.parameters():
+            p.requires_grad_(False)
+        self.register_buffer("c_crossattn", c_crossattn.to(self.weights_dtype), persistent=False)   # [L,1,ctx] CLIP embeddings
+        self.register_buffer("c_concat", c_concat.to(self.weights_dtype), persistent=False)         # [L,4,32,32] VAE modes
+        self.cond_elevation_deg, self.cond_azimuth_deg = cond_elevation_deg, cond_azimuth_deg
+        self.guidance_scale = guidance_scale
+        self.num_train_timesteps = int(model.alphas_cumprod.shape[0])
+        self.grad_clip_val = grad_clip
+        self.set_min_max_steps(min_step_percent, max_step_percent)
+
+    def set_min_max_steps(self, min_step_percent=0.02, max_step_percent=0.98):
+        self.min_step = int(self.num_train_timesteps * min_step_percent)
+        self.max_step = int(self.num_train_timesteps * max_step_percent)
+
+    def encode_images(self, imgs):
+        return self.model.encode_first_stage_sample((imgs * 2.0 - 1.0).to(self.weights_dtype)).to(imgs.dtype)
+
+    @torch.no_grad()
+    def get_cond(self, elevation, azimuth, camera_distances, frame_indices=None):
+        dev = self.c_crossattn.device
+        T = torch.stack([torch.deg2rad((90 - elevation) - (90 - self.cond_elevation_deg)),
+                         torch.sin(torch.deg2rad(azimuth - self.cond_azimuth_deg)),
+                         torch.cos(torch.deg2rad(azimuth - self.cond_azimuth_deg)),
+                         torch.deg2rad(90 - torch.full_like(elevation, self.cond_elevation_deg))], dim=-1)[:, None, :]
+        T = T.to(dev, self.weights_dtype)
+        idx = frame_indices if frame_indices is not None else torch.zeros(len(T), dtype=torch.long, device=dev)
+        clip_emb = self.model.cc_projection(torch.cat([self.c_crossattn[idx], T], dim=-1))
+        return {"c_crossattn": [torch.cat([torch.zeros_like(clip_emb), clip_emb], dim=0)],
+                "c_concat": [torch.cat([torch.zeros_like(self.c_concat[idx]), self.c_concat[idx]], dim=0)]}
+
+    def forward(self, rgb, elevation, azimuth, camera_distances, frame_indices=None, rgb_as_latents=False,
+                noise=None, t=None, **kwargs):
+        B = rgb.shape[0]
+        x = rgb.permute(0, 3, 1, 2)
+        if rgb_as_latents:
+            latents = F.interpolate(x, (32, 32), mode="bilinear", align_corners=False) * 2 - 1
+        else:
+            latents = self.encode_images(F.interpolate(x, (256, 256), mode="bilinear", align_corners=False))
+        cond = self.get_cond(elevation, azimuth, camera_distances, frame_indices)
+        if t is None:
+            t = torch.randint(self.min_step, self.max_step + 1, [B], dtype=torch.long, device=latents.device)
+        with torch.no_grad():
+            if noise is None:
+                noise = torch.randn_like(latents)
+            ac = self.model.alphas_cumprod.to(latents.device)[t].view(-1, 1, 1, 1)
+            noisy = ac.sqrt() * latents + (1 - ac).sqrt() * noise                      # DDIMScheduler.add_noise
+            pred = self.model.apply_model(torch.cat([noisy] * 2).to(self.weights_dtype), torch.cat([t] * 2), cond)
+        unc, cnd = pred.float().chunk(2)
+        pred = unc + self.guidance_scale * (cnd - unc)
+        grad = torch.nan_to_num((1 - ac) * (pred - noise))
+        if self.grad_clip_val is not None:
+            grad = grad.clamp(-self.grad_clip_val, self.grad_clip_val)
+        target = (latents - grad).detach()
+        loss = 0.5 * F.mse_loss(latents, target, reduction="sum") / B        # d loss / d latents == grad
+        return {"loss_sds": loss, "grad_norm": grad.norm(), "min_step": self.min_step, "max_step": self.max_step}
+
+    def update_step(self, epoch, global_step, min_step_percent=None, max_step_percent=None, grad_clip=None):
+        if grad_clip is not None:
+            self.grad_clip_val = grad_clip
+        if min_step_percent is not None and max_step_percent is not None:
+            self.set_min_max_steps(min_step_percent, max_step_percent)
+
+
+StableZero123Guidance = TemporalStableZero123Guidance   # static twin: same step with frame_indices=None

@@ -13,6 +13,10 @@ state, and the outputs / gradients the reference computes for them).
   strain_matrix.npz       strain_tensor_to_matrix (dynamic_sugar.py:29-39), extracted by AST (the
                           enclosing module needs pypose/pytorch3d) and executed.
   schedule_C.npz          C() (threestudio/utils/misc.py:66-101), extracted by AST.
+  zero123_small.npz       extern/ldm_zero123 UNetModel (openaimodel.py:429-842) and AutoencoderKL Encoder
+                          (modules/diffusionmodules/model.py) at reduced width, imported with no-op stubs for the
+                          unused heavy imports; weights come from a name-seeded recipe (seeded_fill) the test
+                          repeats, so only inputs / outputs / key lists are stored.
 """
 import ast
 import importlib.util
@@ -103,9 +107,60 @@ def schedule():
     print("schedule_C.npz written")
 
 
+def seeded_fill(module, base=1000, scale=0.05):
+    """Name-ordered deterministic weights shared by the generator and the test: tensor i (sorted by
+    state-dict key) = randn(seed = base + i) * scale, +1 for normalisation gains."""
+    sd = module.state_dict()
+    with torch.no_grad():
+        for i, k in enumerate(sorted(sd.keys())):
+            t = sd[k]
+            if not t.dtype.is_floating_point:
+                continue
+            g = torch.Generator().manual_seed(base + i)
+            v = torch.randn(t.shape, generator=g) * scale
+            if ("norm" in k or k.endswith("in_layers.0.weight") or k.endswith("out_layers.0.weight") or k == "out.0.weight") and k.endswith("weight") and t.dim() == 1:
+                v = v + 1.0
+            t.copy_(v)
+    return sorted(sd.keys())
+
+
+def zero123_small():
+    import types
+    for name in ["cv2", "torchvision", "torchvision.transforms", "omegaconf", "omegaconf.listconfig", "pytorch_lightning",
+                 "kornia", "clip", "taming", "taming.modules", "taming.modules.vqvae", "taming.modules.vqvae.quantize"]:
+        if name not in sys.modules:
+            sys.modules[name] = types.ModuleType(name)
+    sys.modules["omegaconf.listconfig"].ListConfig = list
+    sys.modules["omegaconf"].ListConfig = list
+    sys.path.insert(0, REF)
+    from extern.ldm_zero123.modules.diffusionmodules.openaimodel import UNetModel
+    from extern.ldm_zero123.modules.diffusionmodules.model import Encoder
+    unet = UNetModel(image_size=32, in_channels=8, out_channels=4, model_channels=32, attention_resolutions=[4, 2, 1],
+                     num_res_blocks=2, channel_mult=[1, 2, 4, 4], num_heads=8, use_spatial_transformer=True,
+                     transformer_depth=1, context_dim=48, use_checkpoint=False, legacy=False).eval()
+    ukeys = seeded_fill(unet, base=1000)
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(2, 8, 16, 16, generator=g)
+    t = torch.tensor([7, 613])
+    ctx = torch.randn(2, 1, 48, generator=g)
+    with torch.no_grad():
+        y = unet(x, t, context=ctx)
+    enc = Encoder(ch=32, out_ch=3, ch_mult=(1, 2, 4, 4), num_res_blocks=2, attn_resolutions=[], dropout=0.0,
+                  in_channels=3, resolution=64, z_channels=4, double_z=True).eval()
+    ekeys = seeded_fill(enc, base=5000)
+    img = torch.randn(2, 3, 64, 64, generator=g)
+    with torch.no_grad():
+        m = enc(img)
+    np.savez_compressed(os.path.join(OUT, "zero123_small.npz"), x=x.numpy(), t=t.numpy(), ctx=ctx.numpy(), y=y.numpy(),
+                        img=img.numpy(), moments=m.numpy(), unet_keys=np.array(ukeys), enc_keys=np.array(ekeys),
+                        unet_params=np.int64(sum(p.numel() for p in unet.parameters())))
+    print("zero123_small.npz written; reduced UNet params:", sum(p.numel() for p in unet.parameters()), "| y std", float(y.std()))
+
+
 if __name__ == "__main__":
     if not os.path.isdir(REF):
         sys.exit("needs /root/reference (authoring container only)")
     deformation()
     strain()
     schedule()
+    zero123_small()
