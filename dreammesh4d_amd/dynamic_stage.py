@@ -1,0 +1,115 @@
+"""One dynamic-stage training iteration on the fast path.
+
+Host-side restatement of the loop body of `SuGaR4DGen.training_step`
+(custom/threestudio-dreammesh4d/system/sugar_4dgen.py:397-429: a zero123 substep + a reference substep
+per iteration), its batch (custom/threestudio-dreammesh4d/data/temporal_image.py:291-324: 4 of L frames,
+one reference view + `random_camera.batch_size` random views per frame), its loss weights
+(configs/sugar_dynamic_dg.yaml:135-158) and its optimiser (geometry/dynamic_sugar.py:167-235,
+geometry/sugar.py:406-416: AdamW, betas (0.9, 0.99), eps 1e-15, groups `deformation` 3.2e-4 / `grid` 3.2e-3).
+
+What runs per iteration on each GPU:
+  HexPlane+MLP at the step's 4 timestamps (1 fused launch) -> render_views for the 8 (frame, view) units
+  (skinning, face->Gaussian, fused RGB+normal raster) -> SDS loss on the random views (Zero123, fp16,
+  no grad through the UNet) + rgb / mask MSE on the reference views -> backward -> ONE gradient
+  all-reduce -> AdamW.
+The mesh regularisers (pytorch3d normal consistency, ARAP) of the reference step are "next" rows
+ and are not part of this loop yet.
+"""
+import math
+
+import torch
+import torch.nn.functional as F
+
+from . import distributed as D
+from . import synthetic as syn
+from .schedule import C
+from .views import render_views
+
+LAMBDA = {"sds_zero123": 0.1, "rgb": 5000.0, "mask": [200, 500.0, 5000.0, 1000]}   # sugar_dynamic_dg.yaml:135-158
+
+
+class DynamicStage:
+    def __init__(self, renderer, net, nodes, static, timestamps, ref_images, ref_masks, ref_camera, guidance=None,
+                 frames_per_step=4, random_views_per_frame=1, deformation_lr=0.00032, grid_lr=0.0032, seed=0):
+        self.r, self.net, self.nodes, self.static = renderer, net, nodes, static
+        self.timestamps = timestamps                     # [L] in (0,1)
+        self.ref_images, self.ref_masks = ref_images, ref_masks          # [L,H,W,3], [L,H,W,1]
+        self.ref_camera = ref_camera
+        self.guidance = guidance
+        self.frames_per_step, self.rv = frames_per_step, random_views_per_frame
+        self.dev = nodes.device
+        self.gen = torch.Generator(device="cpu").manual_seed(seed + 977 * D.rank())   # per-rank seed (launch.py:166)
+        self.opt = torch.optim.AdamW([
+            {"params": net.get_mlp_parameters(), "lr": deformation_lr, "name": "deformation"},
+            {"params": net.get_grid_parameters(), "lr": grid_lr, "name": "grid"}],
+            lr=0.0, betas=(0.9, 0.99), eps=1e-15)
+        self.sched = {"deformation": deformation_lr, "grid": grid_lr}
+        self.reducer = D.GradAllReducer(net.parameters())
+        self.global_step = 0
+        self.bg6 = torch.ones(6, device=self.dev)      # training background is white (diff_sugar_rasterizer_temporal.py:96-101)
+
+    def sample_batch(self):
+        """4 frames of L without replacement (this rank's share) + cameras: the fixed reference camera and
+        random views (elev U[-10,80], azim U[-180,180], dist 3.8, fovy 20 deg; sugar_dynamic_dg.yaml:28-31)."""
+        L = int(self.timestamps.shape[0])
+        if D.world() > 1:
+            frames = D.shard_frames(L, D.rank(), D.world(), self.frames_per_step, self.global_step)
+        else:
+            frames = torch.randperm(L, generator=self.gen)[:self.frames_per_step].tolist()
+        cams, unit_frame, is_ref, elev, azim = [], [], [], [], []
+        H, W = self.r.H, self.r.W
+        for fi, _ in enumerate(frames):
+            cams.append(self.ref_camera)
+            unit_frame.append(fi)
+            is_ref.append(True)
+            elev.append(5.0)
+            azim.append(0.0)
+            for _ in range(self.rv):
+                e = -10.0 + 90.0 * float(torch.rand(1, generator=self.gen))
+                a = -180.0 + 360.0 * float(torch.rand(1, generator=self.gen))
+                cams.append(syn.make_camera(H, W, elev_deg=e, azim_deg=a))
+                unit_frame.append(fi)
+                is_ref.append(False)
+                elev.append(e)
+                azim.append(a)
+        T = lambda a: torch.tensor(a, device=self.dev)
+        return {"frames": frames, "vm": torch.stack([T(c.viewmatrix) for c in cams]),
+                "pm": torch.stack([T(c.projmatrix) for c in cams]), "unit_frame": T(unit_frame),
+                "is_ref": torch.tensor(is_ref, device=self.dev), "elev": T(elev), "azim": T(azim)}
+
+    def update_learning_rate(self, it):
+        for g in self.opt.param_groups:
+            g["lr"] = C(self.sched[g["name"]], 0, it, interpolation="exp")      # spatial_lr_scale = 1 (yaml:81)
+
+    def iteration(self):
+        st, it = self.static, self.global_step
+        self.update_learning_rate(it)
+        if self.guidance is not None:
+            self.guidance.update_step(0, it, min_step_percent=C(0.02, 0, it), max_step_percent=C(0.5, 0, it))
+        b = self.sample_batch()
+        frames_t = self.timestamps[torch.tensor(b["frames"], device=self.dev)]
+        self.opt.zero_grad(set_to_none=True)
+        dx, dr, ds, do = self.net.node_outputs(self.nodes, frames_t)
+        u = b["unit_frame"]
+        out = render_views(self.r, dx[u], dr[u], ds[u], do[u] if do is not None else None, st["q_static"], st["scales"],
+                           st["opacities"], st["rgb"], b["vm"], b["pm"], self.bg6)
+        rgb = out["color"][:, :3].clamp(0, 1).permute(0, 2, 3, 1)          # "render": clamp(0,1) (…temporal.py:229)
+        mask = out["alpha"].permute(0, 2, 3, 1)
+        ref, rnd = b["is_ref"], ~b["is_ref"]
+        fidx = torch.tensor(b["frames"], device=self.dev)[u]
+        loss = rgb.sum() * 0.0
+        terms = {}
+        if ref.any():
+            terms["rgb"] = F.mse_loss(rgb[ref] * self.ref_masks[fidx[ref]], self.ref_images[fidx[ref]] * self.ref_masks[fidx[ref]])
+            terms["mask"] = F.mse_loss(mask[ref], self.ref_masks[fidx[ref]])
+            loss = loss + LAMBDA["rgb"] * terms["rgb"] + C(LAMBDA["mask"], 0, it) * terms["mask"]
+        if self.guidance is not None and rnd.any():
+            g = self.guidance(rgb[rnd], b["elev"][rnd], b["azim"][rnd], torch.full_like(b["elev"][rnd], 3.8),
+                              frame_indices=fidx[rnd])
+            terms["sds"] = g["loss_sds"]
+            loss = loss + LAMBDA["sds_zero123"] * g["loss_sds"]
+        loss.backward()
+        self.reducer()                  # the one exchange step (no-op for a single process)
+        self.opt.step()
+        self.global_step += 1
+        return {"loss": loss.detach(), **{k: v.detach() for k, v in terms.items()}}

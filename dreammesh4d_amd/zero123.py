@@ -32,7 +32,9 @@ class GroupNorm32(nn.GroupNorm):
     """GroupNorm evaluated in fp32 (extern/ldm_zero123/modules/diffusionmodules/util.py:242-244)."""
 
     def forward(self, x):
-        return super().forward(x.float()).type(x.dtype)
+        w = None if self.weight is None else self.weight.float()
+        b = None if self.bias is None else self.bias.float()
+        return F.group_norm(x.float(), self.num_groups, w, b, self.eps).type(x.dtype)
 
 
 def timestep_embedding(t, dim, max_period=10000):
