@@ -43,7 +43,7 @@ class RasterInputs(C.Structure):
 class ViewsStruct(C.Structure):
     """dm4d_views (include/dm4d.h)."""
     _fields_ = [(n, C.c_int32) for n in ("B", "N", "F", "G", "V", "M", "K", "method", "image_height", "image_width")] + \
-               [(n, C.c_float) for n in ("tanfovx", "tanfovy", "scale_modifier")] + [("capacity", C.c_int64)] + \
+               [(n, C.c_float) for n in ("tanfovx", "tanfovy", "scale_modifier")] + [("capacity", C.c_int64), ("record_capacity", C.c_int64)] + \
                [(n, vp) for n in ("bg", "viewmatrix", "projmatrix", "verts", "nbr_idx", "nbr_w", "dx", "dr", "ds",
                                   "d_opacity", "faces", "q_static", "scales", "opacities", "rgb", "vxyz", "vrot",
                                   "means3D", "rotations", "colors", "radii", "out_color", "out_depth", "out_alpha",
@@ -72,14 +72,15 @@ _SIGNATURES = {
     "dm4d_raster_binning_bytes": (C.c_size_t, [C.c_int64]),
     "dm4d_raster_image_bytes": (C.c_size_t, [C.c_int32, C.c_int32]),
     "dm4d_raster_grad_bytes": (C.c_size_t, [C.c_int64, C.c_int32]),
-    "dm4d_selftest_wave_reduce": (C.c_int, [vp, vp, vp]),
     "dm4d_rasterize_prepare": (C.c_int, [C.POINTER(RasterSettings), C.POINTER(RasterInputs), vp, vp, C.c_size_t, vp]),
     "dm4d_rasterize_num_rendered": (C.c_int64, [vp, vp]),
+    "dm4d_rasterize_num_records": (C.c_int64, [vp, vp]),
+    "dm4d_rasterize_counts": (C.c_int, [vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64), vp]),
     "dm4d_rasterize_render": (C.c_int, [C.POINTER(RasterSettings), C.POINTER(RasterInputs), vp, vp, vp, C.c_int64,
                                         vp, vp, vp, vp, vp]),
     "dm4d_rasterize_overflowed": (C.c_int, [vp, vp]),
     "dm4d_rasterize_backward": (C.c_int, [C.POINTER(RasterSettings), C.POINTER(RasterInputs), vp, vp, vp, C.c_int64,
-                                          vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
+                                          vp, vp, C.c_int64, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
     "dm4d_rasterize_forward": (C.c_int64, [C.POINTER(RasterSettings), C.POINTER(RasterInputs), vp, vp, vp, vp,
                                            ALLOC_FN, vp, vp]),
     "dm4d_raster_read_sorted": (C.c_int, [vp, vp, C.c_int32, C.c_int32, C.c_int32, C.c_int64, c_u64, c_u32, c_u32, vp]),
@@ -105,7 +106,8 @@ _SIGNATURES = {
     "dm4d_views_face_scratch_bytes": (C.c_size_t, [C.c_int32] * 2),
     "dm4d_views_forward": (C.c_int, [C.POINTER(ViewsStruct), vp]),
     "dm4d_views_backward": (C.c_int, [C.POINTER(ViewsStruct), C.POINTER(ViewsGrads), vp]),
-    "dm4d_views_counters": (C.c_int, [C.POINTER(ViewsStruct), C.POINTER(C.c_int64), C.POINTER(C.c_int32), vp]),
+    "dm4d_views_counters": (C.c_int, [C.POINTER(ViewsStruct), C.POINTER(C.c_int64), C.POINTER(C.c_int64),
+                                      C.POINTER(C.c_int32), vp]),
 }
 
 

@@ -152,7 +152,7 @@ int dm4d_device_arch(int dev, char *buf, int buflen)
 size_t dm4d_raster_geom_bytes(int32_t N, int32_t H, int32_t W) { return geom_layout(N, H, W).total; }
 size_t dm4d_raster_binning_bytes(int64_t capacity) { return binning_bytes(capacity); }
 size_t dm4d_raster_image_bytes(int32_t H, int32_t W) { return image_bytes(H, W); }
-size_t dm4d_raster_grad_bytes(int64_t capacity, int32_t n_channels) { return grad_bytes(capacity, n_channels > 3 ? 6 : 3); }
+size_t dm4d_raster_grad_bytes(int64_t n_records, int32_t n_channels) { return grad_bytes(n_records, n_channels > 3 ? 6 : 3); }
 
 int dm4d_rasterize_prepare(const dm4d_raster_settings *s, const dm4d_raster_inputs *in, int32_t *radii, void *geom,
                            size_t geom_bytes_, dm4d_stream_t stream)
@@ -182,6 +182,25 @@ int64_t dm4d_rasterize_num_rendered(const void *geom, dm4d_stream_t stream)
     return (int64_t)D;
 }
 
+int dm4d_rasterize_counts(const void *geom, int64_t *num_rendered, int64_t *num_records, dm4d_stream_t stream)
+{
+    if (!geom) { set_error("null geom"); return DM4D_ERR_INVALID; }
+    uint32_t cnt[4] = {0, 0, 0, 0};   // counters live at offset 0 of the geom workspace
+    hipStream_t st = (hipStream_t)stream;
+    DM4D_HIP_CHECK(hipMemcpyAsync(cnt, geom, sizeof(cnt), hipMemcpyDeviceToHost, st));
+    DM4D_HIP_CHECK(hipStreamSynchronize(st));
+    if (num_rendered) *num_rendered = (int64_t)cnt[kCntD];
+    if (num_records) *num_records = (int64_t)cnt[kCntR];
+    return DM4D_OK;
+}
+
+int64_t dm4d_rasterize_num_records(const void *geom, dm4d_stream_t stream)
+{
+    int64_t R = 0;
+    const int rc = dm4d_rasterize_counts(geom, nullptr, &R, stream);
+    return rc ? (int64_t)rc : R;
+}
+
 int dm4d_rasterize_overflowed(const void *geom, dm4d_stream_t stream)
 {
     if (!geom) { set_error("null geom"); return DM4D_ERR_INVALID; }
@@ -206,6 +225,7 @@ int dm4d_rasterize_render(const dm4d_raster_settings *s, const dm4d_raster_input
     d.geom = (char *)geom;
     d.binning = (char *)binning;
     d.cap = (uint32_t)capacity;
+    d.rec_cap = 0xFFFFFFFFu;   // the caller sizes the backward scratch from dm4d_rasterize_num_records
     d.image = (char *)image;
     d.out_color = out_color;
     d.out_depth = out_depth;
@@ -219,7 +239,7 @@ int dm4d_rasterize_render(const dm4d_raster_settings *s, const dm4d_raster_input
 
 int dm4d_rasterize_backward(const dm4d_raster_settings *s, const dm4d_raster_inputs *in, const int32_t *radii,
                             const void *geom, const void *binning, int64_t capacity, const void *image, void *grad,
-                            const float *dL_dcolor, const float *dL_ddepth, const float *dL_dalpha,
+                            int64_t record_capacity, const float *dL_dcolor, const float *dL_ddepth, const float *dL_dalpha,
                             float *dL_dmeans2D, float *dL_dmeans3D, float *dL_dopacity, float *dL_dcolors,
                             float *dL_dsh, float *dL_dscales, float *dL_drotations, float *dL_dcov3D,
                             dm4d_stream_t stream)
@@ -239,6 +259,8 @@ int dm4d_rasterize_backward(const dm4d_raster_settings *s, const dm4d_raster_inp
     d.dL_ddepth = dL_ddepth;
     d.dL_dalpha = dL_dalpha;
     d.dLq = (float *)grad;
+    if (record_capacity < 0 || record_capacity > 0xFFFFFFF0ll) { set_error("record_capacity out of range"); return DM4D_ERR_INVALID; }
+    d.rec_cap = (uint32_t)record_capacity;
     d.o = BwdOutputs{dL_dmeans2D, dL_dmeans3D, dL_dopacity, dL_dcolors, dL_dsh, dL_dscales, dL_drotations, dL_dcov3D};
     rc = launch_render_bwd(d, st);
     if (rc) return rc;
@@ -315,13 +337,6 @@ int dm4d_raster_read_image_state(const void *image, int32_t H, int32_t W, uint32
     DM4D_HIP_CHECK(hipMemcpyAsync(n_contrib, im.n_contrib, P * 4, hipMemcpyDeviceToHost, st));
     DM4D_HIP_CHECK(hipStreamSynchronize(st));
     return DM4D_OK;
-}
-
-/* Self-test of the packed wave reduction: in [16][64] floats, out [16] sums (device pointers). */
-int dm4d_selftest_wave_reduce(const float *in, float *out, dm4d_stream_t stream)
-{
-    if (!in || !out) { set_error("null"); return DM4D_ERR_INVALID; }
-    return launch_selftest_reduce(in, out, (hipStream_t)stream);
 }
 
 int dm4d_mark_visible(int32_t N, const float *means3D, const float *viewmatrix, uint8_t *present, dm4d_stream_t stream)

@@ -177,50 +177,61 @@ __global__ __launch_bounds__(256) void k_hex_bwd_time(HexDesc d, const float *__
                                                       const int32_t *__restrict__ tp_item,
                                                       const float *__restrict__ G, float *const *__restrict__ g_plane)
 {
-    const size_t gid = (size_t)blockIdx.x * 256 + threadIdx.x;
+    // The distinct time rows of this step (<= 2 B) and, per frame, which two of them it touches are the
+    // same for every thread: thread 0 merges them once (fixed order), the per-row sums live in LDS.
+    __shared__ int s_rows[kHexMaxScales][2 * kHexMaxFrames], s_r0[kHexMaxScales][kHexMaxFrames],
+        s_r1[kHexMaxScales][kHexMaxFrames], s_nrows[kHexMaxScales];
+    __shared__ float s_wy[kHexMaxScales][kHexMaxFrames];
+    __shared__ float s_acc[2 * kHexMaxFrames][256];
+    const int tid = threadIdx.x;
+    if (tid < d.S) {
+        const int sc = tid, Ht = d.res[sc][3];
+        int nrows = 0;
+        for (int f = 0; f < d.B; ++f) {
+            int y0;
+            float wy;
+            texel_coord(times[f], Ht, y0, wy);
+            const int yy[2] = {y0, min(y0 + 1, Ht - 1)};
+            int slot[2];
+            for (int k = 0; k < 2; ++k) {
+                int r = 0;
+                while (r < nrows && s_rows[sc][r] != yy[k]) ++r;
+                if (r == nrows) s_rows[sc][nrows++] = yy[k];
+                slot[k] = r;
+            }
+            s_r0[sc][f] = slot[0];
+            s_r1[sc][f] = slot[1];
+            s_wy[sc][f] = wy;
+        }
+        s_nrows[sc] = nrows;
+    }
+    for (int r = 0; r < 2 * d.B; ++r) s_acc[r][tid] = 0.f;
+    __syncthreads();
+    const size_t gid = (size_t)blockIdx.x * 256 + tid;
     if (gid >= (size_t)U * kHexCh) return;
     const int c = (int)(gid % kHexCh), u = (int)(gid / kHexCh);
     const int s = tp_scale[u], p = tp_plane[u];
     const int a0 = c_axis0[p];
-    const int W = d.res[s][a0], H = d.res[s][3];
-    // distinct time rows of this step (<= 2 B), merged in fixed order
-    int rows[2 * kHexMaxFrames];
-    float acc[2 * kHexMaxFrames];
-    int nrows = 0;
+    const int W = d.res[s][a0], H = d.res[s][3], nrows = s_nrows[s];
+    const int e0 = tp_off[u], e1 = tp_off[u + 1];
     for (int f = 0; f < d.B; ++f) {
-        int y0;
-        float wy;
-        texel_coord(times[f], H, y0, wy);
-        const int y1 = min(y0 + 1, H - 1);
-        const int yy[2] = {y0, y1};
-        for (int k = 0; k < 2; ++k) {
-            bool found = false;
-            for (int r = 0; r < nrows; ++r) found |= (rows[r] == yy[k]);
-            if (!found) { rows[nrows] = yy[k]; acc[nrows] = 0.f; ++nrows; }
+        float sum = 0.f;
+        for (int e = e0; e < e1; ++e) {
+            const int m = tp_item[e] >> 1, corner = tp_item[e] & 1;
+            const float xa = (nodes[3 * (size_t)m + a0] - d.lo[a0]) * d.inv[a0] - 1.0f;
+            int x0;
+            float wx;
+            texel_coord(xa, W, x0, wx);
+            const float wcol = corner ? wx : (1.f - wx);
+            sum += G[((((size_t)f * d.M + m) * d.S + s) * kHexPlanes + p) * kHexCh + c] * wcol;
         }
-    }
-    for (int e = tp_off[u]; e < tp_off[u + 1]; ++e) {
-        const int m = tp_item[e] >> 1, corner = tp_item[e] & 1;
-        const float xa = (nodes[3 * (size_t)m + a0] - d.lo[a0]) * d.inv[a0] - 1.0f;
-        int x0;
-        float wx;
-        texel_coord(xa, W, x0, wx);
-        const float wcol = corner ? wx : (1.f - wx);
-        for (int f = 0; f < d.B; ++f) {
-            int y0;
-            float wy;
-            texel_coord(times[f], H, y0, wy);
-            const int y1 = min(y0 + 1, H - 1);
-            const float g = G[((((size_t)f * d.M + m) * d.S + s) * kHexPlanes + p) * kHexCh + c] * wcol;
-            for (int r = 0; r < nrows; ++r) {
-                if (rows[r] == y0) acc[r] += g * (1.f - wy);
-                if (rows[r] == y1) acc[r] += g * wy;
-            }
-        }
+        const float wy = s_wy[s][f];
+        s_acc[s_r0[s][f]][tid] += sum * (1.f - wy);
+        s_acc[s_r1[s][f]][tid] += sum * wy;
     }
     const size_t HW = (size_t)W * H;
     for (int r = 0; r < nrows; ++r)
-        g_plane[s * kHexPlanes + p][(size_t)c * HW + (size_t)rows[r] * W + tp_col[u]] = acc[r];
+        g_plane[s * kHexPlanes + p][(size_t)c * HW + (size_t)s_rows[s][r] * W + tp_col[u]] = s_acc[r][tid];
 }
 
 // ---------------------------------------------------------------------------------------- plan helper

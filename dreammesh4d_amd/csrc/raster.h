@@ -6,10 +6,11 @@
 //   K2 colscan         1 thread / tile       exclusive scan of hist over WGs, tile counts
 //   K3 scatter         1024 Gaussians / WG   duplicates -> per-tile segments via LDS cursors
 //                                            (no global atomics anywhere in binning)
-//   K4 tile_sort       1 workgroup / tile    LDS bitonic sort by (depth bits, id); then the
-//                                            tile's list is split into four 8x8-quadrant lists
-//   K5 render_fwd      1 WAVE / quadrant     own depth-sorted list, no barriers, early exit
-//   B1 render_bwd      1 WAVE / quadrant     per-(duplicate, quadrant) partial grads, no atomics
+//   K4 tile_sort       1 workgroup / tile    LDS depth-bucket sort by (depth bits, id); then the
+//                                            tile's list is split into sixteen 4x4-pixel CELL lists
+//   K5 render_fwd      1 WAVE / 8x8 quadrant one 16-lane DPP row per cell, each row walks its own
+//                                            depth-sorted cell list; no barriers, early exit
+//   B1 render_bwd      1 WAVE / 8x8 quadrant per-(Gaussian, cell) partial-gradient records, no atomics
 //   B2 gather_bwd      1 thread / Gaussian   deterministic gather + preprocess backward
 #pragma once
 #include <stddef.h>
@@ -31,17 +32,19 @@ constexpr int kPreItems = 4;     // Gaussians per thread in K1/K3
 constexpr int kPreBlock = kPreThreads * kPreItems;   // Gaussians per workgroup in K1/K3
 constexpr int kMaxTiles = 36864; // tile histogram lives in LDS (4 B/tile of the 160 KB): <= 3072x3072 px
 constexpr int kMaxChannels = 6;  // colour channels blended per pass: 3 (drop-in operator) or 6 (RGB + normal)
-// floats per (duplicate, quadrant) record of the backward scratch: 2 mean + 3 conic + opacity + depth + C colours
-DM4D_HD static inline int grad_stride(int C) { return C <= 3 ? 12 : 16; }
+constexpr int kCells = 16;       // 4x4-pixel cells per 16x16 tile; cell id = 4 * quadrant + (cx & 1) + 2 * (cy & 1)
+// floats per (Gaussian, cell) record of the backward scratch: 2 mean + 3 conic + opacity + depth + C colours
+DM4D_HD static inline int grad_stride(int C) { return C <= 3 ? 10 : 13; }
 
-enum GeomCounter { kCntD = 0, kCntOverflow = 1 };
+// counters[]: duplicates, duplicate-capacity overflow, records (sum of the Gaussians' cells), record-capacity overflow
+enum GeomCounter { kCntD = 0, kCntOverflow = 1, kCntR = 2, kCntRecOverflow = 3 };
 
 DM4D_HD static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 struct GeomLayout {
     int N, T, nb;
-    size_t counters, xy, depth, conic_opacity, rgb, tiles_touched, offsets, clamped, block_sums, hist,
-        tile_count, tile_start, qcount, qdone, qkmax, zero_begin, zero_bytes, total;
+    size_t counters, xy, depth, conic_opacity, rgb, tiles_touched, offsets, rec_touched, rec_offsets, clamped,
+        block_sums, rec_block_sums, hist, tile_count, tile_start, ccount, cdone, ckmax, zero_begin, zero_bytes, total;
 };
 
 DM4D_HD static inline size_t take_(size_t &o, size_t bytes) { size_t r = o; o = align_up(o + bytes, 256); return r; }
@@ -61,17 +64,20 @@ DM4D_HD static inline GeomLayout geom_layout(int N, int H, int W)
     L.zero_bytes = o;
     L.tile_count = take_(o, (size_t)L.T * 4);
     L.tile_start = take_(o, (size_t)(L.T + 1) * 4);
-    L.qcount = take_(o, (size_t)L.T * 16);   // entries of each quadrant list            [T][4]
-    L.qdone = take_(o, (size_t)L.T * 16);    // entries the forward consumed               [T][4]
-    L.qkmax = take_(o, (size_t)L.T * 16);    // tile-list position bound of those entries  [T][4]
+    L.ccount = take_(o, (size_t)L.T * kCells * 4);   // entries of each cell list                  [T][16]
+    L.cdone = take_(o, (size_t)L.T * kCells * 4);    // entries the forward consumed               [T][16]
+    L.ckmax = take_(o, (size_t)L.T * kCells * 4);    // tile-list position bound of those entries  [T][16]
     L.xy = take_(o, n * 8);
     L.depth = take_(o, n * 4);
     L.conic_opacity = take_(o, n * 16);
     L.rgb = take_(o, n * 12);
     L.tiles_touched = take_(o, n * 4);
     L.offsets = take_(o, n * 4);
+    L.rec_touched = take_(o, n * 4);
+    L.rec_offsets = take_(o, n * 4);
     L.clamped = take_(o, n * 3);
     L.block_sums = take_(o, (size_t)(L.nb + 1) * 4);
+    L.rec_block_sums = take_(o, (size_t)(L.nb + 1) * 4);
     L.hist = take_(o, (size_t)(L.nb > 0 ? L.nb : 1) * L.T * 4);
     L.total = o;
     return L;
@@ -85,14 +91,17 @@ struct GeomPtrs {
     float *rgb;
     uint32_t *tiles_touched;
     uint32_t *offsets;
+    uint32_t *rec_touched;   // cells (4x4 px) inside the Gaussian's alpha >= 1/255 bound and its tile rect
+    uint32_t *rec_offsets;   // exclusive scan of rec_touched: first backward record of the Gaussian
     uint8_t *clamped;
     uint32_t *block_sums;
+    uint32_t *rec_block_sums;
     uint32_t *hist;        // [nb][T] per-WG tile histogram, exclusive-scanned over WGs in place by K2
     uint32_t *tile_count;
     uint32_t *tile_start;
-    uint32_t *qcount;
-    uint32_t *qdone;
-    uint32_t *qkmax;
+    uint32_t *ccount;
+    uint32_t *cdone;
+    uint32_t *ckmax;
 };
 
 DM4D_HD static inline GeomPtrs geom_ptrs(void *base, const GeomLayout &L)
@@ -106,14 +115,17 @@ DM4D_HD static inline GeomPtrs geom_ptrs(void *base, const GeomLayout &L)
     p.rgb = (float *)(b + L.rgb);
     p.tiles_touched = (uint32_t *)(b + L.tiles_touched);
     p.offsets = (uint32_t *)(b + L.offsets);
+    p.rec_touched = (uint32_t *)(b + L.rec_touched);
+    p.rec_offsets = (uint32_t *)(b + L.rec_offsets);
     p.clamped = (uint8_t *)(b + L.clamped);
     p.block_sums = (uint32_t *)(b + L.block_sums);
+    p.rec_block_sums = (uint32_t *)(b + L.rec_block_sums);
     p.hist = (uint32_t *)(b + L.hist);
     p.tile_count = (uint32_t *)(b + L.tile_count);
     p.tile_start = (uint32_t *)(b + L.tile_start);
-    p.qcount = (uint32_t *)(b + L.qcount);
-    p.qdone = (uint32_t *)(b + L.qdone);
-    p.qkmax = (uint32_t *)(b + L.qkmax);
+    p.ccount = (uint32_t *)(b + L.ccount);
+    p.cdone = (uint32_t *)(b + L.cdone);
+    p.ckmax = (uint32_t *)(b + L.ckmax);
     return p;
 }
 
@@ -122,14 +134,15 @@ struct BinPtrs {
     uint32_t *u_idx;
     uint32_t *point_list; // sorted Gaussian ids  (== upstream point_list)
     uint32_t *sorted_pos; // Gaussian-major duplicate index -> position in point_list
-    uint2 *qlist;         // [4][cap] quadrant lists: (Gaussian id, position k in the tile list),
-                          // quadrant q of tile t at qlist[q*cap + tile_start[t] ...]
+    uint2 *clist;         // [16][cap] cell lists: (Gaussian id, position k in the tile list),
+                          // cell c of tile t at clist[c*cap + tile_start[t] ...]
+    uint32_t *cslot;      // [16][cap] backward record of the same entry
     size_t cap;
 };
 DM4D_HD static inline size_t binning_bytes(int64_t cap)
 {
     size_t c = (size_t)(cap > 0 ? cap : 1);
-    return 4 * align_up(c * 4, 256) + align_up(c * 32, 256);
+    return 4 * align_up(c * 4, 256) + align_up(c * kCells * 8, 256) + align_up(c * kCells * 4, 256);
 }
 DM4D_HD static inline BinPtrs bin_ptrs(void *base, int64_t cap)
 {
@@ -141,7 +154,8 @@ DM4D_HD static inline BinPtrs bin_ptrs(void *base, int64_t cap)
     p.u_idx = (uint32_t *)(b + stride);
     p.point_list = (uint32_t *)(b + 2 * stride);
     p.sorted_pos = (uint32_t *)(b + 3 * stride);
-    p.qlist = (uint2 *)(b + 4 * stride);
+    p.clist = (uint2 *)(b + 4 * stride);
+    p.cslot = (uint32_t *)(b + 4 * stride + align_up(c * kCells * 8, 256));
     p.cap = c;
     return p;
 }
@@ -164,10 +178,10 @@ DM4D_HD static inline ImgPtrs img_ptrs(void *base, int H, int W)
     p.n_contrib = (uint32_t *)((char *)base + stride);
     return p;
 }
-DM4D_HD static inline size_t grad_bytes(int64_t cap, int C)
+DM4D_HD static inline size_t grad_bytes(int64_t n_records, int C)
 {
-    size_t c = (size_t)(cap > 0 ? cap : 1);
-    return align_up(4 * c * grad_stride(C) * 4, 256);   // 4 quadrant slices
+    size_t c = (size_t)(n_records > 0 ? n_records : 1);
+    return align_up(c * grad_stride(C) * 4, 256);
 }
 
 // Camera / image constants handed to kernels by value.
@@ -177,29 +191,52 @@ struct ViewParams {
     const float *bg, *view, *proj, *campos;
 };
 
+struct Rect { int x0, y0, x1, y1; };   // tile rect of a Gaussian, [x0, x1) x [y0, y1)
+
+// The 4x4-pixel cells a Gaussian can contribute to form a dense nbx x nby block of the global cell
+// grid (cell (bx, by) = pixels 4bx..4bx+3 x 4by..4by+3; tile = (bx >> 2, by >> 2)).
+struct Bands { int bx0, by0, nbx, nby; };
+
 #ifdef __HIPCC__
-// 4-bit mask of the 8x8 quadrants of the tile with origin (ox, oy) that the alpha >= 1/255
-// support of a splat can reach: exact axis-aligned bound of the ellipse
-// { d : 1/2 d^T A d <= ln(255 o) }, inflated by margins that cover the rounding of log/sqrt/div.
-// Conservative, so culled (splat, pixel) pairs are exactly ones the reference `continue`s on.
-// Used by K4 (to build the quadrant lists) and recomputed by B2 (to find the written records):
-// both run the SAME device code on the SAME inputs, so the masks agree bit-for-bit.
-__device__ __forceinline__ uint32_t quadrant_mask(float x, float y, float ca, float cb, float cc, float o, float ox,
-                                                  float oy)
+__device__ __forceinline__ Rect tile_rect(float px, float py, int r, int gx, int gy)
 {
-    if (o < 1.0f / 255.0f) return 0u;   // alpha <= opacity < 1/255 for every pixel
+    float fr = (float)r;
+    Rect q;
+    q.x0 = min(gx, max(0, f2i_sat((px - fr) / (float)kTile)));
+    q.y0 = min(gy, max(0, f2i_sat((py - fr) / (float)kTile)));
+    q.x1 = min(gx, max(0, f2i_sat((px + fr + (float)(kTile - 1)) / (float)kTile)));
+    q.y1 = min(gy, max(0, f2i_sat((py + fr + (float)(kTile - 1)) / (float)kTile)));
+    return q;
+}
+
+// Cells of the tile rect `rc` that the alpha >= 1/255 support of a splat can reach: exact axis-aligned
+// bound of the ellipse { d : 1/2 d^T A d <= ln(255 o) }, inflated by margins that cover the rounding
+// of log/sqrt/div.  Conservative, so culled (splat, pixel) pairs are exactly ones the reference
+// `continue`s on.  K1 (record count), K4 (cell lists) and B2 (record gather) run this SAME device
+// code on the SAME stored inputs, so they agree bit-for-bit.
+__device__ __forceinline__ Bands cell_bands(float x, float y, float ca, float cb, float cc, float o, const Rect rc)
+{
+    Bands B;
+    B.bx0 = 4 * rc.x0; B.by0 = 4 * rc.y0; B.nbx = 0; B.nby = 0;
+    if (o < 1.0f / 255.0f) return B;   // alpha <= opacity < 1/255 for every pixel
+    int bx1 = 4 * rc.x1, by1 = 4 * rc.y1;
     const float tau = __logf(255.0f * o) * 1.001f + 0.01f;
     const float det = ca * cc - cb * cb;
     const float hx = sqrtf(2.0f * tau * cc / det) * 1.0001f + 0.02f;
     const float hy = sqrtf(2.0f * tau * ca / det) * 1.0001f + 0.02f;
-    if (!(det > 0.f) || !(hx == hx) || !(hy == hy)) return 0xFu;
-    const bool x0 = (x + hx >= ox) && (x - hx <= ox + 7.0f);
-    const bool x1 = (x + hx >= ox + 8.0f) && (x - hx <= ox + 15.0f);
-    const bool y0 = (y + hy >= oy) && (y - hy <= oy + 7.0f);
-    const bool y1 = (y + hy >= oy + 8.0f) && (y - hy <= oy + 15.0f);
-    return (uint32_t)(x0 && y0) | ((uint32_t)(x1 && y0) << 1) | ((uint32_t)(x0 && y1) << 2) |
-           ((uint32_t)(x1 && y1) << 3);
+    if ((det > 0.f) && (hx == hx) && (hy == hy)) {
+        // cell column b holds pixel centres 4b .. 4b+3: reached iff x + hx >= 4b and x - hx <= 4b + 3
+        B.bx0 = max(B.bx0, f2i_sat(ceilf((x - hx - 3.0f) * 0.25f)));
+        B.by0 = max(B.by0, f2i_sat(ceilf((y - hy - 3.0f) * 0.25f)));
+        bx1 = min(bx1 - 1, f2i_sat(floorf((x + hx) * 0.25f))) + 1;
+        by1 = min(by1 - 1, f2i_sat(floorf((y + hy) * 0.25f))) + 1;
+    }
+    const int nbx = bx1 - B.bx0, nby = by1 - B.by0;
+    if (nbx > 0 && nby > 0) { B.nbx = nbx; B.nby = nby; }
+    return B;
 }
+// cell id inside its tile (cx, cy in 0..3): the four cells of an 8x8 quadrant are consecutive
+__device__ __forceinline__ int cell_id(int cx, int cy) { return 4 * ((cx >> 1) + 2 * (cy >> 1)) + (cx & 1) + 2 * (cy & 1); }
 #endif
 
 struct BwdOutputs {
@@ -228,7 +265,7 @@ struct BatchDesc {
     char *image; size_t img_stride;
     float *out_color, *out_depth, *out_alpha;
     const float *dL_dcolor, *dL_ddepth, *dL_dalpha;
-    float *dLq; size_t dlq_stride;
+    float *dLq; size_t dlq_stride; uint32_t rec_cap;   // backward records: capacity (records) per view
     BwdOutputs o;          // per-view stride of each = N * width
 };
 
@@ -242,6 +279,7 @@ struct ViewCtx {
     float *out_color, *out_depth, *out_alpha;
     const float *dL_dcolor, *dL_ddepth, *dL_dalpha;
     float *dLq;
+    uint32_t rec_cap;
     BwdOutputs o;
     const float *colors;   // colours actually blended ([N,C]): colors_precomp or the SH-evaluated rgb
     int T;
@@ -286,6 +324,7 @@ DM4D_HD static inline ViewCtx resolve(const BatchDesc &d, int b)
     c.dL_ddepth = d.dL_ddepth ? d.dL_ddepth + sb * P : nullptr;
     c.dL_dalpha = d.dL_dalpha ? d.dL_dalpha + sb * P : nullptr;
     c.dLq = d.dLq ? d.dLq + sb * d.dlq_stride : nullptr;
+    c.rec_cap = d.rec_cap;
     c.o.dL_dmeans2D = d.o.dL_dmeans2D ? d.o.dL_dmeans2D + sb * N * 3 : nullptr;
     c.o.dL_dmeans3D = d.o.dL_dmeans3D ? d.o.dL_dmeans3D + sb * N * 3 : nullptr;
     c.o.dL_dopacity = d.o.dL_dopacity ? d.o.dL_dopacity + sb * N : nullptr;
@@ -307,6 +346,5 @@ int launch_render_bwd(const BatchDesc &d, hipStream_t st);
 int launch_gather_bwd(const BatchDesc &d, hipStream_t st);
 int launch_zero_counters(const BatchDesc &d, hipStream_t st);
 int launch_mark_visible(int N, const float *means3D, const float *view, uint8_t *present, hipStream_t st);
-int launch_selftest_reduce(const float *in, float *out, hipStream_t st);
 
 }  // namespace dm4d

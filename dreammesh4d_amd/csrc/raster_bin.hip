@@ -5,7 +5,7 @@
 //                     starts (== upstream's `ranges`) follow from a scan K3 does in LDS.
 //   K4 k_tile_sort  : one workgroup per tile; sorts the tile's duplicates by the 64-bit key
 //                     (depth bits << 32 | Gaussian id) with a depth-bucket counting sort in LDS, then
-//                     splits the sorted list into the four 8x8-quadrant lists.
+//                     splits the sorted list into the sixteen 4x4-pixel cell lists.
 //
 // Why not upstream's global radix sort (cub::DeviceRadixSort over tile<<32|depth, 6 passes of
 // 24 B/duplicate): duplicates are already partitioned by tile after K3, a tile's list is a few
@@ -64,77 +64,82 @@ __global__ __launch_bounds__(kColThreads) void k_colscan(BatchDesc d)
 // scatter uses LDS atomics.  O(n) work and 6 barriers instead of the O(n log^2 n) / 55-barrier
 // bitonic network this replaced.
 // Large tiles (n > kSortLdsCap): the same algorithm with the keys resident in HBM/L2 (the bucket-major
-// copy borrows the tile's quadrant-0 list segment, which is only written afterwards).
+// copy borrows the tile's cell-0 list segment, which is only written afterwards).
 constexpr int kSortThreads = 256;
 constexpr int kSortLdsCap = 2048;
 constexpr int kSortPerThread = kSortLdsCap / kSortThreads;
 constexpr int kBins = 1024;
 
-// Gaussian-major duplicate index of (gid, tile): offsets[gid] + position of the tile in gid's rect
-__device__ __forceinline__ uint32_t dup_index(const ViewCtx &c, uint32_t gid, int tx, int ty)
-{
-    const float2 xy = c.g.xy[gid];
-    const float fr = (float)c.radii[gid];
-    const int gx = c.vp.gx;
-    const int x0 = min(gx, max(0, f2i_sat((xy.x - fr) / (float)kTile)));
-    const int y0 = min(c.vp.gy, max(0, f2i_sat((xy.y - fr) / (float)kTile)));
-    const int x1 = min(gx, max(0, f2i_sat((xy.x + fr + (float)(kTile - 1)) / (float)kTile)));
-    return c.g.offsets[gid] + (uint32_t)((ty - y0) * (x1 - x0) + (tx - x0));
-}
-
-// Split the sorted tile list into the four quadrant lists (stable compaction by quadrant_mask) and
-// record where every duplicate landed (sorted_pos).
+// Split the sorted tile list into the sixteen cell lists (stable compaction by the cell block of
+// cell_bands) and record where every duplicate landed (sorted_pos).  Every cell-list entry also gets
+// the index of its backward record: the records of Gaussian i are the dense nby x nbx block of its
+// cells, starting at rec_offsets[i] (K3).
 template <typename GidAt>
 __device__ __forceinline__ void finish_tile(const ViewCtx &c, int tile, uint32_t s, uint32_t n, GidAt &&gid_at)
 {
-    __shared__ uint32_t s_qbase[4];
-    __shared__ uint32_t s_wq[kSortThreads / 64][4];
+    __shared__ uint32_t s_cbase[kCells];
+    __shared__ uint32_t s_wc[kSortThreads / 64][kCells];
     const GeomPtrs &g = c.g;
     const BinPtrs &b = c.b;
     const uint32_t cap = c.cap;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int tx = tile % c.vp.gx, ty = tile / c.vp.gx;
-    const float ox = (float)(tx * kTile), oy = (float)(ty * kTile);
-    if (tid < 4) s_qbase[tid] = 0u;
+    if (tid < kCells) s_cbase[tid] = 0u;
     __syncthreads();
     for (uint32_t e0 = 0; e0 < n; e0 += kSortThreads) {
         const uint32_t e = e0 + tid;
-        uint32_t m = 0u, gid = 0u;
+        uint32_t m = 0u, gid = 0u, rec0 = 0u;
+        int nbx = 0, ox = 0, oy = 0;   // record of cell (cx, cy) of this tile: rec0 + (oy + cy) * nbx + ox + cx
         if (e < n) {
             gid = gid_at(e);
             b.point_list[s + e] = gid;
-            const uint32_t p = dup_index(c, gid, tx, ty);
-            if (p < cap) b.sorted_pos[p] = s + e;
             const float2 xy = g.xy[gid];
             const float4 co = g.conic_opacity[gid];
-            m = quadrant_mask(xy.x, xy.y, co.x, co.y, co.z, co.w, ox, oy);
+            const Rect rc = tile_rect(xy.x, xy.y, c.radii[gid], c.vp.gx, c.vp.gy);
+            // Gaussian-major duplicate index of (gid, tile): offsets[gid] + position of the tile in gid's rect
+            const uint32_t p = g.offsets[gid] + (uint32_t)((ty - rc.y0) * (rc.x1 - rc.x0) + (tx - rc.x0));
+            if (p < cap) b.sorted_pos[p] = s + e;
+            const Bands bd = cell_bands(xy.x, xy.y, co.x, co.y, co.z, co.w, rc);
+            const int cx0 = max(bd.bx0, 4 * tx) - 4 * tx, cx1 = min(bd.bx0 + bd.nbx, 4 * tx + 4) - 4 * tx;
+            const int cy0 = max(bd.by0, 4 * ty) - 4 * ty, cy1 = min(bd.by0 + bd.nby, 4 * ty + 4) - 4 * ty;
+            for (int cy = cy0; cy < cy1; ++cy)
+                for (int cx = cx0; cx < cx1; ++cx) m |= 1u << cell_id(cx, cy);
+            rec0 = g.rec_offsets[gid];
+            nbx = bd.nbx;
+            ox = 4 * tx - bd.bx0;
+            oy = 4 * ty - bd.by0;
         }
-        uint64_t bal[4];
+        uint64_t bal[kCells];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) bal[q] = __ballot((m >> q) & 1u);
+        for (int k = 0; k < kCells; ++k) bal[k] = __ballot((m >> k) & 1u);
         if (lane == 0) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) s_wq[wv][q] = (uint32_t)__popcll(bal[q]);
+            for (int k = 0; k < kCells; ++k) s_wc[wv][k] = (uint32_t)__popcll(bal[k]);
         }
         __syncthreads();
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            if ((m >> q) & 1u) {
-                uint32_t pos = s_qbase[q] + mbcnt(bal[q]);
-                for (int w = 0; w < wv; ++w) pos += s_wq[w][q];
-                if (s + pos < cap) b.qlist[(size_t)q * b.cap + s + pos] = make_uint2(gid, e);
+        for (int k = 0; k < kCells; ++k) {
+            if ((m >> k) & 1u) {
+                uint32_t pos = s_cbase[k] + mbcnt(bal[k]);
+                for (int w = 0; w < wv; ++w) pos += s_wc[w][k];
+                if (s + pos < cap) {
+                    const int qd = k >> 2, rr = k & 3;
+                    const int cx = 2 * (qd & 1) + (rr & 1), cy = 2 * (qd >> 1) + (rr >> 1);
+                    b.clist[(size_t)k * b.cap + s + pos] = make_uint2(gid, e);
+                    b.cslot[(size_t)k * b.cap + s + pos] = rec0 + (uint32_t)((oy + cy) * nbx + ox + cx);
+                }
             }
         }
         __syncthreads();
-        if (tid < 4) {
+        if (tid < kCells) {
             uint32_t add = 0;
 #pragma unroll
-            for (int w = 0; w < kSortThreads / 64; ++w) add += s_wq[w][tid];
-            s_qbase[tid] += add;
+            for (int w = 0; w < kSortThreads / 64; ++w) add += s_wc[w][tid];
+            s_cbase[tid] += add;
         }
         __syncthreads();
     }
-    if (tid < 4) g.qcount[tile * 4 + tid] = s_qbase[tid];
+    if (tid < kCells) g.ccount[tile * kCells + tid] = s_cbase[tid];
 }
 
 __global__ __launch_bounds__(kSortThreads) void k_tile_sort(BatchDesc d)
@@ -155,7 +160,7 @@ __global__ __launch_bounds__(kSortThreads) void k_tile_sort(BatchDesc d)
     if (s >= cap) n = 0;
     else if (s + n > cap) n = cap - s;   // overflow: memory-safe, result flagged invalid by K3
     if (n == 0) {
-        if (tid < 4) g.qcount[t * 4 + tid] = 0u;
+        if (tid < kCells) g.ccount[t * kCells + tid] = 0u;
         return;
     }
     if (n <= (uint32_t)kSortLdsCap) {
@@ -239,10 +244,10 @@ __global__ __launch_bounds__(kSortThreads) void k_tile_sort(BatchDesc d)
         finish_tile(c, t, s, n, [&](uint32_t e) { return (uint32_t)s_a[e]; });
     } else {
         // ---- large tile: the same bucket sort with the keys resident in HBM (L2) ----
-        // temp (bucket-major keys) lives in the tile's own quadrant-0 list segment, which
+        // temp (bucket-major keys) lives in the tile's own cell-0 list segment, which
         // finish_tile() only writes afterwards; the sorted keys go back in place.
         uint32_t *kd = b.u_depth + s, *ki_ = b.u_idx + s;
-        uint64_t *tmp = reinterpret_cast<uint64_t *>(b.qlist + s);
+        uint64_t *tmp = reinterpret_cast<uint64_t *>(b.clist + s);
         uint32_t dmin = 0xFFFFFFFFu, dmax = 0u;
         for (uint32_t e = tid; e < n; e += kSortThreads) {
             const uint32_t dz = kd[e];

@@ -121,18 +121,6 @@ __device__ __forceinline__ void cov2d(const f3 mean, const ViewParams &vp, const
     }
 }
 
-struct Rect { int x0, y0, x1, y1; };
-__device__ __forceinline__ Rect tile_rect(float px, float py, int r, int gx, int gy)
-{
-    float fr = (float)r;
-    Rect q;
-    q.x0 = min(gx, max(0, f2i_sat((px - fr) / (float)kTile)));
-    q.y0 = min(gy, max(0, f2i_sat((py - fr) / (float)kTile)));
-    q.x1 = min(gx, max(0, f2i_sat((px + fr + (float)(kTile - 1)) / (float)kTile)));
-    q.y1 = min(gy, max(0, f2i_sat((py + fr + (float)(kTile - 1)) / (float)kTile)));
-    return q;
-}
-
 #define DM4D_SH_C0 0.28209479177387814f
 
 __device__ __forceinline__ f3 load3(const float *p, int i) { return f3{p[3 * i], p[3 * i + 1], p[3 * i + 2]}; }
@@ -152,17 +140,17 @@ __global__ __launch_bounds__(kPreThreads) void k_preprocess(BatchDesc d)
     const GeomPtrs &g = c.g;
     const int T = c.T;
     __shared__ float sV[16], sP[16];
-    __shared__ uint32_t s_wsum[kPreThreads / 64];
+    __shared__ uint32_t s_wsum[2][kPreThreads / 64];
     const int tid = threadIdx.x;
     if (tid < 16) { sV[tid] = vp.view[tid]; sP[tid] = vp.proj[tid]; }
     for (int t = tid; t < T; t += kPreThreads) s_hist[t] = 0u;
     __syncthreads();
-    uint32_t touched_sum = 0;
+    uint32_t touched_sum = 0, rec_sum = 0;
 #pragma unroll 1
     for (int it = 0; it < kPreItems; ++it) {
         const int i = blockIdx.x * kPreBlock + it * kPreThreads + tid;
         if (i >= in.N) break;
-        uint32_t touched = 0;
+        uint32_t touched = 0, recs = 0;
         int my_radius = 0;
         const f3 p = load3(in.means3D, i);
         const f3 pv = xform4x3(p, sV);
@@ -198,7 +186,10 @@ __global__ __launch_bounds__(kPreThreads) void k_preprocess(BatchDesc d)
                     touched = (uint32_t)area;
                     g.xy[i] = make_float2(px, py);
                     g.depth[i] = pv.z;
-                    g.conic_opacity[i] = make_float4(c[2] * det_inv, -c[1] * det_inv, c[0] * det_inv, in.opacities[i]);
+                    const float4 co = make_float4(c[2] * det_inv, -c[1] * det_inv, c[0] * det_inv, in.opacities[i]);
+                    g.conic_opacity[i] = co;
+                    const Bands bd = cell_bands(px, py, co.x, co.y, co.z, co.w, rc);
+                    recs = (uint32_t)(bd.nbx * bd.nby);
                     if (in.shs) {
                         const float *sh = in.shs + (size_t)i * in.sh_coeffs * 3;
 #pragma unroll
@@ -215,19 +206,23 @@ __global__ __launch_bounds__(kPreThreads) void k_preprocess(BatchDesc d)
         }
         radii[i] = my_radius;
         g.tiles_touched[i] = touched;
+        g.rec_touched[i] = recs;
         touched_sum += touched;
+        rec_sum += recs;
     }
-    const uint32_t ws = wave_sum_u32(touched_sum);
-    if ((tid & 63) == 0) s_wsum[tid >> 6] = ws;
+    const uint32_t ws = wave_sum_u32(touched_sum), wr = wave_sum_u32(rec_sum);
+    if ((tid & 63) == 0) { s_wsum[0][tid >> 6] = ws; s_wsum[1][tid >> 6] = wr; }
     __syncthreads();
     uint32_t *row = g.hist + (size_t)blockIdx.x * T;
     for (int t = tid; t < T; t += kPreThreads) row[t] = s_hist[t];
     if (tid == 0) {
-        uint32_t s = 0;
+        uint32_t s = 0, r = 0;
 #pragma unroll
-        for (int w = 0; w < kPreThreads / 64; ++w) s += s_wsum[w];
+        for (int w = 0; w < kPreThreads / 64; ++w) { s += s_wsum[0][w]; r += s_wsum[1][w]; }
         g.block_sums[blockIdx.x] = s;
-        if (s) atomicAdd(&g.counters[kCntD], s);   // one integer atomic per workgroup
+        g.rec_block_sums[blockIdx.x] = r;
+        if (s) atomicAdd(&g.counters[kCntD], s);   // two integer atomics per workgroup
+        if (r) atomicAdd(&g.counters[kCntR], r);
     }
 }
 
@@ -282,16 +277,18 @@ __global__ __launch_bounds__(kPreThreads) void k_scatter(BatchDesc d)
         if (blockIdx.x == 0 && tid == 0) g.tile_start[T] = total;
     }
     // Gaussian-major duplicate offset of this workgroup = sum of earlier workgroups' duplicates
-    uint32_t carry;
+    uint32_t carry, rcarry;
     {
-        uint32_t loc = 0;
-        for (int w = tid; w < (int)blockIdx.x; w += kPreThreads) loc += g.block_sums[w];
+        uint32_t loc = 0, rloc = 0;
+        for (int w = tid; w < (int)blockIdx.x; w += kPreThreads) { loc += g.block_sums[w]; rloc += g.rec_block_sums[w]; }
         uint32_t total;
         block_excl_scan_256(loc, s_w, &total);
         carry = total;
+        block_excl_scan_256(rloc, s_w, &total);
+        rcarry = total;
     }
     __syncthreads();
-    bool overflow = false;
+    bool overflow = false, rec_overflow = false;
 #pragma unroll 1
     for (int it = 0; it < kPreItems; ++it) {
         const int i = blockIdx.x * kPreBlock + it * kPreThreads + tid;
@@ -299,7 +296,14 @@ __global__ __launch_bounds__(kPreThreads) void k_scatter(BatchDesc d)
         uint32_t total;
         const uint32_t p0 = carry + block_excl_scan_256(touched, s_w, &total);
         carry += total;
-        if (i < N) g.offsets[i] = p0;
+        const uint32_t recs = (i < N) ? g.rec_touched[i] : 0u;
+        const uint32_t r0 = rcarry + block_excl_scan_256(recs, s_w, &total);
+        rcarry += total;
+        if (i < N) {
+            g.offsets[i] = p0;
+            g.rec_offsets[i] = r0;
+            rec_overflow |= (recs > 0u) && ((uint64_t)r0 + recs > (uint64_t)c.rec_cap);
+        }
         if (touched == 0) continue;
         const float2 xy = g.xy[i];
         const Rect rc = tile_rect(xy.x, xy.y, radii[i], vp.gx, vp.gy);
@@ -317,6 +321,7 @@ __global__ __launch_bounds__(kPreThreads) void k_scatter(BatchDesc d)
             }
     }
     if (overflow) g.counters[kCntOverflow] = 1u;
+    if (rec_overflow) g.counters[kCntRecOverflow] = 1u;
 }
 
 // ---------------------------------------------------------------------------------------- B2
@@ -346,34 +351,41 @@ __global__ __launch_bounds__(kPreThreads) void k_gather_bwd(BatchDesc d)
     const int r = radii[i];
     const int C = vp.C;
     if (r > 0) {
-        const int GS = grad_stride(C);
+        const int RS = grad_stride(C);
         const float2 xy = g.xy[i];
         const float4 co = g.conic_opacity[i];
         const Rect rc = tile_rect(xy.x, xy.y, r, vp.gx, vp.gy);
-        uint32_t p = g.offsets[i];
-        for (int y = rc.y0; y < rc.y1; ++y)
-            for (int x = rc.x0; x < rc.x1; ++x, ++p) {
-                const int t = y * vp.gx + x;
-                if (p >= cap) continue;
-                const uint32_t pos = b.sorted_pos[p];
-                if (pos >= cap) continue;
-                const uint32_t k = pos - g.tile_start[t];
-                // the same mask K4 used to build the quadrant lists (same code, same inputs)
-                const uint32_t m = quadrant_mask(xy.x, xy.y, co.x, co.y, co.z, co.w, (float)(x * kTile), (float)(y * kTile));
+        // the same cell block K1 counted and K4 used to build the cell lists (same code, same inputs);
+        // its records are the dense nby x nbx block starting at rec_offsets[i]
+        const Bands bd = cell_bands(xy.x, xy.y, co.x, co.y, co.z, co.w, rc);
+        if (bd.nbx > 0) {
+            const uint32_t rec0 = g.rec_offsets[i], p0 = g.offsets[i];
+            const int rw = rc.x1 - rc.x0;
+            const int bx1 = bd.bx0 + bd.nbx, by1 = bd.by0 + bd.nby;
+            for (int ty = bd.by0 >> 2; ty <= (by1 - 1) >> 2; ++ty)
+                for (int tx = bd.bx0 >> 2; tx <= (bx1 - 1) >> 2; ++tx) {
+                    const uint32_t p = p0 + (uint32_t)((ty - rc.y0) * rw + (tx - rc.x0));
+                    if (p >= cap) continue;
+                    const uint32_t pos = b.sorted_pos[p];
+                    if (pos >= cap) continue;
+                    const int t = ty * vp.gx + tx;
+                    const uint32_t k = pos - g.tile_start[t];
+                    const int cx0 = max(bd.bx0, 4 * tx), cx1 = min(bx1, 4 * tx + 4);
+                    const int cy0 = max(bd.by0, 4 * ty), cy1 = min(by1, 4 * ty + 4);
+                    for (int gy = cy0; gy < cy1; ++gy)
+                        for (int gx_ = cx0; gx_ < cx1; ++gx_) {
+                            if (k >= g.ckmax[t * kCells + cell_id(gx_ & 3, gy & 3)]) continue;   // record not written
+                            const uint32_t slot = rec0 + (uint32_t)((gy - bd.by0) * bd.nbx + (gx_ - bd.bx0));
+                            if (slot >= c.rec_cap) continue;
+                            const float *src = dLt + (size_t)slot * RS;
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    if (!((m >> q) & 1u) || k >= g.qkmax[t * 4 + q]) continue;   // record not written
-                    const float4 *src = reinterpret_cast<const float4 *>(dLt + ((size_t)q * b.cap + pos) * GS);
-                    const float4 a0 = src[0], a1 = src[1], a2 = src[2];
-                    acc[0] += a0.x; acc[1] += a0.y; acc[2] += a0.z; acc[3] += a0.w;
-                    acc[4] += a1.x; acc[5] += a1.y; acc[6] += a1.z; acc[7] += a1.w;
-                    acc[8] += a2.x; acc[9] += a2.y;
-                    if (C > 3) {
-                        const float4 a3 = src[3];
-                        acc[10] += a2.z; acc[11] += a2.w; acc[12] += a3.x;
-                    }
+                            for (int j = 0; j < 10; ++j) acc[j] += src[j];
+                            if (C > 3) {
+                                acc[10] += src[10]; acc[11] += src[11]; acc[12] += src[12];
+                            }
+                        }
                 }
-            }
+        }
     }
     o.dL_dmeans2D[3 * si + 0] = acc[0];
     o.dL_dmeans2D[3 * si + 1] = acc[1];

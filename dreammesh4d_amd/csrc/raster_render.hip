@@ -1,24 +1,27 @@
 // raster_render.hip -- alpha-compositing kernels of the tile rasterizer (gfx950, wave64).
 //
-// Execution unit = ONE WAVE per 8x8-pixel quadrant of a 16x16 tile.  Tiles stay 16x16 (the
-// reference's BLOCK_X x BLOCK_Y) so tile lists, keys, n_contrib and final_T keep their
-// upstream meaning, but K4 splits every tile's depth-sorted list into four quadrant lists using
-// the exact bound of each splat's alpha >= 1/255 ellipse (quadrant_mask, raster.h).  A
-// mesh-bound splat is ~1 px wide, so a quadrant list holds under half of its tile's list, and
-// culled (splat, pixel) pairs are exactly ones the reference `continue`s on: results are
-// unchanged.  One wave per workgroup means no barriers at all, 4x more independent work items
-// than tiles for the 256 CUs to balance, and early exit at 8x8 granularity.
+// Execution unit = ONE WAVE per 8x8-pixel quadrant of a 16x16 tile; inside the wave every 16-lane
+// DPP row owns one 4x4-pixel CELL and walks that cell's own depth-sorted list.  Tiles stay 16x16
+// (the reference's BLOCK_X x BLOCK_Y) so tile lists, keys, n_contrib and final_T keep their upstream
+// meaning, but K4 splits every tile's sorted list into sixteen cell lists using the exact bound of
+// each splat's alpha >= 1/255 ellipse (cell_bands, raster.h).  A mesh-bound splat is ~1 px wide:
+// measured on the bench scene, 41 % of the (entry, pixel) pairs a cell list visits contribute,
+// against 20 % for 8x8 lists and 8 % for whole-tile lists, and the four rows of a wave finish
+// within 11 % of each other -- 1.75x fewer wave iterations than one list per quadrant.  Culled
+// (splat, pixel) pairs are exactly ones the reference `continue`s on: results are unchanged.
+// One wave per workgroup means no barriers at all and early exit at cell granularity.
 //
-// Forward  (K5): 64 list entries at a time are gathered by the 64 lanes (coalesced list read,
-//                L2-resident attribute gathers), double-buffered through wave-private LDS; every
-//                lane then walks the chunk with broadcast LDS reads.  Front-to-back blend;
-//                the wave stops when all 64 pixels are saturated (ballot).
-// Backward (B1): back-to-front over the entries the forward consumed.  The 64-pixel sums of the
-//                10 (13 with 6 colour channels) per-entry gradients use a packed butterfly:
-//                v_permlane32_swap and v_permlane16_swap fold 4 values into one register before
-//                the in-row DPP steps (28 instead of 60 cross-lane instructions), and one
-//                store writes the whole record.  Records are indexed by (quadrant, tile-list
-//                position): no floating-point atomics, gradients are bit-reproducible.
+// Forward  (K5): each row gathers 16 entries of its list (coalesced list read, L2-resident
+//                attribute gathers) into wave-private LDS; the lanes of the row then walk the
+//                chunk with row-broadcast LDS reads (4 distinct addresses per instruction).
+//                Front-to-back blend; the wave stops when all 64 pixels are saturated (ballot).
+// Backward (B1): back-to-front over the entries the forward consumed.  The 16-pixel sums of the
+//                10 (13 with 6 colour channels) per-entry gradients go through LDS TRANSPOSED:
+//                every lane writes its values to [value][lane], lane i of a row reads the 16
+//                floats of value i of its row and adds them -- 7 packed adds on the VALU instead
+//                of a 52-step DPP butterfly -- and the row stores one contiguous record.
+//                Records are indexed by (Gaussian, cell): no floating-point atomics, gradients are
+//                bit-reproducible, and B2 reads every Gaussian's records as one contiguous block.
 //
 // blockIdx -> (tile, quadrant) keeps the 4 quadrants of a tile on ONE XCD (blocks are dispatched
 // round-robin over the 8 XCDs), so the attribute gathers of neighbouring quadrants share an L2.
@@ -32,9 +35,8 @@
 
 namespace dm4d {
 
-typedef unsigned int u2v __attribute__((ext_vector_type(2)));
-
 template <int C> struct StagedN { static constexpr int kVec = (C <= 3) ? 3 : 4; };
+constexpr int kChunk = 16;   // list entries a row stages per step (one per lane of the row)
 
 // gather one list entry: a = (x, y, conic.x, conic.y)  b = (conic.z, opacity, depth, k bits)
 //                        c = colours 0..3               d = colours 4..5
@@ -59,12 +61,41 @@ __device__ __forceinline__ void gather_entry(const uint2 qe, const GeomPtrs &g, 
         r[3] = make_float4(c45.x, c45.y, 0.f, 0.f);
     }
 }
+// An all-zero entry is inert: opacity 0 gives alpha 0 < 1/255, so rows whose list is shorter than the
+// wave's longest one blend padding entries with weight exactly 0.
+__device__ __forceinline__ void zero_entry(float4 (&r)[4])
+{
+#pragma unroll
+    for (int v = 0; v < 4; ++v) r[v] = make_float4(0.f, 0.f, 0.f, 0.f);
+}
 
 __device__ __forceinline__ void block_to_quadrant(int b, int &tile, int &q)
 {
     const int xcd = b & 7, r = b >> 3;
     q = r & 3;
     tile = (r >> 2) * 8 + xcd;
+}
+__device__ __forceinline__ uint32_t row_max_u32(uint32_t v)
+{
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) {
+        const uint32_t w = __shfl_xor(v, o, 64);
+        v = v > w ? v : w;
+    }
+    return v;
+}
+
+// lane -> pixel: row (lane >> 4) = cell (row & 1, row >> 1) of the quadrant, lane & 15 = pixel of the cell
+struct LanePixel { int px, py, row, li, cell; };
+__device__ __forceinline__ LanePixel lane_pixel(int lane, int tx, int ty, int q)
+{
+    LanePixel L;
+    L.row = lane >> 4;
+    L.li = lane & 15;
+    L.px = tx * kTile + (q & 1) * 8 + (L.row & 1) * 4 + (L.li & 3);
+    L.py = ty * kTile + (q >> 1) * 8 + (L.row >> 1) * 4 + (L.li >> 2);
+    L.cell = 4 * q + L.row;
+    return L;
 }
 
 // ---------------------------------------------------------------------------------------- K5
@@ -74,7 +105,7 @@ __global__ __launch_bounds__(64) void k_render_fwd(BatchDesc d)
     constexpr int NV = StagedN<C>::kVec;
     // one wave-private staging buffer: the next chunk waits in registers (prefetched during the
     // blend loop) and is written after the loop -- same wave, program order, no hazard
-    __shared__ float4 s_e[64][NV];
+    __shared__ float4 s_e[4][kChunk][NV];
     const ViewCtx c = resolve(d, blockIdx.y);
     const ViewParams &vp = c.vp;
     const float *__restrict__ colors = c.colors;
@@ -90,14 +121,15 @@ __global__ __launch_bounds__(64) void k_render_fwd(BatchDesc d)
     if (tile >= T) return;
     const int lane = threadIdx.x;
     const int tx = tile % vp.gx, ty = tile / vp.gx;
-    const int px = tx * kTile + (q & 1) * 8 + (lane & 7);
-    const int py = ty * kTile + (q >> 1) * 8 + (lane >> 3);
+    const LanePixel lp = lane_pixel(lane, tx, ty, q);
+    const int px = lp.px, py = lp.py, row = lp.row, li = lp.li;
     const bool inside = px < vp.W && py < vp.H;
     const float pxf = (float)px, pyf = (float)py;
 
     const uint32_t s = g.tile_start[tile];
-    const uint32_t nq = (s < cap) ? g.qcount[tile * 4 + q] : 0u;
-    const uint2 *__restrict__ list = b.qlist + (size_t)q * b.cap + s;
+    const uint32_t nr = (s < cap) ? g.ccount[tile * kCells + lp.cell] : 0u;   // this row's list length
+    const uint32_t nmax = wave_max_u32(nr);
+    const uint2 *__restrict__ list = b.clist + (size_t)lp.cell * b.cap + s;
 
     float T_ = 1.0f, D = 0.f, Wt = 0.f;
     float Cacc[C];
@@ -107,22 +139,22 @@ __global__ __launch_bounds__(64) void k_render_fwd(BatchDesc d)
     bool done = !inside;
 
     float4 r[4];
-    if ((uint32_t)lane < nq) gather_entry<C>(list[lane], g, colors, r);
-    for (uint32_t c0 = 0; c0 < nq; c0 += 64) {
-        const int cnt = (int)min(64u, nq - c0);
+    zero_entry(r);
+    if ((uint32_t)li < nr) gather_entry<C>(list[li], g, colors, r);
+    for (uint32_t c0 = 0; c0 < nmax; c0 += kChunk) {
+        const int cnt = (c0 < nr) ? (int)min((uint32_t)kChunk, nr - c0) : 0;
         __builtin_amdgcn_wave_barrier();
-        if (lane < cnt) {
 #pragma unroll
-            for (int v = 0; v < NV; ++v) s_e[lane][v] = r[v];
-        }
-        if (c0 + 64 + (uint32_t)lane < nq) gather_entry<C>(list[c0 + 64 + lane], g, colors, r);   // prefetch
+        for (int v = 0; v < NV; ++v) s_e[row][li][v] = r[v];
+        zero_entry(r);
+        if (c0 + kChunk + (uint32_t)li < nr) gather_entry<C>(list[c0 + kChunk + li], g, colors, r);   // prefetch
         __builtin_amdgcn_wave_barrier();
-        if (__ballot(!done) == 0) break;   // every pixel of the quadrant is saturated
+        if (__ballot((!done) & (cnt > 0)) == 0) break;   // every pixel with entries left is saturated
         int t = 0;
         do {
             // Branch-free body (selects, not exec-mask branches): lanes that do not take the entry
             // blend with weight 0, which leaves their accumulators bit-identical.
-            const float4 ea = s_e[t][0], eb = s_e[t][1], ec = s_e[t][2];
+            const float4 ea = s_e[row][t][0], eb = s_e[row][t][1], ec = s_e[row][t][2];
             const float dx = ea.x - pxf, dy = ea.y - pyf;
             const float power = -0.5f * ((ea.z * dx) * dx + (eb.x * dy) * dy) - (ea.w * dx) * dy;
             const float alpha = fminf(0.99f, eb.y * det_expf(power));
@@ -135,7 +167,7 @@ __global__ __launch_bounds__(64) void k_render_fwd(BatchDesc d)
             Cacc[1] = __builtin_fmaf(ec.y, w, Cacc[1]);
             Cacc[2] = __builtin_fmaf(ec.z, w, Cacc[2]);
             if (C > 3) {
-                const float4 ed = s_e[t][NV - 1];
+                const float4 ed = s_e[row][t][NV - 1];
                 Cacc[3] = __builtin_fmaf(ec.w, w, Cacc[3]);
                 Cacc[C > 4 ? 4 : 0] = __builtin_fmaf(ed.x, w, Cacc[C > 4 ? 4 : 0]);
                 Cacc[C > 5 ? 5 : 0] = __builtin_fmaf(ed.y, w, Cacc[C > 5 ? 5 : 0]);
@@ -146,7 +178,7 @@ __global__ __launch_bounds__(64) void k_render_fwd(BatchDesc d)
             last = contrib ? __float_as_uint(eb.w) + 1u : last;
             lastj = contrib ? c0 + (uint32_t)t + 1u : lastj;
             done = done | stop;
-        } while (++t < cnt && __ballot(!done) != 0);
+        } while (++t < kChunk && __ballot((!done) & (t < cnt)) != 0);
     }
     if (inside) {
         const size_t P = (size_t)vp.H * vp.W;
@@ -158,43 +190,25 @@ __global__ __launch_bounds__(64) void k_render_fwd(BatchDesc d)
         out_depth[pid] = D;
         out_alpha[pid] = Wt;
     }
-    const uint32_t wj = wave_max_u32(lastj), wk = wave_max_u32(last);
-    if (lane == 0) {
-        g.qdone[tile * 4 + q] = wj;
-        g.qkmax[tile * 4 + q] = wk;
+    const uint32_t wj = row_max_u32(lastj), wk = row_max_u32(last);
+    if (li == 0) {
+        g.cdone[tile * kCells + lp.cell] = wj;
+        g.ckmax[tile * kCells + lp.cell] = wk;
     }
 }
 
 // ---------------------------------------------------------------------------------------- B1
-// Packed 64-lane sums of NV (12 or 16) per-lane values.  After it, register out[r], lanes of row
-// rho (lane >> 4) all hold the total of value 4r + {0,2,1,3}[rho].
-template <int NV>
-__device__ __forceinline__ void wave_reduce_packed(const float (&v)[NV], float (&out)[NV / 4])
-{
-    float p[NV / 2];
-#pragma unroll
-    for (int m = 0; m < NV / 2; ++m) {
-        const u2v x = __builtin_amdgcn_permlane32_swap(__float_as_uint(v[2 * m]), __float_as_uint(v[2 * m + 1]), false, false);
-        p[m] = __uint_as_float(x.x) + __uint_as_float(x.y);
-    }
-#pragma unroll
-    for (int r = 0; r < NV / 4; ++r) {
-        const u2v x = __builtin_amdgcn_permlane16_swap(__float_as_uint(p[2 * r]), __float_as_uint(p[2 * r + 1]), false, false);
-        float o = __uint_as_float(x.x) + __uint_as_float(x.y);
-        o = dpp_add<0xB1>(o);    // quad_perm [1,0,3,2]
-        o = dpp_add<0x4E>(o);    // quad_perm [2,3,0,1]
-        o = dpp_add<0x141>(o);   // row_half_mirror
-        o = dpp_add<0x140>(o);   // row_mirror
-        out[r] = o;
-    }
-}
+typedef float f2v __attribute__((ext_vector_type(2)));
+constexpr int kRedStride = 68;   // floats per value row of the transposed reduction buffer (64 lanes + pad)
 
 template <int C>
 __global__ __launch_bounds__(64) void k_render_bwd(BatchDesc d)
 {
     constexpr int NV = StagedN<C>::kVec;
-    constexpr int GS = (C <= 3) ? 12 : 16;   // == grad_stride(C)
-    __shared__ float4 s_e[64][NV];
+    constexpr int RS = 7 + C;   // == grad_stride(C): floats per record
+    __shared__ float4 s_e[4][kChunk][NV];
+    __shared__ uint32_t s_slot[4][kChunk];
+    __shared__ __attribute__((aligned(16))) float s_red[RS][kRedStride];
     const ViewCtx c = resolve(d, blockIdx.y);
     const ViewParams &vp = c.vp;
     const float *__restrict__ colors = c.colors;
@@ -204,23 +218,25 @@ __global__ __launch_bounds__(64) void k_render_bwd(BatchDesc d)
     const ImgPtrs &im = c.im;
     const float *__restrict__ dL_dcolor = c.dL_dcolor, *__restrict__ dL_ddepth = c.dL_ddepth,
                              *__restrict__ dL_dalpha = c.dL_dalpha;
-    float *__restrict__ dLq = c.dLq;
+    float *__restrict__ rec = c.dLq;
+    const uint32_t rec_cap = c.rec_cap;
     const int T = c.T;
     int tile, q;
     block_to_quadrant(blockIdx.x, tile, q);
     if (tile >= T) return;
     const int lane = threadIdx.x;
     const int tx = tile % vp.gx, ty = tile / vp.gx;
-    const int px = tx * kTile + (q & 1) * 8 + (lane & 7);
-    const int py = ty * kTile + (q >> 1) * 8 + (lane >> 3);
+    const LanePixel lp = lane_pixel(lane, tx, ty, q);
+    const int px = lp.px, py = lp.py, row = lp.row, li = lp.li;
     const bool inside = px < vp.W && py < vp.H;
     const float pxf = (float)px, pyf = (float)py;
 
     const uint32_t s = g.tile_start[tile];
-    const uint32_t nd = (s < cap) ? g.qdone[tile * 4 + q] : 0u;
-    if (nd == 0) return;
-    const uint2 *__restrict__ list = b.qlist + (size_t)q * b.cap + s;
-    float *__restrict__ rec_base = dLq + ((size_t)q * b.cap + s) * GS;
+    const uint32_t nd = (s < cap) ? g.cdone[tile * kCells + lp.cell] : 0u;   // entries this row's forward consumed
+    const uint32_t ndmax = wave_max_u32(nd);
+    if (ndmax == 0) return;
+    const uint2 *__restrict__ list = b.clist + (size_t)lp.cell * b.cap + s;
+    const uint32_t *__restrict__ slots = b.cslot + (size_t)lp.cell * b.cap + s;
 
     const size_t P = (size_t)vp.H * vp.W;
     const size_t pid = (size_t)py * vp.W + px;
@@ -243,24 +259,33 @@ __global__ __launch_bounds__(64) void k_render_bwd(BatchDesc d)
     const float Tb = T_final * bgdot;
     float T_ = T_final, S = 0.f;
     const float half_W = 0.5f * (float)vp.W, half_H = 0.5f * (float)vp.H;
-    // which value this lane stores: register (lane & 15), memory slot 4*(lane&15) + {0,2,1,3}[row]
-    const int my_reg = lane & 15, row = lane >> 4;
-    const int my_slot = 4 * my_reg + ((row == 1) ? 2 : (row == 2) ? 1 : row);
+    // reduction role of this lane: value li of its row (lanes with li >= RS idle in the sum)
+    const int red_i = li < RS ? li : 0;
+    const float4 *red_src = reinterpret_cast<const float4 *>(&s_red[red_i][row * 16]);
 
-    const int c_last = (int)((nd - 1) / 64) * 64;
+    const uint32_t c_last = ((ndmax - 1) / kChunk) * kChunk;
     float4 r[4];
-    if ((uint32_t)(c_last + lane) < nd) gather_entry<C>(list[c_last + lane], g, colors, r);
-    for (int c0 = c_last; c0 >= 0; c0 -= 64) {
-        const int cnt = (int)min(64u, nd - (uint32_t)c0);
+    uint32_t rslot = 0;
+    zero_entry(r);
+    if (c_last + (uint32_t)li < nd) {
+        gather_entry<C>(list[c_last + li], g, colors, r);
+        rslot = slots[c_last + li];
+    }
+    for (uint32_t c0 = c_last;; c0 -= kChunk) {
+        const int cnt = (c0 < nd) ? (int)min((uint32_t)kChunk, nd - c0) : 0;
+        const int tmax = (int)min((uint32_t)kChunk, ndmax - c0);
         __builtin_amdgcn_wave_barrier();
-        if (lane < cnt) {
 #pragma unroll
-            for (int v = 0; v < NV; ++v) s_e[lane][v] = r[v];
+        for (int v = 0; v < NV; ++v) s_e[row][li][v] = r[v];
+        s_slot[row][li] = rslot;
+        zero_entry(r);
+        if (c0 >= (uint32_t)kChunk && c0 - kChunk + (uint32_t)li < nd) {   // prefetch the chunk in front
+            gather_entry<C>(list[c0 - kChunk + li], g, colors, r);
+            rslot = slots[c0 - kChunk + li];
         }
-        if (c0 >= 64) gather_entry<C>(list[c0 - 64 + lane], g, colors, r);   // prefetch the chunk in front
         __builtin_amdgcn_wave_barrier();
-        for (int t = cnt - 1; t >= 0; --t) {
-            const float4 ea = s_e[t][0], eb = s_e[t][1];
+        for (int t = tmax - 1; t >= 0; --t) {
+            const float4 ea = s_e[row][t][0], eb = s_e[row][t][1];
             const uint32_t k = __float_as_uint(eb.w);
             // Branch-free: lanes that do not take the entry contribute exact zeros.
             const float dx = ea.x - pxf, dy = ea.y - pyf;
@@ -268,11 +293,11 @@ __global__ __launch_bounds__(64) void k_render_bwd(BatchDesc d)
             const float Gr = det_expf(power);
             const float alpha = fminf(0.99f, eb.y * Gr);
             const bool contrib = (k < last) & (power <= 0.0f) & (alpha >= 1.0f / 255.0f);
-            const float4 ec = s_e[t][2];
+            const float4 ec = s_e[row][t][2];
             float col[C];
             col[0] = ec.x; col[1] = ec.y; col[2] = ec.z;
             if (C > 3) {
-                const float4 ed = s_e[t][NV - 1];
+                const float4 ed = s_e[row][t][NV - 1];
                 col[3] = ec.w;
                 col[C > 4 ? 4 : 0] = ed.x;
                 col[C > 5 ? 5 : 0] = ed.y;
@@ -289,7 +314,7 @@ __global__ __launch_bounds__(64) void k_render_bwd(BatchDesc d)
             S = __builtin_fmaf(V, w, S);
             const float dL_dG = eb.y * dL_da;
             const float gdx = G * dx, gdy = G * dy;
-            float v[GS];
+            float v[RS];
             v[0] = dL_dG * (-gdx * ea.z - gdy * ea.w) * half_W;
             v[1] = dL_dG * (-gdy * eb.x - gdx * ea.w) * half_H;
             v[2] = -0.5f * gdx * dx * dL_dG;
@@ -299,22 +324,25 @@ __global__ __launch_bounds__(64) void k_render_bwd(BatchDesc d)
             v[6] = w * gD;
 #pragma unroll
             for (int ch = 0; ch < C; ++ch) v[7 + ch] = w * gCol[ch];
+            // transposed reduction: [value][lane] in LDS, lane i of the row sums value i over the row
+            __builtin_amdgcn_wave_barrier();
 #pragma unroll
-            for (int i = 7 + C; i < GS; ++i) v[i] = 0.f;
-            float out[GS / 4];
-            if (__ballot(contrib) != 0) {
-                wave_reduce_packed<GS>(v, out);
-            } else {
-#pragma unroll
-                for (int i = 0; i < GS / 4; ++i) out[i] = 0.f;
-            }
-            if (my_reg < GS / 4) {
-                float val = out[0];
-#pragma unroll
-                for (int i = 1; i < GS / 4; ++i) val = (my_reg == i) ? out[i] : val;
-                rec_base[(size_t)k * GS + my_slot] = val;
-            }
+            for (int i = 0; i < RS; ++i) s_red[i][lane] = v[i];
+            __builtin_amdgcn_wave_barrier();
+            const float4 a0 = red_src[0], a1 = red_src[1], a2 = red_src[2], a3 = red_src[3];
+            // fixed summation tree (deterministic): pairs of packed adds
+            f2v p0 = f2v{a0.x, a0.y} + f2v{a0.z, a0.w};
+            f2v p1 = f2v{a1.x, a1.y} + f2v{a1.z, a1.w};
+            f2v p2 = f2v{a2.x, a2.y} + f2v{a2.z, a2.w};
+            f2v p3 = f2v{a3.x, a3.y} + f2v{a3.z, a3.w};
+            p0 = p0 + p1;
+            p2 = p2 + p3;
+            p0 = p0 + p2;
+            const float total = p0.x + p0.y;
+            const uint32_t slot = s_slot[row][t];
+            if (li < RS && t < cnt && slot < rec_cap) rec[(size_t)slot * RS + li] = total;
         }
+        if (c0 == 0) break;
     }
 }
 
@@ -339,31 +367,6 @@ int launch_render_bwd(const BatchDesc &d, hipStream_t st)
     ProfScope prof_(kKRenderBwd, st);
     if (d.C <= 3) hipLaunchKernelGGL(k_render_bwd<3>, dim3(blocks, d.B), dim3(64), 0, st, d);
     else hipLaunchKernelGGL(k_render_bwd<6>, dim3(blocks, d.B), dim3(64), 0, st, d);
-    DM4D_HIP_CHECK(hipGetLastError());
-    return DM4D_OK;
-}
-
-// ---- self-test of the packed reduction (exported through dm4d_selftest_wave_reduce) ----------
-__global__ void k_selftest_reduce(const float *__restrict__ in /* [16][64] */, float *__restrict__ out /* [16] */)
-{
-    const int lane = threadIdx.x;
-    float v[16];
-#pragma unroll
-    for (int i = 0; i < 16; ++i) v[i] = in[i * 64 + lane];
-    float o[4];
-    wave_reduce_packed<16>(v, o);
-    const int my_reg = lane & 15, row = lane >> 4;
-    const int my_slot = 4 * my_reg + ((row == 1) ? 2 : (row == 2) ? 1 : row);
-    if (my_reg < 4) {
-        float val = o[0];
-#pragma unroll
-        for (int i = 1; i < 4; ++i) val = (my_reg == i) ? o[i] : val;
-        out[my_slot] = val;
-    }
-}
-int launch_selftest_reduce(const float *in, float *out, hipStream_t st)
-{
-    hipLaunchKernelGGL(k_selftest_reduce, dim3(1), dim3(64), 0, st, in, out);
     DM4D_HIP_CHECK(hipGetLastError());
     return DM4D_OK;
 }

@@ -46,6 +46,7 @@ static int views_check(const dm4d_views *v)
         return DM4D_ERR_UNSUPPORTED;
     }
     if (v->capacity <= 0 || v->capacity > 0xFFFFFFF0ll) { set_error("capacity out of range"); return DM4D_ERR_INVALID; }
+    if (v->record_capacity <= 0 || v->record_capacity > 0xFFFFFFF0ll) { set_error("record_capacity out of range"); return DM4D_ERR_INVALID; }
     if (!v->bg || !v->viewmatrix || !v->projmatrix || !v->q_static || !v->scales || !v->opacities || !v->rgb ||
         !v->vxyz || !v->vrot || !v->means3D || !v->rotations || !v->colors || !v->radii || !v->geom || !v->binning ||
         !v->image) {
@@ -73,6 +74,7 @@ static BatchDesc views_batch(const dm4d_views *v)
     d.radii = v->radii; d.radii_stride = (size_t)v->N;
     d.geom = (char *)v->geom; d.geom_stride = geom_layout(v->N, v->image_height, v->image_width).total;
     d.binning = (char *)v->binning; d.bin_stride = binning_bytes(v->capacity); d.cap = (uint32_t)v->capacity;
+    d.rec_cap = (uint32_t)v->record_capacity;
     d.image = (char *)v->image; d.img_stride = image_bytes(v->image_height, v->image_width);
     d.out_color = v->out_color; d.out_depth = v->out_depth; d.out_alpha = v->out_alpha;
     return d;
@@ -87,7 +89,7 @@ extern "C" {
 size_t dm4d_views_geom_bytes(int32_t B, int32_t N, int32_t H, int32_t W) { return (size_t)B * geom_layout(N, H, W).total; }
 size_t dm4d_views_binning_bytes(int32_t B, int64_t capacity) { return (size_t)B * binning_bytes(capacity); }
 size_t dm4d_views_image_bytes(int32_t B, int32_t H, int32_t W) { return (size_t)B * image_bytes(H, W); }
-size_t dm4d_views_grad_bytes(int32_t B, int64_t capacity) { return (size_t)B * grad_bytes(capacity, 6); }
+size_t dm4d_views_grad_bytes(int32_t B, int64_t record_capacity) { return (size_t)B * grad_bytes(record_capacity, 6); }
 size_t dm4d_views_skin_scratch_bytes(int32_t B, int32_t V, int32_t K) { return (size_t)B * dm4d_skin_scratch_bytes(V, K); }
 size_t dm4d_views_face_scratch_bytes(int32_t B, int32_t F) { return (size_t)B * dm4d_face_scratch_bytes(F); }
 
@@ -125,7 +127,7 @@ int dm4d_views_backward(const dm4d_views *v, const dm4d_views_grads *gr, dm4d_st
     hipStream_t st = (hipStream_t)stream;
     BatchDesc d = views_batch(v);
     d.dL_dcolor = gr->dL_dcolor; d.dL_ddepth = gr->dL_ddepth; d.dL_dalpha = gr->dL_dalpha;
-    d.dLq = (float *)gr->grad_scratch; d.dlq_stride = grad_bytes(v->capacity, 6) / 4;
+    d.dLq = (float *)gr->grad_scratch; d.dlq_stride = grad_bytes(v->record_capacity, 6) / 4;
     d.o = BwdOutputs{gr->dL_dmeans2D, gr->dL_dmeans3D, gr->dL_dopacity, gr->dL_dcolors, nullptr, gr->dL_dscales,
                      gr->dL_drotations, nullptr};
     if ((rc = launch_render_bwd(d, st))) return rc;
@@ -140,19 +142,21 @@ int dm4d_views_backward(const dm4d_views *v, const dm4d_views_grads *gr, dm4d_st
                                 (float *)gr->skin_scratch, gr->dL_ddx, gr->dL_ddr, gr->dL_dds, gr->dL_ddo, st);
 }
 
-/* out[b] = {num_rendered, overflow flag} per view (synchronises the stream). */
-int dm4d_views_counters(const dm4d_views *v, int64_t *num_rendered, int32_t *overflowed, dm4d_stream_t stream)
+/* per view: num_rendered, num_records, overflow flags (synchronises the stream). */
+int dm4d_views_counters(const dm4d_views *v, int64_t *num_rendered, int64_t *num_records, int32_t *overflowed,
+                        dm4d_stream_t stream)
 {
     if (!v || !v->geom) { set_error("null views"); return DM4D_ERR_INVALID; }
     hipStream_t st = (hipStream_t)stream;
     const size_t stride = geom_layout(v->N, v->image_height, v->image_width).total;
-    std::vector<uint32_t> tmp((size_t)v->B * 2);
+    std::vector<uint32_t> tmp((size_t)v->B * 4);
     for (int b = 0; b < v->B; ++b)
-        DM4D_HIP_CHECK(hipMemcpyAsync(&tmp[2 * b], (const char *)v->geom + b * stride, 8, hipMemcpyDeviceToHost, st));
+        DM4D_HIP_CHECK(hipMemcpyAsync(&tmp[4 * b], (const char *)v->geom + b * stride, 16, hipMemcpyDeviceToHost, st));
     DM4D_HIP_CHECK(hipStreamSynchronize(st));
     for (int b = 0; b < v->B; ++b) {
-        if (num_rendered) num_rendered[b] = tmp[2 * b + kCntD];
-        if (overflowed) overflowed[b] = tmp[2 * b + kCntOverflow] ? 1 : 0;
+        if (num_rendered) num_rendered[b] = tmp[4 * b + kCntD];
+        if (num_records) num_records[b] = tmp[4 * b + kCntR];
+        if (overflowed) overflowed[b] = (tmp[4 * b + kCntOverflow] ? 1 : 0) | (tmp[4 * b + kCntRecOverflow] ? 2 : 0);
     }
     return DM4D_OK;
 }

@@ -110,8 +110,12 @@ class _RasterizeGaussians(torch.autograd.Function):
             geom = _bytes(geom_bytes, dev)
             _lib.check(L.dm4d_rasterize_prepare(call.settings, call.inputs, _ptr(radii), geom.data_ptr(), geom_bytes,
                                                 st), "dm4d_rasterize_prepare")
-            # the one host sync the upstream operator also has (sizing the duplicate list)
-            D = _lib.check(L.dm4d_rasterize_num_rendered(geom.data_ptr(), st), "dm4d_rasterize_num_rendered")
+            # the one host sync the upstream operator also has (sizing the duplicate list); the same read
+            # returns the number of backward records
+            import ctypes as _C
+            cD, cR = _C.c_int64(0), _C.c_int64(0)
+            _lib.check(L.dm4d_rasterize_counts(geom.data_ptr(), _C.byref(cD), _C.byref(cR), st), "dm4d_rasterize_counts")
+            D, R = int(cD.value), int(cR.value)
             binning = _bytes(L.dm4d_raster_binning_bytes(D), dev)
             image = _bytes(L.dm4d_raster_image_bytes(H, W), dev)
             _lib.check(L.dm4d_rasterize_render(call.settings, call.inputs, _ptr(radii), geom.data_ptr(),
@@ -119,6 +123,7 @@ class _RasterizeGaussians(torch.autograd.Function):
                                                depth.data_ptr(), alpha.data_ptr(), st), "dm4d_rasterize_render")
         ctx.call = call
         ctx.num_rendered = int(D)
+        ctx.num_records = int(R)
         LAST_NUM_RENDERED.append(int(D))
         del LAST_NUM_RENDERED[:-64]
         ctx.shapes = (means3D.shape, means2D.shape, sh.shape, colors_precomp.shape, opacities.shape, scales.shape,
@@ -149,10 +154,11 @@ class _RasterizeGaussians(torch.autograd.Function):
             d_sc = torch.empty(N, 3, **f) if has_sr else None
             d_rot = torch.empty(N, 4, **f) if has_sr else None
             d_cov = torch.empty(N, 6, **f) if not has_sr else None
-            grad = _bytes(L.dm4d_raster_grad_bytes(D, 3), dev)
+            R = ctx.num_records
+            grad = _bytes(L.dm4d_raster_grad_bytes(R, 3), dev)
             _lib.check(L.dm4d_rasterize_backward(
                 call.settings, call.inputs, _ptr(radii), geom.data_ptr(), binning.data_ptr(), D, image.data_ptr(),
-                grad.data_ptr(), g_color.data_ptr(), _ptr(g_depth), _ptr(g_alpha), _ptr(d_m2), _ptr(d_m3),
+                grad.data_ptr(), R, g_color.data_ptr(), _ptr(g_depth), _ptr(g_alpha), _ptr(d_m2), _ptr(d_m3),
                 _ptr(d_op), _ptr(d_col), _ptr(d_sh), _ptr(d_sc), _ptr(d_rot), _ptr(d_cov), st),
                 "dm4d_rasterize_backward")
         ctx.call = None

@@ -33,7 +33,7 @@ class ViewRenderer:
     """Static scene description + capacity policy for ``render_views``."""
 
     def __init__(self, graph: DeformGraph, topo: MeshTopology, image_height, image_width, tanfov, method="hybrid",
-                 scale_modifier=1.0, capacity_factor=6.0):
+                 scale_modifier=1.0, capacity_factor=6.0, record_factor=2.5):
         assert graph.device == topo.device and graph.V == topo.V
         self.graph, self.topo = graph, topo
         self.device = graph.device
@@ -43,6 +43,8 @@ class ViewRenderer:
         self.scale_modifier = float(scale_modifier)
         self.N = topo.F * topo.G
         self.capacity = max(int(capacity_factor * self.N), 1 << 16)
+        # backward records = (Gaussian, 4x4-pixel cell) pairs; ~2 per duplicate for mesh-bound splats
+        self.record_capacity = int(record_factor * self.capacity)
         self.last = None   # (ViewsStruct, keep-alive) of the most recent forward, for check()
         self._ws_pool = []     # recycled (geom, binning, image) workspace sets, keyed by (B, capacity)
         self._scratch = {}     # persistent backward scratch, keyed by (B, capacity)
@@ -64,35 +66,42 @@ class ViewRenderer:
         if len(self._ws_pool) < 4:
             self._ws_pool.append((ws["key"], ws))
 
-    def _bwd_scratch(self, B, capacity):
+    def _bwd_scratch(self, B, record_capacity):
         L = _lib.lib()
-        key = (B, capacity)
+        key = (B, record_capacity)
         if key not in self._scratch:
             g, t, dev = self.graph, self.topo, self.device
             self._scratch = {key: dict(
-                grad=torch.empty(L.dm4d_views_grad_bytes(B, capacity), dtype=torch.uint8, device=dev),
+                grad=torch.empty(L.dm4d_views_grad_bytes(B, record_capacity), dtype=torch.uint8, device=dev),
                 skin=torch.empty(L.dm4d_views_skin_scratch_bytes(B, g.V, g.K), dtype=torch.uint8, device=dev),
                 face=torch.empty(L.dm4d_views_face_scratch_bytes(B, t.F), dtype=torch.uint8, device=dev))}
         return self._scratch[key]
 
     def check(self):
-        """Host check of the duplicate-list capacity (syncs).  Returns num_rendered per view; raises on overflow
-        after doubling the capacity for subsequent calls."""
+        """Host check of the duplicate-list and record capacities (syncs).  Returns num_rendered per view; raises
+        on overflow after enlarging the capacity for subsequent calls."""
         if self.last is None:
             return None
         L = _lib.lib()
         vs, _ = self.last
         B = vs.B
         nr = (C.c_int64 * B)()
+        nrec = (C.c_int64 * B)()
         ov = (C.c_int32 * B)()
         with torch.cuda.device(self.device):
-            _lib.check(L.dm4d_views_counters(C.byref(vs), nr, ov, torch.cuda.current_stream(self.device).cuda_stream),
-                       "dm4d_views_counters")
-        nr = list(nr)
-        if any(ov):
+            _lib.check(L.dm4d_views_counters(C.byref(vs), nr, nrec, ov,
+                                             torch.cuda.current_stream(self.device).cuda_stream), "dm4d_views_counters")
+        nr, nrec = list(nr), list(nrec)
+        self.last_num_records = nrec
+        if any(o & 1 for o in ov):
             self.capacity = int(max(nr) * 1.5) + 1024
+            self.record_capacity = max(self.record_capacity, int(max(nrec) * 1.5) + 1024)
             raise _lib.Dm4dError(f"duplicate list overflow: num_rendered {max(nr)} > capacity; "
                                  f"capacity raised to {self.capacity}, re-run the step")
+        if any(o & 2 for o in ov):
+            self.record_capacity = int(max(nrec) * 1.5) + 1024
+            raise _lib.Dm4dError(f"backward record overflow: {max(nrec)} records > record_capacity; "
+                                 f"raised to {self.record_capacity}, re-run the step")
         return nr
 
 
@@ -114,9 +123,9 @@ class _RenderViews(torch.autograd.Function):
                    rots=torch.empty(B, N, 4, **f), colors=torch.empty(B, N, 6, **f),
                    radii=torch.empty(B, N, dtype=torch.int32, device=dev), color=torch.empty(B, 6, H, W, **f),
                    depth=torch.empty(B, 1, H, W, **f), alpha=torch.empty(B, 1, H, W, **f))
-        cap = r.capacity
+        cap, rcap = r.capacity, r.record_capacity
         ws = r._take_ws(B)
-        vs = ViewsStruct(B, N, t.F, t.G, g.V, g.M, g.K, r.method, H, W, r.tanfov, r.tanfov, r.scale_modifier, cap,
+        vs = ViewsStruct(B, N, t.F, t.G, g.V, g.M, g.K, r.method, H, W, r.tanfov, r.tanfov, r.scale_modifier, cap, rcap,
                          _p(keep["bg"]), _p(keep["vm"]), _p(keep["pm"]), _p(g.verts), _p(g.nbr_idx), _p(g.nbr_w),
                          _p(keep["dx"]), _p(keep["dr"]), _p(keep["ds"]), _p(keep["do"]), _p(t.faces), _p(keep["qs"]),
                          _p(keep["sc"]), _p(keep["op"]), _p(keep["rgb"]), _p(out["vxyz"]), _p(out["vrot"]),
@@ -149,7 +158,7 @@ class _RenderViews(torch.autograd.Function):
                  vr=torch.empty(B, g.V, 4, **f), dx=torch.empty(B, g.M, 3, **f), dr=torch.empty(B, g.M, 4, **f),
                  ds=torch.empty(B, g.M, 6, **f) if ctx.keep["ds"] is not None else None,
                  do=torch.empty(B, g.M, **f) if ctx.keep["do"] is not None else None)
-        scr = r._bwd_scratch(B, vs.capacity)
+        scr = r._bwd_scratch(B, vs.record_capacity)
         gs = ViewsGrads(_p(gc), _p(gd), _p(ga), _p(gx), _p(gr_), _p(g.csr_off), _p(g.csr_items), _p(t.csr_off),
                         _p(t.csr_items), _p(scr["grad"]), _p(scr["skin"]), _p(scr["face"]), _p(o["m2"]), _p(o["m3"]),
                         _p(o["rot"]), _p(o["col"]), _p(o["op"]), _p(o["sc"]), _p(o["vx"]), _p(o["vr"]), _p(o["dx"]),

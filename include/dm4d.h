@@ -95,11 +95,12 @@ typedef struct dm4d_raster_inputs {
 
 /* Workspace sizes (bytes).  geom: per-Gaussian + per-tile state; binning: per
  * (Gaussian,tile) duplicate, `capacity` duplicates; image: per-pixel state;
- * grad: backward scratch for `capacity` duplicates. */
+ * grad: backward scratch for `n_records` (Gaussian, 4x4-pixel cell) records
+ * (dm4d_rasterize_num_records). */
 size_t dm4d_raster_geom_bytes(int32_t N, int32_t image_height, int32_t image_width);
 size_t dm4d_raster_binning_bytes(int64_t capacity);
 size_t dm4d_raster_image_bytes(int32_t image_height, int32_t image_width);
-size_t dm4d_raster_grad_bytes(int64_t capacity, int32_t n_channels);
+size_t dm4d_raster_grad_bytes(int64_t n_records, int32_t n_channels);
 
 /* Stage 1 (no host sync): preprocess every Gaussian, count duplicates per tile, scan.
  * Writes radii[N] and the geom workspace (which must be 16-byte aligned; it need not be
@@ -110,6 +111,12 @@ int dm4d_rasterize_prepare(const dm4d_raster_settings *s, const dm4d_raster_inpu
 
 /* Host read of D: synchronises `stream` (this is the one sync upstream also has). */
 int64_t dm4d_rasterize_num_rendered(const void *geom /* [dev] */, dm4d_stream_t stream);
+/* Host read of R, the number of backward records (sum over the Gaussians of the 4x4-pixel cells their
+ * alpha >= 1/255 support reaches); known after prepare, like D.  Synchronises `stream`. */
+int64_t dm4d_rasterize_num_records(const void *geom /* [dev] */, dm4d_stream_t stream);
+/* Both with one synchronisation. */
+int dm4d_rasterize_counts(const void *geom /* [dev] */, int64_t *num_rendered, int64_t *num_records,
+                          dm4d_stream_t stream);
 
 /* Stage 2: scatter duplicates into per-tile segments, sort every tile by
  * (depth bits, Gaussian id) -- the order of a stable radix sort of tile<<32|depth --,
@@ -126,11 +133,11 @@ int dm4d_rasterize_overflowed(const void *geom, dm4d_stream_t stream);
 
 /* Backward of prepare+render.  dL_ddepth / dL_dalpha may be NULL (treated as zero).
  * Output gradient pointers may be NULL when not wanted, except dL_dmeans2D and
- * dL_dmeans3D.  `grad` is scratch of dm4d_raster_grad_bytes(capacity).
+ * dL_dmeans3D.  `grad` is scratch of dm4d_raster_grad_bytes(record_capacity), record_capacity >= R.
  * Deterministic: no floating-point atomics anywhere. */
 int dm4d_rasterize_backward(const dm4d_raster_settings *s, const dm4d_raster_inputs *in,
                             const int32_t *radii, const void *geom, const void *binning, int64_t capacity,
-                            const void *image, void *grad,
+                            const void *image, void *grad, int64_t record_capacity,
                             const float *dL_dcolor /* [C,H,W] */, const float *dL_ddepth /* [H,W] */,
                             const float *dL_dalpha /* [H,W] */,
                             float *dL_dmeans2D /* [N,3] */, float *dL_dmeans3D /* [N,3] */,
@@ -160,10 +167,6 @@ int dm4d_raster_read_geom(const void *geom, int32_t N, int32_t image_height, int
 int dm4d_raster_read_image_state(const void *image, int32_t image_height, int32_t image_width,
                                  uint32_t *n_contrib /* [host][H,W] */, float *final_T /* [host][H,W] */,
                                  dm4d_stream_t stream);
-
-/* Self-test of the packed 64-lane reduction used by the backward blend kernel:
- * in [16][64] floats, out [16] (device pointers); out[i] = sum_l in[i][l]. */
-int dm4d_selftest_wave_reduce(const float *in, float *out, dm4d_stream_t stream);
 
 /* markVisible: present[i] = view-space z > 0.2 */
 int dm4d_mark_visible(int32_t N, const float *means3D, const float *viewmatrix, uint8_t *present,
@@ -257,6 +260,7 @@ typedef struct dm4d_views {
     int32_t image_height, image_width;
     float tanfovx, tanfovy, scale_modifier;
     int64_t capacity;                          /* duplicates per view the binning workspace can hold */
+    int64_t record_capacity;                   /* backward records per view the grad scratch can hold */
     const float *bg;                           /* [6]   */
     const float *viewmatrix, *projmatrix;      /* [B,16] each, row-vector convention */
     const float *verts;                        /* [V,3] static vertices */
@@ -291,13 +295,15 @@ typedef struct dm4d_views_grads {
 size_t dm4d_views_geom_bytes(int32_t B, int32_t N, int32_t image_height, int32_t image_width);
 size_t dm4d_views_binning_bytes(int32_t B, int64_t capacity);
 size_t dm4d_views_image_bytes(int32_t B, int32_t image_height, int32_t image_width);
-size_t dm4d_views_grad_bytes(int32_t B, int64_t capacity);
+size_t dm4d_views_grad_bytes(int32_t B, int64_t record_capacity);
 size_t dm4d_views_skin_scratch_bytes(int32_t B, int32_t V, int32_t K);
 size_t dm4d_views_face_scratch_bytes(int32_t B, int32_t F);
 int dm4d_views_forward(const dm4d_views *v, dm4d_stream_t stream);
 int dm4d_views_backward(const dm4d_views *v, const dm4d_views_grads *g, dm4d_stream_t stream);
-/* num_rendered[b], overflowed[b] of the last forward (host arrays of B; synchronises the stream). */
-int dm4d_views_counters(const dm4d_views *v, int64_t *num_rendered, int32_t *overflowed, dm4d_stream_t stream);
+/* num_rendered[b], num_records[b], overflowed[b] (bit 0: duplicates > capacity, bit 1: records >
+ * record_capacity) of the last forward (host arrays of B, any may be NULL; synchronises the stream). */
+int dm4d_views_counters(const dm4d_views *v, int64_t *num_rendered, int64_t *num_records, int32_t *overflowed,
+                        dm4d_stream_t stream);
 
 #ifdef __cplusplus
 }

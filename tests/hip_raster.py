@@ -44,6 +44,7 @@ class HipRaster:
         self.geom = torch.empty(gb, dtype=torch.uint8, device=dev)
         _lib.check(L.dm4d_rasterize_prepare(self.settings, self.inputs, _p(self.radii), _p(self.geom), gb, st), "prepare")
         self.D = _lib.check(L.dm4d_rasterize_num_rendered(_p(self.geom), st), "num_rendered")
+        self.R = _lib.check(L.dm4d_rasterize_num_records(_p(self.geom), st), "num_records")
         self.cap = self.D if capacity is None else capacity
         self.binning = torch.empty(L.dm4d_raster_binning_bytes(self.cap), dtype=torch.uint8, device=dev)
         self.image = torch.empty(L.dm4d_raster_image_bytes(H, W), dtype=torch.uint8, device=dev)
@@ -78,7 +79,7 @@ class HipRaster:
         s["keys"], s["values"] = s["keys"][:self.D], s["values"][:self.D]
         return s
 
-    def backward(self, gC, gD=None, gA=None):
+    def backward(self, gC, gD=None, gA=None, record_capacity=None):
         L, dev, N = self.L, self.dev, self.N
         t = lambda a: None if a is None else torch.tensor(np.asarray(a, np.float32), device=dev).contiguous()
         gC, gD, gA = t(gC), t(gD), t(gA)
@@ -88,10 +89,11 @@ class HipRaster:
         o = {"dL_dmeans2D": z(N, 3), "dL_dmeans3D": z(N, 3), "dL_dopacity": z(N), "dL_dcolors": z(N, self.C),
              "dL_dsh": z(N, M, 3) if M else None, "dL_dscales": z(N, 3) if has_sr else None,
              "dL_drots": z(N, 4) if has_sr else None, "dL_dcov3D": z(N, 6)}
-        grad = torch.empty(L.dm4d_raster_grad_bytes(self.cap, self.C), dtype=torch.uint8, device=dev)
+        rcap = self.R if record_capacity is None else record_capacity
+        grad = torch.empty(L.dm4d_raster_grad_bytes(rcap, self.C), dtype=torch.uint8, device=dev)
         st = torch.cuda.current_stream(dev).cuda_stream
         _lib.check(L.dm4d_rasterize_backward(self.settings, self.inputs, _p(self.radii), _p(self.geom),
-                                             _p(self.binning), self.cap, _p(self.image), _p(grad), _p(gC), _p(gD),
+                                             _p(self.binning), self.cap, _p(self.image), _p(grad), rcap, _p(gC), _p(gD),
                                              _p(gA), _p(o["dL_dmeans2D"]), _p(o["dL_dmeans3D"]), _p(o["dL_dopacity"]),
                                              _p(o["dL_dcolors"]), _p(o["dL_dsh"]), _p(o["dL_dscales"]),
                                              _p(o["dL_drots"]), _p(o["dL_dcov3D"]), st), "backward")

@@ -25,7 +25,7 @@ def test_workspace_size_queries_are_monotone_and_aligned():
     assert 0 < a < b and a % 256 == 0 and b % 256 == 0
     assert L.dm4d_raster_binning_bytes(0) > 0
     assert L.dm4d_raster_binning_bytes(10) <= L.dm4d_raster_binning_bytes(1_000_000)
-    assert L.dm4d_raster_grad_bytes(1_000_000, 3) >= 1_000_000 * 40
+    assert L.dm4d_raster_grad_bytes(1_000_000, 3) >= 1_000_000 * 40     # 10 floats per (Gaussian, cell) record
     assert L.dm4d_raster_grad_bytes(1_000_000, 6) > L.dm4d_raster_grad_bytes(1_000_000, 3)
     assert L.dm4d_raster_image_bytes(512, 512) >= 512 * 512 * 8
 
