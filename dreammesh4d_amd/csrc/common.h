@@ -57,6 +57,39 @@ __device__ __forceinline__ float det_expf(float x)
     return __builtin_ldexpf(p, (int)n);
 }
 
+// U independent det_expf evaluations written step-by-step across the U values, so that the instruction stream
+// itself interleaves the U dependency chains (a lone wave issues dependent VALU ops far slower than
+// independent ones).  Bit-identical to det_expf per element.
+template <int U>
+__device__ __forceinline__ void det_expf_n(const float (&xin)[U], float (&out)[U])
+{
+    const float L2E_HI = 0x1.715476p+0f;
+    const float L2E_LO = 0x1.4ae0c0p-26f;
+    float x[U], n[U], f[U], p[U];
+#pragma unroll
+    for (int j = 0; j < U; ++j) x[j] = fmaxf(xin[j], -87.0f);
+#pragma unroll
+    for (int j = 0; j < U; ++j) n[j] = __builtin_rintf(x[j] * L2E_HI);
+#pragma unroll
+    for (int j = 0; j < U; ++j) f[j] = __builtin_fmaf(x[j], L2E_HI, -n[j]);
+#pragma unroll
+    for (int j = 0; j < U; ++j) f[j] = __builtin_fmaf(x[j], L2E_LO, f[j]);
+#pragma unroll
+    for (int j = 0; j < U; ++j) p[j] = __builtin_fmaf(0x1.446c7ep-13f, f[j], 0x1.5f48c8p-10f);
+#pragma unroll
+    for (int j = 0; j < U; ++j) p[j] = __builtin_fmaf(p[j], f[j], 0x1.3b29d8p-7f);
+#pragma unroll
+    for (int j = 0; j < U; ++j) p[j] = __builtin_fmaf(p[j], f[j], 0x1.c6aeccp-5f);
+#pragma unroll
+    for (int j = 0; j < U; ++j) p[j] = __builtin_fmaf(p[j], f[j], 0x1.ebfbe0p-3f);
+#pragma unroll
+    for (int j = 0; j < U; ++j) p[j] = __builtin_fmaf(p[j], f[j], 0x1.62e430p-1f);
+#pragma unroll
+    for (int j = 0; j < U; ++j) p[j] = __builtin_fmaf(p[j], f[j], 1.0f);
+#pragma unroll
+    for (int j = 0; j < U; ++j) out[j] = __builtin_ldexpf(p[j], (int)n[j]);
+}
+
 __device__ __forceinline__ int f2i_sat(float v)
 {
     if (!(v > -1073741824.0f)) return -1073741824;

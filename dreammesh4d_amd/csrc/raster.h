@@ -44,7 +44,7 @@ DM4D_HD static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) /
 struct GeomLayout {
     int N, T, nb;
     size_t counters, xy, depth, conic_opacity, rgb, tiles_touched, offsets, rec_touched, rec_offsets, clamped,
-        block_sums, rec_block_sums, hist, tile_count, tile_start, ccount, cdone, ckmax, zero_begin, zero_bytes, total;
+        block_sums, rec_block_sums, hist, tile_count, tile_start, ccount, cdone, ckmax, order, zero_begin, zero_bytes, total;
 };
 
 DM4D_HD static inline size_t take_(size_t &o, size_t bytes) { size_t r = o; o = align_up(o + bytes, 256); return r; }
@@ -67,6 +67,7 @@ DM4D_HD static inline GeomLayout geom_layout(int N, int H, int W)
     L.ccount = take_(o, (size_t)L.T * kCells * 4);   // entries of each cell list                  [T][16]
     L.cdone = take_(o, (size_t)L.T * kCells * 4);    // entries the forward consumed               [T][16]
     L.ckmax = take_(o, (size_t)L.T * kCells * 4);    // tile-list position bound of those entries  [T][16]
+    L.order = take_(o, (size_t)L.T * 4);             // tiles by descending list length (blend launch order)
     L.xy = take_(o, n * 8);
     L.depth = take_(o, n * 4);
     L.conic_opacity = take_(o, n * 16);
@@ -102,6 +103,7 @@ struct GeomPtrs {
     uint32_t *ccount;
     uint32_t *cdone;
     uint32_t *ckmax;
+    uint32_t *order;
 };
 
 DM4D_HD static inline GeomPtrs geom_ptrs(void *base, const GeomLayout &L)
@@ -126,6 +128,7 @@ DM4D_HD static inline GeomPtrs geom_ptrs(void *base, const GeomLayout &L)
     p.ccount = (uint32_t *)(b + L.ccount);
     p.cdone = (uint32_t *)(b + L.cdone);
     p.ckmax = (uint32_t *)(b + L.ckmax);
+    p.order = (uint32_t *)(b + L.order);
     return p;
 }
 
@@ -340,11 +343,12 @@ DM4D_HD static inline ViewCtx resolve(const BatchDesc &d, int b)
 int launch_preprocess(const BatchDesc &d, hipStream_t st);
 int launch_colscan(const BatchDesc &d, hipStream_t st);
 int launch_scatter(const BatchDesc &d, hipStream_t st);
-int launch_tile_sort(const BatchDesc &d, hipStream_t st);
+int launch_tile_sort(const BatchDesc &d, hipStream_t st);   // + the tile order for the blend kernels
 int launch_render_fwd(const BatchDesc &d, hipStream_t st);
 int launch_render_bwd(const BatchDesc &d, hipStream_t st);
 int launch_gather_bwd(const BatchDesc &d, hipStream_t st);
 int launch_zero_counters(const BatchDesc &d, hipStream_t st);
+int set_trace_buffer(void *dev_ptr, uint32_t min_work);
 int launch_mark_visible(int N, const float *means3D, const float *view, uint8_t *present, hipStream_t st);
 
 }  // namespace dm4d

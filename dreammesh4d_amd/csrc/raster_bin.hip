@@ -308,6 +308,59 @@ __global__ __launch_bounds__(kSortThreads) void k_tile_sort(BatchDesc d)
     }
 }
 
+// ---------------------------------------------------------------------------------------- K4b
+// Launch order of the blend kernels: the (view, tile) pairs of the WHOLE batch by DESCENDING cell-list
+// length (longest-processing-time first).  A wave walks its lists serially, so the longest list
+// (silhouette cells: > 1000 entries against a mean of 85) bounds the kernel from below; started
+// last it runs alone at the end, started first it overlaps with everything else.  One workgroup,
+// 256-bucket counting sort; rank i is stored in the geom workspace of view i / T, slot i % T, as
+// view << 16 | tile.
+__device__ __forceinline__ uint32_t *order_slot(const BatchDesc &d, const GeomLayout &L, uint32_t rank)
+{
+    return reinterpret_cast<uint32_t *>(d.geom + (size_t)(rank / (uint32_t)L.T) * d.geom_stride + L.order) +
+           rank % (uint32_t)L.T;
+}
+constexpr int kOrderThreads = 1024;
+__global__ __launch_bounds__(kOrderThreads) void k_tile_order(BatchDesc d)
+{
+    __shared__ uint32_t s_hist[256], s_cur[256], s_max;
+    const GeomLayout L = geom_layout(d.N, d.H, d.W);
+    const int T = L.T, tid = threadIdx.x;
+    const uint32_t n = (uint32_t)d.B * (uint32_t)T;
+    auto weight = [&](uint32_t i) {
+        const uint32_t v = i / (uint32_t)T, t = i % (uint32_t)T;
+        const uint4 *p = reinterpret_cast<const uint4 *>(d.geom + (size_t)v * d.geom_stride + L.ccount) + (size_t)t * (kCells / 4);
+        uint32_t w = 0;
+#pragma unroll
+        for (int k = 0; k < kCells / 4; ++k) {
+            const uint4 x = p[k];
+            w = max(max(w, x.x), max(max(x.y, x.z), x.w));
+        }
+        return w;
+    };
+    if (tid == 0) s_max = 1u;
+    if (tid < 256) s_hist[tid] = 0u;
+    __syncthreads();
+    uint32_t wmax = 0;
+    for (uint32_t i = tid; i < n; i += kOrderThreads) wmax = max(wmax, weight(i));
+    wmax = wave_max_u32(wmax);
+    if ((tid & 63) == 0) atomicMax(&s_max, wmax);
+    __syncthreads();
+    const float scale = 255.0f / (float)s_max;
+    auto bucket = [&](uint32_t w) { return 255 - min(255, (int)((float)w * scale)); };
+    for (uint32_t i = tid; i < n; i += kOrderThreads) atomicAdd(&s_hist[bucket(weight(i))], 1u);
+    __syncthreads();
+    if (tid == 0) {
+        uint32_t run = 0;
+        for (int b = 0; b < 256; ++b) { s_cur[b] = run; run += s_hist[b]; }
+    }
+    __syncthreads();
+    for (uint32_t i = tid; i < n; i += kOrderThreads) {
+        const uint32_t rank = atomicAdd(&s_cur[bucket(weight(i))], 1u);
+        *order_slot(d, L, rank) = ((i / (uint32_t)T) << 16) | (i % (uint32_t)T);
+    }
+}
+
 int launch_colscan(const BatchDesc &d, hipStream_t st)
 {
     const int T = ((d.W + kTile - 1) / kTile) * ((d.H + kTile - 1) / kTile);
@@ -324,6 +377,8 @@ int launch_tile_sort(const BatchDesc &d, hipStream_t st)
     if (T <= 0) return DM4D_OK;
     ProfScope prof_(kKTileSort, st);
     hipLaunchKernelGGL(k_tile_sort, dim3(T, d.B), dim3(kSortThreads), 0, st, d);
+    DM4D_HIP_CHECK(hipGetLastError());
+    hipLaunchKernelGGL(k_tile_order, dim3(1), dim3(kOrderThreads), 0, st, d);
     DM4D_HIP_CHECK(hipGetLastError());
     return DM4D_OK;
 }

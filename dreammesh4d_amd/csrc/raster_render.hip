@@ -35,8 +35,36 @@
 
 namespace dm4d {
 
+// ---- optional per-wave trace (dm4d_debug_trace): {start, end} in 100 MHz wall-clock ticks, HW_ID, XCC_ID ----
+__device__ uint64_t *g_trace = nullptr;
+__device__ uint32_t g_min_work = 0;   // debug: waves with shorter lists exit at once (isolates the long ones)
+struct WaveTrace {
+    uint64_t *buf, t0;
+    __device__ __forceinline__ WaveTrace() : buf(g_trace), t0(0) { if (buf) t0 = wall_clock64(); }
+    __device__ __forceinline__ void done(uint32_t work) const
+    {
+        if (!buf || threadIdx.x != 0) return;
+        uint64_t *r = buf + 4 * ((size_t)blockIdx.y * gridDim.x + blockIdx.x);
+        uint32_t hw, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        r[0] = t0;
+        r[1] = wall_clock64();
+        r[2] = ((uint64_t)xcc << 32) | hw;
+        r[3] = work;
+    }
+};
+int set_trace_buffer(void *dev_ptr, uint32_t min_work)
+{
+    uint64_t *p = (uint64_t *)dev_ptr;
+    DM4D_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_trace), &p, sizeof(p)));
+    DM4D_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_min_work), &min_work, sizeof(min_work)));
+    return DM4D_OK;
+}
+
 template <int C> struct StagedN { static constexpr int kVec = (C <= 3) ? 3 : 4; };
 constexpr int kChunk = 16;   // list entries a row stages per step (one per lane of the row)
+constexpr int kFwdUnroll = 4, kBwdUnroll = 2;   // entries per inner-loop step (divide kChunk)
 
 // gather one list entry: a = (x, y, conic.x, conic.y)  b = (conic.z, opacity, depth, k bits)
 //                        c = colours 0..3               d = colours 4..5
@@ -69,11 +97,29 @@ __device__ __forceinline__ void zero_entry(float4 (&r)[4])
     for (int v = 0; v < 4; ++v) r[v] = make_float4(0.f, 0.f, 0.f, 0.f);
 }
 
-__device__ __forceinline__ void block_to_quadrant(int b, int &tile, int &q)
+// block -> (view, tile, quadrant): rank in the batch-wide launch order of K4b (longest lists first); the four
+// quadrants of a tile are blocks b, b+8, b+16, b+24 (same XCD).  Returns false past the end.
+__device__ __forceinline__ bool block_to_quadrant(const BatchDesc &d, int b, int &view, int &tile, int &q)
 {
     const int xcd = b & 7, r = b >> 3;
     q = r & 3;
-    tile = (r >> 2) * 8 + xcd;
+    const uint32_t rank = (uint32_t)((r >> 2) * 8 + xcd);
+    const int T = ((d.W + kTile - 1) / kTile) * ((d.H + kTile - 1) / kTile);
+    if (rank >= (uint32_t)d.B * (uint32_t)T) return false;
+    const GeomLayout L = geom_layout(d.N, d.H, d.W);
+    const uint32_t item = reinterpret_cast<const uint32_t *>(d.geom + (size_t)(rank / (uint32_t)T) * d.geom_stride + L.order)[rank % (uint32_t)T];
+    view = (int)(item >> 16);
+    tile = (int)(item & 0xFFFFu);
+    return true;
+}
+// Waves with long lists raise their issue priority: while the bulk of the (short) waves keeps the SIMD
+// saturated a wave only gets a fair share of the issue slots, so the long waves -- started first by K4b --
+// would still finish last.  With priority they run at lone-wave speed from the start.
+__device__ __forceinline__ void set_priority_by_length(uint32_t n)
+{
+    if (n >= 384u) __builtin_amdgcn_s_setprio(3);
+    else if (n >= 192u) __builtin_amdgcn_s_setprio(2);
+    else if (n >= 128u) __builtin_amdgcn_s_setprio(1);
 }
 __device__ __forceinline__ uint32_t row_max_u32(uint32_t v)
 {
@@ -106,7 +152,10 @@ __global__ __launch_bounds__(64) void k_render_fwd(BatchDesc d)
     // one wave-private staging buffer: the next chunk waits in registers (prefetched during the
     // blend loop) and is written after the loop -- same wave, program order, no hazard
     __shared__ float4 s_e[4][kChunk][NV];
-    const ViewCtx c = resolve(d, blockIdx.y);
+    const WaveTrace trace;
+    int view, tile, q;
+    if (!block_to_quadrant(d, blockIdx.x, view, tile, q)) { trace.done(0); return; }
+    const ViewCtx c = resolve(d, view);
     const ViewParams &vp = c.vp;
     const float *__restrict__ colors = c.colors;
     const GeomPtrs &g = c.g;
@@ -115,10 +164,6 @@ __global__ __launch_bounds__(64) void k_render_fwd(BatchDesc d)
     const ImgPtrs &im = c.im;
     float *__restrict__ out_color = c.out_color, *__restrict__ out_depth = c.out_depth,
                        *__restrict__ out_alpha = c.out_alpha;
-    const int T = c.T;
-    int tile, q;
-    block_to_quadrant(blockIdx.x, tile, q);
-    if (tile >= T) return;
     const int lane = threadIdx.x;
     const int tx = tile % vp.gx, ty = tile / vp.gx;
     const LanePixel lp = lane_pixel(lane, tx, ty, q);
@@ -129,6 +174,8 @@ __global__ __launch_bounds__(64) void k_render_fwd(BatchDesc d)
     const uint32_t s = g.tile_start[tile];
     const uint32_t nr = (s < cap) ? g.ccount[tile * kCells + lp.cell] : 0u;   // this row's list length
     const uint32_t nmax = wave_max_u32(nr);
+    set_priority_by_length(nmax);
+    if (nmax < g_min_work) { trace.done(0); return; }
     const uint2 *__restrict__ list = b.clist + (size_t)lp.cell * b.cap + s;
 
     float T_ = 1.0f, D = 0.f, Wt = 0.f;
@@ -152,33 +199,63 @@ __global__ __launch_bounds__(64) void k_render_fwd(BatchDesc d)
         if (__ballot((!done) & (cnt > 0)) == 0) break;   // every pixel with entries left is saturated
         int t = 0;
         do {
-            // Branch-free body (selects, not exec-mask branches): lanes that do not take the entry
-            // blend with weight 0, which leaves their accumulators bit-identical.
-            const float4 ea = s_e[row][t][0], eb = s_e[row][t][1], ec = s_e[row][t][2];
-            const float dx = ea.x - pxf, dy = ea.y - pyf;
-            const float power = -0.5f * ((ea.z * dx) * dx + (eb.x * dy) * dy) - (ea.w * dx) * dy;
-            const float alpha = fminf(0.99f, eb.y * det_expf(power));
-            const float test_T = T_ * (1.0f - alpha);
-            const bool valid = (!done) & (power <= 0.0f) & (alpha >= 1.0f / 255.0f);
-            const bool stop = valid & (test_T < 0.0001f);
-            const bool contrib = valid & (!stop);
-            const float w = contrib ? alpha * T_ : 0.f;
-            Cacc[0] = __builtin_fmaf(ec.x, w, Cacc[0]);
-            Cacc[1] = __builtin_fmaf(ec.y, w, Cacc[1]);
-            Cacc[2] = __builtin_fmaf(ec.z, w, Cacc[2]);
-            if (C > 3) {
-                const float4 ed = s_e[row][t][NV - 1];
-                Cacc[3] = __builtin_fmaf(ec.w, w, Cacc[3]);
-                Cacc[C > 4 ? 4 : 0] = __builtin_fmaf(ed.x, w, Cacc[C > 4 ? 4 : 0]);
-                Cacc[C > 5 ? 5 : 0] = __builtin_fmaf(ed.y, w, Cacc[C > 5 ? 5 : 0]);
+            // kFwdUnroll entries per step: their alphas are independent (a lone wave on a long silhouette list is
+            // bound by the ~25-deep dependent chain of one alpha, not by issue), the blend below is sequential.
+            // Branch-free (selects, not exec-mask branches): lanes that do not take an entry blend with
+            // weight 0, which leaves their accumulators bit-identical; padding entries are inert.
+            float al[kFwdUnroll], pw[kFwdUnroll], ex[kFwdUnroll], op[kFwdUnroll];
+            bool ok[kFwdUnroll];
+            {
+                float dx[kFwdUnroll], dy[kFwdUnroll], qa[kFwdUnroll], qb[kFwdUnroll], qc[kFwdUnroll];
+#pragma unroll
+                for (int j = 0; j < kFwdUnroll; ++j) {
+                    const float4 ea = s_e[row][t + j][0], eb = s_e[row][t + j][1];
+                    dx[j] = ea.x - pxf;
+                    dy[j] = ea.y - pyf;
+                    qa[j] = ea.z; qb[j] = ea.w; qc[j] = eb.x; op[j] = eb.y;
+                }
+                float u[kFwdUnroll], v[kFwdUnroll], w2[kFwdUnroll];
+#pragma unroll
+                for (int j = 0; j < kFwdUnroll; ++j) { u[j] = qa[j] * dx[j]; v[j] = qc[j] * dy[j]; w2[j] = qb[j] * dx[j]; }
+#pragma unroll
+                for (int j = 0; j < kFwdUnroll; ++j) { u[j] = u[j] * dx[j]; v[j] = v[j] * dy[j]; w2[j] = w2[j] * dy[j]; }
+#pragma unroll
+                for (int j = 0; j < kFwdUnroll; ++j) u[j] = u[j] + v[j];
+#pragma unroll
+                for (int j = 0; j < kFwdUnroll; ++j) pw[j] = -0.5f * u[j] - w2[j];
             }
-            D = __builtin_fmaf(eb.z, w, D);
-            Wt = Wt + w;
-            T_ = contrib ? test_T : T_;
-            last = contrib ? __float_as_uint(eb.w) + 1u : last;
-            lastj = contrib ? c0 + (uint32_t)t + 1u : lastj;
-            done = done | stop;
-        } while (++t < kChunk && __ballot((!done) & (t < cnt)) != 0);
+            det_expf_n<kFwdUnroll>(pw, ex);
+#pragma unroll
+            for (int j = 0; j < kFwdUnroll; ++j) al[j] = fminf(0.99f, op[j] * ex[j]);
+#pragma unroll
+            for (int j = 0; j < kFwdUnroll; ++j) ok[j] = (pw[j] <= 0.0f) & (al[j] >= 1.0f / 255.0f);
+#pragma unroll
+            for (int j = 0; j < kFwdUnroll; ++j) {
+                const float4 eb = s_e[row][t + j][1], ec = s_e[row][t + j][2];
+                const float alpha = al[j];
+                const float test_T = T_ * (1.0f - alpha);
+                const bool valid = (!done) & ok[j];
+                const bool stop = valid & (test_T < 0.0001f);
+                const bool contrib = valid & (!stop);
+                const float w = contrib ? alpha * T_ : 0.f;
+                Cacc[0] = __builtin_fmaf(ec.x, w, Cacc[0]);
+                Cacc[1] = __builtin_fmaf(ec.y, w, Cacc[1]);
+                Cacc[2] = __builtin_fmaf(ec.z, w, Cacc[2]);
+                if (C > 3) {
+                    const float4 ed = s_e[row][t + j][NV - 1];
+                    Cacc[3] = __builtin_fmaf(ec.w, w, Cacc[3]);
+                    Cacc[C > 4 ? 4 : 0] = __builtin_fmaf(ed.x, w, Cacc[C > 4 ? 4 : 0]);
+                    Cacc[C > 5 ? 5 : 0] = __builtin_fmaf(ed.y, w, Cacc[C > 5 ? 5 : 0]);
+                }
+                D = __builtin_fmaf(eb.z, w, D);
+                Wt = Wt + w;
+                T_ = contrib ? test_T : T_;
+                last = contrib ? __float_as_uint(eb.w) + 1u : last;
+                lastj = contrib ? c0 + (uint32_t)(t + j) + 1u : lastj;
+                done = done | stop;
+            }
+            t += kFwdUnroll;
+        } while (t < kChunk && __ballot((!done) & (t < cnt)) != 0);
     }
     if (inside) {
         const size_t P = (size_t)vp.H * vp.W;
@@ -195,6 +272,7 @@ __global__ __launch_bounds__(64) void k_render_fwd(BatchDesc d)
         g.cdone[tile * kCells + lp.cell] = wj;
         g.ckmax[tile * kCells + lp.cell] = wk;
     }
+    trace.done(nmax);
 }
 
 // ---------------------------------------------------------------------------------------- B1
@@ -208,8 +286,11 @@ __global__ __launch_bounds__(64) void k_render_bwd(BatchDesc d)
     constexpr int RS = 7 + C;   // == grad_stride(C): floats per record
     __shared__ float4 s_e[4][kChunk][NV];
     __shared__ uint32_t s_slot[4][kChunk];
-    __shared__ __attribute__((aligned(16))) float s_red[RS][kRedStride];
-    const ViewCtx c = resolve(d, blockIdx.y);
+    __shared__ __attribute__((aligned(16))) float s_red[kBwdUnroll][RS][kRedStride];
+    const WaveTrace trace;
+    int view, tile, q;
+    if (!block_to_quadrant(d, blockIdx.x, view, tile, q)) { trace.done(0); return; }
+    const ViewCtx c = resolve(d, view);
     const ViewParams &vp = c.vp;
     const float *__restrict__ colors = c.colors;
     const GeomPtrs &g = c.g;
@@ -220,10 +301,6 @@ __global__ __launch_bounds__(64) void k_render_bwd(BatchDesc d)
                              *__restrict__ dL_dalpha = c.dL_dalpha;
     float *__restrict__ rec = c.dLq;
     const uint32_t rec_cap = c.rec_cap;
-    const int T = c.T;
-    int tile, q;
-    block_to_quadrant(blockIdx.x, tile, q);
-    if (tile >= T) return;
     const int lane = threadIdx.x;
     const int tx = tile % vp.gx, ty = tile / vp.gx;
     const LanePixel lp = lane_pixel(lane, tx, ty, q);
@@ -234,7 +311,8 @@ __global__ __launch_bounds__(64) void k_render_bwd(BatchDesc d)
     const uint32_t s = g.tile_start[tile];
     const uint32_t nd = (s < cap) ? g.cdone[tile * kCells + lp.cell] : 0u;   // entries this row's forward consumed
     const uint32_t ndmax = wave_max_u32(nd);
-    if (ndmax == 0) return;
+    if (ndmax == 0 || ndmax < g_min_work) { trace.done(0); return; }
+    set_priority_by_length(ndmax);
     const uint2 *__restrict__ list = b.clist + (size_t)lp.cell * b.cap + s;
     const uint32_t *__restrict__ slots = b.cslot + (size_t)lp.cell * b.cap + s;
 
@@ -261,7 +339,8 @@ __global__ __launch_bounds__(64) void k_render_bwd(BatchDesc d)
     const float half_W = 0.5f * (float)vp.W, half_H = 0.5f * (float)vp.H;
     // reduction role of this lane: value li of its row (lanes with li >= RS idle in the sum)
     const int red_i = li < RS ? li : 0;
-    const float4 *red_src = reinterpret_cast<const float4 *>(&s_red[red_i][row * 16]);
+    const float4 *red_src = reinterpret_cast<const float4 *>(&s_red[0][red_i][row * 16]);
+    constexpr int kRedBuf4 = RS * kRedStride / 4;   // float4 per reduction buffer
 
     const uint32_t c_last = ((ndmax - 1) / kChunk) * kChunk;
     float4 r[4];
@@ -284,66 +363,86 @@ __global__ __launch_bounds__(64) void k_render_bwd(BatchDesc d)
             rslot = slots[c0 - kChunk + li];
         }
         __builtin_amdgcn_wave_barrier();
-        for (int t = tmax - 1; t >= 0; --t) {
-            const float4 ea = s_e[row][t][0], eb = s_e[row][t][1];
-            const uint32_t k = __float_as_uint(eb.w);
-            // Branch-free: lanes that do not take the entry contribute exact zeros.
-            const float dx = ea.x - pxf, dy = ea.y - pyf;
-            const float power = -0.5f * ((ea.z * dx) * dx + (eb.x * dy) * dy) - (ea.w * dx) * dy;
-            const float Gr = det_expf(power);
-            const float alpha = fminf(0.99f, eb.y * Gr);
-            const bool contrib = (k < last) & (power <= 0.0f) & (alpha >= 1.0f / 255.0f);
-            const float4 ec = s_e[row][t][2];
-            float col[C];
-            col[0] = ec.x; col[1] = ec.y; col[2] = ec.z;
-            if (C > 3) {
-                const float4 ed = s_e[row][t][NV - 1];
-                col[3] = ec.w;
-                col[C > 4 ? 4 : 0] = ed.x;
-                col[C > 5 ? 5 : 0] = ed.y;
+        // kBwdUnroll entries per step (aligned groups, highest first; slots past the row's count hold inert
+        // padding): independent alphas overlap, and one LDS round trip serves the whole group.
+        for (int tg = ((tmax - 1) / kBwdUnroll) * kBwdUnroll; tg >= 0; tg -= kBwdUnroll) {
+            float Gr_[kBwdUnroll], al_[kBwdUnroll], dx_[kBwdUnroll], dy_[kBwdUnroll];
+            bool ok_[kBwdUnroll];
+#pragma unroll
+            for (int j = 0; j < kBwdUnroll; ++j) {
+                const int t = tg + kBwdUnroll - 1 - j;
+                const float4 ea = s_e[row][t][0], eb = s_e[row][t][1];
+                dx_[j] = ea.x - pxf;
+                dy_[j] = ea.y - pyf;
+                const float power = -0.5f * ((ea.z * dx_[j]) * dx_[j] + (eb.x * dy_[j]) * dy_[j]) - (ea.w * dx_[j]) * dy_[j];
+                Gr_[j] = det_expf(power);
+                al_[j] = fminf(0.99f, eb.y * Gr_[j]);
+                ok_[j] = (__float_as_uint(eb.w) < last) & (power <= 0.0f) & (al_[j] >= 1.0f / 255.0f);
             }
-            const float G = contrib ? Gr : 0.f;
-            const float inv_om = __builtin_amdgcn_rcpf(1.f - alpha);
-            const float Tn = T_ * inv_om;
-            T_ = contrib ? Tn : T_;
-            const float w = contrib ? alpha * Tn : 0.f;
-            float V = gA + eb.z * gD;
-#pragma unroll
-            for (int ch = 0; ch < C; ++ch) V = __builtin_fmaf(col[ch], gCol[ch], V);
-            const float dL_da = contrib ? (Tn * V - (S + Tb) * inv_om) : 0.f;
-            S = __builtin_fmaf(V, w, S);
-            const float dL_dG = eb.y * dL_da;
-            const float gdx = G * dx, gdy = G * dy;
-            float v[RS];
-            v[0] = dL_dG * (-gdx * ea.z - gdy * ea.w) * half_W;
-            v[1] = dL_dG * (-gdy * eb.x - gdx * ea.w) * half_H;
-            v[2] = -0.5f * gdx * dx * dL_dG;
-            v[3] = -gdx * dy * dL_dG;
-            v[4] = -0.5f * gdy * dy * dL_dG;
-            v[5] = G * dL_da;
-            v[6] = w * gD;
-#pragma unroll
-            for (int ch = 0; ch < C; ++ch) v[7 + ch] = w * gCol[ch];
-            // transposed reduction: [value][lane] in LDS, lane i of the row sums value i over the row
             __builtin_amdgcn_wave_barrier();
 #pragma unroll
-            for (int i = 0; i < RS; ++i) s_red[i][lane] = v[i];
+            for (int j = 0; j < kBwdUnroll; ++j) {
+                const int t = tg + kBwdUnroll - 1 - j;
+                const float4 ea = s_e[row][t][0], eb = s_e[row][t][1], ec = s_e[row][t][2];
+                // Branch-free: lanes that do not take the entry contribute exact zeros.
+                const float dx = dx_[j], dy = dy_[j], alpha = al_[j];
+                const bool contrib = ok_[j];
+                float col[C];
+                col[0] = ec.x; col[1] = ec.y; col[2] = ec.z;
+                if (C > 3) {
+                    const float4 ed = s_e[row][t][NV - 1];
+                    col[3] = ec.w;
+                    col[C > 4 ? 4 : 0] = ed.x;
+                    col[C > 5 ? 5 : 0] = ed.y;
+                }
+                const float G = contrib ? Gr_[j] : 0.f;
+                const float inv_om = __builtin_amdgcn_rcpf(1.f - alpha);
+                const float Tn = T_ * inv_om;
+                T_ = contrib ? Tn : T_;
+                const float w = contrib ? alpha * Tn : 0.f;
+                float V = gA + eb.z * gD;
+#pragma unroll
+                for (int ch = 0; ch < C; ++ch) V = __builtin_fmaf(col[ch], gCol[ch], V);
+                const float dL_da = contrib ? (Tn * V - (S + Tb) * inv_om) : 0.f;
+                S = __builtin_fmaf(V, w, S);
+                const float dL_dG = eb.y * dL_da;
+                const float gdx = G * dx, gdy = G * dy;
+                float v[RS];
+                v[0] = dL_dG * (-gdx * ea.z - gdy * ea.w) * half_W;
+                v[1] = dL_dG * (-gdy * eb.x - gdx * ea.w) * half_H;
+                v[2] = -0.5f * gdx * dx * dL_dG;
+                v[3] = -gdx * dy * dL_dG;
+                v[4] = -0.5f * gdy * dy * dL_dG;
+                v[5] = G * dL_da;
+                v[6] = w * gD;
+#pragma unroll
+                for (int ch = 0; ch < C; ++ch) v[7 + ch] = w * gCol[ch];
+                // transposed reduction: [value][lane] in LDS, lane i of the row sums value i over the row
+#pragma unroll
+                for (int i = 0; i < RS; ++i) s_red[j][i][lane] = v[i];
+            }
             __builtin_amdgcn_wave_barrier();
-            const float4 a0 = red_src[0], a1 = red_src[1], a2 = red_src[2], a3 = red_src[3];
-            // fixed summation tree (deterministic): pairs of packed adds
-            f2v p0 = f2v{a0.x, a0.y} + f2v{a0.z, a0.w};
-            f2v p1 = f2v{a1.x, a1.y} + f2v{a1.z, a1.w};
-            f2v p2 = f2v{a2.x, a2.y} + f2v{a2.z, a2.w};
-            f2v p3 = f2v{a3.x, a3.y} + f2v{a3.z, a3.w};
-            p0 = p0 + p1;
-            p2 = p2 + p3;
-            p0 = p0 + p2;
-            const float total = p0.x + p0.y;
-            const uint32_t slot = s_slot[row][t];
-            if (li < RS && t < cnt && slot < rec_cap) rec[(size_t)slot * RS + li] = total;
+#pragma unroll
+            for (int j = 0; j < kBwdUnroll; ++j) {
+                const int t = tg + kBwdUnroll - 1 - j;
+                const float4 *src = red_src + j * kRedBuf4;
+                const float4 a0 = src[0], a1 = src[1], a2 = src[2], a3 = src[3];
+                // fixed summation tree (deterministic): pairs of packed adds
+                f2v p0 = f2v{a0.x, a0.y} + f2v{a0.z, a0.w};
+                f2v p1 = f2v{a1.x, a1.y} + f2v{a1.z, a1.w};
+                f2v p2 = f2v{a2.x, a2.y} + f2v{a2.z, a2.w};
+                f2v p3 = f2v{a3.x, a3.y} + f2v{a3.z, a3.w};
+                p0 = p0 + p1;
+                p2 = p2 + p3;
+                p0 = p0 + p2;
+                const float total = p0.x + p0.y;
+                const uint32_t slot = s_slot[row][t];
+                if (li < RS && t < cnt && slot < rec_cap) rec[(size_t)slot * RS + li] = total;
+            }
         }
         if (c0 == 0) break;
     }
+    trace.done(ndmax);
 }
 
 // ---------------------------------------------------------------------------------------- launchers
@@ -351,10 +450,10 @@ int launch_render_fwd(const BatchDesc &d, hipStream_t st)
 {
     const int T = ((d.W + kTile - 1) / kTile) * ((d.H + kTile - 1) / kTile);
     if (T <= 0) return DM4D_OK;
-    const int blocks = ((T + 7) / 8) * 8 * 4;
+    const int blocks = (int)((((int64_t)T * d.B + 7) / 8) * 8 * 4);
     ProfScope prof_(kKRenderFwd, st);
-    if (d.C <= 3) hipLaunchKernelGGL(k_render_fwd<3>, dim3(blocks, d.B), dim3(64), 0, st, d);
-    else hipLaunchKernelGGL(k_render_fwd<6>, dim3(blocks, d.B), dim3(64), 0, st, d);
+    if (d.C <= 3) hipLaunchKernelGGL(k_render_fwd<3>, dim3(blocks), dim3(64), 0, st, d);
+    else hipLaunchKernelGGL(k_render_fwd<6>, dim3(blocks), dim3(64), 0, st, d);
     DM4D_HIP_CHECK(hipGetLastError());
     return DM4D_OK;
 }
@@ -363,10 +462,10 @@ int launch_render_bwd(const BatchDesc &d, hipStream_t st)
 {
     const int T = ((d.W + kTile - 1) / kTile) * ((d.H + kTile - 1) / kTile);
     if (T <= 0) return DM4D_OK;
-    const int blocks = ((T + 7) / 8) * 8 * 4;
+    const int blocks = (int)((((int64_t)T * d.B + 7) / 8) * 8 * 4);
     ProfScope prof_(kKRenderBwd, st);
-    if (d.C <= 3) hipLaunchKernelGGL(k_render_bwd<3>, dim3(blocks, d.B), dim3(64), 0, st, d);
-    else hipLaunchKernelGGL(k_render_bwd<6>, dim3(blocks, d.B), dim3(64), 0, st, d);
+    if (d.C <= 3) hipLaunchKernelGGL(k_render_bwd<3>, dim3(blocks), dim3(64), 0, st, d);
+    else hipLaunchKernelGGL(k_render_bwd<6>, dim3(blocks), dim3(64), 0, st, d);
     DM4D_HIP_CHECK(hipGetLastError());
     return DM4D_OK;
 }

@@ -33,7 +33,7 @@ class ViewRenderer:
     """Static scene description + capacity policy for ``render_views``."""
 
     def __init__(self, graph: DeformGraph, topo: MeshTopology, image_height, image_width, tanfov, method="hybrid",
-                 scale_modifier=1.0, capacity_factor=6.0, record_factor=2.5):
+                 scale_modifier=1.0, capacity_factor=6.0, record_factor=3.0):
         assert graph.device == topo.device and graph.V == topo.V
         self.graph, self.topo = graph, topo
         self.device = graph.device
@@ -45,6 +45,7 @@ class ViewRenderer:
         self.capacity = max(int(capacity_factor * self.N), 1 << 16)
         # backward records = (Gaussian, 4x4-pixel cell) pairs; ~2 per duplicate for mesh-bound splats
         self.record_capacity = int(record_factor * self.capacity)
+        self.calibrated = False   # capacities checked against the first forward (render_views)
         self.last = None   # (ViewsStruct, keep-alive) of the most recent forward, for check()
         self._ws_pool = []     # recycled (geom, binning, image) workspace sets, keyed by (B, capacity)
         self._scratch = {}     # persistent backward scratch, keyed by (B, capacity)
@@ -182,7 +183,16 @@ def render_views(renderer: ViewRenderer, dx, dr, ds, d_opacity, q_static, scales
     """Returns dict: color [B,6,H,W] (RGB | normal), depth [B,1,H,W], alpha [B,1,H,W], radii [B,N] int32,
     vxyz [B,V,3], vrot [B,V,4]."""
     m = renderer.method
-    color, depth, alpha, radii, vxyz, vrot = _RenderViews.apply(
-        renderer, dx, dr, ds if m != 1 else None, d_opacity if m == 2 else None, q_static, scales, opacities, rgb,
-        viewmats, projmats, bg6, None)
+    args = (renderer, dx, dr, ds if m != 1 else None, d_opacity if m == 2 else None, q_static, scales, opacities, rgb,
+            viewmats, projmats, bg6, None)
+    color, depth, alpha, radii, vxyz, vrot = _RenderViews.apply(*args)
+    if not renderer.calibrated:
+        # first call only: one host sync to size the duplicate / record capacities from the real counts
+        # (both are counted exactly even when they overflow); afterwards check() is up to the caller
+        try:
+            renderer.check()
+        except _lib.Dm4dError:
+            color, depth, alpha, radii, vxyz, vrot = _RenderViews.apply(*args)
+            renderer.check()
+        renderer.calibrated = True
     return {"color": color, "depth": depth, "alpha": alpha, "radii": radii, "vxyz": vxyz, "vrot": vrot}

@@ -168,6 +168,12 @@ int dm4d_raster_read_image_state(const void *image, int32_t image_height, int32_
                                  uint32_t *n_contrib /* [host][H,W] */, float *final_T /* [host][H,W] */,
                                  dm4d_stream_t stream);
 
+/* Debug: when `trace` (device, uint64 [blocks, 4]) is non-NULL every wave of the blend kernels records
+ * {start, end} in 100 MHz ticks, {XCC_ID << 32 | HW_ID} and its iteration count at index
+ * blockIdx.y * gridDim.x + blockIdx.x.  NULL switches it off (the default).  min_work > 0 makes waves
+ * whose longest list is shorter exit at once (isolates the long ones; results are then incomplete). */
+int dm4d_debug_trace(void *trace, uint32_t min_work);
+
 /* markVisible: present[i] = view-space z > 0.2 */
 int dm4d_mark_visible(int32_t N, const float *means3D, const float *viewmatrix, uint8_t *present,
                       dm4d_stream_t stream);

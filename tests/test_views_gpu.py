@@ -123,6 +123,7 @@ def test_capacity_overflow_reported():
     sc, graph, topo, qs, scales, opac, rgb, raw, cams, vm, pm = _scene(1200, M, 4, B, H, W, dev, seed=2)
     r = views.ViewRenderer(graph, topo, H, W, cams[0].tanfov)
     r.capacity = 500
+    r.calibrated = True          # skip the first-call calibration: this test wants the lazy check() path
     views.render_views(r, raw["trans"], raw["d_rot"], raw["strain"], raw["d_opacity"].squeeze(-1), qs, scales, opac, rgb,
                        vm, pm, torch.ones(6, device=dev))
     with pytest.raises(_lib.Dm4dError):
@@ -131,3 +132,12 @@ def test_capacity_overflow_reported():
     views.render_views(r, raw["trans"], raw["d_rot"], raw["strain"], raw["d_opacity"].squeeze(-1), qs, scales, opac, rgb,
                        vm, pm, torch.ones(6, device=dev))
     assert min(r.check()) > 500
+    # the first call of a fresh renderer calibrates both capacities by itself (one sync), records included
+    r2 = views.ViewRenderer(graph, topo, H, W, cams[0].tanfov)
+    r2.capacity, r2.record_capacity = 500, 100
+    out = views.render_views(r2, raw["trans"], raw["d_rot"], raw["strain"], raw["d_opacity"].squeeze(-1), qs, scales, opac,
+                             rgb, vm, pm, torch.ones(6, device=dev))
+    assert r2.calibrated and r2.capacity > 500 and r2.record_capacity >= max(r2.last_num_records)
+    ref = views.render_views(r, raw["trans"], raw["d_rot"], raw["strain"], raw["d_opacity"].squeeze(-1), qs, scales, opac,
+                             rgb, vm, pm, torch.ones(6, device=dev))
+    assert torch.equal(out["color"], ref["color"])
