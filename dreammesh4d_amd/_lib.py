@@ -59,6 +59,17 @@ class ViewsGrads(C.Structure):
                                   "dL_ddx", "dL_ddr", "dL_dds", "dL_ddo")]
 
 
+class MlpWeights(C.Structure):
+    """dm4d_mlp_weights (include/dm4d.h)."""
+    _fields_ = [("in_dim", C.c_int32), ("width", C.c_int32), ("n_heads", C.c_int32), ("out_dim", C.c_int32 * 4),
+                ("W0", vp), ("b0", vp), ("W1", vp * 4), ("b1", vp * 4), ("W2", vp * 4), ("b2", vp * 4)]
+
+
+class MlpWeightsGrad(C.Structure):
+    """dm4d_mlp_weights_grad (include/dm4d.h)."""
+    _fields_ = [("W0", vp), ("b0", vp), ("W1", vp * 4), ("b1", vp * 4), ("W2", vp * 4), ("b2", vp * 4)]
+
+
 ALLOC_FN = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_int, C.c_size_t)
 
 _SIGNATURES = {
@@ -99,6 +110,10 @@ _SIGNATURES = {
     "dm4d_hexplane_axis_index": (C.c_int, [C.c_int32] * 2 + [vp] * 5),
     "dm4d_hexplane_scratch_bytes": (C.c_size_t, [C.c_int32] * 3),
     "dm4d_hexplane_backward": (C.c_int, [C.c_int32] * 3 + [vp] * 6 + [C.c_int32] + [vp] * 5 + [C.c_int32] + [vp] * 8),
+    "dm4d_deform_mlp_scratch_bytes": (C.c_size_t, [C.c_int32] * 3),
+    "dm4d_deform_mlp_forward": (C.c_int, [C.c_int32, vp, C.POINTER(MlpWeights), vp, vp, C.POINTER(vp), vp, vp]),
+    "dm4d_deform_mlp_backward": (C.c_int, [C.c_int32, vp, C.POINTER(MlpWeights), vp, vp, C.POINTER(vp), vp,
+                                           C.POINTER(MlpWeightsGrad), vp, vp]),
     "dm4d_views_geom_bytes": (C.c_size_t, [C.c_int32] * 4),
     "dm4d_views_binning_bytes": (C.c_size_t, [C.c_int32, C.c_int64]),
     "dm4d_views_image_bytes": (C.c_size_t, [C.c_int32] * 3),

@@ -110,6 +110,70 @@ class _Deformation(nn.Module):
         return dx, dr, ds, do
 
 
+class _DeformMLP(torch.autograd.Function):
+    """feature_out + the present heads as ONE fused HIP forward and ONE backward (csrc/deform_mlp.hip,
+    C ABI dm4d_deform_mlp_*), instead of ~12 GEMV-sized linears + ~70 elementwise launches."""
+
+    @staticmethod
+    def forward(ctx, feat, n_heads, *params):
+        import ctypes as C
+
+        from . import _lib
+
+        L = _lib.lib()
+        dev = feat.device
+        P, IN = int(feat.shape[0]), int(feat.shape[1])
+        f = feat.detach().to(torch.float32).contiguous()
+        ps = [p.detach() for p in params]
+        for p in ps:
+            if p.dtype != torch.float32 or not p.is_contiguous():
+                raise ValueError("deformation MLP parameters must be contiguous float32")
+        W0, b0 = ps[0], ps[1]
+        heads = [ps[2 + 4 * k: 6 + 4 * k] for k in range(n_heads)]      # (W1, b1, W2, b2) per head
+        w = _lib.MlpWeights()
+        w.in_dim, w.width, w.n_heads = IN, int(W0.shape[0]), n_heads
+        w.W0, w.b0 = W0.data_ptr(), b0.data_ptr()
+        outs = []
+        for k, (W1, b1, W2, b2) in enumerate(heads):
+            w.out_dim[k] = int(W2.shape[0])
+            w.W1[k], w.b1[k], w.W2[k], w.b2[k] = W1.data_ptr(), b1.data_ptr(), W2.data_ptr(), b2.data_ptr()
+            outs.append(torch.empty(P, int(W2.shape[0]), dtype=torch.float32, device=dev))
+        h = torch.empty(P, 64, dtype=torch.float32, device=dev)
+        y = torch.empty(n_heads, P, 64, dtype=torch.float32, device=dev)
+        scratch = torch.empty(L.dm4d_deform_mlp_scratch_bytes(P, IN, n_heads), dtype=torch.uint8, device=dev)
+        optr = (C.c_void_p * 4)(*[o.data_ptr() for o in outs])
+        with torch.cuda.device(dev):
+            _lib.check(L.dm4d_deform_mlp_forward(P, f.data_ptr(), C.byref(w), h.data_ptr(), y.data_ptr(), optr,
+                                                 scratch.data_ptr(), torch.cuda.current_stream(dev).cuda_stream),
+                       "dm4d_deform_mlp_forward")
+        ctx.w, ctx.keep, ctx.n_heads = w, (f, ps, h, y, scratch), n_heads
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *g_outs):
+        import ctypes as C
+
+        from . import _lib
+
+        L = _lib.lib()
+        f, ps, h, y, scratch = ctx.keep
+        dev = f.device
+        P = int(f.shape[0])
+        gs = [None if g is None else g.detach().to(torch.float32).contiguous() for g in g_outs]
+        gptr = (C.c_void_p * 4)(*[None if g is None else g.data_ptr() for g in gs])
+        g_feat = torch.empty_like(f)
+        grads = [torch.empty_like(p) for p in ps]
+        gw = _lib.MlpWeightsGrad()
+        gw.W0, gw.b0 = grads[0].data_ptr(), grads[1].data_ptr()
+        for k in range(ctx.n_heads):
+            gw.W1[k], gw.b1[k], gw.W2[k], gw.b2[k] = (grads[2 + 4 * k + j].data_ptr() for j in range(4))
+        with torch.cuda.device(dev):
+            _lib.check(L.dm4d_deform_mlp_backward(P, f.data_ptr(), C.byref(ctx.w), h.data_ptr(), y.data_ptr(), gptr,
+                                                  g_feat.data_ptr(), C.byref(gw), scratch.data_ptr(),
+                                                  torch.cuda.current_stream(dev).cuda_stream), "dm4d_deform_mlp_backward")
+        return (g_feat, None, *grads)
+
+
 class DeformationNetwork(nn.Module):
     def __init__(self, net_width=64, bounds=1.0, resolution=(64, 64, 64, 25), multires=(1, 2, 4, 8),
                  no_ds=False, no_dr=False, no_do=True, timebase_pe=4, posebase_pe=10, scale_rotation_pe=2,
@@ -148,11 +212,25 @@ class DeformationNetwork(nn.Module):
                 self._hex_plan_key = key
             feat = hx.hexplane_features(self.deformation_net.grid, self._hex_plan, timestamps * 2.0 - 1.0)
             d = self.deformation_net
-            h = d.feature_out(feat.view(B * M, -1)).float()
-            dx = d.pos_deform(h)
-            ds = None if d.no_ds else d.scales_deform(h)
-            dr = None if d.no_dr else d.rotations_deform(h)
-            do = None if d.no_do else d.opacity_deform(h)
+            lin0 = d.feature_out[0]
+            heads = [d.pos_deform] + ([] if d.no_ds else [d.scales_deform]) + ([] if d.no_dr else [d.rotations_deform]) + \
+                    ([] if d.no_do else [d.opacity_deform])
+            if lin0.out_features == 64 and lin0.in_features % 64 == 0 and lin0.in_features <= 256:
+                params = [lin0.weight, lin0.bias]
+                for hd in heads:
+                    params += [hd.feature_out[0].main_stream.weight, hd.feature_out[0].main_stream.bias,
+                               hd.feature_out[1].weight, hd.feature_out[1].bias]
+                outs = list(_DeformMLP.apply(feat.view(B * M, -1), len(heads), *params))
+                dx = outs.pop(0)
+                ds = None if d.no_ds else outs.pop(0)
+                dr = None if d.no_dr else outs.pop(0)
+                do = None if d.no_do else outs.pop(0)
+            else:   # other widths: the same layers as torch ops on the device
+                h = d.feature_out(feat.view(B * M, -1)).float()
+                dx = d.pos_deform(h)
+                ds = None if d.no_ds else d.scales_deform(h)
+                dr = None if d.no_dr else d.rotations_deform(h)
+                do = None if d.no_do else d.opacity_deform(h)
         else:
             pts = nodes.unsqueeze(0).expand(B, M, 3).reshape(-1, 3)
             t = (timestamps.view(B, 1, 1).expand(B, M, 1).reshape(-1, 1)) * 2.0 - 1.0

@@ -253,6 +253,37 @@ int dm4d_hexplane_backward(int32_t S, int32_t M, int32_t B, const int32_t *res, 
                            const int32_t *tp_plane, const int32_t *tp_col, const int32_t *tp_off, const int32_t *tp_item,
                            void *scratch, float *const *g_planes_dev, dm4d_stream_t stream);
 
+/* ------------------------------------------------------------------ deformation MLP (fused) */
+
+/* The MLP behind the HexPlane features of `Deformation.forward_dynamic_delta`
+ * (C/geometry/deformation.py:285-305,430-436,507-512), per row of feat [P,in_dim]:
+ *   h = W0 feat + b0;  x = relu(h);  y_k = x + W1_k x + b1_k;  out_k = W2_k y_k + b2_k
+ * Weights are torch nn.Linear layouts: W [out,in] row-major, b [out]; width must be 64, in_dim a
+ * multiple of 64 (<= 256), out_dim[k] <= 8, up to 4 heads.  All pointers are device pointers. */
+typedef struct dm4d_mlp_weights {
+    int32_t in_dim, width, n_heads;
+    int32_t out_dim[4];
+    const float *W0, *b0;                       /* [64,in_dim] [64] */
+    const float *W1[4], *b1[4];                 /* [64,64] [64]     */
+    const float *W2[4], *b2[4];                 /* [out,64] [out]   */
+} dm4d_mlp_weights;
+typedef struct dm4d_mlp_weights_grad {          /* same shapes; any pointer may be NULL (not wanted) */
+    float *W0, *b0;
+    float *W1[4], *b1[4];
+    float *W2[4], *b2[4];
+} dm4d_mlp_weights_grad;
+
+size_t dm4d_deform_mlp_scratch_bytes(int32_t P, int32_t in_dim, int32_t n_heads);
+/* out[k] [P,out_dim[k]]; h_save [P,64] and y_save [n_heads,P,64] are kept for the backward. */
+int dm4d_deform_mlp_forward(int32_t P, const float *feat, const dm4d_mlp_weights *w, float *h_save, float *y_save,
+                            float *const *out /* [host] n_heads device pointers */, void *scratch,
+                            dm4d_stream_t stream);
+/* g_out[k] may be NULL (zero).  g_feat [P,in_dim] may be NULL.  Parameter gradients are WRITTEN (not
+ * accumulated); their row sums use a fixed order: deterministic, no floating-point atomics. */
+int dm4d_deform_mlp_backward(int32_t P, const float *feat, const dm4d_mlp_weights *w, const float *h_save,
+                             const float *y_save, const float *const *g_out /* [host] */, float *g_feat,
+                             const dm4d_mlp_weights_grad *gw, void *scratch, dm4d_stream_t stream);
+
 /* ------------------------------------------------------------------ batched views (the fast path) */
 
 /* The whole per-view hot path for B (frame, view) units of one scene in 8 launches forward /

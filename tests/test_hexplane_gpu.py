@@ -1,5 +1,5 @@
-"""GPU parity of the fused HexPlane kernels against the PyTorch-op path of the same module (which the
-CPU golden test pins to the reference's geometry/deformation.py)."""
+"""GPU parity of the fused HexPlane kernels and of the fused deformation MLP against the PyTorch-op path of the
+same module (which the CPU golden test pins to the reference's geometry/deformation.py)."""
 import numpy as np
 import pytest
 import torch
@@ -12,14 +12,17 @@ def _need_gpu():
         pytest.skip("no HIP device")
 
 
-@pytest.mark.parametrize("resolution,multires,M,B", [((8, 8, 8, 5), (1, 2), 37, 3), ((64, 64, 64, 25), (1, 2, 4, 8), 1000, 4)])
-def test_fused_hexplane_matches_grid_sample_path(resolution, multires, M, B):
+@pytest.mark.parametrize("resolution,multires,M,B,heads", [((8, 8, 8, 5), (1, 2), 37, 3, "all"),
+                                                           ((64, 64, 64, 25), (1, 2, 4, 8), 1000, 4, "all"),
+                                                           ((16, 16, 16, 7), (1, 2, 4), 333, 2, "pos+rot")])
+def test_fused_hexplane_matches_grid_sample_path(resolution, multires, M, B, heads):
     _need_gpu()
     from dreammesh4d_amd.deformation import DeformationNetwork
 
     dev = torch.device("cuda:0")
     torch.manual_seed(0)
-    net = DeformationNetwork(resolution=resolution, multires=multires, no_ds=False, no_dr=False, no_do=False).to(dev)
+    full = heads == "all"
+    net = DeformationNetwork(resolution=resolution, multires=multires, no_ds=not full, no_dr=False, no_do=not full).to(dev)
     g = torch.Generator().manual_seed(1)
     with torch.no_grad():
         for name, p in net.named_parameters():
@@ -31,6 +34,9 @@ def test_fused_hexplane_matches_grid_sample_path(resolution, multires, M, B):
     ts[0] = 0.0                                                  # t = -1 exactly: lower border of the time axis
     # fused path
     out = net.node_outputs(nodes, ts)
+    present = [x is not None for x in out]
+    assert present == ([True] * 4 if full else [True, True, False, False])
+    out = [x for x in out if x is not None]
     w = [torch.randn(x.shape, generator=g).to(dev) for x in out]
     loss = sum((a * b).sum() for a, b in zip(out, w))
     loss.backward()
@@ -40,7 +46,7 @@ def test_fused_hexplane_matches_grid_sample_path(resolution, multires, M, B):
     pts = nodes.unsqueeze(0).expand(B, M, 3).reshape(-1, 3)
     t = (ts.view(B, 1, 1).expand(B, M, 1).reshape(-1, 1)) * 2.0 - 1.0
     dx, dr, ds, do = net.forward_dynamic_delta(pts, t)
-    ref = (dx.view(B, M, 3), dr.view(B, M, 4), ds.view(B, M, 6), do.view(B, M))
+    ref = (dx.view(B, M, 3), dr.view(B, M, 4)) + ((ds.view(B, M, 6), do.view(B, M)) if full else ())
     for a, b in zip(out, ref):
         assert (a - b).abs().max() < 2e-6
     loss2 = sum((a * b).sum() for a, b in zip(ref, w))
@@ -52,8 +58,8 @@ def test_fused_hexplane_matches_grid_sample_path(resolution, multires, M, B):
         assert (fused[n] - p.grad).abs().max() / scale < 2e-4, n
     # deterministic: the gather backward gives bit-identical gradients on a re-run
     net.zero_grad(set_to_none=True)
-    out3 = net.node_outputs(nodes, ts)
+    out3 = [x for x in net.node_outputs(nodes, ts) if x is not None]
     sum((a * b).sum() for a, b in zip(out3, w)).backward()
     for n, p in net.named_parameters():
-        if "grid" in n and p.grad is not None:
+        if p.grad is not None:       # HexPlane gather backward and the MLP's fixed-order row sums
             assert torch.equal(p.grad, fused[n]), n
