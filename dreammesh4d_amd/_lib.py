@@ -98,6 +98,7 @@ _SIGNATURES = {
     "dm4d_raster_read_geom": (C.c_int, [vp, C.c_int32, C.c_int32, C.c_int32, c_f, c_f, c_f, c_u32, vp]),
     "dm4d_raster_read_image_state": (C.c_int, [vp, C.c_int32, C.c_int32, c_u32, c_f, vp]),
     "dm4d_debug_trace": (C.c_int, [vp, C.c_uint32]),
+    "dm4d_debug_sort_trace": (C.c_int, [vp]),
     "dm4d_mark_visible": (C.c_int, [C.c_int32, vp, vp, vp, vp]),
     "dm4d_dist2_knn3": (C.c_int, [C.c_int32, vp, vp, vp]),
     "dm4d_skin_vertices_forward": (C.c_int, [C.c_int32] * 4 + [vp] * 10),

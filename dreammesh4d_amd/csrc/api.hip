@@ -340,6 +340,7 @@ int dm4d_raster_read_image_state(const void *image, int32_t H, int32_t W, uint32
 }
 
 int dm4d_debug_trace(void *trace, uint32_t min_work) { return set_trace_buffer(trace, min_work); }
+int dm4d_debug_sort_trace(void *trace) { return set_sort_trace_buffer(trace); }
 
 int dm4d_mark_visible(int32_t N, const float *means3D, const float *viewmatrix, uint8_t *present, dm4d_stream_t stream)
 {

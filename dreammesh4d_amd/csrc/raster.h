@@ -43,7 +43,7 @@ DM4D_HD static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) /
 
 struct GeomLayout {
     int N, T, nb;
-    size_t counters, xy, depth, conic_opacity, rgb, tiles_touched, offsets, rec_touched, rec_offsets, clamped,
+    size_t counters, xy, depth, conic_opacity, rgb, tiles_touched, rec_touched, cellinfo, cellmask, clamped,
         block_sums, rec_block_sums, hist, tile_count, tile_start, ccount, cdone, ckmax, order, zero_begin, zero_bytes, total;
 };
 
@@ -73,9 +73,9 @@ DM4D_HD static inline GeomLayout geom_layout(int N, int H, int W)
     L.conic_opacity = take_(o, n * 16);
     L.rgb = take_(o, n * 12);
     L.tiles_touched = take_(o, n * 4);
-    L.offsets = take_(o, n * 4);
     L.rec_touched = take_(o, n * 4);
-    L.rec_offsets = take_(o, n * 4);
+    L.cellinfo = take_(o, n * 16);
+    L.cellmask = take_(o, n * 8);
     L.clamped = take_(o, n * 3);
     L.block_sums = take_(o, (size_t)(L.nb + 1) * 4);
     L.rec_block_sums = take_(o, (size_t)(L.nb + 1) * 4);
@@ -91,9 +91,9 @@ struct GeomPtrs {
     float4 *conic_opacity;
     float *rgb;
     uint32_t *tiles_touched;
-    uint32_t *offsets;
     uint32_t *rec_touched;   // cells (4x4 px) inside the Gaussian's alpha >= 1/255 bound and its tile rect
-    uint32_t *rec_offsets;   // exclusive scan of rec_touched: first backward record of the Gaussian
+    uint4 *cellinfo;         // {bx0 | by0 << 16, nbx | nby << 16, first backward record (scan of rec_touched), dense}
+    uint64_t *cellmask;      // cells of the block the splat really reaches (bit = by * nbx + bx), blocks of <= 64 cells
     uint8_t *clamped;
     uint32_t *block_sums;
     uint32_t *rec_block_sums;
@@ -116,9 +116,9 @@ DM4D_HD static inline GeomPtrs geom_ptrs(void *base, const GeomLayout &L)
     p.conic_opacity = (float4 *)(b + L.conic_opacity);
     p.rgb = (float *)(b + L.rgb);
     p.tiles_touched = (uint32_t *)(b + L.tiles_touched);
-    p.offsets = (uint32_t *)(b + L.offsets);
     p.rec_touched = (uint32_t *)(b + L.rec_touched);
-    p.rec_offsets = (uint32_t *)(b + L.rec_offsets);
+    p.cellinfo = (uint4 *)(b + L.cellinfo);
+    p.cellmask = (uint64_t *)(b + L.cellmask);
     p.clamped = (uint8_t *)(b + L.clamped);
     p.block_sums = (uint32_t *)(b + L.block_sums);
     p.rec_block_sums = (uint32_t *)(b + L.rec_block_sums);
@@ -136,7 +136,6 @@ struct BinPtrs {
     uint32_t *u_depth;    // unsorted duplicates, tile-major segments
     uint32_t *u_idx;
     uint32_t *point_list; // sorted Gaussian ids  (== upstream point_list)
-    uint32_t *sorted_pos; // Gaussian-major duplicate index -> position in point_list
     uint2 *clist;         // [16][cap] cell lists: (Gaussian id, position k in the tile list),
                           // cell c of tile t at clist[c*cap + tile_start[t] ...]
     uint32_t *cslot;      // [16][cap] backward record of the same entry
@@ -145,7 +144,7 @@ struct BinPtrs {
 DM4D_HD static inline size_t binning_bytes(int64_t cap)
 {
     size_t c = (size_t)(cap > 0 ? cap : 1);
-    return 4 * align_up(c * 4, 256) + align_up(c * kCells * 8, 256) + align_up(c * kCells * 4, 256);
+    return 3 * align_up(c * 4, 256) + align_up(c * kCells * 8, 256) + align_up(c * kCells * 4, 256);
 }
 DM4D_HD static inline BinPtrs bin_ptrs(void *base, int64_t cap)
 {
@@ -156,9 +155,8 @@ DM4D_HD static inline BinPtrs bin_ptrs(void *base, int64_t cap)
     p.u_depth = (uint32_t *)(b);
     p.u_idx = (uint32_t *)(b + stride);
     p.point_list = (uint32_t *)(b + 2 * stride);
-    p.sorted_pos = (uint32_t *)(b + 3 * stride);
-    p.clist = (uint2 *)(b + 4 * stride);
-    p.cslot = (uint32_t *)(b + 4 * stride + align_up(c * kCells * 8, 256));
+    p.clist = (uint2 *)(b + 3 * stride);
+    p.cslot = (uint32_t *)(b + 3 * stride + align_up(c * kCells * 8, 256));
     p.cap = c;
     return p;
 }
@@ -215,8 +213,7 @@ __device__ __forceinline__ Rect tile_rect(float px, float py, int r, int gx, int
 // Cells of the tile rect `rc` that the alpha >= 1/255 support of a splat can reach: exact axis-aligned
 // bound of the ellipse { d : 1/2 d^T A d <= ln(255 o) }, inflated by margins that cover the rounding
 // of log/sqrt/div.  Conservative, so culled (splat, pixel) pairs are exactly ones the reference
-// `continue`s on.  K1 (record count), K4 (cell lists) and B2 (record gather) run this SAME device
-// code on the SAME stored inputs, so they agree bit-for-bit.
+// `continue`s on.  Evaluated once per Gaussian in K1 and stored (cellinfo).
 __device__ __forceinline__ Bands cell_bands(float x, float y, float ca, float cb, float cc, float o, const Rect rc)
 {
     Bands B;
@@ -237,6 +234,29 @@ __device__ __forceinline__ Bands cell_bands(float x, float y, float ca, float cb
     const int nbx = bx1 - B.bx0, nby = by1 - B.by0;
     if (nbx > 0 && nby > 0) { B.nbx = nbx; B.nby = nby; }
     return B;
+}
+// Exact refinement of cell_bands for one cell (pixel centres cx0..cx0+3 x cy0..cy0+3): does the ellipse
+// { d : A dx^2 + 2 B dx dy + C dy^2 <= 2 tau } around (x, y) meet the cell's rectangle?  The minimum of the
+// convex form over the rectangle is 0 if the centre is inside, else it lies on one of the four edges, where
+// the form is a 1-D quadratic with a clamped closed-form minimiser.  Margins as in cell_bands (they dwarf
+// the rounding of the blend kernels' own power / exp), so a culled cell holds no pixel with alpha >= 1/255.
+__device__ __forceinline__ bool cell_reached(float x, float y, float A, float B, float C, float tau, float cx0, float cy0)
+{
+    const float x0 = cx0 - 0.02f - x, x1 = cx0 + 3.02f - x, y0 = cy0 - 0.02f - y, y1 = cy0 + 3.02f - y;
+    if (x0 <= 0.f && x1 >= 0.f && y0 <= 0.f && y1 >= 0.f) return true;
+    const float lim = 2.0f * tau * 1.0001f + 0.001f;
+    const float rB_C = -B / C, rB_A = -B / A;
+    bool hit = false;
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+        const float dx = e ? x1 : x0;
+        const float dy = fminf(y1, fmaxf(y0, rB_C * dx));
+        hit |= (A * dx * dx + 2.0f * B * dx * dy + C * dy * dy) <= lim;
+        const float ey = e ? y1 : y0;
+        const float ex = fminf(x1, fmaxf(x0, rB_A * ey));
+        hit |= (A * ex * ex + 2.0f * B * ex * ey + C * ey * ey) <= lim;
+    }
+    return hit;
 }
 // cell id inside its tile (cx, cy in 0..3): the four cells of an 8x8 quadrant are consecutive
 __device__ __forceinline__ int cell_id(int cx, int cy) { return 4 * ((cx >> 1) + 2 * (cy >> 1)) + (cx & 1) + 2 * (cy & 1); }
@@ -343,12 +363,13 @@ DM4D_HD static inline ViewCtx resolve(const BatchDesc &d, int b)
 int launch_preprocess(const BatchDesc &d, hipStream_t st);
 int launch_colscan(const BatchDesc &d, hipStream_t st);
 int launch_scatter(const BatchDesc &d, hipStream_t st);
-int launch_tile_sort(const BatchDesc &d, hipStream_t st);   // + the tile order for the blend kernels
+int launch_tile_sort(const BatchDesc &d, hipStream_t st);
 int launch_render_fwd(const BatchDesc &d, hipStream_t st);
 int launch_render_bwd(const BatchDesc &d, hipStream_t st);
 int launch_gather_bwd(const BatchDesc &d, hipStream_t st);
 int launch_zero_counters(const BatchDesc &d, hipStream_t st);
 int set_trace_buffer(void *dev_ptr, uint32_t min_work);
+int set_sort_trace_buffer(void *dev_ptr);
 int launch_mark_visible(int N, const float *means3D, const float *view, uint8_t *present, hipStream_t st);
 
 }  // namespace dm4d

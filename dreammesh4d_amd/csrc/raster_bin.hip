@@ -65,20 +65,47 @@ __global__ __launch_bounds__(kColThreads) void k_colscan(BatchDesc d)
 // bitonic network this replaced.
 // Large tiles (n > kSortLdsCap): the same algorithm with the keys resident in HBM/L2 (the bucket-major
 // copy borrows the tile's cell-0 list segment, which is only written afterwards).
+// debug (dm4d_debug_trace): per-tile phase timestamps {start, loaded+binned, sorted, end} in 100 MHz ticks
+__device__ uint64_t *g_sort_trace = nullptr;
+int set_sort_trace_buffer(void *dev_ptr)
+{
+    uint64_t *p = (uint64_t *)dev_ptr;
+    DM4D_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_sort_trace), &p, sizeof(p)));
+    return DM4D_OK;
+}
 constexpr int kSortThreads = 256;
 constexpr int kSortLdsCap = 2048;
 constexpr int kSortPerThread = kSortLdsCap / kSortThreads;
 constexpr int kBins = 1024;
 
-// Split the sorted tile list into the sixteen cell lists (stable compaction by the cell block of
-// cell_bands) and record where every duplicate landed (sorted_pos).  Every cell-list entry also gets
-// the index of its backward record: the records of Gaussian i are the dense nby x nbx block of its
-// cells, starting at rec_offsets[i] (K3).
+// Split the sorted tile list into the sixteen cell lists (stable compaction by the Gaussian's cell block,
+// cellinfo / cellmask of K1/K3).  Every cell-list entry also gets the index of its backward record: the
+// records of Gaussian i start at cellinfo[i].z, one per reached cell of its block.
+//
+// Chunks of 2048 entries, 8 CONSECUTIVE entries per thread: all gathers of a chunk are issued together
+// (one memory round trip), the sixteen per-cell counts of a thread travel as four 64-bit words of
+// 16-bit fields through ONE block scan, and each thread then walks its entries in order.  3 barriers per
+// chunk (the first version compacted 256 entries at a time with 16 ballots: 3 barriers and two
+// dependent gathers per 256 entries, 70 % of the kernel).
+constexpr int kFinE = 8;
+__device__ __forceinline__ uint64_t spread4(uint32_t x)   // bit i of x -> 16-bit field i
+{
+    return (uint64_t)(x & 1u) | ((uint64_t)(x & 2u) << 15) | ((uint64_t)(x & 4u) << 30) | ((uint64_t)(x & 8u) << 45);
+}
+__device__ __forceinline__ uint64_t wave_incl_scan_u64(uint64_t v, int lane)
+{
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint64_t w = (uint64_t)__shfl_up((unsigned long long)v, o, 64);
+        if (lane >= o) v += w;
+    }
+    return v;
+}
 template <typename GidAt>
 __device__ __forceinline__ void finish_tile(const ViewCtx &c, int tile, uint32_t s, uint32_t n, GidAt &&gid_at)
 {
     __shared__ uint32_t s_cbase[kCells];
-    __shared__ uint32_t s_wc[kSortThreads / 64][kCells];
+    __shared__ uint64_t s_ws[kSortThreads / 64][4];
     const GeomPtrs &g = c.g;
     const BinPtrs &b = c.b;
     const uint32_t cap = c.cap;
@@ -86,55 +113,87 @@ __device__ __forceinline__ void finish_tile(const ViewCtx &c, int tile, uint32_t
     const int tx = tile % c.vp.gx, ty = tile / c.vp.gx;
     if (tid < kCells) s_cbase[tid] = 0u;
     __syncthreads();
-    for (uint32_t e0 = 0; e0 < n; e0 += kSortThreads) {
-        const uint32_t e = e0 + tid;
-        uint32_t m = 0u, gid = 0u, rec0 = 0u;
-        int nbx = 0, ox = 0, oy = 0;   // record of cell (cx, cy) of this tile: rec0 + (oy + cy) * nbx + ox + cx
-        if (e < n) {
-            gid = gid_at(e);
-            b.point_list[s + e] = gid;
-            const float2 xy = g.xy[gid];
-            const float4 co = g.conic_opacity[gid];
-            const Rect rc = tile_rect(xy.x, xy.y, c.radii[gid], c.vp.gx, c.vp.gy);
-            // Gaussian-major duplicate index of (gid, tile): offsets[gid] + position of the tile in gid's rect
-            const uint32_t p = g.offsets[gid] + (uint32_t)((ty - rc.y0) * (rc.x1 - rc.x0) + (tx - rc.x0));
-            if (p < cap) b.sorted_pos[p] = s + e;
-            const Bands bd = cell_bands(xy.x, xy.y, co.x, co.y, co.z, co.w, rc);
-            const int cx0 = max(bd.bx0, 4 * tx) - 4 * tx, cx1 = min(bd.bx0 + bd.nbx, 4 * tx + 4) - 4 * tx;
-            const int cy0 = max(bd.by0, 4 * ty) - 4 * ty, cy1 = min(bd.by0 + bd.nby, 4 * ty + 4) - 4 * ty;
-            for (int cy = cy0; cy < cy1; ++cy)
-                for (int cx = cx0; cx < cx1; ++cx) m |= 1u << cell_id(cx, cy);
-            rec0 = g.rec_offsets[gid];
-            nbx = bd.nbx;
-            ox = 4 * tx - bd.bx0;
-            oy = 4 * ty - bd.by0;
+    for (uint32_t c0 = 0; c0 < n; c0 += kSortThreads * kFinE) {
+        // consecutive entries per thread in this chunk: as few as cover it, so a short list still uses every thread
+        const uint32_t E = min((uint32_t)kFinE, (n - c0 + kSortThreads - 1) / kSortThreads);
+        const uint32_t e0 = c0 + (uint32_t)tid * E;
+        const uint32_t e1 = min(n, e0 + E);      // this thread's entries: [e0, e1)
+        uint32_t gid[kFinE], m[kFinE];
+        uint4 ci[kFinE];
+        uint64_t cm[kFinE];
+#pragma unroll
+        for (int j = 0; j < kFinE; ++j) {
+            m[j] = 0u;
+            if (e0 + j < e1) {
+                gid[j] = gid_at(e0 + j);
+                ci[j] = g.cellinfo[gid[j]];
+                cm[j] = g.cellmask[gid[j]];   // only meaningful when the block is not dense
+            }
         }
-        uint64_t bal[kCells];
+        uint64_t cnt[4] = {0ull, 0ull, 0ull, 0ull};
 #pragma unroll
-        for (int k = 0; k < kCells; ++k) bal[k] = __ballot((m >> k) & 1u);
-        if (lane == 0) {
+        for (int j = 0; j < kFinE; ++j) {
+            if (e0 + j < e1) {
+                b.point_list[s + e0 + j] = gid[j];
+                const int bx0 = (int)(ci[j].x & 0xFFFFu), by0 = (int)(ci[j].x >> 16);
+                const int nbx = (int)(ci[j].y & 0xFFFFu), nby = (int)(ci[j].y >> 16);
+                const int ox = 4 * tx - bx0, oy = 4 * ty - by0;
+                const bool dense = ci[j].w != 0u;
+                const int cx0 = max(bx0, 4 * tx) - 4 * tx, cx1 = min(bx0 + nbx, 4 * tx + 4) - 4 * tx;
+                const int cy0 = max(by0, 4 * ty) - 4 * ty, cy1 = min(by0 + nby, 4 * ty + 4) - 4 * ty;
+                uint32_t mm = 0u;
+                for (int cy = cy0; cy < cy1; ++cy)
+                    for (int cx = cx0; cx < cx1; ++cx)
+                        if (dense || ((cm[j] >> ((oy + cy) * nbx + ox + cx)) & 1ull)) mm |= 1u << cell_id(cx, cy);
+                m[j] = mm;
 #pragma unroll
-            for (int k = 0; k < kCells; ++k) s_wc[wv][k] = (uint32_t)__popcll(bal[k]);
+                for (int w = 0; w < 4; ++w) cnt[w] += spread4((mm >> (4 * w)) & 15u);
+            }
+        }
+        uint64_t run[4];
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            const uint64_t incl = wave_incl_scan_u64(cnt[w], lane);
+            if (lane == 63) s_ws[wv][w] = incl;
+            run[w] = incl - cnt[w];
         }
         __syncthreads();
 #pragma unroll
-        for (int k = 0; k < kCells; ++k) {
-            if ((m >> k) & 1u) {
-                uint32_t pos = s_cbase[k] + mbcnt(bal[k]);
-                for (int w = 0; w < wv; ++w) pos += s_wc[w][k];
-                if (s + pos < cap) {
-                    const int qd = k >> 2, rr = k & 3;
-                    const int cx = 2 * (qd & 1) + (rr & 1), cy = 2 * (qd >> 1) + (rr >> 1);
-                    b.clist[(size_t)k * b.cap + s + pos] = make_uint2(gid, e);
-                    b.cslot[(size_t)k * b.cap + s + pos] = rec0 + (uint32_t)((oy + cy) * nbx + ox + cx);
+        for (int w = 0; w < 4; ++w)
+            for (int ww = 0; ww < wv; ++ww) run[w] += s_ws[ww][w];
+#pragma unroll
+        for (int j = 0; j < kFinE; ++j) {
+            uint32_t mm = m[j];
+            if (mm) {
+                const int bx0 = (int)(ci[j].x & 0xFFFFu), by0 = (int)(ci[j].x >> 16);
+                const int nbx = (int)(ci[j].y & 0xFFFFu);
+                const int ox = 4 * tx - bx0, oy = 4 * ty - by0;
+                const bool dense = ci[j].w != 0u;
+                const uint32_t rec0 = ci[j].z;
+                while (mm) {
+                    const int k = __builtin_ctz(mm);
+                    mm &= mm - 1u;
+                    const uint64_t rw = (k < 8) ? ((k < 4) ? run[0] : run[1]) : ((k < 12) ? run[2] : run[3]);
+                    const uint32_t pos = s_cbase[k] + (uint32_t)((rw >> (16 * (k & 3))) & 0xFFFFull);
+                    if (s + pos < cap) {
+                        const int qd = k >> 2, rr = k & 3;
+                        const int cx = 2 * (qd & 1) + (rr & 1), cy = 2 * (qd >> 1) + (rr >> 1);
+                        const int bit = (oy + cy) * nbx + ox + cx;
+                        b.clist[(size_t)k * b.cap + s + pos] = make_uint2(gid[j], e0 + j);
+                        // records: dense block index, or the rank of the cell among the cells really reached
+                        b.cslot[(size_t)k * b.cap + s + pos] =
+                            rec0 + (dense ? (uint32_t)bit : (uint32_t)__popcll(cm[j] & ((1ull << bit) - 1ull)));
+                    }
                 }
+#pragma unroll
+                for (int w = 0; w < 4; ++w) run[w] += spread4((m[j] >> (4 * w)) & 15u);
             }
         }
         __syncthreads();
         if (tid < kCells) {
             uint32_t add = 0;
 #pragma unroll
-            for (int w = 0; w < kSortThreads / 64; ++w) add += s_wc[w][tid];
+            for (int w = 0; w < kSortThreads / 64; ++w) add += (uint32_t)((s_ws[w][tid >> 2] >> (16 * (tid & 3))) & 0xFFFFull);
             s_cbase[tid] += add;
         }
         __syncthreads();
@@ -149,12 +208,16 @@ __global__ __launch_bounds__(kSortThreads) void k_tile_sort(BatchDesc d)
     __shared__ uint32_t s_bin[kBins + 1];      // histogram -> bucket ends
     __shared__ uint32_t s_cur[kBins];          // bucket starts / scatter cursors
     __shared__ uint32_t s_red[2 * (kSortThreads / 64)];
-    const ViewCtx c = resolve(d, blockIdx.y);
+    // block -> (view, tile) in the launch order of K3: the r-th longest tile of every view, views interleaved
+    const int view = (int)(blockIdx.x % (uint32_t)d.B);
+    const ViewCtx c = resolve(d, view);
     const GeomPtrs &g = c.g;
     const BinPtrs &b = c.b;
     const uint32_t cap = c.cap;
-    const int t = blockIdx.x;
+    const int t = (int)g.order[blockIdx.x / (uint32_t)d.B];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    uint64_t *tr = g_sort_trace ? g_sort_trace + 5 * (size_t)blockIdx.x : nullptr;
+    if (tr && tid == 0) tr[0] = wall_clock64();
     const uint32_t s = g.tile_start[t];
     uint32_t n = g.tile_count[t];
     if (s >= cap) n = 0;
@@ -202,6 +265,7 @@ __global__ __launch_bounds__(kSortThreads) void k_tile_sort(BatchDesc d)
             }
         }
         __syncthreads();
+        if (tr && tid == 0) tr[1] = wall_clock64();
         // ---- exclusive scan of the kBins counts (kBins / 256 per thread) ----
         {
             constexpr int per = kBins / kSortThreads;
@@ -241,7 +305,9 @@ __global__ __launch_bounds__(kSortThreads) void k_tile_sort(BatchDesc d)
             }
         }
         __syncthreads();
+        if (tr && tid == 0) tr[2] = wall_clock64();
         finish_tile(c, t, s, n, [&](uint32_t e) { return (uint32_t)s_a[e]; });
+        if (tr && tid == 0) { tr[3] = wall_clock64(); tr[4] = n; }
     } else {
         // ---- large tile: the same bucket sort with the keys resident in HBM (L2) ----
         // temp (bucket-major keys) lives in the tile's own cell-0 list segment, which
@@ -304,60 +370,9 @@ __global__ __launch_bounds__(kSortThreads) void k_tile_sort(BatchDesc d)
             ki_[lo + rank] = (uint32_t)k;
         }
         __syncthreads();
+        if (tr && tid == 0) { tr[1] = tr[0]; tr[2] = wall_clock64(); }
         finish_tile(c, t, s, n, [&](uint32_t e) { return ki_[e]; });
-    }
-}
-
-// ---------------------------------------------------------------------------------------- K4b
-// Launch order of the blend kernels: the (view, tile) pairs of the WHOLE batch by DESCENDING cell-list
-// length (longest-processing-time first).  A wave walks its lists serially, so the longest list
-// (silhouette cells: > 1000 entries against a mean of 85) bounds the kernel from below; started
-// last it runs alone at the end, started first it overlaps with everything else.  One workgroup,
-// 256-bucket counting sort; rank i is stored in the geom workspace of view i / T, slot i % T, as
-// view << 16 | tile.
-__device__ __forceinline__ uint32_t *order_slot(const BatchDesc &d, const GeomLayout &L, uint32_t rank)
-{
-    return reinterpret_cast<uint32_t *>(d.geom + (size_t)(rank / (uint32_t)L.T) * d.geom_stride + L.order) +
-           rank % (uint32_t)L.T;
-}
-constexpr int kOrderThreads = 1024;
-__global__ __launch_bounds__(kOrderThreads) void k_tile_order(BatchDesc d)
-{
-    __shared__ uint32_t s_hist[256], s_cur[256], s_max;
-    const GeomLayout L = geom_layout(d.N, d.H, d.W);
-    const int T = L.T, tid = threadIdx.x;
-    const uint32_t n = (uint32_t)d.B * (uint32_t)T;
-    auto weight = [&](uint32_t i) {
-        const uint32_t v = i / (uint32_t)T, t = i % (uint32_t)T;
-        const uint4 *p = reinterpret_cast<const uint4 *>(d.geom + (size_t)v * d.geom_stride + L.ccount) + (size_t)t * (kCells / 4);
-        uint32_t w = 0;
-#pragma unroll
-        for (int k = 0; k < kCells / 4; ++k) {
-            const uint4 x = p[k];
-            w = max(max(w, x.x), max(max(x.y, x.z), x.w));
-        }
-        return w;
-    };
-    if (tid == 0) s_max = 1u;
-    if (tid < 256) s_hist[tid] = 0u;
-    __syncthreads();
-    uint32_t wmax = 0;
-    for (uint32_t i = tid; i < n; i += kOrderThreads) wmax = max(wmax, weight(i));
-    wmax = wave_max_u32(wmax);
-    if ((tid & 63) == 0) atomicMax(&s_max, wmax);
-    __syncthreads();
-    const float scale = 255.0f / (float)s_max;
-    auto bucket = [&](uint32_t w) { return 255 - min(255, (int)((float)w * scale)); };
-    for (uint32_t i = tid; i < n; i += kOrderThreads) atomicAdd(&s_hist[bucket(weight(i))], 1u);
-    __syncthreads();
-    if (tid == 0) {
-        uint32_t run = 0;
-        for (int b = 0; b < 256; ++b) { s_cur[b] = run; run += s_hist[b]; }
-    }
-    __syncthreads();
-    for (uint32_t i = tid; i < n; i += kOrderThreads) {
-        const uint32_t rank = atomicAdd(&s_cur[bucket(weight(i))], 1u);
-        *order_slot(d, L, rank) = ((i / (uint32_t)T) << 16) | (i % (uint32_t)T);
+        if (tr && tid == 0) { tr[3] = wall_clock64(); tr[4] = n; }
     }
 }
 
@@ -376,9 +391,7 @@ int launch_tile_sort(const BatchDesc &d, hipStream_t st)
     const int T = ((d.W + kTile - 1) / kTile) * ((d.H + kTile - 1) / kTile);
     if (T <= 0) return DM4D_OK;
     ProfScope prof_(kKTileSort, st);
-    hipLaunchKernelGGL(k_tile_sort, dim3(T, d.B), dim3(kSortThreads), 0, st, d);
-    DM4D_HIP_CHECK(hipGetLastError());
-    hipLaunchKernelGGL(k_tile_order, dim3(1), dim3(kOrderThreads), 0, st, d);
+    hipLaunchKernelGGL(k_tile_sort, dim3((unsigned)T * (unsigned)d.B), dim3(kSortThreads), 0, st, d);
     DM4D_HIP_CHECK(hipGetLastError());
     return DM4D_OK;
 }

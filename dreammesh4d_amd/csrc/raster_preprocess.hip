@@ -190,6 +190,23 @@ __global__ __launch_bounds__(kPreThreads) void k_preprocess(BatchDesc d)
                     g.conic_opacity[i] = co;
                     const Bands bd = cell_bands(px, py, co.x, co.y, co.z, co.w, rc);
                     recs = (uint32_t)(bd.nbx * bd.nby);
+                    uint32_t dense = 1u;
+                    const float cdet = co.x * co.z - co.y * co.y;
+                    if (recs > 0u && recs <= 64u && cdet > 0.f && co.x > 0.f && co.z > 0.f) {
+                        // small block: keep only the cells the ellipse really meets (a third of the cells of the
+                        // axis-aligned bound of a thin diagonal splat are empty)
+                        const float tau = __logf(255.0f * co.w) * 1.001f + 0.01f;
+                        uint64_t mask = 0ull;
+                        for (int by = 0; by < bd.nby; ++by)
+                            for (int bx = 0; bx < bd.nbx; ++bx)
+                                if (cell_reached(px, py, co.x, co.y, co.z, tau, (float)(4 * (bd.bx0 + bx)), (float)(4 * (bd.by0 + by))))
+                                    mask |= 1ull << (by * bd.nbx + bx);
+                        g.cellmask[i] = mask;
+                        recs = (uint32_t)__popcll(mask);
+                        dense = 0u;
+                    }
+                    g.cellinfo[i] = make_uint4((uint32_t)bd.bx0 | ((uint32_t)bd.by0 << 16),
+                                               (uint32_t)bd.nbx | ((uint32_t)bd.nby << 16), 0u, dense);
                     if (in.shs) {
                         const float *sh = in.shs + (size_t)i * in.sh_coeffs * 3;
 #pragma unroll
@@ -276,14 +293,37 @@ __global__ __launch_bounds__(kPreThreads) void k_scatter(BatchDesc d)
         }
         if (blockIdx.x == 0 && tid == 0) g.tile_start[T] = total;
     }
-    // Gaussian-major duplicate offset of this workgroup = sum of earlier workgroups' duplicates
-    uint32_t carry, rcarry;
+    // Workgroup 0 also publishes the view's tiles by DESCENDING duplicate count (256-bucket counting sort):
+    // the launch order of K4 and of the blend kernels (longest-processing-time first -- a tile's work is
+    // serial in its list length, so the long silhouette tiles must start first to overlap with the rest).
+    if (blockIdx.x == 0) {
+        __shared__ uint32_t s_oh[256], s_oc[256], s_omax;
+        if (tid == 0) s_omax = 1u;
+        s_oh[tid] = 0u;
+        __syncthreads();
+        uint32_t wmax = 0;
+        for (int t = tid; t < T; t += kPreThreads) wmax = max(wmax, g.tile_count[t]);
+        wmax = wave_max_u32(wmax);
+        if ((tid & 63) == 0) atomicMax(&s_omax, wmax);
+        __syncthreads();
+        const float oscale = 255.0f / (float)s_omax;
+        for (int t = tid; t < T; t += kPreThreads)
+            atomicAdd(&s_oh[255 - min(255, (int)((float)g.tile_count[t] * oscale))], 1u);
+        __syncthreads();
+        if (tid == 0) {
+            uint32_t run = 0;
+            for (int k = 0; k < 256; ++k) { s_oc[k] = run; run += s_oh[k]; }
+        }
+        __syncthreads();
+        for (int t = tid; t < T; t += kPreThreads)
+            g.order[atomicAdd(&s_oc[255 - min(255, (int)((float)g.tile_count[t] * oscale))], 1u)] = (uint32_t)t;
+    }
+    // first backward record of this workgroup = records of the earlier workgroups
+    uint32_t rcarry;
     {
-        uint32_t loc = 0, rloc = 0;
-        for (int w = tid; w < (int)blockIdx.x; w += kPreThreads) { loc += g.block_sums[w]; rloc += g.rec_block_sums[w]; }
+        uint32_t rloc = 0;
+        for (int w = tid; w < (int)blockIdx.x; w += kPreThreads) rloc += g.rec_block_sums[w];
         uint32_t total;
-        block_excl_scan_256(loc, s_w, &total);
-        carry = total;
         block_excl_scan_256(rloc, s_w, &total);
         rcarry = total;
     }
@@ -294,14 +334,11 @@ __global__ __launch_bounds__(kPreThreads) void k_scatter(BatchDesc d)
         const int i = blockIdx.x * kPreBlock + it * kPreThreads + tid;
         const uint32_t touched = (i < N) ? g.tiles_touched[i] : 0u;
         uint32_t total;
-        const uint32_t p0 = carry + block_excl_scan_256(touched, s_w, &total);
-        carry += total;
         const uint32_t recs = (i < N) ? g.rec_touched[i] : 0u;
         const uint32_t r0 = rcarry + block_excl_scan_256(recs, s_w, &total);
         rcarry += total;
-        if (i < N) {
-            g.offsets[i] = p0;
-            g.rec_offsets[i] = r0;
+        if (i < N && touched != 0u) {
+            reinterpret_cast<uint32_t *>(g.cellinfo + i)[2] = r0;   // first backward record of the Gaussian
             rec_overflow |= (recs > 0u) && ((uint64_t)r0 + recs > (uint64_t)c.rec_cap);
         }
         if (touched == 0) continue;
@@ -332,8 +369,6 @@ __global__ __launch_bounds__(kPreThreads) void k_gather_bwd(BatchDesc d)
     const dm4d_raster_inputs &in = c.in;
     const int32_t *__restrict__ radii = c.radii;
     const GeomPtrs &g = c.g;
-    const BinPtrs &b = c.b;
-    const uint32_t cap = c.cap;
     const float *__restrict__ dLt = c.dLq;
     const BwdOutputs &o = c.o;
     __shared__ float sV[16], sP[16];
@@ -351,40 +386,18 @@ __global__ __launch_bounds__(kPreThreads) void k_gather_bwd(BatchDesc d)
     const int r = radii[i];
     const int C = vp.C;
     if (r > 0) {
+        // The records of this Gaussian are one contiguous block (its nby x nbx cells, K1); B1 wrote every
+        // one of them -- real sums for the entries the forward consumed, zeros for the rest.
         const int RS = grad_stride(C);
-        const float2 xy = g.xy[i];
-        const float4 co = g.conic_opacity[i];
-        const Rect rc = tile_rect(xy.x, xy.y, r, vp.gx, vp.gy);
-        // the same cell block K1 counted and K4 used to build the cell lists (same code, same inputs);
-        // its records are the dense nby x nbx block starting at rec_offsets[i]
-        const Bands bd = cell_bands(xy.x, xy.y, co.x, co.y, co.z, co.w, rc);
-        if (bd.nbx > 0) {
-            const uint32_t rec0 = g.rec_offsets[i], p0 = g.offsets[i];
-            const int rw = rc.x1 - rc.x0;
-            const int bx1 = bd.bx0 + bd.nbx, by1 = bd.by0 + bd.nby;
-            for (int ty = bd.by0 >> 2; ty <= (by1 - 1) >> 2; ++ty)
-                for (int tx = bd.bx0 >> 2; tx <= (bx1 - 1) >> 2; ++tx) {
-                    const uint32_t p = p0 + (uint32_t)((ty - rc.y0) * rw + (tx - rc.x0));
-                    if (p >= cap) continue;
-                    const uint32_t pos = b.sorted_pos[p];
-                    if (pos >= cap) continue;
-                    const int t = ty * vp.gx + tx;
-                    const uint32_t k = pos - g.tile_start[t];
-                    const int cx0 = max(bd.bx0, 4 * tx), cx1 = min(bx1, 4 * tx + 4);
-                    const int cy0 = max(bd.by0, 4 * ty), cy1 = min(by1, 4 * ty + 4);
-                    for (int gy = cy0; gy < cy1; ++gy)
-                        for (int gx_ = cx0; gx_ < cx1; ++gx_) {
-                            if (k >= g.ckmax[t * kCells + cell_id(gx_ & 3, gy & 3)]) continue;   // record not written
-                            const uint32_t slot = rec0 + (uint32_t)((gy - bd.by0) * bd.nbx + (gx_ - bd.bx0));
-                            if (slot >= c.rec_cap) continue;
-                            const float *src = dLt + (size_t)slot * RS;
+        const uint32_t rec0 = g.cellinfo[i].z, cnt = g.rec_touched[i];
+        const uint32_t end = min(rec0 + cnt, max(rec0, c.rec_cap));
+        for (uint32_t slot = rec0; slot < end; ++slot) {
+            const float *src = dLt + (size_t)slot * RS;
 #pragma unroll
-                            for (int j = 0; j < 10; ++j) acc[j] += src[j];
-                            if (C > 3) {
-                                acc[10] += src[10]; acc[11] += src[11]; acc[12] += src[12];
-                            }
-                        }
-                }
+            for (int j = 0; j < 10; ++j) acc[j] += src[j];
+            if (C > 3) {
+                acc[10] += src[10]; acc[11] += src[11]; acc[12] += src[12];
+            }
         }
     }
     o.dL_dmeans2D[3 * si + 0] = acc[0];

@@ -97,8 +97,8 @@ __device__ __forceinline__ void zero_entry(float4 (&r)[4])
     for (int v = 0; v < 4; ++v) r[v] = make_float4(0.f, 0.f, 0.f, 0.f);
 }
 
-// block -> (view, tile, quadrant): rank in the batch-wide launch order of K4b (longest lists first); the four
-// quadrants of a tile are blocks b, b+8, b+16, b+24 (same XCD).  Returns false past the end.
+// block -> (view, tile, quadrant): rank in the launch order of K3 (the r-th longest tile of every view, views
+// interleaved); the four quadrants of a tile are blocks b, b+8, b+16, b+24 (same XCD).  False past the end.
 __device__ __forceinline__ bool block_to_quadrant(const BatchDesc &d, int b, int &view, int &tile, int &q)
 {
     const int xcd = b & 7, r = b >> 3;
@@ -107,9 +107,8 @@ __device__ __forceinline__ bool block_to_quadrant(const BatchDesc &d, int b, int
     const int T = ((d.W + kTile - 1) / kTile) * ((d.H + kTile - 1) / kTile);
     if (rank >= (uint32_t)d.B * (uint32_t)T) return false;
     const GeomLayout L = geom_layout(d.N, d.H, d.W);
-    const uint32_t item = reinterpret_cast<const uint32_t *>(d.geom + (size_t)(rank / (uint32_t)T) * d.geom_stride + L.order)[rank % (uint32_t)T];
-    view = (int)(item >> 16);
-    tile = (int)(item & 0xFFFFu);
+    view = (int)(rank % (uint32_t)d.B);
+    tile = (int)reinterpret_cast<const uint32_t *>(d.geom + (size_t)view * d.geom_stride + L.order)[rank / (uint32_t)d.B];
     return true;
 }
 // Waves with long lists raise their issue priority: while the bulk of the (short) waves keeps the SIMD
@@ -311,10 +310,23 @@ __global__ __launch_bounds__(64) void k_render_bwd(BatchDesc d)
     const uint32_t s = g.tile_start[tile];
     const uint32_t nd = (s < cap) ? g.cdone[tile * kCells + lp.cell] : 0u;   // entries this row's forward consumed
     const uint32_t ndmax = wave_max_u32(nd);
-    if (ndmax == 0 || ndmax < g_min_work) { trace.done(0); return; }
-    set_priority_by_length(ndmax);
     const uint2 *__restrict__ list = b.clist + (size_t)lp.cell * b.cap + s;
     const uint32_t *__restrict__ slots = b.cslot + (size_t)lp.cell * b.cap + s;
+    {
+        // entries the forward never reached get all-zero records, so that B2 can sum every Gaussian's
+        // contiguous record block without looking anything up
+        const uint32_t nr = (s < cap) ? g.ccount[tile * kCells + lp.cell] : 0u;
+        for (uint32_t j = nd + (uint32_t)li; j < nr; j += 16u) {
+            const uint32_t slot = slots[j];
+            if (slot < rec_cap) {
+                float *dst = rec + (size_t)slot * RS;
+#pragma unroll
+                for (int i = 0; i < RS; ++i) dst[i] = 0.f;
+            }
+        }
+    }
+    if (ndmax == 0 || ndmax < g_min_work) { trace.done(0); return; }
+    set_priority_by_length(ndmax);
 
     const size_t P = (size_t)vp.H * vp.W;
     const size_t pid = (size_t)py * vp.W + px;

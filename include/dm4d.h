@@ -173,6 +173,8 @@ int dm4d_raster_read_image_state(const void *image, int32_t image_height, int32_
  * blockIdx.y * gridDim.x + blockIdx.x.  NULL switches it off (the default).  min_work > 0 makes waves
  * whose longest list is shorter exit at once (isolates the long ones; results are then incomplete). */
 int dm4d_debug_trace(void *trace, uint32_t min_work);
+/* Debug: per-tile phase timestamps of the tile sort, uint64 [views * tiles, 5] = {start, binned, sorted, end, n}. */
+int dm4d_debug_sort_trace(void *trace);
 
 /* markVisible: present[i] = view-space z > 0.2 */
 int dm4d_mark_visible(int32_t N, const float *means3D, const float *viewmatrix, uint8_t *present,
