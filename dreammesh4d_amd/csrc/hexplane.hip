@@ -26,12 +26,19 @@ constexpr int kHexPlanes = 6;     // (x,y) (x,z) (x,t) (y,z) (y,t) (z,t)
 constexpr int kHexMaxScales = 8;
 __constant__ int c_axis0[6] = {0, 0, 0, 1, 1, 2};
 __constant__ int c_axis1[6] = {1, 2, 3, 2, 3, 3};
+static const int c_axis0_host[6] = {0, 0, 0, 1, 1, 2}, c_axis1_host[6] = {1, 2, 3, 2, 3, 3};
 
 struct HexDesc {
     int S, M, B;
     int res[kHexMaxScales][4];                    // resolution of axes x, y, z, t at scale s
     const float *plane[kHexMaxScales][kHexPlanes]; // [32][res[a1]][res[a0]]
     float lo[3], inv[3];                          // x_n = (p - lo) * inv - 1
+};
+// gradient planes of one backward call, passed by value (no device-side pointer table to upload)
+struct HexGrads {
+    float *g[kHexMaxScales * kHexPlanes];
+    unsigned long long end4[kHexMaxScales * kHexPlanes];   // running end (in float4) of the planes, for the zero fill
+    int n;
 };
 
 // grid_sample coordinate (align_corners=True, border padding): index of the lower texel and the
@@ -141,7 +148,7 @@ __global__ __launch_bounds__(256) void k_hex_bwd_spatial(HexDesc d, const float 
                                                          const int32_t *__restrict__ sp_texel,
                                                          const int32_t *__restrict__ sp_off,
                                                          const int32_t *__restrict__ sp_item,
-                                                         const float *__restrict__ G, float *const *__restrict__ g_plane)
+                                                         const float *__restrict__ G, HexGrads hg)
 {
     const size_t gid = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (gid >= (size_t)U * kHexCh) return;
@@ -162,10 +169,13 @@ __global__ __launch_bounds__(256) void k_hex_bwd_spatial(HexDesc d, const float 
         acc += w * gs;
     }
     const size_t HW = (size_t)d.res[s][c_axis0[p]] * d.res[s][c_axis1[p]];
-    g_plane[s * kHexPlanes + p][(size_t)c * HW + sp_texel[u]] = acc;
+    hg.g[s * kHexPlanes + p][(size_t)c * HW + sp_texel[u]] = acc;
 }
 
-// Time planes: one thread per (touched column, channel); rows are the 2 time texels of every frame.
+// Time planes: one thread per (touched column, channel, time-row slot).  The distinct time rows of the step
+// (<= 2 B: the two time texels of every frame, merged in a fixed order) are the same for every column of a
+// scale, so blockIdx.y enumerates row slots and a thread sums, over the column's items, only the frames that
+// touch its row -- 2 B times the parallelism of one thread per column, a quarter of the serial work.
 //   tp_scale[u], tp_plane[u], tp_col[u]; tp_off[U+1], tp_item[] = node * 2 + corner (column corner)
 constexpr int kHexMaxFrames = 16;
 __global__ __launch_bounds__(256) void k_hex_bwd_time(HexDesc d, const float *__restrict__ nodes,
@@ -175,14 +185,11 @@ __global__ __launch_bounds__(256) void k_hex_bwd_time(HexDesc d, const float *__
                                                       const int32_t *__restrict__ tp_col,
                                                       const int32_t *__restrict__ tp_off,
                                                       const int32_t *__restrict__ tp_item,
-                                                      const float *__restrict__ G, float *const *__restrict__ g_plane)
+                                                      const float *__restrict__ G, HexGrads hg)
 {
-    // The distinct time rows of this step (<= 2 B) and, per frame, which two of them it touches are the
-    // same for every thread: thread 0 merges them once (fixed order), the per-row sums live in LDS.
     __shared__ int s_rows[kHexMaxScales][2 * kHexMaxFrames], s_r0[kHexMaxScales][kHexMaxFrames],
         s_r1[kHexMaxScales][kHexMaxFrames], s_nrows[kHexMaxScales];
     __shared__ float s_wy[kHexMaxScales][kHexMaxFrames];
-    __shared__ float s_acc[2 * kHexMaxFrames][256];
     const int tid = threadIdx.x;
     if (tid < d.S) {
         const int sc = tid, Ht = d.res[sc][3];
@@ -205,33 +212,55 @@ __global__ __launch_bounds__(256) void k_hex_bwd_time(HexDesc d, const float *__
         }
         s_nrows[sc] = nrows;
     }
-    for (int r = 0; r < 2 * d.B; ++r) s_acc[r][tid] = 0.f;
     __syncthreads();
     const size_t gid = (size_t)blockIdx.x * 256 + tid;
     if (gid >= (size_t)U * kHexCh) return;
     const int c = (int)(gid % kHexCh), u = (int)(gid / kHexCh);
     const int s = tp_scale[u], p = tp_plane[u];
+    const int r = blockIdx.y;                 // row slot
+    if (r >= s_nrows[s]) return;
     const int a0 = c_axis0[p];
-    const int W = d.res[s][a0], H = d.res[s][3], nrows = s_nrows[s];
-    const int e0 = tp_off[u], e1 = tp_off[u + 1];
-    for (int f = 0; f < d.B; ++f) {
-        float sum = 0.f;
-        for (int e = e0; e < e1; ++e) {
-            const int m = tp_item[e] >> 1, corner = tp_item[e] & 1;
-            const float xa = (nodes[3 * (size_t)m + a0] - d.lo[a0]) * d.inv[a0] - 1.0f;
-            int x0;
-            float wx;
-            texel_coord(xa, W, x0, wx);
-            const float wcol = corner ? wx : (1.f - wx);
-            sum += G[((((size_t)f * d.M + m) * d.S + s) * kHexPlanes + p) * kHexCh + c] * wcol;
+    const int W = d.res[s][a0], H = d.res[s][3];
+    // per frame: weight of this row (0 if the frame does not touch it); both texels may coincide at the border
+    float wf[kHexMaxFrames];
+#pragma unroll
+    for (int f = 0; f < kHexMaxFrames; ++f) {
+        wf[f] = 0.f;
+        if (f < d.B) {
+            const float wy = s_wy[s][f];
+            if (s_r0[s][f] == r) wf[f] += 1.f - wy;
+            if (s_r1[s][f] == r) wf[f] += wy;
         }
-        const float wy = s_wy[s][f];
-        s_acc[s_r0[s][f]][tid] += sum * (1.f - wy);
-        s_acc[s_r1[s][f]][tid] += sum * wy;
+    }
+    float acc = 0.f;
+    for (int e = tp_off[u]; e < tp_off[u + 1]; ++e) {
+        const int m = tp_item[e] >> 1, corner = tp_item[e] & 1;
+        const float xa = (nodes[3 * (size_t)m + a0] - d.lo[a0]) * d.inv[a0] - 1.0f;
+        int x0;
+        float wx;
+        texel_coord(xa, W, x0, wx);
+        const float wcol = corner ? wx : (1.f - wx);
+        float gs = 0.f;
+#pragma unroll
+        for (int f = 0; f < kHexMaxFrames; ++f)
+            if (f < d.B && wf[f] != 0.f)
+                gs += G[((((size_t)f * d.M + m) * d.S + s) * kHexPlanes + p) * kHexCh + c] * wf[f];
+        acc += gs * wcol;
     }
     const size_t HW = (size_t)W * H;
-    for (int r = 0; r < nrows; ++r)
-        g_plane[s * kHexPlanes + p][(size_t)c * HW + (size_t)s_rows[s][r] * W + tp_col[u]] = s_acc[r][tid];
+    hg.g[s * kHexPlanes + p][(size_t)c * HW + (size_t)s_rows[s][r] * W + tp_col[u]] = acc;
+}
+
+// zero fill of all gradient planes in one launch (float4 granularity; plane sizes are multiples of 4 floats)
+__global__ __launch_bounds__(256) void k_hex_zero(HexGrads hg)
+{
+    const unsigned long long total = hg.end4[hg.n - 1];
+    for (unsigned long long i = (unsigned long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (unsigned long long)gridDim.x * 256) {
+        int k = 0;
+        while (i >= hg.end4[k]) ++k;
+        const unsigned long long local = i - (k ? hg.end4[k - 1] : 0ull);
+        reinterpret_cast<float4 *>(hg.g[k])[local] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
 }
 
 // ---------------------------------------------------------------------------------------- plan helper
@@ -310,24 +339,39 @@ int dm4d_hexplane_backward(int32_t S, int32_t M, int32_t B, const int32_t *res, 
                            int32_t n_spatial, const int32_t *sp_scale, const int32_t *sp_plane, const int32_t *sp_texel,
                            const int32_t *sp_off, const int32_t *sp_item, int32_t n_time, const int32_t *tp_scale,
                            const int32_t *tp_plane, const int32_t *tp_col, const int32_t *tp_off, const int32_t *tp_item,
-                           void *scratch, float *const *g_planes_dev, dm4d_stream_t stream)
+                           void *scratch, float *const *g_planes, dm4d_stream_t stream)
 {
     HexDesc d;
     int rc = fill_desc(d, S, M, B, res, planes, aabb_host);
     if (rc) return rc;
-    if (!planes || !nodes || !times || !g_feat || !scratch || !g_planes_dev) { set_error("hexplane: null tensor"); return DM4D_ERR_INVALID; }
+    if (!planes || !nodes || !times || !g_feat || !scratch || !g_planes) { set_error("hexplane: null tensor"); return DM4D_ERR_INVALID; }
     hipStream_t st = (hipStream_t)stream;
+    HexGrads hg;
+    memset(&hg, 0, sizeof(hg));
+    hg.n = S * kHexPlanes;
+    unsigned long long run = 0;
+    for (int s = 0; s < S; ++s)
+        for (int p = 0; p < kHexPlanes; ++p) {
+            const int k = s * kHexPlanes + p;
+            hg.g[k] = g_planes[k];
+            if (!hg.g[k]) { set_error("hexplane: null gradient plane %d", k); return DM4D_ERR_INVALID; }
+            const size_t n = (size_t)kHexCh * d.res[s][c_axis0_host[p]] * d.res[s][c_axis1_host[p]];   // 32 channels: multiple of 4
+            run += n / 4;
+            hg.end4[k] = run;
+        }
+    hipLaunchKernelGGL(k_hex_zero, dim3(2048), dim3(256), 0, st, hg);
+    DM4D_HIP_CHECK(hipGetLastError());
     const size_t total = (size_t)B * M * S * kHexCh;
     hipLaunchKernelGGL(k_hex_bwd_point, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, d, nodes, times, g_feat, (float *)scratch);
     DM4D_HIP_CHECK(hipGetLastError());
     if (n_spatial > 0) {
         hipLaunchKernelGGL(k_hex_bwd_spatial, dim3((unsigned)(((size_t)n_spatial * kHexCh + 255) / 256)), dim3(256), 0, st, d, nodes,
-                           n_spatial, sp_scale, sp_plane, sp_texel, sp_off, sp_item, (const float *)scratch, g_planes_dev);
+                           n_spatial, sp_scale, sp_plane, sp_texel, sp_off, sp_item, (const float *)scratch, hg);
         DM4D_HIP_CHECK(hipGetLastError());
     }
     if (n_time > 0) {
-        hipLaunchKernelGGL(k_hex_bwd_time, dim3((unsigned)(((size_t)n_time * kHexCh + 255) / 256)), dim3(256), 0, st, d, nodes, times,
-                           n_time, tp_scale, tp_plane, tp_col, tp_off, tp_item, (const float *)scratch, g_planes_dev);
+        hipLaunchKernelGGL(k_hex_bwd_time, dim3((unsigned)(((size_t)n_time * kHexCh + 255) / 256), 2 * B), dim3(256), 0, st, d, nodes, times,
+                           n_time, tp_scale, tp_plane, tp_col, tp_off, tp_item, (const float *)scratch, hg);
         DM4D_HIP_CHECK(hipGetLastError());
     }
     return DM4D_OK;

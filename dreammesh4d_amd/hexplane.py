@@ -116,8 +116,8 @@ class _HexPlaneFeatures(torch.autograd.Function):
         dev = t.device
         B = int(t.shape[0])
         g = g_feat.detach().to(torch.float32).contiguous()
-        grads = [torch.zeros_like(p) for p in pl]      # dense, zero except the touched texels
-        gptr = torch.tensor([x.data_ptr() for x in grads], dtype=torch.int64, device=dev)
+        grads = [torch.empty_like(p) for p in pl]      # dense; the C call zero-fills them (one launch) before the gathers
+        gptr = _plane_ptr_array(grads)
         scratch = torch.empty(L.dm4d_hexplane_scratch_bytes(plan.S, plan.M, B), dtype=torch.uint8, device=dev)
         sp, tp = plan.sp, plan.tp
         with torch.cuda.device(dev):
@@ -125,7 +125,7 @@ class _HexPlaneFeatures(torch.autograd.Function):
                 plan.S, plan.M, B, plan.res_c, _plane_ptr_array(pl), plan.aabb_c, _p(plan.nodes), _p(t), _p(g),
                 plan.n_sp, _p(sp["scale"]), _p(sp["plane"]), _p(sp["texel"]), _p(sp["off"]), _p(sp["item"]),
                 plan.n_tp, _p(tp["scale"]), _p(tp["plane"]), _p(tp["col"]), _p(tp["off"]), _p(tp["item"]),
-                _p(scratch), _p(gptr), torch.cuda.current_stream(dev).cuda_stream), "dm4d_hexplane_backward")
+                _p(scratch), gptr, torch.cuda.current_stream(dev).cuda_stream), "dm4d_hexplane_backward")
         return (None, None) + tuple(grads)
 
 

@@ -244,8 +244,9 @@ int dm4d_hexplane_forward(int32_t S, int32_t M, int32_t B, const int32_t *res, c
 int dm4d_hexplane_axis_index(int32_t S, int32_t M, const int32_t *res, const float *aabb_host, const float *nodes,
                              int32_t *i0, dm4d_stream_t stream);
 size_t dm4d_hexplane_scratch_bytes(int32_t S, int32_t M, int32_t B);
-/* Gradients w.r.t. the planes, written (not accumulated) into caller-ZEROED dense planes
- * `g_planes_dev` = DEVICE array of S*6 device pointers.  Atomic-free and deterministic: spatial planes
+/* Gradients w.r.t. the planes, written (not accumulated) into the dense planes `g_planes` = HOST array of
+ * S*6 device pointers (16-byte aligned, uninitialised: the call zero-fills them in one launch and hands the
+ * pointers to its kernels by value).  Atomic-free and deterministic: spatial planes
  * gather per touched texel (sp_*: scale, plane, texel, CSR of items node*4+corner), time planes per touched
  * column (tp_*: scale, plane, column, CSR of items node*2+corner). */
 int dm4d_hexplane_backward(int32_t S, int32_t M, int32_t B, const int32_t *res, const float *const *planes,
@@ -253,7 +254,7 @@ int dm4d_hexplane_backward(int32_t S, int32_t M, int32_t B, const int32_t *res, 
                            int32_t n_spatial, const int32_t *sp_scale, const int32_t *sp_plane, const int32_t *sp_texel,
                            const int32_t *sp_off, const int32_t *sp_item, int32_t n_time, const int32_t *tp_scale,
                            const int32_t *tp_plane, const int32_t *tp_col, const int32_t *tp_off, const int32_t *tp_item,
-                           void *scratch, float *const *g_planes_dev, dm4d_stream_t stream);
+                           void *scratch, float *const *g_planes, dm4d_stream_t stream);
 
 /* ------------------------------------------------------------------ deformation MLP (fused) */
 
