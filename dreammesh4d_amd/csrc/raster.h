@@ -33,8 +33,10 @@ constexpr int kPreBlock = kPreThreads * kPreItems;   // Gaussians per workgroup 
 constexpr int kMaxTiles = 36864; // tile histogram lives in LDS (4 B/tile of the 160 KB): <= 3072x3072 px
 constexpr int kMaxChannels = 6;  // colour channels blended per pass: 3 (drop-in operator) or 6 (RGB + normal)
 constexpr int kCells = 16;       // 4x4-pixel cells per 16x16 tile; cell id = 4 * quadrant + (cx & 1) + 2 * (cy & 1)
-// floats per (Gaussian, cell) record of the backward scratch: 2 mean + 3 conic + opacity + depth + C colours
-DM4D_HD static inline int grad_stride(int C) { return C <= 3 ? 10 : 13; }
+// floats per (Gaussian, cell) record of the backward scratch: 2 mean + 3 conic + opacity + depth + C colours,
+// padded to whole float4s (C = 6: one aligned 64-byte line per record -- measured: 52-byte records cost MORE
+// HBM write traffic than 64-byte ones, partial-line writes)
+DM4D_HD static inline int grad_stride(int C) { return C <= 3 ? 12 : 16; }
 
 // counters[]: duplicates, duplicate-capacity overflow, records (sum of the Gaussians' cells), record-capacity overflow
 enum GeomCounter { kCntD = 0, kCntOverflow = 1, kCntR = 2, kCntRecOverflow = 3 };

@@ -392,11 +392,14 @@ __global__ __launch_bounds__(kPreThreads) void k_gather_bwd(BatchDesc d)
         const uint32_t rec0 = g.cellinfo[i].z, cnt = g.rec_touched[i];
         const uint32_t end = min(rec0 + cnt, max(rec0, c.rec_cap));
         for (uint32_t slot = rec0; slot < end; ++slot) {
-            const float *src = dLt + (size_t)slot * RS;
-#pragma unroll
-            for (int j = 0; j < 10; ++j) acc[j] += src[j];
+            const float4 *src = reinterpret_cast<const float4 *>(dLt + (size_t)slot * RS);
+            const float4 a0 = src[0], a1 = src[1], a2 = src[2];
+            acc[0] += a0.x; acc[1] += a0.y; acc[2] += a0.z; acc[3] += a0.w;
+            acc[4] += a1.x; acc[5] += a1.y; acc[6] += a1.z; acc[7] += a1.w;
+            acc[8] += a2.x; acc[9] += a2.y;
             if (C > 3) {
-                acc[10] += src[10]; acc[11] += src[11]; acc[12] += src[12];
+                const float4 a3 = src[3];
+                acc[10] += a2.z; acc[11] += a2.w; acc[12] += a3.x;
             }
         }
     }

@@ -282,7 +282,8 @@ template <int C>
 __global__ __launch_bounds__(64) void k_render_bwd(BatchDesc d)
 {
     constexpr int NV = StagedN<C>::kVec;
-    constexpr int RS = 7 + C;   // == grad_stride(C): floats per record
+    constexpr int RS = 7 + C;             // values per record
+    constexpr int RSP = (C <= 3) ? 12 : 16;   // == grad_stride(C): floats per (padded) record
     __shared__ float4 s_e[4][kChunk][NV];
     __shared__ uint32_t s_slot[4][kChunk];
     __shared__ __attribute__((aligned(16))) float s_red[kBwdUnroll][RS][kRedStride];
@@ -319,9 +320,9 @@ __global__ __launch_bounds__(64) void k_render_bwd(BatchDesc d)
         for (uint32_t j = nd + (uint32_t)li; j < nr; j += 16u) {
             const uint32_t slot = slots[j];
             if (slot < rec_cap) {
-                float *dst = rec + (size_t)slot * RS;
+                float4 *dst = reinterpret_cast<float4 *>(rec + (size_t)slot * RSP);
 #pragma unroll
-                for (int i = 0; i < RS; ++i) dst[i] = 0.f;
+                for (int i = 0; i < RSP / 4; ++i) dst[i] = make_float4(0.f, 0.f, 0.f, 0.f);
             }
         }
     }
@@ -447,9 +448,9 @@ __global__ __launch_bounds__(64) void k_render_bwd(BatchDesc d)
                 p0 = p0 + p1;
                 p2 = p2 + p3;
                 p0 = p0 + p2;
-                const float total = p0.x + p0.y;
+                const float total = li < RS ? p0.x + p0.y : 0.f;   // lanes RS..RSP-1 write the padding
                 const uint32_t slot = s_slot[row][t];
-                if (li < RS && t < cnt && slot < rec_cap) rec[(size_t)slot * RS + li] = total;
+                if (li < RSP && t < cnt && slot < rec_cap) rec[(size_t)slot * RSP + li] = total;
             }
         }
         if (c0 == 0) break;
