@@ -62,12 +62,28 @@ int set_trace_buffer(void *dev_ptr, uint32_t min_work)
     return DM4D_OK;
 }
 
-template <int C> struct StagedN { static constexpr int kVec = (C <= 3) ? 3 : 4; };
+typedef float f2v __attribute__((ext_vector_type(2)));
+typedef float f4v __attribute__((ext_vector_type(4)));
 constexpr int kChunk = 16;   // list entries a row stages per step (one per lane of the row)
-constexpr int kFwdUnroll = 4, kBwdUnroll = 2;   // entries per inner-loop step (divide kChunk)
+constexpr int kFwdPairs = 2, kBwdPairs = 1;   // PAIRS of entries per inner-loop step
 
-// gather one list entry: a = (x, y, conic.x, conic.y)  b = (conic.z, opacity, depth, k bits)
-//                        c = colours 0..3               d = colours 4..5
+// LDS layout of a staged chunk: one 32-float block per PAIR of consecutive list entries (j even, j + 1),
+// geometry interleaved across the two entries so that a ds_read_b128 delivers register pairs the packed
+// FP32 instructions (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32: two lanes' worth of work per issue slot)
+// consume directly, colours kept per entry as channel pairs for the packed accumulators:
+//   [0..3]   x_j x_j1 y_j y_j1        [4..7]  A_j A_j1 B_j B_j1      [8..11] C_j C_j1 o_j o_j1   (conic A,B,C; opacity)
+//   [12..19] entry j  : c0 c1 c2 c3 | c4 c5 depth 1.0                 [20..27] entry j + 1, same
+//   [28..29] tile-list position k of j, j + 1 (bits)                  [30..35] padding
+// Strides are chosen against LDS bank conflicts (measured: 64 % of the forward's LDS cycles were conflicts
+// with 32-float pairs and 1 KB rows): 36 floats per pair spreads the 8 pairs a row stages at once over all
+// banks, 292 floats per row puts the 4 rows' broadcast reads (4 distinct addresses per instruction) on
+// disjoint bank groups.
+constexpr int kPairFloats = 36;
+constexpr int kRowFloats = (kChunk / 2) * kPairFloats + 4;
+constexpr int kPair4 = kPairFloats / 4;   // float4 per pair block
+
+// gather one list entry: r0 = (x, y, conic.x, conic.y)  r1 = (conic.z, opacity, depth, k bits)
+//                        r2 = colours 0..3               r3 = colours 4..5
 template <int C>
 __device__ __forceinline__ void gather_entry(const uint2 qe, const GeomPtrs &g, const float *__restrict__ colors,
                                              float4 (&r)[4])
@@ -81,6 +97,7 @@ __device__ __forceinline__ void gather_entry(const uint2 qe, const GeomPtrs &g, 
     r[1] = make_float4(co.z, co.w, dep, __uint_as_float(qe.y));
     if (C <= 3) {
         r[2] = make_float4(c[0], c[1], c[2], 0.f);
+        r[3] = make_float4(0.f, 0.f, 0.f, 0.f);
     } else {
         const float2 c01 = *reinterpret_cast<const float2 *>(c);
         const float2 c23 = *reinterpret_cast<const float2 *>(c + 2);
@@ -95,6 +112,61 @@ __device__ __forceinline__ void zero_entry(float4 (&r)[4])
 {
 #pragma unroll
     for (int v = 0; v < 4; ++v) r[v] = make_float4(0.f, 0.f, 0.f, 0.f);
+}
+// lane li of a row stores its gathered entry into the row's chunk (pair li >> 1, half li & 1)
+__device__ __forceinline__ void stage_entry(float *row_base, int li, const float4 (&r)[4])
+{
+    float *pb = row_base + (li >> 1) * kPairFloats;
+    const int h = li & 1;
+    pb[0 + h] = r[0].x; pb[2 + h] = r[0].y; pb[4 + h] = r[0].z; pb[6 + h] = r[0].w;
+    pb[8 + h] = r[1].x; pb[10 + h] = r[1].y; pb[28 + h] = r[1].w;
+    *reinterpret_cast<float4 *>(pb + 12 + 8 * h) = r[2];
+    *reinterpret_cast<float4 *>(pb + 16 + 8 * h) = make_float4(r[3].x, r[3].y, r[1].z, 1.0f);
+}
+
+// N pairs of alphas, written step-by-step across the pairs so that the instruction stream interleaves the
+// independent dependency chains (a lone wave on a long silhouette list issues dependent VALU ops slowly).
+// Per element bit-identical to:  power = -0.5f * ((A dx) dx + (C dy) dy) - (B dx) dy;  G = det_expf(power).
+template <int N>
+__device__ __forceinline__ void pair_gauss(const f4v (&g0)[N], const f4v (&g1)[N], const f4v (&g2)[N], f2v pxf, f2v pyf,
+                                           f2v (&dx)[N], f2v (&dy)[N], f2v (&pw)[N], f2v (&G)[N])
+{
+    f2v u[N], v[N], w[N];
+#pragma unroll
+    for (int j = 0; j < N; ++j) { dx[j] = g0[j].xy - pxf; dy[j] = g0[j].zw - pyf; }
+#pragma unroll
+    for (int j = 0; j < N; ++j) { u[j] = g1[j].xy * dx[j]; v[j] = g2[j].xy * dy[j]; w[j] = g1[j].zw * dx[j]; }
+#pragma unroll
+    for (int j = 0; j < N; ++j) { u[j] = u[j] * dx[j]; v[j] = v[j] * dy[j]; w[j] = w[j] * dy[j]; }
+#pragma unroll
+    for (int j = 0; j < N; ++j) u[j] = u[j] + v[j];
+#pragma unroll
+    for (int j = 0; j < N; ++j) pw[j] = (f2v)(-0.5f) * u[j] - w[j];
+    // det_expf (common.h), two elements per instruction where the ISA has a packed form
+    const float L2E_HI = 0x1.715476p+0f, L2E_LO = 0x1.4ae0c0p-26f;
+    f2v x[N], n[N], f[N], p[N];
+#pragma unroll
+    for (int j = 0; j < N; ++j) x[j] = f2v{fmaxf(pw[j].x, -87.0f), fmaxf(pw[j].y, -87.0f)};
+#pragma unroll
+    for (int j = 0; j < N; ++j) n[j] = __builtin_elementwise_rint(x[j] * (f2v)(L2E_HI));
+#pragma unroll
+    for (int j = 0; j < N; ++j) f[j] = __builtin_elementwise_fma(x[j], (f2v)(L2E_HI), -n[j]);
+#pragma unroll
+    for (int j = 0; j < N; ++j) f[j] = __builtin_elementwise_fma(x[j], (f2v)(L2E_LO), f[j]);
+#pragma unroll
+    for (int j = 0; j < N; ++j) p[j] = __builtin_elementwise_fma((f2v)(0x1.446c7ep-13f), f[j], (f2v)(0x1.5f48c8p-10f));
+#pragma unroll
+    for (int j = 0; j < N; ++j) p[j] = __builtin_elementwise_fma(p[j], f[j], (f2v)(0x1.3b29d8p-7f));
+#pragma unroll
+    for (int j = 0; j < N; ++j) p[j] = __builtin_elementwise_fma(p[j], f[j], (f2v)(0x1.c6aeccp-5f));
+#pragma unroll
+    for (int j = 0; j < N; ++j) p[j] = __builtin_elementwise_fma(p[j], f[j], (f2v)(0x1.ebfbe0p-3f));
+#pragma unroll
+    for (int j = 0; j < N; ++j) p[j] = __builtin_elementwise_fma(p[j], f[j], (f2v)(0x1.62e430p-1f));
+#pragma unroll
+    for (int j = 0; j < N; ++j) p[j] = __builtin_elementwise_fma(p[j], f[j], (f2v)(1.0f));
+#pragma unroll
+    for (int j = 0; j < N; ++j) G[j] = f2v{__builtin_ldexpf(p[j].x, (int)n[j].x), __builtin_ldexpf(p[j].y, (int)n[j].y)};
 }
 
 // block -> (view, tile, quadrant): rank in the launch order of K3 (the r-th longest tile of every view, views
@@ -147,10 +219,9 @@ __device__ __forceinline__ LanePixel lane_pixel(int lane, int tx, int ty, int q)
 template <int C>
 __global__ __launch_bounds__(64) void k_render_fwd(BatchDesc d)
 {
-    constexpr int NV = StagedN<C>::kVec;
     // one wave-private staging buffer: the next chunk waits in registers (prefetched during the
     // blend loop) and is written after the loop -- same wave, program order, no hazard
-    __shared__ float4 s_e[4][kChunk][NV];
+    __shared__ __attribute__((aligned(16))) float s_p[4 * kRowFloats];
     const WaveTrace trace;
     int view, tile, q;
     if (!block_to_quadrant(d, blockIdx.x, view, tile, q)) { trace.done(0); return; }
@@ -168,7 +239,7 @@ __global__ __launch_bounds__(64) void k_render_fwd(BatchDesc d)
     const LanePixel lp = lane_pixel(lane, tx, ty, q);
     const int px = lp.px, py = lp.py, row = lp.row, li = lp.li;
     const bool inside = px < vp.W && py < vp.H;
-    const float pxf = (float)px, pyf = (float)py;
+    const f2v pxf = (f2v)((float)px), pyf = (f2v)((float)py);
 
     const uint32_t s = g.tile_start[tile];
     const uint32_t nr = (s < cap) ? g.ccount[tile * kCells + lp.cell] : 0u;   // this row's list length
@@ -176,11 +247,10 @@ __global__ __launch_bounds__(64) void k_render_fwd(BatchDesc d)
     set_priority_by_length(nmax);
     if (nmax < g_min_work) { trace.done(0); return; }
     const uint2 *__restrict__ list = b.clist + (size_t)lp.cell * b.cap + s;
+    float *row_base = s_p + row * kRowFloats;
 
-    float T_ = 1.0f, D = 0.f, Wt = 0.f;
-    float Cacc[C];
-#pragma unroll
-    for (int ch = 0; ch < C; ++ch) Cacc[ch] = 0.f;
+    float T_ = 1.0f;
+    f2v C01 = (f2v)(0.f), C23 = (f2v)(0.f), C45 = (f2v)(0.f), DW = (f2v)(0.f);   // colours | (depth, alpha) sums
     uint32_t last = 0, lastj = 0;
     bool done = !inside;
 
@@ -190,70 +260,52 @@ __global__ __launch_bounds__(64) void k_render_fwd(BatchDesc d)
     for (uint32_t c0 = 0; c0 < nmax; c0 += kChunk) {
         const int cnt = (c0 < nr) ? (int)min((uint32_t)kChunk, nr - c0) : 0;
         __builtin_amdgcn_wave_barrier();
-#pragma unroll
-        for (int v = 0; v < NV; ++v) s_e[row][li][v] = r[v];
+        stage_entry(row_base, li, r);
         zero_entry(r);
         if (c0 + kChunk + (uint32_t)li < nr) gather_entry<C>(list[c0 + kChunk + li], g, colors, r);   // prefetch
         __builtin_amdgcn_wave_barrier();
         if (__ballot((!done) & (cnt > 0)) == 0) break;   // every pixel with entries left is saturated
         int t = 0;
         do {
-            // kFwdUnroll entries per step: their alphas are independent (a lone wave on a long silhouette list is
-            // bound by the ~25-deep dependent chain of one alpha, not by issue), the blend below is sequential.
-            // Branch-free (selects, not exec-mask branches): lanes that do not take an entry blend with
-            // weight 0, which leaves their accumulators bit-identical; padding entries are inert.
-            float al[kFwdUnroll], pw[kFwdUnroll], ex[kFwdUnroll], op[kFwdUnroll];
-            bool ok[kFwdUnroll];
-            {
-                float dx[kFwdUnroll], dy[kFwdUnroll], qa[kFwdUnroll], qb[kFwdUnroll], qc[kFwdUnroll];
+            // 2 * kFwdPairs entries per step.  Their alphas are independent and evaluated two per packed
+            // instruction; the blend below is sequential and branch-free (selects, not exec-mask branches):
+            // lanes that do not take an entry blend with weight 0, which leaves their accumulators
+            // bit-identical; padding entries are inert.
+            const f4v *P = reinterpret_cast<const f4v *>(row_base + (t >> 1) * kPairFloats);
+            f4v g0[kFwdPairs], g1[kFwdPairs], g2[kFwdPairs];
 #pragma unroll
-                for (int j = 0; j < kFwdUnroll; ++j) {
-                    const float4 ea = s_e[row][t + j][0], eb = s_e[row][t + j][1];
-                    dx[j] = ea.x - pxf;
-                    dy[j] = ea.y - pyf;
-                    qa[j] = ea.z; qb[j] = ea.w; qc[j] = eb.x; op[j] = eb.y;
-                }
-                float u[kFwdUnroll], v[kFwdUnroll], w2[kFwdUnroll];
+            for (int j = 0; j < kFwdPairs; ++j) { g0[j] = P[kPair4 * j + 0]; g1[j] = P[kPair4 * j + 1]; g2[j] = P[kPair4 * j + 2]; }
+            f2v dx[kFwdPairs], dy[kFwdPairs], pw[kFwdPairs], G[kFwdPairs], al[kFwdPairs];
+            pair_gauss<kFwdPairs>(g0, g1, g2, pxf, pyf, dx, dy, pw, G);
 #pragma unroll
-                for (int j = 0; j < kFwdUnroll; ++j) { u[j] = qa[j] * dx[j]; v[j] = qc[j] * dy[j]; w2[j] = qb[j] * dx[j]; }
-#pragma unroll
-                for (int j = 0; j < kFwdUnroll; ++j) { u[j] = u[j] * dx[j]; v[j] = v[j] * dy[j]; w2[j] = w2[j] * dy[j]; }
-#pragma unroll
-                for (int j = 0; j < kFwdUnroll; ++j) u[j] = u[j] + v[j];
-#pragma unroll
-                for (int j = 0; j < kFwdUnroll; ++j) pw[j] = -0.5f * u[j] - w2[j];
+            for (int j = 0; j < kFwdPairs; ++j) {
+                const f2v oa = g2[j].zw * G[j];
+                al[j] = f2v{fminf(0.99f, oa.x), fminf(0.99f, oa.y)};
             }
-            det_expf_n<kFwdUnroll>(pw, ex);
 #pragma unroll
-            for (int j = 0; j < kFwdUnroll; ++j) al[j] = fminf(0.99f, op[j] * ex[j]);
+            for (int j = 0; j < kFwdPairs; ++j) {
 #pragma unroll
-            for (int j = 0; j < kFwdUnroll; ++j) ok[j] = (pw[j] <= 0.0f) & (al[j] >= 1.0f / 255.0f);
-#pragma unroll
-            for (int j = 0; j < kFwdUnroll; ++j) {
-                const float4 eb = s_e[row][t + j][1], ec = s_e[row][t + j][2];
-                const float alpha = al[j];
-                const float test_T = T_ * (1.0f - alpha);
-                const bool valid = (!done) & ok[j];
-                const bool stop = valid & (test_T < 0.0001f);
-                const bool contrib = valid & (!stop);
-                const float w = contrib ? alpha * T_ : 0.f;
-                Cacc[0] = __builtin_fmaf(ec.x, w, Cacc[0]);
-                Cacc[1] = __builtin_fmaf(ec.y, w, Cacc[1]);
-                Cacc[2] = __builtin_fmaf(ec.z, w, Cacc[2]);
-                if (C > 3) {
-                    const float4 ed = s_e[row][t + j][NV - 1];
-                    Cacc[3] = __builtin_fmaf(ec.w, w, Cacc[3]);
-                    Cacc[C > 4 ? 4 : 0] = __builtin_fmaf(ed.x, w, Cacc[C > 4 ? 4 : 0]);
-                    Cacc[C > 5 ? 5 : 0] = __builtin_fmaf(ed.y, w, Cacc[C > 5 ? 5 : 0]);
+                for (int h = 0; h < 2; ++h) {
+                    const f4v e0 = P[kPair4 * j + 3 + 2 * h], e1 = P[kPair4 * j + 4 + 2 * h];
+                    const float alpha = h ? al[j].y : al[j].x, power = h ? pw[j].y : pw[j].x;
+                    const uint32_t kbits = __float_as_uint(h ? P[kPair4 * j + 7].y : P[kPair4 * j + 7].x);
+                    const float test_T = T_ * (1.0f - alpha);
+                    const bool valid = (!done) & (power <= 0.0f) & (alpha >= 1.0f / 255.0f);
+                    const bool stop = valid & (test_T < 0.0001f);
+                    const bool contrib = valid & (!stop);
+                    const float w = contrib ? alpha * T_ : 0.f;
+                    const f2v ww = (f2v)(w);
+                    C01 = __builtin_elementwise_fma(e0.xy, ww, C01);
+                    C23 = __builtin_elementwise_fma(e0.zw, ww, C23);
+                    if (C > 3) C45 = __builtin_elementwise_fma(e1.xy, ww, C45);
+                    DW = __builtin_elementwise_fma(e1.zw, ww, DW);      // depth * w | 1 * w
+                    T_ = contrib ? test_T : T_;
+                    last = contrib ? kbits + 1u : last;
+                    lastj = contrib ? c0 + (uint32_t)(t + 2 * j + h) + 1u : lastj;
+                    done = done | stop;
                 }
-                D = __builtin_fmaf(eb.z, w, D);
-                Wt = Wt + w;
-                T_ = contrib ? test_T : T_;
-                last = contrib ? __float_as_uint(eb.w) + 1u : last;
-                lastj = contrib ? c0 + (uint32_t)(t + j) + 1u : lastj;
-                done = done | stop;
             }
-            t += kFwdUnroll;
+            t += 2 * kFwdPairs;
         } while (t < kChunk && __ballot((!done) & (t < cnt)) != 0);
     }
     if (inside) {
@@ -261,10 +313,11 @@ __global__ __launch_bounds__(64) void k_render_fwd(BatchDesc d)
         const size_t pid = (size_t)py * vp.W + px;
         im.final_T[pid] = T_;
         im.n_contrib[pid] = last;
+        const float Cacc[6] = {C01.x, C01.y, C23.x, C23.y, C45.x, C45.y};
 #pragma unroll
         for (int ch = 0; ch < C; ++ch) out_color[ch * P + pid] = __builtin_fmaf(T_, vp.bg[ch], Cacc[ch]);
-        out_depth[pid] = D;
-        out_alpha[pid] = Wt;
+        out_depth[pid] = DW.x;
+        out_alpha[pid] = DW.y;
     }
     const uint32_t wj = row_max_u32(lastj), wk = row_max_u32(last);
     if (li == 0) {
@@ -275,18 +328,17 @@ __global__ __launch_bounds__(64) void k_render_fwd(BatchDesc d)
 }
 
 // ---------------------------------------------------------------------------------------- B1
-typedef float f2v __attribute__((ext_vector_type(2)));
 constexpr int kRedStride = 68;   // floats per value row of the transposed reduction buffer (64 lanes + pad)
 
 template <int C>
 __global__ __launch_bounds__(64) void k_render_bwd(BatchDesc d)
 {
-    constexpr int NV = StagedN<C>::kVec;
-    constexpr int RS = 7 + C;             // values per record
+    constexpr int RS = 7 + C;                 // values per record
     constexpr int RSP = (C <= 3) ? 12 : 16;   // == grad_stride(C): floats per (padded) record
-    __shared__ float4 s_e[4][kChunk][NV];
+    constexpr int U = 2 * kBwdPairs;          // entries per inner-loop step
+    __shared__ __attribute__((aligned(16))) float s_p[4 * kRowFloats];
     __shared__ uint32_t s_slot[4][kChunk];
-    __shared__ __attribute__((aligned(16))) float s_red[kBwdUnroll][RS][kRedStride];
+    __shared__ __attribute__((aligned(16))) float s_red[U][RS][kRedStride];
     const WaveTrace trace;
     int view, tile, q;
     if (!block_to_quadrant(d, blockIdx.x, view, tile, q)) { trace.done(0); return; }
@@ -306,7 +358,7 @@ __global__ __launch_bounds__(64) void k_render_bwd(BatchDesc d)
     const LanePixel lp = lane_pixel(lane, tx, ty, q);
     const int px = lp.px, py = lp.py, row = lp.row, li = lp.li;
     const bool inside = px < vp.W && py < vp.H;
-    const float pxf = (float)px, pyf = (float)py;
+    const f2v pxf = (f2v)((float)px), pyf = (f2v)((float)py);
 
     const uint32_t s = g.tile_start[tile];
     const uint32_t nd = (s < cap) ? g.cdone[tile * kCells + lp.cell] : 0u;   // entries this row's forward consumed
@@ -328,13 +380,12 @@ __global__ __launch_bounds__(64) void k_render_bwd(BatchDesc d)
     }
     if (ndmax == 0 || ndmax < g_min_work) { trace.done(0); return; }
     set_priority_by_length(ndmax);
+    float *row_base = s_p + row * kRowFloats;
 
     const size_t P = (size_t)vp.H * vp.W;
     const size_t pid = (size_t)py * vp.W + px;
     float T_final = 0.f, gD = 0.f, gA = 0.f;
-    float gCol[C];
-#pragma unroll
-    for (int ch = 0; ch < C; ++ch) gCol[ch] = 0.f;
+    float gCol[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     uint32_t last = 0;
     if (inside) {
         T_final = im.final_T[pid];
@@ -349,7 +400,8 @@ __global__ __launch_bounds__(64) void k_render_bwd(BatchDesc d)
     for (int ch = 0; ch < C; ++ch) bgdot += vp.bg[ch] * gCol[ch];
     const float Tb = T_final * bgdot;
     float T_ = T_final, S = 0.f;
-    const float half_W = 0.5f * (float)vp.W, half_H = 0.5f * (float)vp.H;
+    const f2v g01 = f2v{gCol[0], gCol[1]}, g23 = f2v{gCol[2], gCol[3]}, g45 = f2v{gCol[4], gCol[5]}, gDA = f2v{gD, gA};
+    const f2v halfWH = f2v{0.5f * (float)vp.W, 0.5f * (float)vp.H};
     // reduction role of this lane: value li of its row (lanes with li >= RS idle in the sum)
     const int red_i = li < RS ? li : 0;
     const float4 *red_src = reinterpret_cast<const float4 *>(&s_red[0][red_i][row * 16]);
@@ -367,8 +419,7 @@ __global__ __launch_bounds__(64) void k_render_bwd(BatchDesc d)
         const int cnt = (c0 < nd) ? (int)min((uint32_t)kChunk, nd - c0) : 0;
         const int tmax = (int)min((uint32_t)kChunk, ndmax - c0);
         __builtin_amdgcn_wave_barrier();
-#pragma unroll
-        for (int v = 0; v < NV; ++v) s_e[row][li][v] = r[v];
+        stage_entry(row_base, li, r);
         s_slot[row][li] = rslot;
         zero_entry(r);
         if (c0 >= (uint32_t)kChunk && c0 - kChunk + (uint32_t)li < nd) {   // prefetch the chunk in front
@@ -376,69 +427,65 @@ __global__ __launch_bounds__(64) void k_render_bwd(BatchDesc d)
             rslot = slots[c0 - kChunk + li];
         }
         __builtin_amdgcn_wave_barrier();
-        // kBwdUnroll entries per step (aligned groups, highest first; slots past the row's count hold inert
-        // padding): independent alphas overlap, and one LDS round trip serves the whole group.
-        for (int tg = ((tmax - 1) / kBwdUnroll) * kBwdUnroll; tg >= 0; tg -= kBwdUnroll) {
-            float Gr_[kBwdUnroll], al_[kBwdUnroll], dx_[kBwdUnroll], dy_[kBwdUnroll];
-            bool ok_[kBwdUnroll];
+        // U entries per step (aligned groups, highest first; slots past the row's count hold inert padding):
+        // alphas two per packed instruction, one LDS round trip of the reduction for the whole group.
+        for (int tg = ((tmax - 1) / U) * U; tg >= 0; tg -= U) {
+            const f4v *P4 = reinterpret_cast<const f4v *>(row_base + (tg >> 1) * kPairFloats);
+            f4v g0[kBwdPairs], g1[kBwdPairs], g2[kBwdPairs];
 #pragma unroll
-            for (int j = 0; j < kBwdUnroll; ++j) {
-                const int t = tg + kBwdUnroll - 1 - j;
-                const float4 ea = s_e[row][t][0], eb = s_e[row][t][1];
-                dx_[j] = ea.x - pxf;
-                dy_[j] = ea.y - pyf;
-                const float power = -0.5f * ((ea.z * dx_[j]) * dx_[j] + (eb.x * dy_[j]) * dy_[j]) - (ea.w * dx_[j]) * dy_[j];
-                Gr_[j] = det_expf(power);
-                al_[j] = fminf(0.99f, eb.y * Gr_[j]);
-                ok_[j] = (__float_as_uint(eb.w) < last) & (power <= 0.0f) & (al_[j] >= 1.0f / 255.0f);
-            }
+            for (int j = 0; j < kBwdPairs; ++j) { g0[j] = P4[kPair4 * j + 0]; g1[j] = P4[kPair4 * j + 1]; g2[j] = P4[kPair4 * j + 2]; }
+            f2v dx2[kBwdPairs], dy2[kBwdPairs], pw[kBwdPairs], Gr2[kBwdPairs];
+            pair_gauss<kBwdPairs>(g0, g1, g2, pxf, pyf, dx2, dy2, pw, Gr2);
             __builtin_amdgcn_wave_barrier();
 #pragma unroll
-            for (int j = 0; j < kBwdUnroll; ++j) {
-                const int t = tg + kBwdUnroll - 1 - j;
-                const float4 ea = s_e[row][t][0], eb = s_e[row][t][1], ec = s_e[row][t][2];
+            for (int e = U - 1; e >= 0; --e) {          // back to front inside the group
+                const int j = e >> 1, h = e & 1, t = tg + e;
+                const f4v e0 = P4[kPair4 * j + 3 + 2 * h], e1 = P4[kPair4 * j + 4 + 2 * h];
+                const uint32_t k = __float_as_uint(h ? P4[kPair4 * j + 7].y : P4[kPair4 * j + 7].x);
+                const float dx = h ? dx2[j].y : dx2[j].x, dy = h ? dy2[j].y : dy2[j].x;
+                const float power = h ? pw[j].y : pw[j].x, Gr = h ? Gr2[j].y : Gr2[j].x;
+                const float cA = h ? g1[j].y : g1[j].x, cB = h ? g1[j].w : g1[j].z, cC = h ? g2[j].y : g2[j].x;
+                const float op = h ? g2[j].w : g2[j].z;
                 // Branch-free: lanes that do not take the entry contribute exact zeros.
-                const float dx = dx_[j], dy = dy_[j], alpha = al_[j];
-                const bool contrib = ok_[j];
-                float col[C];
-                col[0] = ec.x; col[1] = ec.y; col[2] = ec.z;
-                if (C > 3) {
-                    const float4 ed = s_e[row][t][NV - 1];
-                    col[3] = ec.w;
-                    col[C > 4 ? 4 : 0] = ed.x;
-                    col[C > 5 ? 5 : 0] = ed.y;
-                }
-                const float G = contrib ? Gr_[j] : 0.f;
+                const float alpha = fminf(0.99f, op * Gr);
+                const bool contrib = (k < last) & (power <= 0.0f) & (alpha >= 1.0f / 255.0f);
+                const float G = contrib ? Gr : 0.f;
                 const float inv_om = __builtin_amdgcn_rcpf(1.f - alpha);
                 const float Tn = T_ * inv_om;
                 T_ = contrib ? Tn : T_;
                 const float w = contrib ? alpha * Tn : 0.f;
-                float V = gA + eb.z * gD;
-#pragma unroll
-                for (int ch = 0; ch < C; ++ch) V = __builtin_fmaf(col[ch], gCol[ch], V);
+                // V = dL/d(blended value of this entry) = depth gD + gA + sum_ch colour_ch gCol_ch
+                f2v va = e1.zw * gDA;
+                va = __builtin_elementwise_fma(e0.xy, g01, va);
+                va = __builtin_elementwise_fma(e0.zw, g23, va);
+                if (C > 3) va = __builtin_elementwise_fma(e1.xy, g45, va);
+                const float V = va.x + va.y;
                 const float dL_da = contrib ? (Tn * V - (S + Tb) * inv_om) : 0.f;
                 S = __builtin_fmaf(V, w, S);
-                const float dL_dG = eb.y * dL_da;
-                const float gdx = G * dx, gdy = G * dy;
-                float v[RS];
-                v[0] = dL_dG * (-gdx * ea.z - gdy * ea.w) * half_W;
-                v[1] = dL_dG * (-gdy * eb.x - gdx * ea.w) * half_H;
-                v[2] = -0.5f * gdx * dx * dL_dG;
-                v[3] = -gdx * dy * dL_dG;
-                v[4] = -0.5f * gdy * dy * dL_dG;
+                const float dL_dG = op * dL_da;
+                const f2v dxy = f2v{dx, dy};
+                const f2v gd = dxy * (f2v)(G);                              // (G dx, G dy)
+                const f2v t1 = gd * f2v{cA, cC}, t2 = gd.yx * (f2v)(cB);    // (gdx A, gdy C), (gdy B, gdx B)
+                const f2v v01 = ((f2v)(dL_dG) * (-(t1 + t2))) * halfWH;     // dL/dmean2D (NDC)
+                const f2v v24 = ((f2v)(-0.5f) * (gd * dxy)) * (f2v)(dL_dG); // dL/dconic A, C
+                const float v3 = (-gd.x * dy) * dL_dG;                      // dL/dconic B
+                const f2v ww = (f2v)(w);
+                const f2v c01 = ww * g01, c23 = ww * g23, c45 = ww * g45;
+                float v[13];
+                v[0] = v01.x; v[1] = v01.y; v[2] = v24.x; v[3] = v3; v[4] = v24.y;
                 v[5] = G * dL_da;
                 v[6] = w * gD;
-#pragma unroll
-                for (int ch = 0; ch < C; ++ch) v[7 + ch] = w * gCol[ch];
+                v[7] = c01.x; v[8] = c01.y; v[9] = c23.x; v[10] = c23.y; v[11] = c45.x; v[12] = c45.y;
                 // transposed reduction: [value][lane] in LDS, lane i of the row sums value i over the row
 #pragma unroll
-                for (int i = 0; i < RS; ++i) s_red[j][i][lane] = v[i];
+                for (int i = 0; i < RS; ++i) s_red[e][i][lane] = v[i];
+                (void)t;
             }
             __builtin_amdgcn_wave_barrier();
 #pragma unroll
-            for (int j = 0; j < kBwdUnroll; ++j) {
-                const int t = tg + kBwdUnroll - 1 - j;
-                const float4 *src = red_src + j * kRedBuf4;
+            for (int e = U - 1; e >= 0; --e) {
+                const int t = tg + e;
+                const float4 *src = red_src + e * kRedBuf4;
                 const float4 a0 = src[0], a1 = src[1], a2 = src[2], a3 = src[3];
                 // fixed summation tree (deterministic): pairs of packed adds
                 f2v p0 = f2v{a0.x, a0.y} + f2v{a0.z, a0.w};
