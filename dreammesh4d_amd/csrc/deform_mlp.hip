@@ -333,8 +333,17 @@ __global__ void k_mlp_reduce(MlpDesc d, MlpGrads g, const float *__restrict__ pa
     const size_t n = partial_floats(d);
     const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (e >= n) return;
-    float a = 0.f;
-    for (int w = 0; w < n_wg; ++w) a += partial[(size_t)w * n + e];
+    // fixed order: four interleaved running sums (loads of different workgroups in flight), combined at the end
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    int w = 0;
+    for (; w + 4 <= n_wg; w += 4) {
+        a0 += partial[(size_t)w * n + e];
+        a1 += partial[(size_t)(w + 1) * n + e];
+        a2 += partial[(size_t)(w + 2) * n + e];
+        a3 += partial[(size_t)(w + 3) * n + e];
+    }
+    for (; w < n_wg; ++w) a0 += partial[(size_t)w * n + e];
+    const float a = (a0 + a1) + (a2 + a3);
     size_t base = 0;
     if (e < (size_t)kW * d.IN) { if (g.W0) g.W0[e] = a; return; }
     base = (size_t)kW * d.IN;

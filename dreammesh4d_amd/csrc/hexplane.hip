@@ -251,16 +251,15 @@ __global__ __launch_bounds__(256) void k_hex_bwd_time(HexDesc d, const float *__
     hg.g[s * kHexPlanes + p][(size_t)c * HW + (size_t)s_rows[s][r] * W + tp_col[u]] = acc;
 }
 
-// zero fill of all gradient planes in one launch (float4 granularity; plane sizes are multiples of 4 floats)
+// zero fill of all gradient planes in one launch: blockIdx.y = plane (float4 granularity; plane sizes are
+// multiples of 4 floats)
 __global__ __launch_bounds__(256) void k_hex_zero(HexGrads hg)
 {
-    const unsigned long long total = hg.end4[hg.n - 1];
-    for (unsigned long long i = (unsigned long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (unsigned long long)gridDim.x * 256) {
-        int k = 0;
-        while (i >= hg.end4[k]) ++k;
-        const unsigned long long local = i - (k ? hg.end4[k - 1] : 0ull);
-        reinterpret_cast<float4 *>(hg.g[k])[local] = make_float4(0.f, 0.f, 0.f, 0.f);
-    }
+    const int k = blockIdx.y;
+    const unsigned long long n4 = hg.end4[k] - (k ? hg.end4[k - 1] : 0ull);
+    float4 *dst = reinterpret_cast<float4 *>(hg.g[k]);
+    for (unsigned long long i = (unsigned long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (unsigned long long)gridDim.x * 256)
+        dst[i] = make_float4(0.f, 0.f, 0.f, 0.f);
 }
 
 // ---------------------------------------------------------------------------------------- plan helper
@@ -359,7 +358,7 @@ int dm4d_hexplane_backward(int32_t S, int32_t M, int32_t B, const int32_t *res, 
             run += n / 4;
             hg.end4[k] = run;
         }
-    hipLaunchKernelGGL(k_hex_zero, dim3(2048), dim3(256), 0, st, hg);
+    hipLaunchKernelGGL(k_hex_zero, dim3(256, hg.n), dim3(256), 0, st, hg);
     DM4D_HIP_CHECK(hipGetLastError());
     const size_t total = (size_t)B * M * S * kHexCh;
     hipLaunchKernelGGL(k_hex_bwd_point, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, d, nodes, times, g_feat, (float *)scratch);

@@ -192,7 +192,8 @@ __global__ __launch_bounds__(kPreThreads) void k_preprocess(BatchDesc d)
                     recs = (uint32_t)(bd.nbx * bd.nby);
                     uint32_t dense = 1u;
                     const float cdet = co.x * co.z - co.y * co.y;
-                    if (recs > 0u && recs <= 64u && cdet > 0.f && co.x > 0.f && co.z > 0.f) {
+                    // (a block that is one cell wide or high is its own exact bound: only corners can be empty)
+                    if (bd.nbx >= 2 && bd.nby >= 2 && recs <= 64u && cdet > 0.f && co.x > 0.f && co.z > 0.f) {
                         // small block: keep only the cells the ellipse really meets (a third of the cells of the
                         // axis-aligned bound of a thin diagonal splat are empty)
                         const float tau = __logf(255.0f * co.w) * 1.001f + 0.01f;
