@@ -109,8 +109,8 @@ class Workload:
         # node attributes once per distinct timestamp of the step (cached per step in the reference,
         # dynamic_sugar.py:367-405), then broadcast to the views of that frame
         dx, dr, ds, do = self.net.node_outputs(self.nodes, self.frame_t)
-        out = self.render_views(self.renderer, dx[self.fidx], dr[self.fidx], ds[self.fidx], do[self.fidx], self.qs,
-                                self.scales, self.opac, self.rgb, self.vm, self.pm, self.bg6)
+        out = self.render_views(self.renderer, dx, dr, ds, do, self.qs, self.scales, self.opac, self.rgb, self.vm, self.pm,
+                                self.bg6, frame_index=self.fidx)
         torch.autograd.backward([out["color"], out["depth"], out["alpha"]], [self.gC, self.gD, self.gA])
         return out
 

@@ -274,6 +274,7 @@ struct BwdOutputs {
 // per-tile load imbalance of a single small image).  The single-view C API is the B = 1 case.
 struct BatchDesc {
     int B, N, C, W, H, sh_coeffs;
+    const int32_t *frame_index;   // optional [B] (device): view -> frame whose means / rotations / colours it renders
     float tanfovx, tanfovy, scale_modifier;
     const float *bg;
     const float *view, *proj, *campos; size_t cam_stride, campos_stride;
@@ -315,6 +316,7 @@ DM4D_HD static inline ViewCtx resolve(const BatchDesc &d, int b)
 {
     ViewCtx c;
     const size_t sb = (size_t)b, N = (size_t)d.N, P = (size_t)d.H * d.W;
+    const size_t sf = d.frame_index ? (size_t)d.frame_index[b] : sb;   // device-only when frame_index is set
     c.vp.W = d.W; c.vp.H = d.H; c.vp.C = d.C;
     c.vp.gx = (d.W + kTile - 1) / kTile;
     c.vp.gy = (d.H + kTile - 1) / kTile;
@@ -328,11 +330,11 @@ DM4D_HD static inline ViewCtx resolve(const BatchDesc &d, int b)
     c.vp.campos = d.campos ? d.campos + sb * d.campos_stride : nullptr;
     c.T = c.vp.gx * c.vp.gy;
     c.in.N = d.N; c.in.sh_coeffs = d.sh_coeffs; c.in.n_channels = d.C;
-    c.in.means3D = d.means3D ? d.means3D + sb * d.means_stride : nullptr;
-    c.in.rotations = d.rotations ? d.rotations + sb * d.rot_stride : nullptr;
+    c.in.means3D = d.means3D ? d.means3D + sf * d.means_stride : nullptr;
+    c.in.rotations = d.rotations ? d.rotations + sf * d.rot_stride : nullptr;
     c.in.scales = d.scales ? d.scales + sb * d.scale_stride : nullptr;
     c.in.opacities = d.opacities ? d.opacities + sb * d.opac_stride : nullptr;
-    c.in.colors_precomp = d.colors ? d.colors + sb * d.color_stride : nullptr;
+    c.in.colors_precomp = d.colors ? d.colors + sf * d.color_stride : nullptr;
     c.in.shs = d.shs ? d.shs + sb * d.sh_stride : nullptr;
     c.in.cov3D_precomp = d.cov3D ? d.cov3D + sb * d.cov_stride : nullptr;
     c.radii = d.radii ? d.radii + sb * d.radii_stride : nullptr;

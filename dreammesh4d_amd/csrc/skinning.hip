@@ -415,19 +415,22 @@ __global__ __launch_bounds__(kSkinThreads) void k_face_bwd_face(int F, int G, in
                                                                 const float *__restrict__ g_means,
                                                                 const float *__restrict__ g_rots,
                                                                 const float *__restrict__ g_normals, int nstride,
-                                                                float *__restrict__ rec /* [F][3][6] */)
+                                                                float *__restrict__ rec /* [F][3][6] */,
+                                                                const int32_t *__restrict__ frame_index, int n_views)
 {
+    // blockIdx.y = frame; the upstream gradients are per VIEW: summed here over the views of the frame in view
+    // order (the backward is linear in them).  frame_index == nullptr: view == frame.
     const int f = blockIdx.x * kSkinThreads + threadIdx.x;
     if (f >= F) return;
+    const size_t n = (size_t)F * G;
+    const int frame = blockIdx.y;
     {
-        const size_t bv = blockIdx.y, n = (size_t)F * G;
+        const size_t bv = blockIdx.y;
         vxyz += bv * V * 3;
         vrot += bv * V * 4;
-        if (g_means) g_means += bv * n * 3;
-        if (g_rots) g_rots += bv * n * 4;
-        if (g_normals) g_normals += bv * n * nstride;
         rec += bv * F * 3 * kCornerRec;
     }
+    const int b0 = frame_index ? 0 : frame, b1 = frame_index ? n_views : frame + 1;
     const int i0 = faces[3 * f], i1 = faces[3 * f + 1], i2 = faces[3 * f + 2];
     const v3 x0 = ld3(vxyz, i0), x1 = ld3(vxyz, i1), x2 = ld3(vxyz, i2);
     const v3 L0 = so3_log(ldq(vrot, i0)), L1 = so3_log(ldq(vrot, i1)), L2 = so3_log(ldq(vrot, i2));
@@ -437,7 +440,9 @@ __global__ __launch_bounds__(kSkinThreads) void k_face_bwd_face(int F, int G, in
         const size_t i = (size_t)f * G + s;
         const float *b = c_bary[bary_row(G)][s];
         if (g_means) {
-            const v3 gm = ld3(g_means, i);
+            v3 gm = mk3(0, 0, 0);
+            for (int bv = b0; bv < b1; ++bv)
+                if (!frame_index || frame_index[bv] == frame) gm = gm + ld3(g_means + (size_t)bv * n * 3, i);
             X[0] = X[0] + b[0] * gm; X[1] = X[1] + b[1] * gm; X[2] = X[2] + b[2] * gm;
         }
         if (g_rots) {
@@ -448,14 +453,23 @@ __global__ __launch_bounds__(kSkinThreads) void k_face_bwd_face(int F, int G, in
             const q4 Q = qmul(qd, qs);
             const float nq = fmaxf(sqrtf(qdot(Q, Q)), 1e-12f);
             const q4 out = qscale(1.f / nq, Q);
-            const float4 go4 = reinterpret_cast<const float4 *>(g_rots)[i];      // grads in w,x,y,z order
-            const q4 go = q4{go4.y, go4.z, go4.w, go4.x};
+            q4 go = q4{0.f, 0.f, 0.f, 0.f};
+            for (int bv = b0; bv < b1; ++bv)
+                if (!frame_index || frame_index[bv] == frame) {
+                    const float4 go4 = reinterpret_cast<const float4 *>(g_rots + (size_t)bv * n * 4)[i];   // grads in w,x,y,z order
+                    go = qadd(go, q4{go4.y, go4.z, go4.w, go4.x});
+                }
             const q4 gQ = qscale(1.f / nq, qadd(go, qscale(-qdot(go, out), out)));
             const q4 gqd = qmul(gQ, qconj(qs));
             const v3 gr = so3_exp_grad(r, gqd);
             R[0] = R[0] + b[0] * gr; R[1] = R[1] + b[1] * gr; R[2] = R[2] + b[2] * gr;
         }
-        if (g_normals) { const float *pn = g_normals + i * nstride; gn = gn + mk3(pn[0], pn[1], pn[2]); }
+        if (g_normals)
+            for (int bv = b0; bv < b1; ++bv)
+                if (!frame_index || frame_index[bv] == frame) {
+                    const float *pn = g_normals + ((size_t)bv * n + i) * nstride;
+                    gn = gn + mk3(pn[0], pn[1], pn[2]);
+                }
     }
     if (g_normals) {
         const v3 e1 = x1 - x0, e2 = x2 - x0, c = cross(e1, e2);
@@ -560,13 +574,15 @@ int face_forward_launch(int B, int F, int G, int V, const int32_t *faces, const 
 int face_backward_launch(int B, int F, int G, int V, const int32_t *faces, const float *vxyz, const float *vrot,
                          const float *qs, const float *g_means, const float *g_rots, const float *g_normals, int nstride,
                          const int32_t *csr_off, const int32_t *csr_items, float *scratch, const float *ext_xyz,
-                         const float *ext_rot, float *o_vxyz, float *o_vrot, hipStream_t st)
+                         const float *ext_rot, float *o_vxyz, float *o_vrot, const int32_t *frame_index, int n_views,
+                         hipStream_t st)
 {
+    // B = frames; with frame_index the upstream gradients g_* are per view ([n_views, N, .])
     if (B <= 0) return DM4D_OK;
     ProfScope prof_(kKFaceBwd, st);
     if (F > 0) {
         hipLaunchKernelGGL(k_face_bwd_face, dim3((F + kSkinThreads - 1) / kSkinThreads, B), dim3(kSkinThreads), 0, st, F, G,
-                           V, faces, vxyz, vrot, qs, g_means, g_rots, g_normals, nstride, scratch);
+                           V, faces, vxyz, vrot, qs, g_means, g_rots, g_normals, nstride, scratch, frame_index, n_views);
         DM4D_HIP_CHECK(hipGetLastError());
     }
     if (V > 0) {
@@ -655,7 +671,7 @@ int dm4d_face_gaussians_backward(int32_t F, int32_t G, int32_t V, const int32_t 
     if (V < 0 || !vert_csr_offsets || !vert_csr_items || !scratch || !dL_dvxyz || !dL_dvrot) { set_error("null csr/scratch/output"); return DM4D_ERR_INVALID; }
     return face_backward_launch(1, F, G, V, faces, vxyz, vrot, q_static_wxyz, dL_dmeans, dL_drotations_wxyz, dL_dnormals,
                                 3, vert_csr_offsets, vert_csr_items, (float *)scratch, nullptr, nullptr, dL_dvxyz,
-                                dL_dvrot, (hipStream_t)stream);
+                                dL_dvrot, nullptr, 1, (hipStream_t)stream);
 }
 
 }  // extern "C"

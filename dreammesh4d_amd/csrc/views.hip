@@ -30,7 +30,8 @@ int face_forward_launch(int B, int F, int G, int V, const int32_t *faces, const 
 int face_backward_launch(int B, int F, int G, int V, const int32_t *faces, const float *vxyz, const float *vrot,
                          const float *qs, const float *g_means, const float *g_rots, const float *g_normals, int nstride,
                          const int32_t *csr_off, const int32_t *csr_items, float *scratch, const float *ext_xyz,
-                         const float *ext_rot, float *o_vxyz, float *o_vrot, hipStream_t st);
+                         const float *ext_rot, float *o_vxyz, float *o_vrot, const int32_t *frame_index, int n_views,
+                         hipStream_t st);
 int skin_check(int method, int V, int M, int K, const void *verts, const void *idx, const void *w, const void *dx,
                const void *dr, const void *ds, const void *dop);
 int face_check(int F, int G, const void *faces, const void *vxyz, const void *vrot, const void *qs);
@@ -39,6 +40,7 @@ static int views_check(const dm4d_views *v)
 {
     if (!v) { set_error("null views"); return DM4D_ERR_INVALID; }
     if (v->B <= 0 || v->B > 65535) { set_error("bad batch size %d", v->B); return DM4D_ERR_INVALID; }
+    if (v->frame_index && (v->n_frames <= 0 || v->n_frames > v->B)) { set_error("n_frames %d out of range (1..B)", v->n_frames); return DM4D_ERR_INVALID; }
     if (v->N != v->F * v->G) { set_error("N (%d) != F*G (%d*%d)", v->N, v->F, v->G); return DM4D_ERR_INVALID; }
     if (v->image_height <= 0 || v->image_width <= 0) { set_error("bad image size"); return DM4D_ERR_INVALID; }
     if ((int64_t)((v->image_height + kTile - 1) / kTile) * ((v->image_width + kTile - 1) / kTile) > kMaxTiles) {
@@ -63,6 +65,7 @@ static BatchDesc views_batch(const dm4d_views *v)
     BatchDesc d;
     memset(&d, 0, sizeof(d));
     d.B = v->B; d.N = v->N; d.C = 6; d.W = v->image_width; d.H = v->image_height;
+    d.frame_index = v->frame_index;
     d.tanfovx = v->tanfovx; d.tanfovy = v->tanfovy; d.scale_modifier = v->scale_modifier;
     d.bg = v->bg;
     d.view = v->viewmatrix; d.proj = v->projmatrix; d.cam_stride = 16;
@@ -99,10 +102,11 @@ int dm4d_views_forward(const dm4d_views *v, dm4d_stream_t stream)
     if (rc) return rc;
     if (!v->out_color || !v->out_depth || !v->out_alpha) { set_error("null output image"); return DM4D_ERR_INVALID; }
     hipStream_t st = (hipStream_t)stream;
-    rc = skin_forward_launch(v->B, v->method, v->V, v->M, v->K, v->verts, v->nbr_idx, v->nbr_w, v->dx, v->dr, v->ds,
+    const int NF = v->frame_index ? v->n_frames : v->B;     // skinning + face transform once per frame
+    rc = skin_forward_launch(NF, v->method, v->V, v->M, v->K, v->verts, v->nbr_idx, v->nbr_w, v->dx, v->dr, v->ds,
                              v->d_opacity, v->vxyz, v->vrot, st);
     if (rc) return rc;
-    rc = face_forward_launch(v->B, v->F, v->G, v->V, v->faces, v->vxyz, v->vrot, v->q_static, v->means3D, v->rotations,
+    rc = face_forward_launch(NF, v->F, v->G, v->V, v->faces, v->vxyz, v->vrot, v->q_static, v->means3D, v->rotations,
                              v->colors + 3, 6, v->rgb, v->colors, st);
     if (rc) return rc;
     const BatchDesc d = views_batch(v);
@@ -132,12 +136,13 @@ int dm4d_views_backward(const dm4d_views *v, const dm4d_views_grads *gr, dm4d_st
                      gr->dL_drotations, nullptr};
     if ((rc = launch_render_bwd(d, st))) return rc;
     if ((rc = launch_gather_bwd(d, st))) return rc;
-    rc = face_backward_launch(v->B, v->F, v->G, v->V, v->faces, v->vxyz, v->vrot, v->q_static, gr->dL_dmeans3D,
+    const int NF = v->frame_index ? v->n_frames : v->B;
+    rc = face_backward_launch(NF, v->F, v->G, v->V, v->faces, v->vxyz, v->vrot, v->q_static, gr->dL_dmeans3D,
                               gr->dL_drotations, gr->dL_dcolors + 3, 6, gr->vert_csr_offsets, gr->vert_csr_items,
                               (float *)gr->face_scratch, gr->dL_dvxyz_ext, gr->dL_dvrot_ext, gr->dL_dvxyz, gr->dL_dvrot,
-                              st);
+                              v->frame_index, v->B, st);
     if (rc) return rc;
-    return skin_backward_launch(v->B, v->method, v->V, v->M, v->K, v->verts, v->nbr_idx, v->nbr_w, v->dx, v->dr, v->ds,
+    return skin_backward_launch(NF, v->method, v->V, v->M, v->K, v->verts, v->nbr_idx, v->nbr_w, v->dx, v->dr, v->ds,
                                 v->d_opacity, gr->dL_dvxyz, gr->dL_dvrot, gr->node_csr_offsets, gr->node_csr_items,
                                 (float *)gr->skin_scratch, gr->dL_ddx, gr->dL_ddr, gr->dL_dds, gr->dL_ddo, st);
 }

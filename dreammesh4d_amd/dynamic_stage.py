@@ -91,8 +91,9 @@ class DynamicStage:
         self.opt.zero_grad(set_to_none=True)
         dx, dr, ds, do = self.net.node_outputs(self.nodes, frames_t)
         u = b["unit_frame"]
-        out = render_views(self.r, dx[u], dr[u], ds[u], do[u] if do is not None else None, st["q_static"], st["scales"],
-                           st["opacities"], st["rgb"], b["vm"], b["pm"], self.bg6)
+        # views of the same frame share its skinning / face transform (reference: cached per timestamp within a step)
+        out = render_views(self.r, dx, dr, ds, do, st["q_static"], st["scales"], st["opacities"], st["rgb"], b["vm"], b["pm"],
+                           self.bg6, frame_index=u)
         rgb = out["color"][:, :3].clamp(0, 1).permute(0, 2, 3, 1)          # "render": clamp(0,1) (…temporal.py:229)
         mask = out["alpha"].permute(0, 2, 3, 1)
         ref, rnd = b["is_ref"], ~b["is_ref"]

@@ -108,20 +108,24 @@ class ViewRenderer:
 
 class _RenderViews(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, r, dx, dr, ds, do, q_static, scales, opacities, rgb, viewmats, projmats, bg6, ext_hook):
+    def forward(ctx, r, dx, dr, ds, do, q_static, scales, opacities, rgb, viewmats, projmats, bg6, frame_index):
         L = _lib.lib()
         g, t, dev = r.graph, r.topo, r.device
         B = int(viewmats.shape[0])
         N, H, W = r.N, r.H, r.W
         f = dict(dtype=torch.float32, device=dev)
+        fidx = None if frame_index is None else frame_index.detach().to(device=dev, dtype=torch.int32).contiguous()
+        NF = B if fidx is None else int(dx.shape[0])      # frames: skinning + face transform run once per frame
+        if fidx is not None and (tuple(fidx.shape) != (B,) or not 0 < NF <= B):
+            raise ValueError(f"frame_index must be [{B}] with 1..{B} frames, got {tuple(fidx.shape)} / {NF} frames")
         keep = dict(dx=_f32(dx), dr=_f32(dr), ds=_f32(ds), do=_f32(do), qs=_f32(q_static), sc=_f32(scales),
                     op=_f32(opacities).reshape(-1), rgb=_f32(rgb), vm=_f32(viewmats).reshape(B, 16),
                     pm=_f32(projmats).reshape(B, 16), bg=_f32(bg6).reshape(6))
-        for k, want in (("dx", (B, g.M, 3)), ("dr", (B, g.M, 4))):
+        for k, want in (("dx", (NF, g.M, 3)), ("dr", (NF, g.M, 4))):
             if tuple(keep[k].shape) != want:
                 raise ValueError(f"{k} must be {want}, got {tuple(keep[k].shape)}")
-        out = dict(vxyz=torch.empty(B, g.V, 3, **f), vrot=torch.empty(B, g.V, 4, **f), means=torch.empty(B, N, 3, **f),
-                   rots=torch.empty(B, N, 4, **f), colors=torch.empty(B, N, 6, **f),
+        out = dict(vxyz=torch.empty(NF, g.V, 3, **f), vrot=torch.empty(NF, g.V, 4, **f), means=torch.empty(NF, N, 3, **f),
+                   rots=torch.empty(NF, N, 4, **f), colors=torch.empty(NF, N, 6, **f),
                    radii=torch.empty(B, N, dtype=torch.int32, device=dev), color=torch.empty(B, 6, H, W, **f),
                    depth=torch.empty(B, 1, H, W, **f), alpha=torch.empty(B, 1, H, W, **f))
         cap, rcap = r.capacity, r.record_capacity
@@ -131,7 +135,8 @@ class _RenderViews(torch.autograd.Function):
                          _p(keep["dx"]), _p(keep["dr"]), _p(keep["ds"]), _p(keep["do"]), _p(t.faces), _p(keep["qs"]),
                          _p(keep["sc"]), _p(keep["op"]), _p(keep["rgb"]), _p(out["vxyz"]), _p(out["vrot"]),
                          _p(out["means"]), _p(out["rots"]), _p(out["colors"]), _p(out["radii"]), _p(out["color"]),
-                         _p(out["depth"]), _p(out["alpha"]), _p(ws["geom"]), _p(ws["binning"]), _p(ws["image"]))
+                         _p(out["depth"]), _p(out["alpha"]), _p(ws["geom"]), _p(ws["binning"]), _p(ws["image"]), _p(fidx), NF)
+        keep["fidx"] = fidx
         with torch.cuda.device(dev):
             _lib.check(L.dm4d_views_forward(C.byref(vs), torch.cuda.current_stream(dev).cuda_stream),
                        "dm4d_views_forward")
@@ -149,16 +154,17 @@ class _RenderViews(torch.autograd.Function):
         r, vs, out = ctx.r, ctx.vs, ctx.out
         g, t, dev = r.graph, r.topo, r.device
         B, N, H, W = vs.B, r.N, r.H, r.W
+        NF = vs.n_frames if ctx.keep["fidx"] is not None else B
         f = dict(dtype=torch.float32, device=dev)
         gc = _f32(g_color) if g_color is not None else torch.zeros(B, 6, H, W, **f)
         gd, ga = _f32(g_depth), _f32(g_alpha)
         gx, gr_ = _f32(g_vxyz), _f32(g_vrot)
         o = dict(m2=torch.empty(B, N, 3, **f), m3=torch.empty(B, N, 3, **f), rot=torch.empty(B, N, 4, **f),
                  col=torch.empty(B, N, 6, **f), op=torch.empty(B, N, **f) if ctx.need_static else None,
-                 sc=torch.empty(B, N, 3, **f) if ctx.need_static else None, vx=torch.empty(B, g.V, 3, **f),
-                 vr=torch.empty(B, g.V, 4, **f), dx=torch.empty(B, g.M, 3, **f), dr=torch.empty(B, g.M, 4, **f),
-                 ds=torch.empty(B, g.M, 6, **f) if ctx.keep["ds"] is not None else None,
-                 do=torch.empty(B, g.M, **f) if ctx.keep["do"] is not None else None)
+                 sc=torch.empty(B, N, 3, **f) if ctx.need_static else None, vx=torch.empty(NF, g.V, 3, **f),
+                 vr=torch.empty(NF, g.V, 4, **f), dx=torch.empty(NF, g.M, 3, **f), dr=torch.empty(NF, g.M, 4, **f),
+                 ds=torch.empty(NF, g.M, 6, **f) if ctx.keep["ds"] is not None else None,
+                 do=torch.empty(NF, g.M, **f) if ctx.keep["do"] is not None else None)
         scr = r._bwd_scratch(B, vs.record_capacity)
         gs = ViewsGrads(_p(gc), _p(gd), _p(ga), _p(gx), _p(gr_), _p(g.csr_off), _p(g.csr_items), _p(t.csr_off),
                         _p(t.csr_items), _p(scr["grad"]), _p(scr["skin"]), _p(scr["face"]), _p(o["m2"]), _p(o["m3"]),
@@ -179,12 +185,17 @@ class _RenderViews(torch.autograd.Function):
 
 
 def render_views(renderer: ViewRenderer, dx, dr, ds, d_opacity, q_static, scales, opacities, rgb, viewmats, projmats,
-                 bg6):
+                 bg6, frame_index=None):
     """Returns dict: color [B,6,H,W] (RGB | normal), depth [B,1,H,W], alpha [B,1,H,W], radii [B,N] int32,
-    vxyz [B,V,3], vrot [B,V,4]."""
+    vxyz [B,V,3], vrot [B,V,4].
+
+    frame_index [B] (int): views that share a timestamp share its skinning and face->Gaussian transform (the
+    reference caches them per timestamp within a step, geometry/dynamic_sugar.py:375-386): dx, dr, ds, d_opacity
+    are then [n_frames, M, .] (the deformation network's output per distinct timestamp), view b renders frame
+    frame_index[b], vxyz / vrot come back per frame, and the node gradients are summed over a frame's views."""
     m = renderer.method
     args = (renderer, dx, dr, ds if m != 1 else None, d_opacity if m == 2 else None, q_static, scales, opacities, rgb,
-            viewmats, projmats, bg6, None)
+            viewmats, projmats, bg6, frame_index)
     color, depth, alpha, radii, vxyz, vrot = _RenderViews.apply(*args)
     if not renderer.calibrated:
         # first call only: one host sync to size the duplicate / record capacities from the real counts

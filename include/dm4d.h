@@ -317,6 +317,14 @@ typedef struct dm4d_views {
     float *out_color, *out_depth, *out_alpha;  /* [B,6,H,W] [B,H,W] [B,H,W] */
     /* workspaces (dm4d_views_*_bytes) */
     void *geom, *binning, *image;
+    /* Views that share a FRAME (timestamp) share its skinning and face->Gaussian transform (the reference caches
+     * them per timestamp within a step, C/geometry/dynamic_sugar.py:375-386).  frame_index == NULL: every view is
+     * its own frame (n_frames is ignored).  Otherwise frame_index [B] (device, values < n_frames) and every
+     * per-"B" tensor above that does not depend on the camera -- dx, dr, ds, d_opacity, vxyz, vrot, means3D,
+     * rotations, colors, and in dm4d_views_grads dL_dvxyz*, dL_dvrot*, dL_ddx..dL_ddo -- has n_frames leading
+     * entries instead of B. */
+    const int32_t *frame_index;
+    int32_t n_frames;
 } dm4d_views;
 
 typedef struct dm4d_views_grads {

@@ -82,6 +82,40 @@ def test_batched_views_equal_per_call_composition():
             assert (a - c).abs().max() <= 1e-5 * c.abs().max(), (k, b)
 
 
+def test_views_sharing_a_frame_equal_per_view_inputs():
+    """frame_index: views of one timestamp share skinning + face transform; images are bit-identical to passing
+    the frame's node outputs once per view, node gradients equal the sum over the frame's views."""
+    _need_gpu()
+    from dreammesh4d_amd import views
+
+    dev = torch.device("cuda:0")
+    B, H, W, M, NF = 5, 128, 160, 90, 2
+    sc, graph, topo, qs, scales, opac, rgb, raw, cams, vm, pm = _scene(2500, M, 4, B, H, W, dev, seed=4)
+    fidx = torch.tensor([0, 1, 1, 0, 1], device=dev)
+    keys = ("trans", "d_rot", "strain", "d_opacity")
+    fr = {k: raw[k][:NF].clone().requires_grad_(True) for k in keys}           # per-frame node outputs
+    pv = {k: raw[k][:NF].clone().requires_grad_(True) for k in keys}
+    bg6 = torch.ones(6, device=dev)
+    gen = torch.Generator().manual_seed(3)
+    gC = torch.randn(B, 6, H, W, generator=gen).to(dev)
+    gA = torch.randn(B, 1, H, W, generator=gen).to(dev)
+    r1 = views.ViewRenderer(graph, topo, H, W, cams[0].tanfov, method="hybrid")
+    o1 = views.render_views(r1, fr["trans"], fr["d_rot"], fr["strain"], fr["d_opacity"].squeeze(-1), qs, scales, opac, rgb,
+                            vm, pm, bg6, frame_index=fidx)
+    assert o1["vxyz"].shape[0] == NF
+    torch.autograd.backward([o1["color"], o1["alpha"]], [gC, gA])
+    r2 = views.ViewRenderer(graph, topo, H, W, cams[0].tanfov, method="hybrid")
+    o2 = views.render_views(r2, pv["trans"][fidx], pv["d_rot"][fidx], pv["strain"][fidx], pv["d_opacity"].squeeze(-1)[fidx],
+                            qs, scales, opac, rgb, vm, pm, bg6)
+    torch.autograd.backward([o2["color"], o2["alpha"]], [gC, gA])
+    for k in ("color", "depth", "alpha", "radii"):
+        assert torch.equal(o1[k], o2[k]), k
+    assert torch.equal(o1["vxyz"][fidx], o2["vxyz"])
+    for k in keys:
+        a, c = fr[k].grad, pv[k].grad
+        assert (a - c).abs().max() <= 2e-5 * c.abs().max(), k
+
+
 def test_batched_view_against_oracle():
     _need_gpu()
     from dreammesh4d_amd import views

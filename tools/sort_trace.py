@@ -12,7 +12,7 @@ L = _lib.lib()
 buf = torch.zeros(8 * 1024, 5, dtype=torch.int64, device=dev)
 _lib.check(L.dm4d_debug_sort_trace(buf.data_ptr()))
 dx, dr, ds, do = wl.net.node_outputs(wl.nodes, wl.frame_t)
-o = wl.render_views(wl.renderer, dx[wl.fidx], dr[wl.fidx], ds[wl.fidx], do[wl.fidx], wl.qs, wl.scales, wl.opac, wl.rgb, wl.vm, wl.pm, wl.bg6)
+o = wl.render_views(wl.renderer, dx, dr, ds, do, wl.qs, wl.scales, wl.opac, wl.rgb, wl.vm, wl.pm, wl.bg6, frame_index=wl.fidx)
 torch.cuda.synchronize()
 _lib.check(L.dm4d_debug_sort_trace(None))
 a = buf.cpu().numpy()

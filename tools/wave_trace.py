@@ -47,7 +47,7 @@ _lib.check(L.dm4d_debug_trace(buf.data_ptr(), MINW))
 # forward only
 out = wl.step.__func__  # noqa
 dx, dr, ds, do = wl.net.node_outputs(wl.nodes, wl.frame_t)
-o = wl.render_views(wl.renderer, dx[wl.fidx], dr[wl.fidx], ds[wl.fidx], do[wl.fidx], wl.qs, wl.scales, wl.opac, wl.rgb, wl.vm, wl.pm, wl.bg6)
+o = wl.render_views(wl.renderer, dx, dr, ds, do, wl.qs, wl.scales, wl.opac, wl.rgb, wl.vm, wl.pm, wl.bg6, frame_index=wl.fidx)
 torch.cuda.synchronize()
 fw = buf.cpu().numpy().copy()
 buf.zero_()
