@@ -373,37 +373,69 @@ __global__ __launch_bounds__(kPreThreads) void k_gather_bwd(BatchDesc d)
     const float *__restrict__ dLt = c.dLq;
     const BwdOutputs &o = c.o;
     __shared__ float sV[16], sP[16];
-    const int tid = threadIdx.x;
+    // per-wave staging chunk: 64 records, padded to 20 floats so that 16 lanes reading 16 different records
+    // with ds_read_b128 hit disjoint bank groups
+    constexpr int kGRec = 64, kGStride = 20;
+    __shared__ __attribute__((aligned(16))) float s_chunk[kPreThreads / 64][kGRec * kGStride];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     if (tid < 16) { sV[tid] = vp.view[tid]; sP[tid] = vp.proj[tid]; }
     __syncthreads();
     const int i = blockIdx.x * kPreThreads + tid;
-    if (i >= in.N) return;
+    const bool live = i < in.N;
     const size_t si = (size_t)i;
 
     // acc: 0,1 dL/dmean2D (NDC) | 2,3,4 dL/dconic (A,B,C) | 5 dL/dopacity | 6 dL/ddepth | 7.. dL/dcolour
     float acc[7 + kMaxChannels];
 #pragma unroll
     for (int k = 0; k < 7 + kMaxChannels; ++k) acc[k] = 0.f;
-    const int r = radii[i];
+    const int r = live ? radii[i] : 0;
     const int C = vp.C;
-    if (r > 0) {
-        // The records of this Gaussian are one contiguous block (its nby x nbx cells, K1); B1 wrote every
-        // one of them -- real sums for the entries the forward consumed, zeros for the rest.
-        const int RS = grad_stride(C);
-        const uint32_t rec0 = g.cellinfo[i].z, cnt = g.rec_touched[i];
-        const uint32_t end = min(rec0 + cnt, max(rec0, c.rec_cap));
-        for (uint32_t slot = rec0; slot < end; ++slot) {
-            const float4 *src = reinterpret_cast<const float4 *>(dLt + (size_t)slot * RS);
-            const float4 a0 = src[0], a1 = src[1], a2 = src[2];
-            acc[0] += a0.x; acc[1] += a0.y; acc[2] += a0.z; acc[3] += a0.w;
-            acc[4] += a1.x; acc[5] += a1.y; acc[6] += a1.z; acc[7] += a1.w;
-            acc[8] += a2.x; acc[9] += a2.y;
-            if (C > 3) {
-                const float4 a3 = src[3];
-                acc[10] += a2.z; acc[11] += a2.w; acc[12] += a3.x;
+    {
+        // The records of a Gaussian are one contiguous block (its reached cells, K1), the blocks of consecutive
+        // Gaussians follow each other (K3's scan), and B1 wrote every record -- real sums for the entries the
+        // forward consumed, zeros for the rest.  So the 64 Gaussians of a wave own ONE contiguous range of
+        // records: the wave streams it through LDS with fully coalesced 1 KB loads and every lane adds up its
+        // own records from there, in record order.
+        const int RS = grad_stride(C), parts = RS / 4;
+        uint32_t rec0 = 0xFFFFFFFFu, end = 0u;
+        if (r > 0) {
+            const uint32_t cnt = g.rec_touched[i];
+            if (cnt > 0u) {
+                rec0 = g.cellinfo[i].z;
+                end = min(rec0 + cnt, max(rec0, c.rec_cap));
+            }
+        }
+        uint32_t R0 = rec0, R1 = end;
+#pragma unroll
+        for (int o2 = 32; o2 > 0; o2 >>= 1) {
+            R0 = min(R0, (uint32_t)__shfl_xor((int)R0, o2, 64));
+            R1 = max(R1, (uint32_t)__shfl_xor((int)R1, o2, 64));
+        }
+        float *chunk = s_chunk[wv];
+        for (uint32_t base = R0; base < R1; base += kGRec) {
+            const uint32_t nrec = min((uint32_t)kGRec, R1 - base);
+            const float4 *src4 = reinterpret_cast<const float4 *>(dLt + (size_t)base * RS);
+            __builtin_amdgcn_wave_barrier();
+            for (uint32_t idx4 = lane; idx4 < nrec * (uint32_t)parts; idx4 += 64u) {
+                const uint32_t rr = idx4 / (uint32_t)parts, part = idx4 % (uint32_t)parts;
+                *reinterpret_cast<float4 *>(chunk + rr * kGStride + part * 4) = src4[idx4];
+            }
+            __builtin_amdgcn_wave_barrier();
+            const uint32_t lo = max(rec0, base), hi = min(end, base + nrec);
+            for (uint32_t slot = lo; slot < hi; ++slot) {
+                const float4 *rp = reinterpret_cast<const float4 *>(chunk + (slot - base) * kGStride);
+                const float4 a0 = rp[0], a1 = rp[1], a2 = rp[2];
+                acc[0] += a0.x; acc[1] += a0.y; acc[2] += a0.z; acc[3] += a0.w;
+                acc[4] += a1.x; acc[5] += a1.y; acc[6] += a1.z; acc[7] += a1.w;
+                acc[8] += a2.x; acc[9] += a2.y;
+                if (C > 3) {
+                    const float4 a3 = rp[3];
+                    acc[10] += a2.z; acc[11] += a2.w; acc[12] += a3.x;
+                }
             }
         }
     }
+    if (!live) return;
     o.dL_dmeans2D[3 * si + 0] = acc[0];
     o.dL_dmeans2D[3 * si + 1] = acc[1];
     o.dL_dmeans2D[3 * si + 2] = 0.f;
