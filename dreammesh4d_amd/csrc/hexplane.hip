@@ -172,10 +172,10 @@ __global__ __launch_bounds__(256) void k_hex_bwd_spatial(HexDesc d, const float 
     hg.g[s * kHexPlanes + p][(size_t)c * HW + sp_texel[u]] = acc;
 }
 
-// Time planes: one thread per (touched column, channel, time-row slot).  The distinct time rows of the step
+// Time planes: one workgroup per (touched column, time-row slot).  The distinct time rows of the step
 // (<= 2 B: the two time texels of every frame, merged in a fixed order) are the same for every column of a
-// scale, so blockIdx.y enumerates row slots and a thread sums, over the column's items, only the frames that
-// touch its row -- 2 B times the parallelism of one thread per column, a quarter of the serial work.
+// scale, so blockIdx.y enumerates row slots and a thread sums, over an eighth of the column's items, only the
+// frames that touch its row (a serial loop over all items of a coarse-scale column was latency-bound).
 //   tp_scale[u], tp_plane[u], tp_col[u]; tp_off[U+1], tp_item[] = node * 2 + corner (column corner)
 constexpr int kHexMaxFrames = 16;
 __global__ __launch_bounds__(256) void k_hex_bwd_time(HexDesc d, const float *__restrict__ nodes,
@@ -213,12 +213,13 @@ __global__ __launch_bounds__(256) void k_hex_bwd_time(HexDesc d, const float *__
         s_nrows[sc] = nrows;
     }
     __syncthreads();
-    const size_t gid = (size_t)blockIdx.x * 256 + tid;
-    if (gid >= (size_t)U * kHexCh) return;
-    const int c = (int)(gid % kHexCh), u = (int)(gid / kHexCh);
+    // workgroup = one (touched column u, row slot r): 32 channels x 8 item lanes; item lane q sums the items
+    // e = e0 + q, e0 + q + 8, ... and the 8 partials are added in lane order (fixed: deterministic)
+    __shared__ float s_part[8][kHexCh];
+    const int u = blockIdx.x, r = blockIdx.y;
+    const int c = tid & (kHexCh - 1), q = tid >> 5;
     const int s = tp_scale[u], p = tp_plane[u];
-    const int r = blockIdx.y;                 // row slot
-    if (r >= s_nrows[s]) return;
+    if (r >= s_nrows[s]) return;              // uniform for the workgroup
     const int a0 = c_axis0[p];
     const int W = d.res[s][a0], H = d.res[s][3];
     // per frame: weight of this row (0 if the frame does not touch it); both texels may coincide at the border
@@ -233,7 +234,7 @@ __global__ __launch_bounds__(256) void k_hex_bwd_time(HexDesc d, const float *__
         }
     }
     float acc = 0.f;
-    for (int e = tp_off[u]; e < tp_off[u + 1]; ++e) {
+    for (int e = tp_off[u] + q; e < tp_off[u + 1]; e += 8) {
         const int m = tp_item[e] >> 1, corner = tp_item[e] & 1;
         const float xa = (nodes[3 * (size_t)m + a0] - d.lo[a0]) * d.inv[a0] - 1.0f;
         int x0;
@@ -247,8 +248,15 @@ __global__ __launch_bounds__(256) void k_hex_bwd_time(HexDesc d, const float *__
                 gs += G[((((size_t)f * d.M + m) * d.S + s) * kHexPlanes + p) * kHexCh + c] * wf[f];
         acc += gs * wcol;
     }
-    const size_t HW = (size_t)W * H;
-    hg.g[s * kHexPlanes + p][(size_t)c * HW + (size_t)s_rows[s][r] * W + tp_col[u]] = acc;
+    s_part[q][c] = acc;
+    __syncthreads();
+    if (q == 0) {
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) t += s_part[k][c];
+        const size_t HW = (size_t)W * H;
+        hg.g[s * kHexPlanes + p][(size_t)c * HW + (size_t)s_rows[s][r] * W + tp_col[u]] = t;
+    }
 }
 
 // zero fill of all gradient planes in one launch: blockIdx.y = plane (float4 granularity; plane sizes are
@@ -369,7 +377,7 @@ int dm4d_hexplane_backward(int32_t S, int32_t M, int32_t B, const int32_t *res, 
         DM4D_HIP_CHECK(hipGetLastError());
     }
     if (n_time > 0) {
-        hipLaunchKernelGGL(k_hex_bwd_time, dim3((unsigned)(((size_t)n_time * kHexCh + 255) / 256), 2 * B), dim3(256), 0, st, d, nodes, times,
+        hipLaunchKernelGGL(k_hex_bwd_time, dim3((unsigned)n_time, 2 * B), dim3(256), 0, st, d, nodes, times,
                            n_time, tp_scale, tp_plane, tp_col, tp_off, tp_item, (const float *)scratch, hg);
         DM4D_HIP_CHECK(hipGetLastError());
     }

@@ -140,18 +140,25 @@ class _RenderViews(torch.autograd.Function):
         with torch.cuda.device(dev):
             _lib.check(L.dm4d_views_forward(C.byref(vs), torch.cuda.current_stream(dev).cuda_stream),
                        "dm4d_views_forward")
-        ctx.r, ctx.vs, ctx.keep, ctx.out, ctx.ws = r, vs, keep, out, ws
+        # Tensors RETURNED from forward must not be kept as plain ctx attributes: output -> grad_fn -> ctx -> output is
+        # a reference cycle through C++ that the Python GC cannot break (it leaked every step's graph: ~150 MB per
+        # step).  They go through save_for_backward; only the internal buffers stay on ctx.
+        returned = ("color", "depth", "alpha", "radii", "vxyz", "vrot")
+        ctx.save_for_backward(*[out[k] for k in returned])
+        ctx.r, ctx.vs, ctx.keep, ctx.ws = r, vs, keep, ws
+        ctx.internal = {k: v for k, v in out.items() if k not in returned}
         ctx.shapes = (dx.shape, dr.shape, None if ds is None else ds.shape, None if do is None else do.shape,
                       scales.shape, opacities.shape, rgb.shape)
         ctx.need_static = any(x.requires_grad for x in (scales, opacities, rgb))
-        r.last = (vs, (keep, out, ws))
+        r.last = (vs, ws)      # for check(): the counters live in ws["geom"]
         ctx.mark_non_differentiable(out["radii"])
         return out["color"], out["depth"], out["alpha"], out["radii"], out["vxyz"], out["vrot"]
 
     @staticmethod
     def backward(ctx, g_color, g_depth, g_alpha, _g_radii, g_vxyz, g_vrot):
         L = _lib.lib()
-        r, vs, out = ctx.r, ctx.vs, ctx.out
+        r, vs = ctx.r, ctx.vs
+        _alive = ctx.saved_tensors      # vs points into these (and into ctx.internal / ctx.keep)
         g, t, dev = r.graph, r.topo, r.device
         B, N, H, W = vs.B, r.N, r.H, r.W
         NF = vs.n_frames if ctx.keep["fidx"] is not None else B
@@ -175,7 +182,7 @@ class _RenderViews(torch.autograd.Function):
                        "dm4d_views_backward")
         s = ctx.shapes
         r._give_ws(ctx.ws)   # stream-ordered reuse by the next forward is safe
-        ctx.ws = None
+        ctx.ws = ctx.internal = None
         r.last_grads = o   # per-view gradients (means2D etc.) for callers that want them
         g_sc = o["sc"].sum(0).reshape(s[4]) if ctx.need_static else None
         g_op = o["op"].sum(0).reshape(s[5]) if ctx.need_static else None

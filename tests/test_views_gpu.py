@@ -116,6 +116,30 @@ def test_views_sharing_a_frame_equal_per_view_inputs():
         assert (a - c).abs().max() <= 2e-5 * c.abs().max(), k
 
 
+def test_steps_do_not_leak_device_memory():
+    """Outputs kept as plain ctx attributes once formed an uncollectable output -> grad_fn -> ctx cycle that
+    leaked every step's graph; device memory must be flat from the second step on."""
+    _need_gpu()
+    from dreammesh4d_amd import views
+
+    dev = torch.device("cuda:0")
+    B, H, W, M = 2, 96, 96, 60
+    sc, graph, topo, qs, scales, opac, rgb, raw, cams, vm, pm = _scene(1200, M, 4, B, H, W, dev, seed=5)
+    r = views.ViewRenderer(graph, topo, H, W, cams[0].tanfov)
+    leaves = {k: v.clone().requires_grad_(True) for k, v in raw.items()}
+    used = []
+    for _ in range(6):
+        out = views.render_views(r, leaves["trans"], leaves["d_rot"], leaves["strain"], leaves["d_opacity"].squeeze(-1), qs,
+                                 scales, opac, rgb, vm, pm, torch.ones(6, device=dev))
+        (out["color"].sum() + out["alpha"].sum()).backward()
+        for v in leaves.values():
+            v.grad = None
+        del out
+        torch.cuda.synchronize()
+        used.append(torch.cuda.memory_allocated())
+    assert max(used[2:]) - min(used[2:]) < (1 << 20), used
+
+
 def test_batched_view_against_oracle():
     _need_gpu()
     from dreammesh4d_amd import views

@@ -5,7 +5,7 @@ dev=torch.device('cuda:0')
 wl=bench.Workload(dev,0,1)
 out=wl.step(); torch.cuda.synchronize()
 r=wl.renderer
-vs,(keep,o,ws)=r.last
+vs,ws=r.last
 from dreammesh4d_amd import _lib
 L=_lib.lib()
 B=vs.B; stride=L.dm4d_views_geom_bytes(1,r.N,512,512)
