@@ -73,9 +73,9 @@ int set_sort_trace_buffer(void *dev_ptr)
     DM4D_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_sort_trace), &p, sizeof(p)));
     return DM4D_OK;
 }
-constexpr int kSortThreads = 256;
-constexpr int kSortLdsCap = 2048;
-constexpr int kSortPerThread = kSortLdsCap / kSortThreads;
+constexpr int kSortPerThread = 8;        // keys a thread holds in registers: LDS capacity = 8 x threads
+constexpr int kSortSmall = 256, kSortLarge = 1024;   // threads of the two variants (tiles <= 2048 / <= 8192 entries)
+constexpr int kLargeRanks = 64;          // tiles per view (the first ranks of K3's longest-first order) the large variant covers
 constexpr int kBins = 1024;
 
 // Split the sorted tile list into the sixteen cell lists (stable compaction by the Gaussian's cell block,
@@ -101,7 +101,7 @@ __device__ __forceinline__ uint64_t wave_incl_scan_u64(uint64_t v, int lane)
     }
     return v;
 }
-template <typename GidAt>
+template <int kSortThreads, typename GidAt>
 __device__ __forceinline__ void finish_tile(const ViewCtx &c, int tile, uint32_t s, uint32_t n, GidAt &&gid_at)
 {
     __shared__ uint32_t s_cbase[kCells];
@@ -201,27 +201,36 @@ __device__ __forceinline__ void finish_tile(const ViewCtx &c, int tile, uint32_t
     if (tid < kCells) g.ccount[tile * kCells + tid] = s_cbase[tid];
 }
 
+template <int kSortThreads>
 __global__ __launch_bounds__(kSortThreads) void k_tile_sort(BatchDesc d)
 {
-    __shared__ uint64_t s_a[kSortLdsCap];      // sorted keys
+    constexpr int kSortLdsCap = kSortPerThread * kSortThreads;
+    constexpr int kWaves = kSortThreads / 64;
+    constexpr bool kIsLarge = kSortThreads == kSortLarge;
+    __shared__ uint32_t s_a[kSortLdsCap];      // sorted Gaussian ids
     __shared__ uint64_t s_b[kSortLdsCap];      // bucket-major keys
     __shared__ uint32_t s_bin[kBins + 1];      // histogram -> bucket ends
     __shared__ uint32_t s_cur[kBins];          // bucket starts / scatter cursors
-    __shared__ uint32_t s_red[2 * (kSortThreads / 64)];
+    __shared__ uint32_t s_red[2 * kWaves];
     // block -> (view, tile) in the launch order of K3: the r-th longest tile of every view, views interleaved
     const int view = (int)(blockIdx.x % (uint32_t)d.B);
+    const uint32_t rank = blockIdx.x / (uint32_t)d.B;
     const ViewCtx c = resolve(d, view);
     const GeomPtrs &g = c.g;
     const BinPtrs &b = c.b;
     const uint32_t cap = c.cap;
-    const int t = (int)g.order[blockIdx.x / (uint32_t)d.B];
+    if (rank >= (uint32_t)c.T) return;
+    const int t = (int)g.order[rank];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    uint64_t *tr = g_sort_trace ? g_sort_trace + 5 * (size_t)blockIdx.x : nullptr;
+    uint64_t *tr = (g_sort_trace && kIsLarge) ? g_sort_trace + 5 * (size_t)blockIdx.x : nullptr;
     if (tr && tid == 0) tr[0] = wall_clock64();
     const uint32_t s = g.tile_start[t];
     uint32_t n = g.tile_count[t];
     if (s >= cap) n = 0;
     else if (s + n > cap) n = cap - s;   // overflow: memory-safe, result flagged invalid by K3
+    // Division of labour: the 256-thread variant takes every tile of <= 2048 entries; the 1024-thread variant
+    // (launched over the first kLargeRanks ranks of every view, on a second stream) takes the larger ones.
+    if (kIsLarge ? (n <= (uint32_t)(kSortPerThread * kSortSmall)) : (n > (uint32_t)kSortLdsCap && rank < (uint32_t)kLargeRanks)) return;
     if (n == 0) {
         if (tid < kCells) g.ccount[t * kCells + tid] = 0u;
         return;
@@ -245,11 +254,11 @@ __global__ __launch_bounds__(kSortThreads) void k_tile_sort(BatchDesc d)
             dmin = min(dmin, (uint32_t)__shfl_xor((int)dmin, o, 64));
             dmax = max(dmax, (uint32_t)__shfl_xor((int)dmax, o, 64));
         }
-        if (lane == 0) { s_red[wv] = dmin; s_red[4 + wv] = dmax; }
+        if (lane == 0) { s_red[wv] = dmin; s_red[kWaves + wv] = dmax; }
         for (int i = tid; i <= kBins; i += kSortThreads) s_bin[i] = 0u;
         __syncthreads();
-        dmin = min(min(s_red[0], s_red[1]), min(s_red[2], s_red[3]));
-        dmax = max(max(s_red[4], s_red[5]), max(s_red[6], s_red[7]));
+#pragma unroll
+        for (int w = 0; w < kWaves; ++w) { dmin = min(dmin, s_red[w]); dmax = max(dmax, s_red[kWaves + w]); }
         // depths are positive floats (> 0.2), so the bit patterns order like the values
         const float zmin = __uint_as_float(dmin), zspan = __uint_as_float(dmax) - zmin;
         const float scale = (zspan > 0.f && zspan < 3.0e38f) ? (float)kBins / zspan : 0.f;
@@ -301,12 +310,12 @@ __global__ __launch_bounds__(kSortThreads) void k_tile_sort(BatchDesc d)
                 const uint32_t lo = s_bin[bin[r]], hi = s_bin[bin[r] + 1];
                 uint32_t rank = 0;
                 for (uint32_t j = lo; j < hi; ++j) rank += (s_b[j] < key[r]) ? 1u : 0u;
-                s_a[lo + rank] = key[r];
+                s_a[lo + rank] = (uint32_t)key[r];       // the Gaussian id is all the later stages need
             }
         }
         __syncthreads();
         if (tr && tid == 0) tr[2] = wall_clock64();
-        finish_tile(c, t, s, n, [&](uint32_t e) { return (uint32_t)s_a[e]; });
+        finish_tile<kSortThreads>(c, t, s, n, [&](uint32_t e) { return s_a[e]; });
         if (tr && tid == 0) { tr[3] = wall_clock64(); tr[4] = n; }
     } else {
         // ---- large tile: the same bucket sort with the keys resident in HBM (L2) ----
@@ -324,11 +333,11 @@ __global__ __launch_bounds__(kSortThreads) void k_tile_sort(BatchDesc d)
             dmin = min(dmin, (uint32_t)__shfl_xor((int)dmin, o, 64));
             dmax = max(dmax, (uint32_t)__shfl_xor((int)dmax, o, 64));
         }
-        if (lane == 0) { s_red[wv] = dmin; s_red[4 + wv] = dmax; }
+        if (lane == 0) { s_red[wv] = dmin; s_red[kWaves + wv] = dmax; }
         for (int i = tid; i <= kBins; i += kSortThreads) s_bin[i] = 0u;
         __syncthreads();
-        dmin = min(min(s_red[0], s_red[1]), min(s_red[2], s_red[3]));
-        dmax = max(max(s_red[4], s_red[5]), max(s_red[6], s_red[7]));
+#pragma unroll
+        for (int w = 0; w < kWaves; ++w) { dmin = min(dmin, s_red[w]); dmax = max(dmax, s_red[kWaves + w]); }
         const float zmin = __uint_as_float(dmin), zspan = __uint_as_float(dmax) - zmin;
         const float scale = (zspan > 0.f && zspan < 3.0e38f) ? (float)kBins / zspan : 0.f;
         auto bin_of = [&](uint32_t dz) {
@@ -371,7 +380,7 @@ __global__ __launch_bounds__(kSortThreads) void k_tile_sort(BatchDesc d)
         }
         __syncthreads();
         if (tr && tid == 0) { tr[1] = tr[0]; tr[2] = wall_clock64(); }
-        finish_tile(c, t, s, n, [&](uint32_t e) { return ki_[e]; });
+        finish_tile<kSortThreads>(c, t, s, n, [&](uint32_t e) { return ki_[e]; });
         if (tr && tid == 0) { tr[3] = wall_clock64(); tr[4] = n; }
     }
 }
@@ -386,13 +395,47 @@ int launch_colscan(const BatchDesc &d, hipStream_t st)
     return DM4D_OK;
 }
 
+// The few tiles of > 2048 entries (silhouettes) would bound K4 from below on the 256-thread variant (their
+// keys do not fit its LDS): they run on the 1024-thread / 104 KB variant, concurrently on a helper stream.
+struct AuxStream { hipStream_t st; hipEvent_t fork, join; bool ok; };
+static AuxStream g_aux[64] = {};
+static AuxStream *aux_stream()
+{
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+    AuxStream &a = g_aux[dev];
+    if (!a.ok) {
+        if (hipStreamCreateWithFlags(&a.st, hipStreamNonBlocking) != hipSuccess) return nullptr;
+        if (hipEventCreateWithFlags(&a.fork, hipEventDisableTiming) != hipSuccess) return nullptr;
+        if (hipEventCreateWithFlags(&a.join, hipEventDisableTiming) != hipSuccess) return nullptr;
+        a.ok = true;
+    }
+    return &a;
+}
+
 int launch_tile_sort(const BatchDesc &d, hipStream_t st)
 {
     const int T = ((d.W + kTile - 1) / kTile) * ((d.H + kTile - 1) / kTile);
     if (T <= 0) return DM4D_OK;
+    AuxStream *a = aux_stream();
+    const unsigned large_blocks = (unsigned)min(T, kLargeRanks) * (unsigned)d.B;
     ProfScope prof_(kKTileSort, st);
-    hipLaunchKernelGGL(k_tile_sort, dim3((unsigned)T * (unsigned)d.B), dim3(kSortThreads), 0, st, d);
+    // The large variant goes FIRST on the caller's stream (it needs whole CUs: 1024 threads + 104 KB of LDS per
+    // workgroup; started after the small variant has filled the machine it waits for CUs to drain -- measured: its
+    // workgroups then started 90 us late); the small variant runs beside it on the helper stream.
+    hipStream_t sst = a ? a->st : st;
+    if (a) {
+        DM4D_HIP_CHECK(hipEventRecord(a->fork, st));
+        DM4D_HIP_CHECK(hipStreamWaitEvent(a->st, a->fork, 0));
+    }
+    hipLaunchKernelGGL(k_tile_sort<kSortLarge>, dim3(large_blocks), dim3(kSortLarge), 0, st, d);
     DM4D_HIP_CHECK(hipGetLastError());
+    hipLaunchKernelGGL(k_tile_sort<kSortSmall>, dim3((unsigned)T * (unsigned)d.B), dim3(kSortSmall), 0, sst, d);
+    DM4D_HIP_CHECK(hipGetLastError());
+    if (a) {
+        DM4D_HIP_CHECK(hipEventRecord(a->join, a->st));
+        DM4D_HIP_CHECK(hipStreamWaitEvent(st, a->join, 0));
+    }
     return DM4D_OK;
 }
 
