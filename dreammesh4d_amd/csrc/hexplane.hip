@@ -82,7 +82,8 @@ __device__ __forceinline__ void node_coords(const HexDesc &d, const float *__res
 // ---------------------------------------------------------------------------------------- forward
 // one thread per (frame, node, scale, channel); 32 consecutive lanes = the 32 channels of one query
 __global__ __launch_bounds__(256) void k_hex_fwd(HexDesc d, const float *__restrict__ nodes,
-                                                 const float *__restrict__ times, float *__restrict__ feat)
+                                                 const float *__restrict__ times, float *__restrict__ feat,
+                                                 float *__restrict__ samples /* [B][M][S][6][32] or nullptr */)
 {
     const size_t gid = (size_t)blockIdx.x * 256 + threadIdx.x;
     const size_t total = (size_t)d.B * d.M * d.S * kHexCh;
@@ -94,20 +95,21 @@ __global__ __launch_bounds__(256) void k_hex_fwd(HexDesc d, const float *__restr
     float xn[4];
     node_coords(d, nodes, times, f, m, xn);
     float acc = 1.f;
+    float *sv = samples ? samples + ((((size_t)f * d.M + m) * d.S + s) * kHexPlanes) * kHexCh + c : nullptr;
 #pragma unroll
     for (int p = 0; p < kHexPlanes; ++p) {
         const Sample q = plane_sample(d, s, p, xn);
         const size_t cs = (size_t)c * d.res[s][c_axis0[p]] * d.res[s][c_axis1[p]];
-        acc = acc * sample_value(d.plane[s][p], cs, q);
+        const float v = sample_value(d.plane[s][p], cs, q);
+        if (sv) sv[(size_t)p * kHexCh] = v;      // kept for the backward (the channel-major planes make every
+        acc = acc * v;                           // sample 4 scattered 4-byte reads: not worth repeating)
     }
     feat[((size_t)f * d.M + m) * (d.S * kHexCh) + s * kHexCh + c] = acc;
 }
 
 // ---------------------------------------------------------------------------------------- backward 1
-// G[f][m][s][p][c] = dL/dfeat * prod_{p' != p} sample_{p'}
-__global__ __launch_bounds__(256) void k_hex_bwd_point(HexDesc d, const float *__restrict__ nodes,
-                                                       const float *__restrict__ times,
-                                                       const float *__restrict__ g_feat, float *__restrict__ G)
+// G[f][m][s][p][c] = dL/dfeat * prod_{p' != p} sample_{p'}, computed IN PLACE over the samples the forward saved
+__global__ __launch_bounds__(256) void k_hex_bwd_point(HexDesc d, const float *__restrict__ g_feat, float *__restrict__ G)
 {
     const size_t gid = (size_t)blockIdx.x * 256 + threadIdx.x;
     const size_t total = (size_t)d.B * d.M * d.S * kHexCh;
@@ -116,15 +118,10 @@ __global__ __launch_bounds__(256) void k_hex_bwd_point(HexDesc d, const float *_
     const int s = (int)((gid / kHexCh) % d.S);
     const int m = (int)((gid / ((size_t)kHexCh * d.S)) % d.M);
     const int f = (int)(gid / ((size_t)kHexCh * d.S * d.M));
-    float xn[4];
-    node_coords(d, nodes, times, f, m, xn);
+    float *o = G + ((((size_t)f * d.M + m) * d.S + s) * kHexPlanes) * kHexCh + c;
     float v[kHexPlanes];
 #pragma unroll
-    for (int p = 0; p < kHexPlanes; ++p) {
-        const Sample q = plane_sample(d, s, p, xn);
-        const size_t cs = (size_t)c * d.res[s][c_axis0[p]] * d.res[s][c_axis1[p]];
-        v[p] = sample_value(d.plane[s][p], cs, q);
-    }
+    for (int p = 0; p < kHexPlanes; ++p) v[p] = o[(size_t)p * kHexCh];
     const float g = g_feat[((size_t)f * d.M + m) * (d.S * kHexCh) + s * kHexCh + c];
     float pre[kHexPlanes], suf[kHexPlanes];
     pre[0] = 1.f;
@@ -133,7 +130,6 @@ __global__ __launch_bounds__(256) void k_hex_bwd_point(HexDesc d, const float *_
     suf[kHexPlanes - 1] = 1.f;
 #pragma unroll
     for (int p = kHexPlanes - 2; p >= 0; --p) suf[p] = suf[p + 1] * v[p + 1];
-    float *o = G + ((((size_t)f * d.M + m) * d.S + s) * kHexPlanes) * kHexCh + c;
 #pragma unroll
     for (int p = 0; p < kHexPlanes; ++p) o[(size_t)p * kHexCh] = g * (pre[p] * suf[p]);
 }
@@ -327,14 +323,15 @@ int dm4d_hexplane_axis_index(int32_t S, int32_t M, const int32_t *res, const flo
 
 int dm4d_hexplane_forward(int32_t S, int32_t M, int32_t B, const int32_t *res, const float *const *planes,
                           const float *aabb_host, const float *nodes, const float *times, float *feat,
-                          dm4d_stream_t stream)
+                          void *samples, dm4d_stream_t stream)
 {
     HexDesc d;
     int rc = fill_desc(d, S, M, B, res, planes, aabb_host);
     if (rc) return rc;
     if (!planes || !nodes || !times || !feat) { set_error("hexplane: null tensor"); return DM4D_ERR_INVALID; }
     const size_t total = (size_t)B * M * S * kHexCh;
-    hipLaunchKernelGGL(k_hex_fwd, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, d, nodes, times, feat);
+    hipLaunchKernelGGL(k_hex_fwd, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, d, nodes, times, feat,
+                       (float *)samples);
     DM4D_HIP_CHECK(hipGetLastError());
     return DM4D_OK;
 }
@@ -369,7 +366,7 @@ int dm4d_hexplane_backward(int32_t S, int32_t M, int32_t B, const int32_t *res, 
     hipLaunchKernelGGL(k_hex_zero, dim3(256, hg.n), dim3(256), 0, st, hg);
     DM4D_HIP_CHECK(hipGetLastError());
     const size_t total = (size_t)B * M * S * kHexCh;
-    hipLaunchKernelGGL(k_hex_bwd_point, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, d, nodes, times, g_feat, (float *)scratch);
+    hipLaunchKernelGGL(k_hex_bwd_point, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, d, g_feat, (float *)scratch);
     DM4D_HIP_CHECK(hipGetLastError());
     if (n_spatial > 0) {
         hipLaunchKernelGGL(k_hex_bwd_spatial, dim3((unsigned)(((size_t)n_spatial * kHexCh + 255) / 256)), dim3(256), 0, st, d, nodes,

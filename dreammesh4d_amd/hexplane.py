@@ -102,11 +102,13 @@ class _HexPlaneFeatures(torch.autograd.Function):
                 raise ValueError("HexPlane planes must be contiguous float32")
         t = times.detach().to(torch.float32).contiguous()
         feat = torch.empty(B, plan.M, plan.S * 32, dtype=torch.float32, device=dev)
+        need_bwd = any(p.requires_grad for p in planes)
+        samples = torch.empty(L.dm4d_hexplane_scratch_bytes(plan.S, plan.M, B), dtype=torch.uint8, device=dev) if need_bwd else None
         with torch.cuda.device(dev):
             _lib.check(L.dm4d_hexplane_forward(plan.S, plan.M, B, plan.res_c, _plane_ptr_array(pl), plan.aabb_c,
-                                               _p(plan.nodes), _p(t), _p(feat), torch.cuda.current_stream(dev).cuda_stream),
-                       "dm4d_hexplane_forward")
-        ctx.plan, ctx.t, ctx.planes = plan, t, pl
+                                               _p(plan.nodes), _p(t), _p(feat), _p(samples),
+                                               torch.cuda.current_stream(dev).cuda_stream), "dm4d_hexplane_forward")
+        ctx.plan, ctx.t, ctx.planes, ctx.samples = plan, t, pl, samples
         return feat
 
     @staticmethod
@@ -118,7 +120,7 @@ class _HexPlaneFeatures(torch.autograd.Function):
         g = g_feat.detach().to(torch.float32).contiguous()
         grads = [torch.empty_like(p) for p in pl]      # dense; the C call zero-fills them (one launch) before the gathers
         gptr = _plane_ptr_array(grads)
-        scratch = torch.empty(L.dm4d_hexplane_scratch_bytes(plan.S, plan.M, B), dtype=torch.uint8, device=dev)
+        scratch, ctx.samples = ctx.samples, None      # the forward's plane samples; the backward works in place
         sp, tp = plan.sp, plan.tp
         with torch.cuda.device(dev):
             _lib.check(L.dm4d_hexplane_backward(

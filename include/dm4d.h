@@ -235,10 +235,11 @@ int dm4d_face_gaussians_backward(int32_t F, int32_t G, int32_t V, const int32_t 
  * sample (align_corners, border padding).  `res` [S,4] (host) = resolution of x,y,z,t per scale;
  * `planes` = HOST array of S*6 device pointers, plane (s,p) is [32, res[a1], res[a0]] (the reference's
  * parameter layout, so its checkpoints load unchanged); `aabb_host` [2,3] (host); nodes [M,3], times [B]
- * (already mapped to [-1,1]), feat [B,M,S*32] on the device. */
+ * (already mapped to [-1,1]), feat [B,M,S*32] on the device.  `samples` (device, dm4d_hexplane_scratch_bytes,
+ * or NULL for inference) receives the 6 plane samples of every feature; dm4d_hexplane_backward consumes it. */
 int dm4d_hexplane_forward(int32_t S, int32_t M, int32_t B, const int32_t *res, const float *const *planes,
                           const float *aabb_host, const float *nodes, const float *times, float *feat,
-                          dm4d_stream_t stream);
+                          void *samples, dm4d_stream_t stream);
 /* Plan helper: lower texel index of every node along x,y,z per scale, i0 [S,3,M] (device), computed with
  * the kernels' own arithmetic; the host builds the static gather lists of the backward from it. */
 int dm4d_hexplane_axis_index(int32_t S, int32_t M, const int32_t *res, const float *aabb_host, const float *nodes,
@@ -254,7 +255,7 @@ int dm4d_hexplane_backward(int32_t S, int32_t M, int32_t B, const int32_t *res, 
                            int32_t n_spatial, const int32_t *sp_scale, const int32_t *sp_plane, const int32_t *sp_texel,
                            const int32_t *sp_off, const int32_t *sp_item, int32_t n_time, const int32_t *tp_scale,
                            const int32_t *tp_plane, const int32_t *tp_col, const int32_t *tp_off, const int32_t *tp_item,
-                           void *scratch, float *const *g_planes, dm4d_stream_t stream);
+                           void *samples /* from the forward; overwritten */, float *const *g_planes, dm4d_stream_t stream);
 
 /* ------------------------------------------------------------------ deformation MLP (fused) */
 
