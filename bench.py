@@ -131,9 +131,12 @@ def main():
     from dreammesh4d_amd import _lib
     L = _lib.lib()
 
-    from dreammesh4d_amd.distributed import GradAllReducer
+    from dreammesh4d_amd.distributed import GradAllReducer, touched_from_plan
     wl = Workload(dev, rank, world)
-    reducer = GradAllReducer(wl.net.parameters())     # 35.76 M floats = 143 MB, one message
+    wl.step()                                          # builds the HexPlane gather plan of the (static) node set
+    # 35.76 M parameters, but the spatial grids only receive gradient at the texels the static nodes touch (the
+    # same on every rank): the exchanged message is the touched texels + the time planes + the MLP
+    reducer = GradAllReducer(wl.net.parameters(), touched=touched_from_plan(wl.net.deformation_net.grid, wl.net._hex_plan))
 
     def step():
         wl.step()
@@ -147,15 +150,13 @@ def main():
     for _ in range(args.warmup):
         step()
     sync()
-    # settle: keep stepping (untimed) until the GPU has been busy for >= 1 s, so that the clock / power state the
-    # device idled into while the host built the scene does not leak into the timed region (observed: a run
-    # started right after an idle period can spend its first few hundred ms at a fraction of the clock)
-    settle, t_settle = 0, time.perf_counter()
-    while time.perf_counter() - t_settle < 1.0:
-        for _ in range(20):
-            step()
-        sync()
-        settle += 20
+    # settle: a FIXED number of extra untimed steps (about 0.8 s of GPU work; the same count on every rank, so
+    # the ranks stay in lockstep), so that the clock / power state the device idled into while the host built the
+    # scene does not leak into the timed region
+    settle = 400
+    for _ in range(settle):
+        step()
+    sync()
     D_views = wl.renderer.check()      # also validates the duplicate-list capacity
     L.dm4d_profile_enable(1 << K_RENDER_BWD)
     t0 = time.perf_counter()
@@ -207,6 +208,7 @@ def main():
                                    f"512x512; per view: skinning + face->Gaussian + RGB pass + normal pass, fwd+bwd",
                        "views_per_step_per_gpu": VIEWS_PER_STEP, "untimed_settle_steps": settle, "frames_per_step_per_gpu": FRAMES_PER_STEP,
                        "mean_duplicates_D": round(D_mean), "allreduce_bytes_per_step": reducer.nbytes if world > 1 else 0,
+                       "allreduce_message_bytes": reducer.nbytes, "dense_gradient_bytes": 4 * reducer.dense_elements,
                        "whole_view_frac_of_hbm_roofline":
                            round(value / world * b_view / (HBM_PEAK_GBS * 1e9), 5),
                        "parallelism": f"dp{world} (frames sharded, 1 grad all-reduce/step)" if world > 1 else "single GPU"},

@@ -70,6 +70,15 @@ class MlpWeightsGrad(C.Structure):
     _fields_ = [("W0", vp), ("b0", vp), ("W1", vp * 4), ("b1", vp * 4), ("W2", vp * 4), ("b2", vp * 4)]
 
 
+MAX_GRAD_SEGMENTS = 64
+
+
+class GradSegments(C.Structure):
+    """dm4d_grad_segments (include/dm4d.h)."""
+    _fields_ = [("n_segments", C.c_int32), ("grad", vp * MAX_GRAD_SEGMENTS), ("index", vp * MAX_GRAD_SEGMENTS),
+                ("count", C.c_int64 * MAX_GRAD_SEGMENTS), ("offset", C.c_int64 * MAX_GRAD_SEGMENTS)]
+
+
 ALLOC_FN = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_int, C.c_size_t)
 
 _SIGNATURES = {
@@ -115,6 +124,8 @@ _SIGNATURES = {
     "dm4d_deform_mlp_forward": (C.c_int, [C.c_int32, vp, C.POINTER(MlpWeights), vp, vp, C.POINTER(vp), vp, vp]),
     "dm4d_deform_mlp_backward": (C.c_int, [C.c_int32, vp, C.POINTER(MlpWeights), vp, vp, C.POINTER(vp), vp,
                                            C.POINTER(MlpWeightsGrad), vp, vp]),
+    "dm4d_grad_pack": (C.c_int, [C.POINTER(GradSegments), vp, vp]),
+    "dm4d_grad_unpack": (C.c_int, [C.POINTER(GradSegments), vp, C.c_float, vp]),
     "dm4d_views_geom_bytes": (C.c_size_t, [C.c_int32] * 4),
     "dm4d_views_binning_bytes": (C.c_size_t, [C.c_int32, C.c_int64]),
     "dm4d_views_image_bytes": (C.c_size_t, [C.c_int32] * 3),

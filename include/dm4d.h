@@ -288,6 +288,24 @@ int dm4d_deform_mlp_backward(int32_t P, const float *feat, const dm4d_mlp_weight
                              const float *y_save, const float *const *g_out /* [host] */, float *g_feat,
                              const dm4d_mlp_weights_grad *gw, void *scratch, dm4d_stream_t stream);
 
+/* ------------------------------------------------------------------ data-parallel gradient message */
+
+/* The one exchange step of the path is an all-reduce of the parameter gradients.  The
+ * message is one flat float32 buffer of up to DM4D_MAX_GRAD_SEGMENTS segments: segment k holds count[k] elements
+ * at offset[k]; they are the whole gradient tensor grad[k] (index[k] == NULL) or its elements index[k][0..count)
+ * (int64, device) -- for the HexPlane spatial planes only the texels the static graph nodes touch.  One launch
+ * packs, one unpacks (message * scale -> gradients).  pack: grad[k] == NULL contributes zeros. */
+#define DM4D_MAX_GRAD_SEGMENTS 64
+typedef struct dm4d_grad_segments {
+    int32_t n_segments;
+    float *grad[DM4D_MAX_GRAD_SEGMENTS];
+    const int64_t *index[DM4D_MAX_GRAD_SEGMENTS];
+    int64_t count[DM4D_MAX_GRAD_SEGMENTS];
+    int64_t offset[DM4D_MAX_GRAD_SEGMENTS];
+} dm4d_grad_segments;
+int dm4d_grad_pack(const dm4d_grad_segments *segments, float *flat, dm4d_stream_t stream);
+int dm4d_grad_unpack(const dm4d_grad_segments *segments, const float *flat, float scale, dm4d_stream_t stream);
+
 /* ------------------------------------------------------------------ batched views (the fast path) */
 
 /* The whole per-view hot path for B (frame, view) units of one scene in 8 launches forward /

@@ -50,6 +50,37 @@ def test_grad_allreduce_and_frame_sharding_world2():
     assert set(a["frames"]).isdisjoint(b["frames"]) and len(a["frames"]) == 4
 
 
+def _worker_sparse(rank, world, port, out):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.manual_seed(0)
+    grid = torch.nn.Parameter(torch.zeros(1, 4, 5, 6))           # a "plane": gradient only at the touched elements
+    dense = torch.nn.Parameter(torch.zeros(7))
+    idx = torch.tensor([3, 17, 18, 64, 119])
+    g = torch.zeros(grid.numel())
+    g[idx] = torch.arange(1.0, 6.0) * (rank + 1)
+    grid.grad = g.view_as(grid).clone()
+    dense.grad = torch.full((7,), float(rank))
+    red = D.GradAllReducer([grid, dense], touched={grid: idx})
+    red()
+    out[rank] = {"grid": grid.grad.clone(), "dense": dense.grad.clone(), "nbytes": red.nbytes}
+    dist.destroy_process_group()
+
+
+def test_structured_sparse_allreduce_world2():
+    """Only the touched elements of a grid travel; the result equals the dense mean."""
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker_sparse, args=(2, _free_port(), out), nprocs=2, join=True)
+    a, b = out[0], out[1]
+    assert torch.equal(a["grid"], b["grid"]) and torch.equal(a["dense"], b["dense"])
+    want = torch.zeros(120)
+    want[torch.tensor([3, 17, 18, 64, 119])] = torch.arange(1.0, 6.0) * 1.5
+    assert torch.equal(a["grid"].view(-1), want)
+    assert torch.equal(a["dense"], torch.full((7,), 0.5))
+    assert a["nbytes"] == (5 + 7) * 4
+
+
 def test_shard_frames_covers_the_timeline():
     seen = set()
     for r in range(8):

@@ -56,6 +56,16 @@ def test_fused_hexplane_matches_grid_sample_path(resolution, multires, M, B, hea
             continue
         scale = p.grad.abs().max() + 1e-12
         assert (fused[n] - p.grad).abs().max() / scale < 2e-4, n
+    # the structured-sparse exchange of the multi-GPU step relies on this: spatial planes get gradient ONLY at the
+    # plan's touched texels
+    from dreammesh4d_amd.distributed import touched_from_plan
+    touched = touched_from_plan(net.deformation_net.grid, net._hex_plan)
+    assert len(touched) == 3 * len(multires)
+    for par, idx in touched.items():
+        mask = torch.ones(par.numel(), dtype=torch.bool, device=dev)
+        mask[idx] = False
+        assert not fused[[n for n, q in net.named_parameters() if q is par][0]].view(-1)[mask].any()
+        assert idx.numel() == idx.unique().numel() <= par.numel()
     # deterministic: the gather backward gives bit-identical gradients on a re-run
     net.zero_grad(set_to_none=True)
     out3 = [x for x in net.node_outputs(nodes, ts) if x is not None]
@@ -63,3 +73,32 @@ def test_fused_hexplane_matches_grid_sample_path(resolution, multires, M, B, hea
     for n, p in net.named_parameters():
         if p.grad is not None:       # HexPlane gather backward and the MLP's fixed-order row sums
             assert torch.equal(p.grad, fused[n]), n
+
+
+def test_gradient_message_pack_unpack_matches_torch_path():
+    """csrc/gradpack.hip (one launch each way) against the torch-op path the gloo CPU tests exercise."""
+    _need_gpu()
+    from dreammesh4d_amd.distributed import GradAllReducer
+
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(0)
+    shapes = [(1, 8, 9, 7), (13,), (5, 6), (3,)]
+    params = [torch.nn.Parameter(torch.zeros(s, device=dev)) for s in shapes]
+    idx = torch.randperm(8 * 9 * 7, generator=g)[:40].sort().values.to(dev)
+    grads = [torch.randn(s, generator=g).to(dev) for s in shapes]
+    sparse = torch.zeros(8 * 9 * 7, device=dev)
+    sparse[idx] = grads[0].view(-1)[idx]
+    grads[0] = sparse.view(shapes[0])
+    for p, gr in zip(params, grads):
+        p.grad = gr.clone()
+    params[3].grad = None                                    # a parameter that got no gradient
+    red = GradAllReducer(params, touched={params[0]: idx})
+    red.pack()
+    want = torch.cat([grads[0].view(-1)[idx], grads[1].view(-1), grads[2].view(-1), torch.zeros(3, device=dev)])
+    assert torch.equal(red.flat, want)
+    assert red.nbytes == (40 + 13 + 30 + 3) * 4 and red.dense_elements == 8 * 9 * 7 + 13 + 30 + 3
+    red.flat.mul_(2.0)                                       # stand-in for the all-reduce (sum of 2 equal ranks)
+    red.unpack(0.5)
+    for p, gr in zip(params[:3], grads[:3]):
+        assert torch.equal(p.grad, gr)
+    assert params[3].grad is not None and not params[3].grad.any()
