@@ -41,6 +41,15 @@ def bary_coords(n_per_face, device=None, dtype=torch.float32):
     return torch.tensor(_BARY[int(n_per_face)], dtype=dtype, device=device)[..., None]
 
 
+def circle_radius(n_per_face, init_gs_scales_s=1.0):
+    """``surface_triangle_circle_radius`` (sugar.py:236-267): radius of the circles packed into a unit triangle."""
+    import math
+
+    r = {1: 1.0 / 2.0 / math.sqrt(3.0), 3: 1.0 / 2.0 / (math.sqrt(3.0) + 1.0), 4: 1.0 / (4.0 * math.sqrt(3.0)),
+         6: 1.0 / (4.0 + 2.0 * math.sqrt(3.0))}[int(n_per_face)]
+    return r * init_gs_scales_s
+
+
 def points(verts, faces, bary):
     fv = verts[faces]                                    # [F,3,3]
     return (fv[:, None] * bary[None]).sum(dim=-2).reshape(-1, 3)

@@ -1,0 +1,241 @@
+"""Mesh-bound Gaussian geometry of the dynamic stage: the host-side mirror of ``DynamicSuGaRModel``
+(custom/threestudio-dreammesh4d/geometry/dynamic_sugar.py:42-899, registered as ``dynamic-sugar``) on top of the
+static ``SuGaRModel`` state (geometry/sugar.py:33-978, ``sugar``).
+
+Attribute and parameter names follow the reference (``_points``, ``_surface_mesh_faces``, ``_scales``,
+``_quaternions``, ``all_densities``, ``_sh_coordinates_dc``, ``surface_mesh_thickness``, ``_deformation``,
+``_deform_graph_node_xyz``, ``_xyz_neighbor_node_idx``, ``_xyz_neighbor_nodes_weights``), so a reference
+checkpoint's geometry entries load by name.  The method surface is the one the reference's renderer and systems
+use: ``get_xyz_verts``, ``get_faces``, ``get_scaling``, ``get_opacity``,
+``get_points_rgb()``, ``get_timed_gs_all_single_time``, ``get_timed_gs_normals``, ``get_timed_vertex_xyz``,
+``get_timed_vertex_rotation``, ``get_timed_face_normals``, ``optimizer`` / ``update_learning_rate`` ...
+
+Everything time-dependent runs on the HIP kernels behind ``ops`` / ``views`` / ``deformation``; the static SuGaR
+properties are the torch ops of ``geometry.py`` (evaluated once: the static parameters are frozen in the dynamic
+stage, dynamic_sugar.py:77-87).  What is NOT mirrored: building the deformation graph from geodesic distances
+(open3d / potpourri3d, :745-861; next) -- the graph (node positions, K neighbours and
+weights per vertex) is an input here -- and the reference's ``discrete`` dynamic mode (per-frame tables).
+"""
+import torch
+import torch.nn as nn
+
+from . import geometry as geo
+from . import ops
+from .deformation import DeformationNetwork
+from .schedule import C
+
+
+def RGB2SH(rgb):
+    return (rgb - 0.5) / 0.28209479177387814
+
+
+class DynamicSuGaR(nn.Module):
+    def __init__(self, verts, faces, node_xyz, nbr_idx, nbr_w, n_gaussians_per_surface_triangle=6,
+                 skinning_method="hybrid", spatial_extent=3.8, vertex_colors=None, log_scales=None, complex_numbers=None,
+                 densities=None, sh_dc=None, deformation_kwargs=None, deformation_lr=0.00032, grid_lr=0.0032,
+                 device="cuda"):
+        super().__init__()
+        dev = torch.device(device)
+        T = lambda a, dt=torch.float32: torch.as_tensor(a, dtype=dt, device=dev)
+        verts, faces = T(verts), T(faces, torch.long)
+        G = int(n_gaussians_per_surface_triangle)
+        F_, V = int(faces.shape[0]), int(verts.shape[0])
+        N = F_ * G
+        self.cfg_n_gaussians_per_surface_triangle = G
+        self.skinning_method = skinning_method
+        self.register_buffer("_surface_mesh_faces", faces)
+        self.surface_mesh_thickness = nn.Parameter(T(spatial_extent / 1_000_000), requires_grad=False)
+        self._points = nn.Parameter(verts, requires_grad=False)
+        # static Gaussian state (frozen in the dynamic stage); defaults follow sugar.py:201-233,300-327
+        if sh_dc is None:
+            if vertex_colors is None:
+                vertex_colors = torch.full((V, 3), 0.5, device=dev)
+            bary = geo.bary_coords(G, dev)                                   # [G,3,1]
+            colors = (T(vertex_colors)[faces][:, None] * bary[None]).sum(-2).reshape(-1, 3)
+            sh_dc = RGB2SH(colors).unsqueeze(1)
+        self._sh_coordinates_dc = nn.Parameter(T(sh_dc).reshape(N, 1, 3), requires_grad=False)
+        self._sh_coordinates_rest = nn.Parameter(torch.zeros(N, 0, 3, device=dev), requires_grad=False)
+        if densities is None:
+            densities = torch.full((N, 1), 2.9444, device=dev)               # sigmoid^-1(0.95)
+        self.all_densities = nn.Parameter(T(densities).reshape(N, 1), requires_grad=False)
+        if log_scales is None:
+            fv = verts[faces]
+            s = (fv - fv[:, [1, 2, 0]]).norm(dim=-1).min(dim=-1)[0] * geo.circle_radius(G)
+            log_scales = torch.log(s.clamp_min(1e-7)).reshape(F_, 1, 1).expand(-1, G, 2).reshape(-1, 2)
+        self._scales = nn.Parameter(T(log_scales).reshape(N, 2).clone(), requires_grad=False)
+        if complex_numbers is None:
+            complex_numbers = torch.zeros(N, 2, device=dev)
+            complex_numbers[:, 0] = 1.0
+        self._quaternions = nn.Parameter(T(complex_numbers).reshape(N, 2).clone(), requires_grad=False)
+        # deformation graph (input; see module docstring)
+        self._deform_graph_node_xyz = T(node_xyz)
+        self._xyz_neighbor_node_idx = T(nbr_idx, torch.long)
+        self._xyz_neighbor_nodes_weights = T(nbr_w)
+        M = int(self._deform_graph_node_xyz.shape[0])
+        self.graph = ops.DeformGraph(verts, self._xyz_neighbor_node_idx, self._xyz_neighbor_nodes_weights, M, dev)
+        self.topo = ops.MeshTopology(faces, V, G, dev)
+        # deformation network: heads as in dynamic_sugar.py:141-147
+        kw = dict(no_dr=False, no_ds=skinning_method == "dqs", no_do=skinning_method != "hybrid")
+        kw.update(deformation_kwargs or {})
+        self._deformation = DeformationNetwork(**kw).to(dev)
+        self.training_setup_dynamic(deformation_lr, grid_lr)
+        self.active_sh_degree = 0
+        self._static_cache = None
+        self._deformed_vert_positions = {}
+        self.global_step = 0
+
+    # ------------------------------------------------------------------ sizes / device
+    @property
+    def device(self):
+        return self._points.device
+
+    @property
+    def n_verts(self):
+        return int(self._points.shape[0])
+
+    @property
+    def n_faces(self):
+        return int(self._surface_mesh_faces.shape[0])
+
+    @property
+    def n_gaussians(self):
+        return self.n_faces * self.cfg_n_gaussians_per_surface_triangle
+
+    # ------------------------------------------------------------------ static SuGaR properties (sugar.py)
+    def _static(self):
+        if self._static_cache is None:
+            G = self.cfg_n_gaussians_per_surface_triangle
+            with torch.no_grad():
+                self._static_cache = dict(
+                    q=geo.quaternions(self._points, self._surface_mesh_faces, self._quaternions, G),
+                    scaling=geo.scaling(self._scales, float(self.surface_mesh_thickness)),
+                    opacity=geo.strengths(self.all_densities),
+                    rgb=geo.points_rgb(self._sh_coordinates_dc),
+                    xyz=geo.points(self._points, self._surface_mesh_faces, geo.bary_coords(G, self.device)))
+        return self._static_cache
+
+    def invalidate_static(self):
+        """Call after changing a static parameter (they are frozen during the dynamic stage)."""
+        self._static_cache = None
+
+    @property
+    def get_xyz_verts(self):
+        return self._points
+
+    @property
+    def get_faces(self):
+        return self._surface_mesh_faces
+
+    @property
+    def get_xyz(self):
+        return self._static()["xyz"]
+
+    @property
+    def get_scaling(self):
+        return self._static()["scaling"]
+
+    @property
+    def get_rotation(self):
+        return self._static()["q"]
+
+    @property
+    def static_quaternions(self):
+        return self._static()["q"]
+
+    @property
+    def get_opacity(self):
+        return self._static()["opacity"].reshape(-1, 1)
+
+    @property
+    def get_features(self):
+        return torch.cat([self._sh_coordinates_dc, self._sh_coordinates_rest], dim=1)
+
+    def get_points_rgb(self):
+        return self._static()["rgb"]
+
+    # ------------------------------------------------------------------ optimiser (dynamic_sugar.py:167-279, sugar.py:406-416)
+    def training_setup_dynamic(self, deformation_lr=0.00032, grid_lr=0.0032):
+        self._lr = {"deformation": deformation_lr, "grid": grid_lr}
+        self.optimize_list = [
+            {"params": self._deformation.get_mlp_parameters(), "lr": deformation_lr, "name": "deformation"},
+            {"params": self._deformation.get_grid_parameters(), "lr": grid_lr, "name": "grid"}]
+        self.optimize_params = [d["name"] for d in self.optimize_list]
+        self.optimizer = torch.optim.Adam(self.optimize_list, lr=0.0, eps=1e-15)
+
+    def merge_optimizer(self, net_optimizer):
+        """AdamW over the geometry's groups + the system's groups (sugar.py:406-416)."""
+        groups = list(self.optimize_list) + (list(net_optimizer.param_groups) if net_optimizer is not None else [])
+        self.optimizer = torch.optim.AdamW(groups, lr=0.0, betas=(0.9, 0.99), eps=1e-15)
+        return self.optimizer
+
+    def update_learning_rate(self, iteration):
+        for g in self.optimizer.param_groups:
+            if g.get("name") in self._lr:
+                g["lr"] = C(self._lr[g["name"]], 0, iteration, interpolation="exp")
+
+    def update_step(self, epoch, global_step, on_load_weights=False):
+        self._deformed_vert_positions = {}
+        self.global_step = global_step
+
+    # ------------------------------------------------------------------ time-dependent quantities
+    def _times(self, timestamp, frame_idx):
+        if timestamp is None:
+            raise NotImplementedError("frame_idx without timestamp (the reference's `discrete` mode) is not mirrored")
+        return torch.as_tensor(timestamp, dtype=torch.float32, device=self.device).reshape(-1)
+
+    def timed_node_outputs(self, timestamp, frame_idx=None):
+        """Raw deformation-network outputs once per DISTINCT timestamp of the batch (the reference caches them per
+        (t, f) within a step, dynamic_sugar.py:367-405) + the view -> frame map: dx [F,M,3], dr [F,M,4],
+        ds [F,M,6] | None, do [F,M] | None, frame_index [B] int32."""
+        t = self._times(timestamp, frame_idx)
+        uniq, inv = torch.unique(t, sorted=True, return_inverse=True)
+        dx, dr, ds, do = self._deformation.node_outputs(self._deform_graph_node_xyz, uniq)
+        return dx, dr, ds, do, inv.to(torch.int32)
+
+    def get_timed_vertex_attributes(self, timestamp=None, frame_idx=None):
+        """{"xyz": [N_t,V,3], "rotation": [N_t,V,4] (x,y,z,w)} (dynamic_sugar.py:468-613)."""
+        t = self._times(timestamp, frame_idx)
+        dx, dr, ds, do = self._deformation.node_outputs(self._deform_graph_node_xyz, t)
+        xyz, rot = [], []
+        for i in range(int(t.shape[0])):       # convenience accessor; the training path is views.render_views
+            x, r = ops.skin_vertices(self.graph, dx[i], dr[i], None if ds is None else ds[i],
+                                     None if do is None else do[i], self.skinning_method)
+            xyz.append(x)
+            rot.append(r)
+        return {"xyz": torch.stack(xyz), "rotation": torch.stack(rot)}
+
+    def get_timed_vertex_xyz(self, timestamp=None, frame_idx=None):
+        return self.get_timed_vertex_attributes(timestamp, frame_idx)["xyz"]
+
+    def get_timed_vertex_rotation(self, timestamp=None, frame_idx=None, return_matrix=False):
+        q = self.get_timed_vertex_attributes(timestamp, frame_idx)["rotation"]
+        if not return_matrix:
+            return q
+        x, y, z, w = q.unbind(-1)
+        return torch.stack([1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w),
+                            2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w),
+                            2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)], -1).reshape(*q.shape[:-1], 3, 3)
+
+    def get_timed_gs_attributes(self, timestamp=None, frame_idx=None):
+        """Per timestamp: {"xyz" [N_t,N,3], "rotation" [N_t,N,4] (w,x,y,z), "normals" [N_t,N,3]} (:657-706, :330-364)."""
+        va = self.get_timed_vertex_attributes(timestamp, frame_idx)
+        res = [ops.face_gaussians(self.topo, x, r, self.static_quaternions) for x, r in zip(va["xyz"], va["rotation"])]
+        return {"xyz": torch.stack([m for m, _, _ in res]), "rotation": torch.stack([q for _, q, _ in res]),
+                "normals": torch.stack([n for _, _, n in res]), "vertex_xyz": va["xyz"]}
+
+    def get_timed_gs_all_single_time(self, timestamp=None, frame_idx=None):
+        """(means3D, scales, rotations, opacity, colors_precomp) of ONE timestamp (dynamic_sugar.py:708-724)."""
+        t = None if timestamp is None else torch.as_tensor(timestamp).reshape(1)
+        a = self.get_timed_gs_attributes(t, frame_idx)
+        return a["xyz"][0], self.get_scaling, a["rotation"][0], self.get_opacity, self.get_points_rgb()
+
+    def get_timed_gs_normals(self, timestamp=None, frame_idx=None):
+        return self.get_timed_gs_attributes(timestamp, frame_idx)["normals"]
+
+    def get_timed_face_normals(self, timestamp=None, frame_idx=None):
+        G = self.cfg_n_gaussians_per_surface_triangle
+        return self.get_timed_gs_normals(timestamp, frame_idx)[:, ::G]
+
+    def get_timed_surface_mesh(self, timestamp=None, frame_idx=None):
+        """(deformed vertices [N_t,V,3], faces [F,3]) -- the reference returns a pytorch3d ``Meshes`` of them."""
+        return self.get_timed_vertex_xyz(timestamp, frame_idx), self._surface_mesh_faces

@@ -108,7 +108,7 @@ class ViewRenderer:
 
 class _RenderViews(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, r, dx, dr, ds, do, q_static, scales, opacities, rgb, viewmats, projmats, bg6, frame_index):
+    def forward(ctx, r, dx, dr, ds, do, q_static, scales, opacities, rgb, viewmats, projmats, bg6, frame_index, means2D):
         L = _lib.lib()
         g, t, dev = r.graph, r.topo, r.device
         B = int(viewmats.shape[0])
@@ -187,22 +187,26 @@ class _RenderViews(torch.autograd.Function):
         g_sc = o["sc"].sum(0).reshape(s[4]) if ctx.need_static else None
         g_op = o["op"].sum(0).reshape(s[5]) if ctx.need_static else None
         g_rgb = o["col"][:, :, :3].sum(0).reshape(s[6]) if ctx.need_static else None
+        g_m2 = o["m2"] if ctx.needs_input_grad[13] else None       # screen-space mean gradients ("viewspace_points")
         return (None, o["dx"].reshape(s[0]), o["dr"].reshape(s[1]), None if o["ds"] is None else o["ds"].reshape(s[2]),
-                None if o["do"] is None else o["do"].reshape(s[3]), None, g_sc, g_op, g_rgb, None, None, None, None)
+                None if o["do"] is None else o["do"].reshape(s[3]), None, g_sc, g_op, g_rgb, None, None, None, None, g_m2)
 
 
 def render_views(renderer: ViewRenderer, dx, dr, ds, d_opacity, q_static, scales, opacities, rgb, viewmats, projmats,
-                 bg6, frame_index=None):
+                 bg6, frame_index=None, means2D=None):
     """Returns dict: color [B,6,H,W] (RGB | normal), depth [B,1,H,W], alpha [B,1,H,W], radii [B,N] int32,
     vxyz [B,V,3], vrot [B,V,4].
 
     frame_index [B] (int): views that share a timestamp share its skinning and face->Gaussian transform (the
     reference caches them per timestamp within a step, geometry/dynamic_sugar.py:375-386): dx, dr, ds, d_opacity
     are then [n_frames, M, .] (the deformation network's output per distinct timestamp), view b renders frame
-    frame_index[b], vxyz / vrot come back per frame, and the node gradients are summed over a frame's views."""
+    frame_index[b], vxyz / vrot come back per frame, and the node gradients are summed over a frame's views.
+
+    means2D [B,N,3] (optional, zeros with requires_grad): the reference's screen-space gradient carrier
+    (``viewspace_points``); its gradient is dL/d(mean2D) of every view."""
     m = renderer.method
     args = (renderer, dx, dr, ds if m != 1 else None, d_opacity if m == 2 else None, q_static, scales, opacities, rgb,
-            viewmats, projmats, bg6, frame_index)
+            viewmats, projmats, bg6, frame_index, means2D)
     color, depth, alpha, radii, vxyz, vrot = _RenderViews.apply(*args)
     if not renderer.calibrated:
         # first call only: one host sync to size the duplicate / record capacities from the real counts

@@ -1,0 +1,160 @@
+"""GPU tests of the renderer glue (rows A6 / A7) over the DynamicSuGaR geometry: the reference's batch dict in,
+the reference's output dict out; consistent with views.render_views on the same inputs."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from dreammesh4d_amd import synthetic as syn
+
+pytestmark = pytest.mark.gpu
+
+
+def _need_gpu():
+    if not torch.cuda.is_available():
+        pytest.skip("no HIP device")
+
+
+def _build(dev, n_faces=1500, M=80, H=96, W=96, B=5):
+    from dreammesh4d_amd import renderer as R, sugar
+
+    sc = syn.mesh_bound_scene(n_faces, n_nodes=M, k=4, seed=3)
+    geo = sugar.DynamicSuGaR(sc["verts"], sc["faces"], sc["nodes"], sc["nbr_idx"], sc["nbr_w"], complex_numbers=sc["complex"],
+                             log_scales=sc["log_scales"], densities=sc["densities"], sh_dc=sc["sh_dc"],
+                             deformation_kwargs=dict(resolution=(16, 16, 16, 9), multires=(1, 2)), device=dev)
+    g = torch.Generator().manual_seed(5)
+    with torch.no_grad():
+        for name, p in geo._deformation.named_parameters():
+            if "_deform" in name:
+                p.add_((0.03 * torch.randn(p.shape, generator=g)).to(dev))
+    cams = [syn.make_camera(H, W, elev_deg=5 + 9 * b, azim_deg=-100 + 55 * b) for b in range(B)]
+    c2w = torch.stack([torch.tensor(c.c2w, dtype=torch.float32) for c in cams]).to(dev)
+    focal = 0.5 * H / math.tan(0.5 * cams[0].fovy)
+    ro, rd = R.rays(R.ray_directions(H, W, focal, device=dev), c2w)
+    ts = torch.tensor([0.2, 0.7, 0.2, 0.45, 0.7], device=dev)[:B]
+    batch = {"c2w": c2w, "fovy": torch.full((B,), cams[0].fovy, device=dev), "height": H, "width": W, "rays_o": ro,
+             "rays_d": rd, "timestamp": ts, "frame_indices": torch.arange(B, device=dev)}
+    return geo, R.DiffGaussianTemporal(geo), batch, cams
+
+
+def test_batch_forward_keys_shapes_and_consistency_with_render_views():
+    _need_gpu()
+    from dreammesh4d_amd import views
+
+    dev = torch.device("cuda:0")
+    geo, rend, batch, cams = _build(dev)
+    B, H, W, N = 5, 96, 96, geo.n_gaussians
+    out = rend.batch_forward(batch)
+    for k in ("comp_rgb", "comp_normal", "comp_normal_from_dist"):
+        assert out[k].shape == (B, H, W, 3) and torch.isfinite(out[k]).all(), k
+    for k in ("comp_depth", "comp_mask"):
+        assert out[k].shape == (B, H, W, 1), k
+    assert len(out["viewspace_points"]) == B and out["viewspace_points"][0].shape == (N, 3)
+    assert out["visibility_filter"][0].dtype == torch.bool and out["radii"][0].dtype == torch.int32
+    assert float(out["comp_rgb"].detach().min()) >= 0.0 and float(out["comp_rgb"].detach().max()) <= 1.0
+    # same pixels as the low-level call with the camera matrices of the parity tests' numpy helper
+    dx, dr, ds, do, fidx = geo.timed_node_outputs(batch["timestamp"])
+    assert fidx.tolist() == [0, 2, 0, 1, 2] and dx.shape[0] == 3            # 3 distinct timestamps for 5 views
+    T = lambda a: torch.tensor(np.asarray(a), device=dev)
+    vm = torch.stack([T(c.viewmatrix) for c in cams])
+    pm = torch.stack([T(c.projmatrix) for c in cams])
+    r = views.ViewRenderer(geo.graph, geo.topo, H, W, cams[0].tanfov, method="hybrid")
+    ref = views.render_views(r, dx, dr, ds, do, geo.static_quaternions, geo.get_scaling, geo.get_opacity.reshape(-1),
+                             geo.get_points_rgb(), vm, pm, torch.ones(6, device=dev), frame_index=fidx)
+    # (the camera matrices differ in the last float32 bit -- torch.linalg.inv vs float64 numpy -- which moves splat
+    # edges by ~1e-6 px: identical up to isolated edge pixels)
+    def close(a, b, mean_tol=2e-6, max_tol=2e-2):
+        d = (a.detach() - b.detach()).abs()
+        return float(d.mean()) < mean_tol and float(d.max()) < max_tol
+
+    assert close(out["comp_rgb"], ref["color"][:, :3].clamp(0, 1).permute(0, 2, 3, 1))
+    assert close(out["comp_mask"], ref["alpha"].permute(0, 2, 3, 1))
+    # the rasterized normal map: n * 0.5 * alpha + 0.5 of the normalised normal channels
+    n = torch.nn.functional.normalize(ref["color"][:, 3:], dim=1) * 0.5 * ref["alpha"] + 0.5
+    assert close(out["comp_normal"], n.permute(0, 2, 3, 1), mean_tol=2e-5, max_tol=0.5)
+    # inside the silhouette both normal estimates are unit vectors mapped to [0,1] and roughly agree
+    m = (out["comp_mask"][..., 0] > 0.99)
+    a = (out["comp_normal"][m] - 0.5) * 2
+    b = (out["comp_normal_from_dist"][m] - 0.5) * 2
+    assert m.float().mean() > 0.05 and ((a * b).sum(-1) > 0.0).float().mean() > 0.8
+
+
+def test_gradients_reach_the_deformation_network_and_the_viewspace_points():
+    _need_gpu()
+    dev = torch.device("cuda:0")
+    geo, rend, batch, _ = _build(dev)
+    out = rend.batch_forward(batch)
+    g = torch.Generator().manual_seed(1)
+    w = [torch.randn(out[k].shape, generator=g).to(dev) for k in ("comp_rgb", "comp_normal", "comp_normal_from_dist", "comp_depth", "comp_mask")]
+    loss = sum((out[k] * wk).sum() for k, wk in zip(("comp_rgb", "comp_normal", "comp_normal_from_dist", "comp_depth", "comp_mask"), w))
+    loss.backward()
+    grads = {n: p.grad for n, p in geo._deformation.named_parameters() if p.requires_grad}
+    # timenet is constructed and optimised but never used, in the reference too (deformation.py:489-493)
+    assert {n for n, v in grads.items() if v is None} == {n for n in grads if n.startswith("timenet")}
+    grads = {n: v for n, v in grads.items() if v is not None}
+    bad = [n for n, v in grads.items() if not torch.isfinite(v).all()]
+    assert not bad, bad
+    assert sum(float(v.abs().sum()) for n, v in grads.items() if "grid" in n) > 0
+    assert all(v.grad is not None for v in out["viewspace_points"])
+    assert float(torch.stack([v.grad for v in out["viewspace_points"]]).abs().sum()) > 0
+    # static parameters are frozen in the dynamic stage
+    assert geo._scales.grad is None and geo.all_densities.grad is None
+
+
+def test_eval_mode_inverts_the_background_and_single_view_forward_matches_the_batch():
+    _need_gpu()
+    from dreammesh4d_amd import renderer as R
+
+    dev = torch.device("cuda:0")
+    geo, rend, batch, cams = _build(dev, B=2)
+    with torch.no_grad():
+        tr = rend.batch_forward(batch)
+        ev = rend.eval().batch_forward(batch)
+        rend.train()
+        corner_t, corner_e = tr["comp_rgb"][0, 0, 0], ev["comp_rgb"][0, 0, 0]
+        assert torch.allclose(corner_t, torch.ones(3, device=dev)) and torch.allclose(corner_e, torch.zeros(3, device=dev))
+        f = torch.tensor([cams[1].fovy], device=dev)
+        wv, full, ctr = R.cam_info_gaussian(batch["c2w"][1:2], f, f)
+        cam = R.Camera(FoVx=f[0], FoVy=f[0], camera_center=ctr[0], image_width=96, image_height=96,
+                       world_view_transform=wv[0], full_proj_transform=full[0], timestamp=batch["timestamp"][1],
+                       frame_idx=batch["frame_indices"][1])
+        one = rend.forward(cam, rend.background_tensor, rays_o=batch["rays_o"], rays_d=batch["rays_d"], batch_idx=1)
+    assert (one["render"].permute(1, 2, 0) - tr["comp_rgb"][1]).abs().max() < 2e-6
+    assert (one["normal"].permute(1, 2, 0) - tr["comp_normal"][1]).abs().max() < 2e-6
+    assert (one["normal_from_dist"].permute(1, 2, 0) - tr["comp_normal_from_dist"][1]).abs().max() < 2e-6
+    assert set(one) == {"render", "normal", "normal_from_dist", "depth", "mask", "viewspace_points", "visibility_filter",
+                        "radii", "raw_normal", "raw_normal_from_dist"}
+
+
+def test_geometry_surface_matches_the_low_level_ops():
+    _need_gpu()
+    from dreammesh4d_amd import ops
+
+    dev = torch.device("cuda:0")
+    geo, _, batch, _ = _build(dev, B=2)
+    t = batch["timestamp"][:2]
+    with torch.no_grad():
+        means, scales, rots, opac, rgb = geo.get_timed_gs_all_single_time(t[0])
+        assert means.shape == (geo.n_gaussians, 3) and scales.shape == (geo.n_gaussians, 3) and rots.shape == (geo.n_gaussians, 4)
+        assert opac.shape == (geo.n_gaussians, 1) and rgb.shape == (geo.n_gaussians, 3)
+        vx = geo.get_timed_vertex_xyz(t)
+        assert vx.shape == (2, geo.n_verts, 3)
+        Rm = geo.get_timed_vertex_rotation(t, return_matrix=True)
+        eye = torch.eye(3, device=dev)
+        assert (Rm @ Rm.transpose(-1, -2) - eye).abs().max() < 1e-4
+        nrm = geo.get_timed_gs_normals(t)
+        assert (nrm.norm(dim=-1) - 1).abs().max() < 1e-4
+        assert geo.get_timed_face_normals(t).shape == (2, geo.n_faces, 3)
+        # identity deformation (zero heads) reproduces the static geometry
+        for name, p in geo._deformation.named_parameters():
+            if "_deform" in name:
+                p.zero_()
+        m0 = geo.get_timed_gs_all_single_time(t[0])[0]
+        assert (m0 - geo.get_xyz).abs().max() < 1e-5
+    names = set(geo.state_dict())
+    assert {"_points", "_surface_mesh_faces", "_scales", "_quaternions", "all_densities", "_sh_coordinates_dc",
+            "surface_mesh_thickness", "_deformation.deformation_net.grid.grids.0.0"} <= names
+    opt = geo.merge_optimizer(None)
+    geo.update_learning_rate(0)
+    assert {g["name"] for g in opt.param_groups} == {"deformation", "grid"}
