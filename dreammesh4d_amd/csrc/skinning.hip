@@ -420,8 +420,17 @@ __global__ __launch_bounds__(kSkinThreads) void k_face_bwd_face(int F, int G, in
 {
     // blockIdx.y = frame; the upstream gradients are per VIEW: summed here over the views of the frame in view
     // order (the backward is linear in them).  frame_index == nullptr: view == frame.
-    const int f = blockIdx.x * kSkinThreads + threadIdx.x;
-    if (f >= F) return;
+    //
+    // One thread per (face, slot) = per Gaussian (coalesced reads of the per-Gaussian gradients; the Exp / Exp-gradient
+    // of a slot is the heavy part and runs G-wide in parallel); the G slot results of a face meet in LDS and the
+    // slot-0 thread adds them in slot order (fixed: deterministic) and finishes the face.
+    __shared__ float s_log[kSkinThreads][3];        // per thread of a face's first three slots: Log of vertex (tid % G)
+    __shared__ float s_val[kSkinThreads][9];        // per slot: gm (3), gr (3), gn (3)
+    const int tid = threadIdx.x;
+    const int faces_per_wg = kSkinThreads / G;
+    const int fl = tid / G, sl = tid - fl * G;      // face in workgroup, slot
+    const int f = blockIdx.x * faces_per_wg + fl;
+    const bool live = fl < faces_per_wg && f < F;
     const size_t n = (size_t)F * G;
     const int frame = blockIdx.y;
     {
@@ -431,21 +440,36 @@ __global__ __launch_bounds__(kSkinThreads) void k_face_bwd_face(int F, int G, in
         rec += bv * F * 3 * kCornerRec;
     }
     const int b0 = frame_index ? 0 : frame, b1 = frame_index ? n_views : frame + 1;
-    const int i0 = faces[3 * f], i1 = faces[3 * f + 1], i2 = faces[3 * f + 2];
-    const v3 x0 = ld3(vxyz, i0), x1 = ld3(vxyz, i1), x2 = ld3(vxyz, i2);
-    const v3 L0 = so3_log(ldq(vrot, i0)), L1 = so3_log(ldq(vrot, i1)), L2 = so3_log(ldq(vrot, i2));
-    v3 X[3] = {mk3(0, 0, 0), mk3(0, 0, 0), mk3(0, 0, 0)}, R[3] = {mk3(0, 0, 0), mk3(0, 0, 0), mk3(0, 0, 0)};
-    v3 gn = mk3(0, 0, 0);
-    for (int s = 0; s < G; ++s) {
-        const size_t i = (size_t)f * G + s;
-        const float *b = c_bary[bary_row(G)][s];
-        if (g_means) {
-            v3 gm = mk3(0, 0, 0);
+    const int base = fl * G;                        // first thread of this face
+    // phase A: Log of the three vertex rotations, one per thread (G >= 3) or all by slot 0 (G == 1)
+    if (live && g_rots) {
+        if (G >= 3) {
+            if (sl < 3) {
+                const v3 L = so3_log(ldq(vrot, faces[3 * f + sl]));
+                s_log[base + sl][0] = L.x; s_log[base + sl][1] = L.y; s_log[base + sl][2] = L.z;
+            }
+        }      // G == 1: the single slot computes the three logs itself (below)
+    }
+    __syncthreads();
+    // phase B: per slot
+    if (live) {
+        const size_t i = (size_t)f * G + sl;
+        const float *b = c_bary[bary_row(G)][sl];
+        v3 gm = mk3(0, 0, 0), gr = mk3(0, 0, 0), gn = mk3(0, 0, 0);
+        if (g_means)
             for (int bv = b0; bv < b1; ++bv)
                 if (!frame_index || frame_index[bv] == frame) gm = gm + ld3(g_means + (size_t)bv * n * 3, i);
-            X[0] = X[0] + b[0] * gm; X[1] = X[1] + b[1] * gm; X[2] = X[2] + b[2] * gm;
-        }
         if (g_rots) {
+            v3 L0, L1, L2;
+            if (G >= 3) {
+                L0 = mk3(s_log[base][0], s_log[base][1], s_log[base][2]);
+                L1 = mk3(s_log[base + 1][0], s_log[base + 1][1], s_log[base + 1][2]);
+                L2 = mk3(s_log[base + 2][0], s_log[base + 2][1], s_log[base + 2][2]);
+            } else {
+                L0 = so3_log(ldq(vrot, faces[3 * f]));
+                L1 = so3_log(ldq(vrot, faces[3 * f + 1]));
+                L2 = so3_log(ldq(vrot, faces[3 * f + 2]));
+            }
             const v3 r = (b[0] * L0 + b[1] * L1) + b[2] * L2;
             const q4 qd = so3_exp(r);
             const float4 qs4 = reinterpret_cast<const float4 *>(q_static)[i];
@@ -461,8 +485,7 @@ __global__ __launch_bounds__(kSkinThreads) void k_face_bwd_face(int F, int G, in
                 }
             const q4 gQ = qscale(1.f / nq, qadd(go, qscale(-qdot(go, out), out)));
             const q4 gqd = qmul(gQ, qconj(qs));
-            const v3 gr = so3_exp_grad(r, gqd);
-            R[0] = R[0] + b[0] * gr; R[1] = R[1] + b[1] * gr; R[2] = R[2] + b[2] * gr;
+            gr = so3_exp_grad(r, gqd);
         }
         if (g_normals)
             for (int bv = b0; bv < b1; ++bv)
@@ -470,12 +493,29 @@ __global__ __launch_bounds__(kSkinThreads) void k_face_bwd_face(int F, int G, in
                     const float *pn = g_normals + ((size_t)bv * n + i) * nstride;
                     gn = gn + mk3(pn[0], pn[1], pn[2]);
                 }
+        float *o = s_val[tid];
+        o[0] = gm.x; o[1] = gm.y; o[2] = gm.z; o[3] = gr.x; o[4] = gr.y; o[5] = gr.z; o[6] = gn.x; o[7] = gn.y; o[8] = gn.z;
+    }
+    __syncthreads();
+    // phase C: slot 0 adds the slots in order and finishes the face
+    if (!live || sl != 0) return;
+    v3 X[3] = {mk3(0, 0, 0), mk3(0, 0, 0), mk3(0, 0, 0)}, R[3] = {mk3(0, 0, 0), mk3(0, 0, 0), mk3(0, 0, 0)};
+    v3 gn = mk3(0, 0, 0);
+    for (int s2 = 0; s2 < G; ++s2) {
+        const float *b = c_bary[bary_row(G)][s2];
+        const float *o = s_val[base + s2];
+        const v3 gm = mk3(o[0], o[1], o[2]), gr = mk3(o[3], o[4], o[5]);
+        if (g_means) { X[0] = X[0] + b[0] * gm; X[1] = X[1] + b[1] * gm; X[2] = X[2] + b[2] * gm; }
+        if (g_rots) { R[0] = R[0] + b[0] * gr; R[1] = R[1] + b[1] * gr; R[2] = R[2] + b[2] * gr; }
+        gn = gn + mk3(o[6], o[7], o[8]);
     }
     if (g_normals) {
+        const int i0 = faces[3 * f], i1 = faces[3 * f + 1], i2 = faces[3 * f + 2];
+        const v3 x0 = ld3(vxyz, i0), x1 = ld3(vxyz, i1), x2 = ld3(vxyz, i2);
         const v3 e1 = x1 - x0, e2 = x2 - x0, c = cross(e1, e2);
         const float cn = fmaxf(sqrtf(dot(c, c)), 1e-12f);
-        const v3 n = (1.f / cn) * c;
-        const v3 gc = (1.f / cn) * (gn - dot(gn, n) * n);
+        const v3 nn = (1.f / cn) * c;
+        const v3 gc = (1.f / cn) * (gn - dot(gn, nn) * nn);
         const v3 ge1 = cross(e2, gc), ge2 = cross(gc, e1);
         X[1] = X[1] + ge1;
         X[2] = X[2] + ge2;
@@ -581,7 +621,8 @@ int face_backward_launch(int B, int F, int G, int V, const int32_t *faces, const
     if (B <= 0) return DM4D_OK;
     ProfScope prof_(kKFaceBwd, st);
     if (F > 0) {
-        hipLaunchKernelGGL(k_face_bwd_face, dim3((F + kSkinThreads - 1) / kSkinThreads, B), dim3(kSkinThreads), 0, st, F, G,
+        const int fpw = kSkinThreads / G;      // faces per workgroup (one thread per Gaussian)
+        hipLaunchKernelGGL(k_face_bwd_face, dim3((F + fpw - 1) / fpw, B), dim3(kSkinThreads), 0, st, F, G,
                            V, faces, vxyz, vrot, qs, g_means, g_rots, g_normals, nstride, scratch, frame_index, n_views);
         DM4D_HIP_CHECK(hipGetLastError());
     }
