@@ -531,6 +531,9 @@ __global__ __launch_bounds__(kSkinThreads) void k_face_bwd_face(int F, int G, in
 
 // per vertex: fixed-order sum over incident face corners (static CSR), then Log backward
 // ext_*: optional extra upstream gradients on the deformed vertices (mesh regularisers), added here
+// 8 lanes per vertex: lane c sums the corners e = c, c + 8, ... (a pole of a UV sphere has hundreds of incident
+// faces: one thread per vertex made that vertex the critical path of the whole launch), then a fixed-order
+// butterfly over the 8 lanes; lane 0 finishes the vertex.
 __global__ __launch_bounds__(kSkinThreads) void k_face_bwd_vertex(int V, int F, const int32_t *__restrict__ csr_off,
                                                                   const int32_t *__restrict__ csr_item /* 3f+j */,
                                                                   const float *__restrict__ vrot,
@@ -539,8 +542,9 @@ __global__ __launch_bounds__(kSkinThreads) void k_face_bwd_vertex(int V, int F, 
                                                                   const float *__restrict__ ext_rot,
                                                                   float *__restrict__ g_vxyz, float *__restrict__ g_vrot)
 {
-    const int v = blockIdx.x * kSkinThreads + threadIdx.x;
-    if (v >= V) return;
+    const int gid = blockIdx.x * kSkinThreads + threadIdx.x;
+    const int v = gid >> 3, c = gid & 7;
+    const bool live = v < V;
     {
         const size_t bv = blockIdx.y;
         vrot += bv * V * 4;
@@ -550,14 +554,24 @@ __global__ __launch_bounds__(kSkinThreads) void k_face_bwd_vertex(int V, int F, 
         if (ext_xyz) ext_xyz += bv * V * 3;
         if (ext_rot) ext_rot += bv * V * 4;
     }
-    v3 X = ext_xyz ? ld3(ext_xyz, v) : mk3(0, 0, 0), R = mk3(0, 0, 0);
-    for (int e = csr_off[v]; e < csr_off[v + 1]; ++e) {
-        const float *r = rec + (size_t)csr_item[e] * kCornerRec;
-        X = X + mk3(r[0], r[1], r[2]);
-        R = R + mk3(r[3], r[4], r[5]);
+    float a[kCornerRec] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (live)
+        for (int e = csr_off[v] + c; e < csr_off[v + 1]; e += 8) {
+            const float2 *r = reinterpret_cast<const float2 *>(rec + (size_t)csr_item[e] * kCornerRec);
+            const float2 r0 = r[0], r1 = r[1], r2 = r[2];
+            a[0] += r0.x; a[1] += r0.y; a[2] += r1.x; a[3] += r1.y; a[4] += r2.x; a[5] += r2.y;
+        }
+#pragma unroll
+    for (int i = 0; i < kCornerRec; ++i) {
+        a[i] += __shfl_xor(a[i], 1, 64);
+        a[i] += __shfl_xor(a[i], 2, 64);
+        a[i] += __shfl_xor(a[i], 4, 64);
     }
+    if (!live || c != 0) return;
+    v3 X = mk3(a[0], a[1], a[2]);
+    if (ext_xyz) X = X + ld3(ext_xyz, v);
     st3(g_vxyz, v, X);
-    q4 g = so3_log_grad(ldq(vrot, v), R);
+    q4 g = so3_log_grad(ldq(vrot, v), mk3(a[3], a[4], a[5]));
     if (ext_rot) g = qadd(g, ldq(ext_rot, v));
     reinterpret_cast<float4 *>(g_vrot)[v] = make_float4(g.x, g.y, g.z, g.w);
 }
@@ -627,7 +641,7 @@ int face_backward_launch(int B, int F, int G, int V, const int32_t *faces, const
         DM4D_HIP_CHECK(hipGetLastError());
     }
     if (V > 0) {
-        hipLaunchKernelGGL(k_face_bwd_vertex, dim3((V + kSkinThreads - 1) / kSkinThreads, B), dim3(kSkinThreads), 0, st, V,
+        hipLaunchKernelGGL(k_face_bwd_vertex, dim3((8 * V + kSkinThreads - 1) / kSkinThreads, B), dim3(kSkinThreads), 0, st, V,
                            F, csr_off, csr_items, vrot, (const float *)scratch, ext_xyz, ext_rot, o_vxyz, o_vrot);
         DM4D_HIP_CHECK(hipGetLastError());
     }
