@@ -124,6 +124,8 @@ _SIGNATURES = {
     "dm4d_deform_mlp_forward": (C.c_int, [C.c_int32, vp, C.POINTER(MlpWeights), vp, vp, C.POINTER(vp), vp, vp]),
     "dm4d_deform_mlp_backward": (C.c_int, [C.c_int32, vp, C.POINTER(MlpWeights), vp, vp, C.POINTER(vp), vp,
                                            C.POINTER(MlpWeightsGrad), vp, vp]),
+    "dm4d_arap_energy_forward": (C.c_int, [C.c_int32, C.c_int32] + [vp] * 9),
+    "dm4d_arap_energy_backward": (C.c_int, [C.c_int32, C.c_int32] + [vp] * 11),
     "dm4d_grad_pack": (C.c_int, [C.POINTER(GradSegments), vp, vp]),
     "dm4d_grad_unpack": (C.c_int, [C.POINTER(GradSegments), vp, C.c_float, vp]),
     "dm4d_views_geom_bytes": (C.c_size_t, [C.c_int32] * 4),

@@ -1,0 +1,144 @@
+// meshreg.hip -- mesh regularisers of the dynamic stage on the deformed vertices (gfx950).
+//
+// As-rigid-as-possible energy with GIVEN vertex rotations (the skinned rotations), as the reference's
+// ARAPCoach.compute_arap_energy(xyz_prime, vert_rotations) is called every iteration for the key frames and for
+// 10 densely sampled inter-frames (custom/threestudio-dreammesh4d/utils/arap_utils.py:183-224,
+// system/sugar_4dgen.py:304-311,331-385):
+//
+//     E_t = sum_i sum_{j in N(i)} w_ij || (x'_i - x'_j) - R_i (x_i - x_j) ||^2
+//
+// The reference materialises [V, max_valence, 3] edge tensors and runs bmm / norm / sum per timestamp in a Python
+// loop; here one launch covers all T timestamps over a static CSR adjacency (weights and rest edges precomputed
+// once).  The backward gathers: vertex i adds the terms of its own edges and, through the reverse-edge index,
+// of the edges that point at it -- no atomics, deterministic.
+#include "common.h"
+#include "../../include/dm4d.h"
+
+namespace dm4d {
+
+struct ArapAdj {
+    int V;
+    const int32_t *off, *nbr, *rev;   // CSR [V+1], [E], [E] (rev[e] = index of the edge nbr[e] -> i)
+    const float *w, *e;               // [E], [E,3]: weight, rest edge x_i - x_j
+};
+
+__device__ __forceinline__ void edge_residual(const float *__restrict__ xi, const float *__restrict__ xj,
+                                              const float *__restrict__ R, const float *__restrict__ e, float s[3])
+{
+#pragma unroll
+    for (int a = 0; a < 3; ++a) s[a] = (xi[a] - xj[a]) - ((R[3 * a] * e[0] + R[3 * a + 1] * e[1]) + R[3 * a + 2] * e[2]);
+}
+
+// per (timestamp, vertex): energy of its outgoing edges
+__global__ __launch_bounds__(256) void k_arap_fwd(ArapAdj a, const float *__restrict__ xyz, const float *__restrict__ rot,
+                                                  float *__restrict__ energy /* [T][V] */)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= a.V) return;
+    const size_t t = blockIdx.y;
+    xyz += t * a.V * 3;
+    rot += t * a.V * 9;
+    float R[9], xi[3];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) R[k] = rot[9 * (size_t)i + k];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) xi[k] = xyz[3 * (size_t)i + k];
+    float acc = 0.f;
+    for (int eidx = a.off[i]; eidx < a.off[i + 1]; ++eidx) {
+        const int j = a.nbr[eidx];
+        float s[3];
+        edge_residual(xi, xyz + 3 * (size_t)j, R, a.e + 3 * (size_t)eidx, s);
+        acc += a.w[eidx] * ((s[0] * s[0] + s[1] * s[1]) + s[2] * s[2]);
+    }
+    energy[t * a.V + i] = acc;
+}
+
+// per (timestamp, vertex): dE/dx'_i and dE/dR_i, scaled by the upstream gradient of E_t
+__global__ __launch_bounds__(256) void k_arap_bwd(ArapAdj a, const float *__restrict__ xyz, const float *__restrict__ rot,
+                                                  const float *__restrict__ g_energy /* [T] */, float *__restrict__ g_xyz,
+                                                  float *__restrict__ g_rot)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= a.V) return;
+    const size_t t = blockIdx.y;
+    xyz += t * a.V * 3;
+    rot += t * a.V * 9;
+    const float ge = 2.0f * g_energy[t];
+    float R[9], xi[3], gx[3] = {0.f, 0.f, 0.f}, gR[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < 9; ++k) R[k] = rot[9 * (size_t)i + k];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) xi[k] = xyz[3 * (size_t)i + k];
+    for (int eidx = a.off[i]; eidx < a.off[i + 1]; ++eidx) {
+        const int j = a.nbr[eidx], m = a.rev[eidx];
+        const float *xj = xyz + 3 * (size_t)j;
+        const float *e = a.e + 3 * (size_t)eidx;
+        float s[3], sr[3];
+        edge_residual(xi, xj, R, e, s);                                        // own edge i -> j
+        edge_residual(xj, xi, rot + 9 * (size_t)j, a.e + 3 * (size_t)m, sr);   // reverse edge j -> i
+        const float w = a.w[eidx], wr = a.w[m];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            gx[c] += w * s[c] - wr * sr[c];
+#pragma unroll
+            for (int b = 0; b < 3; ++b) gR[3 * c + b] -= w * s[c] * e[b];
+        }
+    }
+    if (g_xyz) {
+        float *o = g_xyz + (t * a.V + i) * 3;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) o[c] = ge * gx[c];
+    }
+    if (g_rot) {
+        float *o = g_rot + (t * a.V + i) * 9;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) o[k] = ge * gR[k];
+    }
+}
+
+static int arap_check(int T, int V, const void *off, const void *nbr, const void *rev, const void *w, const void *e,
+                      const void *xyz, const void *rot)
+{
+    if (T < 0 || V < 0) { set_error("arap: negative T/V"); return DM4D_ERR_INVALID; }
+    if (T > 65535) { set_error("arap: more than 65535 timestamps per call"); return DM4D_ERR_INVALID; }
+    if (T > 0 && V > 0 && (!off || !nbr || !rev || !w || !e || !xyz || !rot)) { set_error("arap: null tensor"); return DM4D_ERR_INVALID; }
+    return DM4D_OK;
+}
+
+}  // namespace dm4d
+
+using namespace dm4d;
+
+extern "C" {
+
+int dm4d_arap_energy_forward(int32_t T, int32_t V, const int32_t *csr_offsets, const int32_t *neighbors,
+                             const int32_t *reverse_edge, const float *weights, const float *rest_edges,
+                             const float *xyz_prime, const float *rotations, float *vertex_energy, dm4d_stream_t stream)
+{
+    int rc = arap_check(T, V, csr_offsets, neighbors, reverse_edge, weights, rest_edges, xyz_prime, rotations);
+    if (rc) return rc;
+    if (T == 0 || V == 0) return DM4D_OK;
+    if (!vertex_energy) { set_error("arap: null output"); return DM4D_ERR_INVALID; }
+    ArapAdj a{V, csr_offsets, neighbors, reverse_edge, weights, rest_edges};
+    hipLaunchKernelGGL(k_arap_fwd, dim3((V + 255) / 256, T), dim3(256), 0, (hipStream_t)stream, a, xyz_prime, rotations, vertex_energy);
+    DM4D_HIP_CHECK(hipGetLastError());
+    return DM4D_OK;
+}
+
+int dm4d_arap_energy_backward(int32_t T, int32_t V, const int32_t *csr_offsets, const int32_t *neighbors,
+                              const int32_t *reverse_edge, const float *weights, const float *rest_edges,
+                              const float *xyz_prime, const float *rotations, const float *g_energy, float *g_xyz,
+                              float *g_rotations, dm4d_stream_t stream)
+{
+    int rc = arap_check(T, V, csr_offsets, neighbors, reverse_edge, weights, rest_edges, xyz_prime, rotations);
+    if (rc) return rc;
+    if (T == 0 || V == 0) return DM4D_OK;
+    if (!g_energy) { set_error("arap: null upstream gradient"); return DM4D_ERR_INVALID; }
+    ArapAdj a{V, csr_offsets, neighbors, reverse_edge, weights, rest_edges};
+    hipLaunchKernelGGL(k_arap_bwd, dim3((V + 255) / 256, T), dim3(256), 0, (hipStream_t)stream, a, xyz_prime, rotations, g_energy,
+                       g_xyz, g_rotations);
+    DM4D_HIP_CHECK(hipGetLastError());
+    return DM4D_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,122 @@
+"""Mesh regularisers of the dynamic stage: host mirror of ``ARAPCoach``
+(custom/threestudio-dreammesh4d/utils/arap_utils.py:17-224) for the way the system uses it --
+``compute_arap_energy(xyz_prime, vert_rotations)`` with the skinned vertex rotations, once per key frame and per
+inter-frame timestamp (system/sugar_4dgen.py:304-311,331-385) -- on one HIP launch for all timestamps
+(csrc/meshreg.hip, C ABI ``dm4d_arap_energy_*``).
+
+The static part (one-ring neighbours, the reference's cotangent weights, rest edges) is computed once on the
+host with the reference's arithmetic, quirk included (dense branch of ``produce_cot_weights_nfmt``: the weight of
+the directed edge (f_a, f_b) of a face is assigned 0.5 * cot(angle at f_a) / 4, then W + W^T).  The SVD branch
+(rotations fitted from the deformation) is not on the dynamic stage's path and is not mirrored.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+
+
+def _one_ring(faces, n_verts):
+    nb = [set() for _ in range(n_verts)]
+    for f in np.asarray(faces):
+        for j in range(3):
+            nb[int(f[j])].add(int(f[(j + 1) % 3]))
+            nb[int(f[j])].add(int(f[(j + 2) % 3]))
+    return [sorted(s) for s in nb]
+
+
+def _cot_weight_matrix(verts, faces):
+    faces_t = torch.as_tensor(np.asarray(faces), dtype=torch.long)
+    fv = verts[faces_t]
+    v0, v1, v2 = fv[:, 0], fv[:, 1], fv[:, 2]
+    A, B, Cc = (v1 - v2).norm(dim=1), (v0 - v2).norm(dim=1), (v0 - v1).norm(dim=1)
+    s = 0.5 * (A + B + Cc)
+    area = (s * (s - A) * (s - B) * (s - Cc)).clamp_(min=1e-12).sqrt()      # Heron (arap_utils.py:118-121)
+    A2, B2, C2 = A * A, B * B, Cc * Cc
+    cot = torch.stack([(B2 + C2 - A2) / area, (A2 + C2 - B2) / area, (A2 + B2 - C2) / area], dim=1) / 4.0
+    i, j = faces_t[:, [0, 1, 2]].flatten(), faces_t[:, [1, 2, 0]].flatten()
+    return i, j, 0.5 * cot.flatten()
+
+
+class _ArapEnergy(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, coach, xyz, rot):
+        L = _lib.lib()
+        dev = coach.device
+        x = xyz.detach().to(torch.float32).contiguous()
+        r = rot.detach().to(torch.float32).contiguous()
+        T, V = int(x.shape[0]), coach.n_verts
+        ev = torch.empty(T, V, dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            _lib.check(L.dm4d_arap_energy_forward(T, V, coach._off.data_ptr(), coach._nbr.data_ptr(), coach._rev.data_ptr(),
+                                                  coach._w.data_ptr(), coach._e.data_ptr(), x.data_ptr(), r.data_ptr(),
+                                                  ev.data_ptr(), torch.cuda.current_stream(dev).cuda_stream),
+                       "dm4d_arap_energy_forward")
+        ctx.coach = coach
+        ctx.save_for_backward(x, r)
+        return ev.sum(dim=1)
+
+    @staticmethod
+    def backward(ctx, g_energy):
+        L = _lib.lib()
+        coach = ctx.coach
+        x, r = ctx.saved_tensors
+        dev = coach.device
+        T, V = int(x.shape[0]), coach.n_verts
+        g = g_energy.detach().to(torch.float32).contiguous()
+        gx = torch.empty_like(x) if ctx.needs_input_grad[1] else None
+        gr = torch.empty_like(r) if ctx.needs_input_grad[2] else None
+        with torch.cuda.device(dev):
+            _lib.check(L.dm4d_arap_energy_backward(T, V, coach._off.data_ptr(), coach._nbr.data_ptr(), coach._rev.data_ptr(),
+                                                   coach._w.data_ptr(), coach._e.data_ptr(), x.data_ptr(), r.data_ptr(),
+                                                   g.data_ptr(), None if gx is None else gx.data_ptr(),
+                                                   None if gr is None else gr.data_ptr(),
+                                                   torch.cuda.current_stream(dev).cuda_stream), "dm4d_arap_energy_backward")
+        return None, gx, gr
+
+
+class ARAPCoach:
+    """``ARAPCoach(verts, faces, device)`` of the reference, mesh (faces given) variant."""
+
+    def __init__(self, verts, faces, device):
+        self.device = torch.device(device)
+        verts_c = torch.as_tensor(verts, dtype=torch.float32).detach().cpu()
+        faces_n = np.asarray(torch.as_tensor(faces).cpu() if torch.is_tensor(faces) else faces)
+        self.verts = verts_c.to(self.device)
+        self.faces = faces_n
+        self.n_verts, self.n_faces = int(verts_c.shape[0]), int(len(faces_n))
+        nb = _one_ring(faces_n, self.n_verts)
+        self.one_ring_neighbors = {i: n for i, n in enumerate(nb)}
+        self.max_n_neighbors = max((len(n) for n in nb), default=0)
+        off = np.zeros(self.n_verts + 1, np.int64)
+        off[1:] = np.cumsum([len(n) for n in nb])
+        nbr = np.concatenate([np.asarray(n, np.int64) for n in nb]) if len(nb) else np.zeros(0, np.int64)
+        src = np.repeat(np.arange(self.n_verts), np.diff(off))
+        # weights: directed assignment (later faces win), then symmetrised -- as W[i, j] = ...; W = W + W.T
+        i, j, wd = _cot_weight_matrix(verts_c, faces_n)
+        directed = {}
+        for a, b, v in zip(i.tolist(), j.tolist(), wd.tolist()):
+            directed[(a, b)] = v
+        w = np.asarray([np.float32(np.float32(directed.get((a, b), 0.0)) + np.float32(directed.get((b, a), 0.0)))
+                        for a, b in zip(src.tolist(), nbr.tolist())], np.float32)
+        pos = {(a, b): k for k, (a, b) in enumerate(zip(src.tolist(), nbr.tolist()))}
+        rev = np.asarray([pos[(b, a)] for a, b in zip(src.tolist(), nbr.tolist())], np.int64)
+        e = (verts_c[src] - verts_c[nbr]).numpy()
+        T = lambda a, dt: torch.as_tensor(a, dtype=dt, device=self.device).contiguous()
+        self._off, self._nbr, self._rev = T(off, torch.int32), T(nbr, torch.int32), T(rev, torch.int32)
+        self._w, self._e = T(w, torch.float32), T(e, torch.float32)
+        self.edge_weights, self.edge_sources, self.edge_targets = w, src, nbr
+
+    def compute_arap_energy(self, xyz_prime, vert_rotations):
+        """xyz_prime [V,3] + vert_rotations [V,3,3] -> scalar (the reference's call), or batched
+        [T,V,3] + [T,V,3,3] -> [T] (all timestamps of an iteration in one launch)."""
+        if vert_rotations is None:
+            raise NotImplementedError("the SVD branch (rotations fitted to the deformation) is not on the dynamic stage's path")
+        if not xyz_prime.is_cuda:
+            raise _lib.Dm4dError("ARAP energy runs on the HIP device (no CPU fallback in the product)")
+        single = xyz_prime.dim() == 2
+        x = xyz_prime[None] if single else xyz_prime
+        r = vert_rotations[None] if single else vert_rotations
+        E = _ArapEnergy.apply(self, x, r.reshape(x.shape[0], self.n_verts, 3, 3))
+        return E[0] if single else E

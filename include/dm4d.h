@@ -288,6 +288,23 @@ int dm4d_deform_mlp_backward(int32_t P, const float *feat, const dm4d_mlp_weight
                              const float *y_save, const float *const *g_out /* [host] */, float *g_feat,
                              const dm4d_mlp_weights_grad *gw, void *scratch, dm4d_stream_t stream);
 
+/* ------------------------------------------------------------------ mesh regularisers */
+
+/* As-rigid-as-possible energy with GIVEN vertex rotations, for T timestamps in one launch:
+ *   E_t = sum_i sum_{j in N(i)} w_ij || (x'_i - x'_j) - R_i (x_i - x_j) ||^2
+ * = ARAPCoach.compute_arap_energy(xyz_prime, vert_rotations) of C/utils/arap_utils.py:183-224 as called per
+ * timestamp by C/system/sugar_4dgen.py:374-385.  Static adjacency (device): CSR csr_offsets [V+1], neighbors [E],
+ * reverse_edge [E] (index of the edge j -> i), weights [E], rest_edges [E,3] = x_i - x_j.  xyz_prime [T,V,3],
+ * rotations [T,V,3,3] row-major.  forward writes vertex_energy [T,V] (E_t = its row sum); backward writes
+ * g_xyz [T,V,3] and g_rotations [T,V,3,3] (either may be NULL) for the upstream g_energy [T].  Atomic-free. */
+int dm4d_arap_energy_forward(int32_t T, int32_t V, const int32_t *csr_offsets, const int32_t *neighbors,
+                             const int32_t *reverse_edge, const float *weights, const float *rest_edges,
+                             const float *xyz_prime, const float *rotations, float *vertex_energy, dm4d_stream_t stream);
+int dm4d_arap_energy_backward(int32_t T, int32_t V, const int32_t *csr_offsets, const int32_t *neighbors,
+                              const int32_t *reverse_edge, const float *weights, const float *rest_edges,
+                              const float *xyz_prime, const float *rotations, const float *g_energy, float *g_xyz,
+                              float *g_rotations, dm4d_stream_t stream);
+
 /* ------------------------------------------------------------------ data-parallel gradient message */
 
 /* The one exchange step of the path is an all-reduce of the parameter gradients.  The

@@ -13,6 +13,9 @@ state, and the outputs / gradients the reference computes for them).
   strain_matrix.npz       strain_tensor_to_matrix (dynamic_sugar.py:29-39), extracted by AST (the
                           enclosing module needs pypose/pytorch3d) and executed.
   schedule_C.npz          C() (threestudio/utils/misc.py:66-101), extracted by AST.
+  arap_small.npz          ARAPCoach (custom/threestudio-dreammesh4d/utils/arap_utils.py:17-224), imported with stubs for
+                          threestudio.utils.typing / open3d: energy with GIVEN vertex rotations (the dynamic stage's
+                          use, system/sugar_4dgen.py:374-385) of a deformed 120-face sphere + autograd gradients.
   zero123_small.npz       extern/ldm_zero123 UNetModel (openaimodel.py:429-842) and AutoencoderKL Encoder
                           (modules/diffusionmodules/model.py) at reduced width, imported with no-op stubs for the
                           unused heavy imports; weights come from a name-seeded recipe (seeded_fill) the test
@@ -157,10 +160,56 @@ def zero123_small():
     print("zero123_small.npz written; reduced UNet params:", sum(p.numel() for p in unet.parameters()), "| y std", float(y.std()))
 
 
+def arap():
+    import types
+    import typing
+
+    ty = types.ModuleType("threestudio.utils.typing")
+    for n in dir(typing):
+        if not n.startswith("_"):
+            setattr(ty, n, getattr(typing, n))
+
+    class _SubMeta(type):
+        def __getitem__(cls, k):
+            return cls
+
+    class _Sub(metaclass=_SubMeta):
+        pass
+
+    ty.Float = ty.Int = ty.Num = ty.Bool = _Sub
+    ty.Tensor = torch.Tensor
+    sys.modules.update({"threestudio": types.ModuleType("threestudio"), "threestudio.utils": types.ModuleType("threestudio.utils"),
+                        "threestudio.utils.typing": ty, "open3d": types.ModuleType("open3d")})
+    spec = importlib.util.spec_from_file_location("ref_arap", os.path.join(C_DIR, "utils", "arap_utils.py"))
+    ref = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ref)
+    sys.path.insert(0, os.path.dirname(os.path.dirname(OUT)))
+    from dreammesh4d_amd import synthetic as syn
+
+    verts_np, faces_np = syn.uv_sphere(120, radius=0.6)
+    verts = torch.tensor(verts_np, dtype=torch.float32)
+    coach = ref.ARAPCoach(verts, np.asarray(faces_np), torch.device("cpu"))
+    g = torch.Generator().manual_seed(21)
+    xyz = (verts + 0.05 * torch.randn(verts.shape, generator=g)).requires_grad_(True)
+    q = torch.nn.functional.normalize(torch.cat([0.15 * torch.randn(len(verts), 3, generator=g), torch.ones(len(verts), 1)], -1), dim=-1)
+    x, y, z, w = q.unbind(-1)
+    R = torch.stack([1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w),
+                     2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w),
+                     2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)], -1).reshape(-1, 3, 3).requires_grad_(True)
+    E = coach.compute_arap_energy(xyz_prime=xyz, vert_rotations=R)
+    E.backward()
+    np.savez_compressed(os.path.join(OUT, "arap_small.npz"), verts=verts_np.astype(np.float32), faces=np.asarray(faces_np, np.int64),
+                        xyz_prime=xyz.detach().numpy(), rotations=R.detach().numpy(), energy=np.float64(E.item()),
+                        g_xyz=xyz.grad.numpy(), g_rot=R.grad.numpy(),
+                        energy_rigid=np.float64(coach.compute_arap_energy(verts + 0.3, torch.eye(3)[None].repeat(len(verts), 1, 1)).item()))
+    print("arap_small.npz: V", len(verts), "F", len(faces_np), "E", float(E))
+
+
 if __name__ == "__main__":
     if not os.path.isdir(REF):
         sys.exit("needs /root/reference (authoring container only)")
     deformation()
+    arap()
     strain()
     schedule()
     zero123_small()
