@@ -104,6 +104,7 @@ __global__ __launch_bounds__(256) void k_mlp_fwd(MlpDesc d, const float *__restr
         const float b = d.b0[o];
 #pragma unroll
         for (int j = 0; j < 8; ++j) acc[j] = b;
+#pragma unroll 8
         for (int i = 0; i < IN; ++i) {
             const float w = d.W0T[i * kW + o];
             const float4 f0 = *reinterpret_cast<const float4 *>(&s_a[i * kLd + rg * 8]);
@@ -129,6 +130,7 @@ __global__ __launch_bounds__(256) void k_mlp_fwd(MlpDesc d, const float *__restr
 #pragma unroll
         for (int j = 0; j < 8; ++j) acc[j] = x[j] + b;
         const float *__restrict__ W1T = d.W1T[k];
+#pragma unroll 8
         for (int i = 0; i < kW; ++i) {
             const float w = W1T[i * kW + o];
             const float4 f0 = *reinterpret_cast<const float4 *>(&s_x[i * kLd + rg * 8]);
@@ -222,6 +224,7 @@ __global__ __launch_bounds__(256) void k_mlp_bwd(MlpDesc d, const float *__restr
         // ---- dx += W1^T dy ----
         {
             const float *__restrict__ W1 = d.W1[k];
+#pragma unroll 8
             for (int jn = 0; jn < kW; ++jn) {
                 const float w = W1[jn * kW + o];
                 const float4 f0 = *reinterpret_cast<const float4 *>(&s_dy[jn * kLd + rg * 8]);
@@ -237,6 +240,7 @@ __global__ __launch_bounds__(256) void k_mlp_bwd(MlpDesc d, const float *__restr
             float a[16];
 #pragma unroll
             for (int q = 0; q < 16; ++q) a[q] = 0.f;
+#pragma unroll 4
             for (int r = 0; r < kRT; ++r) {
                 const float xv = s_xr[r * ldx + o];
 #pragma unroll
@@ -283,6 +287,7 @@ __global__ __launch_bounds__(256) void k_mlp_bwd(MlpDesc d, const float *__restr
                 float a[16];
 #pragma unroll
                 for (int q = 0; q < 16; ++q) a[q] = 0.f;
+#pragma unroll 4
                 for (int r = 0; r < kRT; ++r) {
                     const float fv = s_a[r * lda + i];
 #pragma unroll
@@ -308,6 +313,7 @@ __global__ __launch_bounds__(256) void k_mlp_bwd(MlpDesc d, const float *__restr
                 float a[8];
 #pragma unroll
                 for (int q = 0; q < 8; ++q) a[q] = 0.f;
+#pragma unroll 8
                 for (int oo = 0; oo < kW; ++oo) {
                     const float w = d.W0[(size_t)oo * IN + i];
                     const float4 f0 = *reinterpret_cast<const float4 *>(&s_dh[oo * kLd + rg2 * rows + r0]);
