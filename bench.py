@@ -123,12 +123,18 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (no CPU fallback in the product path)")
-    dev = torch.device(f"cuda:{local}")
+    # DM4D_BENCH_BACKEND=gloo: functional rehearsal of the N > 1 control flow on a box with fewer GPUs than ranks
+    # (ranks share devices, the exchange goes through gloo); never a performance number
+    backend = os.environ.get("DM4D_BENCH_BACKEND", "nccl")
+    dev = torch.device(f"cuda:{local % torch.cuda.device_count() if backend != 'nccl' else local}")
     torch.cuda.set_device(dev)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
     from dreammesh4d_amd import _lib
     L = _lib.lib()
 
@@ -147,6 +153,7 @@ def main():
         torch.cuda.synchronize(dev)
         if world > 1:
             dist.barrier()
+            torch.cuda.synchronize(dev)
 
     for _ in range(args.warmup):
         step()
@@ -168,7 +175,7 @@ def main():
     L.dm4d_profile_enable(0)
     wl.renderer.check()
     if world > 1:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        t = torch.tensor([elapsed], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -203,7 +210,7 @@ def main():
             "metric": "rendered views/sec (fwd+bwd, 512^2, 200k Gaussians)",
             "value": round(value, 3), "unit": "views/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic" if backend == "nccl" else f"synthetic (REHEARSAL over {backend}: not a performance number)",
             "config": {"workload": f"sugar_dynamic_dg (configs[3] per-GPU share): mesh-bound {N} Gaussians "
                                    f"({wl.topo.F} faces x 6), {N_NODES} graph nodes K={K_NBR} hybrid LBS/DQS skinning, "
                                    f"512x512; per view: skinning + face->Gaussian + RGB pass + normal pass, fwd+bwd",

@@ -72,7 +72,12 @@ class GradAllReducer:
         if w == 1:
             return
         self.pack()
-        dist.all_reduce(self.flat)      # one message; RCCL picks ring / direct on the xGMI mesh
+        if self.flat.is_cuda and dist.get_backend() == "gloo":
+            host = self.flat.cpu()      # functional rehearsals over gloo: stage through the host
+            dist.all_reduce(host)
+            self.flat.copy_(host)
+        else:
+            dist.all_reduce(self.flat)  # one message; RCCL picks ring / direct on the xGMI mesh
         self.unpack(1.0 / w)
 
     # On a HIP device packing and unpacking are ONE launch each (csrc/gradpack.hip, C ABI dm4d_grad_pack / _unpack)
