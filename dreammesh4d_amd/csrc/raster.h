@@ -36,7 +36,9 @@ constexpr int kCells = 16;       // 4x4-pixel cells per 16x16 tile; cell id = 4 
 // floats per (Gaussian, cell) record of the backward scratch: 2 mean + 3 conic + opacity + depth + C colours,
 // padded to whole float4s (C = 6: one aligned 64-byte line per record -- measured: 52-byte records cost MORE
 // HBM write traffic than 64-byte ones, partial-line writes)
-DM4D_HD static inline int grad_stride(int C) { return C <= 3 ? 12 : 16; }
+// floats per backward record.  lean (6-channel batched path with the static appearance frozen): 9 values
+// (mean2D 2 | conic 3 | depth | colour channels 3..5) instead of 13 (+ opacity, colour channels 0..2)
+DM4D_HD static inline int grad_stride(int C, bool lean = false) { return (C <= 3 || lean) ? 12 : 16; }
 
 // counters[]: duplicates, duplicate-capacity overflow, records (sum of the Gaussians' cells), record-capacity overflow
 enum GeomCounter { kCntD = 0, kCntOverflow = 1, kCntR = 2, kCntRecOverflow = 3 };
@@ -292,6 +294,7 @@ struct BatchDesc {
     float *out_color, *out_depth, *out_alpha;
     const float *dL_dcolor, *dL_ddepth, *dL_dalpha;
     float *dLq; size_t dlq_stride; uint32_t rec_cap;   // backward records: capacity (records) per view
+    int lean;              // backward: lean records (see grad_stride); requires C == 6
     BwdOutputs o;          // per-view stride of each = N * width
 };
 

@@ -396,7 +396,8 @@ __global__ __launch_bounds__(kPreThreads) void k_gather_bwd(BatchDesc d)
         // forward consumed, zeros for the rest.  So the 64 Gaussians of a wave own ONE contiguous range of
         // records: the wave streams it through LDS with fully coalesced 1 KB loads and every lane adds up its
         // own records from there, in record order.
-        const int RS = grad_stride(C), parts = RS / 4;
+        const bool lean = d.lean != 0;
+        const int RS = grad_stride(C, lean), parts = RS / 4;
         uint32_t rec0 = 0xFFFFFFFFu, end = 0u;
         if (r > 0) {
             const uint32_t cnt = g.rec_touched[i];
@@ -426,6 +427,10 @@ __global__ __launch_bounds__(kPreThreads) void k_gather_bwd(BatchDesc d)
                 const float4 *rp = reinterpret_cast<const float4 *>(chunk + (slot - base) * kGStride);
                 const float4 a0 = rp[0], a1 = rp[1], a2 = rp[2];
                 acc[0] += a0.x; acc[1] += a0.y; acc[2] += a0.z; acc[3] += a0.w;
+                if (lean) {   // mean2D 2 | conic 3 | depth | colour channels 3..5
+                    acc[4] += a1.x; acc[6] += a1.y; acc[10] += a1.z; acc[11] += a1.w; acc[12] += a2.x;
+                    continue;
+                }
                 acc[4] += a1.x; acc[5] += a1.y; acc[6] += a1.z; acc[7] += a1.w;
                 acc[8] += a2.x; acc[9] += a2.y;
                 if (C > 3) {

@@ -330,11 +330,11 @@ __global__ __launch_bounds__(64) void k_render_fwd(BatchDesc d)
 // ---------------------------------------------------------------------------------------- B1
 constexpr int kRedStride = 68;   // floats per value row of the transposed reduction buffer (64 lanes + pad)
 
-template <int C>
+template <int C, bool LEAN>
 __global__ __launch_bounds__(64) void k_render_bwd(BatchDesc d)
 {
-    constexpr int RS = 7 + C;                 // values per record
-    constexpr int RSP = (C <= 3) ? 12 : 16;   // == grad_stride(C): floats per (padded) record
+    constexpr int RS = LEAN ? 9 : 7 + C;              // values per record
+    constexpr int RSP = (C <= 3 || LEAN) ? 12 : 16;   // == grad_stride(C, LEAN): floats per (padded) record
     constexpr int U = 2 * kBwdPairs;          // entries per inner-loop step
     __shared__ __attribute__((aligned(16))) float s_p[4 * kRowFloats];
     __shared__ uint32_t s_slot[4][kChunk];
@@ -473,9 +473,14 @@ __global__ __launch_bounds__(64) void k_render_bwd(BatchDesc d)
                 const f2v c01 = ww * g01, c23 = ww * g23, c45 = ww * g45;
                 float v[13];
                 v[0] = v01.x; v[1] = v01.y; v[2] = v24.x; v[3] = v3; v[4] = v24.y;
-                v[5] = G * dL_da;
-                v[6] = w * gD;
-                v[7] = c01.x; v[8] = c01.y; v[9] = c23.x; v[10] = c23.y; v[11] = c45.x; v[12] = c45.y;
+                if (LEAN) {   // static appearance frozen: no dL/dopacity, no dL/dcolour for channels 0..2
+                    v[5] = w * gD;
+                    v[6] = c23.y; v[7] = c45.x; v[8] = c45.y;
+                } else {
+                    v[5] = G * dL_da;
+                    v[6] = w * gD;
+                    v[7] = c01.x; v[8] = c01.y; v[9] = c23.x; v[10] = c23.y; v[11] = c45.x; v[12] = c45.y;
+                }
                 // transposed reduction: [value][lane] in LDS, lane i of the row sums value i over the row
 #pragma unroll
                 for (int i = 0; i < RS; ++i) s_red[e][i][lane] = v[i];
@@ -524,8 +529,10 @@ int launch_render_bwd(const BatchDesc &d, hipStream_t st)
     if (T <= 0) return DM4D_OK;
     const int blocks = (int)((((int64_t)T * d.B + 7) / 8) * 8 * 4);
     ProfScope prof_(kKRenderBwd, st);
-    if (d.C <= 3) hipLaunchKernelGGL(k_render_bwd<3>, dim3(blocks), dim3(64), 0, st, d);
-    else hipLaunchKernelGGL(k_render_bwd<6>, dim3(blocks), dim3(64), 0, st, d);
+    if (d.lean && d.C != 6) { set_error("lean backward records need 6 channels"); return DM4D_ERR_INVALID; }
+    if (d.C <= 3) hipLaunchKernelGGL((k_render_bwd<3, false>), dim3(blocks), dim3(64), 0, st, d);
+    else if (d.lean) hipLaunchKernelGGL((k_render_bwd<6, true>), dim3(blocks), dim3(64), 0, st, d);
+    else hipLaunchKernelGGL((k_render_bwd<6, false>), dim3(blocks), dim3(64), 0, st, d);
     DM4D_HIP_CHECK(hipGetLastError());
     return DM4D_OK;
 }

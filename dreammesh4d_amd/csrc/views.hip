@@ -134,6 +134,9 @@ int dm4d_views_backward(const dm4d_views *v, const dm4d_views_grads *gr, dm4d_st
     d.dLq = (float *)gr->grad_scratch; d.dlq_stride = grad_bytes(v->record_capacity, 6) / 4;
     d.o = BwdOutputs{gr->dL_dmeans2D, gr->dL_dmeans3D, gr->dL_dopacity, gr->dL_dcolors, nullptr, gr->dL_dscales,
                      gr->dL_drotations, nullptr};
+    // static appearance frozen (the dynamic stage, static_learnable = False, C/geometry/dynamic_sugar.py:79-87): the
+    // blend backward neither reduces nor records dL/dopacity and dL/d(rgb), 9 values per record instead of 13
+    d.lean = gr->dL_dopacity ? 0 : 1;
     if ((rc = launch_render_bwd(d, st))) return rc;
     if ((rc = launch_gather_bwd(d, st))) return rc;
     const int NF = v->frame_index ? v->n_frames : v->B;

@@ -371,7 +371,12 @@ typedef struct dm4d_views_grads {
     void *grad_scratch, *skin_scratch, *face_scratch;   /* dm4d_views_{grad,skin_scratch,face_scratch}_bytes */
     /* outputs (per view; the caller reduces the static ones over B) */
     float *dL_dmeans2D, *dL_dmeans3D, *dL_drotations;   /* [B,N,3] [B,N,3] [B,N,4] */
-    float *dL_dcolors, *dL_dopacity, *dL_dscales;       /* [B,N,6] [B,N] [B,N,3]; opacity/scales may be NULL */
+    float *dL_dcolors, *dL_dopacity, *dL_dscales;       /* [B,N,6] [B,N] [B,N,3]; opacity/scales may be NULL.
+                                                         * dL_dopacity == NULL declares the static appearance
+                                                         * (opacities, rgb) frozen, as in the reference's dynamic
+                                                         * stage (C/geometry/dynamic_sugar.py:79-87): channels 0..2 of
+                                                         * dL_dcolors are then written as zeros and the blend backward
+                                                         * skips both reductions */
     float *dL_dvxyz, *dL_dvrot;                         /* [B,V,3] [B,V,4] */
     float *dL_ddx, *dL_ddr, *dL_dds, *dL_ddo;           /* [B,M,3] [B,M,4] [B,M,6] [B,M] */
 } dm4d_views_grads;

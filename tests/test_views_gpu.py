@@ -116,6 +116,41 @@ def test_views_sharing_a_frame_equal_per_view_inputs():
         assert (a - c).abs().max() <= 2e-5 * c.abs().max(), k
 
 
+def test_frozen_static_appearance_uses_lean_records_with_identical_gradients():
+    """With scales / opacities / rgb frozen (the reference's dynamic stage) the blend backward keeps 9 of the 13 values
+    per record; every gradient that is still produced must be bit-identical to the full backward's."""
+    _need_gpu()
+    from dreammesh4d_amd import views
+
+    dev = torch.device("cuda:0")
+    B, H, W, M = 3, 144, 176, 100
+    sc, graph, topo, qs, scales, opac, rgb, raw, cams, vm, pm = _scene(2400, M, 4, B, H, W, dev, seed=2)
+    gen = torch.Generator().manual_seed(1)
+    gC = torch.randn(B, 6, H, W, generator=gen).to(dev)
+    gD = (0.1 * torch.randn(B, 1, H, W, generator=gen)).to(dev)
+    gA = torch.randn(B, 1, H, W, generator=gen).to(dev)
+    res = {}
+    for mode in ("frozen", "learnable"):
+        r = views.ViewRenderer(graph, topo, H, W, cams[0].tanfov, method="hybrid")
+        leaves = {k: v.clone().requires_grad_(True) for k, v in raw.items()}
+        st = [t.clone().requires_grad_(mode == "learnable") for t in (scales, opac, rgb)]
+        m2 = torch.zeros(B, r.N, 3, device=dev, requires_grad=True)
+        out = views.render_views(r, leaves["trans"], leaves["d_rot"], leaves["strain"], leaves["d_opacity"].squeeze(-1), qs,
+                                 st[0], st[1], st[2], vm, pm, torch.ones(6, device=dev), means2D=m2)
+        r.check()
+        torch.autograd.backward([out["color"], out["depth"], out["alpha"]], [gC, gD, gA])
+        res[mode] = {k: v.grad.clone() for k, v in leaves.items()}
+        res[mode]["m2"] = m2.grad.clone()
+        res[mode]["normal_grad"] = r.last_grads["col"][:, :, 3:].clone()
+        res[mode]["rgb_grad"] = r.last_grads["col"][:, :, :3].clone()
+        res[mode]["static"] = [t.grad for t in st]
+    assert all(g is None for g in res["frozen"]["static"]) and all(g is not None for g in res["learnable"]["static"])
+    assert float(res["learnable"]["rgb_grad"].abs().max()) > 0 and float(res["frozen"]["rgb_grad"].abs().max()) == 0
+    for k in ("trans", "d_rot", "strain", "d_opacity", "m2", "normal_grad"):
+        assert float(res["frozen"][k].abs().max()) > 0, k
+        assert torch.equal(res["frozen"][k], res["learnable"][k]), k
+
+
 def test_steps_do_not_leak_device_memory():
     """Outputs kept as plain ctx attributes once formed an uncollectable output -> grad_fn -> ctx cycle that
     leaked every step's graph; device memory must be flat from the second step on."""
