@@ -30,6 +30,7 @@ static const int c_axis0_host[6] = {0, 0, 0, 1, 1, 2}, c_axis1_host[6] = {1, 2, 
 
 struct HexDesc {
     int S, M, B;
+    int cl;                                       // plane storage: 0 = [32][H][W], 1 = [H][W][32] (channels-last)
     int res[kHexMaxScales][4];                    // resolution of axes x, y, z, t at scale s
     const float *plane[kHexMaxScales][kHexPlanes]; // [32][res[a1]][res[a0]]
     float lo[3], inv[3];                          // x_n = (p - lo) * inv - 1
@@ -67,9 +68,17 @@ __device__ __forceinline__ Sample plane_sample(const HexDesc &d, int s, int p, c
     q.w00 = (1.f - wx) * (1.f - wy); q.w01 = wx * (1.f - wy); q.w10 = (1.f - wx) * wy; q.w11 = wx * wy;
     return q;
 }
-__device__ __forceinline__ float sample_value(const float *__restrict__ pl, size_t cs, const Sample &q)
+// element (channel c, texel) of a plane with HW texels
+__device__ __forceinline__ size_t plane_elem(const HexDesc &d, int c, size_t HW, size_t texel)
 {
-    return ((pl[cs + q.i00] * q.w00 + pl[cs + q.i01] * q.w01) + pl[cs + q.i10] * q.w10) + pl[cs + q.i11] * q.w11;
+    return d.cl ? texel * kHexCh + c : (size_t)c * HW + texel;
+}
+// base = offset of the channel, ts = stride between texels (channels-last: the 32 channels of a texel are one
+// 128-byte line, so the 32 lanes of a query read 4 lines per plane instead of 128 scattered words)
+__device__ __forceinline__ float sample_value(const float *__restrict__ pl, size_t base, size_t ts, const Sample &q)
+{
+    return ((pl[base + q.i00 * ts] * q.w00 + pl[base + q.i01 * ts] * q.w01) + pl[base + q.i10 * ts] * q.w10) +
+           pl[base + q.i11 * ts] * q.w11;
 }
 __device__ __forceinline__ void node_coords(const HexDesc &d, const float *__restrict__ nodes,
                                             const float *__restrict__ times, int f, int m, float xn[4])
@@ -99,8 +108,8 @@ __global__ __launch_bounds__(256) void k_hex_fwd(HexDesc d, const float *__restr
 #pragma unroll
     for (int p = 0; p < kHexPlanes; ++p) {
         const Sample q = plane_sample(d, s, p, xn);
-        const size_t cs = (size_t)c * d.res[s][c_axis0[p]] * d.res[s][c_axis1[p]];
-        const float v = sample_value(d.plane[s][p], cs, q);
+        const size_t HW = (size_t)d.res[s][c_axis0[p]] * d.res[s][c_axis1[p]];
+        const float v = sample_value(d.plane[s][p], d.cl ? (size_t)c : (size_t)c * HW, d.cl ? (size_t)kHexCh : (size_t)1, q);
         if (sv) sv[(size_t)p * kHexCh] = v;      // kept for the backward (the channel-major planes make every
         acc = acc * v;                           // sample 4 scattered 4-byte reads: not worth repeating)
     }
@@ -165,7 +174,7 @@ __global__ __launch_bounds__(256) void k_hex_bwd_spatial(HexDesc d, const float 
         acc += w * gs;
     }
     const size_t HW = (size_t)d.res[s][c_axis0[p]] * d.res[s][c_axis1[p]];
-    hg.g[s * kHexPlanes + p][(size_t)c * HW + sp_texel[u]] = acc;
+    hg.g[s * kHexPlanes + p][plane_elem(d, c, HW, (size_t)sp_texel[u])] = acc;
 }
 
 // Time planes: one workgroup per (touched column, time-row slot).  The distinct time rows of the step
@@ -251,7 +260,7 @@ __global__ __launch_bounds__(256) void k_hex_bwd_time(HexDesc d, const float *__
 #pragma unroll
         for (int k = 0; k < 8; ++k) t += s_part[k][c];
         const size_t HW = (size_t)W * H;
-        hg.g[s * kHexPlanes + p][(size_t)c * HW + (size_t)s_rows[s][r] * W + tp_col[u]] = t;
+        hg.g[s * kHexPlanes + p][plane_elem(d, c, HW, (size_t)s_rows[s][r] * W + tp_col[u])] = t;
     }
 }
 
@@ -280,7 +289,8 @@ __global__ void k_hex_axis_index(HexDesc d, const float *__restrict__ nodes, int
     i0[gid] = x0;
 }
 
-static int fill_desc(HexDesc &d, int S, int M, int B, const int32_t *res, const float *const *planes, const float *aabb)
+static int fill_desc(HexDesc &d, int S, int M, int B, const int32_t *res, const float *const *planes, const float *aabb,
+                     int channel_last = 0)
 {
     if (S <= 0 || S > kHexMaxScales || M <= 0 || B <= 0 || B > kHexMaxFrames) {
         set_error("hexplane: bad S/M/B (%d/%d/%d; S <= %d, B <= %d)", S, M, B, kHexMaxScales, kHexMaxFrames);
@@ -289,6 +299,7 @@ static int fill_desc(HexDesc &d, int S, int M, int B, const int32_t *res, const 
     if (!res || !aabb) { set_error("hexplane: null res/aabb"); return DM4D_ERR_INVALID; }
     memset(&d, 0, sizeof(d));
     d.S = S; d.M = M; d.B = B;
+    d.cl = channel_last ? 1 : 0;
     for (int s = 0; s < S; ++s) {
         for (int a = 0; a < 4; ++a) {
             d.res[s][a] = res[s * 4 + a];
@@ -322,11 +333,11 @@ int dm4d_hexplane_axis_index(int32_t S, int32_t M, const int32_t *res, const flo
 }
 
 int dm4d_hexplane_forward(int32_t S, int32_t M, int32_t B, const int32_t *res, const float *const *planes,
-                          const float *aabb_host, const float *nodes, const float *times, float *feat,
-                          void *samples, dm4d_stream_t stream)
+                          int32_t channel_last, const float *aabb_host, const float *nodes, const float *times,
+                          float *feat, void *samples, dm4d_stream_t stream)
 {
     HexDesc d;
-    int rc = fill_desc(d, S, M, B, res, planes, aabb_host);
+    int rc = fill_desc(d, S, M, B, res, planes, aabb_host, channel_last);
     if (rc) return rc;
     if (!planes || !nodes || !times || !feat) { set_error("hexplane: null tensor"); return DM4D_ERR_INVALID; }
     const size_t total = (size_t)B * M * S * kHexCh;
@@ -339,14 +350,15 @@ int dm4d_hexplane_forward(int32_t S, int32_t M, int32_t B, const int32_t *res, c
 size_t dm4d_hexplane_scratch_bytes(int32_t S, int32_t M, int32_t B) { return (size_t)B * M * S * kHexPlanes * kHexCh * 4; }
 
 int dm4d_hexplane_backward(int32_t S, int32_t M, int32_t B, const int32_t *res, const float *const *planes,
-                           const float *aabb_host, const float *nodes, const float *times, const float *g_feat,
+                           int32_t channel_last, const float *aabb_host, const float *nodes, const float *times,
+                           const float *g_feat,
                            int32_t n_spatial, const int32_t *sp_scale, const int32_t *sp_plane, const int32_t *sp_texel,
                            const int32_t *sp_off, const int32_t *sp_item, int32_t n_time, const int32_t *tp_scale,
                            const int32_t *tp_plane, const int32_t *tp_col, const int32_t *tp_off, const int32_t *tp_item,
                            void *scratch, float *const *g_planes, dm4d_stream_t stream)
 {
     HexDesc d;
-    int rc = fill_desc(d, S, M, B, res, planes, aabb_host);
+    int rc = fill_desc(d, S, M, B, res, planes, aabb_host, channel_last);
     if (rc) return rc;
     if (!planes || !nodes || !times || !g_feat || !scratch || !g_planes) { set_error("hexplane: null tensor"); return DM4D_ERR_INVALID; }
     hipStream_t st = (hipStream_t)stream;

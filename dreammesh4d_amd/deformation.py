@@ -37,12 +37,15 @@ class HexPlaneField(nn.Module):
             reso = [int(r) * int(mult) for r in resolution[:3]] + [int(resolution[3])]
             planes = nn.ParameterList()
             for a0, a1 in PLANE_AXES:
-                p = nn.Parameter(torch.empty(1, channels, reso[a1], reso[a0]))
+                w = torch.empty(1, channels, reso[a1], reso[a0])
                 if 3 in (a0, a1):
-                    nn.init.ones_(p)                      # time planes start at 1 (:132-133)
+                    nn.init.ones_(w)                      # time planes start at 1 (:132-133)
                 else:
-                    nn.init.uniform_(p, a=0.1, b=0.5)
-                planes.append(p)
+                    nn.init.uniform_(w, a=0.1, b=0.5)
+                # Same [1,C,H,W] parameter as the reference (names, shapes, state dict), held in channels_last
+                # memory format: the C channels of a texel are one 128-byte line for the HIP query
+                # (csrc/hexplane.hip), instead of C words H*W*4 bytes apart.
+                planes.append(nn.Parameter(w.contiguous(memory_format=torch.channels_last)))
             self.grids.append(planes)
         self.feat_dim = channels * len(multires)
 
@@ -57,7 +60,7 @@ class HexPlaneField(nn.Module):
             for plane, (a0, a1) in zip(planes, PLANE_AXES):
                 uv = x4[:, [a0, a1]].view(1, 1, -1, 2)    # grid_sample: (x=width=a0, y=height=a1)
                 s = F.grid_sample(plane, uv, mode="bilinear", padding_mode="border", align_corners=True)
-                s = s.view(plane.shape[1], -1).t()        # [P, channels]
+                s = s.reshape(plane.shape[1], -1).t()     # [P, channels]
                 acc = s if acc is None else acc * s
             feats.append(acc)
         return torch.cat(feats, dim=-1)

@@ -37,7 +37,7 @@ def shard_frames(n_frames: int, rank_: int, world_: int, frames_per_rank: int = 
 class GradAllReducer:
     """One all-reduce per step over one flat float32 buffer.
 
-    `touched` (optional): {parameter: LongTensor of flat element indices}.  For those parameters only the listed
+    `touched` (optional): {parameter: LongTensor of element indices in STORAGE order (`storage_flat`)}.  For those parameters only the listed
     elements are exchanged; every rank must pass the SAME index sets and the gradient must be zero elsewhere on
     every rank.  That is the case for the HexPlane grids: the graph nodes are static and identical on all ranks, so
     the spatial planes only ever receive gradient at the texels the nodes touch (`touched_from_plan`) -- 1.0 M of
@@ -93,10 +93,11 @@ class GradAllReducer:
         seg.n_segments = len(self.params)
         for k, (p, o, ix) in enumerate(zip(self.params, self.offsets, self.index)):
             if p.grad is None and for_unpack:
-                p.grad = torch.zeros_like(p)
+                p.grad = torch.zeros_like(p, memory_format=torch.preserve_format)
             g = p.grad
-            if g is not None and (g.dtype != torch.float32 or not g.is_contiguous()):
-                raise ValueError("gradients must be contiguous float32")
+            if g is not None and (g.dtype != torch.float32 or g.stride() != p.stride()):
+                raise ValueError("gradients must be float32 with the parameter's strides")
+            storage_flat(p)                                     # dense (contiguous or channels_last), else raises
             seg.grad[k] = None if g is None else g.data_ptr()
             seg.index[k] = None if ix is None else ix.data_ptr()
             seg.count[k] = p.numel() if ix is None else ix.numel()
@@ -121,9 +122,9 @@ class GradAllReducer:
             if p.grad is None:
                 seg.zero_()
             elif ix is None:
-                seg.copy_(p.grad.reshape(-1))
+                seg.copy_(storage_flat(p.grad))
             else:
-                torch.index_select(p.grad.reshape(-1), 0, ix, out=seg)
+                torch.index_select(storage_flat(p.grad), 0, ix, out=seg)
 
     def unpack(self, scale):
         flat = self.flat
@@ -141,21 +142,30 @@ class GradAllReducer:
         for p, o, ix in zip(self.params, self.offsets, self.index):
             n = p.numel() if ix is None else ix.numel()
             seg = flat[o:o + n]
+            if p.grad is None:
+                p.grad = torch.zeros_like(p, memory_format=torch.preserve_format)
+            elif p.grad.stride() != p.stride():
+                raise ValueError("gradients must have the parameter's strides")
             if ix is None:
-                if p.grad is None:
-                    p.grad = seg.view_as(p).clone()
-                else:
-                    p.grad.copy_(seg.view_as(p))
+                storage_flat(p.grad).copy_(seg)
             else:
-                if p.grad is None:
-                    p.grad = torch.zeros_like(p)
-                p.grad.view(-1).index_copy_(0, ix, seg)
+                storage_flat(p.grad).index_copy_(0, ix, seg)
+
+
+def storage_flat(t):
+    """1-D view of a dense tensor in STORAGE order (contiguous and channels_last tensors alike)."""
+    if t.is_contiguous():
+        return t.view(-1)
+    if t.dim() == 4 and t.is_contiguous(memory_format=torch.channels_last):
+        return t.as_strided((t.numel(),), (1,), t.storage_offset())
+    raise ValueError("parameters / gradients must be dense (contiguous or channels_last)")
 
 
 def touched_from_plan(field, plan):
-    """{spatial plane parameter: flat indices of the elements that can receive gradient} from a `hexplane.HexPlan`
-    (its `sp` lists are the touched texels per (scale, plane); element = channel * H * W + texel).  The time planes
-    are exchanged densely (which rows a step touches depends on the rank's timestamps)."""
+    """{spatial plane parameter: STORAGE indices of the elements that can receive gradient} from a `hexplane.HexPlan`
+    (its `sp` lists are the touched texels per (scale, plane); element = channel * H * W + texel for a contiguous
+    plane, texel * C + channel for a channels_last one).  The time planes are exchanged densely (which rows a step
+    touches depends on the rank's timestamps)."""
     sc, pl, tx = (plan.sp[k].to(torch.long) for k in ("scale", "plane", "texel"))
     out = {}
     for s, planes in enumerate(field.grids):
@@ -165,5 +175,10 @@ def touched_from_plan(field, plan):
                 continue
             C, HW = int(par.shape[1]), int(par.shape[2]) * int(par.shape[3])
             t = tx[m]
-            out[par] = (torch.arange(C, device=t.device, dtype=torch.long)[:, None] * HW + t[None, :]).reshape(-1)
+            ch = torch.arange(C, device=t.device, dtype=torch.long)
+            if par.is_contiguous():
+                out[par] = (ch[:, None] * HW + t[None, :]).reshape(-1)
+            else:
+                storage_flat(par)                               # raises unless channels_last
+                out[par] = (t[:, None] * C + ch[None, :]).reshape(-1)
     return out

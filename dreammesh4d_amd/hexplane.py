@@ -85,6 +85,16 @@ class HexPlan:
         self.n_sp, self.n_tp = len(sp["texel"]), len(tp["col"])
 
 
+def plane_layout(planes):
+    """0 if every plane is a contiguous [1,32,H,W] tensor, 1 if every plane is in torch.channels_last memory format
+    (storage [H][W][32], what `HexPlaneField` allocates: one 128-byte line per texel); anything else is an error."""
+    if all(p.dtype == torch.float32 and p.is_contiguous(memory_format=torch.channels_last) and p.shape[1] > 1 for p in planes):
+        return 1
+    if all(p.dtype == torch.float32 and p.is_contiguous() for p in planes):
+        return 0
+    raise ValueError("HexPlane planes must be float32 and all contiguous or all channels_last")
+
+
 def _plane_ptr_array(planes):
     arr = (C.c_void_p * len(planes))(*[p.data_ptr() for p in planes])
     return arr
@@ -97,18 +107,16 @@ class _HexPlaneFeatures(torch.autograd.Function):
         dev = times.device
         B = int(times.shape[0])
         pl = [p.detach() for p in planes]
-        for p in pl:
-            if p.dtype != torch.float32 or not p.is_contiguous():
-                raise ValueError("HexPlane planes must be contiguous float32")
+        cl = plane_layout(pl)
         t = times.detach().to(torch.float32).contiguous()
         feat = torch.empty(B, plan.M, plan.S * 32, dtype=torch.float32, device=dev)
         need_bwd = any(p.requires_grad for p in planes)
         samples = torch.empty(L.dm4d_hexplane_scratch_bytes(plan.S, plan.M, B), dtype=torch.uint8, device=dev) if need_bwd else None
         with torch.cuda.device(dev):
-            _lib.check(L.dm4d_hexplane_forward(plan.S, plan.M, B, plan.res_c, _plane_ptr_array(pl), plan.aabb_c,
+            _lib.check(L.dm4d_hexplane_forward(plan.S, plan.M, B, plan.res_c, _plane_ptr_array(pl), cl, plan.aabb_c,
                                                _p(plan.nodes), _p(t), _p(feat), _p(samples),
                                                torch.cuda.current_stream(dev).cuda_stream), "dm4d_hexplane_forward")
-        ctx.plan, ctx.t, ctx.planes, ctx.samples = plan, t, pl, samples
+        ctx.plan, ctx.t, ctx.planes, ctx.samples, ctx.cl = plan, t, pl, samples, cl
         return feat
 
     @staticmethod
@@ -118,13 +126,14 @@ class _HexPlaneFeatures(torch.autograd.Function):
         dev = t.device
         B = int(t.shape[0])
         g = g_feat.detach().to(torch.float32).contiguous()
-        grads = [torch.empty_like(p) for p in pl]      # dense; the C call zero-fills them (one launch) before the gathers
+        # dense, in the planes' own memory format; the C call zero-fills them (one launch) before the gathers
+        grads = [torch.empty_like(p, memory_format=torch.preserve_format) for p in pl]
         gptr = _plane_ptr_array(grads)
         scratch, ctx.samples = ctx.samples, None      # the forward's plane samples; the backward works in place
         sp, tp = plan.sp, plan.tp
         with torch.cuda.device(dev):
             _lib.check(L.dm4d_hexplane_backward(
-                plan.S, plan.M, B, plan.res_c, _plane_ptr_array(pl), plan.aabb_c, _p(plan.nodes), _p(t), _p(g),
+                plan.S, plan.M, B, plan.res_c, _plane_ptr_array(pl), ctx.cl, plan.aabb_c, _p(plan.nodes), _p(t), _p(g),
                 plan.n_sp, _p(sp["scale"]), _p(sp["plane"]), _p(sp["texel"]), _p(sp["off"]), _p(sp["item"]),
                 plan.n_tp, _p(tp["scale"]), _p(tp["plane"]), _p(tp["col"]), _p(tp["off"]), _p(tp["item"]),
                 _p(scratch), gptr, torch.cuda.current_stream(dev).cuda_stream), "dm4d_hexplane_backward")

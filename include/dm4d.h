@@ -233,13 +233,16 @@ int dm4d_face_gaussians_backward(int32_t F, int32_t G, int32_t V, const int32_t 
 /* Fused multi-scale HexPlane query of the deformation network (C/geometry/deformation.py:88-113,141-174,
  * 226-240) for M static nodes x B timestamps: feat[f, m, s*32 + c] = prod over the 6 planes of the bilinear
  * sample (align_corners, border padding).  `res` [S,4] (host) = resolution of x,y,z,t per scale;
- * `planes` = HOST array of S*6 device pointers, plane (s,p) is [32, res[a1], res[a0]] (the reference's
- * parameter layout, so its checkpoints load unchanged); `aabb_host` [2,3] (host); nodes [M,3], times [B]
+ * `planes` = HOST array of S*6 device pointers, plane (s,p) is the reference's [1, 32, res[a1], res[a0]] parameter
+ * stored either as [32][res[a1]][res[a0]] (channel_last == 0, a contiguous tensor) or as [res[a1]][res[a0]][32]
+ * (channel_last != 0: the same tensor in torch.channels_last memory format -- state dicts and checkpoints are
+ * unchanged, but the 32 channels of a texel are one 128-byte line instead of 32 scattered words; all planes and
+ * gradient planes of a call share the layout); `aabb_host` [2,3] (host); nodes [M,3], times [B]
  * (already mapped to [-1,1]), feat [B,M,S*32] on the device.  `samples` (device, dm4d_hexplane_scratch_bytes,
  * or NULL for inference) receives the 6 plane samples of every feature; dm4d_hexplane_backward consumes it. */
 int dm4d_hexplane_forward(int32_t S, int32_t M, int32_t B, const int32_t *res, const float *const *planes,
-                          const float *aabb_host, const float *nodes, const float *times, float *feat,
-                          void *samples, dm4d_stream_t stream);
+                          int32_t channel_last, const float *aabb_host, const float *nodes, const float *times,
+                          float *feat, void *samples, dm4d_stream_t stream);
 /* Plan helper: lower texel index of every node along x,y,z per scale, i0 [S,3,M] (device), computed with
  * the kernels' own arithmetic; the host builds the static gather lists of the backward from it. */
 int dm4d_hexplane_axis_index(int32_t S, int32_t M, const int32_t *res, const float *aabb_host, const float *nodes,
@@ -251,7 +254,8 @@ size_t dm4d_hexplane_scratch_bytes(int32_t S, int32_t M, int32_t B);
  * gather per touched texel (sp_*: scale, plane, texel, CSR of items node*4+corner), time planes per touched
  * column (tp_*: scale, plane, column, CSR of items node*2+corner). */
 int dm4d_hexplane_backward(int32_t S, int32_t M, int32_t B, const int32_t *res, const float *const *planes,
-                           const float *aabb_host, const float *nodes, const float *times, const float *g_feat,
+                           int32_t channel_last, const float *aabb_host, const float *nodes, const float *times,
+                           const float *g_feat,
                            int32_t n_spatial, const int32_t *sp_scale, const int32_t *sp_plane, const int32_t *sp_texel,
                            const int32_t *sp_off, const int32_t *sp_item, int32_t n_time, const int32_t *tp_scale,
                            const int32_t *tp_plane, const int32_t *tp_col, const int32_t *tp_off, const int32_t *tp_item,

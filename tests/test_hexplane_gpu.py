@@ -15,7 +15,10 @@ def _need_gpu():
 @pytest.mark.parametrize("resolution,multires,M,B,heads", [((8, 8, 8, 5), (1, 2), 37, 3, "all"),
                                                            ((64, 64, 64, 25), (1, 2, 4, 8), 1000, 4, "all"),
                                                            ((16, 16, 16, 7), (1, 2, 4), 333, 2, "pos+rot")])
-def test_fused_hexplane_matches_grid_sample_path(resolution, multires, M, B, heads):
+@pytest.mark.parametrize("layout", ["channels_last", "contiguous"])
+def test_fused_hexplane_matches_grid_sample_path(resolution, multires, M, B, heads, layout):
+    """Both plane storages the C ABI accepts: the module's own (torch.channels_last) and the reference's contiguous
+    [1,32,H,W] tensors."""
     _need_gpu()
     from dreammesh4d_amd.deformation import DeformationNetwork
 
@@ -23,6 +26,11 @@ def test_fused_hexplane_matches_grid_sample_path(resolution, multires, M, B, hea
     torch.manual_seed(0)
     full = heads == "all"
     net = DeformationNetwork(resolution=resolution, multires=multires, no_ds=not full, no_dr=False, no_do=not full).to(dev)
+    planes = [p for grid in net.deformation_net.grid.grids for p in grid]
+    assert all(p.is_contiguous(memory_format=torch.channels_last) and p.shape[1] == 32 for p in planes)
+    if layout == "contiguous":
+        for p in planes:
+            p.data = p.data.contiguous()
     g = torch.Generator().manual_seed(1)
     with torch.no_grad():
         for name, p in net.named_parameters():
@@ -58,13 +66,15 @@ def test_fused_hexplane_matches_grid_sample_path(resolution, multires, M, B, hea
         assert (fused[n] - p.grad).abs().max() / scale < 2e-4, n
     # the structured-sparse exchange of the multi-GPU step relies on this: spatial planes get gradient ONLY at the
     # plan's touched texels
-    from dreammesh4d_amd.distributed import touched_from_plan
+    from dreammesh4d_amd.distributed import storage_flat, touched_from_plan
     touched = touched_from_plan(net.deformation_net.grid, net._hex_plan)
     assert len(touched) == 3 * len(multires)
     for par, idx in touched.items():
         mask = torch.ones(par.numel(), dtype=torch.bool, device=dev)
         mask[idx] = False
-        assert not fused[[n for n, q in net.named_parameters() if q is par][0]].view(-1)[mask].any()
+        gpar = fused[[n for n, q in net.named_parameters() if q is par][0]]
+        assert gpar.stride() == par.stride()
+        assert not storage_flat(gpar)[mask].any() and storage_flat(gpar)[idx].any()
         assert idx.numel() == idx.unique().numel() <= par.numel()
     # deterministic: the gather backward gives bit-identical gradients on a re-run
     net.zero_grad(set_to_none=True)
