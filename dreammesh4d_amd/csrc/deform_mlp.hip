@@ -1,4 +1,4 @@
-// deform_mlp.hip -- the MLP of the deformation network, fused (gfx950).
+// deform_mlp.hip -- the MLP of the deformation network on the FP32 matrix cores (gfx950).
 //
 // After the HexPlane features (hexplane.hip) the reference runs, per query point
 // (custom/threestudio-dreammesh4d/geometry/deformation.py:285-305,430-436,507-512):
@@ -7,18 +7,23 @@
 //     y_k   = x + W1_k x + b1_k                              residual Linear(64, 64) (heads: pos, scales, rot, opacity)
 //     out_k = W2_k y_k + b2_k                                Linear(64, {3, 6, 4, 1})
 // as ~12 GEMV-sized linears plus ~25 elementwise kernels forward and ~45 backward per step -- for
-// 4000 rows.  Here: 2 launches forward, 2 backward, activations kept in LDS.
+// 4000 rows.  Here every product is a chain of v_mfma_f32_16x16x4_f32 (f32 in, f32 accumulate: exact
+// float32, bitwise an fmaf chain), 2 launches forward and 3 backward.
 //
-//   k_mlp_pack : transposes the weights once per call into [in][out] order (the forward streams a
-//                weight row per input with lanes along `out`: coalesced, L1-resident)
-//   k_mlp_fwd  : one workgroup = 32 rows; thread (o, row group) keeps 8 rows of output o in
-//                registers; saves h and y_k for the backward
-//   k_mlp_bwd  : one workgroup = 32 rows; dy_k, dx, dh, d feat and the workgroup's PARTIAL weight
-//                gradients (fixed summation order)
-//   k_mlp_reduce: sums the partials over the workgroups in order -> deterministic parameter
-//                gradients, no floating-point atomics
+// Everything is computed TRANSPOSED: features are the M dimension of the MFMA, the 16 data rows of a
+// workgroup its N dimension.  The D tile of one layer -- lane l holds features 4 (l >> 4) .. + 3 of data row
+// l & 15 -- is then exactly the B operand the next layer wants (B[k = l >> 4][n = l & 15], one MFMA per
+// register), so activations go from layer to layer without a transpose; only the four 16-feature tiles of a
+// 64-wide layer (one per wave) are exchanged through 4 KB of LDS.  The A operands are rows of the weights
+// in their nn.Linear layout ([out][in]: lane l reads W[16 w + (l & 15)][16 s + 4 (l >> 4) .. + 3] as one
+// float4); the backward's transposed products read the [in][out] copies k_mlp_pack writes.
 //
-// Arithmetic is float32 FMA chains in a fixed order (results agree with rocBLAS to rounding).
+//   k_mlp_pack  : W0, W1_k -> transposed copies (once per forward call)
+//   k_mlp_fwd   : workgroup = 16 rows x 4 waves (wave = 16 of the 64 features); saves h and y_k
+//   k_mlp_bwd   : workgroup = 16 rows: dy_k, dx, dh (kept for k_mlp_wgrad), d feat
+//   k_mlp_wgrad : every parameter gradient is sum_rows L[row][m] R[row][n]; one workgroup per 16x16 output
+//                 tile and row slice (split-K), rows in a fixed order
+//   k_mlp_reduce: sums the row-slice partials in order -> deterministic, no floating-point atomics
 #include <string.h>
 
 #include "common.h"
@@ -26,12 +31,15 @@
 
 namespace dm4d {
 
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
 constexpr int kW = 64;        // hidden width (DeformationNetwork(net_width=64))
-constexpr int kRT = 32;       // rows per workgroup
-constexpr int kLd = 36;       // LDS row stride in floats for [k][row] tiles (16-B aligned, 32 rows + pad)
+constexpr int kRT = 16;       // rows per workgroup == N of the MFMA
 constexpr int kMaxHeads = 4;
 constexpr int kMaxOut = 8;
 constexpr int kMaxIn = 256;
+constexpr int kXs = 17;       // float4 stride of a feature quad in the LDS exchange tiles (16 rows + pad)
+constexpr int kKSplit = 8;    // row slices of the parameter-gradient products
 
 struct MlpDesc {
     int P, IN, n_heads;
@@ -39,8 +47,10 @@ struct MlpDesc {
     const float *W0, *b0;
     const float *W1[kMaxHeads], *b1[kMaxHeads], *W2[kMaxHeads], *b2[kMaxHeads];
     float *W0T;                 // [IN][64]
-    float *W1T[kMaxHeads];      // [64][64]
-    float *W2T[kMaxHeads];      // [64][out]
+    float *W1T[kMaxHeads];      // [64 in][64 out]
+    float *DY;                  // [n_heads][P][64]  dL/dy_k   (backward)
+    float *DH;                  // [P][64]           dL/dh     (backward)
+    float *partial;             // [kKSplit][partial_floats]
 };
 
 struct MlpGrads {
@@ -48,6 +58,7 @@ struct MlpGrads {
     float *W1[kMaxHeads], *b1[kMaxHeads], *W2[kMaxHeads], *b2[kMaxHeads];
 };
 
+// partial layout: W0 [64][IN] | b0 [64] | per head: W1 [64][64] | b1 [64] | W2 [od][64] | b2 [od]
 __host__ __device__ static inline size_t partial_floats(const MlpDesc &d)
 {
     size_t n = (size_t)kW * d.IN + kW;
@@ -55,31 +66,30 @@ __host__ __device__ static inline size_t partial_floats(const MlpDesc &d)
     return n;
 }
 
+__device__ __forceinline__ f32x4 mfma4(const float4 a, const float4 b, f32x4 c)
+{
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b.x, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b.y, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b.z, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b.w, c, 0, 0, 0);
+    return c;
+}
+__device__ __forceinline__ float4 ld4(const float *p) { return *reinterpret_cast<const float4 *>(p); }
+__device__ __forceinline__ float4 to4(const f32x4 v) { return make_float4(v.x, v.y, v.z, v.w); }
+
 // ------------------------------------------------------------------------------------------ pack
 __global__ void k_mlp_pack(MlpDesc d)
 {
     const int gid = blockIdx.x * 256 + threadIdx.x;
-    int base = 0;
     if (gid < d.IN * kW) {   // W0 [64][IN] -> W0T [IN][64]
         const int i = gid / kW, o = gid % kW;
         d.W0T[gid] = d.W0[(size_t)o * d.IN + i];
         return;
     }
-    base = d.IN * kW;
-    for (int k = 0; k < d.n_heads; ++k) {
-        if (gid < base + kW * kW) {
-            const int e = gid - base, i = e / kW, o = e % kW;
-            d.W1T[k][e] = d.W1[k][o * kW + i];
-            return;
-        }
-        base += kW * kW;
-        const int od = d.out_dim[k];
-        if (gid < base + kW * od) {
-            const int e = gid - base, i = e / od, c = e % od;
-            d.W2T[k][e] = d.W2[k][c * kW + i];
-            return;
-        }
-        base += kW * od;
+    const int e = gid - d.IN * kW, k = e / (kW * kW);
+    if (k < d.n_heads) {
+        const int r = e % (kW * kW), i = r / kW, o = r % kW;
+        d.W1T[k][r] = d.W1[k][o * kW + i];
     }
 }
 
@@ -88,268 +98,214 @@ __global__ __launch_bounds__(256) void k_mlp_fwd(MlpDesc d, const float *__restr
                                                  float *__restrict__ Ys, float *out0, float *out1, float *out2,
                                                  float *out3)
 {
-    __shared__ __attribute__((aligned(16))) float s_a[kMaxIn * kLd];   // feat^T [IN][row]
-    __shared__ __attribute__((aligned(16))) float s_x[kW * kLd];       // relu(h)^T [64][row]
-    __shared__ __attribute__((aligned(16))) float s_y[kW * kLd];       // y_k^T [64][row]
-    const int tid = threadIdx.x, o = tid & 63, rg = tid >> 6;
-    const int row0 = blockIdx.x * kRT;
-    const int IN = d.IN;
-    for (int e = tid; e < kRT * IN; e += 256) {
-        const int r = e / IN, i = e % IN;
-        s_a[i * kLd + r] = (row0 + r < d.P) ? feat[(size_t)(row0 + r) * IN + i] : 0.f;
+    __shared__ float4 s_f[(kMaxIn / 4) * kXs];          // feat tile   [feature quad][row]
+    __shared__ float4 s_x[(kW / 4) * kXs];              // relu(h)
+    __shared__ float4 s_y[kMaxHeads][(kW / 4) * kXs];   // y_k
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, i = lane & 15, kq = lane >> 4;
+    const int row0 = blockIdx.x * kRT, IN = d.IN, nq = IN / 4;
+    const int row = row0 + i;                            // this lane's data row (N index of every tile)
+    for (int e = tid; e < kRT * nq; e += 256) {
+        const int r = e / nq, q = e % nq;
+        s_f[q * kXs + r] = (row0 + r < d.P) ? ld4(feat + (size_t)(row0 + r) * IN + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
+    const int fo = 16 * w + 4 * kq;                      // first of this lane's 4 output features
+    const float4 b0 = ld4(d.b0 + fo);
+    f32x4 acc0 = {b0.x, b0.y, b0.z, b0.w}, acc1 = {0.f, 0.f, 0.f, 0.f};
     __syncthreads();
-    float acc[8];
     {
-        const float b = d.b0[o];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) acc[j] = b;
-#pragma unroll 8
-        for (int i = 0; i < IN; ++i) {
-            const float w = d.W0T[i * kW + o];
-            const float4 f0 = *reinterpret_cast<const float4 *>(&s_a[i * kLd + rg * 8]);
-            const float4 f1 = *reinterpret_cast<const float4 *>(&s_a[i * kLd + rg * 8 + 4]);
-            acc[0] = __builtin_fmaf(w, f0.x, acc[0]); acc[1] = __builtin_fmaf(w, f0.y, acc[1]);
-            acc[2] = __builtin_fmaf(w, f0.z, acc[2]); acc[3] = __builtin_fmaf(w, f0.w, acc[3]);
-            acc[4] = __builtin_fmaf(w, f1.x, acc[4]); acc[5] = __builtin_fmaf(w, f1.y, acc[5]);
-            acc[6] = __builtin_fmaf(w, f1.z, acc[6]); acc[7] = __builtin_fmaf(w, f1.w, acc[7]);
+        const float *__restrict__ Wrow = d.W0 + (size_t)(16 * w + i) * IN + 4 * kq;
+        for (int s = 0; s < IN / 16; s += 2) {           // two accumulators: the chains do not wait on each other
+            acc0 = mfma4(ld4(Wrow + 16 * s), s_f[(4 * s + kq) * kXs + i], acc0);
+            acc1 = mfma4(ld4(Wrow + 16 * s + 16), s_f[(4 * s + 4 + kq) * kXs + i], acc1);
         }
     }
-    float x[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const int r = row0 + rg * 8 + j;
-        if (r < d.P) Hs[(size_t)r * kW + o] = acc[j];
-        x[j] = fmaxf(acc[j], 0.f);
-        s_x[o * kLd + rg * 8 + j] = x[j];
+    const f32x4 h = acc0 + acc1;
+    if (row < d.P) *reinterpret_cast<float4 *>(Hs + (size_t)row * kW + fo) = to4(h);
+    const f32x4 x = {fmaxf(h.x, 0.f), fmaxf(h.y, 0.f), fmaxf(h.z, 0.f), fmaxf(h.w, 0.f)};
+    s_x[(4 * w + kq) * kXs + i] = to4(x);
+    __syncthreads();
+    for (int k = 0; k < d.n_heads; ++k) {
+        const float4 b1 = ld4(d.b1[k] + fo);
+        f32x4 a0 = {x.x + b1.x, x.y + b1.y, x.z + b1.z, x.w + b1.w}, a1 = {0.f, 0.f, 0.f, 0.f};
+        const float *__restrict__ Wrow = d.W1[k] + (size_t)(16 * w + i) * kW + 4 * kq;
+        a0 = mfma4(ld4(Wrow), s_x[kq * kXs + i], a0);
+        a1 = mfma4(ld4(Wrow + 16), s_x[(4 + kq) * kXs + i], a1);
+        a0 = mfma4(ld4(Wrow + 32), s_x[(8 + kq) * kXs + i], a0);
+        a1 = mfma4(ld4(Wrow + 48), s_x[(12 + kq) * kXs + i], a1);
+        const f32x4 y = a0 + a1;
+        if (row < d.P) *reinterpret_cast<float4 *>(Ys + ((size_t)k * d.P + row) * kW + fo) = to4(y);
+        s_y[k][(4 * w + kq) * kXs + i] = to4(y);
     }
     __syncthreads();
-    float *outs[kMaxHeads] = {out0, out1, out2, out3};
-    for (int k = 0; k < d.n_heads; ++k) {
-        const float b = d.b1[k][o];
+    // out_k = W2_k y_k + b2_k: wave k takes head k (M = the <= 8 outputs, padded to one 16-row tile)
+    if (w < d.n_heads) {
+        const int k = w, od = d.out_dim[k];
+        f32x4 a = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int j = 0; j < 8; ++j) acc[j] = x[j] + b;
-        const float *__restrict__ W1T = d.W1T[k];
-#pragma unroll 8
-        for (int i = 0; i < kW; ++i) {
-            const float w = W1T[i * kW + o];
-            const float4 f0 = *reinterpret_cast<const float4 *>(&s_x[i * kLd + rg * 8]);
-            const float4 f1 = *reinterpret_cast<const float4 *>(&s_x[i * kLd + rg * 8 + 4]);
-            acc[0] = __builtin_fmaf(w, f0.x, acc[0]); acc[1] = __builtin_fmaf(w, f0.y, acc[1]);
-            acc[2] = __builtin_fmaf(w, f0.z, acc[2]); acc[3] = __builtin_fmaf(w, f0.w, acc[3]);
-            acc[4] = __builtin_fmaf(w, f1.x, acc[4]); acc[5] = __builtin_fmaf(w, f1.y, acc[5]);
-            acc[6] = __builtin_fmaf(w, f1.z, acc[6]); acc[7] = __builtin_fmaf(w, f1.w, acc[7]);
-        }
+        for (int j = 0; j < 4; ++j)
+            if (4 * kq + j < od) a[j] = d.b2[k][4 * kq + j];
+        const float *__restrict__ Wrow = d.W2[k] + (size_t)i * kW + 4 * kq;
+        const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int r = row0 + rg * 8 + j;
-            if (r < d.P) Ys[((size_t)k * d.P + r) * kW + o] = acc[j];
-            s_y[o * kLd + rg * 8 + j] = acc[j];
+        for (int s = 0; s < 4; ++s) a = mfma4(i < od ? ld4(Wrow + 16 * s) : z, s_y[k][(4 * s + kq) * kXs + i], a);
+        float *outs[kMaxHeads] = {out0, out1, out2, out3};
+        if (row < d.P) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (4 * kq + j < od) outs[k][(size_t)row * od + 4 * kq + j] = a[j];
         }
-        __syncthreads();
-        const int od = d.out_dim[k];
-        const int r = tid & 31, c = tid >> 5;    // 8 output columns x 32 rows
-        if (c < od && row0 + r < d.P) {
-            float a = d.b2[k][c];
-            const float *__restrict__ W2T = d.W2T[k];
-            for (int i = 0; i < kW; ++i) a = __builtin_fmaf(W2T[i * od + c], s_y[i * kLd + r], a);
-            outs[k][(size_t)(row0 + r) * od + c] = a;
-        }
-        __syncthreads();
     }
 }
 
-// ------------------------------------------------------------------------------------------ backward
-// LDS tiles, all [k][row] with stride kLd unless noted
-__global__ __launch_bounds__(256) void k_mlp_bwd(MlpDesc d, const float *__restrict__ feat, const float *__restrict__ Hs,
-                                                 const float *__restrict__ Ys, const float *g0, const float *g1,
-                                                 const float *g2, const float *g3, float *__restrict__ g_feat,
-                                                 float *__restrict__ partial)
+// ------------------------------------------------------------------------------------------ backward (activations)
+__global__ __launch_bounds__(256) void k_mlp_bwd(MlpDesc d, const float *__restrict__ Hs, const float *g0, const float *g1,
+                                                 const float *g2, const float *g3, float *__restrict__ g_feat)
 {
-    __shared__ __attribute__((aligned(16))) float s_a[kRT * (kMaxIn + 4)];  // feat, row-major [row][IN + 4]  (dW0)
-    __shared__ __attribute__((aligned(16))) float s_xr[kRT * (kW + 4)];     // relu(h)   [row][64 + 4]       (dW1)
-    __shared__ __attribute__((aligned(16))) float s_dy[kW * kLd];           // dy_k^T    [64][row]           (dx, dW1, db1)
-    __shared__ __attribute__((aligned(16))) float s_dh[kW * kLd];           // dh^T      [64][row]           (dW0, db0, d feat)
-    __shared__ __attribute__((aligned(16))) float s_g[kMaxOut * kLd];       // g_out_k^T [out][row]
-    const int tid = threadIdx.x, o = tid & 63, rg = tid >> 6;
-    const int row0 = blockIdx.x * kRT;
-    const int IN = d.IN, lda = IN + 4, ldx = kW + 4;
-    float *__restrict__ part = partial + (size_t)blockIdx.x * partial_floats(d);
+    __shared__ float4 s_dy[(kW / 4) * kXs];
+    __shared__ float4 s_dh[(kW / 4) * kXs];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, i = lane & 15, kq = lane >> 4;
+    const int row0 = blockIdx.x * kRT, IN = d.IN;
+    const int row = row0 + i;
+    const int fo = 16 * w + 4 * kq;
     const float *gs[kMaxHeads] = {g0, g1, g2, g3};
-
-    for (int e = tid; e < kRT * IN; e += 256) {
-        const int r = e / IN, i = e % IN;
-        s_a[r * lda + i] = (row0 + r < d.P) ? feat[(size_t)(row0 + r) * IN + i] : 0.f;
-    }
-    float hpre[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const int r = row0 + rg * 8 + j;
-        hpre[j] = (r < d.P) ? Hs[(size_t)r * kW + o] : 0.f;
-        s_xr[(rg * 8 + j) * ldx + o] = fmaxf(hpre[j], 0.f);
-    }
-    float dx[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) dx[j] = 0.f;
-    size_t poff = (size_t)kW * IN + kW;    // head partials follow dW0, db0
-    __syncthreads();
-
+    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+    const float4 hpre = (row < d.P) ? ld4(Hs + (size_t)row * kW + fo) : z;
+    f32x4 dx = {0.f, 0.f, 0.f, 0.f};
     for (int k = 0; k < d.n_heads; ++k) {
         const int od = d.out_dim[k];
-        // ---- g_out tile ----
-        for (int e = tid; e < kRT * od; e += 256) {
-            const int r = e / od, c = e % od;
-            s_g[c * kLd + r] = (gs[k] && row0 + r < d.P) ? gs[k][(size_t)(row0 + r) * od + c] : 0.f;
-        }
-        __syncthreads();
-        // ---- dy = W2^T g  (thread: output o, 8 rows) ----
-        float dy[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) dy[j] = 0.f;
-        for (int c = 0; c < od; ++c) {
-            const float w = d.W2[k][c * kW + o];
-            const float4 f0 = *reinterpret_cast<const float4 *>(&s_g[c * kLd + rg * 8]);
-            const float4 f1 = *reinterpret_cast<const float4 *>(&s_g[c * kLd + rg * 8 + 4]);
-            dy[0] = __builtin_fmaf(w, f0.x, dy[0]); dy[1] = __builtin_fmaf(w, f0.y, dy[1]);
-            dy[2] = __builtin_fmaf(w, f0.z, dy[2]); dy[3] = __builtin_fmaf(w, f0.w, dy[3]);
-            dy[4] = __builtin_fmaf(w, f1.x, dy[4]); dy[5] = __builtin_fmaf(w, f1.y, dy[5]);
-            dy[6] = __builtin_fmaf(w, f1.z, dy[6]); dy[7] = __builtin_fmaf(w, f1.w, dy[7]);
-        }
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            s_dy[o * kLd + rg * 8 + j] = dy[j];
-            dx[j] += dy[j];                        // y = x + W1 x + b1: the identity branch
-        }
-        __syncthreads();
-        // ---- dx += W1^T dy ----
-        {
-            const float *__restrict__ W1 = d.W1[k];
-#pragma unroll 8
-            for (int jn = 0; jn < kW; ++jn) {
-                const float w = W1[jn * kW + o];
-                const float4 f0 = *reinterpret_cast<const float4 *>(&s_dy[jn * kLd + rg * 8]);
-                const float4 f1 = *reinterpret_cast<const float4 *>(&s_dy[jn * kLd + rg * 8 + 4]);
-                dx[0] = __builtin_fmaf(w, f0.x, dx[0]); dx[1] = __builtin_fmaf(w, f0.y, dx[1]);
-                dx[2] = __builtin_fmaf(w, f0.z, dx[2]); dx[3] = __builtin_fmaf(w, f0.w, dx[3]);
-                dx[4] = __builtin_fmaf(w, f1.x, dx[4]); dx[5] = __builtin_fmaf(w, f1.y, dx[5]);
-                dx[6] = __builtin_fmaf(w, f1.z, dx[6]); dx[7] = __builtin_fmaf(w, f1.w, dx[7]);
+        // dy[f][r] = sum_c W2[c][f] g[r][c]      (A[m = i][k = kq] = W2[4 t + kq][16 w + i], B[kq][n = i] = g[row][4 t + kq])
+        f32x4 dy = {0.f, 0.f, 0.f, 0.f};
+        if (gs[k]) {
+            for (int t = 0; 4 * t < od; ++t) {
+                const int c = 4 * t + kq;
+                const float a = (c < od) ? d.W2[k][c * kW + 16 * w + i] : 0.f;
+                const float b = (c < od && row < d.P) ? gs[k][(size_t)row * od + c] : 0.f;
+                dy = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, dy, 0, 0, 0);
             }
         }
-        // ---- partial dW1[jn][i] = sum_r dy[r][jn] x[r][i]: thread (i = o, jn = rg*16 .. +15) ----
-        {
-            float a[16];
-#pragma unroll
-            for (int q = 0; q < 16; ++q) a[q] = 0.f;
-#pragma unroll 4
-            for (int r = 0; r < kRT; ++r) {
-                const float xv = s_xr[r * ldx + o];
-#pragma unroll
-                for (int q = 0; q < 16; ++q) a[q] = __builtin_fmaf(s_dy[(rg * 16 + q) * kLd + r], xv, a[q]);
-            }
-#pragma unroll
-            for (int q = 0; q < 16; ++q) part[poff + (size_t)(rg * 16 + q) * kW + o] = a[q];
-        }
-        // ---- partial db1[o] (wave 0), dW2[c][o], db2[c] ----
-        if (rg == 0) {
-            float a = 0.f;
-            for (int r = 0; r < kRT; ++r) a += s_dy[o * kLd + r];
-            part[poff + (size_t)kW * kW + o] = a;
-        }
-        for (int c = rg; c < od; c += 4) {
-            float a = 0.f;
-            for (int r = 0; r < kRT; ++r) {
-                const float yv = (row0 + r < d.P) ? Ys[((size_t)k * d.P + row0 + r) * kW + o] : 0.f;
-                a = __builtin_fmaf(s_g[c * kLd + r], yv, a);
-            }
-            part[poff + (size_t)kW * kW + kW + (size_t)c * kW + o] = a;
-        }
-        if (tid < od) {
-            float a = 0.f;
-            for (int r = 0; r < kRT; ++r) a += s_g[tid * kLd + r];
-            part[poff + (size_t)kW * kW + kW + (size_t)od * kW + tid] = a;
-        }
-        poff += (size_t)kW * kW + kW + (size_t)od * kW + od;
+        if (row < d.P) *reinterpret_cast<float4 *>(d.DY + ((size_t)k * d.P + row) * kW + fo) = to4(dy);
+        __syncthreads();                                   // the previous head's readers are done with s_dy
+        s_dy[(4 * w + kq) * kXs + i] = to4(dy);
         __syncthreads();
+        // dx += dy + W1^T dy                     (A[m = i][k] = W1[k][16 w + i] = W1T[16 w + i][k])
+        const float *__restrict__ Wrow = d.W1T[k] + (size_t)(16 * w + i) * kW + 4 * kq;
+        f32x4 a1 = dy;
+        dx = mfma4(ld4(Wrow), s_dy[kq * kXs + i], dx);
+        a1 = mfma4(ld4(Wrow + 16), s_dy[(4 + kq) * kXs + i], a1);
+        dx = mfma4(ld4(Wrow + 32), s_dy[(8 + kq) * kXs + i], dx);
+        a1 = mfma4(ld4(Wrow + 48), s_dy[(12 + kq) * kXs + i], a1);
+        dx = dx + a1;
     }
-    // ---- dh = dx * (h > 0) ----
-#pragma unroll
-    for (int j = 0; j < 8; ++j) s_dh[o * kLd + rg * 8 + j] = hpre[j] > 0.f ? dx[j] : 0.f;
+    const f32x4 dh = {hpre.x > 0.f ? dx.x : 0.f, hpre.y > 0.f ? dx.y : 0.f, hpre.z > 0.f ? dx.z : 0.f, hpre.w > 0.f ? dx.w : 0.f};
+    if (row < d.P) *reinterpret_cast<float4 *>(d.DH + (size_t)row * kW + fo) = to4(dh);
+    s_dh[(4 * w + kq) * kXs + i] = to4(dh);
     __syncthreads();
-    // ---- partial dW0[oo][i] = sum_r dh[r][oo] feat[r][i]: thread i (IN / 64 columns each... ) ----
-    // thread (i = tid % IN_T, og): IN may be 64..256; each thread owns column(s) i and a slice of outputs
-    {
-        const int cols = IN;                       // columns
-        const int tpc = 256 / min(256, cols);      // threads per column group (1, 2 or 4)
-        const int per = kW / tpc;                  // outputs per thread (64, 32 or 16)
-        for (int i = tid % (256 / tpc); i < cols; i += 256 / tpc) {
-            const int og = tid / (256 / tpc);
-            for (int o0 = 0; o0 < per; o0 += 16) {
-                float a[16];
-#pragma unroll
-                for (int q = 0; q < 16; ++q) a[q] = 0.f;
-#pragma unroll 4
-                for (int r = 0; r < kRT; ++r) {
-                    const float fv = s_a[r * lda + i];
-#pragma unroll
-                    for (int q = 0; q < 16; ++q) a[q] = __builtin_fmaf(s_dh[(og * per + o0 + q) * kLd + r], fv, a[q]);
-                }
-#pragma unroll
-                for (int q = 0; q < 16; ++q) part[(size_t)(og * per + o0 + q) * IN + i] = a[q];
-            }
+    // d feat[r][in] = sum_o W0[o][in] dh[r][o]   (M tiles of 16 inputs, wave w takes tiles w, w + 4, ...)
+    if (g_feat) {
+        for (int mt = w; mt < IN / 16; mt += 4) {
+            const float *__restrict__ Wrow = d.W0T + (size_t)(16 * mt + i) * kW + 4 * kq;
+            f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
+            a0 = mfma4(ld4(Wrow), s_dh[kq * kXs + i], a0);
+            a1 = mfma4(ld4(Wrow + 16), s_dh[(4 + kq) * kXs + i], a1);
+            a0 = mfma4(ld4(Wrow + 32), s_dh[(8 + kq) * kXs + i], a0);
+            a1 = mfma4(ld4(Wrow + 48), s_dh[(12 + kq) * kXs + i], a1);
+            if (row < d.P) *reinterpret_cast<float4 *>(g_feat + (size_t)row * IN + 16 * mt + 4 * kq) = to4(a0 + a1);
         }
     }
-    if (rg == 0) {
-        float a = 0.f;
-        for (int r = 0; r < kRT; ++r) a += s_dh[o * kLd + r];
-        part[(size_t)kW * IN + o] = a;
+}
+
+// ------------------------------------------------------------------------------------------ backward (parameters)
+// out[m][n] = sum_rows L[row][m] R[row][n] for one 16x16 tile of one parameter and one row slice.  Tiles, in
+// blockIdx.x order:  dW0 (L = dh, R = feat) 4 x (IN/16 + 1)  |  per head: dW1 (L = dy_k, R = relu(h)) 4 x 5,
+// dW2 (L = g_k, R = y_k) 1 x 5.  The last column tile of every group is the bias: R = 1.
+__global__ __launch_bounds__(256) void k_mlp_wgrad(MlpDesc d, const float *__restrict__ feat, const float *__restrict__ Hs,
+                                                   const float *__restrict__ Ys, const float *g0, const float *g1,
+                                                   const float *g2, const float *g3)
+{
+    __shared__ float s_part[3][64][5];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, i = lane & 15, kq = lane >> 4;
+    const float *gs[kMaxHeads] = {g0, g1, g2, g3};
+    const int IN = d.IN, P = d.P;
+    // ---- decode the tile ----
+    int t = blockIdx.x;
+    const float *L = nullptr, *R = nullptr;
+    int ldL = kW, ldR = kW, Mdim = kW, Ndim = kW, mt = 0, nt = 0;
+    bool relu = false;
+    size_t w_off = 0, b_off = 0;          // offsets of the weight / bias block inside a partial
+    const int n0 = 4 * (IN / 16 + 1);
+    if (t < n0) {
+        mt = t / (IN / 16 + 1); nt = t % (IN / 16 + 1);
+        L = d.DH; R = feat; ldR = IN; Ndim = IN;
+        w_off = 0; b_off = (size_t)kW * IN;
+    } else {
+        t -= n0;
+        const int k = t / 25, u = t % 25;
+        size_t off = (size_t)kW * IN + kW;
+        for (int kk = 0; kk < k; ++kk) off += (size_t)kW * kW + kW + (size_t)d.out_dim[kk] * kW + d.out_dim[kk];
+        if (u < 20) {
+            mt = u / 5; nt = u % 5;
+            L = d.DY + (size_t)k * P * kW; R = Hs; relu = true;
+            w_off = off; b_off = off + (size_t)kW * kW;
+        } else {
+            mt = 0; nt = u - 20;
+            const int od = d.out_dim[k];
+            L = gs[k]; ldL = od; Mdim = od;
+            R = Ys + (size_t)k * P * kW;
+            w_off = off + (size_t)kW * kW + kW; b_off = w_off + (size_t)od * kW;
+        }
     }
-    // ---- d feat[r][i] = sum_o W0[o][i] dh[r][o]: thread (i, 16 or 8 rows) ----
-    if (g_feat) {
-        const int tpc = 256 / min(256, IN);        // row groups
-        const int rows = kRT / tpc;                // rows per thread: 32, 16 or 8
-        for (int i = tid % (256 / tpc); i < IN; i += 256 / tpc) {
-            const int rg2 = tid / (256 / tpc);
-            for (int r0 = 0; r0 < rows; r0 += 8) {
-                float a[8];
+    const bool bias = nt * 16 >= Ndim;
+    // ---- this workgroup's row slice, in steps of 4 rows (the K of one MFMA); wave w takes steps w, w + 4, ... ----
+    const int steps = (P + 3) / 4, per = (steps + kKSplit - 1) / kKSplit;
+    const int s0 = blockIdx.y * per, s1 = min(steps, s0 + per);
+    const int mcol = 16 * mt + i, ncol = 16 * nt + i;
+    const bool mok = L != nullptr && mcol < Mdim;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int s = s0 + w; s < s1; s += 4) {
+        const int r = 4 * s + kq;
+        const bool rok = r < P;
+        const float a = (mok && rok) ? L[(size_t)r * ldL + mcol] : 0.f;
+        float b = 0.f;
+        if (rok) {
+            if (bias) b = 1.f;
+            else {
+                b = R[(size_t)r * ldR + ncol];
+                if (relu) b = fmaxf(b, 0.f);
+            }
+        }
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc, 0, 0, 0);
+    }
+    // ---- waves 1..3 -> LDS, wave 0 adds them in order and writes the partial ----
+    if (w > 0) {
 #pragma unroll
-                for (int q = 0; q < 8; ++q) a[q] = 0.f;
-#pragma unroll 8
-                for (int oo = 0; oo < kW; ++oo) {
-                    const float w = d.W0[(size_t)oo * IN + i];
-                    const float4 f0 = *reinterpret_cast<const float4 *>(&s_dh[oo * kLd + rg2 * rows + r0]);
-                    const float4 f1 = *reinterpret_cast<const float4 *>(&s_dh[oo * kLd + rg2 * rows + r0 + 4]);
-                    a[0] = __builtin_fmaf(w, f0.x, a[0]); a[1] = __builtin_fmaf(w, f0.y, a[1]);
-                    a[2] = __builtin_fmaf(w, f0.z, a[2]); a[3] = __builtin_fmaf(w, f0.w, a[3]);
-                    a[4] = __builtin_fmaf(w, f1.x, a[4]); a[5] = __builtin_fmaf(w, f1.y, a[5]);
-                    a[6] = __builtin_fmaf(w, f1.z, a[6]); a[7] = __builtin_fmaf(w, f1.w, a[7]);
-                }
+        for (int j = 0; j < 4; ++j) s_part[w - 1][lane][j] = acc[j];
+    }
+    __syncthreads();
+    if (w == 0) {
+        float *part = d.partial + (size_t)blockIdx.y * partial_floats(d);
 #pragma unroll
-                for (int q = 0; q < 8; ++q) {
-                    const int r = row0 + rg2 * rows + r0 + q;
-                    if (r < d.P) g_feat[(size_t)r * IN + i] = a[q];
-                }
+        for (int j = 0; j < 4; ++j) {
+            const float v = ((acc[j] + s_part[0][lane][j]) + s_part[1][lane][j]) + s_part[2][lane][j];
+            const int m = 16 * mt + 4 * kq + j;     // D: row = 4 (lane >> 4) + j, column = lane & 15
+            if (m >= Mdim) continue;
+            if (bias) {
+                if (i == 0) part[b_off + m] = v;
+            } else {
+                part[w_off + (size_t)m * Ndim + ncol] = v;
             }
         }
     }
 }
 
-// sum of the workgroup partials in workgroup order
-__global__ void k_mlp_reduce(MlpDesc d, MlpGrads g, const float *__restrict__ partial, int n_wg)
+// sum of the row-slice partials in slice order
+__global__ void k_mlp_reduce(MlpDesc d, MlpGrads g, int n_part)
 {
     const size_t n = partial_floats(d);
     const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (e >= n) return;
-    // fixed order: four interleaved running sums (loads of different workgroups in flight), combined at the end
-    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-    int w = 0;
-    for (; w + 4 <= n_wg; w += 4) {
-        a0 += partial[(size_t)w * n + e];
-        a1 += partial[(size_t)(w + 1) * n + e];
-        a2 += partial[(size_t)(w + 2) * n + e];
-        a3 += partial[(size_t)(w + 3) * n + e];
-    }
-    for (; w < n_wg; ++w) a0 += partial[(size_t)w * n + e];
-    const float a = (a0 + a1) + (a2 + a3);
+    const float *__restrict__ partial = d.partial;
+    float a = 0.f;
+    for (int w = 0; w < n_part; ++w) a += partial[(size_t)w * n + e];
     size_t base = 0;
     if (e < (size_t)kW * d.IN) { if (g.W0) g.W0[e] = a; return; }
     base = (size_t)kW * d.IN;
@@ -368,6 +324,19 @@ __global__ void k_mlp_reduce(MlpDesc d, MlpGrads g, const float *__restrict__ pa
     }
 }
 
+// scratch: W0T | W1T x heads | DY | DH | partials   (floats; every block a multiple of 4 floats)
+static size_t scratch_floats(int P, int in_dim, int n_heads, size_t *dy_off, size_t *dh_off, size_t *part_off)
+{
+    size_t n = (size_t)kW * in_dim + (size_t)n_heads * kW * kW;
+    if (dy_off) *dy_off = n;
+    n += (size_t)n_heads * P * kW;
+    if (dh_off) *dh_off = n;
+    n += (size_t)P * kW;
+    if (part_off) *part_off = n;
+    n += (size_t)kKSplit * ((size_t)kW * in_dim + kW + (size_t)n_heads * (kW * kW + kW + kMaxOut * kW + kMaxOut));
+    return n;
+}
+
 static int fill_mlp(MlpDesc &d, int P, const dm4d_mlp_weights *w, void *scratch)
 {
     if (!w || P < 0) { set_error("deform_mlp: null weights / negative P"); return DM4D_ERR_INVALID; }
@@ -381,7 +350,9 @@ static int fill_mlp(MlpDesc &d, int P, const dm4d_mlp_weights *w, void *scratch)
     d.P = P; d.IN = w->in_dim; d.n_heads = w->n_heads;
     d.W0 = w->W0; d.b0 = w->b0;
     float *s = (float *)scratch;
-    d.W0T = s; s += (size_t)kW * d.IN;
+    size_t dy_off, dh_off, part_off;
+    scratch_floats(P, d.IN, d.n_heads, &dy_off, &dh_off, &part_off);
+    d.W0T = s;
     for (int k = 0; k < d.n_heads; ++k) {
         if (w->out_dim[k] < 1 || w->out_dim[k] > kMaxOut || !w->W1[k] || !w->b1[k] || !w->W2[k] || !w->b2[k]) {
             set_error("deform_mlp: head %d incomplete or out_dim %d > %d", k, w->out_dim[k], kMaxOut);
@@ -389,11 +360,15 @@ static int fill_mlp(MlpDesc &d, int P, const dm4d_mlp_weights *w, void *scratch)
         }
         d.out_dim[k] = w->out_dim[k];
         d.W1[k] = w->W1[k]; d.b1[k] = w->b1[k]; d.W2[k] = w->W2[k]; d.b2[k] = w->b2[k];
-        d.W1T[k] = s; s += kW * kW;
-        d.W2T[k] = s; s += kW * kMaxOut;
+        d.W1T[k] = s ? s + (size_t)kW * d.IN + (size_t)k * kW * kW : nullptr;
     }
+    d.DY = s ? s + dy_off : nullptr;
+    d.DH = s ? s + dh_off : nullptr;
+    d.partial = s ? s + part_off : nullptr;
     return DM4D_OK;
 }
+
+static bool aligned16(const void *p) { return ((uintptr_t)p & 15) == 0; }
 
 }  // namespace dm4d
 
@@ -401,13 +376,10 @@ using namespace dm4d;
 
 extern "C" {
 
-/* scratch: transposed weights + per-workgroup partial weight gradients */
+/* scratch: transposed weights + the backward's dy_k / dh + the row-slice partial parameter gradients */
 size_t dm4d_deform_mlp_scratch_bytes(int32_t P, int32_t in_dim, int32_t n_heads)
 {
-    const size_t wg = (size_t)((P > 0 ? P : 1) + kRT - 1) / kRT;
-    const size_t per_wg = (size_t)kW * in_dim + kW + (size_t)n_heads * (kW * kW + kW + kMaxOut * kW + kMaxOut);
-    const size_t wt = (size_t)kW * in_dim + (size_t)n_heads * (kW * kW + kW * kMaxOut);
-    return (wt + wg * per_wg) * sizeof(float) + 256;
+    return scratch_floats(P > 0 ? P : 0, in_dim, n_heads, nullptr, nullptr, nullptr) * sizeof(float) + 256;
 }
 
 int dm4d_deform_mlp_forward(int32_t P, const float *feat, const dm4d_mlp_weights *w, float *h_save, float *y_save,
@@ -418,14 +390,16 @@ int dm4d_deform_mlp_forward(int32_t P, const float *feat, const dm4d_mlp_weights
     if (rc) return rc;
     if (P == 0) return DM4D_OK;
     if (!feat || !h_save || !y_save || !out || !scratch) { set_error("deform_mlp: null tensor"); return DM4D_ERR_INVALID; }
+    bool al = aligned16(feat) && aligned16(h_save) && aligned16(y_save) && aligned16(scratch) && aligned16(w->W0) && aligned16(w->b0);
     float *o[kMaxHeads] = {nullptr, nullptr, nullptr, nullptr};
     for (int k = 0; k < d.n_heads; ++k) {
         o[k] = out[k];
         if (!o[k]) { set_error("deform_mlp: null output %d", k); return DM4D_ERR_INVALID; }
+        al = al && aligned16(w->W1[k]) && aligned16(w->b1[k]) && aligned16(w->W2[k]);
     }
+    if (!al) { set_error("deform_mlp: tensors must be 16-byte aligned"); return DM4D_ERR_INVALID; }
     hipStream_t st = (hipStream_t)stream;
-    int n_w = d.IN * kW;
-    for (int k = 0; k < d.n_heads; ++k) n_w += kW * kW + kW * d.out_dim[k];
+    const int n_w = d.IN * kW + d.n_heads * kW * kW;
     hipLaunchKernelGGL(k_mlp_pack, dim3((n_w + 255) / 256), dim3(256), 0, st, d);
     DM4D_HIP_CHECK(hipGetLastError());
     hipLaunchKernelGGL(k_mlp_fwd, dim3((P + kRT - 1) / kRT), dim3(256), 0, st, d, feat, h_save, y_save, o[0], o[1], o[2], o[3]);
@@ -443,6 +417,10 @@ int dm4d_deform_mlp_backward(int32_t P, const float *feat, const dm4d_mlp_weight
     if (!gw) { set_error("deform_mlp: null gradient struct"); return DM4D_ERR_INVALID; }
     if (P == 0) return DM4D_OK;
     if (!feat || !h_save || !y_save || !g_out || !scratch) { set_error("deform_mlp: null tensor"); return DM4D_ERR_INVALID; }
+    if (!(aligned16(feat) && aligned16(h_save) && aligned16(y_save) && aligned16(g_feat) && aligned16(scratch))) {
+        set_error("deform_mlp: tensors must be 16-byte aligned");
+        return DM4D_ERR_INVALID;
+    }
     const float *g[kMaxHeads] = {nullptr, nullptr, nullptr, nullptr};
     for (int k = 0; k < d.n_heads; ++k) g[k] = g_out[k];   // NULL = zero gradient for that head
     MlpGrads mg;
@@ -450,13 +428,13 @@ int dm4d_deform_mlp_backward(int32_t P, const float *feat, const dm4d_mlp_weight
     mg.W0 = gw->W0; mg.b0 = gw->b0;
     for (int k = 0; k < d.n_heads; ++k) { mg.W1[k] = gw->W1[k]; mg.b1[k] = gw->b1[k]; mg.W2[k] = gw->W2[k]; mg.b2[k] = gw->b2[k]; }
     hipStream_t st = (hipStream_t)stream;
-    const int n_wg = (P + kRT - 1) / kRT;
-    size_t wt = (size_t)kW * d.IN + (size_t)d.n_heads * (kW * kW + kW * kMaxOut);
-    float *partial = (float *)scratch + wt;
-    hipLaunchKernelGGL(k_mlp_bwd, dim3(n_wg), dim3(256), 0, st, d, feat, h_save, y_save, g[0], g[1], g[2], g[3], g_feat, partial);
+    hipLaunchKernelGGL(k_mlp_bwd, dim3((P + kRT - 1) / kRT), dim3(256), 0, st, d, h_save, g[0], g[1], g[2], g[3], g_feat);
+    DM4D_HIP_CHECK(hipGetLastError());
+    const int n_tiles = 4 * (d.IN / 16 + 1) + 25 * d.n_heads;
+    hipLaunchKernelGGL(k_mlp_wgrad, dim3(n_tiles, kKSplit), dim3(256), 0, st, d, feat, h_save, y_save, g[0], g[1], g[2], g[3]);
     DM4D_HIP_CHECK(hipGetLastError());
     const size_t n = partial_floats(d);
-    hipLaunchKernelGGL(k_mlp_reduce, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d, mg, (const float *)partial, n_wg);
+    hipLaunchKernelGGL(k_mlp_reduce, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d, mg, kKSplit);
     DM4D_HIP_CHECK(hipGetLastError());
     return DM4D_OK;
 }
