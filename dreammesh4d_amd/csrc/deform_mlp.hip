@@ -8,7 +8,7 @@
 //     out_k = W2_k y_k + b2_k                                Linear(64, {3, 6, 4, 1})
 // as ~12 GEMV-sized linears plus ~25 elementwise kernels forward and ~45 backward per step -- for
 // 4000 rows.  Here every product is a chain of v_mfma_f32_16x16x4_f32 (f32 in, f32 accumulate: exact
-// float32, bitwise an fmaf chain), 2 launches forward and 3 backward.
+// float32, bitwise an fmaf chain), 1 launch forward and 3 backward.
 //
 // Everything is computed TRANSPOSED: features are the M dimension of the MFMA, the 16 data rows of a
 // workgroup its N dimension.  The D tile of one layer -- lane l holds features 4 (l >> 4) .. + 3 of data row
@@ -16,9 +16,8 @@
 // register), so activations go from layer to layer without a transpose; only the four 16-feature tiles of a
 // 64-wide layer (one per wave) are exchanged through 4 KB of LDS.  The A operands are rows of the weights
 // in their nn.Linear layout ([out][in]: lane l reads W[16 w + (l & 15)][16 s + 4 (l >> 4) .. + 3] as one
-// float4); the backward's transposed products read the [in][out] copies k_mlp_pack writes.
+// float4); the backward's transposed products read [in][out] copies that the forward writes on the side.
 //
-//   k_mlp_pack  : W0, W1_k -> transposed copies (once per forward call)
 //   k_mlp_fwd   : workgroup = 16 rows x 4 waves (wave = 16 of the 64 features); saves h and y_k
 //   k_mlp_bwd   : workgroup = 16 rows: dy_k, dx, dh (kept for k_mlp_wgrad), d feat
 //   k_mlp_wgrad : every parameter gradient is sum_rows L[row][m] R[row][n]; one workgroup per 16x16 output
@@ -46,7 +45,7 @@ struct MlpDesc {
     int out_dim[kMaxHeads];
     const float *W0, *b0;
     const float *W1[kMaxHeads], *b1[kMaxHeads], *W2[kMaxHeads], *b2[kMaxHeads];
-    float *W0T;                 // [IN][64]
+    float *W0T;                 // [IN][64]          transposed copies for the backward (written by the forward)
     float *W1T[kMaxHeads];      // [64 in][64 out]
     float *DY;                  // [n_heads][P][64]  dL/dy_k   (backward)
     float *DH;                  // [P][64]           dL/dh     (backward)
@@ -77,22 +76,6 @@ __device__ __forceinline__ f32x4 mfma4(const float4 a, const float4 b, f32x4 c)
 __device__ __forceinline__ float4 ld4(const float *p) { return *reinterpret_cast<const float4 *>(p); }
 __device__ __forceinline__ float4 to4(const f32x4 v) { return make_float4(v.x, v.y, v.z, v.w); }
 
-// ------------------------------------------------------------------------------------------ pack
-__global__ void k_mlp_pack(MlpDesc d)
-{
-    const int gid = blockIdx.x * 256 + threadIdx.x;
-    if (gid < d.IN * kW) {   // W0 [64][IN] -> W0T [IN][64]
-        const int i = gid / kW, o = gid % kW;
-        d.W0T[gid] = d.W0[(size_t)o * d.IN + i];
-        return;
-    }
-    const int e = gid - d.IN * kW, k = e / (kW * kW);
-    if (k < d.n_heads) {
-        const int r = e % (kW * kW), i = r / kW, o = r % kW;
-        d.W1T[k][r] = d.W1[k][o * kW + i];
-    }
-}
-
 // ------------------------------------------------------------------------------------------ forward
 __global__ __launch_bounds__(256) void k_mlp_fwd(MlpDesc d, const float *__restrict__ feat, float *__restrict__ Hs,
                                                  float *__restrict__ Ys, float *out0, float *out1, float *out2,
@@ -111,12 +94,28 @@ __global__ __launch_bounds__(256) void k_mlp_fwd(MlpDesc d, const float *__restr
     const int fo = 16 * w + 4 * kq;                      // first of this lane's 4 output features
     const float4 b0 = ld4(d.b0 + fo);
     f32x4 acc0 = {b0.x, b0.y, b0.z, b0.w}, acc1 = {0.f, 0.f, 0.f, 0.f};
-    __syncthreads();
+    // every A operand of the wave (its 16 rows of W0 and of the heads' W1) is requested up front: one memory
+    // round trip for the whole kernel instead of one per 16 inputs
+    float4 wa[kMaxIn / 16], wh[kMaxHeads][4];
     {
         const float *__restrict__ Wrow = d.W0 + (size_t)(16 * w + i) * IN + 4 * kq;
-        for (int s = 0; s < IN / 16; s += 2) {           // two accumulators: the chains do not wait on each other
-            acc0 = mfma4(ld4(Wrow + 16 * s), s_f[(4 * s + kq) * kXs + i], acc0);
-            acc1 = mfma4(ld4(Wrow + 16 * s + 16), s_f[(4 * s + 4 + kq) * kXs + i], acc1);
+#pragma unroll
+        for (int s = 0; s < kMaxIn / 16; ++s)
+            if (16 * s < IN) wa[s] = ld4(Wrow + 16 * s);
+#pragma unroll
+        for (int k = 0; k < kMaxHeads; ++k)
+            if (k < d.n_heads) {
+                const float *__restrict__ W1row = d.W1[k] + (size_t)(16 * w + i) * kW + 4 * kq;
+#pragma unroll
+                for (int s = 0; s < 4; ++s) wh[k][s] = ld4(W1row + 16 * s);
+            }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int s = 0; s < kMaxIn / 16; s += 2) {           // two accumulators: the chains do not wait on each other
+        if (16 * s < IN) {
+            acc0 = mfma4(wa[s], s_f[(4 * s + kq) * kXs + i], acc0);
+            acc1 = mfma4(wa[s + 1], s_f[(4 * s + 4 + kq) * kXs + i], acc1);
         }
     }
     const f32x4 h = acc0 + acc1;
@@ -124,14 +123,15 @@ __global__ __launch_bounds__(256) void k_mlp_fwd(MlpDesc d, const float *__restr
     const f32x4 x = {fmaxf(h.x, 0.f), fmaxf(h.y, 0.f), fmaxf(h.z, 0.f), fmaxf(h.w, 0.f)};
     s_x[(4 * w + kq) * kXs + i] = to4(x);
     __syncthreads();
-    for (int k = 0; k < d.n_heads; ++k) {
+#pragma unroll
+    for (int k = 0; k < kMaxHeads; ++k) {
+        if (k >= d.n_heads) break;
         const float4 b1 = ld4(d.b1[k] + fo);
         f32x4 a0 = {x.x + b1.x, x.y + b1.y, x.z + b1.z, x.w + b1.w}, a1 = {0.f, 0.f, 0.f, 0.f};
-        const float *__restrict__ Wrow = d.W1[k] + (size_t)(16 * w + i) * kW + 4 * kq;
-        a0 = mfma4(ld4(Wrow), s_x[kq * kXs + i], a0);
-        a1 = mfma4(ld4(Wrow + 16), s_x[(4 + kq) * kXs + i], a1);
-        a0 = mfma4(ld4(Wrow + 32), s_x[(8 + kq) * kXs + i], a0);
-        a1 = mfma4(ld4(Wrow + 48), s_x[(12 + kq) * kXs + i], a1);
+        a0 = mfma4(wh[k][0], s_x[kq * kXs + i], a0);
+        a1 = mfma4(wh[k][1], s_x[(4 + kq) * kXs + i], a1);
+        a0 = mfma4(wh[k][2], s_x[(8 + kq) * kXs + i], a0);
+        a1 = mfma4(wh[k][3], s_x[(12 + kq) * kXs + i], a1);
         const f32x4 y = a0 + a1;
         if (row < d.P) *reinterpret_cast<float4 *>(Ys + ((size_t)k * d.P + row) * kW + fo) = to4(y);
         s_y[k][(4 * w + kq) * kXs + i] = to4(y);
@@ -155,6 +155,19 @@ __global__ __launch_bounds__(256) void k_mlp_fwd(MlpDesc d, const float *__restr
                 if (4 * kq + j < od) outs[k][(size_t)row * od + 4 * kq + j] = a[j];
         }
     }
+    // side job: this workgroup's slice of the [in][out] copies of W0 and W1_k the backward reads
+    if (d.W0T) {
+        const int n_w = IN * kW + d.n_heads * kW * kW, per = (n_w + (int)gridDim.x - 1) / (int)gridDim.x;
+        const int e1 = min(n_w, ((int)blockIdx.x + 1) * per);
+        for (int e = (int)blockIdx.x * per + tid; e < e1; e += 256) {
+            if (e < IN * kW) {
+                d.W0T[e] = d.W0[(size_t)(e % kW) * IN + e / kW];
+            } else {
+                const int r = e - IN * kW, k = r / (kW * kW), q = r % (kW * kW);
+                d.W1T[k][q] = d.W1[k][(q % kW) * kW + q / kW];
+            }
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------ backward (activations)
@@ -171,7 +184,18 @@ __global__ __launch_bounds__(256) void k_mlp_bwd(MlpDesc d, const float *__restr
     const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
     const float4 hpre = (row < d.P) ? ld4(Hs + (size_t)row * kW + fo) : z;
     f32x4 dx = {0.f, 0.f, 0.f, 0.f};
-    for (int k = 0; k < d.n_heads; ++k) {
+    // the wave's rows of every W1T (A[m = i][k] = W1[k][16 w + i] = W1T[16 w + i][k]), requested up front
+    float4 wh[kMaxHeads][4];
+#pragma unroll
+    for (int k = 0; k < kMaxHeads; ++k)
+        if (k < d.n_heads) {
+            const float *__restrict__ Wrow = d.W1T[k] + (size_t)(16 * w + i) * kW + 4 * kq;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) wh[k][s] = ld4(Wrow + 16 * s);
+        }
+#pragma unroll
+    for (int k = 0; k < kMaxHeads; ++k) {
+        if (k >= d.n_heads) break;
         const int od = d.out_dim[k];
         // dy[f][r] = sum_c W2[c][f] g[r][c]      (A[m = i][k = kq] = W2[4 t + kq][16 w + i], B[kq][n = i] = g[row][4 t + kq])
         f32x4 dy = {0.f, 0.f, 0.f, 0.f};
@@ -187,13 +211,12 @@ __global__ __launch_bounds__(256) void k_mlp_bwd(MlpDesc d, const float *__restr
         __syncthreads();                                   // the previous head's readers are done with s_dy
         s_dy[(4 * w + kq) * kXs + i] = to4(dy);
         __syncthreads();
-        // dx += dy + W1^T dy                     (A[m = i][k] = W1[k][16 w + i] = W1T[16 w + i][k])
-        const float *__restrict__ Wrow = d.W1T[k] + (size_t)(16 * w + i) * kW + 4 * kq;
+        // dx += dy + W1^T dy
         f32x4 a1 = dy;
-        dx = mfma4(ld4(Wrow), s_dy[kq * kXs + i], dx);
-        a1 = mfma4(ld4(Wrow + 16), s_dy[(4 + kq) * kXs + i], a1);
-        dx = mfma4(ld4(Wrow + 32), s_dy[(8 + kq) * kXs + i], dx);
-        a1 = mfma4(ld4(Wrow + 48), s_dy[(12 + kq) * kXs + i], a1);
+        dx = mfma4(wh[k][0], s_dy[kq * kXs + i], dx);
+        a1 = mfma4(wh[k][1], s_dy[(4 + kq) * kXs + i], a1);
+        dx = mfma4(wh[k][2], s_dy[(8 + kq) * kXs + i], dx);
+        a1 = mfma4(wh[k][3], s_dy[(12 + kq) * kXs + i], a1);
         dx = dx + a1;
     }
     const f32x4 dh = {hpre.x > 0.f ? dx.x : 0.f, hpre.y > 0.f ? dx.y : 0.f, hpre.z > 0.f ? dx.z : 0.f, hpre.w > 0.f ? dx.w : 0.f};
@@ -203,12 +226,15 @@ __global__ __launch_bounds__(256) void k_mlp_bwd(MlpDesc d, const float *__restr
     // d feat[r][in] = sum_o W0[o][in] dh[r][o]   (M tiles of 16 inputs, wave w takes tiles w, w + 4, ...)
     if (g_feat) {
         for (int mt = w; mt < IN / 16; mt += 4) {
-            const float *__restrict__ Wrow = d.W0T + (size_t)(16 * mt + i) * kW + 4 * kq;
+            const float *__restrict__ Wrow = d.W0T + (size_t)(16 * mt + i) * kW + 4 * kq;   // A[m = i][k = o] = W0[o][16 mt + i]
+            float4 wc[4];
+#pragma unroll
+            for (int s = 0; s < 4; ++s) wc[s] = ld4(Wrow + 16 * s);
             f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
-            a0 = mfma4(ld4(Wrow), s_dh[kq * kXs + i], a0);
-            a1 = mfma4(ld4(Wrow + 16), s_dh[(4 + kq) * kXs + i], a1);
-            a0 = mfma4(ld4(Wrow + 32), s_dh[(8 + kq) * kXs + i], a0);
-            a1 = mfma4(ld4(Wrow + 48), s_dh[(12 + kq) * kXs + i], a1);
+            a0 = mfma4(wc[0], s_dh[kq * kXs + i], a0);
+            a1 = mfma4(wc[1], s_dh[(4 + kq) * kXs + i], a1);
+            a0 = mfma4(wc[2], s_dh[(8 + kq) * kXs + i], a0);
+            a1 = mfma4(wc[3], s_dh[(12 + kq) * kXs + i], a1);
             if (row < d.P) *reinterpret_cast<float4 *>(g_feat + (size_t)row * IN + 16 * mt + 4 * kq) = to4(a0 + a1);
         }
     }
@@ -261,19 +287,18 @@ __global__ __launch_bounds__(256) void k_mlp_wgrad(MlpDesc d, const float *__res
     const int mcol = 16 * mt + i, ncol = 16 * nt + i;
     const bool mok = L != nullptr && mcol < Mdim;
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-    for (int s = s0 + w; s < s1; s += 4) {
-        const int r = 4 * s + kq;
-        const bool rok = r < P;
-        const float a = (mok && rok) ? L[(size_t)r * ldL + mcol] : 0.f;
-        float b = 0.f;
-        if (rok) {
-            if (bias) b = 1.f;
-            else {
-                b = R[(size_t)r * ldR + ncol];
-                if (relu) b = fmaxf(b, 0.f);
-            }
+    constexpr int kU = 8;                  // steps whose operands are requested together
+    for (int sb = s0 + w; sb < s1; sb += 4 * kU) {
+        float a[kU], b[kU];
+#pragma unroll
+        for (int u = 0; u < kU; ++u) {
+            const int s = sb + 4 * u, r = 4 * s + kq;
+            const bool rok = s < s1 && r < P;
+            a[u] = (mok && rok) ? L[(size_t)r * ldL + mcol] : 0.f;
+            b[u] = !rok ? 0.f : bias ? 1.f : R[(size_t)r * ldR + ncol];
         }
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc, 0, 0, 0);
+#pragma unroll
+        for (int u = 0; u < kU; ++u) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u], relu ? fmaxf(b[u], 0.f) : b[u], acc, 0, 0, 0);
     }
     // ---- waves 1..3 -> LDS, wave 0 adds them in order and writes the partial ----
     if (w > 0) {
@@ -354,13 +379,13 @@ static int fill_mlp(MlpDesc &d, int P, const dm4d_mlp_weights *w, void *scratch)
     scratch_floats(P, d.IN, d.n_heads, &dy_off, &dh_off, &part_off);
     d.W0T = s;
     for (int k = 0; k < d.n_heads; ++k) {
+        d.W1T[k] = s ? s + (size_t)kW * d.IN + (size_t)k * kW * kW : nullptr;
         if (w->out_dim[k] < 1 || w->out_dim[k] > kMaxOut || !w->W1[k] || !w->b1[k] || !w->W2[k] || !w->b2[k]) {
             set_error("deform_mlp: head %d incomplete or out_dim %d > %d", k, w->out_dim[k], kMaxOut);
             return DM4D_ERR_INVALID;
         }
         d.out_dim[k] = w->out_dim[k];
         d.W1[k] = w->W1[k]; d.b1[k] = w->b1[k]; d.W2[k] = w->W2[k]; d.b2[k] = w->b2[k];
-        d.W1T[k] = s ? s + (size_t)kW * d.IN + (size_t)k * kW * kW : nullptr;
     }
     d.DY = s ? s + dy_off : nullptr;
     d.DH = s ? s + dh_off : nullptr;
@@ -399,9 +424,6 @@ int dm4d_deform_mlp_forward(int32_t P, const float *feat, const dm4d_mlp_weights
     }
     if (!al) { set_error("deform_mlp: tensors must be 16-byte aligned"); return DM4D_ERR_INVALID; }
     hipStream_t st = (hipStream_t)stream;
-    const int n_w = d.IN * kW + d.n_heads * kW * kW;
-    hipLaunchKernelGGL(k_mlp_pack, dim3((n_w + 255) / 256), dim3(256), 0, st, d);
-    DM4D_HIP_CHECK(hipGetLastError());
     hipLaunchKernelGGL(k_mlp_fwd, dim3((P + kRT - 1) / kRT), dim3(256), 0, st, d, feat, h_save, y_save, o[0], o[1], o[2], o[3]);
     DM4D_HIP_CHECK(hipGetLastError());
     return DM4D_OK;
