@@ -177,10 +177,12 @@ __global__ __launch_bounds__(256) void k_hex_bwd_spatial(HexDesc d, const float 
     hg.g[s * kHexPlanes + p][plane_elem(d, c, HW, (size_t)sp_texel[u])] = acc;
 }
 
-// Time planes: one workgroup per (touched column, time-row slot).  The distinct time rows of the step
-// (<= 2 B: the two time texels of every frame, merged in a fixed order) are the same for every column of a
-// scale, so blockIdx.y enumerates row slots and a thread sums, over an eighth of the column's items, only the
-// frames that touch its row (a serial loop over all items of a coarse-scale column was latency-bound).
+// Time planes: one workgroup per touched column.  A column's gradient at time row y is
+//   sum_f w(y, f) * sum_items wcol(item) * G[f][node(item)]
+// -- the inner sum does not depend on the row, so a thread (channel, item lane q) accumulates ONE value per frame
+// over the items e = e0 + q, e0 + q + 8, ... (every G element is read once), the 8 item lanes are added in lane
+// order, and the column's distinct time rows (<= 2 B: the two time texels of every frame, merged in a fixed
+// order) are then combined from the per-frame sums.  Deterministic.
 //   tp_scale[u], tp_plane[u], tp_col[u]; tp_off[U+1], tp_item[] = node * 2 + corner (column corner)
 constexpr int kHexMaxFrames = 16;
 __global__ __launch_bounds__(256) void k_hex_bwd_time(HexDesc d, const float *__restrict__ nodes,
@@ -192,53 +194,38 @@ __global__ __launch_bounds__(256) void k_hex_bwd_time(HexDesc d, const float *__
                                                       const int32_t *__restrict__ tp_item,
                                                       const float *__restrict__ G, HexGrads hg)
 {
-    __shared__ int s_rows[kHexMaxScales][2 * kHexMaxFrames], s_r0[kHexMaxScales][kHexMaxFrames],
-        s_r1[kHexMaxScales][kHexMaxFrames], s_nrows[kHexMaxScales];
-    __shared__ float s_wy[kHexMaxScales][kHexMaxFrames];
+    __shared__ int s_rows[2 * kHexMaxFrames], s_r0[kHexMaxFrames], s_r1[kHexMaxFrames], s_nrows;
+    __shared__ float s_wy[kHexMaxFrames];
+    __shared__ float s_part[8][kHexMaxFrames][kHexCh];
     const int tid = threadIdx.x;
-    if (tid < d.S) {
-        const int sc = tid, Ht = d.res[sc][3];
+    const int u = blockIdx.x;
+    const int s = tp_scale[u], p = tp_plane[u];
+    const int a0 = c_axis0[p];
+    const int W = d.res[s][a0], H = d.res[s][3];
+    if (tid == 0) {
         int nrows = 0;
         for (int f = 0; f < d.B; ++f) {
             int y0;
             float wy;
-            texel_coord(times[f], Ht, y0, wy);
-            const int yy[2] = {y0, min(y0 + 1, Ht - 1)};
+            texel_coord(times[f], H, y0, wy);
+            const int yy[2] = {y0, min(y0 + 1, H - 1)};
             int slot[2];
             for (int k = 0; k < 2; ++k) {
                 int r = 0;
-                while (r < nrows && s_rows[sc][r] != yy[k]) ++r;
-                if (r == nrows) s_rows[sc][nrows++] = yy[k];
+                while (r < nrows && s_rows[r] != yy[k]) ++r;
+                if (r == nrows) s_rows[nrows++] = yy[k];
                 slot[k] = r;
             }
-            s_r0[sc][f] = slot[0];
-            s_r1[sc][f] = slot[1];
-            s_wy[sc][f] = wy;
+            s_r0[f] = slot[0];
+            s_r1[f] = slot[1];
+            s_wy[f] = wy;
         }
-        s_nrows[sc] = nrows;
+        s_nrows = nrows;
     }
-    __syncthreads();
-    // workgroup = one (touched column u, row slot r): 32 channels x 8 item lanes; item lane q sums the items
-    // e = e0 + q, e0 + q + 8, ... and the 8 partials are added in lane order (fixed: deterministic)
-    __shared__ float s_part[8][kHexCh];
-    const int u = blockIdx.x, r = blockIdx.y;
     const int c = tid & (kHexCh - 1), q = tid >> 5;
-    const int s = tp_scale[u], p = tp_plane[u];
-    if (r >= s_nrows[s]) return;              // uniform for the workgroup
-    const int a0 = c_axis0[p];
-    const int W = d.res[s][a0], H = d.res[s][3];
-    // per frame: weight of this row (0 if the frame does not touch it); both texels may coincide at the border
-    float wf[kHexMaxFrames];
+    float acc[kHexMaxFrames];
 #pragma unroll
-    for (int f = 0; f < kHexMaxFrames; ++f) {
-        wf[f] = 0.f;
-        if (f < d.B) {
-            const float wy = s_wy[s][f];
-            if (s_r0[s][f] == r) wf[f] += 1.f - wy;
-            if (s_r1[s][f] == r) wf[f] += wy;
-        }
-    }
-    float acc = 0.f;
+    for (int f = 0; f < kHexMaxFrames; ++f) acc[f] = 0.f;
     for (int e = tp_off[u] + q; e < tp_off[u + 1]; e += 8) {
         const int m = tp_item[e] >> 1, corner = tp_item[e] & 1;
         const float xa = (nodes[3 * (size_t)m + a0] - d.lo[a0]) * d.inv[a0] - 1.0f;
@@ -246,21 +233,32 @@ __global__ __launch_bounds__(256) void k_hex_bwd_time(HexDesc d, const float *__
         float wx;
         texel_coord(xa, W, x0, wx);
         const float wcol = corner ? wx : (1.f - wx);
-        float gs = 0.f;
+        const float *__restrict__ Gm = G + (((size_t)m * d.S + s) * kHexPlanes + p) * kHexCh + c;
+        const size_t fstride = (size_t)d.M * d.S * kHexPlanes * kHexCh;
 #pragma unroll
         for (int f = 0; f < kHexMaxFrames; ++f)
-            if (f < d.B && wf[f] != 0.f)
-                gs += G[((((size_t)f * d.M + m) * d.S + s) * kHexPlanes + p) * kHexCh + c] * wf[f];
-        acc += gs * wcol;
+            if (f < d.B) acc[f] += Gm[f * fstride] * wcol;
     }
-    s_part[q][c] = acc;
-    __syncthreads();
-    if (q == 0) {
-        float t = 0.f;
 #pragma unroll
-        for (int k = 0; k < 8; ++k) t += s_part[k][c];
-        const size_t HW = (size_t)W * H;
-        hg.g[s * kHexPlanes + p][plane_elem(d, c, HW, (size_t)s_rows[s][r] * W + tp_col[u])] = t;
+    for (int f = 0; f < kHexMaxFrames; ++f)
+        if (f < d.B) s_part[q][f][c] = acc[f];
+    __syncthreads();
+    // thread (c, q): time-row slots q, q + 8, ...
+    const size_t HW = (size_t)W * H;
+    for (int r = q; r < s_nrows; r += 8) {
+        float t = 0.f;
+        for (int f = 0; f < d.B; ++f) {
+            float wf = 0.f;
+            if (s_r0[f] == r) wf += 1.f - s_wy[f];
+            if (s_r1[f] == r) wf += s_wy[f];     // both texels may coincide at the border
+            if (wf != 0.f) {
+                float sf = 0.f;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) sf += s_part[k][f][c];
+                t += sf * wf;
+            }
+        }
+        hg.g[s * kHexPlanes + p][plane_elem(d, c, HW, (size_t)s_rows[r] * W + tp_col[u])] = t;
     }
 }
 
@@ -386,7 +384,7 @@ int dm4d_hexplane_backward(int32_t S, int32_t M, int32_t B, const int32_t *res, 
         DM4D_HIP_CHECK(hipGetLastError());
     }
     if (n_time > 0) {
-        hipLaunchKernelGGL(k_hex_bwd_time, dim3((unsigned)n_time, 2 * B), dim3(256), 0, st, d, nodes, times,
+        hipLaunchKernelGGL(k_hex_bwd_time, dim3((unsigned)n_time), dim3(256), 0, st, d, nodes, times,
                            n_time, tp_scale, tp_plane, tp_col, tp_off, tp_item, (const float *)scratch, hg);
         DM4D_HIP_CHECK(hipGetLastError());
     }
