@@ -413,14 +413,31 @@ __global__ __launch_bounds__(kPreThreads) void k_gather_bwd(BatchDesc d)
             R1 = max(R1, (uint32_t)__shfl_xor((int)R1, o2, 64));
         }
         float *chunk = s_chunk[wv];
+        // software pipeline: the next chunk's loads are in flight while this one is summed
+        float4 p0, p1, p2, p3;
+        p0 = p1 = p2 = p3 = make_float4(0.f, 0.f, 0.f, 0.f);
+#define DM4D_FETCH(BASE)                                                                                   \
+        {                                                                                                  \
+            const uint32_t n4_ = min((uint32_t)kGRec, R1 - (BASE)) * (uint32_t)parts;                      \
+            const float4 *src4_ = reinterpret_cast<const float4 *>(dLt + (size_t)(BASE) * RS);             \
+            if ((uint32_t)lane < n4_) p0 = src4_[lane];                                                    \
+            if ((uint32_t)lane + 64u < n4_) p1 = src4_[lane + 64];                                         \
+            if ((uint32_t)lane + 128u < n4_) p2 = src4_[lane + 128];                                       \
+            if (parts > 3 && (uint32_t)lane + 192u < n4_) p3 = src4_[lane + 192];                          \
+        }
+#define DM4D_STAGE(Q, V)                                                                                   \
+        {                                                                                                  \
+            const uint32_t idx4_ = (uint32_t)lane + 64u * (Q);                                             \
+            if (idx4_ < nrec * (uint32_t)parts)                                                            \
+                *reinterpret_cast<float4 *>(chunk + (idx4_ / (uint32_t)parts) * kGStride + (idx4_ % (uint32_t)parts) * 4) = V; \
+        }
+        if (R0 < R1) DM4D_FETCH(R0)
         for (uint32_t base = R0; base < R1; base += kGRec) {
             const uint32_t nrec = min((uint32_t)kGRec, R1 - base);
-            const float4 *src4 = reinterpret_cast<const float4 *>(dLt + (size_t)base * RS);
             __builtin_amdgcn_wave_barrier();
-            for (uint32_t idx4 = lane; idx4 < nrec * (uint32_t)parts; idx4 += 64u) {
-                const uint32_t rr = idx4 / (uint32_t)parts, part = idx4 % (uint32_t)parts;
-                *reinterpret_cast<float4 *>(chunk + rr * kGStride + part * 4) = src4[idx4];
-            }
+            DM4D_STAGE(0, p0) DM4D_STAGE(1, p1) DM4D_STAGE(2, p2)
+            if (parts > 3) DM4D_STAGE(3, p3)
+            if (base + kGRec < R1) DM4D_FETCH(base + kGRec)
             __builtin_amdgcn_wave_barrier();
             const uint32_t lo = max(rec0, base), hi = min(end, base + nrec);
             for (uint32_t slot = lo; slot < hi; ++slot) {
@@ -439,6 +456,8 @@ __global__ __launch_bounds__(kPreThreads) void k_gather_bwd(BatchDesc d)
                 }
             }
         }
+#undef DM4D_FETCH
+#undef DM4D_STAGE
     }
     if (!live) return;
     o.dL_dmeans2D[3 * si + 0] = acc[0];
