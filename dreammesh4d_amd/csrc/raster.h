@@ -41,14 +41,21 @@ constexpr int kCells = 16;       // 4x4-pixel cells per 16x16 tile; cell id = 4 
 DM4D_HD static inline int grad_stride(int C, bool lean = false) { return (C <= 3 || lean) ? 12 : 16; }
 
 // counters[]: duplicates, duplicate-capacity overflow, records (sum of the Gaussians' cells), record-capacity overflow
-enum GeomCounter { kCntD = 0, kCntOverflow = 1, kCntR = 2, kCntRecOverflow = 3 };
+// kCntLong: number of LONG cells (cell lists of >= kLongCell entries, K4 appends them to `longlist`)
+enum GeomCounter { kCntD = 0, kCntOverflow = 1, kCntR = 2, kCntRecOverflow = 3, kCntLong = 4 };
+// A wave of the blend kernels walks four cell lists side by side, one entry per row and step, so the launch cannot
+// end before its longest list (silhouette cells hold > 1000 entries against a mean of 75: measured, the longest
+// wave alone took as long as the whole launch).  Cells with at least this many entries are therefore left out of
+// the regular kernels and blended by k_render_{fwd,bwd}_long: one wave per cell, its four rows evaluating four
+// CONSECUTIVE entries of the one list for the same 16 pixels, the sequential transmittance chain run by row 0.
+constexpr uint32_t kLongCell = 384;
 
 DM4D_HD static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 struct GeomLayout {
     int N, T, nb;
     size_t counters, xy, depth, conic_opacity, rgb, tiles_touched, rec_touched, cellinfo, cellmask, clamped,
-        block_sums, rec_block_sums, hist, tile_count, tile_start, ccount, cdone, ckmax, order, zero_begin, zero_bytes, total;
+        block_sums, rec_block_sums, hist, tile_count, tile_start, ccount, cdone, ckmax, order, longlist, zero_begin, zero_bytes, total;
 };
 
 DM4D_HD static inline size_t take_(size_t &o, size_t bytes) { size_t r = o; o = align_up(o + bytes, 256); return r; }
@@ -72,6 +79,7 @@ DM4D_HD static inline GeomLayout geom_layout(int N, int H, int W)
     L.cdone = take_(o, (size_t)L.T * kCells * 4);    // entries the forward consumed               [T][16]
     L.ckmax = take_(o, (size_t)L.T * kCells * 4);    // tile-list position bound of those entries  [T][16]
     L.order = take_(o, (size_t)L.T * 4);             // tiles by descending list length (blend launch order)
+    L.longlist = take_(o, (size_t)L.T * kCells * 4); // tile * 16 + cell of the long cells, in no particular order
     L.xy = take_(o, n * 8);
     L.depth = take_(o, n * 4);
     L.conic_opacity = take_(o, n * 16);
@@ -108,6 +116,7 @@ struct GeomPtrs {
     uint32_t *cdone;
     uint32_t *ckmax;
     uint32_t *order;
+    uint32_t *longlist;
 };
 
 DM4D_HD static inline GeomPtrs geom_ptrs(void *base, const GeomLayout &L)
@@ -133,6 +142,7 @@ DM4D_HD static inline GeomPtrs geom_ptrs(void *base, const GeomLayout &L)
     p.cdone = (uint32_t *)(b + L.cdone);
     p.ckmax = (uint32_t *)(b + L.ckmax);
     p.order = (uint32_t *)(b + L.order);
+    p.longlist = (uint32_t *)(b + L.longlist);
     return p;
 }
 
@@ -371,6 +381,10 @@ int launch_preprocess(const BatchDesc &d, hipStream_t st);
 int launch_colscan(const BatchDesc &d, hipStream_t st);
 int launch_scatter(const BatchDesc &d, hipStream_t st);
 int launch_tile_sort(const BatchDesc &d, hipStream_t st);
+// per-device helper stream for launches that run beside the caller's stream (fork / join events); nullptr if it
+// cannot be created (callers then launch on the caller's stream)
+struct AuxStream { hipStream_t st; hipEvent_t fork, join; bool ok; };
+AuxStream *aux_stream();
 int launch_render_fwd(const BatchDesc &d, hipStream_t st);
 int launch_render_bwd(const BatchDesc &d, hipStream_t st);
 int launch_gather_bwd(const BatchDesc &d, hipStream_t st);

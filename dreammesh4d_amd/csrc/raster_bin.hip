@@ -198,7 +198,11 @@ __device__ __forceinline__ void finish_tile(const ViewCtx &c, int tile, uint32_t
         }
         __syncthreads();
     }
-    if (tid < kCells) g.ccount[tile * kCells + tid] = s_cbase[tid];
+    if (tid < kCells) {
+        g.ccount[tile * kCells + tid] = s_cbase[tid];
+        // long cells are blended by their own kernels (raster.h, kLongCell); which slot a cell gets does not matter
+        if (s_cbase[tid] >= kLongCell) g.longlist[atomicAdd(&g.counters[kCntLong], 1u)] = (uint32_t)(tile * kCells + tid);
+    }
 }
 
 template <int kSortThreads>
@@ -397,9 +401,8 @@ int launch_colscan(const BatchDesc &d, hipStream_t st)
 
 // The few tiles of > 2048 entries (silhouettes) would bound K4 from below on the 256-thread variant (their
 // keys do not fit its LDS): they run on the 1024-thread / 104 KB variant, concurrently on a helper stream.
-struct AuxStream { hipStream_t st; hipEvent_t fork, join; bool ok; };
 static AuxStream g_aux[64] = {};
-static AuxStream *aux_stream()
+AuxStream *aux_stream()
 {
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;

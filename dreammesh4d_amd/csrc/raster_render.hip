@@ -361,14 +361,15 @@ __global__ __launch_bounds__(64) void k_render_bwd(BatchDesc d)
     const f2v pxf = (f2v)((float)px), pyf = (f2v)((float)py);
 
     const uint32_t s = g.tile_start[tile];
-    const uint32_t nd = (s < cap) ? g.cdone[tile * kCells + lp.cell] : 0u;   // entries this row's forward consumed
+    uint32_t nr = (s < cap) ? g.ccount[tile * kCells + lp.cell] : 0u;
+    uint32_t nd = (s < cap) ? g.cdone[tile * kCells + lp.cell] : 0u;   // entries this row's forward consumed
+    if (nr >= kLongCell) nr = nd = 0u;                                  // long cell: k_render_bwd_long's
     const uint32_t ndmax = wave_max_u32(nd);
     const uint2 *__restrict__ list = b.clist + (size_t)lp.cell * b.cap + s;
     const uint32_t *__restrict__ slots = b.cslot + (size_t)lp.cell * b.cap + s;
     {
         // entries the forward never reached get all-zero records, so that B2 can sum every Gaussian's
         // contiguous record block without looking anything up
-        const uint32_t nr = (s < cap) ? g.ccount[tile * kCells + lp.cell] : 0u;
         for (uint32_t j = nd + (uint32_t)li; j < nr; j += 16u) {
             const uint32_t slot = slots[j];
             if (slot < rec_cap) {
@@ -510,7 +511,192 @@ __global__ __launch_bounds__(64) void k_render_bwd(BatchDesc d)
     trace.done(ndmax);
 }
 
+// ---------------------------------------------------------------------------------------- B1 (long cells)
+// One wave per long cell (raster.h, kLongCell).  Lane = (entry slot r = lane >> 4, pixel p = lane & 15 of the cell):
+// the four rows take four CONSECUTIVE list entries of the one cell for the same 16 pixels.  Per step: every row
+// evaluates alpha and V of its entry; row 0 runs the sequential (T, S) chain over the four entries back to front
+// and hands (w, dL/dalpha) back; every row then forms the gradient values of its entry and reduces them over its
+// 16 lanes exactly as k_render_bwd does.  Same operations on the same values in the same order: the records are
+// bit-identical, but a 1200-entry silhouette cell no longer costs the launch 1200 serial reduction round trips.
+// Staging (64 entries per chunk, one per lane): [0..5] x y A B C opacity | [6] k bits | [8..13] colours | [14] depth | [15] 1
+template <int C, bool LEAN>
+__global__ __launch_bounds__(64) void k_render_bwd_long(BatchDesc d)
+{
+    constexpr int RS = LEAN ? 9 : 7 + C;
+    constexpr int RSP = (C <= 3 || LEAN) ? 12 : 16;
+    __shared__ __attribute__((aligned(16))) float s_e[64 * 16];
+    __shared__ uint32_t s_slot[64];
+    __shared__ __attribute__((aligned(16))) float s_x1[16 * 8];    // [pixel][entry slot] (alpha or -1, V)
+    __shared__ __attribute__((aligned(16))) float s_x2[64 * 2];    // [entry slot][pixel] (w, dL/dalpha)
+    __shared__ __attribute__((aligned(16))) float s_red[RS][kRedStride];
+    const int view = (int)(blockIdx.x % (uint32_t)d.B);
+    const uint32_t first = blockIdx.x / (uint32_t)d.B, step = gridDim.x / (uint32_t)d.B;
+    const ViewCtx c = resolve(d, view);
+    const ViewParams &vp = c.vp;
+    const float *__restrict__ colors = c.colors;
+    const GeomPtrs &g = c.g;
+    const BinPtrs &b = c.b;
+    const ImgPtrs &im = c.im;
+    float *__restrict__ rec = c.dLq;
+    const uint32_t rec_cap = c.rec_cap;
+    const int lane = threadIdx.x, r = lane >> 4, p = lane & 15;
+    const uint32_t n_long = min(g.counters[kCntLong], (uint32_t)(c.T * kCells));
+    const f2v halfWH = f2v{0.5f * (float)vp.W, 0.5f * (float)vp.H};
+    const int red_i = p < RS ? p : 0;
+    const float4 *red_src = reinterpret_cast<const float4 *>(&s_red[red_i][r * 16]);
+    for (uint32_t it = first; it < n_long; it += step) {
+        const uint32_t cellid = g.longlist[it];
+        const int tile = (int)(cellid / kCells), cell = (int)(cellid % kCells);
+        const int tx = tile % vp.gx, ty = tile / vp.gx, q = cell >> 2, rw = cell & 3;
+        const int px = tx * kTile + (q & 1) * 8 + (rw & 1) * 4 + (p & 3);
+        const int py = ty * kTile + (q >> 1) * 8 + (rw >> 1) * 4 + (p >> 2);
+        const bool inside = px < vp.W && py < vp.H;
+        const float pxf = (float)px, pyf = (float)py;
+        const uint32_t s = g.tile_start[tile];
+        const uint32_t nr = g.ccount[cellid], nd = min(g.cdone[cellid], nr);
+        const uint2 *__restrict__ list = b.clist + (size_t)cell * b.cap + s;
+        const uint32_t *__restrict__ slots = b.cslot + (size_t)cell * b.cap + s;
+        for (uint32_t j = nd + (uint32_t)lane; j < nr; j += 64u) {     // zero records for the unconsumed entries
+            const uint32_t slot = slots[j];
+            if (slot < rec_cap) {
+                float4 *dst = reinterpret_cast<float4 *>(rec + (size_t)slot * RSP);
+#pragma unroll
+                for (int i = 0; i < RSP / 4; ++i) dst[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
+        if (nd == 0u) continue;
+        // every row holds the pixel's upstream gradients (V and the contribution test need them)
+        const size_t P = (size_t)vp.H * vp.W;
+        const size_t pid = (size_t)py * vp.W + px;
+        float T_final = 0.f, gD = 0.f, gA = 0.f;
+        float gCol[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        uint32_t last = 0;
+        if (inside) {
+            T_final = im.final_T[pid];
+            last = im.n_contrib[pid];
+#pragma unroll
+            for (int ch = 0; ch < C; ++ch) gCol[ch] = c.dL_dcolor[ch * P + pid];
+            if (c.dL_ddepth) gD = c.dL_ddepth[pid];
+            if (c.dL_dalpha) gA = c.dL_dalpha[pid];
+        }
+        float bgdot = 0.f;
+#pragma unroll
+        for (int ch = 0; ch < C; ++ch) bgdot += vp.bg[ch] * gCol[ch];
+        const float Tb = T_final * bgdot;
+        float T_ = T_final, S = 0.f;
+        const f2v g01 = f2v{gCol[0], gCol[1]}, g23 = f2v{gCol[2], gCol[3]}, g45 = f2v{gCol[4], gCol[5]}, gDA = f2v{gD, gA};
+
+        const uint32_t c_last = ((nd - 1u) / 64u) * 64u;
+        float4 e[4];
+        uint32_t eslot = 0;
+        zero_entry(e);
+        if (c_last + (uint32_t)lane < nd) {
+            gather_entry<C>(list[c_last + lane], g, colors, e);
+            eslot = slots[c_last + lane];
+        }
+        for (uint32_t c0 = c_last;; c0 -= 64u) {
+            const int cnt = (int)min(64u, nd - c0);
+            __builtin_amdgcn_wave_barrier();
+            {
+                float *se = s_e + lane * 16;
+                *reinterpret_cast<float4 *>(se) = e[0];                                              // x y A B
+                *reinterpret_cast<float4 *>(se + 4) = make_float4(e[1].x, e[1].y, e[1].w, 0.f);     // C opacity k
+                *reinterpret_cast<float4 *>(se + 8) = e[2];                                          // colours 0..3
+                *reinterpret_cast<float4 *>(se + 12) = make_float4(e[3].x, e[3].y, e[1].z, 1.0f);   // colours 4 5, depth, 1
+                s_slot[lane] = eslot;
+            }
+            zero_entry(e);
+            if (c0 >= 64u) {                                               // prefetch the chunk in front (all < nd)
+                gather_entry<C>(list[c0 - 64u + lane], g, colors, e);
+                eslot = slots[c0 - 64u + lane];
+            }
+            __builtin_amdgcn_wave_barrier();
+            for (int tg = ((cnt - 1) / 4) * 4; tg >= 0; tg -= 4) {
+                // ---- every row: its entry t = tg + r (slots past the count hold inert padding: opacity 0) ----
+                const float *se = s_e + (tg + r) * 16;
+                const float4 ga = *reinterpret_cast<const float4 *>(se), gb = *reinterpret_cast<const float4 *>(se + 4);
+                const f4v e0 = *reinterpret_cast<const f4v *>(se + 8), e1 = *reinterpret_cast<const f4v *>(se + 12);
+                const float cA = ga.z, cB = ga.w, cC = gb.x, op = gb.y;
+                const uint32_t k = __float_as_uint(gb.z);
+                const float dx = ga.x - pxf, dy = ga.y - pyf;
+                const float power = -0.5f * ((cA * dx) * dx + (cC * dy) * dy) - (cB * dx) * dy;
+                const float Gr = det_expf(power);
+                const float alpha_r = fminf(0.99f, op * Gr);
+                const bool contrib_r = (k < last) & (power <= 0.0f) & (alpha_r >= 1.0f / 255.0f);
+                f2v va = e1.zw * gDA;
+                va = __builtin_elementwise_fma(e0.xy, g01, va);
+                va = __builtin_elementwise_fma(e0.zw, g23, va);
+                if (C > 3) va = __builtin_elementwise_fma(e1.xy, g45, va);
+                *reinterpret_cast<float2 *>(s_x1 + (p * 4 + r) * 2) = make_float2(contrib_r ? alpha_r : -1.0f, va.x + va.y);
+                __builtin_amdgcn_wave_barrier();
+                // ---- row 0: the sequential chain, back to front ----
+                {
+                    const float4 x01 = *reinterpret_cast<const float4 *>(s_x1 + p * 8), x23 = *reinterpret_cast<const float4 *>(s_x1 + p * 8 + 4);
+                    const float al[4] = {x01.x, x01.z, x23.x, x23.z}, Vv[4] = {x01.y, x01.w, x23.y, x23.w};
+#pragma unroll
+                    for (int h = 3; h >= 0; --h) {
+                        const bool contrib = al[h] >= 0.0f;
+                        const float alpha = contrib ? al[h] : 0.0f;
+                        const float V = Vv[h];
+                        const float inv_om = __builtin_amdgcn_rcpf(1.f - alpha);
+                        const float Tn = T_ * inv_om;
+                        T_ = contrib ? Tn : T_;
+                        const float w = contrib ? alpha * Tn : 0.f;
+                        const float dL_da = contrib ? (Tn * V - (S + Tb) * inv_om) : 0.f;
+                        S = __builtin_fmaf(V, w, S);
+                        if (r == 0) *reinterpret_cast<float2 *>(s_x2 + (h * 16 + p) * 2) = make_float2(w, dL_da);
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
+                // ---- every row: the gradient values of its entry, reduced over its 16 lanes ----
+                const float2 wd = *reinterpret_cast<const float2 *>(s_x2 + (r * 16 + p) * 2);
+                const float w = wd.x, dL_da = wd.y;
+                const float G = contrib_r ? Gr : 0.f;
+                const float dL_dG = op * dL_da;
+                const f2v dxy = f2v{dx, dy};
+                const f2v gd = dxy * (f2v)(G);
+                const f2v t1 = gd * f2v{cA, cC}, t2 = gd.yx * (f2v)(cB);
+                const f2v v01 = ((f2v)(dL_dG) * (-(t1 + t2))) * halfWH;
+                const f2v v24 = ((f2v)(-0.5f) * (gd * dxy)) * (f2v)(dL_dG);
+                const float v3 = (-gd.x * dy) * dL_dG;
+                const f2v ww = (f2v)(w);
+                const f2v c01 = ww * g01, c23 = ww * g23, c45 = ww * g45;
+                float v[13];
+                v[0] = v01.x; v[1] = v01.y; v[2] = v24.x; v[3] = v3; v[4] = v24.y;
+                if (LEAN) {
+                    v[5] = w * gD;
+                    v[6] = c23.y; v[7] = c45.x; v[8] = c45.y;
+                } else {
+                    v[5] = G * dL_da;
+                    v[6] = w * gD;
+                    v[7] = c01.x; v[8] = c01.y; v[9] = c23.x; v[10] = c23.y; v[11] = c45.x; v[12] = c45.y;
+                }
+#pragma unroll
+                for (int i = 0; i < RS; ++i) s_red[i][lane] = v[i];
+                __builtin_amdgcn_wave_barrier();
+                {
+                    const float4 a0 = red_src[0], a1 = red_src[1], a2 = red_src[2], a3 = red_src[3];
+                    f2v p0 = f2v{a0.x, a0.y} + f2v{a0.z, a0.w};
+                    f2v p1 = f2v{a1.x, a1.y} + f2v{a1.z, a1.w};
+                    f2v p2 = f2v{a2.x, a2.y} + f2v{a2.z, a2.w};
+                    f2v p3 = f2v{a3.x, a3.y} + f2v{a3.z, a3.w};
+                    p0 = p0 + p1;
+                    p2 = p2 + p3;
+                    p0 = p0 + p2;
+                    const float total = p < RS ? p0.x + p0.y : 0.f;
+                    const int t = tg + r;
+                    const uint32_t slot = s_slot[t < 64 ? t : 63];
+                    if (p < RSP && t < cnt && slot < rec_cap) rec[(size_t)slot * RSP + p] = total;
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
+            if (c0 == 0u) break;
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------- launchers
+constexpr int kLongWaves = 2048;   // waves per view of the long-cell kernel (each loops over the long cells it owns)
 int launch_render_fwd(const BatchDesc &d, hipStream_t st)
 {
     const int T = ((d.W + kTile - 1) / kTile) * ((d.H + kTile - 1) / kTile);
@@ -530,10 +716,26 @@ int launch_render_bwd(const BatchDesc &d, hipStream_t st)
     const int blocks = (int)((((int64_t)T * d.B + 7) / 8) * 8 * 4);
     ProfScope prof_(kKRenderBwd, st);
     if (d.lean && d.C != 6) { set_error("lean backward records need 6 channels"); return DM4D_ERR_INVALID; }
+    // the long cells go first, on the helper stream, beside the regular kernel
+    AuxStream *a = aux_stream();
+    hipStream_t lst = a ? a->st : st;
+    if (a) {
+        DM4D_HIP_CHECK(hipEventRecord(a->fork, st));
+        DM4D_HIP_CHECK(hipStreamWaitEvent(a->st, a->fork, 0));
+    }
+    const int long_blocks = min(T * kCells, kLongWaves) * d.B;
+    if (d.C <= 3) hipLaunchKernelGGL((k_render_bwd_long<3, false>), dim3(long_blocks), dim3(64), 0, lst, d);
+    else if (d.lean) hipLaunchKernelGGL((k_render_bwd_long<6, true>), dim3(long_blocks), dim3(64), 0, lst, d);
+    else hipLaunchKernelGGL((k_render_bwd_long<6, false>), dim3(long_blocks), dim3(64), 0, lst, d);
+    DM4D_HIP_CHECK(hipGetLastError());
     if (d.C <= 3) hipLaunchKernelGGL((k_render_bwd<3, false>), dim3(blocks), dim3(64), 0, st, d);
     else if (d.lean) hipLaunchKernelGGL((k_render_bwd<6, true>), dim3(blocks), dim3(64), 0, st, d);
     else hipLaunchKernelGGL((k_render_bwd<6, false>), dim3(blocks), dim3(64), 0, st, d);
     DM4D_HIP_CHECK(hipGetLastError());
+    if (a) {
+        DM4D_HIP_CHECK(hipEventRecord(a->join, a->st));
+        DM4D_HIP_CHECK(hipStreamWaitEvent(st, a->join, 0));
+    }
     return DM4D_OK;
 }
 
