@@ -541,6 +541,7 @@ __global__ __launch_bounds__(64) void k_render_bwd_long(BatchDesc d)
     const uint32_t rec_cap = c.rec_cap;
     const int lane = threadIdx.x, r = lane >> 4, p = lane & 15;
     const uint32_t n_long = min(g.counters[kCntLong], (uint32_t)(c.T * kCells));
+    if (first < n_long) __builtin_amdgcn_s_setprio(3);   // the launch's critical path: issue before the regular kernel's waves
     const f2v halfWH = f2v{0.5f * (float)vp.W, 0.5f * (float)vp.H};
     const int red_i = p < RS ? p : 0;
     const float4 *red_src = reinterpret_cast<const float4 *>(&s_red[red_i][r * 16]);
