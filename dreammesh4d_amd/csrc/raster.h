@@ -249,28 +249,41 @@ __device__ __forceinline__ Bands cell_bands(float x, float y, float ca, float cb
     if (nbx > 0 && nby > 0) { B.nbx = nbx; B.nby = nby; }
     return B;
 }
-// Exact refinement of cell_bands for one cell (pixel centres cx0..cx0+3 x cy0..cy0+3): does the ellipse
-// { d : A dx^2 + 2 B dx dy + C dy^2 <= 2 tau } around (x, y) meet the cell's rectangle?  The minimum of the
-// convex form over the rectangle is 0 if the centre is inside, else it lies on one of the four edges, where
-// the form is a 1-D quadratic with a clamped closed-form minimiser.  Margins as in cell_bands (they dwarf
-// the rounding of the blend kernels' own power / exp), so a culled cell holds no pixel with alpha >= 1/255.
-__device__ __forceinline__ bool cell_reached(float x, float y, float A, float B, float C, float tau, float cx0, float cy0)
+// Exact refinement of cell_bands, one ROW of cells at a time.  The ellipse E = { d : A dx^2 + 2 B dx dy + C dy^2 <= L }
+// around (x, y) meets the cell [cx0, cx0 + 3] x [cy0, cy0 + 3] (pixel centres, +- 0.02) iff the cell's column
+// range overlaps the x-extent of E intersected with the row's strip -- E and the strip are convex, so that
+// intersection projects onto an interval [xlo, xhi].  On the strip the right boundary xr(dy) = (-B dy + sqrt(A L -
+// det dy^2)) / A is concave and peaks at dy = -B sqrt(L / (det C)) (the rightmost point of E), the left boundary is
+// its mirror image; clamping those two ordinates to the strip gives the extent with two square roots per ROW,
+// where testing every cell against the four edges cost ~45 operations per CELL (36 of K1's 78 us).  Margins as in
+// cell_bands (they dwarf the rounding of the blend kernels' own power / exp): a culled cell holds no pixel with
+// alpha >= 1/255.
+struct EllipseRows { float L, det, ystar, yext, invA, B; };
+__device__ __forceinline__ EllipseRows ellipse_rows(float A, float B, float C, float tau)
 {
-    const float x0 = cx0 - 0.02f - x, x1 = cx0 + 3.02f - x, y0 = cy0 - 0.02f - y, y1 = cy0 + 3.02f - y;
-    if (x0 <= 0.f && x1 >= 0.f && y0 <= 0.f && y1 >= 0.f) return true;
-    const float lim = 2.0f * tau * 1.0001f + 0.001f;
-    const float rB_C = -B / C, rB_A = -B / A;
-    bool hit = false;
-#pragma unroll
-    for (int e = 0; e < 2; ++e) {
-        const float dx = e ? x1 : x0;
-        const float dy = fminf(y1, fmaxf(y0, rB_C * dx));
-        hit |= (A * dx * dx + 2.0f * B * dx * dy + C * dy * dy) <= lim;
-        const float ey = e ? y1 : y0;
-        const float ex = fminf(x1, fmaxf(x0, rB_A * ey));
-        hit |= (A * ex * ex + 2.0f * B * ex * ey + C * ey * ey) <= lim;
-    }
-    return hit;
+    EllipseRows e;
+    e.L = 2.0f * tau * 1.0001f + 0.001f;
+    e.det = A * C - B * B;
+    e.ystar = B * sqrtf(e.L / (e.det * C));     // |ordinate| of the leftmost / rightmost point
+    e.yext = sqrtf(A * e.L / e.det) * 1.0001f;  // half extent in y
+    e.invA = 1.0f / A;
+    e.B = B;
+    return e;
+}
+// cell columns [b0, b1] (absolute cell indices, possibly empty: b0 > b1) of the row of cells whose pixel centres are
+// cy0 .. cy0 + 3 that the ellipse around (x, y) reaches
+__device__ __forceinline__ void row_span(const EllipseRows &e, float x, float y, float cy0, int &b0, int &b1)
+{
+    const float ya = fmaxf(cy0 - 0.02f - y, -e.yext), yb = fminf(cy0 + 3.02f - y, e.yext);
+    b0 = 1; b1 = 0;
+    if (!(ya <= yb)) return;
+    const float yr = fminf(yb, fmaxf(ya, -e.ystar)), yl = fminf(yb, fmaxf(ya, e.ystar));
+    const float A_L = e.L / e.invA;
+    const float xhi = (-e.B * yr + sqrtf(fmaxf(0.f, A_L - e.det * yr * yr))) * e.invA;
+    const float xlo = (-e.B * yl - sqrtf(fmaxf(0.f, A_L - e.det * yl * yl))) * e.invA;
+    const float m = 1.0e-4f * (fabsf(xhi) + fabsf(xlo)) + 0.02f;      // rounding of the two roots + the pixel margin
+    b0 = f2i_sat(ceilf((x + xlo - m - 3.0f) * 0.25f));
+    b1 = f2i_sat(floorf((x + xhi + m) * 0.25f));
 }
 // cell id inside its tile (cx, cy in 0..3): the four cells of an 8x8 quadrant are consecutive
 __device__ __forceinline__ int cell_id(int cx, int cy) { return 4 * ((cx >> 1) + 2 * (cy >> 1)) + (cx & 1) + 2 * (cy & 1); }

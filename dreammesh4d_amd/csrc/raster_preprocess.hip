@@ -197,11 +197,15 @@ __global__ __launch_bounds__(kPreThreads) void k_preprocess(BatchDesc d)
                         // small block: keep only the cells the ellipse really meets (a third of the cells of the
                         // axis-aligned bound of a thin diagonal splat are empty)
                         const float tau = __logf(255.0f * co.w) * 1.001f + 0.01f;
+                        const EllipseRows er = ellipse_rows(co.x, co.y, co.z, tau);
                         uint64_t mask = 0ull;
-                        for (int by = 0; by < bd.nby; ++by)
-                            for (int bx = 0; bx < bd.nbx; ++bx)
-                                if (cell_reached(px, py, co.x, co.y, co.z, tau, (float)(4 * (bd.bx0 + bx)), (float)(4 * (bd.by0 + by))))
-                                    mask |= 1ull << (by * bd.nbx + bx);
+                        for (int by = 0; by < bd.nby; ++by) {
+                            int b0, b1;
+                            row_span(er, px, py, (float)(4 * (bd.by0 + by)), b0, b1);
+                            b0 = max(b0 - bd.bx0, 0);
+                            b1 = min(b1 - bd.bx0, bd.nbx - 1);
+                            if (b0 <= b1) mask |= ((~0ull >> (63 - (b1 - b0))) << b0) << (by * bd.nbx);
+                        }
                         g.cellmask[i] = mask;
                         recs = (uint32_t)__popcll(mask);
                         dense = 0u;
