@@ -258,9 +258,12 @@ def dynamic_stage_iterations(wl, dev, n=10):
     static = {"q_static": wl.qs, "scales": wl.scales, "opacities": wl.opac, "rgb": wl.rgb}
     ref_img = torch.rand(N_FRAMES, H, W, 3, generator=g).to(dev)
     ref_mask = (torch.rand(N_FRAMES, H, W, 1, generator=g) > 0.5).float().to(dev)
+    from dreammesh4d_amd.mesh_reg import MeshNormalConsistency
+
     stage = DynamicStage(wl.renderer, wl.net, wl.nodes, static, wl.timestamps, ref_img, ref_mask,
                          syn.make_camera(H, W, elev_deg=5.0, azim_deg=0.0), guidance=guid, frames_per_step=FRAMES_PER_STEP,
-                         random_views_per_frame=VIEWS_PER_FRAME - 1)
+                         random_views_per_frame=VIEWS_PER_FRAME - 1,
+                         normal_consistency=MeshNormalConsistency(wl.sc["faces"], len(wl.sc["verts"]), dev))
     for _ in range(3):
         stage.iteration()
     torch.cuda.synchronize(dev)
@@ -270,7 +273,7 @@ def dynamic_stage_iterations(wl, dev, n=10):
     torch.cuda.synchronize(dev)
     dt = time.perf_counter() - t0
     return {"dynamic_stage_iters_per_sec": round(n / dt, 3), "dynamic_stage_ms_per_iteration": round(1e3 * dt / n, 2),
-            "dynamic_stage_note": "8 views/iteration, full-size Zero123 fp16 with random weights, AdamW step included"}
+            "dynamic_stage_note": "8 views/iteration, full-size Zero123 fp16 with random weights, mesh normal consistency, AdamW step included"}
 
 
 def cpu_baseline(wl, n_views):

@@ -96,6 +96,85 @@ __global__ __launch_bounds__(256) void k_arap_bwd(ArapAdj a, const float *__rest
     }
 }
 
+
+// ---------------------------------------------------------------------------------------- normal consistency
+// pytorch3d.loss.mesh_normal_consistency of the T deformed meshes (system/sugar_4dgen.py:214-226, lambda 100 in
+// configs/sugar_dynamic_dg.yaml:146).  For every PAIR of faces that share an edge (v0, v1) with opposite vertices
+// a and b:   n0 = (v1 - v0) x (a - v0),  n1 = -((v1 - v0) x (b - v0)),  term = 1 - cos(n0, n1);
+// loss_t = mean of the terms (pytorch3d then averages over the meshes of the batch).  The pairs are static (the
+// topology never changes), so the forward is one thread per (mesh, pair) and the backward a gather per (mesh,
+// vertex) over the (pair, role) items that touch it -- role 0..3 = v0, v1, a, b -- no atomics, deterministic.
+struct NcPairs { int P; const int32_t *v; /* [P][4] = v0, v1, a, b */ };
+
+__device__ __forceinline__ void cross3(const float a[3], const float b[3], float o[3])
+{
+    o[0] = a[1] * b[2] - a[2] * b[1];
+    o[1] = a[2] * b[0] - a[0] * b[2];
+    o[2] = a[0] * b[1] - a[1] * b[0];
+}
+// e = v1 - v0, a = va - v0, b = vb - v0;  n0 = e x a, m = b x e (= -(e x b)); returns cos, norms clamped at 1e-8
+// the way torch.cosine_similarity clamps them
+__device__ __forceinline__ float nc_pair(const float *__restrict__ xyz, const int32_t *__restrict__ q, float e[3], float a[3],
+                                         float b[3], float n0[3], float m[3], float &l0, float &l1)
+{
+    const float *p0 = xyz + 3 * (size_t)q[0], *p1 = xyz + 3 * (size_t)q[1], *pa = xyz + 3 * (size_t)q[2], *pb = xyz + 3 * (size_t)q[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { e[k] = p1[k] - p0[k]; a[k] = pa[k] - p0[k]; b[k] = pb[k] - p0[k]; }
+    cross3(e, a, n0);
+    cross3(b, e, m);
+    l0 = fmaxf(sqrtf((n0[0] * n0[0] + n0[1] * n0[1]) + n0[2] * n0[2]), 1e-8f);
+    l1 = fmaxf(sqrtf((m[0] * m[0] + m[1] * m[1]) + m[2] * m[2]), 1e-8f);
+    return ((n0[0] * m[0] + n0[1] * m[1]) + n0[2] * m[2]) / (l0 * l1);
+}
+
+__global__ __launch_bounds__(256) void k_nc_fwd(NcPairs pr, int V, const float *__restrict__ xyz, float *__restrict__ terms /* [T][P] */)
+{
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= pr.P) return;
+    const size_t t = blockIdx.y;
+    float e[3], a[3], b[3], n0[3], m[3], l0, l1;
+    const float c = nc_pair(xyz + t * V * 3, pr.v + 4 * (size_t)p, e, a, b, n0, m, l0, l1);
+    terms[t * pr.P + p] = 1.0f - c;
+}
+
+// items of vertex i: item = pair * 4 + role, CSR offsets [V+1]
+__global__ __launch_bounds__(256) void k_nc_bwd(NcPairs pr, int V, const int32_t *__restrict__ off, const int32_t *__restrict__ items,
+                                                const float *__restrict__ xyz, const float *__restrict__ g_loss /* [T] */,
+                                                float *__restrict__ g_xyz)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= V) return;
+    const size_t t = blockIdx.y;
+    const float *x = xyz + t * V * 3;
+    float acc[3] = {0.f, 0.f, 0.f};
+    for (int k = off[i]; k < off[i + 1]; ++k) {
+        const int p = items[k] >> 2, role = items[k] & 3;
+        float e[3], a[3], b[3], n0[3], m[3], l0, l1;
+        const float c = nc_pair(x, pr.v + 4 * (size_t)p, e, a, b, n0, m, l0, l1);
+        // d(1 - c)/dn0 = -(m / (l0 l1) - c n0 / l0^2),  d(1 - c)/dm = -(n0 / (l0 l1) - c m / l1^2)
+        float g0[3], g1[3];
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            g0[d] = -(m[d] / (l0 * l1) - c * n0[d] / (l0 * l0));
+            g1[d] = -(n0[d] / (l0 * l1) - c * m[d] / (l1 * l1));
+        }
+        // n0 = e x a: d/de = a x g0, d/da = g0 x e;   m = b x e: d/db = e x g1, d/de = g1 x b
+        float dE0[3], dE1[3], dA[3], dB[3];
+        cross3(a, g0, dE0);
+        cross3(g1, b, dE1);
+        cross3(g0, e, dA);
+        cross3(e, g1, dB);
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            const float dE = dE0[d] + dE1[d];
+            acc[d] += role == 0 ? -((dE + dA[d]) + dB[d]) : role == 1 ? dE : role == 2 ? dA[d] : dB[d];
+        }
+    }
+    const float s = g_loss[t] / (float)pr.P;
+#pragma unroll
+    for (int d = 0; d < 3; ++d) g_xyz[(t * V + i) * 3 + d] = acc[d] * s;
+}
+
 static int arap_check(int T, int V, const void *off, const void *nbr, const void *rev, const void *w, const void *e,
                       const void *xyz, const void *rot)
 {
@@ -137,6 +216,32 @@ int dm4d_arap_energy_backward(int32_t T, int32_t V, const int32_t *csr_offsets, 
     ArapAdj a{V, csr_offsets, neighbors, reverse_edge, weights, rest_edges};
     hipLaunchKernelGGL(k_arap_bwd, dim3((V + 255) / 256, T), dim3(256), 0, (hipStream_t)stream, a, xyz_prime, rotations, g_energy,
                        g_xyz, g_rotations);
+    DM4D_HIP_CHECK(hipGetLastError());
+    return DM4D_OK;
+}
+
+int dm4d_normal_consistency_forward(int32_t T, int32_t V, int32_t P, const int32_t *pairs, const float *xyz, float *terms,
+                                    dm4d_stream_t stream)
+{
+    if (T < 0 || V < 0 || P < 0) { set_error("normal consistency: negative size"); return DM4D_ERR_INVALID; }
+    if (T == 0 || P == 0) return DM4D_OK;
+    if (!pairs || !xyz || !terms) { set_error("normal consistency: null tensor"); return DM4D_ERR_INVALID; }
+    NcPairs pr{P, pairs};
+    hipLaunchKernelGGL(k_nc_fwd, dim3((P + 255) / 256, T), dim3(256), 0, (hipStream_t)stream, pr, V, xyz, terms);
+    DM4D_HIP_CHECK(hipGetLastError());
+    return DM4D_OK;
+}
+
+int dm4d_normal_consistency_backward(int32_t T, int32_t V, int32_t P, const int32_t *pairs, const int32_t *vert_offsets,
+                                     const int32_t *vert_items, const float *xyz, const float *g_loss, float *g_xyz,
+                                     dm4d_stream_t stream)
+{
+    if (T < 0 || V < 0 || P < 0) { set_error("normal consistency: negative size"); return DM4D_ERR_INVALID; }
+    if (T == 0 || V == 0) return DM4D_OK;
+    if (!pairs || !vert_offsets || !vert_items || !xyz || !g_loss || !g_xyz) { set_error("normal consistency: null tensor"); return DM4D_ERR_INVALID; }
+    NcPairs pr{P > 0 ? P : 1, pairs};
+    hipLaunchKernelGGL(k_nc_bwd, dim3((V + 255) / 256, T), dim3(256), 0, (hipStream_t)stream, pr, V, vert_offsets, vert_items, xyz,
+                       g_loss, g_xyz);
     DM4D_HIP_CHECK(hipGetLastError());
     return DM4D_OK;
 }

@@ -12,8 +12,10 @@ What runs per iteration on each GPU:
   (skinning, face->Gaussian, fused RGB+normal raster) -> SDS loss on the random views (Zero123, fp16,
   no grad through the UNet) + rgb / mask MSE on the reference views -> backward -> ONE gradient
   all-reduce -> AdamW.
-The mesh regularisers (pytorch3d normal consistency, ARAP) of the reference step are "next" rows
- and are not part of this loop yet.
+Of the reference step's mesh regularisers ("next" rows) the normal consistency of the
+step's deformed meshes (system/sugar_4dgen.py:214-226, lambda 100) is part of this loop when a
+`mesh_reg.MeshNormalConsistency` is passed; the ARAP terms (key frame + 10 inter-frames, their own deformation
+queries, :304-311,331-385) are available as `mesh_reg.ARAPCoach` and not wired in here.
 """
 import math
 
@@ -25,17 +27,20 @@ from . import synthetic as syn
 from .schedule import C
 from .views import render_views
 
-LAMBDA = {"sds_zero123": 0.1, "rgb": 5000.0, "mask": [200, 500.0, 5000.0, 1000]}   # sugar_dynamic_dg.yaml:135-158
+LAMBDA = {"sds_zero123": 0.1, "rgb": 5000.0, "mask": [200, 500.0, 5000.0, 1000],      # sugar_dynamic_dg.yaml:135-158
+          "normal_consistency": 100.0}
 
 
 class DynamicStage:
     def __init__(self, renderer, net, nodes, static, timestamps, ref_images, ref_masks, ref_camera, guidance=None,
-                 frames_per_step=4, random_views_per_frame=1, deformation_lr=0.00032, grid_lr=0.0032, seed=0):
+                 frames_per_step=4, random_views_per_frame=1, deformation_lr=0.00032, grid_lr=0.0032, seed=0,
+                 normal_consistency=None):
         self.r, self.net, self.nodes, self.static = renderer, net, nodes, static
         self.timestamps = timestamps                     # [L] in (0,1)
         self.ref_images, self.ref_masks = ref_images, ref_masks          # [L,H,W,3], [L,H,W,1]
         self.ref_camera = ref_camera
         self.guidance = guidance
+        self.normal_consistency = normal_consistency     # mesh_reg.MeshNormalConsistency of the surface mesh, or None
         self.frames_per_step, self.rv = frames_per_step, random_views_per_frame
         self.dev = nodes.device
         self.gen = torch.Generator(device="cpu").manual_seed(seed + 977 * D.rank())   # per-rank seed (launch.py:166)
@@ -109,6 +114,10 @@ class DynamicStage:
                               frame_indices=fidx[rnd])
             terms["sds"] = g["loss_sds"]
             loss = loss + LAMBDA["sds_zero123"] * g["loss_sds"]
+        if self.normal_consistency is not None:
+            # mesh_normal_consistency(get_timed_surface_mesh(batch timestamps)): the step's deformed meshes, one per frame
+            terms["normal_consistency"] = self.normal_consistency(out["vxyz"])
+            loss = loss + LAMBDA["normal_consistency"] * terms["normal_consistency"]
         loss.backward()
         self.reducer()                  # the one exchange step (no-op for a single process)
         self.opt.step()

@@ -120,3 +120,82 @@ class ARAPCoach:
         r = vert_rotations[None] if single else vert_rotations
         E = _ArapEnergy.apply(self, x, r.reshape(x.shape[0], self.n_verts, 3, 3))
         return E[0] if single else E
+
+
+class _NormalConsistency(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, nc, xyz):
+        L = _lib.lib()
+        dev = nc.device
+        x = xyz.detach().to(torch.float32).contiguous()
+        T = int(x.shape[0])
+        terms = torch.empty(T, nc.n_pairs, dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            _lib.check(L.dm4d_normal_consistency_forward(T, nc.n_verts, nc.n_pairs, nc._pairs.data_ptr(), x.data_ptr(),
+                                                         terms.data_ptr(), torch.cuda.current_stream(dev).cuda_stream),
+                       "dm4d_normal_consistency_forward")
+        ctx.nc = nc
+        ctx.save_for_backward(x)
+        return terms.sum(dim=1) / float(max(nc.n_pairs, 1))
+
+    @staticmethod
+    def backward(ctx, g_loss):
+        L = _lib.lib()
+        nc = ctx.nc
+        (x,) = ctx.saved_tensors
+        dev = nc.device
+        T = int(x.shape[0])
+        g = g_loss.detach().to(torch.float32).contiguous()
+        gx = torch.empty_like(x)
+        with torch.cuda.device(dev):
+            _lib.check(L.dm4d_normal_consistency_backward(T, nc.n_verts, nc.n_pairs, nc._pairs.data_ptr(), nc._off.data_ptr(),
+                                                          nc._items.data_ptr(), x.data_ptr(), g.data_ptr(), gx.data_ptr(),
+                                                          torch.cuda.current_stream(dev).cuda_stream),
+                       "dm4d_normal_consistency_backward")
+        return None, gx
+
+
+class MeshNormalConsistency:
+    """``pytorch3d.loss.mesh_normal_consistency(Meshes(verts=[T x V x 3], faces=[same F x 3] * T))`` for the T deformed
+    surface meshes of an iteration (system/sugar_4dgen.py:214-226: ``get_timed_surface_mesh`` of the batch's
+    timestamps, lambda_normal_consistency = 100) on one HIP launch (csrc/meshreg.hip).  The face pairs that share an
+    edge are enumerated once, in pytorch3d's order; pytorch3d itself is not vendored by the reference nor installed
+    here, so parity rests on its published algorithm (oracle/mesh_reg.py, closed-form cases) -- unpinned."""
+
+    def __init__(self, faces, n_verts, device):
+        self.device = torch.device(device)
+        f = np.asarray(torch.as_tensor(faces).cpu() if torch.is_tensor(faces) else faces, np.int64)
+        self.n_verts = int(n_verts)
+        e = np.stack([f[:, [1, 2]], f[:, [2, 0]], f[:, [0, 1]]], 1).reshape(-1, 2)   # edge opposite to corner k of a face
+        opp = f.reshape(-1)
+        e = np.sort(e, axis=1)
+        key = e[:, 0] * (int(f.max()) + 1 if f.size else 1) + e[:, 1]
+        order = np.argsort(key, kind="stable")
+        key_s, e_s, opp_s = key[order], e[order], opp[order]
+        bounds = np.flatnonzero(np.concatenate([[True], key_s[1:] != key_s[:-1], [True]])) if len(key_s) else np.zeros(1, np.int64)
+        rows = []
+        for s0, s1 in zip(bounds[:-1], bounds[1:]):
+            for i in range(s0, s1):
+                for j in range(i + 1, s1):
+                    rows.append((e_s[s0, 0], e_s[s0, 1], opp_s[i], opp_s[j]))
+        pairs = np.asarray(rows, np.int64).reshape(-1, 4)
+        self.n_pairs = int(len(pairs))
+        # vertex -> (pair, role) items for the gather backward
+        vert = pairs.reshape(-1)
+        item = np.arange(vert.size, dtype=np.int64)                                    # pair * 4 + role
+        order = np.argsort(vert, kind="stable")
+        off = np.zeros(self.n_verts + 1, np.int64)
+        np.add.at(off, vert + 1, 1)
+        off = np.cumsum(off)
+        T_ = lambda a: torch.as_tensor(np.ascontiguousarray(a), dtype=torch.int32, device=self.device)
+        self._pairs = T_(pairs if self.n_pairs else np.zeros((1, 4), np.int64))
+        self._off, self._items = T_(off), T_(item[order] if vert.size else np.zeros(1, np.int64))
+
+    def __call__(self, verts):
+        """verts [T,V,3] (or [V,3]) on the HIP device -> scalar loss (mean over the meshes, as pytorch3d returns)."""
+        if not verts.is_cuda:
+            raise _lib.Dm4dError("mesh normal consistency runs on the HIP device (no CPU fallback in the product)")
+        x = verts[None] if verts.dim() == 2 else verts
+        if self.n_pairs == 0:
+            return x.sum() * 0.0
+        return _NormalConsistency.apply(self, x).mean()

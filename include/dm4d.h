@@ -309,6 +309,20 @@ int dm4d_arap_energy_backward(int32_t T, int32_t V, const int32_t *csr_offsets, 
                               const float *xyz_prime, const float *rotations, const float *g_energy, float *g_xyz,
                               float *g_rotations, dm4d_stream_t stream);
 
+/* pytorch3d.loss.mesh_normal_consistency (pytorch3d@stable, un-vendored: C/requirements.txt:46) of T deformed meshes
+ * of one topology, as C/system/sugar_4dgen.py:214-226 applies it to the step's surface meshes (lambda 100,
+ * C/configs/sugar_dynamic_dg.yaml:146).  `pairs` [P,4] (device, static): for every pair of faces sharing an edge,
+ * (v0, v1, a, b) = the edge's vertices (v0 < v1) and the two opposite vertices, in pytorch3d's order (edges sorted,
+ * incidences of an edge in face order, all i < j combinations).  terms [T,P] = 1 - cos((v1-v0)x(a-v0), -(v1-v0)x(b-v0));
+ * the loss of mesh t is the mean of its terms and pytorch3d returns the mean over the meshes (host side).
+ * Backward: vert_offsets [V+1] / vert_items (item = pair * 4 + role, role = 0..3 for v0, v1, a, b) list the pairs that
+ * touch every vertex; g_loss [T] = dL/d(loss_t); g_xyz [T,V,3] is WRITTEN (gather, no atomics, deterministic). */
+int dm4d_normal_consistency_forward(int32_t T, int32_t V, int32_t P, const int32_t *pairs, const float *xyz, float *terms,
+                                    dm4d_stream_t stream);
+int dm4d_normal_consistency_backward(int32_t T, int32_t V, int32_t P, const int32_t *pairs, const int32_t *vert_offsets,
+                                     const int32_t *vert_items, const float *xyz, const float *g_loss, float *g_xyz,
+                                     dm4d_stream_t stream);
+
 /* ------------------------------------------------------------------ data-parallel gradient message */
 
 /* The one exchange step of the path is an all-reduce of the parameter gradients.  The

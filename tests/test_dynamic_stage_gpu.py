@@ -15,7 +15,7 @@ def _need_gpu():
         pytest.skip("no HIP device")
 
 
-def _build(dev, with_guidance):
+def _build(dev, with_guidance, with_nc=False):
     from dreammesh4d_amd import geometry as geo, ops, synthetic as syn, views, zero123 as z
     from dreammesh4d_amd.deformation import DeformationNetwork
     from dreammesh4d_amd.dynamic_stage import DynamicStage
@@ -57,8 +57,11 @@ def _build(dev, with_guidance):
         # fp32 weights: a RANDOM-INIT UNet can overflow fp16 at some timesteps (the real checkpoint does not)
         guid = z.TemporalStableZero123Guidance(model, torch.randn(L, 1, 32), torch.randn(L, 4, 32, 32),
                                                cond_elevation_deg=5.0, half_precision_weights=False).to(dev)
+    from dreammesh4d_amd.mesh_reg import MeshNormalConsistency
+
     stage = DynamicStage(r, net, nodes, static, ts, ref_img, ref_mask, cam, guidance=guid, frames_per_step=4,
-                         random_views_per_frame=1, deformation_lr=2e-3, grid_lr=2e-2)
+                         random_views_per_frame=1, deformation_lr=2e-3, grid_lr=2e-2,
+                         normal_consistency=MeshNormalConsistency(sc["faces"], len(sc["verts"]), dev) if with_nc else None)
     return stage
 
 
@@ -76,10 +79,11 @@ def test_iteration_fits_reference_frames():
 
 def test_iteration_with_zero123_sds_runs_and_updates_the_network():
     _need_gpu()
-    stage = _build(torch.device("cuda:0"), with_guidance=True)
+    stage = _build(torch.device("cuda:0"), with_guidance=True, with_nc=True)
     before = [p.detach().clone() for p in stage.net.get_mlp_parameters()]
     out = stage.iteration()
-    assert {"rgb", "mask", "sds", "loss"} <= set(out) and all(torch.isfinite(v) for v in out.values())
+    assert {"rgb", "mask", "sds", "normal_consistency", "loss"} <= set(out) and all(torch.isfinite(v) for v in out.values())
+    assert 0.0 <= float(out["normal_consistency"]) < 0.2      # a smooth sphere: neighbouring faces are nearly coplanar
     # the heads are zero-initialised (deformation.py:507-512), so the grids only get gradient from step 2 on
     out = stage.iteration()
     assert all(torch.isfinite(v) for v in out.values())

@@ -33,3 +33,32 @@ def test_adjacency_is_symmetric_and_reverse_edges_are_consistent():
     assert np.array_equal(src[rev], nbr) and np.array_equal(nbr[rev], src) and np.array_equal(rev[rev], np.arange(len(rev)))
     assert np.allclose(adj["w"][rev], adj["w"])                 # W + W^T is symmetric
     assert np.allclose(adj["e"][rev], -adj["e"])
+
+
+def test_normal_consistency_oracle_closed_forms():
+    """oracle/mesh_reg.py::normal_consistency restates pytorch3d.loss.mesh_normal_consistency (parity unpinned: the
+    package is neither vendored by the reference nor installed); these are the cases with a known answer."""
+    import itertools
+
+    from oracle import mesh_reg as M
+
+    # two triangles over the edge (0, 1): flat -> 0, folded by 90 degrees -> 1, folded flat onto each other -> 2
+    faces = np.array([[0, 1, 2], [1, 0, 3]])
+    for v3, want in (((0, -1, 0), 0.0), ((0, 0, 1), 1.0), ((0, 1, 0), 2.0)):
+        v = torch.tensor([[[0, 0, 0], [1, 0, 0], [0, 1, 0], v3]], dtype=torch.float64)
+        assert abs(float(M.normal_consistency(v, faces)) - want) < 1e-12
+    # a cube (12 triangles, outward orientation): 18 edges = 6 face diagonals (coplanar, 0) + 12 cube edges (90 deg, 1)
+    corners = np.array(list(itertools.product((0, 1), repeat=3)), np.float64)
+    quads = [(0, 1, 3, 2), (4, 6, 7, 5), (0, 4, 5, 1), (2, 3, 7, 6), (0, 2, 6, 4), (1, 5, 7, 3)]
+    cube = np.array([t for a, b, c, d in quads for t in ((a, b, c), (a, c, d))])
+    pr = M.normal_consistency_pairs(cube)
+    assert pr.shape == (18, 4) and (pr[:, 0] < pr[:, 1]).all()
+    v = torch.tensor(corners[None])
+    assert abs(float(M.normal_consistency(v, cube)) - 12.0 / 18.0) < 1e-12
+    # invariant under rigid motion and uniform scale, batched mean over meshes
+    R = torch.linalg.qr(torch.randn(3, 3, dtype=torch.float64, generator=torch.Generator().manual_seed(0)))[0]
+    v2 = torch.cat([v, 2.5 * v @ R.T + 0.3])
+    assert abs(float(M.normal_consistency(v2, cube)) - 12.0 / 18.0) < 1e-12
+    # an edge shared by three faces contributes all three pairs
+    fan = np.array([[0, 1, 2], [0, 1, 3], [0, 1, 4]])
+    assert M.normal_consistency_pairs(fan).shape == (3, 4)

@@ -93,3 +93,37 @@ def test_arap_through_the_geometry_accessors():
     E.sum().backward()
     gr = [p.grad for n, p in geo._deformation.named_parameters() if "pos_deform" in n]
     assert all(v is not None and torch.isfinite(v).all() for v in gr) and sum(float(v.abs().sum()) for v in gr) > 0
+
+
+def test_normal_consistency_against_the_oracle():
+    """csrc/meshreg.hip::k_nc_* (MeshNormalConsistency) vs oracle/mesh_reg.py::normal_consistency (float64 autograd)
+    on T deformed copies of a closed mesh plus a non-manifold fan; value and vertex gradients."""
+    _need_gpu()
+    from dreammesh4d_amd.mesh_reg import MeshNormalConsistency
+    from oracle import mesh_reg as M
+
+    dev = torch.device("cuda:0")
+    sc = syn.mesh_bound_scene(1200, n_nodes=40, k=4, seed=3)
+    verts, faces = np.asarray(sc["verts"], np.float64), np.asarray(sc["faces"], np.int64)
+    V = len(verts)
+    faces = np.concatenate([faces, [[0, 1, V - 1], [0, 1, V - 2]]])          # extra faces on one edge: 3+ faces share it
+    g = torch.Generator().manual_seed(0)
+    T = 3
+    x64 = (torch.tensor(verts)[None] + 0.02 * torch.randn(T, V, 3, dtype=torch.float64, generator=g)).requires_grad_(True)
+    want = M.normal_consistency(x64, faces)
+    want.backward()
+    nc = MeshNormalConsistency(faces, V, dev)
+    assert nc.n_pairs == len(M.normal_consistency_pairs(faces)) > 1.5 * 1200 - 10
+    assert np.array_equal(nc._pairs.cpu().numpy(), M.normal_consistency_pairs(faces))
+    x = x64.detach().float().to(dev).requires_grad_(True)
+    got = nc(x)
+    got.backward()
+    assert abs(float(got) - float(want)) < 2e-6 * max(1.0, abs(float(want)))
+    gw = x64.grad.numpy()
+    assert np.abs(x.grad.cpu().numpy() - gw).max() < 2e-4 * np.abs(gw).max()
+    # deterministic (gather backward)
+    x2 = x.detach().clone().requires_grad_(True)
+    nc(x2).backward()
+    assert torch.equal(x.grad, x2.grad)
+    # a single [V,3] mesh is the T = 1 batch
+    assert abs(float(nc(x.detach()[0])) - float(M.normal_consistency(x64.detach()[:1], faces))) < 2e-6
