@@ -258,12 +258,13 @@ def dynamic_stage_iterations(wl, dev, n=10):
     static = {"q_static": wl.qs, "scales": wl.scales, "opacities": wl.opac, "rgb": wl.rgb}
     ref_img = torch.rand(N_FRAMES, H, W, 3, generator=g).to(dev)
     ref_mask = (torch.rand(N_FRAMES, H, W, 1, generator=g) > 0.5).float().to(dev)
-    from dreammesh4d_amd.mesh_reg import MeshNormalConsistency
+    from dreammesh4d_amd.mesh_reg import ARAPCoach, MeshNormalConsistency
 
     stage = DynamicStage(wl.renderer, wl.net, wl.nodes, static, wl.timestamps, ref_img, ref_mask,
                          syn.make_camera(H, W, elev_deg=5.0, azim_deg=0.0), guidance=guid, frames_per_step=FRAMES_PER_STEP,
                          random_views_per_frame=VIEWS_PER_FRAME - 1,
-                         normal_consistency=MeshNormalConsistency(wl.sc["faces"], len(wl.sc["verts"]), dev))
+                         normal_consistency=MeshNormalConsistency(wl.sc["faces"], len(wl.sc["verts"]), dev),
+                         arap=ARAPCoach(wl.sc["verts"], wl.sc["faces"], dev), milestone_arap_reg=0)
     for _ in range(3):
         stage.iteration()
     torch.cuda.synchronize(dev)
@@ -273,7 +274,7 @@ def dynamic_stage_iterations(wl, dev, n=10):
     torch.cuda.synchronize(dev)
     dt = time.perf_counter() - t0
     return {"dynamic_stage_iters_per_sec": round(n / dt, 3), "dynamic_stage_ms_per_iteration": round(1e3 * dt / n, 2),
-            "dynamic_stage_note": "8 views/iteration, full-size Zero123 fp16 with random weights, mesh normal consistency, AdamW step included"}
+            "dynamic_stage_note": "8 views/iteration, full-size Zero123 fp16 with random weights, mesh normal consistency + key-frame ARAP, AdamW step included"}
 
 
 def cpu_baseline(wl, n_views):

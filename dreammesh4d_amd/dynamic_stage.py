@@ -14,8 +14,10 @@ What runs per iteration on each GPU:
   all-reduce -> AdamW.
 Of the reference step's mesh regularisers ("next" rows) the normal consistency of the
 step's deformed meshes (system/sugar_4dgen.py:214-226, lambda 100) is part of this loop when a
-`mesh_reg.MeshNormalConsistency` is passed; the ARAP terms (key frame + 10 inter-frames, their own deformation
-queries, :304-311,331-385) are available as `mesh_reg.ARAPCoach` and not wired in here.
+`mesh_reg.MeshNormalConsistency` is passed, and the two ARAP terms when a `mesh_reg.ARAPCoach` is passed: the
+key-frame energy of the step's frames (ref substep, :304-311) and, every `inter_frame_reg` iterations, the energy at
+`num_inter_frames` timestamps densely sampled in a random window (:331-385; their own deformation query + skinning,
+no rendering), both from `milestone_arap_reg` on, with the skinned vertex rotations (:369-385).
 """
 import math
 
@@ -28,19 +30,31 @@ from .schedule import C
 from .views import render_views
 
 LAMBDA = {"sds_zero123": 0.1, "rgb": 5000.0, "mask": [200, 500.0, 5000.0, 1000],      # sugar_dynamic_dg.yaml:135-158
-          "normal_consistency": 100.0}
+          "normal_consistency": 100.0, "arap_reg_key_frame": 10.0, "arap_reg_inter_frame": 10.0}
+
+
+def quat_xyzw_to_matrix(q):
+    """[..., 4] (x, y, z, w) unit quaternions -> [..., 3, 3] (get_timed_vertex_rotation(return_matrix=True))."""
+    x, y, z, w = q.unbind(-1)
+    return torch.stack([1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w),
+                        2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w),
+                        2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)], -1).reshape(*q.shape[:-1], 3, 3)
 
 
 class DynamicStage:
     def __init__(self, renderer, net, nodes, static, timestamps, ref_images, ref_masks, ref_camera, guidance=None,
                  frames_per_step=4, random_views_per_frame=1, deformation_lr=0.00032, grid_lr=0.0032, seed=0,
-                 normal_consistency=None):
+                 normal_consistency=None, arap=None, milestone_arap_reg=100, inter_frame_reg=0, num_inter_frames=10,
+                 length_inter_frames=0.1):
         self.r, self.net, self.nodes, self.static = renderer, net, nodes, static
         self.timestamps = timestamps                     # [L] in (0,1)
         self.ref_images, self.ref_masks = ref_images, ref_masks          # [L,H,W,3], [L,H,W,1]
         self.ref_camera = ref_camera
         self.guidance = guidance
         self.normal_consistency = normal_consistency     # mesh_reg.MeshNormalConsistency of the surface mesh, or None
+        self.arap = arap                                  # mesh_reg.ARAPCoach of the surface mesh, or None
+        self.milestone_arap_reg, self.inter_frame_reg = milestone_arap_reg, inter_frame_reg      # yaml:126-127 (inter_frame_reg: 0 as shipped)
+        self.num_inter_frames, self.length_inter_frames = num_inter_frames, length_inter_frames  # yaml:51-52
         self.frames_per_step, self.rv = frames_per_step, random_views_per_frame
         self.dev = nodes.device
         self.gen = torch.Generator(device="cpu").manual_seed(seed + 977 * D.rank())   # per-rank seed (launch.py:166)
@@ -82,6 +96,22 @@ class DynamicStage:
                 "pm": torch.stack([T(c.projmatrix) for c in cams]), "unit_frame": T(unit_frame),
                 "is_ref": torch.tensor(is_ref, device=self.dev), "elev": T(elev), "azim": T(azim)}
 
+    def inter_frame_arap(self):
+        """ARAP energy at `num_inter_frames` timestamps of a random window of length `length_inter_frames`
+        (training_substep_inter_frames, sugar_4dgen.py:331-385): deformation query + skinning only."""
+        from . import ops
+
+        start = float(torch.rand(1, generator=self.gen)) * (1.0 - self.length_inter_frames)
+        ts = torch.linspace(start, start + self.length_inter_frames, self.num_inter_frames, device=self.dev)
+        dx, dr, ds, do = self.net.node_outputs(self.nodes, ts)
+        xyz, rot = [], []
+        for i in range(self.num_inter_frames):
+            x, q = ops.skin_vertices(self.r.graph, dx[i], dr[i], None if ds is None else ds[i], None if do is None else do[i],
+                                     self.r.method_name)
+            xyz.append(x)
+            rot.append(q)
+        return self.arap.compute_arap_energy(torch.stack(xyz), quat_xyzw_to_matrix(torch.stack(rot))).sum()
+
     def update_learning_rate(self, it):
         for g in self.opt.param_groups:
             g["lr"] = C(self.sched[g["name"]], 0, it, interpolation="exp")      # spatial_lr_scale = 1 (yaml:81)
@@ -118,6 +148,12 @@ class DynamicStage:
             # mesh_normal_consistency(get_timed_surface_mesh(batch timestamps)): the step's deformed meshes, one per frame
             terms["normal_consistency"] = self.normal_consistency(out["vxyz"])
             loss = loss + LAMBDA["normal_consistency"] * terms["normal_consistency"]
+        if self.arap is not None and it >= self.milestone_arap_reg:
+            terms["arap_reg_key_frame"] = self.arap.compute_arap_energy(out["vxyz"], quat_xyzw_to_matrix(out["vrot"])).sum()
+            loss = loss + LAMBDA["arap_reg_key_frame"] * terms["arap_reg_key_frame"]
+            if self.inter_frame_reg > 0 and it % self.inter_frame_reg == 0:
+                terms["arap_reg_inter_frame"] = self.inter_frame_arap()
+                loss = loss + LAMBDA["arap_reg_inter_frame"] * terms["arap_reg_inter_frame"]
         loss.backward()
         self.reducer()                  # the one exchange step (no-op for a single process)
         self.opt.step()

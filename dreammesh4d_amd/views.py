@@ -39,7 +39,7 @@ class ViewRenderer:
         self.device = graph.device
         self.H, self.W = int(image_height), int(image_width)
         self.tanfov = float(tanfov)
-        self.method = METHODS[method]
+        self.method, self.method_name = METHODS[method], method
         self.scale_modifier = float(scale_modifier)
         self.N = topo.F * topo.G
         self.capacity = max(int(capacity_factor * self.N), 1 << 16)

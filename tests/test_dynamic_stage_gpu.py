@@ -57,11 +57,13 @@ def _build(dev, with_guidance, with_nc=False):
         # fp32 weights: a RANDOM-INIT UNet can overflow fp16 at some timesteps (the real checkpoint does not)
         guid = z.TemporalStableZero123Guidance(model, torch.randn(L, 1, 32), torch.randn(L, 4, 32, 32),
                                                cond_elevation_deg=5.0, half_precision_weights=False).to(dev)
-    from dreammesh4d_amd.mesh_reg import MeshNormalConsistency
+    from dreammesh4d_amd.mesh_reg import ARAPCoach, MeshNormalConsistency
 
     stage = DynamicStage(r, net, nodes, static, ts, ref_img, ref_mask, cam, guidance=guid, frames_per_step=4,
                          random_views_per_frame=1, deformation_lr=2e-3, grid_lr=2e-2,
-                         normal_consistency=MeshNormalConsistency(sc["faces"], len(sc["verts"]), dev) if with_nc else None)
+                         normal_consistency=MeshNormalConsistency(sc["faces"], len(sc["verts"]), dev) if with_nc else None,
+                         arap=ARAPCoach(sc["verts"], sc["faces"], dev) if with_nc else None, milestone_arap_reg=1,
+                         inter_frame_reg=1)
     return stage
 
 
@@ -84,9 +86,11 @@ def test_iteration_with_zero123_sds_runs_and_updates_the_network():
     out = stage.iteration()
     assert {"rgb", "mask", "sds", "normal_consistency", "loss"} <= set(out) and all(torch.isfinite(v) for v in out.values())
     assert 0.0 <= float(out["normal_consistency"]) < 0.2      # a smooth sphere: neighbouring faces are nearly coplanar
+    assert "arap_reg_key_frame" not in out                    # before milestone_arap_reg
     # the heads are zero-initialised (deformation.py:507-512), so the grids only get gradient from step 2 on
     out = stage.iteration()
     assert all(torch.isfinite(v) for v in out.values())
+    assert {"arap_reg_key_frame", "arap_reg_inter_frame"} <= set(out) and float(out["arap_reg_key_frame"]) >= 0.0
     grid_grad = [p.grad for p in stage.net.get_grid_parameters() if p.requires_grad]   # aabb is frozen
     assert all(g is not None and torch.isfinite(g).all() for g in grid_grad) and any(g.abs().sum() > 0 for g in grid_grad)
     after = stage.net.get_mlp_parameters()
