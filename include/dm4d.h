@@ -323,6 +323,21 @@ int dm4d_normal_consistency_backward(int32_t T, int32_t V, int32_t P, const int3
                                      const int32_t *vert_items, const float *xyz, const float *g_loss, float *g_xyz,
                                      dm4d_stream_t stream);
 
+/* ------------------------------------------------------------------ deformation-graph construction */
+
+/* K nearest graph nodes of every mesh vertex in geodesic (shortest edge path) distance + skinning weights: the output
+ * of DynamicSuGaRModel.build_deformation_graph(mode="geodisc") (C/geometry/dynamic_sugar.py:745-861), i.e.
+ * _xyz_neighbor_node_idx [V,K] (int64) and the row-normalised _xyz_neighbor_nodes_weights [V,K] =
+ * (1 - |v - node_k| / |v - node_{K+1}|)^2 (:845,859-861).  The reference runs one CPU heat-method solve per VERTEX
+ * (potpourri3d, un-vendored); here the M nodes are the sources of one [M,V] relaxation over the mesh edges.
+ * Static inputs (device): one-ring CSR csr_offsets [V+1] / neighbors [E] / edge_lengths [E]; verts [V,3];
+ * node_xyz [M,3]; node_vertex [M] = the mesh vertex nearest to each node (:806-812).  scratch:
+ * dm4d_graph_geodesic_scratch_bytes.  Synchronises the stream (convergence test). */
+size_t dm4d_graph_geodesic_scratch_bytes(int32_t V, int32_t M);
+int dm4d_graph_geodesic_knn(int32_t V, int32_t M, int32_t K, const int32_t *csr_offsets, const int32_t *neighbors,
+                            const float *edge_lengths, const float *verts, const float *node_xyz, const int32_t *node_vertex,
+                            void *scratch, int64_t *neighbor_idx, float *neighbor_weights, dm4d_stream_t stream);
+
 /* ------------------------------------------------------------------ data-parallel gradient message */
 
 /* The one exchange step of the path is an all-reduce of the parameter gradients.  The
