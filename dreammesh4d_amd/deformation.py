@@ -150,6 +150,7 @@ class _DeformMLP(torch.autograd.Function):
                                                  scratch.data_ptr(), torch.cuda.current_stream(dev).cuda_stream),
                        "dm4d_deform_mlp_forward")
         ctx.w, ctx.keep, ctx.n_heads = w, (f, ps, h, y, scratch), n_heads
+        ctx.set_materialize_grads(False)     # an unused head arrives as None (the C call takes NULL), not as a zero tensor
         return tuple(outs)
 
     @staticmethod

@@ -152,6 +152,7 @@ class _RenderViews(torch.autograd.Function):
         ctx.need_static = any(x.requires_grad for x in (scales, opacities, rgb))
         r.last = (vs, ws)      # for check(): the counters live in ws["geom"]
         ctx.mark_non_differentiable(out["radii"])
+        ctx.set_materialize_grads(False)     # outputs nobody used arrive as None, not as zero tensors (a fill launch each)
         return out["color"], out["depth"], out["alpha"], out["radii"], out["vxyz"], out["vrot"]
 
     @staticmethod
