@@ -42,7 +42,8 @@ DM4D_HD static inline int grad_stride(int C, bool lean = false) { return (C <= 3
 
 // counters[]: duplicates, duplicate-capacity overflow, records (sum of the Gaussians' cells), record-capacity overflow
 // kCntLong: number of LONG cells (cell lists of >= kLongCell entries, K4 appends them to `longlist`)
-enum GeomCounter { kCntD = 0, kCntOverflow = 1, kCntR = 2, kCntRecOverflow = 3, kCntLong = 4 };
+// kCntLongEarly: the long cells of the tiles the large sort variant handled (`earlylist`), see k_render_fwd_long
+enum GeomCounter { kCntD = 0, kCntOverflow = 1, kCntR = 2, kCntRecOverflow = 3, kCntLong = 4, kCntLongEarly = 5 };
 // A wave of the blend kernels walks four cell lists side by side, one entry per row and step, so the launch cannot
 // end before its longest list (silhouette cells hold > 1000 entries against a mean of 75: measured, the longest
 // wave alone took as long as the whole launch).  Cells with at least this many entries are therefore left out of
@@ -55,7 +56,7 @@ DM4D_HD static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) /
 struct GeomLayout {
     int N, T, nb;
     size_t counters, xy, depth, conic_opacity, rgb, tiles_touched, rec_touched, cellinfo, cellmask, clamped,
-        block_sums, rec_block_sums, hist, tile_count, tile_start, ccount, cdone, ckmax, order, longlist, zero_begin, zero_bytes, total;
+        block_sums, rec_block_sums, hist, tile_count, tile_start, ccount, cdone, ckmax, order, longlist, earlylist, cflag, zero_begin, zero_bytes, total;
 };
 
 DM4D_HD static inline size_t take_(size_t &o, size_t bytes) { size_t r = o; o = align_up(o + bytes, 256); return r; }
@@ -80,6 +81,8 @@ DM4D_HD static inline GeomLayout geom_layout(int N, int H, int W)
     L.ckmax = take_(o, (size_t)L.T * kCells * 4);    // tile-list position bound of those entries  [T][16]
     L.order = take_(o, (size_t)L.T * 4);             // tiles by descending list length (blend launch order)
     L.longlist = take_(o, (size_t)L.T * kCells * 4); // tile * 16 + cell of the long cells, in no particular order
+    L.earlylist = take_(o, (size_t)L.T * kCells * 4);   // the long cells of the tiles sorted by the large variant
+    L.cflag = take_(o, (size_t)L.T * kCells * 4);       // 1: the cell is on earlylist (its forward is k_render_fwd_long's)
     L.xy = take_(o, n * 8);
     L.depth = take_(o, n * 4);
     L.conic_opacity = take_(o, n * 16);
@@ -117,6 +120,8 @@ struct GeomPtrs {
     uint32_t *ckmax;
     uint32_t *order;
     uint32_t *longlist;
+    uint32_t *earlylist;
+    uint32_t *cflag;
 };
 
 DM4D_HD static inline GeomPtrs geom_ptrs(void *base, const GeomLayout &L)
@@ -143,6 +148,8 @@ DM4D_HD static inline GeomPtrs geom_ptrs(void *base, const GeomLayout &L)
     p.ckmax = (uint32_t *)(b + L.ckmax);
     p.order = (uint32_t *)(b + L.order);
     p.longlist = (uint32_t *)(b + L.longlist);
+    p.earlylist = (uint32_t *)(b + L.earlylist);
+    p.cflag = (uint32_t *)(b + L.cflag);
     return p;
 }
 
@@ -396,9 +403,10 @@ int launch_scatter(const BatchDesc &d, hipStream_t st);
 int launch_tile_sort(const BatchDesc &d, hipStream_t st);
 // per-device helper stream for launches that run beside the caller's stream (fork / join events); nullptr if it
 // cannot be created (callers then launch on the caller's stream)
-struct AuxStream { hipStream_t st; hipEvent_t fork, join; bool ok; };
+struct AuxStream { hipStream_t st, st2; hipEvent_t fork, join, fork2, join2; bool ok; bool pending2; };
 AuxStream *aux_stream();
 int launch_render_fwd(const BatchDesc &d, hipStream_t st);
+int launch_render_fwd_long(const BatchDesc &d, hipStream_t st);   // the long cells of the large tiles (earlylist)
 int launch_render_bwd(const BatchDesc &d, hipStream_t st);
 int launch_gather_bwd(const BatchDesc &d, hipStream_t st);
 int launch_zero_counters(const BatchDesc &d, hipStream_t st);

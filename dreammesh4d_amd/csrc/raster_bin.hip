@@ -200,8 +200,13 @@ __device__ __forceinline__ void finish_tile(const ViewCtx &c, int tile, uint32_t
     }
     if (tid < kCells) {
         g.ccount[tile * kCells + tid] = s_cbase[tid];
-        // long cells are blended by their own kernels (raster.h, kLongCell); which slot a cell gets does not matter
-        if (s_cbase[tid] >= kLongCell) g.longlist[atomicAdd(&g.counters[kCntLong], 1u)] = (uint32_t)(tile * kCells + tid);
+        // long cells are blended by their own kernels (raster.h, kLongCell); which slot a cell gets does not matter.
+        // The backward takes all of them (longlist); the forward only those of the tiles THIS, the large, variant
+        // sorts: it finishes long before the small variant, so their forward starts that much earlier.
+        const bool is_long = s_cbase[tid] >= kLongCell, early = is_long && kSortThreads == kSortLarge;
+        if (is_long) g.longlist[atomicAdd(&g.counters[kCntLong], 1u)] = (uint32_t)(tile * kCells + tid);
+        if (early) g.earlylist[atomicAdd(&g.counters[kCntLongEarly], 1u)] = (uint32_t)(tile * kCells + tid);
+        g.cflag[tile * kCells + tid] = early ? 1u : 0u;
     }
 }
 
@@ -236,7 +241,7 @@ __global__ __launch_bounds__(kSortThreads) void k_tile_sort(BatchDesc d)
     // (launched over the first kLargeRanks ranks of every view, on a second stream) takes the larger ones.
     if (kIsLarge ? (n <= (uint32_t)(kSortPerThread * kSortSmall)) : (n > (uint32_t)kSortLdsCap && rank < (uint32_t)kLargeRanks)) return;
     if (n == 0) {
-        if (tid < kCells) g.ccount[t * kCells + tid] = 0u;
+        if (tid < kCells) { g.ccount[t * kCells + tid] = 0u; g.cflag[t * kCells + tid] = 0u; }
         return;
     }
     if (n <= (uint32_t)kSortLdsCap) {
@@ -409,8 +414,12 @@ AuxStream *aux_stream()
     AuxStream &a = g_aux[dev];
     if (!a.ok) {
         if (hipStreamCreateWithFlags(&a.st, hipStreamNonBlocking) != hipSuccess) return nullptr;
+        if (hipStreamCreateWithFlags(&a.st2, hipStreamNonBlocking) != hipSuccess) return nullptr;
         if (hipEventCreateWithFlags(&a.fork, hipEventDisableTiming) != hipSuccess) return nullptr;
         if (hipEventCreateWithFlags(&a.join, hipEventDisableTiming) != hipSuccess) return nullptr;
+        if (hipEventCreateWithFlags(&a.fork2, hipEventDisableTiming) != hipSuccess) return nullptr;
+        if (hipEventCreateWithFlags(&a.join2, hipEventDisableTiming) != hipSuccess) return nullptr;
+        a.pending2 = false;
         a.ok = true;
     }
     return &a;
@@ -433,6 +442,16 @@ int launch_tile_sort(const BatchDesc &d, hipStream_t st)
     }
     hipLaunchKernelGGL(k_tile_sort<kSortLarge>, dim3(large_blocks), dim3(kSortLarge), 0, st, d);
     DM4D_HIP_CHECK(hipGetLastError());
+    if (a) {
+        // the forward of the large tiles' long cells starts as soon as THEIR sort is done, on a second helper stream,
+        // beside the small variant and later the regular forward kernel (launch_render_fwd joins it)
+        DM4D_HIP_CHECK(hipEventRecord(a->fork2, st));
+        DM4D_HIP_CHECK(hipStreamWaitEvent(a->st2, a->fork2, 0));
+        int rc2 = launch_render_fwd_long(d, a->st2);
+        if (rc2) return rc2;
+        DM4D_HIP_CHECK(hipEventRecord(a->join2, a->st2));
+        a->pending2 = true;
+    }
     hipLaunchKernelGGL(k_tile_sort<kSortSmall>, dim3((unsigned)T * (unsigned)d.B), dim3(kSortSmall), 0, sst, d);
     DM4D_HIP_CHECK(hipGetLastError());
     if (a) {

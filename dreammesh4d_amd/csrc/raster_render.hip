@@ -242,7 +242,9 @@ __global__ __launch_bounds__(64) void k_render_fwd(BatchDesc d)
     const f2v pxf = (f2v)((float)px), pyf = (f2v)((float)py);
 
     const uint32_t s = g.tile_start[tile];
-    const uint32_t nr = (s < cap) ? g.ccount[tile * kCells + lp.cell] : 0u;   // this row's list length
+    uint32_t nr = (s < cap) ? g.ccount[tile * kCells + lp.cell] : 0u;   // this row's list length
+    const bool row_long = (s < cap) && g.cflag[tile * kCells + lp.cell] != 0u;   // blended by k_render_fwd_long
+    if (row_long) nr = 0u;
     const uint32_t nmax = wave_max_u32(nr);
     set_priority_by_length(nmax);
     if (nmax < g_min_work) { trace.done(0); return; }
@@ -252,7 +254,7 @@ __global__ __launch_bounds__(64) void k_render_fwd(BatchDesc d)
     float T_ = 1.0f;
     f2v C01 = (f2v)(0.f), C23 = (f2v)(0.f), C45 = (f2v)(0.f), DW = (f2v)(0.f);   // colours | (depth, alpha) sums
     uint32_t last = 0, lastj = 0;
-    bool done = !inside;
+    bool done = !inside | row_long;
 
     float4 r[4];
     zero_entry(r);
@@ -308,7 +310,7 @@ __global__ __launch_bounds__(64) void k_render_fwd(BatchDesc d)
             t += 2 * kFwdPairs;
         } while (t < kChunk && __ballot((!done) & (t < cnt)) != 0);
     }
-    if (inside) {
+    if (inside && !row_long) {
         const size_t P = (size_t)vp.H * vp.W;
         const size_t pid = (size_t)py * vp.W + px;
         im.final_T[pid] = T_;
@@ -320,11 +322,128 @@ __global__ __launch_bounds__(64) void k_render_fwd(BatchDesc d)
         out_alpha[pid] = DW.y;
     }
     const uint32_t wj = row_max_u32(lastj), wk = row_max_u32(last);
-    if (li == 0) {
+    if (li == 0 && !row_long) {
         g.cdone[tile * kCells + lp.cell] = wj;
         g.ckmax[tile * kCells + lp.cell] = wk;
     }
     trace.done(nmax);
+}
+
+// ---------------------------------------------------------------------------------------- K5 (long cells of the large tiles)
+// One wave per cell of `earlylist` (raster.h: the long cells of the tiles the LARGE sort variant handled -- the
+// silhouette tiles, whose lists are the longest of the launch).  Lane = (entry slot r = lane >> 4, pixel p = lane & 15
+// of the cell): the four rows evaluate the alphas of four CONSECUTIVE list entries for the same 16 pixels, hand them to
+// row 0 through 256 bytes of LDS, and row 0 runs the sequential blend -- the same operations on the same values in the
+// same order as k_render_fwd, so the image is bit-identical.  The point is WHEN it runs: the large sort variant is
+// done ~90 us before the small one, so these cells -- the tail the regular kernel used to end with -- are blended
+// beside the small variant's sort, on their own stream (regular kernel 252 -> 204 us; run beside the regular kernel
+// instead, the same code gained nothing: 247 us against 219).
+// Staging: 64 entries per chunk, one per lane: [0..5] x y A B C opacity | [6] k bits | [8..13] colours | [14] depth | [15] 1
+template <int C>
+__global__ __launch_bounds__(64) void k_render_fwd_long(BatchDesc d)
+{
+    __shared__ __attribute__((aligned(16))) float s_e[64 * 16];
+    __shared__ __attribute__((aligned(16))) float s_a[64];      // alphas [pixel][entry slot]
+    const int view = (int)(blockIdx.x % (uint32_t)d.B);
+    const uint32_t first = blockIdx.x / (uint32_t)d.B, step = gridDim.x / (uint32_t)d.B;
+    const ViewCtx c = resolve(d, view);
+    const ViewParams &vp = c.vp;
+    const float *__restrict__ colors = c.colors;
+    const GeomPtrs &g = c.g;
+    const BinPtrs &b = c.b;
+    const ImgPtrs &im = c.im;
+    const int lane = threadIdx.x, r = lane >> 4, p = lane & 15;
+    const uint32_t n_long = min(g.counters[kCntLongEarly], (uint32_t)(c.T * kCells));
+    if (first < n_long) __builtin_amdgcn_s_setprio(3);
+    for (uint32_t it = first; it < n_long; it += step) {
+        const uint32_t cellid = g.earlylist[it];
+        const int tile = (int)(cellid / kCells), cell = (int)(cellid % kCells);
+        const int tx = tile % vp.gx, ty = tile / vp.gx, q = cell >> 2, rw = cell & 3;
+        const int px = tx * kTile + (q & 1) * 8 + (rw & 1) * 4 + (p & 3);
+        const int py = ty * kTile + (q >> 1) * 8 + (rw >> 1) * 4 + (p >> 2);
+        const bool inside = px < vp.W && py < vp.H;
+        const float pxf = (float)px, pyf = (float)py;
+        const uint32_t s = g.tile_start[tile];
+        const uint32_t nr = g.ccount[cellid];
+        const uint2 *__restrict__ list = b.clist + (size_t)cell * b.cap + s;
+
+        float T_ = 1.0f;
+        f2v C01 = (f2v)(0.f), C23 = (f2v)(0.f), C45 = (f2v)(0.f), DW = (f2v)(0.f);
+        uint32_t last = 0, lastj = 0;
+        bool done = !inside | (r != 0);      // the pixel state lives in row 0
+
+        float4 e[4];
+        zero_entry(e);
+        if ((uint32_t)lane < nr) gather_entry<C>(list[lane], g, colors, e);
+        for (uint32_t c0 = 0; c0 < nr; c0 += 64u) {
+            const int cnt = (int)min(64u, nr - c0);
+            __builtin_amdgcn_wave_barrier();
+            {
+                float *se = s_e + lane * 16;
+                *reinterpret_cast<float4 *>(se) = e[0];                                              // x y A B
+                *reinterpret_cast<float4 *>(se + 4) = make_float4(e[1].x, e[1].y, e[1].w, 0.f);     // C opacity k
+                *reinterpret_cast<float4 *>(se + 8) = e[2];                                          // colours 0..3
+                *reinterpret_cast<float4 *>(se + 12) = make_float4(e[3].x, e[3].y, e[1].z, 1.0f);   // colours 4 5, depth, 1
+            }
+            zero_entry(e);
+            if (c0 + 64u + (uint32_t)lane < nr) gather_entry<C>(list[c0 + 64u + lane], g, colors, e);   // prefetch
+            __builtin_amdgcn_wave_barrier();
+            if (__ballot(!done) == 0) break;
+            for (int t = 0; t < cnt; t += 4) {
+                // ---- the four rows: alpha of entry t + r at pixel p (padding entries are inert: opacity 0) ----
+                const float4 ga = *reinterpret_cast<const float4 *>(s_e + (t + r) * 16);
+                const float4 gb = *reinterpret_cast<const float4 *>(s_e + (t + r) * 16 + 4);
+                const float dx = ga.x - pxf, dy = ga.y - pyf;
+                const float power = -0.5f * ((ga.z * dx) * dx + (gb.x * dy) * dy) - (ga.w * dx) * dy;
+                const float alpha_r = fminf(0.99f, gb.y * det_expf(power));
+                s_a[p * 4 + r] = ((power <= 0.0f) & (alpha_r >= 1.0f / 255.0f)) ? alpha_r : -1.0f;
+                __builtin_amdgcn_wave_barrier();
+                const float4 a4 = *reinterpret_cast<const float4 *>(s_a + p * 4);
+                const float al[4] = {a4.x, a4.y, a4.z, a4.w};
+                // ---- row 0: the sequential blend of the four entries ----
+#pragma unroll
+                for (int h = 0; h < 4; ++h) {
+                    const float *se = s_e + (t + h) * 16;
+                    const f4v e0 = *reinterpret_cast<const f4v *>(se + 8), e1 = *reinterpret_cast<const f4v *>(se + 12);
+                    const uint32_t kbits = __float_as_uint(se[6]);
+                    const float alpha = al[h];
+                    const float test_T = T_ * (1.0f - alpha);
+                    const bool valid = (!done) & (alpha >= 0.0f);
+                    const bool stop = valid & (test_T < 0.0001f);
+                    const bool contrib = valid & (!stop);
+                    const float w = contrib ? alpha * T_ : 0.f;
+                    const f2v ww = (f2v)(w);
+                    C01 = __builtin_elementwise_fma(e0.xy, ww, C01);
+                    C23 = __builtin_elementwise_fma(e0.zw, ww, C23);
+                    if (C > 3) C45 = __builtin_elementwise_fma(e1.xy, ww, C45);
+                    DW = __builtin_elementwise_fma(e1.zw, ww, DW);
+                    T_ = contrib ? test_T : T_;
+                    last = contrib ? kbits + 1u : last;
+                    lastj = contrib ? c0 + (uint32_t)(t + h) + 1u : lastj;
+                    done = done | stop;
+                }
+                __builtin_amdgcn_wave_barrier();
+                if (__ballot(!done) == 0) break;
+            }
+        }
+        if (inside && r == 0) {
+            const size_t P = (size_t)vp.H * vp.W;
+            const size_t pid = (size_t)py * vp.W + px;
+            im.final_T[pid] = T_;
+            im.n_contrib[pid] = last;
+            const float Cacc[6] = {C01.x, C01.y, C23.x, C23.y, C45.x, C45.y};
+#pragma unroll
+            for (int ch = 0; ch < C; ++ch) c.out_color[ch * P + pid] = __builtin_fmaf(T_, vp.bg[ch], Cacc[ch]);
+            c.out_depth[pid] = DW.x;
+            c.out_alpha[pid] = DW.y;
+        }
+        const uint32_t wj = row_max_u32(lastj), wk = row_max_u32(last);
+        if (lane == 0) {
+            g.cdone[cellid] = wj;
+            g.ckmax[cellid] = wk;
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
 }
 
 // ---------------------------------------------------------------------------------------- B1
@@ -708,8 +827,28 @@ int launch_render_fwd(const BatchDesc &d, hipStream_t st)
     if (T <= 0) return DM4D_OK;
     const int blocks = (int)((((int64_t)T * d.B + 7) / 8) * 8 * 4);
     ProfScope prof_(kKRenderFwd, st);
+    AuxStream *a = aux_stream();
+    if (!a) {                       // no helper streams: the long cells of the large tiles right here
+        int rc = launch_render_fwd_long(d, st);
+        if (rc) return rc;
+    }
     if (d.C <= 3) hipLaunchKernelGGL(k_render_fwd<3>, dim3(blocks), dim3(64), 0, st, d);
     else hipLaunchKernelGGL(k_render_fwd<6>, dim3(blocks), dim3(64), 0, st, d);
+    DM4D_HIP_CHECK(hipGetLastError());
+    if (a && a->pending2) {         // k_render_fwd_long, started by launch_tile_sort right after the large variant
+        DM4D_HIP_CHECK(hipStreamWaitEvent(st, a->join2, 0));
+        a->pending2 = false;
+    }
+    return DM4D_OK;
+}
+
+int launch_render_fwd_long(const BatchDesc &d, hipStream_t st)
+{
+    const int T = ((d.W + kTile - 1) / kTile) * ((d.H + kTile - 1) / kTile);
+    if (T <= 0) return DM4D_OK;
+    const int long_blocks = min(T * kCells, kLongWaves) * d.B;
+    if (d.C <= 3) hipLaunchKernelGGL(k_render_fwd_long<3>, dim3(long_blocks), dim3(64), 0, st, d);
+    else hipLaunchKernelGGL(k_render_fwd_long<6>, dim3(long_blocks), dim3(64), 0, st, d);
     DM4D_HIP_CHECK(hipGetLastError());
     return DM4D_OK;
 }
