@@ -820,7 +820,7 @@ __global__ __launch_bounds__(64) void k_render_bwd_long(BatchDesc d)
 }
 
 // ---------------------------------------------------------------------------------------- launchers
-constexpr int kLongWaves = 2048;   // waves per view of the long-cell kernel (each loops over the long cells it owns)
+constexpr int kLongWaves = 128;    // waves per view of the long-cell kernel (each loops over the long cells it owns)
 int launch_render_fwd(const BatchDesc &d, hipStream_t st)
 {
     const int T = ((d.W + kTile - 1) / kTile) * ((d.H + kTile - 1) / kTile);
