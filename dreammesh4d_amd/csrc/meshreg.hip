@@ -175,6 +175,55 @@ __global__ __launch_bounds__(256) void k_nc_bwd(NcPairs pr, int V, const int32_t
     for (int d = 0; d < 3; ++d) g_xyz[(t * V + i) * 3 + d] = acc[d] * s;
 }
 
+
+// ---------------------------------------------------------------------------------------- Laplacian smoothing
+// pytorch3d.loss.mesh_laplacian_smoothing(meshes, "uniform") (static stage: lambda 1, configs/sugar_static_refine.yaml:122;
+// system/sugar_static.py:246-254; dynamic stage: system/sugar_4dgen.py:227-230, lambda 0 as shipped):
+//   term_i = || (1 / deg_i) sum_{j in N(i)} v_j - v_i ||,  loss_t = mean_i term_i  (pytorch3d: then mean over meshes).
+// Forward: one thread per (mesh, vertex), keeps the unit vector u_i of the Laplacian for the backward.  Backward
+// (gather over the symmetric one-ring): d loss_t / d v_i = (-u_i + sum_{j in N(i)} u_j / deg_j) / V.
+__global__ __launch_bounds__(256) void k_lap_fwd(int V, const int32_t *__restrict__ off, const int32_t *__restrict__ nbr,
+                                                 const float *__restrict__ xyz, float *__restrict__ terms, float *__restrict__ unit)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= V) return;
+    const size_t t = blockIdx.y;
+    const float *x = xyz + t * V * 3;
+    float s[3] = {0.f, 0.f, 0.f};
+    const int e0 = off[i], e1 = off[i + 1];
+    for (int e = e0; e < e1; ++e) {
+        const float *xj = x + 3 * (size_t)nbr[e];
+        s[0] += xj[0]; s[1] += xj[1]; s[2] += xj[2];
+    }
+    const float inv = e1 > e0 ? 1.0f / (float)(e1 - e0) : 0.f;
+    float d[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) d[k] = e1 > e0 ? s[k] * inv - x[3 * (size_t)i + k] : 0.f;     // isolated vertex: row of zeros
+    const float n = sqrtf((d[0] * d[0] + d[1] * d[1]) + d[2] * d[2]);
+    terms[t * V + i] = n;
+    const float r = n > 0.f ? 1.0f / n : 0.f;                                                 // norm's subgradient at 0
+#pragma unroll
+    for (int k = 0; k < 3; ++k) unit[(t * V + i) * 3 + k] = d[k] * r;
+}
+
+__global__ __launch_bounds__(256) void k_lap_bwd(int V, const int32_t *__restrict__ off, const int32_t *__restrict__ nbr,
+                                                 const float *__restrict__ unit, const float *__restrict__ g_loss, float *__restrict__ g_xyz)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= V) return;
+    const size_t t = blockIdx.y;
+    const float *u = unit + t * V * 3;
+    float a[3] = {-u[3 * (size_t)i], -u[3 * (size_t)i + 1], -u[3 * (size_t)i + 2]};
+    for (int e = off[i]; e < off[i + 1]; ++e) {
+        const int j = nbr[e];
+        const float w = 1.0f / (float)(off[j + 1] - off[j]);
+        a[0] += u[3 * (size_t)j] * w; a[1] += u[3 * (size_t)j + 1] * w; a[2] += u[3 * (size_t)j + 2] * w;
+    }
+    const float s = g_loss[t] / (float)V;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) g_xyz[(t * V + i) * 3 + k] = a[k] * s;
+}
+
 static int arap_check(int T, int V, const void *off, const void *nbr, const void *rev, const void *w, const void *e,
                       const void *xyz, const void *rot)
 {
@@ -242,6 +291,28 @@ int dm4d_normal_consistency_backward(int32_t T, int32_t V, int32_t P, const int3
     NcPairs pr{P > 0 ? P : 1, pairs};
     hipLaunchKernelGGL(k_nc_bwd, dim3((V + 255) / 256, T), dim3(256), 0, (hipStream_t)stream, pr, V, vert_offsets, vert_items, xyz,
                        g_loss, g_xyz);
+    DM4D_HIP_CHECK(hipGetLastError());
+    return DM4D_OK;
+}
+
+int dm4d_laplacian_smoothing_forward(int32_t T, int32_t V, const int32_t *csr_offsets, const int32_t *neighbors, const float *xyz,
+                                     float *terms, float *unit, dm4d_stream_t stream)
+{
+    if (T < 0 || V < 0) { set_error("laplacian smoothing: negative size"); return DM4D_ERR_INVALID; }
+    if (T == 0 || V == 0) return DM4D_OK;
+    if (!csr_offsets || !neighbors || !xyz || !terms || !unit) { set_error("laplacian smoothing: null tensor"); return DM4D_ERR_INVALID; }
+    hipLaunchKernelGGL(k_lap_fwd, dim3((V + 255) / 256, T), dim3(256), 0, (hipStream_t)stream, V, csr_offsets, neighbors, xyz, terms, unit);
+    DM4D_HIP_CHECK(hipGetLastError());
+    return DM4D_OK;
+}
+
+int dm4d_laplacian_smoothing_backward(int32_t T, int32_t V, const int32_t *csr_offsets, const int32_t *neighbors, const float *unit,
+                                      const float *g_loss, float *g_xyz, dm4d_stream_t stream)
+{
+    if (T < 0 || V < 0) { set_error("laplacian smoothing: negative size"); return DM4D_ERR_INVALID; }
+    if (T == 0 || V == 0) return DM4D_OK;
+    if (!csr_offsets || !neighbors || !unit || !g_loss || !g_xyz) { set_error("laplacian smoothing: null tensor"); return DM4D_ERR_INVALID; }
+    hipLaunchKernelGGL(k_lap_bwd, dim3((V + 255) / 256, T), dim3(256), 0, (hipStream_t)stream, V, csr_offsets, neighbors, unit, g_loss, g_xyz);
     DM4D_HIP_CHECK(hipGetLastError());
     return DM4D_OK;
 }

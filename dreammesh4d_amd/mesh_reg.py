@@ -199,3 +199,59 @@ class MeshNormalConsistency:
         if self.n_pairs == 0:
             return x.sum() * 0.0
         return _NormalConsistency.apply(self, x).mean()
+
+
+class _LaplacianSmoothing(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, ls, xyz):
+        L = _lib.lib()
+        dev = ls.device
+        x = xyz.detach().to(torch.float32).contiguous()
+        T = int(x.shape[0])
+        terms = torch.empty(T, ls.n_verts, dtype=torch.float32, device=dev)
+        unit = torch.empty(T, ls.n_verts, 3, dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            _lib.check(L.dm4d_laplacian_smoothing_forward(T, ls.n_verts, ls._off.data_ptr(), ls._nbr.data_ptr(), x.data_ptr(),
+                                                          terms.data_ptr(), unit.data_ptr(), torch.cuda.current_stream(dev).cuda_stream),
+                       "dm4d_laplacian_smoothing_forward")
+        ctx.ls = ls
+        ctx.save_for_backward(unit)
+        return terms.sum(dim=1) / float(max(ls.n_verts, 1))
+
+    @staticmethod
+    def backward(ctx, g_loss):
+        L = _lib.lib()
+        ls = ctx.ls
+        (unit,) = ctx.saved_tensors
+        dev = ls.device
+        T = int(unit.shape[0])
+        g = g_loss.detach().to(torch.float32).contiguous()
+        gx = torch.empty_like(unit)
+        with torch.cuda.device(dev):
+            _lib.check(L.dm4d_laplacian_smoothing_backward(T, ls.n_verts, ls._off.data_ptr(), ls._nbr.data_ptr(), unit.data_ptr(),
+                                                           g.data_ptr(), gx.data_ptr(), torch.cuda.current_stream(dev).cuda_stream),
+                       "dm4d_laplacian_smoothing_backward")
+        return None, gx
+
+
+class MeshLaplacianSmoothing:
+    """``pytorch3d.loss.mesh_laplacian_smoothing(Meshes(...), method="uniform")`` for T meshes of one topology
+    (static stage: system/sugar_static.py:246-254, lambda 1; dynamic stage: system/sugar_4dgen.py:227-230, lambda 0 as
+    shipped) on csrc/meshreg.hip.  pytorch3d is not vendored / installed: parity rests on its published algorithm
+    (oracle/mesh_reg.py::laplacian_smoothing, closed-form cases) -- unpinned."""
+
+    def __init__(self, faces, n_verts, device):
+        from .graph_build import mesh_edge_csr
+
+        self.device = torch.device(device)
+        self.n_verts = int(n_verts)
+        f = np.asarray(torch.as_tensor(faces).cpu() if torch.is_tensor(faces) else faces, np.int64)
+        off, nbr, _ = mesh_edge_csr(np.zeros((self.n_verts, 3)), f)
+        T_ = lambda a: torch.as_tensor(np.ascontiguousarray(a), dtype=torch.int32, device=self.device)
+        self._off, self._nbr = T_(off), T_(nbr if len(nbr) else np.zeros(1, np.int64))
+
+    def __call__(self, verts):
+        if not verts.is_cuda:
+            raise _lib.Dm4dError("mesh Laplacian smoothing runs on the HIP device (no CPU fallback in the product)")
+        x = verts[None] if verts.dim() == 2 else verts
+        return _LaplacianSmoothing.apply(self, x).mean()

@@ -323,6 +323,16 @@ int dm4d_normal_consistency_backward(int32_t T, int32_t V, int32_t P, const int3
                                      const int32_t *vert_items, const float *xyz, const float *g_loss, float *g_xyz,
                                      dm4d_stream_t stream);
 
+/* pytorch3d.loss.mesh_laplacian_smoothing(meshes, method="uniform") of T meshes of one topology (static stage lambda 1,
+ * C/configs/sugar_static_refine.yaml:122, C/system/sugar_static.py:246-254; dynamic stage C/system/sugar_4dgen.py:227-230):
+ * terms [T,V] = || mean of the one-ring neighbours - v_i ||; loss_t = mean_i, pytorch3d returns the mean over meshes.
+ * csr_offsets [V+1] / neighbors [E]: symmetric one-ring.  unit [T,V,3] (forward output, backward input) = the unit
+ * Laplacian vectors.  g_xyz [T,V,3] is WRITTEN (gather, deterministic); g_loss [T]. */
+int dm4d_laplacian_smoothing_forward(int32_t T, int32_t V, const int32_t *csr_offsets, const int32_t *neighbors, const float *xyz,
+                                     float *terms, float *unit, dm4d_stream_t stream);
+int dm4d_laplacian_smoothing_backward(int32_t T, int32_t V, const int32_t *csr_offsets, const int32_t *neighbors, const float *unit,
+                                      const float *g_loss, float *g_xyz, dm4d_stream_t stream);
+
 /* ------------------------------------------------------------------ deformation-graph construction */
 
 /* K nearest graph nodes of every mesh vertex in geodesic (shortest edge path) distance + skinning weights: the output

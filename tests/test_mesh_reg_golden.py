@@ -62,3 +62,24 @@ def test_normal_consistency_oracle_closed_forms():
     # an edge shared by three faces contributes all three pairs
     fan = np.array([[0, 1, 2], [0, 1, 3], [0, 1, 4]])
     assert M.normal_consistency_pairs(fan).shape == (3, 4)
+
+
+def test_laplacian_smoothing_oracle_closed_forms():
+    """oracle/mesh_reg.py::laplacian_smoothing (pytorch3d's uniform Laplacian loss, parity unpinned): known answers."""
+    from oracle import mesh_reg as M
+
+    # a regular hexagon fan: the centre is the mean of its ring (term 0); a rim vertex has neighbours centre + two rim
+    ang = np.arange(6) * np.pi / 3
+    v = np.concatenate([[[0, 0, 0]], np.stack([np.cos(ang), np.sin(ang), np.zeros(6)], 1)])
+    faces = np.array([[0, 1 + k, 1 + (k + 1) % 6] for k in range(6)])
+    rim = np.linalg.norm((v[0] + v[2] + v[6]) / 3 - v[1])
+    want = 6 * rim / 7
+    got = float(M.laplacian_smoothing(torch.tensor(v[None]), faces))
+    assert abs(got - want) < 1e-12
+    # lifting the centre by h adds h to its own term
+    v2 = v.copy(); v2[0, 2] = 0.5
+    terms_rim = np.linalg.norm((v2[0] + v[2] + v[6]) / 3 - v[1])
+    assert abs(float(M.laplacian_smoothing(torch.tensor(v2[None]), faces)) - (0.5 + 6 * terms_rim) / 7) < 1e-12
+    # translation invariant, scales linearly, batched mean
+    b = torch.tensor(np.stack([v, 3.0 * v + 1.0]))
+    assert abs(float(M.laplacian_smoothing(b, faces)) - (want + 3 * want) / 2) < 1e-12

@@ -127,3 +127,28 @@ def test_normal_consistency_against_the_oracle():
     assert torch.equal(x.grad, x2.grad)
     # a single [V,3] mesh is the T = 1 batch
     assert abs(float(nc(x.detach()[0])) - float(M.normal_consistency(x64.detach()[:1], faces))) < 2e-6
+
+
+def test_laplacian_smoothing_against_the_oracle():
+    _need_gpu()
+    from dreammesh4d_amd.mesh_reg import MeshLaplacianSmoothing
+    from oracle import mesh_reg as M
+
+    dev = torch.device("cuda:0")
+    sc = syn.mesh_bound_scene(900, n_nodes=30, k=4, seed=4)
+    verts, faces = np.asarray(sc["verts"], np.float64), np.asarray(sc["faces"], np.int64)
+    V = len(verts)
+    g = torch.Generator().manual_seed(0)
+    x64 = (torch.tensor(verts)[None] + 0.03 * torch.randn(3, V, 3, dtype=torch.float64, generator=g)).requires_grad_(True)
+    want = M.laplacian_smoothing(x64, faces)
+    want.backward()
+    ls = MeshLaplacianSmoothing(faces, V, dev)
+    x = x64.detach().float().to(dev).requires_grad_(True)
+    got = ls(x)
+    got.backward()
+    assert abs(float(got) - float(want)) < 2e-6 * max(1.0, abs(float(want)))
+    gw = x64.grad.numpy()
+    assert np.abs(x.grad.cpu().numpy() - gw).max() < 2e-4 * np.abs(gw).max()
+    x2 = x.detach().clone().requires_grad_(True)
+    ls(x2).backward()
+    assert torch.equal(x.grad, x2.grad)
