@@ -74,11 +74,16 @@ class _Call:
         keep["proj"] = _f32(rs.projmatrix, dev)
         keep["campos"] = _f32(rs.campos, dev)
         self.M = int(keep["sh"].shape[1]) if keep["sh"] is not None and keep["sh"].dim() == 3 else 0
+        # extension of the upstream operator: colors_precomp [N,6] and a 6-vector bg blend two colour sets (RGB | normal,
+        # the two passes of the reference's renderers, …_normal.py:161-195) over ONE binning and blend
+        self.C = 6 if keep["col"] is not None and keep["col"].dim() == 2 and keep["col"].shape[1] == 6 else 3
+        if self.C == 6 and keep["bg"].numel() != 6:
+            raise ValueError("6-channel colors_precomp needs a 6-element bg")
         self.settings = _lib.RasterSettings(self.H, self.W, float(rs.tanfovx), float(rs.tanfovy),
                                             float(rs.scale_modifier), int(rs.sh_degree), int(bool(rs.prefiltered)),
                                             int(bool(rs.debug)), _ptr(keep["bg"]), _ptr(keep["view"]),
                                             _ptr(keep["proj"]), _ptr(keep["campos"]))
-        self.inputs = _lib.RasterInputs(self.N, self.M, 3, _ptr(keep["means3D"]), _ptr(keep["sh"]), _ptr(keep["col"]),
+        self.inputs = _lib.RasterInputs(self.N, self.M, self.C, _ptr(keep["means3D"]), _ptr(keep["sh"]), _ptr(keep["col"]),
                                         _ptr(keep["opac"]), _ptr(keep["scales"]), _ptr(keep["rots"]),
                                         _ptr(keep["cov"]))
 
@@ -102,7 +107,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         dev, N, H, W = call.dev, call.N, call.H, call.W
         with torch.cuda.device(dev):
             st = _stream(dev)
-            color = torch.empty(3, H, W, dtype=torch.float32, device=dev)
+            color = torch.empty(call.C, H, W, dtype=torch.float32, device=dev)
             depth = torch.empty(1, H, W, dtype=torch.float32, device=dev)
             alpha = torch.empty(1, H, W, dtype=torch.float32, device=dev)
             radii = torch.empty(N, dtype=torch.int32, device=dev)
@@ -142,20 +147,20 @@ class _RasterizeGaussians(torch.autograd.Function):
         f = dict(dtype=torch.float32, device=dev)
         with torch.cuda.device(dev):
             st = _stream(dev)
-            g_color = _f32(grad_color, dev) if grad_color is not None else torch.zeros(3, H, W, **f)
+            g_color = _f32(grad_color, dev) if grad_color is not None else torch.zeros(call.C, H, W, **f)
             g_depth = _f32(grad_depth, dev) if grad_depth is not None else None
             g_alpha = _f32(grad_alpha, dev) if grad_alpha is not None else None
             d_m2 = torch.empty(N, 3, **f)
             d_m3 = torch.empty(N, 3, **f)
             d_op = torch.empty(N, **f)
-            d_col = torch.empty(N, 3, **f)
+            d_col = torch.empty(N, call.C, **f)
             d_sh = torch.empty(N, call.M, 3, **f) if call.M > 0 else None
             has_sr = call.keep["scales"] is not None
             d_sc = torch.empty(N, 3, **f) if has_sr else None
             d_rot = torch.empty(N, 4, **f) if has_sr else None
             d_cov = torch.empty(N, 6, **f) if not has_sr else None
             R = ctx.num_records
-            grad = _bytes(L.dm4d_raster_grad_bytes(R, 3), dev)
+            grad = _bytes(L.dm4d_raster_grad_bytes(R, call.C), dev)
             _lib.check(L.dm4d_rasterize_backward(
                 call.settings, call.inputs, _ptr(radii), geom.data_ptr(), binning.data_ptr(), D, image.data_ptr(),
                 grad.data_ptr(), R, g_color.data_ptr(), _ptr(g_depth), _ptr(g_alpha), _ptr(d_m2), _ptr(d_m3),

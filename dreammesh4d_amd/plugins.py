@@ -4,7 +4,9 @@ The reference binds its YAML configs to classes registered under these names
 (``@threestudio.register(name)``, threestudio/__init__.py:5-32):
 
     diff-sugar-rasterizer-temporal      C/renderer/diff_sugar_rasterizer_temporal.py:56
+    diff-sugar-rasterizer-normal        C/renderer/diff_sugar_rasterizer_normal.py:54
     dynamic-sugar                       C/geometry/dynamic_sugar.py:42
+    sugar                               C/geometry/sugar.py:33
     temporal-stable-zero123-guidance    C/guidance/temporal_stable_zero123_guidance.py:76
     stable-zero123-guidance             threestudio/models/guidance/stable_zero123_guidance.py:75
 
@@ -14,13 +16,15 @@ The reference binds its YAML configs to classes registered under these names
 scope, so the classes take plain constructor arguments instead of a ``cfg`` dataclass: a
 maintainer wires ``cfg`` fields to them in a three-line subclass.
 """
-from .renderer import DiffGaussianTemporal
-from .sugar import DynamicSuGaR
+from .renderer import DiffGaussianTemporal, DiffSuGaRNormal
+from .sugar import DynamicSuGaR, SuGaR
 from .zero123 import StableZero123Guidance, TemporalStableZero123Guidance
 
 PLUGINS = {
     "diff-sugar-rasterizer-temporal": DiffGaussianTemporal,
+    "diff-sugar-rasterizer-normal": DiffSuGaRNormal,
     "dynamic-sugar": DynamicSuGaR,
+    "sugar": SuGaR,
     "temporal-stable-zero123-guidance": TemporalStableZero123Guidance,
     "stable-zero123-guidance": StableZero123Guidance,
 }

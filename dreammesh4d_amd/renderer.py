@@ -209,3 +209,89 @@ class DiffGaussianTemporal:
         return {"render": color[:3].clamp(0, 1), "normal": n_map, "normal_from_dist": nd_map, "depth": depth,
                 "mask": alpha, "viewspace_points": vsp, "visibility_filter": out["radii"][0] > 0,
                 "radii": out["radii"][0], "raw_normal": _where_detached(n_raw, mask3), "raw_normal_from_dist": nd_raw}
+
+
+class DiffSuGaRNormal:
+    """The reference's ``diff-sugar-rasterizer-normal`` renderer (custom/threestudio-dreammesh4d/renderer/
+    diff_sugar_rasterizer_normal.py:54-226) over a static ``sugar.SuGaR`` geometry: per view the RGB pass and the
+    normal pass of the reference (:161-195) as ONE call of the drop-in operator with 6-channel colours (RGB | Gaussian
+    normal; both passes share geometry, binning and blend), then the reference's epilogue (normal from depth, masks,
+    detach rules :196-207).  Every static parameter receives its gradient through the operator's backward.
+    Colours come from the degree-0 SH as precomputed RGB (``active_sh_degree = 0``: identical values; the operator's own
+    SH path is the single-pass alternative)."""
+
+    def __init__(self, geometry, back_ground_color=(1.0, 1.0, 1.0), invert_bg_prob=1.0, training=True, seed=0):
+        self.geometry = geometry
+        self.training = training
+        self.invert_bg_prob = invert_bg_prob
+        self.background_tensor = torch.tensor(back_ground_color, dtype=torch.float32, device=geometry.device)
+        self._rng = torch.Generator(device="cpu").manual_seed(seed)
+
+    def train(self, mode=True):
+        self.training = mode
+        return self
+
+    def eval(self):
+        return self.train(False)
+
+    def forward(self, viewpoint_camera: Camera, bg_color=None, scaling_modifier=1.0, override_color=None,
+                compute_normal_from_dist=True, **kwargs) -> Dict:
+        from . import diff_gaussian_rasterization as dgr
+
+        g = self.geometry
+        bg = self.background_tensor if bg_color is None else bg_color.to(g.device)
+        # training: the background is inverted when a uniform draw EXCEEDS invert_bg_prob (…_normal.py:93-98)
+        if self.training and float(torch.rand(1, generator=self._rng)) > self.invert_bg_prob:
+            bg = 1.0 - bg
+        H, W = int(viewpoint_camera.image_height), int(viewpoint_camera.image_width)
+        means3D = g.get_xyz
+        vsp = torch.zeros_like(means3D, requires_grad=True)
+        rgb = g.get_points_rgb() if override_color is None else override_color
+        rs = dgr.GaussianRasterizationSettings(
+            image_height=H, image_width=W, tanfovx=math.tan(0.5 * float(viewpoint_camera.FoVx)),
+            tanfovy=math.tan(0.5 * float(viewpoint_camera.FoVy)), bg=torch.cat([bg, bg]), scale_modifier=scaling_modifier,
+            viewmatrix=viewpoint_camera.world_view_transform, projmatrix=viewpoint_camera.full_proj_transform,
+            sh_degree=g.active_sh_degree, campos=viewpoint_camera.camera_center, prefiltered=False, debug=False)
+        color, radii, depth, alpha = dgr.GaussianRasterizer(rs)(
+            means3D=means3D, means2D=vsp, opacities=g.get_opacity, colors_precomp=torch.cat([rgb, g.get_gs_normals], dim=1),
+            scales=g.get_scaling, rotations=g.get_rotation)
+        mask = alpha > 0.99
+        mask3 = mask.expand(3, H, W)
+        nd_raw = nd_map = None
+        if compute_normal_from_dist and "rays_d" in kwargs:
+            bi = kwargs.get("batch_idx", 0)
+            xyz = kwargs["rays_o"][bi] + depth.permute(1, 2, 0) * kwargs["rays_d"][bi]                  # :162-163 (before the detach)
+            nd_raw = F.normalize(depth_to_normal(xyz.permute(2, 0, 1)[None])[0], dim=0)
+            nd_map = _where_detached(nd_raw * 0.5 * alpha + 0.5, mask3)
+            nd_raw = _where_detached(nd_raw, mask3)
+        n_raw = F.normalize(color[3:], dim=0)
+        n_map = _where_detached(n_raw * 0.5 * alpha + 0.5, mask3)
+        return {"render": color[:3].clamp(0, 1), "normal": n_map, "normal_from_dist": nd_map, "mask": alpha,
+                "depth": _where_detached(depth, mask), "viewspace_points": vsp, "visibility_filter": radii > 0, "radii": radii,
+                "raw_normal": n_raw, "raw_normal_from_dist": nd_raw}
+
+    def batch_forward(self, batch: Dict) -> Dict:
+        """``GaussianBatchRenderer.batch_forward`` (renderer/gaussian_batch_renderer.py:9-122) for the static geometry."""
+        g = self.geometry
+        c2w = batch["c2w"].to(g.device)
+        B = int(c2w.shape[0])
+        H, W = int(batch["height"]), int(batch["width"])
+        fovy = torch.as_tensor(batch["fovy"], dtype=torch.float32, device=g.device).reshape(-1).expand(B)
+        w2c, full, center = cam_info_gaussian(c2w, fovy, fovy, 0.1, 100.0)
+        outs = []
+        for b in range(B):
+            cam = Camera(FoVx=float(fovy[b]), FoVy=float(fovy[b]), image_width=W, image_height=H, world_view_transform=w2c[b],
+                         full_proj_transform=full[b], camera_center=center[b], timestamp=None, frame_idx=None)
+            kw = {}
+            if batch.get("rays_d") is not None:
+                kw = dict(rays_o=batch["rays_o"].to(g.device), rays_d=batch["rays_d"].to(g.device), batch_idx=b)
+            outs.append(self.forward(cam, self.background_tensor, **kw))
+        st = lambda k: torch.stack([o[k] for o in outs]).permute(0, 2, 3, 1)
+        res = {"comp_rgb": st("render"), "comp_normal": st("normal"), "comp_depth": st("depth"), "comp_mask": st("mask"),
+               "viewspace_points": [o["viewspace_points"] for o in outs], "visibility_filter": [o["visibility_filter"] for o in outs],
+               "radii": [o["radii"] for o in outs]}
+        if outs[0]["normal_from_dist"] is not None:
+            res["comp_normal_from_dist"] = st("normal_from_dist")
+        return res
+
+    __call__ = batch_forward

@@ -239,3 +239,131 @@ class DynamicSuGaR(nn.Module):
     def get_timed_surface_mesh(self, timestamp=None, frame_idx=None):
         """(deformed vertices [N_t,V,3], faces [F,3]) -- the reference returns a pytorch3d ``Meshes`` of them."""
         return self.get_timed_vertex_xyz(timestamp, frame_idx), self._surface_mesh_faces
+
+
+class SuGaR(nn.Module):
+    """Static mesh-bound Gaussians: the host-side mirror of ``SuGaRModel`` bound to a surface mesh
+    (custom/threestudio-dreammesh4d/geometry/sugar.py:33-978, registered as ``sugar``), the geometry of the static
+    (refinement) stage -- configs/sugar_static_refine.yaml.  Same parameter names as the reference (``_points``,
+    ``_surface_mesh_faces``, ``surface_mesh_thickness``, ``_scales``, ``_quaternions``, ``all_densities``,
+    ``_sh_coordinates_dc`` / ``_rest``), so its checkpoints load by name (wire_formats.load_geometry).  Unlike the
+    dynamic stage every property is differentiable here: they are the torch ops of geometry.py evaluated per call
+    (positions, scales, opacities, colours are LEARNT in this stage, sugar.py:329-382), and they feed the HIP
+    rasterizer through the drop-in operator.  The mesh-extraction / texture-baking half of SuGaRModel is out of scope."""
+
+    def __init__(self, verts, faces, n_gaussians_per_surface_triangle=6, spatial_extent=3.8, vertex_colors=None,
+                 learn_positions=True, learn_opacities=True, learn_scales=True, freeze_gaussians=False,
+                 position_lr=0.001, feature_lr=0.01, opacity_lr=0.05, scaling_lr=0.005, rotation_lr=0.005,
+                 spatial_lr_scale=10.0, device="cuda"):
+        super().__init__()
+        dev = torch.device(device)
+        T = lambda a, dt=torch.float32: torch.as_tensor(a, dtype=dt, device=dev)
+        verts, faces = T(verts), T(faces, torch.long)
+        G = int(n_gaussians_per_surface_triangle)
+        F_, V = int(faces.shape[0]), int(verts.shape[0])
+        N = F_ * G
+        self.cfg_n_gaussians_per_surface_triangle = G
+        self.active_sh_degree = 0
+        self.register_buffer("_surface_mesh_faces", faces)
+        self.register_buffer("_bary", geo.bary_coords(G, dev))
+        self.surface_mesh_thickness = nn.Parameter(T(spatial_extent / 1_000_000), requires_grad=False)
+        self._points = nn.Parameter(verts.clone(), requires_grad=learn_positions)
+        if vertex_colors is None:
+            vertex_colors = torch.full((V, 3), 0.5, device=dev)
+        colors = (T(vertex_colors)[faces][:, None] * self._bary[None]).sum(-2).reshape(-1, 3)    # sugar.py:209-224
+        self._sh_coordinates_dc = nn.Parameter(RGB2SH(colors).unsqueeze(1), requires_grad=not freeze_gaussians)
+        self._sh_coordinates_rest = nn.Parameter(torch.zeros(N, 0, 3, device=dev), requires_grad=not freeze_gaussians)
+        self.all_densities = nn.Parameter(torch.full((N, 1), 2.9444, device=dev), requires_grad=learn_opacities)   # sigmoid^-1(0.95)
+        fv = verts[faces]
+        s0 = (fv - fv[:, [1, 2, 0]]).norm(dim=-1).min(dim=-1)[0] * geo.circle_radius(G)           # sugar.py:262-268
+        self._scales = nn.Parameter(torch.log(s0.clamp_min(1e-7)).reshape(F_, 1, 1).expand(-1, G, 2).reshape(-1, 2).clone(),
+                                    requires_grad=learn_scales)
+        cx = torch.zeros(N, 2, device=dev)
+        cx[:, 0] = 1.0
+        self._quaternions = nn.Parameter(cx, requires_grad=learn_scales)       # (the reference ties it to learn_scales, :170)
+        self._lr = dict(points=position_lr, f_dc=feature_lr, f_rest=feature_lr, all_densities=opacity_lr, scales=scaling_lr,
+                        quaternions=rotation_lr)
+        self.spatial_lr_scale = spatial_lr_scale
+        self.training_setup()
+
+    @property
+    def device(self):
+        return self._points.device
+
+    @property
+    def n_verts(self):
+        return int(self._points.shape[0])
+
+    @property
+    def n_gaussians(self):
+        return int(self._surface_mesh_faces.shape[0]) * self.cfg_n_gaussians_per_surface_triangle
+
+    # ---- the property surface the renderer and the systems use (sugar.py:471-570)
+    @property
+    def get_xyz_verts(self):
+        return self._points
+
+    @property
+    def get_faces(self):
+        return self._surface_mesh_faces
+
+    @property
+    def get_xyz(self):
+        return geo.points(self._points, self._surface_mesh_faces, self._bary)
+
+    @property
+    def get_scaling(self):
+        return geo.scaling(self._scales, float(self.surface_mesh_thickness))
+
+    @property
+    def get_rotation(self):
+        return geo.quaternions(self._points, self._surface_mesh_faces, self._quaternions, self.cfg_n_gaussians_per_surface_triangle)
+
+    @property
+    def get_opacity(self):
+        return geo.strengths(self.all_densities).reshape(-1, 1)
+
+    @property
+    def get_features(self):
+        return torch.cat([self._sh_coordinates_dc, self._sh_coordinates_rest], dim=1)
+
+    def get_points_rgb(self):
+        return geo.points_rgb(self._sh_coordinates_dc)
+
+    @property
+    def get_face_normals(self):
+        return geo.face_normals(self._points, self._surface_mesh_faces)
+
+    @property
+    def get_gs_normals(self):
+        return self.get_face_normals.repeat_interleave(self.cfg_n_gaussians_per_surface_triangle, dim=0)
+
+    # ---- optimiser (sugar.py:329-416)
+    def training_setup(self):
+        ls = self._lr
+        cand = [("points", self._points, C(ls["points"], 0, 0) * self.spatial_lr_scale), ("f_dc", self._sh_coordinates_dc, C(ls["f_dc"], 0, 0)),
+                ("f_rest", self._sh_coordinates_rest, C(ls["f_rest"], 0, 0) / 20.0), ("all_densities", self.all_densities, C(ls["all_densities"], 0, 0)),
+                ("scales", self._scales, C(ls["scales"], 0, 0)), ("quaternions", self._quaternions, C(ls["quaternions"], 0, 0))]
+        self.optimize_list = [{"params": [p], "lr": lr, "name": n} for n, p, lr in cand if p.requires_grad]
+        self.optimize_params = [d["name"] for d in self.optimize_list]
+        self.optimizer = torch.optim.Adam(self.optimize_list, lr=0.0, eps=1e-15)
+
+    def update_learning_rate(self, iteration):
+        """Only the position and feature rates follow a schedule (sugar.py:386-403)."""
+        for gq in self.optimizer.param_groups:
+            n = gq.get("name")
+            if n == "points":
+                gq["lr"] = C(self._lr["points"], 0, iteration, interpolation="exp") * self.spatial_lr_scale
+            elif n == "f_dc":
+                gq["lr"] = C(self._lr["f_dc"], 0, iteration, interpolation="exp")
+            elif n == "f_rest":
+                gq["lr"] = C(self._lr["f_rest"], 0, iteration, interpolation="exp") / 20.0
+
+    def merge_optimizer(self, net_optimizer):
+        groups = list(self.optimize_list) + ([{"params": g["params"], "lr": g["lr"]} for g in net_optimizer.param_groups]
+                                             if net_optimizer is not None else [])
+        self.optimizer = torch.optim.AdamW(groups, lr=0.0, betas=(0.9, 0.99), eps=1e-15)
+        return self.optimizer
+
+    def update_step(self, epoch, global_step, on_load_weights=False):
+        self.global_step = global_step
