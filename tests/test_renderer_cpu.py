@@ -70,8 +70,8 @@ def test_rays_hit_the_projected_pixel():
 def test_plugin_names_cover_the_reference_registry_entries_of_the_hot_path():
     from dreammesh4d_amd import plugins
 
-    assert set(plugins.PLUGINS) == {"diff-sugar-rasterizer-temporal", "dynamic-sugar", "temporal-stable-zero123-guidance",
-                                    "stable-zero123-guidance"}
+    assert set(plugins.PLUGINS) == {"diff-sugar-rasterizer-temporal", "diff-sugar-rasterizer-normal", "dynamic-sugar", "sugar",
+                                    "temporal-stable-zero123-guidance", "stable-zero123-guidance"}
     reg = {}
     fake = types.SimpleNamespace(register=lambda name: (lambda cls: reg.setdefault(name, cls)))
     names = plugins.register(fake, prefix="")
@@ -83,3 +83,9 @@ def test_plugin_names_cover_the_reference_registry_entries_of_the_hot_path():
         assert callable(getattr(plugins.PLUGINS["dynamic-sugar"], meth))
     for prop in ("get_xyz", "get_scaling", "get_rotation", "get_opacity", "get_features", "get_xyz_verts", "get_faces"):
         assert isinstance(getattr(plugins.PLUGINS["dynamic-sugar"], prop), property)
+        assert isinstance(getattr(plugins.PLUGINS["sugar"], prop), property)
+    assert isinstance(plugins.PLUGINS["sugar"].get_gs_normals, property)
+    for meth in ("batch_forward", "forward"):
+        assert callable(getattr(plugins.PLUGINS["diff-sugar-rasterizer-normal"], meth))
+    for meth in ("get_points_rgb", "merge_optimizer", "update_learning_rate", "update_step", "training_setup"):
+        assert callable(getattr(plugins.PLUGINS["sugar"], meth))
