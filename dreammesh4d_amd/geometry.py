@@ -78,8 +78,11 @@ def matrix_to_quaternion(R):
     pytorch3d.transforms.matrix_to_quaternion, standardised to w >= 0."""
     m = R.reshape(R.shape[:-2] + (9,))
     m00, m01, m02, m10, m11, m12, m20, m21, m22 = m.unbind(-1)
-    q_abs = torch.sqrt(torch.clamp(torch.stack([1 + m00 + m11 + m22, 1 + m00 - m11 - m22,
-                                                1 - m00 + m11 - m22, 1 - m00 - m11 + m22], dim=-1), min=0.0))
+    x = torch.stack([1 + m00 + m11 + m22, 1 + m00 - m11 - m22, 1 - m00 + m11 - m22, 1 - m00 - m11 + m22], dim=-1)
+    # pytorch3d's _sqrt_positive_part: sqrt with a ZERO subgradient where x <= 0 (sqrt(clamp(x, 0)) back-propagates
+    # inf * 0 = NaN there -- it broke the static stage, where the vertices are learnt, within three iterations)
+    pos = x > 0
+    q_abs = torch.where(pos, torch.sqrt(torch.where(pos, x, torch.ones_like(x))), torch.zeros_like(x))
     cand = torch.stack([
         torch.stack([q_abs[..., 0] ** 2, m21 - m12, m02 - m20, m10 - m01], dim=-1),
         torch.stack([m21 - m12, q_abs[..., 1] ** 2, m10 + m01, m02 + m20], dim=-1),

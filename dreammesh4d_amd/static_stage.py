@@ -1,0 +1,89 @@
+"""One static-stage (SuGaR refinement) training iteration: host-side restatement of ``SuGaRStatic.training_step``
+(custom/threestudio-dreammesh4d/system/sugar_static.py:110-340, stage "sugar") with the loss weights of
+configs/sugar_static_refine.yaml:105-133 and the optimiser of geometry/sugar.py:329-416 (AdamW, betas (0.9, 0.99),
+eps 1e-15; groups points / f_dc / f_rest / all_densities / scales / quaternions).
+
+Per iteration: a reference substep -- the reference view, rgb and mask MSE against the input image (:151-160) -- and a
+random substep -- `random_camera.batch_size` views (elev U[-10,80], azim U[-180,180], dist 3.8, fovy 20 deg; yaml:21-28):
+Zero123 SDS (:197-205), the mesh regularisers of the surface mesh (normal consistency 10, Laplacian smoothing 1,
+:246-254) and the total-variation terms of rgb / depth / normal (:274-290, threestudio/utils/loss.py:8-16).  Every view is
+one fused RGB + normal call of the HIP rasterizer through ``renderer.DiffSuGaRNormal``; the geometry's properties are
+torch ops (they are learnt here), the regularisers run on csrc/meshreg.hip.  Data-parallel training (static stage:
+~1.7 MB of gradients) uses the same ``distributed.GradAllReducer``.
+"""
+import torch
+import torch.nn.functional as F
+
+from . import distributed as D
+from . import synthetic as syn
+from .schedule import C
+
+# sugar_static_refine.yaml:105-133 (terms with lambda 0 and the stage-"gaussian" SuGaR regularisers, which start at
+# step 3000 of a 2000-step schedule, are not part of the loop)
+LAMBDA = {"sds": 0.01, "rgb": 1000.0, "mask": 100.0, "normal_consistency": 10.0, "laplacian_smoothing": 1.0, "rgb_tv": 1.0,
+          "normal_tv": 1.0, "depth_tv": 1.0}
+
+
+def tv_loss(x):
+    """threestudio/utils/loss.py:8-16 on [B,C,H,W]."""
+    b, c, h, w = x.shape
+    h_tv = (x[:, :, 1:, :] - x[:, :, :h - 1, :]).pow(2).sum()
+    w_tv = (x[:, :, :, 1:] - x[:, :, :, :w - 1]).pow(2).sum()
+    return 2 * (h_tv / (c * (h - 1) * w) + w_tv / (c * h * (w - 1))) / b
+
+
+class StaticStage:
+    def __init__(self, geometry, renderer, ref_image, ref_mask, H, W, guidance=None, random_views=4, normal_consistency=None,
+                 laplacian_smoothing=None, seed=0):
+        self.g, self.r = geometry, renderer
+        self.ref_image, self.ref_mask = ref_image, ref_mask            # [1,H,W,3], [1,H,W,1]
+        self.H, self.W = H, W
+        self.guidance = guidance
+        self.rv = random_views
+        self.nc, self.lap = normal_consistency, laplacian_smoothing    # mesh_reg.MeshNormalConsistency / MeshLaplacianSmoothing
+        self.dev = geometry.device
+        self.gen = torch.Generator(device="cpu").manual_seed(seed + 977 * D.rank())
+        self.opt = geometry.merge_optimizer(None)
+        self.reducer = D.GradAllReducer([p for p in geometry.parameters() if p.requires_grad and p.numel()])
+        self.ref_cam = syn.make_camera(H, W, elev_deg=5.0, azim_deg=0.0)                # yaml:11-14
+        self.global_step = 0
+
+    def _batch(self, cams):
+        c2w = torch.stack([torch.tensor(c.c2w, dtype=torch.float32) for c in cams])
+        return {"c2w": c2w, "fovy": torch.tensor([c.fovy for c in cams], dtype=torch.float32), "height": self.H, "width": self.W}
+
+    def iteration(self):
+        g, it = self.g, self.global_step
+        g.update_learning_rate(it)
+        self.opt.zero_grad(set_to_none=True)
+        terms = {}
+        # ---- reference substep
+        out = self.r.batch_forward(self._batch([self.ref_cam]))
+        m = self.ref_mask.float()
+        terms["rgb"] = F.mse_loss(self.ref_image * m, out["comp_rgb"] * m)
+        terms["mask"] = F.mse_loss(m, out["comp_mask"])
+        loss = LAMBDA["rgb"] * terms["rgb"] + LAMBDA["mask"] * terms["mask"]
+        # ---- random substep
+        u = torch.rand(self.rv, 2, generator=self.gen)
+        elev, azim = -10.0 + 90.0 * u[:, 0], -180.0 + 360.0 * u[:, 1]
+        cams = [syn.make_camera(self.H, self.W, elev_deg=float(e), azim_deg=float(a)) for e, a in zip(elev, azim)]
+        out = self.r.batch_forward(self._batch(cams))
+        if self.guidance is not None:
+            self.guidance.update_step(0, it)
+            go = self.guidance(out["comp_rgb"], elev.to(self.dev), azim.to(self.dev), torch.full((self.rv,), 3.8, device=self.dev))
+            terms["sds"] = go["loss_sds"]
+            loss = loss + LAMBDA["sds"] * terms["sds"]
+        if self.nc is not None:
+            terms["normal_consistency"] = self.nc(g.get_xyz_verts)
+            loss = loss + LAMBDA["normal_consistency"] * terms["normal_consistency"]
+        if self.lap is not None:
+            terms["laplacian_smoothing"] = self.lap(g.get_xyz_verts)
+            loss = loss + LAMBDA["laplacian_smoothing"] * terms["laplacian_smoothing"]
+        for k, key in (("rgb_tv", "comp_rgb"), ("depth_tv", "comp_depth"), ("normal_tv", "comp_normal")):
+            terms[k] = tv_loss(out[key].permute(0, 3, 1, 2))
+            loss = loss + LAMBDA[k] * terms[k]
+        loss.backward()
+        self.reducer()
+        self.opt.step()
+        self.global_step += 1
+        return {"loss": loss.detach(), **{k: v.detach() for k, v in terms.items()}}
