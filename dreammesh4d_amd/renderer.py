@@ -234,8 +234,15 @@ class DiffSuGaRNormal:
     def eval(self):
         return self.train(False)
 
+    def gaussians(self):
+        """The geometry's per-Gaussian attributes, evaluated ONCE for all the views of a batch (the reference re-evaluates
+        the properties for every view; the autograd graph is the same, shared)."""
+        g = self.geometry
+        return dict(xyz=g.get_xyz, opacity=g.get_opacity, scaling=g.get_scaling, rotation=g.get_rotation, rgb=g.get_points_rgb(),
+                    normals=g.get_gs_normals)
+
     def forward(self, viewpoint_camera: Camera, bg_color=None, scaling_modifier=1.0, override_color=None,
-                compute_normal_from_dist=True, **kwargs) -> Dict:
+                compute_normal_from_dist=True, gaussians=None, **kwargs) -> Dict:
         from . import diff_gaussian_rasterization as dgr
 
         g = self.geometry
@@ -244,17 +251,18 @@ class DiffSuGaRNormal:
         if self.training and float(torch.rand(1, generator=self._rng)) > self.invert_bg_prob:
             bg = 1.0 - bg
         H, W = int(viewpoint_camera.image_height), int(viewpoint_camera.image_width)
-        means3D = g.get_xyz
+        ga = self.gaussians() if gaussians is None else gaussians
+        means3D = ga["xyz"]
         vsp = torch.zeros_like(means3D, requires_grad=True)
-        rgb = g.get_points_rgb() if override_color is None else override_color
+        rgb = ga["rgb"] if override_color is None else override_color
         rs = dgr.GaussianRasterizationSettings(
             image_height=H, image_width=W, tanfovx=math.tan(0.5 * float(viewpoint_camera.FoVx)),
             tanfovy=math.tan(0.5 * float(viewpoint_camera.FoVy)), bg=torch.cat([bg, bg]), scale_modifier=scaling_modifier,
             viewmatrix=viewpoint_camera.world_view_transform, projmatrix=viewpoint_camera.full_proj_transform,
             sh_degree=g.active_sh_degree, campos=viewpoint_camera.camera_center, prefiltered=False, debug=False)
         color, radii, depth, alpha = dgr.GaussianRasterizer(rs)(
-            means3D=means3D, means2D=vsp, opacities=g.get_opacity, colors_precomp=torch.cat([rgb, g.get_gs_normals], dim=1),
-            scales=g.get_scaling, rotations=g.get_rotation)
+            means3D=means3D, means2D=vsp, opacities=ga["opacity"], colors_precomp=torch.cat([rgb, ga["normals"]], dim=1),
+            scales=ga["scaling"], rotations=ga["rotation"])
         mask = alpha > 0.99
         mask3 = mask.expand(3, H, W)
         nd_raw = nd_map = None
@@ -279,12 +287,13 @@ class DiffSuGaRNormal:
         fovy = torch.as_tensor(batch["fovy"], dtype=torch.float32, device=g.device).reshape(-1).expand(B)
         w2c, full, center = cam_info_gaussian(c2w, fovy, fovy, 0.1, 100.0)
         outs = []
+        ga = self.gaussians()
         for b in range(B):
             cam = Camera(FoVx=float(fovy[b]), FoVy=float(fovy[b]), image_width=W, image_height=H, world_view_transform=w2c[b],
                          full_proj_transform=full[b], camera_center=center[b], timestamp=None, frame_idx=None)
-            kw = {}
+            kw = {"gaussians": ga}
             if batch.get("rays_d") is not None:
-                kw = dict(rays_o=batch["rays_o"].to(g.device), rays_d=batch["rays_d"].to(g.device), batch_idx=b)
+                kw.update(rays_o=batch["rays_o"].to(g.device), rays_d=batch["rays_d"].to(g.device), batch_idx=b)
             outs.append(self.forward(cam, self.background_tensor, **kw))
         st = lambda k: torch.stack([o[k] for o in outs]).permute(0, 2, 3, 1)
         res = {"comp_rgb": st("render"), "comp_normal": st("normal"), "comp_depth": st("depth"), "comp_mask": st("mask"),
