@@ -48,7 +48,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-iters", action="store_true", help="skip the dynamic-stage iterations/sec measurement")
-    ap.add_argument("--cpu-baseline-views", type=int, default=4)
+    ap.add_argument("--cpu-baseline-views", type=int, default=24)     # ~12 s of host work at ~2 views/s
     return ap.parse_args()
 
 
