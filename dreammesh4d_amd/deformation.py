@@ -214,7 +214,11 @@ class DeformationNetwork(nn.Module):
             if getattr(self, "_hex_plan_key", None) != key:
                 self._hex_plan = hx.HexPlan(self.deformation_net.grid, nodes)
                 self._hex_plan_key = key
-            feat = hx.hexplane_features(self.deformation_net.grid, self._hex_plan, timestamps * 2.0 - 1.0)
+            # 2 t - 1 (dynamic_sugar.py:431) in one launch: addcmul(-1, t, 2) rounds exactly like (t * 2) - 1 (2 t is exact)
+            c = getattr(self, "_affine_consts", None)
+            if c is None or c[0].device != timestamps.device:
+                c = self._affine_consts = (torch.tensor(-1.0, device=timestamps.device), torch.tensor(2.0, device=timestamps.device))
+            feat = hx.hexplane_features(self.deformation_net.grid, self._hex_plan, torch.addcmul(c[0], timestamps.float(), c[1]))
             d = self.deformation_net
             lin0 = d.feature_out[0]
             heads = [d.pos_deform] + ([] if d.no_ds else [d.scales_deform]) + ([] if d.no_dr else [d.rotations_deform]) + \
