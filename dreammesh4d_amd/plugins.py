@@ -9,6 +9,8 @@ The reference binds its YAML configs to classes registered under these names
     sugar                               C/geometry/sugar.py:33
     temporal-stable-zero123-guidance    C/guidance/temporal_stable_zero123_guidance.py:76
     stable-zero123-guidance             threestudio/models/guidance/stable_zero123_guidance.py:75
+    solid-color-background              threestudio/models/background/solid_color_background.py:14
+    no-material                         threestudio/models/materials/no_material.py:16
 
 ``PLUGINS`` maps every name to the class of this package that implements its hot-path surface;
 ``register(threestudio_module)`` enters them into a threestudio registry (when threestudio is importable,
@@ -17,6 +19,7 @@ scope, so the classes take plain constructor arguments ins
 maintainer wires ``cfg`` fields to them in a three-line subclass.
 """
 from .renderer import DiffGaussianTemporal, DiffSuGaRNormal
+from .shims import NoMaterial, SolidColorBackground
 from .sugar import DynamicSuGaR, SuGaR
 from .zero123 import StableZero123Guidance, TemporalStableZero123Guidance
 
@@ -27,6 +30,8 @@ PLUGINS = {
     "sugar": SuGaR,
     "temporal-stable-zero123-guidance": TemporalStableZero123Guidance,
     "stable-zero123-guidance": StableZero123Guidance,
+    "solid-color-background": SolidColorBackground,
+    "no-material": NoMaterial,
 }
 
 
