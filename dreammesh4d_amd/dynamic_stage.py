@@ -61,7 +61,7 @@ class DynamicStage:
         self.opt = torch.optim.AdamW([
             {"params": net.get_mlp_parameters(), "lr": deformation_lr, "name": "deformation"},
             {"params": net.get_grid_parameters(), "lr": grid_lr, "name": "grid"}],
-            lr=0.0, betas=(0.9, 0.99), eps=1e-15)
+            lr=0.0, betas=(0.9, 0.99), eps=1e-15, **({"fused": True} if self.dev.type == "cuda" else {}))   # one multi-tensor launch
         self.sched = {"deformation": deformation_lr, "grid": grid_lr}
         self.reducer = D.GradAllReducer(net.parameters())
         self.global_step = 0
