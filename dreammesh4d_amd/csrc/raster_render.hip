@@ -339,20 +339,25 @@ __global__ __launch_bounds__(64) void k_render_fwd(BatchDesc d)
 // beside the small variant's sort, on their own stream (regular kernel 252 -> 204 us; run beside the regular kernel
 // instead, the same code gained nothing: 247 us against 219).
 // Staging: 64 entries per chunk, one per lane: [0..5] x y A B C opacity | [6] k bits | [8..13] colours | [14] depth | [15] 1
+// Four cells per workgroup (one per wave, no workgroup barrier): the long-running waves then share few CUs instead of
+// taking one SIMD on most of them, which slowed the barrier-coupled workgroups of K4's small variant running beside.
 template <int C>
-__global__ __launch_bounds__(64) void k_render_fwd_long(BatchDesc d)
+__global__ __launch_bounds__(256) void k_render_fwd_long(BatchDesc d)
 {
-    __shared__ __attribute__((aligned(16))) float s_e[64 * 16];
-    __shared__ __attribute__((aligned(16))) float s_a[64];      // alphas [pixel][entry slot]
-    const int view = (int)(blockIdx.x % (uint32_t)d.B);
-    const uint32_t first = blockIdx.x / (uint32_t)d.B, step = gridDim.x / (uint32_t)d.B;
+    __shared__ __attribute__((aligned(16))) float s_e_all[4][64 * 16];
+    __shared__ __attribute__((aligned(16))) float s_a_all[4][64];      // alphas [pixel][entry slot]
+    float *s_e = s_e_all[threadIdx.x >> 6], *s_a = s_a_all[threadIdx.x >> 6];
+    const uint32_t wave = blockIdx.x * 4u + (threadIdx.x >> 6), n_waves = gridDim.x * 4u;
+    const int view = (int)(wave % (uint32_t)d.B);
+    const uint32_t first = wave / (uint32_t)d.B, step = n_waves / (uint32_t)d.B;
+    if (first >= step) return;                 // the few waves past the last full round of views
     const ViewCtx c = resolve(d, view);
     const ViewParams &vp = c.vp;
     const float *__restrict__ colors = c.colors;
     const GeomPtrs &g = c.g;
     const BinPtrs &b = c.b;
     const ImgPtrs &im = c.im;
-    const int lane = threadIdx.x, r = lane >> 4, p = lane & 15;
+    const int lane = threadIdx.x & 63, r = lane >> 4, p = lane & 15;
     const uint32_t n_long = min(g.counters[kCntLongEarly], (uint32_t)(c.T * kCells));
     if (first < n_long) __builtin_amdgcn_s_setprio(3);
     for (uint32_t it = first; it < n_long; it += step) {
@@ -846,9 +851,9 @@ int launch_render_fwd_long(const BatchDesc &d, hipStream_t st)
 {
     const int T = ((d.W + kTile - 1) / kTile) * ((d.H + kTile - 1) / kTile);
     if (T <= 0) return DM4D_OK;
-    const int long_blocks = min(T * kCells, kLongWaves) * d.B;
-    if (d.C <= 3) hipLaunchKernelGGL(k_render_fwd_long<3>, dim3(long_blocks), dim3(64), 0, st, d);
-    else hipLaunchKernelGGL(k_render_fwd_long<6>, dim3(long_blocks), dim3(64), 0, st, d);
+    const int long_blocks = (min(T * kCells, kLongWaves) * d.B + 3) / 4 * 4 / 4;   // 4 waves (cells) per workgroup, a multiple of B waves in all
+    if (d.C <= 3) hipLaunchKernelGGL(k_render_fwd_long<3>, dim3(long_blocks), dim3(256), 0, st, d);
+    else hipLaunchKernelGGL(k_render_fwd_long<6>, dim3(long_blocks), dim3(256), 0, st, d);
     DM4D_HIP_CHECK(hipGetLastError());
     return DM4D_OK;
 }
