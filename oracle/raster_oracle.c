@@ -422,7 +422,7 @@ static void render_tile_backward(const dm4d_oracle_in *in, const dm4d_oracle_sta
                                  double *acc /* [D][10]: xy(2) conic(3) opac color(3) depth */)
 {
     int W = in->W, H = in->H;
-    uint32_t start = st->ranges[2 * (ty * gx + tx)], end = st->ranges[2 * (ty * gx + tx) + 1];
+    uint32_t start = st->ranges[2 * (ty * gx + tx)];   /* the walk stops at n_contrib, inside [start, range end) */
     const float ddelx_dx = 0.5f * (float)W, ddely_dy = 0.5f * (float)H;
     for (int ly = 0; ly < TILE; ++ly)
         for (int lx = 0; lx < TILE; ++lx) {
