@@ -183,6 +183,35 @@ def test_oversized_tile_uses_global_sort_path():
     _assert_grads(h.backward(gC), o.backward(gC))
 
 
+@pytest.mark.parametrize("n", [1500, 5000])
+def test_deep_translucent_stack_long_cells(n):
+    """Thousands of faint splats on a few pixels: cell lists far beyond kLongCell (384) that the forward really
+    consumes to the end.  n = 1500 keeps every tile within the small sort variant (long cells blended by the regular
+    forward, k_render_bwd_long in the backward); n = 5000 goes through the large variant, whose long cells take the
+    early forward kernel (k_render_fwd_long) as well.  Forward bit-identical, gradients within the usual bar."""
+    _need_gpu()
+    rng = np.random.default_rng(n)
+    sc = syn.random_splat_scene(n, seed=n, log_scale_mean=math.log(0.004), log_scale_std=0.3)
+    sc["means3D"] = (rng.normal(size=(n, 3)) * 0.006).astype(np.float32)
+    sc["opacities"] = rng.uniform(0.004, 0.02, size=sc["opacities"].shape).astype(np.float32)
+    cam = syn.make_camera(64, 64)
+    o, h, out = _both(sc, cam)
+    per_tile = (o.s["ranges"][:, 1].astype(np.int64) - o.s["ranges"][:, 0]).max()
+    assert (per_tile <= 2048) if n == 1500 else (per_tile > 2048)
+    assert o.s["n_contrib"].max() > 384 * 2          # the blend really walks the long lists
+    assert 0.0 < o.s["final_T"].min() and o.s["final_T"].min() < 0.5
+    _assert_forward_parity(o, h, out)
+    gC = rng.normal(size=(3, 64, 64)).astype(np.float32)
+    gD = rng.normal(size=(64, 64)).astype(np.float32)
+    gA = rng.normal(size=(64, 64)).astype(np.float32)
+    g = h.backward(gC, gD, gA)
+    _assert_grads(g, o.backward(gC, gD, gA))
+    g2 = h.backward(gC, gD, gA)
+    for k in g:
+        if g[k] is not None:
+            assert np.array_equal(g[k].view(np.uint32), g2[k].view(np.uint32)), k
+
+
 def test_giant_splat_covers_every_tile():
     _need_gpu()
     sc = syn.random_splat_scene(64, seed=10, log_scale_mean=math.log(0.02), log_scale_std=0.3)
