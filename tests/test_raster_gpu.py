@@ -319,15 +319,23 @@ def test_record_count_matches_the_cell_blocks():
             assert np.array_equal(g1[k], g2[k], equal_nan=True), k      # deterministic, capacity-independent
 
 
-def test_fused_six_channel_pass_equals_two_passes():
+@pytest.mark.parametrize("crowded", [False, True])
+def test_fused_six_channel_pass_equals_two_passes(crowded):
     """C = 6 (RGB + normal in one pass) must equal the reference's two passes: same image planes,
-    summed geometry gradients, per-pass colour gradients."""
+    summed geometry gradients, per-pass colour gradients.  crowded: 5000 faint splats on a few pixels, i.e. the
+    6-channel long-cell kernels (k_render_fwd_long<6>, k_render_bwd_long<6, false>)."""
     _need_gpu()
     from tests.hip_raster import HipRaster
 
-    n, H, W = 20_000, 200, 264
-    sc = syn.random_splat_scene(n, seed=31, log_scale_mean=math.log(0.012), log_scale_std=0.5)
     rng = np.random.default_rng(31)
+    if crowded:
+        n, H, W = 5_000, 64, 64
+        sc = syn.random_splat_scene(n, seed=31, log_scale_mean=math.log(0.004), log_scale_std=0.3)
+        sc["means3D"] = (rng.normal(size=(n, 3)) * 0.006).astype(np.float32)
+        sc["opacities"] = rng.uniform(0.004, 0.02, size=sc["opacities"].shape).astype(np.float32)
+    else:
+        n, H, W = 20_000, 200, 264
+        sc = syn.random_splat_scene(n, seed=31, log_scale_mean=math.log(0.012), log_scale_std=0.5)
     nrm = rng.normal(size=(n, 3)).astype(np.float32)
     nrm /= np.linalg.norm(nrm, axis=1, keepdims=True)
     cam = syn.make_camera(H, W, elev_deg=25, azim_deg=100)
