@@ -463,6 +463,17 @@ __global__ __launch_bounds__(kPreThreads) void k_gather_bwd(BatchDesc d)
 #undef DM4D_FETCH
 #undef DM4D_STAGE
     }
+    {
+        // B1's records carry the moments sum_pixels q (dx, dy, dx^2, dx dy, dy^2), q = dL/dG G (raster_render.hip):
+        // dL/dmean2D (NDC) = -(A m0 + B m1, B m0 + C m1) (W/2, H/2); dL/dconic = (-m2 / 2, -m3, -m4 / 2)
+        const float4 co = (live && r > 0) ? g.conic_opacity[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+        const float m0 = acc[0], m1 = acc[1];
+        acc[0] = -(co.x * m0 + co.y * m1) * (0.5f * (float)vp.W);
+        acc[1] = -(co.y * m0 + co.z * m1) * (0.5f * (float)vp.H);
+        acc[2] = -0.5f * acc[2];
+        acc[3] = -acc[3];
+        acc[4] = -0.5f * acc[4];
+    }
     if (!live) return;
     o.dL_dmeans2D[3 * si + 0] = acc[0];
     o.dL_dmeans2D[3 * si + 1] = acc[1];

@@ -529,7 +529,6 @@ __global__ __launch_bounds__(64) void k_render_bwd(BatchDesc d)
     const float Tb = T_final * bgdot;
     float T_ = T_final, S = 0.f;
     const f2v g01 = f2v{gCol[0], gCol[1]}, g23 = f2v{gCol[2], gCol[3]}, g45 = f2v{gCol[4], gCol[5]}, gDA = f2v{gD, gA};
-    const f2v halfWH = f2v{0.5f * (float)vp.W, 0.5f * (float)vp.H};
     // reduction role of this lane: value li of its row (lanes with li >= RS idle in the sum)
     const int red_i = li < RS ? li : 0;
     const float4 *red_src = reinterpret_cast<const float4 *>(&s_red[0][red_i][row * 8]);
@@ -572,7 +571,6 @@ __global__ __launch_bounds__(64) void k_render_bwd(BatchDesc d)
                 const uint32_t k = __float_as_uint(h ? P4[kPair4 * j + 7].y : P4[kPair4 * j + 7].x);
                 const float dx = h ? dx2[j].y : dx2[j].x, dy = h ? dy2[j].y : dy2[j].x;
                 const float power = h ? pw[j].y : pw[j].x, Gr = h ? Gr2[j].y : Gr2[j].x;
-                const float cA = h ? g1[j].y : g1[j].x, cB = h ? g1[j].w : g1[j].z, cC = h ? g2[j].y : g2[j].x;
                 const float op = h ? g2[j].w : g2[j].z;
                 // Branch-free: lanes that do not take the entry contribute exact zeros.
                 const float alpha = fminf(0.99f, op * Gr);
@@ -590,13 +588,13 @@ __global__ __launch_bounds__(64) void k_render_bwd(BatchDesc d)
                 const float V = va.x + va.y;
                 const float dL_da = contrib ? (Tn * V - (S + Tb) * inv_om) : 0.f;
                 S = __builtin_fmaf(V, w, S);
-                const float dL_dG = op * dL_da;
+                // dL/dmean2D and dL/dconic are linear in the five moments sum_pixels q (dx, dy, dx^2, dx dy, dy^2),
+                // q = dL/dG G: the records carry the moments, B2 applies the (per-Gaussian) map once (k_gather_bwd)
+                const float q = (op * dL_da) * G;
                 const f2v dxy = f2v{dx, dy};
-                const f2v gd = dxy * (f2v)(G);                              // (G dx, G dy)
-                const f2v t1 = gd * f2v{cA, cC}, t2 = gd.yx * (f2v)(cB);    // (gdx A, gdy C), (gdy B, gdx B)
-                const f2v v01 = ((f2v)(dL_dG) * (-(t1 + t2))) * halfWH;     // dL/dmean2D (NDC)
-                const f2v v24 = ((f2v)(-0.5f) * (gd * dxy)) * (f2v)(dL_dG); // dL/dconic A, C
-                const float v3 = (-gd.x * dy) * dL_dG;                      // dL/dconic B
+                const f2v v01 = dxy * (f2v)(q);                             // q dx, q dy
+                const f2v v24 = v01 * dxy;                                  // q dx^2, q dy^2
+                const float v3 = v01.x * dy;                                // q dx dy
                 const f2v ww = (f2v)(w);
                 const f2v c01 = ww * g01, c23 = ww * g23, c45 = ww * g45;
                 float v[13];
@@ -670,7 +668,6 @@ __global__ __launch_bounds__(64) void k_render_bwd_long(BatchDesc d)
     const int lane = threadIdx.x, r = lane >> 4, p = lane & 15;
     const uint32_t n_long = min(g.counters[kCntLong], (uint32_t)(c.T * kCells));
     if (first < n_long) __builtin_amdgcn_s_setprio(3);   // the launch's critical path: issue before the regular kernel's waves
-    const f2v halfWH = f2v{0.5f * (float)vp.W, 0.5f * (float)vp.H};
     const int red_i = p < RS ? p : 0;
     const float4 *red_src = reinterpret_cast<const float4 *>(&s_red[red_i][r * 16]);
     for (uint32_t it = first; it < n_long; it += step) {
@@ -781,13 +778,11 @@ __global__ __launch_bounds__(64) void k_render_bwd_long(BatchDesc d)
                 const float2 wd = *reinterpret_cast<const float2 *>(s_x2 + (r * 16 + p) * 2);
                 const float w = wd.x, dL_da = wd.y;
                 const float G = contrib_r ? Gr : 0.f;
-                const float dL_dG = op * dL_da;
+                const float q = (op * dL_da) * G;                           // moments, as in k_render_bwd
                 const f2v dxy = f2v{dx, dy};
-                const f2v gd = dxy * (f2v)(G);
-                const f2v t1 = gd * f2v{cA, cC}, t2 = gd.yx * (f2v)(cB);
-                const f2v v01 = ((f2v)(dL_dG) * (-(t1 + t2))) * halfWH;
-                const f2v v24 = ((f2v)(-0.5f) * (gd * dxy)) * (f2v)(dL_dG);
-                const float v3 = (-gd.x * dy) * dL_dG;
+                const f2v v01 = dxy * (f2v)(q);
+                const f2v v24 = v01 * dxy;
+                const float v3 = v01.x * dy;
                 const f2v ww = (f2v)(w);
                 const f2v c01 = ww * g01, c23 = ww * g23, c45 = ww * g45;
                 float v[13];
