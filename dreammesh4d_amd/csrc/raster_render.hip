@@ -452,6 +452,29 @@ __global__ __launch_bounds__(256) void k_render_fwd_long(BatchDesc d)
 }
 
 // ---------------------------------------------------------------------------------------- B1
+// r[i] (lanes 0..7 of every row) = v[i] + v[i] of lane l + 8; lanes 8..15 keep r[i].  One instruction per value
+// (v_add_f32 with a bank-masked row rotation), which the compiler cannot form from update_dpp + add.  s_nop: a DPP read
+// of a VGPR needs 2 wait states after the VALU write of it (inline asm is opaque to the hazard recogniser).
+#define DM4D_DPPADD(O, I) "v_add_f32_dpp %" O ", %" I ", %" I " row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+template <int RS>
+__device__ __forceinline__ void pair_sum_low_half(float (&r)[RS], const float (&v)[13])
+{
+    static_assert(RS == 9 || RS == 10 || RS == 13, "record sizes of grad_stride()");
+    if constexpr (RS == 9) {
+        asm volatile("s_nop 1\n\t" DM4D_DPPADD("0", "9") DM4D_DPPADD("1", "10") DM4D_DPPADD("2", "11") DM4D_DPPADD("3", "12") DM4D_DPPADD("4", "13") DM4D_DPPADD("5", "14") DM4D_DPPADD("6", "15") DM4D_DPPADD("7", "16") DM4D_DPPADD("8", "17")
+                     : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]), "+v"(r[6]), "+v"(r[7]), "+v"(r[8])
+                     : "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "v"(v[4]), "v"(v[5]), "v"(v[6]), "v"(v[7]), "v"(v[8]));
+    } else if constexpr (RS == 10) {
+        asm volatile("s_nop 1\n\t" DM4D_DPPADD("0", "10") DM4D_DPPADD("1", "11") DM4D_DPPADD("2", "12") DM4D_DPPADD("3", "13") DM4D_DPPADD("4", "14") DM4D_DPPADD("5", "15") DM4D_DPPADD("6", "16") DM4D_DPPADD("7", "17") DM4D_DPPADD("8", "18") DM4D_DPPADD("9", "19")
+                     : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]), "+v"(r[6]), "+v"(r[7]), "+v"(r[8]), "+v"(r[9])
+                     : "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "v"(v[4]), "v"(v[5]), "v"(v[6]), "v"(v[7]), "v"(v[8]), "v"(v[9]));
+    } else {
+        asm volatile("s_nop 1\n\t" DM4D_DPPADD("0", "13") DM4D_DPPADD("1", "14") DM4D_DPPADD("2", "15") DM4D_DPPADD("3", "16") DM4D_DPPADD("4", "17") DM4D_DPPADD("5", "18") DM4D_DPPADD("6", "19") DM4D_DPPADD("7", "20") DM4D_DPPADD("8", "21") DM4D_DPPADD("9", "22") DM4D_DPPADD("10", "23") DM4D_DPPADD("11", "24") DM4D_DPPADD("12", "25")
+                     : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]), "+v"(r[6]), "+v"(r[7]), "+v"(r[8]), "+v"(r[9]), "+v"(r[10]), "+v"(r[11]), "+v"(r[12])
+                     : "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "v"(v[4]), "v"(v[5]), "v"(v[6]), "v"(v[7]), "v"(v[8]), "v"(v[9]), "v"(v[10]), "v"(v[11]), "v"(v[12]));
+    }
+}
+#undef DM4D_DPPADD
 constexpr int kRedStride = 68;   // floats per value row of the transposed reduction buffer (64 lanes + pad)
 constexpr int kRedHalf = 36;     // the same with 8 lanes per row (32 + pad)
 
@@ -564,6 +587,7 @@ __global__ __launch_bounds__(64) void k_render_bwd(BatchDesc d)
             f2v dx2[kBwdPairs], dy2[kBwdPairs], pw[kBwdPairs], Gr2[kBwdPairs];
             pair_gauss<kBwdPairs>(g0, g1, g2, pxf, pyf, dx2, dy2, pw, Gr2);
             __builtin_amdgcn_wave_barrier();
+            float rsum[RS];
 #pragma unroll
             for (int e = U - 1; e >= 0; --e) {          // back to front inside the group
                 const int j = e >> 1, h = e & 1, t = tg + e;
@@ -607,13 +631,19 @@ __global__ __launch_bounds__(64) void k_render_bwd(BatchDesc d)
                     v[6] = w * gD;
                     v[7] = c01.x; v[8] = c01.y; v[9] = c23.x; v[10] = c23.y; v[11] = c45.x; v[12] = c45.y;
                 }
-                // transposed reduction: [value][lane] in LDS, lane i of the row sums value i over the row
+                // transposed reduction: [value][lane] in LDS, lane i of the row sums value i over the row.
+                // v[i] of lane l + v[i] of lane l ^ 8 first (row_ror:8): the odd entry of the pair in all lanes, then
+                // the even entry over it in lanes 0..7 of every row (bank_mask 0x3), so that ONE unmasked LDS write
+                // per value stores both entries (lanes 0..7: entry e = 0, lanes 8..15: entry e = 1).
+                static_assert(U == 2, "the pair reduction below");
+                if (e & 1) {
 #pragma unroll
-                for (int i = 0; i < RS; ++i)      // v[i] of lane l + v[i] of lane l ^ 8 (row_ror:8)
-                    v[i] += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v[i]), 0x128, 0xf, 0xf, true));
-                if (li < 8) {
+                    for (int i = 0; i < RS; ++i)
+                        rsum[i] = v[i] + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v[i]), 0x128, 0xf, 0xf, true));
+                } else {
+                    pair_sum_low_half<RS>(rsum, v);
 #pragma unroll
-                    for (int i = 0; i < RS; ++i) s_red[e][i][row * 8 + li] = v[i];
+                    for (int i = 0; i < RS; ++i) s_red[li >> 3][i][row * 8 + (li & 7)] = rsum[i];
                 }
                 (void)t;
             }
