@@ -485,7 +485,7 @@ __global__ __launch_bounds__(64) void k_render_bwd(BatchDesc d)
     constexpr int RSP = (C <= 3 || LEAN) ? 12 : 16;   // == grad_stride(C, LEAN): floats per (padded) record
     constexpr int U = 2 * kBwdPairs;          // entries per inner-loop step
     __shared__ __attribute__((aligned(16))) float s_p[4 * kRowFloats];
-    __shared__ uint32_t s_slot[4][kChunk];
+    __shared__ __attribute__((aligned(8))) uint32_t s_slot[4][kChunk];
     // reduction buffer: lanes l and l + 8 of a row are added with one DPP row rotation first, so only 8 lanes per
     // row go through LDS (half the reduction's LDS bytes, and 2.4 KB less LDS per wave: 16 -> 20 waves per CU)
     __shared__ __attribute__((aligned(16))) float s_red[U][RS][kRedHalf];
@@ -514,7 +514,7 @@ __global__ __launch_bounds__(64) void k_render_bwd(BatchDesc d)
     uint32_t nr = (s < cap) ? g.ccount[tile * kCells + lp.cell] : 0u;
     uint32_t nd = (s < cap) ? g.cdone[tile * kCells + lp.cell] : 0u;   // entries this row's forward consumed
     if (nr >= kLongCell) nr = nd = 0u;                                  // long cell: k_render_bwd_long's
-    const uint32_t ndmax = wave_max_u32(nd);
+    const uint32_t ndmax = (uint32_t)__builtin_amdgcn_readfirstlane((int)wave_max_u32(nd));   // uniform: scalar loop control
     const uint2 *__restrict__ list = b.clist + (size_t)lp.cell * b.cap + s;
     const uint32_t *__restrict__ slots = b.cslot + (size_t)lp.cell * b.cap + s;
     {
@@ -584,6 +584,7 @@ __global__ __launch_bounds__(64) void k_render_bwd(BatchDesc d)
             f4v g0[kBwdPairs], g1[kBwdPairs], g2[kBwdPairs];
 #pragma unroll
             for (int j = 0; j < kBwdPairs; ++j) { g0[j] = P4[kPair4 * j + 0]; g1[j] = P4[kPair4 * j + 1]; g2[j] = P4[kPair4 * j + 2]; }
+            const uint2 slot2 = *reinterpret_cast<const uint2 *>(&s_slot[row][tg]);   // record slots of the pair (tg is even)
             f2v dx2[kBwdPairs], dy2[kBwdPairs], pw[kBwdPairs], Gr2[kBwdPairs];
             pair_gauss<kBwdPairs>(g0, g1, g2, pxf, pyf, dx2, dy2, pw, Gr2);
             __builtin_amdgcn_wave_barrier();
@@ -648,18 +649,24 @@ __global__ __launch_bounds__(64) void k_render_bwd(BatchDesc d)
                 (void)t;
             }
             __builtin_amdgcn_wave_barrier();
+            {
+                // all LDS reads of the pair first (one wait), then the two predicated record stores
+                float total[U];
 #pragma unroll
-            for (int e = U - 1; e >= 0; --e) {
-                const int t = tg + e;
-                const float4 *src = red_src + e * kRedBuf4;
-                const float4 a0 = src[0], a1 = src[1];
-                // fixed summation tree (deterministic): pairs of packed adds
-                f2v p0 = f2v{a0.x, a0.y} + f2v{a0.z, a0.w};
-                f2v p1 = f2v{a1.x, a1.y} + f2v{a1.z, a1.w};
-                p0 = p0 + p1;
-                const float total = li < RS ? p0.x + p0.y : 0.f;   // lanes RS..RSP-1 write the padding
-                const uint32_t slot = s_slot[row][t];
-                if (li < RSP && t < cnt && slot < rec_cap) rec[(size_t)slot * RSP + li] = total;
+                for (int e = 0; e < U; ++e) {
+                    const float4 *src = red_src + e * kRedBuf4;
+                    const float4 a0 = src[0], a1 = src[1];
+                    // fixed summation tree (deterministic): pairs of packed adds
+                    f2v p0 = f2v{a0.x, a0.y} + f2v{a0.z, a0.w};
+                    f2v p1 = f2v{a1.x, a1.y} + f2v{a1.z, a1.w};
+                    p0 = p0 + p1;
+                    total[e] = li < RS ? p0.x + p0.y : 0.f;   // lanes RS..RSP-1 write the padding
+                }
+#pragma unroll
+                for (int e = U - 1; e >= 0; --e) {
+                    const uint32_t slot = e ? slot2.y : slot2.x;
+                    if (li < RSP && tg + e < cnt && slot < rec_cap) rec[(size_t)slot * RSP + li] = total[e];
+                }
             }
         }
         if (c0 == 0) break;
