@@ -550,7 +550,7 @@ __global__ __launch_bounds__(64) void k_render_bwd(BatchDesc d)
 #pragma unroll
     for (int ch = 0; ch < C; ++ch) bgdot += vp.bg[ch] * gCol[ch];
     const float Tb = T_final * bgdot;
-    float T_ = T_final, S = 0.f;
+    float T_ = T_final, S = Tb;   // S: sum V w of the entries behind + T_final bg.g
     const f2v g01 = f2v{gCol[0], gCol[1]}, g23 = f2v{gCol[2], gCol[3]}, g45 = f2v{gCol[4], gCol[5]}, gDA = f2v{gD, gA};
     // reduction role of this lane: value li of its row (lanes with li >= RS idle in the sum)
     const int red_i = li < RS ? li : 0;
@@ -598,20 +598,23 @@ __global__ __launch_bounds__(64) void k_render_bwd(BatchDesc d)
                 const float power = h ? pw[j].y : pw[j].x, Gr = h ? Gr2[j].y : Gr2[j].x;
                 const float op = h ? g2[j].w : g2[j].z;
                 // Branch-free: lanes that do not take the entry contribute exact zeros.
-                const float alpha = fminf(0.99f, op * Gr);
-                const bool contrib = (k < last) & (power <= 0.0f) & (alpha >= 1.0f / 255.0f);
+                // (alpha and G are 0 there, so w and q are; dL/dalpha itself needs no mask: it is finite and only
+                // ever multiplied by G.)  S carries sum V w + T_final bg.g.
+                const float alpha_r = fminf(0.99f, op * Gr);
+                const bool contrib = (k < last) & (power <= 0.0f) & (alpha_r >= 1.0f / 255.0f);
+                const float alpha = contrib ? alpha_r : 0.f;
                 const float G = contrib ? Gr : 0.f;
                 const float inv_om = __builtin_amdgcn_rcpf(1.f - alpha);
                 const float Tn = T_ * inv_om;
                 T_ = contrib ? Tn : T_;
-                const float w = contrib ? alpha * Tn : 0.f;
+                const float w = alpha * Tn;
                 // V = dL/d(blended value of this entry) = depth gD + gA + sum_ch colour_ch gCol_ch
                 f2v va = e1.zw * gDA;
                 va = __builtin_elementwise_fma(e0.xy, g01, va);
                 va = __builtin_elementwise_fma(e0.zw, g23, va);
                 if (C > 3) va = __builtin_elementwise_fma(e1.xy, g45, va);
                 const float V = va.x + va.y;
-                const float dL_da = contrib ? (Tn * V - (S + Tb) * inv_om) : 0.f;
+                const float dL_da = Tn * V - S * inv_om;
                 S = __builtin_fmaf(V, w, S);
                 // dL/dmean2D and dL/dconic are linear in the five moments sum_pixels q (dx, dy, dx^2, dx dy, dy^2),
                 // q = dL/dG G: the records carry the moments, B2 applies the (per-Gaussian) map once (k_gather_bwd)
@@ -660,12 +663,12 @@ __global__ __launch_bounds__(64) void k_render_bwd(BatchDesc d)
                     f2v p0 = f2v{a0.x, a0.y} + f2v{a0.z, a0.w};
                     f2v p1 = f2v{a1.x, a1.y} + f2v{a1.z, a1.w};
                     p0 = p0 + p1;
-                    total[e] = li < RS ? p0.x + p0.y : 0.f;   // lanes RS..RSP-1 write the padding
+                    total[e] = p0.x + p0.y;
                 }
 #pragma unroll
                 for (int e = U - 1; e >= 0; --e) {
                     const uint32_t slot = e ? slot2.y : slot2.x;
-                    if (li < RSP && tg + e < cnt && slot < rec_cap) rec[(size_t)slot * RSP + li] = total[e];
+                    if (li < RS && tg + e < cnt && slot < rec_cap) rec[(size_t)slot * RSP + li] = total[e];   // the padding floats stay unwritten (never read as values)
                 }
             }
         }
@@ -746,7 +749,7 @@ __global__ __launch_bounds__(64) void k_render_bwd_long(BatchDesc d)
 #pragma unroll
         for (int ch = 0; ch < C; ++ch) bgdot += vp.bg[ch] * gCol[ch];
         const float Tb = T_final * bgdot;
-        float T_ = T_final, S = 0.f;
+        float T_ = T_final, S = Tb;   // S: sum V w of the entries behind + T_final bg.g
         const f2v g01 = f2v{gCol[0], gCol[1]}, g23 = f2v{gCol[2], gCol[3]}, g45 = f2v{gCol[4], gCol[5]}, gDA = f2v{gD, gA};
 
         const uint32_t c_last = ((nd - 1u) / 64u) * 64u;
@@ -804,8 +807,8 @@ __global__ __launch_bounds__(64) void k_render_bwd_long(BatchDesc d)
                         const float inv_om = __builtin_amdgcn_rcpf(1.f - alpha);
                         const float Tn = T_ * inv_om;
                         T_ = contrib ? Tn : T_;
-                        const float w = contrib ? alpha * Tn : 0.f;
-                        const float dL_da = contrib ? (Tn * V - (S + Tb) * inv_om) : 0.f;
+                        const float w = alpha * Tn;
+                        const float dL_da = Tn * V - S * inv_om;   // unmasked: only ever multiplied by the masked G
                         S = __builtin_fmaf(V, w, S);
                         if (r == 0) *reinterpret_cast<float2 *>(s_x2 + (h * 16 + p) * 2) = make_float2(w, dL_da);
                     }
@@ -844,10 +847,10 @@ __global__ __launch_bounds__(64) void k_render_bwd_long(BatchDesc d)
                     p0 = p0 + p1;
                     p2 = p2 + p3;
                     p0 = p0 + p2;
-                    const float total = p < RS ? p0.x + p0.y : 0.f;
+                    const float total = p0.x + p0.y;
                     const int t = tg + r;
                     const uint32_t slot = s_slot[t < 64 ? t : 63];
-                    if (p < RSP && t < cnt && slot < rec_cap) rec[(size_t)slot * RSP + p] = total;
+                    if (p < RS && t < cnt && slot < rec_cap) rec[(size_t)slot * RSP + p] = total;
                 }
                 __builtin_amdgcn_wave_barrier();
             }
