@@ -677,6 +677,20 @@ __global__ __launch_bounds__(64) void k_render_bwd(BatchDesc d)
     trace.done(ndmax);
 }
 
+// x of row r (16 lanes) -> o[r] in every row, same lane of the row.  v_permlane16_swap exchanges the odd rows of its
+// first operand with the even rows of the second, v_permlane32_swap the upper half of the first with the lower half
+// of the second (gfx950).
+__device__ __forceinline__ void rows_allgather(float x, float (&o)[4])
+{
+    const unsigned a = __float_as_uint(x);
+    const auto s16 = __builtin_amdgcn_permlane16_swap(a, a, false, false);          // [x0 x0 x2 x2], [x1 x1 x3 x3]
+    const auto e = __builtin_amdgcn_permlane32_swap(s16[0], s16[0], false, false);  // x0 everywhere, x2 everywhere
+    const auto f = __builtin_amdgcn_permlane32_swap(s16[1], s16[1], false, false);  // x1, x3
+    o[0] = __uint_as_float(e[0]);
+    o[1] = __uint_as_float(f[0]);
+    o[2] = __uint_as_float(e[1]);
+    o[3] = __uint_as_float(f[1]);
+}
 // ---------------------------------------------------------------------------------------- B1 (long cells)
 // One wave per long cell (raster.h, kLongCell).  Lane = (entry slot r = lane >> 4, pixel p = lane & 15 of the cell):
 // the four rows take four CONSECUTIVE list entries of the one cell for the same 16 pixels.  Per step: every row
@@ -692,8 +706,6 @@ __global__ __launch_bounds__(64) void k_render_bwd_long(BatchDesc d)
     constexpr int RSP = (C <= 3 || LEAN) ? 12 : 16;
     __shared__ __attribute__((aligned(16))) float s_e[64 * 16];
     __shared__ uint32_t s_slot[64];
-    __shared__ __attribute__((aligned(16))) float s_x1[16 * 8];    // [pixel][entry slot] (alpha or -1, V)
-    __shared__ __attribute__((aligned(16))) float s_x2[64 * 2];    // [entry slot][pixel] (w, dL/dalpha)
     __shared__ __attribute__((aligned(16))) float s_red[RS][kRedStride];
     const int view = (int)(blockIdx.x % (uint32_t)d.B);
     const uint32_t first = blockIdx.x / (uint32_t)d.B, step = gridDim.x / (uint32_t)d.B;
@@ -793,12 +805,15 @@ __global__ __launch_bounds__(64) void k_render_bwd_long(BatchDesc d)
                 va = __builtin_elementwise_fma(e0.xy, g01, va);
                 va = __builtin_elementwise_fma(e0.zw, g23, va);
                 if (C > 3) va = __builtin_elementwise_fma(e1.xy, g45, va);
-                *reinterpret_cast<float2 *>(s_x1 + (p * 4 + r) * 2) = make_float2(contrib_r ? alpha_r : -1.0f, va.x + va.y);
-                __builtin_amdgcn_wave_barrier();
-                // ---- row 0: the sequential chain, back to front ----
+                // all four rows get the (alpha or -1, V) of all four entries: three gfx950 lane swaps per value (VALU, no
+                // LDS round trip -- the long waves wait behind the regular kernel's LDS traffic otherwise)
+                float al[4], Vv[4];
+                rows_allgather(contrib_r ? alpha_r : -1.0f, al);
+                rows_allgather(va.x + va.y, Vv);
+                // ---- the sequential (T, S) chain over the four entries, back to front: every row runs it on the same
+                // values (bit-identical T_ and S in all four), and keeps the (w, dL/dalpha) of its own entry ----
+                float w = 0.f, dL_da = 0.f;
                 {
-                    const float4 x01 = *reinterpret_cast<const float4 *>(s_x1 + p * 8), x23 = *reinterpret_cast<const float4 *>(s_x1 + p * 8 + 4);
-                    const float al[4] = {x01.x, x01.z, x23.x, x23.z}, Vv[4] = {x01.y, x01.w, x23.y, x23.w};
 #pragma unroll
                     for (int h = 3; h >= 0; --h) {
                         const bool contrib = al[h] >= 0.0f;
@@ -807,16 +822,14 @@ __global__ __launch_bounds__(64) void k_render_bwd_long(BatchDesc d)
                         const float inv_om = __builtin_amdgcn_rcpf(1.f - alpha);
                         const float Tn = T_ * inv_om;
                         T_ = contrib ? Tn : T_;
-                        const float w = alpha * Tn;
-                        const float dL_da = Tn * V - S * inv_om;   // unmasked: only ever multiplied by the masked G
-                        S = __builtin_fmaf(V, w, S);
-                        if (r == 0) *reinterpret_cast<float2 *>(s_x2 + (h * 16 + p) * 2) = make_float2(w, dL_da);
+                        const float w_h = alpha * Tn;
+                        const float d_h = Tn * V - S * inv_om;   // unmasked: only ever multiplied by the masked G
+                        S = __builtin_fmaf(V, w_h, S);
+                        w = (r == h) ? w_h : w;
+                        dL_da = (r == h) ? d_h : dL_da;
                     }
                 }
-                __builtin_amdgcn_wave_barrier();
                 // ---- every row: the gradient values of its entry, reduced over its 16 lanes ----
-                const float2 wd = *reinterpret_cast<const float2 *>(s_x2 + (r * 16 + p) * 2);
-                const float w = wd.x, dL_da = wd.y;
                 const float G = contrib_r ? Gr : 0.f;
                 const float q = (op * dL_da) * G;                           // moments, as in k_render_bwd
                 const f2v dxy = f2v{dx, dy};
