@@ -341,12 +341,25 @@ __global__ __launch_bounds__(64) void k_render_fwd(BatchDesc d)
 // Staging: 64 entries per chunk, one per lane: [0..5] x y A B C opacity | [6] k bits | [8..13] colours | [14] depth | [15] 1
 // Four cells per workgroup (one per wave, no workgroup barrier): the long-running waves then share few CUs instead of
 // taking one SIMD on most of them, which slowed the barrier-coupled workgroups of K4's small variant running beside.
+// x of row r (16 lanes) -> o[r] in every row, same lane of the row.  v_permlane16_swap exchanges the odd rows of its
+// first operand with the even rows of the second, v_permlane32_swap the upper half of the first with the lower half
+// of the second (gfx950).
+__device__ __forceinline__ void rows_allgather(float x, float (&o)[4])
+{
+    const unsigned a = __float_as_uint(x);
+    const auto s16 = __builtin_amdgcn_permlane16_swap(a, a, false, false);          // [x0 x0 x2 x2], [x1 x1 x3 x3]
+    const auto e = __builtin_amdgcn_permlane32_swap(s16[0], s16[0], false, false);  // x0 everywhere, x2 everywhere
+    const auto f = __builtin_amdgcn_permlane32_swap(s16[1], s16[1], false, false);  // x1, x3
+    o[0] = __uint_as_float(e[0]);
+    o[1] = __uint_as_float(f[0]);
+    o[2] = __uint_as_float(e[1]);
+    o[3] = __uint_as_float(f[1]);
+}
 template <int C>
 __global__ __launch_bounds__(256) void k_render_fwd_long(BatchDesc d)
 {
     __shared__ __attribute__((aligned(16))) float s_e_all[4][64 * 16];
-    __shared__ __attribute__((aligned(16))) float s_a_all[4][64];      // alphas [pixel][entry slot]
-    float *s_e = s_e_all[threadIdx.x >> 6], *s_a = s_a_all[threadIdx.x >> 6];
+    float *s_e = s_e_all[threadIdx.x >> 6];
     const uint32_t wave = blockIdx.x * 4u + (threadIdx.x >> 6), n_waves = gridDim.x * 4u;
     const int view = (int)(wave % (uint32_t)d.B);
     const uint32_t first = wave / (uint32_t)d.B, step = n_waves / (uint32_t)d.B;
@@ -401,10 +414,8 @@ __global__ __launch_bounds__(256) void k_render_fwd_long(BatchDesc d)
                 const float dx = ga.x - pxf, dy = ga.y - pyf;
                 const float power = -0.5f * ((ga.z * dx) * dx + (gb.x * dy) * dy) - (ga.w * dx) * dy;
                 const float alpha_r = fminf(0.99f, gb.y * det_expf(power));
-                s_a[p * 4 + r] = ((power <= 0.0f) & (alpha_r >= 1.0f / 255.0f)) ? alpha_r : -1.0f;
-                __builtin_amdgcn_wave_barrier();
-                const float4 a4 = *reinterpret_cast<const float4 *>(s_a + p * 4);
-                const float al[4] = {a4.x, a4.y, a4.z, a4.w};
+                float al[4];     // the four alphas of the pixel, in every row (lane swaps, no LDS round trip)
+                rows_allgather(((power <= 0.0f) & (alpha_r >= 1.0f / 255.0f)) ? alpha_r : -1.0f, al);
                 // ---- row 0: the sequential blend of the four entries ----
 #pragma unroll
                 for (int h = 0; h < 4; ++h) {
@@ -677,20 +688,6 @@ __global__ __launch_bounds__(64) void k_render_bwd(BatchDesc d)
     trace.done(ndmax);
 }
 
-// x of row r (16 lanes) -> o[r] in every row, same lane of the row.  v_permlane16_swap exchanges the odd rows of its
-// first operand with the even rows of the second, v_permlane32_swap the upper half of the first with the lower half
-// of the second (gfx950).
-__device__ __forceinline__ void rows_allgather(float x, float (&o)[4])
-{
-    const unsigned a = __float_as_uint(x);
-    const auto s16 = __builtin_amdgcn_permlane16_swap(a, a, false, false);          // [x0 x0 x2 x2], [x1 x1 x3 x3]
-    const auto e = __builtin_amdgcn_permlane32_swap(s16[0], s16[0], false, false);  // x0 everywhere, x2 everywhere
-    const auto f = __builtin_amdgcn_permlane32_swap(s16[1], s16[1], false, false);  // x1, x3
-    o[0] = __uint_as_float(e[0]);
-    o[1] = __uint_as_float(f[0]);
-    o[2] = __uint_as_float(e[1]);
-    o[3] = __uint_as_float(f[1]);
-}
 // ---------------------------------------------------------------------------------------- B1 (long cells)
 // One wave per long cell (raster.h, kLongCell).  Lane = (entry slot r = lane >> 4, pixel p = lane & 15 of the cell):
 // the four rows take four CONSECUTIVE list entries of the one cell for the same 16 pixels.  Per step: every row
