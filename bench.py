@@ -221,7 +221,7 @@ def main():
                        "whole_view_frac_of_hbm_roofline":
                            round(value / world * b_view / (HBM_PEAK_GBS * 1e9), 5),
                        "parallelism": f"dp{world} (frames sharded, 1 grad all-reduce/step)" if world > 1 else "single GPU"},
-            "roofline": {"bound": "hbm", "kernel": "k_render_bwd<6, true> + k_render_bwd_long<6, true> beside it (one launch pair per step, batched over its views)",
+            "roofline": {"bound": "hbm", "kernel": "k_render_bwd<6, true> (one launch per step, batched over its views: long-cell blocks first, then the quadrants)",
                          "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                          "alg_bytes_per_launch": round(alg_bytes), "avg_launch_us": round(avg_s * 1e6, 2),

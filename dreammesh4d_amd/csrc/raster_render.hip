@@ -489,20 +489,31 @@ __device__ __forceinline__ void pair_sum_low_half(float (&r)[RS], const float (&
 constexpr int kRedStride = 68;   // floats per value row of the transposed reduction buffer (64 lanes + pad)
 constexpr int kRedHalf = 36;     // the same with 8 lanes per row (32 + pad)
 
+// LDS of one wave of the backward kernel (floats): the regular blocks' staging rows + record slots + reduction
+// buffer, or the long-cell blocks' chunk + slots + reduction buffer -- the two kinds of block share one launch.
 template <int C, bool LEAN>
-__global__ __launch_bounds__(64) void k_render_bwd(BatchDesc d)
+struct BwdSmem {
+    static constexpr int RS = LEAN ? 9 : 7 + C;
+    static constexpr int U = 2 * kBwdPairs;
+    static constexpr int regular = 4 * kRowFloats + 4 * kChunk + U * RS * kRedHalf;
+    static constexpr int longc = 64 * 16 + 64 + RS * kRedStride;
+    static constexpr int floats = regular > longc ? regular : longc;
+};
+
+template <int C, bool LEAN>
+__device__ __forceinline__ void render_bwd_cells(const BatchDesc &d, const uint32_t bid, float *smem)
 {
     constexpr int RS = LEAN ? 9 : 7 + C;              // values per record
     constexpr int RSP = (C <= 3 || LEAN) ? 12 : 16;   // == grad_stride(C, LEAN): floats per (padded) record
     constexpr int U = 2 * kBwdPairs;          // entries per inner-loop step
-    __shared__ __attribute__((aligned(16))) float s_p[4 * kRowFloats];
-    __shared__ __attribute__((aligned(8))) uint32_t s_slot[4][kChunk];
+    float *s_p = smem;                                                                       // [4 * kRowFloats]
+    uint32_t (*s_slot)[kChunk] = reinterpret_cast<uint32_t (*)[kChunk]>(smem + 4 * kRowFloats);   // [4][kChunk]
     // reduction buffer: lanes l and l + 8 of a row are added with one DPP row rotation first, so only 8 lanes per
     // row go through LDS (half the reduction's LDS bytes, and 2.4 KB less LDS per wave: 16 -> 20 waves per CU)
-    __shared__ __attribute__((aligned(16))) float s_red[U][RS][kRedHalf];
+    float (*s_red)[RS][kRedHalf] = reinterpret_cast<float (*)[RS][kRedHalf]>(smem + 4 * kRowFloats + 4 * kChunk);   // [U]
     const WaveTrace trace;
     int view, tile, q;
-    if (!block_to_quadrant(d, blockIdx.x, view, tile, q)) { trace.done(0); return; }
+    if (!block_to_quadrant(d, bid, view, tile, q)) { trace.done(0); return; }
     const ViewCtx c = resolve(d, view);
     const ViewParams &vp = c.vp;
     const float *__restrict__ colors = c.colors;
@@ -697,15 +708,15 @@ __global__ __launch_bounds__(64) void k_render_bwd(BatchDesc d)
 // bit-identical, but a 1200-entry silhouette cell no longer costs the launch 1200 serial reduction round trips.
 // Staging (64 entries per chunk, one per lane): [0..5] x y A B C opacity | [6] k bits | [8..13] colours | [14] depth | [15] 1
 template <int C, bool LEAN>
-__global__ __launch_bounds__(64) void k_render_bwd_long(BatchDesc d)
+__device__ __forceinline__ void render_bwd_long_cells(const BatchDesc &d, const uint32_t bid, const uint32_t nblocks, float *smem)
 {
     constexpr int RS = LEAN ? 9 : 7 + C;
     constexpr int RSP = (C <= 3 || LEAN) ? 12 : 16;
-    __shared__ __attribute__((aligned(16))) float s_e[64 * 16];
-    __shared__ uint32_t s_slot[64];
-    __shared__ __attribute__((aligned(16))) float s_red[RS][kRedStride];
-    const int view = (int)(blockIdx.x % (uint32_t)d.B);
-    const uint32_t first = blockIdx.x / (uint32_t)d.B, step = gridDim.x / (uint32_t)d.B;
+    float *s_e = smem;                                                              // [64 * 16]
+    uint32_t *s_slot = reinterpret_cast<uint32_t *>(smem + 64 * 16);               // [64]
+    float (*s_red)[kRedStride] = reinterpret_cast<float (*)[kRedStride]>(smem + 64 * 16 + 64);   // [RS]
+    const int view = (int)(bid % (uint32_t)d.B);
+    const uint32_t first = bid / (uint32_t)d.B, step = nblocks / (uint32_t)d.B;
     const ViewCtx c = resolve(d, view);
     const ViewParams &vp = c.vp;
     const float *__restrict__ colors = c.colors;
@@ -870,6 +881,17 @@ __global__ __launch_bounds__(64) void k_render_bwd_long(BatchDesc d)
 }
 
 // ---------------------------------------------------------------------------------------- launchers
+// One launch for both kinds of block: the first `long_blocks` workgroups take the long cells (they are dispatched
+// first and raise their issue priority: the launch's critical path), the rest the regular quadrants.  A separate
+// launch on a helper stream cost a fork / join pair of stream events per step (~18 us).
+template <int C, bool LEAN>
+__global__ __launch_bounds__(64) void k_render_bwd(BatchDesc d, uint32_t long_blocks)
+{
+    __shared__ __attribute__((aligned(16))) float smem[BwdSmem<C, LEAN>::floats];
+    if (blockIdx.x < long_blocks) render_bwd_long_cells<C, LEAN>(d, blockIdx.x, long_blocks, smem);
+    else render_bwd_cells<C, LEAN>(d, blockIdx.x - long_blocks, smem);
+}
+
 constexpr int kLongWaves = 128;    // waves per view of the long-cell kernel (each loops over the long cells it owns)
 int launch_render_fwd(const BatchDesc &d, hipStream_t st)
 {
@@ -910,26 +932,13 @@ int launch_render_bwd(const BatchDesc &d, hipStream_t st)
     const int blocks = (int)((((int64_t)T * d.B + 7) / 8) * 8 * 4);
     ProfScope prof_(kKRenderBwd, st);
     if (d.lean && d.C != 6) { set_error("lean backward records need 6 channels"); return DM4D_ERR_INVALID; }
-    // the long cells go first, on the helper stream, beside the regular kernel
-    AuxStream *a = aux_stream();
-    hipStream_t lst = a ? a->st : st;
-    if (a) {
-        DM4D_HIP_CHECK(hipEventRecord(a->fork, st));
-        DM4D_HIP_CHECK(hipStreamWaitEvent(a->st, a->fork, 0));
-    }
-    const int long_blocks = min(T * kCells, kLongWaves) * d.B;
-    if (d.C <= 3) hipLaunchKernelGGL((k_render_bwd_long<3, false>), dim3(long_blocks), dim3(64), 0, lst, d);
-    else if (d.lean) hipLaunchKernelGGL((k_render_bwd_long<6, true>), dim3(long_blocks), dim3(64), 0, lst, d);
-    else hipLaunchKernelGGL((k_render_bwd_long<6, false>), dim3(long_blocks), dim3(64), 0, lst, d);
+    // the long cells' blocks first (multiple of 8 of them: the regular blocks keep their XCD), then the quadrants
+    const uint32_t long_blocks = (uint32_t)(min(T * kCells, kLongWaves) * d.B);
+    const dim3 grid(long_blocks + (uint32_t)blocks);
+    if (d.C <= 3) hipLaunchKernelGGL((k_render_bwd<3, false>), grid, dim3(64), 0, st, d, long_blocks);
+    else if (d.lean) hipLaunchKernelGGL((k_render_bwd<6, true>), grid, dim3(64), 0, st, d, long_blocks);
+    else hipLaunchKernelGGL((k_render_bwd<6, false>), grid, dim3(64), 0, st, d, long_blocks);
     DM4D_HIP_CHECK(hipGetLastError());
-    if (d.C <= 3) hipLaunchKernelGGL((k_render_bwd<3, false>), dim3(blocks), dim3(64), 0, st, d);
-    else if (d.lean) hipLaunchKernelGGL((k_render_bwd<6, true>), dim3(blocks), dim3(64), 0, st, d);
-    else hipLaunchKernelGGL((k_render_bwd<6, false>), dim3(blocks), dim3(64), 0, st, d);
-    DM4D_HIP_CHECK(hipGetLastError());
-    if (a) {
-        DM4D_HIP_CHECK(hipEventRecord(a->join, a->st));
-        DM4D_HIP_CHECK(hipStreamWaitEvent(st, a->join, 0));
-    }
     return DM4D_OK;
 }
 

@@ -187,7 +187,7 @@ def test_oversized_tile_uses_global_sort_path():
 def test_deep_translucent_stack_long_cells(n):
     """Thousands of faint splats on a few pixels: cell lists far beyond kLongCell (384) that the forward really
     consumes to the end.  n = 1500 keeps every tile within the small sort variant (long cells blended by the regular
-    forward, k_render_bwd_long in the backward); n = 5000 goes through the large variant, whose long cells take the
+    forward, the long-cell blocks of k_render_bwd in the backward); n = 5000 goes through the large variant, whose long cells take the
     early forward kernel (k_render_fwd_long) as well.  Forward bit-identical, gradients within the usual bar."""
     _need_gpu()
     rng = np.random.default_rng(n)
@@ -323,7 +323,7 @@ def test_record_count_matches_the_cell_blocks():
 def test_fused_six_channel_pass_equals_two_passes(crowded):
     """C = 6 (RGB + normal in one pass) must equal the reference's two passes: same image planes,
     summed geometry gradients, per-pass colour gradients.  crowded: 5000 faint splats on a few pixels, i.e. the
-    6-channel long-cell kernels (k_render_fwd_long<6>, k_render_bwd_long<6, false>)."""
+    6-channel long-cell kernels (k_render_fwd_long<6>, the long-cell blocks of k_render_bwd<6, false>)."""
     _need_gpu()
     from tests.hip_raster import HipRaster
 

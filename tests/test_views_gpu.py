@@ -120,7 +120,7 @@ def test_views_sharing_a_frame_equal_per_view_inputs():
 def test_frozen_static_appearance_uses_lean_records_with_identical_gradients(H, W):
     """With scales / opacities / rgb frozen (the reference's dynamic stage) the blend backward keeps 9 of the 13 values
     per record; every gradient that is still produced must be bit-identical to the full backward's.  The 40x48 image
-    crowds the 14,400 splats into a few cells, so most of them are LONG cells (k_render_bwd_long, both variants)."""
+    crowds the 14,400 splats into a few cells, so most of them are LONG cells (the long-cell blocks of k_render_bwd, both variants)."""
     _need_gpu()
     from dreammesh4d_amd import views
 
