@@ -18,6 +18,9 @@
 #include "common.h"
 #include "raster.h"
 
+#ifndef DM4D_GREC
+#define DM4D_GREC 128
+#endif
 namespace dm4d {
 
 struct f3 { float x, y, z; };
@@ -367,6 +370,7 @@ __global__ __launch_bounds__(kPreThreads) void k_scatter(BatchDesc d)
 }
 
 // ---------------------------------------------------------------------------------------- B2
+template <int PARTS>   // float4 per record: 3 (12-float records: 3 channels, or lean 6-channel) or 4 (16 floats)
 __global__ __launch_bounds__(kPreThreads) void k_gather_bwd(BatchDesc d)
 {
     const ViewCtx c = resolve(d, blockIdx.y);
@@ -377,9 +381,12 @@ __global__ __launch_bounds__(kPreThreads) void k_gather_bwd(BatchDesc d)
     const float *__restrict__ dLt = c.dLq;
     const BwdOutputs &o = c.o;
     __shared__ float sV[16], sP[16];
-    // per-wave staging chunk: 64 records, padded to 20 floats so that 16 lanes reading 16 different records
-    // with ds_read_b128 hit disjoint bank groups
-    constexpr int kGRec = 64, kGStride = 20;
+    // per-wave staging window of kGRec records.  In a window of n records only ~n / 8 lanes (Gaussians) have
+    // anything to add and the wave loops for the longest of them, so a larger window means fewer, better filled
+    // iterations.  Row stride: 12 floats for the 12-float records (16 lanes reading 16 consecutive records with
+    // ds_read_b128 hit disjoint bank groups: 12 i mod 64 are 16 different multiples of 4), 20 for the 16-float ones.
+    constexpr int kGRec = DM4D_GREC, kGStride = PARTS == 3 ? 12 : 20;
+    constexpr int NQ = kGRec * PARTS / 64;      // float4 a lane holds of a window in flight
     __shared__ __attribute__((aligned(16))) float s_chunk[kPreThreads / 64][kGRec * kGStride];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     if (tid < 16) { sV[tid] = vp.view[tid]; sP[tid] = vp.proj[tid]; }
@@ -401,7 +408,7 @@ __global__ __launch_bounds__(kPreThreads) void k_gather_bwd(BatchDesc d)
         // records: the wave streams it through LDS with fully coalesced 1 KB loads and every lane adds up its
         // own records from there, in record order.
         const bool lean = d.lean != 0;
-        const int RS = grad_stride(C, lean), parts = RS / 4;
+        constexpr int RS = PARTS * 4;
         uint32_t rec0 = 0xFFFFFFFFu, end = 0u;
         if (r > 0) {
             const uint32_t cnt = g.rec_touched[i];
@@ -417,30 +424,27 @@ __global__ __launch_bounds__(kPreThreads) void k_gather_bwd(BatchDesc d)
             R1 = max(R1, (uint32_t)__shfl_xor((int)R1, o2, 64));
         }
         float *chunk = s_chunk[wv];
-        // software pipeline: the next chunk's loads are in flight while this one is summed
-        float4 p0, p1, p2, p3;
-        p0 = p1 = p2 = p3 = make_float4(0.f, 0.f, 0.f, 0.f);
+        // software pipeline: the next window's loads are in flight while this one is summed
+        float4 pq[NQ];
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) pq[q] = make_float4(0.f, 0.f, 0.f, 0.f);
 #define DM4D_FETCH(BASE)                                                                                   \
         {                                                                                                  \
-            const uint32_t n4_ = min((uint32_t)kGRec, R1 - (BASE)) * (uint32_t)parts;                      \
+            const uint32_t n4_ = min((uint32_t)kGRec, R1 - (BASE)) * (uint32_t)PARTS;                      \
             const float4 *src4_ = reinterpret_cast<const float4 *>(dLt + (size_t)(BASE) * RS);             \
-            if ((uint32_t)lane < n4_) p0 = src4_[lane];                                                    \
-            if ((uint32_t)lane + 64u < n4_) p1 = src4_[lane + 64];                                         \
-            if ((uint32_t)lane + 128u < n4_) p2 = src4_[lane + 128];                                       \
-            if (parts > 3 && (uint32_t)lane + 192u < n4_) p3 = src4_[lane + 192];                          \
-        }
-#define DM4D_STAGE(Q, V)                                                                                   \
-        {                                                                                                  \
-            const uint32_t idx4_ = (uint32_t)lane + 64u * (Q);                                             \
-            if (idx4_ < nrec * (uint32_t)parts)                                                            \
-                *reinterpret_cast<float4 *>(chunk + (idx4_ / (uint32_t)parts) * kGStride + (idx4_ % (uint32_t)parts) * 4) = V; \
+            _Pragma("unroll") for (int q = 0; q < NQ; ++q)                                                 \
+                if ((uint32_t)lane + 64u * q < n4_) pq[q] = src4_[lane + 64 * q];                          \
         }
         if (R0 < R1) DM4D_FETCH(R0)
         for (uint32_t base = R0; base < R1; base += kGRec) {
             const uint32_t nrec = min((uint32_t)kGRec, R1 - base);
             __builtin_amdgcn_wave_barrier();
-            DM4D_STAGE(0, p0) DM4D_STAGE(1, p1) DM4D_STAGE(2, p2)
-            if (parts > 3) DM4D_STAGE(3, p3)
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                const uint32_t idx4 = (uint32_t)lane + 64u * q;
+                if (idx4 < nrec * (uint32_t)PARTS)
+                    *reinterpret_cast<float4 *>(chunk + (idx4 / (uint32_t)PARTS) * kGStride + (idx4 % (uint32_t)PARTS) * 4) = pq[q];
+            }
             if (base + kGRec < R1) DM4D_FETCH(base + kGRec)
             __builtin_amdgcn_wave_barrier();
             const uint32_t lo = max(rec0, base), hi = min(end, base + nrec);
@@ -461,7 +465,6 @@ __global__ __launch_bounds__(kPreThreads) void k_gather_bwd(BatchDesc d)
             }
         }
 #undef DM4D_FETCH
-#undef DM4D_STAGE
     }
     {
         // B1's records carry the moments sum_pixels q (dx, dy, dx^2, dx dy, dy^2), q = dL/dG G (raster_render.hip):
@@ -671,7 +674,8 @@ int launch_gather_bwd(const BatchDesc &d, hipStream_t st)
     const int nb = (d.N + kPreThreads - 1) / kPreThreads;
     if (nb == 0) return DM4D_OK;
     ProfScope prof_(kKGatherBwd, st);
-    hipLaunchKernelGGL(k_gather_bwd, dim3(nb, d.B), dim3(kPreThreads), 0, st, d);
+    if (grad_stride(d.C, d.lean != 0) == 12) hipLaunchKernelGGL(k_gather_bwd<3>, dim3(nb, d.B), dim3(kPreThreads), 0, st, d);
+    else hipLaunchKernelGGL(k_gather_bwd<4>, dim3(nb, d.B), dim3(kPreThreads), 0, st, d);
     DM4D_HIP_CHECK(hipGetLastError());
     return DM4D_OK;
 }
