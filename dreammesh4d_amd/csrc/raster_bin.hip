@@ -88,9 +88,10 @@ constexpr int kBins = 1024;
 // chunk (the first version compacted 256 entries at a time with 16 ballots: 3 barriers and two
 // dependent gathers per 256 entries, 70 % of the kernel).
 constexpr int kFinE = 8;
-__device__ __forceinline__ uint64_t spread4(uint32_t x)   // bit i of x -> 16-bit field i
+__device__ __forceinline__ uint64_t spread4(uint32_t x)   // bit i of x (< 16) -> 16-bit field i
 {
-    return (uint64_t)(x & 1u) | ((uint64_t)(x & 2u) << 15) | ((uint64_t)(x & 4u) << 30) | ((uint64_t)(x & 8u) << 45);
+    // four copies of x at bit offsets 0, 15, 30, 45: bit i of copy i sits at 16 i
+    return ((uint64_t)x * 0x0000200040008001ull) & 0x0001000100010001ull;
 }
 __device__ __forceinline__ uint64_t wave_incl_scan_u64(uint64_t v, int lane)
 {
@@ -141,10 +142,18 @@ __device__ __forceinline__ void finish_tile(const ViewCtx &c, int tile, uint32_t
                 const bool dense = ci[j].w != 0u;
                 const int cx0 = max(bx0, 4 * tx) - 4 * tx, cx1 = min(bx0 + nbx, 4 * tx + 4) - 4 * tx;
                 const int cy0 = max(by0, 4 * ty) - 4 * ty, cy1 = min(by0 + nby, 4 * ty + 4) - 4 * ty;
+                // the tile's 4 x 4 window of the Gaussian's cell block, a row (nibble) at a time: bit cx of row cy is
+                // bit (oy + cy) * nbx + ox + cx of the block mask; cells cx = 0..3 of row cy have the ids
+                // 8 (cy >> 1) + 2 (cy & 1) + {0, 1, 4, 5}
+                const uint32_t xmask = cx1 > cx0 ? ((1u << (cx1 - cx0)) - 1u) << cx0 : 0u;   // (the block may miss the tile)
                 uint32_t mm = 0u;
-                for (int cy = cy0; cy < cy1; ++cy)
-                    for (int cx = cx0; cx < cx1; ++cx)
-                        if (dense || ((cm[j] >> ((oy + cy) * nbx + ox + cx)) & 1ull)) mm |= 1u << cell_id(cx, cy);
+#pragma unroll
+                for (int cy = 0; cy < 4; ++cy) {
+                    const int sh = (oy + cy) * nbx + ox;
+                    uint32_t nib = dense ? xmask : (uint32_t)(sh >= 0 ? (cm[j] >> (sh & 63)) : (cm[j] << ((-sh) & 63))) & xmask;
+                    nib = (cy >= cy0 && cy < cy1) ? nib : 0u;
+                    mm |= ((nib & 3u) | ((nib & 12u) << 2)) << (8 * (cy >> 1) + 2 * (cy & 1));
+                }
                 m[j] = mm;
 #pragma unroll
                 for (int w = 0; w < 4; ++w) cnt[w] += spread4((mm >> (4 * w)) & 15u);
