@@ -118,9 +118,9 @@ __global__ __launch_bounds__(256) void k_hex_fwd(HexDesc d, const float *__restr
 
 // ---------------------------------------------------------------------------------------- backward 1
 // G[f][m][s][p][c] = dL/dfeat * prod_{p' != p} sample_{p'}, computed IN PLACE over the samples the forward saved
-__global__ __launch_bounds__(256) void k_hex_bwd_point(HexDesc d, const float *__restrict__ g_feat, float *__restrict__ G)
+__device__ __forceinline__ void hex_bwd_point(const HexDesc &d, const unsigned bid, const float *__restrict__ g_feat, float *__restrict__ G)
 {
-    const size_t gid = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t gid = (size_t)bid * 256 + threadIdx.x;
     const size_t total = (size_t)d.B * d.M * d.S * kHexCh;
     if (gid >= total) return;
     const int c = (int)(gid % kHexCh);
@@ -147,15 +147,15 @@ __global__ __launch_bounds__(256) void k_hex_bwd_point(HexDesc d, const float *_
 // Spatial planes: one thread per (touched texel, channel).  Plan arrays (built once per node set):
 //   sp_scale[u], sp_plane[u], sp_texel[u]  for the U touched texels
 //   sp_off[U+1], sp_item[]                 item = node * 4 + corner  (corner = 2*row + col)
-__global__ __launch_bounds__(256) void k_hex_bwd_spatial(HexDesc d, const float *__restrict__ nodes, int U,
-                                                         const int32_t *__restrict__ sp_scale,
-                                                         const int32_t *__restrict__ sp_plane,
-                                                         const int32_t *__restrict__ sp_texel,
-                                                         const int32_t *__restrict__ sp_off,
-                                                         const int32_t *__restrict__ sp_item,
-                                                         const float *__restrict__ G, HexGrads hg)
+__device__ __forceinline__ void hex_bwd_spatial(const HexDesc &d, const unsigned bid, const float *__restrict__ nodes, int U,
+                                                const int32_t *__restrict__ sp_scale,
+                                                const int32_t *__restrict__ sp_plane,
+                                                const int32_t *__restrict__ sp_texel,
+                                                const int32_t *__restrict__ sp_off,
+                                                const int32_t *__restrict__ sp_item,
+                                                const float *__restrict__ G, const HexGrads &hg)
 {
-    const size_t gid = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t gid = (size_t)bid * 256 + threadIdx.x;
     if (gid >= (size_t)U * kHexCh) return;
     const int c = (int)(gid % kHexCh), u = (int)(gid / kHexCh);
     const int s = sp_scale[u], p = sp_plane[u];
@@ -185,20 +185,20 @@ __global__ __launch_bounds__(256) void k_hex_bwd_spatial(HexDesc d, const float 
 // order) are then combined from the per-frame sums.  Deterministic.
 //   tp_scale[u], tp_plane[u], tp_col[u]; tp_off[U+1], tp_item[] = node * 2 + corner (column corner)
 constexpr int kHexMaxFrames = 16;
-__global__ __launch_bounds__(256) void k_hex_bwd_time(HexDesc d, const float *__restrict__ nodes,
-                                                      const float *__restrict__ times, int U,
-                                                      const int32_t *__restrict__ tp_scale,
-                                                      const int32_t *__restrict__ tp_plane,
-                                                      const int32_t *__restrict__ tp_col,
-                                                      const int32_t *__restrict__ tp_off,
-                                                      const int32_t *__restrict__ tp_item,
-                                                      const float *__restrict__ G, HexGrads hg)
+__device__ __forceinline__ void hex_bwd_time(const HexDesc &d, const unsigned bid, const float *__restrict__ nodes,
+                                             const float *__restrict__ times, int U,
+                                             const int32_t *__restrict__ tp_scale,
+                                             const int32_t *__restrict__ tp_plane,
+                                             const int32_t *__restrict__ tp_col,
+                                             const int32_t *__restrict__ tp_off,
+                                             const int32_t *__restrict__ tp_item,
+                                             const float *__restrict__ G, const HexGrads &hg)
 {
     __shared__ int s_rows[2 * kHexMaxFrames], s_r0[kHexMaxFrames], s_r1[kHexMaxFrames], s_nrows;
     __shared__ float s_wy[kHexMaxFrames];
     __shared__ float s_part[8][kHexMaxFrames][kHexCh];
     const int tid = threadIdx.x;
-    const int u = blockIdx.x;
+    const int u = (int)bid;
     const int s = tp_scale[u], p = tp_plane[u];
     const int a0 = c_axis0[p];
     const int W = d.res[s][a0], H = d.res[s][3];
@@ -264,13 +264,41 @@ __global__ __launch_bounds__(256) void k_hex_bwd_time(HexDesc d, const float *__
 
 // zero fill of all gradient planes in one launch: blockIdx.y = plane (float4 granularity; plane sizes are
 // multiples of 4 floats)
-__global__ __launch_bounds__(256) void k_hex_zero(HexGrads hg)
+constexpr unsigned kHexZeroBlocks = 256;   // per plane
+__device__ __forceinline__ void hex_zero(const HexGrads &hg, const unsigned bid)
 {
-    const int k = blockIdx.y;
+    const int k = (int)(bid / kHexZeroBlocks);
+    const unsigned bx = bid % kHexZeroBlocks;
     const unsigned long long n4 = hg.end4[k] - (k ? hg.end4[k - 1] : 0ull);
     float4 *dst = reinterpret_cast<float4 *>(hg.g[k]);
-    for (unsigned long long i = (unsigned long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (unsigned long long)gridDim.x * 256)
+    for (unsigned long long i = (unsigned long long)bx * 256 + threadIdx.x; i < n4; i += (unsigned long long)kHexZeroBlocks * 256)
         dst[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+}
+
+// The backward is a chain of small, latency-bound launches on M = 1000 nodes; independent ones share a launch
+// (different blocks do different jobs, side by side) instead of queueing behind each other:
+//   launch A: the per-point products (blocks [0, point_blocks)) | the zero fill of the gradient planes (the rest)
+//   launch B: the time planes' columns (blocks [0, n_time): the longer job first) | the spatial planes' texels
+__global__ __launch_bounds__(256) void k_hex_bwd_point_zero(HexDesc d, const float *__restrict__ g_feat, float *__restrict__ G,
+                                                            HexGrads hg, unsigned point_blocks)
+{
+    if (blockIdx.x < point_blocks) hex_bwd_point(d, blockIdx.x, g_feat, G);
+    else hex_zero(hg, blockIdx.x - point_blocks);
+}
+
+struct HexPlan {
+    int n_spatial, n_time;
+    const int32_t *sp_scale, *sp_plane, *sp_texel, *sp_off, *sp_item;
+    const int32_t *tp_scale, *tp_plane, *tp_col, *tp_off, *tp_item;
+};
+__global__ __launch_bounds__(256) void k_hex_bwd_planes(HexDesc d, const float *__restrict__ nodes, const float *__restrict__ times,
+                                                        HexPlan pl, const float *__restrict__ G, HexGrads hg)
+{
+    if (blockIdx.x < (unsigned)pl.n_time)
+        hex_bwd_time(d, blockIdx.x, nodes, times, pl.n_time, pl.tp_scale, pl.tp_plane, pl.tp_col, pl.tp_off, pl.tp_item, G, hg);
+    else
+        hex_bwd_spatial(d, blockIdx.x - (unsigned)pl.n_time, nodes, pl.n_spatial, pl.sp_scale, pl.sp_plane, pl.sp_texel, pl.sp_off,
+                        pl.sp_item, G, hg);
 }
 
 // ---------------------------------------------------------------------------------------- plan helper
@@ -373,19 +401,17 @@ int dm4d_hexplane_backward(int32_t S, int32_t M, int32_t B, const int32_t *res, 
             run += n / 4;
             hg.end4[k] = run;
         }
-    hipLaunchKernelGGL(k_hex_zero, dim3(256, hg.n), dim3(256), 0, st, hg);
-    DM4D_HIP_CHECK(hipGetLastError());
     const size_t total = (size_t)B * M * S * kHexCh;
-    hipLaunchKernelGGL(k_hex_bwd_point, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, d, g_feat, (float *)scratch);
+    const unsigned point_blocks = (unsigned)((total + 255) / 256);
+    hipLaunchKernelGGL(k_hex_bwd_point_zero, dim3(point_blocks + kHexZeroBlocks * (unsigned)hg.n), dim3(256), 0, st, d, g_feat,
+                       (float *)scratch, hg, point_blocks);
     DM4D_HIP_CHECK(hipGetLastError());
-    if (n_spatial > 0) {
-        hipLaunchKernelGGL(k_hex_bwd_spatial, dim3((unsigned)(((size_t)n_spatial * kHexCh + 255) / 256)), dim3(256), 0, st, d, nodes,
-                           n_spatial, sp_scale, sp_plane, sp_texel, sp_off, sp_item, (const float *)scratch, hg);
-        DM4D_HIP_CHECK(hipGetLastError());
-    }
-    if (n_time > 0) {
-        hipLaunchKernelGGL(k_hex_bwd_time, dim3((unsigned)n_time), dim3(256), 0, st, d, nodes, times,
-                           n_time, tp_scale, tp_plane, tp_col, tp_off, tp_item, (const float *)scratch, hg);
+    HexPlan pl = {n_spatial, n_time, sp_scale, sp_plane, sp_texel, sp_off, sp_item, tp_scale, tp_plane, tp_col, tp_off, tp_item};
+    const unsigned sp_blocks = (unsigned)(((size_t)(n_spatial > 0 ? n_spatial : 0) * kHexCh + 255) / 256);
+    if (n_time < 0) pl.n_time = 0;
+    if (sp_blocks + (unsigned)pl.n_time > 0) {
+        hipLaunchKernelGGL(k_hex_bwd_planes, dim3((unsigned)pl.n_time + sp_blocks), dim3(256), 0, st, d, nodes, times, pl,
+                           (const float *)scratch, hg);
         DM4D_HIP_CHECK(hipGetLastError());
     }
     return DM4D_OK;
