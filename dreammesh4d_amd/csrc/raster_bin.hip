@@ -20,34 +20,58 @@ namespace dm4d {
 
 // ---------------------------------------------------------------------------------------- K2
 // hist[w][t] (duplicates of workgroup w in tile t) -> exclusive scan over w in place, and
-// tile_count[t] = column total.  One thread per tile; consecutive threads read consecutive
-// tiles of one histogram row, so every step is a coalesced row access; 8 rows in flight.
-constexpr int kColThreads = 64;
+// tile_count[t] = column total.  A column is only ~200 rows, but walked by one thread it is ~25 dependent memory
+// round trips (the kernel was 13 us of pure latency).  So kColSegs threads share a column: thread (segment, tile)
+// loads its rows in ONE round trip (consecutive threads = consecutive tiles of a row: coalesced), the segment
+// totals meet in LDS, and every thread writes its rows back with its offset.
+constexpr int kColTiles = 64, kColSegs = 16, kColRows = 16;   // tiles per workgroup, threads per column, rows held in registers
+constexpr int kColThreads = kColTiles * kColSegs;
 __global__ __launch_bounds__(kColThreads) void k_colscan(BatchDesc d)
 {
+    __shared__ uint32_t s_part[kColSegs][kColTiles];
     const ViewCtx c = resolve(d, blockIdx.y);
     const GeomPtrs &g = c.g;
     const int T = c.T, nb = (c.in.N + kPreBlock - 1) / kPreBlock;
-    const int t = blockIdx.x * kColThreads + threadIdx.x;
-    if (t >= T) return;
-    uint32_t run = 0;
-    int w = 0;
-    for (; w + 8 <= nb; w += 8) {
-        uint32_t v[8];
+    const int tl = threadIdx.x % kColTiles, seg = threadIdx.x / kColTiles;
+    const int t = blockIdx.x * kColTiles + tl;
+    const bool live = t < T;
+    const int rps = (nb + kColSegs - 1) / kColSegs;            // rows per segment
+    const int w0 = min(seg * rps, nb), w1 = min(w0 + rps, nb);
+    uint32_t v[kColRows];
+    uint32_t sum = 0;
+    if (rps <= kColRows) {
 #pragma unroll
-        for (int k = 0; k < 8; ++k) v[k] = g.hist[(size_t)(w + k) * T + t];
+        for (int k = 0; k < kColRows; ++k) {
+            v[k] = (live && w0 + k < w1) ? g.hist[(size_t)(w0 + k) * T + t] : 0u;
+            sum += v[k];
+        }
+    } else if (live) {
+        for (int w = w0; w < w1; ++w) sum += g.hist[(size_t)w * T + t];
+    }
+    s_part[seg][tl] = sum;
+    __syncthreads();
+    uint32_t run = 0, total = 0;
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            g.hist[(size_t)(w + k) * T + t] = run;
+    for (int k = 0; k < kColSegs; ++k) {
+        const uint32_t pk = s_part[k][tl];
+        run += (k < seg) ? pk : 0u;
+        total += pk;
+    }
+    if (!live) return;
+    if (rps <= kColRows) {
+#pragma unroll
+        for (int k = 0; k < kColRows; ++k) {
+            if (w0 + k < w1) g.hist[(size_t)(w0 + k) * T + t] = run;
             run += v[k];
         }
+    } else {
+        for (int w = w0; w < w1; ++w) {
+            const uint32_t x = g.hist[(size_t)w * T + t];
+            g.hist[(size_t)w * T + t] = run;
+            run += x;
+        }
     }
-    for (; w < nb; ++w) {
-        const uint32_t v = g.hist[(size_t)w * T + t];
-        g.hist[(size_t)w * T + t] = run;
-        run += v;
-    }
-    g.tile_count[t] = run;
+    if (seg == 0) g.tile_count[t] = total;
 }
 
 // ---------------------------------------------------------------------------------------- K4
@@ -408,7 +432,7 @@ int launch_colscan(const BatchDesc &d, hipStream_t st)
     const int T = ((d.W + kTile - 1) / kTile) * ((d.H + kTile - 1) / kTile);
     if (T <= 0) return DM4D_OK;
     ProfScope prof_(kKColscan, st);
-    hipLaunchKernelGGL(k_colscan, dim3((T + kColThreads - 1) / kColThreads, d.B), dim3(kColThreads), 0, st, d);
+    hipLaunchKernelGGL(k_colscan, dim3((T + kColTiles - 1) / kColTiles, d.B), dim3(kColThreads), 0, st, d);
     DM4D_HIP_CHECK(hipGetLastError());
     return DM4D_OK;
 }

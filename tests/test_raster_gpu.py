@@ -212,6 +212,17 @@ def test_deep_translucent_stack_long_cells(n):
             assert np.array_equal(g[k].view(np.uint32), g2[k].view(np.uint32)), k
 
 
+def test_more_than_256_binning_workgroups():
+    """270,000 Gaussians = 264 workgroups of K1: the per-tile column scan (k_colscan) keeps a column segment in
+    registers up to 256 workgroups and falls back to a two-pass walk beyond (BASELINE configs[4] has 977)."""
+    _need_gpu()
+    sc = syn.random_splat_scene(270_000, seed=77, log_scale_mean=math.log(0.003), log_scale_std=0.4)
+    cam = syn.make_camera(80, 112)
+    o, h, out = _both(sc, cam)
+    assert o.D > 400_000
+    _assert_forward_parity(o, h, out)
+
+
 def test_giant_splat_covers_every_tile():
     _need_gpu()
     sc = syn.random_splat_scene(64, seed=10, log_scale_mean=math.log(0.02), log_scale_std=0.3)
