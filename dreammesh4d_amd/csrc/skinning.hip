@@ -313,6 +313,108 @@ __global__ __launch_bounds__(kSkinThreads) void k_skin_bwd_vertex(SkinArgs a0, c
     }
 }
 
+// K == 4 (the shipped configuration): the four neighbours of a vertex on the four lanes of a DPP quad.  The vertex
+// kernel above is one long dependent chain per thread on V x frames = 67 k threads (one wave per SIMD: nothing hides
+// its latency); here every lane evaluates ONE neighbour (its node attributes once, not once per phase), the blended
+// quantities are quad sums ((k0 + k1) + (k2 + k3), fixed order), the vertex-level part is replicated and every lane
+// writes its own record: 4x the threads, a third of the chain.
+__device__ __forceinline__ float quad_sum(float x)
+{
+    x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0xB1, 0xf, 0xf, true));   // quad_perm [1,0,3,2]
+    x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x4E, 0xf, 0xf, true));   // quad_perm [2,3,0,1]
+    return x;
+}
+__device__ __forceinline__ v3 quad_sum3(v3 a) { return mk3(quad_sum(a.x), quad_sum(a.y), quad_sum(a.z)); }
+__device__ __forceinline__ q4 quad_sum4(q4 a) { return q4{quad_sum(a.x), quad_sum(a.y), quad_sum(a.z), quad_sum(a.w)}; }
+
+__global__ __launch_bounds__(kSkinThreads) void k_skin_bwd_vertex_k4(SkinArgs a0, const float *__restrict__ g_xyz,
+                                                                     const float *__restrict__ g_rot,
+                                                                     float *__restrict__ rec)
+{
+    const int gid = blockIdx.x * kSkinThreads + threadIdx.x;
+    const int k = gid & 3;
+    const bool live = (gid >> 2) < a0.V;
+    const int v = live ? (gid >> 2) : a0.V - 1;       // whole quads stay active (DPP); dead quads do not store
+    const SkinArgs a = skin_view(a0, blockIdx.y);
+    if (g_xyz) g_xyz += (size_t)blockIdx.y * a.V * 3;
+    if (g_rot) g_rot += (size_t)blockIdx.y * a.V * 4;
+    rec += (size_t)blockIdx.y * a.V * 4 * kNodeRec;
+    const v3 p = ld3(a.verts, v);
+    const v3 gx = g_xyz ? ld3(g_xyz, v) : mk3(0, 0, 0);
+    const q4 gq = g_rot ? ldq(g_rot, v) : q4{0, 0, 0, 0};
+    const int m = a.nbr_idx[(size_t)v * 4 + k];
+    const float w = a.nbr_w[(size_t)v * 4 + k];
+    const NodeAttr n = node_attr(m, a.dx, a.dr, a.ds, a.dop);
+    // ---- the forward blend state: this neighbour's terms, summed over the quad ----
+    const v3 y = mk3(n.S[0] * p.x + n.S[1] * p.y + n.S[2] * p.z, n.S[3] * p.x + n.S[4] * p.y + n.S[5] * p.z,
+                     n.S[6] * p.x + n.S[7] * p.y + n.S[8] * p.z);
+    const float qn = sqrtf(qdot(n.q, n.q));
+    const q4 qr = qscale(1.f / qn, n.q);
+    const q4 av = q4{0.5f * n.t.x, 0.5f * n.t.y, 0.5f * n.t.z, 0.f};
+    v3 x_lbs = mk3(0, 0, 0);
+    q4 br = q4{0, 0, 0, 0}, bd = q4{0, 0, 0, 0};
+    if (a.method != kDqs) x_lbs = quad_sum3(w * (qact(n.q, y) + n.t));
+    if (a.method != kLbs) {
+        br = quad_sum4(qscale(w, qr));
+        bd = quad_sum4(qscale(w, qmul(av, qr)));
+    }
+    const float eta_raw = quad_sum(w * n.o);
+    const v3 rho = quad_sum3(w * so3_log(n.q));
+    // ---- gradients of the blended quantities (the same in the four lanes) ----
+    float eta = 1.f, g_eta = 0.f;
+    v3 g_lbs = gx, g_dqs = mk3(0, 0, 0);
+    q4 g_br = q4{0, 0, 0, 0}, g_bd = q4{0, 0, 0, 0};
+    if (a.method != kLbs) {
+        const float nn = sqrtf(qdot(br, br));
+        const q4 rh = qscale(1.f / nn, br), dh = qscale(1.f / nn, bd);
+        if (a.method == kDqs) { g_dqs = gx; g_lbs = mk3(0, 0, 0); }
+        else {
+            const v3 x_dqs = qact(rh, p) + qv(qmul(qscale(2.f, dh), qconj(rh)));
+            eta = fminf(eta_raw + 0.4f, 1.0f);
+            g_lbs = eta * gx;
+            g_dqs = (1.f - eta) * gx;
+            g_eta = (eta_raw + 0.4f < 1.0f) ? dot(gx, x_lbs - x_dqs) : 0.f;
+        }
+        q4 g_rh = qact_grad_q(rh, p, g_dqs);
+        const q4 G = q4{g_dqs.x, g_dqs.y, g_dqs.z, 0.f};
+        const q4 g_dh = qscale(2.f, qmul(G, rh));
+        const q4 g_b = qmul(qconj(qscale(2.f, dh)), G);
+        g_rh = qadd(g_rh, q4{-g_b.x, -g_b.y, -g_b.z, g_b.w});
+        g_bd = qscale(1.f / nn, g_dh);
+        g_br = qadd(qscale(1.f / nn, g_rh), qscale(-(qdot(g_rh, rh) + qdot(g_dh, dh)) / nn, rh));
+    }
+    const v3 g_rho = so3_exp_grad(rho, gq);
+    // ---- this neighbour's gradients ----
+    v3 g_t = mk3(0, 0, 0);
+    q4 g_q = so3_log_grad(n.q, w * g_rho);
+    float g_S[6] = {0, 0, 0, 0, 0, 0};
+    if (a.method != kDqs) {
+        const v3 h = w * g_lbs;
+        g_t = g_t + h;
+        g_q = qadd(g_q, qact_grad_q(n.q, y, h));
+        const v3 gy = qact_grad_p(n.q, h);
+        g_S[0] = gy.x * p.x; g_S[1] = gy.y * p.y; g_S[2] = gy.z * p.z;
+        g_S[3] = gy.x * p.y + gy.y * p.x;
+        g_S[4] = gy.x * p.z + gy.z * p.x;
+        g_S[5] = gy.y * p.z + gy.z * p.y;
+    }
+    if (a.method != kLbs) {
+        const q4 g_d = qscale(w, g_bd);
+        const q4 g_a = qmul(g_d, qconj(qr));
+        g_t = g_t + 0.5f * qv(g_a);
+        q4 g_qr = qadd(qmul(qconj(av), g_d), qscale(w, g_br));
+        g_q = qadd(g_q, qscale(1.f / qn, qadd(g_qr, qscale(-qdot(g_qr, qr), qr))));
+    }
+    const q4 g_p = qscale(1.f / n.pn, qadd(g_q, qscale(-qdot(g_q, n.q), n.q)));
+    const float g_o = w * g_eta;
+    if (!live) return;
+    float *r = rec + ((size_t)v * 4 + k) * kNodeRec;
+    r[0] = g_t.x; r[1] = g_t.y; r[2] = g_t.z;
+    r[3] = g_p.x; r[4] = g_p.y; r[5] = g_p.z; r[6] = g_p.w;
+    r[7] = g_S[0]; r[8] = g_S[1]; r[9] = g_S[2]; r[10] = g_S[3]; r[11] = g_S[4]; r[12] = g_S[5];
+    r[13] = g_o * n.o * (1.f - n.o);
+}
+
 // ---------------------------------------------------------------------------------------- backward 2
 // per node: fixed-order sum of the records of every (vertex, k) that references it (static CSR)
 __global__ __launch_bounds__(64) void k_skin_bwd_node(int M, const int32_t *__restrict__ csr_off,
@@ -603,8 +705,12 @@ int skin_backward_launch(int B, int method, int V, int M, int K, const float *ve
     SkinArgs a{method, V, M, K, verts, idx, w, dx, dr, method == kDqs ? nullptr : ds, method == kHybrid ? dop : nullptr};
     ProfScope prof_(kKSkinBwd, st);
     if (V > 0) {
-        hipLaunchKernelGGL(k_skin_bwd_vertex, dim3((V + kSkinThreads - 1) / kSkinThreads, B), dim3(kSkinThreads), 0, st, a,
-                           g_xyz, g_rot, scratch);
+        if (K == 4)
+            hipLaunchKernelGGL(k_skin_bwd_vertex_k4, dim3((4 * V + kSkinThreads - 1) / kSkinThreads, B), dim3(kSkinThreads), 0, st, a,
+                               g_xyz, g_rot, scratch);
+        else
+            hipLaunchKernelGGL(k_skin_bwd_vertex, dim3((V + kSkinThreads - 1) / kSkinThreads, B), dim3(kSkinThreads), 0, st, a,
+                               g_xyz, g_rot, scratch);
         DM4D_HIP_CHECK(hipGetLastError());
     }
     hipLaunchKernelGGL(k_skin_bwd_node, dim3(M, B), dim3(64), 0, st, M, csr_off, csr_items,
