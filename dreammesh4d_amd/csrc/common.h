@@ -131,13 +131,20 @@ __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v)
     return v;
 }
 // inclusive prefix sum across the wave
-__device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v, int lane)
+// Six DPP adds (row shifts by 1, 2, 4, 8 with zero fill, then lane 15 / lane 31 broadcast into the following rows),
+// all on the VALU: the __shfl_up version this replaces went through the LDS crossbar six times, each a dependent
+// round trip.
+__device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v, int /*lane*/)
 {
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        uint32_t w = __shfl_up(v, o, 64);
-        if (lane >= o) v += w;
-    }
+#define DM4D_DPP_ADD(CTRL, ROWMASK) \
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROWMASK, 0xf, false)
+    DM4D_DPP_ADD(0x111, 0xf);   // row_shr:1
+    DM4D_DPP_ADD(0x112, 0xf);   // row_shr:2
+    DM4D_DPP_ADD(0x114, 0xf);   // row_shr:4
+    DM4D_DPP_ADD(0x118, 0xf);   // row_shr:8
+    DM4D_DPP_ADD(0x142, 0xa);   // row_bcast:15 -> rows 1 and 3
+    DM4D_DPP_ADD(0x143, 0xc);   // row_bcast:31 -> rows 2 and 3
+#undef DM4D_DPP_ADD
     return v;
 }
 __device__ __forceinline__ int lane_id() { return (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }

@@ -117,14 +117,11 @@ __device__ __forceinline__ uint64_t spread4(uint32_t x)   // bit i of x (< 16) -
     // four copies of x at bit offsets 0, 15, 30, 45: bit i of copy i sits at 16 i
     return ((uint64_t)x * 0x0000200040008001ull) & 0x0001000100010001ull;
 }
+// four 16-bit fields that never overflow into each other: the two halves are scanned as independent 32-bit words
 __device__ __forceinline__ uint64_t wave_incl_scan_u64(uint64_t v, int lane)
 {
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const uint64_t w = (uint64_t)__shfl_up((unsigned long long)v, o, 64);
-        if (lane >= o) v += w;
-    }
-    return v;
+    const uint32_t lo = wave_incl_scan_u32((uint32_t)v, lane), hi = wave_incl_scan_u32((uint32_t)(v >> 32), lane);
+    return ((uint64_t)hi << 32) | lo;
 }
 template <int kSortThreads, typename GidAt>
 __device__ __forceinline__ void finish_tile(const ViewCtx &c, int tile, uint32_t s, uint32_t n, GidAt &&gid_at)
