@@ -115,21 +115,44 @@ __device__ __forceinline__ float wave_sum_row3(float v)
     v = dpp_add<0x143, 0xC>(v);  // row_bcast31 into rows 2,3
     return v;
 }
+// Wave-wide integer reductions, every lane (uniform result): four DPP row rotations leave each row's result in all
+// of its lanes, the four rows are combined on the scalar unit -- no trips through the LDS crossbar (__shfl_xor).
+template <int CTRL>
+__device__ __forceinline__ uint32_t dpp_u32(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xF, 0xF, false); }
+#define DM4D_ROW_ALLREDUCE(OP)                       \
+    v = OP(v, dpp_u32<0x121>(v)); /* row_ror:1 */    \
+    v = OP(v, dpp_u32<0x122>(v)); /* row_ror:2 */    \
+    v = OP(v, dpp_u32<0x124>(v)); /* row_ror:4 */    \
+    v = OP(v, dpp_u32<0x128>(v)); /* row_ror:8 */
+#define DM4D_ROWS_COMBINE(OP)                                                                         \
+    OP(OP((uint32_t)__builtin_amdgcn_readlane((int)v, 0), (uint32_t)__builtin_amdgcn_readlane((int)v, 16)), \
+       OP((uint32_t)__builtin_amdgcn_readlane((int)v, 32), (uint32_t)__builtin_amdgcn_readlane((int)v, 48)))
+__device__ __forceinline__ uint32_t op_add_u32(uint32_t a, uint32_t b) { return a + b; }
+__device__ __forceinline__ uint32_t op_max_u32(uint32_t a, uint32_t b) { return a > b ? a : b; }
+__device__ __forceinline__ uint32_t op_min_u32(uint32_t a, uint32_t b) { return a < b ? a : b; }
 __device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v)
 {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
+    DM4D_ROW_ALLREDUCE(op_add_u32)
+    return DM4D_ROWS_COMBINE(op_add_u32);
 }
 __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v)
 {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        uint32_t w = __shfl_xor(v, o, 64);
-        v = v > w ? v : w;
-    }
+    DM4D_ROW_ALLREDUCE(op_max_u32)
+    return DM4D_ROWS_COMBINE(op_max_u32);
+}
+__device__ __forceinline__ uint32_t wave_min_u32(uint32_t v)
+{
+    DM4D_ROW_ALLREDUCE(op_min_u32)
+    return DM4D_ROWS_COMBINE(op_min_u32);
+}
+// maximum over the 16 lanes of a DPP row, in every lane of the row
+__device__ __forceinline__ uint32_t row_allmax_u32(uint32_t v)
+{
+    DM4D_ROW_ALLREDUCE(op_max_u32)
     return v;
 }
+#undef DM4D_ROW_ALLREDUCE
+#undef DM4D_ROWS_COMBINE
 // inclusive prefix sum across the wave
 // Six DPP adds (row shifts by 1, 2, 4, 8 with zero fill, then lane 15 / lane 31 broadcast into the following rows),
 // all on the VALU: the __shfl_up version this replaces went through the LDS crossbar six times, each a dependent

@@ -289,10 +289,8 @@ __global__ __launch_bounds__(kSortThreads) void k_tile_sort(BatchDesc d)
                 dmax = max(dmax, dz);
             }
         }
-        for (int o = 32; o > 0; o >>= 1) {
-            dmin = min(dmin, (uint32_t)__shfl_xor((int)dmin, o, 64));
-            dmax = max(dmax, (uint32_t)__shfl_xor((int)dmax, o, 64));
-        }
+        dmin = wave_min_u32(dmin);
+        dmax = wave_max_u32(dmax);
         if (lane == 0) { s_red[wv] = dmin; s_red[kWaves + wv] = dmax; }
         for (int i = tid; i <= kBins; i += kSortThreads) s_bin[i] = 0u;
         __syncthreads();
@@ -368,10 +366,8 @@ __global__ __launch_bounds__(kSortThreads) void k_tile_sort(BatchDesc d)
             dmin = min(dmin, dz);
             dmax = max(dmax, dz);
         }
-        for (int o = 32; o > 0; o >>= 1) {
-            dmin = min(dmin, (uint32_t)__shfl_xor((int)dmin, o, 64));
-            dmax = max(dmax, (uint32_t)__shfl_xor((int)dmax, o, 64));
-        }
+        dmin = wave_min_u32(dmin);
+        dmax = wave_max_u32(dmax);
         if (lane == 0) { s_red[wv] = dmin; s_red[kWaves + wv] = dmax; }
         for (int i = tid; i <= kBins; i += kSortThreads) s_bin[i] = 0u;
         __syncthreads();

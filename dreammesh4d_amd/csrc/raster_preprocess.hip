@@ -418,11 +418,8 @@ __global__ __launch_bounds__(kPreThreads) void k_gather_bwd(BatchDesc d)
             }
         }
         uint32_t R0 = rec0, R1 = end;
-#pragma unroll
-        for (int o2 = 32; o2 > 0; o2 >>= 1) {
-            R0 = min(R0, (uint32_t)__shfl_xor((int)R0, o2, 64));
-            R1 = max(R1, (uint32_t)__shfl_xor((int)R1, o2, 64));
-        }
+        R0 = wave_min_u32(R0);
+        R1 = wave_max_u32(R1);
         float *chunk = s_chunk[wv];
         // software pipeline: the next window's loads are in flight while this one is summed
         float4 pq[NQ];

@@ -192,15 +192,7 @@ __device__ __forceinline__ void set_priority_by_length(uint32_t n)
     else if (n >= 192u) __builtin_amdgcn_s_setprio(2);
     else if (n >= 128u) __builtin_amdgcn_s_setprio(1);
 }
-__device__ __forceinline__ uint32_t row_max_u32(uint32_t v)
-{
-#pragma unroll
-    for (int o = 8; o > 0; o >>= 1) {
-        const uint32_t w = __shfl_xor(v, o, 64);
-        v = v > w ? v : w;
-    }
-    return v;
-}
+__device__ __forceinline__ uint32_t row_max_u32(uint32_t v) { return row_allmax_u32(v); }
 
 // lane -> pixel: row (lane >> 4) = cell (row & 1, row >> 1) of the quadrant, lane & 15 = pixel of the cell
 struct LanePixel { int px, py, row, li, cell; };

@@ -444,11 +444,8 @@ __global__ __launch_bounds__(64) void k_skin_bwd_node(int M, const int32_t *__re
         for (int i = 0; i < kNodeRec; ++i) acc[i] += r[i];
     }
 #pragma unroll
-    for (int i = 0; i < kNodeRec; ++i) {
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) acc[i] += __shfl_xor(acc[i], o, 64);
-    }
-    if (lane != 0) return;
+    for (int i = 0; i < kNodeRec; ++i) acc[i] = wave_sum_row3(acc[i]);   // fixed order, on the VALU; total in row 3
+    if (lane != 63) return;
     if (g_dx) { g_dx[3 * m] = acc[0]; g_dx[3 * m + 1] = acc[1]; g_dx[3 * m + 2] = acc[2]; }
     if (g_dr) { g_dr[4 * m] = acc[3]; g_dr[4 * m + 1] = acc[4]; g_dr[4 * m + 2] = acc[5]; g_dr[4 * m + 3] = acc[6]; }
     if (g_ds) { for (int i = 0; i < 6; ++i) g_ds[6 * m + i] = acc[7 + i]; }
@@ -665,9 +662,9 @@ __global__ __launch_bounds__(kSkinThreads) void k_face_bwd_vertex(int V, int F, 
         }
 #pragma unroll
     for (int i = 0; i < kCornerRec; ++i) {
-        a[i] += __shfl_xor(a[i], 1, 64);
-        a[i] += __shfl_xor(a[i], 2, 64);
-        a[i] += __shfl_xor(a[i], 4, 64);
+        a[i] = dpp_add<0xB1>(a[i]);     // lane ^ 1 (quad_perm [1,0,3,2])
+        a[i] = dpp_add<0x4E>(a[i]);     // lane ^ 2 (quad_perm [2,3,0,1])
+        a[i] = dpp_add<0x141>(a[i]);    // the other quad of the 8 lanes (row_half_mirror: its lanes all hold that quad's sum)
     }
     if (!live || c != 0) return;
     v3 X = mk3(a[0], a[1], a[2]);
