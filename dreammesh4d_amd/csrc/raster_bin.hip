@@ -241,7 +241,7 @@ __device__ __forceinline__ void finish_tile(const ViewCtx &c, int tile, uint32_t
 }
 
 template <int kSortThreads>
-__global__ __launch_bounds__(kSortThreads) void k_tile_sort(BatchDesc d)
+__global__ __launch_bounds__(kSortThreads, 4) void k_tile_sort(BatchDesc d)
 {
     constexpr int kSortLdsCap = kSortPerThread * kSortThreads;
     constexpr int kWaves = kSortThreads / 64;
