@@ -182,3 +182,17 @@ def touched_from_plan(field, plan):
                 storage_flat(par)                               # raises unless channels_last
                 out[par] = (t[:, None] * C + ch[None, :]).reshape(-1)
     return out
+
+
+def all_reduce_max(t):
+    """In-place MAX over the ranks of a small tensor (the overflow flag of a step: if ANY rank's forward overflowed, every
+    rank skips the optimiser step, so the replicas stay identical).  No-op for a single process."""
+    if world() == 1:
+        return t
+    if t.is_cuda and dist.get_backend() == "gloo":
+        host = t.cpu()
+        dist.all_reduce(host, op=dist.ReduceOp.MAX)
+        t.copy_(host)
+    else:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return t

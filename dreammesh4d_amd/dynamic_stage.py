@@ -48,7 +48,10 @@ class DynamicStage:
                  length_inter_frames=0.1):
         self.r, self.net, self.nodes, self.static = renderer, net, nodes, static
         self.timestamps = timestamps                     # [L] in (0,1)
-        self.ref_images, self.ref_masks = ref_images, ref_masks          # [L,H,W,3], [L,H,W,1]
+        # [L,H,W,3], [L,H,W,1]; the reference's gt image is composited on white outside the mask
+        # (data/temporal_image.py:201-202) and the dynamic step compares it UNMASKED (system/sugar_4dgen.py:164-167)
+        self.ref_masks = ref_masks
+        self.ref_images = ref_images * ref_masks + (1.0 - ref_masks)
         self.ref_camera = ref_camera
         self.guidance = guidance
         self.normal_consistency = normal_consistency     # mesh_reg.MeshNormalConsistency of the surface mesh, or None
@@ -65,6 +68,7 @@ class DynamicStage:
         self.sched = {"deformation": deformation_lr, "grid": grid_lr}
         self.reducer = D.GradAllReducer(net.parameters())
         self.global_step = 0
+        self.poll_every = 8              # iterations between sync-free looks at the rasterizer's capacity counters
         self.bg6 = torch.ones(6, device=self.dev)      # training background is white (diff_sugar_rasterizer_temporal.py:96-101)
 
     def sample_batch(self):
@@ -136,7 +140,7 @@ class DynamicStage:
         loss = rgb.sum() * 0.0
         terms = {}
         if ref.any():
-            terms["rgb"] = F.mse_loss(rgb[ref] * self.ref_masks[fidx[ref]], self.ref_images[fidx[ref]] * self.ref_masks[fidx[ref]])
+            terms["rgb"] = F.mse_loss(self.ref_images[fidx[ref]], rgb[ref])     # unmasked: colour outside the silhouette is penalised
             terms["mask"] = F.mse_loss(mask[ref], self.ref_masks[fidx[ref]])
             loss = loss + LAMBDA["rgb"] * terms["rgb"] + C(LAMBDA["mask"], 0, it) * terms["mask"]
         if self.guidance is not None and rnd.any():
@@ -156,6 +160,15 @@ class DynamicStage:
                 loss = loss + LAMBDA["arap_reg_inter_frame"] * terms["arap_reg_inter_frame"]
         loss.backward()
         self.reducer()                  # the one exchange step (no-op for a single process)
+        if self.dev.type == "cuda":
+            # a forward that overflowed its duplicate / record capacity rendered a wrong image: the fused AdamW skips the
+            # step on the device (found_inf, as a GradScaler would) -- no host sync; poll() reports it a step or two later
+            flag = self.r.overflow_flag()
+            if D.world() > 1:
+                D.all_reduce_max(flag)
+            self.opt.found_inf, self.opt.grad_scale = flag, None
         self.opt.step()
         self.global_step += 1
+        if self.dev.type == "cuda" and self.global_step % self.poll_every == 0:
+            self.r.poll()
         return {"loss": loss.detach(), **{k: v.detach() for k, v in terms.items()}}

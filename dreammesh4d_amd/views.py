@@ -46,6 +46,8 @@ class ViewRenderer:
         # backward records = (Gaussian, 4x4-pixel cell) pairs; ~2 per duplicate for mesh-bound splats
         self.record_capacity = int(record_factor * self.capacity)
         self.calibrated = False   # capacities checked against the first forward (render_views)
+        self.headroom = 1.5       # capacities are kept >= headroom x the largest count seen (cameras / strain move D)
+        self._pending = None      # (pinned int32 [B, 4], event): counters of an earlier forward on their way to the host
         self.last = None   # (ViewsStruct, keep-alive) of the most recent forward, for check()
         self._ws_pool = []     # recycled (geom, binning, image) workspace sets, keyed by (B, capacity)
         self._scratch = {}     # persistent backward scratch, keyed by (B, capacity)
@@ -78,6 +80,51 @@ class ViewRenderer:
                 face=torch.empty(L.dm4d_views_face_scratch_bytes(B, t.F), dtype=torch.uint8, device=dev))}
         return self._scratch[key]
 
+    def counters_i32(self):
+        """[B, 4] int32 device view of the last forward's counters {D, duplicate overflow, R, record overflow}
+        (csrc/raster.h GeomCounter; every view's geom workspace starts with them)."""
+        vs, ws = self.last
+        per_view = ws["geom"].numel() // vs.B
+        return ws["geom"].view(torch.int32).view(vs.B, per_view // 4)[:, :4]
+
+    def overflow_flag(self):
+        """float32 [1] on the device: 1.0 if the last forward dropped duplicates or backward records, else 0.0 -- no host
+        sync.  Training loops hand it to the fused AdamW as `found_inf` (the step is then skipped on the device, the way
+        a GradScaler skips a step) and call poll() at their leisure."""
+        c = self.counters_i32()
+        return ((c[:, 1] | c[:, 3]) != 0).any().to(torch.float32).reshape(1)
+
+    def poll(self):
+        """Sync-free capacity monitor: queues an async copy of the last forward's counters into pinned memory and looks at
+        the copy queued by the PREVIOUS call if it has landed.  Raises Dm4dError (after enlarging the capacities for the
+        following forwards) if that forward overflowed; otherwise keeps the capacities >= headroom x the counts seen."""
+        done = None
+        if self._pending is not None and self._pending[1].query():
+            done, self._pending = self._pending[0], None
+        if self._pending is None and self.last is not None:
+            c = self.counters_i32()
+            host = torch.empty(c.shape, dtype=torch.int32, pin_memory=True)
+            host.copy_(c, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(self.device))
+            self._pending = (host, ev)
+        if done is None:
+            return None
+        d, r_ = int(done[:, 0].max()), int(done[:, 2].max())
+        over = bool((done[:, 1] != 0).any() or (done[:, 3] != 0).any())
+        self._grow(d, r_)
+        if over:
+            raise _lib.Dm4dError(f"a forward overflowed its workspaces (num_rendered {d}, records {r_}); capacities raised to "
+                                 f"{self.capacity} / {self.record_capacity}; the optimiser step of that iteration was skipped "
+                                 "on the device if overflow_flag() was given to it")
+        return d, r_
+
+    def _grow(self, d, r_):
+        if d * self.headroom > self.capacity:
+            self.capacity = int(d * self.headroom) + 1024
+        if r_ * self.headroom > self.record_capacity:
+            self.record_capacity = int(r_ * self.headroom) + 1024
+
     def check(self):
         """Host check of the duplicate-list and record capacities (syncs).  Returns num_rendered per view; raises
         on overflow after enlarging the capacity for subsequent calls."""
@@ -103,6 +150,7 @@ class ViewRenderer:
             self.record_capacity = int(max(nrec) * 1.5) + 1024
             raise _lib.Dm4dError(f"backward record overflow: {max(nrec)} records > record_capacity; "
                                  f"raised to {self.record_capacity}, re-run the step")
+        self._grow(max(nr), max(nrec))     # headroom for the forwards that follow
         return nr
 
 
@@ -159,6 +207,9 @@ class _RenderViews(torch.autograd.Function):
     def backward(ctx, g_color, g_depth, g_alpha, _g_radii, g_vxyz, g_vrot):
         L = _lib.lib()
         r, vs = ctx.r, ctx.vs
+        if ctx.ws is None:
+            raise RuntimeError("render_views: backward called a second time (retain_graph): the rasterizer workspaces of "
+                               "this forward were recycled by the first backward; run the forward again")
         _alive = ctx.saved_tensors      # vs points into these (and into ctx.internal / ctx.keep)
         g, t, dev = r.graph, r.topo, r.device
         B, N, H, W = vs.B, r.N, r.H, r.W

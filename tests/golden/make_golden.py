@@ -10,6 +10,9 @@ state, and the outputs / gradients the reference computes for them).
                           torch only) -- DeformationNetwork with a reduced HexPlane
                           (resolution [8,8,8,5], multires [1,2]), heads perturbed away from their
                           zero init; forward_dynamic_delta outputs and parameter gradients.
+  deformation_nodes.npz   the same reference network (state of deformation_small.npz) queried the way the hot path
+                          queries it (dynamic_sugar.py:420-431): M static nodes x B timestamps, t = 2*ts - 1, outputs
+                          [B,M,*] and parameter gradients -- what the -m gpu test compares the HIP kernels with.
   strain_matrix.npz       strain_tensor_to_matrix (dynamic_sugar.py:29-39), extracted by AST (the
                           enclosing module needs pypose/pytorch3d) and executed.
   schedule_C.npz          C() (threestudio/utils/misc.py:66-101), extracted by AST.
@@ -88,6 +91,39 @@ def deformation():
     # full-size parameter count of the shipped configuration (35,755,892)
     full = ref.DeformationNetwork(ref.ModelHiddenParams(None))
     print("deformation_small.npz written; full-size params:", sum(p.numel() for p in full.parameters()))
+
+
+def deformation_nodes():
+    spec = importlib.util.spec_from_file_location("ref_deformation", os.path.join(C_DIR, "geometry", "deformation.py"))
+    ref = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ref)
+    z = np.load(os.path.join(OUT, "deformation_small.npz"))
+    args = ref.ModelHiddenParams(None)
+    args.kplanes_config = dict(args.kplanes_config, resolution=[8, 8, 8, 5])
+    args.multires = [1, 2]
+    args.no_ds, args.no_dr, args.no_do = False, False, False
+    net = ref.DeformationNetwork(args)
+    net.load_state_dict({k[len("state/"):]: torch.tensor(z[k]) for k in z.files if k.startswith("state/")}, strict=True)
+    g = torch.Generator().manual_seed(11)
+    M, B = 41, 3
+    nodes = torch.rand(M, 3, generator=g) * 1.6 - 0.8
+    nodes[0] = torch.tensor([1.3, -1.2, 0.0])          # outside the aabb: border padding
+    nodes[1] = torch.tensor([-1.0, 1.0, 0.999])        # on / next to the upper border
+    ts = torch.tensor([0.0, 0.37, 0.96875])            # t = -1 exactly (lower border of the time axis) and two interior
+    pts = nodes.unsqueeze(0).expand(B, M, 3).reshape(-1, 3)
+    t = ts.view(B, 1, 1).expand(B, M, 1).reshape(-1, 1) * 2.0 - 1.0
+    dx, dr, ds, do = net.forward_dynamic_delta(pts, t)
+    w = [torch.randn(x.shape, generator=g) for x in (dx, dr, ds, do)]
+    loss = sum((a * b).sum() for a, b in zip((dx, dr, ds, do), w))
+    loss.backward()
+    out = {"nodes": nodes.numpy(), "ts": ts.numpy(), "dx": dx.detach().view(B, M, 3).numpy(), "dr": dr.detach().view(B, M, 4).numpy(),
+           "ds": ds.detach().view(B, M, 6).numpy(), "do": do.detach().view(B, M).numpy(), "loss": np.float64(loss.item())}
+    for i, (x, k) in enumerate(zip(w, (3, 4, 6, 1))):
+        out[f"w{i}"] = x.view(B, M, k).numpy()
+    for k, p in net.named_parameters():
+        out["grad/" + k] = (p.grad if p.grad is not None else torch.zeros_like(p)).numpy()
+    np.savez_compressed(os.path.join(OUT, "deformation_nodes.npz"), **out)
+    print("deformation_nodes.npz written; loss", float(loss))
 
 
 def strain():
@@ -209,6 +245,7 @@ if __name__ == "__main__":
     if not os.path.isdir(REF):
         sys.exit("needs /root/reference (authoring container only)")
     deformation()
+    deformation_nodes()
     arap()
     strain()
     schedule()

@@ -141,10 +141,27 @@ def test_oracle_matches_dense_autograd(seed, H, W):
     t = lambda a: torch.tensor(np.asarray(a, np.float64), dtype=torch.float64)
     leaves = {k: t(sc[k]).requires_grad_(True) for k in ("means3D", "opacities", "colors", "scales", "rotations")}
     m2d = torch.zeros(n, 3, dtype=torch.float64, requires_grad=True)
-    mn, mx = _rects(o, cam)
+    # integer / ordering state: the dense restatement's OWN float64 decisions (preprocess_fp64 takes nothing from the
+    # oracle); only Gaussians within float32 rounding of a decision boundary fall back to the oracle's value
+    from tests.dense_reference import preprocess_fp64
+    p = preprocess_fp64(sc["means3D"], sc["scales"], sc["rotations"], cam.viewmatrix, cam.projmatrix, cam.tanfov,
+                        cam.tanfov, H, W, scale_mod=1.1)
+    mn_o, mx_o = _rects(o, cam)
+    safe = p["margin"] > 2e-3
+    assert safe.sum() >= n - 8
+    assert np.array_equal(p["radii"][safe], o.s["radii"][safe])
+    vis = safe & p["visible"]
+    assert np.array_equal(p["rect_min"][vis], mn_o[vis]) and np.array_equal(p["rect_max"][vis], mx_o[vis])
+    radii = np.where(safe, p["radii"], o.s["radii"])
+    mn = np.where(safe[:, None], p["rect_min"], mn_o)
+    mx = np.where(safe[:, None], p["rect_max"], mx_o)
+    shown = [i for i in range(n) if radii[i] > 0]
+    order_own = sorted(shown, key=lambda i: (p["depth"][i], i))
+    order_orc = sorted(shown, key=lambda i: (float(o.s["depths"][i]), i))
+    assert order_own == order_orc          # no float32 depth ties in this scene: the fp64 order is the oracle's
     C, D, A = dense_rasterize(leaves["means3D"], m2d, leaves["opacities"], leaves["colors"], leaves["scales"],
                               leaves["rotations"], t(cam.viewmatrix), t(cam.projmatrix), t([0.3, 0.6, 0.9]),
-                              cam.tanfov, cam.tanfov, H, W, 1.1, o.s["radii"], mn, mx, o.s["depths"])
+                              cam.tanfov, cam.tanfov, H, W, 1.1, radii, mn, mx, p["depth"])
     assert np.abs(C.detach().numpy() - o.s["out_color"]).max() < 2e-5
     assert np.abs(D.detach().numpy() - o.s["out_depth"]).max() < 1e-4
     assert np.abs(A.detach().numpy() - o.s["out_alpha"]).max() < 2e-5
@@ -164,3 +181,52 @@ def test_oracle_matches_dense_autograd(seed, H, W):
     close("scales", g["dL_dscales"], leaves["scales"].grad)
     close("rotations", g["dL_drots"], leaves["rotations"].grad)
     assert (o.s["radii"] > 0).sum() > n // 2
+
+
+@pytest.mark.parametrize("n,H,W,seed,lsm,spread", [(20_000, 256, 256, 0, math.log(0.008), 1.0),
+                                                    (5_000, 100, 173, 1, math.log(0.03), 1.0),
+                                                    (4_000, 64, 96, 2, math.log(0.05), 3.5)])   # many off-screen / behind
+def test_preprocess_decisions_match_independent_fp64(n, H, W, seed, lsm, spread):
+    """Cull, radius, tile rect, tiles_touched and the depth ORDER of the oracle (float32, restating upstream) against an
+    independent float64 statement of the same published algorithm (tests/dense_reference.py::preprocess_fp64, which
+    takes nothing from the oracle).  They must agree for every Gaussian whose decisions are not within float32
+    rounding of a boundary; the boundary cases are counted and must stay a tiny fraction."""
+    from tests.dense_reference import preprocess_fp64
+
+    sc = syn.random_splat_scene(n, seed=seed, log_scale_mean=lsm, log_scale_std=0.6)
+    sc["means3D"] = (sc["means3D"] * spread).astype(np.float32)
+    if spread > 1:
+        sc["means3D"][: n // 10] += (syn.make_camera(H, W, azim_deg=30.0).campos * 1.2).astype(np.float32)   # behind / near the camera
+    cam = syn.make_camera(H, W, elev_deg=15.0, azim_deg=30.0)
+    o = _oracle(sc, cam, scale_mod=1.0)
+    p = preprocess_fp64(sc["means3D"], sc["scales"], sc["rotations"], cam.viewmatrix, cam.projmatrix, cam.tanfov, cam.tanfov, H, W)
+    safe = p["margin"] > 2e-3            # float32 evaluation error of 3 sigma / pixel coordinates is ~1e-4 here
+    n_boundary = int((~safe).sum())
+    assert n_boundary < 0.02 * n, n_boundary
+    assert np.array_equal(o.s["radii"][safe], p["radii"][safe])
+    assert np.array_equal(o.s["tiles_touched"][safe].astype(np.int64), p["tiles_touched"][safe])
+    mn, mx = _rects(o, cam)
+    vis = safe & p["visible"]
+    assert np.array_equal(mn[vis], p["rect_min"][vis]) and np.array_equal(mx[vis], p["rect_max"][vis])
+    # boundary cases may differ, but only by one unit of the decision
+    d_r = np.abs(o.s["radii"].astype(np.int64) - p["radii"])
+    both = (o.s["radii"] > 0) & p["visible"]
+    assert d_r[both].max(initial=0) <= 1
+    # pixel coordinates and depths themselves
+    assert np.abs(o.s["xy"][both] - p["xy"][both]).max() < 2e-3
+    assert np.abs(o.s["depths"][both] - p["depth"][both]).max() < 1e-5
+    # depth order of the sorted list: within every tile the oracle's order is the fp64 order, except between
+    # neighbours whose fp64 depths are closer than float32 resolution
+    vals, ranges = o.s["values"], o.s["ranges"]
+    z = p["depth"]
+    inversions = tight = 0
+    for s, e in ranges:
+        if e - s < 2:
+            continue
+        zz = z[vals[s:e]]
+        bad = np.nonzero(np.diff(zz) < 0)[0]
+        inversions += len(bad)
+        tight += int((np.abs(np.diff(zz))[bad] < 1e-6).sum())
+    assert inversions == tight, (inversions, tight)
+    print(f"preprocess decisions: {n_boundary} of {n} Gaussians within rounding of a boundary (excluded), "
+          f"{int((d_r > 0).sum())} radius differences among them, {inversions} depth-order inversions (all below float32 resolution)")

@@ -14,7 +14,8 @@ from dreammesh4d_amd import synthetic as syn
 pytestmark = pytest.mark.gpu
 
 TOL = 1e-4      # north_star tolerance for RGB L-inf
-GRAD_RTOL = 2e-3
+GRAD_RTOL = 1e-4   # relative, per element
+GRAD_ATOL = 5e-6   # x max|oracle gradient| of the tensor, per element
 
 
 def _need_gpu():
@@ -73,12 +74,21 @@ def _assert_forward_parity(o, h, out, exact=True):
 
 
 def _assert_grads(g, og, keys=("dL_dmeans2D", "dL_dopacity", "dL_dcolors", "dL_dmeans3D", "dL_dscales", "dL_drots")):
+    """Per ELEMENT: |hip - oracle| <= GRAD_RTOL * |oracle| + GRAD_ATOL * max|oracle| (of that tensor).  The kernel sums a
+    Gaussian's per-pixel terms in float32 in its own order (16-pixel cell sums, then cells), the oracle in upstream's
+    pixel order: the difference is rounding noise of the LARGEST terms of the sum, hence the absolute part."""
+    worst = {}
     for k in keys:
         a, b = g[k], og[k]
         assert a is not None and b is not None, k
         assert np.isfinite(a).all(), k
-        scale = np.abs(b).max() + 1e-20
-        assert np.abs(a - b.reshape(a.shape)).max() / scale < GRAD_RTOL, (k, np.abs(a - b.reshape(a.shape)).max() / scale)
+        b = b.reshape(a.shape)
+        bound = GRAD_RTOL * np.abs(b) + GRAD_ATOL * (np.abs(b).max() + 1e-30)
+        ratio = np.abs(a - b) / bound
+        worst[k] = float(ratio.max()) if ratio.size else 0.0
+        assert worst[k] <= 1.0, (k, worst[k], int(ratio.argmax()), a.reshape(-1)[ratio.argmax()], b.reshape(-1)[ratio.argmax()])
+    print("grad error / bound:", {k: round(v, 3) for k, v in worst.items()})
+    return worst
 
 
 @pytest.mark.parametrize("n,H,W,seed,lsm", [
@@ -372,3 +382,67 @@ def test_fused_six_channel_pass_equals_two_passes(crowded):
     _assert_grads(g, summed, keys=tuple(summed))
     _assert_grads({"a": g["dL_dcolors"][:, :3], "b": g["dL_dcolors"][:, 3:]},
                   {"a": g1["dL_dcolors"], "b": g2["dL_dcolors"]}, keys=("a", "b"))
+
+
+def test_one_shot_forward_with_alloc_callback():
+    """dm4d_rasterize_forward (include/dm4d.h): the entry in the shape of upstream's RasterizeGaussiansCUDA, which asks
+    the CALLER for its three workspaces through a callback (upstream's resize functors).  The callback here hands out
+    torch tensors; the result must be the staged path's, bit for bit, and the workspaces must serve the backward."""
+    _need_gpu()
+    import ctypes as C
+
+    from dreammesh4d_amd import _lib
+    from tests.hip_raster import HipRaster
+
+    sc = syn.random_splat_scene(6000, seed=12, log_scale_mean=math.log(0.02), log_scale_std=0.5)
+    cam = syn.make_camera(112, 144, elev_deg=20, azim_deg=75)
+    o = _oracle(sc, cam, (1, 1, 1), 1.0, colors_precomp=sc["colors"], scales=sc["scales"], rotations=sc["rotations"])
+    h = HipRaster(cam)
+    h.forward(sc["means3D"], sc["opacities"], colors=sc["colors"], scales=sc["scales"], rotations=sc["rotations"])
+    L, dev, st = h.L, h.dev, torch.cuda.current_stream(h.dev).cuda_stream
+    held, calls = {}, []
+
+    def alloc(ctx, which, nbytes):
+        calls.append((which, nbytes))
+        held[which] = torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=dev)
+        assert held[which].data_ptr() % 16 == 0
+        return held[which].data_ptr()
+
+    cb = _lib.ALLOC_FN(alloc)
+    color, depth, alpha = torch.empty(3, cam.H, cam.W, device=dev), torch.empty(cam.H, cam.W, device=dev), torch.empty(cam.H, cam.W, device=dev)
+    radii = torch.empty(h.N, dtype=torch.int32, device=dev)
+    D = _lib.check(L.dm4d_rasterize_forward(h.settings, h.inputs, color.data_ptr(), depth.data_ptr(), alpha.data_ptr(),
+                                            radii.data_ptr(), cb, None, st), "dm4d_rasterize_forward")
+    torch.cuda.synchronize()
+    assert D == o.D == h.D
+    assert [w for w, _ in calls] == [0, 1, 2]                       # geom, then (after the one sync) binning and image
+    assert calls[0][1] == L.dm4d_raster_geom_bytes(h.N, cam.H, cam.W) and calls[1][1] == L.dm4d_raster_binning_bytes(D)
+    assert np.array_equal(color.cpu().numpy().view(np.uint32), o.s["out_color"].view(np.uint32))
+    assert np.array_equal(depth.cpu().numpy().view(np.uint32), o.s["out_depth"].view(np.uint32))
+    assert np.array_equal(alpha.cpu().numpy().view(np.uint32), o.s["out_alpha"].view(np.uint32))
+    assert np.array_equal(radii.cpu().numpy(), o.s["radii"])
+    # the caller-owned workspaces feed the backward
+    h.geom, h.binning, h.image, h.radii, h.cap = held[0], held[1], held[2], radii, D
+    gC = np.random.default_rng(5).normal(size=(3, cam.H, cam.W)).astype(np.float32)
+    _assert_grads(h.backward(gC), o.backward(gC))
+    # a failing allocator is an error code, not a crash
+    bad = _lib.ALLOC_FN(lambda ctx, which, nbytes: None if which == 1 else held[which].data_ptr())
+    rc = L.dm4d_rasterize_forward(h.settings, h.inputs, color.data_ptr(), depth.data_ptr(), alpha.data_ptr(),
+                                  radii.data_ptr(), bad, None, st)
+    assert rc == -3 and b"alloc" in L.dm4d_last_error()
+
+
+def test_cfg5_one_million_gaussians_1024_oracle_parity():
+    """BASELINE configs[4] at the operator: 1,000,002 Gaussians at 1024^2 = 4096 tiles (44-bit keys upstream), 977
+    binning workgroups.  Full forward parity (keys, values, ranges, radii, n_contrib, final_T, image bit-identical) and
+    the gradient bar, against the oracle."""
+    _need_gpu()
+    sc = syn.random_splat_scene(1_000_002, seed=50, log_scale_mean=math.log(0.0025), log_scale_std=0.35)
+    cam = syn.make_camera(1024, 1024, elev_deg=25.0, azim_deg=130.0)
+    o, h, out = _both(sc, cam)
+    assert o.s["ranges"].shape[0] == 4096 and o.D > 2_000_000
+    _assert_forward_parity(o, h, out)
+    rng = np.random.default_rng(50)
+    gC = rng.normal(size=(3, 1024, 1024)).astype(np.float32)
+    gA = rng.normal(size=(1024, 1024)).astype(np.float32)
+    _assert_grads(h.backward(gC, None, gA), o.backward(gC, None, gA))
