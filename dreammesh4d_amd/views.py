@@ -88,11 +88,11 @@ class ViewRenderer:
         return ws["geom"].view(torch.int32).view(vs.B, per_view // 4)[:, :4]
 
     def overflow_flag(self):
-        """float32 [1] on the device: 1.0 if the last forward dropped duplicates or backward records, else 0.0 -- no host
+        """float32 scalar on the device: 1.0 if the last forward dropped duplicates or backward records, else 0.0 -- no host
         sync.  Training loops hand it to the fused AdamW as `found_inf` (the step is then skipped on the device, the way
         a GradScaler skips a step) and call poll() at their leisure."""
         c = self.counters_i32()
-        return ((c[:, 1] | c[:, 3]) != 0).any().to(torch.float32).reshape(1)
+        return ((c[:, 1] | c[:, 3]) != 0).any().to(torch.float32)
 
     def poll(self):
         """Sync-free capacity monitor: queues an async copy of the last forward's counters into pinned memory and looks at

@@ -137,6 +137,22 @@ class RasterOracle:
         return g
 
 
+    def preprocess_backward(self, rel_noise=0.0, seed=0):
+        """Stage 2 alone (conic / mean2D / depth / colour gradients -> parameter gradients) from the blend-level
+        gradients of the last backward(), each multiplied by (1 + rel_noise * N(0,1)) first.  Returns a new dict;
+        self.g is untouched."""
+        L = lib()
+        rng = np.random.default_rng(seed)
+        g = {k: (None if v is None else v.copy()) for k, v in self.g.items()}
+        if rel_noise:
+            for k in ("dL_dmeans2D", "dL_dconic", "dL_dcolors", "dL_ddepths"):
+                g[k] = (g[k] * (1.0 + rel_noise * rng.standard_normal(g[k].shape))).astype(np.float32)
+        gs = _Grads(*[_p(g[n]) for n, _ in _Grads._fields_])
+        if L.dm4d_oracle_preprocess_backward(C.byref(self._in), C.byref(self._st), C.byref(gs)) != 0:
+            raise RuntimeError("oracle preprocess backward failed")
+        return g
+
+
 def expf(x):
     L = lib()
     L.dm4d_oracle_expf.restype = C.c_float

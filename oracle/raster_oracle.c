@@ -627,6 +627,20 @@ int dm4d_oracle_rasterize_backward(const dm4d_oracle_in *in, const dm4d_oracle_s
     return 0;
 }
 
+/* Stage 2 of the backward alone: g->dL_dmeans2D, dL_dconic, dL_dcolors and dL_ddepths are INPUTS (as the blend stage
+ * left them, or perturbed by the caller), the per-parameter gradients are recomputed from them.  The parity tests use
+ * it to measure how much this ill-conditioned chain (conic -> cov2D -> cov3D -> scale / rotation) amplifies rounding
+ * noise of the blend-level sums on the scene at hand. */
+int dm4d_oracle_preprocess_backward(const dm4d_oracle_in *in, const dm4d_oracle_state *st, dm4d_oracle_grads *g)
+{
+    int N = in->N, W = in->W, H = in->H;
+    float fy = (float)H / (2.0f * in->tanfovy);
+    float fx = (float)W / (2.0f * in->tanfovx);
+#pragma omp parallel for schedule(static)
+    for (int i = 0; i < N; ++i) preprocess_backward_one(in, st, i, fx, fy, g);
+    return 0;
+}
+
 /* markVisible: view-space z > 0.2 */
 void dm4d_oracle_mark_visible(int N, const float *means3D, const float *viewmatrix, uint8_t *present)
 {

@@ -68,7 +68,7 @@ def _seeded_fill(module, base, scale=0.05):
     return seeded_fill(module, base, scale)
 
 
-@pytest.mark.parametrize("dtype,tol_unet,tol_enc", [(torch.float32, 2e-4, 2e-4), (torch.float16, 2e-2, 2e-2)])
+@pytest.mark.parametrize("dtype,tol_unet,tol_enc", [(torch.float32, 5e-5, 5e-5), (torch.float16, 2e-2, 2e-2)])
 def test_zero123_mirror_on_device_vs_reference_golden(dtype, tol_unet, tol_enc):
     """tol = max |y - y_ref| / max |y_ref| (the reference values are fp32 on CPU).  fp32: MIOpen / rocBLAS pick other
     algorithms and summation orders than the CPU; fp16: 10-bit mantissa through ~60 conv / attention layers."""

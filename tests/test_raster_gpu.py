@@ -73,20 +73,50 @@ def _assert_forward_parity(o, h, out, exact=True):
         assert np.array_equal(alpha.view(np.uint32), o.s["out_alpha"].view(np.uint32))
 
 
-def _assert_grads(g, og, keys=("dL_dmeans2D", "dL_dopacity", "dL_dcolors", "dL_dmeans3D", "dL_dscales", "dL_drots")):
-    """Per ELEMENT: |hip - oracle| <= GRAD_RTOL * |oracle| + GRAD_ATOL * max|oracle| (of that tensor).  The kernel sums a
-    Gaussian's per-pixel terms in float32 in its own order (16-pixel cell sums, then cells), the oracle in upstream's
-    pixel order: the difference is rounding noise of the LARGEST terms of the sum, hence the absolute part."""
+BLEND_KEYS = ("dL_dmeans2D", "dL_dopacity", "dL_dcolors")          # sums of per-pixel terms, straight out of the blend backward
+DERIVED_KEYS = ("dL_dmeans3D", "dL_dscales", "dL_drots", "dL_dcov3D", "dL_dsh")   # pushed through the preprocess backward
+NOISE = 2e-6       # relative rounding noise of a float32 blend-level sum (what GRAD_RTOL / GRAD_ATOL admit is larger)
+
+
+def _assert_grads(g, og, keys=("dL_dmeans2D", "dL_dopacity", "dL_dcolors", "dL_dmeans3D", "dL_dscales", "dL_drots"), o=None):
+    """Per ELEMENT: |hip - oracle| <= GRAD_RTOL * |oracle| + GRAD_ATOL * max|oracle| (of that tensor) [+ 8 * sens].
+
+    Blend-level gradients (means2D, opacity, colours): the kernel sums a Gaussian's per-pixel terms in float32 in its own
+    order (16-pixel cell sums, then cells), the oracle accumulates them in double in upstream's pixel order; the
+    difference is rounding noise of the largest terms of the sum, hence the absolute part.
+    Derived gradients (means3D, scales, rotations, cov3D): the preprocess backward is ill-conditioned for the thin
+    mesh-bound splats (scale 3.8e-6 along the normal, conic -> cov2D -> cov3D -> scale / rotation), so identical code
+    fed with blend-level sums that differ in the last bits gives visibly different results.  `sens` measures exactly
+    that ON THE ORACLE: its own stage 2 re-run with its blend-level gradients perturbed by NOISE (relative, two seeds);
+    the bar then admits 8 x the larger response.  Requires `o` (the RasterOracle whose backward() produced `og`)."""
     worst = {}
+    sens = {}
+    if o is not None and any(k in DERIVED_KEYS for k in keys):
+        for oi in (o if isinstance(o, (list, tuple)) else [o]):      # several oracles: `og` is the SUM of their gradients
+            base = oi.preprocess_backward(0.0)
+            if oi is o:
+                for k in keys:
+                    if k in DERIVED_KEYS and og.get(k) is not None:
+                        assert np.array_equal(base[k], og[k]), k               # stage 2 alone reproduces the full backward
+            p1, p2 = oi.preprocess_backward(NOISE, seed=1), oi.preprocess_backward(NOISE, seed=2)
+            for k in keys:
+                if k in DERIVED_KEYS and base.get(k) is not None:
+                    sens[k] = sens.get(k, 0.0) + np.maximum(np.abs(p1[k] - base[k]), np.abs(p2[k] - base[k]))
     for k in keys:
         a, b = g[k], og[k]
         assert a is not None and b is not None, k
         assert np.isfinite(a).all(), k
         b = b.reshape(a.shape)
         bound = GRAD_RTOL * np.abs(b) + GRAD_ATOL * (np.abs(b).max() + 1e-30)
+        if k in DERIVED_KEYS:
+            assert k in sens, f"{k}: derived gradients need the oracle object (o=...) for the conditioning term"
+            # a Gaussian's sensitivity is a property of the Gaussian: use the largest response over its components
+            s_ = sens[k].reshape(a.shape[0], -1).max(axis=1)
+            bound = bound + 8.0 * s_.reshape((-1,) + (1,) * (a.ndim - 1))
         ratio = np.abs(a - b) / bound
         worst[k] = float(ratio.max()) if ratio.size else 0.0
-        assert worst[k] <= 1.0, (k, worst[k], int(ratio.argmax()), a.reshape(-1)[ratio.argmax()], b.reshape(-1)[ratio.argmax()])
+        i = int(ratio.argmax()) if ratio.size else 0
+        assert worst[k] <= 1.0, (k, worst[k], i, a.reshape(-1)[i], b.reshape(-1)[i])
     print("grad error / bound:", {k: round(v, 3) for k, v in worst.items()})
     return worst
 
@@ -108,7 +138,7 @@ def test_forward_backward_parity(n, H, W, seed, lsm):
     gA = rng.normal(size=(H, W)).astype(np.float32)
     og = o.backward(gC, gD, gA)
     g = h.backward(gC, gD, gA)
-    _assert_grads(g, og)
+    _assert_grads(g, og, o=o)
     g2 = h.backward(gC, gD, gA)   # deterministic: no float atomics anywhere
     for k in g:
         if g[k] is not None:
@@ -124,7 +154,7 @@ def test_sh_degree0_path_and_null_grads():
     gC = np.random.default_rng(0).normal(size=(3, 96, 96)).astype(np.float32)
     og = o.backward(gC, None, None)
     g = h.backward(gC, None, None)
-    _assert_grads(g, og, keys=("dL_dmeans2D", "dL_dopacity", "dL_dmeans3D", "dL_dscales", "dL_drots", "dL_dsh"))
+    _assert_grads(g, og, keys=("dL_dmeans2D", "dL_dopacity", "dL_dmeans3D", "dL_dscales", "dL_drots", "dL_dsh"), o=o)
     assert (o.s["clamped"].sum() > 0)
 
 
@@ -144,7 +174,7 @@ def test_cov3d_precomp_path():
     gC = np.random.default_rng(1).normal(size=(3, 80, 64)).astype(np.float32)
     og = o.backward(gC)
     g = h.backward(gC)
-    _assert_grads(g, og, keys=("dL_dmeans2D", "dL_dopacity", "dL_dcolors", "dL_dmeans3D", "dL_dcov3D"))
+    _assert_grads(g, og, keys=("dL_dmeans2D", "dL_dopacity", "dL_dcolors", "dL_dmeans3D", "dL_dcov3D"), o=o)
 
 
 def test_edge_cases_empty_and_culled():
@@ -190,7 +220,7 @@ def test_oversized_tile_uses_global_sort_path():
     assert (o.s["ranges"][:, 1].astype(np.int64) - o.s["ranges"][:, 0]).max() > 4096
     _assert_forward_parity(o, h, out)
     gC = rng.normal(size=(3, 64, 64)).astype(np.float32)
-    _assert_grads(h.backward(gC), o.backward(gC))
+    _assert_grads(h.backward(gC), o.backward(gC), o=o)
 
 
 @pytest.mark.parametrize("n", [1500, 5000])
@@ -215,7 +245,7 @@ def test_deep_translucent_stack_long_cells(n):
     gD = rng.normal(size=(64, 64)).astype(np.float32)
     gA = rng.normal(size=(64, 64)).astype(np.float32)
     g = h.backward(gC, gD, gA)
-    _assert_grads(g, o.backward(gC, gD, gA))
+    _assert_grads(g, o.backward(gC, gD, gA), o=o)
     g2 = h.backward(gC, gD, gA)
     for k in g:
         if g[k] is not None:
@@ -244,7 +274,7 @@ def test_giant_splat_covers_every_tile():
     assert o.s["tiles_touched"][0] == 8 * 6
     _assert_forward_parity(o, h, out)
     gC = np.random.default_rng(2).normal(size=(3, 128, 96)).astype(np.float32)
-    _assert_grads(h.backward(gC), o.backward(gC))
+    _assert_grads(h.backward(gC), o.backward(gC), o=o)
 
 
 def test_capacity_overflow_is_flagged_not_fatal():
@@ -274,7 +304,7 @@ def test_full_size_200k_512():
     gC = rng.normal(size=(3, 512, 512)).astype(np.float32)
     gD = rng.normal(size=(512, 512)).astype(np.float32) * 0.1
     gA = rng.normal(size=(512, 512)).astype(np.float32)
-    _assert_grads(h.backward(gC, gD, gA), o.backward(gC, gD, gA))
+    _assert_grads(h.backward(gC, gD, gA), o.backward(gC, gD, gA), o=o)
 
 
 def test_autograd_operator_matches_oracle():
@@ -312,7 +342,7 @@ def test_autograd_operator_matches_oracle():
     got = {"dL_dmeans2D": m2.grad.cpu().numpy(), "dL_dopacity": op.grad.cpu().numpy()[:, 0],
            "dL_dcolors": col.grad.cpu().numpy(), "dL_dmeans3D": m3.grad.cpu().numpy(),
            "dL_dscales": scl.grad.cpu().numpy(), "dL_drots": rot.grad.cpu().numpy()}
-    _assert_grads(got, og)
+    _assert_grads(got, og, o=o)
     vis = rast.markVisible(m3)
     assert vis.dtype == torch.bool and bool(vis.all())
 
@@ -333,7 +363,7 @@ def test_record_count_matches_the_cell_blocks():
                   rs.randn(128, 128).astype(np.float32))
     og = o.backward(gC, gD, gA)
     g1 = h.backward(gC, gD, gA)
-    _assert_grads(g1, og)
+    _assert_grads(g1, og, o=o)
     g2 = h.backward(gC, gD, gA, record_capacity=h.R + 1000)
     for k in g1:
         if g1[k] is not None:
@@ -379,7 +409,7 @@ def test_fused_six_channel_pass_equals_two_passes(crowded):
     g1, g2 = o1.backward(gC, gD, gA), o2.backward(gN, None, None)
     g = h.backward(np.concatenate([gC, gN]), gD, gA)
     summed = {k: g1[k] + g2[k] for k in ("dL_dmeans2D", "dL_dopacity", "dL_dmeans3D", "dL_dscales", "dL_drots")}
-    _assert_grads(g, summed, keys=tuple(summed))
+    _assert_grads(g, summed, keys=tuple(summed), o=[o1, o2])
     _assert_grads({"a": g["dL_dcolors"][:, :3], "b": g["dL_dcolors"][:, 3:]},
                   {"a": g1["dL_dcolors"], "b": g2["dL_dcolors"]}, keys=("a", "b"))
 
@@ -424,7 +454,7 @@ def test_one_shot_forward_with_alloc_callback():
     # the caller-owned workspaces feed the backward
     h.geom, h.binning, h.image, h.radii, h.cap = held[0], held[1], held[2], radii, D
     gC = np.random.default_rng(5).normal(size=(3, cam.H, cam.W)).astype(np.float32)
-    _assert_grads(h.backward(gC), o.backward(gC))
+    _assert_grads(h.backward(gC), o.backward(gC), o=o)
     # a failing allocator is an error code, not a crash
     bad = _lib.ALLOC_FN(lambda ctx, which, nbytes: None if which == 1 else held[which].data_ptr())
     rc = L.dm4d_rasterize_forward(h.settings, h.inputs, color.data_ptr(), depth.data_ptr(), alpha.data_ptr(),
@@ -445,4 +475,4 @@ def test_cfg5_one_million_gaussians_1024_oracle_parity():
     rng = np.random.default_rng(50)
     gC = rng.normal(size=(3, 1024, 1024)).astype(np.float32)
     gA = rng.normal(size=(1024, 1024)).astype(np.float32)
-    _assert_grads(h.backward(gC, None, gA), o.backward(gC, None, gA))
+    _assert_grads(h.backward(gC, None, gA), o.backward(gC, None, gA), o=o)
