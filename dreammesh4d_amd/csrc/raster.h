@@ -50,6 +50,12 @@ enum GeomCounter { kCntD = 0, kCntOverflow = 1, kCntR = 2, kCntRecOverflow = 3, 
 // the regular kernels and blended by k_render_{fwd,bwd}_long: one wave per cell, its four rows evaluating four
 // CONSECUTIVE entries of the one list for the same 16 pixels, the sequential transmittance chain run by row 0.
 constexpr uint32_t kLongCell = 384;
+// The entry-parallel backward gives cells with at least this many entries a whole wave (64 entries per step) instead
+// of a DPP row (16 per step): `longlist` holds them.
+#ifndef DM4D_WIDE_BWD
+#define DM4D_WIDE_BWD 128
+#endif
+constexpr uint32_t kWideBwd = DM4D_WIDE_BWD;
 
 DM4D_HD static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 

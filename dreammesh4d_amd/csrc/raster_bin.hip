@@ -234,7 +234,7 @@ __device__ __forceinline__ void finish_tile(const ViewCtx &c, int tile, uint32_t
         // The backward takes all of them (longlist); the forward only those of the tiles THIS, the large, variant
         // sorts: it finishes long before the small variant, so their forward starts that much earlier.
         const bool is_long = s_cbase[tid] >= kLongCell, early = is_long && kSortThreads == kSortLarge;
-        if (is_long) g.longlist[atomicAdd(&g.counters[kCntLong], 1u)] = (uint32_t)(tile * kCells + tid);
+        if (s_cbase[tid] >= kWideBwd) g.longlist[atomicAdd(&g.counters[kCntLong], 1u)] = (uint32_t)(tile * kCells + tid);
         if (early) g.earlylist[atomicAdd(&g.counters[kCntLongEarly], 1u)] = (uint32_t)(tile * kCells + tid);
         g.cflag[tile * kCells + tid] = early ? 1u : 0u;
     }

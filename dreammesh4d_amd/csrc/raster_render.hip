@@ -65,7 +65,7 @@ int set_trace_buffer(void *dev_ptr, uint32_t min_work)
 typedef float f2v __attribute__((ext_vector_type(2)));
 typedef float f4v __attribute__((ext_vector_type(4)));
 constexpr int kChunk = 16;   // list entries a row stages per step (one per lane of the row)
-constexpr int kFwdPairs = 2, kBwdPairs = 1;   // PAIRS of entries per inner-loop step
+constexpr int kFwdPairs = 2;   // PAIRS of entries per inner-loop step of the forward
 
 // LDS layout of a staged chunk: one 32-float block per PAIR of consecutive list entries (j even, j + 1),
 // geometry interleaved across the two entries so that a ds_read_b128 delivers register pairs the packed
@@ -455,281 +455,383 @@ __global__ __launch_bounds__(256) void k_render_fwd_long(BatchDesc d)
 }
 
 // ---------------------------------------------------------------------------------------- B1
-// r[i] (lanes 0..7 of every row) = v[i] + v[i] of lane l + 8; lanes 8..15 keep r[i].  One instruction per value
-// (v_add_f32 with a bank-masked row rotation), which the compiler cannot form from update_dpp + add.  s_nop: a DPP read
-// of a VGPR needs 2 wait states after the VALU write of it (inline asm is opaque to the hazard recogniser).
-#define DM4D_DPPADD(O, I) "v_add_f32_dpp %" O ", %" I ", %" I " row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
-template <int RS>
-__device__ __forceinline__ void pair_sum_low_half(float (&r)[RS], const float (&v)[13])
+// ENTRY-PARALLEL blend backward.  A lane owns one LIST ENTRY (a Gaussian of a 4x4-pixel cell's depth-sorted list) and walks
+// the cell's 16 pixels serially, so the 16-pixel sums of an entry's gradient values are plain FMAs into the lane's own
+// registers: no cross-lane reduction per value, no LDS, and the lane ends up holding the entry's complete
+// (Gaussian, cell) record.  What IS sequential along the list -- the transmittance in front of an entry and the
+// colour sum behind it -- becomes two scans ACROSS LANES per pixel (DPP row shifts: on the VALU, no LDS):
+//     P_inc(l) = prod_{i behind or at l} (1 - alpha_i)      T_before(l) = T_behind_chunk / P_inc(l)
+//     S_exc(l) = sum_{i behind l} V_i w_i                   dL/dalpha_l = T_before V_l - (S_exc + S_behind_chunk) / (1 - alpha_l)
+// with the per-pixel carries (T, S behind the chunk) handed from chunk to chunk, back to front.  The per-pixel
+// quantities an iteration needs (upstream gradients, n_contrib, the carries) live in the lane that owns that pixel
+// (lane p of the row holds pixel p) and reach the other lanes as DPP `row_newbcast:p` operands of the VOP2
+// instructions that consume them -- a broadcast costs no instruction.
+//   regular blocks: wave = 8x8 quadrant, DPP row = cell, lane = entry of a 16-entry chunk of the row's list;
+//   wide blocks:    wave = ONE cell with a long list (>= kWideBwd entries, K4's `longlist`), lane = entry of a
+//                   64-entry chunk; the scans cross the rows with row_bcast:15 / :31.  A 1200-entry silhouette cell is
+//                   19 chunks instead of 75, and the launch no longer ends with it.
+// Lanes hold the chunk REVERSED (lane 0 = the entry farthest back), so "behind" = lower lanes and the scans are the
+// plain prefix scans row_shr / row_bcast were made for.
+// The record a lane writes is what B2 (k_gather_bwd) expects: moments sum q (dx, dy, dx^2, dx dy, dy^2), q = dL/dG G
+// (dL/dmean2D and dL/dconic are linear maps of them, applied once per Gaussian in B2), dL/dopacity, dL/ddepth, dL/dcolour.
+// Deterministic: fixed order everywhere, no atomics.
+#define DM4D_RM " row_mask:0xf bank_mask:0xf\n\t"
+template <int P>
+__device__ __forceinline__ float row_bcast(float v)   // lane P of the row, in every lane of the row
 {
-    static_assert(RS == 9 || RS == 10 || RS == 13, "record sizes of grad_stride()");
-    if constexpr (RS == 9) {
-        asm volatile("s_nop 1\n\t" DM4D_DPPADD("0", "9") DM4D_DPPADD("1", "10") DM4D_DPPADD("2", "11") DM4D_DPPADD("3", "12") DM4D_DPPADD("4", "13") DM4D_DPPADD("5", "14") DM4D_DPPADD("6", "15") DM4D_DPPADD("7", "16") DM4D_DPPADD("8", "17")
-                     : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]), "+v"(r[6]), "+v"(r[7]), "+v"(r[8])
-                     : "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "v"(v[4]), "v"(v[5]), "v"(v[6]), "v"(v[7]), "v"(v[8]));
-    } else if constexpr (RS == 10) {
-        asm volatile("s_nop 1\n\t" DM4D_DPPADD("0", "10") DM4D_DPPADD("1", "11") DM4D_DPPADD("2", "12") DM4D_DPPADD("3", "13") DM4D_DPPADD("4", "14") DM4D_DPPADD("5", "15") DM4D_DPPADD("6", "16") DM4D_DPPADD("7", "17") DM4D_DPPADD("8", "18") DM4D_DPPADD("9", "19")
-                     : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]), "+v"(r[6]), "+v"(r[7]), "+v"(r[8]), "+v"(r[9])
-                     : "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "v"(v[4]), "v"(v[5]), "v"(v[6]), "v"(v[7]), "v"(v[8]), "v"(v[9]));
-    } else {
-        asm volatile("s_nop 1\n\t" DM4D_DPPADD("0", "13") DM4D_DPPADD("1", "14") DM4D_DPPADD("2", "15") DM4D_DPPADD("3", "16") DM4D_DPPADD("4", "17") DM4D_DPPADD("5", "18") DM4D_DPPADD("6", "19") DM4D_DPPADD("7", "20") DM4D_DPPADD("8", "21") DM4D_DPPADD("9", "22") DM4D_DPPADD("10", "23") DM4D_DPPADD("11", "24") DM4D_DPPADD("12", "25")
-                     : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]), "+v"(r[6]), "+v"(r[7]), "+v"(r[8]), "+v"(r[9]), "+v"(r[10]), "+v"(r[11]), "+v"(r[12])
-                     : "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "v"(v[4]), "v"(v[5]), "v"(v[6]), "v"(v[7]), "v"(v[8]), "v"(v[9]), "v"(v[10]), "v"(v[11]), "v"(v[12]));
-    }
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x150 + P, 0xf, 0xf, true));
 }
-#undef DM4D_DPPADD
-constexpr int kRedStride = 68;   // floats per value row of the transposed reduction buffer (64 lanes + pad)
-constexpr int kRedHalf = 36;     // the same with 8 lanes per row (32 + pad)
+// inclusive prefix scans over the lanes of a row (WIDE: of the wave) of two independent values at once: the two chains
+// are interleaved so that a DPP read of a freshly written VGPR has its two wait states (inline asm is opaque to the
+// compiler's hazard recogniser; the leading s_nop covers the producer of the inputs)
+// a, b: in place; ea, eb (preset to the identity by the caller): the same scans EXCLUSIVE (the value of the lane below;
+// the first lane of the row / wave keeps the identity)
+#define DM4D_SCAN2(OP, SHIFT, BC)                                                                                                  \
+    asm volatile("s_nop 1\n\t"                                                                                                     \
+                 OP " %0, %0, %0 row_shr:1" DM4D_RM OP " %1, %1, %1 row_shr:1" DM4D_RM "s_nop 0\n\t"                               \
+                 OP " %0, %0, %0 row_shr:2" DM4D_RM OP " %1, %1, %1 row_shr:2" DM4D_RM "s_nop 0\n\t"                               \
+                 OP " %0, %0, %0 row_shr:4" DM4D_RM OP " %1, %1, %1 row_shr:4" DM4D_RM "s_nop 0\n\t"                               \
+                 OP " %0, %0, %0 row_shr:8" DM4D_RM OP " %1, %1, %1 row_shr:8" DM4D_RM "s_nop 0\n\t"                               \
+                 BC                                                                                                                \
+                 "v_mov_b32_dpp %2, %0 " SHIFT DM4D_RM "v_mov_b32_dpp %3, %1 " SHIFT DM4D_RM "s_nop 1\n\t"                        \
+                 : "+v"(a), "+v"(b), "+v"(ea), "+v"(eb))
+#define DM4D_BC(OP)                                                                                                                \
+    OP " %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t" OP " %1, %1, %1 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"     \
+    "s_nop 0\n\t"                                                                                                                  \
+    OP " %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t" OP " %1, %1, %1 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"     \
+    "s_nop 0\n\t"
+template <bool WIDE>
+__device__ __forceinline__ void scan2_mul(float &a, float &b, float &ea, float &eb)
+{
+    if (WIDE) DM4D_SCAN2("v_mul_f32_dpp", "wave_shr:1", DM4D_BC("v_mul_f32_dpp"));
+    else DM4D_SCAN2("v_mul_f32_dpp", "row_shr:1", "");
+}
+template <bool WIDE>
+__device__ __forceinline__ void scan2_add(float &a, float &b, float &ea, float &eb)
+{
+    if (WIDE) DM4D_SCAN2("v_add_f32_dpp", "wave_shr:1", DM4D_BC("v_add_f32_dpp"));
+    else DM4D_SCAN2("v_add_f32_dpp", "row_shr:1", "");
+}
+#undef DM4D_SCAN2
+#undef DM4D_BC
 
-// LDS of one wave of the backward kernel (floats): the regular blocks' staging rows + record slots + reduction
-// buffer, or the long-cell blocks' chunk + slots + reduction buffer -- the two kinds of block share one launch.
-template <int C, bool LEAN>
-struct BwdSmem {
-    static constexpr int RS = LEAN ? 9 : 7 + C;
-    static constexpr int U = 2 * kBwdPairs;
-    static constexpr int regular = 4 * kRowFloats + 4 * kChunk + U * RS * kRedHalf;
-    static constexpr int longc = 64 * 16 + 64 + RS * kRedStride;
-    static constexpr int floats = regular > longc ? regular : longc;
+// per-pixel state of the backward, held by the lane that owns the pixel (lane p of every row: pixel p of the row's cell)
+template <int C>
+struct PixelRegs {
+    float last;      // n_contrib as float bits of the uint (compared as uint)
+    float T, S;      // carries: transmittance behind the current chunk, sum V w behind it + T_final bg.g
+    float g[C];      // dL/dcolour
+    float gD, gA;
+};
+// one list entry, held by the lane that owns it
+template <int C>
+struct EntryRegs {
+    float dx[4], dy[4];          // x - (cell x0 + i), y - (cell y0 + j): bit-identical to the forward's xy - pixf
+    float Adx2[4], Cdy2[4], Bdx[4];
+    float o, dep;
+    float c[C];
+    uint32_t k;
 };
 
-template <int C, bool LEAN>
-__device__ __forceinline__ void render_bwd_cells(const BatchDesc &d, const uint32_t bid, float *smem)
+// V of the lane's entry at pixel P = gA + sum_ch colour_ch g_ch + depth gD, with the pixel's values broadcast from lane P
+template <int C, int P>
+__device__ __forceinline__ float entry_V(const EntryRegs<C> &e, const PixelRegs<C> &px)
 {
-    constexpr int RS = LEAN ? 9 : 7 + C;              // values per record
-    constexpr int RSP = (C <= 3 || LEAN) ? 12 : 16;   // == grad_stride(C, LEAN): floats per (padded) record
-    constexpr int U = 2 * kBwdPairs;          // entries per inner-loop step
-    float *s_p = smem;                                                                       // [4 * kRowFloats]
-    uint32_t (*s_slot)[kChunk] = reinterpret_cast<uint32_t (*)[kChunk]>(smem + 4 * kRowFloats);   // [4][kChunk]
-    // reduction buffer: lanes l and l + 8 of a row are added with one DPP row rotation first, so only 8 lanes per
-    // row go through LDS (half the reduction's LDS bytes, and 2.4 KB less LDS per wave: 16 -> 20 waves per CU)
-    float (*s_red)[RS][kRedHalf] = reinterpret_cast<float (*)[RS][kRedHalf]>(smem + 4 * kRowFloats + 4 * kChunk);   // [U]
+    float V;
+    if constexpr (C == 6) {
+        asm("v_mov_b32_dpp %0, %1 row_newbcast:%15" DM4D_RM
+            "v_fmac_f32_dpp %0, %2, %9 row_newbcast:%15" DM4D_RM "v_fmac_f32_dpp %0, %3, %10 row_newbcast:%15" DM4D_RM
+            "v_fmac_f32_dpp %0, %4, %11 row_newbcast:%15" DM4D_RM "v_fmac_f32_dpp %0, %5, %12 row_newbcast:%15" DM4D_RM
+            "v_fmac_f32_dpp %0, %6, %13 row_newbcast:%15" DM4D_RM "v_fmac_f32_dpp %0, %7, %14 row_newbcast:%15" DM4D_RM
+            "v_fmac_f32_dpp %0, %8, %16 row_newbcast:%15" DM4D_RM
+            : "=&v"(V)
+            : "v"(px.gA), "v"(px.g[0]), "v"(px.g[1]), "v"(px.g[2]), "v"(px.g[C > 3 ? 3 : 0]), "v"(px.g[C > 3 ? 4 : 0]), "v"(px.g[C > 3 ? 5 : 0]), "v"(px.gD),
+              "v"(e.c[0]), "v"(e.c[1]), "v"(e.c[2]), "v"(e.c[C > 3 ? 3 : 0]), "v"(e.c[C > 3 ? 4 : 0]), "v"(e.c[C > 3 ? 5 : 0]), "n"(P), "v"(e.dep));
+    } else {
+        asm("v_mov_b32_dpp %0, %1 row_newbcast:%9" DM4D_RM
+            "v_fmac_f32_dpp %0, %2, %6 row_newbcast:%9" DM4D_RM "v_fmac_f32_dpp %0, %3, %7 row_newbcast:%9" DM4D_RM
+            "v_fmac_f32_dpp %0, %4, %8 row_newbcast:%9" DM4D_RM "v_fmac_f32_dpp %0, %5, %10 row_newbcast:%9" DM4D_RM
+            : "=&v"(V)
+            : "v"(px.gA), "v"(px.g[0]), "v"(px.g[1]), "v"(px.g[2]), "v"(px.gD), "v"(e.c[0]), "v"(e.c[1]), "v"(e.c[2]), "n"(P), "v"(e.dep));
+    }
+    return V;
+}
+// acc += (lane P's g) * w
+template <int P>
+__device__ __forceinline__ void fmac_bcast(float &acc, float g, float w)
+{
+    asm("v_fmac_f32_dpp %0, %1, %2 row_newbcast:%3" DM4D_RM : "+v"(acc) : "v"(g), "v"(w), "n"(P));
+}
+template <int P>
+__device__ __forceinline__ float mul_bcast(float g, float x)     // (lane P's g) * x
+{
+    float r;
+    asm("v_mul_f32_dpp %0, %1, %2 row_newbcast:%3" DM4D_RM : "=v"(r) : "v"(g), "v"(x), "n"(P));
+    return r;
+}
+template <int P>
+__device__ __forceinline__ float add_bcast(float g, float x)     // (lane P's g) + x
+{
+    float r;
+    asm("v_add_f32_dpp %0, %1, %2 row_newbcast:%3" DM4D_RM : "=v"(r) : "v"(g), "v"(x), "n"(P));
+    return r;
+}
+
+// Pixels P and P + 1 of the cell for the lane's entry (two independent chains side by side: the dependent DPP steps of
+// one hide behind the other).  acc: the lane's record.  carry: LDS [16][2] of this row (WIDE: of the wave), written
+// by the lane that holds the chunk's FRONT entry: the carries the chunk in front starts from.
+template <int C, bool LEAN, bool WIDE, int P>
+__device__ __forceinline__ void pixel_pair(const EntryRegs<C> &e, const PixelRegs<C> &px, float (&acc)[13], const bool front_lane,
+                                           float2 *carry)
+{
+    float pw[2], G[2], a[2], Gm[2], om[2], Pinc[2], Pexc[2], V[2], Tb[2], inv_om[2], w[2], Sinc[2], Sexc[2], Stot[2];
+    bool contrib[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        constexpr int dummy = 0; (void)dummy;
+        const int i = (P + h) & 3, j = (P + h) >> 2;
+        const float u = e.Adx2[i] + e.Cdy2[j];
+        const float wv = e.Bdx[i] * e.dy[j];
+        pw[h] = __builtin_fmaf(-0.5f, u, -wv);      // == (-0.5f * u) - wv of the forward: the product by -0.5 is exact
+    }
+    det_expf_n<2>(pw, G);
+    {
+        const uint32_t l0 = __float_as_uint(row_bcast<P>(px.last)), l1 = __float_as_uint(row_bcast<P + 1>(px.last));
+        const float ar0 = fminf(0.99f, e.o * G[0]), ar1 = fminf(0.99f, e.o * G[1]);
+        contrib[0] = (e.k < l0) & (pw[0] <= 0.0f) & (ar0 >= 1.0f / 255.0f);
+        contrib[1] = (e.k < l1) & (pw[1] <= 0.0f) & (ar1 >= 1.0f / 255.0f);
+        a[0] = contrib[0] ? ar0 : 0.f; a[1] = contrib[1] ? ar1 : 0.f;
+        Gm[0] = contrib[0] ? G[0] : 0.f; Gm[1] = contrib[1] ? G[1] : 0.f;
+    }
+    om[0] = 1.f - a[0]; om[1] = 1.f - a[1];
+    Pinc[0] = om[0]; Pinc[1] = om[1];
+    Pexc[0] = Pexc[1] = 1.0f;
+    scan2_mul<WIDE>(Pinc[0], Pinc[1], Pexc[0], Pexc[1]);     // product over the entries behind, this one included / excluded
+    V[0] = entry_V<C, P>(e, px);
+    V[1] = entry_V<C, P + 1>(e, px);
+    const float R0 = __builtin_amdgcn_rcpf(Pinc[0]), R1 = __builtin_amdgcn_rcpf(Pinc[1]);
+    Tb[0] = mul_bcast<P>(px.T, R0);                          // transmittance in front of the entry
+    Tb[1] = mul_bcast<P + 1>(px.T, R1);
+    inv_om[0] = Pexc[0] * R0; inv_om[1] = Pexc[1] * R1;      // 1 / (1 - alpha)
+    w[0] = a[0] * Tb[0]; w[1] = a[1] * Tb[1];
+    Sinc[0] = V[0] * w[0]; Sinc[1] = V[1] * w[1];
+    Sexc[0] = Sexc[1] = 0.0f;
+    scan2_add<WIDE>(Sinc[0], Sinc[1], Sexc[0], Sexc[1]);
+    Stot[0] = add_bcast<P>(px.S, Sexc[0]);                   // everything behind the entry
+    Stot[1] = add_bcast<P + 1>(px.S, Sexc[1]);
+    if (front_lane) {      // what the chunk in front starts from, relative to this chunk's carries: T *= x, S += y
+        carry[P] = make_float2(R0, Sinc[0]);
+        carry[P + 1] = make_float2(R1, Sinc[1]);
+    }
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int i = (P + h) & 3, j = (P + h) >> 2;
+        const float dL_da = Tb[h] * V[h] - Stot[h] * inv_om[h];
+        const float q = (e.o * dL_da) * Gm[h];
+        const float qx = q * e.dx[i], qy = q * e.dy[j];
+        acc[0] += qx; acc[1] += qy;
+        acc[2] = __builtin_fmaf(qx, e.dx[i], acc[2]);
+        acc[3] = __builtin_fmaf(qx, e.dy[j], acc[3]);
+        acc[4] = __builtin_fmaf(qy, e.dy[j], acc[4]);
+        if (!LEAN) acc[5] = __builtin_fmaf(Gm[h], dL_da, acc[5]);
+    }
+    // w g_ch sums: the pixel's gradients straight from lane P / P + 1
+    if constexpr (LEAN) {
+        fmac_bcast<P>(acc[5], px.gD, w[0]); fmac_bcast<P + 1>(acc[5], px.gD, w[1]);
+        fmac_bcast<P>(acc[6], px.g[C > 3 ? 3 : 0], w[0]); fmac_bcast<P + 1>(acc[6], px.g[C > 3 ? 3 : 0], w[1]);
+        fmac_bcast<P>(acc[7], px.g[C > 3 ? 4 : 0], w[0]); fmac_bcast<P + 1>(acc[7], px.g[C > 3 ? 4 : 0], w[1]);
+        fmac_bcast<P>(acc[8], px.g[C > 3 ? 5 : 0], w[0]); fmac_bcast<P + 1>(acc[8], px.g[C > 3 ? 5 : 0], w[1]);
+    } else {
+        fmac_bcast<P>(acc[6], px.gD, w[0]); fmac_bcast<P + 1>(acc[6], px.gD, w[1]);
+#pragma unroll
+        for (int ch = 0; ch < C; ++ch) { fmac_bcast<P>(acc[7 + ch], px.g[ch], w[0]); fmac_bcast<P + 1>(acc[7 + ch], px.g[ch], w[1]); }
+    }
+    // pin the pair's accumulations HERE: volatile asm statements keep their order, so without this the compiler sinks the
+    // tails of all eight pairs below the last scan (they only feed `acc`) and keeps ~8 values per pair alive until then
+    // (147 VGPRs instead of ~100)
+    asm volatile("" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]), "+v"(acc[4]), "+v"(acc[5]), "+v"(acc[6]), "+v"(acc[7]), "+v"(acc[8]));
+    if (!LEAN) asm volatile("" : "+v"(acc[9]), "+v"(acc[C > 3 ? 10 : 9]), "+v"(acc[C > 3 ? 11 : 9]), "+v"(acc[C > 3 ? 12 : 9]));
+}
+#undef DM4D_RM
+
+// the 16 pixels of the cell for the lane's entry
+template <int C, bool LEAN, bool WIDE>
+__device__ __forceinline__ void cell_pixels(const EntryRegs<C> &e, const PixelRegs<C> &px, float (&acc)[13], const bool front_lane, float2 *carry)
+{
+    pixel_pair<C, LEAN, WIDE, 0>(e, px, acc, front_lane, carry);
+    pixel_pair<C, LEAN, WIDE, 2>(e, px, acc, front_lane, carry);
+    pixel_pair<C, LEAN, WIDE, 4>(e, px, acc, front_lane, carry);
+    pixel_pair<C, LEAN, WIDE, 6>(e, px, acc, front_lane, carry);
+    pixel_pair<C, LEAN, WIDE, 8>(e, px, acc, front_lane, carry);
+    pixel_pair<C, LEAN, WIDE, 10>(e, px, acc, front_lane, carry);
+    pixel_pair<C, LEAN, WIDE, 12>(e, px, acc, front_lane, carry);
+    pixel_pair<C, LEAN, WIDE, 14>(e, px, acc, front_lane, carry);
+}
+
+// gather the lane's entry (list position j of the cell list; `live` false: an inert entry) and derive what the pixel
+// loop needs
+template <int C>
+__device__ __forceinline__ void load_entry(EntryRegs<C> &e, uint32_t &slot, const bool live, const uint2 *__restrict__ list,
+                                           const uint32_t *__restrict__ slots, const uint32_t j, const GeomPtrs &g,
+                                           const float *__restrict__ colors, const float cx0, const float cy0)
+{
+    float x = 0.f, y = 0.f, cA = 0.f, cB = 0.f, cC = 0.f;
+    e.o = 0.f; e.dep = 0.f; e.k = 0xFFFFFFFFu; slot = 0xFFFFFFFFu;
+#pragma unroll
+    for (int ch = 0; ch < C; ++ch) e.c[ch] = 0.f;
+    if (live) {
+        const uint2 qe = list[j];
+        slot = slots[j];
+        const uint32_t gid = qe.x;
+        e.k = qe.y;
+        const float2 xy = g.xy[gid];
+        const float4 co = g.conic_opacity[gid];
+        e.dep = g.depth[gid];
+        const float *c = colors + (size_t)C * gid;
+        if (C <= 3) { e.c[0] = c[0]; e.c[1] = c[1]; e.c[2] = c[2]; }
+        else {
+            const float2 c01 = *reinterpret_cast<const float2 *>(c), c23 = *reinterpret_cast<const float2 *>(c + 2),
+                         c45 = *reinterpret_cast<const float2 *>(c + 4);
+            e.c[0] = c01.x; e.c[1] = c01.y; e.c[2] = c23.x; e.c[C > 3 ? 3 : 0] = c23.y; e.c[C > 3 ? 4 : 0] = c45.x; e.c[C > 3 ? 5 : 0] = c45.y;
+        }
+        x = xy.x; y = xy.y; cA = co.x; cB = co.y; cC = co.z; e.o = co.w;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        e.dx[i] = x - (cx0 + (float)i);           // cx0 + i is an exact small integer: == xy.x - (float)px
+        e.dy[i] = y - (cy0 + (float)i);
+        e.Adx2[i] = (cA * e.dx[i]) * e.dx[i];
+        e.Cdy2[i] = (cC * e.dy[i]) * e.dy[i];
+        e.Bdx[i] = cB * e.dx[i];
+    }
+}
+
+// pixel state of lane (pixel `li` of the cell at (cx0, cy0)); outside the image: nothing contributes
+template <int C>
+__device__ __forceinline__ void load_pixel(PixelRegs<C> &px, const ViewCtx &c, const int pxi, const int pyi)
+{
+    const ViewParams &vp = c.vp;
+    const bool inside = pxi < vp.W && pyi < vp.H;
+    const size_t P = (size_t)vp.H * vp.W, pid = (size_t)pyi * vp.W + pxi;
+    float T_final = 0.f;
+    uint32_t last = 0;
+    px.gD = px.gA = 0.f;
+#pragma unroll
+    for (int ch = 0; ch < C; ++ch) px.g[ch] = 0.f;
+    if (inside) {
+        T_final = c.im.final_T[pid];
+        last = c.im.n_contrib[pid];
+#pragma unroll
+        for (int ch = 0; ch < C; ++ch) px.g[ch] = c.dL_dcolor[ch * P + pid];
+        if (c.dL_ddepth) px.gD = c.dL_ddepth[pid];
+        if (c.dL_dalpha) px.gA = c.dL_dalpha[pid];
+    }
+    float bgdot = 0.f;
+#pragma unroll
+    for (int ch = 0; ch < C; ++ch) bgdot += vp.bg[ch] * px.g[ch];
+    px.last = __uint_as_float(last);
+    px.T = T_final;
+    px.S = T_final * bgdot;
+}
+
+template <int RSP>
+__device__ __forceinline__ void store_record(float *__restrict__ rec, const uint32_t slot, const float (&acc)[13])
+{
+    float4 *dst = reinterpret_cast<float4 *>(rec + (size_t)slot * RSP);
+    dst[0] = make_float4(acc[0], acc[1], acc[2], acc[3]);
+    dst[1] = make_float4(acc[4], acc[5], acc[6], acc[7]);
+    dst[2] = make_float4(acc[8], acc[9], acc[10], acc[11]);
+    if (RSP > 12) dst[3] = make_float4(acc[12], 0.f, 0.f, 0.f);
+}
+
+// LDS of one wave of the backward kernel: the carries of its rows
+struct BwdSmemV2 { float2 carry[4][16]; };
+
+// regular blocks: wave = quadrant, row = cell
+template <int C, bool LEAN>
+__device__ __forceinline__ void render_bwd_cells(const BatchDesc &d, const uint32_t bid, BwdSmemV2 &sm)
+{
+    constexpr int RSP = (C <= 3 || LEAN) ? 12 : 16;   // == grad_stride(C, LEAN)
     const WaveTrace trace;
     int view, tile, q;
     if (!block_to_quadrant(d, bid, view, tile, q)) { trace.done(0); return; }
     const ViewCtx c = resolve(d, view);
     const ViewParams &vp = c.vp;
-    const float *__restrict__ colors = c.colors;
     const GeomPtrs &g = c.g;
     const BinPtrs &b = c.b;
-    const uint32_t cap = c.cap;
-    const ImgPtrs &im = c.im;
-    const float *__restrict__ dL_dcolor = c.dL_dcolor, *__restrict__ dL_ddepth = c.dL_ddepth,
-                             *__restrict__ dL_dalpha = c.dL_dalpha;
     float *__restrict__ rec = c.dLq;
     const uint32_t rec_cap = c.rec_cap;
     const int lane = threadIdx.x;
     const int tx = tile % vp.gx, ty = tile / vp.gx;
     const LanePixel lp = lane_pixel(lane, tx, ty, q);
-    const int px = lp.px, py = lp.py, row = lp.row, li = lp.li;
-    const bool inside = px < vp.W && py < vp.H;
-    const f2v pxf = (f2v)((float)px), pyf = (f2v)((float)py);
+    const int row = lp.row, li = lp.li;
 
     const uint32_t s = g.tile_start[tile];
-    uint32_t nr = (s < cap) ? g.ccount[tile * kCells + lp.cell] : 0u;
-    uint32_t nd = (s < cap) ? g.cdone[tile * kCells + lp.cell] : 0u;   // entries this row's forward consumed
-    if (nr >= kLongCell) nr = nd = 0u;                                  // long cell: k_render_bwd_long's
-    const uint32_t ndmax = (uint32_t)__builtin_amdgcn_readfirstlane((int)wave_max_u32(nd));   // uniform: scalar loop control
+    uint32_t nr = (s < c.cap) ? g.ccount[tile * kCells + lp.cell] : 0u;
+    uint32_t nd = (s < c.cap) ? min(g.cdone[tile * kCells + lp.cell], nr) : 0u;   // entries this row's forward consumed
+    if (nr >= kWideBwd) nr = nd = 0u;                                               // a wide block's
+    const uint32_t ndmax = (uint32_t)__builtin_amdgcn_readfirstlane((int)wave_max_u32(nd));
     const uint2 *__restrict__ list = b.clist + (size_t)lp.cell * b.cap + s;
     const uint32_t *__restrict__ slots = b.cslot + (size_t)lp.cell * b.cap + s;
-    {
-        // entries the forward never reached get all-zero records, so that B2 can sum every Gaussian's
-        // contiguous record block without looking anything up
-        for (uint32_t j = nd + (uint32_t)li; j < nr; j += 16u) {
-            const uint32_t slot = slots[j];
-            if (slot < rec_cap) {
-                float4 *dst = reinterpret_cast<float4 *>(rec + (size_t)slot * RSP);
+    // entries the forward never reached get all-zero records, so that B2 can sum every Gaussian's contiguous record
+    // block without looking anything up
+    for (uint32_t j = nd + (uint32_t)li; j < nr; j += 16u) {
+        const uint32_t slot = slots[j];
+        if (slot < rec_cap) {
+            float4 *dst = reinterpret_cast<float4 *>(rec + (size_t)slot * RSP);
 #pragma unroll
-                for (int i = 0; i < RSP / 4; ++i) dst[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-            }
+            for (int i = 0; i < RSP / 4; ++i) dst[i] = make_float4(0.f, 0.f, 0.f, 0.f);
         }
     }
     if (ndmax == 0 || ndmax < g_min_work) { trace.done(0); return; }
     set_priority_by_length(ndmax);
-    float *row_base = s_p + row * kRowFloats;
-
-    const size_t P = (size_t)vp.H * vp.W;
-    const size_t pid = (size_t)py * vp.W + px;
-    float T_final = 0.f, gD = 0.f, gA = 0.f;
-    float gCol[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    uint32_t last = 0;
-    if (inside) {
-        T_final = im.final_T[pid];
-        last = im.n_contrib[pid];
+    PixelRegs<C> px;
+    load_pixel<C>(px, c, lp.px, lp.py);
+    const float cx0 = (float)(lp.px - (li & 3)), cy0 = (float)(lp.py - (li >> 2));
+    float2 *carry = sm.carry[row];
+    const bool front_lane = li == 15;
+    for (uint32_t c0 = ((ndmax - 1u) / 16u) * 16u;; c0 -= 16u) {
+        const uint32_t j = c0 + 15u - (uint32_t)li;       // reversed: lane 0 holds the entry farthest back
+        EntryRegs<C> e;
+        uint32_t slot;
+        load_entry<C>(e, slot, j < nd, list, slots, j, g, c.colors, cx0, cy0);
+        float acc[13];
 #pragma unroll
-        for (int ch = 0; ch < C; ++ch) gCol[ch] = dL_dcolor[ch * P + pid];
-        if (dL_ddepth) gD = dL_ddepth[pid];
-        if (dL_dalpha) gA = dL_dalpha[pid];
-    }
-    float bgdot = 0.f;
-#pragma unroll
-    for (int ch = 0; ch < C; ++ch) bgdot += vp.bg[ch] * gCol[ch];
-    const float Tb = T_final * bgdot;
-    float T_ = T_final, S = Tb;   // S: sum V w of the entries behind + T_final bg.g
-    const f2v g01 = f2v{gCol[0], gCol[1]}, g23 = f2v{gCol[2], gCol[3]}, g45 = f2v{gCol[4], gCol[5]}, gDA = f2v{gD, gA};
-    // reduction role of this lane: value li of its row (lanes with li >= RS idle in the sum)
-    const int red_i = li < RS ? li : 0;
-    const float4 *red_src = reinterpret_cast<const float4 *>(&s_red[0][red_i][row * 8]);
-    constexpr int kRedBuf4 = RS * kRedHalf / 4;   // float4 per reduction buffer
-
-    const uint32_t c_last = ((ndmax - 1) / kChunk) * kChunk;
-    float4 r[4];
-    uint32_t rslot = 0;
-    zero_entry(r);
-    if (c_last + (uint32_t)li < nd) {
-        gather_entry<C>(list[c_last + li], g, colors, r);
-        rslot = slots[c_last + li];
-    }
-    for (uint32_t c0 = c_last;; c0 -= kChunk) {
-        const int cnt = (c0 < nd) ? (int)min((uint32_t)kChunk, nd - c0) : 0;
-        const int tmax = (int)min((uint32_t)kChunk, ndmax - c0);
+        for (int i = 0; i < 13; ++i) acc[i] = 0.f;
+        cell_pixels<C, LEAN, false>(e, px, acc, front_lane, carry);
+        if (j < nd && slot < rec_cap) store_record<RSP>(rec, slot, acc);
+        if (c0 == 0u) break;
         __builtin_amdgcn_wave_barrier();
-        stage_entry(row_base, li, r);
-        s_slot[row][li] = rslot;
-        zero_entry(r);
-        if (c0 >= (uint32_t)kChunk && c0 - kChunk + (uint32_t)li < nd) {   // prefetch the chunk in front
-            gather_entry<C>(list[c0 - kChunk + li], g, colors, r);
-            rslot = slots[c0 - kChunk + li];
-        }
+        const float2 cr = carry[li];
+        px.T *= cr.x; px.S += cr.y;
         __builtin_amdgcn_wave_barrier();
-        // U entries per step (aligned groups, highest first; slots past the row's count hold inert padding):
-        // alphas two per packed instruction, one LDS round trip of the reduction for the whole group.
-        for (int tg = ((tmax - 1) / U) * U; tg >= 0; tg -= U) {
-            const f4v *P4 = reinterpret_cast<const f4v *>(row_base + (tg >> 1) * kPairFloats);
-            f4v g0[kBwdPairs], g1[kBwdPairs], g2[kBwdPairs];
-#pragma unroll
-            for (int j = 0; j < kBwdPairs; ++j) { g0[j] = P4[kPair4 * j + 0]; g1[j] = P4[kPair4 * j + 1]; g2[j] = P4[kPair4 * j + 2]; }
-            const uint2 slot2 = *reinterpret_cast<const uint2 *>(&s_slot[row][tg]);   // record slots of the pair (tg is even)
-            f2v dx2[kBwdPairs], dy2[kBwdPairs], pw[kBwdPairs], Gr2[kBwdPairs];
-            pair_gauss<kBwdPairs>(g0, g1, g2, pxf, pyf, dx2, dy2, pw, Gr2);
-            __builtin_amdgcn_wave_barrier();
-            float rsum[RS];
-#pragma unroll
-            for (int e = U - 1; e >= 0; --e) {          // back to front inside the group
-                const int j = e >> 1, h = e & 1, t = tg + e;
-                const f4v e0 = P4[kPair4 * j + 3 + 2 * h], e1 = P4[kPair4 * j + 4 + 2 * h];
-                const uint32_t k = __float_as_uint(h ? P4[kPair4 * j + 7].y : P4[kPair4 * j + 7].x);
-                const float dx = h ? dx2[j].y : dx2[j].x, dy = h ? dy2[j].y : dy2[j].x;
-                const float power = h ? pw[j].y : pw[j].x, Gr = h ? Gr2[j].y : Gr2[j].x;
-                const float op = h ? g2[j].w : g2[j].z;
-                // Branch-free: lanes that do not take the entry contribute exact zeros.
-                // (alpha and G are 0 there, so w and q are; dL/dalpha itself needs no mask: it is finite and only
-                // ever multiplied by G.)  S carries sum V w + T_final bg.g.
-                const float alpha_r = fminf(0.99f, op * Gr);
-                const bool contrib = (k < last) & (power <= 0.0f) & (alpha_r >= 1.0f / 255.0f);
-                const float alpha = contrib ? alpha_r : 0.f;
-                const float G = contrib ? Gr : 0.f;
-                const float inv_om = __builtin_amdgcn_rcpf(1.f - alpha);
-                const float Tn = T_ * inv_om;
-                T_ = contrib ? Tn : T_;
-                const float w = alpha * Tn;
-                // V = dL/d(blended value of this entry) = depth gD + gA + sum_ch colour_ch gCol_ch
-                f2v va = e1.zw * gDA;
-                va = __builtin_elementwise_fma(e0.xy, g01, va);
-                va = __builtin_elementwise_fma(e0.zw, g23, va);
-                if (C > 3) va = __builtin_elementwise_fma(e1.xy, g45, va);
-                const float V = va.x + va.y;
-                const float dL_da = Tn * V - S * inv_om;
-                S = __builtin_fmaf(V, w, S);
-                // dL/dmean2D and dL/dconic are linear in the five moments sum_pixels q (dx, dy, dx^2, dx dy, dy^2),
-                // q = dL/dG G: the records carry the moments, B2 applies the (per-Gaussian) map once (k_gather_bwd)
-                const float q = (op * dL_da) * G;
-                const f2v dxy = f2v{dx, dy};
-                const f2v v01 = dxy * (f2v)(q);                             // q dx, q dy
-                const f2v v24 = v01 * dxy;                                  // q dx^2, q dy^2
-                const float v3 = v01.x * dy;                                // q dx dy
-                const f2v ww = (f2v)(w);
-                const f2v c01 = ww * g01, c23 = ww * g23, c45 = ww * g45;
-                float v[13];
-                v[0] = v01.x; v[1] = v01.y; v[2] = v24.x; v[3] = v3; v[4] = v24.y;
-                if (LEAN) {   // static appearance frozen: no dL/dopacity, no dL/dcolour for channels 0..2
-                    v[5] = w * gD;
-                    v[6] = c23.y; v[7] = c45.x; v[8] = c45.y;
-                } else {
-                    v[5] = G * dL_da;
-                    v[6] = w * gD;
-                    v[7] = c01.x; v[8] = c01.y; v[9] = c23.x; v[10] = c23.y; v[11] = c45.x; v[12] = c45.y;
-                }
-                // transposed reduction: [value][lane] in LDS, lane i of the row sums value i over the row.
-                // v[i] of lane l + v[i] of lane l ^ 8 first (row_ror:8): the odd entry of the pair in all lanes, then
-                // the even entry over it in lanes 0..7 of every row (bank_mask 0x3), so that ONE unmasked LDS write
-                // per value stores both entries (lanes 0..7: entry e = 0, lanes 8..15: entry e = 1).
-                static_assert(U == 2, "the pair reduction below");
-                if (e & 1) {
-#pragma unroll
-                    for (int i = 0; i < RS; ++i)
-                        rsum[i] = v[i] + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v[i]), 0x128, 0xf, 0xf, true));
-                } else {
-                    pair_sum_low_half<RS>(rsum, v);
-#pragma unroll
-                    for (int i = 0; i < RS; ++i) s_red[li >> 3][i][row * 8 + (li & 7)] = rsum[i];
-                }
-                (void)t;
-            }
-            __builtin_amdgcn_wave_barrier();
-            {
-                // all LDS reads of the pair first (one wait), then the two predicated record stores
-                float total[U];
-#pragma unroll
-                for (int e = 0; e < U; ++e) {
-                    const float4 *src = red_src + e * kRedBuf4;
-                    const float4 a0 = src[0], a1 = src[1];
-                    // fixed summation tree (deterministic): pairs of packed adds
-                    f2v p0 = f2v{a0.x, a0.y} + f2v{a0.z, a0.w};
-                    f2v p1 = f2v{a1.x, a1.y} + f2v{a1.z, a1.w};
-                    p0 = p0 + p1;
-                    total[e] = p0.x + p0.y;
-                }
-#pragma unroll
-                for (int e = U - 1; e >= 0; --e) {
-                    const uint32_t slot = e ? slot2.y : slot2.x;
-                    if (li < RS && tg + e < cnt && slot < rec_cap) rec[(size_t)slot * RSP + li] = total[e];   // the padding floats stay unwritten (never read as values)
-                }
-            }
-        }
-        if (c0 == 0) break;
     }
     trace.done(ndmax);
 }
 
-// ---------------------------------------------------------------------------------------- B1 (long cells)
-// One wave per long cell (raster.h, kLongCell).  Lane = (entry slot r = lane >> 4, pixel p = lane & 15 of the cell):
-// the four rows take four CONSECUTIVE list entries of the one cell for the same 16 pixels.  Per step: every row
-// evaluates alpha and V of its entry; row 0 runs the sequential (T, S) chain over the four entries back to front
-// and hands (w, dL/dalpha) back; every row then forms the gradient values of its entry and reduces them over its
-// 16 lanes exactly as k_render_bwd does.  Same operations on the same values in the same order: the records are
-// bit-identical, but a 1200-entry silhouette cell no longer costs the launch 1200 serial reduction round trips.
-// Staging (64 entries per chunk, one per lane): [0..5] x y A B C opacity | [6] k bits | [8..13] colours | [14] depth | [15] 1
+// wide blocks: wave = one long cell
 template <int C, bool LEAN>
-__device__ __forceinline__ void render_bwd_long_cells(const BatchDesc &d, const uint32_t bid, const uint32_t nblocks, float *smem)
+__device__ __forceinline__ void render_bwd_wide_cells(const BatchDesc &d, const uint32_t bid, const uint32_t nblocks, BwdSmemV2 &sm)
 {
-    constexpr int RS = LEAN ? 9 : 7 + C;
     constexpr int RSP = (C <= 3 || LEAN) ? 12 : 16;
-    float *s_e = smem;                                                              // [64 * 16]
-    uint32_t *s_slot = reinterpret_cast<uint32_t *>(smem + 64 * 16);               // [64]
-    float (*s_red)[kRedStride] = reinterpret_cast<float (*)[kRedStride]>(smem + 64 * 16 + 64);   // [RS]
     const int view = (int)(bid % (uint32_t)d.B);
     const uint32_t first = bid / (uint32_t)d.B, step = nblocks / (uint32_t)d.B;
     const ViewCtx c = resolve(d, view);
     const ViewParams &vp = c.vp;
-    const float *__restrict__ colors = c.colors;
     const GeomPtrs &g = c.g;
     const BinPtrs &b = c.b;
-    const ImgPtrs &im = c.im;
     float *__restrict__ rec = c.dLq;
     const uint32_t rec_cap = c.rec_cap;
-    const int lane = threadIdx.x, r = lane >> 4, p = lane & 15;
+    const int lane = threadIdx.x, p = lane & 15;
     const uint32_t n_long = min(g.counters[kCntLong], (uint32_t)(c.T * kCells));
-    if (first < n_long) __builtin_amdgcn_s_setprio(3);   // the launch's critical path: issue before the regular kernel's waves
-    const int red_i = p < RS ? p : 0;
-    const float4 *red_src = reinterpret_cast<const float4 *>(&s_red[red_i][r * 16]);
+    if (first < n_long) __builtin_amdgcn_s_setprio(3);   // the launch's critical path: issue before the regular blocks' waves
+    float2 *carry = sm.carry[0];
+    const bool front_lane = lane == 63;
     for (uint32_t it = first; it < n_long; it += step) {
         const uint32_t cellid = g.longlist[it];
         const int tile = (int)(cellid / kCells), cell = (int)(cellid % kCells);
         const int tx = tile % vp.gx, ty = tile / vp.gx, q = cell >> 2, rw = cell & 3;
-        const int px = tx * kTile + (q & 1) * 8 + (rw & 1) * 4 + (p & 3);
-        const int py = ty * kTile + (q >> 1) * 8 + (rw >> 1) * 4 + (p >> 2);
-        const bool inside = px < vp.W && py < vp.H;
-        const float pxf = (float)px, pyf = (float)py;
+        const int cxi = tx * kTile + (q & 1) * 8 + (rw & 1) * 4, cyi = ty * kTile + (q >> 1) * 8 + (rw >> 1) * 4;
         const uint32_t s = g.tile_start[tile];
         const uint32_t nr = g.ccount[cellid], nd = min(g.cdone[cellid], nr);
         const uint2 *__restrict__ list = b.clist + (size_t)cell * b.cap + s;
@@ -743,148 +845,42 @@ __device__ __forceinline__ void render_bwd_long_cells(const BatchDesc &d, const 
             }
         }
         if (nd == 0u) continue;
-        // every row holds the pixel's upstream gradients (V and the contribution test need them)
-        const size_t P = (size_t)vp.H * vp.W;
-        const size_t pid = (size_t)py * vp.W + px;
-        float T_final = 0.f, gD = 0.f, gA = 0.f;
-        float gCol[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        uint32_t last = 0;
-        if (inside) {
-            T_final = im.final_T[pid];
-            last = im.n_contrib[pid];
+        PixelRegs<C> px;                                   // every row holds the cell's 16 pixels (lane p of the row: pixel p)
+        load_pixel<C>(px, c, cxi + (p & 3), cyi + (p >> 2));
+        const float cx0 = (float)cxi, cy0 = (float)cyi;
+        for (uint32_t c0 = ((nd - 1u) / 64u) * 64u;; c0 -= 64u) {
+            const uint32_t j = c0 + 63u - (uint32_t)lane;
+            EntryRegs<C> e;
+            uint32_t slot;
+            load_entry<C>(e, slot, j < nd, list, slots, j, g, c.colors, cx0, cy0);
+            float acc[13];
 #pragma unroll
-            for (int ch = 0; ch < C; ++ch) gCol[ch] = c.dL_dcolor[ch * P + pid];
-            if (c.dL_ddepth) gD = c.dL_ddepth[pid];
-            if (c.dL_dalpha) gA = c.dL_dalpha[pid];
-        }
-        float bgdot = 0.f;
-#pragma unroll
-        for (int ch = 0; ch < C; ++ch) bgdot += vp.bg[ch] * gCol[ch];
-        const float Tb = T_final * bgdot;
-        float T_ = T_final, S = Tb;   // S: sum V w of the entries behind + T_final bg.g
-        const f2v g01 = f2v{gCol[0], gCol[1]}, g23 = f2v{gCol[2], gCol[3]}, g45 = f2v{gCol[4], gCol[5]}, gDA = f2v{gD, gA};
-
-        const uint32_t c_last = ((nd - 1u) / 64u) * 64u;
-        float4 e[4];
-        uint32_t eslot = 0;
-        zero_entry(e);
-        if (c_last + (uint32_t)lane < nd) {
-            gather_entry<C>(list[c_last + lane], g, colors, e);
-            eslot = slots[c_last + lane];
-        }
-        for (uint32_t c0 = c_last;; c0 -= 64u) {
-            const int cnt = (int)min(64u, nd - c0);
-            __builtin_amdgcn_wave_barrier();
-            {
-                float *se = s_e + lane * 16;
-                *reinterpret_cast<float4 *>(se) = e[0];                                              // x y A B
-                *reinterpret_cast<float4 *>(se + 4) = make_float4(e[1].x, e[1].y, e[1].w, 0.f);     // C opacity k
-                *reinterpret_cast<float4 *>(se + 8) = e[2];                                          // colours 0..3
-                *reinterpret_cast<float4 *>(se + 12) = make_float4(e[3].x, e[3].y, e[1].z, 1.0f);   // colours 4 5, depth, 1
-                s_slot[lane] = eslot;
-            }
-            zero_entry(e);
-            if (c0 >= 64u) {                                               // prefetch the chunk in front (all < nd)
-                gather_entry<C>(list[c0 - 64u + lane], g, colors, e);
-                eslot = slots[c0 - 64u + lane];
-            }
-            __builtin_amdgcn_wave_barrier();
-            for (int tg = ((cnt - 1) / 4) * 4; tg >= 0; tg -= 4) {
-                // ---- every row: its entry t = tg + r (slots past the count hold inert padding: opacity 0) ----
-                const float *se = s_e + (tg + r) * 16;
-                const float4 ga = *reinterpret_cast<const float4 *>(se), gb = *reinterpret_cast<const float4 *>(se + 4);
-                const f4v e0 = *reinterpret_cast<const f4v *>(se + 8), e1 = *reinterpret_cast<const f4v *>(se + 12);
-                const float cA = ga.z, cB = ga.w, cC = gb.x, op = gb.y;
-                const uint32_t k = __float_as_uint(gb.z);
-                const float dx = ga.x - pxf, dy = ga.y - pyf;
-                const float power = -0.5f * ((cA * dx) * dx + (cC * dy) * dy) - (cB * dx) * dy;
-                const float Gr = det_expf(power);
-                const float alpha_r = fminf(0.99f, op * Gr);
-                const bool contrib_r = (k < last) & (power <= 0.0f) & (alpha_r >= 1.0f / 255.0f);
-                f2v va = e1.zw * gDA;
-                va = __builtin_elementwise_fma(e0.xy, g01, va);
-                va = __builtin_elementwise_fma(e0.zw, g23, va);
-                if (C > 3) va = __builtin_elementwise_fma(e1.xy, g45, va);
-                // all four rows get the (alpha or -1, V) of all four entries: three gfx950 lane swaps per value (VALU, no
-                // LDS round trip -- the long waves wait behind the regular kernel's LDS traffic otherwise)
-                float al[4], Vv[4];
-                rows_allgather(contrib_r ? alpha_r : -1.0f, al);
-                rows_allgather(va.x + va.y, Vv);
-                // ---- the sequential (T, S) chain over the four entries, back to front: every row runs it on the same
-                // values (bit-identical T_ and S in all four), and keeps the (w, dL/dalpha) of its own entry ----
-                float w = 0.f, dL_da = 0.f;
-                {
-#pragma unroll
-                    for (int h = 3; h >= 0; --h) {
-                        const bool contrib = al[h] >= 0.0f;
-                        const float alpha = contrib ? al[h] : 0.0f;
-                        const float V = Vv[h];
-                        const float inv_om = __builtin_amdgcn_rcpf(1.f - alpha);
-                        const float Tn = T_ * inv_om;
-                        T_ = contrib ? Tn : T_;
-                        const float w_h = alpha * Tn;
-                        const float d_h = Tn * V - S * inv_om;   // unmasked: only ever multiplied by the masked G
-                        S = __builtin_fmaf(V, w_h, S);
-                        w = (r == h) ? w_h : w;
-                        dL_da = (r == h) ? d_h : dL_da;
-                    }
-                }
-                // ---- every row: the gradient values of its entry, reduced over its 16 lanes ----
-                const float G = contrib_r ? Gr : 0.f;
-                const float q = (op * dL_da) * G;                           // moments, as in k_render_bwd
-                const f2v dxy = f2v{dx, dy};
-                const f2v v01 = dxy * (f2v)(q);
-                const f2v v24 = v01 * dxy;
-                const float v3 = v01.x * dy;
-                const f2v ww = (f2v)(w);
-                const f2v c01 = ww * g01, c23 = ww * g23, c45 = ww * g45;
-                float v[13];
-                v[0] = v01.x; v[1] = v01.y; v[2] = v24.x; v[3] = v3; v[4] = v24.y;
-                if (LEAN) {
-                    v[5] = w * gD;
-                    v[6] = c23.y; v[7] = c45.x; v[8] = c45.y;
-                } else {
-                    v[5] = G * dL_da;
-                    v[6] = w * gD;
-                    v[7] = c01.x; v[8] = c01.y; v[9] = c23.x; v[10] = c23.y; v[11] = c45.x; v[12] = c45.y;
-                }
-#pragma unroll
-                for (int i = 0; i < RS; ++i) s_red[i][lane] = v[i];
-                __builtin_amdgcn_wave_barrier();
-                {
-                    const float4 a0 = red_src[0], a1 = red_src[1], a2 = red_src[2], a3 = red_src[3];
-                    f2v p0 = f2v{a0.x, a0.y} + f2v{a0.z, a0.w};
-                    f2v p1 = f2v{a1.x, a1.y} + f2v{a1.z, a1.w};
-                    f2v p2 = f2v{a2.x, a2.y} + f2v{a2.z, a2.w};
-                    f2v p3 = f2v{a3.x, a3.y} + f2v{a3.z, a3.w};
-                    p0 = p0 + p1;
-                    p2 = p2 + p3;
-                    p0 = p0 + p2;
-                    const float total = p0.x + p0.y;
-                    const int t = tg + r;
-                    const uint32_t slot = s_slot[t < 64 ? t : 63];
-                    if (p < RS && t < cnt && slot < rec_cap) rec[(size_t)slot * RSP + p] = total;
-                }
-                __builtin_amdgcn_wave_barrier();
-            }
+            for (int i = 0; i < 13; ++i) acc[i] = 0.f;
+            cell_pixels<C, LEAN, true>(e, px, acc, front_lane, carry);
+            if (j < nd && slot < rec_cap) store_record<RSP>(rec, slot, acc);
             if (c0 == 0u) break;
+            __builtin_amdgcn_wave_barrier();
+            const float2 cr = carry[p];
+            px.T *= cr.x; px.S += cr.y;
+            __builtin_amdgcn_wave_barrier();
         }
+        __builtin_amdgcn_wave_barrier();
     }
 }
 
 // ---------------------------------------------------------------------------------------- launchers
-// One launch for both kinds of block: the first `long_blocks` workgroups take the long cells (they are dispatched
-// first and raise their issue priority: the launch's critical path), the rest the regular quadrants.  A separate
-// launch on a helper stream cost a fork / join pair of stream events per step (~18 us).
+// One launch for both kinds of block: the first `wide_blocks` workgroups take the wide cells (they are dispatched
+// first and raise their issue priority: the launch's critical path), the rest the regular quadrants.
 template <int C, bool LEAN>
-__global__ __launch_bounds__(64) void k_render_bwd(BatchDesc d, uint32_t long_blocks)
+__global__ __launch_bounds__(64) void k_render_bwd(BatchDesc d, uint32_t wide_blocks)
 {
-    __shared__ __attribute__((aligned(16))) float smem[BwdSmem<C, LEAN>::floats];
-    if (blockIdx.x < long_blocks) render_bwd_long_cells<C, LEAN>(d, blockIdx.x, long_blocks, smem);
-    else render_bwd_cells<C, LEAN>(d, blockIdx.x - long_blocks, smem);
+    __shared__ BwdSmemV2 sm;
+    if (blockIdx.x < wide_blocks) render_bwd_wide_cells<C, LEAN>(d, blockIdx.x, wide_blocks, sm);
+    else render_bwd_cells<C, LEAN>(d, blockIdx.x - wide_blocks, sm);
 }
 
-constexpr int kLongWaves = 128;    // waves per view of the long-cell kernel (each loops over the long cells it owns)
+constexpr int kLongWaves = 128;    // waves per view of the forward's long-cell kernel (each loops over the long cells it owns)
+constexpr int kWideWaves = 256;    // wide blocks per view of the backward (each loops over the wide cells it owns)
 int launch_render_fwd(const BatchDesc &d, hipStream_t st)
 {
     const int T = ((d.W + kTile - 1) / kTile) * ((d.H + kTile - 1) / kTile);
@@ -925,7 +921,7 @@ int launch_render_bwd(const BatchDesc &d, hipStream_t st)
     ProfScope prof_(kKRenderBwd, st);
     if (d.lean && d.C != 6) { set_error("lean backward records need 6 channels"); return DM4D_ERR_INVALID; }
     // the long cells' blocks first (multiple of 8 of them: the regular blocks keep their XCD), then the quadrants
-    const uint32_t long_blocks = (uint32_t)(min(T * kCells, kLongWaves) * d.B);
+    const uint32_t long_blocks = (uint32_t)(min(T * kCells, kWideWaves) * d.B);
     const dim3 grid(long_blocks + (uint32_t)blocks);
     if (d.C <= 3) hipLaunchKernelGGL((k_render_bwd<3, false>), grid, dim3(64), 0, st, d, long_blocks);
     else if (d.lean) hipLaunchKernelGGL((k_render_bwd<6, true>), grid, dim3(64), 0, st, d, long_blocks);
