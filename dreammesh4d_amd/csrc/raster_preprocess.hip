@@ -478,7 +478,12 @@ __global__ __launch_bounds__(kPreThreads) void k_gather_bwd(BatchDesc d)
     o.dL_dmeans2D[3 * si + 0] = acc[0];
     o.dL_dmeans2D[3 * si + 1] = acc[1];
     o.dL_dmeans2D[3 * si + 2] = 0.f;
-    if (o.dL_dopacity) o.dL_dopacity[si] = acc[5];
+    if (o.dL_dopacity) {
+        // the records carry sum q = opacity * sum G dL/dalpha (B1's q already holds the opacity factor; a Gaussian with
+        // opacity < 1/255 contributes nowhere, its sum is an exact 0)
+        const float op_ = in.opacities[i];
+        o.dL_dopacity[si] = (r > 0 && op_ > 0.f) ? acc[5] / op_ : 0.f;
+    }
     if (o.dL_dcolors) {
         for (int ch = 0; ch < C; ++ch) o.dL_dcolors[(size_t)C * si + ch] = acc[7 + ch];
     }

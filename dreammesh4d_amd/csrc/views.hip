@@ -11,6 +11,7 @@
 // (custom/threestudio-dreammesh4d/renderer/diff_sugar_rasterizer_temporal.py:161-217) share one
 // binning and one blend.  This is what custom/.../renderer/gaussian_batch_renderer.py:21-76 does with a
 // Python loop over views and two rasterizer calls (two host syncs) per view.
+#include <stdlib.h>
 #include <string.h>
 #include <vector>
 #include "common.h"
@@ -83,6 +84,46 @@ static BatchDesc views_batch(const dm4d_views *v)
     return d;
 }
 
+// views [b0, b0 + nb) of a batch as a batch of their own
+static BatchDesc sub_batch(const BatchDesc &d, int b0, int nb)
+{
+    BatchDesc s = d;
+    const size_t b = (size_t)b0, N = (size_t)d.N, P = (size_t)d.H * d.W;
+    s.B = nb;
+    if (d.frame_index) s.frame_index = d.frame_index + b0;
+    else {
+        if (d.means3D) s.means3D = d.means3D + b * d.means_stride;
+        if (d.rotations) s.rotations = d.rotations + b * d.rot_stride;
+        if (d.colors) s.colors = d.colors + b * d.color_stride;
+    }
+    s.view = d.view + b * d.cam_stride; s.proj = d.proj + b * d.cam_stride;
+    if (d.campos) s.campos = d.campos + b * d.campos_stride;
+    if (d.scales) s.scales = d.scales + b * d.scale_stride;
+    if (d.opacities) s.opacities = d.opacities + b * d.opac_stride;
+    if (d.shs) s.shs = d.shs + b * d.sh_stride;
+    if (d.cov3D) s.cov3D = d.cov3D + b * d.cov_stride;
+    if (d.radii) s.radii = d.radii + b * d.radii_stride;
+    s.geom = d.geom + b * d.geom_stride;
+    if (d.binning) s.binning = d.binning + b * d.bin_stride;
+    if (d.image) s.image = d.image + b * d.img_stride;
+    if (d.out_color) s.out_color = d.out_color + b * d.C * P;
+    if (d.out_depth) s.out_depth = d.out_depth + b * P;
+    if (d.out_alpha) s.out_alpha = d.out_alpha + b * P;
+    if (d.dL_dcolor) s.dL_dcolor = d.dL_dcolor + b * d.C * P;
+    if (d.dL_ddepth) s.dL_ddepth = d.dL_ddepth + b * P;
+    if (d.dL_dalpha) s.dL_dalpha = d.dL_dalpha + b * P;
+    if (d.dLq) s.dLq = d.dLq + b * d.dlq_stride;
+    if (d.o.dL_dmeans2D) s.o.dL_dmeans2D = d.o.dL_dmeans2D + b * N * 3;
+    if (d.o.dL_dmeans3D) s.o.dL_dmeans3D = d.o.dL_dmeans3D + b * N * 3;
+    if (d.o.dL_dopacity) s.o.dL_dopacity = d.o.dL_dopacity + b * N;
+    if (d.o.dL_dcolors) s.o.dL_dcolors = d.o.dL_dcolors + b * N * d.C;
+    if (d.o.dL_dsh) s.o.dL_dsh = d.o.dL_dsh + b * N * d.sh_coeffs * 3;
+    if (d.o.dL_dscales) s.o.dL_dscales = d.o.dL_dscales + b * N * 3;
+    if (d.o.dL_drotations) s.o.dL_drotations = d.o.dL_drotations + b * N * 4;
+    if (d.o.dL_dcov3D) s.o.dL_dcov3D = d.o.dL_dcov3D + b * N * 6;
+    return s;
+}
+
 }  // namespace dm4d
 
 using namespace dm4d;
@@ -137,8 +178,16 @@ int dm4d_views_backward(const dm4d_views *v, const dm4d_views_grads *gr, dm4d_st
     // static appearance frozen (the dynamic stage, static_learnable = False, C/geometry/dynamic_sugar.py:79-87): the
     // blend backward neither reduces nor records dL/dopacity and dL/d(rgb), 9 values per record instead of 13
     d.lean = gr->dL_dopacity ? 0 : 1;
-    if ((rc = launch_render_bwd(d, st))) return rc;
-    if ((rc = launch_gather_bwd(d, st))) return rc;
+    // The blend backward writes one record per (Gaussian, cell) and the gather reads them back: in groups of views whose
+    // records fit the 256 MB memory-side cache the round trip stays off HBM (8 views at once: 466 MB).
+    static const int group_env = getenv("DM4D_BWD_GROUP") ? atoi(getenv("DM4D_BWD_GROUP")) : 0;
+    const int group = group_env > 0 ? group_env : v->B;
+    for (int b0 = 0; b0 < v->B; b0 += group) {
+        BatchDesc sb = sub_batch(d, b0, v->B - b0 < group ? v->B - b0 : group);
+        if (getenv("DM4D_BWD_REUSE")) sb.dLq = d.dLq;      // experiment: every group writes its records to the same scratch
+        if ((rc = launch_render_bwd(sb, st))) return rc;
+        if ((rc = launch_gather_bwd(sb, st))) return rc;
+    }
     const int NF = v->frame_index ? v->n_frames : v->B;
     rc = face_backward_launch(NF, v->F, v->G, v->V, v->faces, v->vxyz, v->vrot, v->q_static, gr->dL_dmeans3D,
                               gr->dL_drotations, gr->dL_dcolors + 3, 6, gr->vert_csr_offsets, gr->vert_csr_items,

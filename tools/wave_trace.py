@@ -9,7 +9,7 @@ for _ in range(3):
     wl.step()
 torch.cuda.synchronize()
 L = _lib.lib()
-B, blocks = 1, 8 * 4096
+B, blocks = 1, 8 * 4096 + 8 * 256      # backward: 8 x 256 wide blocks first, then the quadrants
 buf = torch.zeros(B * blocks, 4, dtype=torch.int64, device=dev)
 
 def analyse(name, a):
@@ -55,5 +55,7 @@ torch.autograd.backward([o["color"], o["depth"], o["alpha"]], [wl.gC, wl.gD, wl.
 torch.cuda.synchronize()
 bw = buf.cpu().numpy().copy()
 _lib.check(L.dm4d_debug_trace(None, 0))
-analyse("render_fwd", fw)
-analyse("render_bwd", bw)
+analyse("render_fwd", fw[:8 * 4096])
+analyse("render_bwd (wide blocks: one wave per long cell)", bw[:8 * 256])
+analyse("render_bwd (regular blocks)", bw[8 * 256:])
+analyse("render_bwd (all)", bw)
