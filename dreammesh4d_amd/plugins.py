@@ -1,7 +1,7 @@
 """threestudio plugin names of the hot path (boundary B1).
 
 The reference binds its YAML configs to classes registered under these names
-(``@threestudio.register(name)``, threestudio/__init__.py:5-32):
+(``@threestudio.register(name)``, threestudio/__init__.py:5-32) and constructs them as ``cls(cfg, *args)``:
 
     diff-sugar-rasterizer-temporal      C/renderer/diff_sugar_rasterizer_temporal.py:56
     diff-sugar-rasterizer-normal        C/renderer/diff_sugar_rasterizer_normal.py:54
@@ -12,32 +12,18 @@ The reference binds its YAML configs to classes registered under these names
     solid-color-background              threestudio/models/background/solid_color_background.py:14
     no-material                         threestudio/models/materials/no_material.py:16
 
-``PLUGINS`` maps every name to the class of this package that implements its hot-path surface;
-``register(threestudio_module)`` enters them into a threestudio registry (when threestudio is importable,
-``register()`` with no argument imports it).  threestudio's launcher / trainer / config parsing are out of
-scope, so the classes take plain constructor arguments instead of a ``cfg`` dataclass: a
-maintainer wires ``cfg`` fields to them in a three-line subclass.
+``PLUGINS`` maps every name to its cfg-constructed class (dreammesh4d_amd/threestudio_host.py: the ``Config``
+dataclasses of the reference, ``configure``, ``update_step``); ``threestudio_host.find(name)`` is the registry without
+threestudio; ``register(threestudio_module)`` enters the classes into a real threestudio registry under the
+REFERENCE's names (prefix "" -- they replace the CUDA-backed plugins; pass a prefix to let both coexist).
 """
-from .renderer import DiffGaussianTemporal, DiffSuGaRNormal
-from .shims import NoMaterial, SolidColorBackground
-from .sugar import DynamicSuGaR, SuGaR
-from .zero123 import StableZero123Guidance, TemporalStableZero123Guidance
+from . import threestudio_host as host
 
-PLUGINS = {
-    "diff-sugar-rasterizer-temporal": DiffGaussianTemporal,
-    "diff-sugar-rasterizer-normal": DiffSuGaRNormal,
-    "dynamic-sugar": DynamicSuGaR,
-    "sugar": SuGaR,
-    "temporal-stable-zero123-guidance": TemporalStableZero123Guidance,
-    "stable-zero123-guidance": StableZero123Guidance,
-    "solid-color-background": SolidColorBackground,
-    "no-material": NoMaterial,
-}
+PLUGINS = dict(host.__modules__)
 
 
-def register(threestudio=None, prefix="dm4d-"):
-    """Registers the classes as ``<prefix><name>`` (default prefix so that they can coexist with the reference's
-    own CUDA-backed plugins; pass prefix="" to take the reference's names over).  Returns the registered names."""
+def register(threestudio=None, prefix=""):
+    """Registers the classes as ``<prefix><name>`` in `threestudio` (imported when not given).  Returns the names."""
     if threestudio is None:
         import threestudio  # noqa: F811  (only when the caller has it)
     names = []

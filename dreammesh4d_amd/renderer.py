@@ -217,8 +217,9 @@ class DiffSuGaRNormal:
     normal pass of the reference (:161-195) as ONE call of the drop-in operator with 6-channel colours (RGB | Gaussian
     normal; both passes share geometry, binning and blend), then the reference's epilogue (normal from depth, masks,
     detach rules :196-207).  Every static parameter receives its gradient through the operator's backward.
-    Colours come from the degree-0 SH as precomputed RGB (``active_sh_degree = 0``: identical values; the operator's own
-    SH path is the single-pass alternative)."""
+    Colours: the reference passes ``shs = get_features`` (the DC term clipped to +-color_clip) and lets the rasterizer
+    evaluate max(SH_C0 sh + 0.5, 0) with a zero gradient where clamped; ``SuGaR.get_rendered_rgb`` is exactly that as
+    torch ops (same float32 values, same gradient mask), which is what lets the two passes share one 6-channel call."""
 
     def __init__(self, geometry, back_ground_color=(1.0, 1.0, 1.0), invert_bg_prob=1.0, training=True, seed=0):
         self.geometry = geometry
@@ -238,7 +239,7 @@ class DiffSuGaRNormal:
         """The geometry's per-Gaussian attributes, evaluated ONCE for all the views of a batch (the reference re-evaluates
         the properties for every view; the autograd graph is the same, shared)."""
         g = self.geometry
-        return dict(xyz=g.get_xyz, opacity=g.get_opacity, scaling=g.get_scaling, rotation=g.get_rotation, rgb=g.get_points_rgb(),
+        return dict(xyz=g.get_xyz, opacity=g.get_opacity, scaling=g.get_scaling, rotation=g.get_rotation, rgb=g.get_rendered_rgb(),
                     normals=g.get_gs_normals)
 
     def forward(self, viewpoint_camera: Camera, bg_color=None, scaling_modifier=1.0, override_color=None,

@@ -16,6 +16,8 @@ stage, dynamic_sugar.py:77-87).  What is NOT mirrored: building the deformation 
 (open3d / potpourri3d, :745-861; next) -- the graph (node positions, K neighbours and
 weights per vertex) is an input here -- and the reference's ``discrete`` dynamic mode (per-frame tables).
 """
+import math
+
 import torch
 import torch.nn as nn
 
@@ -33,7 +35,10 @@ class DynamicSuGaR(nn.Module):
     def __init__(self, verts, faces, node_xyz, nbr_idx, nbr_w, n_gaussians_per_surface_triangle=6,
                  skinning_method="hybrid", spatial_extent=3.8, vertex_colors=None, log_scales=None, complex_numbers=None,
                  densities=None, sh_dc=None, deformation_kwargs=None, deformation_lr=0.00032, grid_lr=0.0032,
-                 device="cuda"):
+                 d_scale=False, init_gs_opacity=0.5, init_gs_scales_s=1.7, learn_opacities=True, device="cuda"):
+        """Defaults of the optional static state follow ``SuGaRModel.Config`` (sugar.py:35-72: init_gs_opacity 0.5,
+        init_gs_scales_s 1.7; 0.9999 when the opacities are not learnt, :100-107); a dynamic-stage run normally loads the
+        static stage's checkpoint over them (``weights``)."""
         super().__init__()
         dev = torch.device(device)
         T = lambda a, dt=torch.float32: torch.as_tensor(a, dtype=dt, device=dev)
@@ -56,11 +61,12 @@ class DynamicSuGaR(nn.Module):
         self._sh_coordinates_dc = nn.Parameter(T(sh_dc).reshape(N, 1, 3), requires_grad=False)
         self._sh_coordinates_rest = nn.Parameter(torch.zeros(N, 0, 3, device=dev), requires_grad=False)
         if densities is None:
-            densities = torch.full((N, 1), 2.9444, device=dev)               # sigmoid^-1(0.95)
+            o0 = init_gs_opacity if learn_opacities else 0.9999              # sugar.py:100-107
+            densities = torch.full((N, 1), math.log(o0 / (1.0 - o0)), device=dev)
         self.all_densities = nn.Parameter(T(densities).reshape(N, 1), requires_grad=False)
         if log_scales is None:
             fv = verts[faces]
-            s = (fv - fv[:, [1, 2, 0]]).norm(dim=-1).min(dim=-1)[0] * geo.circle_radius(G)
+            s = (fv - fv[:, [1, 2, 0]]).norm(dim=-1).min(dim=-1)[0] * geo.circle_radius(G, init_gs_scales_s)
             log_scales = torch.log(s.clamp_min(1e-7)).reshape(F_, 1, 1).expand(-1, G, 2).reshape(-1, 2)
         self._scales = nn.Parameter(T(log_scales).reshape(N, 2).clone(), requires_grad=False)
         if complex_numbers is None:
@@ -75,7 +81,11 @@ class DynamicSuGaR(nn.Module):
         self.graph = ops.DeformGraph(verts, self._xyz_neighbor_node_idx, self._xyz_neighbor_nodes_weights, M, dev)
         self.topo = ops.MeshTopology(faces, V, G, dev)
         # deformation network: heads as in dynamic_sugar.py:141-147
-        kw = dict(no_dr=False, no_ds=skinning_method == "dqs", no_do=skinning_method != "hybrid")
+        self.d_scale = bool(d_scale)
+        if self.d_scale:
+            raise NotImplementedError("d_scale: true (the per-vertex scale blend, dynamic_sugar.py:595-612,682-704) is not built yet; "
+                                      "configs/sugar_dynamic_dg.yaml sets d_scale: false")
+        kw = dict(no_dr=False, no_ds=not (d_scale or skinning_method in ("hybrid", "lbs")), no_do=skinning_method != "hybrid")
         kw.update(deformation_kwargs or {})
         self._deformation = DeformationNetwork(**kw).to(dev)
         self.training_setup_dynamic(deformation_lr, grid_lr)
@@ -253,8 +263,11 @@ class SuGaR(nn.Module):
 
     def __init__(self, verts, faces, n_gaussians_per_surface_triangle=6, spatial_extent=3.8, vertex_colors=None,
                  learn_positions=True, learn_opacities=True, learn_scales=True, freeze_gaussians=False,
-                 position_lr=0.001, feature_lr=0.01, opacity_lr=0.05, scaling_lr=0.005, rotation_lr=0.005,
-                 spatial_lr_scale=10.0, device="cuda"):
+                 position_lr=0.00048, feature_lr=0.001, opacity_lr=0.02, scaling_lr=0.005, rotation_lr=0.001,
+                 spatial_lr_scale=10.0, init_gs_opacity=0.9, init_gs_scales_s=1.3, color_clip=2.0, device="cuda"):
+        """The keyword defaults are the values configs/sugar_static_refine.yaml ships (learning rates :49-58, init_gs_opacity
+        0.9, init_gs_scales_s 1.3 :64-66); ``SuGaRModel.Config``'s own defaults (sugar.py:35-72: 0.5, 1.7, lr 0.001 / 0.01 /
+        0.05 / 0.005 / 0.005) are what threestudio_host.SuGaRModel passes when a cfg leaves them out."""
         super().__init__()
         dev = torch.device(device)
         T = lambda a, dt=torch.float32: torch.as_tensor(a, dtype=dt, device=dev)
@@ -273,9 +286,12 @@ class SuGaR(nn.Module):
         colors = (T(vertex_colors)[faces][:, None] * self._bary[None]).sum(-2).reshape(-1, 3)    # sugar.py:209-224
         self._sh_coordinates_dc = nn.Parameter(RGB2SH(colors).unsqueeze(1), requires_grad=not freeze_gaussians)
         self._sh_coordinates_rest = nn.Parameter(torch.zeros(N, 0, 3, device=dev), requires_grad=not freeze_gaussians)
-        self.all_densities = nn.Parameter(torch.full((N, 1), 2.9444, device=dev), requires_grad=learn_opacities)   # sigmoid^-1(0.95)
+        o0 = init_gs_opacity if learn_opacities else 0.9999                                       # sugar.py:100-107
+        self.all_densities = nn.Parameter(torch.full((N, 1), math.log(o0 / (1.0 - o0)), device=dev), requires_grad=learn_opacities)
+        self._color_clip_cfg = color_clip
+        self.color_clip = C(color_clip, 0, 0)                                                     # sugar.py:384
         fv = verts[faces]
-        s0 = (fv - fv[:, [1, 2, 0]]).norm(dim=-1).min(dim=-1)[0] * geo.circle_radius(G)           # sugar.py:262-268
+        s0 = (fv - fv[:, [1, 2, 0]]).norm(dim=-1).min(dim=-1)[0] * geo.circle_radius(G, init_gs_scales_s)   # sugar.py:262-268
         self._scales = nn.Parameter(torch.log(s0.clamp_min(1e-7)).reshape(F_, 1, 1).expand(-1, G, 2).reshape(-1, 2).clone(),
                                     requires_grad=learn_scales)
         cx = torch.zeros(N, 2, device=dev)
@@ -325,10 +341,18 @@ class SuGaR(nn.Module):
 
     @property
     def get_features(self):
-        return torch.cat([self._sh_coordinates_dc, self._sh_coordinates_rest], dim=1)
+        """``sh_coordinates`` (sugar.py:457-462): the DC term clipped to +-color_clip."""
+        return torch.cat([self._sh_coordinates_dc.clip(-self.color_clip, self.color_clip), self._sh_coordinates_rest], dim=1)
 
     def get_points_rgb(self):
         return geo.points_rgb(self._sh_coordinates_dc)
+
+    def get_rendered_rgb(self):
+        """The colours the reference's static renderer blends: it hands ``shs = get_features`` to the rasterizer
+        (diff_sugar_rasterizer_normal.py:151-154), whose degree-0 evaluation is max(SH_C0 sh + 0.5, 0) with a zero
+        gradient where clamped -- the same values and the same gradient mask, as torch ops, so that the RGB pass and the
+        normal pass can share ONE 6-channel call."""
+        return geo.points_rgb(self._sh_coordinates_dc.clip(-self.color_clip, self.color_clip)).clamp_min(0.0)
 
     @property
     def get_face_normals(self):
@@ -358,12 +382,14 @@ class SuGaR(nn.Module):
                 gq["lr"] = C(self._lr["f_dc"], 0, iteration, interpolation="exp")
             elif n == "f_rest":
                 gq["lr"] = C(self._lr["f_rest"], 0, iteration, interpolation="exp") / 20.0
+        self.color_clip = C(self._color_clip_cfg, 0, iteration)                                   # sugar.py:404
 
     def merge_optimizer(self, net_optimizer):
         groups = list(self.optimize_list) + ([{"params": g["params"], "lr": g["lr"]} for g in net_optimizer.param_groups]
                                              if net_optimizer is not None else [])
         self.optimizer = torch.optim.AdamW(groups, lr=0.0, betas=(0.9, 0.99), eps=1e-15)
         return self.optimizer
+
 
     def update_step(self, epoch, global_step, on_load_weights=False):
         self.global_step = global_step

@@ -1,0 +1,637 @@
+"""A minimal host for the reference's plugin API (boundary B1): what the YAML configs of
+custom/threestudio-dreammesh4d bind to, without threestudio, OmegaConf or Lightning.
+
+The reference constructs every component as ``threestudio.find(cfg.<x>_type)(cfg.<x>, *args)``
+(threestudio/__init__.py:5-32): a class registered under a name, whose ``__init__(cfg, *args, **kwargs)`` parses ``cfg``
+into its nested ``Config`` dataclass, sets ``self.device``, calls ``self.configure(*args, **kwargs)`` and answers
+``update_step(epoch, global_step, on_load_weights)`` (threestudio/utils/base.py:21-57,70-118).  This module provides
+
+* ``register(name)`` / ``find(name)``          -- the registry, pre-populated under the REFERENCE's names with the classes below
+* ``parse_structured(Config, cfg)``           -- dataclass from a dict: unknown keys raise, as OmegaConf's structured mode does
+* ``resolve(root)``                           -- the ``${a.b}`` references and the resolvers the reference registers
+                                                 (threestudio/utils/config.py:11-28) on a plain nested dict
+* ``Updateable`` / ``BaseObject`` / ``BaseModule``
+* the eight classes of the hot path, each constructible as ``cls(cfg_dict, *args)``:
+    ``dynamic-sugar`` (C/geometry/dynamic_sugar.py:42-164), ``sugar`` (C/geometry/sugar.py:33-117),
+    ``diff-sugar-rasterizer-temporal`` (C/renderer/diff_sugar_rasterizer_temporal.py:56-80),
+    ``diff-sugar-rasterizer-normal`` (C/renderer/diff_sugar_rasterizer_normal.py:54-78),
+    ``temporal-stable-zero123-guidance`` (C/guidance/temporal_stable_zero123_guidance.py:76-172),
+    ``stable-zero123-guidance`` (threestudio/models/guidance/stable_zero123_guidance.py:75-170),
+    ``solid-color-background``, ``no-material``
+* ``parse_optimizer(config, model)``           -- threestudio/systems/utils.py:55-89 for the optimisers torch ships
+
+What it does NOT contain: the launcher, the systems, the data modules, the exporters.  Two
+set-up steps of the reference need packages that are not in the tree and are therefore inputs here, as extra ``cfg``
+keys the reference's dataclasses do not have: the CLIP image embeddings of the conditioning frames
+(``cond_embeddings_path``: a torch file {"c_crossattn" [L,1,768], "c_concat" [L,4,32,32]}; the reference computes them
+with the checkpoint's CLIP encoder in ``prepare_embeddings``, guidance :141-199), and the deformation graph's node
+samples when reproducibility across runs is wanted (``dg_node_seed``; the reference draws them with open3d's
+``sample_points_uniformly``, dynamic_sugar.py:752-753).
+"""
+import dataclasses
+import math
+import os
+import re
+from dataclasses import dataclass, field
+from typing import Any, Optional, Tuple
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import renderer as _renderer
+from . import shims as _shims
+from . import sugar as _sugar
+from . import zero123 as _z
+
+__modules__ = {}
+
+
+def register(name):
+    def decorator(cls):
+        if name in __modules__:
+            raise ValueError(f"Module {name} already exists! Names of extensions conflict!")
+        __modules__[name] = cls
+        return cls
+
+    return decorator
+
+
+def find(name):
+    """``threestudio.find``: a registered class, or ``main:sub1,sub2`` = a new class deriving from (sub1, sub2, main)."""
+    if ":" in name:
+        main_name, sub_name = name.split(":")
+        name_list = sub_name.split(",") + [main_name]
+        return type(f"{main_name}.{sub_name}", tuple(__modules__[n] for n in name_list), {})
+    return __modules__[name]
+
+
+# ------------------------------------------------------------------------------------------------ config
+def _c_max(value):
+    """``C_max`` of threestudio/utils/config.py:31-50: the largest value a scheduled scalar takes."""
+    if isinstance(value, (int, float)):
+        return value
+    value = list(value)
+    if len(value) >= 6:
+        value = [value[0], value[1], max([value[2]] + [value[i] for i in range(4, len(value), 2)]), value[3]]
+    if len(value) == 3:
+        value = [0] + value
+    if len(value) != 4:
+        raise TypeError("Scalar specification only supports a 3/4-list or a piecewise list")
+    return max(value[1], value[2])
+
+
+_RESOLVERS = {
+    "calc_exp_lr_decay_rate": lambda factor, n: factor ** (1.0 / n), "add": lambda a, b: a + b, "sub": lambda a, b: a - b,
+    "mul": lambda a, b: a * b, "div": lambda a, b: a / b, "idiv": lambda a, b: a // b, "basename": lambda p: os.path.basename(p),
+    "rmspace": lambda s, sub: s.replace(" ", sub), "tuple2": lambda s: [float(s), float(s)], "gt0": lambda s: s > 0,
+    "cmaxgt0": lambda s: _c_max(s) > 0, "not": lambda s: not s, "cmaxgt0orcmaxgt0": lambda a, b: _c_max(a) > 0 or _c_max(b) > 0,
+}
+_MISSING = "???"
+
+
+def _lookup(root, path):
+    node = root
+    for key in path.split("."):
+        node = node[int(key)] if isinstance(node, (list, tuple)) else node[key]
+    return node
+
+
+def _split_args(s):
+    out, depth, cur = [], 0, ""
+    for ch in s:
+        if ch == "," and depth == 0:
+            out.append(cur)
+            cur = ""
+            continue
+        depth += ch == "{"
+        depth -= ch == "}"
+        cur += ch
+    return out + [cur]
+
+
+def _literal(s):
+    s = s.strip()
+    for conv in (int, float):
+        try:
+            return conv(s)
+        except ValueError:
+            pass
+    return {"true": True, "false": False, "null": None}.get(s.lower(), s)
+
+
+def _resolve_value(v, root, stack=()):
+    if isinstance(v, dict):
+        return {k: _resolve_value(x, root, stack) for k, x in v.items()}
+    if isinstance(v, (list, tuple)):
+        return [_resolve_value(x, root, stack) for x in v]
+    if not isinstance(v, str) or "${" not in v:
+        return v
+
+    def expr(e):
+        e = e.strip()
+        if ":" in e and re.match(r"^[A-Za-z_][A-Za-z0-9_]*:", e):
+            fn, args = e.split(":", 1)
+            if fn not in _RESOLVERS:
+                raise KeyError(f"unknown resolver {fn!r} in {v!r}")
+            return _RESOLVERS[fn](*[_resolve_value(a.strip(), root, stack) if "${" in a else _literal(a) for a in _split_args(args)])
+        if e in stack:
+            raise ValueError(f"circular reference {e!r}")
+        return _resolve_value(_lookup(root, e), root, stack + (e,))
+
+    m = re.fullmatch(r"\$\{(.*)\}", v.strip(), flags=re.S)
+    if m and v.strip().count("${") - v.strip().count("}") <= 0 and _balanced(m.group(1)):
+        return expr(m.group(1))                      # the whole string is one interpolation: keep the value's type
+    # string interpolation
+    out, i = "", 0
+    while i < len(v):
+        if v.startswith("${", i):
+            j, depth = i + 2, 1
+            while depth:
+                depth += v.startswith("${", j)
+                depth -= v[j] == "}"
+                j += 1
+            out += str(expr(v[i + 2:j - 1]))
+            i = j
+        else:
+            out += v[i]
+            i += 1
+    return out
+
+
+def _balanced(s):
+    depth = 0
+    for i, ch in enumerate(s):
+        if s.startswith("${", i):
+            depth += 1
+        elif ch == "}":
+            depth -= 1
+            if depth < 0:
+                return False
+    return depth == 0
+
+
+def resolve(root):
+    """A nested dict with every ``${...}`` replaced (OmegaConf.resolve for the forms the reference's YAMLs use)."""
+    return _resolve_value(root, root)
+
+
+def parse_structured(fields, cfg=None):
+    """``parse_structured(self.Config, cfg)`` (threestudio/utils/config.py:121-123): the dataclass with its defaults
+    overridden by ``cfg``; a key the dataclass does not declare is an error; ``???`` is a missing mandatory value."""
+    cfg = {} if cfg is None else (dataclasses.asdict(cfg) if dataclasses.is_dataclass(cfg) else dict(cfg))
+    names = {f.name for f in dataclasses.fields(fields)}
+    unknown = [k for k in cfg if k not in names]
+    if unknown:
+        raise KeyError(f"{fields.__qualname__}: unknown configuration key(s) {unknown}")
+    out = fields(**cfg)
+    for f in dataclasses.fields(fields):
+        if getattr(out, f.name) == _MISSING:
+            raise ValueError(f"{fields.__qualname__}.{f.name} is a mandatory value (???) that was not set")
+    return out
+
+
+def get_device():
+    return torch.device("cuda:%d" % int(os.environ.get("LOCAL_RANK", "0")) if torch.cuda.is_available() else "cpu")
+
+
+class Updateable:
+    def do_update_step(self, epoch, global_step, on_load_weights=False):
+        for attr in self.__dir__():
+            if attr.startswith("_"):
+                continue
+            try:
+                module = getattr(self, attr)
+            except Exception:
+                continue
+            if isinstance(module, Updateable) and module is not self:
+                module.do_update_step(epoch, global_step, on_load_weights=on_load_weights)
+        self.update_step(epoch, global_step, on_load_weights=on_load_weights)
+
+    def update_step(self, epoch, global_step, on_load_weights=False):
+        pass
+
+
+class BaseObject(Updateable):
+    @dataclass
+    class Config:
+        pass
+
+    def __init__(self, cfg=None, *args, **kwargs):
+        super().__init__()
+        self.cfg = parse_structured(self.Config, cfg)
+        self.device = get_device()
+        self.configure(*args, **kwargs)
+
+    def configure(self, *args, **kwargs):
+        pass
+
+
+class BaseModule(nn.Module, Updateable):
+    @dataclass
+    class Config:
+        weights: Optional[str] = None
+
+    def __init__(self, cfg=None, *args, **kwargs):
+        nn.Module.__init__(self)
+        self.cfg = parse_structured(self.Config, cfg)
+        self.configure(*args, **kwargs)
+        if self.cfg.weights is not None:               # "path/to/ckpt:module_name" (base.py:104-113)
+            from .wire_formats import load_module_weights
+
+            path, module_name = self.cfg.weights.split(":")
+            state, epoch, step = load_module_weights(path, module_name=module_name, map_location="cpu")
+            self.load_state_dict(state, strict=False)
+            self.do_update_step(epoch, step, on_load_weights=True)
+
+    def configure(self, *args, **kwargs):
+        pass
+
+
+# ------------------------------------------------------------------------------------------------ shims
+@register("solid-color-background")
+class SolidColorBackground(_shims.SolidColorBackground, Updateable):
+    @dataclass
+    class Config:
+        weights: Optional[str] = None
+        n_output_dims: int = 3
+        color: Tuple = (1.0, 1.0, 1.0)
+        learned: bool = False
+        random_aug: bool = False
+        random_aug_prob: float = 0.5
+
+    def __init__(self, cfg=None):
+        self.cfg = c = parse_structured(self.Config, cfg)
+        super().__init__(c.n_output_dims, tuple(c.color), c.learned, c.random_aug, c.random_aug_prob)
+
+
+@register("no-material")
+class NoMaterial(_shims.NoMaterial, Updateable):
+    @dataclass
+    class Config:
+        weights: Optional[str] = None
+        n_output_dims: int = 3
+        color_activation: str = "sigmoid"
+        input_feature_dims: Optional[int] = None
+        mlp_network_config: Optional[dict] = None
+        requires_normal: bool = False
+
+    def __init__(self, cfg=None):
+        self.cfg = c = parse_structured(self.Config, cfg)
+        if c.input_feature_dims is not None or c.mlp_network_config is not None:
+            raise NotImplementedError("no-material with a feature network (tiny-cuda-nn) is not on the hot path")
+        super().__init__(c.n_output_dims, c.color_activation, c.requires_normal)
+
+
+# ------------------------------------------------------------------------------------------------ geometry
+def sample_points_uniformly(verts, faces, n, seed=0):
+    """Area-weighted uniform samples on the mesh surface (what open3d's ``sample_points_uniformly`` draws; its own
+    random stream is not reproduced -- the node set is random in the reference too)."""
+    rng = np.random.default_rng(seed)
+    v, f = np.asarray(verts, np.float64), np.asarray(faces, np.int64)
+    a, b, c = v[f[:, 0]], v[f[:, 1]], v[f[:, 2]]
+    area = 0.5 * np.linalg.norm(np.cross(b - a, c - a), axis=1)
+    tri = rng.choice(len(f), size=n, p=area / area.sum())
+    r1, r2 = np.sqrt(rng.random(n)), rng.random(n)
+    return ((1 - r1)[:, None] * a[tri] + (r1 * (1 - r2))[:, None] * b[tri] + (r1 * r2)[:, None] * c[tri]).astype(np.float32)
+
+
+def prune_isolated_points(verts, faces, colors):
+    """``SuGaRModel.prune_isolated_points`` (sugar.py:119-161): keep the first connected component (over the one-ring
+    graph, searched from vertex 0, 1, ...) that holds more than 75 % of the vertices, drop the faces that lose a corner."""
+    import scipy.sparse as sp
+    from scipy.sparse.csgraph import connected_components
+
+    V = len(verts)
+    e = np.concatenate([faces[:, [0, 1]], faces[:, [1, 2]], faces[:, [2, 0]]])
+    g = sp.coo_matrix((np.ones(len(e)), (e[:, 0], e[:, 1])), shape=(V, V))
+    _, lab = connected_components(g, directed=False)
+    size = np.bincount(lab)
+    big = [c for c in np.unique(lab) if size[c] > math.ceil(V * 0.75)]
+    if not big:
+        raise AssertionError("no connected component holds more than 75 % of the vertices")
+    first = min(int(np.nonzero(lab == c)[0][0]) for c in big)
+    keep = lab == lab[first]
+    new = -np.ones(V, np.int64)
+    new[keep] = np.arange(int(keep.sum()))
+    nf = new[faces]
+    return verts[keep], nf[(nf >= 0).all(axis=1)], colors[keep]
+
+
+def _load_mesh(cfg, o3d_mesh=None):
+    from .wire_formats import read_ply
+
+    if o3d_mesh is not None:             # anything with .vertices / .triangles / .vertex_colors (the reference passes an open3d mesh)
+        verts, faces = np.asarray(o3d_mesh.vertices, np.float64), np.asarray(o3d_mesh.triangles, np.int64)
+        colors = np.asarray(getattr(o3d_mesh, "vertex_colors", np.zeros((0, 3))), np.float64)
+    else:
+        if not cfg.surface_mesh_to_bind_path:
+            raise ValueError("surface_mesh_to_bind_path is empty: the mesh-bound geometry needs the refined mesh of the static stage")
+        m = read_ply(cfg.surface_mesh_to_bind_path)
+        verts, faces, colors = m["verts"], m["faces"], (m["colors"] if m["colors"] is not None else np.zeros((0, 3)))
+    if len(colors) == 0:
+        colors = np.ones_like(verts) * 0.5
+    return prune_isolated_points(verts, faces, colors)
+
+
+@dataclass
+class _SuGaRConfig:                                   # SuGaRModel.Config (sugar.py:35-72), BaseGeometry.Config
+    weights: Optional[str] = None
+    sh_levels: int = 1
+    position_lr: Any = 0.001
+    feature_lr: Any = 0.01
+    opacity_lr: Any = 0.05
+    scaling_lr: Any = 0.005
+    rotation_lr: Any = 0.005
+    learnable_positions: bool = False
+    triangle_scale: float = 1.0
+    n_gaussians_per_surface_triangle: int = 1
+    keep_track_of_knn: bool = False
+    knn_to_track: int = 16
+    beta_mode: str = "average"
+    primitive_types: str = "diamond"
+    surface_mesh_to_bind_path: str = ""
+    learn_surface_mesh_positions: bool = True
+    learn_surface_mesh_opacity: bool = True
+    learn_surface_mesh_scales: bool = True
+    freeze_gaussians: bool = False
+    spatial_lr_scale: float = 10.0
+    spatial_extent: float = 3.5
+    color_clip: Any = 2.0
+    gs_color_inherit_vertices: bool = True
+    init_gs_opacity: float = 0.5
+    geometry_convert_from: str = ""
+    square_size_in_texture: int = 10
+    pred_normal: bool = False
+    init_gs_scales_s: float = 1.7
+
+
+@register("sugar")
+class SuGaRModel(_sugar.SuGaR, Updateable):
+    Config = _SuGaRConfig
+
+    def __init__(self, cfg=None, o3d_mesh=None):
+        self.cfg = c = parse_structured(self.Config, cfg)
+        verts, faces, colors = _load_mesh(c, o3d_mesh)
+        super().__init__(verts, faces, n_gaussians_per_surface_triangle=c.n_gaussians_per_surface_triangle,
+                         spatial_extent=c.spatial_extent, vertex_colors=colors if c.gs_color_inherit_vertices else None,
+                         learn_positions=c.learn_surface_mesh_positions, learn_opacities=c.learn_surface_mesh_opacity,
+                         learn_scales=c.learn_surface_mesh_scales, freeze_gaussians=c.freeze_gaussians,
+                         position_lr=c.position_lr, feature_lr=c.feature_lr, opacity_lr=c.opacity_lr, scaling_lr=c.scaling_lr,
+                         rotation_lr=c.rotation_lr, spatial_lr_scale=c.spatial_lr_scale, init_gs_opacity=c.init_gs_opacity,
+                         init_gs_scales_s=c.init_gs_scales_s, color_clip=c.color_clip, device=get_device())
+        if c.weights is not None:
+            from .wire_formats import load_module_weights
+
+            path, module_name = c.weights.split(":")
+            state, epoch, step = load_module_weights(path, module_name=module_name, map_location="cpu")
+            self.load_state_dict(state, strict=False)
+            self.do_update_step(epoch, step, on_load_weights=True)
+
+
+@dataclass
+class _DynamicSuGaRConfig(_SuGaRConfig):              # DynamicSuGaRModel.Config (dynamic_sugar.py:44-74)
+    num_frames: int = 14
+    static_learnable: bool = False
+    use_deform_graph: bool = True
+    dynamic_mode: str = "deformation"
+    n_dg_nodes: int = 1000
+    dg_node_connectivity: int = 8
+    dg_trans_lr: Any = 0.001
+    dg_rot_lr: Any = 0.001
+    dg_scale_lr: Any = 0.001
+    vert_trans_lr: Any = 0.001
+    vert_rot_lr: Any = 0.001
+    vert_scale_lr: Any = 0.001
+    deformation_lr: Any = 0.001
+    grid_lr: Any = 0.001
+    d_xyz: bool = True
+    d_rotation: bool = True
+    d_opacity: bool = False
+    d_scale: bool = True
+    dist_mode: str = "eucdisc"
+    skinning_method: str = "hybrid"
+    dg_node_seed: int = 0                             # (not a reference key: seed of the node samples, see the module docstring)
+
+
+@register("dynamic-sugar")
+class DynamicSuGaRModel(_sugar.DynamicSuGaR, Updateable):
+    Config = _DynamicSuGaRConfig
+
+    def __init__(self, cfg=None, o3d_mesh=None):
+        from .graph_build import build_deformation_graph
+
+        self.cfg = c = parse_structured(self.Config, cfg)
+        if c.dynamic_mode != "deformation" or not c.use_deform_graph:
+            raise NotImplementedError("only dynamic_mode: deformation with use_deform_graph: true (the shipped configuration; "
+                                      "`discrete` + hybrid cannot even be constructed in the reference, SURVEY.md Appendix A)")
+        dev = get_device()
+        verts, faces, colors = _load_mesh(c, o3d_mesh)
+        nodes = sample_points_uniformly(verts, faces, c.n_dg_nodes, seed=c.dg_node_seed)
+        idx, w = build_deformation_graph(verts, faces, nodes, c.dg_node_connectivity, c.dist_mode, device=dev)
+        super().__init__(verts, faces, nodes, idx, w, n_gaussians_per_surface_triangle=c.n_gaussians_per_surface_triangle,
+                         skinning_method=c.skinning_method, spatial_extent=c.spatial_extent,
+                         vertex_colors=colors if c.gs_color_inherit_vertices else None, deformation_lr=c.deformation_lr,
+                         grid_lr=c.grid_lr, d_scale=c.d_scale, init_gs_opacity=c.init_gs_opacity,
+                         init_gs_scales_s=c.init_gs_scales_s, learn_opacities=c.learn_surface_mesh_opacity, device=dev)
+        self.num_frames, self.dynamic_mode = c.num_frames, c.dynamic_mode
+        if c.static_learnable:
+            raise NotImplementedError("static_learnable: true (the dynamic stage freezes the static SuGaR state, dynamic_sugar.py:79-87)")
+        if c.weights is not None:
+            from .wire_formats import load_geometry
+
+            path, _ = c.weights.split(":")
+            load_geometry(self, path, strict=False)
+
+
+# ------------------------------------------------------------------------------------------------ renderers
+@dataclass
+class _RasterizerConfig:                              # Rasterizer.Config -> Renderer.Config (renderers/base.py:17-19)
+    weights: Optional[str] = None
+    radius: float = 1.0
+    debug: bool = False
+    invert_bg_prob: float = 1.0
+    back_ground_color: Tuple = (1, 1, 1)
+
+
+class _RendererPlugin(Updateable):
+    Config = _RasterizerConfig
+
+    def _init_plugin(self, cfg, geometry, material, background):
+        self.cfg = parse_structured(self.Config, cfg)
+        self.configure(geometry, material, background)
+
+    def configure(self, geometry, material, background):
+        # non-owning references, as threestudio's Renderer keeps them (renderers/base.py:28-35)
+        self.sub_modules = {"geometry": geometry, "material": material, "background": background}
+
+    @property
+    def material(self):
+        return self.sub_modules["material"]
+
+    @property
+    def background(self):
+        return self.sub_modules["background"]
+
+
+@register("diff-sugar-rasterizer-temporal")
+class DiffGaussian(_renderer.DiffGaussianTemporal, _RendererPlugin):
+    def __init__(self, cfg=None, geometry=None, material=None, background=None):
+        self._init_plugin(cfg, geometry, material, background)
+        _renderer.DiffGaussianTemporal.__init__(self, geometry, back_ground_color=tuple(float(x) for x in self.cfg.back_ground_color))
+
+
+@register("diff-sugar-rasterizer-normal")
+class DiffSuGaR(_renderer.DiffSuGaRNormal, _RendererPlugin):
+    def __init__(self, cfg=None, geometry=None, material=None, background=None):
+        self._init_plugin(cfg, geometry, material, background)
+        _renderer.DiffSuGaRNormal.__init__(self, geometry, back_ground_color=tuple(float(x) for x in self.cfg.back_ground_color),
+                                           invert_bg_prob=self.cfg.invert_bg_prob)
+
+
+# ------------------------------------------------------------------------------------------------ guidance
+def _zero123_from_config(pretrained_config, pretrained_model_name_or_path, device):
+    """``load_model_from_config`` (guidance :53-73): the LatentDiffusion hyper-parameters from the model YAML
+    (load/zero123/sd-objaverse-finetune-c_concat-256.yaml), the weights from the checkpoint's ``state_dict``."""
+    import yaml
+
+    with open(pretrained_config) as fh:
+        conf = yaml.safe_load(fh)
+    p = conf["model"]["params"]
+    up, dd = p["unet_config"]["params"], p["first_stage_config"]["params"]["ddconfig"]
+    unet_kwargs = dict(in_channels=up["in_channels"], out_channels=up["out_channels"], model_channels=up["model_channels"],
+                       attention_resolutions=tuple(up["attention_resolutions"]), num_res_blocks=up["num_res_blocks"],
+                       channel_mult=tuple(up["channel_mult"]), num_heads=up["num_heads"], context_dim=up["context_dim"])
+    vae_kwargs = dict(ch=dd["ch"], ch_mult=tuple(dd["ch_mult"]), num_res_blocks=dd["num_res_blocks"], in_channels=dd["in_channels"],
+                      z_channels=dd["z_channels"])
+    with torch.device(device):
+        model = _z.Zero123(unet_kwargs=unet_kwargs, vae_kwargs=vae_kwargs, scale_factor=p.get("scale_factor", 0.18215),
+                           timesteps=p["timesteps"], linear_start=p["linear_start"], linear_end=p["linear_end"])
+    if not os.path.exists(pretrained_model_name_or_path):
+        raise FileNotFoundError(f"{pretrained_model_name_or_path}: the Zero123 checkpoint (load/zero123/download.sh) is not there")
+    sd = torch.load(pretrained_model_name_or_path, map_location="cpu")
+    missing = _z.load_zero123_state_dict(model, sd.get("state_dict", sd))
+    if missing:
+        raise KeyError(f"checkpoint lacks {len(missing)} tensors of the UNet / VAE encoder / cc_projection, e.g. {missing[:3]}")
+    return model
+
+
+@dataclass
+class _TemporalZero123Config:                         # TemporalStableZero123Guidance.Config (guidance :79-103)
+    pretrained_model_name_or_path: str = "load/zero123/stable-zero123.ckpt"
+    pretrained_config: str = "load/zero123/sd-objaverse-finetune-c_concat-256.yaml"
+    vram_O: bool = True
+    num_frames: int = 14
+    cond_video_dir: str = "load/videos/anya"
+    cond_elevation_deg: float = 0.0
+    cond_azimuth_deg: float = 0.0
+    cond_camera_distance: float = 1.2
+    guidance_scale: float = 5.0
+    grad_clip: Optional[Any] = None
+    half_precision_weights: bool = True
+    min_step_percent: float = 0.02
+    max_step_percent: float = 0.98
+    chunk_size: Optional[int] = None
+    cond_embeddings_path: Optional[str] = None        # (not a reference key, see the module docstring)
+
+
+def _load_embeddings(c, n):
+    if not c.cond_embeddings_path:
+        raise NotImplementedError("the CLIP image encoder of `prepare_embeddings` is not part of this package: pass the "
+                                  "conditioning embeddings as cond_embeddings_path (a torch file with c_crossattn, c_concat)")
+    e = torch.load(c.cond_embeddings_path, map_location="cpu")
+    cc, ct = e["c_crossattn"], e["c_concat"]
+    if cc.shape[0] < n or ct.shape[0] < n:
+        raise ValueError(f"{c.cond_embeddings_path}: {cc.shape[0]} frames of embeddings, the configuration names {n}")
+    return cc[:n], ct[:n]
+
+
+@register("temporal-stable-zero123-guidance")
+class TemporalStableZero123Guidance(_z.TemporalStableZero123Guidance, Updateable):
+    Config = _TemporalZero123Config
+    _frames_key = "num_frames"
+
+    def __init__(self, cfg=None, model=None):
+        """``model``: an already built ``zero123.Zero123`` (tests, random weights); otherwise the checkpoint is loaded."""
+        c = parse_structured(self.Config, cfg)
+        dev = get_device()
+        if model is None:
+            model = _zero123_from_config(c.pretrained_config, c.pretrained_model_name_or_path, dev)
+        cc, ct = _load_embeddings(c, getattr(c, self._frames_key) if self._frames_key else 1)
+        grad_clip = c.grad_clip
+        _z.TemporalStableZero123Guidance.__init__(
+            self, model, cc, ct, cond_elevation_deg=c.cond_elevation_deg, cond_azimuth_deg=c.cond_azimuth_deg,
+            guidance_scale=c.guidance_scale, min_step_percent=_scalar0(c.min_step_percent), max_step_percent=_scalar0(c.max_step_percent),
+            grad_clip=None if grad_clip is None else _scalar0(grad_clip), half_precision_weights=c.half_precision_weights)
+        self.cfg = c
+        self.to(dev)
+
+    def update_step(self, epoch, global_step, on_load_weights=False):
+        """guidance :376-388: the scheduled grad clip and the min / max timestep fractions."""
+        from .schedule import C
+
+        c = self.cfg
+        _z.TemporalStableZero123Guidance.update_step(
+            self, epoch, global_step, min_step_percent=C(c.min_step_percent, epoch, global_step),
+            max_step_percent=C(c.max_step_percent, epoch, global_step),
+            grad_clip=None if c.grad_clip is None else C(c.grad_clip, epoch, global_step))
+
+
+def _scalar0(v):
+    from .schedule import C
+
+    return C(v, 0, 0)
+
+
+@dataclass
+class _StaticZero123Config:                           # StableZero123Guidance.Config (stable_zero123_guidance.py:78-100)
+    pretrained_model_name_or_path: str = "load/zero123/stable-zero123.ckpt"
+    pretrained_config: str = "load/zero123/sd-objaverse-finetune-c_concat-256.yaml"
+    vram_O: bool = True
+    cond_image_path: str = "load/images/hamburger_rgba.png"
+    cond_elevation_deg: float = 0.0
+    cond_azimuth_deg: float = 0.0
+    cond_camera_distance: float = 1.2
+    guidance_scale: float = 5.0
+    grad_clip: Optional[Any] = None
+    half_precision_weights: bool = False
+    min_step_percent: float = 0.02
+    max_step_percent: float = 0.98
+    cond_embeddings_path: Optional[str] = None
+
+
+@register("stable-zero123-guidance")
+class StableZero123Guidance(TemporalStableZero123Guidance):
+    Config = _StaticZero123Config
+    _frames_key = None
+
+    def __call__(self, rgb, elevation, azimuth, camera_distances, rgb_as_latents=False, **kwargs):
+        fi = torch.zeros(rgb.shape[0], dtype=torch.long, device=rgb.device)     # one conditioning image
+        return _z.TemporalStableZero123Guidance.__call__(self, rgb, elevation, azimuth, camera_distances, frame_indices=fi,
+                                                         rgb_as_latents=rgb_as_latents, **kwargs)
+
+
+# ------------------------------------------------------------------------------------------------ optimiser
+def _get_parameters(model, name):
+    module = model
+    for part in name.split("."):
+        module = getattr(module, part)
+    if isinstance(module, nn.Module):
+        return module.parameters()
+    if isinstance(module, nn.Parameter):
+        return [module]
+    return []
+
+
+def parse_optimizer(config, model):
+    """``parse_optimizer`` (threestudio/systems/utils.py:55-89): ``config.params`` = {dotted module name: group args}
+    (else all parameters), ``config.name`` an optimiser of torch.optim, ``config.args`` its arguments."""
+    params = config.get("params")
+    if params is not None:
+        groups = [{"params": list(_get_parameters(model, name)), "name": name, **dict(args)} for name, args in params.items()]
+    else:
+        groups = list(model.parameters())
+    name = config["name"]
+    if name in ("FusedAdam", "Adan"):
+        raise NotImplementedError(f"optimizer {name} is an external package the shipped configurations do not use")
+    return getattr(torch.optim, name)(groups, **dict(config.get("args", {})))

@@ -1,0 +1,183 @@
+"""-m gpu: the plugins of the hot path constructed the way threestudio constructs them -- ``find(<x>_type)(cfg.<x>, *args)``
+-- from the ``system`` blocks of the two shipped configurations, then driven through one step.
+
+The blocks below are the keys / values of custom/threestudio-dreammesh4d/configs/sugar_dynamic_dg.yaml (:50-170) and
+configs/sugar_static_refine.yaml (:30-150), typed in (only what a run has to provide -- ``???`` entries, the mesh and the
+Zero123 checkpoint -- is filled with test stand-ins: a small sphere PLY, a reduced-width random-weight Zero123, seeded
+conditioning embeddings)."""
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+DATA = {"default_camera_distance": 3.8, "default_elevation_deg": 5.0, "default_azimuth_deg": 0.0, "default_fovy_deg": 20.0,
+        "video_length": 32, "height": 512, "width": 512}
+
+DYNAMIC_SYSTEM = {     # sugar_dynamic_dg.yaml, system:
+    "stage": "motion", "num_inter_frames": 10, "length_inter_frames": 0.1,
+    "geometry_type": "dynamic-sugar",
+    "geometry": {"num_frames": 32, "use_deform_graph": True, "dynamic_mode": "deformation", "n_dg_nodes": 1000, "dg_node_connectivity": 4,
+                 "dg_trans_lr": 0.002, "dg_rot_lr": 0.001, "dg_scale_lr": 0.001, "vert_trans_lr": 0.001, "vert_rot_lr": 0.001,
+                 "vert_scale_lr": 0.001, "deformation_lr": 0.00032, "grid_lr": 0.0032, "d_scale": False,
+                 "spatial_extent": "${data.default_camera_distance}", "spatial_lr_scale": 1, "surface_mesh_to_bind_path": "",
+                 "n_gaussians_per_surface_triangle": 6, "dist_mode": "geodisc", "skinning_method": "hybrid"},
+    "renderer_type": "diff-sugar-rasterizer-temporal", "renderer": {"debug": False, "invert_bg_prob": 1.0},
+    "material_type": "no-material", "material": {"n_output_dims": 0},
+    "background_type": "solid-color-background",
+    "guidance_zero123_type": "temporal-stable-zero123-guidance",
+    "guidance_zero123": {"num_frames": "${data.video_length}", "pretrained_config": "./load/zero123/sd-objaverse-finetune-c_concat-256.yaml",
+                         "pretrained_model_name_or_path": "???", "vram_O": "${not:${gt0:${system.freq.guidance_eval}}}",
+                         "cond_video_dir": "???", "cond_elevation_deg": "${data.default_elevation_deg}",
+                         "cond_azimuth_deg": "${data.default_azimuth_deg}", "cond_camera_distance": "${data.default_camera_distance}",
+                         "guidance_scale": 3.0, "min_step_percent": 0.02, "max_step_percent": 0.5, "chunk_size": None},
+    "freq": {"ref_only_steps": 0, "guidance_eval": 0, "inter_frame_reg": 0, "milestone_arap_reg": 100},
+    "loss": {"lambda_sds_zero123": 0.1, "lambda_rgb": 5000.0, "lambda_mask": [200, 500.0, 5000.0, 1000], "lambda_depth": 0.0,
+             "lambda_normal_consistency": 100.0, "lambda_arap_reg_key_frame": 10.0, "lambda_arap_reg_inter_frame": 10.0},
+    "optimizer": {"name": "Adam", "args": {"lr": 0.01, "betas": [0.9, 0.99], "eps": 1.0e-15}, "params": {"background": {"lr": 0.001}}},
+}
+
+STATIC_SYSTEM = {      # sugar_static_refine.yaml, system:
+    "stage": "sugar",
+    "geometry_type": "sugar",
+    "geometry": {"position_lr": 0.00048, "feature_lr": 0.001, "opacity_lr": 0.02, "scaling_lr": 0.005, "rotation_lr": 0.001,
+                 "spatial_extent": "${data.default_camera_distance}", "spatial_lr_scale": 1, "n_gaussians_per_surface_triangle": 6,
+                 "learnable_positions": True, "surface_mesh_to_bind_path": "???", "init_gs_opacity": 0.9, "init_gs_scales_s": 1.3},
+    "renderer_type": "diff-sugar-rasterizer-normal", "renderer": {"debug": False, "invert_bg_prob": 1.0},
+    "material_type": "no-material", "material": {"n_output_dims": 0},
+    "background_type": "solid-color-background",
+    "guidance_type": "stable-zero123-guidance",
+    "guidance": {"pretrained_config": "./load/zero123/sd-objaverse-finetune-c_concat-256.yaml", "pretrained_model_name_or_path": "???",
+                 "vram_O": "${not:${gt0:${system.freq.guidance_eval}}}", "cond_image_path": "load/images/x_rgba.png",
+                 "cond_elevation_deg": "${data.default_elevation_deg}", "cond_azimuth_deg": "${data.default_azimuth_deg}",
+                 "cond_camera_distance": "${data.default_camera_distance}", "guidance_scale": 3.5, "min_step_percent": 0.02,
+                 "max_step_percent": 0.2},
+    "freq": {"ref_only_steps": 0, "guidance_eval": 0, "input_normal": 10000, "start_sugar_reg": 3000, "reset_neighbors": 50},
+    "loss": {"lambda_sds": 0.01, "lambda_rgb": 1000.0, "lambda_mask": 100.0, "lambda_normal_consistency": 10.0, "lambda_laplacian_smoothing": 1.0},
+    "optimizer": {"name": "Adam", "args": {"lr": 0.01, "betas": [0.9, 0.99], "eps": 1.0e-15}, "params": {"background": {"lr": 0.001}}},
+}
+
+
+def _stand_ins(tmp_path, n_frames, dev):
+    """What a run provides next to the YAML: the refined mesh (PLY), the Zero123 model, the conditioning embeddings."""
+    from dreammesh4d_amd import synthetic as syn, wire_formats as wf, zero123 as z
+
+    v, f = syn.uv_sphere(6000, radius=0.6)
+    mesh = str(tmp_path / "exported_mesh.ply")
+    wf.write_ply(mesh, np.asarray(v), np.asarray(f), colors=np.random.default_rng(0).random((len(v), 3)))
+    torch.manual_seed(0)
+    model = z.Zero123(unet_kwargs=dict(model_channels=32, context_dim=32, num_heads=4), vae_kwargs=dict(ch=32)).to(dev)
+    for p in model.model.diffusion_model.out.parameters():
+        torch.nn.init.normal_(p, std=0.05)
+    emb = str(tmp_path / "cond_embeddings.pt")
+    torch.save({"c_crossattn": torch.randn(n_frames, 1, 32), "c_concat": torch.randn(n_frames, 4, 32, 32)}, emb)
+    return mesh, model, emb
+
+
+def _batch(B, H, W, dev, timestamps=None):
+    from dreammesh4d_amd import renderer as R, synthetic as syn
+
+    fovy = math.radians(20.0)
+    c2w = torch.stack([torch.tensor(syn.orbit_c2w(10.0 + 15 * b, 40.0 * b, 3.8), dtype=torch.float32) for b in range(B)]).to(dev)
+    dirs = R.ray_directions(H, W, 0.5 * H / math.tan(0.5 * fovy), device=dev)
+    rays_o, rays_d = R.rays(dirs, c2w)
+    batch = {"c2w": c2w, "fovy": torch.full((B,), fovy, device=dev), "height": H, "width": W, "rays_o": rays_o, "rays_d": rays_d}
+    if timestamps is not None:
+        batch["timestamp"] = timestamps
+        batch["frame_indices"] = torch.arange(B, device=dev)
+    return batch
+
+
+def test_dynamic_stage_plugins_from_the_shipped_config_block(tmp_path):
+    if not torch.cuda.is_available():
+        pytest.skip("no HIP device")
+    from dreammesh4d_amd import threestudio_host as ts
+    from dreammesh4d_amd.schedule import C
+
+    dev = torch.device("cuda:0")
+    mesh, model, emb = _stand_ins(tmp_path, 32, dev)
+    cfg = ts.resolve({"data": DATA, "system": DYNAMIC_SYSTEM})["system"]
+    cfg["geometry"]["surface_mesh_to_bind_path"] = mesh                      # the `???` / command-line entries of a run
+    cfg["guidance_zero123"].update(pretrained_model_name_or_path="(test: model passed in)", cond_video_dir="(test)", cond_embeddings_path=emb)
+    # ---- what BaseLift3DSystem.configure does (threestudio/systems/base.py:262-282): find(type)(cfg, ...)
+    geometry = ts.find(cfg["geometry_type"])(cfg["geometry"])
+    material = ts.find(cfg["material_type"])(cfg["material"])
+    background = ts.find(cfg["background_type"])(cfg.get("background"))
+    renderer = ts.find(cfg["renderer_type"])(cfg["renderer"], geometry=geometry, material=material, background=background)
+    guidance = ts.find(cfg["guidance_zero123_type"])(cfg["guidance_zero123"], model=model)
+    assert geometry.cfg.spatial_extent == 3.8 and geometry.cfg.dg_node_connectivity == 4 and geometry.skinning_method == "hybrid"
+    assert geometry._xyz_neighbor_node_idx.shape == (geometry.n_verts, 4) and geometry._deform_graph_node_xyz.shape == (1000, 3)
+    assert abs(float(geometry.surface_mesh_thickness) - 3.8e-6) < 1e-12 and geometry.n_gaussians == geometry.n_faces * 6
+    assert not any(p.requires_grad for p in (geometry._points, geometry._scales, geometry.all_densities, geometry._sh_coordinates_dc))
+    assert renderer.geometry is geometry and renderer.material is material and renderer.background is background
+    assert guidance.cfg.num_frames == 32 and guidance.cfg.vram_O is True and guidance.guidance_scale == 3.0 and guidance.max_step == 500
+    # ---- configure_optimizers (C/system/sugar_4dgen.py:66-76): parse_optimizer(cfg.optimizer, self) merged into the geometry's AdamW
+    system = torch.nn.Module()
+    system.geometry, system.background = geometry, background
+    opt = geometry.merge_optimizer(ts.parse_optimizer(cfg["optimizer"], system))
+    names = [g.get("name") for g in opt.param_groups]
+    assert isinstance(opt, torch.optim.AdamW) and names[:2] == ["deformation", "grid"] and len(opt.param_groups) == 3
+    # perturb the zero-initialised heads so that the mesh moves
+    with torch.no_grad():
+        for n, p in geometry._deformation.named_parameters():
+            if "_deform" in n:
+                p.add_(0.01 * torch.randn_like(p))
+    # ---- one training substep the way the system drives the plugins
+    for m in (geometry, renderer, guidance):
+        m.do_update_step(0, 0)
+    geometry.update_learning_rate(0)
+    B, H, W = 4, 256, 256
+    ts_ = torch.linspace(0, 1, 34, device=dev)[1:-1][[3, 3, 17, 17]]
+    out = renderer.batch_forward(_batch(B, H, W, dev, timestamps=ts_))
+    assert set(out) >= {"comp_rgb", "comp_normal", "comp_normal_from_dist", "comp_depth", "comp_mask", "viewspace_points", "visibility_filter", "radii"}
+    assert out["comp_rgb"].shape == (B, H, W, 3) and out["comp_mask"].shape == (B, H, W, 1)
+    g = guidance(out["comp_rgb"], torch.tensor([10.0, 25.0, 40.0, 55.0], device=dev), torch.tensor([0.0, 40.0, 80.0, 120.0], device=dev),
+                 torch.full((B,), 3.8, device=dev), frame_indices=torch.tensor([3, 3, 17, 17], device=dev))
+    loss = C(cfg["loss"]["lambda_sds_zero123"], 0, 0) * g["loss_sds"] + C(cfg["loss"]["lambda_mask"], 0, 0) * out["comp_mask"].mean()
+    before = [p.detach().clone() for p in geometry._deformation.get_mlp_parameters()]
+    opt.zero_grad()
+    loss.backward()
+    opt.step()
+    assert any(not torch.equal(a, b) for a, b in zip(before, geometry._deformation.get_mlp_parameters()))
+    assert all(torch.isfinite(p).all() for p in geometry._deformation.parameters())
+    assert out["viewspace_points"][0].grad is not None
+
+
+def test_static_stage_plugins_from_the_shipped_config_block(tmp_path):
+    if not torch.cuda.is_available():
+        pytest.skip("no HIP device")
+    from dreammesh4d_amd import threestudio_host as ts
+
+    dev = torch.device("cuda:0")
+    mesh, model, emb = _stand_ins(tmp_path, 1, dev)
+    cfg = ts.resolve({"data": DATA, "system": STATIC_SYSTEM})["system"]
+    with pytest.raises(ValueError):
+        ts.find("sugar")(cfg["geometry"])                                     # surface_mesh_to_bind_path: ??? not provided
+    cfg["geometry"]["surface_mesh_to_bind_path"] = mesh
+    cfg["guidance"].update(pretrained_model_name_or_path="(test: model passed in)", cond_embeddings_path=emb)
+    geometry = ts.find(cfg["geometry_type"])(cfg["geometry"])
+    renderer = ts.find(cfg["renderer_type"])(cfg["renderer"], geometry=geometry, material=ts.find(cfg["material_type"])(cfg["material"]),
+                                             background=ts.find(cfg["background_type"])(None))
+    guidance = ts.find(cfg["guidance_type"])(cfg["guidance"], model=model)
+    assert abs(float(torch.sigmoid(geometry.all_densities[0])) - 0.9) < 1e-6                     # init_gs_opacity: 0.9
+    lr = {g["name"]: g["lr"] for g in geometry.optimizer.param_groups}
+    assert lr["points"] == 0.00048 * 1 and lr["f_dc"] == 0.001 and lr["all_densities"] == 0.02 and lr["quaternions"] == 0.001
+    assert geometry.color_clip == 2.0 and guidance.guidance_scale == 3.5 and guidance.max_step == 200 and guidance.weights_dtype == torch.float32
+    # colours leave [-clip, clip] / go negative: the rendered colour is clamped with a zero gradient there (advisor finding)
+    with torch.no_grad():
+        geometry._sh_coordinates_dc[0] = 5.0
+        geometry._sh_coordinates_dc[1] = -3.0
+    rgb = geometry.get_rendered_rgb()
+    assert abs(float(rgb[0, 0]) - (0.28209479177387814 * 2.0 + 0.5)) < 1e-6 and float(rgb[1, 0]) == 0.0
+    B, H, W = 2, 256, 256
+    out = renderer.batch_forward(_batch(B, H, W, dev))
+    g = guidance(out["comp_rgb"], torch.tensor([10.0, 25.0], device=dev), torch.tensor([0.0, 40.0], device=dev), torch.full((B,), 3.8, device=dev))
+    opt = geometry.merge_optimizer(None)
+    (g["loss_sds"] + out["comp_mask"].mean() + out["comp_normal"].mean()).backward()
+    assert not geometry._sh_coordinates_dc.grad[0].any() and not geometry._sh_coordinates_dc.grad[1].any()    # clipped / clamped: no gradient
+    assert geometry._sh_coordinates_dc.grad[2:].abs().sum() > 0 and geometry._points.grad.abs().sum() > 0
+    opt.step()
+    assert all(torch.isfinite(p).all() for p in geometry.parameters())

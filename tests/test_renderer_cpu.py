@@ -73,10 +73,10 @@ def test_plugin_names_cover_the_reference_registry_entries_of_the_hot_path():
     assert set(plugins.PLUGINS) == {"diff-sugar-rasterizer-temporal", "diff-sugar-rasterizer-normal", "dynamic-sugar", "sugar",
                                     "temporal-stable-zero123-guidance", "stable-zero123-guidance", "solid-color-background",
                                     "no-material"}
-    bgm = plugins.PLUGINS["solid-color-background"](color=(0.2, 0.4, 0.6)).eval()
+    bgm = plugins.PLUGINS["solid-color-background"]({"color": (0.2, 0.4, 0.6)}).eval()
     out = bgm(torch.zeros(2, 3, 5, 3))
     assert out.shape == (2, 3, 5, 3) and torch.allclose(out[1, 2, 4], torch.tensor([0.2, 0.4, 0.6]))
-    aug = plugins.PLUGINS["solid-color-background"](random_aug=True, random_aug_prob=1.0).train()(torch.zeros(2, 3, 5, 3))
+    aug = plugins.PLUGINS["solid-color-background"]({"random_aug": True, "random_aug_prob": 1.0}).train()(torch.zeros(2, 3, 5, 3))
     assert torch.equal(aug[0, 0, 0], aug[0, 2, 4]) and not torch.equal(aug[0, 0, 0], aug[1, 0, 0])      # one colour per batch item
     mat = plugins.PLUGINS["no-material"]()
     assert torch.allclose(mat(torch.zeros(4, 3)), torch.full((4, 3), 0.5))
