@@ -166,7 +166,8 @@ class _RasterizeGaussians(torch.autograd.Function):
                 grad.data_ptr(), R, g_color.data_ptr(), _ptr(g_depth), _ptr(g_alpha), _ptr(d_m2), _ptr(d_m3),
                 _ptr(d_op), _ptr(d_col), _ptr(d_sh), _ptr(d_sc), _ptr(d_rot), _ptr(d_cov), st),
                 "dm4d_rasterize_backward")
-        ctx.call = None
+        # ctx.call stays (it only holds the detached inputs, the workspaces are saved tensors the C backward does not
+        # modify): a second backward through the operator -- retain_graph=True, two losses -- works as upstream's does
 
         def shaped(t, shape):
             return None if t is None or len(shape) == 0 or 0 in shape else t.reshape(shape)

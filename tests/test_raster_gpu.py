@@ -345,6 +345,19 @@ def test_autograd_operator_matches_oracle():
     _assert_grads(got, og, o=o)
     vis = rast.markVisible(m3)
     assert vis.dtype == torch.bool and bool(vis.all())
+    # a second backward through the same graph (retain_graph, or two losses back-propagated separately): same gradients
+    c2, _, _, a2 = rast(means3D=m3, means2D=m2, opacities=op, colors_precomp=col, scales=scl, rotations=rot)
+    l1, l2 = (c2 * T(gC)).sum(), (a2 * T(gA)).sum()
+    for t in (m3, m2, op, col, scl, rot):
+        t.grad = None
+    l1.backward(retain_graph=True)
+    g_first = m3.grad.clone()
+    l2.backward()
+    both = m3.grad.clone()
+    for t in (m3, m2, op, col, scl, rot):
+        t.grad = None
+    (l1 + l2).backward()
+    assert torch.isfinite(g_first).all() and torch.allclose(m3.grad, both, rtol=1e-4, atol=1e-6 * float(both.abs().max()))
 
 
 def test_record_count_matches_the_cell_blocks():
