@@ -90,3 +90,58 @@ def test_shard_frames_covers_the_timeline():
     assert seen == set(range(32))
     assert D.shard_frames(32, 0, 1, 4, iteration=3) == [12, 13, 14, 15]
     assert D.world() == 1 and D.rank() == 0
+
+
+def _worker_sharded(rank, world, port, out):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+
+    def build():
+        torch.manual_seed(0)
+        grid = torch.nn.Parameter(torch.randn(1, 4, 5, 6))          # a "plane": gradient only at the touched elements
+        mlp = torch.nn.Linear(6, 3)
+        unused = torch.nn.Parameter(torch.ones(5))
+        return grid, mlp, unused
+
+    idx = torch.tensor([3, 17, 18, 64, 119])
+    results = {}
+    for mode in ("replicated", "sharded"):
+        grid, mlp, unused = build()
+        groups = [{"params": list(mlp.parameters()) + [unused], "lr": 3.2e-4, "name": "deformation"}, {"params": [grid], "lr": 3.2e-3, "name": "grid"}]
+        params = list(mlp.parameters()) + [unused, grid]
+        red = D.GradAllReducer(params, touched={grid: idx})
+        opt = torch.optim.AdamW(groups, lr=0.0, betas=(0.9, 0.99), eps=1e-15, foreach=False) if mode == "replicated" else \
+            D.ShardedAdamW(groups, red, betas=(0.9, 0.99), eps=1e-15)
+        for it in range(3):
+            opt.zero_grad(set_to_none=True)
+            x = torch.full((2, 6), float(rank + 1 + it))
+            loss = mlp(x).pow(2).sum() + (grid.view(-1)[idx] * float(rank + 2)).pow(2).sum()      # unused gets no gradient
+            loss.backward()
+            for g in (opt.param_groups):
+                g["lr"] = g["lr"] * 0.9                                 # a schedule, as update_learning_rate applies
+            if mode == "replicated":
+                red()
+            opt.step()
+        results[mode] = [p.detach().clone() for p in params]
+        if mode == "sharded":
+            results["state_elems"] = opt.exp_avg.numel()
+            results["message"] = red.flat.numel()
+    out[rank] = results
+    dist.destroy_process_group()
+
+
+def test_sharded_adamw_matches_the_replicated_step_world2():
+    """reduce-scatter -> AdamW on 1/world of the message -> all-gather == all-reduce -> replicated torch AdamW: identical
+    parameters on both ranks after 3 steps with changing learning rates, incl. a parameter that never gets a gradient
+    and the untouched elements of a structured-sparse plane (weight decay only)."""
+    world = 2
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker_sharded, args=(world, _free_port(), out), nprocs=world, join=True)
+    a, b = out[0], out[1]
+    for pa, pb in zip(a["sharded"], b["sharded"]):
+        assert torch.equal(pa, pb)                                            # replicas stay identical
+    for ps, pr in zip(a["sharded"], a["replicated"]):
+        assert torch.allclose(ps, pr, rtol=1e-6, atol=1e-7), (ps - pr).abs().max()
+    assert not torch.equal(a["replicated"][-1], torch.zeros_like(a["replicated"][-1]))
+    assert a["state_elems"] == (a["message"] + 1) // 2                        # each rank holds half of the moments

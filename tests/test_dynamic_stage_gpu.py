@@ -96,3 +96,38 @@ def test_iteration_with_zero123_sds_runs_and_updates_the_network():
     after = stage.net.get_mlp_parameters()
     assert any(not torch.equal(a, b) for a, b in zip(after, before))
     assert stage.guidance.max_step == 500 and stage.guidance.min_step == 20      # yaml:118-119 (0.02 / 0.5)
+
+
+def _torchrun(args, env=None, timeout=600):
+    import os, socket, subprocess, sys
+
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    e = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", **(env or {}))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port)] + args
+    return subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=e, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+@pytest.mark.parametrize("mode", ["replicated", "sharded"])
+def test_two_rank_rehearsal_replicas_stay_identical(mode):
+    """The N > 1 control flow end to end with 2 ranks sharing the one GPU of the box over gloo: frames sharded, the
+    structured-sparse gradient exchange, AdamW (replicated after an all-reduce, or sharded: reduce-scatter -> AdamW on the
+    slice -> all-gather): bit-identical parameters on both ranks after 2 iterations."""
+    if not torch.cuda.is_available():
+        pytest.skip("no HIP device")
+    r = _torchrun(["tests/dp_rehearsal_worker.py", mode])
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    assert f"DP_REHEARSAL_OK mode={mode}" in r.stdout, r.stdout[-2000:]
+
+
+def test_bench_rehearsal_two_ranks_over_gloo():
+    """bench.py's own N = 2 launch line (torch.distributed.run, one rank per GPU) in its rehearsal mode."""
+    if not torch.cuda.is_available():
+        pytest.skip("no HIP device")
+    import json
+
+    r = _torchrun(["bench.py", "--gpus", "2", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-iters"], env={"DM4D_BENCH_BACKEND": "gloo"})
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["steps"] == 2 and "REHEARSAL" in line["data"]
+    assert line["config"]["allreduce_bytes_per_step"] == line["config"]["allreduce_message_bytes"] < line["config"]["dense_gradient_bytes"] / 5
