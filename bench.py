@@ -105,6 +105,13 @@ class Workload:
         self.gA = torch.randn(B, 1, H, W, generator=g).to(dev)
         self.render_views = views.render_views
 
+    def set_static_learnable(self, flag):
+        """False (the dynamic stage: static_learnable = False, dynamic_sugar.py:79-87): the blend backward neither reduces nor
+        records dL/dopacity, dL/d rgb, dL/dscales (lean records).  True: the FULL backward (what sugar_static_refine trains)."""
+        for t in (self.scales, self.opac, self.rgb):
+            t.requires_grad_(flag)
+            t.grad = None
+
     def step(self):
         self.net.zero_grad(set_to_none=True)
         # node attributes once per distinct timestamp of the step (cached per step in the reference,
@@ -183,6 +190,25 @@ def main():
     tot_ms = ctypes.c_double(0.0)
     n_launch = L.dm4d_profile_collect(K_RENDER_BWD, ctypes.byref(tot_ms))
     D_mean = float(np.mean(D_views))
+    # the same steps with the static appearance learnable: the FULL (non-lean) blend backward, reported beside the headline
+    full = None
+    if world == 1:
+        wl.set_static_learnable(True)
+        for _ in range(5):
+            step()
+        sync()
+        L.dm4d_profile_enable(1 << K_RENDER_BWD)
+        t1 = time.perf_counter()
+        n_full = min(args.steps, 20)
+        for _ in range(n_full):
+            step()
+        sync()
+        el_full = time.perf_counter() - t1
+        L.dm4d_profile_enable(0)
+        fm = ctypes.c_double(0.0)
+        fn = L.dm4d_profile_collect(K_RENDER_BWD, ctypes.byref(fm))
+        full = (el_full / n_full, fm.value / max(fn, 1) * 1e-3, int(fn))
+        wl.set_static_learnable(False)
 
     if rank == 0:
         units = world * VIEWS_PER_STEP * args.steps
@@ -198,11 +224,11 @@ def main():
         V = len(wl.sc["verts"])
         b_view = 2 * ((104 * N + 84 * D_mean + 28 * H * W) + (228 * N + 48 * D_mean + 40 * H * W)) + 40 * V + 28 * N + 12288 * N_NODES
         # HBM traffic of the dominant kernel per launch from the committed PMC passes of this same workload
-        # (profiles/r01_pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs, FETCH_SIZE x2
+        # (profiles/r02_pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs, FETCH_SIZE x2
         # per MI355X_MICROARCH.md's gfx950 correction).  The workload is seeded, so it is launch-invariant.
         traffic = None
         try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")))
             # the stage = the regular kernel + the long-cell kernel that runs beside it (both inside the timed scope)
             traffic = round(sum(v["bytes_corrected"] for k, v in pmc.items() if k.startswith("dm4d::k_render_bwd")))
         except Exception:
@@ -221,12 +247,18 @@ def main():
                        "whole_view_frac_of_hbm_roofline":
                            round(value / world * b_view / (HBM_PEAK_GBS * 1e9), 5),
                        "parallelism": f"dp{world} (frames sharded, 1 grad all-reduce/step)" if world > 1 else "single GPU"},
-            "roofline": {"bound": "hbm", "kernel": "k_render_bwd<6, true> (one launch per step, batched over its views: long-cell blocks first, then the quadrants)",
+            "roofline": {"bound": "hbm", "kernel": "k_render_bwd<6, true> (entry-parallel blend backward, one launch per step batched over its views: wide blocks for the long cells first, then the quadrants)",
                          "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                          "alg_bytes_per_launch": round(alg_bytes), "avg_launch_us": round(avg_s * 1e6, 2),
                          "launches_timed": int(n_launch)},
         }
+        if full is not None:
+            fa = alg_bytes / full[1] / 1e9 if full[1] > 0 else 0.0
+            out["roofline_full"] = {"bound": "hbm", "kernel": "k_render_bwd<6, false> (static appearance learnable: dL/dopacity, dL/d rgb, dL/dscales reduced and recorded too)",
+                                    "achieved": round(fa, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(fa / HBM_PEAK_GBS, 5),
+                                    "alg_bytes_per_launch": round(alg_bytes), "avg_launch_us": round(full[1] * 1e6, 2), "launches_timed": full[2],
+                                    "ms_per_step": round(full[0] * 1e3, 4), "views_per_s": round(VIEWS_PER_STEP / full[0], 1)}
         if world == 1 and not args.no_iters:
             # BASELINE.json's second metric, reported beside the headline one (never used for `value`)
             try:

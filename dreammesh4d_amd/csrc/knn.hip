@@ -2,13 +2,24 @@
 // nearest other points (call site: custom/threestudio-dreammesh4d/geometry/gaussian_base.py:435-438;
 // the CUDA package DSaurus/simple-knn is un-vendored, requirements.txt:50).
 //
-// It is a one-off at geometry initialisation, not part of the per-iteration loop, so the design
-// goal is exactness and simplicity: an LDS-tiled exhaustive search.  Every workgroup stages 1024
-// candidate points (12 KB) at a time in LDS with coalesced loads and each lane keeps its 3 best
-// squared distances in registers; LDS reads are broadcasts.  N = 200k -> 4e10 pair evaluations,
-// ~30 ms on MI355X; upstream's Morton-box pruning returns the same values (it is exact too).
-// d2 = (dx*dx + dy*dy) + dz*dz without contraction, result = ((b0 + b1) + b2) / 3 with
-// b0 <= b1 <= b2 -- the arithmetic contract that makes the output bit-identical to the checker.
+// Two exact searches behind one arithmetic contract (d2 = (dx*dx + dy*dy) + dz*dz without contraction,
+// result = ((b0 + b1) + b2) / 3 with b0 <= b1 <= b2: bit-identical to the checker, whatever the search order):
+//   * dm4d_dist2_knn3: LDS-tiled exhaustive search, O(N^2), no scratch -- small clouds.
+//   * dm4d_dist2_knn3_ws: the upstream structure (bounds -> Morton codes -> sort -> boxes of 1024
+//     consecutive points with their min / max corner -> per point, only the boxes that can hold something closer than
+//     its current third-best), restated for wave64:
+//       K11 k_knn_bounds   min / max corner of the cloud (integer atomics on order-preserving keys: deterministic)
+//       K12 k_knn_codes    18-bit Morton prefix (6 bits per axis) of every point + bucket histogram
+//           k_knn_scan     exclusive scan of the 262,144 bucket counts (one workgroup)
+//           k_knn_scatter  points into bucket order (a counting sort on the Morton prefix: the order INSIDE a bucket
+//                          depends on atomic cursors and is irrelevant -- any spatially coherent order gives the same,
+//                          exact, result)
+//       K13 k_knn_boxes    min / max corner of every box of 1024 consecutive sorted points
+//       K14 k_knn_search   a WAVE = 64 consecutive sorted points (neighbours in space): its own box first, then every box
+//                          one of its lanes still needs (ballot); the box's points are read by all lanes at once
+//                          (uniform addresses: scalar loads) and EVERY lane tries them -- an extra candidate can only
+//                          improve a lane's three best, never break exactness.
+//     1 M points: ~8 boxes per wave instead of 977.
 #include <float.h>
 
 #include "common.h"
@@ -18,6 +29,16 @@ namespace dm4d {
 
 constexpr int kKnnThreads = 256;
 constexpr int kKnnTile = 1024;
+
+__device__ __forceinline__ void push3(float &b0, float &b1, float &b2, const float dd)
+{
+    // branch-free insertion into the sorted triple
+    const float n2 = fminf(b2, fmaxf(b1, dd));
+    const float n1 = fminf(b1, fmaxf(b0, dd));
+    b0 = fminf(b0, dd);
+    b1 = n1;
+    b2 = n2;
+}
 
 __global__ __launch_bounds__(kKnnThreads) void k_dist2_knn3(int N, const float *__restrict__ pts, float *__restrict__ out)
 {
@@ -39,15 +60,175 @@ __global__ __launch_bounds__(kKnnThreads) void k_dist2_knn3(int N, const float *
             const float dx = px - s_x[j], dy = py - s_y[j], dz = pz - s_z[j];
             float dd = (dx * dx + dy * dy) + dz * dz;
             dd = (base + j == i) ? FLT_MAX : dd;        // exclude self by index (duplicates count)
-            // branch-free insertion into the sorted triple
-            const float n2 = fminf(b2, fmaxf(b1, dd));
-            const float n1 = fminf(b1, fmaxf(b0, dd));
-            b0 = fminf(b0, dd);
-            b1 = n1;
-            b2 = n2;
+            push3(b0, b1, b2, dd);
         }
     }
     if (i < N) out[i] = ((b0 + b1) + b2) / 3.0f;
+}
+
+// ---------------------------------------------------------------------------------------- box-pruned search
+constexpr int kKnnBits = 6;                          // Morton bits per axis of the bucket key
+constexpr int kKnnBuckets = 1 << (3 * kKnnBits);     // 262,144
+constexpr int kKnnBox = 1024;                        // points per box (upstream's BOX_SIZE)
+
+struct KnnLayout {
+    size_t bounds, hist, cursor, key, sx, sy, sz, sidx, bmin, bmax, total;
+};
+static inline KnnLayout knn_layout(int N)
+{
+    KnnLayout L;
+    size_t o = 0;
+    const size_t n = (size_t)(N > 0 ? N : 1), nb = (n + kKnnBox - 1) / kKnnBox;
+    L.bounds = take_(o, 6 * 4);
+    L.hist = take_(o, ((size_t)kKnnBuckets + 1) * 4);
+    L.cursor = take_(o, (size_t)kKnnBuckets * 4);
+    L.key = take_(o, n * 4);
+    L.sx = take_(o, n * 4); L.sy = take_(o, n * 4); L.sz = take_(o, n * 4); L.sidx = take_(o, n * 4);
+    L.bmin = take_(o, nb * 12); L.bmax = take_(o, nb * 12);
+    L.total = o;
+    return L;
+}
+
+// order-preserving float <-> uint (for integer atomicMin / atomicMax)
+__device__ __forceinline__ uint32_t f2key(float f) { const uint32_t u = __float_as_uint(f); return (u & 0x80000000u) ? ~u : (u | 0x80000000u); }
+__device__ __forceinline__ float key2f(uint32_t k) { return __uint_as_float((k & 0x80000000u) ? (k & 0x7FFFFFFFu) : ~k); }
+
+__global__ void k_knn_init(uint32_t *bounds, uint32_t *hist)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < 3) { bounds[i] = 0xFFFFFFFFu; bounds[3 + i] = 0u; }
+    if (i <= kKnnBuckets) hist[i] = 0u;
+}
+__global__ __launch_bounds__(kKnnThreads) void k_knn_bounds(int N, const float *__restrict__ pts, uint32_t *bounds)
+{
+    __shared__ uint32_t s[6];
+    if (threadIdx.x < 3) { s[threadIdx.x] = 0xFFFFFFFFu; s[3 + threadIdx.x] = 0u; }
+    __syncthreads();
+    for (int i = blockIdx.x * kKnnThreads + threadIdx.x; i < N; i += gridDim.x * kKnnThreads)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const uint32_t key = f2key(pts[3 * (size_t)i + k]);
+            atomicMin(&s[k], key);
+            atomicMax(&s[3 + k], key);
+        }
+    __syncthreads();
+    if (threadIdx.x < 3) { atomicMin(&bounds[threadIdx.x], s[threadIdx.x]); atomicMax(&bounds[3 + threadIdx.x], s[3 + threadIdx.x]); }
+}
+__global__ __launch_bounds__(kKnnThreads) void k_knn_codes(int N, const float *__restrict__ pts, const uint32_t *__restrict__ bounds,
+                                                            uint32_t *__restrict__ key, uint32_t *hist)
+{
+    const int i = blockIdx.x * kKnnThreads + threadIdx.x;
+    if (i >= N) return;
+    uint32_t code = 0;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const float mn = key2f(bounds[k]), mx = key2f(bounds[3 + k]);
+        const float ext = mx - mn;
+        float t = ext > 0.f ? (pts[3 * (size_t)i + k] - mn) / ext : 0.f;
+        t = fminf(fmaxf(t, 0.f), 1.f);
+        uint32_t c = (uint32_t)(t * (float)((1 << kKnnBits) - 1));
+        c = min(c, (uint32_t)((1 << kKnnBits) - 1));
+        uint32_t r = 0;
+#pragma unroll
+        for (int b = 0; b < kKnnBits; ++b) r |= ((c >> b) & 1u) << (3 * b + k);
+        code |= r;
+    }
+    key[i] = code;
+    atomicAdd(&hist[code], 1u);
+}
+// exclusive scan of kKnnBuckets + 1 counters in place; one workgroup of 1024 threads
+__global__ __launch_bounds__(1024) void k_knn_scan(uint32_t *hist, uint32_t *cursor)
+{
+    __shared__ uint32_t s_part[1024];
+    constexpr int per = kKnnBuckets / 1024;
+    const int tid = threadIdx.x;
+    uint32_t sum = 0;
+    for (int j = 0; j < per; ++j) sum += hist[tid * per + j];
+    s_part[tid] = sum;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+        const uint32_t v = tid >= off ? s_part[tid - off] : 0u;
+        __syncthreads();
+        s_part[tid] += v;
+        __syncthreads();
+    }
+    uint32_t run = s_part[tid] - sum;
+    for (int j = 0; j < per; ++j) {
+        const uint32_t c = hist[tid * per + j];
+        hist[tid * per + j] = run;
+        cursor[tid * per + j] = run;
+        run += c;
+    }
+    if (tid == 1023) hist[kKnnBuckets] = run;
+}
+__global__ __launch_bounds__(kKnnThreads) void k_knn_scatter(int N, const float *__restrict__ pts, const uint32_t *__restrict__ key,
+                                                              uint32_t *cursor, float *__restrict__ sx, float *__restrict__ sy,
+                                                              float *__restrict__ sz, uint32_t *__restrict__ sidx)
+{
+    const int i = blockIdx.x * kKnnThreads + threadIdx.x;
+    if (i >= N) return;
+    const uint32_t pos = atomicAdd(&cursor[key[i]], 1u);
+    sx[pos] = pts[3 * (size_t)i]; sy[pos] = pts[3 * (size_t)i + 1]; sz[pos] = pts[3 * (size_t)i + 2];
+    sidx[pos] = (uint32_t)i;
+}
+__global__ __launch_bounds__(kKnnThreads) void k_knn_boxes(int N, const float *__restrict__ sx, const float *__restrict__ sy,
+                                                            const float *__restrict__ sz, float *__restrict__ bmin, float *__restrict__ bmax)
+{
+    __shared__ float s_mn[3][kKnnThreads / 64], s_mx[3][kKnnThreads / 64];
+    const int box = blockIdx.x, tid = threadIdx.x;
+    float mn[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, mx[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+    for (int j = tid; j < kKnnBox; j += kKnnThreads) {
+        const int e = box * kKnnBox + j;
+        if (e < N) {
+            const float v[3] = {sx[e], sy[e], sz[e]};
+#pragma unroll
+            for (int k = 0; k < 3; ++k) { mn[k] = fminf(mn[k], v[k]); mx[k] = fmaxf(mx[k], v[k]); }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+        for (int off = 32; off > 0; off >>= 1) { mn[k] = fminf(mn[k], __shfl_xor(mn[k], off)); mx[k] = fmaxf(mx[k], __shfl_xor(mx[k], off)); }
+    if ((tid & 63) == 0)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { s_mn[k][tid >> 6] = mn[k]; s_mx[k][tid >> 6] = mx[k]; }
+    __syncthreads();
+    if (tid < 3) {
+        float a = s_mn[tid][0], b = s_mx[tid][0];
+        for (int w = 1; w < kKnnThreads / 64; ++w) { a = fminf(a, s_mn[tid][w]); b = fmaxf(b, s_mx[tid][w]); }
+        bmin[3 * box + tid] = a; bmax[3 * box + tid] = b;
+    }
+}
+// one wave per 64 consecutive sorted points
+__global__ __launch_bounds__(64) void k_knn_search(int N, int n_boxes, const float *__restrict__ sx, const float *__restrict__ sy,
+                                                    const float *__restrict__ sz, const uint32_t *__restrict__ sidx,
+                                                    const float *__restrict__ bmin, const float *__restrict__ bmax, float *__restrict__ out)
+{
+    const int pos = blockIdx.x * 64 + threadIdx.x;
+    const bool live = pos < N;
+    const int e = live ? pos : N - 1;
+    const float px = sx[e], py = sy[e], pz = sz[e];
+    float b0 = FLT_MAX, b1 = FLT_MAX, b2 = FLT_MAX;
+    const int own = (blockIdx.x * 64) / kKnnBox;
+    for (int it = -1; it < n_boxes; ++it) {
+        const int box = it < 0 ? own : it;
+        if (it == own) continue;
+        if (it >= 0) {
+            // squared distance to the box, shrunk by a rounding margin: a box is only skipped when it cannot hold a candidate
+            const float ax = fmaxf(fmaxf(bmin[3 * box] - px, px - bmax[3 * box]), 0.f);
+            const float ay = fmaxf(fmaxf(bmin[3 * box + 1] - py, py - bmax[3 * box + 1]), 0.f);
+            const float az = fmaxf(fmaxf(bmin[3 * box + 2] - pz, pz - bmax[3 * box + 2]), 0.f);
+            const float dbox = ((ax * ax + ay * ay) + az * az) * 0.99999f;
+            if (__ballot(live && dbox <= b2) == 0ull) continue;
+        }
+        const int lo = box * kKnnBox, hi = min(lo + kKnnBox, N);
+        for (int j = lo; j < hi; ++j) {        // uniform addresses: one scalar load per value, every lane tries the candidate
+            const float dx = px - sx[j], dy = py - sy[j], dz = pz - sz[j];
+            float dd = (dx * dx + dy * dy) + dz * dz;
+            dd = (j == pos) ? FLT_MAX : dd;     // exclude self (by position: the same point), duplicates count
+            push3(b0, b1, b2, dd);
+        }
+    }
+    if (live) out[sidx[pos]] = ((b0 + b1) + b2) / 3.0f;
 }
 
 }  // namespace dm4d
@@ -61,6 +242,32 @@ extern "C" int dm4d_dist2_knn3(int32_t N, const float *points, float *out, dm4d_
     hipStream_t st = (hipStream_t)stream;
     ProfScope prof_(kKKnn, st);
     hipLaunchKernelGGL(k_dist2_knn3, dim3((N + kKnnThreads - 1) / kKnnThreads), dim3(kKnnThreads), 0, st, N, points, out);
+    DM4D_HIP_CHECK(hipGetLastError());
+    return DM4D_OK;
+}
+
+extern "C" size_t dm4d_knn_scratch_bytes(int32_t N) { return knn_layout(N).total; }
+
+extern "C" int dm4d_dist2_knn3_ws(int32_t N, const float *points, float *out, void *scratch, size_t scratch_bytes, dm4d_stream_t stream)
+{
+    if (N < 0 || (N > 0 && (!points || !out))) { set_error("bad arguments"); return DM4D_ERR_INVALID; }
+    if (N == 0) return DM4D_OK;
+    const KnnLayout L = knn_layout(N);
+    if (!scratch || scratch_bytes < L.total) { set_error("kNN scratch too small: %zu < %zu bytes", scratch_bytes, L.total); return DM4D_ERR_CAPACITY; }
+    hipStream_t st = (hipStream_t)stream;
+    ProfScope prof_(kKKnn, st);
+    char *b = (char *)scratch;
+    uint32_t *bounds = (uint32_t *)(b + L.bounds), *hist = (uint32_t *)(b + L.hist), *cursor = (uint32_t *)(b + L.cursor), *key = (uint32_t *)(b + L.key);
+    float *sx = (float *)(b + L.sx), *sy = (float *)(b + L.sy), *sz = (float *)(b + L.sz), *bmin = (float *)(b + L.bmin), *bmax = (float *)(b + L.bmax);
+    uint32_t *sidx = (uint32_t *)(b + L.sidx);
+    const int nblk = (N + kKnnThreads - 1) / kKnnThreads, n_boxes = (N + kKnnBox - 1) / kKnnBox;
+    hipLaunchKernelGGL(k_knn_init, dim3((kKnnBuckets + 256) / 256), dim3(256), 0, st, bounds, hist);
+    hipLaunchKernelGGL(k_knn_bounds, dim3(nblk < 1024 ? nblk : 1024), dim3(kKnnThreads), 0, st, N, points, bounds);
+    hipLaunchKernelGGL(k_knn_codes, dim3(nblk), dim3(kKnnThreads), 0, st, N, points, bounds, key, hist);
+    hipLaunchKernelGGL(k_knn_scan, dim3(1), dim3(1024), 0, st, hist, cursor);
+    hipLaunchKernelGGL(k_knn_scatter, dim3(nblk), dim3(kKnnThreads), 0, st, N, points, key, cursor, sx, sy, sz, sidx);
+    hipLaunchKernelGGL(k_knn_boxes, dim3(n_boxes), dim3(kKnnThreads), 0, st, N, sx, sy, sz, bmin, bmax);
+    hipLaunchKernelGGL(k_knn_search, dim3((N + 63) / 64), dim3(64), 0, st, N, n_boxes, sx, sy, sz, sidx, bmin, bmax, out);
     DM4D_HIP_CHECK(hipGetLastError());
     return DM4D_OK;
 }

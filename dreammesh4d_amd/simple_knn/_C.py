@@ -5,6 +5,8 @@ import torch
 
 from .. import _lib
 
+BRUTE_FORCE_MAX = 8192
+
 
 def distCUDA2(points: torch.Tensor) -> torch.Tensor:
     if points.device.type != "cuda":
@@ -14,7 +16,13 @@ def distCUDA2(points: torch.Tensor) -> torch.Tensor:
     L = _lib.lib()
     p = points.detach().to(torch.float32).contiguous()
     out = torch.empty(p.shape[0], dtype=torch.float32, device=p.device)
+    n = int(p.shape[0])
     with torch.cuda.device(p.device):
-        _lib.check(L.dm4d_dist2_knn3(p.shape[0], p.data_ptr() if p.numel() else None, out.data_ptr() if p.numel() else None,
-                                     torch.cuda.current_stream(p.device).cuda_stream), "dm4d_dist2_knn3")
+        st = torch.cuda.current_stream(p.device).cuda_stream
+        if n <= BRUTE_FORCE_MAX:       # exhaustive LDS-tiled search: no scratch, fastest for small clouds
+            _lib.check(L.dm4d_dist2_knn3(n, p.data_ptr() if n else None, out.data_ptr() if n else None, st), "dm4d_dist2_knn3")
+        else:                          # Morton-ordered 1024-point boxes (upstream's structure): same values, O(N) boxes visited
+            nbytes = L.dm4d_knn_scratch_bytes(n)
+            scratch = torch.empty(nbytes, dtype=torch.uint8, device=p.device)
+            _lib.check(L.dm4d_dist2_knn3_ws(n, p.data_ptr(), out.data_ptr(), scratch.data_ptr(), nbytes, st), "dm4d_dist2_knn3_ws")
     return out

@@ -185,6 +185,12 @@ int dm4d_mark_visible(int32_t N, const float *means3D, const float *viewmatrix, 
 /* simple_knn._C.distCUDA2 (C/geometry/gaussian_base.py:435-438): out[i] = mean of the squared distances
  * from point i to its 3 nearest OTHER points (self excluded by index).  points [N,3], out [N]. */
 int dm4d_dist2_knn3(int32_t N, const float *points, float *out, dm4d_stream_t stream);
+/* The same values (bit for bit) through upstream's structure -- Morton-ordered boxes of 1024 points, a point only visits
+ * the boxes that can hold something closer than its current third-best (simple-knn's coord2Morton / boxMinMax /
+ * boxMeanDist) -- for large clouds: dm4d_dist2_knn3 above is an O(N^2) exhaustive search.  `scratch` [dev]:
+ * dm4d_knn_scratch_bytes(N) bytes, 256-byte aligned, uninitialised. */
+size_t dm4d_knn_scratch_bytes(int32_t N);
+int dm4d_dist2_knn3_ws(int32_t N, const float *points, float *out, void *scratch, size_t scratch_bytes, dm4d_stream_t stream);
 
 /* ------------------------------------------------------------------ skinning / face -> Gaussians */
 
