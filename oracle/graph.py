@@ -32,3 +32,77 @@ def geodesic_graph(verts, faces, node_xyz, K):
         idx[i] = kn1[:K]
         w[i] = (1.0 - eu[:K] / eu[-1]) ** 2                                                    # :855
     return idx, w / w.sum(axis=1, keepdims=True), d
+
+
+def heat_method_distances(verts, faces, sources):
+    """Geodesic distance from each source vertex by the HEAT METHOD (Crane, Weischedel, Wardetzky 2013) -- the published
+    algorithm behind ``potpourri3d.MeshHeatMethodDistanceSolver(V, F).compute_distance(i)`` that the reference calls once
+    per vertex (dynamic_sugar.py:802,834).  potpourri3d (geometry-central) is not in the tree: this restates the paper
+    with its default time step t = (mean edge length)^2: cotan Laplacian L, lumped mass A, solve (A + t L) u = delta_i,
+    X = -grad u / |grad u| per face, solve L phi = div X, shift so that phi(source) = 0.  -> [len(sources), V], float64.
+    PARITY UNPINNED against the library's build (its robust-Laplacian / Delaunay options are not reproduced)."""
+    import scipy.sparse as sp
+    from scipy.sparse.linalg import splu
+
+    v = np.asarray(verts, np.float64)
+    f = np.asarray(faces, np.int64)
+    V = len(v)
+    p0, p1, p2 = v[f[:, 0]], v[f[:, 1]], v[f[:, 2]]
+    nrm = np.cross(p1 - p0, p2 - p0)
+    dbl = np.linalg.norm(nrm, axis=1)                          # 2 * area
+    un = nrm / dbl[:, None]
+    # cotan weights: for corner k the opposite edge (k+1, k+2)
+    I, J, W = [], [], []
+    for k in range(3):
+        a, b, c = f[:, k], f[:, (k + 1) % 3], f[:, (k + 2) % 3]
+        u_, w_ = v[b] - v[a], v[c] - v[a]
+        cot = (u_ * w_).sum(1) / np.linalg.norm(np.cross(u_, w_), axis=1)
+        I += [b, c, b, c]; J += [c, b, b, c]; W += [-0.5 * cot, -0.5 * cot, 0.5 * cot, 0.5 * cot]
+    L = sp.coo_matrix((np.concatenate(W), (np.concatenate(I), np.concatenate(J))), shape=(V, V)).tocsc()   # positive semi-definite
+    area = np.zeros(V)
+    for k in range(3):
+        np.add.at(area, f[:, k], dbl / 6.0)
+    A = sp.diags(area).tocsc()
+    e = np.concatenate([p1 - p0, p2 - p1, p0 - p2])
+    t = np.mean(np.linalg.norm(e, axis=1)) ** 2
+    heat = splu((A + t * L).tocsc())
+    poisson = splu((L + 1e-10 * sp.identity(V)).tocsc())
+    out = np.zeros((len(sources), V))
+    for s, src in enumerate(sources):
+        rhs = np.zeros(V); rhs[src] = 1.0
+        u = heat.solve(rhs)
+        # gradient of u per face: sum_k u_k (N x e_k) / (2A), e_k the edge opposite to corner k
+        g = np.zeros((len(f), 3))
+        for k in range(3):
+            ek = v[f[:, (k + 2) % 3]] - v[f[:, (k + 1) % 3]]
+            g += u[f[:, k]][:, None] * np.cross(un, ek)
+        g /= dbl[:, None]
+        X = -g / np.maximum(np.linalg.norm(g, axis=1), 1e-300)[:, None]
+        div = np.zeros(V)
+        for k in range(3):
+            a, b, c = f[:, k], f[:, (k + 1) % 3], f[:, (k + 2) % 3]
+            e1, e2 = v[b] - v[a], v[c] - v[a]
+            # cot of the angles at b and c
+            cb = ((v[a] - v[b]) * (v[c] - v[b])).sum(1) / np.linalg.norm(np.cross(v[a] - v[b], v[c] - v[b]), axis=1)
+            cc = ((v[a] - v[c]) * (v[b] - v[c])).sum(1) / np.linalg.norm(np.cross(v[a] - v[c], v[b] - v[c]), axis=1)
+            np.add.at(div, a, 0.5 * (cc * (e1 * X).sum(1) + cb * (e2 * X).sum(1)))
+        phi = poisson.solve(-div)
+        out[s] = phi - phi[src]
+    return out
+
+
+def heat_graph(verts, faces, node_xyz, K):
+    """``build_deformation_graph(mode="geodisc")`` as the reference runs it (:819-847): for every vertex i the heat-method
+    distances from i, read at the nodes' nearest mesh vertices, the K + 1 nearest nodes, Euclidean weights."""
+    v = np.asarray(verts, np.float64)
+    n = np.asarray(node_xyz, np.float64)
+    node_vertex = np.array([np.argmin(np.linalg.norm(v - p, axis=1)) for p in n])
+    d = heat_method_distances(verts, faces, np.arange(len(v)))[:, node_vertex]              # [V, M]
+    idx = np.zeros((len(v), K), np.int64)
+    w = np.zeros((len(v), K), np.float64)
+    for i in range(len(v)):
+        kn1 = np.argsort(d[i])[:K + 1]
+        eu = np.linalg.norm(v[i] - n[kn1], axis=-1)
+        idx[i] = kn1[:K]
+        w[i] = (1.0 - eu[:K] / eu[-1]) ** 2
+    return idx, w / w.sum(axis=1, keepdims=True), d
