@@ -12,7 +12,14 @@
 // there are no atomics and the gradients are bit-reproducible.
 //
 // Everything is HBM-bound gather work on a few hundred KB: vertex and node tables stay in L2.
-// Gradients are the exact (Euclidean) derivatives of the forward (DESIGN.md "gradient convention").
+// Gradients, two conventions (DESIGN.md "gradient convention"):
+//   exact   the Euclidean derivatives of the forward function;
+//   pypose  (DM4D_GRAD_PYPOSE or-ed into `method` / `G`) what the reference's autograd returns: pypose LieTensor
+//           operations (SO3 Act / Log / Mul, so3 Exp) hand back LEFT-PERTURBATION tangent gradients zero-padded into the
+//           quaternion storage, and take the first three components of an incoming quaternion-storage gradient as such
+//           a tangent gradient; torch ops in between (F.normalize, .tensor(), the dual-quaternion algebra) stay Euclidean.
+//           Restated from pypose 0.6.7's published backward rules (pypose/lietensor/operation.py: SO3_Log, so3_Exp,
+//           SO3_Act, SO3_Mul; so3_Jl / so3_Jl_inv); the package is not in the tree: PARITY UNPINNED.
 #include "common.h"
 #include "raster.h"
 
@@ -115,6 +122,44 @@ __device__ __forceinline__ v3 so3_exp_grad(v3 r, q4 g)
     return a * gx + (da_over_t * dot(r, gx) - 0.5f * a * g.w) * r;
 }
 
+// ---- pypose's convention -------------------------------------------------------------------------------------------
+// g Jl(x) and g Jl^-1(x) (row vector times the left Jacobian of SO(3) / its inverse), K = hat(x):
+//   Jl = I + (1 - cos t)/t^2 K + (t - sin t)/t^3 K^2      Jl^-1 = I - K/2 + (1/t^2 - (1 + cos t)/(2 t sin t)) K^2
+//   g K = g x x,  g K^2 = (g x x) x x
+__device__ __forceinline__ v3 row_times_Jl(v3 x, v3 g)
+{
+    const float t2 = dot(x, x), t = sqrtf(t2);
+    float c1, c2;
+    if (t < 1e-3f) { c1 = 0.5f - t2 / 24.f; c2 = 1.f / 6.f - t2 / 120.f; }
+    else { c1 = (1.f - cosf(t)) / t2; c2 = (t - sinf(t)) / (t2 * t); }
+    const v3 gk = cross(g, x), gkk = cross(gk, x);
+    return g + c1 * gk + c2 * gkk;
+}
+__device__ __forceinline__ v3 row_times_Jl_inv(v3 x, v3 g)
+{
+    const float t2 = dot(x, x), t = sqrtf(t2);
+    float c2;
+    if (t < 1e-3f) c2 = 1.f / 12.f + t2 / 720.f;
+    else c2 = (1.f - 0.5f * t * (1.f + cosf(t)) / sinf(t)) / t2;
+    const v3 gk = cross(g, x), gkk = cross(gk, x);
+    return g - 0.5f * gk + c2 * gkk;
+}
+// SO3_Log.backward: (g Jl^-1(Log q), 0)
+__device__ __forceinline__ q4 so3_log_grad_pp(q4 q, v3 g)
+{
+    const v3 r = row_times_Jl_inv(so3_log(q), g);
+    return q4{r.x, r.y, r.z, 0.f};
+}
+// so3_Exp.backward: g[:3] Jl(r)
+__device__ __forceinline__ v3 so3_exp_grad_pp(v3 r, q4 g) { return row_times_Jl(r, qv(g)); }
+// SO3_Act.backward w.r.t. the rotation: (h (-hat(R y)), 0) = ((R y) x h, 0)
+__device__ __forceinline__ q4 qact_grad_q_pp(q4 q, v3 y, v3 h)
+{
+    const v3 r = cross(qact(q, y), h);
+    return q4{r.x, r.y, r.z, 0.f};
+}
+constexpr int kPypose = 0x100;     // == DM4D_GRAD_PYPOSE
+
 // ---- node attributes from the raw deformation-network outputs --------------------------------
 struct NodeAttr { q4 q; float pn; v3 t; float S[9]; float o; };
 __device__ __forceinline__ NodeAttr node_attr(int m, const float *dx, const float *dr, const float *ds, const float *dop)
@@ -145,6 +190,7 @@ constexpr int kNodeRec = 14;   // dx3 dr4 ds6 do1
 
 struct SkinArgs {
     int method, V, M, K;
+    int pypose;                          // gradient convention of the backward (see the file header)
     const float *verts; const int32_t *nbr_idx; const float *nbr_w;
     const float *dx, *dr, *ds, *dop;     // [B][M][3|4|6|1]: blockIdx.y selects the view
 };
@@ -263,7 +309,7 @@ __global__ __launch_bounds__(kSkinThreads) void k_skin_bwd_vertex(SkinArgs a0, c
             g_eta = (eta_raw + 0.4f < 1.0f) ? dot(gx, x_lbs - x_dqs) : 0.f;
         }
         // x_dqs = R(rh) p + (2 dh * conj(rh)).xyz
-        q4 g_rh = qact_grad_q(rh, p, g_dqs);
+        q4 g_rh = a.pypose ? qact_grad_q_pp(rh, p, g_dqs) : qact_grad_q(rh, p, g_dqs);     // q_r.matrix() of transform_point_simple
         const q4 G = q4{g_dqs.x, g_dqs.y, g_dqs.z, 0.f};
         const q4 g_dh = qscale(2.f, qmul(G, rh));                    // dL/da = G * conj(b), b = conj(rh)
         const q4 g_b = qmul(qconj(qscale(2.f, dh)), G);              // dL/db = conj(a) * G
@@ -271,21 +317,21 @@ __global__ __launch_bounds__(kSkinThreads) void k_skin_bwd_vertex(SkinArgs a0, c
         g_bd = qscale(1.f / nn, g_dh);
         g_br = qadd(qscale(1.f / nn, g_rh), qscale(-(qdot(g_rh, rh) + qdot(g_dh, dh)) / nn, rh));
     }
-    const v3 g_rho = so3_exp_grad(rho, gq);
+    const v3 g_rho = a.pypose ? so3_exp_grad_pp(rho, gq) : so3_exp_grad(rho, gq);
     // ---- per-neighbour gradients ----
     for (int k = 0; k < a.K; ++k) {
         const int m = a.nbr_idx[(size_t)v * a.K + k];
         const float w = a.nbr_w[(size_t)v * a.K + k];
         const NodeAttr n = node_attr(m, a.dx, a.dr, a.ds, a.dop);
         v3 g_t = mk3(0, 0, 0);
-        q4 g_q = so3_log_grad(n.q, w * g_rho);
+        q4 g_q = a.pypose ? so3_log_grad_pp(n.q, w * g_rho) : so3_log_grad(n.q, w * g_rho);
         float g_S[6] = {0, 0, 0, 0, 0, 0};
         if (a.method != kDqs) {
             const v3 h = w * g_lbs;
             const v3 y = mk3(n.S[0] * p.x + n.S[1] * p.y + n.S[2] * p.z, n.S[3] * p.x + n.S[4] * p.y + n.S[5] * p.z,
                              n.S[6] * p.x + n.S[7] * p.y + n.S[8] * p.z);
             g_t = g_t + h;
-            g_q = qadd(g_q, qact_grad_q(n.q, y, h));
+            g_q = qadd(g_q, a.pypose ? qact_grad_q_pp(n.q, y, h) : qact_grad_q(n.q, y, h));
             const v3 gy = qact_grad_p(n.q, h);
             g_S[0] = gy.x * p.x; g_S[1] = gy.y * p.y; g_S[2] = gy.z * p.z;
             g_S[3] = gy.x * p.y + gy.y * p.x;
@@ -375,7 +421,7 @@ __global__ __launch_bounds__(kSkinThreads) void k_skin_bwd_vertex_k4(SkinArgs a0
             g_dqs = (1.f - eta) * gx;
             g_eta = (eta_raw + 0.4f < 1.0f) ? dot(gx, x_lbs - x_dqs) : 0.f;
         }
-        q4 g_rh = qact_grad_q(rh, p, g_dqs);
+        q4 g_rh = a.pypose ? qact_grad_q_pp(rh, p, g_dqs) : qact_grad_q(rh, p, g_dqs);     // q_r.matrix() of transform_point_simple
         const q4 G = q4{g_dqs.x, g_dqs.y, g_dqs.z, 0.f};
         const q4 g_dh = qscale(2.f, qmul(G, rh));
         const q4 g_b = qmul(qconj(qscale(2.f, dh)), G);
@@ -383,15 +429,15 @@ __global__ __launch_bounds__(kSkinThreads) void k_skin_bwd_vertex_k4(SkinArgs a0
         g_bd = qscale(1.f / nn, g_dh);
         g_br = qadd(qscale(1.f / nn, g_rh), qscale(-(qdot(g_rh, rh) + qdot(g_dh, dh)) / nn, rh));
     }
-    const v3 g_rho = so3_exp_grad(rho, gq);
+    const v3 g_rho = a.pypose ? so3_exp_grad_pp(rho, gq) : so3_exp_grad(rho, gq);
     // ---- this neighbour's gradients ----
     v3 g_t = mk3(0, 0, 0);
-    q4 g_q = so3_log_grad(n.q, w * g_rho);
+    q4 g_q = a.pypose ? so3_log_grad_pp(n.q, w * g_rho) : so3_log_grad(n.q, w * g_rho);
     float g_S[6] = {0, 0, 0, 0, 0, 0};
     if (a.method != kDqs) {
         const v3 h = w * g_lbs;
         g_t = g_t + h;
-        g_q = qadd(g_q, qact_grad_q(n.q, y, h));
+        g_q = qadd(g_q, a.pypose ? qact_grad_q_pp(n.q, y, h) : qact_grad_q(n.q, y, h));
         const v3 gy = qact_grad_p(n.q, h);
         g_S[0] = gy.x * p.x; g_S[1] = gy.y * p.y; g_S[2] = gy.z * p.z;
         g_S[3] = gy.x * p.y + gy.y * p.x;
@@ -515,7 +561,7 @@ __global__ __launch_bounds__(kSkinThreads) void k_face_bwd_face(int F, int G, in
                                                                 const float *__restrict__ g_rots,
                                                                 const float *__restrict__ g_normals, int nstride,
                                                                 float *__restrict__ rec /* [F][3][6] */,
-                                                                const int32_t *__restrict__ frame_index, int n_views)
+                                                                const int32_t *__restrict__ frame_index, int n_views, int pypose)
 {
     // blockIdx.y = frame; the upstream gradients are per VIEW: summed here over the views of the frame in view
     // order (the backward is linear in them).  frame_index == nullptr: view == frame.
@@ -583,8 +629,8 @@ __global__ __launch_bounds__(kSkinThreads) void k_face_bwd_face(int F, int G, in
                     go = qadd(go, q4{go4.y, go4.z, go4.w, go4.x});
                 }
             const q4 gQ = qscale(1.f / nq, qadd(go, qscale(-qdot(go, out), out)));
-            const q4 gqd = qmul(gQ, qconj(qs));
-            gr = so3_exp_grad(r, gqd);
+            if (pypose) gr = so3_exp_grad_pp(r, gQ);     // SO3_Mul.backward: X_grad = (g[:3], 0); so3_Exp.backward: g[:3] Jl(r)
+            else gr = so3_exp_grad(r, qmul(gQ, qconj(qs)));
         }
         if (g_normals)
             for (int bv = b0; bv < b1; ++bv)
@@ -639,7 +685,7 @@ __global__ __launch_bounds__(kSkinThreads) void k_face_bwd_vertex(int V, int F, 
                                                                   const float *__restrict__ rec,
                                                                   const float *__restrict__ ext_xyz,
                                                                   const float *__restrict__ ext_rot,
-                                                                  float *__restrict__ g_vxyz, float *__restrict__ g_vrot)
+                                                                  float *__restrict__ g_vxyz, float *__restrict__ g_vrot, int pypose)
 {
     const int gid = blockIdx.x * kSkinThreads + threadIdx.x;
     const int v = gid >> 3, c = gid & 7;
@@ -670,7 +716,7 @@ __global__ __launch_bounds__(kSkinThreads) void k_face_bwd_vertex(int V, int F, 
     v3 X = mk3(a[0], a[1], a[2]);
     if (ext_xyz) X = X + ld3(ext_xyz, v);
     st3(g_vxyz, v, X);
-    q4 g = so3_log_grad(ldq(vrot, v), mk3(a[3], a[4], a[5]));
+    q4 g = pypose ? so3_log_grad_pp(ldq(vrot, v), mk3(a[3], a[4], a[5])) : so3_log_grad(ldq(vrot, v), mk3(a[3], a[4], a[5]));
     if (ext_rot) g = qadd(g, ldq(ext_rot, v));
     reinterpret_cast<float4 *>(g_vrot)[v] = make_float4(g.x, g.y, g.z, g.w);
 }
@@ -686,7 +732,8 @@ int skin_forward_launch(int B, int method, int V, int M, int K, const float *ver
                         float *out_rot, hipStream_t st)
 {
     if (V <= 0 || B <= 0) return DM4D_OK;
-    SkinArgs a{method, V, M, K, verts, idx, w, dx, dr, method == kDqs ? nullptr : ds, method == kHybrid ? dop : nullptr};
+    method &= 0xff;
+    SkinArgs a{method, V, M, K, 0, verts, idx, w, dx, dr, method == kDqs ? nullptr : ds, method == kHybrid ? dop : nullptr};
     ProfScope prof_(kKSkinFwd, st);
     hipLaunchKernelGGL(k_skin_fwd, dim3((V + kSkinThreads - 1) / kSkinThreads, B), dim3(kSkinThreads), 0, st, a, out_xyz, out_rot);
     DM4D_HIP_CHECK(hipGetLastError());
@@ -699,7 +746,9 @@ int skin_backward_launch(int B, int method, int V, int M, int K, const float *ve
                          float *o_dx, float *o_dr, float *o_ds, float *o_do, hipStream_t st)
 {
     if (B <= 0) return DM4D_OK;
-    SkinArgs a{method, V, M, K, verts, idx, w, dx, dr, method == kDqs ? nullptr : ds, method == kHybrid ? dop : nullptr};
+    const int pypose = (method & kPypose) ? 1 : 0;
+    method &= 0xff;
+    SkinArgs a{method, V, M, K, pypose, verts, idx, w, dx, dr, method == kDqs ? nullptr : ds, method == kHybrid ? dop : nullptr};
     ProfScope prof_(kKSkinBwd, st);
     if (V > 0) {
         if (K == 4)
@@ -721,6 +770,7 @@ int face_forward_launch(int B, int F, int G, int V, const int32_t *faces, const 
                         float *colors6, hipStream_t st)
 {
     if (F <= 0 || B <= 0) return DM4D_OK;
+    G &= 0xff;
     ProfScope prof_(kKFaceFwd, st);
     hipLaunchKernelGGL(k_face_fwd, dim3((F * G + kSkinThreads - 1) / kSkinThreads, B), dim3(kSkinThreads), 0, st, F, G, V,
                        faces, vxyz, vrot, qs, means, rots, normals, nstride, rgb, colors6);
@@ -736,16 +786,18 @@ int face_backward_launch(int B, int F, int G, int V, const int32_t *faces, const
 {
     // B = frames; with frame_index the upstream gradients g_* are per view ([n_views, N, .])
     if (B <= 0) return DM4D_OK;
+    const int pypose = (G & kPypose) ? 1 : 0;
+    G &= 0xff;
     ProfScope prof_(kKFaceBwd, st);
     if (F > 0) {
         const int fpw = kSkinThreads / G;      // faces per workgroup (one thread per Gaussian)
         hipLaunchKernelGGL(k_face_bwd_face, dim3((F + fpw - 1) / fpw, B), dim3(kSkinThreads), 0, st, F, G,
-                           V, faces, vxyz, vrot, qs, g_means, g_rots, g_normals, nstride, scratch, frame_index, n_views);
+                           V, faces, vxyz, vrot, qs, g_means, g_rots, g_normals, nstride, scratch, frame_index, n_views, pypose);
         DM4D_HIP_CHECK(hipGetLastError());
     }
     if (V > 0) {
         hipLaunchKernelGGL(k_face_bwd_vertex, dim3((8 * V + kSkinThreads - 1) / kSkinThreads, B), dim3(kSkinThreads), 0, st, V,
-                           F, csr_off, csr_items, vrot, (const float *)scratch, ext_xyz, ext_rot, o_vxyz, o_vrot);
+                           F, csr_off, csr_items, vrot, (const float *)scratch, ext_xyz, ext_rot, o_vxyz, o_vrot, pypose);
         DM4D_HIP_CHECK(hipGetLastError());
     }
     return DM4D_OK;
@@ -754,7 +806,8 @@ int face_backward_launch(int B, int F, int G, int V, const int32_t *faces, const
 int skin_check(int method, int V, int M, int K, const void *verts, const void *idx, const void *w, const void *dx,
                const void *dr, const void *ds, const void *dop)
 {
-    if (method < 0 || method > 2) { set_error("method must be 0 (lbs), 1 (dqs) or 2 (hybrid)"); return DM4D_ERR_INVALID; }
+    if ((method & ~kPypose) < 0 || (method & ~kPypose) > 2) { set_error("method must be 0 (lbs), 1 (dqs) or 2 (hybrid), optionally | DM4D_GRAD_PYPOSE"); return DM4D_ERR_INVALID; }
+    method &= 0xff;
     if (V < 0 || M <= 0 || K <= 0 || K > kMaxK) { set_error("bad V/M/K (%d/%d/%d)", V, M, K); return DM4D_ERR_INVALID; }
     if (V > 0 && (!verts || !idx || !w || !dx || !dr)) { set_error("null input"); return DM4D_ERR_INVALID; }
     if (method != kDqs && !ds) { set_error("lbs/hybrid need the strain output ds"); return DM4D_ERR_INVALID; }
@@ -764,6 +817,7 @@ int skin_check(int method, int V, int M, int K, const void *verts, const void *i
 
 int face_check(int F, int G, const void *faces, const void *vxyz, const void *vrot, const void *qs)
 {
+    G &= ~kPypose;
     if (F < 0 || !(G == 1 || G == 3 || G == 4 || G == 6)) { set_error("bad F/G (%d/%d); G must be 1, 3, 4 or 6", F, G); return DM4D_ERR_INVALID; }
     if (F > 0 && (!faces || !vxyz || !vrot || !qs)) { set_error("null input"); return DM4D_ERR_INVALID; }
     return DM4D_OK;

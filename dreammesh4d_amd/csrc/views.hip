@@ -189,7 +189,7 @@ int dm4d_views_backward(const dm4d_views *v, const dm4d_views_grads *gr, dm4d_st
         if ((rc = launch_gather_bwd(sb, st))) return rc;
     }
     const int NF = v->frame_index ? v->n_frames : v->B;
-    rc = face_backward_launch(NF, v->F, v->G, v->V, v->faces, v->vxyz, v->vrot, v->q_static, gr->dL_dmeans3D,
+    rc = face_backward_launch(NF, v->F, v->G | (v->method & 0x100), v->V, v->faces, v->vxyz, v->vrot, v->q_static, gr->dL_dmeans3D,
                               gr->dL_drotations, gr->dL_dcolors + 3, 6, gr->vert_csr_offsets, gr->vert_csr_items,
                               (float *)gr->face_scratch, gr->dL_dvxyz_ext, gr->dL_dvrot_ext, gr->dL_dvxyz, gr->dL_dvrot,
                               v->frame_index, v->B, st);

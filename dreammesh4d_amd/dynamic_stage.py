@@ -33,12 +33,10 @@ LAMBDA = {"sds_zero123": 0.1, "rgb": 5000.0, "mask": [200, 500.0, 5000.0, 1000],
           "normal_consistency": 100.0, "arap_reg_key_frame": 10.0, "arap_reg_inter_frame": 10.0}
 
 
-def quat_xyzw_to_matrix(q):
-    """[..., 4] (x, y, z, w) unit quaternions -> [..., 3, 3] (get_timed_vertex_rotation(return_matrix=True))."""
-    x, y, z, w = q.unbind(-1)
-    return torch.stack([1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w),
-                        2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w),
-                        2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)], -1).reshape(*q.shape[:-1], 3, 3)
+def quat_xyzw_to_matrix(q, grad_mode=None):
+    from .ops import quat_xyzw_to_matrix as f
+
+    return f(q, grad_mode)
 
 
 class DynamicStage:
@@ -118,10 +116,10 @@ class DynamicStage:
         xyz, rot = [], []
         for i in range(self.num_inter_frames):
             x, q = ops.skin_vertices(self.r.graph, dx[i], dr[i], None if ds is None else ds[i], None if do is None else do[i],
-                                     self.r.method_name)
+                                     self.r.method_name, grad_mode=self.r.grad_mode)
             xyz.append(x)
             rot.append(q)
-        return self.arap.compute_arap_energy(torch.stack(xyz), quat_xyzw_to_matrix(torch.stack(rot))).sum()
+        return self.arap.compute_arap_energy(torch.stack(xyz), quat_xyzw_to_matrix(torch.stack(rot), self.r.grad_mode)).sum()
 
     def update_learning_rate(self, it):
         for g in self.opt.param_groups:
@@ -160,7 +158,7 @@ class DynamicStage:
             terms["normal_consistency"] = self.normal_consistency(out["vxyz"])
             loss = loss + LAMBDA["normal_consistency"] * terms["normal_consistency"]
         if self.arap is not None and it >= self.milestone_arap_reg:
-            terms["arap_reg_key_frame"] = self.arap.compute_arap_energy(out["vxyz"], quat_xyzw_to_matrix(out["vrot"])).sum()
+            terms["arap_reg_key_frame"] = self.arap.compute_arap_energy(out["vxyz"], quat_xyzw_to_matrix(out["vrot"], self.r.grad_mode)).sum()
             loss = loss + LAMBDA["arap_reg_key_frame"] * terms["arap_reg_key_frame"]
             if self.inter_frame_reg > 0 and it % self.inter_frame_reg == 0:
                 terms["arap_reg_inter_frame"] = self.inter_frame_arap()

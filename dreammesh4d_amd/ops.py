@@ -16,6 +16,8 @@ import torch
 from . import _lib
 
 METHODS = {"lbs": 0, "dqs": 1, "hybrid": 2}
+GRAD_MODES = {"exact": 0, "pypose": 0x100}      # DM4D_GRAD_PYPOSE (include/dm4d.h): the reference's pypose autograd convention
+DEFAULT_GRAD_MODE = "pypose"                    # what the reference trains with (DESIGN.md "gradient convention")
 
 
 def _p(t):
@@ -82,6 +84,7 @@ class _SkinVertices(torch.autograd.Function):
     def forward(ctx, graph, method, dx, dr, ds, do):
         L = _lib.lib()
         g = graph
+        flags, method = method & 0x100, method & 0xff
         dev = g.device
         dx_, dr_, ds_, do_ = _f32(dx), _f32(dr), _f32(ds), _f32(do)
         xyz = torch.empty(g.V, 3, dtype=torch.float32, device=dev)
@@ -90,7 +93,7 @@ class _SkinVertices(torch.autograd.Function):
             _lib.check(L.dm4d_skin_vertices_forward(method, g.V, g.M, g.K, _p(g.verts), _p(g.nbr_idx), _p(g.nbr_w),
                                                     _p(dx_), _p(dr_), _p(ds_), _p(do_), _p(xyz), _p(rot), _st(dev)),
                        "dm4d_skin_vertices_forward")
-        ctx.graph, ctx.method = g, method
+        ctx.graph, ctx.method = g, method | flags
         ctx.save_for_backward(dx_, dr_, *( [ds_] if ds_ is not None else []), *([do_] if do_ is not None else []))
         ctx.has = (ds_ is not None, do_ is not None)
         ctx.shapes = (dx.shape, dr.shape, None if ds is None else ds.shape, None if do is None else do.shape)
@@ -121,19 +124,21 @@ class _SkinVertices(torch.autograd.Function):
                 None if o_do is None else o_do.reshape(s[3]))
 
 
-def skin_vertices(graph: DeformGraph, dx, dr, ds=None, d_opacity=None, method="hybrid"):
-    """Raw deformation-network outputs for one timestamp -> (vertex xyz [V,3], vertex rotation [V,4] xyzw)."""
+def skin_vertices(graph: DeformGraph, dx, dr, ds=None, d_opacity=None, method="hybrid", grad_mode=None):
+    """Raw deformation-network outputs for one timestamp -> (vertex xyz [V,3], vertex rotation [V,4] xyzw).
+    grad_mode: "pypose" (default: the reference's autograd convention) or "exact" (Euclidean gradient of the forward)."""
     m = METHODS[method]
+    gm = GRAD_MODES[grad_mode or DEFAULT_GRAD_MODE]
     if m != 1 and ds is None:
         raise ValueError("lbs / hybrid skinning needs the strain head output")
     if m == 2 and d_opacity is None:
         raise ValueError("hybrid skinning needs the opacity head output")
-    return _SkinVertices.apply(graph, m, dx, dr, ds if m != 1 else None, d_opacity if m == 2 else None)
+    return _SkinVertices.apply(graph, m | gm, dx, dr, ds if m != 1 else None, d_opacity if m == 2 else None)
 
 
 class _FaceGaussians(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, topo, vxyz, vrot, q_static, want_normals):
+    def forward(ctx, topo, vxyz, vrot, q_static, want_normals, flags):
         L = _lib.lib()
         t = topo
         dev = t.device
@@ -145,7 +150,7 @@ class _FaceGaussians(torch.autograd.Function):
         with torch.cuda.device(dev):
             _lib.check(L.dm4d_face_gaussians_forward(t.F, t.G, _p(t.faces), _p(vx), _p(vr), _p(qs), _p(means), _p(rots),
                                                      _p(normals), _st(dev)), "dm4d_face_gaussians_forward")
-        ctx.topo = t
+        ctx.topo, ctx.flags = t, flags
         ctx.save_for_backward(vx, vr, qs)
         if normals is None:
             normals = torch.empty(0, **f)
@@ -163,12 +168,43 @@ class _FaceGaussians(torch.autograd.Function):
         gm, gr = _f32(g_means), _f32(g_rots)
         gn = _f32(g_normals) if g_normals is not None and g_normals.numel() else None
         with torch.cuda.device(dev):
-            _lib.check(L.dm4d_face_gaussians_backward(t.F, t.G, t.V, _p(t.faces), _p(vx), _p(vr), _p(qs), _p(gm), _p(gr),
+            _lib.check(L.dm4d_face_gaussians_backward(t.F, t.G | ctx.flags, t.V, _p(t.faces), _p(vx), _p(vr), _p(qs), _p(gm), _p(gr),
                                                       _p(gn), _p(t.csr_off), _p(t.csr_items), _p(scratch), _p(o_x),
                                                       _p(o_r), _st(dev)), "dm4d_face_gaussians_backward")
-        return None, o_x, o_r, None, None
+        return None, o_x, o_r, None, None, None
 
 
-def face_gaussians(topo: MeshTopology, vxyz, vrot, q_static_wxyz, want_normals=True):
+def face_gaussians(topo: MeshTopology, vxyz, vrot, q_static_wxyz, want_normals=True, grad_mode=None):
     """Deformed vertices -> (means [N,3], rotations [N,4] wxyz, normals [N,3] or empty)."""
-    return _FaceGaussians.apply(topo, vxyz, vrot, q_static_wxyz, bool(want_normals))
+    return _FaceGaussians.apply(topo, vxyz, vrot, q_static_wxyz, bool(want_normals), GRAD_MODES[grad_mode or DEFAULT_GRAD_MODE])
+
+
+class _MatrixPypose(torch.autograd.Function):
+    """``SO3.matrix()`` of a unit quaternion with pypose's backward (SO3_Act on the basis vectors): the gradient with
+    respect to the quaternion storage is (sum_i R e_i x G[:, i], 0)."""
+
+    @staticmethod
+    def forward(ctx, q):
+        x, y, z, w = q.unbind(-1)
+        R = torch.stack([1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w),
+                         2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w),
+                         2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)], -1).reshape(*q.shape[:-1], 3, 3)
+        ctx.save_for_backward(R)
+        return R
+
+    @staticmethod
+    def backward(ctx, G):
+        (R,) = ctx.saved_tensors
+        t = torch.linalg.cross(R.transpose(-1, -2), G.transpose(-1, -2), dim=-1).sum(dim=-2)     # sum over the columns i
+        return torch.cat([t, torch.zeros_like(t[..., :1])], dim=-1)
+
+
+def quat_xyzw_to_matrix(q, grad_mode=None):
+    """[..., 4] (x, y, z, w) unit quaternions -> [..., 3, 3] (``get_timed_vertex_rotation(return_matrix=True)``,
+    dynamic_sugar.py:640-655: a pypose ``.matrix()``), in the chosen gradient convention."""
+    if (grad_mode or DEFAULT_GRAD_MODE) == "pypose":
+        return _MatrixPypose.apply(q)
+    x, y, z, w = q.unbind(-1)
+    return torch.stack([1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w),
+                        2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w),
+                        2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)], -1).reshape(*q.shape[:-1], 3, 3)

@@ -219,12 +219,7 @@ class DynamicSuGaR(nn.Module):
 
     def get_timed_vertex_rotation(self, timestamp=None, frame_idx=None, return_matrix=False):
         q = self.get_timed_vertex_attributes(timestamp, frame_idx)["rotation"]
-        if not return_matrix:
-            return q
-        x, y, z, w = q.unbind(-1)
-        return torch.stack([1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w),
-                            2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w),
-                            2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)], -1).reshape(*q.shape[:-1], 3, 3)
+        return ops.quat_xyzw_to_matrix(q) if return_matrix else q        # pypose .matrix() (and its gradient convention)
 
     def get_timed_gs_attributes(self, timestamp=None, frame_idx=None):
         """Per timestamp: {"xyz" [N_t,N,3], "rotation" [N_t,N,4] (w,x,y,z), "normals" [N_t,N,3]} (:657-706, :330-364)."""

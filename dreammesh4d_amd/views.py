@@ -13,7 +13,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from .ops import METHODS, DeformGraph, MeshTopology
+from .ops import DEFAULT_GRAD_MODE, GRAD_MODES, METHODS, DeformGraph, MeshTopology
 
 vp = C.c_void_p
 
@@ -33,13 +33,17 @@ class ViewRenderer:
     """Static scene description + capacity policy for ``render_views``."""
 
     def __init__(self, graph: DeformGraph, topo: MeshTopology, image_height, image_width, tanfov, method="hybrid",
-                 scale_modifier=1.0, capacity_factor=6.0, record_factor=3.0):
+                 scale_modifier=1.0, capacity_factor=6.0, record_factor=3.0, grad_mode=None):
         assert graph.device == topo.device and graph.V == topo.V
         self.graph, self.topo = graph, topo
         self.device = graph.device
         self.H, self.W = int(image_height), int(image_width)
         self.tanfov = float(tanfov)
         self.method, self.method_name = METHODS[method], method
+        # gradient convention of the skinning / face->Gaussian backward: "pypose" (default, what the reference's autograd
+        # returns) or "exact" (DESIGN.md "gradient convention")
+        self.grad_mode = grad_mode or DEFAULT_GRAD_MODE
+        self.method_flags = GRAD_MODES[self.grad_mode]
         self.scale_modifier = float(scale_modifier)
         self.N = topo.F * topo.G
         self.capacity = max(int(capacity_factor * self.N), 1 << 16)
@@ -178,7 +182,7 @@ class _RenderViews(torch.autograd.Function):
                    depth=torch.empty(B, 1, H, W, **f), alpha=torch.empty(B, 1, H, W, **f))
         cap, rcap = r.capacity, r.record_capacity
         ws = r._take_ws(B)
-        vs = ViewsStruct(B, N, t.F, t.G, g.V, g.M, g.K, r.method, H, W, r.tanfov, r.tanfov, r.scale_modifier, cap, rcap,
+        vs = ViewsStruct(B, N, t.F, t.G, g.V, g.M, g.K, r.method | r.method_flags, H, W, r.tanfov, r.tanfov, r.scale_modifier, cap, rcap,
                          _p(keep["bg"]), _p(keep["vm"]), _p(keep["pm"]), _p(g.verts), _p(g.nbr_idx), _p(g.nbr_w),
                          _p(keep["dx"]), _p(keep["dr"]), _p(keep["ds"]), _p(keep["do"]), _p(t.faces), _p(keep["qs"]),
                          _p(keep["sc"]), _p(keep["op"]), _p(keep["rgb"]), _p(out["vxyz"]), _p(out["vrot"]),

@@ -194,6 +194,16 @@ int dm4d_dist2_knn3_ws(int32_t N, const float *points, float *out, void *scratch
 
 /* ------------------------------------------------------------------ skinning / face -> Gaussians */
 
+/* Gradient convention of the skinning / face->Gaussian BACKWARD entries: the default is the exact (Euclidean) gradient of the
+ * forward function; with DM4D_GRAD_PYPOSE or-ed into `method` (dm4d_skin_vertices_backward, dm4d_views.method) or into `G`
+ * (dm4d_face_gaussians_backward) the rotation operations return what the reference's pypose LieTensor autograd returns
+ * (SO3 Log / Act / Mul, so3 Exp: left-perturbation tangent gradients zero-padded into the quaternion storage,
+ * C/geometry/dynamic_sugar.py:461,530-586,669-676,877-889) -- the gradient the reference actually trains its rotation
+ * head with.  Restated from pypose 0.6.7's published rules (the package is not in the tree): parity unpinned.  The
+ * dual-quaternion algebra of the DQS branch (C/utils/dual_quaternions.py:115-131,184-231, SO3 products of NON-unit
+ * operands) stays Euclidean in both modes. */
+#define DM4D_GRAD_PYPOSE 0x100
+
 /* Sparse-control skinning of the V mesh vertices by M deformation-graph nodes, K neighbours each
  * (C/geometry/dynamic_sugar.py:408-465 node attributes, :487-613 vertex skinning;
  * C/utils/dual_quaternions.py:94-131,184-197,224-231).  method: 0 = "lbs", 1 = "dqs", 2 = "hybrid"

@@ -22,10 +22,18 @@ PARITY UNPINNED for those conventions; pinned here (tests/test_oracle_skinning.p
 closed-form identities: identity deformation == static geometry, single rigid motion
 => LBS == DQS == the rigid transform, Log/Exp round trip, R(q) orthonormal.
 
-GRADIENTS: autograd of this file gives the EXACT (Euclidean) gradient of the forward
-function.  pypose's LieTensor autograd instead returns left-perturbation tangent gradients
-zero-padded into the quaternion storage (DESIGN.md "gradient convention"); the product
-kernels follow this file, i.e. the exact gradient.
+GRADIENTS, two conventions (``grad_mode``):
+  "exact"   autograd of this file's tensor ops: the exact (Euclidean) gradient of the forward function;
+  "pypose"  what the reference's autograd returns.  pypose's LieTensor operations have hand-written backward rules
+            (pypose/lietensor/operation.py, release 0.6.7) that hand back LEFT-PERTURBATION tangent gradients zero-padded
+            into the quaternion storage and read the first three components of an incoming storage gradient as such a
+            tangent gradient:
+               SO3_Log.backward   (g Jl^-1(out), 0)                  so3_Exp.backward   g[:3] Jl(x)
+               SO3_Act.backward   X: (g (-hat(out)), 0), p: g R(X)    SO3_Mul.backward   X: (g[:3], 0), Y: (g[:3] R(X), 0)
+            with Jl the left Jacobian of SO(3).  The custom autograd Functions below restate exactly these rules (forward
+            values are the same functions as in "exact" mode).  The torch ops around them (F.normalize, .tensor(), the
+            dual-quaternion algebra of the DQS branch, whose SO3 products take NON-unit operands) stay Euclidean.
+            pypose is not in the tree: PARITY UNPINNED.
 """
 import math
 
@@ -96,6 +104,98 @@ def quat_matrix(q):
     return torch.stack(cols, dim=-1)  # [..., 3, 3], column j = R e_j
 
 
+# ----------------------------------------------------------------------------- pypose's backward rules
+def _hat_row(g, x):
+    """g K for K = hat(x): the row vector g x x."""
+    return torch.linalg.cross(g, x, dim=-1)
+
+
+def _row_times_Jl(x, g):
+    t2 = (x * x).sum(-1, keepdim=True)
+    t = t2.sqrt()
+    small = t < 1e-6
+    ts = torch.where(small, torch.ones_like(t), t)
+    c1 = torch.where(small, 0.5 - t2 / 24.0, (1.0 - torch.cos(ts)) / (ts * ts))
+    c2 = torch.where(small, 1.0 / 6.0 - t2 / 120.0, (ts - torch.sin(ts)) / (ts ** 3))
+    gk = _hat_row(g, x)
+    return g + c1 * gk + c2 * _hat_row(gk, x)
+
+
+def _row_times_Jl_inv(x, g):
+    t2 = (x * x).sum(-1, keepdim=True)
+    t = t2.sqrt()
+    small = t < 1e-6
+    ts = torch.where(small, torch.ones_like(t), t)
+    c2 = torch.where(small, 1.0 / 12.0 + t2 / 720.0, (1.0 - 0.5 * ts * (1.0 + torch.cos(ts)) / torch.sin(ts)) / (ts * ts))
+    gk = _hat_row(g, x)
+    return g - 0.5 * gk + c2 * _hat_row(gk, x)
+
+
+def _pad0(t):
+    return torch.cat([t, torch.zeros_like(t[..., :1])], dim=-1)
+
+
+class _LogPP(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, q):
+        out = so3_log(q)
+        ctx.save_for_backward(out)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (out,) = ctx.saved_tensors
+        return _pad0(_row_times_Jl_inv(out, g))
+
+
+class _ExpPP(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        ctx.save_for_backward(x)
+        return so3_exp(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        (x,) = ctx.saved_tensors
+        return _row_times_Jl(x, g[..., :3])
+
+
+class _ActPP(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, q, p):
+        out = quat_act(q, p)
+        ctx.save_for_backward(q, out)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        q, out = ctx.saved_tensors
+        gq = _pad0(torch.linalg.cross(out, g, dim=-1))                 # g (-hat(out)) = out x g
+        gp = quat_act(quat_conj(q), g)                                   # g R(X) = R^T g for a unit quaternion
+        return gq, gp
+
+
+class _MulPP(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, b):
+        ctx.save_for_backward(a)
+        return quat_mul(a, b)
+
+    @staticmethod
+    def backward(ctx, g):
+        (a,) = ctx.saved_tensors
+        g3 = g[..., :3]
+        return _pad0(g3), _pad0(quat_act(quat_conj(a), g3))
+
+
+def _ops(grad_mode):
+    if grad_mode == "pypose":
+        return _LogPP.apply, _ExpPP.apply, _ActPP.apply, _MulPP.apply
+    if grad_mode != "exact":
+        raise ValueError(grad_mode)
+    return so3_log, so3_exp, quat_act, quat_mul
+
+
 # ----------------------------------------------------------------------------- A2 node attributes
 def strain_to_matrix(s):
     """I + sym(ds): diag = ds[0:3], (01)=ds[3], (02)=ds[4], (12)=ds[5]  (dynamic_sugar.py:29-39)."""
@@ -115,9 +215,10 @@ def node_attributes(dx, dr, ds=None, do=None):
 
 
 # ----------------------------------------------------------------------------- A3 vertex skinning
-def skin_vertices(verts, nbr_idx, nbr_w, trans, rot, S=None, opacity=None, method="hybrid"):
+def skin_vertices(verts, nbr_idx, nbr_w, trans, rot, S=None, opacity=None, method="hybrid", grad_mode="exact"):
     """verts [V,3]; nbr_idx [V,K] long; nbr_w [V,K]; node tables trans [M,3], rot [M,4] (unit, xyzw),
     S [M,3,3], opacity [M,1].  Returns (xyz [V,3], vrot [V,4] xyzw)."""
+    log_, exp_, act_, _ = _ops(grad_mode)
     t_k = trans[nbr_idx]          # [V,K,3]
     q_k = rot[nbr_idx]            # [V,K,4]
     w = nbr_w[..., None]
@@ -125,8 +226,7 @@ def skin_vertices(verts, nbr_idx, nbr_w, trans, rot, S=None, opacity=None, metho
     if method in ("lbs", "hybrid"):
         S_k = S[nbr_idx]                                        # [V,K,3,3]
         sv = (S_k @ verts[:, None, :, None]).squeeze(-1)        # S_k v
-        R_k = quat_matrix(q_k)
-        x_k = (R_k @ sv[..., None]).squeeze(-1) + t_k
+        x_k = act_(q_k, sv) + t_k                               # rots.matrix() @ (S v): the matrix IS Act on the basis
         x_lbs = (w * x_k).sum(dim=1)
     if method in ("dqs", "hybrid"):
         q_r = q_k / q_k.norm(dim=-1, keepdim=True)
@@ -137,7 +237,7 @@ def skin_vertices(verts, nbr_idx, nbr_w, trans, rot, S=None, opacity=None, metho
         nrm = br.norm(dim=-1, keepdim=True)
         br, bd = br / nrm, bd / nrm
         tr = quat_mul(2.0 * bd, quat_conj(br))[..., :3]
-        x_dqs = (quat_matrix(br) @ verts[..., None]).squeeze(-1) + tr
+        x_dqs = act_(br, verts) + tr                            # transform_point_simple: q_r.matrix() @ p + translation
     if method == "lbs":
         xyz = x_lbs
     elif method == "dqs":
@@ -148,7 +248,7 @@ def skin_vertices(verts, nbr_idx, nbr_w, trans, rot, S=None, opacity=None, metho
         xyz = eta * x_lbs + (1 - eta) * x_dqs
     else:
         raise ValueError(method)
-    vrot = so3_exp((w * so3_log(q_k)).sum(dim=1))
+    vrot = exp_((w * log_(q_k)).sum(dim=1))
     return xyz, vrot
 
 
@@ -192,17 +292,18 @@ def static_quaternions(verts, faces, cplx, n_per_face=6):
 
 
 # ----------------------------------------------------------------------------- A4/A5 face -> Gaussians
-def face_gaussians(vxyz, vrot, faces, q_static_wxyz, n_per_face=6):
+def face_gaussians(vxyz, vrot, faces, q_static_wxyz, n_per_face=6, grad_mode="exact"):
     """vxyz [V,3], vrot [V,4] xyzw (deformed).  Returns means [N,3], rotations [N,4] wxyz (unit),
     normals [N,3] (deformed-mesh unit face normals repeated per Gaussian)."""
     bary = bary_table(n_per_face, vxyz.dtype)                   # [G,3]
     fv = vxyz[faces]                                            # [F,3,3]
     means = (fv[:, None] * bary[None, :, :, None]).sum(dim=-2).reshape(-1, 3)
-    logs = so3_log(vrot[faces])                                 # [F,3,3]
+    log_, exp_, _, mul_ = _ops(grad_mode)
+    logs = log_(vrot[faces])                                    # [F,3,3]
     r = (logs[:, None] * bary[None, :, :, None]).sum(dim=-2).reshape(-1, 3)
-    q_def = so3_exp(r)                                          # xyzw
+    q_def = exp_(r)                                             # xyzw
     q_st = q_static_wxyz[:, [1, 2, 3, 0]]
-    q = quat_mul(q_def, q_st)[:, [3, 0, 1, 2]]
+    q = mul_(q_def, q_st)[:, [3, 0, 1, 2]]
     q = torch.nn.functional.normalize(q, dim=-1)
     normals = face_normals(vxyz, faces).repeat_interleave(n_per_face, dim=0)
     return means, q, normals

@@ -136,3 +136,67 @@ def test_uv_sphere_face_counts():
         fv = v[fc]
         n = np.cross(fv[:, 1] - fv[:, 0], fv[:, 2] - fv[:, 0])
         assert np.all((n * fv.mean(1)).sum(1) > 0)
+
+
+def test_pypose_convention_rules_are_the_left_tangent_derivatives():
+    """The "pypose" gradient mode (oracle/skinning.py) restates pypose's backward rules; this pins their MATHEMATICS by finite
+    differences in float64: the rules return d/d(phi) at phi = 0 of f(Exp(phi) X) (left perturbation), zero-padded."""
+    from oracle import skinning as sk
+
+    D = torch.float64
+    g = torch.Generator().manual_seed(0)
+    q = torch.nn.functional.normalize(torch.randn(7, 4, generator=g, dtype=D), dim=-1)
+    q = torch.where(q[:, 3:] < 0, -q, q)                                   # Log's principal branch
+    p = torch.randn(7, 3, generator=g, dtype=D)
+    h = torch.randn(7, 3, generator=g, dtype=D)
+    eps = 1e-6
+
+    def perturbed(i, sgn):
+        phi = torch.zeros(7, 3, dtype=D)
+        phi[:, i] = sgn * eps
+        return sk.quat_mul(sk.so3_exp(phi), q)
+
+    # SO3_Act: X_grad[:3] = d/dphi <h, (Exp(phi) X) p>
+    qa = q.clone().requires_grad_(True)
+    (sk._ActPP.apply(qa, p) * h).sum().backward()
+    fd = torch.stack([((sk.quat_act(perturbed(i, +1), p) - sk.quat_act(perturbed(i, -1), p)) * h).sum(-1) / (2 * eps) for i in range(3)], -1)
+    assert torch.allclose(qa.grad[:, :3], fd, atol=1e-7) and not qa.grad[:, 3].any()
+    # SO3_Log: X_grad[:3] = d/dphi <h, Log(Exp(phi) X)>
+    ql = q.clone().requires_grad_(True)
+    (sk._LogPP.apply(ql) * h).sum().backward()
+    fd = torch.stack([((sk.so3_log(perturbed(i, +1)) - sk.so3_log(perturbed(i, -1))) * h).sum(-1) / (2 * eps) for i in range(3)], -1)
+    assert torch.allclose(ql.grad[:, :3], fd, atol=1e-6) and not ql.grad[:, 3].any()
+    # so3_Exp reads an incoming storage gradient's first three components as the left-tangent gradient of its output:
+    # Exp then Log is the identity, so Log's rule after Exp's must hand the tangent gradient back unchanged
+    x = 0.7 * torch.randn(7, 3, generator=g, dtype=D)
+    xe = x.clone().requires_grad_(True)
+    (sk._LogPP.apply(sk._ExpPP.apply(xe)) * h).sum().backward()
+    assert torch.allclose(xe.grad, h, atol=1e-9)
+    # SO3_Mul: the left perturbation of X Y is the left perturbation of X; a perturbation of Y is rotated by X
+    y = torch.nn.functional.normalize(torch.randn(7, 4, generator=g, dtype=D), dim=-1)
+    g4 = torch.randn(7, 4, generator=g, dtype=D)
+    xa, ya = q.clone().requires_grad_(True), y.clone().requires_grad_(True)
+    (sk._MulPP.apply(xa, ya) * g4).sum().backward()
+    assert torch.equal(xa.grad[:, :3], g4[:, :3]) and torch.allclose(ya.grad[:, :3], sk.quat_act(sk.quat_conj(q), g4[:, :3]))
+
+
+def test_pypose_and_exact_gradients_of_the_rotation_head_differ_by_one_half_near_identity():
+    """DESIGN.md "gradient convention": for a small rotation delta the Euclidean gradient with respect to the quaternion's
+    vector part is twice the tangent gradient (q ~ (phi / 2, 1)), so the reference's convention halves the rotation head's
+    gradient relative to the exact one."""
+    from oracle import skinning as sk
+
+    D = torch.float64
+    g = torch.Generator().manual_seed(1)
+    sc = syn.mesh_bound_scene(400, n_nodes=30, k=4, seed=2)
+    verts, idx, w = torch.tensor(sc["verts"], dtype=D), torch.tensor(sc["nbr_idx"]), torch.tensor(sc["nbr_w"], dtype=D)
+    dx, ds, do = torch.zeros(30, 3, dtype=D), torch.zeros(30, 6, dtype=D), torch.zeros(30, 1, dtype=D)
+    gx = torch.randn(len(verts), 3, generator=g, dtype=D)
+    grads = {}
+    for mode in ("exact", "pypose"):
+        dr = (1e-4 * torch.randn(30, 4, generator=torch.Generator().manual_seed(5), dtype=D)).requires_grad_(True)
+        trans, q, S, op = sk.node_attributes(dx, dr, ds, do)
+        xyz, _ = sk.skin_vertices(verts, idx, w, trans, q, S, op, "lbs", grad_mode=mode)
+        (xyz * gx).sum().backward()
+        grads[mode] = dr.grad[:, :3].clone()
+    assert torch.allclose(grads["pypose"], 0.5 * grads["exact"], rtol=2e-3, atol=1e-6 * float(grads["exact"].abs().max()))

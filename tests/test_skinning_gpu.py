@@ -32,9 +32,12 @@ def _close(a, b, rtol, name):
     assert err < rtol, (name, err)
 
 
+@pytest.mark.parametrize("grad_mode", ["exact", "pypose"])
 @pytest.mark.parametrize("method", ["lbs", "dqs", "hybrid"])
 @pytest.mark.parametrize("n_faces,M,K", [(2000, 150, 4), (600, 40, 8)])
-def test_skin_vertices_parity(method, n_faces, M, K):
+def test_skin_vertices_parity(method, n_faces, M, K, grad_mode):
+    """grad_mode "exact": fp64 autograd of the oracle's tensor ops; "pypose": the oracle's restatement of pypose's backward
+    rules (oracle/skinning.py: SO3_Log / so3_Exp / SO3_Act / SO3_Mul) -- the convention the reference trains with."""
     _need_gpu()
     from dreammesh4d_amd import ops
     from oracle import skinning as sk
@@ -43,13 +46,13 @@ def test_skin_vertices_parity(method, n_faces, M, K):
     sc, raw = _setup(n_faces, M, K, seed=K)
     graph = ops.DeformGraph(sc["verts"], sc["nbr_idx"], sc["nbr_w"], M, dev)
     leaves = {k: v.to(dev).requires_grad_(True) for k, v in raw.items()}
-    xyz, rot = ops.skin_vertices(graph, leaves["dx"], leaves["dr"], leaves["ds"], leaves["do"].view(-1), method=method)
+    xyz, rot = ops.skin_vertices(graph, leaves["dx"], leaves["dr"], leaves["ds"], leaves["do"].view(-1), method=method, grad_mode=grad_mode)
     # oracle in float64 on the float32 inputs
     o = {k: v.to(D).requires_grad_(True) for k, v in raw.items()}
     verts, idx = torch.tensor(sc["verts"], dtype=D), torch.tensor(sc["nbr_idx"])
     w = torch.tensor(sc["nbr_w"], dtype=D)
     trans, q, S, op = sk.node_attributes(o["dx"], o["dr"], o["ds"], o["do"])
-    oxyz, orot = sk.skin_vertices(verts, idx, w, trans, q, S, op, method)
+    oxyz, orot = sk.skin_vertices(verts, idx, w, trans, q, S, op, method, grad_mode=grad_mode)
     assert np.abs(xyz.detach().cpu().numpy() - oxyz.detach().numpy()).max() < 2e-6
     assert np.abs(rot.detach().cpu().numpy() - orot.detach().numpy()).max() < 2e-6
     gen = torch.Generator().manual_seed(1)
@@ -66,13 +69,14 @@ def test_skin_vertices_parity(method, n_faces, M, K):
     g1 = leaves["dr"].grad.clone()
     for v in leaves.values():
         v.grad = None
-    xyz2, rot2 = ops.skin_vertices(graph, leaves["dx"], leaves["dr"], leaves["ds"], leaves["do"].view(-1), method=method)
+    xyz2, rot2 = ops.skin_vertices(graph, leaves["dx"], leaves["dr"], leaves["ds"], leaves["do"].view(-1), method=method, grad_mode=grad_mode)
     torch.autograd.backward([xyz2, rot2], [gx.to(dev), gr.to(dev)])
     assert torch.equal(g1, leaves["dr"].grad)
 
 
+@pytest.mark.parametrize("grad_mode", ["exact", "pypose"])
 @pytest.mark.parametrize("G", [6, 1, 3, 4])
-def test_face_gaussians_parity(G):
+def test_face_gaussians_parity(G, grad_mode):
     _need_gpu()
     from dreammesh4d_amd import ops
     from oracle import skinning as sk
@@ -89,9 +93,9 @@ def test_face_gaussians_parity(G):
     qs = sk.static_quaternions(verts, faces, cplx, n_per_face=G).float()
     topo = ops.MeshTopology(sc["faces"], V, G, dev)
     lx, lr = vxyz.to(dev).requires_grad_(True), vrot.to(dev).requires_grad_(True)
-    means, rots, normals = ops.face_gaussians(topo, lx, lr, qs.to(dev))
+    means, rots, normals = ops.face_gaussians(topo, lx, lr, qs.to(dev), grad_mode=grad_mode)
     ox, orr = vxyz.to(D).requires_grad_(True), vrot.to(D).requires_grad_(True)
-    om, oq, on = sk.face_gaussians(ox, orr, faces, qs.to(D), n_per_face=G)
+    om, oq, on = sk.face_gaussians(ox, orr, faces, qs.to(D), n_per_face=G, grad_mode=grad_mode)
     assert means.shape == (N, 3) and rots.shape == (N, 4) and normals.shape == (N, 3)
     assert np.abs(means.detach().cpu().numpy() - om.detach().numpy()).max() < 1e-6
     assert np.abs(rots.detach().cpu().numpy() - oq.detach().numpy()).max() < 2e-6
@@ -148,3 +152,25 @@ def test_full_size_200k_mesh_forward():
     assert np.abs(means.cpu().numpy() - om.numpy()).max() < 2e-6
     assert np.abs(rots.cpu().numpy() - oq.numpy()).max() < 4e-6
     assert np.abs(normals.cpu().numpy() - on.numpy()).max() < 1e-4
+
+
+def test_pypose_matrix_gradient_convention_on_device():
+    """ops.quat_xyzw_to_matrix(grad_mode="pypose") (the ARAP term's vertex rotation matrices, dynamic_sugar.py:640-655) against
+    the oracle's SO3_Act rule applied to the three basis vectors."""
+    _need_gpu()
+    from dreammesh4d_amd import ops
+    from oracle import skinning as sk
+
+    g = torch.Generator().manual_seed(2)
+    q = torch.nn.functional.normalize(torch.randn(50, 4, generator=g, dtype=D), dim=-1)
+    G_ = torch.randn(50, 3, 3, generator=g, dtype=D)
+    qd = q.float().cuda().requires_grad_(True)
+    R = ops.quat_xyzw_to_matrix(qd, "pypose")
+    R.backward(G_.float().cuda())
+    qo = q.clone().requires_grad_(True)
+    eye = torch.eye(3, dtype=D)
+    Ro = torch.stack([sk._ActPP.apply(qo, eye[j].expand(50, 3)) for j in range(3)], dim=-1)
+    assert np.abs(R.detach().cpu().numpy() - Ro.detach().numpy()).max() < 1e-6
+    Ro.backward(G_)
+    _close(qd.grad.cpu(), qo.grad, 1e-5, "pypose matrix gradient")
+    assert not qd.grad[:, 3].any()                                        # tangent gradient padded with a zero

@@ -60,8 +60,8 @@ def test_batched_views_equal_per_call_composition():
     torch.autograd.backward([out["color"], out["depth"], out["alpha"], out["vxyz"]], [gC, gD, gA, gV])
     for b in range(B):
         l2 = {k: raw[k][b].clone().requires_grad_(True) for k in raw}
-        xyz, vrot = ops.skin_vertices(graph, l2["trans"], l2["d_rot"], l2["strain"], l2["d_opacity"].view(-1), "hybrid")
-        means, rots, normals = ops.face_gaussians(topo, xyz, vrot, qs)
+        xyz, vrot = ops.skin_vertices(graph, l2["trans"], l2["d_rot"], l2["strain"], l2["d_opacity"].view(-1), "hybrid", grad_mode=r.grad_mode)
+        means, rots, normals = ops.face_gaussians(topo, xyz, vrot, qs, grad_mode=r.grad_mode)
         assert torch.equal(out["vxyz"][b], xyz) and torch.equal(out["vrot"][b], vrot)
         h = HipRaster(cams[b], bg=(1, 1, 1, 1, 1, 1))
         col6 = torch.cat([rgb, normals.detach()], dim=1).cpu().numpy()
