@@ -79,6 +79,8 @@ class DynamicSuGaR(nn.Module):
         self._xyz_neighbor_nodes_weights = T(nbr_w)
         M = int(self._deform_graph_node_xyz.shape[0])
         self.graph = ops.DeformGraph(verts, self._xyz_neighbor_node_idx, self._xyz_neighbor_nodes_weights, M, dev)
+        self.graph.verts = self._points.data           # one storage: load_state_dict copies stage-2 vertices in place, skinning sees them
+        self.register_load_state_dict_post_hook(lambda module, incompatible_keys: module.invalidate_static())
         self.topo = ops.MeshTopology(faces, V, G, dev)
         # deformation network: heads as in dynamic_sugar.py:141-147
         self.d_scale = bool(d_scale)

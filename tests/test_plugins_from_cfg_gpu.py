@@ -181,3 +181,74 @@ def test_static_stage_plugins_from_the_shipped_config_block(tmp_path):
     assert geometry._sh_coordinates_dc.grad[2:].abs().sum() > 0 and geometry._points.grad.abs().sum() > 0
     opt.step()
     assert all(torch.isfinite(p).all() for p in geometry.parameters())
+
+
+def test_checkpoint_hand_off_static_stage_to_dynamic_stage_and_resume(tmp_path):
+    """the stage-2 checkpoint (``geometry.*`` keys of a Lightning ``state_dict``, threestudio/utils/misc.py:33-63) is
+    what the dynamic stage starts from (``system.weights``, loaded non-strict: the deformation network and the graph are new) --
+    the same Gaussians must come out of both geometries -- and a dynamic-stage checkpoint resumes bit-identically."""
+    if not torch.cuda.is_available():
+        pytest.skip("no HIP device")
+    from dreammesh4d_amd import threestudio_host as ts, wire_formats as wf
+
+    dev = torch.device("cuda:0")
+    mesh, _, _ = _stand_ins(tmp_path, 1, dev)
+    scfg = ts.resolve({"data": DATA, "system": STATIC_SYSTEM})["system"]
+    scfg["geometry"]["surface_mesh_to_bind_path"] = mesh
+    static = ts.find("sugar")(scfg["geometry"])
+    bg = ts.find("solid-color-background")(None)
+    torch.manual_seed(3)
+    with torch.no_grad():                                                       # "trained": every learnable tensor moved
+        # (colours kept inside (0, 1): the static renderer clamps SH colours at 0, the dynamic one blends SH2RGB as is --
+        #  sugar.py:640-661 vs the rasterizer's SH path -- so the two stages only agree where nothing is clamped)
+        static._sh_coordinates_dc.copy_((torch.rand_like(static._sh_coordinates_dc) * 0.9 + 0.05 - 0.5) / 0.28209479177387814)
+        static._scales.add_(0.2 * torch.randn_like(static._scales))
+        static._quaternions.add_(0.2 * torch.randn_like(static._quaternions))
+        static.all_densities.add_(torch.randn_like(static.all_densities))
+        static._points.add_(0.002 * torch.randn_like(static._points))
+    ck = tmp_path / "static_last.ckpt"
+    wf.save_checkpoint(ck, {"geometry": static, "background": bg}, epoch=0, global_step=2000)
+    keys = set(torch.load(ck, weights_only=False)["state_dict"])
+    assert {"geometry._points", "geometry._surface_mesh_faces", "geometry.surface_mesh_thickness", "geometry.all_densities",
+            "geometry._sh_coordinates_dc", "geometry._sh_coordinates_rest", "geometry._scales", "geometry._quaternions"} <= keys
+    # ---- dynamic stage: constructed from the mesh, then the stage-2 weights (the vertices in the file win over the PLY's)
+    dcfg = ts.resolve({"data": DATA, "system": DYNAMIC_SYSTEM})["system"]
+    dcfg["geometry"]["surface_mesh_to_bind_path"] = mesh
+    dyn = ts.find("dynamic-sugar")(dcfg["geometry"])
+    missing, unexpected, epoch, step = wf.load_geometry(dyn, ck, strict=False)
+    assert (epoch, step) == (0, 2000)
+    assert all(k.startswith(("_deformation", "_deform_graph", "_xyz_neighbor", "_dg_", "_vert_")) for k in missing), missing
+    assert all(k in ("_bary",) for k in unexpected), unexpected
+    for name in ("_points", "_scales", "_quaternions", "all_densities", "_sh_coordinates_dc", "_surface_mesh_faces"):
+        assert torch.equal(getattr(dyn, name), getattr(static, name)), name
+    mat = ts.find("no-material")({"n_output_dims": 0})
+    r_static = ts.find("diff-sugar-rasterizer-normal")(scfg["renderer"], geometry=static, material=mat, background=bg)
+    r_dyn = ts.find("diff-sugar-rasterizer-temporal")(dcfg["renderer"], geometry=dyn, material=mat, background=bg)
+    B, H, W = 2, 192, 192
+    t_mid = torch.tensor([0.4, 0.4], device=dev)
+    with torch.no_grad():
+        a = r_static.batch_forward(_batch(B, H, W, dev))
+        b = r_dyn.batch_forward(_batch(B, H, W, dev, timestamps=t_mid))
+    # zero-initialised deformation heads: the dynamic geometry at any timestamp IS the static one (skinning by identity transforms)
+    assert float((a["comp_rgb"] - b["comp_rgb"]).abs().max()) < 2e-3 and float((a["comp_rgb"] - b["comp_rgb"]).abs().mean()) < 1e-5
+    assert float((a["comp_mask"] - b["comp_mask"]).abs().mean()) < 1e-5
+    # ---- resume: a dynamic checkpoint into a freshly constructed geometry (the graph is not in the file -- as in the reference it is
+    #      rebuilt from the mesh at construction; `dg_node_seed` makes the node samples the same ones)
+    with torch.no_grad():
+        for n, p in dyn._deformation.named_parameters():
+            if "_deform" in n or "grids" in n:
+                p.add_(0.02 * torch.randn_like(p))
+    ck2 = tmp_path / "dynamic_last.ckpt"
+    wf.save_checkpoint(ck2, {"geometry": dyn}, epoch=1, global_step=700)
+    dcfg2 = ts.resolve({"data": DATA, "system": DYNAMIC_SYSTEM})["system"]
+    dcfg2["geometry"].update(surface_mesh_to_bind_path=mesh)
+    dyn2 = ts.find("dynamic-sugar")(dcfg2["geometry"])
+    missing, unexpected, epoch, step = wf.load_geometry(dyn2, ck2, strict=True)
+    assert not missing and not unexpected and (epoch, step) == (1, 700)
+    r_dyn2 = ts.find("diff-sugar-rasterizer-temporal")(dcfg2["renderer"], geometry=dyn2, material=mat, background=bg)
+    with torch.no_grad():
+        c = r_dyn.batch_forward(_batch(B, H, W, dev, timestamps=t_mid))
+        d = r_dyn2.batch_forward(_batch(B, H, W, dev, timestamps=t_mid))
+    assert float((c["comp_rgb"] - b["comp_rgb"]).abs().max()) > 1e-3           # the deformation moved the mesh
+    for k in ("comp_rgb", "comp_mask", "comp_depth", "comp_normal"):
+        assert torch.equal(c[k], d[k]), k

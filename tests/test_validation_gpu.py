@@ -50,6 +50,26 @@ def test_sweep_equals_per_frame_rendering():
                                        T(c.viewmatrix)[None], T(c.projmatrix)[None], bg6)
                 assert torch.equal(o["color"][0, :3].clamp(0, 1).permute(1, 2, 0), got["comp_rgb"][f, a])
                 assert torch.equal(o["depth"][0].permute(1, 2, 0), got["depth"][f, a])
+    # one unit against the CPU oracle (float64 skinning + face Gaussians, float32 rasterizer): frame 3 from azimuth 120
+    from oracle import raster as orc, skinning as sk
+
+    D = torch.float64
+    tt = lambda a: torch.tensor(np.asarray(a), dtype=D)
+    f, a = 3, 1
+    with torch.no_grad():
+        dx, dr, ds, do = net.node_outputs(nodes, ts[f:f + 1])
+    trans, q, S, op = sk.node_attributes(dx[0].cpu().to(D), dr[0].cpu().to(D), ds[0].cpu().to(D), do[0].cpu().to(D).reshape(M, -1))
+    xyz, vrot = sk.skin_vertices(tt(sc["verts"]), torch.tensor(sc["nbr_idx"]), tt(sc["nbr_w"]), trans, q, S, op, "hybrid")
+    qs64 = sk.static_quaternions(tt(sc["verts"]), torch.tensor(sc["faces"]), tt(sc["complex"]))
+    means, rots, _ = sk.face_gaussians(xyz, vrot, torch.tensor(sc["faces"]), qs64)
+    c = syn.make_camera(H, W, elev_deg=0.0, azim_deg=az[a])
+    o = orc.RasterOracle(image_height=H, image_width=W, tanfovx=c.tanfov, tanfovy=c.tanfov, bg=(0, 0, 0), scale_modifier=1.0,
+                         viewmatrix=c.viewmatrix, projmatrix=c.projmatrix, campos=c.campos)
+    o.forward(means.float().numpy(), static["opacities"].view(-1).cpu().numpy(), colors_precomp=static["rgb"].cpu().numpy(),
+              scales=static["scales"].cpu().numpy(), rotations=rots.float().numpy())
+    want = np.clip(np.moveaxis(o.s["out_color"], 0, -1), 0, 1)
+    assert np.abs(got["comp_rgb"][f, a].cpu().numpy() - want).max() < 2e-3
+    assert np.abs(got["opacity"][f, a, :, :, 0].cpu().numpy() - o.s["out_alpha"]).max() < 2e-3 and (o.s["out_alpha"] > 0.5).mean() > 0.1
     # streaming variant hands the same chunks to the callback
     seen = []
     assert validation.sweep(r, net, nodes, static, ts, azimuths_deg=az, frames_per_call=4,
