@@ -1,0 +1,89 @@
+"""GroupNorm (+ SiLU) of the Zero123 SDS step for channels-last activations: the torch-side binding of
+csrc/groupnorm.hip (``dm4d_groupnorm_nhwc_forward`` / ``_backward``, include/dm4d.h).
+
+``group_norm(module, x, silu=False, add=None)`` evaluates ``act(module(x + add[:, :, None, None]))`` for a
+``torch.nn.GroupNorm`` -- the "GroupNorm32, SiLU" pairs of the reference's ResBlocks
+(extern/ldm_zero123/modules/diffusionmodules/openaimodel.py:214-275), the VAE encoder's "Normalize, nonlinearity"
+(diffusionmodules/model.py) and the plain norms in front of the attention blocks.  On a HIP device with a dense
+channels-last input the HIP kernels run (two launches, the activation read twice and written once); anything else --
+CPU tensors of the golden-vector tests, NCHW tensors -- takes torch's own operators, literally as the reference writes
+them.  gamma / beta are treated as frozen: the guidance model is not trained (guidance/...zero123_guidance.py:90-91),
+so backward returns dL/dx only.
+"""
+import torch
+import torch.nn.functional as F
+
+from . import _lib
+
+_DTYPES = {torch.float16: 0, torch.float32: 1}      # DM4D_GN_F16, DM4D_GN_F32
+MAX_SPLITS = 128                                    # DM4D_GN_MAX_SPLITS
+
+
+def _splits(hw):
+    """Workgroups per sample: slabs of >= 16 positions, at most DM4D_GN_MAX_SPLITS."""
+    return max(1, min(MAX_SPLITS, hw // 16))
+
+
+def is_channels_last(x):
+    return x.dim() == 4 and x.is_contiguous(memory_format=torch.channels_last)
+
+
+class _GroupNormNHWC(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, add, groups, eps, silu):
+        N, C, H, W = x.shape
+        L = _lib.lib()
+        y = torch.empty_like(x)                                    # same (channels-last) strides
+        S = _splits(H * W)
+        stats = torch.empty(N, groups, 2, device=x.device, dtype=torch.float32)
+        scratch = torch.empty(N, S, groups, 2, device=x.device, dtype=torch.float32)
+        _lib.check(L.dm4d_groupnorm_nhwc_forward(N, H * W, C, groups, _DTYPES[x.dtype], x.data_ptr(),
+                                                 0 if add is None else add.data_ptr(), weight.data_ptr(), bias.data_ptr(), eps,
+                                                 int(silu), y.data_ptr(), stats.data_ptr(), scratch.data_ptr(), S,
+                                                 torch.cuda.current_stream(x.device).cuda_stream), "groupnorm forward")
+        ctx.save_for_backward(x, weight, bias, stats)
+        ctx.cfg = (groups, bool(silu), S)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight, bias, stats = ctx.saved_tensors
+        groups, silu, S = ctx.cfg
+        N, C, H, W = x.shape
+        if not is_channels_last(dy):
+            dy = dy.contiguous(memory_format=torch.channels_last)
+        L = _lib.lib()
+        dx = torch.empty_like(x)
+        scratch = torch.empty(N, S, groups, 2, device=x.device, dtype=torch.float32)
+        _lib.check(L.dm4d_groupnorm_nhwc_backward(N, H * W, C, groups, _DTYPES[x.dtype], x.data_ptr(), weight.data_ptr(),
+                                                  bias.data_ptr(), stats.data_ptr(), int(silu), dy.data_ptr(), dx.data_ptr(),
+                                                  scratch.data_ptr(), S, torch.cuda.current_stream(x.device).cuda_stream),
+                   "groupnorm backward")
+        return dx, None, None, None, None, None, None
+
+
+def fused_ok(module, x):
+    w = module.weight
+    return (x.is_cuda and is_channels_last(x) and x.dtype in _DTYPES and w is not None and module.bias is not None
+            and w.dtype == x.dtype and x.shape[1] % (8 if x.dtype == torch.float16 else 4) == 0 and x.shape[0] > 0
+            and not (torch.is_grad_enabled() and (w.requires_grad or module.bias.requires_grad)))
+
+
+def group_norm(module, x, silu=False, add=None, float32=False):
+    """act(GroupNorm(x + add[:, :, None, None])).  `float32`: the reference's GroupNorm32 (statistics and affine map
+    evaluated in float32 around half-precision storage) -- what the HIP kernels do for every input."""
+    if fused_ok(module, x):
+        if add is not None:
+            if torch.is_grad_enabled() and (x.requires_grad or add.requires_grad):      # the fusion of `add` is forward-only
+                x, add = x + add.type(x.dtype)[:, :, None, None], None
+            else:
+                add = add.to(x.dtype).contiguous()
+        return _GroupNormNHWC.apply(x, module.weight, module.bias, add, module.num_groups, module.eps, silu)
+    if add is not None:
+        x = x + add.type(x.dtype)[:, :, None, None]
+    if float32 and not (x.is_cuda and x.dtype in (torch.float16, torch.bfloat16) and module.weight.dtype == x.dtype):
+        y = F.group_norm(x.float(), module.num_groups, module.weight.float(), module.bias.float(), module.eps).type(x.dtype)
+    else:
+        # (half tensors on a device: the library kernel already accumulates in float32 and rounds once)
+        y = F.group_norm(x, module.num_groups, module.weight, module.bias, module.eps)
+    return F.silu(y) if silu else y

@@ -12,7 +12,11 @@ and of the pieces of the vendored LDM they call:
   extern/ldm_zero123/models/diffusion/ddpm.py:653 (cc_projection), :1953-1956 (hybrid conditioning).
 
 This is where MFMA belongs on this path: dense conv / GEMM through PyTorch-ROCm (MIOpen / hipBLASLt), fp16
-weights, attention through F.scaled_dot_product_attention instead of einsum + softmax.  No hand kernel.
+weights, attention through F.scaled_dot_product_attention instead of einsum + softmax.  On a HIP device the
+activations are kept channels-last (NHWC) end to end -- MIOpen's implicit-GEMM convolutions are NHWC kernels and wrap
+NCHW tensors in transposes, 11 % of the step in profiles/r02_zero123.md -- the 1x1 convolutions around the attention
+blocks become plain GEMMs on the token view of the same memory, and every GroupNorm (+ SiLU, + the ResBlock's
+timestep-embedding add) is ONE hand-written HIP operator (fused_norm.py, csrc/groupnorm.hip).
 
 Module and parameter names follow the LDM checkpoint layout (`model.diffusion_model.*`,
 `first_stage_model.encoder.*`, `first_stage_model.quant_conv.*`, `cc_projection.*`) so
@@ -26,21 +30,31 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from .fused_norm import group_norm, is_channels_last
+
 
 # ----------------------------------------------------------------------------- building blocks
 class GroupNorm32(nn.GroupNorm):
-    """GroupNorm evaluated in fp32 (extern/ldm_zero123/modules/diffusionmodules/util.py:242-244)."""
+    """GroupNorm evaluated in fp32 (extern/ldm_zero123/modules/diffusionmodules/util.py:242-244).  Half tensors on a device:
+    both the HIP operator and the library kernel accumulate the statistics and evaluate the affine map in float32 and round
+    once on output -- within 1 half-precision ulp of casting to float32 around it (measured), without the cast launches.
+    float32 modules (the golden-vector tests) take the reference's literal path."""
 
     def forward(self, x):
-        if x.is_cuda and x.dtype in (torch.float16, torch.bfloat16) and self.weight is not None and self.weight.dtype == x.dtype:
-            # the device kernel already accumulates the statistics and evaluates the affine map in float32 for half inputs
-            # (acc_type) and rounds once on output: within 1 half-precision ulp of casting to float32 around it (measured),
-            # without the four cast launches per call (61 calls per UNet forward).  float32 modules (the golden-vector
-            # tests) take the reference's literal path below.
-            return F.group_norm(x, self.num_groups, self.weight, self.bias, self.eps)
-        w = None if self.weight is None else self.weight.float()
-        b = None if self.bias is None else self.bias.float()
-        return F.group_norm(x.float(), self.num_groups, w, b, self.eps).type(x.dtype)
+        return group_norm(self, x, float32=True)
+
+
+def _to_nhwc(x):
+    return x if is_channels_last(x) else x.contiguous(memory_format=torch.channels_last)
+
+
+def _conv1x1(conv, x):
+    """A 1x1 convolution; on a channels-last tensor a GEMM over the [B, H*W, C] token view of the same memory."""
+    if x.is_cuda and is_channels_last(x):
+        B, Cc, Hh, Ww = x.shape
+        y = F.linear(x.permute(0, 2, 3, 1).reshape(B, Hh * Ww, Cc), conv.weight.flatten(1), conv.bias)
+        return y.view(B, Hh, Ww, -1).permute(0, 3, 1, 2)
+    return conv(x)
 
 
 def timestep_embedding(t, dim, max_period=10000):
@@ -83,9 +97,11 @@ class ResBlock(nn.Module):
         self.skip_connection = nn.Identity() if ch == out_ch else nn.Conv2d(ch, out_ch, 1)
 
     def forward(self, x, emb):
-        h = self.in_layers(x)
-        h = h + self.emb_layers(emb).type(h.dtype)[:, :, None, None]
-        return self.skip_connection(x) + self.out_layers(h)
+        h = self.in_layers[2](group_norm(self.in_layers[0], x, silu=True, float32=True))
+        # h + emb[:, :, None, None], GroupNorm, SiLU (openaimodel.py:259-275) in one operator; Dropout(0) is the identity
+        h = group_norm(self.out_layers[0], h, silu=True, add=self.emb_layers(emb), float32=True)
+        skip = x if isinstance(self.skip_connection, nn.Identity) else _conv1x1(self.skip_connection, x)
+        return skip + self.out_layers[3](h)
 
 
 class CrossAttention(nn.Module):
@@ -157,12 +173,12 @@ class SpatialTransformer(nn.Module):
 
     def forward(self, x, context):
         B, Cc, Hh, Ww = x.shape
-        h = self.proj_in(self.norm(x))
-        h = h.flatten(2).transpose(1, 2)                      # b (h w) c
+        h = _conv1x1(self.proj_in, group_norm(self.norm, x))
+        h = h.flatten(2).transpose(1, 2)                      # b (h w) c  (a view of a channels-last tensor)
         for blk in self.transformer_blocks:
             h = blk(h, context)
         h = h.transpose(1, 2).reshape(B, -1, Hh, Ww)
-        return self.proj_out(h) + x
+        return _conv1x1(self.proj_out, h) + x
 
 
 class _Seq(nn.Sequential):
@@ -184,6 +200,7 @@ class UNetModel(nn.Module):
                  num_res_blocks=2, channel_mult=(1, 2, 4, 4), num_heads=8, context_dim=768, transformer_depth=1):
         super().__init__()
         self.model_channels = model_channels
+        self.channels_last = True             # activations NHWC on a HIP device (see the module docstring)
         emb = model_channels * 4
         self.time_embed = nn.Sequential(nn.Linear(model_channels, emb), nn.SiLU(), nn.Linear(emb, emb))
         att = lambda ch: SpatialTransformer(ch, num_heads, ch // num_heads, context_dim, transformer_depth)
@@ -219,14 +236,15 @@ class UNetModel(nn.Module):
 
     def forward(self, x, timesteps, context):
         emb = self.time_embed(timestep_embedding(timesteps, self.model_channels).type(x.dtype))
-        hs, h = [], x
+        hs, h = [], (_to_nhwc(x) if x.is_cuda and self.channels_last else x)
         for m in self.input_blocks:
             h = m(h, emb, context)
             hs.append(h)
         h = self.middle_block(h, emb, context)
         for m in self.output_blocks:
             h = m(torch.cat([h, hs.pop()], dim=1), emb, context)
-        return self.out(h.type(x.dtype))
+        h = self.out[2](group_norm(self.out[0], h.type(x.dtype), silu=True, float32=True))
+        return h.contiguous()
 
 
 # ----------------------------------------------------------------------------- VAE encoder
@@ -242,8 +260,8 @@ class _VaeRes(nn.Module):
             self.nin_shortcut = nn.Conv2d(cin, cout, 1)
 
     def forward(self, x):
-        h = self.conv1(F.silu(self.norm1(x)))
-        h = self.conv2(self.dropout(F.silu(self.norm2(h))))
+        h = self.conv1(group_norm(self.norm1, x, silu=True))
+        h = self.conv2(self.dropout(group_norm(self.norm2, h, silu=True)))
         return (self.nin_shortcut(x) if hasattr(self, "nin_shortcut") else x) + h
 
 
@@ -255,10 +273,10 @@ class _VaeAttn(nn.Module):
 
     def forward(self, x):
         B, Cc, Hh, Ww = x.shape
-        h = self.norm(x)
-        q, k, v = (f(h).flatten(2).transpose(1, 2)[:, None] for f in (self.q, self.k, self.v))   # b 1 (hw) c
+        h = group_norm(self.norm, x)
+        q, k, v = (_conv1x1(f, h).flatten(2).transpose(1, 2)[:, None] for f in (self.q, self.k, self.v))   # b 1 (hw) c
         o = F.scaled_dot_product_attention(q, k, v)[:, 0].transpose(1, 2).reshape(B, Cc, Hh, Ww)
-        return x + self.proj_out(o)
+        return x + _conv1x1(self.proj_out, o)
 
 
 class _VaeDown(nn.Module):
@@ -277,6 +295,7 @@ class _Level(nn.Module):
 class VaeEncoder(nn.Module):
     def __init__(self, ch=128, ch_mult=(1, 2, 4, 4), num_res_blocks=2, in_channels=3, z_channels=4):
         super().__init__()
+        self.channels_last = True
         self.conv_in = nn.Conv2d(in_channels, ch, 3, padding=1)
         self.down = nn.ModuleList()
         cin = ch
@@ -298,14 +317,14 @@ class VaeEncoder(nn.Module):
         self.conv_out = nn.Conv2d(cin, 2 * z_channels, 3, padding=1)
 
     def forward(self, x):
-        h = self.conv_in(x)
+        h = self.conv_in(_to_nhwc(x) if x.is_cuda and self.channels_last else x)
         for lvl in self.down:
             for b in lvl.block:
                 h = b(h)
             if hasattr(lvl, "downsample"):
                 h = lvl.downsample(h)
         h = self.mid.block_2(self.mid.attn_1(self.mid.block_1(h)))
-        return self.conv_out(F.silu(self.norm_out(h)))
+        return self.conv_out(group_norm(self.norm_out, h, silu=True)).contiguous()
 
 
 class FirstStage(nn.Module):
@@ -386,7 +405,7 @@ class TemporalStableZero123Guidance(nn.Module):
 
     def __init__(self, model: Zero123, c_crossattn, c_concat, cond_elevation_deg=0.0, cond_azimuth_deg=0.0,
                  guidance_scale=3.0, min_step_percent=0.02, max_step_percent=0.98, grad_clip=None,
-                 half_precision_weights=True, use_graphs=True):
+                 half_precision_weights=True, use_graphs=True, channels_last=True):
         super().__init__()
         # The SDS step is ~2000 small launches (UNet forward at 32x32 latents, VAE encoder forward + backward) whose
         # shapes never change: on a HIP device both halves are captured once per batch size as hipGraphs
@@ -396,6 +415,10 @@ class TemporalStableZero123Guidance(nn.Module):
         self._unet_graphs, self._enc_graphed, self._graph_error = {}, {}, None
         self.weights_dtype = torch.float16 if half_precision_weights else torch.float32
         self.model = model.to(self.weights_dtype)
+        # NHWC activations + filters on a HIP device (module docstring); `channels_last=False` keeps the NCHW library path
+        self.model.model.diffusion_model.channels_last = self.model.first_stage_model.encoder.channels_last = bool(channels_last)
+        if channels_last:
+            self.model.to(memory_format=torch.channels_last)
         for p in self.model.parameters():
             p.requires_grad_(False)
         self.register_buffer("c_crossattn", c_crossattn.to(self.weights_dtype), persistent=False)   # [L,1,ctx] CLIP embeddings

@@ -180,6 +180,29 @@ int dm4d_debug_sort_trace(void *trace);
 int dm4d_mark_visible(int32_t N, const float *means3D, const float *viewmatrix, uint8_t *present,
                       dm4d_stream_t stream);
 
+/* ------------------------------------------------------------------ Zero123 SDS step: GroupNorm (+ SiLU) over NHWC activations */
+
+/* torch.nn.GroupNorm followed (silu != 0) by SiLU, for activations stored channels-last -- what
+ * extern/ldm_zero123/modules/diffusionmodules/util.py:242-244 (GroupNorm32), openaimodel.py:259-275 (ResBlock
+ * "GroupNorm, SiLU, conv") and diffusionmodules/model.py (Normalize, nonlinearity) evaluate ~100 times per SDS step:
+ *     y[n, p, c] = act( (x[n, p, c] + add[n, c] - mean[n, g]) * rstd[n, g] * gamma[c] + beta[c] ),   g = c / (C / G)
+ * x, y [N, HW, C]; add [N, C] or NULL (the ResBlock's timestep-embedding term); gamma, beta [C]; all of `dtype`
+ * (DM4D_GN_F16: 16-bit floats, C % 8 == 0; DM4D_GN_F32: C % 4 == 0); statistics in float32 over the C / G channels of a
+ * group and all HW positions, biased variance, as torch.  stats [N, G, 2] (out): mean, rstd -- what backward needs.
+ * scratch [N, splits, G, 2] floats, uninitialised; 1 <= splits <= DM4D_GN_MAX_SPLITS = workgroups per sample (each
+ * owns ceil(HW / splits) consecutive positions).  Results do not depend on run-to-run scheduling (no atomics). */
+#define DM4D_GN_F16 0
+#define DM4D_GN_F32 1
+#define DM4D_GN_MAX_SPLITS 128
+int dm4d_groupnorm_nhwc_forward(int32_t N, int32_t HW, int32_t C, int32_t G, int32_t dtype, const void *x, const void *add,
+                                const void *gamma, const void *beta, float eps, int32_t silu, void *y, float *stats,
+                                float *scratch, int32_t splits, dm4d_stream_t stream);
+/* dL/dx of the above for frozen gamma / beta (the guidance model is not trained): x as given to forward (with `add` == NULL),
+ * stats from forward, dy / dx [N, HW, C]. */
+int dm4d_groupnorm_nhwc_backward(int32_t N, int32_t HW, int32_t C, int32_t G, int32_t dtype, const void *x, const void *gamma,
+                                 const void *beta, const float *stats, int32_t silu, const void *dy, void *dx,
+                                 float *scratch, int32_t splits, dm4d_stream_t stream);
+
 /* ------------------------------------------------------------------ simple-knn */
 
 /* simple_knn._C.distCUDA2 (C/geometry/gaussian_base.py:435-438): out[i] = mean of the squared distances

@@ -1,0 +1,128 @@
+"""-m gpu: the NHWC GroupNorm (+ SiLU, + per-(sample, channel) add) operator of the Zero123 step (csrc/groupnorm.hip through
+dreammesh4d_amd/fused_norm.py) against plain PyTorch float32 of the same op -- forward and dL/dx -- for the channel counts of
+the UNet (320 ... 2560: 10 ... 80 channels per group) and of the VAE encoder (128 ... 512), ragged slabs, float16 and float32
+storage; and the guidance step with NHWC activations against the NCHW library path."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+SHAPES = [(2, 320, 32, 32), (3, 2560, 8, 8), (2, 128, 64, 64), (1, 960, 16, 16), (2, 64, 5, 7), (2, 1920, 16, 16), (1, 512, 32, 32),
+          (2, 32, 3, 3), (1, 1280, 1, 1)]
+
+
+def _need_gpu():
+    if not torch.cuda.is_available():
+        pytest.skip("no HIP device")
+
+
+def _reference(x, add, w, b, G, eps, silu):
+    z = x.float() if add is None else x.float() + add.float()[:, :, None, None]
+    y = F.group_norm(z, G, w.float(), b.float(), eps)
+    return F.silu(y) if silu else y
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.float32])
+@pytest.mark.parametrize("shape", SHAPES)
+def test_forward_and_input_gradient_against_float32_torch(shape, dtype):
+    _need_gpu()
+    from dreammesh4d_amd import fused_norm
+
+    dev = torch.device("cuda:0")
+    N, C, H, W = shape
+    G = 32
+    g = torch.Generator(device="cpu").manual_seed(N * 1000 + C + H)
+    x = (torch.randn(shape, generator=g) * 2.0 + 0.5).to(dev, dtype).contiguous(memory_format=torch.channels_last)
+    add = torch.randn(N, C, generator=g).to(dev, dtype)
+    m = torch.nn.GroupNorm(G, C, eps=1e-5).to(dev, dtype)
+    with torch.no_grad():
+        m.weight.copy_(1.0 + 0.3 * torch.randn(C, generator=g))
+        m.bias.copy_(0.2 * torch.randn(C, generator=g))
+    for p in m.parameters():
+        p.requires_grad_(False)
+    tol = dict(rtol=2e-3, atol=2e-3) if dtype == torch.float16 else dict(rtol=2e-5, atol=2e-5)
+    for silu in (False, True):
+        for a in (None, add):
+            assert fused_norm.fused_ok(m, x)
+            with torch.no_grad():
+                y = fused_norm.group_norm(m, x, silu=silu, add=a)
+                y2 = fused_norm.group_norm(m, x, silu=silu, add=a)
+            assert y.shape == x.shape and y.dtype == dtype and fused_norm.is_channels_last(y)
+            assert torch.equal(y, y2)                                         # no atomics: reproducible
+            want = _reference(x, a, m.weight, m.bias, G, m.eps, silu)
+            torch.testing.assert_close(y.float(), want, **tol)
+        # dL/dx (frozen gamma / beta)
+        xg = x.clone().requires_grad_(True)
+        dy = torch.randn(shape, generator=g).to(dev, dtype).contiguous(memory_format=torch.channels_last)
+        y = fused_norm.group_norm(m, xg, silu=silu)
+        y.backward(dy)
+        xr = x.float().clone().requires_grad_(True)
+        _reference(xr, None, m.weight, m.bias, G, m.eps, silu).backward(dy.float())
+        scale = float(xr.grad.abs().max())
+        gtol = (4e-3 if dtype == torch.float16 else 3e-5) * max(scale, 1e-3)
+        assert float((xg.grad.float() - xr.grad).abs().max()) <= gtol, (silu, float((xg.grad.float() - xr.grad).abs().max()), scale)
+        assert fused_norm.is_channels_last(xg.grad)
+    # an NCHW gradient arriving at a channels-last operator
+    xg = x.clone().requires_grad_(True)
+    y = fused_norm.group_norm(m, xg, silu=True)
+    (y.contiguous() * 2.0).sum().backward()
+    assert torch.isfinite(xg.grad).all()
+
+
+def test_what_falls_back_to_torch_and_what_is_rejected():
+    _need_gpu()
+    from dreammesh4d_amd import _lib, fused_norm
+
+    dev = torch.device("cuda:0")
+    m = torch.nn.GroupNorm(32, 64).to(dev)
+    x = torch.randn(2, 64, 8, 8, device=dev)
+    assert not fused_norm.fused_ok(m, x)                                                        # NCHW
+    assert not fused_norm.fused_ok(m, x.contiguous(memory_format=torch.channels_last))          # trainable gamma with grad enabled
+    with torch.no_grad():
+        assert fused_norm.fused_ok(m, x.contiguous(memory_format=torch.channels_last))
+        y = fused_norm.group_norm(m, x, silu=True)                                               # torch path
+        torch.testing.assert_close(y, F.silu(m(x)))
+    assert not fused_norm.fused_ok(m.half(), x.contiguous(memory_format=torch.channels_last))   # dtype mismatch
+    L = _lib.lib()
+    s = torch.cuda.current_stream().cuda_stream
+    z = torch.zeros(64, device=dev)
+    p = z.data_ptr()
+    assert L.dm4d_groupnorm_nhwc_forward(1, 4, 6, 4, 1, p, 0, p, p, 1e-5, 0, p, p, p, 1, s) != 0       # C not a multiple of G
+    assert L.dm4d_groupnorm_nhwc_forward(1, 4, 8, 4, 7, p, 0, p, p, 1e-5, 0, p, p, p, 1, s) != 0       # dtype
+    assert L.dm4d_groupnorm_nhwc_forward(1, 4, 8, 4, 1, p, 0, p, p, 1e-5, 0, p, p, p, 1000, s) != 0    # splits
+    assert L.dm4d_groupnorm_nhwc_forward(1, 4, 8, 4, 1, 0, 0, p, p, 1e-5, 0, p, p, p, 1, s) != 0       # null x
+    assert L.dm4d_groupnorm_nhwc_forward(0, 4, 8, 4, 1, 0, 0, 0, 0, 1e-5, 0, 0, 0, 0, 1, s) == 0       # empty batch
+
+
+def test_guidance_step_nhwc_against_the_nchw_library_path():
+    """The whole SDS step (UNet under no_grad + VAE encoder forward / backward) with channels-last activations and the HIP
+    GroupNorm against the NCHW path through torch's GroupNorm: same loss and same gradient up to float16 rounding."""
+    _need_gpu()
+    from dreammesh4d_amd import zero123 as z
+
+    dev = torch.device("cuda:0")
+    outs = []
+    for cl in (False, True):
+        torch.manual_seed(0)
+        model = z.Zero123(unet_kwargs=dict(model_channels=64, context_dim=32, num_heads=4), vae_kwargs=dict(ch=32)).to(dev)
+        with torch.no_grad():
+            for p in model.model.diffusion_model.out.parameters():
+                torch.nn.init.normal_(p, std=0.05)
+            for blk in model.model.diffusion_model.modules():       # zero-initialised convolutions: give them something to do
+                if isinstance(blk, z.ResBlock):
+                    torch.nn.init.normal_(blk.out_layers[3].weight, std=0.02)
+                if isinstance(blk, z.SpatialTransformer):
+                    torch.nn.init.normal_(blk.proj_out.weight, std=0.02)
+        g = torch.Generator(device="cpu").manual_seed(1)
+        guid = z.TemporalStableZero123Guidance(model, torch.randn(4, 1, 32, generator=g), torch.randn(4, 4, 32, 32, generator=g),
+                                               cond_elevation_deg=5.0, half_precision_weights=True, use_graphs=False, channels_last=cl).to(dev)
+        rgb = torch.rand(2, 256, 256, 3, generator=g).to(dev).requires_grad_(True)
+        out = guid(rgb, torch.tensor([10.0, 20.0], device=dev), torch.tensor([30.0, 200.0], device=dev), torch.full((2,), 3.8, device=dev),
+                   frame_indices=torch.tensor([1, 3], device=dev), noise=torch.randn(2, 4, 32, 32, generator=g).to(dev),
+                   t=torch.tensor([300, 420], device=dev))
+        out["loss_sds"].backward()
+        outs.append((float(out["loss_sds"]), rgb.grad.clone()))
+    (l0, g0), (l1, g1) = outs
+    assert abs(l0 - l1) <= 2e-2 * abs(l0), (l0, l1)
+    assert float((g0 - g1).abs().max()) <= 0.05 * float(g0.abs().max()) and float((g0 - g1).norm()) <= 0.02 * float(g0.norm())

@@ -1,7 +1,7 @@
 """Time of the Zero123 SDS step (full size, fp16, random weights; 4 SDS views = UNet batch 8 at 32x32 latents + VAE encoder at
 256^2 batch 4 with backward to the images) under a few PyTorch-ROCm settings."""
 import sys, time, torch
-sys.path.insert(0, '/root/repo')
+sys.path.insert(0, '.')
 from dreammesh4d_amd import zero123 as z
 dev = torch.device('cuda:0')
 L = 32
@@ -11,9 +11,7 @@ def build(cl):
         model = z.Zero123()
     g = torch.Generator(device="cpu").manual_seed(0)
     guid = z.TemporalStableZero123Guidance(model, torch.randn(L, 1, 768, generator=g), torch.randn(L, 4, 32, 32, generator=g),
-                                           cond_elevation_deg=5.0, half_precision_weights=True).to(dev)
-    if cl:
-        guid.model.to(memory_format=torch.channels_last)
+                                           cond_elevation_deg=5.0, half_precision_weights=True, channels_last=cl).to(dev)
     return guid
 def run(guid, n=10):
     rgb = torch.rand(4, 512, 512, 3, device=dev, requires_grad=True)
@@ -26,7 +24,8 @@ def run(guid, n=10):
         guid(rgb, el, az, torch.full_like(el, 3.8), frame_indices=fi)["loss_sds"].backward()
     torch.cuda.synchronize()
     return (time.perf_counter() - t0) / n * 1e3
-for name, bench_flag, cl in (("default", False, False), ("miopen benchmark", True, False), ("channels_last", False, True), ("both", True, True)):
+for name, bench_flag, cl in (("nchw, library GroupNorm", False, False), ("nhwc, HIP GroupNorm+SiLU", False, True),
+                             ("nhwc + miopen benchmark", True, True)):
     torch.backends.cudnn.benchmark = bench_flag
     guid = build(cl)
     print(f"{name:18s} {run(guid):7.2f} ms per SDS step", flush=True)

@@ -4,7 +4,7 @@ step, its split, FLOPs (torch.utils.flop_counter) and achieved TFLOP/s against t
   python tools/zero123_profile.py            -> one JSON line
   python tools/zero123_profile.py --steps-only N   -> just N steady-state steps (the command rocprofv3 wraps)"""
 import json, sys, time, torch
-sys.path.insert(0, '/root/repo')
+sys.path.insert(0, '.'); sys.path.insert(0, '/root/repo')
 from dreammesh4d_amd import zero123 as z
 dev = torch.device('cuda:0'); L = 32
 torch.manual_seed(0)
