@@ -105,7 +105,7 @@ _SIGNATURES = {
                                            ALLOC_FN, vp, vp]),
     "dm4d_raster_read_sorted": (C.c_int, [vp, vp, C.c_int32, C.c_int32, C.c_int32, C.c_int64, c_u64, c_u32, c_u32, vp]),
     "dm4d_raster_read_geom": (C.c_int, [vp, C.c_int32, C.c_int32, C.c_int32, c_f, c_f, c_f, c_u32, vp]),
-    "dm4d_raster_read_image_state": (C.c_int, [vp, C.c_int32, C.c_int32, c_u32, c_f, vp]),
+    "dm4d_raster_read_image_state": (C.c_int, [vp, vp, vp, C.c_int32, C.c_int32, C.c_int32, C.c_int64, c_u32, c_f, vp]),
     "dm4d_debug_trace": (C.c_int, [vp, C.c_uint32]),
     "dm4d_debug_sort_trace": (C.c_int, [vp]),
     "dm4d_mark_visible": (C.c_int, [C.c_int32, vp, vp, vp, vp]),

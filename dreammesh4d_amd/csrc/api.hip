@@ -50,6 +50,7 @@ static int check_settings(const dm4d_raster_settings *s, const dm4d_raster_input
         return DM4D_ERR_UNSUPPORTED;
     }
     if (in->N < 0) { set_error("negative N"); return DM4D_ERR_INVALID; }
+    if (in->N > (1 << kGidBits)) { set_error("N = %d: at most %d Gaussians per view", in->N, 1 << kGidBits); return DM4D_ERR_UNSUPPORTED; }
     if (!s->bg || !s->viewmatrix || !s->projmatrix) { set_error("bg/viewmatrix/projmatrix must be device pointers"); return DM4D_ERR_INVALID; }
     if (in->N > 0) {
         if (!in->means3D || !in->opacities) { set_error("means3D/opacities missing"); return DM4D_ERR_INVALID; }
@@ -327,16 +328,24 @@ int dm4d_raster_read_geom(const void *geom, int32_t N, int32_t H, int32_t W, flo
     return DM4D_OK;
 }
 
-int dm4d_raster_read_image_state(const void *image, int32_t H, int32_t W, uint32_t *n_contrib, float *final_T,
-                                 dm4d_stream_t stream)
+int dm4d_raster_read_image_state(const void *geom, const void *binning, const void *image, int32_t N, int32_t H, int32_t W,
+                                 int64_t D, uint32_t *n_contrib, float *final_T, dm4d_stream_t stream)
 {
     hipStream_t st = (hipStream_t)stream;
     const ImgPtrs im = img_ptrs(const_cast<void *>(image), H, W);
     const size_t P = (size_t)H * W;
-    DM4D_HIP_CHECK(hipMemcpyAsync(final_T, im.final_T, P * 4, hipMemcpyDeviceToHost, st));
-    DM4D_HIP_CHECK(hipMemcpyAsync(n_contrib, im.n_contrib, P * 4, hipMemcpyDeviceToHost, st));
-    DM4D_HIP_CHECK(hipStreamSynchronize(st));
-    return DM4D_OK;
+    // the kernels count contributors in cell-list positions; upstream's n_contrib counts tile-list positions
+    uint32_t *tmp = nullptr;
+    DM4D_HIP_CHECK(hipMalloc(&tmp, (P > 0 ? P : 1) * 4));
+    int rc = launch_n_contrib_tile_positions(const_cast<void *>(geom), const_cast<void *>(binning), const_cast<void *>(image), N, H, W, D, tmp, st);
+    if (rc == DM4D_OK) {
+        hipError_t e = hipMemcpyAsync(final_T, im.final_T, P * 4, hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess) e = hipMemcpyAsync(n_contrib, tmp, P * 4, hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess) e = hipStreamSynchronize(st);
+        if (e != hipSuccess) { set_error("read_image_state: %s", hipGetErrorString(e)); rc = DM4D_ERR_HIP; }
+    }
+    (void)hipFree(tmp);
+    return rc;
 }
 
 int dm4d_debug_trace(void *trace, uint32_t min_work) { return set_trace_buffer(trace, min_work); }

@@ -50,6 +50,10 @@ enum GeomCounter { kCntD = 0, kCntOverflow = 1, kCntR = 2, kCntRecOverflow = 3, 
 // the regular kernels and blended by k_render_{fwd,bwd}_long: one wave per cell, its four rows evaluating four
 // CONSECUTIVE entries of the one list for the same 16 pixels, the sequential transmittance chain run by row 0.
 constexpr uint32_t kLongCell = 384;
+constexpr int kGidBits = 25;           // cell-list word: Gaussian id (N <= 2^25) | record rank << 25
+constexpr uint32_t kRankBig = 127u;    // rank field: index of the cell's record among the Gaussian's records, or kRankBig: a dense block of
+                                       // more cells than the field holds, the blend backward computes the index from cellinfo
+constexpr uint32_t kGidMask = (1u << kGidBits) - 1u;
 // The entry-parallel backward gives cells with at least this many entries a whole wave (64 entries per step) instead
 // of a DPP row (16 per step): `longlist` holds them.
 #ifndef DM4D_WIDE_BWD
@@ -61,8 +65,8 @@ DM4D_HD static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) /
 
 struct GeomLayout {
     int N, T, nb;
-    size_t counters, xy, depth, conic_opacity, rgb, tiles_touched, rec_touched, cellinfo, cellmask, clamped,
-        block_sums, rec_block_sums, hist, tile_count, tile_start, ccount, cdone, ckmax, order, longlist, earlylist, cflag, zero_begin, zero_bytes, total;
+    size_t counters, xy, depth, conic_opacity, rgb, tiles_touched, rec_touched, rec0, cellinfo, cellmask, clamped,
+        block_sums, rec_block_sums, hist, tile_count, tile_start, ccount, cdone, order, longlist, earlylist, cflag, zero_begin, zero_bytes, total;
 };
 
 DM4D_HD static inline size_t take_(size_t &o, size_t bytes) { size_t r = o; o = align_up(o + bytes, 256); return r; }
@@ -84,7 +88,6 @@ DM4D_HD static inline GeomLayout geom_layout(int N, int H, int W)
     L.tile_start = take_(o, (size_t)(L.T + 1) * 4);
     L.ccount = take_(o, (size_t)L.T * kCells * 4);   // entries of each cell list                  [T][16]
     L.cdone = take_(o, (size_t)L.T * kCells * 4);    // entries the forward consumed               [T][16]
-    L.ckmax = take_(o, (size_t)L.T * kCells * 4);    // tile-list position bound of those entries  [T][16]
     L.order = take_(o, (size_t)L.T * 4);             // tiles by descending list length (blend launch order)
     L.longlist = take_(o, (size_t)L.T * kCells * 4); // tile * 16 + cell of the long cells, in no particular order
     L.earlylist = take_(o, (size_t)L.T * kCells * 4);   // the long cells of the tiles sorted by the large variant
@@ -95,6 +98,7 @@ DM4D_HD static inline GeomLayout geom_layout(int N, int H, int W)
     L.rgb = take_(o, n * 12);
     L.tiles_touched = take_(o, n * 4);
     L.rec_touched = take_(o, n * 4);
+    L.rec0 = take_(o, n * 4);
     L.cellinfo = take_(o, n * 16);
     L.cellmask = take_(o, n * 8);
     L.clamped = take_(o, n * 3);
@@ -113,6 +117,7 @@ struct GeomPtrs {
     float *rgb;
     uint32_t *tiles_touched;
     uint32_t *rec_touched;   // cells (4x4 px) inside the Gaussian's alpha >= 1/255 bound and its tile rect
+    uint32_t *rec0;          // first backward record of the Gaussian (== cellinfo.z; compact copy for the blend backward's gathers)
     uint4 *cellinfo;         // {bx0 | by0 << 16, nbx | nby << 16, first backward record (scan of rec_touched), dense}
     uint64_t *cellmask;      // cells of the block the splat really reaches (bit = by * nbx + bx), blocks of <= 64 cells
     uint8_t *clamped;
@@ -123,7 +128,6 @@ struct GeomPtrs {
     uint32_t *tile_start;
     uint32_t *ccount;
     uint32_t *cdone;
-    uint32_t *ckmax;
     uint32_t *order;
     uint32_t *longlist;
     uint32_t *earlylist;
@@ -141,6 +145,7 @@ DM4D_HD static inline GeomPtrs geom_ptrs(void *base, const GeomLayout &L)
     p.rgb = (float *)(b + L.rgb);
     p.tiles_touched = (uint32_t *)(b + L.tiles_touched);
     p.rec_touched = (uint32_t *)(b + L.rec_touched);
+    p.rec0 = (uint32_t *)(b + L.rec0);
     p.cellinfo = (uint4 *)(b + L.cellinfo);
     p.cellmask = (uint64_t *)(b + L.cellmask);
     p.clamped = (uint8_t *)(b + L.clamped);
@@ -151,7 +156,6 @@ DM4D_HD static inline GeomPtrs geom_ptrs(void *base, const GeomLayout &L)
     p.tile_start = (uint32_t *)(b + L.tile_start);
     p.ccount = (uint32_t *)(b + L.ccount);
     p.cdone = (uint32_t *)(b + L.cdone);
-    p.ckmax = (uint32_t *)(b + L.ckmax);
     p.order = (uint32_t *)(b + L.order);
     p.longlist = (uint32_t *)(b + L.longlist);
     p.earlylist = (uint32_t *)(b + L.earlylist);
@@ -163,15 +167,16 @@ struct BinPtrs {
     uint32_t *u_depth;    // unsorted duplicates, tile-major segments
     uint32_t *u_idx;
     uint32_t *point_list; // sorted Gaussian ids  (== upstream point_list)
-    uint2 *clist;         // [16][cap] cell lists: (Gaussian id, position k in the tile list),
-                          // cell c of tile t at clist[c*cap + tile_start[t] ...]
-    uint32_t *cslot;      // [16][cap] backward record of the same entry
+    uint32_t *clist;      // [16][cap] cell lists, cell c of tile t at clist[c*cap + tile_start[t] ...], in tile-list order.
+                          // One word per entry: Gaussian id | rank << kGidBits, rank = which of the Gaussian's backward
+                          // records (cellinfo.z + rank) belongs to this cell.  Positions in a cell list stand in for the
+                          // tile-list positions upstream counts with (n_contrib): the list is a subsequence of the tile list.
     size_t cap;
 };
 DM4D_HD static inline size_t binning_bytes(int64_t cap)
 {
     size_t c = (size_t)(cap > 0 ? cap : 1);
-    return 3 * align_up(c * 4, 256) + align_up(c * kCells * 8, 256) + align_up(c * kCells * 4, 256);
+    return 3 * align_up(c * 4, 256) + align_up(c * kCells * 4, 256);
 }
 DM4D_HD static inline BinPtrs bin_ptrs(void *base, int64_t cap)
 {
@@ -182,8 +187,7 @@ DM4D_HD static inline BinPtrs bin_ptrs(void *base, int64_t cap)
     p.u_depth = (uint32_t *)(b);
     p.u_idx = (uint32_t *)(b + stride);
     p.point_list = (uint32_t *)(b + 2 * stride);
-    p.clist = (uint2 *)(b + 3 * stride);
-    p.cslot = (uint32_t *)(b + 3 * stride + align_up(c * kCells * 8, 256));
+    p.clist = (uint32_t *)(b + 3 * stride);
     p.cap = c;
     return p;
 }
@@ -416,6 +420,7 @@ int launch_render_fwd_long(const BatchDesc &d, hipStream_t st);   // the long ce
 int launch_render_bwd(const BatchDesc &d, hipStream_t st);
 int launch_gather_bwd(const BatchDesc &d, hipStream_t st);
 int launch_zero_counters(const BatchDesc &d, hipStream_t st);
+int launch_n_contrib_tile_positions(void *geom, void *binning, void *image, int N, int H, int W, int64_t cap, uint32_t *out, hipStream_t st);
 int set_trace_buffer(void *dev_ptr, uint32_t min_work);
 int set_sort_trace_buffer(void *dev_ptr);
 int launch_mark_visible(int N, const float *means3D, const float *view, uint8_t *present, hipStream_t st);

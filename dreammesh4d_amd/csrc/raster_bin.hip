@@ -103,8 +103,11 @@ constexpr int kLargeRanks = 64;          // tiles per view (the first ranks of K
 constexpr int kBins = 1024;
 
 // Split the sorted tile list into the sixteen cell lists (stable compaction by the Gaussian's cell block,
-// cellinfo / cellmask of K1/K3).  Every cell-list entry also gets the index of its backward record: the
-// records of Gaussian i start at cellinfo[i].z, one per reached cell of its block.
+// cellinfo / cellmask of K1/K3).  A cell-list entry is ONE 32-bit word: the Gaussian id and, in the top bits, which of
+// the Gaussian's backward records (they start at rec0[i], one per reached cell of its block) belongs to this cell
+// (raster.h, BinPtrs::clist).  Round 1 wrote 12 bytes per entry -- id, tile-list position, record index: 230 MB per
+// step on the bench scene; the position is not needed (the blend kernels count contributors in cell-list positions,
+// the list being a subsequence of the tile list) and the record index is rec0 + a small rank.
 //
 // Chunks of 2048 entries, 8 CONSECUTIVE entries per thread: all gathers of a chunk are issued together
 // (one memory round trip), the sixteen per-cell counts of a thread travel as four 64-bit words of
@@ -199,7 +202,6 @@ __device__ __forceinline__ void finish_tile(const ViewCtx &c, int tile, uint32_t
                 const int nbx = (int)(ci[j].y & 0xFFFFu);
                 const int ox = 4 * tx - bx0, oy = 4 * ty - by0;
                 const bool dense = ci[j].w != 0u;
-                const uint32_t rec0 = ci[j].z;
                 while (mm) {
                     const int k = __builtin_ctz(mm);
                     mm &= mm - 1u;
@@ -209,10 +211,10 @@ __device__ __forceinline__ void finish_tile(const ViewCtx &c, int tile, uint32_t
                         const int qd = k >> 2, rr = k & 3;
                         const int cx = 2 * (qd & 1) + (rr & 1), cy = 2 * (qd >> 1) + (rr >> 1);
                         const int bit = (oy + cy) * nbx + ox + cx;
-                        b.clist[(size_t)k * b.cap + s + pos] = make_uint2(gid[j], e0 + j);
-                        // records: dense block index, or the rank of the cell among the cells really reached
-                        b.cslot[(size_t)k * b.cap + s + pos] =
-                            rec0 + (dense ? (uint32_t)bit : (uint32_t)__popcll(cm[j] & ((1ull << bit) - 1ull)));
+                        // the entry's backward record is rec0[gid] + rank: the cell's index in a dense block, or its rank
+                        // among the cells really reached (< 64); kRankBig: a dense block too large for the field
+                        const uint32_t rank = dense ? min((uint32_t)bit, kRankBig) : (uint32_t)__popcll(cm[j] & ((1ull << bit) - 1ull));
+                        b.clist[(size_t)k * b.cap + s + pos] = gid[j] | (rank << kGidBits);
                     }
                 }
 #pragma unroll
@@ -356,10 +358,10 @@ __global__ __launch_bounds__(kSortThreads, 4) void k_tile_sort(BatchDesc d)
         if (tr && tid == 0) { tr[3] = wall_clock64(); tr[4] = n; }
     } else {
         // ---- large tile: the same bucket sort with the keys resident in HBM (L2) ----
-        // temp (bucket-major keys) lives in the tile's own cell-0 list segment, which
+        // temp (bucket-major keys, as two 32-bit halves) lives in the tile's own cell-0 and cell-1 list segments, which
         // finish_tile() only writes afterwards; the sorted keys go back in place.
         uint32_t *kd = b.u_depth + s, *ki_ = b.u_idx + s;
-        uint64_t *tmp = reinterpret_cast<uint64_t *>(b.clist + s);
+        uint32_t *tmp_hi = b.clist + s, *tmp_lo = b.clist + b.cap + s;      // (cells 0 and 1: n words each)
         uint32_t dmin = 0xFFFFFFFFu, dmax = 0u;
         for (uint32_t e = tid; e < n; e += kSortThreads) {
             const uint32_t dz = kd[e];
@@ -401,15 +403,17 @@ __global__ __launch_bounds__(kSortThreads, 4) void k_tile_sort(BatchDesc d)
         __syncthreads();
         for (uint32_t e = tid; e < n; e += kSortThreads) {
             const uint32_t dz = kd[e];
-            tmp[atomicAdd(&s_cur[bin_of(dz)], 1u)] = ((uint64_t)dz << 32) | ki_[e];
+            const uint32_t at = atomicAdd(&s_cur[bin_of(dz)], 1u);
+            tmp_hi[at] = dz;
+            tmp_lo[at] = ki_[e];
         }
         __syncthreads();   // workgroup-scope: tmp writes visible to the whole workgroup
         for (uint32_t e = tid; e < n; e += kSortThreads) {
-            const uint64_t k = tmp[e];
+            const uint64_t k = ((uint64_t)tmp_hi[e] << 32) | tmp_lo[e];
             const uint32_t bn = bin_of((uint32_t)(k >> 32));
             const uint32_t lo = s_bin[bn], hi = s_bin[bn + 1];
             uint32_t rank = 0;
-            for (uint32_t j = lo; j < hi; ++j) rank += (tmp[j] < k) ? 1u : 0u;
+            for (uint32_t j = lo; j < hi; ++j) rank += ((((uint64_t)tmp_hi[j] << 32) | tmp_lo[j]) < k) ? 1u : 0u;
             kd[lo + rank] = (uint32_t)(k >> 32);
             ki_[lo + rank] = (uint32_t)k;
         }

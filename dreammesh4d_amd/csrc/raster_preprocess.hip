@@ -347,6 +347,7 @@ __global__ __launch_bounds__(kPreThreads) void k_scatter(BatchDesc d)
         rcarry += total;
         if (i < N && touched != 0u) {
             reinterpret_cast<uint32_t *>(g.cellinfo + i)[2] = r0;   // first backward record of the Gaussian
+            g.rec0[i] = r0;
             rec_overflow |= (recs > 0u) && ((uint64_t)r0 + recs > (uint64_t)c.rec_cap);
         }
         if (touched == 0) continue;

@@ -73,7 +73,7 @@ constexpr int kFwdPairs = 2;   // PAIRS of entries per inner-loop step of the fo
 // consume directly, colours kept per entry as channel pairs for the packed accumulators:
 //   [0..3]   x_j x_j1 y_j y_j1        [4..7]  A_j A_j1 B_j B_j1      [8..11] C_j C_j1 o_j o_j1   (conic A,B,C; opacity)
 //   [12..19] entry j  : c0 c1 c2 c3 | c4 c5 depth 1.0                 [20..27] entry j + 1, same
-//   [28..29] tile-list position k of j, j + 1 (bits)                  [30..35] padding
+//   [28..35] padding
 // Strides are chosen against LDS bank conflicts (measured: 64 % of the forward's LDS cycles were conflicts
 // with 32-float pairs and 1 KB rows): 36 floats per pair spreads the 8 pairs a row stages at once over all
 // banks, 292 floats per row puts the 4 rows' broadcast reads (4 distinct addresses per instruction) on
@@ -82,19 +82,19 @@ constexpr int kPairFloats = 36;
 constexpr int kRowFloats = (kChunk / 2) * kPairFloats + 4;
 constexpr int kPair4 = kPairFloats / 4;   // float4 per pair block
 
-// gather one list entry: r0 = (x, y, conic.x, conic.y)  r1 = (conic.z, opacity, depth, k bits)
+// gather one list entry: r0 = (x, y, conic.x, conic.y)  r1 = (conic.z, opacity, depth, -)
 //                        r2 = colours 0..3               r3 = colours 4..5
 template <int C>
-__device__ __forceinline__ void gather_entry(const uint2 qe, const GeomPtrs &g, const float *__restrict__ colors,
+__device__ __forceinline__ void gather_entry(const uint32_t word, const GeomPtrs &g, const float *__restrict__ colors,
                                              float4 (&r)[4])
 {
-    const uint32_t gid = qe.x;
+    const uint32_t gid = word & kGidMask;
     const float2 xy = g.xy[gid];
     const float4 co = g.conic_opacity[gid];
     const float dep = g.depth[gid];
     const float *c = colors + (size_t)C * gid;
     r[0] = make_float4(xy.x, xy.y, co.x, co.y);
-    r[1] = make_float4(co.z, co.w, dep, __uint_as_float(qe.y));
+    r[1] = make_float4(co.z, co.w, dep, 0.f);
     if (C <= 3) {
         r[2] = make_float4(c[0], c[1], c[2], 0.f);
         r[3] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -119,7 +119,7 @@ __device__ __forceinline__ void stage_entry(float *row_base, int li, const float
     float *pb = row_base + (li >> 1) * kPairFloats;
     const int h = li & 1;
     pb[0 + h] = r[0].x; pb[2 + h] = r[0].y; pb[4 + h] = r[0].z; pb[6 + h] = r[0].w;
-    pb[8 + h] = r[1].x; pb[10 + h] = r[1].y; pb[28 + h] = r[1].w;
+    pb[8 + h] = r[1].x; pb[10 + h] = r[1].y;
     *reinterpret_cast<float4 *>(pb + 12 + 8 * h) = r[2];
     *reinterpret_cast<float4 *>(pb + 16 + 8 * h) = make_float4(r[3].x, r[3].y, r[1].z, 1.0f);
 }
@@ -240,12 +240,12 @@ __global__ __launch_bounds__(64) void k_render_fwd(BatchDesc d)
     const uint32_t nmax = wave_max_u32(nr);
     set_priority_by_length(nmax);
     if (nmax < g_min_work) { trace.done(0); return; }
-    const uint2 *__restrict__ list = b.clist + (size_t)lp.cell * b.cap + s;
+    const uint32_t *__restrict__ list = b.clist + (size_t)lp.cell * b.cap + s;
     float *row_base = s_p + row * kRowFloats;
 
     float T_ = 1.0f;
     f2v C01 = (f2v)(0.f), C23 = (f2v)(0.f), C45 = (f2v)(0.f), DW = (f2v)(0.f);   // colours | (depth, alpha) sums
-    uint32_t last = 0, lastj = 0;
+    uint32_t lastj = 0;       // list position + 1 of the pixel's last contributor (n_contrib, counted in the CELL list)
     bool done = !inside | row_long;
 
     float4 r[4];
@@ -282,7 +282,6 @@ __global__ __launch_bounds__(64) void k_render_fwd(BatchDesc d)
                 for (int h = 0; h < 2; ++h) {
                     const f4v e0 = P[kPair4 * j + 3 + 2 * h], e1 = P[kPair4 * j + 4 + 2 * h];
                     const float alpha = h ? al[j].y : al[j].x, power = h ? pw[j].y : pw[j].x;
-                    const uint32_t kbits = __float_as_uint(h ? P[kPair4 * j + 7].y : P[kPair4 * j + 7].x);
                     const float test_T = T_ * (1.0f - alpha);
                     const bool valid = (!done) & (power <= 0.0f) & (alpha >= 1.0f / 255.0f);
                     const bool stop = valid & (test_T < 0.0001f);
@@ -294,7 +293,6 @@ __global__ __launch_bounds__(64) void k_render_fwd(BatchDesc d)
                     if (C > 3) C45 = __builtin_elementwise_fma(e1.xy, ww, C45);
                     DW = __builtin_elementwise_fma(e1.zw, ww, DW);      // depth * w | 1 * w
                     T_ = contrib ? test_T : T_;
-                    last = contrib ? kbits + 1u : last;
                     lastj = contrib ? c0 + (uint32_t)(t + 2 * j + h) + 1u : lastj;
                     done = done | stop;
                 }
@@ -306,18 +304,15 @@ __global__ __launch_bounds__(64) void k_render_fwd(BatchDesc d)
         const size_t P = (size_t)vp.H * vp.W;
         const size_t pid = (size_t)py * vp.W + px;
         im.final_T[pid] = T_;
-        im.n_contrib[pid] = last;
+        im.n_contrib[pid] = lastj;
         const float Cacc[6] = {C01.x, C01.y, C23.x, C23.y, C45.x, C45.y};
 #pragma unroll
         for (int ch = 0; ch < C; ++ch) out_color[ch * P + pid] = __builtin_fmaf(T_, vp.bg[ch], Cacc[ch]);
         out_depth[pid] = DW.x;
         out_alpha[pid] = DW.y;
     }
-    const uint32_t wj = row_max_u32(lastj), wk = row_max_u32(last);
-    if (li == 0 && !row_long) {
-        g.cdone[tile * kCells + lp.cell] = wj;
-        g.ckmax[tile * kCells + lp.cell] = wk;
-    }
+    const uint32_t wj = row_max_u32(lastj);
+    if (li == 0 && !row_long) g.cdone[tile * kCells + lp.cell] = wj;
     trace.done(nmax);
 }
 
@@ -330,7 +325,7 @@ __global__ __launch_bounds__(64) void k_render_fwd(BatchDesc d)
 // done ~90 us before the small one, so these cells -- the tail the regular kernel used to end with -- are blended
 // beside the small variant's sort, on their own stream (regular kernel 252 -> 204 us; run beside the regular kernel
 // instead, the same code gained nothing: 247 us against 219).
-// Staging: 64 entries per chunk, one per lane: [0..5] x y A B C opacity | [6] k bits | [8..13] colours | [14] depth | [15] 1
+// Staging: 64 entries per chunk, one per lane: [0..5] x y A B C opacity | [8..13] colours | [14] depth | [15] 1
 // Four cells per workgroup (one per wave, no workgroup barrier): the long-running waves then share few CUs instead of
 // taking one SIMD on most of them, which slowed the barrier-coupled workgroups of K4's small variant running beside.
 // x of row r (16 lanes) -> o[r] in every row, same lane of the row.  v_permlane16_swap exchanges the odd rows of its
@@ -375,11 +370,11 @@ __global__ __launch_bounds__(256) void k_render_fwd_long(BatchDesc d)
         const float pxf = (float)px, pyf = (float)py;
         const uint32_t s = g.tile_start[tile];
         const uint32_t nr = g.ccount[cellid];
-        const uint2 *__restrict__ list = b.clist + (size_t)cell * b.cap + s;
+        const uint32_t *__restrict__ list = b.clist + (size_t)cell * b.cap + s;
 
         float T_ = 1.0f;
         f2v C01 = (f2v)(0.f), C23 = (f2v)(0.f), C45 = (f2v)(0.f), DW = (f2v)(0.f);
-        uint32_t last = 0, lastj = 0;
+        uint32_t lastj = 0;
         bool done = !inside | (r != 0);      // the pixel state lives in row 0
 
         float4 e[4];
@@ -391,7 +386,7 @@ __global__ __launch_bounds__(256) void k_render_fwd_long(BatchDesc d)
             {
                 float *se = s_e + lane * 16;
                 *reinterpret_cast<float4 *>(se) = e[0];                                              // x y A B
-                *reinterpret_cast<float4 *>(se + 4) = make_float4(e[1].x, e[1].y, e[1].w, 0.f);     // C opacity k
+                *reinterpret_cast<float4 *>(se + 4) = make_float4(e[1].x, e[1].y, 0.f, 0.f);        // C opacity
                 *reinterpret_cast<float4 *>(se + 8) = e[2];                                          // colours 0..3
                 *reinterpret_cast<float4 *>(se + 12) = make_float4(e[3].x, e[3].y, e[1].z, 1.0f);   // colours 4 5, depth, 1
             }
@@ -413,7 +408,6 @@ __global__ __launch_bounds__(256) void k_render_fwd_long(BatchDesc d)
                 for (int h = 0; h < 4; ++h) {
                     const float *se = s_e + (t + h) * 16;
                     const f4v e0 = *reinterpret_cast<const f4v *>(se + 8), e1 = *reinterpret_cast<const f4v *>(se + 12);
-                    const uint32_t kbits = __float_as_uint(se[6]);
                     const float alpha = al[h];
                     const float test_T = T_ * (1.0f - alpha);
                     const bool valid = (!done) & (alpha >= 0.0f);
@@ -426,7 +420,6 @@ __global__ __launch_bounds__(256) void k_render_fwd_long(BatchDesc d)
                     if (C > 3) C45 = __builtin_elementwise_fma(e1.xy, ww, C45);
                     DW = __builtin_elementwise_fma(e1.zw, ww, DW);
                     T_ = contrib ? test_T : T_;
-                    last = contrib ? kbits + 1u : last;
                     lastj = contrib ? c0 + (uint32_t)(t + h) + 1u : lastj;
                     done = done | stop;
                 }
@@ -438,18 +431,15 @@ __global__ __launch_bounds__(256) void k_render_fwd_long(BatchDesc d)
             const size_t P = (size_t)vp.H * vp.W;
             const size_t pid = (size_t)py * vp.W + px;
             im.final_T[pid] = T_;
-            im.n_contrib[pid] = last;
+            im.n_contrib[pid] = lastj;
             const float Cacc[6] = {C01.x, C01.y, C23.x, C23.y, C45.x, C45.y};
 #pragma unroll
             for (int ch = 0; ch < C; ++ch) c.out_color[ch * P + pid] = __builtin_fmaf(T_, vp.bg[ch], Cacc[ch]);
             c.out_depth[pid] = DW.x;
             c.out_alpha[pid] = DW.y;
         }
-        const uint32_t wj = row_max_u32(lastj), wk = row_max_u32(last);
-        if (lane == 0) {
-            g.cdone[cellid] = wj;
-            g.ckmax[cellid] = wk;
-        }
+        const uint32_t wj = row_max_u32(lastj);
+        if (lane == 0) g.cdone[cellid] = wj;
         __builtin_amdgcn_wave_barrier();
     }
 }
@@ -653,22 +643,36 @@ __device__ __forceinline__ void cell_pixels(const EntryRegs<C> &e, float (&acc)[
     pixel_pair<C, LEAN, WIDE, 14>(e, acc, front_lane, tab);
 }
 
+// backward record of a cell-list entry (raster.h, BinPtrs::clist): the Gaussian's first record + the rank K4 stored with the
+// entry, or -- dense blocks too large for the rank field -- the cell's index in the block.  (gx, gy): the cell.
+__device__ __forceinline__ uint32_t entry_slot(const uint32_t word, const GeomPtrs &g, const int gx, const int gy)
+{
+    const uint32_t gid = word & kGidMask;
+    uint32_t rank = word >> kGidBits;
+    if (rank == kRankBig) {
+        const uint4 ci = g.cellinfo[gid];
+        const int bx0 = (int)(ci.x & 0xFFFFu), by0 = (int)(ci.x >> 16), nbx = (int)(ci.y & 0xFFFFu);
+        rank = (uint32_t)((gy - by0) * nbx + (gx - bx0));
+    }
+    return g.rec0[gid] + rank;
+}
+
 // gather the lane's entry (list position j of the cell list; `live` false: an inert entry) and derive what the pixel
 // loop needs
 template <int C>
-__device__ __forceinline__ void load_entry(EntryRegs<C> &e, uint32_t &slot, const bool live, const uint2 *__restrict__ list,
-                                           const uint32_t *__restrict__ slots, const uint32_t j, const GeomPtrs &g,
-                                           const float *__restrict__ colors, const float cx0, const float cy0)
+__device__ __forceinline__ void load_entry(EntryRegs<C> &e, uint32_t &slot, const bool live, const uint32_t *__restrict__ list,
+                                           const uint32_t j, const GeomPtrs &g, const float *__restrict__ colors,
+                                           const float cx0, const float cy0, const int gx, const int gy)
 {
     float x = 0.f, y = 0.f, cA = 0.f, cB = 0.f, cC = 0.f;
     e.o = 0.f; e.dep = 0.f; e.k = 0xFFFFFFFFu; slot = 0xFFFFFFFFu;
 #pragma unroll
     for (int ch = 0; ch < C; ++ch) e.c[ch] = 0.f;
     if (live) {
-        const uint2 qe = list[j];
-        slot = slots[j];
-        const uint32_t gid = qe.x;
-        e.k = qe.y;
+        const uint32_t word = list[j];
+        slot = entry_slot(word, g, gx, gy);
+        const uint32_t gid = word & kGidMask;
+        e.k = j;                       // n_contrib counts cell-list positions
         const float2 xy = g.xy[gid];
         const float4 co = g.conic_opacity[gid];
         e.dep = g.depth[gid];
@@ -778,12 +782,12 @@ __device__ __forceinline__ void render_bwd_cells(const BatchDesc &d, const uint3
     uint32_t nd = (s < c.cap) ? min(g.cdone[tile * kCells + lp.cell], nr) : 0u;   // entries this row's forward consumed
     if (nr >= kWideBwd) nr = nd = 0u;                                               // a wide block's
     const uint32_t ndmax = (uint32_t)__builtin_amdgcn_readfirstlane((int)wave_max_u32(nd));
-    const uint2 *__restrict__ list = b.clist + (size_t)lp.cell * b.cap + s;
-    const uint32_t *__restrict__ slots = b.cslot + (size_t)lp.cell * b.cap + s;
+    const uint32_t *__restrict__ list = b.clist + (size_t)lp.cell * b.cap + s;
+    const int gx = lp.px >> 2, gy = lp.py >> 2;      // the row's cell, in cells from the image origin (as cellinfo counts)
     // entries the forward never reached get all-zero records, so that B2 can sum every Gaussian's contiguous record
     // block without looking anything up
     for (uint32_t j = nd + (uint32_t)li; j < nr; j += 16u) {
-        const uint32_t slot = slots[j];
+        const uint32_t slot = entry_slot(list[j], g, gx, gy);
         if (slot < rec_cap) {
             float4 *dst = reinterpret_cast<float4 *>(rec + (size_t)slot * RSP);
 #pragma unroll
@@ -801,7 +805,7 @@ __device__ __forceinline__ void render_bwd_cells(const BatchDesc &d, const uint3
         const uint32_t j = c0 + 15u - (uint32_t)li;       // reversed: lane 0 holds the entry farthest back
         EntryRegs<C> e;
         uint32_t slot;
-        load_entry<C>(e, slot, j < nd, list, slots, j, g, c.colors, cx0, cy0);
+        load_entry<C>(e, slot, j < nd, list, j, g, c.colors, cx0, cy0, gx, gy);
         float acc[13];
 #pragma unroll
         for (int i = 0; i < 13; ++i) acc[i] = 0.f;
@@ -839,10 +843,10 @@ __device__ __forceinline__ void render_bwd_wide_cells(const BatchDesc &d, const 
         const int cxi = tx * kTile + (q & 1) * 8 + (rw & 1) * 4, cyi = ty * kTile + (q >> 1) * 8 + (rw >> 1) * 4;
         const uint32_t s = g.tile_start[tile];
         const uint32_t nr = g.ccount[cellid], nd = min(g.cdone[cellid], nr);
-        const uint2 *__restrict__ list = b.clist + (size_t)cell * b.cap + s;
-        const uint32_t *__restrict__ slots = b.cslot + (size_t)cell * b.cap + s;
+        const uint32_t *__restrict__ list = b.clist + (size_t)cell * b.cap + s;
+        const int gx = cxi >> 2, gy = cyi >> 2;
         for (uint32_t j = nd + (uint32_t)lane; j < nr; j += 64u) {     // zero records for the unconsumed entries
-            const uint32_t slot = slots[j];
+            const uint32_t slot = entry_slot(list[j], g, gx, gy);
             if (slot < rec_cap) {
                 float4 *dst = reinterpret_cast<float4 *>(rec + (size_t)slot * RSP);
 #pragma unroll
@@ -859,7 +863,7 @@ __device__ __forceinline__ void render_bwd_wide_cells(const BatchDesc &d, const 
             const uint32_t j = c0 + 63u - (uint32_t)lane;
             EntryRegs<C> e;
             uint32_t slot;
-            load_entry<C>(e, slot, j < nd, list, slots, j, g, c.colors, cx0, cy0);
+            load_entry<C>(e, slot, j < nd, list, j, g, c.colors, cx0, cy0, gx, gy);
             float acc[13];
 #pragma unroll
             for (int i = 0; i < 13; ++i) acc[i] = 0.f;
@@ -870,6 +874,41 @@ __device__ __forceinline__ void render_bwd_wide_cells(const BatchDesc &d, const 
         __builtin_amdgcn_wave_barrier();
     }
     trace.done(traced);
+}
+
+// ---------------------------------------------------------------------------------------- debug read-out of n_contrib
+// The kernels count a pixel's contributors in its CELL list (positions in a subsequence of the tile list); upstream's
+// n_contrib is the position of the last contributor in the TILE list + 1.  dm4d_raster_read_image_state translates: the
+// pixel's last cell-list entry names a Gaussian, which occurs once in the tile's sorted list.
+__global__ __launch_bounds__(256) void k_n_contrib_tile_positions(GeomPtrs g, BinPtrs b, ImgPtrs im, int H, int W, uint32_t cap,
+                                                                   uint32_t *__restrict__ out)
+{
+    const int pid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (pid >= H * W) return;
+    const int px = pid % W, py = pid / W, gx = (W + kTile - 1) / kTile;
+    const int tile = (py / kTile) * gx + px / kTile;
+    const int ix = px % kTile, iy = py % kTile;
+    const int cell = 4 * ((ix >> 3) + 2 * (iy >> 3)) + ((ix >> 2) & 1) + 2 * ((iy >> 2) & 1);
+    const uint32_t lastj = im.n_contrib[pid];
+    uint32_t res = 0u;
+    const uint32_t s = g.tile_start[tile], e = min(g.tile_start[tile + 1], cap);
+    if (lastj > 0u && s + lastj - 1u < cap) {
+        const uint32_t gid = b.clist[(size_t)cell * b.cap + s + lastj - 1u] & kGidMask;
+        for (uint32_t k = s; k < e; ++k)
+            if (b.point_list[k] == gid) { res = k - s + 1u; break; }
+    }
+    out[pid] = res;
+}
+int launch_n_contrib_tile_positions(void *geom, void *binning, void *image, int N, int H, int W, int64_t cap, uint32_t *out, hipStream_t st)
+{
+    const GeomLayout L = geom_layout(N, H, W);
+    const GeomPtrs g = geom_ptrs(geom, L);
+    const BinPtrs b = bin_ptrs(binning, cap);
+    const ImgPtrs im = img_ptrs(image, H, W);
+    const int P = H * W;
+    if (P > 0) hipLaunchKernelGGL(k_n_contrib_tile_positions, dim3((P + 255) / 256), dim3(256), 0, st, g, b, im, H, W, (uint32_t)b.cap, out);
+    DM4D_HIP_CHECK(hipGetLastError());
+    return DM4D_OK;
 }
 
 // ---------------------------------------------------------------------------------------- launchers

@@ -43,6 +43,7 @@ static int views_check(const dm4d_views *v)
     if (v->B <= 0 || v->B > 65535) { set_error("bad batch size %d", v->B); return DM4D_ERR_INVALID; }
     if (v->frame_index && (v->n_frames <= 0 || v->n_frames > v->B)) { set_error("n_frames %d out of range (1..B)", v->n_frames); return DM4D_ERR_INVALID; }
     if (v->N != v->F * v->G) { set_error("N (%d) != F*G (%d*%d)", v->N, v->F, v->G); return DM4D_ERR_INVALID; }
+    if (v->N > (1 << kGidBits)) { set_error("N = %d: at most %d Gaussians per view", v->N, 1 << kGidBits); return DM4D_ERR_UNSUPPORTED; }
     if (v->image_height <= 0 || v->image_width <= 0) { set_error("bad image size"); return DM4D_ERR_INVALID; }
     if ((int64_t)((v->image_height + kTile - 1) / kTile) * ((v->image_width + kTile - 1) / kTile) > kMaxTiles) {
         set_error("image has more than %d tiles", kMaxTiles);

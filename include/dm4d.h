@@ -164,9 +164,11 @@ int dm4d_raster_read_geom(const void *geom, int32_t N, int32_t image_height, int
                           float *xy /* [host][N,2] */, float *depths /* [N] */,
                           float *conic_opacity /* [N,4] */, uint32_t *tiles_touched /* [N] */,
                           dm4d_stream_t stream);
-int dm4d_raster_read_image_state(const void *image, int32_t image_height, int32_t image_width,
-                                 uint32_t *n_contrib /* [host][H,W] */, float *final_T /* [host][H,W] */,
-                                 dm4d_stream_t stream);
+int dm4d_raster_read_image_state(const void *geom, const void *binning, const void *image, int32_t N, int32_t image_height,
+                                 int32_t image_width, int64_t D /* capacity given to dm4d_rasterize_render */,
+                                 uint32_t *n_contrib /* [host][H,W]: upstream's meaning, last contributor's position in the
+                                                        tile list + 1 (translated from the cell-list positions kept on device) */,
+                                 float *final_T /* [host][H,W] */, dm4d_stream_t stream);
 
 /* Debug: when `trace` (device, uint64 [blocks, 4]) is non-NULL every wave of the blend kernels records
  * {start, end} in 100 MHz ticks, {XCC_ID << 32 | HW_ID} and its iteration count at index

@@ -72,8 +72,8 @@ class HipRaster:
         _lib.check(L.dm4d_raster_read_sorted(_p(self.geom), _p(self.binning), N, H, W, min(self.D, self.cap),
                                              f(s["keys"], _lib.c_u64), f(s["values"], _lib.c_u32),
                                              f(s["ranges"], _lib.c_u32), st))
-        _lib.check(L.dm4d_raster_read_image_state(_p(self.image), H, W, f(s["n_contrib"], _lib.c_u32),
-                                                  f(s["final_T"], _lib.c_f), st))
+        _lib.check(L.dm4d_raster_read_image_state(_p(self.geom), _p(self.binning), _p(self.image), N, H, W, self.cap,
+                                                  f(s["n_contrib"], _lib.c_u32), f(s["final_T"], _lib.c_f), st))
         for k in ("xy", "depths", "conic_opacity", "tiles_touched"):
             s[k] = s[k][:N]
         s["keys"], s["values"] = s["keys"][:self.D], s["values"][:self.D]

@@ -352,7 +352,7 @@ def test_autograd_operator_matches_oracle():
         t.grad = None
     l1.backward(retain_graph=True)
     g_first = m3.grad.clone()
-    l2.backward()
+    l2.backward(retain_graph=True)
     both = m3.grad.clone()
     for t in (m3, m2, op, col, scl, rot):
         t.grad = None
