@@ -100,10 +100,20 @@ class DynamicStage:
                 is_ref.append(False)
                 elev.append(e)
                 azim.append(a)
-        T = lambda a: torch.tensor(a, device=self.dev)
-        return {"frames": frames, "vm": torch.stack([T(c.viewmatrix) for c in cams]),
-                "pm": torch.stack([T(c.projmatrix) for c in cams]), "unit_frame": T(unit_frame),
-                "is_ref": torch.tensor(is_ref, device=self.dev), "elev": T(elev), "azim": T(azim)}
+        # everything the step indexes with is decided here, on the host: index lists instead of boolean masks, one upload
+        # per array -- `x[mask]` / `mask.any()` on device tensors cost a host synchronisation each (six per iteration)
+        import numpy as np
+
+        T = lambda a, dt=None: torch.as_tensor(np.asarray(a), dtype=dt).to(self.dev, non_blocking=True)
+        ref_idx = [i for i, r in enumerate(is_ref) if r]
+        rnd_idx = [i for i, r in enumerate(is_ref) if not r]
+        fidx = [frames[u] for u in unit_frame]
+        return {"frames": frames, "vm": T(np.stack([c.viewmatrix for c in cams]), torch.float32),
+                "pm": T(np.stack([c.projmatrix for c in cams]), torch.float32), "unit_frame": T(unit_frame, torch.int64),
+                "ref_idx": T(ref_idx, torch.int64), "rnd_idx": T(rnd_idx, torch.int64), "n_ref": len(ref_idx), "n_rnd": len(rnd_idx),
+                "frames_t_idx": T(frames, torch.int64), "fidx_ref": T([fidx[i] for i in ref_idx], torch.int64),
+                "fidx_rnd": T([fidx[i] for i in rnd_idx], torch.int64),
+                "elev_rnd": T([elev[i] for i in rnd_idx], torch.float32), "azim_rnd": T([azim[i] for i in rnd_idx], torch.float32)}
 
     def inter_frame_arap(self):
         """ARAP energy at `num_inter_frames` timestamps of a random window of length `length_inter_frames`
@@ -131,7 +141,7 @@ class DynamicStage:
         if self.guidance is not None:
             self.guidance.update_step(0, it, min_step_percent=C(0.02, 0, it), max_step_percent=C(0.5, 0, it))
         b = self.sample_batch()
-        frames_t = self.timestamps[torch.tensor(b["frames"], device=self.dev)]
+        frames_t = self.timestamps[b["frames_t_idx"]]
         self.opt.zero_grad(set_to_none=True)
         dx, dr, ds, do = self.net.node_outputs(self.nodes, frames_t)
         u = b["unit_frame"]
@@ -140,17 +150,16 @@ class DynamicStage:
                            self.bg6, frame_index=u)
         rgb = out["color"][:, :3].clamp(0, 1).permute(0, 2, 3, 1)          # "render": clamp(0,1) (…temporal.py:229)
         mask = out["alpha"].permute(0, 2, 3, 1)
-        ref, rnd = b["is_ref"], ~b["is_ref"]
-        fidx = torch.tensor(b["frames"], device=self.dev)[u]
         loss = rgb.sum() * 0.0
         terms = {}
-        if ref.any():
-            terms["rgb"] = F.mse_loss(self.ref_images[fidx[ref]], rgb[ref])     # unmasked: colour outside the silhouette is penalised
-            terms["mask"] = F.mse_loss(mask[ref], self.ref_masks[fidx[ref]])
+        if b["n_ref"]:
+            ref = b["ref_idx"]
+            terms["rgb"] = F.mse_loss(self.ref_images[b["fidx_ref"]], rgb[ref])     # unmasked: colour outside the silhouette is penalised
+            terms["mask"] = F.mse_loss(mask[ref], self.ref_masks[b["fidx_ref"]])
             loss = loss + LAMBDA["rgb"] * terms["rgb"] + C(LAMBDA["mask"], 0, it) * terms["mask"]
-        if self.guidance is not None and rnd.any():
-            g = self.guidance(rgb[rnd], b["elev"][rnd], b["azim"][rnd], torch.full_like(b["elev"][rnd], 3.8),
-                              frame_indices=fidx[rnd])
+        if self.guidance is not None and b["n_rnd"]:
+            g = self.guidance(rgb[b["rnd_idx"]], b["elev_rnd"], b["azim_rnd"], torch.full_like(b["elev_rnd"], 3.8),
+                              frame_indices=b["fidx_rnd"])
             terms["sds"] = g["loss_sds"]
             loss = loss + LAMBDA["sds_zero123"] * g["loss_sds"]
         if self.normal_consistency is not None:

@@ -1,5 +1,5 @@
 import sys, numpy as np, torch
-sys.path.insert(0,'/root/repo')
+sys.path.insert(0,'.')
 import bench
 dev=torch.device('cuda:0')
 wl=bench.Workload(dev,0,1)
