@@ -7,8 +7,9 @@
 // transposes MIOpen wraps around its NHWC convolution kernels, and the SiLU launches on top.  With the activations kept
 // NHWC end to end the convolutions need no transposes, and this file is the normalisation for that layout:
 //     y = silu?( (x + add[n, c] - mean[n, g]) * rstd[n, g] * gamma[c] + beta[c] )
-// `add` (optional, forward only) is the per-(sample, channel) timestep-embedding term a ResBlock adds between its first
-// convolution and its second GroupNorm (openaimodel.py:259-275): folded in here instead of a launch of its own.
+// `add` (optional; a constant as far as backward is concerned) is the per-(sample, channel) term between a ResBlock's first
+// convolution and its second GroupNorm -- the timestep embedding (openaimodel.py:259-275) and that convolution's bias, or the
+// bias alone (stride 0 over the samples) in the VAE encoder: folded in here instead of launches of their own.
 //
 // HBM-bound: an activation is read twice (statistics, apply) and written once; statistics are float32 whatever the
 // storage type.  One workgroup owns a contiguous slab of rows (pixels) of one sample -- in NHWC the slab is one
@@ -35,7 +36,7 @@ template <> struct GnVec<_Float16> { static constexpr int n = 8; typedef _Float1
 template <> struct GnVec<float> { static constexpr int n = 4; typedef float type __attribute__((ext_vector_type(4))); };
 
 struct GnArgs {
-    int N, HW, C, G, splits, rows_per_split, silu;
+    int N, HW, C, G, splits, rows_per_split, silu, add_stride;
     float eps;
     const void *x, *add, *gamma, *beta, *dy;
     void *out;          // y (forward apply) | dx (backward apply)
@@ -66,7 +67,7 @@ __global__ __launch_bounds__(kGnThreads) void k_groupnorm(GnArgs a)
     const size_t sample = (size_t)n * a.HW * C;
     const T *__restrict__ x = (const T *)a.x + sample;
     const T *__restrict__ dy = kBwd ? (const T *)a.dy + sample : nullptr;
-    const T *__restrict__ add = (!kBwd && a.add) ? (const T *)a.add + (size_t)n * C : nullptr;
+    const T *__restrict__ add = a.add ? (const T *)a.add + (size_t)n * a.add_stride : nullptr;
 
     // ---- prologue: the sample's group statistics, from the slabs' partial sums.  J lanes per group sum every J-th slab, lane 0
     //      of the group adds the J results: a fixed order, and one round trip to the scratch instead of `splits` of them
@@ -126,7 +127,7 @@ __global__ __launch_bounds__(kGnThreads) void k_groupnorm(GnArgs a)
                     k1[i] = __builtin_fmaf(ad - mean, k0[i], bet);
                     k2[i] = k3[i] = k4[i] = k5[i] = 0.f;
                 } else {                             // xhat = x rstd + (-mean rstd);  z = xhat gam + bet
-                    k0[i] = rstd; k1[i] = -mean * rstd; k2[i] = gam; k3[i] = bet;
+                    k0[i] = rstd; k1[i] = (ad - mean) * rstd; k2[i] = gam; k3[i] = bet;
                     k4[i] = (MODE == kGnBwdApply) ? g_c[g] : 0.f;
                     k5[i] = (MODE == kGnBwdApply) ? g_d[g] : 0.f;
                 }
@@ -257,22 +258,25 @@ static int gn_check(int N, int HW, int C, int G, int dtype, int splits, const vo
 using namespace dm4d;
 
 extern "C" int dm4d_groupnorm_nhwc_forward(int32_t N, int32_t HW, int32_t C, int32_t G, int32_t dtype, const void *x,
-                                           const void *add, const void *gamma, const void *beta, float eps, int32_t silu,
-                                           void *y, float *stats, float *scratch, int32_t splits, dm4d_stream_t stream)
+                                           const void *add, int32_t add_stride, const void *gamma, const void *beta, float eps,
+                                           int32_t silu, void *y, float *stats, float *scratch, int32_t splits, dm4d_stream_t stream)
 {
     int rc = gn_check(N, HW, C, G, dtype, splits, x, gamma, beta, y, stats, scratch);
     if (rc != DM4D_OK || N == 0) return rc;
-    GnArgs a{N, HW, C, G, splits, (HW + splits - 1) / splits, silu, eps, x, add, gamma, beta, nullptr, y, stats, scratch};
+    if (add && add_stride != 0 && add_stride != C) { set_error("groupnorm: add_stride must be 0 or C"); return DM4D_ERR_INVALID; }
+    GnArgs a{N, HW, C, G, splits, (HW + splits - 1) / splits, silu, add_stride, eps, x, add, gamma, beta, nullptr, y, stats, scratch};
     return dtype == DM4D_GN_F16 ? gn_launch<_Float16>(a, false, (hipStream_t)stream) : gn_launch<float>(a, false, (hipStream_t)stream);
 }
 
 extern "C" int dm4d_groupnorm_nhwc_backward(int32_t N, int32_t HW, int32_t C, int32_t G, int32_t dtype, const void *x,
-                                            const void *gamma, const void *beta, const float *stats, int32_t silu,
+                                            const void *add, int32_t add_stride, const void *gamma, const void *beta,
+                                            const float *stats, int32_t silu,
                                             const void *dy, void *dx, float *scratch, int32_t splits, dm4d_stream_t stream)
 {
     int rc = gn_check(N, HW, C, G, dtype, splits, x, gamma, beta, dx, stats, scratch);
     if (rc != DM4D_OK || N == 0) return rc;
     if (!dy) { set_error("groupnorm: null pointer"); return DM4D_ERR_INVALID; }
-    GnArgs a{N, HW, C, G, splits, (HW + splits - 1) / splits, silu, 0.f, x, nullptr, gamma, beta, dy, dx, const_cast<float *>(stats), scratch};
+    if (add && add_stride != 0 && add_stride != C) { set_error("groupnorm: add_stride must be 0 or C"); return DM4D_ERR_INVALID; }
+    GnArgs a{N, HW, C, G, splits, (HW + splits - 1) / splits, silu, add_stride, 0.f, x, add, gamma, beta, dy, dx, const_cast<float *>(stats), scratch};
     return dtype == DM4D_GN_F16 ? gn_launch<_Float16>(a, true, (hipStream_t)stream) : gn_launch<float>(a, true, (hipStream_t)stream);
 }

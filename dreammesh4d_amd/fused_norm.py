@@ -1,5 +1,6 @@
-"""GroupNorm (+ SiLU) of the Zero123 SDS step for channels-last activations: the torch-side binding of
-csrc/groupnorm.hip (``dm4d_groupnorm_nhwc_forward`` / ``_backward``, include/dm4d.h).
+"""GroupNorm (+ SiLU) and two fused elementwise operators of the Zero123 SDS step for channels-last activations: the
+torch-side binding of csrc/groupnorm.hip (``dm4d_groupnorm_nhwc_forward`` / ``_backward``) and csrc/pointwise.hip
+(``dm4d_add_bias_nhwc``, ``dm4d_geglu``), include/dm4d.h.
 
 ``group_norm(module, x, silu=False, add=None)`` evaluates ``act(module(x + add[:, :, None, None]))`` for a
 ``torch.nn.GroupNorm`` -- the "GroupNorm32, SiLU" pairs of the reference's ResBlocks
@@ -37,28 +38,29 @@ class _GroupNormNHWC(torch.autograd.Function):
         S = _splits(H * W)
         stats = torch.empty(N, groups, 2, device=x.device, dtype=torch.float32)
         scratch = torch.empty(N, S, groups, 2, device=x.device, dtype=torch.float32)
+        add_stride = 0 if add is None or add.dim() == 1 else C                      # [C]: the same for every sample
         _lib.check(L.dm4d_groupnorm_nhwc_forward(N, H * W, C, groups, _DTYPES[x.dtype], x.data_ptr(),
-                                                 0 if add is None else add.data_ptr(), weight.data_ptr(), bias.data_ptr(), eps,
-                                                 int(silu), y.data_ptr(), stats.data_ptr(), scratch.data_ptr(), S,
+                                                 0 if add is None else add.data_ptr(), add_stride, weight.data_ptr(), bias.data_ptr(),
+                                                 eps, int(silu), y.data_ptr(), stats.data_ptr(), scratch.data_ptr(), S,
                                                  torch.cuda.current_stream(x.device).cuda_stream), "groupnorm forward")
-        ctx.save_for_backward(x, weight, bias, stats)
-        ctx.cfg = (groups, bool(silu), S)
+        ctx.save_for_backward(x, weight, bias, stats, add)
+        ctx.cfg = (groups, bool(silu), S, add_stride)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, weight, bias, stats = ctx.saved_tensors
-        groups, silu, S = ctx.cfg
+        x, weight, bias, stats, add = ctx.saved_tensors
+        groups, silu, S, add_stride = ctx.cfg
         N, C, H, W = x.shape
         if not is_channels_last(dy):
             dy = dy.contiguous(memory_format=torch.channels_last)
         L = _lib.lib()
         dx = torch.empty_like(x)
         scratch = torch.empty(N, S, groups, 2, device=x.device, dtype=torch.float32)
-        _lib.check(L.dm4d_groupnorm_nhwc_backward(N, H * W, C, groups, _DTYPES[x.dtype], x.data_ptr(), weight.data_ptr(),
-                                                  bias.data_ptr(), stats.data_ptr(), int(silu), dy.data_ptr(), dx.data_ptr(),
-                                                  scratch.data_ptr(), S, torch.cuda.current_stream(x.device).cuda_stream),
-                   "groupnorm backward")
+        _lib.check(L.dm4d_groupnorm_nhwc_backward(N, H * W, C, groups, _DTYPES[x.dtype], x.data_ptr(),
+                                                  0 if add is None else add.data_ptr(), add_stride, weight.data_ptr(), bias.data_ptr(),
+                                                  stats.data_ptr(), int(silu), dy.data_ptr(), dx.data_ptr(), scratch.data_ptr(), S,
+                                                  torch.cuda.current_stream(x.device).cuda_stream), "groupnorm backward")
         return dx, None, None, None, None, None, None
 
 
@@ -70,20 +72,58 @@ def fused_ok(module, x):
 
 
 def group_norm(module, x, silu=False, add=None, float32=False):
-    """act(GroupNorm(x + add[:, :, None, None])).  `float32`: the reference's GroupNorm32 (statistics and affine map
-    evaluated in float32 around half-precision storage) -- what the HIP kernels do for every input."""
+    """act(GroupNorm(x + add)), add [N, C] (per sample and channel) or [C] (per channel).  `float32`: the reference's
+    GroupNorm32 (statistics and affine map evaluated in float32 around half-precision storage) -- what the HIP kernels do
+    for every input."""
     if fused_ok(module, x):
         if add is not None:
-            if torch.is_grad_enabled() and (x.requires_grad or add.requires_grad):      # the fusion of `add` is forward-only
-                x, add = x + add.type(x.dtype)[:, :, None, None], None
+            if torch.is_grad_enabled() and add.requires_grad:        # the operator treats `add` as a constant
+                x, add = x + (add if add.dim() == 1 else add[:, :, None, None]).type(x.dtype).view(-1, x.shape[1], 1, 1), None
             else:
-                add = add.to(x.dtype).contiguous()
+                add = add.detach().to(x.dtype).contiguous()
         return _GroupNormNHWC.apply(x, module.weight, module.bias, add, module.num_groups, module.eps, silu)
     if add is not None:
-        x = x + add.type(x.dtype)[:, :, None, None]
+        x = x + add.type(x.dtype).view(-1, x.shape[1], 1, 1)
     if float32 and not (x.is_cuda and x.dtype in (torch.float16, torch.bfloat16) and module.weight.dtype == x.dtype):
         y = F.group_norm(x.float(), module.num_groups, module.weight.float(), module.bias.float(), module.eps).type(x.dtype)
     else:
         # (half tensors on a device: the library kernel already accumulates in float32 and rounds once)
         y = F.group_norm(x, module.num_groups, module.weight, module.bias, module.eps)
     return F.silu(y) if silu else y
+
+
+# ----------------------------------------------------------------------------- a + b + bias[c], GEGLU
+class _AddBias(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, b, bias):
+        N, C, H, W = a.shape
+        y = torch.empty_like(a)
+        _lib.check(_lib.lib().dm4d_add_bias_nhwc(N * H * W, C, _DTYPES[a.dtype], a.data_ptr(), b.data_ptr(), bias.data_ptr(), y.data_ptr(),
+                                                 torch.cuda.current_stream(a.device).cuda_stream), "add_bias")
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        return dy, dy, None            # (the bias is a frozen parameter)
+
+
+def add_bias(a, b, bias):
+    """a + b + bias[None, :, None, None]: the end of a ResBlock (skip + convolution output + the convolution's bias)."""
+    if (a.is_cuda and is_channels_last(a) and is_channels_last(b) and a.dtype in _DTYPES and b.dtype == a.dtype and bias.dtype == a.dtype
+            and a.shape == b.shape and a.shape[1] % (8 if a.dtype == torch.float16 else 4) == 0 and a.numel() > 0
+            and not (torch.is_grad_enabled() and bias.requires_grad)):
+        return _AddBias.apply(a, b, bias)
+    return a + (b + bias.view(1, -1, 1, 1))
+
+
+def geglu(proj):
+    """x * gelu(gate) for proj = [x | gate] on the last axis (extern/ldm_zero123/modules/attention.py:48-56)."""
+    D = proj.shape[-1] // 2
+    if (proj.is_cuda and proj.is_contiguous() and proj.dtype in _DTYPES and D % (8 if proj.dtype == torch.float16 else 4) == 0
+            and proj.numel() > 0 and not (torch.is_grad_enabled() and proj.requires_grad)):
+        y = torch.empty(proj.shape[:-1] + (D,), device=proj.device, dtype=proj.dtype)
+        _lib.check(_lib.lib().dm4d_geglu(proj.numel() // (2 * D), D, _DTYPES[proj.dtype], proj.data_ptr(), y.data_ptr(),
+                                         torch.cuda.current_stream(proj.device).cuda_stream), "geglu")
+        return y
+    x, gate = proj.chunk(2, dim=-1)
+    return x * F.gelu(gate)

@@ -30,7 +30,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from .fused_norm import group_norm, is_channels_last
+from .fused_norm import add_bias, geglu, group_norm, is_channels_last
 
 
 # ----------------------------------------------------------------------------- building blocks
@@ -46,6 +46,16 @@ class GroupNorm32(nn.GroupNorm):
 
 def _to_nhwc(x):
     return x if is_channels_last(x) else x.contiguous(memory_format=torch.channels_last)
+
+
+def _fold_bias(conv, x):
+    """On a HIP device with NHWC activations a 3x3 convolution's bias is folded into the operator that follows it (the
+    GroupNorm's `add`, the residual add): MIOpen's NHWC convolutions add it in a separate kernel otherwise."""
+    return x.is_cuda and is_channels_last(x) and conv.bias is not None and not (torch.is_grad_enabled() and conv.bias.requires_grad)
+
+
+def _conv_nobias(conv, x):
+    return F.conv2d(x, conv.weight, None, conv.stride, conv.padding)
 
 
 def _conv1x1(conv, x):
@@ -97,11 +107,15 @@ class ResBlock(nn.Module):
         self.skip_connection = nn.Identity() if ch == out_ch else nn.Conv2d(ch, out_ch, 1)
 
     def forward(self, x, emb):
-        h = self.in_layers[2](group_norm(self.in_layers[0], x, silu=True, float32=True))
-        # h + emb[:, :, None, None], GroupNorm, SiLU (openaimodel.py:259-275) in one operator; Dropout(0) is the identity
-        h = group_norm(self.out_layers[0], h, silu=True, add=self.emb_layers(emb), float32=True)
+        conv1, conv2 = self.in_layers[2], self.out_layers[3]
+        h = group_norm(self.in_layers[0], x, silu=True, float32=True)
         skip = x if isinstance(self.skip_connection, nn.Identity) else _conv1x1(self.skip_connection, x)
-        return skip + self.out_layers[3](h)
+        # h + emb[:, :, None, None], GroupNorm, SiLU (openaimodel.py:259-275) in one operator; Dropout(0) is the identity
+        if _fold_bias(conv1, h):
+            h = group_norm(self.out_layers[0], _conv_nobias(conv1, h), silu=True, add=self.emb_layers(emb) + conv1.bias, float32=True)
+            return add_bias(skip, _conv_nobias(conv2, h), conv2.bias)
+        h = group_norm(self.out_layers[0], conv1(h), silu=True, add=self.emb_layers(emb), float32=True)
+        return skip + conv2(h)
 
 
 class CrossAttention(nn.Module):
@@ -132,8 +146,7 @@ class GEGLU(nn.Module):
         self.proj = nn.Linear(dim_in, dim_out * 2)
 
     def forward(self, x):
-        x, gate = self.proj(x).chunk(2, dim=-1)
-        return x * F.gelu(gate)
+        return geglu(self.proj(x))
 
 
 class FeedForward(nn.Module):
@@ -260,9 +273,13 @@ class _VaeRes(nn.Module):
             self.nin_shortcut = nn.Conv2d(cin, cout, 1)
 
     def forward(self, x):
-        h = self.conv1(group_norm(self.norm1, x, silu=True))
-        h = self.conv2(self.dropout(group_norm(self.norm2, h, silu=True)))
-        return (self.nin_shortcut(x) if hasattr(self, "nin_shortcut") else x) + h
+        skip = _conv1x1(self.nin_shortcut, x) if hasattr(self, "nin_shortcut") else x
+        h = group_norm(self.norm1, x, silu=True)
+        if _fold_bias(self.conv1, h):
+            h = group_norm(self.norm2, _conv_nobias(self.conv1, h), silu=True, add=self.conv1.bias)
+            return add_bias(skip, _conv_nobias(self.conv2, h), self.conv2.bias)      # (Dropout(0) is the identity)
+        h = self.conv2(self.dropout(group_norm(self.norm2, self.conv1(h), silu=True)))
+        return skip + h
 
 
 class _VaeAttn(nn.Module):

@@ -197,13 +197,22 @@ int dm4d_mark_visible(int32_t N, const float *means3D, const float *viewmatrix, 
 #define DM4D_GN_F32 1
 #define DM4D_GN_MAX_SPLITS 128
 int dm4d_groupnorm_nhwc_forward(int32_t N, int32_t HW, int32_t C, int32_t G, int32_t dtype, const void *x, const void *add,
+                                int32_t add_stride /* C: add is [N, C]; 0: add is [C], the same for every sample */,
                                 const void *gamma, const void *beta, float eps, int32_t silu, void *y, float *stats,
                                 float *scratch, int32_t splits, dm4d_stream_t stream);
-/* dL/dx of the above for frozen gamma / beta (the guidance model is not trained): x as given to forward (with `add` == NULL),
- * stats from forward, dy / dx [N, HW, C]. */
-int dm4d_groupnorm_nhwc_backward(int32_t N, int32_t HW, int32_t C, int32_t G, int32_t dtype, const void *x, const void *gamma,
-                                 const void *beta, const float *stats, int32_t silu, const void *dy, void *dx,
-                                 float *scratch, int32_t splits, dm4d_stream_t stream);
+/* dL/dx of the above for frozen gamma / beta and a constant `add` (the guidance model is not trained): x, add as given to
+ * forward, stats from forward, dy / dx [N, HW, C]. */
+int dm4d_groupnorm_nhwc_backward(int32_t N, int32_t HW, int32_t C, int32_t G, int32_t dtype, const void *x, const void *add,
+                                 int32_t add_stride, const void *gamma, const void *beta, const float *stats, int32_t silu,
+                                 const void *dy, void *dx, float *scratch, int32_t splits, dm4d_stream_t stream);
+
+/* y[r, c] = a[r, c] + b[r, c] + bias[c] over [rows, C] (the end of a ResBlock: skip + convolution output + that convolution's
+ * bias -- openaimodel.py:259-275, diffusionmodules/model.py ResnetBlock); dtype as above, C % 8 == 0 (F16) / % 4 (F32). */
+int dm4d_add_bias_nhwc(int64_t rows, int32_t C, int32_t dtype, const void *a, const void *b, const void *bias, void *y,
+                       dm4d_stream_t stream);
+/* GEGLU (extern/ldm_zero123/modules/attention.py:48-56): y[r, d] = proj[r, d] * gelu(proj[r, D + d]), exact (erf) GELU;
+ * proj [rows, 2 D], y [rows, D]. */
+int dm4d_geglu(int64_t rows, int32_t D, int32_t dtype, const void *proj, void *y, dm4d_stream_t stream);
 
 /* ------------------------------------------------------------------ simple-knn */
 

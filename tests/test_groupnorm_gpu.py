@@ -63,6 +63,18 @@ def test_forward_and_input_gradient_against_float32_torch(shape, dtype):
         gtol = (4e-3 if dtype == torch.float16 else 3e-5) * max(scale, 1e-3)
         assert float((xg.grad.float() - xr.grad).abs().max()) <= gtol, (silu, float((xg.grad.float() - xr.grad).abs().max()), scale)
         assert fused_norm.is_channels_last(xg.grad)
+    # a per-channel constant in front of the norm (a convolution's bias folded in), with dL/dx
+    cb = (0.5 * torch.randn(C, generator=g)).to(dev, dtype)
+    xg = x.clone().requires_grad_(True)
+    dy = torch.randn(shape, generator=g).to(dev, dtype).contiguous(memory_format=torch.channels_last)
+    y = fused_norm.group_norm(m, xg, silu=True, add=cb)
+    y.backward(dy)
+    xr = x.float().clone().requires_grad_(True)
+    yr = F.silu(F.group_norm(xr + cb.float().view(1, C, 1, 1), G, m.weight.float(), m.bias.float(), m.eps))
+    yr.backward(dy.float())
+    torch.testing.assert_close(y.float(), yr, **tol)
+    scale = float(xr.grad.abs().max())
+    assert float((xg.grad.float() - xr.grad).abs().max()) <= (4e-3 if dtype == torch.float16 else 3e-5) * max(scale, 1e-3)
     # an NCHW gradient arriving at a channels-last operator
     xg = x.clone().requires_grad_(True)
     y = fused_norm.group_norm(m, xg, silu=True)
@@ -88,11 +100,14 @@ def test_what_falls_back_to_torch_and_what_is_rejected():
     s = torch.cuda.current_stream().cuda_stream
     z = torch.zeros(64, device=dev)
     p = z.data_ptr()
-    assert L.dm4d_groupnorm_nhwc_forward(1, 4, 6, 4, 1, p, 0, p, p, 1e-5, 0, p, p, p, 1, s) != 0       # C not a multiple of G
-    assert L.dm4d_groupnorm_nhwc_forward(1, 4, 8, 4, 7, p, 0, p, p, 1e-5, 0, p, p, p, 1, s) != 0       # dtype
-    assert L.dm4d_groupnorm_nhwc_forward(1, 4, 8, 4, 1, p, 0, p, p, 1e-5, 0, p, p, p, 1000, s) != 0    # splits
-    assert L.dm4d_groupnorm_nhwc_forward(1, 4, 8, 4, 1, 0, 0, p, p, 1e-5, 0, p, p, p, 1, s) != 0       # null x
-    assert L.dm4d_groupnorm_nhwc_forward(0, 4, 8, 4, 1, 0, 0, 0, 0, 1e-5, 0, 0, 0, 0, 1, s) == 0       # empty batch
+    assert L.dm4d_groupnorm_nhwc_forward(1, 4, 6, 4, 1, p, 0, 0, p, p, 1e-5, 0, p, p, p, 1, s) != 0       # C not a multiple of G
+    assert L.dm4d_groupnorm_nhwc_forward(1, 4, 8, 4, 7, p, 0, 0, p, p, 1e-5, 0, p, p, p, 1, s) != 0       # dtype
+    assert L.dm4d_groupnorm_nhwc_forward(1, 4, 8, 4, 1, p, 0, 0, p, p, 1e-5, 0, p, p, p, 1000, s) != 0    # splits
+    assert L.dm4d_groupnorm_nhwc_forward(1, 4, 8, 4, 1, 0, 0, 0, p, p, 1e-5, 0, p, p, p, 1, s) != 0       # null x
+    assert L.dm4d_groupnorm_nhwc_forward(1, 4, 8, 4, 1, p, p, 3, p, p, 1e-5, 0, p, p, p, 1, s) != 0       # add_stride not 0 / C
+    assert L.dm4d_groupnorm_nhwc_forward(0, 4, 8, 4, 1, 0, 0, 0, 0, 0, 1e-5, 0, 0, 0, 0, 1, s) == 0       # empty batch
+    assert L.dm4d_add_bias_nhwc(4, 6, 1, p, p, p, p, s) != 0 and L.dm4d_geglu(4, 6, 1, p, p, s) != 0     # C / D not a multiple of 4
+    assert L.dm4d_add_bias_nhwc(0, 8, 1, 0, 0, 0, 0, s) == 0 and L.dm4d_geglu(0, 8, 1, 0, 0, s) == 0
 
 
 def test_guidance_step_nhwc_against_the_nchw_library_path():
@@ -126,3 +141,36 @@ def test_guidance_step_nhwc_against_the_nchw_library_path():
     (l0, g0), (l1, g1) = outs
     assert abs(l0 - l1) <= 2e-2 * abs(l0), (l0, l1)
     assert float((g0 - g1).abs().max()) <= 0.05 * float(g0.abs().max()) and float((g0 - g1).norm()) <= 0.02 * float(g0.norm())
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.float32])
+def test_residual_bias_add_and_geglu(dtype):
+    """csrc/pointwise.hip: a + b + bias[c] on NHWC activations (with its pass-through gradient) and GEGLU, against torch."""
+    _need_gpu()
+    from dreammesh4d_amd import fused_norm
+
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device="cpu").manual_seed(5)
+    tol = dict(rtol=2e-3, atol=2e-3) if dtype == torch.float16 else dict(rtol=1e-6, atol=1e-6)
+    for shape in ((2, 320, 32, 32), (3, 64, 5, 7), (1, 1280, 8, 8)):
+        a = torch.randn(shape, generator=g).to(dev, dtype).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+        b = torch.randn(shape, generator=g).to(dev, dtype).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+        bias = torch.randn(shape[1], generator=g).to(dev, dtype)
+        y = fused_norm.add_bias(a, b, bias)
+        assert fused_norm.is_channels_last(y) and y.grad_fn is not None and type(y.grad_fn).__name__.startswith("_AddBias")
+        torch.testing.assert_close(y.float(), a.float() + b.float() + bias.float().view(1, -1, 1, 1), **tol)
+        dy = torch.randn(shape, generator=g).to(dev, dtype)
+        y.backward(dy)
+        assert torch.equal(a.grad, dy) and torch.equal(b.grad, dy)
+        y2 = fused_norm.add_bias(a.detach().contiguous(), b.detach(), bias)              # NCHW operand: torch path
+        torch.testing.assert_close(y2.float(), y.detach().float(), **tol)
+    for rows, D in (((8, 1024), 1280), ((2, 7), 40), ((3, 64), 5120)):
+        p = torch.randn(*rows, 2 * D, generator=g).to(dev, dtype)
+        with torch.no_grad():
+            y = fused_norm.geglu(p)
+        x_, gate = p.float().chunk(2, dim=-1)
+        torch.testing.assert_close(y.float(), x_ * F.gelu(gate), **tol)
+        assert y.shape == (*rows, D) and y.dtype == dtype
+        pr = p.clone().requires_grad_(True)                                               # gradient wanted: torch path
+        fused_norm.geglu(pr).sum().backward()
+        assert pr.grad is not None
