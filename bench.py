@@ -229,8 +229,10 @@ def main():
         traffic = None
         try:
             pmc = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")))
-            # the stage = the regular kernel + the long-cell kernel that runs beside it (both inside the timed scope)
-            traffic = round(sum(v["bytes_corrected"] for k, v in pmc.items() if k.startswith("dm4d::k_render_bwd")))
+            # the timed kernel: the lean variant (one launch takes the wide blocks and the quadrants).  (Until r02's last
+            # refresh this summed every k_render_bwd* entry of the file -- the non-lean variant of the roofline_full leg
+            # included -- and so reported twice the kernel's traffic.)
+            traffic = round(pmc["dm4d::k_render_bwd<6, true>"]["bytes_corrected"])
         except Exception:
             pass
         out = {
