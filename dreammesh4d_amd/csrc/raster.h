@@ -317,6 +317,7 @@ struct BwdOutputs {
 struct BatchDesc {
     int B, N, C, W, H, sh_coeffs;
     const int32_t *frame_index;   // optional [B] (device): view -> frame whose means / rotations / colours it renders
+    int scales_by_frame;          // scales are per FRAME (indexed like means3D) instead of per view / shared
     float tanfovx, tanfovy, scale_modifier;
     const float *bg;
     const float *view, *proj, *campos; size_t cam_stride, campos_stride;
@@ -375,7 +376,7 @@ DM4D_HD static inline ViewCtx resolve(const BatchDesc &d, int b)
     c.in.N = d.N; c.in.sh_coeffs = d.sh_coeffs; c.in.n_channels = d.C;
     c.in.means3D = d.means3D ? d.means3D + sf * d.means_stride : nullptr;
     c.in.rotations = d.rotations ? d.rotations + sf * d.rot_stride : nullptr;
-    c.in.scales = d.scales ? d.scales + sb * d.scale_stride : nullptr;
+    c.in.scales = d.scales ? d.scales + (d.scales_by_frame ? sf : sb) * d.scale_stride : nullptr;
     c.in.opacities = d.opacities ? d.opacities + sb * d.opac_stride : nullptr;
     c.in.colors_precomp = d.colors ? d.colors + sf * d.color_stride : nullptr;
     c.in.shs = d.shs ? d.shs + sb * d.sh_stride : nullptr;

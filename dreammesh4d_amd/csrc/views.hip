@@ -74,7 +74,7 @@ static BatchDesc views_batch(const dm4d_views *v)
     d.means3D = v->means3D; d.means_stride = (size_t)v->N * 3;
     d.rotations = v->rotations; d.rot_stride = (size_t)v->N * 4;
     d.colors = v->colors; d.color_stride = (size_t)v->N * 6;
-    d.scales = v->scales; d.scale_stride = 0;
+    d.scales = v->scales; d.scale_stride = v->scales_per_frame ? (size_t)v->N * 3 : 0; d.scales_by_frame = v->scales_per_frame ? 1 : 0;
     d.opacities = v->opacities; d.opac_stride = 0;
     d.radii = v->radii; d.radii_stride = (size_t)v->N;
     d.geom = (char *)v->geom; d.geom_stride = geom_layout(v->N, v->image_height, v->image_width).total;
@@ -99,7 +99,7 @@ static BatchDesc sub_batch(const BatchDesc &d, int b0, int nb)
     }
     s.view = d.view + b * d.cam_stride; s.proj = d.proj + b * d.cam_stride;
     if (d.campos) s.campos = d.campos + b * d.campos_stride;
-    if (d.scales) s.scales = d.scales + b * d.scale_stride;
+    if (d.scales && !(d.scales_by_frame && d.frame_index)) s.scales = d.scales + b * d.scale_stride;   // (per-frame: resolved through frame_index)
     if (d.opacities) s.opacities = d.opacities + b * d.opac_stride;
     if (d.shs) s.shs = d.shs + b * d.sh_stride;
     if (d.cov3D) s.cov3D = d.cov3D + b * d.cov_stride;

@@ -208,3 +208,49 @@ def quat_xyzw_to_matrix(q, grad_mode=None):
     return torch.stack([1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w),
                         2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w),
                         2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)], -1).reshape(*q.shape[:-1], 3, 3)
+
+
+# ----------------------------------------------------------------------------- d_scale branch (dynamic_sugar.py:592-612,682-704)
+# `d_scale: true` also stretches the Gaussians by the blended strain of the graph nodes.  The shipped configuration sets it
+# to false, so this branch is not on the measured path: the two small blends below are plain torch operators on device
+# tensors (autograd provides their backward); the per-frame scales they produce go through the HIP rasterizer like any
+# other input (views.render_views accepts [n_frames, N, 3] scales and returns their gradient).
+def strain_to_matrix(ds):
+    """I + sym(ds) [...,3,3] from the strain head's 6-vector (diag = ds[0:3], (01) = ds[3], (02) = ds[4], (12) = ds[5];
+    strain_tensor_to_matrix, dynamic_sugar.py:29-39)."""
+    one = torch.ones_like(ds[..., 0])
+    return torch.stack([one + ds[..., 0], ds[..., 3], ds[..., 4], ds[..., 3], one + ds[..., 1], ds[..., 5],
+                        ds[..., 4], ds[..., 5], one + ds[..., 2]], dim=-1).reshape(ds.shape[:-1] + (3, 3))
+
+
+def vertex_scale_matrices(graph: DeformGraph, ds, d_opacity=None, method="hybrid"):
+    """Per-vertex scale matrices [n_frames, V, 3, 3] of the `d_scale` branch (dynamic_sugar.py:593-611): lbs: the weighted
+    sum of the neighbour nodes' strain matrices; hybrid: weighted by the nodes' opacities as well, plus (1 - lbs weight) I
+    with the lbs weight clamp(sum_k w_k o_k + 0.4, max = 1) of the position blend (:572-578).  ds [n_frames, M, 6] raw strain
+    head outputs, d_opacity [n_frames, M] raw opacity logits."""
+    if method not in ("lbs", "hybrid"):
+        raise ValueError("d_scale needs skinning_method lbs or hybrid (the reference defines no vertex scale for dqs)")
+    idx = graph.nbr_idx.long()
+    S = strain_to_matrix(ds)[:, idx]                                   # [n_frames, V, K, 3, 3]
+    w = graph.nbr_w[None, :, :, None, None]
+    if method == "lbs":
+        return (w * S).sum(dim=2)
+    if d_opacity is None:
+        raise ValueError("hybrid skinning needs the opacity head output")
+    o = torch.sigmoid(d_opacity)[:, idx]                               # [n_frames, V, K]
+    lbs_w = torch.clamp((graph.nbr_w[None] * o).sum(dim=-1) + 0.4, max=1.0)
+    eye = torch.eye(3, dtype=S.dtype, device=S.device)
+    return (w * o[..., None, None] * S).sum(dim=2) + (1.0 - lbs_w)[..., None, None] * eye
+
+
+def gaussian_scales(topo: MeshTopology, vertex_scales, scaling):
+    """Scales [n_frames, N, 3] of the bound Gaussians under `d_scale` (dynamic_sugar.py:697-704): the barycentric blend of
+    the three corner vertices' scale matrices applied to the static scaling vector (thickness, s1, s2)."""
+    from . import geometry as geo
+
+    G = topo.G
+    bary = geo.bary_coords(G, vertex_scales.device, vertex_scales.dtype)[..., 0]      # [G, 3]
+    corner = vertex_scales[:, topo.faces.long()]                                      # [n_frames, F, 3, 3, 3]
+    D = torch.einsum("gc,tfcij->tfgij", bary, corner)                                 # [n_frames, F, G, 3, 3]
+    sc = scaling.reshape(topo.F, G, 3)
+    return torch.einsum("tfgij,fgj->tfgi", D, sc).reshape(vertex_scales.shape[0], topo.F * G, 3)

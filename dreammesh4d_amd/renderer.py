@@ -149,7 +149,8 @@ class DiffGaussianTemporal:
         r = self._renderer(H, W, math.tan(0.5 * fov0))
         # per-view leaves whose .grad receives dL/d(screen-space mean), like the reference's `screenspace_points`
         vsp = [torch.zeros(g.n_gaussians, 3, device=g.device, requires_grad=True) for _ in range(B)]
-        out = views.render_views(r, dx, dr, ds, do, g.static_quaternions, g.get_scaling, g.get_opacity.reshape(-1),
+        scales = g.timed_scales(ds, do) if g.d_scale else g.get_scaling      # per frame under d_scale (dynamic_sugar.py:717-720)
+        out = views.render_views(r, dx, dr, ds, do, g.static_quaternions, scales, g.get_opacity.reshape(-1),
                                  g.get_points_rgb(), w2c, full, torch.cat([bg, bg]), frame_index=frame_index,
                                  means2D=torch.stack(vsp))
         g._deformed_vert_positions = out["vxyz"]                      # read by the mesh regularisers of the system
@@ -189,7 +190,8 @@ class DiffGaussianTemporal:
         dx, dr, ds, do, frame_index = g.timed_node_outputs(ts, fi)
         r = self._renderer(H, W, math.tan(0.5 * float(viewpoint_camera.FoVy)))
         vsp = torch.zeros(g.n_gaussians, 3, device=g.device, requires_grad=True)
-        out = views.render_views(r, dx, dr, ds, do, g.static_quaternions, g.get_scaling, g.get_opacity.reshape(-1),
+        scales = g.timed_scales(ds, do) if g.d_scale else g.get_scaling      # per frame under d_scale (dynamic_sugar.py:717-720)
+        out = views.render_views(r, dx, dr, ds, do, g.static_quaternions, scales, g.get_opacity.reshape(-1),
                                  g.get_points_rgb(), viewpoint_camera.world_view_transform[None],
                                  viewpoint_camera.full_proj_transform[None], torch.cat([bg, bg]),
                                  frame_index=frame_index, means2D=vsp[None])

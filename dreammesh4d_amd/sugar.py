@@ -84,9 +84,9 @@ class DynamicSuGaR(nn.Module):
         self.topo = ops.MeshTopology(faces, V, G, dev)
         # deformation network: heads as in dynamic_sugar.py:141-147
         self.d_scale = bool(d_scale)
-        if self.d_scale:
-            raise NotImplementedError("d_scale: true (the per-vertex scale blend, dynamic_sugar.py:595-612,682-704) is not built yet; "
-                                      "configs/sugar_dynamic_dg.yaml sets d_scale: false")
+        if self.d_scale and skinning_method not in ("lbs", "hybrid"):
+            raise ValueError("d_scale: true needs skinning_method lbs or hybrid (the reference defines no vertex scale for dqs, "
+                             "dynamic_sugar.py:593-611)")
         kw = dict(no_dr=False, no_ds=not (d_scale or skinning_method in ("hybrid", "lbs")), no_do=skinning_method != "hybrid")
         kw.update(deformation_kwargs or {})
         self._deformation = DeformationNetwork(**kw).to(dev)
@@ -214,7 +214,17 @@ class DynamicSuGaR(nn.Module):
                                      None if do is None else do[i], self.skinning_method)
             xyz.append(x)
             rot.append(r)
-        return {"xyz": torch.stack(xyz), "rotation": torch.stack(rot)}
+        out = {"xyz": torch.stack(xyz), "rotation": torch.stack(rot)}
+        if self.d_scale:
+            out["scale"] = ops.vertex_scale_matrices(self.graph, ds, do, self.skinning_method)      # [N_t,V,3,3] (:593-611)
+        return out
+
+    def timed_scales(self, ds, do):
+        """Gaussian scales [n_frames, N, 3] under `d_scale` (dynamic_sugar.py:697-704) from the raw strain / opacity head
+        outputs of the step's frames; None without `d_scale` (the static scaling is used)."""
+        if not self.d_scale:
+            return None
+        return ops.gaussian_scales(self.topo, ops.vertex_scale_matrices(self.graph, ds, do, self.skinning_method), self.get_scaling)
 
     def get_timed_vertex_xyz(self, timestamp=None, frame_idx=None):
         return self.get_timed_vertex_attributes(timestamp, frame_idx)["xyz"]
@@ -227,14 +237,18 @@ class DynamicSuGaR(nn.Module):
         """Per timestamp: {"xyz" [N_t,N,3], "rotation" [N_t,N,4] (w,x,y,z), "normals" [N_t,N,3]} (:657-706, :330-364)."""
         va = self.get_timed_vertex_attributes(timestamp, frame_idx)
         res = [ops.face_gaussians(self.topo, x, r, self.static_quaternions) for x, r in zip(va["xyz"], va["rotation"])]
-        return {"xyz": torch.stack([m for m, _, _ in res]), "rotation": torch.stack([q for _, q, _ in res]),
-                "normals": torch.stack([n for _, _, n in res]), "vertex_xyz": va["xyz"]}
+        out = {"xyz": torch.stack([m for m, _, _ in res]), "rotation": torch.stack([q for _, q, _ in res]),
+               "normals": torch.stack([n for _, _, n in res]), "vertex_xyz": va["xyz"]}
+        if self.d_scale:
+            out["scale"] = ops.gaussian_scales(self.topo, va["scale"], self.get_scaling)
+        return out
 
     def get_timed_gs_all_single_time(self, timestamp=None, frame_idx=None):
         """(means3D, scales, rotations, opacity, colors_precomp) of ONE timestamp (dynamic_sugar.py:708-724)."""
         t = None if timestamp is None else torch.as_tensor(timestamp).reshape(1)
         a = self.get_timed_gs_attributes(t, frame_idx)
-        return a["xyz"][0], self.get_scaling, a["rotation"][0], self.get_opacity, self.get_points_rgb()
+        scales = a["scale"][0] if self.d_scale else self.get_scaling                   # (:717-720)
+        return a["xyz"][0], scales, a["rotation"][0], self.get_opacity, self.get_points_rgb()
 
     def get_timed_gs_normals(self, timestamp=None, frame_idx=None):
         return self.get_timed_gs_attributes(timestamp, frame_idx)["normals"]

@@ -176,6 +176,10 @@ class _RenderViews(torch.autograd.Function):
         for k, want in (("dx", (NF, g.M, 3)), ("dr", (NF, g.M, 4))):
             if tuple(keep[k].shape) != want:
                 raise ValueError(f"{k} must be {want}, got {tuple(keep[k].shape)}")
+        # scales [N,3] (shared by all views) or [NF,N,3] (per frame: the reference's d_scale branch)
+        sc_per_frame = keep["sc"].dim() == 3
+        if tuple(keep["sc"].shape) not in ((N, 3), (NF, N, 3)):
+            raise ValueError(f"scales must be [{N},3] or [{NF},{N},3], got {tuple(keep['sc'].shape)}")
         out = dict(vxyz=torch.empty(NF, g.V, 3, **f), vrot=torch.empty(NF, g.V, 4, **f), means=torch.empty(NF, N, 3, **f),
                    rots=torch.empty(NF, N, 4, **f), colors=torch.empty(NF, N, 6, **f),
                    radii=torch.empty(B, N, dtype=torch.int32, device=dev), color=torch.empty(B, 6, H, W, **f),
@@ -187,7 +191,8 @@ class _RenderViews(torch.autograd.Function):
                          _p(keep["dx"]), _p(keep["dr"]), _p(keep["ds"]), _p(keep["do"]), _p(t.faces), _p(keep["qs"]),
                          _p(keep["sc"]), _p(keep["op"]), _p(keep["rgb"]), _p(out["vxyz"]), _p(out["vrot"]),
                          _p(out["means"]), _p(out["rots"]), _p(out["colors"]), _p(out["radii"]), _p(out["color"]),
-                         _p(out["depth"]), _p(out["alpha"]), _p(ws["geom"]), _p(ws["binning"]), _p(ws["image"]), _p(fidx), NF)
+                         _p(out["depth"]), _p(out["alpha"]), _p(ws["geom"]), _p(ws["binning"]), _p(ws["image"]), _p(fidx), NF,
+                         1 if sc_per_frame else 0)
         keep["fidx"] = fidx
         with torch.cuda.device(dev):
             _lib.check(L.dm4d_views_forward(C.byref(vs), torch.cuda.current_stream(dev).cuda_stream),
@@ -240,7 +245,13 @@ class _RenderViews(torch.autograd.Function):
         r._give_ws(ctx.ws)   # stream-ordered reuse by the next forward is safe
         ctx.ws = ctx.internal = None
         r.last_grads = o   # per-view gradients (means2D etc.) for callers that want them
-        g_sc = o["sc"].sum(0).reshape(s[4]) if ctx.need_static else None
+        if not ctx.need_static:
+            g_sc = None
+        elif len(s[4]) == 3:        # per-frame scales: a frame's gradient is the sum over its views
+            fi = ctx.keep["fidx"]
+            g_sc = o["sc"] if fi is None else torch.zeros(s[4], **f).index_add_(0, fi.long(), o["sc"])
+        else:
+            g_sc = o["sc"].sum(0).reshape(s[4])
         g_op = o["op"].sum(0).reshape(s[5]) if ctx.need_static else None
         g_rgb = o["col"][:, :, :3].sum(0).reshape(s[6]) if ctx.need_static else None
         g_m2 = o["m2"] if ctx.needs_input_grad[13] else None       # screen-space mean gradients ("viewspace_points")

@@ -454,6 +454,10 @@ typedef struct dm4d_views {
      * entries instead of B. */
     const int32_t *frame_index;
     int32_t n_frames;
+    /* 0: `scales` is [N,3], shared by all views.  1: `scales` is per frame, [n_frames (B without frame_index), N, 3] -- the
+     * reference's `d_scale: true` branch, where the deformation also stretches the Gaussians
+     * (C/geometry/dynamic_sugar.py:682-704,717-720); dm4d_views_grads.dL_dscales stays per VIEW. */
+    int32_t scales_per_frame;
 } dm4d_views;
 
 typedef struct dm4d_views_grads {

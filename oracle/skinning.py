@@ -315,3 +315,28 @@ def static_attributes(log_scales, densities, sh_dc, thickness):
     opac = torch.sigmoid(densities.view(-1, 1))
     rgb = (sh_dc * SH_C0 + 0.5).view(-1, 3)
     return scales, opac, rgb
+
+
+# ----------------------------------------------------------------------------- d_scale branch
+def vertex_scales(nbr_idx, nbr_w, S, opacity=None, method="hybrid"):
+    """dynamic_sugar.py:593-611: per-vertex scale matrices [V,3,3] from the node strain matrices S [M,3,3] (and, hybrid, the
+    node opacities [M,1], with the position blend's lbs weight of :572-578)."""
+    Sn = S[nbr_idx]                                          # [V,K,3,3]
+    if method == "lbs":
+        return (nbr_w[..., None, None] * Sn).sum(dim=-3)
+    if method != "hybrid":
+        raise ValueError("the reference defines vertex scales for lbs and hybrid only")
+    on = opacity[nbr_idx]                                    # [V,K,1]
+    lbs_w = torch.clamp((nbr_w[..., None] * on).sum(dim=-2) + 0.4, max=1.0)      # [V,1]
+    out = (nbr_w[..., None, None] * on[..., None] * Sn).sum(dim=-3)
+    return out + (1.0 - lbs_w)[..., None] * torch.eye(3, dtype=S.dtype)
+
+
+def gaussian_scales(faces, n_per_face, vertex_scale, scaling):
+    """dynamic_sugar.py:697-704: gs_timed_dscale = sum_c bary_c * vert_scale[corner c]; scales = dscale @ scaling.
+    faces [F,3], vertex_scale [V,3,3], scaling [N,3] -> [N,3]."""
+    bary = bary_table(int(n_per_face), vertex_scale.dtype)                       # [G,3]
+    conn = faces.repeat_interleave(int(n_per_face), dim=0)                       # _gs_vert_connections [N,3]
+    w = bary.repeat(faces.shape[0], 1)                                           # _gs_bary_weights     [N,3]
+    d = (w[..., None, None] * vertex_scale[conn]).sum(dim=-3)                    # [N,3,3]
+    return torch.einsum("pij,pj->pi", d, scaling)

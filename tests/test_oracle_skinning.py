@@ -200,3 +200,39 @@ def test_pypose_and_exact_gradients_of_the_rotation_head_differ_by_one_half_near
         (xyz * gx).sum().backward()
         grads[mode] = dr.grad[:, :3].clone()
     assert torch.allclose(grads["pypose"], 0.5 * grads["exact"], rtol=2e-3, atol=1e-6 * float(grads["exact"].abs().max()))
+
+
+def test_d_scale_restatement_against_explicit_loops():
+    """oracle.skinning.vertex_scales / gaussian_scales (dynamic_sugar.py:593-611, 697-704) against the formulas written out
+    vertex by vertex / Gaussian by Gaussian."""
+    import numpy as np
+    import torch
+
+    from oracle import skinning as sk
+
+    g = torch.Generator().manual_seed(0)
+    D = torch.float64
+    V, M, K, F_ = 7, 5, 3, 4
+    idx = torch.randint(0, M, (V, K), generator=g)
+    w = torch.rand(V, K, generator=g, dtype=D)
+    w = w / w.sum(-1, keepdim=True)
+    S = sk.strain_to_matrix(0.3 * torch.randn(M, 6, generator=g, dtype=D))
+    op = torch.rand(M, 1, generator=g, dtype=D)
+    assert torch.equal(S, S.transpose(-1, -2)) and float((S[0] - torch.eye(3, dtype=D)).abs().max()) > 0
+    lbs, hyb = sk.vertex_scales(idx, w, S, None, "lbs"), sk.vertex_scales(idx, w, S, op, "hybrid")
+    for v in range(V):
+        a = sum(w[v, k] * S[idx[v, k]] for k in range(K))
+        lw = min(float(sum(w[v, k] * op[idx[v, k], 0] for k in range(K))) + 0.4, 1.0)
+        b = sum(w[v, k] * op[idx[v, k], 0] * S[idx[v, k]] for k in range(K)) + (1.0 - lw) * torch.eye(3, dtype=D)
+        assert torch.allclose(lbs[v], a, rtol=0, atol=1e-14) and torch.allclose(hyb[v], b, rtol=0, atol=1e-14)
+    faces = torch.randint(0, V, (F_, 3), generator=g)
+    scaling = torch.rand(F_ * 6, 3, generator=g, dtype=D)
+    gs = sk.gaussian_scales(faces, 6, hyb, scaling)
+    bary = np.asarray(sk.BARY6)
+    for p in range(F_ * 6):
+        f, j = divmod(p, 6)
+        d = sum(bary[j, c] * hyb[faces[f, c]] for c in range(3))
+        assert torch.allclose(gs[p], d @ scaling[p], rtol=0, atol=1e-14)
+    import pytest
+    with pytest.raises(ValueError):
+        sk.vertex_scales(idx, w, S, op, "dqs")
