@@ -33,6 +33,10 @@ import torch.nn.functional as F
 from .fused_norm import add_bias, geglu, group_norm, is_channels_last
 
 
+# cross-attention over a one-token context evaluated in closed form (CrossAttention.single_token); False: the general path
+SINGLE_TOKEN_SHORTCUT = True
+
+
 # ----------------------------------------------------------------------------- building blocks
 class GroupNorm32(nn.GroupNorm):
     """GroupNorm evaluated in fp32 (extern/ldm_zero123/modules/diffusionmodules/util.py:242-244).  Half tensors on a device:
@@ -129,9 +133,18 @@ class CrossAttention(nn.Module):
         self.to_v = nn.Linear(context_dim, inner, bias=False)
         self.to_out = nn.Sequential(nn.Linear(inner, query_dim), nn.Dropout(0.0))
 
+    def single_token(self, context):
+        """Cross-attention over ONE context token (Zero123's conditioning is a single CLIP + pose embedding per sample,
+        ddpm.py:1953-1956): the softmax over a single key is exactly 1, so every query's output is to_out(to_v(context)),
+        whatever the queries are -- [B, 1, query_dim], to be broadcast over the positions.  The same numbers as the general
+        path without its query projection, attention and output GEMM over all positions."""
+        return self.to_out(self.to_v(context))
+
     def forward(self, x, context=None):
         ctx = x if context is None else context
         B, L, _ = x.shape
+        if context is not None and ctx.shape[1] == 1 and SINGLE_TOKEN_SHORTCUT:
+            return self.single_token(ctx).expand(B, L, -1)
         h = self.heads
         q = self.to_q(x).view(B, L, h, -1).transpose(1, 2)
         k = self.to_k(ctx).view(B, ctx.shape[1], h, -1).transpose(1, 2)
@@ -168,7 +181,10 @@ class BasicTransformerBlock(nn.Module):
 
     def forward(self, x, context):
         x = self.attn1(self.norm1(x)) + x
-        x = self.attn2(self.norm2(x), context) + x
+        if context is not None and context.shape[1] == 1 and SINGLE_TOKEN_SHORTCUT:
+            x = x + self.attn2.single_token(context)          # (norm2 only feeds the queries, which do not matter here)
+        else:
+            x = self.attn2(self.norm2(x), context) + x
         return self.ff(self.norm3(x)) + x
 
 

@@ -113,3 +113,44 @@ def test_cond_layout_schedule_and_full_image_path():
     assert torch.isfinite(rgb.grad).all() and rgb.grad.abs().sum() > 0
     guid.update_step(0, 10, min_step_percent=0.02, max_step_percent=0.5)
     assert guid.max_step == 500
+
+
+def test_single_token_cross_attention_in_closed_form():
+    """Zero123's context is one token per sample: softmax over a single key is exactly 1, so cross-attention is
+    to_out(to_v(context)) broadcast over the positions (zero123.CrossAttention.single_token).  Same numbers as the general
+    path (query projection, attention, output GEMM over all positions); longer contexts take the general path."""
+    import torch
+
+    from dreammesh4d_amd import zero123 as z
+
+    torch.manual_seed(0)
+    unet = z.UNetModel(model_channels=32, context_dim=24, num_heads=4)
+    with torch.no_grad():
+        for m in unet.modules():
+            if isinstance(m, z.SpatialTransformer):
+                torch.nn.init.normal_(m.proj_out.weight, std=0.1)
+            if isinstance(m, z.ResBlock):
+                torch.nn.init.normal_(m.out_layers[3].weight, std=0.05)
+        torch.nn.init.normal_(unet.out[2].weight, std=0.1)
+    x, t = torch.randn(2, 8, 16, 16), torch.tensor([100, 700])
+    ctx1, ctx3 = torch.randn(2, 1, 24), torch.randn(2, 3, 24)
+    try:
+        with torch.no_grad():
+            z.SINGLE_TOKEN_SHORTCUT = True
+            a1, a3 = unet(x, t, ctx1), unet(x, t, ctx3)
+            z.SINGLE_TOKEN_SHORTCUT = False
+            b1, b3 = unet(x, t, ctx1), unet(x, t, ctx3)
+    finally:
+        z.SINGLE_TOKEN_SHORTCUT = True
+    assert float(a1.abs().max()) > 1e-3
+    assert float((a1 - b1).abs().max()) <= 2e-6 * float(b1.abs().max())
+    assert torch.equal(a3, b3)
+    att = [m for m in unet.modules() if isinstance(m, z.CrossAttention)][1]          # an attn2
+    q = torch.randn(2, 5, att.to_q.in_features)
+    c = torch.randn(2, 1, att.to_k.in_features)
+    z.SINGLE_TOKEN_SHORTCUT = False
+    try:
+        general = att(q, c)
+    finally:
+        z.SINGLE_TOKEN_SHORTCUT = True
+    assert torch.allclose(att(q, c), general, rtol=1e-6, atol=1e-7) and att(q, c).shape == (2, 5, att.to_q.in_features)
