@@ -248,15 +248,21 @@ __global__ __launch_bounds__(64) void k_render_fwd(BatchDesc d)
     uint32_t lastj = 0;       // list position + 1 of the pixel's last contributor (n_contrib, counted in the CELL list)
     bool done = !inside | row_long;
 
+    // two-deep prefetch: the LIST word of the chunk after next is loaded while the attributes of the next chunk are
+    // gathered (list word -> attribute gather is a dependent pair of memory round trips; one chunk of blending is
+    // shorter than the two of them)
     float4 r[4];
     zero_entry(r);
     if ((uint32_t)li < nr) gather_entry<C>(list[li], g, colors, r);
+    uint32_t wnext = (kChunk + (uint32_t)li < nr) ? list[kChunk + li] : 0u;
     for (uint32_t c0 = 0; c0 < nmax; c0 += kChunk) {
         const int cnt = (c0 < nr) ? (int)min((uint32_t)kChunk, nr - c0) : 0;
         __builtin_amdgcn_wave_barrier();
         stage_entry(row_base, li, r);
         zero_entry(r);
-        if (c0 + kChunk + (uint32_t)li < nr) gather_entry<C>(list[c0 + kChunk + li], g, colors, r);   // prefetch
+        const uint32_t wcur = wnext;
+        if (c0 + 2 * kChunk + (uint32_t)li < nr) wnext = list[c0 + 2 * kChunk + li];
+        if (c0 + kChunk + (uint32_t)li < nr) gather_entry<C>(wcur, g, colors, r);   // prefetch
         __builtin_amdgcn_wave_barrier();
         if (__ballot((!done) & (cnt > 0)) == 0) break;   // every pixel with entries left is saturated
         int t = 0;
@@ -380,6 +386,7 @@ __global__ __launch_bounds__(256) void k_render_fwd_long(BatchDesc d)
         float4 e[4];
         zero_entry(e);
         if ((uint32_t)lane < nr) gather_entry<C>(list[lane], g, colors, e);
+        uint32_t wnext = (64u + (uint32_t)lane < nr) ? list[64u + lane] : 0u;      // two-deep prefetch as in k_render_fwd
         for (uint32_t c0 = 0; c0 < nr; c0 += 64u) {
             const int cnt = (int)min(64u, nr - c0);
             __builtin_amdgcn_wave_barrier();
@@ -391,7 +398,9 @@ __global__ __launch_bounds__(256) void k_render_fwd_long(BatchDesc d)
                 *reinterpret_cast<float4 *>(se + 12) = make_float4(e[3].x, e[3].y, e[1].z, 1.0f);   // colours 4 5, depth, 1
             }
             zero_entry(e);
-            if (c0 + 64u + (uint32_t)lane < nr) gather_entry<C>(list[c0 + 64u + lane], g, colors, e);   // prefetch
+            const uint32_t wcur = wnext;
+            if (c0 + 128u + (uint32_t)lane < nr) wnext = list[c0 + 128u + lane];
+            if (c0 + 64u + (uint32_t)lane < nr) gather_entry<C>(wcur, g, colors, e);   // prefetch
             __builtin_amdgcn_wave_barrier();
             if (__ballot(!done) == 0) break;
             for (int t = 0; t < cnt; t += 4) {

@@ -1,6 +1,6 @@
 """Per-wave timeline of the blend kernels on the bench workload (dm4d_debug_trace)."""
 import sys, numpy as np, torch
-sys.path.insert(0, '/root/repo')
+sys.path.insert(0, '.')
 import bench
 from dreammesh4d_amd import _lib
 dev = torch.device('cuda:0')
