@@ -51,3 +51,32 @@ def test_product_has_no_cpu_fallback():
     with pytest.raises(RuntimeError, match="no CPU path"):
         dgr.GaussianRasterizer(rs)(means3D=z, means2D=z, opacities=torch.ones(4, 1), colors_precomp=z,
                                    scales=z + 1, rotations=torch.zeros(4, 4))
+
+
+def test_argument_validation_is_host_side():
+    """Entry points reject bad arguments before touching the device (so this runs without a GPU): the rasterizer's limits,
+    the GroupNorm / pointwise operators' shape rules; the message is available through dm4d_last_error."""
+    import ctypes as C
+
+    from dreammesh4d_amd import _lib
+
+    L = _lib.lib()
+    dummy = (C.c_float * 64)()
+    p = C.cast(dummy, C.c_void_p)
+    s = _lib.RasterSettings(64, 64, 0.2, 0.2, 1.0, 0, 0, 0, p, p, p, p)
+    too_many = _lib.RasterInputs((1 << 25) + 1, 0, 3, p, None, p, p, p, p, None)
+    assert L.dm4d_rasterize_prepare(C.byref(s), C.byref(too_many), p, p, 64, None) == -4            # DM4D_ERR_UNSUPPORTED
+    assert b"at most 33554432 Gaussians" in L.dm4d_last_error()
+    bad_size = _lib.RasterSettings(0, 64, 0.2, 0.2, 1.0, 0, 0, 0, p, p, p, p)
+    ok_in = _lib.RasterInputs(4, 0, 3, p, None, p, p, p, p, None)
+    assert L.dm4d_rasterize_prepare(C.byref(bad_size), C.byref(ok_in), p, p, 64, None) == -1        # DM4D_ERR_INVALID
+    both = _lib.RasterInputs(4, 1, 3, p, p, p, p, p, p, None)                                        # shs AND colors_precomp
+    assert L.dm4d_rasterize_prepare(C.byref(s), C.byref(both), p, p, 64, None) == -1
+    assert L.dm4d_rasterize_prepare(C.byref(s), C.byref(ok_in), p, p, 64, None) == -3               # workspace too small: DM4D_ERR_CAPACITY
+    assert b"geom workspace too small" in L.dm4d_last_error()
+    # GroupNorm / pointwise operators
+    assert L.dm4d_groupnorm_nhwc_forward(1, 4, 6, 4, 1, p, None, 0, p, p, 1e-5, 0, p, p, p, 1, None) == -1      # C % G
+    assert L.dm4d_groupnorm_nhwc_forward(1, 4, 8, 4, 1, p, p, 3, p, p, 1e-5, 0, p, p, p, 1, None) == -1         # add_stride
+    assert L.dm4d_groupnorm_nhwc_backward(1, 4, 8, 4, 1, p, None, 0, p, p, p, 0, None, p, p, 1, None) == -1     # dy missing
+    assert L.dm4d_add_bias_nhwc(4, 6, 1, p, p, p, p, None) == -1 and L.dm4d_geglu(4, 6, 0, p, p, None) == -1
+    assert L.dm4d_add_bias_nhwc(0, 8, 1, None, None, None, None, None) == 0 and L.dm4d_geglu(0, 8, 1, None, None, None) == 0
