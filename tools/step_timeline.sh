@@ -1,0 +1,29 @@
+#!/bin/bash
+# Start / end of every kernel of ONE steady-state bench step relative to the step's first kernel (rocprofv3 --kernel-trace),
+# for several builds of libdm4d_hip.so on the same box:   tools/step_timeline.sh a.so b.so ...
+REPO=${GRAFT_REPO_ROOT:-/root/repo}
+cp $REPO/dreammesh4d_amd/libdm4d_hip.so /tmp/libdm4d_keep.so
+cd /tmp && export TMPDIR=/tmp
+ALL=${ALL:-0}
+for v in "$@"; do
+  cp $REPO/$v $REPO/dreammesh4d_amd/libdm4d_hip.so
+  rm -rf /tmp/stl
+  rocprofv3 --kernel-trace --output-format csv -d /tmp/stl -o k -- python $REPO/bench.py --no-cpu-baseline --no-iters --steps 30 --warmup 5 > /dev/null 2>&1
+  echo "== $v"
+  python - <<PY
+import csv, glob
+f = glob.glob('/tmp/stl/**/k_kernel_trace.csv', recursive=True)[0]
+rows = [r for r in csv.DictReader(open(f))]
+rows.sort(key=lambda r: int(r['Start_Timestamp']))
+# steps start at k_hex_fwd; take the 20th from the end
+starts = [i for i, r in enumerate(rows) if 'k_hex_fwd' in r['Kernel_Name']]
+i0, i1 = starts[-20], starts[-19]
+t0 = int(rows[i0]['Start_Timestamp'])
+for r in rows[i0:i1]:
+    n = r['Kernel_Name'].replace('void ', '').split('(')[0]
+    if 'dm4d' not in n and '$ALL' != '1': continue
+    print(f"  {(int(r['Start_Timestamp'])-t0)/1e3:8.1f} -> {(int(r['End_Timestamp'])-t0)/1e3:8.1f} us  {n[:90]}")
+print(f"  step: {(int(rows[i1]['Start_Timestamp'])-t0)/1e3:.1f} us")
+PY
+done
+cp /tmp/libdm4d_keep.so $REPO/dreammesh4d_amd/libdm4d_hip.so
