@@ -2,7 +2,7 @@
 Gaussians, 512^2, 4 frames x (1 reference view + 1 SDS view) per iteration, full-size Zero123 (SD-1.x UNet 860 M
 parameters + VAE encoder, fp16, RANDOM weights -- the checkpoint is not in the tree), AdamW step included."""
 import json, sys, time, torch
-sys.path.insert(0, '/root/repo')
+sys.path.insert(0, '.'); sys.path.insert(0, '/root/repo')
 import bench
 from dreammesh4d_amd import zero123 as z, synthetic as syn
 from dreammesh4d_amd.dynamic_stage import DynamicStage
