@@ -97,7 +97,10 @@ class Workload:
         self.fidx = torch.tensor([self.frames.index(f) for f in self.unit_frames], device=dev)   # unit -> row of this step's frames
         self.frame_t = self.timestamps[torch.tensor(self.frames, device=dev)]
         self.bg6 = torch.ones(6, device=dev)
-        self.renderer = views.ViewRenderer(self.graph, self.topo, H, W, self.cams[0].tanfov, method="hybrid")
+        # DM4D_TILE_RECORDS=1: the experimental (Gaussian, tile) backward records summed in LDS (round 3: correct, but slower
+        # on gfx950 -- profiles/r03_tile_records.md); default: the bit-reproducible (Gaussian, cell) records
+        self.renderer = views.ViewRenderer(self.graph, self.topo, H, W, self.cams[0].tanfov, method="hybrid",
+                                           deterministic=os.environ.get("DM4D_TILE_RECORDS", "0") != "1")
         g = torch.Generator(device="cpu").manual_seed(2)
         B = VIEWS_PER_STEP
         self.gC = torch.randn(B, 6, H, W, generator=g).to(dev)

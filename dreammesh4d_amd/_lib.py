@@ -47,7 +47,7 @@ class ViewsStruct(C.Structure):
                [(n, vp) for n in ("bg", "viewmatrix", "projmatrix", "verts", "nbr_idx", "nbr_w", "dx", "dr", "ds",
                                   "d_opacity", "faces", "q_static", "scales", "opacities", "rgb", "vxyz", "vrot",
                                   "means3D", "rotations", "colors", "radii", "out_color", "out_depth", "out_alpha",
-                                  "geom", "binning", "image", "frame_index")] + [("n_frames", C.c_int32), ("scales_per_frame", C.c_int32)]
+                                  "geom", "binning", "image", "frame_index")] + [("n_frames", C.c_int32), ("scales_per_frame", C.c_int32), ("record_mode", C.c_int32)]
 
 
 class ViewsGrads(C.Structure):

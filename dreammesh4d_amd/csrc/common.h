@@ -33,6 +33,18 @@ struct ProfScope {
     ~ProfScope();
 };
 
+// fire-and-forget float add in LDS (ds_add_f32, no return value)
+__device__ __forceinline__ void lds_fadd(float *p, float v)
+{
+#if defined(DM4D_LDS_ACC_STORE)
+    *p = v;          // timing experiment only
+#elif defined(DM4D_LDS_ACC_NONE)
+    if (v == 123.456f) *p = v;
+#else
+    __builtin_amdgcn_ds_faddf((__attribute__((address_space(3))) float *)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP, false);
+#endif
+}
+
 __device__ __forceinline__ float as_f(uint32_t u) { return __uint_as_float(u); }
 __device__ __forceinline__ uint32_t as_u(float f) { return __float_as_uint(f); }
 

@@ -60,6 +60,24 @@ constexpr uint32_t kGidMask = (1u << kGidBits) - 1u;
 #define DM4D_WIDE_BWD 128
 #endif
 constexpr uint32_t kWideBwd = DM4D_WIDE_BWD;
+// tile-record mode: (Gaussian, tile) accumulators a workgroup of k_render_bwd_tile holds in LDS at a time (a window of the
+// tile list; longer lists take several windows, back to front)
+#ifndef DM4D_TILE_WINDOW
+#define DM4D_TILE_WINDOW 496
+#endif
+constexpr int kTileWindow = DM4D_TILE_WINDOW;
+// tiles a Gaussian's cell block spans (tile-record mode: one record each, row-major from (tx0, ty0))
+struct TileSpan { int tx0, ty0, tnx, tny; };
+DM4D_HD static inline TileSpan tile_span(uint32_t cellinfo_x, uint32_t cellinfo_y)
+{
+    const int bx0 = (int)(cellinfo_x & 0xFFFFu), by0 = (int)(cellinfo_x >> 16);
+    const int nbx = (int)(cellinfo_y & 0xFFFFu), nby = (int)(cellinfo_y >> 16);
+    TileSpan t;
+    t.tx0 = bx0 >> 2; t.ty0 = by0 >> 2;
+    t.tnx = (nbx > 0 && nby > 0) ? ((bx0 + nbx - 1) >> 2) - t.tx0 + 1 : 0;
+    t.tny = (nbx > 0 && nby > 0) ? ((by0 + nby - 1) >> 2) - t.ty0 + 1 : 0;
+    return t;
+}
 
 DM4D_HD static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
@@ -171,12 +189,14 @@ struct BinPtrs {
                           // One word per entry: Gaussian id | rank << kGidBits, rank = which of the Gaussian's backward
                           // records (cellinfo.z + rank) belongs to this cell.  Positions in a cell list stand in for the
                           // tile-list positions upstream counts with (n_contrib): the list is a subsequence of the tile list.
+    uint16_t *cpos;       // [16][cap], parallel to clist, written in tile-record mode only: the entry's position in the TILE list
+                          // (the slot of its (Gaussian, tile) accumulator in the LDS of k_render_bwd_tile)
     size_t cap;
 };
 DM4D_HD static inline size_t binning_bytes(int64_t cap)
 {
     size_t c = (size_t)(cap > 0 ? cap : 1);
-    return 3 * align_up(c * 4, 256) + align_up(c * kCells * 4, 256);
+    return 3 * align_up(c * 4, 256) + align_up(c * kCells * 4, 256) + align_up(c * kCells * 2, 256);
 }
 DM4D_HD static inline BinPtrs bin_ptrs(void *base, int64_t cap)
 {
@@ -188,6 +208,7 @@ DM4D_HD static inline BinPtrs bin_ptrs(void *base, int64_t cap)
     p.u_idx = (uint32_t *)(b + stride);
     p.point_list = (uint32_t *)(b + 2 * stride);
     p.clist = (uint32_t *)(b + 3 * stride);
+    p.cpos = (uint16_t *)(b + 3 * stride + align_up(c * kCells * 4, 256));
     p.cap = c;
     return p;
 }
@@ -336,6 +357,10 @@ struct BatchDesc {
     const float *dL_dcolor, *dL_ddepth, *dL_dalpha;
     float *dLq; size_t dlq_stride; uint32_t rec_cap;   // backward records: capacity (records) per view
     int lean;              // backward: lean records (see grad_stride); requires C == 6
+    int tile_records;      // 1: ONE backward record per (Gaussian, tile) instead of per (Gaussian, cell): K1 counts tiles, K4
+                           // also writes cpos, the blend backward is k_render_bwd_tile (a workgroup per tile sums its
+                           // sixteen cells' records in LDS with ds_add_f32: the order of the additions, and so the last
+                           // bits of the gradients, vary from run to run).  Must be the same for forward and backward.
     BwdOutputs o;          // per-view stride of each = N * width
 };
 
@@ -354,6 +379,7 @@ struct ViewCtx {
     const float *colors;   // colours actually blended ([N,C]): colors_precomp or the SH-evaluated rgb
     int T;
     uint32_t cap;
+    int trec;              // BatchDesc::tile_records
 };
 
 DM4D_HD static inline ViewCtx resolve(const BatchDesc &d, int b)
@@ -387,6 +413,7 @@ DM4D_HD static inline ViewCtx resolve(const BatchDesc &d, int b)
     c.b = bin_ptrs(d.binning ? d.binning + sb * d.bin_stride : nullptr, d.cap);
     c.im = img_ptrs(d.image ? d.image + sb * d.img_stride : nullptr, d.H, d.W);
     c.cap = d.cap;
+    c.trec = d.tile_records;
     c.colors = c.in.colors_precomp ? c.in.colors_precomp : c.g.rgb;
     c.out_color = d.out_color ? d.out_color + sb * d.C * P : nullptr;
     c.out_depth = d.out_depth ? d.out_depth + sb * P : nullptr;

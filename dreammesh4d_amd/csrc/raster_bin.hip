@@ -215,6 +215,7 @@ __device__ __forceinline__ void finish_tile(const ViewCtx &c, int tile, uint32_t
                         // among the cells really reached (< 64); kRankBig: a dense block too large for the field
                         const uint32_t rank = dense ? min((uint32_t)bit, kRankBig) : (uint32_t)__popcll(cm[j] & ((1ull << bit) - 1ull));
                         b.clist[(size_t)k * b.cap + s + pos] = gid[j] | (rank << kGidBits);
+                        if (c.trec) b.cpos[(size_t)k * b.cap + s + pos] = (uint16_t)min(e0 + (uint32_t)j, 0xFFFFu);
                     }
                 }
 #pragma unroll
@@ -230,6 +231,7 @@ __device__ __forceinline__ void finish_tile(const ViewCtx &c, int tile, uint32_t
         }
         __syncthreads();
     }
+    if (c.trec && n > 0x10000u && tid == 0) g.counters[kCntRecOverflow] = 1u;   // cpos holds 16-bit tile-list positions
     if (tid < kCells) {
         g.ccount[tile * kCells + tid] = s_cbase[tid];
         // long cells are blended by their own kernels (raster.h, kLongCell); which slot a cell gets does not matter.

@@ -215,6 +215,10 @@ __global__ __launch_bounds__(kPreThreads) void k_preprocess(BatchDesc d)
                     }
                     g.cellinfo[i] = make_uint4((uint32_t)bd.bx0 | ((uint32_t)bd.by0 << 16),
                                                (uint32_t)bd.nbx | ((uint32_t)bd.nby << 16), 0u, dense);
+                    if (d.tile_records) {      // tile-record mode: one backward record per tile the cell block spans
+                        const TileSpan ts = tile_span((uint32_t)bd.bx0 | ((uint32_t)bd.by0 << 16), (uint32_t)bd.nbx | ((uint32_t)bd.nby << 16));
+                        recs = (uint32_t)(ts.tnx * ts.tny);
+                    }
                     if (in.shs) {
                         const float *sh = in.shs + (size_t)i * in.sh_coeffs * 3;
 #pragma unroll

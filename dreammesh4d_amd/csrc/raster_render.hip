@@ -668,18 +668,21 @@ __device__ __forceinline__ uint32_t entry_slot(const uint32_t word, const GeomPt
 
 // gather the lane's entry (list position j of the cell list; `live` false: an inert entry) and derive what the pixel
 // loop needs
-template <int C>
+template <int C, bool SLOT = true>
 __device__ __forceinline__ void load_entry(EntryRegs<C> &e, uint32_t &slot, const bool live, const uint32_t *__restrict__ list,
                                            const uint32_t j, const GeomPtrs &g, const float *__restrict__ colors,
                                            const float cx0, const float cy0, const int gx, const int gy)
 {
-    float x = 0.f, y = 0.f, cA = 0.f, cB = 0.f, cC = 0.f;
+    // An inert entry (opacity 0: alpha = 0 whatever the rest) sits far off the cell with a unit conic, so that its power is
+    // hugely negative: with an all-zero entry power == 0 lands exactly on the "within 1e-6 of power == 0" test of
+    // pixel_pair and sends the WHOLE wave through the det_expf fallback for every pixel pair a padded chunk evaluates
+    float x = -1.0e3f, y = 0.f, cA = 1.f, cB = 0.f, cC = 0.f;
     e.o = 0.f; e.dep = 0.f; e.k = 0xFFFFFFFFu; slot = 0xFFFFFFFFu;
 #pragma unroll
     for (int ch = 0; ch < C; ++ch) e.c[ch] = 0.f;
     if (live) {
         const uint32_t word = list[j];
-        slot = entry_slot(word, g, gx, gy);
+        if (SLOT) slot = entry_slot(word, g, gx, gy);
         const uint32_t gid = word & kGidMask;
         e.k = j;                       // n_contrib counts cell-list positions
         const float2 xy = g.xy[gid];
@@ -885,6 +888,191 @@ __device__ __forceinline__ void render_bwd_wide_cells(const BatchDesc &d, const 
     trace.done(traced);
 }
 
+
+// ---------------------------------------------------------------------------------------- B1, tile-record mode
+// ONE WORKGROUP PER TILE (4 waves).  The entry-parallel arithmetic above is unchanged -- a lane still ends a chunk holding
+// the complete record of its (Gaussian, cell) entry -- but instead of going to HBM as its own record it is ADDED, with
+// ds_add_f32, to the accumulator of the entry's (Gaussian, TILE) pair in the workgroup's LDS: slot = the entry's position in
+// the tile list (cpos, written by K4 beside the cell lists).  When the sixteen cells are done the workgroup writes one record
+// per tile-list entry: 3.4x fewer records than (Gaussian, cell) pairs on the bench scene (0.18 GB per 8-view step instead of
+// 0.61 GB), and B2 reads that much less.  The order in which the cells' contributions meet in an accumulator depends on how
+// the waves are scheduled, so the last bits of the gradients vary from run to run (upstream's float atomicAdd has the same
+// property); the deterministic kernels above stay the default of the C ABI and of the parity tests.
+// (Global float atomics instead of LDS ones are not an option: measured with tools/ubench/atomics.hip, the L2 retires
+// ~125 G atomic dwords per second whatever their locality -- 0.9 ms for the 115 M of a step.)
+//   LDS holds kTileWindow accumulators: longer tile lists are processed in WINDOWS of tile-list positions, back to front;
+//   a row only takes the entries of its list whose position lies in the current window (the lists are ordered by
+//   position, so these are the next entries from the back), the per-pixel carries simply stay in the row's pixel table
+//   between windows.
+//   Cells with >= kWideBwd entries are walked by a whole wave (64 entries per step, as in the wide blocks above), dealt
+//   round-robin to the four waves before they turn to their quadrants.
+#ifndef DM4D_TILE_WAVES
+#define DM4D_TILE_WAVES 5
+#endif
+template <int C, bool LEAN, int WN>
+__global__ __launch_bounds__(256, DM4D_TILE_WAVES) void k_render_bwd_tile(BatchDesc d)
+{
+    constexpr int LN = PixTab<C>::kLine;
+    constexpr int NV = LEAN ? 9 : (C > 3 ? 13 : 10);      // values of a record
+    constexpr int RSP = (C <= 3 || LEAN) ? 12 : 16;       // floats of a record in memory (== grad_stride)
+    __shared__ float s_acc[WN * NV];
+    __shared__ __attribute__((aligned(16))) float s_tab[kCells][16 * LN];
+    __shared__ uint32_t s_pos[kCells], s_cnt[kCells];
+    __shared__ uint32_t s_slot[WN];     // record slot of every tile-list entry of the window (resolved while the tables load)
+    __shared__ uint32_t s_done;
+    const int T = ((d.W + kTile - 1) / kTile) * ((d.H + kTile - 1) / kTile);
+    const uint32_t rank = blockIdx.x;
+    const int view = (int)(rank % (uint32_t)d.B);
+    const ViewCtx c = resolve(d, view);
+    const ViewParams &vp = c.vp;
+    const GeomPtrs &g = c.g;
+    const BinPtrs &b = c.b;
+    const int tile = (int)g.order[rank / (uint32_t)d.B];
+    (void)T;
+    const uint32_t s = g.tile_start[tile];
+    uint32_t n = g.tile_count[tile];
+    if (s >= c.cap) n = 0;
+    else if (s + n > c.cap) n = c.cap - s;
+    if (n == 0) return;
+#ifdef DM4D_TILE_SKIP_ABOVE
+    if (n > DM4D_TILE_SKIP_ABOVE) return;      // timing experiment only (wrong gradients)
+#endif
+    float *__restrict__ rec = c.dLq;
+    const uint32_t rec_cap = c.rec_cap;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int tx = tile % vp.gx, ty = tile / vp.gx;
+    if (n >= 2048u) __builtin_amdgcn_s_setprio(3);
+    else if (n >= 1024u) __builtin_amdgcn_s_setprio(2);
+    else if (n >= 512u) __builtin_amdgcn_s_setprio(1);
+    {   // pixel tables of the sixteen cells: thread = pixel
+        const int cell = tid >> 4, p = tid & 15, q = cell >> 2, rw = cell & 3;
+        load_pixel<C>(s_tab[cell] + p * LN, c, tx * kTile + (q & 1) * 8 + (rw & 1) * 4 + (p & 3), ty * kTile + (q >> 1) * 8 + (rw >> 1) * 4 + (p >> 2));
+        if (tid == 0) s_done = 0u;
+        if (tid < kCells) {
+            const uint32_t nr = g.ccount[tile * kCells + tid];
+            s_cnt[tid] = nr;
+            s_pos[tid] = min(g.cdone[tile * kCells + tid], nr);      // entries the forward consumed: [0, pos) are left to do
+        }
+    }
+    for (uint32_t hi = n; hi > 0u;) {
+        const uint32_t lo = hi > (uint32_t)WN ? hi - (uint32_t)WN : 0u;
+        for (uint32_t i = tid; i < (hi - lo) * (uint32_t)NV; i += 256u) s_acc[i] = 0.f;
+        // Gaussian-major record slot of the window's tile-list entries = first record of the Gaussian + the rank of this tile
+        // among the tiles its cell block spans (two dependent gathers: resolved here, off the critical path of the flush)
+        for (uint32_t i = tid; i < hi - lo; i += 256u) {
+            const uint32_t gid = b.point_list[s + lo + i];
+            const uint4 ci = g.cellinfo[gid];
+            const TileSpan ts = tile_span(ci.x, ci.y);
+            const int ox = tx - ts.tx0, oy = ty - ts.ty0;
+            const uint32_t slot = ci.z + (uint32_t)(oy * ts.tnx + ox);
+            s_slot[i] = (ox >= 0 && ox < ts.tnx && oy >= 0 && oy < ts.tny && slot < rec_cap) ? slot : 0xFFFFFFFFu;
+        }
+        __syncthreads();
+        // ---- the wide cells of the tile, dealt to the waves ----
+        uint32_t widx = 0;
+        for (int cell = 0; cell < kCells; ++cell) {
+            if (s_cnt[cell] < kWideBwd) continue;
+            if ((widx++ & 3u) != (uint32_t)wave) continue;
+            const int q = cell >> 2, rw = cell & 3;
+            const int cxi = tx * kTile + (q & 1) * 8 + (rw & 1) * 4, cyi = ty * kTile + (q >> 1) * 8 + (rw >> 1) * 4;
+            const uint32_t *__restrict__ list = b.clist + (size_t)cell * b.cap + s;
+            const uint16_t *__restrict__ kp = b.cpos + (size_t)cell * b.cap + s;
+            float *tab = s_tab[cell];
+            uint32_t p = s_pos[cell];
+            for (;;) {
+                const bool inb = (uint32_t)lane < p;
+                const uint32_t j = p - 1u - (uint32_t)lane;
+                const uint32_t kk = inb ? (uint32_t)kp[j] : 0u;
+                const bool live = inb && kk >= lo;
+                const uint64_t bl = __builtin_amdgcn_ballot_w64(live);
+                if (bl == 0ull) break;
+                EntryRegs<C> e;
+                uint32_t unused;
+                load_entry<C, false>(e, unused, live, list, j, g, c.colors, (float)cxi, (float)cyi, cxi >> 2, cyi >> 2);
+                float acc[13];
+#pragma unroll
+                for (int i = 0; i < 13; ++i) acc[i] = 0.f;
+                cell_pixels<C, LEAN, true>(e, acc, lane == 63, tab);
+                if (live) {
+                    float *a = s_acc + (kk - lo) * (uint32_t)NV;
+#pragma unroll
+                    for (int i = 0; i < NV; ++i) lds_fadd(a + i, acc[i]);
+                }
+                __builtin_amdgcn_wave_barrier();
+                p -= (uint32_t)__builtin_popcountll(bl);
+            }
+            if (lane == 0) s_pos[cell] = p;
+        }
+        // ---- this wave's quadrant: row = cell ----
+        {
+            const int row = lane >> 4, li = lane & 15, cell = 4 * wave + row;
+            const int cxi = tx * kTile + (wave & 1) * 8 + (row & 1) * 4, cyi = ty * kTile + (wave >> 1) * 8 + (row >> 1) * 4;
+            const uint32_t *__restrict__ list = b.clist + (size_t)cell * b.cap + s;
+            const uint16_t *__restrict__ kp = b.cpos + (size_t)cell * b.cap + s;
+            float *tab = s_tab[cell];
+            const bool is_wide = s_cnt[cell] >= kWideBwd;
+            uint32_t p = is_wide ? 0u : s_pos[cell];
+            for (;;) {
+                const bool inb = (uint32_t)li < p;
+                const uint32_t j = p - 1u - (uint32_t)li;
+                const uint32_t kk = inb ? (uint32_t)kp[j] : 0u;
+                const bool live = inb && kk >= lo;
+                const uint64_t bl = __builtin_amdgcn_ballot_w64(live);
+                if (bl == 0ull) break;
+                EntryRegs<C> e;
+                uint32_t unused;
+                load_entry<C, false>(e, unused, live, list, j, g, c.colors, (float)cxi, (float)cyi, cxi >> 2, cyi >> 2);
+                float acc[13];
+#pragma unroll
+                for (int i = 0; i < 13; ++i) acc[i] = 0.f;
+                // (a wide cell's table belongs to the wave that walks it: this row is inert and must not write its carries back)
+                cell_pixels<C, LEAN, false>(e, acc, li == 15 && !is_wide, tab);
+                if (live) {
+                    float *a = s_acc + (kk - lo) * (uint32_t)NV;
+#pragma unroll
+                    for (int i = 0; i < NV; ++i) lds_fadd(a + i, acc[i]);
+                }
+                __builtin_amdgcn_wave_barrier();
+                p -= (uint32_t)__builtin_popcount((uint32_t)(bl >> (16 * row)) & 0xFFFFu);
+            }
+            if (li == 0 && !is_wide) s_pos[cell] = p;
+        }
+        // A tile of ONE window needs no barrier here: a wave that is done leaves (its wave slot and registers are free for
+        // the next workgroup's waves at once), the last one out writes the records.
+        const bool single = n <= (uint32_t)WN;
+        uint32_t fw = (uint32_t)wave, fstep = 256u;
+        if (single) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            uint32_t prev = 0;
+            if (lane == 0) prev = __hip_atomic_fetch_add(&s_done, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
+            prev = (uint32_t)__builtin_amdgcn_readfirstlane((int)prev);
+            if (prev != 3u) return;
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            fw = 0u; fstep = 64u;
+        } else __syncthreads();
+        // ---- one record per tile-list entry of the window; lanes 4i .. 4i+2 write the 16-byte parts of record i ----
+        for (uint32_t base = fw * 64u; base < hi - lo; base += fstep) {
+            const int part = lane & 3;
+#pragma unroll
+            for (int pp = 0; pp < 4; ++pp) {
+                const uint32_t entry = base + 16u * pp + ((uint32_t)lane >> 2);
+                const uint32_t sl = entry < hi - lo ? s_slot[entry] : 0xFFFFFFFFu;
+                if (part < RSP / 4 && sl != 0xFFFFFFFFu) {
+                    const float *a = s_acc + entry * (uint32_t)NV;
+                    float4 v;
+                    v.x = (4 * part + 0 < NV) ? a[4 * part + 0] : 0.f;
+                    v.y = (4 * part + 1 < NV) ? a[4 * part + 1] : 0.f;
+                    v.z = (4 * part + 2 < NV) ? a[4 * part + 2] : 0.f;
+                    v.w = (4 * part + 3 < NV) ? a[4 * part + 3] : 0.f;
+                    reinterpret_cast<float4 *>(rec + (size_t)sl * RSP)[part] = v;
+                }
+            }
+        }
+        hi = lo;
+        if (hi > 0u) __syncthreads();
+    }
+}
+
 // ---------------------------------------------------------------------------------------- debug read-out of n_contrib
 // The kernels count a pixel's contributors in its CELL list (positions in a subsequence of the tile list); upstream's
 // n_contrib is the position of the last contributor in the TILE list + 1.  dm4d_raster_read_image_state translates: the
@@ -972,6 +1160,14 @@ int launch_render_bwd(const BatchDesc &d, hipStream_t st)
     const int blocks = (int)((((int64_t)T * d.B + 7) / 8) * 8 * 4);
     ProfScope prof_(kKRenderBwd, st);
     if (d.lean && d.C != 6) { set_error("lean backward records need 6 channels"); return DM4D_ERR_INVALID; }
+    if (d.tile_records) {      // one workgroup per tile, (Gaussian, tile) records summed in LDS
+        const dim3 tgrid((unsigned)T * (unsigned)d.B);
+        if (d.C <= 3) hipLaunchKernelGGL((k_render_bwd_tile<3, false, kTileWindow>), tgrid, dim3(256), 0, st, d);
+        else if (d.lean) hipLaunchKernelGGL((k_render_bwd_tile<6, true, kTileWindow>), tgrid, dim3(256), 0, st, d);
+        else hipLaunchKernelGGL((k_render_bwd_tile<6, false, kTileWindow>), tgrid, dim3(256), 0, st, d);
+        DM4D_HIP_CHECK(hipGetLastError());
+        return DM4D_OK;
+    }
     // the long cells' blocks first (multiple of 8 of them: the regular blocks keep their XCD), then the quadrants
     const uint32_t long_blocks = (uint32_t)(min(T * kCells, kWideWaves) * d.B);
     const dim3 grid(long_blocks + (uint32_t)blocks);

@@ -50,6 +50,7 @@ static int views_check(const dm4d_views *v)
         return DM4D_ERR_UNSUPPORTED;
     }
     if (v->capacity <= 0 || v->capacity > 0xFFFFFFF0ll) { set_error("capacity out of range"); return DM4D_ERR_INVALID; }
+    if (v->record_mode != DM4D_RECORDS_CELL && v->record_mode != DM4D_RECORDS_TILE) { set_error("bad record_mode %d", v->record_mode); return DM4D_ERR_INVALID; }
     if (v->record_capacity <= 0 || v->record_capacity > 0xFFFFFFF0ll) { set_error("record_capacity out of range"); return DM4D_ERR_INVALID; }
     if (!v->bg || !v->viewmatrix || !v->projmatrix || !v->q_static || !v->scales || !v->opacities || !v->rgb ||
         !v->vxyz || !v->vrot || !v->means3D || !v->rotations || !v->colors || !v->radii || !v->geom || !v->binning ||
@@ -80,6 +81,7 @@ static BatchDesc views_batch(const dm4d_views *v)
     d.geom = (char *)v->geom; d.geom_stride = geom_layout(v->N, v->image_height, v->image_width).total;
     d.binning = (char *)v->binning; d.bin_stride = binning_bytes(v->capacity); d.cap = (uint32_t)v->capacity;
     d.rec_cap = (uint32_t)v->record_capacity;
+    d.tile_records = v->record_mode == DM4D_RECORDS_TILE ? 1 : 0;
     d.image = (char *)v->image; d.img_stride = image_bytes(v->image_height, v->image_width);
     d.out_color = v->out_color; d.out_depth = v->out_depth; d.out_alpha = v->out_alpha;
     return d;

@@ -458,7 +458,15 @@ typedef struct dm4d_views {
      * reference's `d_scale: true` branch, where the deformation also stretches the Gaussians
      * (C/geometry/dynamic_sugar.py:682-704,717-720); dm4d_views_grads.dL_dscales stays per VIEW. */
     int32_t scales_per_frame;
+    /* Backward records.  0 (DM4D_RECORDS_CELL): one per (Gaussian, 4x4-pixel cell), no atomics anywhere, gradients
+     * bit-reproducible from run to run -- the parity tests' mode.  1 (DM4D_RECORDS_TILE): one per (Gaussian, tile), the
+     * sixteen cells of a tile summed in LDS with ds_add_f32 by one workgroup: 3.4x fewer records to write and read back,
+     * the last bits of the gradients depend on the order the waves were scheduled in (as with upstream's float
+     * atomicAdd).  The forward image is bit-identical in both modes.  Forward and backward of a step must agree. */
+    int32_t record_mode;
 } dm4d_views;
+#define DM4D_RECORDS_CELL 0
+#define DM4D_RECORDS_TILE 1
 
 typedef struct dm4d_views_grads {
     const float *dL_dcolor, *dL_ddepth, *dL_dalpha;     /* [B,6,H,W] [B,H,W] [B,H,W]; depth/alpha may be NULL */
