@@ -80,6 +80,7 @@ class Workload:
             for name, p in self.net.named_parameters():
                 if "_deform" in name:
                     p.add_((0.02 * torch.randn(p.shape, generator=g0)).to(dev))
+        self.net.grads_in_place = True     # persistent HexPlane gradient planes (the step drops its gradients with set_to_none)
         self.nodes = T(sc["nodes"])
         self.timestamps = torch.linspace(0, 1, N_FRAMES + 2)[1:-1].to(dev)            # data/temporal_image.py:155-158
         # rank r renders frames {4r .. 4r+3} (mod L), VIEWS_PER_FRAME cameras each

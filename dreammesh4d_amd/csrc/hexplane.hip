@@ -40,6 +40,7 @@ struct HexGrads {
     float *g[kHexMaxScales * kHexPlanes];
     unsigned long long end4[kHexMaxScales * kHexPlanes];   // running end (in float4) of the planes, for the zero fill
     int n;
+    unsigned long long keep_mask;                          // planes the zero fill leaves alone (DM4D_HEX_KEEP_SPATIAL)
 };
 
 // grid_sample coordinate (align_corners=True, border padding): index of the lower texel and the
@@ -268,6 +269,7 @@ constexpr unsigned kHexZeroBlocks = 256;   // per plane
 __device__ __forceinline__ void hex_zero(const HexGrads &hg, const unsigned bid)
 {
     const int k = (int)(bid / kHexZeroBlocks);
+    if ((hg.keep_mask >> k) & 1u) return;      // a spatial plane the caller keeps zero outside its touched texels
     const unsigned bx = bid % kHexZeroBlocks;
     const unsigned long long n4 = hg.end4[k] - (k ? hg.end4[k - 1] : 0ull);
     float4 *dst = reinterpret_cast<float4 *>(hg.g[k]);
@@ -363,7 +365,7 @@ int dm4d_hexplane_forward(int32_t S, int32_t M, int32_t B, const int32_t *res, c
                           float *feat, void *samples, dm4d_stream_t stream)
 {
     HexDesc d;
-    int rc = fill_desc(d, S, M, B, res, planes, aabb_host, channel_last);
+    int rc = fill_desc(d, S, M, B, res, planes, aabb_host, channel_last & DM4D_HEX_CHANNELS_LAST);
     if (rc) return rc;
     if (!planes || !nodes || !times || !feat) { set_error("hexplane: null tensor"); return DM4D_ERR_INVALID; }
     const size_t total = (size_t)B * M * S * kHexCh;
@@ -384,13 +386,20 @@ int dm4d_hexplane_backward(int32_t S, int32_t M, int32_t B, const int32_t *res, 
                            void *scratch, float *const *g_planes, dm4d_stream_t stream)
 {
     HexDesc d;
-    int rc = fill_desc(d, S, M, B, res, planes, aabb_host, channel_last);
+    int rc = fill_desc(d, S, M, B, res, planes, aabb_host, channel_last & DM4D_HEX_CHANNELS_LAST);
     if (rc) return rc;
     if (!planes || !nodes || !times || !g_feat || !scratch || !g_planes) { set_error("hexplane: null tensor"); return DM4D_ERR_INVALID; }
     hipStream_t st = (hipStream_t)stream;
     HexGrads hg;
     memset(&hg, 0, sizeof(hg));
     hg.n = S * kHexPlanes;
+    // DM4D_HEX_KEEP_SPATIAL: the spatial gradient planes (xy, xz, yz: 134 of the 143 MB at the reference's resolutions) are
+    // PERSISTENT buffers that hold zeros outside the texels this plan touches -- the nodes are static, so those texels are
+    // the same every step and every one of them is overwritten below: nothing to clear.  The time planes' touched rows
+    // move with the timestamps; they are small and cleared as before.
+    if (channel_last & DM4D_HEX_KEEP_SPATIAL)
+        for (int s = 0; s < S; ++s)
+            for (int p : {0, 1, 3}) hg.keep_mask |= 1ull << (s * kHexPlanes + p);
     unsigned long long run = 0;
     for (int s = 0; s < S; ++s)
         for (int p = 0; p < kHexPlanes; ++p) {

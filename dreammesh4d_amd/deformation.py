@@ -210,15 +210,13 @@ class DeformationNetwork(nn.Module):
         if nodes.is_cuda:
             from . import hexplane as hx
 
-            key = (nodes.data_ptr(), M, nodes.device)
-            if getattr(self, "_hex_plan_key", None) != key:
-                self._hex_plan = hx.HexPlan(self.deformation_net.grid, nodes)
-                self._hex_plan_key = key
+            self.build_plan(nodes)
             # 2 t - 1 (dynamic_sugar.py:431) in one launch: addcmul(-1, t, 2) rounds exactly like (t * 2) - 1 (2 t is exact)
             c = getattr(self, "_affine_consts", None)
             if c is None or c[0].device != timestamps.device:
                 c = self._affine_consts = (torch.tensor(-1.0, device=timestamps.device), torch.tensor(2.0, device=timestamps.device))
-            feat = hx.hexplane_features(self.deformation_net.grid, self._hex_plan, torch.addcmul(c[0], timestamps.float(), c[1]))
+            feat = hx.hexplane_features(self.deformation_net.grid, self._hex_plan, torch.addcmul(c[0], timestamps.float(), c[1]),
+                                        grads_in_place=getattr(self, "grads_in_place", False))
             d = self.deformation_net
             lin0 = d.feature_out[0]
             heads = [d.pos_deform] + ([] if d.no_ds else [d.scales_deform]) + ([] if d.no_dr else [d.rotations_deform]) + \
@@ -246,6 +244,18 @@ class DeformationNetwork(nn.Module):
         r = lambda x, k: None if x is None else x.view(B, M, k)
         do = None if do is None else do.view(B, M)
         return r(dx, 3), r(dr, 4), r(ds, 6), do
+
+    def build_plan(self, nodes):
+        """The static gather lists of the fused HexPlane backward for this node set (built once; the nodes never move).
+        Training loops call it in their constructor so that everything derived from the plan -- the structured-sparse
+        gradient message, the sharded optimiser's state -- exists before the first step."""
+        from . import hexplane as hx
+
+        key = (nodes.data_ptr(), int(nodes.shape[0]), nodes.device)
+        if getattr(self, "_hex_plan_key", None) != key:
+            self._hex_plan = hx.HexPlan(self.deformation_net.grid, nodes)
+            self._hex_plan_key = key
+        return self._hex_plan
 
     def get_mlp_parameters(self):
         return [p for n, p in self.named_parameters() if "grid" not in n]

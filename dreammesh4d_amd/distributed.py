@@ -229,6 +229,8 @@ class ShardedAdamW:
         self.exp_avg = torch.zeros(self.chunk, dtype=torch.float32, device=dev)
         self.exp_avg_sq = torch.zeros(self.chunk, dtype=torch.float32, device=dev)
         self.step_count = 0
+        self.step_t = None               # steps APPLIED (device scalar: a step masked by found_inf does not count)
+        self.pending_decay = None        # per group: product of the decay factors not yet applied to the untouched elements
         # group id of every message element of the local slice (learning rates are per group)
         gid_of = {}
         for gi, g in enumerate(self.param_groups):
@@ -255,12 +257,17 @@ class ShardedAdamW:
             flat[o:o + cnt].copy_(src if ix is None else src.index_select(0, ix))
 
     @torch.no_grad()
-    def step(self):
+    def step(self, found_inf=None):
+        """found_inf (optional, scalar float tensor on the device, 1.0 = skip): the step is then masked ON THE DEVICE the way a
+        fused torch optimiser skips on `found_inf` (no host sync): parameters, both moments and the step counter keep
+        their values.  The collectives still run, so the ranks stay in lockstep; every rank must pass the same flag."""
         red, w = self.reducer, world()
         n = red.flat.numel()
+        dev = self.padded.device
+        keep = None if found_inf is None else (found_inf.reshape(()).to(dev) == 0)          # bool scalar: True = apply
         red.pack()
         self.padded[:n].copy_(red.flat)
-        g_shard = torch.empty(self.chunk, dtype=torch.float32, device=self.padded.device)
+        g_shard = torch.empty(self.chunk, dtype=torch.float32, device=dev)
         gloo = w > 1 and dist.get_backend() == "gloo"
         if w == 1:
             g_shard.copy_(self.padded)
@@ -271,18 +278,32 @@ class ShardedAdamW:
         else:
             dist.reduce_scatter_tensor(g_shard, self.padded)
         g_shard.mul_(1.0 / w)
-        # ---- AdamW on the slice: torch/optim/adamw.py::_single_tensor_adamw, operation for operation
+        # ---- AdamW on the slice: torch/optim/adamw.py::_single_tensor_adamw, operation for operation (the step count lives
+        #      on the device so that a skipped step does not advance the bias corrections)
         self._pack_params()
-        p = self.padded[self.lo:self.hi].clone()
-        self.step_count += 1
+        p_old = self.padded[self.lo:self.hi].clone()
+        if self.step_t is None:
+            self.step_t = torch.zeros((), dtype=torch.float64, device=dev)
+        step_new = self.step_t + 1.0
         b1, b2 = self.betas
-        lr = torch.tensor([float(g["lr"]) for g in self.param_groups], dtype=torch.float32, device=p.device)[self.gid]
-        p.mul_(1.0 - lr * self.weight_decay)
-        self.exp_avg.lerp_(g_shard, 1.0 - b1)
-        self.exp_avg_sq.mul_(b2).addcmul_(g_shard, g_shard, value=1.0 - b2)
-        bc1, bc2_sqrt = 1.0 - b1 ** self.step_count, (1.0 - b2 ** self.step_count) ** 0.5
-        denom = (self.exp_avg_sq.sqrt() / bc2_sqrt).add_(self.eps)
-        p.addcdiv_(self.exp_avg * (-(lr / bc1)), denom)
+        lr_g = torch.tensor([float(g["lr"]) for g in self.param_groups], dtype=torch.float32, device=dev)
+        lr = lr_g[self.gid]
+        p = p_old * (1.0 - lr * self.weight_decay)
+        exp_avg = torch.lerp(self.exp_avg, g_shard, 1.0 - b1)
+        exp_avg_sq = (self.exp_avg_sq * b2).addcmul_(g_shard, g_shard, value=1.0 - b2)
+        bc1 = (1.0 - torch.pow(torch.tensor(b1, dtype=torch.float64, device=dev), step_new)).to(torch.float32)
+        bc2_sqrt = torch.sqrt(1.0 - torch.pow(torch.tensor(b2, dtype=torch.float64, device=dev), step_new)).to(torch.float32)
+        denom = (exp_avg_sq.sqrt() / bc2_sqrt).add_(self.eps)
+        p.addcdiv_(exp_avg * (-(lr / bc1)), denom)
+        decay_g = (1.0 - lr_g.double() * self.weight_decay)             # this step's decay factor per group
+        if keep is not None:
+            p = torch.where(keep, p, p_old)
+            exp_avg = torch.where(keep, exp_avg, self.exp_avg)
+            exp_avg_sq = torch.where(keep, exp_avg_sq, self.exp_avg_sq)
+            step_new = torch.where(keep, step_new, self.step_t)
+            decay_g = torch.where(keep, decay_g, torch.ones_like(decay_g))
+        self.exp_avg, self.exp_avg_sq, self.step_t = exp_avg, exp_avg_sq, step_new
+        self.step_count += 1            # steps ATTEMPTED (host-side bookkeeping only)
         # ---- everyone gets every slice
         if w == 1:
             self.padded.copy_(p)
@@ -292,13 +313,16 @@ class ShardedAdamW:
             self.padded.copy_(torch.cat(parts))
         else:
             dist.all_gather_into_tensor(self.padded, p)
-        # ---- back into the parameters; elements outside the message only decay
-        for g in self.param_groups:
-            decay = 1.0 - float(g["lr"]) * self.weight_decay
-            for q in g["params"]:
-                k = [i for i, x in enumerate(red.params) if x is q]
-                if k and red.index[k[0]] is not None:
-                    q.data.mul_(decay)          # the touched elements are overwritten just below
+        # ---- back into the parameters.  Elements outside the message (HexPlane texels no node touches) have zero gradient
+        #      and zero moments on every rank: their whole update is the weight decay -- and no forward ever READS them (the
+        #      nodes are static).  Multiplying 134 MB of grids by the decay every step (round 2: a torch op per tensor) is
+        #      therefore deferred: the product of the steps' decay factors is kept per group on the device and applied by
+        #      materialize() (checkpointing, state_dict, tests) in one multi-tensor launch.
+        self.pending_decay = decay_g if self.pending_decay is None else self.pending_decay * decay_g
+        self._unpack_message()
+
+    def _unpack_message(self):
+        red = self.reducer
         for q, o, ix in zip(red.params, red.offsets, red.index):
             cnt = q.numel() if ix is None else ix.numel()
             seg = self.padded[o:o + cnt]
@@ -306,3 +330,21 @@ class ShardedAdamW:
                 storage_flat(q.data).copy_(seg)
             else:
                 storage_flat(q.data).index_copy_(0, ix, seg)
+
+    @torch.no_grad()
+    def materialize(self):
+        """Apply the deferred weight decay of the elements outside the message (see step()); afterwards every parameter
+        element equals what the replicated AdamW would hold.  Call before reading the parameters as a whole (checkpoints)."""
+        if self.pending_decay is None:
+            return
+        red = self.reducer
+        sparse = {id(x) for x, ix in zip(red.params, red.index) if ix is not None}
+        any_ = False
+        for gi, g in enumerate(self.param_groups):
+            tensors = [q.data for q in g["params"] if id(q) in sparse]
+            if tensors:
+                torch._foreach_mul_(tensors, self.pending_decay[gi].to(torch.float32))      # one multi-tensor launch per group
+                any_ = True
+        if any_:
+            self._unpack_message()                     # the touched elements carry their own (exact) values
+        self.pending_decay = None

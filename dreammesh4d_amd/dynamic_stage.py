@@ -43,8 +43,11 @@ class DynamicStage:
     def __init__(self, renderer, net, nodes, static, timestamps, ref_images, ref_masks, ref_camera, guidance=None,
                  frames_per_step=4, random_views_per_frame=1, deformation_lr=0.00032, grid_lr=0.0032, seed=0,
                  normal_consistency=None, arap=None, milestone_arap_reg=100, inter_frame_reg=0, num_inter_frames=10,
-                 length_inter_frames=0.1, sharded_optimizer=False):
+                 length_inter_frames=0.1, sharded_optimizer=False, lambdas=None):
         self.r, self.net, self.nodes, self.static = renderer, net, nodes, static
+        # loss weights: `system.loss` of the configuration (from_cfg), defaulting to the shipped sugar_dynamic_dg.yaml values
+        self.lam = dict(LAMBDA)
+        self.lam.update(lambdas or {})
         self.timestamps = timestamps                     # [L] in (0,1)
         # [L,H,W,3], [L,H,W,1]; the reference's gt image is composited on white outside the mask
         # (data/temporal_image.py:201-202) and the dynamic step compares it UNMASKED (system/sugar_4dgen.py:164-167)
@@ -60,18 +63,24 @@ class DynamicStage:
         self.dev = nodes.device
         self.gen = torch.Generator(device="cpu").manual_seed(seed + 977 * D.rank())   # per-rank seed (launch.py:166)
         self.opt = torch.optim.AdamW([
-            {"params": net.get_mlp_parameters(), "lr": deformation_lr, "name": "deformation"},
-            {"params": net.get_grid_parameters(), "lr": grid_lr, "name": "grid"}],
+            {"params": net.get_mlp_parameters(), "lr": C(deformation_lr, 0, 0, interpolation="exp"), "name": "deformation"},
+            {"params": net.get_grid_parameters(), "lr": C(grid_lr, 0, 0, interpolation="exp"), "name": "grid"}],
             lr=0.0, betas=(0.9, 0.99), eps=1e-15, **({"fused": True} if self.dev.type == "cuda" else {}))   # one multi-tensor launch
         self.sched = {"deformation": deformation_lr, "grid": grid_lr}
-        # The exchange: the dense reducer until the HexPlane gather plan of the (static) node set exists, i.e. until the
-        # first query; from then on the structured-sparse message (touched texels + time planes + MLP: 13.5 MB instead of
-        # 143 MB at the shipped size, distributed.GradAllReducer).  sharded_optimizer: reduce-scatter -> AdamW on this
-        # rank's slice of the message -> all-gather (distributed.ShardedAdamW) instead of all-reduce + replicated AdamW.
-        self.reducer = D.GradAllReducer(net.parameters())
-        self._sparse_reducer = False
+        # The exchange: the structured-sparse message (touched texels + time planes + MLP: 13.5 MB instead of 143 MB at the
+        # shipped size, distributed.GradAllReducer) FROM THE FIRST STEP: the HexPlane gather plan of the (static) node set
+        # is built here, not by the first query, so the reducer -- and the sharded optimiser's moments -- are never rebuilt
+        # mid-run.  sharded_optimizer: reduce-scatter -> AdamW on this rank's slice of the message -> all-gather
+        # (distributed.ShardedAdamW) instead of all-reduce + replicated AdamW.
+        if self.dev.type == "cuda":
+            plan = net.build_plan(nodes)
+            self.reducer = D.GradAllReducer(net.parameters(), touched=D.touched_from_plan(net.deformation_net.grid, plan))
+            net.grads_in_place = True     # persistent HexPlane gradient planes: this loop drops its gradients every step
+        else:
+            self.reducer = D.GradAllReducer(net.parameters())
         self.sharded_optimizer = bool(sharded_optimizer)
-        self.sharded = None
+        self.sharded = D.ShardedAdamW(self.opt.param_groups, self.reducer, betas=(0.9, 0.99), eps=1e-15) if self.sharded_optimizer else None
+        self.overflow_skipped = 0        # iterations whose optimiser step was skipped on the device (reported by poll)
         self.global_step = 0
         self.poll_every = 8              # iterations between sync-free looks at the rasterizer's capacity counters
         self.bg6 = torch.ones(6, device=self.dev)      # training background is white (diff_sugar_rasterizer_temporal.py:96-101)
@@ -156,44 +165,78 @@ class DynamicStage:
             ref = b["ref_idx"]
             terms["rgb"] = F.mse_loss(self.ref_images[b["fidx_ref"]], rgb[ref])     # unmasked: colour outside the silhouette is penalised
             terms["mask"] = F.mse_loss(mask[ref], self.ref_masks[b["fidx_ref"]])
-            loss = loss + LAMBDA["rgb"] * terms["rgb"] + C(LAMBDA["mask"], 0, it) * terms["mask"]
+            loss = loss + self.lam["rgb"] * terms["rgb"] + C(self.lam["mask"], 0, it) * terms["mask"]
         if self.guidance is not None and b["n_rnd"]:
             g = self.guidance(rgb[b["rnd_idx"]], b["elev_rnd"], b["azim_rnd"], torch.full_like(b["elev_rnd"], 3.8),
                               frame_indices=b["fidx_rnd"])
             terms["sds"] = g["loss_sds"]
-            loss = loss + LAMBDA["sds_zero123"] * g["loss_sds"]
+            loss = loss + C(self.lam["sds_zero123"], 0, it) * g["loss_sds"]
         if self.normal_consistency is not None:
             # mesh_normal_consistency(get_timed_surface_mesh(batch timestamps)): the step's deformed meshes, one per frame
             terms["normal_consistency"] = self.normal_consistency(out["vxyz"])
-            loss = loss + LAMBDA["normal_consistency"] * terms["normal_consistency"]
+            loss = loss + C(self.lam["normal_consistency"], 0, it) * terms["normal_consistency"]
         if self.arap is not None and it >= self.milestone_arap_reg:
             terms["arap_reg_key_frame"] = self.arap.compute_arap_energy(out["vxyz"], quat_xyzw_to_matrix(out["vrot"], self.r.grad_mode)).sum()
-            loss = loss + LAMBDA["arap_reg_key_frame"] * terms["arap_reg_key_frame"]
+            loss = loss + C(self.lam["arap_reg_key_frame"], 0, it) * terms["arap_reg_key_frame"]
             if self.inter_frame_reg > 0 and it % self.inter_frame_reg == 0:
                 terms["arap_reg_inter_frame"] = self.inter_frame_arap()
-                loss = loss + LAMBDA["arap_reg_inter_frame"] * terms["arap_reg_inter_frame"]
+                loss = loss + C(self.lam["arap_reg_inter_frame"], 0, it) * terms["arap_reg_inter_frame"]
         loss.backward()
-        if not self._sparse_reducer and getattr(self.net, "_hex_plan", None) is not None:
-            self.reducer = D.GradAllReducer(self.net.parameters(), touched=D.touched_from_plan(self.net.deformation_net.grid, self.net._hex_plan))
-            self._sparse_reducer = True
-        if self.sharded_optimizer:
-            if self.sharded is None or self.sharded.reducer is not self.reducer:
-                self.sharded = D.ShardedAdamW(self.opt.param_groups, self.reducer, betas=(0.9, 0.99), eps=1e-15)
-            for gs, go in zip(self.sharded.param_groups, self.opt.param_groups):
-                gs["lr"] = go["lr"]
-            self.sharded.step()         # the exchange (reduce-scatter / all-gather) is inside
-            self.global_step += 1
-            return {"loss": loss.detach(), **{k: v.detach() for k, v in terms.items()}}
-        self.reducer()                  # the one exchange step (no-op for a single process)
+        # A forward that overflowed its duplicate / record capacity rendered a wrong image: the optimiser step is skipped ON
+        # THE DEVICE (found_inf, as a GradScaler would; no host sync), on EVERY rank (MAX over the ranks of the flag: the
+        # replicas stay identical) and for BOTH optimisers; poll() notices a step or two later and enlarges the capacities.
+        flag = None
         if self.dev.type == "cuda":
-            # a forward that overflowed its duplicate / record capacity rendered a wrong image: the fused AdamW skips the
-            # step on the device (found_inf, as a GradScaler would) -- no host sync; poll() reports it a step or two later
             flag = self.r.overflow_flag()
             if D.world() > 1:
                 D.all_reduce_max(flag)
-            self.opt.found_inf, self.opt.grad_scale = flag, None
-        self.opt.step()
+        if self.sharded_optimizer:
+            for gs, go in zip(self.sharded.param_groups, self.opt.param_groups):
+                gs["lr"] = go["lr"]
+            self.sharded.step(found_inf=flag)         # the exchange (reduce-scatter / all-gather) is inside
+        else:
+            self.reducer()                  # the one exchange step (no-op for a single process)
+            if flag is not None:
+                self.opt.found_inf, self.opt.grad_scale = flag, None
+            self.opt.step()
         self.global_step += 1
+        terms = {k: v.detach() for k, v in terms.items()}
         if self.dev.type == "cuda" and self.global_step % self.poll_every == 0:
-            self.r.poll()
-        return {"loss": loss.detach(), **{k: v.detach() for k, v in terms.items()}}
+            # poll() raises after it has ALREADY enlarged the capacities, and only on the rank that overflowed: the step was
+            # skipped on the device, so the loop just carries on (all ranks on the same control path) and reports it
+            from ._lib import Dm4dError
+
+            try:
+                self.r.poll()
+            except Dm4dError as e:
+                self.overflow_skipped += 1
+                terms["overflow_skipped"] = str(e)
+        return {"loss": loss.detach(), **terms}
+
+    def state_for_checkpoint(self):
+        """Parameters as a replicated AdamW would hold them (the sharded optimiser defers the weight decay of the HexPlane
+        texels no node touches: distributed.ShardedAdamW.materialize)."""
+        if self.sharded is not None:
+            self.sharded.materialize()
+        return self.net.state_dict()
+
+    @classmethod
+    def from_cfg(cls, system_cfg, renderer, net, nodes, static, timestamps, ref_images, ref_masks, ref_camera, **kw):
+        """The stage as `system:` of configs/sugar_dynamic_dg.yaml describes it (the block of the YAML as a dict, resolved):
+        loss weights from `system.loss` (lambda_*; lists are C() schedules, system/sugar_4dgen.py:296-330), `system.freq`
+        (milestone_arap_reg, inter_frame_reg), `num_inter_frames` / `length_inter_frames` (:51-52), the learning rates of
+        `system.geometry` (deformation_lr, grid_lr).  Terms whose weight is 0 in the configuration (lambda_depth ...) are
+        not part of this loop."""
+        loss = dict(system_cfg.get("loss", {}))
+        lam = {k[len("lambda_"):]: v for k, v in loss.items() if k.startswith("lambda_")}
+        unknown = {k for k, v in lam.items() if k not in LAMBDA and v not in (0, 0.0, None)}
+        if unknown:
+            raise NotImplementedError(f"loss terms with a non-zero weight that this loop does not compute: {sorted(unknown)}")
+        freq, geo = system_cfg.get("freq", {}), system_cfg.get("geometry", {})
+        args = dict(lambdas={k: v for k, v in lam.items() if k in LAMBDA},
+                    milestone_arap_reg=int(freq.get("milestone_arap_reg", 100)), inter_frame_reg=int(freq.get("inter_frame_reg", 0)),
+                    num_inter_frames=int(system_cfg.get("num_inter_frames", 10)),
+                    length_inter_frames=float(system_cfg.get("length_inter_frames", 0.1)),
+                    deformation_lr=geo.get("deformation_lr", 0.00032), grid_lr=geo.get("grid_lr", 0.0032))
+        args.update(kw)
+        return cls(renderer, net, nodes, static, timestamps, ref_images, ref_masks, ref_camera, **args)

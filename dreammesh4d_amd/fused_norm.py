@@ -19,6 +19,48 @@ from . import _lib
 _DTYPES = {torch.float16: 0, torch.float32: 1}      # DM4D_GN_F16, DM4D_GN_F32
 MAX_SPLITS = 128                                    # DM4D_GN_MAX_SPLITS
 
+# A tensor on a HIP device that does NOT take the HIP operator (a layout regression upstream: NCHW activations, an odd
+# channel count, a dtype mismatch) silently costs the step its fused kernels.  Every such call is counted here, by operator
+# and reason; `expect_fused()` turns them into an error (the guidance step runs under it, tests assert the count is 0).
+FALLBACKS = {}
+
+
+def _fallback(op, x, reason):
+    if x.is_cuda:
+        key = (op, reason)
+        FALLBACKS[key] = FALLBACKS.get(key, 0) + 1
+
+
+def fallback_count():
+    return sum(FALLBACKS.values())
+
+
+class expect_fused:
+    """Context: device tensors inside are expected to take the HIP operators.  Leaving it with new fallbacks warns (once per
+    process, with the operators and reasons); under DM4D_STRICT_FUSED=1 -- the GPU tests -- it raises."""
+    _warned = False
+
+    def __enter__(self):
+        self.before = dict(FALLBACKS)
+        return self
+
+    def __exit__(self, et, ev, tb):
+        if et is not None:
+            return False
+        new = {k: v - self.before.get(k, 0) for k, v in FALLBACKS.items() if v != self.before.get(k, 0)}
+        if new:
+            import os
+            import warnings
+
+            msg = (f"fused_norm: {sum(new.values())} call(s) on device tensors fell back to torch operators: {new} (the HIP operators "
+                   "need dense channels_last activations with C % 8 == 0 (fp16) / C % 4 == 0 (fp32) and frozen affine parameters)")
+            if os.environ.get("DM4D_STRICT_FUSED", "0") == "1":
+                raise RuntimeError(msg)
+            if not expect_fused._warned:
+                warnings.warn(msg)
+                expect_fused._warned = True
+        return False
+
 
 def _splits(hw):
     """Workgroups per sample: slabs of >= 16 positions, at most DM4D_GN_MAX_SPLITS."""
@@ -39,7 +81,8 @@ class _GroupNormNHWC(torch.autograd.Function):
         stats = torch.empty(N, groups, 2, device=x.device, dtype=torch.float32)
         scratch = torch.empty(N, S, groups, 2, device=x.device, dtype=torch.float32)
         add_stride = 0 if add is None or add.dim() == 1 else C                      # [C]: the same for every sample
-        _lib.check(L.dm4d_groupnorm_nhwc_forward(N, H * W, C, groups, _DTYPES[x.dtype], x.data_ptr(),
+        with torch.cuda.device(x.device):
+            _lib.check(L.dm4d_groupnorm_nhwc_forward(N, H * W, C, groups, _DTYPES[x.dtype], x.data_ptr(),
                                                  0 if add is None else add.data_ptr(), add_stride, weight.data_ptr(), bias.data_ptr(),
                                                  eps, int(silu), y.data_ptr(), stats.data_ptr(), scratch.data_ptr(), S,
                                                  torch.cuda.current_stream(x.device).cuda_stream), "groupnorm forward")
@@ -57,7 +100,8 @@ class _GroupNormNHWC(torch.autograd.Function):
         L = _lib.lib()
         dx = torch.empty_like(x)
         scratch = torch.empty(N, S, groups, 2, device=x.device, dtype=torch.float32)
-        _lib.check(L.dm4d_groupnorm_nhwc_backward(N, H * W, C, groups, _DTYPES[x.dtype], x.data_ptr(),
+        with torch.cuda.device(x.device):
+            _lib.check(L.dm4d_groupnorm_nhwc_backward(N, H * W, C, groups, _DTYPES[x.dtype], x.data_ptr(),
                                                   0 if add is None else add.data_ptr(), add_stride, weight.data_ptr(), bias.data_ptr(),
                                                   stats.data_ptr(), int(silu), dy.data_ptr(), dx.data_ptr(), scratch.data_ptr(), S,
                                                   torch.cuda.current_stream(x.device).cuda_stream), "groupnorm backward")
@@ -75,6 +119,12 @@ def group_norm(module, x, silu=False, add=None, float32=False):
     """act(GroupNorm(x + add)), add [N, C] (per sample and channel) or [C] (per channel).  `float32`: the reference's
     GroupNorm32 (statistics and affine map evaluated in float32 around half-precision storage) -- what the HIP kernels do
     for every input."""
+    if add is not None:
+        C = x.shape[1]
+        if add.dim() == 2 and add.shape[0] == 1 and x.shape[0] != 1:
+            add = add.reshape(-1)                                        # [1, C]: one row for every sample
+        if tuple(add.shape) not in ((C,), (x.shape[0], C)):
+            raise ValueError(f"group_norm: add must be [{C}] or [{x.shape[0]}, {C}], got {tuple(add.shape)}")
     if fused_ok(module, x):
         if add is not None:
             if torch.is_grad_enabled() and add.requires_grad:        # the operator treats `add` as a constant
@@ -82,6 +132,7 @@ def group_norm(module, x, silu=False, add=None, float32=False):
             else:
                 add = add.detach().to(x.dtype).contiguous()
         return _GroupNormNHWC.apply(x, module.weight, module.bias, add, module.num_groups, module.eps, silu)
+    _fallback("group_norm", x, "layout" if not is_channels_last(x) else "dtype/channels/trainable affine")
     if add is not None:
         x = x + add.type(x.dtype).view(-1, x.shape[1], 1, 1)
     if float32 and not (x.is_cuda and x.dtype in (torch.float16, torch.bfloat16) and module.weight.dtype == x.dtype):
@@ -98,7 +149,8 @@ class _AddBias(torch.autograd.Function):
     def forward(ctx, a, b, bias):
         N, C, H, W = a.shape
         y = torch.empty_like(a)
-        _lib.check(_lib.lib().dm4d_add_bias_nhwc(N * H * W, C, _DTYPES[a.dtype], a.data_ptr(), b.data_ptr(), bias.data_ptr(), y.data_ptr(),
+        with torch.cuda.device(a.device):
+            _lib.check(_lib.lib().dm4d_add_bias_nhwc(N * H * W, C, _DTYPES[a.dtype], a.data_ptr(), b.data_ptr(), bias.data_ptr(), y.data_ptr(),
                                                  torch.cuda.current_stream(a.device).cuda_stream), "add_bias")
         return y
 
@@ -113,6 +165,7 @@ def add_bias(a, b, bias):
             and a.shape == b.shape and a.shape[1] % (8 if a.dtype == torch.float16 else 4) == 0 and a.numel() > 0
             and not (torch.is_grad_enabled() and bias.requires_grad)):
         return _AddBias.apply(a, b, bias)
+    _fallback("add_bias", a, "layout" if not (is_channels_last(a) and is_channels_last(b)) else "dtype/channels/trainable bias")
     return a + (b + bias.view(1, -1, 1, 1))
 
 
@@ -122,8 +175,10 @@ def geglu(proj):
     if (proj.is_cuda and proj.is_contiguous() and proj.dtype in _DTYPES and D % (8 if proj.dtype == torch.float16 else 4) == 0
             and proj.numel() > 0 and not (torch.is_grad_enabled() and proj.requires_grad)):
         y = torch.empty(proj.shape[:-1] + (D,), device=proj.device, dtype=proj.dtype)
-        _lib.check(_lib.lib().dm4d_geglu(proj.numel() // (2 * D), D, _DTYPES[proj.dtype], proj.data_ptr(), y.data_ptr(),
+        with torch.cuda.device(proj.device):
+            _lib.check(_lib.lib().dm4d_geglu(proj.numel() // (2 * D), D, _DTYPES[proj.dtype], proj.data_ptr(), y.data_ptr(),
                                          torch.cuda.current_stream(proj.device).cuda_stream), "geglu")
         return y
+    _fallback("geglu", proj, "layout" if not proj.is_contiguous() else "dtype/width/requires_grad")
     x, gate = proj.chunk(2, dim=-1)
     return x * F.gelu(gate)

@@ -83,6 +83,7 @@ class HexPlan:
         self.sp = {k: T(v) for k, v in sp.items()}
         self.tp = {k: T(v) for k, v in tp.items()}
         self.n_sp, self.n_tp = len(sp["texel"]), len(tp["col"])
+        self.grad_buffers = None     # persistent dense gradient planes (hexplane_features(..., grads_in_place=True))
 
 
 def plane_layout(planes):
@@ -102,7 +103,7 @@ def _plane_ptr_array(planes):
 
 class _HexPlaneFeatures(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, plan, times, *planes):
+    def forward(ctx, plan, times, in_place, *planes):
         L = _lib.lib()
         dev = times.device
         B = int(times.shape[0])
@@ -117,6 +118,8 @@ class _HexPlaneFeatures(torch.autograd.Function):
                                                _p(plan.nodes), _p(t), _p(feat), _p(samples),
                                                torch.cuda.current_stream(dev).cuda_stream), "dm4d_hexplane_forward")
         ctx.plan, ctx.t, ctx.planes, ctx.samples, ctx.cl = plan, t, pl, samples, cl
+        # grads_in_place: the Parameters themselves (leaves, not outputs: no reference cycle), see backward()
+        ctx.params = list(planes) if in_place and all(p.is_leaf for p in planes) else None
         return feat
 
     @staticmethod
@@ -126,21 +129,44 @@ class _HexPlaneFeatures(torch.autograd.Function):
         dev = t.device
         B = int(t.shape[0])
         g = g_feat.detach().to(torch.float32).contiguous()
-        # dense, in the planes' own memory format; the C call zero-fills them (one launch) before the gathers
-        grads = [torch.empty_like(p, memory_format=torch.preserve_format) for p in pl]
+        # In-place mode (a training loop that drops its gradients with zero_grad(set_to_none=True) every step): the dense
+        # gradient planes are PERSISTENT buffers of the plan, installed as `.grad` of the plane Parameters right here.
+        # The nodes are static, so the spatial planes receive gradient at the same texels every step and each of those is
+        # overwritten by the gather: the 134 MB zero fill of the spatial planes disappears (the C call clears only the small
+        # time planes, DM4D_HEX_KEEP_SPATIAL).  Handing the buffers to autograd instead would make AccumulateGrad CLONE them
+        # (it only steals a gradient nobody else references).  Falls back to the plain path whenever a `.grad` is already
+        # present (gradient accumulation over several backwards).
+        in_place = ctx.params is not None and all(p.grad is None for p in ctx.params)
+        flags = ctx.cl
+        if in_place:
+            if plan.grad_buffers is None or any(b.shape != p.shape or b.stride() != p.stride() or b.device != p.device
+                                                for b, p in zip(plan.grad_buffers, pl)):
+                plan.grad_buffers = [torch.zeros_like(p, memory_format=torch.preserve_format) for p in pl]
+            grads = plan.grad_buffers
+            flags |= 2        # DM4D_HEX_KEEP_SPATIAL
+        else:
+            # dense, in the planes' own memory format; the C call zero-fills them (one launch) before the gathers
+            grads = [torch.empty_like(p, memory_format=torch.preserve_format) for p in pl]
         gptr = _plane_ptr_array(grads)
         scratch, ctx.samples = ctx.samples, None      # the forward's plane samples; the backward works in place
         sp, tp = plan.sp, plan.tp
         with torch.cuda.device(dev):
             _lib.check(L.dm4d_hexplane_backward(
-                plan.S, plan.M, B, plan.res_c, _plane_ptr_array(pl), ctx.cl, plan.aabb_c, _p(plan.nodes), _p(t), _p(g),
+                plan.S, plan.M, B, plan.res_c, _plane_ptr_array(pl), flags, plan.aabb_c, _p(plan.nodes), _p(t), _p(g),
                 plan.n_sp, _p(sp["scale"]), _p(sp["plane"]), _p(sp["texel"]), _p(sp["off"]), _p(sp["item"]),
                 plan.n_tp, _p(tp["scale"]), _p(tp["plane"]), _p(tp["col"]), _p(tp["off"]), _p(tp["item"]),
                 _p(scratch), gptr, torch.cuda.current_stream(dev).cuda_stream), "dm4d_hexplane_backward")
-        return (None, None) + tuple(grads)
+        if in_place:
+            for p, gbuf in zip(ctx.params, grads):
+                p.grad = gbuf
+            return (None, None, None) + (None,) * len(grads)
+        return (None, None, None) + tuple(grads)
 
 
-def hexplane_features(field, plan: HexPlan, times_pm1):
-    """field: HexPlaneField; times_pm1 [B] already in [-1, 1] -> features [B, M, 32 * n_scales]."""
+def hexplane_features(field, plan: HexPlan, times_pm1, grads_in_place=False):
+    """field: HexPlaneField; times_pm1 [B] already in [-1, 1] -> features [B, M, 32 * n_scales].
+
+    grads_in_place: the backward installs persistent gradient buffers as `.grad` of the planes instead of returning
+    fresh tensors (see _HexPlaneFeatures.backward); for loops that call zero_grad(set_to_none=True) every step."""
     planes = [p for grid in field.grids for p in grid]
-    return _HexPlaneFeatures.apply(plan, times_pm1, *planes)
+    return _HexPlaneFeatures.apply(plan, times_pm1, bool(grads_in_place), *planes)

@@ -11,6 +11,10 @@ The reference binds its YAML configs to classes registered under these names
     stable-zero123-guidance             threestudio/models/guidance/stable_zero123_guidance.py:75
     solid-color-background              threestudio/models/background/solid_color_background.py:14
     no-material                         threestudio/models/materials/no_material.py:16
+    sugar-4dgen-system                  C/system/sugar_4dgen.py:28          (thin cfg adapter over DynamicStage, not Lightning)
+    sugar-static-system                 C/system/sugar_static.py            (thin cfg adapter over StaticStage)
+    temporal-image-datamodule           C/data/temporal_image.py:483        (frames handed over as arrays)
+    single-image-datamodule             threestudio/data/image.py
 
 ``PLUGINS`` maps every name to its cfg-constructed class (dreammesh4d_amd/threestudio_host.py: the ``Config``
 dataclasses of the reference, ``configure``, ``update_step``); ``threestudio_host.find(name)`` is the registry without

@@ -34,8 +34,10 @@ def tv_loss(x):
 
 class StaticStage:
     def __init__(self, geometry, renderer, ref_image, ref_mask, H, W, guidance=None, random_views=4, normal_consistency=None,
-                 laplacian_smoothing=None, seed=0):
+                 laplacian_smoothing=None, seed=0, lambdas=None):
         self.g, self.r = geometry, renderer
+        self.lam = dict(LAMBDA)            # `system.loss` of the configuration (from_cfg); defaults: sugar_static_refine.yaml
+        self.lam.update(lambdas or {})
         self.ref_image, self.ref_mask = ref_image, ref_mask            # [1,H,W,3], [1,H,W,1]
         self.H, self.W = H, W
         self.guidance = guidance
@@ -62,7 +64,7 @@ class StaticStage:
         m = self.ref_mask.float()
         terms["rgb"] = F.mse_loss(self.ref_image * m, out["comp_rgb"] * m)
         terms["mask"] = F.mse_loss(m, out["comp_mask"])
-        loss = LAMBDA["rgb"] * terms["rgb"] + LAMBDA["mask"] * terms["mask"]
+        loss = C(self.lam["rgb"], 0, it) * terms["rgb"] + C(self.lam["mask"], 0, it) * terms["mask"]
         # ---- random substep
         u = torch.rand(self.rv, 2, generator=self.gen)
         elev, azim = -10.0 + 90.0 * u[:, 0], -180.0 + 360.0 * u[:, 1]
@@ -72,18 +74,33 @@ class StaticStage:
             self.guidance.update_step(0, it)
             go = self.guidance(out["comp_rgb"], elev.to(self.dev), azim.to(self.dev), torch.full((self.rv,), 3.8, device=self.dev))
             terms["sds"] = go["loss_sds"]
-            loss = loss + LAMBDA["sds"] * terms["sds"]
+            loss = loss + C(self.lam["sds"], 0, it) * terms["sds"]
         if self.nc is not None:
             terms["normal_consistency"] = self.nc(g.get_xyz_verts)
-            loss = loss + LAMBDA["normal_consistency"] * terms["normal_consistency"]
+            loss = loss + C(self.lam["normal_consistency"], 0, it) * terms["normal_consistency"]
         if self.lap is not None:
             terms["laplacian_smoothing"] = self.lap(g.get_xyz_verts)
-            loss = loss + LAMBDA["laplacian_smoothing"] * terms["laplacian_smoothing"]
+            loss = loss + C(self.lam["laplacian_smoothing"], 0, it) * terms["laplacian_smoothing"]
         for k, key in (("rgb_tv", "comp_rgb"), ("depth_tv", "comp_depth"), ("normal_tv", "comp_normal")):
             terms[k] = tv_loss(out[key].permute(0, 3, 1, 2))
-            loss = loss + LAMBDA[k] * terms[k]
+            loss = loss + C(self.lam[k], 0, it) * terms[k]
         loss.backward()
         self.reducer()
         self.opt.step()
         self.global_step += 1
         return {"loss": loss.detach(), **{k: v.detach() for k, v in terms.items()}}
+
+    @classmethod
+    def from_cfg(cls, system_cfg, geometry, renderer, ref_image, ref_mask, H, W, **kw):
+        """The stage as `system:` of configs/sugar_static_refine.yaml describes it: loss weights from `system.loss`
+        (lambda_*, C() schedules allowed); terms this loop does not compute must have weight 0 (or start after the run:
+        the stage-"gaussian" SuGaR regularisers begin at freq.start_sugar_reg = 3000 of a 2000-step schedule)."""
+        loss = dict(system_cfg.get("loss", {}))
+        lam = {k[len("lambda_"):]: v for k, v in loss.items() if k.startswith("lambda_")}
+        later = ("opacity_max", "opacity_binary", "sugar_density_reg", "sugar_sdf_normal_reg")          # SuGaR terms gated by freq.start_sugar_reg
+        unknown = {k for k, v in lam.items() if k not in LAMBDA and k not in later and v not in (0, 0.0, None)}
+        if unknown:
+            raise NotImplementedError(f"loss terms with a non-zero weight that this loop does not compute: {sorted(unknown)}")
+        args = dict(lambdas={k: v for k, v in lam.items() if k in LAMBDA})
+        args.update(kw)
+        return cls(geometry, renderer, ref_image, ref_mask, H, W, **args)

@@ -114,9 +114,24 @@ class DynamicSuGaR(nn.Module):
         return self.n_faces * self.cfg_n_gaussians_per_surface_triangle
 
     # ------------------------------------------------------------------ static SuGaR properties (sugar.py)
+    def set_static_learnable(self, flag=True):
+        """`static_learnable: true` (dynamic_sugar.py:47,79-87): the static appearance tensors keep requires_grad, the
+        rasterizer then runs its FULL backward (dL/dopacity, dL/d rgb, dL/dscales reduced and recorded as well).  As in the
+        reference they are NOT added to the optimiser (training_setup_dynamic, :167-235): they only receive `.grad`."""
+        self.static_learnable = bool(flag)
+        for p in (self._scales, self.all_densities, self._sh_coordinates_dc):
+            p.requires_grad_(self.static_learnable)
+        self.invalidate_static()
+
     def _static(self):
+        G = self.cfg_n_gaussians_per_surface_triangle
+        if getattr(self, "static_learnable", False):       # differentiable, recomputed (three small elementwise ops)
+            with torch.no_grad():
+                q = geo.quaternions(self._points, self._surface_mesh_faces, self._quaternions, G)
+                xyz = geo.points(self._points, self._surface_mesh_faces, geo.bary_coords(G, self.device))
+            return dict(q=q, xyz=xyz, scaling=geo.scaling(self._scales, float(self.surface_mesh_thickness)),
+                        opacity=geo.strengths(self.all_densities), rgb=geo.points_rgb(self._sh_coordinates_dc))
         if self._static_cache is None:
-            G = self.cfg_n_gaussians_per_surface_triangle
             with torch.no_grad():
                 self._static_cache = dict(
                     q=geo.quaternions(self._points, self._surface_mesh_faces, self._quaternions, G),

@@ -436,7 +436,12 @@ class DynamicSuGaRModel(_sugar.DynamicSuGaR, Updateable):
                          init_gs_scales_s=c.init_gs_scales_s, learn_opacities=c.learn_surface_mesh_opacity, device=dev)
         self.num_frames, self.dynamic_mode = c.num_frames, c.dynamic_mode
         if c.static_learnable:
-            raise NotImplementedError("static_learnable: true (the dynamic stage freezes the static SuGaR state, dynamic_sugar.py:79-87)")
+            # dynamic_sugar.py:79-87: the static SuGaR tensors keep requires_grad (they receive gradients -- the FULL blend
+            # backward, dL/dopacity / dL/d rgb / dL/dscales reduced and recorded too -- but training_setup_dynamic puts only
+            # the deformation network into the optimiser, :167-235).  Gradients reach the appearance tensors (_scales,
+            # all_densities, _sh_coordinates_dc); dL/d(static vertices) and dL/d(static in-plane rotation) THROUGH the
+            # skinning are not produced by the HIP skinning kernels (they take the static mesh as a constant).
+            self.set_static_learnable(True)
         if c.weights is not None:
             from .wire_formats import load_geometry
 
@@ -635,3 +640,154 @@ def parse_optimizer(config, model):
     if name in ("FusedAdam", "Adan"):
         raise NotImplementedError(f"optimizer {name} is an external package the shipped configurations do not use")
     return getattr(torch.optim, name)(groups, **dict(config.get("args", {})))
+
+
+# ------------------------------------------------------------------------------------------------ datamodules, systems
+# Thin configuration adapters, NOT Lightning: what `launch.py` does with `data_type` / `system_type` -- find(type)(cfg) -- gives
+# an object that holds the parsed block and drives `DynamicStage` / `StaticStage` (the training_step bodies of
+# C/system/sugar_4dgen.py:397-429 and C/system/sugar_static.py:110-340).  Image files are outside the path: the frames are
+# handed over as arrays (the reference reads `<video_frames_dir>/*.png` with cv2, C/data/temporal_image.py:166-214).
+@dataclass
+class _TemporalDataConfig:                            # TemporalRandomImageDataModuleConfig (C/data/temporal_image.py:33-70): the keys the path reads
+    height: Any = 512
+    width: Any = 512
+    default_elevation_deg: float = 5.0
+    default_azimuth_deg: float = 0.0
+    default_camera_distance: float = 3.8
+    default_fovy_deg: float = 20.0
+    video_length: int = 32
+    num_frames: int = 4                               # frames sampled per iteration (yaml:11)
+    norm_timestamp: bool = True
+    video_frames_dir: Optional[str] = None
+    random_camera: Any = None                         # {batch_size, elevation_range, azimuth_range, ...} (yaml:21-48)
+    batch_size: int = 1
+    requires_depth: bool = False
+    requires_normal: bool = False
+    use_random_camera: bool = True
+    rays_d_normalize: bool = False
+
+
+@register("temporal-image-datamodule")
+class TemporalImageDataModule:
+    Config = _TemporalDataConfig
+
+    def __init__(self, cfg=None, frames=None, masks=None):
+        """frames [L,H,W,3] in [0,1], masks [L,H,W,1] (float or bool): the video of `video_frames_dir`, already decoded."""
+        self.cfg = c = parse_structured(self.Config, {k: v for k, v in dict(cfg or {}).items() if k in {f.name for f in dataclasses.fields(self.Config)}})
+        self.height, self.width = _scalar0(c.height), _scalar0(c.width)
+        L = int(c.video_length)
+        self.frames, self.masks = frames, masks
+        if frames is not None and int(frames.shape[0]) != L:
+            raise ValueError(f"video_length {L} but {int(frames.shape[0])} frames")
+        # timestamps exclude 0 and 1 (C/data/temporal_image.py:155-158)
+        self.timestamps = torch.linspace(0, 1, L + 2)[1:-1] if c.norm_timestamp else torch.arange(L, dtype=torch.float32)
+        rc = dict(c.random_camera or {})
+        self.random_views_per_frame = int(rc.get("batch_size", 1))
+
+    def ref_camera(self):
+        from . import synthetic as syn
+
+        c = self.cfg
+        return syn.make_camera(int(self.height), int(self.width), elev_deg=c.default_elevation_deg, azim_deg=c.default_azimuth_deg,
+                               dist=c.default_camera_distance, fovy_deg=c.default_fovy_deg)
+
+
+@register("single-image-datamodule")
+class SingleImageDataModule(TemporalImageDataModule):
+    """C/../threestudio/data/image.py: one reference image = a video of length 1."""
+
+    def __init__(self, cfg=None, image=None, mask=None):
+        cfg = dict(cfg or {})
+        cfg["video_length"] = 1
+        super().__init__(cfg, None if image is None else image.reshape(1, *image.shape[-3:]),
+                         None if mask is None else mask.reshape(1, *mask.shape[-3:]))
+
+
+class _SystemBase:
+    """BaseLift3DSystem.configure (threestudio/systems/base.py:262-282): the plugins of a `system:` block by name."""
+
+    def _plugins(self, cfg, guidance_key, model):
+        self.cfg = cfg
+        self.geometry = find(cfg["geometry_type"])(cfg["geometry"])
+        self.material = find(cfg["material_type"])(cfg.get("material"))
+        self.background = find(cfg["background_type"])(cfg.get("background"))
+        self.renderer = find(cfg["renderer_type"])(cfg.get("renderer"), geometry=self.geometry, material=self.material,
+                                                   background=self.background)
+        gcfg = cfg.get(guidance_key)
+        self.guidance = find(cfg[guidance_key + "_type"])(gcfg, model=model) if gcfg is not None and model is not None else None
+
+    def do_update_step(self, epoch, global_step):
+        for m in (self.geometry, self.renderer, self.guidance):
+            if m is not None and hasattr(m, "do_update_step"):
+                m.do_update_step(epoch, global_step)
+
+
+@register("sugar-4dgen-system")
+class SuGaR4DGen(_SystemBase):
+    """C/system/sugar_4dgen.py:28 -- `system_type: sugar-4dgen-system`.  __init__(cfg, data, model): `cfg` the resolved
+    `system:` block, `data` a TemporalImageDataModule holding the frames, `model` the Zero123 network (the checkpoint of
+    `guidance_zero123.pretrained_model_name_or_path` is not in the tree; None = no SDS term).  training_step() is one
+    iteration of `DynamicStage`, with `system.loss`, `system.freq`, `num_inter_frames`, `length_inter_frames` and the
+    geometry's learning rates taken from the block."""
+
+    def __init__(self, cfg, data, model=None, **stage_kw):
+        from . import mesh_reg, views
+        from .dynamic_stage import DynamicStage
+
+        self._plugins(cfg, "guidance_zero123", model)
+        g = self.geometry
+        dev = g.device
+        H, W = int(data.height), int(data.width)
+        cam = data.ref_camera()
+        self.view_renderer = views.ViewRenderer(g.graph, g.topo, H, W, cam.tanfov, method=g.skinning_method)
+        static = {"q_static": g.static_quaternions, "scales": g.get_scaling, "opacities": g.get_opacity, "rgb": g.get_points_rgb()}
+        loss = dict(cfg.get("loss", {}))
+        faces = g.get_faces.detach().cpu().numpy()
+        verts = g.get_xyz_verts.detach().cpu().numpy()
+        nc = mesh_reg.MeshNormalConsistency(faces, g.n_verts, dev) if _nonzero(loss.get("lambda_normal_consistency")) else None
+        arap = mesh_reg.ARAPCoach(verts, faces, dev) if _nonzero(loss.get("lambda_arap_reg_key_frame")) or \
+            _nonzero(loss.get("lambda_arap_reg_inter_frame")) else None
+        self.stage = DynamicStage.from_cfg(cfg, self.view_renderer, g._deformation, g._deform_graph_node_xyz, static,
+                                           data.timestamps.to(dev), data.frames.to(dev), data.masks.to(dev).float(), cam,
+                                           guidance=self.guidance, frames_per_step=int(data.cfg.num_frames),
+                                           random_views_per_frame=data.random_views_per_frame, normal_consistency=nc, arap=arap,
+                                           **stage_kw)
+
+    def training_step(self):
+        self.do_update_step(0, self.stage.global_step)
+        return self.stage.iteration()
+
+
+@register("sugar-static-system")
+class SuGaRStatic(_SystemBase):
+    """C/system/sugar_static.py -- `system_type: sugar-static-system` (stage "sugar"): one StaticStage iteration per
+    training_step, loss weights from `system.loss`."""
+
+    def __init__(self, cfg, data, model=None, **stage_kw):
+        from . import mesh_reg
+        from .static_stage import StaticStage
+
+        self._plugins(cfg, "guidance", model)
+        g = self.geometry
+        dev = g.device
+        H, W = int(data.height), int(data.width)
+        loss = dict(cfg.get("loss", {}))
+        faces = g.get_faces.detach().cpu().numpy()
+        nc = mesh_reg.MeshNormalConsistency(faces, g.n_verts, dev) if _nonzero(loss.get("lambda_normal_consistency")) else None
+        lap = mesh_reg.MeshLaplacianSmoothing(faces, g.n_verts, dev) if _nonzero(loss.get("lambda_laplacian_smoothing")) else None
+        rc = dict(getattr(data.cfg, "random_camera", None) or {})
+        self.stage = StaticStage.from_cfg(cfg, g, self.renderer, data.frames.to(dev), data.masks.to(dev).float(), H, W,
+                                          guidance=self.guidance, random_views=int(rc.get("batch_size", 4)),
+                                          normal_consistency=nc, laplacian_smoothing=lap, **stage_kw)
+
+    def training_step(self):
+        self.do_update_step(0, self.stage.global_step)
+        return self.stage.iteration()
+
+
+def _nonzero(v):
+    if v is None:
+        return False
+    if isinstance(v, (list, tuple)):
+        return any(float(x) != 0.0 for x in v[1:3])
+    return float(v) != 0.0

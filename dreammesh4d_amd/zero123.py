@@ -525,6 +525,16 @@ class TemporalStableZero123Guidance(nn.Module):
 
     def forward(self, rgb, elevation, azimuth, camera_distances, frame_indices=None, rgb_as_latents=False,
                 noise=None, t=None, **kwargs):
+        # on a HIP device every GroupNorm / residual add / GEGLU of the step is expected on its HIP operator: a layout
+        # regression upstream (NCHW activations ...) is reported instead of silently costing the fused kernels
+        from .fused_norm import expect_fused
+
+        if not (rgb.is_cuda and self.model.model.diffusion_model.channels_last):      # CPU golden tests / the NCHW library path
+            return self._forward(rgb, elevation, azimuth, camera_distances, frame_indices, rgb_as_latents, noise, t)
+        with expect_fused():
+            return self._forward(rgb, elevation, azimuth, camera_distances, frame_indices, rgb_as_latents, noise, t)
+
+    def _forward(self, rgb, elevation, azimuth, camera_distances, frame_indices=None, rgb_as_latents=False, noise=None, t=None):
         B = rgb.shape[0]
         x = rgb.permute(0, 3, 1, 2)
         if rgb_as_latents:

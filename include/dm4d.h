@@ -298,6 +298,12 @@ int dm4d_hexplane_forward(int32_t S, int32_t M, int32_t B, const int32_t *res, c
 int dm4d_hexplane_axis_index(int32_t S, int32_t M, const int32_t *res, const float *aabb_host, const float *nodes,
                              int32_t *i0, dm4d_stream_t stream);
 size_t dm4d_hexplane_scratch_bytes(int32_t S, int32_t M, int32_t B);
+/* `channel_last` of dm4d_hexplane_forward / _backward is a flag word: */
+#define DM4D_HEX_CHANNELS_LAST 1   /* planes (and gradient planes) are stored [H][W][32] */
+#define DM4D_HEX_KEEP_SPATIAL  2   /* backward only: the SPATIAL gradient planes (xy, xz, yz) are persistent buffers of the caller
+                                    * that already hold zeros outside the texels of this plan (e.g. zero-initialised once, then only
+                                    * ever written by this call with the same plan): their zero fill is skipped -- 134 of the 143 MB
+                                    * a step would otherwise clear.  The time planes are cleared as usual. */
 /* Gradients w.r.t. the planes, written (not accumulated) into the dense planes `g_planes` = HOST array of
  * S*6 device pointers (16-byte aligned, uninitialised: the call zero-fills them in one launch and hands the
  * pointers to its kernels by value).  Atomic-free and deterministic: spatial planes

@@ -1,7 +1,8 @@
 """Worker of tests/test_dynamic_stage_gpu.py::test_two_rank_rehearsal_*: launched by torch.distributed.run with 2 ranks that SHARE
 cuda:0 and exchange over gloo (a functional rehearsal of the N > 1 control flow on a 1-GPU box; never a performance number).
 Runs 2 dynamic-stage iterations (frames sharded by rank, one gradient exchange, AdamW) and checks that the replicas hold
-bit-identical parameters afterwards; argv[1] = "replicated" | "sharded"."""
+bit-identical parameters afterwards; argv[1] = "replicated" | "sharded" | "compare" (3 iterations through BOTH optimisers: the
+sharded one must reproduce the replicated parameters)."""
 import os
 import sys
 
@@ -31,25 +32,54 @@ def main():
     static = {"q_static": geo.quaternions(verts, faces, T(sc["complex"]), 6), "scales": geo.scaling(T(sc["log_scales"]), syn.THICKNESS),
               "opacities": geo.strengths(T(sc["densities"])), "rgb": geo.points_rgb(T(sc["sh_dc"]))}
     cam = syn.make_camera(H, W, elev_deg=5.0, azim_deg=0.0)
-    r = views.ViewRenderer(graph, topo, H, W, cam.tanfov, method="hybrid")
-    torch.manual_seed(0)                                   # identical initial replicas (DDP would broadcast rank 0's)
-    net = DeformationNetwork(resolution=(16, 16, 16, 9), multires=(1, 2), no_ds=False, no_dr=False, no_do=False).to(dev)
-    with torch.no_grad():
-        for name, p in net.named_parameters():
-            if "_deform" in name:
-                p.add_(0.01 * torch.randn_like(p))
     g = torch.Generator().manual_seed(1)
     ref_img = torch.rand(L, H, W, 3, generator=g).to(dev)
     ref_mask = (torch.rand(L, H, W, 1, generator=g) > 0.5).float().to(dev)
-    stage = DynamicStage(r, net, T(sc["nodes"]), static, torch.linspace(0, 1, L + 2, device=dev)[1:-1], ref_img, ref_mask, cam, guidance=None,
-                         frames_per_step=4, random_views_per_frame=1, sharded_optimizer=(mode == "sharded"))
-    frames = []
-    for _ in range(2):
-        out = stage.iteration()
-        frames.append(D.shard_frames(L, rank, world, 4, stage.global_step - 1))
-        assert torch.isfinite(out["loss"])
-    assert stage._sparse_reducer and stage.reducer.nbytes < 4 * stage.reducer.dense_elements       # the structured-sparse message
-    flat = torch.cat([p.detach().reshape(-1) for p in net.parameters()]).cpu()
+
+    def build(sharded):
+        torch.manual_seed(0)                               # identical initial replicas (DDP would broadcast rank 0's)
+        net = DeformationNetwork(resolution=(16, 16, 16, 9), multires=(1, 2), no_ds=False, no_dr=False, no_do=False).to(dev)
+        with torch.no_grad():
+            for name, p in net.named_parameters():
+                if "_deform" in name:
+                    p.add_(0.01 * torch.randn_like(p))
+        r = views.ViewRenderer(graph, topo, H, W, cam.tanfov, method="hybrid")
+        return DynamicStage(r, net, T(sc["nodes"]), static, torch.linspace(0, 1, L + 2, device=dev)[1:-1], ref_img, ref_mask, cam,
+                            guidance=None, frames_per_step=4, random_views_per_frame=1, sharded_optimizer=sharded), net
+
+    def run(stage, n):
+        frames = []
+        for _ in range(n):
+            out = stage.iteration()
+            frames.append(D.shard_frames(L, rank, world, 4, stage.global_step - 1))
+            assert torch.isfinite(out["loss"])
+        return frames
+
+    def flat_params(stage, net):
+        stage.state_for_checkpoint()                       # (the sharded optimiser's deferred decay of the untouched texels)
+        return torch.cat([p.detach().reshape(-1) for p in net.parameters()]).cpu()
+
+    if mode == "compare":
+        # sharded == replicated: the same 3 iterations (same seeds, same frames, same cameras) through both optimisers
+        (st_r, net_r), (st_s, net_s) = build(False), build(True)
+        assert st_s.sharded is not None and st_s.sharded.reducer is st_s.reducer            # created in the constructor, never rebuilt
+        run(st_r, 3)
+        run(st_s, 3)
+        a, b = flat_params(st_r, net_r), flat_params(st_s, net_s)
+        err = float((a - b).abs().max() / a.abs().max())
+        assert err < 2e-6, f"sharded optimiser diverged from the replicated one: {err}"
+        both = [torch.empty_like(b) for _ in range(world)]
+        dist.all_gather(both, b)
+        if rank == 0:
+            assert torch.equal(both[0], both[1])
+            print(f"DP_REHEARSAL_OK mode=compare max_rel_diff={err:.2e} moment_elems_per_rank={st_s.sharded.exp_avg.numel()} "
+                  f"message_elems={st_s.reducer.flat.numel()}", flush=True)
+        dist.destroy_process_group()
+        return
+    stage, net = build(mode == "sharded")
+    frames = run(stage, 2)
+    assert stage.reducer.nbytes < 4 * stage.reducer.dense_elements       # the structured-sparse message, from the first step
+    flat = flat_params(stage, net)
     both = [torch.empty_like(flat) for _ in range(world)]
     dist.all_gather(both, flat)
     other_frames = [None] * world

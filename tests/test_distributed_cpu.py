@@ -112,16 +112,22 @@ def _worker_sharded(rank, world, port, out):
         red = D.GradAllReducer(params, touched={grid: idx})
         opt = torch.optim.AdamW(groups, lr=0.0, betas=(0.9, 0.99), eps=1e-15, foreach=False) if mode == "replicated" else \
             D.ShardedAdamW(groups, red, betas=(0.9, 0.99), eps=1e-15)
-        for it in range(3):
+        for it in range(4):
             opt.zero_grad(set_to_none=True)
             x = torch.full((2, 6), float(rank + 1 + it))
             loss = mlp(x).pow(2).sum() + (grid.view(-1)[idx] * float(rank + 2)).pow(2).sum()      # unused gets no gradient
             loss.backward()
             for g in (opt.param_groups):
                 g["lr"] = g["lr"] * 0.9                                 # a schedule, as update_learning_rate applies
+            overflow = it == 1                                          # a forward that overflowed its workspaces: the step is skipped
             if mode == "replicated":
                 red()
-            opt.step()
+                if not overflow:
+                    opt.step()
+            else:
+                opt.step(found_inf=torch.tensor(1.0 if overflow else 0.0))     # masked on the device; the collectives still run
+        if mode == "sharded":
+            opt.materialize()        # the deferred weight decay of the elements outside the message
         results[mode] = [p.detach().clone() for p in params]
         if mode == "sharded":
             results["state_elems"] = opt.exp_avg.numel()
@@ -132,8 +138,9 @@ def _worker_sharded(rank, world, port, out):
 
 def test_sharded_adamw_matches_the_replicated_step_world2():
     """reduce-scatter -> AdamW on 1/world of the message -> all-gather == all-reduce -> replicated torch AdamW: identical
-    parameters on both ranks after 3 steps with changing learning rates, incl. a parameter that never gets a gradient
-    and the untouched elements of a structured-sparse plane (weight decay only)."""
+    parameters on both ranks after 4 iterations with changing learning rates -- one of them skipped on an overflow flag
+    (found_inf: parameters, moments and the bias-correction step count must not move) --, incl. a parameter that never
+    gets a gradient and the untouched elements of a structured-sparse plane (weight decay only, applied lazily)."""
     world = 2
     mgr = mp.Manager()
     out = mgr.dict()

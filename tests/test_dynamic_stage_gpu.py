@@ -108,11 +108,13 @@ def _torchrun(args, env=None, timeout=600):
     return subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=e, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
-@pytest.mark.parametrize("mode", ["replicated", "sharded"])
+@pytest.mark.parametrize("mode", ["replicated", "sharded", "compare"])
 def test_two_rank_rehearsal_replicas_stay_identical(mode):
     """The N > 1 control flow end to end with 2 ranks sharing the one GPU of the box over gloo: frames sharded, the
     structured-sparse gradient exchange, AdamW (replicated after an all-reduce, or sharded: reduce-scatter -> AdamW on the
-    slice -> all-gather): bit-identical parameters on both ranks after 2 iterations."""
+    slice -> all-gather): bit-identical parameters on both ranks after 2 iterations.  compare: 3 iterations through both
+    optimisers from the same seeds -- the sharded one (created in the constructor, moments never reset, overflow flag
+    honoured, untouched texels decayed lazily) reproduces the replicated parameters to float32 rounding."""
     if not torch.cuda.is_available():
         pytest.skip("no HIP device")
     r = _torchrun(["tests/dp_rehearsal_worker.py", mode])

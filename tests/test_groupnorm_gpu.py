@@ -114,7 +114,9 @@ def test_guidance_step_nhwc_against_the_nchw_library_path():
     """The whole SDS step (UNet under no_grad + VAE encoder forward / backward) with channels-last activations and the HIP
     GroupNorm against the NCHW path through torch's GroupNorm: same loss and same gradient up to float16 rounding."""
     _need_gpu()
-    from dreammesh4d_amd import zero123 as z
+    import os
+
+    from dreammesh4d_amd import fused_norm, zero123 as z
 
     dev = torch.device("cuda:0")
     outs = []
@@ -138,6 +140,25 @@ def test_guidance_step_nhwc_against_the_nchw_library_path():
                    t=torch.tensor([300, 420], device=dev))
         out["loss_sds"].backward()
         outs.append((float(out["loss_sds"]), rgb.grad.clone()))
+        if cl:
+            # every GroupNorm / residual add / GEGLU of the NHWC step ran on its HIP operator; a layout regression is LOUD:
+            # an NCHW activation reaching group_norm inside the step is counted and (strict mode) raises
+            assert fused_norm.fallback_count() == before, fused_norm.FALLBACKS
+            os.environ["DM4D_STRICT_FUSED"] = "1"
+            try:
+                with pytest.raises(RuntimeError, match="fell back to torch operators"):
+                    with fused_norm.expect_fused():
+                        with torch.no_grad():
+                            fused_norm.group_norm(torch.nn.GroupNorm(32, 64).to(dev), torch.randn(2, 64, 8, 8, device=dev))
+            finally:
+                del os.environ["DM4D_STRICT_FUSED"]
+            assert fused_norm.fallback_count() == before + 1
+        else:
+            before = fused_norm.fallback_count()
+    with pytest.raises(ValueError):                                    # `add` of the wrong shape is rejected, not read out of bounds
+        with torch.no_grad():
+            fused_norm.group_norm(torch.nn.GroupNorm(32, 64).to(dev), torch.randn(2, 64, 8, 8, device=dev).contiguous(memory_format=torch.channels_last),
+                                  add=torch.zeros(3, 64, device=dev))
     (l0, g0), (l1, g1) = outs
     assert abs(l0 - l1) <= 2e-2 * abs(l0), (l0, l1)
     assert float((g0 - g1).abs().max()) <= 0.05 * float(g0.abs().max()) and float((g0 - g1).norm()) <= 0.02 * float(g0.norm())

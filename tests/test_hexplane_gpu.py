@@ -112,3 +112,49 @@ def test_gradient_message_pack_unpack_matches_torch_path():
     for p, gr in zip(params[:3], grads[:3]):
         assert torch.equal(p.grad, gr)
     assert params[3].grad is not None and not params[3].grad.any()
+
+
+def test_in_place_gradient_buffers_equal_fresh_gradients_over_steps():
+    """`grads_in_place`: persistent dense gradient planes installed as `.grad` (no 134 MB zero fill per step:
+    DM4D_HEX_KEEP_SPATIAL).  Over steps whose timestamps MOVE (other time rows are touched every step) the gradients must
+    be bit-identical to the plain path's, the buffers must be the same storage every step, and a backward that finds a
+    `.grad` in place (accumulation) must fall back to the plain path and accumulate."""
+    _need_gpu()
+    from dreammesh4d_amd.deformation import DeformationNetwork
+
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(3)
+    nets = []
+    for in_place in (False, True):
+        torch.manual_seed(0)
+        net = DeformationNetwork(resolution=(16, 16, 16, 9), multires=(1, 2, 4), no_ds=False, no_dr=False, no_do=False).to(dev)
+        with torch.no_grad():
+            gg = torch.Generator().manual_seed(1)
+            for name, p in net.named_parameters():
+                if "_deform" in name:
+                    p.add_((0.05 * torch.randn(p.shape, generator=gg)).to(dev))
+        net.grads_in_place = in_place
+        nets.append(net)
+    M, B = 300, 3
+    nodes = (torch.rand(M, 3, generator=g) * 1.3 - 0.65).to(dev)
+    ptrs = None
+    for step in range(4):
+        ts = torch.rand(B, generator=g).to(dev)
+        w = None
+        grads = []
+        for net in nets:
+            if step != 3:
+                net.zero_grad(set_to_none=True)      # step 3: gradients of step 2 left in place -> accumulation
+            out = [x for x in net.node_outputs(nodes, ts) if x is not None]
+            if w is None:
+                w = [torch.randn(x.shape, generator=g).to(dev) for x in out]
+            sum((a * b).sum() for a, b in zip(out, w)).backward()
+            grads.append({n: p.grad for n, p in net.named_parameters() if p.grad is not None})
+        assert grads[0].keys() == grads[1].keys()
+        for n in grads[0]:
+            assert torch.equal(grads[0][n], grads[1][n]), (step, n)
+        planes = [p for grid in nets[1].deformation_net.grid.grids for p in grid]
+        now = [p.grad.data_ptr() for p in planes]
+        assert ptrs is None or now == ptrs, step           # the same persistent storage every step
+        ptrs = now
+        assert nets[1]._hex_plan.grad_buffers is not None and all(p.grad is b for p, b in zip(planes, nets[1]._hex_plan.grad_buffers))

@@ -252,3 +252,87 @@ def test_checkpoint_hand_off_static_stage_to_dynamic_stage_and_resume(tmp_path):
     assert float((c["comp_rgb"] - b["comp_rgb"]).abs().max()) > 1e-3           # the deformation moved the mesh
     for k in ("comp_rgb", "comp_mask", "comp_depth", "comp_normal"):
         assert torch.equal(c[k], d[k]), k
+
+
+def test_systems_and_datamodules_by_name_drive_an_iteration_from_the_config_block(tmp_path):
+    """`sugar-4dgen-system` / `sugar-static-system` / `temporal-image-datamodule` / `single-image-datamodule`
+    are registered names; constructed as find(type)(cfg, ...) they read `system.loss`, `system.freq`, `num_inter_frames`,
+    `length_inter_frames` and the geometry's learning rates from the block (C/system/sugar_4dgen.py:28-76,296-330) and one
+    training_step is one full iteration (render, losses, backward, optimiser)."""
+    if not torch.cuda.is_available():
+        pytest.skip("no HIP device")
+    import copy
+
+    from dreammesh4d_amd import threestudio_host as ts
+
+    dev = torch.device("cuda:0")
+    L = 8
+    mesh, model, emb = _stand_ins(tmp_path, L, dev)
+    data_cfg = dict(DATA, video_length=L, height=128, width=128, num_frames=4, random_camera={"batch_size": 1})
+    g = torch.Generator().manual_seed(0)
+    frames, masks = torch.rand(L, 128, 128, 3, generator=g), (torch.rand(L, 128, 128, 1, generator=g) > 0.5).float()
+    data = ts.find("temporal-image-datamodule")(data_cfg, frames=frames, masks=masks)
+    assert torch.allclose(data.timestamps, torch.linspace(0, 1, L + 2)[1:-1]) and data.random_views_per_frame == 1
+    cfg = copy.deepcopy(ts.resolve({"data": DATA, "system": DYNAMIC_SYSTEM})["system"])
+    cfg["geometry"].update(surface_mesh_to_bind_path=mesh, n_dg_nodes=120, num_frames=L)
+    cfg["guidance_zero123"].update(pretrained_model_name_or_path="(test)", cond_video_dir="(test)", cond_embeddings_path=emb, num_frames=L)
+    cfg["loss"].update(lambda_rgb=1234.0, lambda_mask=[0, 7.0, 70.0, 10])          # not the defaults: they must come from the block
+    cfg["freq"].update(milestone_arap_reg=1)
+    cfg["num_inter_frames"], cfg["length_inter_frames"] = 3, 0.2
+    system = ts.find("sugar-4dgen-system")(cfg, data, model=model)
+    st = system.stage
+    assert st.lam["rgb"] == 1234.0 and st.lam["mask"] == [0, 7.0, 70.0, 10] and st.lam["sds_zero123"] == 0.1
+    assert st.milestone_arap_reg == 1 and st.num_inter_frames == 3 and st.length_inter_frames == 0.2 and st.frames_per_step == 4
+    assert st.sched == {"deformation": 0.00032, "grid": 0.0032} and st.arap is not None and st.normal_consistency is not None
+    with torch.no_grad():
+        for n, p in system.geometry._deformation.named_parameters():
+            if "_deform" in n:
+                p.add_(0.01 * torch.randn_like(p))
+    before = [p.detach().clone() for p in system.geometry._deformation.get_mlp_parameters()]
+    t0 = system.training_step()
+    t1 = system.training_step()
+    assert {"rgb", "mask", "sds", "normal_consistency"} <= set(t0) and "arap_reg_key_frame" in t1
+    assert all(torch.isfinite(v).all() for v in t1.values() if torch.is_tensor(v)) and st.global_step == 2
+    assert any(not torch.equal(a, b) for a, b in zip(before, system.geometry._deformation.get_mlp_parameters()))
+    # a term the loop does not compute must not be silently dropped
+    bad = copy.deepcopy(cfg)
+    bad["loss"]["lambda_depth"] = 0.05
+    with pytest.raises(NotImplementedError):
+        ts.find("sugar-4dgen-system")(bad, data, model=None)
+    # ---- static stage by name
+    scfg = copy.deepcopy(ts.resolve({"data": DATA, "system": STATIC_SYSTEM})["system"])
+    scfg["geometry"]["surface_mesh_to_bind_path"] = mesh
+    scfg["guidance"].update(pretrained_model_name_or_path="(test)", cond_embeddings_path=emb)
+    scfg["loss"].update(lambda_rgb=77.0, lambda_opacity_binary=1.0)             # (a stage-"gaussian" term: gated by start_sugar_reg)
+    sdata = ts.find("single-image-datamodule")(dict(DATA, height=128, width=128, random_camera={"batch_size": 2}), image=frames[0], mask=masks[0])
+    s_model = _stand_ins(tmp_path, 1, dev)[1]
+    ssys = ts.find("sugar-static-system")(scfg, sdata, model=s_model)
+    assert ssys.stage.lam["rgb"] == 77.0 and ssys.stage.rv == 2
+    out = ssys.training_step()
+    assert torch.isfinite(out["loss"]) and ssys.stage.global_step == 1
+
+
+def test_static_learnable_dynamic_geometry_gets_appearance_gradients(tmp_path):
+    """`static_learnable: true` (dynamic_sugar.py:47,79-87): the static appearance tensors receive gradients through the
+    FULL blend backward and -- as in the reference's training_setup_dynamic -- stay out of the optimiser."""
+    if not torch.cuda.is_available():
+        pytest.skip("no HIP device")
+    import copy
+
+    from dreammesh4d_amd import threestudio_host as ts
+
+    dev = torch.device("cuda:0")
+    mesh, _, _ = _stand_ins(tmp_path, 1, dev)
+    cfg = copy.deepcopy(ts.resolve({"data": DATA, "system": DYNAMIC_SYSTEM})["system"])
+    cfg["geometry"].update(surface_mesh_to_bind_path=mesh, n_dg_nodes=100, static_learnable=True)
+    geometry = ts.find("dynamic-sugar")(cfg["geometry"])
+    assert all(p.requires_grad for p in (geometry._scales, geometry.all_densities, geometry._sh_coordinates_dc))
+    opt_params = {id(p) for g in geometry.optimizer.param_groups for p in g["params"]}
+    assert not any(id(p) in opt_params for p in (geometry._scales, geometry.all_densities, geometry._sh_coordinates_dc))
+    renderer = ts.find("diff-sugar-rasterizer-temporal")(cfg["renderer"], geometry=geometry, material=ts.find("no-material")(None),
+                                                         background=ts.find("solid-color-background")(None))
+    B, H, W = 2, 128, 128
+    out = renderer.batch_forward(_batch(B, H, W, dev, timestamps=torch.tensor([0.3, 0.6], device=dev)))
+    (out["comp_rgb"].mean() + out["comp_mask"].mean()).backward()
+    for p in (geometry._scales, geometry.all_densities, geometry._sh_coordinates_dc):
+        assert p.grad is not None and torch.isfinite(p.grad).all() and p.grad.abs().sum() > 0

@@ -72,7 +72,8 @@ def test_plugin_names_cover_the_reference_registry_entries_of_the_hot_path():
 
     assert set(plugins.PLUGINS) == {"diff-sugar-rasterizer-temporal", "diff-sugar-rasterizer-normal", "dynamic-sugar", "sugar",
                                     "temporal-stable-zero123-guidance", "stable-zero123-guidance", "solid-color-background",
-                                    "no-material"}
+                                    "no-material", "sugar-4dgen-system", "sugar-static-system", "temporal-image-datamodule",
+                                    "single-image-datamodule"}
     bgm = plugins.PLUGINS["solid-color-background"]({"color": (0.2, 0.4, 0.6)}).eval()
     out = bgm(torch.zeros(2, 3, 5, 3))
     assert out.shape == (2, 3, 5, 3) and torch.allclose(out[1, 2, 4], torch.tensor([0.2, 0.4, 0.6]))

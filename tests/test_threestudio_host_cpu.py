@@ -14,7 +14,8 @@ from dreammesh4d_amd import threestudio_host as host
 
 def test_registry_has_the_reference_names_and_find_composes():
     want = {"diff-sugar-rasterizer-temporal", "diff-sugar-rasterizer-normal", "dynamic-sugar", "sugar",
-            "temporal-stable-zero123-guidance", "stable-zero123-guidance", "solid-color-background", "no-material"}
+            "temporal-stable-zero123-guidance", "stable-zero123-guidance", "solid-color-background", "no-material",
+            "sugar-4dgen-system", "sugar-static-system", "temporal-image-datamodule", "single-image-datamodule"}
     assert set(host.__modules__) == want
     assert host.find("sugar") is host.SuGaRModel
     with pytest.raises(ValueError):
@@ -131,3 +132,41 @@ def test_prune_isolated_points_and_surface_sampling():
     pts = host.sample_points_uniformly(v, f, 500, seed=1)
     assert pts.shape == (500, 3) and np.abs(np.linalg.norm(pts, axis=1) - 0.5).max() < 0.04      # on the (200-face) sphere
     assert np.array_equal(pts, host.sample_points_uniformly(v, f, 500, seed=1))
+
+
+def test_stage_loss_weights_come_from_the_config_block():
+    """DynamicStage.from_cfg / StaticStage.from_cfg read `system.loss` (lambda_* -> the loop's terms; C() schedules kept as
+    lists), `system.freq`, `num_inter_frames`, `length_inter_frames`; a non-zero weight for a term the loop does not
+    compute is an error, not a silently dropped term (C/system/sugar_4dgen.py:296-330)."""
+    import torch
+
+    from dreammesh4d_amd.dynamic_stage import DynamicStage, LAMBDA
+    from dreammesh4d_amd.static_stage import StaticStage
+
+    class _Stop(Exception):
+        pass
+
+    seen = {}
+
+    def fake_init(self, *a, **kw):
+        seen.update(kw)
+        raise _Stop
+
+    real = DynamicStage.__init__
+    DynamicStage.__init__ = fake_init
+    try:
+        cfg = {"loss": {"lambda_rgb": 1.5, "lambda_mask": [0, 1.0, 2.0, 10], "lambda_depth": 0.0, "lambda_sds_zero123": 0.3},
+               "freq": {"milestone_arap_reg": 7, "inter_frame_reg": 2}, "num_inter_frames": 5, "length_inter_frames": 0.25,
+               "geometry": {"deformation_lr": 1e-3, "grid_lr": [0, 1e-2, 1e-3, 100]}}
+        with pytest.raises(_Stop):
+            DynamicStage.from_cfg(cfg, *[None] * 8)
+        assert seen["lambdas"] == {"rgb": 1.5, "mask": [0, 1.0, 2.0, 10], "sds_zero123": 0.3}
+        assert (seen["milestone_arap_reg"], seen["inter_frame_reg"], seen["num_inter_frames"], seen["length_inter_frames"]) == (7, 2, 5, 0.25)
+        assert seen["deformation_lr"] == 1e-3 and seen["grid_lr"] == [0, 1e-2, 1e-3, 100]
+        with pytest.raises(NotImplementedError):
+            DynamicStage.from_cfg({"loss": {"lambda_depth": 0.05}}, *[None] * 8)
+    finally:
+        DynamicStage.__init__ = real
+    assert set(LAMBDA) == {"sds_zero123", "rgb", "mask", "normal_consistency", "arap_reg_key_frame", "arap_reg_inter_frame"}
+    with pytest.raises(NotImplementedError):
+        StaticStage.from_cfg({"loss": {"lambda_normal_smooth": 1.0}}, None, None, None, None, 8, 8)
