@@ -148,7 +148,10 @@ class DynamicStage:
         st, it = self.static, self.global_step
         self.update_learning_rate(it)
         if self.guidance is not None:
-            self.guidance.update_step(0, it, min_step_percent=C(0.02, 0, it), max_step_percent=C(0.5, 0, it))
+            if hasattr(self.guidance, "cfg"):      # the cfg-constructed plugin schedules its own timestep range / grad clip
+                self.guidance.update_step(0, it)
+            else:                                   # yaml:115-116
+                self.guidance.update_step(0, it, min_step_percent=C(0.02, 0, it), max_step_percent=C(0.5, 0, it))
         b = self.sample_batch()
         frames_t = self.timestamps[b["frames_t_idx"]]
         self.opt.zero_grad(set_to_none=True)

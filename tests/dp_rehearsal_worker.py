@@ -67,7 +67,10 @@ def main():
         run(st_s, 3)
         a, b = flat_params(st_r, net_r), flat_params(st_s, net_s)
         err = float((a - b).abs().max() / a.abs().max())
-        assert err < 2e-6, f"sharded optimiser diverged from the replicated one: {err}"
+        # (the replicated side is torch's FUSED multi-tensor AdamW, whose operation order differs from the single-tensor
+        #  formula the sharded step follows; with eps = 1e-15 the update is ~lr * sign(g), so last-bit differences of the
+        #  moments show at 1e-6 of the parameter scale)
+        assert err < 2e-5, f"sharded optimiser diverged from the replicated one: {err}"
         both = [torch.empty_like(b) for _ in range(world)]
         dist.all_gather(both, b)
         if rank == 0:
