@@ -95,7 +95,8 @@ class Workload:
                 self.unit_frames.append(fr)
         self.vm = torch.stack([T(c.viewmatrix) for c in self.cams])
         self.pm = torch.stack([T(c.projmatrix) for c in self.cams])
-        self.fidx = torch.tensor([self.frames.index(f) for f in self.unit_frames], device=dev)   # unit -> row of this step's frames
+        # unit -> row of this step's frames (int32, what the C ABI takes: an int64 index tensor costs a conversion kernel per step)
+        self.fidx = torch.tensor([self.frames.index(f) for f in self.unit_frames], device=dev, dtype=torch.int32)
         self.frame_t = self.timestamps[torch.tensor(self.frames, device=dev)]
         self.bg6 = torch.ones(6, device=dev)
         # DM4D_TILE_RECORDS=1: the experimental (Gaussian, tile) backward records summed in LDS (round 3: correct, but slower

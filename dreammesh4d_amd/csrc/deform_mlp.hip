@@ -77,20 +77,16 @@ __device__ __forceinline__ float4 ld4(const float *p) { return *reinterpret_cast
 __device__ __forceinline__ float4 to4(const f32x4 v) { return make_float4(v.x, v.y, v.z, v.w); }
 
 // ------------------------------------------------------------------------------------------ forward
-__global__ __launch_bounds__(256) void k_mlp_fwd(MlpDesc d, const float *__restrict__ feat, float *__restrict__ Hs,
-                                                 float *__restrict__ Ys, float *out0, float *out1, float *out2,
-                                                 float *out3)
+// the workgroup's 16 rows x IN feature tile is in s_f ([feature quad][row], written by the caller; this function starts
+// with the barrier that publishes it); bx / nbx: the workgroup's index / count among the forward's workgroups
+__device__ __forceinline__ void mlp_fwd_block(const MlpDesc &d, const int bx, const int nbx, const float4 *s_f, float *__restrict__ Hs,
+                                              float *__restrict__ Ys, float *out0, float *out1, float *out2, float *out3)
 {
-    __shared__ float4 s_f[(kMaxIn / 4) * kXs];          // feat tile   [feature quad][row]
     __shared__ float4 s_x[(kW / 4) * kXs];              // relu(h)
     __shared__ float4 s_y[kMaxHeads][(kW / 4) * kXs];   // y_k
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, i = lane & 15, kq = lane >> 4;
-    const int row0 = blockIdx.x * kRT, IN = d.IN, nq = IN / 4;
+    const int row0 = bx * kRT, IN = d.IN;
     const int row = row0 + i;                            // this lane's data row (N index of every tile)
-    for (int e = tid; e < kRT * nq; e += 256) {
-        const int r = e / nq, q = e % nq;
-        s_f[q * kXs + r] = (row0 + r < d.P) ? ld4(feat + (size_t)(row0 + r) * IN + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
     const int fo = 16 * w + 4 * kq;                      // first of this lane's 4 output features
     const float4 b0 = ld4(d.b0 + fo);
     f32x4 acc0 = {b0.x, b0.y, b0.z, b0.w}, acc1 = {0.f, 0.f, 0.f, 0.f};
@@ -157,9 +153,9 @@ __global__ __launch_bounds__(256) void k_mlp_fwd(MlpDesc d, const float *__restr
     }
     // side job: this workgroup's slice of the [in][out] copies of W0 and W1_k the backward reads
     if (d.W0T) {
-        const int n_w = IN * kW + d.n_heads * kW * kW, per = (n_w + (int)gridDim.x - 1) / (int)gridDim.x;
-        const int e1 = min(n_w, ((int)blockIdx.x + 1) * per);
-        for (int e = (int)blockIdx.x * per + tid; e < e1; e += 256) {
+        const int n_w = IN * kW + d.n_heads * kW * kW, per = (n_w + nbx - 1) / nbx;
+        const int e1 = min(n_w, (bx + 1) * per);
+        for (int e = bx * per + tid; e < e1; e += 256) {
             if (e < IN * kW) {
                 d.W0T[e] = d.W0[(size_t)(e % kW) * IN + e / kW];
             } else {
@@ -168,6 +164,19 @@ __global__ __launch_bounds__(256) void k_mlp_fwd(MlpDesc d, const float *__restr
             }
         }
     }
+}
+
+__global__ __launch_bounds__(256) void k_mlp_fwd(MlpDesc d, const float *__restrict__ feat, float *__restrict__ Hs,
+                                                 float *__restrict__ Ys, float *out0, float *out1, float *out2,
+                                                 float *out3)
+{
+    __shared__ float4 s_f[(kMaxIn / 4) * kXs];          // feat tile   [feature quad][row]
+    const int tid = threadIdx.x, row0 = blockIdx.x * kRT, IN = d.IN, nq = IN / 4;
+    for (int e = tid; e < kRT * nq; e += 256) {
+        const int r = e / nq, q = e % nq;
+        s_f[q * kXs + r] = (row0 + r < d.P) ? ld4(feat + (size_t)(row0 + r) * IN + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    mlp_fwd_block(d, (int)blockIdx.x, (int)gridDim.x, s_f, Hs, Ys, out0, out1, out2, out3);
 }
 
 // ------------------------------------------------------------------------------------------ backward (activations)
@@ -244,16 +253,16 @@ __global__ __launch_bounds__(256) void k_mlp_bwd(MlpDesc d, const float *__restr
 // out[m][n] = sum_rows L[row][m] R[row][n] for one 16x16 tile of one parameter and one row slice.  Tiles, in
 // blockIdx.x order:  dW0 (L = dh, R = feat) 4 x (IN/16 + 1)  |  per head: dW1 (L = dy_k, R = relu(h)) 4 x 5,
 // dW2 (L = g_k, R = y_k) 1 x 5.  The last column tile of every group is the bias: R = 1.
-__global__ __launch_bounds__(256) void k_mlp_wgrad(MlpDesc d, const float *__restrict__ feat, const float *__restrict__ Hs,
-                                                   const float *__restrict__ Ys, const float *g0, const float *g1,
-                                                   const float *g2, const float *g3)
+__device__ __forceinline__ void mlp_wgrad_block(const MlpDesc &d, const int bx, const int by, const float *__restrict__ feat,
+                                                const float *__restrict__ Hs, const float *__restrict__ Ys, const float *g0,
+                                                const float *g1, const float *g2, const float *g3)
 {
     __shared__ float s_part[3][64][5];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, i = lane & 15, kq = lane >> 4;
     const float *gs[kMaxHeads] = {g0, g1, g2, g3};
     const int IN = d.IN, P = d.P;
     // ---- decode the tile ----
-    int t = blockIdx.x;
+    int t = bx;
     const float *L = nullptr, *R = nullptr;
     int ldL = kW, ldR = kW, Mdim = kW, Ndim = kW, mt = 0, nt = 0;
     bool relu = false;
@@ -283,7 +292,7 @@ __global__ __launch_bounds__(256) void k_mlp_wgrad(MlpDesc d, const float *__res
     const bool bias = nt * 16 >= Ndim;
     // ---- this workgroup's row slice, in steps of 4 rows (the K of one MFMA); wave w takes steps w, w + 4, ... ----
     const int steps = (P + 3) / 4, per = (steps + kKSplit - 1) / kKSplit;
-    const int s0 = blockIdx.y * per, s1 = min(steps, s0 + per);
+    const int s0 = by * per, s1 = min(steps, s0 + per);
     const int mcol = 16 * mt + i, ncol = 16 * nt + i;
     const bool mok = L != nullptr && mcol < Mdim;
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
@@ -307,7 +316,7 @@ __global__ __launch_bounds__(256) void k_mlp_wgrad(MlpDesc d, const float *__res
     }
     __syncthreads();
     if (w == 0) {
-        float *part = d.partial + (size_t)blockIdx.y * partial_floats(d);
+        float *part = d.partial + (size_t)by * partial_floats(d);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const float v = ((acc[j] + s_part[0][lane][j]) + s_part[1][lane][j]) + s_part[2][lane][j];
@@ -322,11 +331,18 @@ __global__ __launch_bounds__(256) void k_mlp_wgrad(MlpDesc d, const float *__res
     }
 }
 
+__global__ __launch_bounds__(256) void k_mlp_wgrad(MlpDesc d, const float *__restrict__ feat, const float *__restrict__ Hs,
+                                                   const float *__restrict__ Ys, const float *g0, const float *g1,
+                                                   const float *g2, const float *g3)
+{
+    mlp_wgrad_block(d, (int)blockIdx.x, (int)blockIdx.y, feat, Hs, Ys, g0, g1, g2, g3);
+}
+
 // sum of the row-slice partials in slice order
-__global__ void k_mlp_reduce(MlpDesc d, MlpGrads g, int n_part)
+__device__ __forceinline__ void mlp_reduce_block(const MlpDesc &d, const MlpGrads &g, int n_part, const unsigned bx)
 {
     const size_t n = partial_floats(d);
-    const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t e = (size_t)bx * 256 + threadIdx.x;
     if (e >= n) return;
     const float *__restrict__ partial = d.partial;
     float a = 0.f;
@@ -348,6 +364,8 @@ __global__ void k_mlp_reduce(MlpDesc d, MlpGrads g, int n_part)
         base += od;
     }
 }
+
+__global__ __launch_bounds__(256) void k_mlp_reduce(MlpDesc d, MlpGrads g, int n_part) { mlp_reduce_block(d, g, n_part, blockIdx.x); }
 
 // scratch: W0T | W1T x heads | DY | DH | partials   (floats; every block a multiple of 4 floats)
 static size_t scratch_floats(int P, int in_dim, int n_heads, size_t *dy_off, size_t *dh_off, size_t *part_off)

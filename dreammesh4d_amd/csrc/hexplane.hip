@@ -31,6 +31,7 @@ static const int c_axis0_host[6] = {0, 0, 0, 1, 1, 2}, c_axis1_host[6] = {1, 2, 
 struct HexDesc {
     int S, M, B;
     int cl;                                       // plane storage: 0 = [32][H][W], 1 = [H][W][32] (channels-last)
+    int t01;                                      // times are timestamps in [0, 1]; the kernels map them to 2 t - 1
     int res[kHexMaxScales][4];                    // resolution of axes x, y, z, t at scale s
     const float *plane[kHexMaxScales][kHexPlanes]; // [32][res[a1]][res[a0]]
     float lo[3], inv[3];                          // x_n = (p - lo) * inv - 1
@@ -86,22 +87,15 @@ __device__ __forceinline__ void node_coords(const HexDesc &d, const float *__res
 {
 #pragma unroll
     for (int a = 0; a < 3; ++a) xn[a] = (nodes[3 * (size_t)m + a] - d.lo[a]) * d.inv[a] - 1.0f;
-    xn[3] = times[f];
+    xn[3] = d.t01 ? times[f] * 2.0f - 1.0f : times[f];      // DM4D_HEX_TIMES_01: 2 t - 1 (dynamic_sugar.py:431), exactly as torch rounds it
 }
 
 // ---------------------------------------------------------------------------------------- forward
-// one thread per (frame, node, scale, channel); 32 consecutive lanes = the 32 channels of one query
-__global__ __launch_bounds__(256) void k_hex_fwd(HexDesc d, const float *__restrict__ nodes,
-                                                 const float *__restrict__ times, float *__restrict__ feat,
-                                                 float *__restrict__ samples /* [B][M][S][6][32] or nullptr */)
+// feature (frame f, node m, scale s, channel c): product of the six plane samples; the samples are kept for the backward
+__device__ __forceinline__ float hex_feature(const HexDesc &d, const float *__restrict__ nodes, const float *__restrict__ times,
+                                             const int f, const int m, const int s, const int c, float *__restrict__ feat,
+                                             float *__restrict__ samples)
 {
-    const size_t gid = (size_t)blockIdx.x * 256 + threadIdx.x;
-    const size_t total = (size_t)d.B * d.M * d.S * kHexCh;
-    if (gid >= total) return;
-    const int c = (int)(gid % kHexCh);
-    const int s = (int)((gid / kHexCh) % d.S);
-    const int m = (int)((gid / ((size_t)kHexCh * d.S)) % d.M);
-    const int f = (int)(gid / ((size_t)kHexCh * d.S * d.M));
     float xn[4];
     node_coords(d, nodes, times, f, m, xn);
     float acc = 1.f;
@@ -115,6 +109,21 @@ __global__ __launch_bounds__(256) void k_hex_fwd(HexDesc d, const float *__restr
         acc = acc * v;                           // sample 4 scattered 4-byte reads: not worth repeating)
     }
     feat[((size_t)f * d.M + m) * (d.S * kHexCh) + s * kHexCh + c] = acc;
+    return acc;
+}
+// one thread per (frame, node, scale, channel); 32 consecutive lanes = the 32 channels of one query
+__global__ __launch_bounds__(256) void k_hex_fwd(HexDesc d, const float *__restrict__ nodes,
+                                                 const float *__restrict__ times, float *__restrict__ feat,
+                                                 float *__restrict__ samples /* [B][M][S][6][32] or nullptr */)
+{
+    const size_t gid = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t total = (size_t)d.B * d.M * d.S * kHexCh;
+    if (gid >= total) return;
+    const int c = (int)(gid % kHexCh);
+    const int s = (int)((gid / kHexCh) % d.S);
+    const int m = (int)((gid / ((size_t)kHexCh * d.S)) % d.M);
+    const int f = (int)(gid / ((size_t)kHexCh * d.S * d.M));
+    hex_feature(d, nodes, times, f, m, s, c, feat, samples);
 }
 
 // ---------------------------------------------------------------------------------------- backward 1
@@ -208,7 +217,7 @@ __device__ __forceinline__ void hex_bwd_time(const HexDesc &d, const unsigned bi
         for (int f = 0; f < d.B; ++f) {
             int y0;
             float wy;
-            texel_coord(times[f], H, y0, wy);
+            texel_coord(d.t01 ? times[f] * 2.0f - 1.0f : times[f], H, y0, wy);
             const int yy[2] = {y0, min(y0 + 1, H - 1)};
             int slot[2];
             for (int k = 0; k < 2; ++k) {
@@ -367,6 +376,7 @@ int dm4d_hexplane_forward(int32_t S, int32_t M, int32_t B, const int32_t *res, c
     HexDesc d;
     int rc = fill_desc(d, S, M, B, res, planes, aabb_host, channel_last & DM4D_HEX_CHANNELS_LAST);
     if (rc) return rc;
+    d.t01 = (channel_last & DM4D_HEX_TIMES_01) ? 1 : 0;
     if (!planes || !nodes || !times || !feat) { set_error("hexplane: null tensor"); return DM4D_ERR_INVALID; }
     const size_t total = (size_t)B * M * S * kHexCh;
     hipLaunchKernelGGL(k_hex_fwd, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, d, nodes, times, feat,
@@ -388,6 +398,7 @@ int dm4d_hexplane_backward(int32_t S, int32_t M, int32_t B, const int32_t *res, 
     HexDesc d;
     int rc = fill_desc(d, S, M, B, res, planes, aabb_host, channel_last & DM4D_HEX_CHANNELS_LAST);
     if (rc) return rc;
+    d.t01 = (channel_last & DM4D_HEX_TIMES_01) ? 1 : 0;
     if (!planes || !nodes || !times || !g_feat || !scratch || !g_planes) { set_error("hexplane: null tensor"); return DM4D_ERR_INVALID; }
     hipStream_t st = (hipStream_t)stream;
     HexGrads hg;

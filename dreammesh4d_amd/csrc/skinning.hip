@@ -184,6 +184,7 @@ __device__ __forceinline__ NodeAttr node_attr(int m, const float *dx, const floa
 }
 
 constexpr int kSkinThreads = 256;
+struct ZeroList { char *base; size_t stride; int n; };     // n blocks of 64 words at base + i * stride to clear (k_face_fwd)
 enum { kLbs = 0, kDqs = 1, kHybrid = 2 };
 constexpr int kMaxK = 8;
 constexpr int kNodeRec = 14;   // dx3 dr4 ds6 do1
@@ -516,8 +517,12 @@ __global__ __launch_bounds__(kSkinThreads) void k_face_fwd(int F, int G, int V, 
                                                            const float *__restrict__ q_static /* [N,4] wxyz */,
                                                            float *__restrict__ means, float *__restrict__ rots,
                                                            float *__restrict__ normals, int nstride,
-                                                           const float *__restrict__ rgb, float *__restrict__ colors6)
+                                                           const float *__restrict__ rgb, float *__restrict__ colors6, ZeroList zl)
 {
+    // side job of the first workgroup (batched path): clear the rasterizer's per-view counters, which K1 -- the next launch --
+    // adds to; as a launch of its own this was 5.6 us of the step's serial chain
+    if (zl.n > 0 && blockIdx.x == 0 && blockIdx.y == 0)
+        for (int t = threadIdx.x; t < zl.n * 64; t += kSkinThreads) reinterpret_cast<uint32_t *>(zl.base + (size_t)(t >> 6) * zl.stride)[t & 63] = 0u;
     const int i = blockIdx.x * kSkinThreads + threadIdx.x;
     if (i >= F * G) return;
     {
@@ -767,13 +772,14 @@ int skin_backward_launch(int B, int method, int V, int M, int K, const float *ve
 
 int face_forward_launch(int B, int F, int G, int V, const int32_t *faces, const float *vxyz, const float *vrot,
                         const float *qs, float *means, float *rots, float *normals, int nstride, const float *rgb,
-                        float *colors6, hipStream_t st)
+                        float *colors6, hipStream_t st, char *zero_base, size_t zero_stride, int zero_n)
 {
-    if (F <= 0 || B <= 0) return DM4D_OK;
+    if (F <= 0 || B <= 0) return zero_n > 0 ? DM4D_ERR_INVALID : DM4D_OK;
     G &= 0xff;
     ProfScope prof_(kKFaceFwd, st);
+    const ZeroList zl = {zero_base, zero_stride, zero_base ? zero_n : 0};
     hipLaunchKernelGGL(k_face_fwd, dim3((F * G + kSkinThreads - 1) / kSkinThreads, B), dim3(kSkinThreads), 0, st, F, G, V,
-                       faces, vxyz, vrot, qs, means, rots, normals, nstride, rgb, colors6);
+                       faces, vxyz, vrot, qs, means, rots, normals, nstride, rgb, colors6, zl);
     DM4D_HIP_CHECK(hipGetLastError());
     return DM4D_OK;
 }
@@ -867,7 +873,7 @@ int dm4d_face_gaussians_forward(int32_t F, int32_t G, const int32_t *faces, cons
     if (F == 0) return DM4D_OK;
     if (!means || !rotations_wxyz) { set_error("null output"); return DM4D_ERR_INVALID; }
     return face_forward_launch(1, F, G, 0, faces, vxyz, vrot, q_static_wxyz, means, rotations_wxyz, normals, 3, nullptr,
-                               nullptr, (hipStream_t)stream);
+                               nullptr, (hipStream_t)stream, nullptr, 0, 0);
 }
 
 size_t dm4d_face_scratch_bytes(int32_t F) { return (size_t)(F > 0 ? F : 1) * 3 * kCornerRec * 4; }

@@ -27,7 +27,7 @@ int skin_backward_launch(int B, int method, int V, int M, int K, const float *ve
                          float *o_dx, float *o_dr, float *o_ds, float *o_do, hipStream_t st);
 int face_forward_launch(int B, int F, int G, int V, const int32_t *faces, const float *vxyz, const float *vrot,
                         const float *qs, float *means, float *rots, float *normals, int nstride, const float *rgb,
-                        float *colors6, hipStream_t st);
+                        float *colors6, hipStream_t st, char *zero_base = nullptr, size_t zero_stride = 0, int zero_n = 0);
 int face_backward_launch(int B, int F, int G, int V, const int32_t *faces, const float *vxyz, const float *vrot,
                          const float *qs, const float *g_means, const float *g_rots, const float *g_normals, int nstride,
                          const int32_t *csr_off, const int32_t *csr_items, float *scratch, const float *ext_xyz,
@@ -150,11 +150,11 @@ int dm4d_views_forward(const dm4d_views *v, dm4d_stream_t stream)
     rc = skin_forward_launch(NF, v->method, v->V, v->M, v->K, v->verts, v->nbr_idx, v->nbr_w, v->dx, v->dr, v->ds,
                              v->d_opacity, v->vxyz, v->vrot, st);
     if (rc) return rc;
-    rc = face_forward_launch(NF, v->F, v->G, v->V, v->faces, v->vxyz, v->vrot, v->q_static, v->means3D, v->rotations,
-                             v->colors + 3, 6, v->rgb, v->colors, st);
-    if (rc) return rc;
     const BatchDesc d = views_batch(v);
-    if ((rc = launch_zero_counters(d, st))) return rc;
+    // (the face kernel's first workgroup also clears the B views' counters for K1: one launch less on the serial chain)
+    rc = face_forward_launch(NF, v->F, v->G, v->V, v->faces, v->vxyz, v->vrot, v->q_static, v->means3D, v->rotations,
+                             v->colors + 3, 6, v->rgb, v->colors, st, d.geom, d.geom_stride, d.B);
+    if (rc) return rc;
     if ((rc = launch_preprocess(d, st))) return rc;
     if ((rc = launch_colscan(d, st))) return rc;
     if ((rc = launch_scatter(d, st))) return rc;

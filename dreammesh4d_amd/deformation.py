@@ -178,6 +178,101 @@ class _DeformMLP(torch.autograd.Function):
         return (g_feat, None, *grads)
 
 
+class _NodeNetwork(torch.autograd.Function):
+    """HexPlane query + MLP of the graph nodes as ONE operator (csrc/nodenet.hip, C ABI dm4d_nodenet_*): 1 launch forward,
+    3 backward, the 2 t - 1 of the timestamps inside -- against 1 + 1 + 1 forward and 2 + 3 backward for
+    ``hexplane._HexPlaneFeatures`` + ``_DeformMLP`` + the torch kernel in front.  Bit-identical results (the same kernel
+    bodies).  Inputs: (plan, timestamps in [0,1] [B], grads_in_place, n_heads, n_planes, *planes, *mlp parameters)."""
+
+    @staticmethod
+    def forward(ctx, plan, timestamps, in_place, n_heads, n_planes, *params):
+        import ctypes as C
+
+        from . import _lib, hexplane as hx
+
+        L = _lib.lib()
+        planes, mlp = params[:n_planes], params[n_planes:]
+        pl = [p.detach() for p in planes]
+        ps = [p.detach() for p in mlp]
+        for p in ps:
+            if p.dtype != torch.float32 or not p.is_contiguous():
+                raise ValueError("deformation MLP parameters must be contiguous float32")
+        dev = timestamps.device
+        B, M, S = int(timestamps.shape[0]), plan.M, plan.S
+        P, IN = B * M, S * 32
+        t = timestamps.detach().to(torch.float32).contiguous()
+        flags = hx.plane_layout(pl) | 4          # DM4D_HEX_CHANNELS_LAST?, DM4D_HEX_TIMES_01
+        W0, b0 = ps[0], ps[1]
+        heads = [ps[2 + 4 * k: 6 + 4 * k] for k in range(n_heads)]
+        w = _lib.MlpWeights()
+        w.in_dim, w.width, w.n_heads = IN, int(W0.shape[0]), n_heads
+        w.W0, w.b0 = W0.data_ptr(), b0.data_ptr()
+        outs = []
+        for k, (W1, b1, W2, b2) in enumerate(heads):
+            w.out_dim[k] = int(W2.shape[0])
+            w.W1[k], w.b1[k], w.W2[k], w.b2[k] = W1.data_ptr(), b1.data_ptr(), W2.data_ptr(), b2.data_ptr()
+            outs.append(torch.empty(P, int(W2.shape[0]), dtype=torch.float32, device=dev))
+        f = dict(dtype=torch.float32, device=dev)
+        feat, h, y = torch.empty(P, IN, **f), torch.empty(P, 64, **f), torch.empty(n_heads, P, 64, **f)
+        samples = torch.empty(L.dm4d_hexplane_scratch_bytes(S, M, B), dtype=torch.uint8, device=dev)
+        scratch = torch.empty(L.dm4d_nodenet_scratch_bytes(S, M, B, n_heads), dtype=torch.uint8, device=dev)
+        optr = (C.c_void_p * 4)(*[o.data_ptr() for o in outs])
+        with torch.cuda.device(dev):
+            _lib.check(L.dm4d_nodenet_forward(S, M, B, plan.res_c, hx._plane_ptr_array(pl), flags, plan.aabb_c, plan.nodes.data_ptr(),
+                                              t.data_ptr(), C.byref(w), feat.data_ptr(), samples.data_ptr(), h.data_ptr(), y.data_ptr(),
+                                              optr, scratch.data_ptr(), torch.cuda.current_stream(dev).cuda_stream), "dm4d_nodenet_forward")
+        ctx.plan, ctx.w, ctx.flags, ctx.n_heads = plan, w, flags, n_heads
+        ctx.keep = (t, pl, ps, feat, samples, h, y, scratch)
+        ctx.plane_params = list(planes) if in_place and all(p.is_leaf for p in planes) else None
+        ctx.set_materialize_grads(False)
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *g_outs):
+        import ctypes as C
+
+        from . import _lib, hexplane as hx
+
+        L = _lib.lib()
+        plan, n_heads = ctx.plan, ctx.n_heads
+        t, pl, ps, feat, samples, h, y, scratch = ctx.keep
+        dev = t.device
+        B, M, S = int(t.shape[0]), plan.M, plan.S
+        gs = [None if g is None else g.detach().to(torch.float32).contiguous() for g in g_outs]
+        gptr = (C.c_void_p * 4)(*[None if g is None else g.data_ptr() for g in gs])
+        g_feat = torch.empty_like(feat)
+        grads = [torch.empty_like(p) for p in ps]
+        gw = _lib.MlpWeightsGrad()
+        gw.W0, gw.b0 = grads[0].data_ptr(), grads[1].data_ptr()
+        for k in range(n_heads):
+            gw.W1[k], gw.b1[k], gw.W2[k], gw.b2[k] = (grads[2 + 4 * k + j].data_ptr() for j in range(4))
+        # persistent gradient planes installed as `.grad` (hexplane._HexPlaneFeatures.backward explains why and when)
+        in_place = ctx.plane_params is not None and all(p.grad is None for p in ctx.plane_params)
+        flags = ctx.flags
+        if in_place:
+            if plan.grad_buffers is None or any(b.shape != p.shape or b.stride() != p.stride() or b.device != p.device
+                                                for b, p in zip(plan.grad_buffers, pl)):
+                plan.grad_buffers = [torch.zeros_like(p, memory_format=torch.preserve_format) for p in pl]
+            pg = plan.grad_buffers
+            flags |= 2        # DM4D_HEX_KEEP_SPATIAL
+        else:
+            pg = [torch.empty_like(p, memory_format=torch.preserve_format) for p in pl]
+        sp, tp = plan.sp, plan.tp
+        _p = lambda x: x.data_ptr()
+        with torch.cuda.device(dev):
+            _lib.check(L.dm4d_nodenet_backward(
+                S, M, B, plan.res_c, hx._plane_ptr_array(pl), flags, plan.aabb_c, _p(plan.nodes), _p(t), C.byref(ctx.w), _p(feat), _p(samples),
+                _p(h), _p(y), gptr, plan.n_sp, _p(sp["scale"]), _p(sp["plane"]), _p(sp["texel"]), _p(sp["off"]), _p(sp["item"]),
+                plan.n_tp, _p(tp["scale"]), _p(tp["plane"]), _p(tp["col"]), _p(tp["off"]), _p(tp["item"]), _p(g_feat),
+                hx._plane_ptr_array(pg), C.byref(gw), _p(scratch), torch.cuda.current_stream(dev).cuda_stream), "dm4d_nodenet_backward")
+        ctx.keep = None
+        if in_place:
+            for p, gbuf in zip(ctx.plane_params, pg):
+                p.grad = gbuf
+            return (None,) * 5 + (None,) * len(pg) + tuple(grads)
+        return (None,) * 5 + tuple(pg) + tuple(grads)
+
+
 class DeformationNetwork(nn.Module):
     def __init__(self, net_width=64, bounds=1.0, resolution=(64, 64, 64, 25), multires=(1, 2, 4, 8),
                  no_ds=False, no_dr=False, no_do=True, timebase_pe=4, posebase_pe=10, scale_rotation_pe=2,
@@ -211,22 +306,30 @@ class DeformationNetwork(nn.Module):
             from . import hexplane as hx
 
             self.build_plan(nodes)
-            # 2 t - 1 (dynamic_sugar.py:431) in one launch: addcmul(-1, t, 2) rounds exactly like (t * 2) - 1 (2 t is exact)
-            c = getattr(self, "_affine_consts", None)
-            if c is None or c[0].device != timestamps.device:
-                c = self._affine_consts = (torch.tensor(-1.0, device=timestamps.device), torch.tensor(2.0, device=timestamps.device))
-            feat = hx.hexplane_features(self.deformation_net.grid, self._hex_plan, torch.addcmul(c[0], timestamps.float(), c[1]),
-                                        grads_in_place=getattr(self, "grads_in_place", False))
             d = self.deformation_net
             lin0 = d.feature_out[0]
             heads = [d.pos_deform] + ([] if d.no_ds else [d.scales_deform]) + ([] if d.no_dr else [d.rotations_deform]) + \
                     ([] if d.no_do else [d.opacity_deform])
-            if lin0.out_features == 64 and lin0.in_features % 64 == 0 and lin0.in_features <= 256:
-                params = [lin0.weight, lin0.bias]
-                for hd in heads:
-                    params += [hd.feature_out[0].main_stream.weight, hd.feature_out[0].main_stream.bias,
-                               hd.feature_out[1].weight, hd.feature_out[1].bias]
-                outs = list(_DeformMLP.apply(feat.view(B * M, -1), len(heads), *params))
+            fused_mlp = lin0.out_features == 64 and lin0.in_features % 64 == 0 and lin0.in_features <= 256
+            params = [lin0.weight, lin0.bias]
+            for hd in heads:
+                params += [hd.feature_out[0].main_stream.weight, hd.feature_out[0].main_stream.bias,
+                           hd.feature_out[1].weight, hd.feature_out[1].bias]
+            in_place = getattr(self, "grads_in_place", False)
+            if fused_mlp and getattr(self, "fuse_node_network", True) and B <= 16:
+                # query + MLP as one operator (csrc/nodenet.hip), the 2 t - 1 of dynamic_sugar.py:431 inside
+                planes = [p for grid in d.grid.grids for p in grid]
+                outs = list(_NodeNetwork.apply(self._hex_plan, timestamps, in_place, len(heads), len(planes), *planes, *params))
+                feat = None
+            else:
+                # 2 t - 1 in one launch: addcmul(-1, t, 2) rounds exactly like (t * 2) - 1 (2 t is exact)
+                c = getattr(self, "_affine_consts", None)
+                if c is None or c[0].device != timestamps.device:
+                    c = self._affine_consts = (torch.tensor(-1.0, device=timestamps.device), torch.tensor(2.0, device=timestamps.device))
+                feat = hx.hexplane_features(d.grid, self._hex_plan, torch.addcmul(c[0], timestamps.float(), c[1]), grads_in_place=in_place)
+                if fused_mlp:
+                    outs = list(_DeformMLP.apply(feat.view(B * M, -1), len(heads), *params))
+            if fused_mlp:
                 dx = outs.pop(0)
                 ds = None if d.no_ds else outs.pop(0)
                 dr = None if d.no_dr else outs.pop(0)

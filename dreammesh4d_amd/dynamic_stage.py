@@ -118,7 +118,7 @@ class DynamicStage:
         rnd_idx = [i for i, r in enumerate(is_ref) if not r]
         fidx = [frames[u] for u in unit_frame]
         return {"frames": frames, "vm": T(np.stack([c.viewmatrix for c in cams]), torch.float32),
-                "pm": T(np.stack([c.projmatrix for c in cams]), torch.float32), "unit_frame": T(unit_frame, torch.int64),
+                "pm": T(np.stack([c.projmatrix for c in cams]), torch.float32), "unit_frame": T(unit_frame, torch.int32),
                 "ref_idx": T(ref_idx, torch.int64), "rnd_idx": T(rnd_idx, torch.int64), "n_ref": len(ref_idx), "n_rnd": len(rnd_idx),
                 "frames_t_idx": T(frames, torch.int64), "fidx_ref": T([fidx[i] for i in ref_idx], torch.int64),
                 "fidx_rnd": T([fidx[i] for i in rnd_idx], torch.int64),

@@ -304,6 +304,8 @@ size_t dm4d_hexplane_scratch_bytes(int32_t S, int32_t M, int32_t B);
                                     * that already hold zeros outside the texels of this plan (e.g. zero-initialised once, then only
                                     * ever written by this call with the same plan): their zero fill is skipped -- 134 of the 143 MB
                                     * a step would otherwise clear.  The time planes are cleared as usual. */
+#define DM4D_HEX_TIMES_01      4   /* `times` are timestamps in [0, 1]; the kernels map them to 2 t - 1 themselves
+                                    * (C/geometry/dynamic_sugar.py:431), saving the caller an elementwise launch */
 /* Gradients w.r.t. the planes, written (not accumulated) into the dense planes `g_planes` = HOST array of
  * S*6 device pointers (16-byte aligned, uninitialised: the call zero-fills them in one launch and hands the
  * pointers to its kernels by value).  Atomic-free and deterministic: spatial planes
@@ -504,6 +506,25 @@ int dm4d_views_backward(const dm4d_views *v, const dm4d_views_grads *g, dm4d_str
  * record_capacity) of the last forward (host arrays of B, any may be NULL; synchronises the stream). */
 int dm4d_views_counters(const dm4d_views *v, int64_t *num_rendered, int64_t *num_records, int32_t *overflowed,
                         dm4d_stream_t stream);
+
+/* ------------------------------------------------------------------ deformation network of the nodes, fused
+ * dm4d_hexplane_forward + dm4d_deform_mlp_forward in ONE launch (the 16 x in_dim feature tile of a workgroup goes straight
+ * into the MLP's first layer), their backward in three launches instead of five (independent jobs side by side).
+ * Arguments as the two operators' (`flags` = the DM4D_HEX_* word; in_dim of `w` must be S * 32; `feat` [B*M, S*32] and
+ * `samples` (dm4d_hexplane_scratch_bytes) are outputs of the forward the backward reads; `scratch`:
+ * dm4d_nodenet_scratch_bytes, shared by forward and backward; g_feat [B*M, S*32] is a work buffer of the backward).
+ * Results are bit-identical to the two-operator path.  C/geometry/deformation.py:88-305,430-436. */
+size_t dm4d_nodenet_scratch_bytes(int32_t S, int32_t M, int32_t B, int32_t n_heads);
+int dm4d_nodenet_forward(int32_t S, int32_t M, int32_t B, const int32_t *res, const float *const *planes, int32_t flags,
+                         const float *aabb_host, const float *nodes, const float *times, const dm4d_mlp_weights *w, float *feat,
+                         void *samples, float *h_save, float *y_save, float *const *out, void *scratch, dm4d_stream_t stream);
+int dm4d_nodenet_backward(int32_t S, int32_t M, int32_t B, const int32_t *res, const float *const *planes, int32_t flags,
+                          const float *aabb_host, const float *nodes, const float *times, const dm4d_mlp_weights *w,
+                          const float *feat, void *samples, const float *h_save, const float *y_save, const float *const *g_out,
+                          int32_t n_spatial, const int32_t *sp_scale, const int32_t *sp_plane, const int32_t *sp_texel,
+                          const int32_t *sp_off, const int32_t *sp_item, int32_t n_time, const int32_t *tp_scale,
+                          const int32_t *tp_plane, const int32_t *tp_col, const int32_t *tp_off, const int32_t *tp_item,
+                          float *g_feat, float *const *g_planes, const dm4d_mlp_weights_grad *gw, void *scratch, dm4d_stream_t stream);
 
 #ifdef __cplusplus
 }

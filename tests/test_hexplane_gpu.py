@@ -158,3 +158,41 @@ def test_in_place_gradient_buffers_equal_fresh_gradients_over_steps():
         assert ptrs is None or now == ptrs, step           # the same persistent storage every step
         ptrs = now
         assert nets[1]._hex_plan.grad_buffers is not None and all(p.grad is b for p, b in zip(planes, nets[1]._hex_plan.grad_buffers))
+
+
+@pytest.mark.parametrize("heads", ["all", "pos+rot"])
+def test_node_network_operator_is_bit_identical_to_the_two_operator_path(heads):
+    """csrc/nodenet.hip (HexPlane query + MLP in one launch, 2 t - 1 inside, the backward's independent jobs side by side) runs
+    the same kernel bodies as hexplane.hip + deform_mlp.hip behind torch's addcmul: outputs and every gradient bit for bit."""
+    _need_gpu()
+    from dreammesh4d_amd.deformation import DeformationNetwork
+
+    dev = torch.device("cuda:0")
+    full = heads == "all"
+    g = torch.Generator().manual_seed(5)
+    M, B = 700, 4
+    nodes = (torch.rand(M, 3, generator=g) * 1.3 - 0.65).to(dev)
+    ts = torch.rand(B, generator=g).to(dev)
+    ts[1] = 0.0
+    res = []
+    for fuse in (True, False):
+        torch.manual_seed(0)
+        net = DeformationNetwork(resolution=(16, 16, 16, 9), multires=(1, 2, 4, 8), no_ds=not full, no_dr=False, no_do=not full).to(dev)
+        with torch.no_grad():
+            gg = torch.Generator().manual_seed(1)
+            for name, p in net.named_parameters():
+                if "_deform" in name:
+                    p.add_((0.05 * torch.randn(p.shape, generator=gg)).to(dev))
+        net.fuse_node_network = fuse
+        out = [x for x in net.node_outputs(nodes, ts) if x is not None]
+        gw = torch.Generator().manual_seed(2)
+        w = [torch.randn(x.shape, generator=gw).to(dev) for x in out]
+        sum((a * b).sum() for a, b in zip(out, w)).backward()
+        res.append(([o.detach() for o in out], {n: p.grad for n, p in net.named_parameters() if p.grad is not None}))
+    (o1, g1), (o2, g2) = res
+    assert len(o1) == len(o2) == (4 if full else 2)
+    for a, b in zip(o1, o2):
+        assert torch.equal(a, b)
+    assert g1.keys() == g2.keys() and len(g1) > 20
+    for n in g1:
+        assert torch.equal(g1[n], g2[n]), n
