@@ -44,7 +44,7 @@ HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8 TB/s peak
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--steps", type=int, default=400)      # ~0.45 s timed: 50 steps sit inside the clock / power fluctuation of a box (+-4 %)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-iters", action="store_true", help="skip the dynamic-stage iterations/sec measurement")
@@ -103,6 +103,7 @@ class Workload:
         # on gfx950 -- profiles/r03_tile_records.md); default: the bit-reproducible (Gaussian, cell) records
         self.renderer = views.ViewRenderer(self.graph, self.topo, H, W, self.cams[0].tanfov, method="hybrid",
                                            deterministic=os.environ.get("DM4D_TILE_RECORDS", "0") != "1")
+        self.renderer.fuse_face_backward = os.environ.get("DM4D_FUSE_FACE_BWD", "0") == "1"     # (A/B: gather + face backward as one kernel)
         g = torch.Generator(device="cpu").manual_seed(2)
         B = VIEWS_PER_STEP
         self.gC = torch.randn(B, 6, H, W, generator=g).to(dev)

@@ -375,30 +375,34 @@ __global__ __launch_bounds__(kPreThreads) void k_scatter(BatchDesc d)
 }
 
 // ---------------------------------------------------------------------------------------- B2
-template <int PARTS>   // float4 per record: 3 (12-float records: 3 channels, or lean 6-channel) or 4 (16 floats)
-__global__ __launch_bounds__(kPreThreads) void k_gather_bwd(BatchDesc d)
+// What one Gaussian of one view gets back from B2: its gradients w.r.t. the 3D mean, the rotation (w, x, y, z) and the blended
+// colour channels -- kept in registers by the fused gather + face kernel (gather_face.hip), which never writes them per view.
+struct GatherOut { float dmean[3], drot[4], dcol[kMaxChannels]; };
+
+// PARTS: float4 per record: 3 (12-float records: 3 channels, or lean 6-channel) or 4 (16 floats).
+// The body of B2 for Gaussian i of the view `c` (every lane of the wave calls it, for 64 CONSECUTIVE Gaussians of the SAME view:
+// the record streaming is wave-cooperative).  sV / sP: the view's matrices in LDS; chunk: this wave's staging window.
+// Per-view outputs (c.o.*) are written where their pointer is set.
+template <int PARTS>
+__device__ __forceinline__ void gather_gaussian(const BatchDesc &d, const ViewCtx &c, const int i, const bool live, const float *sV,
+                                                const float *sP, float *chunk, GatherOut &res)
 {
-    const ViewCtx c = resolve(d, blockIdx.y);
     const ViewParams &vp = c.vp;
     const dm4d_raster_inputs &in = c.in;
     const int32_t *__restrict__ radii = c.radii;
     const GeomPtrs &g = c.g;
     const float *__restrict__ dLt = c.dLq;
     const BwdOutputs &o = c.o;
-    __shared__ float sV[16], sP[16];
-    // per-wave staging window of kGRec records.  In a window of n records only ~n / 8 lanes (Gaussians) have
-    // anything to add and the wave loops for the longest of them, so a larger window means fewer, better filled
-    // iterations.  Row stride: 12 floats for the 12-float records (16 lanes reading 16 consecutive records with
-    // ds_read_b128 hit disjoint bank groups: 12 i mod 64 are 16 different multiples of 4), 20 for the 16-float ones.
     constexpr int kGRec = DM4D_GREC, kGStride = PARTS == 3 ? 12 : 20;
     constexpr int NQ = kGRec * PARTS / 64;      // float4 a lane holds of a window in flight
-    __shared__ __attribute__((aligned(16))) float s_chunk[kPreThreads / 64][kGRec * kGStride];
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    if (tid < 16) { sV[tid] = vp.view[tid]; sP[tid] = vp.proj[tid]; }
-    __syncthreads();
-    const int i = blockIdx.x * kPreThreads + tid;
-    const bool live = i < in.N;
+    const int lane = threadIdx.x & 63;
     const size_t si = (size_t)i;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) res.dmean[k] = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) res.drot[k] = 0.f;
+#pragma unroll
+    for (int k = 0; k < kMaxChannels; ++k) res.dcol[k] = 0.f;
 
     // acc: 0,1 dL/dmean2D (NDC) | 2,3,4 dL/dconic (A,B,C) | 5 dL/dopacity | 6 dL/ddepth | 7.. dL/dcolour
     float acc[7 + kMaxChannels];
@@ -425,7 +429,6 @@ __global__ __launch_bounds__(kPreThreads) void k_gather_bwd(BatchDesc d)
         uint32_t R0 = rec0, R1 = end;
         R0 = wave_min_u32(R0);
         R1 = wave_max_u32(R1);
-        float *chunk = s_chunk[wv];
         // software pipeline: the next window's loads are in flight while this one is summed
         float4 pq[NQ];
 #pragma unroll
@@ -480,9 +483,13 @@ __global__ __launch_bounds__(kPreThreads) void k_gather_bwd(BatchDesc d)
         acc[4] = -0.5f * acc[4];
     }
     if (!live) return;
-    o.dL_dmeans2D[3 * si + 0] = acc[0];
-    o.dL_dmeans2D[3 * si + 1] = acc[1];
-    o.dL_dmeans2D[3 * si + 2] = 0.f;
+    if (o.dL_dmeans2D) {
+        o.dL_dmeans2D[3 * si + 0] = acc[0];
+        o.dL_dmeans2D[3 * si + 1] = acc[1];
+        o.dL_dmeans2D[3 * si + 2] = 0.f;
+    }
+#pragma unroll
+    for (int ch = 0; ch < kMaxChannels; ++ch) res.dcol[ch] = acc[7 + ch];
     if (o.dL_dopacity) {
         // the records carry sum q = opacity * sum G dL/dalpha (B1's q already holds the opacity factor; a Gaussian with
         // opacity < 1/255 contributes nowhere, its sum is an exact 0)
@@ -611,9 +618,15 @@ __global__ __launch_bounds__(kPreThreads) void k_gather_bwd(BatchDesc d)
             drot[3] = 2 * (-2 * z * dR[0] - rr * dR[1] + x * dR[2] + rr * dR[3] - 2 * z * dR[4] + y * dR[5] + x * dR[6] + y * dR[7]);
         }
     }
-    o.dL_dmeans3D[3 * si + 0] = dmean[0];
-    o.dL_dmeans3D[3 * si + 1] = dmean[1];
-    o.dL_dmeans3D[3 * si + 2] = dmean[2];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) res.dmean[k] = dmean[k];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) res.drot[k] = drot[k];
+    if (o.dL_dmeans3D) {
+        o.dL_dmeans3D[3 * si + 0] = dmean[0];
+        o.dL_dmeans3D[3 * si + 1] = dmean[1];
+        o.dL_dmeans3D[3 * si + 2] = dmean[2];
+    }
     if (o.dL_dcov3D) {
 #pragma unroll
         for (int k = 0; k < 6; ++k) o.dL_dcov3D[6 * si + k] = dcov[k];
@@ -625,6 +638,25 @@ __global__ __launch_bounds__(kPreThreads) void k_gather_bwd(BatchDesc d)
     }
     if (o.dL_drotations)
         reinterpret_cast<float4 *>(o.dL_drotations)[i] = make_float4(drot[0], drot[1], drot[2], drot[3]);
+}
+
+constexpr int kGatherChunkFloats(int parts) { return DM4D_GREC * (parts == 3 ? 12 : 20); }
+template <int PARTS>
+__global__ __launch_bounds__(kPreThreads) void k_gather_bwd(BatchDesc d)
+{
+    const ViewCtx c = resolve(d, blockIdx.y);
+    __shared__ float sV[16], sP[16];
+    // per-wave staging window of kGRec records.  In a window of n records only ~n / 8 lanes (Gaussians) have
+    // anything to add and the wave loops for the longest of them, so a larger window means fewer, better filled
+    // iterations.  Row stride: 12 floats for the 12-float records (16 lanes reading 16 consecutive records with
+    // ds_read_b128 hit disjoint bank groups: 12 i mod 64 are 16 different multiples of 4), 20 for the 16-float ones.
+    __shared__ __attribute__((aligned(16))) float s_chunk[kPreThreads / 64][kGatherChunkFloats(PARTS)];
+    const int tid = threadIdx.x;
+    if (tid < 16) { sV[tid] = c.vp.view[tid]; sP[tid] = c.vp.proj[tid]; }
+    __syncthreads();
+    const int i = blockIdx.x * kPreThreads + tid;
+    GatherOut res;
+    gather_gaussian<PARTS>(d, c, i, i < c.in.N, sV, sP, s_chunk[tid >> 6], res);
 }
 
 __global__ void k_mark_visible(int N, const float *__restrict__ means3D, const float *__restrict__ view,

@@ -558,41 +558,22 @@ __global__ __launch_bounds__(kSkinThreads) void k_face_fwd(int F, int G, int V, 
 }
 
 constexpr int kCornerRec = 6;   // dL/dx (3) + dL/d(rotation-vector blend) (3) per face corner
-__global__ __launch_bounds__(kSkinThreads) void k_face_bwd_face(int F, int G, int V, const int32_t *__restrict__ faces,
-                                                                const float *__restrict__ vxyz,
-                                                                const float *__restrict__ vrot,
-                                                                const float *__restrict__ q_static,
-                                                                const float *__restrict__ g_means,
-                                                                const float *__restrict__ g_rots,
-                                                                const float *__restrict__ g_normals, int nstride,
-                                                                float *__restrict__ rec /* [F][3][6] */,
-                                                                const int32_t *__restrict__ frame_index, int n_views, int pypose)
+// The face part of the face -> Gaussian backward for the workgroup's faces, given every thread's (= Gaussian's, slot sl of face
+// f) upstream gradients ALREADY SUMMED over the views of the frame: gm = dL/dmean, go = dL/drotation (x, y, z, w), gn =
+// dL/dnormal.  vxyz / vrot / rec: the frame's.  Called by every thread of the workgroup (two barriers inside).
+// The Exp / Exp-gradient of a slot is the heavy part and runs G-wide in parallel; the G slot results of a face meet in LDS and
+// the slot-0 thread adds them in slot order (fixed: deterministic) and finishes the face.
+__device__ __forceinline__ void face_bwd_finish(const int F, const int G, const int32_t *__restrict__ faces,
+                                                const float *__restrict__ vxyz, const float *__restrict__ vrot,
+                                                const float *__restrict__ q_static, const bool has_means, const bool has_rots,
+                                                const bool has_normals, const bool live, const int f, const int sl, const int base,
+                                                const v3 gm, const q4 go, const v3 gn_in, float *__restrict__ rec, const int pypose)
 {
-    // blockIdx.y = frame; the upstream gradients are per VIEW: summed here over the views of the frame in view
-    // order (the backward is linear in them).  frame_index == nullptr: view == frame.
-    //
-    // One thread per (face, slot) = per Gaussian (coalesced reads of the per-Gaussian gradients; the Exp / Exp-gradient
-    // of a slot is the heavy part and runs G-wide in parallel); the G slot results of a face meet in LDS and the
-    // slot-0 thread adds them in slot order (fixed: deterministic) and finishes the face.
     __shared__ float s_log[kSkinThreads][3];        // per thread of a face's first three slots: Log of vertex (tid % G)
     __shared__ float s_val[kSkinThreads][9];        // per slot: gm (3), gr (3), gn (3)
     const int tid = threadIdx.x;
-    const int faces_per_wg = kSkinThreads / G;
-    const int fl = tid / G, sl = tid - fl * G;      // face in workgroup, slot
-    const int f = blockIdx.x * faces_per_wg + fl;
-    const bool live = fl < faces_per_wg && f < F;
-    const size_t n = (size_t)F * G;
-    const int frame = blockIdx.y;
-    {
-        const size_t bv = blockIdx.y;
-        vxyz += bv * V * 3;
-        vrot += bv * V * 4;
-        rec += bv * F * 3 * kCornerRec;
-    }
-    const int b0 = frame_index ? 0 : frame, b1 = frame_index ? n_views : frame + 1;
-    const int base = fl * G;                        // first thread of this face
     // phase A: Log of the three vertex rotations, one per thread (G >= 3) or all by slot 0 (G == 1)
-    if (live && g_rots) {
+    if (live && has_rots) {
         if (G >= 3) {
             if (sl < 3) {
                 const v3 L = so3_log(ldq(vrot, faces[3 * f + sl]));
@@ -605,11 +586,8 @@ __global__ __launch_bounds__(kSkinThreads) void k_face_bwd_face(int F, int G, in
     if (live) {
         const size_t i = (size_t)f * G + sl;
         const float *b = c_bary[bary_row(G)][sl];
-        v3 gm = mk3(0, 0, 0), gr = mk3(0, 0, 0), gn = mk3(0, 0, 0);
-        if (g_means)
-            for (int bv = b0; bv < b1; ++bv)
-                if (!frame_index || frame_index[bv] == frame) gm = gm + ld3(g_means + (size_t)bv * n * 3, i);
-        if (g_rots) {
+        v3 gr = mk3(0, 0, 0);
+        if (has_rots) {
             v3 L0, L1, L2;
             if (G >= 3) {
                 L0 = mk3(s_log[base][0], s_log[base][1], s_log[base][2]);
@@ -627,24 +605,12 @@ __global__ __launch_bounds__(kSkinThreads) void k_face_bwd_face(int F, int G, in
             const q4 Q = qmul(qd, qs);
             const float nq = fmaxf(sqrtf(qdot(Q, Q)), 1e-12f);
             const q4 out = qscale(1.f / nq, Q);
-            q4 go = q4{0.f, 0.f, 0.f, 0.f};
-            for (int bv = b0; bv < b1; ++bv)
-                if (!frame_index || frame_index[bv] == frame) {
-                    const float4 go4 = reinterpret_cast<const float4 *>(g_rots + (size_t)bv * n * 4)[i];   // grads in w,x,y,z order
-                    go = qadd(go, q4{go4.y, go4.z, go4.w, go4.x});
-                }
             const q4 gQ = qscale(1.f / nq, qadd(go, qscale(-qdot(go, out), out)));
             if (pypose) gr = so3_exp_grad_pp(r, gQ);     // SO3_Mul.backward: X_grad = (g[:3], 0); so3_Exp.backward: g[:3] Jl(r)
             else gr = so3_exp_grad(r, qmul(gQ, qconj(qs)));
         }
-        if (g_normals)
-            for (int bv = b0; bv < b1; ++bv)
-                if (!frame_index || frame_index[bv] == frame) {
-                    const float *pn = g_normals + ((size_t)bv * n + i) * nstride;
-                    gn = gn + mk3(pn[0], pn[1], pn[2]);
-                }
         float *o = s_val[tid];
-        o[0] = gm.x; o[1] = gm.y; o[2] = gm.z; o[3] = gr.x; o[4] = gr.y; o[5] = gr.z; o[6] = gn.x; o[7] = gn.y; o[8] = gn.z;
+        o[0] = gm.x; o[1] = gm.y; o[2] = gm.z; o[3] = gr.x; o[4] = gr.y; o[5] = gr.z; o[6] = gn_in.x; o[7] = gn_in.y; o[8] = gn_in.z;
     }
     __syncthreads();
     // phase C: slot 0 adds the slots in order and finishes the face
@@ -654,12 +620,12 @@ __global__ __launch_bounds__(kSkinThreads) void k_face_bwd_face(int F, int G, in
     for (int s2 = 0; s2 < G; ++s2) {
         const float *b = c_bary[bary_row(G)][s2];
         const float *o = s_val[base + s2];
-        const v3 gm = mk3(o[0], o[1], o[2]), gr = mk3(o[3], o[4], o[5]);
-        if (g_means) { X[0] = X[0] + b[0] * gm; X[1] = X[1] + b[1] * gm; X[2] = X[2] + b[2] * gm; }
-        if (g_rots) { R[0] = R[0] + b[0] * gr; R[1] = R[1] + b[1] * gr; R[2] = R[2] + b[2] * gr; }
+        const v3 gm2 = mk3(o[0], o[1], o[2]), gr = mk3(o[3], o[4], o[5]);
+        if (has_means) { X[0] = X[0] + b[0] * gm2; X[1] = X[1] + b[1] * gm2; X[2] = X[2] + b[2] * gm2; }
+        if (has_rots) { R[0] = R[0] + b[0] * gr; R[1] = R[1] + b[1] * gr; R[2] = R[2] + b[2] * gr; }
         gn = gn + mk3(o[6], o[7], o[8]);
     }
-    if (g_normals) {
+    if (has_normals) {
         const int i0 = faces[3 * f], i1 = faces[3 * f + 1], i2 = faces[3 * f + 2];
         const v3 x0 = ld3(vxyz, i0), x1 = ld3(vxyz, i1), x2 = ld3(vxyz, i2);
         const v3 e1 = x1 - x0, e2 = x2 - x0, c = cross(e1, e2);
@@ -677,6 +643,54 @@ __global__ __launch_bounds__(kSkinThreads) void k_face_bwd_face(int F, int G, in
         o[j * kCornerRec + 0] = X[j].x; o[j * kCornerRec + 1] = X[j].y; o[j * kCornerRec + 2] = X[j].z;
         o[j * kCornerRec + 3] = R[j].x; o[j * kCornerRec + 4] = R[j].y; o[j * kCornerRec + 5] = R[j].z;
     }
+}
+
+__global__ __launch_bounds__(kSkinThreads) void k_face_bwd_face(int F, int G, int V, const int32_t *__restrict__ faces,
+                                                                const float *__restrict__ vxyz,
+                                                                const float *__restrict__ vrot,
+                                                                const float *__restrict__ q_static,
+                                                                const float *__restrict__ g_means,
+                                                                const float *__restrict__ g_rots,
+                                                                const float *__restrict__ g_normals, int nstride,
+                                                                float *__restrict__ rec /* [F][3][6] */,
+                                                                const int32_t *__restrict__ frame_index, int n_views, int pypose)
+{
+    // blockIdx.y = frame; the upstream gradients are per VIEW: summed here over the views of the frame in view
+    // order (the backward is linear in them).  frame_index == nullptr: view == frame.
+    // One thread per (face, slot) = per Gaussian (coalesced reads of the per-Gaussian gradients).
+    const int tid = threadIdx.x;
+    const int faces_per_wg = kSkinThreads / G;
+    const int fl = tid / G, sl = tid - fl * G;      // face in workgroup, slot
+    const int f = blockIdx.x * faces_per_wg + fl;
+    const bool live = fl < faces_per_wg && f < F;
+    const size_t n = (size_t)F * G;
+    const int frame = blockIdx.y;
+    {
+        const size_t bv = blockIdx.y;
+        vxyz += bv * V * 3;
+        vrot += bv * V * 4;
+        rec += bv * F * 3 * kCornerRec;
+    }
+    const int b0 = frame_index ? 0 : frame, b1 = frame_index ? n_views : frame + 1;
+    v3 gm = mk3(0, 0, 0), gn = mk3(0, 0, 0);
+    q4 go = q4{0.f, 0.f, 0.f, 0.f};
+    if (live) {
+        const size_t i = (size_t)f * G + sl;
+        for (int bv = b0; bv < b1; ++bv) {
+            if (frame_index && frame_index[bv] != frame) continue;
+            if (g_means) gm = gm + ld3(g_means + (size_t)bv * n * 3, i);
+            if (g_rots) {
+                const float4 go4 = reinterpret_cast<const float4 *>(g_rots + (size_t)bv * n * 4)[i];   // grads in w,x,y,z order
+                go = qadd(go, q4{go4.y, go4.z, go4.w, go4.x});
+            }
+            if (g_normals) {
+                const float *pn = g_normals + ((size_t)bv * n + i) * nstride;
+                gn = gn + mk3(pn[0], pn[1], pn[2]);
+            }
+        }
+    }
+    face_bwd_finish(F, G, faces, vxyz, vrot, q_static, g_means != nullptr, g_rots != nullptr, g_normals != nullptr, live, f, sl, fl * G,
+                    gm, go, gn, rec, pypose);
 }
 
 // per vertex: fixed-order sum over incident face corners (static CSR), then Log backward
@@ -795,7 +809,7 @@ int face_backward_launch(int B, int F, int G, int V, const int32_t *faces, const
     const int pypose = (G & kPypose) ? 1 : 0;
     G &= 0xff;
     ProfScope prof_(kKFaceBwd, st);
-    if (F > 0) {
+    if (F > 0 && !(n_views < 0)) {         // n_views < 0: the corner records were already written (fused gather + face kernel)
         const int fpw = kSkinThreads / G;      // faces per workgroup (one thread per Gaussian)
         hipLaunchKernelGGL(k_face_bwd_face, dim3((F + fpw - 1) / fpw, B), dim3(kSkinThreads), 0, st, F, G,
                            V, faces, vxyz, vrot, qs, g_means, g_rots, g_normals, nstride, scratch, frame_index, n_views, pypose);

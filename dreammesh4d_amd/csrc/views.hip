@@ -33,6 +33,8 @@ int face_backward_launch(int B, int F, int G, int V, const int32_t *faces, const
                          const int32_t *csr_off, const int32_t *csr_items, float *scratch, const float *ext_xyz,
                          const float *ext_rot, float *o_vxyz, float *o_vrot, const int32_t *frame_index, int n_views,
                          hipStream_t st);
+int launch_gather_face_bwd(const BatchDesc &d, int n_frames, int F, int G, int V, const int32_t *faces, const float *vxyz, const float *vrot,
+                           const float *qs, float *face_scratch, hipStream_t st);
 int skin_check(int method, int V, int M, int K, const void *verts, const void *idx, const void *w, const void *dx,
                const void *dr, const void *ds, const void *dop);
 int face_check(int F, int G, const void *faces, const void *vxyz, const void *vrot, const void *qs);
@@ -167,11 +169,18 @@ int dm4d_views_backward(const dm4d_views *v, const dm4d_views_grads *gr, dm4d_st
     int rc = views_check(v);
     if (rc) return rc;
     if (!gr || !gr->dL_dcolor || !gr->grad_scratch || !gr->skin_scratch || !gr->face_scratch || !gr->node_csr_offsets ||
-        !gr->node_csr_items || !gr->vert_csr_offsets || !gr->vert_csr_items || !gr->dL_dmeans2D || !gr->dL_dmeans3D ||
-        !gr->dL_drotations || !gr->dL_dcolors || !gr->dL_dvxyz || !gr->dL_dvrot || !gr->dL_ddx || !gr->dL_ddr) {
+        !gr->node_csr_items || !gr->vert_csr_offsets || !gr->vert_csr_items || !gr->dL_dvxyz || !gr->dL_dvrot || !gr->dL_ddx || !gr->dL_ddr) {
         set_error("null tensor in dm4d_views_grads");
         return DM4D_ERR_INVALID;
     }
+    // The per-VIEW Gaussian gradients are optional as a group: all three NULL = the caller only wants what flows on to the
+    // vertices / nodes, and B2 + the face kernel run as one (gather_face.hip: nothing is written per view, dL_dmeans2D too
+    // becomes optional); all three set = the two-kernel path that materialises them.
+    const int n_view_grads = (gr->dL_dmeans3D ? 1 : 0) + (gr->dL_drotations ? 1 : 0) + (gr->dL_dcolors ? 1 : 0);
+    if (n_view_grads != 0 && n_view_grads != 3) { set_error("dL_dmeans3D, dL_drotations, dL_dcolors: all or none"); return DM4D_ERR_INVALID; }
+    const bool fused_face = n_view_grads == 0;
+    if (fused_face && (gr->dL_dopacity || gr->dL_dscales)) { set_error("dL_dopacity / dL_dscales need the per-view gradient tensors"); return DM4D_ERR_INVALID; }
+    if (!fused_face && !gr->dL_dmeans2D) { set_error("null dL_dmeans2D"); return DM4D_ERR_INVALID; }
     hipStream_t st = (hipStream_t)stream;
     BatchDesc d = views_batch(v);
     d.dL_dcolor = gr->dL_dcolor; d.dL_ddepth = gr->dL_ddepth; d.dL_dalpha = gr->dL_dalpha;
@@ -189,13 +198,15 @@ int dm4d_views_backward(const dm4d_views *v, const dm4d_views_grads *gr, dm4d_st
         BatchDesc sb = sub_batch(d, b0, v->B - b0 < group ? v->B - b0 : group);
         if (getenv("DM4D_BWD_REUSE")) sb.dLq = d.dLq;      // experiment: every group writes its records to the same scratch
         if ((rc = launch_render_bwd(sb, st))) return rc;
-        if ((rc = launch_gather_bwd(sb, st))) return rc;
+        if (!fused_face && (rc = launch_gather_bwd(sb, st))) return rc;
     }
     const int NF = v->frame_index ? v->n_frames : v->B;
+    if (fused_face && (rc = launch_gather_face_bwd(d, NF, v->F, v->G | (v->method & 0x100), v->V, v->faces, v->vxyz, v->vrot, v->q_static,
+                                                   (float *)gr->face_scratch, st))) return rc;
     rc = face_backward_launch(NF, v->F, v->G | (v->method & 0x100), v->V, v->faces, v->vxyz, v->vrot, v->q_static, gr->dL_dmeans3D,
-                              gr->dL_drotations, gr->dL_dcolors + 3, 6, gr->vert_csr_offsets, gr->vert_csr_items,
+                              gr->dL_drotations, fused_face ? nullptr : gr->dL_dcolors + 3, 6, gr->vert_csr_offsets, gr->vert_csr_items,
                               (float *)gr->face_scratch, gr->dL_dvxyz_ext, gr->dL_dvrot_ext, gr->dL_dvxyz, gr->dL_dvrot,
-                              v->frame_index, v->B, st);
+                              v->frame_index, fused_face ? -1 : v->B, st);
     if (rc) return rc;
     return skin_backward_launch(NF, v->method, v->V, v->M, v->K, v->verts, v->nbr_idx, v->nbr_w, v->dx, v->dr, v->ds,
                                 v->d_opacity, gr->dL_dvxyz, gr->dL_dvrot, gr->node_csr_offsets, gr->node_csr_items,

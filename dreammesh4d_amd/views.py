@@ -49,6 +49,12 @@ class ViewRenderer:
         # tests).  False: (Gaussian, tile) records summed in LDS with float atomics -- the training mode: 3.4x fewer
         # records, gradients equal up to the order of float additions (include/dm4d.h, dm4d_views.record_mode)
         self.deterministic = bool(deterministic)
+        # True: the backward does not materialise the per-VIEW Gaussian gradients (dL/dmeans3D, dL/drotations, dL/dcolors):
+        # the record gather and the face backward run as ONE kernel (csrc/gather_face.hip; bit-identical node gradients).
+        # Measured on the bench scene (tools/env_bench_long.sh, one box, 400 steps): 214 us against 168 + 32 us for the two
+        # kernels, 1.157 against 1.136 ms per step -- a thread that loops over the frame's views has half the loads in flight
+        # of two threads that take one view each, and B2 is bandwidth-bound.  Hence off by default.
+        self.fuse_face_backward = False
         self.N = topo.F * topo.G
         self.capacity = max(int(capacity_factor * self.N), 1 << 16)
         # backward records = (Gaussian, 4x4-pixel cell) pairs; ~2 per duplicate for mesh-bound splats
@@ -231,8 +237,11 @@ class _RenderViews(torch.autograd.Function):
         gc = _f32(g_color) if g_color is not None else torch.zeros(B, 6, H, W, **f)
         gd, ga = _f32(g_depth), _f32(g_alpha)
         gx, gr_ = _f32(g_vxyz), _f32(g_vrot)
-        o = dict(m2=torch.empty(B, N, 3, **f), m3=torch.empty(B, N, 3, **f), rot=torch.empty(B, N, 4, **f),
-                 col=torch.empty(B, N, 6, **f), op=torch.empty(B, N, **f) if ctx.need_static else None,
+        per_view = ctx.need_static or not r.fuse_face_backward
+        want_m2 = per_view or ctx.needs_input_grad[13]
+        o = dict(m2=torch.empty(B, N, 3, **f) if want_m2 else None, m3=torch.empty(B, N, 3, **f) if per_view else None,
+                 rot=torch.empty(B, N, 4, **f) if per_view else None,
+                 col=torch.empty(B, N, 6, **f) if per_view else None, op=torch.empty(B, N, **f) if ctx.need_static else None,
                  sc=torch.empty(B, N, 3, **f) if ctx.need_static else None, vx=torch.empty(NF, g.V, 3, **f),
                  vr=torch.empty(NF, g.V, 4, **f), dx=torch.empty(NF, g.M, 3, **f), dr=torch.empty(NF, g.M, 4, **f),
                  ds=torch.empty(NF, g.M, 6, **f) if ctx.keep["ds"] is not None else None,

@@ -236,3 +236,39 @@ def test_capacity_overflow_reported():
     ref = views.render_views(r, raw["trans"], raw["d_rot"], raw["strain"], raw["d_opacity"].squeeze(-1), qs, scales, opac,
                              rgb, vm, pm, torch.ones(6, device=dev))
     assert torch.equal(out["color"], ref["color"])
+
+
+@pytest.mark.parametrize("H,W,shared", [(144, 176, True), (40, 48, False)])
+def test_fused_gather_and_face_backward_is_bit_identical(H, W, shared):
+    """`fuse_face_backward`: B2 and the face part of the face->Gaussian backward as ONE kernel (csrc/gather_face.hip), nothing
+    materialised per view; default: the two-kernel path.  Same code, same order of the views: node gradients, the external
+    vertex gradient path and the optional screen-space gradient must agree bit for bit."""
+    _need_gpu()
+    from dreammesh4d_amd import views
+
+    dev = torch.device("cuda:0")
+    B, M = 4, 100
+    sc, graph, topo, qs, scales, opac, rgb, raw, cams, vm, pm = _scene(2400, M, 4, B, H, W, dev, seed=5)
+    fidx = torch.tensor([0, 1, 1, 0], device=dev, dtype=torch.int32) if shared else None
+    NF = 2 if shared else B
+    gen = torch.Generator().manual_seed(2)
+    gC = torch.randn(B, 6, H, W, generator=gen).to(dev)
+    gD = (0.1 * torch.randn(B, 1, H, W, generator=gen)).to(dev)
+    gA = torch.randn(B, 1, H, W, generator=gen).to(dev)
+    gV = (0.01 * torch.randn(NF, graph.V, 3, generator=gen)).to(dev)
+    res = []
+    for keep in (False, True):
+        for want_m2 in (False, True):
+            r = views.ViewRenderer(graph, topo, H, W, cams[0].tanfov, method="hybrid")
+            r.fuse_face_backward = not keep
+            leaves = {k: v[:NF].clone().requires_grad_(True) for k, v in raw.items()}
+            m2 = torch.zeros(B, r.N, 3, device=dev, requires_grad=True) if want_m2 else None
+            out = views.render_views(r, leaves["trans"], leaves["d_rot"], leaves["strain"], leaves["d_opacity"].squeeze(-1), qs, scales,
+                                     opac, rgb, vm, pm, torch.ones(6, device=dev), frame_index=fidx, means2D=m2)
+            torch.autograd.backward([out["color"], out["depth"], out["alpha"], out["vxyz"]], [gC, gD, gA, gV])
+            assert (r.last_grads["m3"] is not None) == keep
+            res.append(({k: v.grad.clone() for k, v in leaves.items()}, None if m2 is None else m2.grad.clone()))
+    for g, m2g in res[1:]:
+        for k in g:
+            assert torch.equal(g[k], res[0][0][k]), k
+    assert torch.equal(res[1][1], res[3][1]) and float(res[1][1].abs().max()) > 0
