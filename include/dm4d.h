@@ -511,6 +511,29 @@ int dm4d_views_backward(const dm4d_views *v, const dm4d_views_grads *g, dm4d_str
 int dm4d_views_counters(const dm4d_views *v, int64_t *num_rendered, int64_t *num_records, int32_t *overflowed,
                         dm4d_stream_t stream);
 
+/* ------------------------------------------------------------------ heat-method geodesics of the deformation graph
+ * The device pieces of build_deformation_graph(mode="geodisc") with the reference's own distance, the heat method
+ * (C/geometry/dynamic_sugar.py:794-861; csrc/heat.hip explains the M-instead-of-V Poisson solves):
+ *
+ * dm4d_cg_batched_f64: Jacobi-preconditioned conjugate gradients A X = B for S right-hand sides at once, A sparse symmetric
+ * positive (semi-)definite in CSR (float64, int32 indices, diagonal included), X / B stored unknown-major [V][S] (device);
+ * X holds the initial guess on entry.  diag_inv [V] = 1 / diagonal.  Stops when every column's |r| / |b| <= tol or after
+ * max_iter iterations; the residual is looked at (one host sync) every check_every iterations.  All reductions are
+ * two-stage and in fixed order: bit-reproducible.  Returns the number of iterations run (>= 0) or a negative error;
+ * *final_rel_residual (host, optional) = the worst column's |r| / |b|. */
+size_t dm4d_cg_batched_scratch_bytes(int32_t V, int32_t S);
+int dm4d_cg_batched_f64(int32_t V, int32_t S, const int32_t *csr_offsets, const int32_t *csr_cols, const double *csr_vals,
+                        const double *diag_inv, const double *B, double *X, void *scratch, int32_t max_iter, double tol,
+                        int32_t check_every, double *final_rel_residual, dm4d_stream_t stream);
+/* XT [3F][S] = -grad u / |grad u| per face and source from the heat solutions U [V][S]; G [F][3][3] (float64): grad u on
+ * face f = sum_k u[faces[f][k]] G[f][k]. */
+int dm4d_heat_face_directions(int32_t F, int32_t S, const int32_t *faces, const double *G, const double *U, double *XT, dm4d_stream_t stream);
+/* For the S source vertices first_vertex .. first_vertex + S - 1: the K nearest of M nodes by score[m * ld + s] (smaller =
+ * nearer; ties to the lower node index) and the reference's weights (1 - e_k / e_{K+1})^2 of the EUCLIDEAN distances to the node
+ * positions, rows normalised (:842-861); neighbor_idx [V,K] int64 / neighbor_weights [V,K] are indexed by vertex. */
+int dm4d_graph_select_knn(int32_t S, int32_t M, int32_t K, const double *score, int32_t ld, int32_t first_vertex, const float *verts,
+                          const float *node_xyz, int64_t *neighbor_idx, float *neighbor_weights, dm4d_stream_t stream);
+
 /* ------------------------------------------------------------------ deformation network of the nodes, fused
  * dm4d_hexplane_forward + dm4d_deform_mlp_forward in ONE launch (the 16 x in_dim feature tile of a workgroup goes straight
  * into the MLP's first layer), their backward in three launches instead of five (independent jobs side by side).
