@@ -159,6 +159,22 @@ __device__ __forceinline__ q4 qact_grad_q_pp(q4 q, v3 y, v3 h)
     return q4{r.x, r.y, r.z, 0.f};
 }
 constexpr int kPypose = 0x100;     // == DM4D_GRAD_PYPOSE
+// Gradient of the quaternion product Z = A * B of the dual-quaternion algebra (dual_quaternions.py:115-131: q_d = (t / 2) * q_r;
+// :224-231: translation = (2 q_d) * conj(q_r)) given g = dL/dZ.  exact: gA = g * conj(B), gB = conj(A) * g.  pypose: the operands
+// are pp.SO3 LieTensors (of NON-unit quaternions) and `*` is SO3_Mul, whose backward hands back
+//     X_grad = (g[:3], 0)        Y_grad = (g[:3] SO3_Adj(X), 0),   SO3_Adj(X) = I + 2 w hat(v) + 2 hat(v)^2 of X's components as they are
+// (pypose 0.6.7, lietensor/operation.py; the row vector times that matrix is qact(conj(X), g[:3]), also for a non-unit X).
+__device__ __forceinline__ void dqs_mul_grad(const int pypose, const q4 A, const q4 B, const q4 g, q4 &gA, q4 &gB)
+{
+    if (pypose) {
+        gA = q4{g.x, g.y, g.z, 0.f};
+        const v3 r = qact(qconj(A), qv(g));
+        gB = q4{r.x, r.y, r.z, 0.f};
+    } else {
+        gA = qmul(g, qconj(B));
+        gB = qmul(qconj(A), g);
+    }
+}
 
 // ---- node attributes from the raw deformation-network outputs --------------------------------
 struct NodeAttr { q4 q; float pn; v3 t; float S[9]; float o; };
@@ -312,8 +328,9 @@ __global__ __launch_bounds__(kSkinThreads) void k_skin_bwd_vertex(SkinArgs a0, c
         // x_dqs = R(rh) p + (2 dh * conj(rh)).xyz
         q4 g_rh = a.pypose ? qact_grad_q_pp(rh, p, g_dqs) : qact_grad_q(rh, p, g_dqs);     // q_r.matrix() of transform_point_simple
         const q4 G = q4{g_dqs.x, g_dqs.y, g_dqs.z, 0.f};
-        const q4 g_dh = qscale(2.f, qmul(G, rh));                    // dL/da = G * conj(b), b = conj(rh)
-        const q4 g_b = qmul(qconj(qscale(2.f, dh)), G);              // dL/db = conj(a) * G
+        q4 g_dh, g_b;                                                // translation = (2 dh) * conj(rh): a = 2 dh, b = conj(rh)
+        dqs_mul_grad(a.pypose, qscale(2.f, dh), qconj(rh), G, g_dh, g_b);
+        g_dh = qscale(2.f, g_dh);
         g_rh = qadd(g_rh, q4{-g_b.x, -g_b.y, -g_b.z, g_b.w});
         g_bd = qscale(1.f / nn, g_dh);
         g_br = qadd(qscale(1.f / nn, g_rh), qscale(-(qdot(g_rh, rh) + qdot(g_dh, dh)) / nn, rh));
@@ -344,9 +361,10 @@ __global__ __launch_bounds__(kSkinThreads) void k_skin_bwd_vertex(SkinArgs a0, c
             const q4 qr = qscale(1.f / qn, n.q);
             const q4 av = q4{0.5f * n.t.x, 0.5f * n.t.y, 0.5f * n.t.z, 0.f};
             const q4 g_d = qscale(w, g_bd);
-            const q4 g_a = qmul(g_d, qconj(qr));
+            q4 g_a, g_qr;                                               // q_d = (t / 2) * q_r
+            dqs_mul_grad(a.pypose, av, qr, g_d, g_a, g_qr);
             g_t = g_t + 0.5f * qv(g_a);
-            q4 g_qr = qadd(qmul(qconj(av), g_d), qscale(w, g_br));
+            g_qr = qadd(g_qr, qscale(w, g_br));
             g_q = qadd(g_q, qscale(1.f / qn, qadd(g_qr, qscale(-qdot(g_qr, qr), qr))));
         }
         // through q = pp / |pp|
@@ -424,8 +442,9 @@ __global__ __launch_bounds__(kSkinThreads) void k_skin_bwd_vertex_k4(SkinArgs a0
         }
         q4 g_rh = a.pypose ? qact_grad_q_pp(rh, p, g_dqs) : qact_grad_q(rh, p, g_dqs);     // q_r.matrix() of transform_point_simple
         const q4 G = q4{g_dqs.x, g_dqs.y, g_dqs.z, 0.f};
-        const q4 g_dh = qscale(2.f, qmul(G, rh));
-        const q4 g_b = qmul(qconj(qscale(2.f, dh)), G);
+        q4 g_dh, g_b;                                                // translation = (2 dh) * conj(rh): a = 2 dh, b = conj(rh)
+        dqs_mul_grad(a.pypose, qscale(2.f, dh), qconj(rh), G, g_dh, g_b);
+        g_dh = qscale(2.f, g_dh);
         g_rh = qadd(g_rh, q4{-g_b.x, -g_b.y, -g_b.z, g_b.w});
         g_bd = qscale(1.f / nn, g_dh);
         g_br = qadd(qscale(1.f / nn, g_rh), qscale(-(qdot(g_rh, rh) + qdot(g_dh, dh)) / nn, rh));
@@ -447,9 +466,10 @@ __global__ __launch_bounds__(kSkinThreads) void k_skin_bwd_vertex_k4(SkinArgs a0
     }
     if (a.method != kLbs) {
         const q4 g_d = qscale(w, g_bd);
-        const q4 g_a = qmul(g_d, qconj(qr));
+        q4 g_a, g_qr;                                                   // q_d = (t / 2) * q_r
+        dqs_mul_grad(a.pypose, av, qr, g_d, g_a, g_qr);
         g_t = g_t + 0.5f * qv(g_a);
-        q4 g_qr = qadd(qmul(qconj(av), g_d), qscale(w, g_br));
+        g_qr = qadd(g_qr, qscale(w, g_br));
         g_q = qadd(g_q, qscale(1.f / qn, qadd(g_qr, qscale(-qdot(g_qr, qr), qr))));
     }
     const q4 g_p = qscale(1.f / n.pn, qadd(g_q, qscale(-qdot(g_q, n.q), n.q)));

@@ -31,8 +31,10 @@ GRADIENTS, two conventions (``grad_mode``):
                SO3_Log.backward   (g Jl^-1(out), 0)                  so3_Exp.backward   g[:3] Jl(x)
                SO3_Act.backward   X: (g (-hat(out)), 0), p: g R(X)    SO3_Mul.backward   X: (g[:3], 0), Y: (g[:3] R(X), 0)
             with Jl the left Jacobian of SO(3).  The custom autograd Functions below restate exactly these rules (forward
-            values are the same functions as in "exact" mode).  The torch ops around them (F.normalize, .tensor(), the
-            dual-quaternion algebra of the DQS branch, whose SO3 products take NON-unit operands) stay Euclidean.
+            values are the same functions as in "exact" mode), incl. the two SO3 products of the dual-quaternion algebra of
+            the DQS branch (q_d = (t / 2) * q_r, translation = (2 q_d) * conj(q_r): pp.SO3 LieTensors of NON-unit quaternions,
+            whose SO3_Mul backward is the same rule with SO3_Adj(X) evaluated on X's components as they are).  The torch ops
+            around them (F.normalize, .tensor(), divisions by the norm, weighted sums) stay Euclidean.
             pypose is not in the tree: PARITY UNPINNED.
 """
 import math
@@ -218,7 +220,7 @@ def node_attributes(dx, dr, ds=None, do=None):
 def skin_vertices(verts, nbr_idx, nbr_w, trans, rot, S=None, opacity=None, method="hybrid", grad_mode="exact"):
     """verts [V,3]; nbr_idx [V,K] long; nbr_w [V,K]; node tables trans [M,3], rot [M,4] (unit, xyzw),
     S [M,3,3], opacity [M,1].  Returns (xyz [V,3], vrot [V,4] xyzw)."""
-    log_, exp_, act_, _ = _ops(grad_mode)
+    log_, exp_, act_, mul_ = _ops(grad_mode)
     t_k = trans[nbr_idx]          # [V,K,3]
     q_k = rot[nbr_idx]            # [V,K,4]
     w = nbr_w[..., None]
@@ -231,12 +233,12 @@ def skin_vertices(verts, nbr_idx, nbr_w, trans, rot, S=None, opacity=None, metho
     if method in ("dqs", "hybrid"):
         q_r = q_k / q_k.norm(dim=-1, keepdim=True)
         t4 = torch.cat([t_k, torch.zeros_like(t_k[..., :1])], dim=-1)
-        q_d = quat_mul(0.5 * t4, q_r)
+        q_d = mul_(0.5 * t4, q_r)                               # pp.SO3(0.5 * pp.SO3(t)) * q_r: SO3_Mul (dual_quaternions.py:124-130)
         br = (q_r * w).sum(dim=1)
         bd = (q_d * w).sum(dim=1)
         nrm = br.norm(dim=-1, keepdim=True)
         br, bd = br / nrm, bd / nrm
-        tr = quat_mul(2.0 * bd, quat_conj(br))[..., :3]
+        tr = mul_(2.0 * bd, quat_conj(br))[..., :3]             # .translation: pp.SO3(2 q_d) * conj(q_r), SO3_Mul (:224-231)
         x_dqs = act_(br, verts) + tr                            # transform_point_simple: q_r.matrix() @ p + translation
     if method == "lbs":
         xyz = x_lbs

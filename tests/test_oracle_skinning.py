@@ -236,3 +236,41 @@ def test_d_scale_restatement_against_explicit_loops():
     import pytest
     with pytest.raises(ValueError):
         sk.vertex_scales(idx, w, S, op, "dqs")
+
+
+def test_pypose_mul_rule_with_non_unit_operands_as_the_dqs_branch_uses_it():
+    """The DQS algebra multiplies pp.SO3 LieTensors of NON-unit quaternions (dual_quaternions.py:115-131,224-231).  SO3_Mul's
+    backward is then no derivative of anything; the restated rule is checked literally: X_grad = (g[:3], 0),
+    Y_grad = (g[:3] @ A(X), 0) with A(X) = I + 2 w hat(v) + 2 hat(v)^2 built from X's components as they are -- and the DQS
+    skinning gradient in pypose mode differs from the exact one (it is a different convention), while the forward is the same."""
+    import torch
+
+    from oracle import skinning as sk
+
+    g = torch.Generator().manual_seed(0)
+    X = (torch.randn(7, 4, generator=g, dtype=torch.float64) * 1.7).requires_grad_(True)      # non-unit
+    Y = (torch.randn(7, 4, generator=g, dtype=torch.float64) * 0.6).requires_grad_(True)
+    G = torch.randn(7, 4, generator=g, dtype=torch.float64)
+    Z = sk._MulPP.apply(X, Y)
+    assert torch.equal(Z, sk.quat_mul(X, Y))
+    Z.backward(G)
+    v, w = X.detach()[:, :3], X.detach()[:, 3]
+    hat = torch.zeros(7, 3, 3, dtype=torch.float64)
+    hat[:, 0, 1], hat[:, 0, 2], hat[:, 1, 0], hat[:, 1, 2], hat[:, 2, 0], hat[:, 2, 1] = -v[:, 2], v[:, 1], v[:, 2], -v[:, 0], -v[:, 1], v[:, 0]
+    A = torch.eye(3, dtype=torch.float64) + 2 * w[:, None, None] * hat + 2 * hat @ hat
+    assert torch.allclose(X.grad, torch.cat([G[:, :3], torch.zeros(7, 1, dtype=torch.float64)], 1))
+    assert torch.allclose(Y.grad[:, :3], torch.einsum("ni,nij->nj", G[:, :3], A)) and not Y.grad[:, 3].any()
+    # the DQS skinning: same forward in both modes, different rotation / translation gradients
+    V, M, K = 40, 9, 4
+    verts = torch.randn(V, 3, generator=g, dtype=torch.float64) * 0.3
+    idx = torch.stack([torch.randperm(M, generator=g)[:K] for _ in range(V)])
+    wts = torch.softmax(torch.randn(V, K, generator=g, dtype=torch.float64), 1)
+    grads = {}
+    for mode in ("exact", "pypose"):
+        dx = (0.1 * torch.randn(M, 3, generator=torch.Generator().manual_seed(1), dtype=torch.float64)).requires_grad_(True)
+        dr = (0.2 * torch.randn(M, 4, generator=torch.Generator().manual_seed(2), dtype=torch.float64)).requires_grad_(True)
+        t, q, _, _ = sk.node_attributes(dx, dr)
+        xyz, rot = sk.skin_vertices(verts, idx, wts, t, q, None, None, "dqs", grad_mode=mode)
+        grads[mode] = (xyz.detach().clone(),) + torch.autograd.grad((xyz * verts).sum(), [dx, dr])
+    assert torch.equal(grads["exact"][0], grads["pypose"][0])
+    assert not torch.allclose(grads["exact"][2], grads["pypose"][2], rtol=1e-3, atol=1e-9)
