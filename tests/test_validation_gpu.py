@@ -50,26 +50,44 @@ def test_sweep_equals_per_frame_rendering():
                                        T(c.viewmatrix)[None], T(c.projmatrix)[None], bg6)
                 assert torch.equal(o["color"][0, :3].clamp(0, 1).permute(1, 2, 0), got["comp_rgb"][f, a])
                 assert torch.equal(o["depth"][0].permute(1, 2, 0), got["depth"][f, a])
-    # one unit against the CPU oracle (float64 skinning + face Gaussians, float32 rasterizer): frame 3 from azimuth 120
+    # one unit against the CPU oracle: frame 3 from azimuth 120.  Two stages, each at its own bar (the round-2 version compared
+    # the image of float32 HIP skinning with the image of float64 oracle skinning at 2e-3: a pixel-level decision flips where a
+    # vertex moves by 1e-7).  (i) the rasterizer: the oracle blends the HIP path's OWN Gaussians -- the forward contract is
+    # bit-identity, north_star's bar is 1e-4; (ii) skinning + face->Gaussian: float32 kernels against the float64 oracle.
     from oracle import raster as orc, skinning as sk
 
     D = torch.float64
     tt = lambda a: torch.tensor(np.asarray(a), dtype=D)
     f, a = 3, 1
+    c = syn.make_camera(H, W, elev_deg=0.0, azim_deg=az[a])
     with torch.no_grad():
         dx, dr, ds, do = net.node_outputs(nodes, ts[f:f + 1])
-    trans, q, S, op = sk.node_attributes(dx[0].cpu().to(D), dr[0].cpu().to(D), ds[0].cpu().to(D), do[0].cpu().to(D).reshape(M, -1))
-    xyz, vrot = sk.skin_vertices(tt(sc["verts"]), torch.tensor(sc["nbr_idx"]), tt(sc["nbr_w"]), trans, q, S, op, "hybrid")
-    qs64 = sk.static_quaternions(tt(sc["verts"]), torch.tensor(sc["faces"]), tt(sc["complex"]))
-    means, rots, _ = sk.face_gaussians(xyz, vrot, torch.tensor(sc["faces"]), qs64)
-    c = syn.make_camera(H, W, elev_deg=0.0, azim_deg=az[a])
+        unit = views.render_views(r, dx, dr, ds, do, static["q_static"], static["scales"], static["opacities"], static["rgb"],
+                                  T(c.viewmatrix)[None], T(c.projmatrix)[None], bg6)
+        hm, hq, hn = ops.face_gaussians(topo, unit["vxyz"][0], unit["vrot"][0], static["q_static"])
     o = orc.RasterOracle(image_height=H, image_width=W, tanfovx=c.tanfov, tanfovy=c.tanfov, bg=(0, 0, 0), scale_modifier=1.0,
                          viewmatrix=c.viewmatrix, projmatrix=c.projmatrix, campos=c.campos)
-    o.forward(means.float().numpy(), static["opacities"].view(-1).cpu().numpy(), colors_precomp=static["rgb"].cpu().numpy(),
-              scales=static["scales"].cpu().numpy(), rotations=rots.float().numpy())
+    o.forward(hm.cpu().numpy(), static["opacities"].view(-1).cpu().numpy(), colors_precomp=static["rgb"].cpu().numpy(),
+              scales=static["scales"].cpu().numpy(), rotations=hq.cpu().numpy())
     want = np.clip(np.moveaxis(o.s["out_color"], 0, -1), 0, 1)
-    assert np.abs(got["comp_rgb"][f, a].cpu().numpy() - want).max() < 2e-3
-    assert np.abs(got["opacity"][f, a, :, :, 0].cpu().numpy() - o.s["out_alpha"]).max() < 2e-3 and (o.s["out_alpha"] > 0.5).mean() > 0.1
+    mine = got["comp_rgb"][f, a].cpu().numpy()
+    assert np.abs(mine - want).max() <= 1e-4 and np.array_equal(mine.view(np.uint32), want.view(np.uint32))      # (in fact bit-identical)
+    assert np.array_equal(got["opacity"][f, a, :, :, 0].cpu().numpy().view(np.uint32), o.s["out_alpha"].view(np.uint32))
+    assert (o.s["out_alpha"] > 0.5).mean() > 0.1
+    o2 = orc.RasterOracle(image_height=H, image_width=W, tanfovx=c.tanfov, tanfovy=c.tanfov, bg=(0, 0, 0), scale_modifier=1.0,
+                          viewmatrix=c.viewmatrix, projmatrix=c.projmatrix, campos=c.campos)
+    o2.forward(hm.cpu().numpy(), static["opacities"].view(-1).cpu().numpy(), colors_precomp=hn.cpu().numpy(),
+               scales=static["scales"].cpu().numpy(), rotations=hq.cpu().numpy())
+    nrm = torch.nn.functional.normalize(torch.tensor(np.moveaxis(o2.s["out_color"], 0, -1)), dim=-1).numpy()
+    want_n = nrm * 0.5 * o.s["out_alpha"][..., None] + 0.5
+    assert np.abs(got["comp_normal"][f, a].cpu().numpy() - want_n).max() <= 1e-4
+    # (ii) the deformation stage of the same unit, float32 on the device against float64 on the host
+    trans, q, S, op = sk.node_attributes(dx[0].cpu().to(D), dr[0].cpu().to(D), ds[0].cpu().to(D), do[0].cpu().to(D).reshape(M, -1))
+    xyz, vrot = sk.skin_vertices(tt(sc["verts"]), torch.tensor(sc["nbr_idx"]), tt(sc["nbr_w"]), trans, q, S, op, "hybrid")
+    assert np.abs(unit["vxyz"][0].cpu().numpy() - xyz.numpy()).max() < 2e-6 and np.abs(unit["vrot"][0].cpu().numpy() - vrot.numpy()).max() < 2e-6
+    qs64 = sk.static_quaternions(tt(sc["verts"]), torch.tensor(sc["faces"]), tt(sc["complex"]))
+    om, oq, on = sk.face_gaussians(unit["vxyz"][0].cpu().to(D), unit["vrot"][0].cpu().to(D), torch.tensor(sc["faces"]), qs64)
+    assert np.abs(hm.cpu().numpy() - om.numpy()).max() < 2e-6 and np.abs(hq.cpu().numpy() - oq.numpy()).max() < 4e-6
     # streaming variant hands the same chunks to the callback
     seen = []
     assert validation.sweep(r, net, nodes, static, ts, azimuths_deg=az, frames_per_call=4,
