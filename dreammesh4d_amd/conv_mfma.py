@@ -1,0 +1,75 @@
+"""3x3 / stride 1 / padding 1 convolution of NHWC float16 activations on the hand-written MFMA implicit-GEMM kernel
+(csrc/conv_mfma.hip, C ABI ``dm4d_conv3x3_nhwc_f16``): the convolutions of the Zero123 UNet (forward only: the guidance model
+runs under ``torch.no_grad``, extern/ldm_zero123/modules/diffusionmodules/openaimodel.py:214-275,429-842).
+
+``conv3x3(x, w_ohwi, bias, residual=None)``: x [N,C,H,W] in torch.channels_last memory format (storage [N][H][W][C]),
+w_ohwi = ``pack_weight(conv.weight)`` ([C_out][3][3][C_in] contiguous: what a channels_last weight tensor already is in
+memory), optional bias [C_out] and residual (same shape / format as the output; the ResBlock's skip connection rides in the
+epilogue).  `conv3x3` itself carries no autograd (the UNet runs under no_grad); `conv3x3_frozen` is the autograd form for
+frozen parameters (the VAE encoder the rendered image is differentiated through, stable_zero123_guidance.py:153-160): its data
+gradient is the same kernel on the flipped, transposed filter."""
+import torch
+
+from . import _lib
+
+def supported(x, w):
+    """Shapes / layouts the kernel takes (everything else stays on the library path)."""
+    return (x.is_cuda and x.dtype == torch.float16 and x.dim() == 4 and x.is_contiguous(memory_format=torch.channels_last)
+            and w.dim() == 4 and tuple(w.shape[2:]) == (3, 3) and w.dtype == torch.float16 and w.shape[1] == x.shape[1]
+            and x.shape[1] % 32 == 0 and w.shape[0] % 32 == 0 and x.shape[0] > 0)
+
+
+def pack_weight(w):
+    """[C_out, C_in, 3, 3] -> [C_out, 3, 3, C_in] contiguous (a no-copy view for a channels_last weight)."""
+    return w.detach().permute(0, 2, 3, 1).contiguous()
+
+
+def conv3x3(x, w_ohwi, bias=None, residual=None):
+    N, Ci, H, W = x.shape
+    Co = int(w_ohwi.shape[0])
+    if not (x.is_cuda and x.dtype == torch.float16 and x.is_contiguous(memory_format=torch.channels_last) and Ci % 32 == 0 and Co % 32 == 0):
+        raise ValueError("conv3x3: x must be a channels_last float16 HIP tensor with C_in and C_out multiples of 32 (see supported())")
+    if tuple(w_ohwi.shape) != (Co, 3, 3, Ci) or not w_ohwi.is_contiguous():
+        raise ValueError(f"conv3x3: weight must be [C_out,3,3,{Ci}] contiguous (pack_weight), got {tuple(w_ohwi.shape)}")
+    if residual is not None and (tuple(residual.shape) != (N, Co, H, W) or not residual.is_contiguous(memory_format=torch.channels_last)
+                                 or residual.dtype != torch.float16):
+        raise ValueError("conv3x3: residual must be a channels_last float16 tensor of the output's shape")
+    L = _lib.lib()
+    y = torch.empty((N, Co, H, W), device=x.device, dtype=torch.float16, memory_format=torch.channels_last)
+    # split-K partial sums of the small problems: from the caching allocator per call (stream-ordered, and a hipGraph capture
+    # gets it from the graph's own pool)
+    buf = torch.empty(L.dm4d_conv3x3_scratch_bytes(N, H, W, Ci, Co), dtype=torch.uint8, device=x.device)
+    with torch.cuda.device(x.device):
+        _lib.check(L.dm4d_conv3x3_nhwc_f16(N, H, W, Ci, Co, x.data_ptr(), w_ohwi.data_ptr(), 0 if bias is None else bias.data_ptr(),
+                                           0 if residual is None else residual.data_ptr(), y.data_ptr(), buf.data_ptr(),
+                                           torch.cuda.current_stream(x.device).cuda_stream), "dm4d_conv3x3_nhwc_f16")
+    return y
+
+
+def pack_weight_transposed(w):
+    """The filter of the DATA GRADIENT: dL/dx = conv3x3(dL/dy, w') with w'[ci][ky][kx][co] = w[co][2 - ky][2 - kx][ci]
+    (stride 1, padding 1): [C_in, 3, 3, C_out] contiguous."""
+    return w.detach().flip(2, 3).permute(1, 2, 3, 0).contiguous()
+
+
+class _Conv3x3Frozen(torch.autograd.Function):
+    """conv3x3 with FROZEN filter and bias (the guidance's VAE encoder: gradients flow to the image only): forward and data
+    gradient both on the MFMA kernel; `residual` passes its gradient through."""
+
+    @staticmethod
+    def forward(ctx, x, w_ohwi, w_t, bias, residual):
+        ctx.save_for_backward(w_t)
+        ctx.has_res = residual is not None
+        return conv3x3(x, w_ohwi, bias, residual)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (w_t,) = ctx.saved_tensors
+        if not dy.is_contiguous(memory_format=torch.channels_last):
+            dy = dy.contiguous(memory_format=torch.channels_last)
+        dx = conv3x3(dy, w_t) if ctx.needs_input_grad[0] else None
+        return dx, None, None, None, (dy if ctx.has_res else None)
+
+
+def conv3x3_frozen(x, w_ohwi, w_t, bias=None, residual=None):
+    return _Conv3x3Frozen.apply(x, w_ohwi, w_t, bias, residual)

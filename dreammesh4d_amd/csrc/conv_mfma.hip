@@ -1,0 +1,672 @@
+// conv_mfma.hip -- 3x3 convolution (stride 1, padding 1) of NHWC float16 activations as an implicit GEMM on the gfx950
+// matrix cores: the convolutions of the Zero123 SDS step (SD-1.x UNet at batch 8 / 32^2 ... 4^2 latents, VAE encoder at batch
+// 4 / 256^2 ... 32^2), where MIOpen's `igemm_fwd_gtcx35_nhwc_fp16` kernels reach 4-17 % of the dense fp16 peak
+// (tools/conv_shapes.py, profiles/r03_zero123.md).
+//
+//     y[p][co] = bias[co] (+ res[p][co]) + sum_{tap, ci} x[pixel(p) + tap][ci] * w[co][tap][ci]
+//
+// GEMM view: M = N H W output pixels, N = C_out, K = 9 C_in; both operands are K-CONTIGUOUS in memory -- an input pixel's
+// channels (NHWC) and a filter's taps x channels (torch's channels_last weight IS [C_out][3][3][C_in]) -- which is exactly the
+// fragment the f16 MFMA wants from a lane (v_mfma_f32_32x32x16_f16: lane l holds 8 consecutive k of row l & 31).  So:
+//   * a k-tile = one tap x 32 channels: 64 contiguous bytes per pixel / per filter, four 16-byte pieces;
+//   * global -> LDS by LDS-DMA (`global_load_lds_dwordx4`: no VGPR round trip, no ds_write -- the write path of the LDS is four
+//     times slower than its read path on this chip), the padding taps read a zero line;
+//   * the DMA lands 64 lanes x 16 B LINEARLY, but the per-lane SOURCE is free: lane -> (row, piece) is chosen so that piece c of row
+//     r sits at slot 4 r + (c ^ ((r >> 2) & 3)), which makes every ds_read_b128 of a fragment (16 lanes = 16 rows, one piece)
+//     hit 16 different 16-byte columns of the 256-byte LDS row: conflict-free (MI355X_MICROARCH.md, LDS lane groups);
+//   * a 3-deep ring of k-tiles, raw s_barrier + counted vmcnt: the DMA of tile k + 2 is in flight while tile k is multiplied;
+//   * workgroup = 4 waves, each a 64 x 64 block of the output tile (2 x 2 MFMA tiles: 4 ds_read_b128 feed 4 MFMAs);
+//   * small problems (the 8^2 and 4^2 levels: 512 / 128 pixels) split K over workgroups; partial sums in float32, reduced
+//     with the epilogue (bias, residual, conversion) by a second kernel.
+// Forward only: the UNet runs without gradients; the data gradient of a stride-1 convolution is the same operator on the
+// flipped / transposed filter.
+#include <stdlib.h>
+#include <type_traits>
+#include "common.h"
+#include "../../include/dm4d.h"
+
+namespace dm4d {
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int kCvBK = 32;            // channels per k-tile (one tap)
+
+__device__ __attribute__((aligned(64))) uint4 g_conv_zero[4];     // the line the padding taps read (never written)
+
+struct ConvDesc {
+    int N, H, W, Cin, Cout, M;       // M = N H W
+    const _Float16 *x, *w, *bias, *res;
+    _Float16 *y;
+    float *partial;                  // [splits][M][Cout] when splits > 1
+    int splits, kt_total, kt_per;    // k-tiles (9 Cin / 32) in all / per split
+    int probe;                       // timing experiments only (-DDM4D_CONV_PROBE, env DM4D_CONV_PROBE): 1 no stores, 2 no MFMA, 4 no DMA
+};
+#ifdef DM4D_CONV_PROBE
+#define CV_PROBE(bit) (cv_probe & (bit))
+#else
+#define CV_PROBE(bit) false
+#endif
+
+// slot (16-byte unit) of piece c of row r in a stage's operand tile
+__device__ __forceinline__ int cv_slot(int r, int c) { return 4 * r + (c ^ ((r >> 2) & 3)); }
+
+// WM x WN waves, each MB x NB MFMA tiles of 32 x 32: workgroup tile (32 MB WM) x (32 NB WN).  What decides the speed of these
+// shapes is the traffic between L2 and the CUs: a k-tile moves (BM + BN) x 64 bytes for BM x BN x 64 flops, i.e. 64 flop/B at
+// 128 x 128 -- 39 TB/s at the MFMA peak, which the L2 does not deliver -- 85 at 256 x 128 and 98 at 256 x 160.
+// ---- epilogue shared by both kernels.  The FILTER fragment is the MFMA's A operand, so D[row][col] has col = lane & 31 = the
+// wave's pixel row (tile row `row_of[i]`), row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5) = output channel: a lane holds 4 consecutive
+// channels of one pixel per register quad.  `pix(row)` maps a tile row to its output pixel (or -1).
+//   split-K: float32 partial sums, one 16-byte store per quad.
+//   else: float16 (+ bias, one rounding) through LDS as [tile row][channel] rows of BN halves + 16 bytes, so that every global
+//   store (and residual load) is 16 bytes per lane, 16 lanes per 256-byte run of a pixel's channels; the residual is added there
+//   (rounded again, like the separate residual add it replaces).
+template <int BM, int BN, int NW, int MB, int NB, class Pix>
+__device__ __forceinline__ void conv_epilogue(const ConvDesc &d, f32x16 (&acc)[MB][NB], const int (&row_of)[MB], int col0, int n0, char *stg, int tid,
+                                              int lane, [[maybe_unused]] int cv_probe, Pix pix)
+{
+    if (d.splits > 1) {
+#pragma unroll
+        for (int i = 0; i < MB; ++i) {
+            const int px = pix(row_of[i]);
+            if (px < 0) continue;
+#pragma unroll
+            for (int j = 0; j < NB; ++j)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int co = n0 + col0 + 32 * j + 8 * q + 4 * (lane >> 5);
+                    if (co >= d.Cout || CV_PROBE(1)) continue;
+                    *reinterpret_cast<float4 *>(d.partial + ((size_t)blockIdx.z * d.M + px) * d.Cout + co) =
+                        make_float4(acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]);
+                }
+        }
+        return;
+    }
+    constexpr int kRowB = BN * 2 + 16;
+    __builtin_amdgcn_s_barrier();                 // every wave is done with the operand buffers the staging tile overlays
+#pragma unroll
+    for (int i = 0; i < MB; ++i)
+#pragma unroll
+        for (int j = 0; j < NB; ++j)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+                const int cl = col0 + 32 * j + 8 * q + 4 * (lane >> 5);             // channel within the tile
+                f16x4 h, bq;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) bq[k] = (_Float16)0.f;
+                if (d.bias && n0 + cl < d.Cout) bq = *reinterpret_cast<const f16x4 *>(d.bias + n0 + cl);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) h[k] = (_Float16)(acc[i][j][4 * q + k] + (float)bq[k]);
+                *reinterpret_cast<f16x4 *>(stg + (size_t)row_of[i] * kRowB + 2 * cl) = h;
+            }
+    __syncthreads();
+    constexpr int kPieces = BN / 8;                         // 16-byte pieces per pixel row
+    constexpr int kRowsPerPass = 64 * NW / kPieces;
+    static_assert((64 * NW) % kPieces == 0, "tile width");
+    const int piece = tid % kPieces, co = n0 + 8 * piece;
+    if (co >= d.Cout) return;
+#pragma unroll 4
+    for (int row = tid / kPieces; row < BM; row += kRowsPerPass) {
+        const int px = pix(row);
+        if (px < 0 || CV_PROBE(1)) continue;
+        f16x8 v = *reinterpret_cast<const f16x8 *>(stg + (size_t)row * kRowB + 16 * piece);
+        const size_t o = (size_t)px * d.Cout + co;
+        if (d.res) {
+            const f16x8 rv = *reinterpret_cast<const f16x8 *>(d.res + o);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] = (_Float16)((float)v[k] + (float)rv[k]);
+        }
+        *reinterpret_cast<f16x8 *>(d.y + o) = v;
+    }
+}
+
+// (the body is a __device__ function: the host pass cannot instantiate a __global__ template that uses the buffer builtins)
+template <int WM, int WN, int MB, int NB, int kCvStages>
+__device__ __forceinline__ void conv3x3_tile(const ConvDesc &d)
+{
+    constexpr int NW = WM * WN, BM = 32 * MB * WM, BN = 32 * NB * WN;
+    constexpr int A_INSTR = (BM * 4 + 64 * NW - 1) / (64 * NW), B_INSTR = (BN * 4 + 64 * NW - 1) / (64 * NW);   // DMA instructions per wave and stage
+    constexpr int A_SLOTS = A_INSTR * 64 * NW, B_SLOTS = B_INSTR * 64 * NW;         // 16-byte slots per stage (rows past BM / BN: padding)
+    extern __shared__ __attribute__((aligned(1024))) uint4 smem[];                  // [stage][A_SLOTS + B_SLOTS]
+    [[maybe_unused]] const int cv_probe = d.probe;
+    if (CV_PROBE(8)) return;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);            // (provably wave-uniform: LDS-DMA bases stay in SGPRs)
+    const int wm = wave % WM, wn = wave / WM;
+    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+    const int kt0 = blockIdx.z * d.kt_per, kt1 = min(d.kt_total, kt0 + d.kt_per);
+    const int HW = d.H * d.W, cpt = d.Cin / kCvBK;                        // k-tiles per tap
+    constexpr unsigned kOob = 0x80000000u;                                // a voffset past every descriptor's range: the DMA writes zeros
+
+    // ---- the DMA's addresses.  The loop must not spend VALU issue slots on them (measured: with MFMA, DMA and stores removed
+    // the old loop still took a third of the kernel -- ~100 scalar / vector instructions per k-tile beside its 8 MFMAs), so:
+    //   source = buffer descriptor (SGPRs) + per-lane byte offset (a VGPR that changes only when the TAP changes) + a
+    //   wave-uniform byte offset (an SGPR, + 64 per k-tile).  The input's descriptor starts (W + 1) pixels BEFORE the tensor so
+    //   that the uniform tap offset ((dy + 1) W + dx + 1) C_in is never negative; a lane whose tap falls outside the image (or
+    //   whose row is past M / C_out) carries kOob and the hardware's range check fills its 16 bytes with zeros.
+    const auto a_rs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<_Float16 *>(d.x) - (size_t)(d.W + 1) * d.Cin, 0, (int)(((size_t)d.M + 2 * d.W + 2) * d.Cin * 2), 0x00020000);
+    const auto b_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16 *>(d.w), 0, (int)((size_t)d.Cout * 9 * d.Cin * 2), 0x00020000);
+    unsigned a_vo[A_INSTR], a_taps[A_INSTR], a_cur[A_INSTR], b_vo[B_INSTR];
+#pragma unroll
+    for (int i = 0; i < A_INSTR; ++i) {
+        const int s = 64 * (wave * A_INSTR + i) + lane, r = s >> 2, c = (s & 3) ^ ((r >> 2) & 3);
+        const int p = m0 + r;
+        const bool ok = r < BM && p < d.M;
+        const int pp = ok ? p : 0, y = (pp % HW) / d.W, x = pp % d.W;
+        a_vo[i] = (unsigned)pp * (unsigned)(d.Cin * 2) + 16u * c;
+        unsigned taps = 0;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int yy = y + tap / 3 - 1, xx = x + tap % 3 - 1;
+            if (ok && (unsigned)yy < (unsigned)d.H && (unsigned)xx < (unsigned)d.W) taps |= 1u << tap;
+        }
+        a_taps[i] = taps;
+    }
+#pragma unroll
+    for (int i = 0; i < B_INSTR; ++i) {
+        const int s = 64 * (wave * B_INSTR + i) + lane, r = s >> 2, c = (s & 3) ^ ((r >> 2) & 3);
+        const int co = n0 + r;
+        b_vo[i] = (r < BN && co < d.Cout) ? (unsigned)co * (unsigned)(9 * d.Cin * 2) + 16u * c : kOob;
+    }
+    // the issue stream's position: tap, chunk and the two uniform offsets
+    int is_tap = kt0 / cpt, is_chunk = kt0 % cpt;
+    int is_a = ((is_tap / 3) * d.W + is_tap % 3) * d.Cin * 2 + is_chunk * (kCvBK * 2);
+    int is_b = (is_tap * d.Cin + is_chunk * kCvBK) * 2;
+    auto set_tap = [&]() {
+#pragma unroll
+        for (int i = 0; i < A_INSTR; ++i) a_cur[i] = ((a_taps[i] >> is_tap) & 1u) ? a_vo[i] : kOob;
+    };
+    set_tap();
+    constexpr int kStageSlots = A_SLOTS + B_SLOTS;
+    auto issue = [&](int stage) {       // the next k-tile of the stream into `stage`
+        if (!(CV_PROBE(4))) {
+            uint4 *sa = smem + stage * kStageSlots, *sb = sa + A_SLOTS;
+#pragma unroll
+            for (int i = 0; i < A_INSTR; ++i)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rs, (__attribute__((address_space(3))) void *)(sa + 64 * (wave * A_INSTR + i)), 16, a_cur[i], is_a, 0, 0);
+#pragma unroll
+            for (int i = 0; i < B_INSTR; ++i)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(b_rs, (__attribute__((address_space(3))) void *)(sb + 64 * (wave * B_INSTR + i)), 16, b_vo[i], is_b, 0, 0);
+        }
+        is_a += kCvBK * 2;
+        is_b += kCvBK * 2;
+        if (++is_chunk == cpt) {        // next tap: same channels from the start, the pixel one to the right (or a row down)
+            is_chunk = 0;
+            ++is_tap;
+            is_a = ((is_tap / 3) * d.W + is_tap % 3) * d.Cin * 2;
+            set_tap();
+        }
+    };
+
+    f32x16 acc[MB][NB];
+#pragma unroll
+    for (int i = 0; i < MB; ++i)
+#pragma unroll
+        for (int j = 0; j < NB; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // ---- main loop.  A k-tile is two MFMA k-steps (ks = 0, 1: 16 channels each).  The fragments of the NEXT half step are read
+    // from LDS while the MFMAs of the current one run (two register sets).  One barrier per k-tile, in the MIDDLE of it: before
+    // it every wave has issued all its reads of tile t and consumed those of tile t - 1, so after it the DMA of tile t + S - 1 may
+    // overwrite the stage of tile t - 1, and tile t + 1 -- issued S - 2 tiles ago -- has landed for everyone.  The loop is
+    // unrolled over the ring so that every LDS address is a register + an immediate.
+    f16x8 ra[2][MB] = {}, rb[2][NB] = {};
+    int a_row[MB], b_row[NB];
+#pragma unroll
+    for (int i = 0; i < MB; ++i) a_row[i] = 32 * (MB * wm + i) + (lane & 31);
+#pragma unroll
+    for (int j = 0; j < NB; ++j) b_row[j] = 32 * (NB * wn + j) + (lane & 31);
+    unsigned fa[2][MB], fb[2][NB];                         // the lane's fragment addresses (LDS bytes) in stage 0
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) uint4 *)smem;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+        for (int i = 0; i < MB; ++i) fa[ks][i] = lds0 + 16u * cv_slot(a_row[i], 2 * ks + (lane >> 5));
+#pragma unroll
+        for (int j = 0; j < NB; ++j) fb[ks][j] = lds0 + 16u * (A_SLOTS + cv_slot(b_row[j], 2 * ks + (lane >> 5)));
+    }
+    auto read = [&](auto KS, auto STAGE) {
+        constexpr int ks = decltype(KS)::value, stage = decltype(STAGE)::value;
+        if (CV_PROBE(64)) return;
+#pragma unroll
+        for (int i = 0; i < MB; ++i) ra[ks][i] = *reinterpret_cast<const __attribute__((address_space(3))) f16x8 *>(fa[ks][i] + stage * (kStageSlots * 16));
+#pragma unroll
+        for (int j = 0; j < NB; ++j) rb[ks][j] = *reinterpret_cast<const __attribute__((address_space(3))) f16x8 *>(fb[ks][j] + stage * (kStageSlots * 16));
+    };
+    // the FILTER fragment is the MFMA's A operand: D[row = filter][col = pixel], so a lane ends up with 4 consecutive output
+    // channels of one pixel per register quad (the epilogue packs them)
+    auto mma = [&](auto KS) {
+        constexpr int ks = decltype(KS)::value;
+        if (CV_PROBE(2)) { acc[0][0][0] += (float)ra[ks][0][0] + (float)rb[ks][0][0]; return; }
+#pragma unroll
+        for (int i = 0; i < MB; ++i)
+#pragma unroll
+            for (int j = 0; j < NB; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(rb[ks][j], ra[ks][i], acc[i][j], 0, 0, 0);
+    };
+    using K0 = std::integral_constant<int, 0>;
+    using K1 = std::integral_constant<int, 1>;
+
+    constexpr int S = kCvStages;
+    constexpr int kPerStage = A_INSTR + B_INSTR;          // DMA instructions a wave has in flight per k-tile
+    static_assert(S >= 3 && S <= 4, "ring depth");
+    const int nk = CV_PROBE(16) ? 1 : kt1 - kt0;
+#pragma unroll
+    for (int p = 0; p < S - 1; ++p)
+        if (p < nk) issue(p);
+    {   // tile 0 has landed; tiles 1 .. S - 2 may be in flight
+        const int fly = min(S - 2, nk - 1);
+        if (fly >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * kPerStage) : "memory");
+        else if (fly == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kPerStage) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+    if (nk > 0) read(K0{}, std::integral_constant<int, 0>{});
+    // tile t (not the last) in ring stage U = t % S
+    auto body = [&](auto U, int t) {
+        constexpr int u = decltype(U)::value;
+        read(K1{}, U);
+        __builtin_amdgcn_sched_barrier(0);      // reads first, THEN the MFMAs they overlap with (the scheduler otherwise sinks them to 1-2 MFMAs before their use)
+        mma(K0{});
+        if (S == 4 && t + 2 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kPerStage) : "memory");     // tile t + 2 may be in flight
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (!CV_PROBE(32)) __builtin_amdgcn_s_barrier();
+        if (t + S - 1 < nk) issue((u + S - 1) % S);
+        read(K0{}, std::integral_constant<int, (u + 1) % S>{});
+        __builtin_amdgcn_sched_barrier(0);
+        mma(K1{});
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    auto tail = [&](auto U) {           // the last tile: nothing left to fetch
+        read(K1{}, U);
+        mma(K0{});
+        mma(K1{});
+    };
+    int t = 0;
+    for (; t + S < nk; t += S) {
+        body(std::integral_constant<int, 0>{}, t);
+        body(std::integral_constant<int, 1>{}, t + 1);
+        body(std::integral_constant<int, 2>{}, t + 2);
+        if constexpr (S == 4) body(std::integral_constant<int, 3>{}, t + 3);
+    }
+    // 1 .. S tiles left, starting in stage 0
+    if (nk > 0) {
+        const int left = nk - t;
+        if (left == 1) tail(std::integral_constant<int, 0>{});
+        else {
+            body(std::integral_constant<int, 0>{}, t);
+            if (left == 2) tail(std::integral_constant<int, 1>{});
+            else {
+                body(std::integral_constant<int, 1>{}, t + 1);
+                if (left == 3) tail(std::integral_constant<int, 2>{});
+                else if constexpr (S == 4) {
+                    body(std::integral_constant<int, 2>{}, t + 2);
+                    tail(std::integral_constant<int, 3>{});
+                }
+            }
+        }
+    }
+
+    static_assert((size_t)BM * (BN * 2 + 16) <= (size_t)kCvStages * (A_SLOTS + B_SLOTS) * 16, "epilogue staging does not fit the ring");
+    conv_epilogue<BM, BN, NW>(d, acc, a_row, 32 * NB * wn, n0, reinterpret_cast<char *>(smem), tid, lane, cv_probe,
+                              [&](int row) { const int px = m0 + row; return px < d.M ? px : -1; });
+}
+
+template <int WM, int WN, int MB, int NB, int kCvStages>
+__global__ __launch_bounds__(64 * WM * WN) void k_conv3x3(ConvDesc d)
+{
+    conv3x3_tile<WM, WN, MB, NB, kCvStages>(d);
+}
+
+// ---------------------------------------------------------------------------------------- direct variant
+// The implicit-GEMM kernel fetches every input pixel NINE times (once per tap), and what its loop is short of is DMA ISSUE
+// slots: a 1 KB LDS-DMA piece costs a wave ~60-180 cycles of issue (MI355X_MICROARCH.md), a 128 x 128 x 32 k-tile is 16 of
+// them for 8 MFMAs per wave.  Here the workgroup's 256 output pixels are a TH x TW block of the image (TW = min(W, 32), TH =
+// 256 / TW; rows are GLOBAL rows g = n H + y, so at W = 8 the block spans 4 images) and their (TH + 2) x (TW + 2) input PATCH
+// of one 32-channel chunk is brought into LDS once for all nine taps: a tap only shifts the patch pixel a fragment row reads.
+// Per k-tile that is 8 pieces of filters + 1/9 of <= 22 KB of patch for 256 x 128 x 32 MACs: 10.4 pieces per 64 MFMAs instead
+// of 24 (256 x 128 implicit GEMM).
+//   8 waves (4 x 2), each 64 x 64; filters: ring of 9 (tap, chunk) tiles (stage = tap: compile time in the unrolled tap loop), fetched
+//   4 k-tiles ahead (with one workgroup of 227 registers per CU nothing else hides the L2 latency);
+//   patch: double buffer, the next chunk's 3 pieces per wave issued at taps 0, 1, 2 of the current chunk; fragments of the next
+//   half k-tile are read while the MFMAs of the current one run; one barrier per k-tile, in its middle (see conv3x3_tile).
+//   Addresses: buffer descriptors + per-lane offsets that never change + wave-uniform SGPR offsets -- no VALU in the loop for
+//   the DMA.  A fragment row whose tap crosses the top / bottom of its image reads a ZERO region in front of each patch buffer
+//   (its patch pixel index is set to -2: the +-1 of the horizontal taps stays inside the 256 zero bytes); left / right image
+//   borders and rows past the tensor are zeros in the patch itself (the descriptor's range check).
+//   W a power of two >= 8 (conv_plan sends everything else to the implicit GEMM).
+constexpr int kDirPieces = 3;                                   // patch pieces per wave: 3 x 8 x 64 lanes / 4 = 384 pixels >= 34 x 10
+constexpr int kDirPatchSlots = kDirPieces * 512;
+constexpr int kDirZeroSlots = 16;                               // 256 bytes of zeros in front of each patch buffer
+constexpr int kDirBSlots = 512;
+constexpr int kDirRing = 9;                                     // filter ring: one stage per tap
+constexpr int kDirAhead = 4;                                    // filter tiles in flight ahead of the one being multiplied
+constexpr int kDirLdsSlots = 2 * (kDirZeroSlots + kDirPatchSlots) + kDirRing * kDirBSlots;
+
+// DMA instructions a wave issues in the iteration of tap `tap` (more: a chunk follows this one)
+constexpr int dir_issues(int tap, bool more) { return ((tap < kDirPieces && more) ? 1 : 0) + ((tap + kDirAhead < 9 || more) ? 1 : 0); }
+// ... and how many it may leave in flight at the barrier of tap `tap`: everything issued after the filters of k-tile + 1, i.e. in the
+// previous kDirAhead - 2 iterations (those before tap 0 belong to the previous chunk, which had a successor)
+constexpr int dir_in_flight(int tap, bool more)
+{
+    int n = 0;
+    for (int k = 1; k <= kDirAhead - 2; ++k) n += tap - k >= 0 ? dir_issues(tap - k, more) : dir_issues(tap - k + 9, true);
+    return n;
+}
+
+__device__ __forceinline__ void conv3x3_direct_tile(const ConvDesc &d, int chunks_per_split, int lgTW)
+{
+    constexpr int BM = 256, BN = 128, NW = 8;
+    extern __shared__ __attribute__((aligned(1024))) uint4 smem[];
+    [[maybe_unused]] const int cv_probe = d.probe;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave & 3, wn = wave >> 2;
+    const int W = d.W, TW = 1 << lgTW, PW = TW + 2, TH = BM >> lgTW, R = d.N * d.H;
+    const int ncb = W >> lgTW, rblk = blockIdx.x / ncb, cb = blockIdx.x - rblk * ncb;
+    const int g0 = rblk * TH, x0 = cb << lgTW, n0 = blockIdx.y * BN;
+    const int cpt = d.Cin / kCvBK;
+    const int ch0 = blockIdx.z * chunks_per_split, nch = min(cpt, ch0 + chunks_per_split) - ch0;
+    const int patch_px = (TH + 2) * PW;
+    constexpr unsigned kOob = 0x80000000u;
+    // LDS: [zeros | patch 0 | zeros | patch 1 | filter ring]
+    uint4 *const s_patch0 = smem + kDirZeroSlots;
+    constexpr int kPatchStride = kDirZeroSlots + kDirPatchSlots;          // slots from patch 0 to patch 1
+    uint4 *const s_b = smem + 2 * kPatchStride;                           // [kDirRing][kDirBSlots]
+    if (tid < kDirZeroSlots) { smem[tid] = make_uint4(0u, 0u, 0u, 0u); smem[kPatchStride + tid] = make_uint4(0u, 0u, 0u, 0u); }
+
+    const auto a_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16 *>(d.x) - (size_t)(W + 1) * d.Cin, 0,
+                                                        (int)(((size_t)d.M + 2 * W + 2) * d.Cin * 2), 0x00020000);
+    const auto b_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16 *>(d.w), 0, (int)((size_t)d.Cout * 9 * d.Cin * 2), 0x00020000);
+    // patch piece i of this lane: pixel q of the patch, 16-byte piece c (swizzled like every operand tile)
+    unsigned p_vo[kDirPieces];
+#pragma unroll
+    for (int i = 0; i < kDirPieces; ++i) {
+        const int s = 64 * (wave * kDirPieces + i) + lane, q = s >> 2, c = (s & 3) ^ ((q >> 2) & 3);
+        const int pr = q / PW, pc = q - pr * PW;
+        const int g = g0 - 1 + pr, x = x0 - 1 + pc;
+        const bool ok = q < patch_px && (unsigned)x < (unsigned)W && (unsigned)g < (unsigned)R;
+        p_vo[i] = ok ? (unsigned)((g + 1) * W + x + 1) * (unsigned)(d.Cin * 2) + 16u * c : kOob;       // (descriptor starts W + 1 pixels early)
+    }
+    unsigned b_vo;
+    {
+        const int s = 64 * wave + lane, r = s >> 2, c = (s & 3) ^ ((r >> 2) & 3);
+        const int co = n0 + r;
+        b_vo = co < d.Cout ? (unsigned)co * (unsigned)(9 * d.Cin * 2) + 16u * c : kOob;
+    }
+    const int cin2 = d.Cin * 2;
+    auto issue_patch = [&](int piece, int buf, int chunk) {              // chunk: relative to ch0
+        if (CV_PROBE(4)) return;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rs, (__attribute__((address_space(3))) void *)(s_patch0 + buf * kPatchStride + 64 * (wave * kDirPieces + piece)),
+                                                 16, p_vo[piece], (ch0 + chunk) * (kCvBK * 2), 0, 0);
+    };
+    auto issue_b = [&](int tap, int stage, int chunk) {
+        if (CV_PROBE(4)) return;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(b_rs, (__attribute__((address_space(3))) void *)(s_b + stage * kDirBSlots + 64 * wave), 16, b_vo,
+                                                 tap * cin2 + (ch0 + chunk) * (kCvBK * 2), 0, 0);
+    };
+
+    // ---- fragment rows of this lane: patch pixel for the three tap rows (dy = -1, 0, +1), -2 where the tap row is outside the image
+    int row_of[2], qa[2][3];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int r = 64 * wm + 32 * i + (lane & 31), tr = r >> lgTW, tc = r & (TW - 1);
+        const int g = g0 + tr, y = g % d.H;
+        const bool row_ok = g < R;
+        const int q = (tr + 1) * PW + tc + 1;
+        row_of[i] = r;
+        qa[i][0] = (row_ok && y > 0) ? q - PW : -2;
+        qa[i][1] = row_ok ? q : -2;
+        qa[i][2] = (row_ok && y < d.H - 1) ? q + PW : -2;
+    }
+    const int hi = lane >> 5;
+    unsigned fb[2][2];                                      // filter fragment byte addresses in ring stage 0
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+            fb[ks][j] = (unsigned)(size_t)(__attribute__((address_space(3))) uint4 *)(s_b + cv_slot(64 * wn + 32 * j + (lane & 31), 2 * ks + hi));
+    const unsigned pb0 = (unsigned)(size_t)(__attribute__((address_space(3))) uint4 *)s_patch0;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    f16x8 ra[2][2] = {}, rb[2][2] = {};
+    // fragments of half step ks of tap TAP from patch buffer at byte address `pbase`, filter stage TAP % 3
+    auto read = [&](auto KS, auto TAP, unsigned pbase) {
+        constexpr int ks = decltype(KS)::value, tap = decltype(TAP)::value, dyi = tap / 3, dx = tap % 3 - 1;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int q = qa[i][dyi] + dx;
+            const unsigned a = pbase + 16u * (unsigned)(4 * q + ((2 * ks + hi) ^ ((q >> 2) & 3)));
+            ra[ks][i] = *reinterpret_cast<const __attribute__((address_space(3))) f16x8 *>(a);
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+            rb[ks][j] = *reinterpret_cast<const __attribute__((address_space(3))) f16x8 *>(fb[ks][j] + tap * (kDirBSlots * 16));
+    };
+    auto mma = [&](auto KS) {
+        constexpr int ks = decltype(KS)::value;
+        if (CV_PROBE(2)) { acc[0][0][0] += (float)ra[ks][0][0] + (float)rb[ks][0][0]; return; }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(rb[ks][j], ra[ks][i], acc[i][j], 0, 0, 0);
+    };
+    using K0 = std::integral_constant<int, 0>;
+    using K1 = std::integral_constant<int, 1>;
+#define DM4D_TAP(n) std::integral_constant<int, n>{}
+
+    // prologue: the first patch, the first kDirAhead filter tiles
+    if (nch > 0) {
+#pragma unroll
+        for (int i = 0; i < kDirPieces; ++i) issue_patch(i, 0, 0);
+#pragma unroll
+        for (int k = 0; k < kDirAhead; ++k) issue_b(k, k, 0);
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kDirAhead - 1) : "memory");
+    }
+    __syncthreads();                                        // (also publishes the zero regions)
+    if (nch > 0) read(K0{}, DM4D_TAP(0), pb0);
+    // k-tile (chunk ch, tap TAP), not the last one: its second half, the barrier, the DMA of k-tile + kDirAhead (and of a piece of the
+    // next patch, BEFORE it: the DMA retires in order), the first half of k-tile + 1
+    auto body = [&](auto TAP, int ch, unsigned pcur, unsigned pnext, bool more) {
+        constexpr int tap = decltype(TAP)::value;
+        read(K1{}, TAP, pcur);
+        __builtin_amdgcn_sched_barrier(0);      // reads first, THEN the MFMAs they overlap with (the scheduler otherwise sinks them to 1-2 MFMAs before their use)
+        mma(K0{});
+        // k-tile + 1's filters (and every patch piece issued before them) have landed
+        if (more) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(dir_in_flight(tap, true)) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(dir_in_flight(tap, false)) : "memory");
+        __builtin_amdgcn_s_barrier();
+        if (tap < kDirPieces && more) issue_patch(tap, (ch + 1) & 1, ch + 1);
+        if (tap + kDirAhead < 9) issue_b(tap + kDirAhead, tap + kDirAhead, ch);
+        else if (more) issue_b(tap + kDirAhead - 9, tap + kDirAhead - 9, ch + 1);
+        read(K0{}, std::integral_constant<int, (tap + 1) % 9>{}, tap == 8 ? pnext : pcur);
+        __builtin_amdgcn_sched_barrier(0);
+        mma(K1{});
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    for (int ch = 0; ch < nch; ++ch) {
+        const unsigned pcur = pb0 + (unsigned)(ch & 1) * (kPatchStride * 16), pnext = pb0 + (unsigned)((ch + 1) & 1) * (kPatchStride * 16);
+        const bool more = ch + 1 < nch;
+        body(DM4D_TAP(0), ch, pcur, pnext, more);
+        body(DM4D_TAP(1), ch, pcur, pnext, more);
+        body(DM4D_TAP(2), ch, pcur, pnext, more);
+        body(DM4D_TAP(3), ch, pcur, pnext, more);
+        body(DM4D_TAP(4), ch, pcur, pnext, more);
+        body(DM4D_TAP(5), ch, pcur, pnext, more);
+        body(DM4D_TAP(6), ch, pcur, pnext, more);
+        body(DM4D_TAP(7), ch, pcur, pnext, more);
+        if (more) body(DM4D_TAP(8), ch, pcur, pnext, more);
+        else {                                              // the last k-tile: nothing left to fetch
+            read(K1{}, DM4D_TAP(8), pcur);
+            mma(K0{});
+            mma(K1{});
+        }
+    }
+#undef DM4D_TAP
+    static_assert((size_t)BM * (BN * 2 + 16) <= (size_t)kDirLdsSlots * 16, "epilogue staging does not fit");
+    conv_epilogue<BM, BN, NW>(d, acc, row_of, 64 * wn, n0, reinterpret_cast<char *>(smem), tid, lane, cv_probe, [&](int row) {
+        const int g = g0 + (row >> lgTW);
+        return g < R ? g * W + x0 + (row & (TW - 1)) : -1;
+    });
+}
+
+__global__ __launch_bounds__(512) void k_conv3x3_direct(ConvDesc d, int chunks_per_split, int lgTW)
+{
+    conv3x3_direct_tile(d, chunks_per_split, lgTW);
+}
+
+// y = sum over splits of partial + bias (+ res), 8 outputs per thread
+__global__ __launch_bounds__(256) void k_conv_reduce(ConvDesc d)
+{
+    const size_t e = ((size_t)blockIdx.x * 256 + threadIdx.x) * 8, total = (size_t)d.M * d.Cout;
+    if (e >= total) return;
+    float v[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] = 0.f;
+    for (int s = 0; s < d.splits; ++s) {
+        const float4 *p = reinterpret_cast<const float4 *>(d.partial + (size_t)s * total + e);
+        const float4 a = p[0], b = p[1];
+        v[0] += a.x; v[1] += a.y; v[2] += a.z; v[3] += a.w; v[4] += b.x; v[5] += b.y; v[6] += b.z; v[7] += b.w;
+    }
+    const int co = (int)(e % d.Cout);       // Cout is a multiple of 8: the 8 outputs share a pixel
+    f16x8 out;
+    f16x8 bv, rv;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { bv[k] = (_Float16)0.f; rv[k] = (_Float16)0.f; }
+    if (d.bias) bv = *reinterpret_cast<const f16x8 *>(d.bias + co);
+    if (d.res) rv = *reinterpret_cast<const f16x8 *>(d.res + e);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) out[k] = (_Float16)(v[k] + (float)bv[k] + (float)rv[k]);
+    *reinterpret_cast<f16x8 *>(d.y + e) = out;
+}
+
+// tile configurations (DM4D_CONV_CFG): 0: 128 x 128, 4 waves of 64 x 64, 3-deep ring | 3: the same, 4-deep | 4: 128 x 128, 8 waves of
+// 32 x 64 | 6: the same, 4-deep | 5: 256 x 128, 8 waves of 64 x 64, 3-deep | 8: the same, 4-deep | 7: the direct kernel (256 x 128)
+static void cfg_tile(int cfg, int &BM, int &BN)
+{
+    BM = (cfg == 1 || cfg == 5 || cfg == 7 || cfg == 8) ? 256 : 128;
+    BN = 128;
+}
+static int conv_plan(int M, int W, int Cout, int kt_total, int &cfg, int &splits)
+{
+    const char *force = getenv("DM4D_CONV_CFG");
+    if (force) cfg = atoi(force);
+    // measured per shape (tools/conv_shapes.py, profiles/r03_zero123.md): the direct kernel wins on the VAE encoder's wide images
+    // (W >= 64: 1.3-1.5x), the 128 x 128 implicit GEMM with two 4-wave workgroups per CU is as fast or faster everywhere else
+    else if (W >= 64 && (W & (W - 1)) == 0) cfg = 7;
+    else cfg = 3;
+    int BM, BN;
+    cfg_tile(cfg, BM, BN);
+    const long tiles = (long)((M + BM - 1) / BM) * ((Cout + BN - 1) / BN);
+    splits = 1;
+    const char *fs = getenv("DM4D_CONV_SPLITS");
+    if (fs) splits = atoi(fs);
+    else {
+        // split K only until every CU has ONE workgroup, and never below 30 k-tiles per workgroup: the float32 partial sums cost
+        // splits x M x C_out x 8 bytes of traffic and a second launch (measured optimum on the UNet's 4^2 .. 16^2 levels,
+        // tools/scratch/conv_splits.py: 12 / 24 splits at 4^2, 6 at 8^2, 3 at 16^2, none at 32^2)
+        splits = (int)(256 / tiles);
+        if (splits > kt_total / 30) splits = kt_total / 30;
+    }
+    if (splits < 1) splits = 1;
+    if (splits > 64) splits = 64;
+    return 0;
+}
+
+template <int WM, int WN, int MB, int NB, int kCvStages>
+static int conv_launch(const ConvDesc &d, hipStream_t st)
+{
+    constexpr int NW = WM * WN, BM = 32 * MB * WM, BN = 32 * NB * WN;
+    constexpr int A_INSTR = (BM * 4 + 64 * NW - 1) / (64 * NW), B_INSTR = (BN * 4 + 64 * NW - 1) / (64 * NW);
+    const size_t lds = (size_t)kCvStages * (A_INSTR + B_INSTR) * 64 * NW * 16;
+    const dim3 grid((d.M + BM - 1) / BM, (d.Cout + BN - 1) / BN, d.splits);
+    DM4D_HIP_CHECK(hipFuncSetAttribute((const void *)k_conv3x3<WM, WN, MB, NB, kCvStages>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL((k_conv3x3<WM, WN, MB, NB, kCvStages>), grid, dim3(64 * NW), lds, st, d);
+    DM4D_HIP_CHECK(hipGetLastError());
+    return DM4D_OK;
+}
+
+}  // namespace dm4d
+
+using namespace dm4d;
+
+extern "C" {
+
+size_t dm4d_conv3x3_scratch_bytes(int32_t N, int32_t H, int32_t W, int32_t Cin, int32_t Cout)
+{
+    if (N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return 256;
+    int cfg, splits;
+    conv_plan(N * H * W, W, Cout, 9 * Cin / kCvBK, cfg, splits);
+    return splits > 1 ? (size_t)splits * N * H * W * Cout * 4 + 256 : 256;
+}
+
+int dm4d_conv3x3_nhwc_f16(int32_t N, int32_t H, int32_t W, int32_t Cin, int32_t Cout, const void *x, const void *w, const void *bias,
+                          const void *residual, void *y, void *scratch, dm4d_stream_t stream)
+{
+    if (N < 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) { set_error("conv3x3: bad shape"); return DM4D_ERR_INVALID; }
+    if (N == 0) return DM4D_OK;
+    if (Cin % kCvBK != 0 || Cout % 8 != 0) { set_error("conv3x3: C_in must be a multiple of %d and C_out of 8 (got %d, %d)", kCvBK, Cin, Cout); return DM4D_ERR_UNSUPPORTED; }
+    if ((int64_t)N * H * W > 0x7FFFFFFF / 4) { set_error("conv3x3: too many pixels"); return DM4D_ERR_UNSUPPORTED; }
+    if (!x || !w || !y) { set_error("conv3x3: null tensor"); return DM4D_ERR_INVALID; }
+    if ((((uintptr_t)x | (uintptr_t)w | (uintptr_t)y | (uintptr_t)bias | (uintptr_t)residual) & 15) != 0) { set_error("conv3x3: tensors must be 16-byte aligned"); return DM4D_ERR_INVALID; }
+    ConvDesc d;
+    d.N = N; d.H = H; d.W = W; d.Cin = Cin; d.Cout = Cout; d.M = N * H * W;
+    d.x = (const _Float16 *)x; d.w = (const _Float16 *)w; d.bias = (const _Float16 *)bias; d.res = (const _Float16 *)residual;
+    d.y = (_Float16 *)y;
+    d.kt_total = 9 * Cin / kCvBK;
+    d.probe = 0;
+#ifdef DM4D_CONV_PROBE
+    if (const char *pe = getenv("DM4D_CONV_PROBE")) d.probe = atoi(pe);
+#endif
+    int cfg;
+    conv_plan(d.M, W, Cout, d.kt_total, cfg, d.splits);
+    d.kt_per = (d.kt_total + d.splits - 1) / d.splits;
+    d.splits = (d.kt_total + d.kt_per - 1) / d.kt_per;
+    d.partial = (float *)scratch;
+    if (d.splits > 1 && !scratch) { set_error("conv3x3: this shape needs the split-K scratch (dm4d_conv3x3_scratch_bytes)"); return DM4D_ERR_INVALID; }
+    hipStream_t st = (hipStream_t)stream;
+    int rc;
+    switch (cfg) {
+    case 0: rc = conv_launch<2, 2, 2, 2, 3>(d, st); break;
+    case 1: rc = conv_launch<2, 2, 4, 2, 3>(d, st); break;       // 256 x 128, 4 waves of 128 x 64, 3-deep (two workgroups per CU)
+    case 3: rc = conv_launch<2, 2, 2, 2, 4>(d, st); break;
+    case 4: rc = conv_launch<4, 2, 1, 2, 3>(d, st); break;
+    case 6: rc = conv_launch<4, 2, 1, 2, 4>(d, st); break;
+    case 5: rc = conv_launch<4, 2, 2, 2, 3>(d, st); break;
+    case 8: rc = conv_launch<4, 2, 2, 2, 4>(d, st); break;
+    case 7: {      // direct: 256 pixels x 128 filters, the input patch resident in LDS for the nine taps
+        const int W_ = d.W;
+        if (W_ < 8 || (W_ & (W_ - 1)) != 0) { set_error("conv3x3 direct: W must be a power of two >= 8"); return DM4D_ERR_UNSUPPORTED; }
+        int lgTW = 3;
+        while ((1 << lgTW) < W_ && lgTW < 5) ++lgTW;                       // TW = min(W, 32)
+        const int TH = 256 >> lgTW, R = d.N * d.H, cpt = d.Cin / kCvBK;
+        const size_t lds = (size_t)kDirLdsSlots * 16;
+        const int chunks_per_split = (cpt + d.splits - 1) / d.splits;
+        d.splits = (cpt + chunks_per_split - 1) / chunks_per_split;
+        const dim3 grid((unsigned)(((R + TH - 1) / TH) * (W_ >> lgTW)), (d.Cout + 127) / 128, d.splits);
+        DM4D_HIP_CHECK(hipFuncSetAttribute((const void *)k_conv3x3_direct, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(k_conv3x3_direct, grid, dim3(512), lds, st, d, chunks_per_split, lgTW);
+        DM4D_HIP_CHECK(hipGetLastError());
+        rc = DM4D_OK;
+        break;
+    }
+    default: set_error("conv3x3: bad configuration %d", cfg); return DM4D_ERR_INVALID;
+    }
+    if (rc) return rc;
+    if (d.splits > 1) {
+        const size_t total = (size_t)d.M * Cout;
+        hipLaunchKernelGGL(k_conv_reduce, dim3((unsigned)((total / 8 + 255) / 256)), dim3(256), 0, st, d);
+        DM4D_HIP_CHECK(hipGetLastError());
+    }
+    return DM4D_OK;
+}
+
+}  // extern "C"

@@ -25,6 +25,7 @@ load/zero123/download.sh).  Architecture parity is pinned by tests/golden/zero12
 reduced-width UNet and encoder of the REFERENCE code, filled by a name-seeded recipe both sides share.
 """
 import math
+import os
 
 import torch
 import torch.nn as nn
@@ -62,6 +63,40 @@ def _conv_nobias(conv, x):
     return F.conv2d(x, conv.weight, None, conv.stride, conv.padding)
 
 
+_USE_MFMA_CONV = os.environ.get("DM4D_MFMA_CONV", "1") != "0"      # (A/B switch: "0" keeps every convolution on the library)
+
+
+def _conv3x3(conv, x, bias=True, residual=None):
+    """A 3x3 / stride 1 / padding 1 convolution (+ bias, + residual) with FROZEN parameters (the guidance model is not
+    trained).  On a HIP device with channels-last float16 activations: the hand-written MFMA implicit-GEMM kernel
+    (csrc/conv_mfma.hip), bias and residual in its epilogue -- without autograd in the UNet, with the data gradient on the same
+    kernel (transposed, flipped filter) in the VAE encoder.  Anything else: the library convolution, literally as the
+    reference writes it."""
+    from . import conv_mfma
+
+    w = conv.weight
+    frozen = not (w.requires_grad or (conv.bias is not None and conv.bias.requires_grad))
+    if (_USE_MFMA_CONV and frozen and conv.stride == (1, 1) and conv.padding == (1, 1) and conv.dilation == (1, 1) and conv.groups == 1
+            and conv_mfma.supported(x, w) and (residual is None or (residual.dtype == x.dtype and residual.shape[1] == w.shape[0]))):
+        need_grad = torch.is_grad_enabled() and (x.requires_grad or (residual is not None and residual.requires_grad))
+        key = (w.data_ptr(), w._version)
+        packed = getattr(conv, "_dm4d_ohwi", None)
+        if packed is None or packed[0] != key:
+            packed = conv._dm4d_ohwi = [key, conv_mfma.pack_weight(w), None]
+        b = conv.bias if bias else None
+        res = None if residual is None else _to_nhwc(residual)
+        if not need_grad:
+            return conv_mfma.conv3x3(x, packed[1], b, res)
+        if w.shape[1] % 32 == 0 and w.shape[0] % 32 == 0:          # the data gradient swaps the channel counts
+            if packed[2] is None:
+                packed[2] = conv_mfma.pack_weight_transposed(w)
+            return conv_mfma.conv3x3_frozen(x, packed[1], packed[2], b, res)
+    if residual is not None and bias and _fold_bias(conv, x):
+        return add_bias(residual, _conv_nobias(conv, x), conv.bias)      # (one fused kernel for skip + bias)
+    y = F.conv2d(x, w, conv.bias if bias else None, conv.stride, conv.padding)
+    return y if residual is None else residual + y
+
+
 def _conv1x1(conv, x):
     """A 1x1 convolution; on a channels-last tensor a GEMM over the [B, H*W, C] token view of the same memory."""
     if x.is_cuda and is_channels_last(x):
@@ -87,7 +122,7 @@ class Upsample(nn.Module):
         self.conv = nn.Conv2d(ch, ch, 3, padding=1)
 
     def forward(self, x):
-        return self.conv(F.interpolate(x, scale_factor=2, mode="nearest"))
+        return _conv3x3(self.conv, F.interpolate(x, scale_factor=2, mode="nearest"))
 
 
 class Downsample(nn.Module):
@@ -116,8 +151,8 @@ class ResBlock(nn.Module):
         skip = x if isinstance(self.skip_connection, nn.Identity) else _conv1x1(self.skip_connection, x)
         # h + emb[:, :, None, None], GroupNorm, SiLU (openaimodel.py:259-275) in one operator; Dropout(0) is the identity
         if _fold_bias(conv1, h):
-            h = group_norm(self.out_layers[0], _conv_nobias(conv1, h), silu=True, add=self.emb_layers(emb) + conv1.bias, float32=True)
-            return add_bias(skip, _conv_nobias(conv2, h), conv2.bias)
+            h = group_norm(self.out_layers[0], _conv3x3(conv1, h, bias=False), silu=True, add=self.emb_layers(emb) + conv1.bias, float32=True)
+            return _conv3x3(conv2, h, bias=True, residual=skip)        # skip + bias in the convolution's epilogue
         h = group_norm(self.out_layers[0], conv1(h), silu=True, add=self.emb_layers(emb), float32=True)
         return skip + conv2(h)
 
@@ -292,8 +327,8 @@ class _VaeRes(nn.Module):
         skip = _conv1x1(self.nin_shortcut, x) if hasattr(self, "nin_shortcut") else x
         h = group_norm(self.norm1, x, silu=True)
         if _fold_bias(self.conv1, h):
-            h = group_norm(self.norm2, _conv_nobias(self.conv1, h), silu=True, add=self.conv1.bias)
-            return add_bias(skip, _conv_nobias(self.conv2, h), self.conv2.bias)      # (Dropout(0) is the identity)
+            h = group_norm(self.norm2, _conv3x3(self.conv1, h, bias=False), silu=True, add=self.conv1.bias)
+            return _conv3x3(self.conv2, h, bias=True, residual=skip)                  # (Dropout(0) is the identity)
         h = self.conv2(self.dropout(group_norm(self.norm2, self.conv1(h), silu=True)))
         return skip + h
 

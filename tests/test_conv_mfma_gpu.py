@@ -1,0 +1,85 @@
+"""csrc/conv_mfma.hip: the 3x3 / stride 1 / padding 1 NHWC float16 convolution of the Zero123 UNet and VAE encoder on MFMA
+(threestudio/models/guidance/stable_zero123_guidance.py:222-233 runs ldm's UNet, whose ResBlocks and Up/Downsample are
+torch Conv2d).  Checked against torch's convolution of the same float16 operands, accumulated in float32 -- the bar is the
+float16 rounding of the OUTPUT (2^-10 relative to the largest partial sum scale), for every tile configuration the plan
+can choose: the direct kernel (UNet 8^2..32^2), the split-K implicit GEMM (4^2) and the plain implicit GEMM (VAE)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+SHAPES = [  # N, H, W, Cin, Cout       (a subset of the 22 shapes of one SDS step, tools/conv_shapes.py has all)
+    (8, 32, 32, 320, 320), (8, 32, 32, 640, 320), (8, 16, 16, 640, 640), (8, 16, 16, 1280, 640), (8, 8, 8, 1280, 1280),
+    (8, 8, 8, 2560, 1280), (8, 4, 4, 1280, 1280), (2, 128, 128, 128, 128), (2, 64, 64, 128, 256), (1, 32, 32, 512, 512),
+    (3, 16, 16, 64, 96), (1, 5, 7, 32, 32),       # ragged: M not a multiple of any tile, W not a power of two
+]
+
+
+def _need_gpu():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a HIP device")
+
+
+def _ref(x, w, bias, res):
+    y = F.conv2d(x.float(), w.float(), None if bias is None else bias.float(), 1, 1)
+    return y if res is None else y + res.float()
+
+
+@pytest.mark.parametrize("shape", SHAPES)
+@pytest.mark.parametrize("epilogue", ["plain", "bias+residual"])
+def test_conv3x3_matches_float32_accumulated_reference(shape, epilogue):
+    _need_gpu()
+    from dreammesh4d_amd import conv_mfma
+
+    N, H, W, Ci, Co = shape
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(Ci + Co + H)
+    x = torch.randn(N, Ci, H, W, generator=g).to(dev).half().contiguous(memory_format=torch.channels_last)
+    w = (torch.randn(Co, Ci, 3, 3, generator=g) * (9 * Ci) ** -0.5).to(dev).half()
+    bias = res = None
+    if epilogue != "plain":
+        bias = torch.randn(Co, generator=g).to(dev).half()
+        res = torch.randn(N, Co, H, W, generator=g).to(dev).half().contiguous(memory_format=torch.channels_last)
+    assert conv_mfma.supported(x, w)
+    y = conv_mfma.conv3x3(x, conv_mfma.pack_weight(w), bias, res)
+    assert y.shape == (N, Co, H, W) and y.dtype == torch.float16 and y.is_contiguous(memory_format=torch.channels_last)
+    ref = _ref(x, w, bias, res)
+    err = (y.float() - ref).abs().max().item()
+    assert err <= 2 ** -10 * ref.abs().max().item() + 1e-6, (err, ref.abs().max().item())
+    assert torch.equal(y, conv_mfma.conv3x3(x, conv_mfma.pack_weight(w), bias, res))       # fixed reduction order
+
+
+def test_frozen_conv_data_gradient_and_residual_gradient():
+    _need_gpu()
+    from dreammesh4d_amd import conv_mfma
+
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(5)
+    N, H, W, Ci, Co = 2, 24, 20, 64, 128
+    x = torch.randn(N, Ci, H, W, generator=g).to(dev).half().contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    r = torch.randn(N, Co, H, W, generator=g).to(dev).half().contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    w = (torch.randn(Co, Ci, 3, 3, generator=g) * (9 * Ci) ** -0.5).to(dev).half()
+    b = torch.randn(Co, generator=g).to(dev).half()
+    gy = torch.randn(N, Co, H, W, generator=g).to(dev).half().contiguous(memory_format=torch.channels_last)
+    y = conv_mfma.conv3x3_frozen(x, conv_mfma.pack_weight(w), conv_mfma.pack_weight_transposed(w), b, r)
+    y.backward(gy)
+    x32, r32 = x.detach().float().requires_grad_(True), r.detach().float().requires_grad_(True)
+    (F.conv2d(x32, w.float(), b.float(), 1, 1) + r32).backward(gy.float())
+    assert (x.grad.float() - x32.grad).abs().max() <= 2 ** -10 * x32.grad.abs().max() + 1e-6
+    assert torch.equal(r.grad, gy)
+
+
+def test_unsupported_operands_are_rejected_not_miscomputed():
+    _need_gpu()
+    from dreammesh4d_amd import conv_mfma
+
+    dev = torch.device("cuda:0")
+    w = torch.zeros(32, 32, 3, 3, device=dev, dtype=torch.float16)
+    x = torch.zeros(1, 32, 8, 8, device=dev, dtype=torch.float16)
+    assert not conv_mfma.supported(x, w)                                                     # NCHW-contiguous
+    assert not conv_mfma.supported(x.float().contiguous(memory_format=torch.channels_last), w.float())
+    assert not conv_mfma.supported(torch.zeros(1, 48, 8, 8, device=dev, dtype=torch.float16).contiguous(memory_format=torch.channels_last),
+                                   torch.zeros(32, 48, 3, 3, device=dev, dtype=torch.float16))
+    with pytest.raises((ValueError, RuntimeError)):
+        conv_mfma.conv3x3(x, conv_mfma.pack_weight(w))
