@@ -73,3 +73,39 @@ class _Conv3x3Frozen(torch.autograd.Function):
 
 def conv3x3_frozen(x, w_ohwi, w_t, bias=None, residual=None):
     return _Conv3x3Frozen.apply(x, w_ohwi, w_t, bias, residual)
+
+
+class _ConvFirstFrozen(torch.autograd.Function):
+    """The VAE encoder's first convolution (image, <= 4 channels -> 128 feature channels) with frozen parameters: forward on the
+    library, data gradient on ``dm4d_conv3x3_c128_small_nhwc_f16`` (a 128 -> 3 channel convolution with the flipped, transposed
+    filter: memory bound, where the library's grouped-convolution kernel took 0.5 ms of the 13 ms SDS step)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, w_t):
+        ctx.save_for_backward(w_t)
+        return torch.nn.functional.conv2d(x, w, b, 1, 1)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (w_t,) = ctx.saved_tensors
+        if not ctx.needs_input_grad[0]:
+            return None, None, None, None
+        if not dy.is_contiguous(memory_format=torch.channels_last):
+            dy = dy.contiguous(memory_format=torch.channels_last)
+        N, C, H, W = dy.shape
+        Ci = int(w_t.shape[0])
+        dx = torch.empty((N, Ci, H, W), device=dy.device, dtype=torch.float16, memory_format=torch.channels_last)
+        with torch.cuda.device(dy.device):
+            _lib.check(_lib.lib().dm4d_conv3x3_c128_small_nhwc_f16(N, H, W, Ci, dy.data_ptr(), w_t.data_ptr(), dx.data_ptr(),
+                                                                   torch.cuda.current_stream(dy.device).cuda_stream), "dm4d_conv3x3_c128_small_nhwc_f16")
+        return dx, None, None, None
+
+
+def first_conv_supported(x, w):
+    return (x.is_cuda and x.dtype == torch.float16 and w.dtype == torch.float16 and x.dim() == 4 and tuple(w.shape[2:]) == (3, 3)
+            and w.shape[0] == 128 and 1 <= w.shape[1] <= 4 and x.shape[1] == w.shape[1])
+
+
+def conv3x3_first_frozen(x, w, b, w_t):
+    """x [N, C<=4, H, W] -> [N, 128, H, W]; w_t = pack_weight_transposed(w) ([C, 3, 3, 128])."""
+    return _ConvFirstFrozen.apply(x, w, b, w_t)

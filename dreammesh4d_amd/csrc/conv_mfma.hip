@@ -548,6 +548,63 @@ __global__ __launch_bounds__(256) void k_conv_reduce(ConvDesc d)
     *reinterpret_cast<f16x8 *>(d.y + e) = out;
 }
 
+// ---------------------------------------------------------------------------------------- 128 channels -> <= 4 channels
+// The data gradient of the VAE encoder's first convolution (3 -> 128 channels at 256^2: dL/dimage from dL/dfeatures, the library
+// spends ~0.5 ms of the 13 ms SDS step in a CK grouped-convolution kernel on it) is a convolution from 128 channels to THREE:
+// 1.8 GFLOP over 67 MB -- memory bound, and no shape for a 128-wide MFMA tile.  VALU instead: 16 lanes share a pixel (8
+// channels each: one coalesced 256-byte row per tap), the filters of a lane's channels stay in registers for the whole kernel
+// (COUT x 9 x 8 halves), v_dot2_f32_f16 accumulates in float32, the 16 partial sums meet in a 4-step butterfly.
+template <int COUT>
+__global__ __launch_bounds__(256) void k_conv3x3_c128_small(int N, int H, int W, const _Float16 *__restrict__ x, const _Float16 *__restrict__ w,
+                                                            _Float16 *__restrict__ y, int iters)
+{
+    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+    const int lane = threadIdx.x & 63, sub = lane & 15, grp = lane >> 4;
+    const int M = N * H * W;
+    h2 wr[COUT][9][4];
+#pragma unroll
+    for (int co = 0; co < COUT; ++co)
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const uint4 v = *reinterpret_cast<const uint4 *>(w + (size_t)(co * 9 + tap) * 128 + 8 * sub);
+            const h2 *h = reinterpret_cast<const h2 *>(&v);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) wr[co][tap][k] = h[k];
+        }
+    const int wave = blockIdx.x * 4 + (threadIdx.x >> 6);
+    for (int it = 0; it < iters; ++it) {
+        const int p = (wave * iters + it) * 4 + grp;
+        if (p >= M) break;                                       // (whole 16-lane groups leave together: the butterfly stays inside a group)
+        const int xx0 = p % W, yy0 = (p / W) % H;
+        float acc[COUT];
+#pragma unroll
+        for (int co = 0; co < COUT; ++co) acc[co] = 0.f;
+        uint4 v[9];
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int dy = tap / 3 - 1, dx = tap % 3 - 1;
+            const bool ok = (unsigned)(yy0 + dy) < (unsigned)H && (unsigned)(xx0 + dx) < (unsigned)W;
+            v[tap] = ok ? *reinterpret_cast<const uint4 *>(x + (size_t)(p + dy * W + dx) * 128 + 8 * sub) : make_uint4(0u, 0u, 0u, 0u);
+        }
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const h2 *h = reinterpret_cast<const h2 *>(&v[tap]);
+#pragma unroll
+            for (int co = 0; co < COUT; ++co)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) acc[co] = __builtin_amdgcn_fdot2(h[k], wr[co][tap][k], acc[co], false);
+        }
+#pragma unroll
+        for (int co = 0; co < COUT; ++co)
+#pragma unroll
+            for (int m = 1; m < 16; m <<= 1) acc[co] += __shfl_xor(acc[co], m, 16);
+        float mine = acc[0];
+#pragma unroll
+        for (int co = 1; co < COUT; ++co) mine = sub == co ? acc[co] : mine;
+        if (sub < COUT) y[(size_t)p * COUT + sub] = (_Float16)mine;
+    }
+}
+
 // tile configurations (DM4D_CONV_CFG): 0: 128 x 128, 4 waves of 64 x 64, 3-deep ring | 3: the same, 4-deep | 4: 128 x 128, 8 waves of
 // 32 x 64 | 6: the same, 4-deep | 5: 256 x 128, 8 waves of 64 x 64, 3-deep | 8: the same, 4-deep | 7: the direct kernel (256 x 128)
 static void cfg_tile(int cfg, int &BM, int &BN)
@@ -613,7 +670,8 @@ int dm4d_conv3x3_nhwc_f16(int32_t N, int32_t H, int32_t W, int32_t Cin, int32_t 
 {
     if (N < 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) { set_error("conv3x3: bad shape"); return DM4D_ERR_INVALID; }
     if (N == 0) return DM4D_OK;
-    if (Cin % kCvBK != 0 || Cout % 8 != 0) { set_error("conv3x3: C_in must be a multiple of %d and C_out of 8 (got %d, %d)", kCvBK, Cin, Cout); return DM4D_ERR_UNSUPPORTED; }
+    if (Cin % kCvBK != 0 || Cout % 32 != 0) { set_error("conv3x3: C_in and C_out must be multiples of %d (got %d, %d)", kCvBK, Cin, Cout); return DM4D_ERR_UNSUPPORTED; }
+    if (((int64_t)N * H * W + 2 * W + 2) * Cin * 2 >= 0x7FFF0000LL || (int64_t)Cout * 9 * Cin * 2 >= 0x7FFF0000LL) { set_error("conv3x3: tensor too large for a 32-bit buffer descriptor"); return DM4D_ERR_UNSUPPORTED; }
     if ((int64_t)N * H * W > 0x7FFFFFFF / 4) { set_error("conv3x3: too many pixels"); return DM4D_ERR_UNSUPPORTED; }
     if (!x || !w || !y) { set_error("conv3x3: null tensor"); return DM4D_ERR_INVALID; }
     if ((((uintptr_t)x | (uintptr_t)w | (uintptr_t)y | (uintptr_t)bias | (uintptr_t)residual) & 15) != 0) { set_error("conv3x3: tensors must be 16-byte aligned"); return DM4D_ERR_INVALID; }
@@ -666,6 +724,30 @@ int dm4d_conv3x3_nhwc_f16(int32_t N, int32_t H, int32_t W, int32_t Cin, int32_t 
         hipLaunchKernelGGL(k_conv_reduce, dim3((unsigned)((total / 8 + 255) / 256)), dim3(256), 0, st, d);
         DM4D_HIP_CHECK(hipGetLastError());
     }
+    return DM4D_OK;
+}
+
+int dm4d_conv3x3_c128_small_nhwc_f16(int32_t N, int32_t H, int32_t W, int32_t Cout, const void *x, const void *w, void *y, dm4d_stream_t stream)
+{
+    if (N < 0 || H <= 0 || W <= 0) { set_error("conv3x3_c128_small: bad shape"); return DM4D_ERR_INVALID; }
+    if (Cout < 1 || Cout > 4) { set_error("conv3x3_c128_small: C_out must be 1 .. 4 (got %d)", Cout); return DM4D_ERR_UNSUPPORTED; }
+    if (N == 0) return DM4D_OK;
+    if ((int64_t)N * H * W > 0x7FFFFFFF / 4) { set_error("conv3x3_c128_small: too many pixels"); return DM4D_ERR_UNSUPPORTED; }
+    if (!x || !w || !y) { set_error("conv3x3_c128_small: null tensor"); return DM4D_ERR_INVALID; }
+    if ((((uintptr_t)x | (uintptr_t)w) & 15) != 0 || ((uintptr_t)y & 1) != 0) { set_error("conv3x3_c128_small: x, w must be 16-byte aligned"); return DM4D_ERR_INVALID; }
+    const int M = N * H * W, iters = 16;
+    const int waves = (M + 4 * iters - 1) / (4 * iters);
+    const dim3 grid((waves + 3) / 4), block(256);
+    hipStream_t st = (hipStream_t)stream;
+    const _Float16 *xp = (const _Float16 *)x, *wp = (const _Float16 *)w;
+    _Float16 *yp = (_Float16 *)y;
+    switch (Cout) {
+    case 1: hipLaunchKernelGGL(k_conv3x3_c128_small<1>, grid, block, 0, st, N, H, W, xp, wp, yp, iters); break;
+    case 2: hipLaunchKernelGGL(k_conv3x3_c128_small<2>, grid, block, 0, st, N, H, W, xp, wp, yp, iters); break;
+    case 3: hipLaunchKernelGGL(k_conv3x3_c128_small<3>, grid, block, 0, st, N, H, W, xp, wp, yp, iters); break;
+    default: hipLaunchKernelGGL(k_conv3x3_c128_small<4>, grid, block, 0, st, N, H, W, xp, wp, yp, iters); break;
+    }
+    DM4D_HIP_CHECK(hipGetLastError());
     return DM4D_OK;
 }
 

@@ -384,8 +384,22 @@ class VaeEncoder(nn.Module):
         self.norm_out = nn.GroupNorm(32, cin, eps=1e-6)
         self.conv_out = nn.Conv2d(cin, 2 * z_channels, 3, padding=1)
 
+    def _first(self, x):
+        """conv_in; with frozen parameters on a HIP device its data gradient (image <- 128 channels) runs on the HIP kernel."""
+        from . import conv_mfma
+
+        c = self.conv_in
+        if (_USE_MFMA_CONV and torch.is_grad_enabled() and x.requires_grad and not c.weight.requires_grad and not c.bias.requires_grad
+                and is_channels_last(x) and conv_mfma.first_conv_supported(x, c.weight)):
+            key = (c.weight.data_ptr(), c.weight._version)
+            packed = getattr(c, "_dm4d_wt", None)
+            if packed is None or packed[0] != key:
+                packed = c._dm4d_wt = (key, conv_mfma.pack_weight_transposed(c.weight))
+            return conv_mfma.conv3x3_first_frozen(x, c.weight, c.bias, packed[1])
+        return c(x)
+
     def forward(self, x):
-        h = self.conv_in(_to_nhwc(x) if x.is_cuda and self.channels_last else x)
+        h = self._first(_to_nhwc(x) if x.is_cuda and self.channels_last else x)
         for lvl in self.down:
             for b in lvl.block:
                 h = b(h)

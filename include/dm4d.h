@@ -514,13 +514,20 @@ int dm4d_views_counters(const dm4d_views *v, int64_t *num_rendered, int64_t *num
 /* ------------------------------------------------------------------ 3x3 convolution on the matrix cores (Zero123 UNet)
  * y = conv3x3(x, w) + bias (+ residual): stride 1, padding 1, float16, float32 accumulation (v_mfma_f32_32x32x16_f16).
  * x [N,H,W,C_in], y / residual [N,H,W,C_out] (NHWC = torch.channels_last storage), w [C_out,3,3,C_in] (a channels_last
- * torch weight as it lies in memory), bias [C_out] or NULL; C_in % 32 == 0, C_out % 8 == 0; 16-byte aligned device pointers.
+ * torch weight as it lies in memory), bias [C_out] or NULL; C_in % 32 == 0, C_out % 32 == 0; 16-byte aligned device pointers.
  * `scratch` (dm4d_conv3x3_scratch_bytes, may be NULL when that returns <= 256): float32 partial sums of the split-K
- * launches of small problems.  Forward only (the guidance UNet runs without gradients,
- * extern/ldm_zero123/modules/diffusionmodules/openaimodel.py:214-275). */
+ * launches of small problems.  The operator is the forward convolution (the guidance UNet runs without gradients,
+ * extern/ldm_zero123/modules/diffusionmodules/openaimodel.py:214-275); the data gradient of a stride-1 convolution is the
+ * same operator on the flipped, transposed filter (the VAE encoder's backward, dreammesh4d_amd/conv_mfma.py). */
 size_t dm4d_conv3x3_scratch_bytes(int32_t N, int32_t H, int32_t W, int32_t Cin, int32_t Cout);
 int dm4d_conv3x3_nhwc_f16(int32_t N, int32_t H, int32_t W, int32_t Cin, int32_t Cout, const void *x, const void *w, const void *bias,
                           const void *residual, void *y, void *scratch, dm4d_stream_t stream);
+/* y = conv3x3(x, w) from exactly 128 channels to C_out <= 4 (stride 1, padding 1, float16, float32 accumulation, no bias):
+ * x [N,H,W,128], w [C_out,3,3,128], y [N,H,W,C_out].  The data gradient of the VAE encoder's first convolution (image <-
+ * 128 feature channels, ldm Encoder.conv_in, extern/ldm_zero123/modules/diffusionmodules/model.py:368-371): memory bound,
+ * on the vector ALUs (v_dot2_f32_f16). */
+int dm4d_conv3x3_c128_small_nhwc_f16(int32_t N, int32_t H, int32_t W, int32_t Cout, const void *x, const void *w, void *y,
+                                     dm4d_stream_t stream);
 
 /* ------------------------------------------------------------------ heat-method geodesics of the deformation graph
  * The device pieces of build_deformation_graph(mode="geodisc") with the reference's own distance, the heat method

@@ -83,3 +83,26 @@ def test_unsupported_operands_are_rejected_not_miscomputed():
                                    torch.zeros(32, 48, 3, 3, device=dev, dtype=torch.float16))
     with pytest.raises((ValueError, RuntimeError)):
         conv_mfma.conv3x3(x, conv_mfma.pack_weight(w))
+
+
+def test_first_convolution_data_gradient_on_the_small_cout_kernel():
+    """128 -> 3 channels (the image gradient of the VAE encoder's conv_in): against torch's float32 autograd of the same operands."""
+    _need_gpu()
+    from dreammesh4d_amd import conv_mfma
+
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(9)
+    for (N, H, W) in ((2, 64, 48), (1, 17, 9)):
+        x = torch.rand(N, 3, H, W, generator=g).to(dev).half().contiguous(memory_format=torch.channels_last).requires_grad_(True)
+        w = (torch.randn(128, 3, 3, 3, generator=g) * 0.2).to(dev).half()
+        b = torch.randn(128, generator=g).to(dev).half()
+        gy = torch.randn(N, 128, H, W, generator=g).to(dev).half().contiguous(memory_format=torch.channels_last)
+        assert conv_mfma.first_conv_supported(x, w)
+        y = conv_mfma.conv3x3_first_frozen(x, w, b, conv_mfma.pack_weight_transposed(w))
+        y.backward(gy)
+        x32 = x.detach().float().requires_grad_(True)
+        y32 = F.conv2d(x32, w.float(), b.float(), 1, 1)
+        y32.backward(gy.float())
+        assert (y.float() - y32).abs().max() <= 2 ** -9 * y32.abs().max()
+        assert x.grad.shape == x.shape and x.grad.is_contiguous(memory_format=torch.channels_last)
+        assert (x.grad.float() - x32.grad).abs().max() <= 2 ** -10 * x32.grad.abs().max() + 1e-6
