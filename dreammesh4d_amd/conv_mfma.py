@@ -12,6 +12,8 @@ import torch
 
 from . import _lib
 
+FLOPS = [0]        # multiply-add flops launched through this module (tools/zero123_profile.py: torch's flop counter cannot see them)
+
 def supported(x, w):
     """Shapes / layouts the kernel takes (everything else stays on the library path)."""
     return (x.is_cuda and x.dtype == torch.float16 and x.dim() == 4 and x.is_contiguous(memory_format=torch.channels_last)
@@ -34,6 +36,7 @@ def conv3x3(x, w_ohwi, bias=None, residual=None):
     if residual is not None and (tuple(residual.shape) != (N, Co, H, W) or not residual.is_contiguous(memory_format=torch.channels_last)
                                  or residual.dtype != torch.float16):
         raise ValueError("conv3x3: residual must be a channels_last float16 tensor of the output's shape")
+    FLOPS[0] += 2 * N * H * W * Ci * Co * 9
     L = _lib.lib()
     y = torch.empty((N, Co, H, W), device=x.device, dtype=torch.float16, memory_format=torch.channels_last)
     # split-K partial sums of the small problems: from the caching allocator per call (stream-ordered, and a hipGraph capture
@@ -94,6 +97,7 @@ class _ConvFirstFrozen(torch.autograd.Function):
             dy = dy.contiguous(memory_format=torch.channels_last)
         N, C, H, W = dy.shape
         Ci = int(w_t.shape[0])
+        FLOPS[0] += 2 * N * H * W * Ci * C * 9
         dx = torch.empty((N, Ci, H, W), device=dy.device, dtype=torch.float16, memory_format=torch.channels_last)
         with torch.cuda.device(dy.device):
             _lib.check(_lib.lib().dm4d_conv3x3_c128_small_nhwc_f16(N, H, W, Ci, dy.data_ptr(), w_t.data_ptr(), dx.data_ptr(),
