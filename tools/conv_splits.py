@@ -1,3 +1,5 @@
+"""Split-K scan of the small UNet convolution shapes (DM4D_CONV_SPLITS) against the plan's own choice: where the rule of
+csrc/conv_mfma.hip::conv_plan comes from (profiles/r03_zero123.md)."""
 import os, sys, time
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 import torch

@@ -1,3 +1,5 @@
+"""Time of one Zero123 SDS step (full-size UNet + VAE encoder, fp16, random weights, hipGraph replay) and its loss: run with
+DM4D_MFMA_CONV=0 / 1 for the A/B of the hand-written convolutions (profiles/r03_zero123.md)."""
 import sys, os, time, torch
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 from dreammesh4d_amd import zero123 as z
