@@ -110,6 +110,12 @@ class Workload:
         self.gD = (0.1 * torch.randn(B, 1, H, W, generator=g)).to(dev)
         self.gA = torch.randn(B, 1, H, W, generator=g).to(dev)
         self.render_views = views.render_views
+        # The shipped dynamic configuration has NO depth loss (configs/sugar_dynamic_dg.yaml:142-154: lambda_depth, lambda_depth_rel,
+        # lambda_depth_tv, lambda_normal_depth_consistency = 0), so in the reference's iteration no gradient reaches the depth
+        # image: the headline step feeds none either (the blend backward then writes 32-byte records).  The step WITH a depth
+        # gradient is timed beside it (`with_depth_gradient`), and `roofline_full` always has one.
+        self.depth_grad = os.environ.get("DM4D_BENCH_DEPTH_GRAD", "0") == "1"
+        self._params = list(self.net.parameters())
 
     def set_static_learnable(self, flag):
         """False (the dynamic stage: static_learnable = False, dynamic_sugar.py:79-87): the blend backward neither reduces nor
@@ -119,13 +125,18 @@ class Workload:
             t.grad = None
 
     def step(self):
-        self.net.zero_grad(set_to_none=True)
+        # (Module.zero_grad walks the module tree: 0.14 ms of the host's ~0.8 ms per step; the parameter list is fixed)
+        for p in self._params:
+            p.grad = None
         # node attributes once per distinct timestamp of the step (cached per step in the reference,
         # dynamic_sugar.py:367-405), then broadcast to the views of that frame
         dx, dr, ds, do = self.net.node_outputs(self.nodes, self.frame_t)
         out = self.render_views(self.renderer, dx, dr, ds, do, self.qs, self.scales, self.opac, self.rgb, self.vm, self.pm,
                                 self.bg6, frame_index=self.fidx)
-        torch.autograd.backward([out["color"], out["depth"], out["alpha"]], [self.gC, self.gD, self.gA])
+        if self.depth_grad:
+            torch.autograd.backward([out["color"], out["depth"], out["alpha"]], [self.gC, self.gD, self.gA])
+        else:
+            torch.autograd.backward([out["color"], out["alpha"]], [self.gC, self.gA])
         return out
 
 
@@ -198,7 +209,26 @@ def main():
     D_mean = float(np.mean(D_views))
     # the same steps with the static appearance learnable: the FULL (non-lean) blend backward, reported beside the headline
     full = None
+    with_depth = None
+    if world == 1 and not wl.depth_grad:      # the same step with a gradient on the depth image (48-byte records)
+        wl.depth_grad = True
+        for _ in range(5):
+            step()
+        sync()
+        L.dm4d_profile_enable(1 << K_RENDER_BWD)
+        t1 = time.perf_counter()
+        n_wd = min(args.steps, 100)
+        for _ in range(n_wd):
+            step()
+        sync()
+        el_wd = time.perf_counter() - t1
+        L.dm4d_profile_enable(0)
+        wm = ctypes.c_double(0.0)
+        wn = L.dm4d_profile_collect(K_RENDER_BWD, ctypes.byref(wm))
+        with_depth = (el_wd / n_wd, wm.value / max(wn, 1) * 1e-3, int(wn))
     if world == 1:
+        keep_depth = wl.depth_grad
+        wl.depth_grad = True
         wl.set_static_learnable(True)
         for _ in range(5):
             step()
@@ -215,6 +245,7 @@ def main():
         fn = L.dm4d_profile_collect(K_RENDER_BWD, ctypes.byref(fm))
         full = (el_full / n_full, fm.value / max(fn, 1) * 1e-3, int(fn))
         wl.set_static_learnable(False)
+        wl.depth_grad = keep_depth and os.environ.get("DM4D_BENCH_DEPTH_GRAD", "0") == "1"
 
     if rank == 0:
         units = world * VIEWS_PER_STEP * args.steps
@@ -238,7 +269,8 @@ def main():
             # the timed kernel: the lean variant (one launch takes the wide blocks and the quadrants).  (Until r02's last
             # refresh this summed every k_render_bwd* entry of the file -- the non-lean variant of the roofline_full leg
             # included -- and so reported twice the kernel's traffic.)
-            traffic = round(pmc["dm4d::k_render_bwd<6, true>"]["bytes_corrected"])
+            key = "dm4d::k_render_bwd<6, 1>" if wl.depth_grad else "dm4d::k_render_bwd<6, 2>"
+            traffic = round(pmc[key]["bytes_corrected"])
         except Exception:
             pass
         out = {
@@ -248,14 +280,16 @@ def main():
             "vs_baseline": None, "dtype": "f32", "data": "synthetic" if backend == "nccl" else f"synthetic (REHEARSAL over {backend}: not a performance number)",
             "config": {"workload": f"sugar_dynamic_dg (configs[3] per-GPU share): mesh-bound {N} Gaussians "
                                    f"({wl.topo.F} faces x 6), {N_NODES} graph nodes K={K_NBR} hybrid LBS/DQS skinning, "
-                                   f"512x512; per view: skinning + face->Gaussian + RGB pass + normal pass, fwd+bwd",
+                                   f"512x512; per view: skinning + face->Gaussian + RGB pass + normal pass, fwd+bwd"
+                                   + ("" if wl.depth_grad else "; no gradient on the depth image, as in the shipped configuration (no depth loss)"),
                        "views_per_step_per_gpu": VIEWS_PER_STEP, "untimed_settle_steps": settle, "frames_per_step_per_gpu": FRAMES_PER_STEP,
                        "mean_duplicates_D": round(D_mean), "allreduce_bytes_per_step": reducer.nbytes if world > 1 else 0,
                        "allreduce_message_bytes": reducer.nbytes, "dense_gradient_bytes": 4 * reducer.dense_elements,
                        "whole_view_frac_of_hbm_roofline":
                            round(value / world * b_view / (HBM_PEAK_GBS * 1e9), 5),
                        "parallelism": f"dp{world} (frames sharded, 1 grad all-reduce/step)" if world > 1 else "single GPU"},
-            "roofline": {"bound": "hbm", "kernel": "k_render_bwd<6, true> (entry-parallel blend backward, one launch per step batched over its views: wide blocks for the long cells first, then the quadrants)",
+            "roofline": {"bound": "hbm", "kernel": ("k_render_bwd<6, 1>" if wl.depth_grad else "k_render_bwd<6, 2>") + " (entry-parallel blend backward, one launch per step batched over its views: wide blocks for the long cells first, then the quadrants; "
+                                                       + ("48-byte lean records)" if wl.depth_grad else "32-byte lean records: no depth gradient)"),
                          "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                          "alg_bytes_per_launch": round(alg_bytes), "avg_launch_us": round(avg_s * 1e6, 2),
@@ -263,10 +297,15 @@ def main():
         }
         if full is not None:
             fa = alg_bytes / full[1] / 1e9 if full[1] > 0 else 0.0
-            out["roofline_full"] = {"bound": "hbm", "kernel": "k_render_bwd<6, false> (static appearance learnable: dL/dopacity, dL/d rgb, dL/dscales reduced and recorded too)",
+            out["roofline_full"] = {"bound": "hbm", "kernel": "k_render_bwd<6, 0> (static appearance learnable AND a depth gradient: dL/dopacity, dL/d rgb, dL/dscales reduced and recorded too, 64-byte records)",
                                     "achieved": round(fa, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(fa / HBM_PEAK_GBS, 5),
                                     "alg_bytes_per_launch": round(alg_bytes), "avg_launch_us": round(full[1] * 1e6, 2), "launches_timed": full[2],
                                     "ms_per_step": round(full[0] * 1e3, 4), "views_per_s": round(VIEWS_PER_STEP / full[0], 1)}
+        if with_depth is not None:
+            wa = alg_bytes / with_depth[1] / 1e9 if with_depth[1] > 0 else 0.0
+            out["with_depth_gradient"] = {"kernel": "k_render_bwd<6, 1> (the same step with a gradient on the depth image: 48-byte lean records)",
+                                          "ms_per_step": round(with_depth[0] * 1e3, 4), "views_per_s": round(VIEWS_PER_STEP / with_depth[0], 1),
+                                          "avg_launch_us": round(with_depth[1] * 1e6, 2), "frac": round(wa / HBM_PEAK_GBS, 5), "launches_timed": with_depth[2]}
         if world == 1 and not args.no_iters:
             # BASELINE.json's second metric, reported beside the headline one (never used for `value`)
             try:
@@ -341,7 +380,7 @@ def cpu_baseline(wl, n_views):
         xyz, vrot = sk.skin_vertices(verts, idx, w, trans, q, S, op, "hybrid")
         means, rots, normals = sk.face_gaussians(xyz, vrot, faces, qs)
         g_means, g_rots, g_nrm = 0, 0, None
-        for colors, g_c, g_d, g_a in ((rgb.numpy(), gC[u, :3], gD[u, 0], gA[u, 0]), (normals.detach().numpy(), gC[u, 3:], None, None)):
+        for colors, g_c, g_d, g_a in ((rgb.numpy(), gC[u, :3], gD[u, 0] if wl.depth_grad else None, gA[u, 0]), (normals.detach().numpy(), gC[u, 3:], None, None)):
             o = orc.RasterOracle(image_height=H, image_width=W, tanfovx=cam.tanfov, tanfovy=cam.tanfov, bg=(1, 1, 1),
                                  scale_modifier=1.0, viewmatrix=cam.viewmatrix, projmatrix=cam.projmatrix,
                                  campos=cam.campos)

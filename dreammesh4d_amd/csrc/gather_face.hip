@@ -57,7 +57,9 @@ int launch_gather_face_bwd(const BatchDesc &d, int n_frames, int F, int G, int V
     ProfScope prof_(kKGatherBwd, st);
     const int fpw = kSkinThreads / G;
     const dim3 grid((F + fpw - 1) / fpw, n_frames);
-    if (grad_stride(d.C, d.lean != 0) == 12)
+    if (grad_stride(d.C, d.lean) == 8)
+        hipLaunchKernelGGL(k_gather_face_bwd<2>, grid, dim3(kSkinThreads), 0, st, d, F, G, V, faces, vxyz, vrot, qs, face_scratch, pypose);
+    else if (grad_stride(d.C, d.lean) == 12)
         hipLaunchKernelGGL(k_gather_face_bwd<3>, grid, dim3(kSkinThreads), 0, st, d, F, G, V, faces, vxyz, vrot, qs, face_scratch, pypose);
     else
         hipLaunchKernelGGL(k_gather_face_bwd<4>, grid, dim3(kSkinThreads), 0, st, d, F, G, V, faces, vxyz, vrot, qs, face_scratch, pypose);

@@ -379,7 +379,7 @@ __global__ __launch_bounds__(kPreThreads) void k_scatter(BatchDesc d)
 // colour channels -- kept in registers by the fused gather + face kernel (gather_face.hip), which never writes them per view.
 struct GatherOut { float dmean[3], drot[4], dcol[kMaxChannels]; };
 
-// PARTS: float4 per record: 3 (12-float records: 3 channels, or lean 6-channel) or 4 (16 floats).
+// PARTS: float4 per record: 2 (lean without depth gradient), 3 (12-float records: 3 channels, or lean 6-channel) or 4 (16 floats).
 // The body of B2 for Gaussian i of the view `c` (every lane of the wave calls it, for 64 CONSECUTIVE Gaussians of the SAME view:
 // the record streaming is wave-cooperative).  sV / sP: the view's matrices in LDS; chunk: this wave's staging window.
 // Per-view outputs (c.o.*) are written where their pointer is set.
@@ -393,7 +393,7 @@ __device__ __forceinline__ void gather_gaussian(const BatchDesc &d, const ViewCt
     const GeomPtrs &g = c.g;
     const float *__restrict__ dLt = c.dLq;
     const BwdOutputs &o = c.o;
-    constexpr int kGRec = DM4D_GREC, kGStride = PARTS == 3 ? 12 : 20;
+    constexpr int kGRec = DM4D_GREC, kGStride = PARTS <= 3 ? 12 : 20;
     constexpr int NQ = kGRec * PARTS / 64;      // float4 a lane holds of a window in flight
     const int lane = threadIdx.x & 63;
     const size_t si = (size_t)i;
@@ -455,8 +455,13 @@ __device__ __forceinline__ void gather_gaussian(const BatchDesc &d, const ViewCt
             const uint32_t lo = max(rec0, base), hi = min(end, base + nrec);
             for (uint32_t slot = lo; slot < hi; ++slot) {
                 const float4 *rp = reinterpret_cast<const float4 *>(chunk + (slot - base) * kGStride);
-                const float4 a0 = rp[0], a1 = rp[1], a2 = rp[2];
+                const float4 a0 = rp[0], a1 = rp[1];
                 acc[0] += a0.x; acc[1] += a0.y; acc[2] += a0.z; acc[3] += a0.w;
+                if (PARTS == 2) {   // mean2D 2 | conic 3 | colour channels 3..5
+                    acc[4] += a1.x; acc[10] += a1.y; acc[11] += a1.z; acc[12] += a1.w;
+                    continue;
+                }
+                const float4 a2 = rp[2];
                 if (lean) {   // mean2D 2 | conic 3 | depth | colour channels 3..5
                     acc[4] += a1.x; acc[6] += a1.y; acc[10] += a1.z; acc[11] += a1.w; acc[12] += a2.x;
                     continue;
@@ -640,7 +645,7 @@ __device__ __forceinline__ void gather_gaussian(const BatchDesc &d, const ViewCt
         reinterpret_cast<float4 *>(o.dL_drotations)[i] = make_float4(drot[0], drot[1], drot[2], drot[3]);
 }
 
-constexpr int kGatherChunkFloats(int parts) { return DM4D_GREC * (parts == 3 ? 12 : 20); }
+constexpr int kGatherChunkFloats(int parts) { return DM4D_GREC * (parts <= 3 ? 12 : 20); }
 template <int PARTS>
 __global__ __launch_bounds__(kPreThreads) void k_gather_bwd(BatchDesc d)
 {
@@ -713,7 +718,8 @@ int launch_gather_bwd(const BatchDesc &d, hipStream_t st)
     const int nb = (d.N + kPreThreads - 1) / kPreThreads;
     if (nb == 0) return DM4D_OK;
     ProfScope prof_(kKGatherBwd, st);
-    if (grad_stride(d.C, d.lean != 0) == 12) hipLaunchKernelGGL(k_gather_bwd<3>, dim3(nb, d.B), dim3(kPreThreads), 0, st, d);
+    if (grad_stride(d.C, d.lean) == 8) hipLaunchKernelGGL(k_gather_bwd<2>, dim3(nb, d.B), dim3(kPreThreads), 0, st, d);
+    else if (grad_stride(d.C, d.lean) == 12) hipLaunchKernelGGL(k_gather_bwd<3>, dim3(nb, d.B), dim3(kPreThreads), 0, st, d);
     else hipLaunchKernelGGL(k_gather_bwd<4>, dim3(nb, d.B), dim3(kPreThreads), 0, st, d);
     DM4D_HIP_CHECK(hipGetLastError());
     return DM4D_OK;

@@ -531,7 +531,7 @@ struct EntryRegs {
 
 // Pixels P and P + 1 of the cell for the lane's entry (two independent chains side by side: the dependent DPP steps of
 // one hide behind the other).  acc: the lane's record.  tab: the row's (WIDE: wave's) pixel table.
-template <int C, bool LEAN, bool WIDE, int P>
+template <int C, int LEAN, bool WIDE, int P>
 __device__ __forceinline__ void pixel_pair(const EntryRegs<C> &e, float (&acc)[13], const bool front_lane, float *tab)
 {
     constexpr int LN = PixTab<C>::kLine;
@@ -618,7 +618,11 @@ __device__ __forceinline__ void pixel_pair(const EntryRegs<C> &e, float (&acc)[1
         acc[2] = __builtin_fmaf(qx, e.dx[i], acc[2]);
         acc[3] = __builtin_fmaf(qx, e.dy[j], acc[3]);
         acc[4] = __builtin_fmaf(qy, e.dy[j], acc[4]);
-        if constexpr (LEAN) {
+        if constexpr (LEAN == 2) {       // no depth gradient: 8 values
+            acc[5] = __builtin_fmaf(w[h], g[h][3], acc[5]);
+            acc[6] = __builtin_fmaf(w[h], g[h][4], acc[6]);
+            acc[7] = __builtin_fmaf(w[h], g[h][5], acc[7]);
+        } else if constexpr (LEAN == 1) {
             acc[5] = __builtin_fmaf(w[h], gD[h], acc[5]);
             acc[6] = __builtin_fmaf(w[h], g[h][3], acc[6]);
             acc[7] = __builtin_fmaf(w[h], g[h][4], acc[7]);
@@ -639,7 +643,7 @@ __device__ __forceinline__ void pixel_pair(const EntryRegs<C> &e, float (&acc)[1
 #undef DM4D_RM
 
 // the 16 pixels of the cell for the lane's entry
-template <int C, bool LEAN, bool WIDE>
+template <int C, int LEAN, bool WIDE>
 __device__ __forceinline__ void cell_pixels(const EntryRegs<C> &e, float (&acc)[13], const bool front_lane, float *tab)
 {
     pixel_pair<C, LEAN, WIDE, 0>(e, acc, front_lane, tab);
@@ -753,7 +757,7 @@ __device__ __forceinline__ void store_records(float *__restrict__ rec, const uin
     float4 *mine = reinterpret_cast<float4 *>(st.rec[lane]);
     mine[0] = make_float4(acc[0], acc[1], acc[2], acc[3]);
     mine[1] = make_float4(acc[4], acc[5], acc[6], acc[7]);
-    mine[2] = make_float4(acc[8], acc[9], acc[10], acc[11]);
+    if (RSP > 8) mine[2] = make_float4(acc[8], acc[9], acc[10], acc[11]);
     if (RSP > 12) mine[3] = make_float4(acc[12], 0.f, 0.f, 0.f);
     st.slot[lane] = slot;
     __builtin_amdgcn_wave_barrier();
@@ -771,10 +775,10 @@ __device__ __forceinline__ void store_records(float *__restrict__ rec, const uin
 template <int C, int RSP> struct BwdSmemV2 { __attribute__((aligned(16))) float tab[4][16 * PixTab<C>::kLine]; RecStage<RSP> stage; };
 
 // regular blocks: wave = quadrant, row = cell
-template <int C, bool LEAN>
-__device__ __forceinline__ void render_bwd_cells(const BatchDesc &d, const uint32_t bid, BwdSmemV2<C, (C <= 3 || LEAN) ? 12 : 16> &sm)
+template <int C, int LEAN>
+__device__ __forceinline__ void render_bwd_cells(const BatchDesc &d, const uint32_t bid, BwdSmemV2<C, (LEAN == 2 ? 8 : (C <= 3 || LEAN) ? 12 : 16)> &sm)
 {
-    constexpr int RSP = (C <= 3 || LEAN) ? 12 : 16;   // == grad_stride(C, LEAN)
+    constexpr int RSP = (LEAN == 2 ? 8 : (C <= 3 || LEAN) ? 12 : 16);   // == grad_stride(C, LEAN)
     const WaveTrace trace;
     int view, tile, q;
     if (!block_to_quadrant(d, bid, view, tile, q)) { trace.done(0); return; }
@@ -829,10 +833,10 @@ __device__ __forceinline__ void render_bwd_cells(const BatchDesc &d, const uint3
 }
 
 // wide blocks: wave = one long cell
-template <int C, bool LEAN>
-__device__ __forceinline__ void render_bwd_wide_cells(const BatchDesc &d, const uint32_t bid, const uint32_t nblocks, BwdSmemV2<C, (C <= 3 || LEAN) ? 12 : 16> &sm)
+template <int C, int LEAN>
+__device__ __forceinline__ void render_bwd_wide_cells(const BatchDesc &d, const uint32_t bid, const uint32_t nblocks, BwdSmemV2<C, (LEAN == 2 ? 8 : (C <= 3 || LEAN) ? 12 : 16)> &sm)
 {
-    constexpr int RSP = (C <= 3 || LEAN) ? 12 : 16;
+    constexpr int RSP = (LEAN == 2 ? 8 : (C <= 3 || LEAN) ? 12 : 16);
     const WaveTrace trace;
     uint32_t traced = 0;
     const int view = (int)(bid % (uint32_t)d.B);
@@ -909,12 +913,12 @@ __device__ __forceinline__ void render_bwd_wide_cells(const BatchDesc &d, const 
 #ifndef DM4D_TILE_WAVES
 #define DM4D_TILE_WAVES 5
 #endif
-template <int C, bool LEAN, int WN>
+template <int C, int LEAN, int WN>
 __global__ __launch_bounds__(256, DM4D_TILE_WAVES) void k_render_bwd_tile(BatchDesc d)
 {
     constexpr int LN = PixTab<C>::kLine;
     constexpr int NV = LEAN ? 9 : (C > 3 ? 13 : 10);      // values of a record
-    constexpr int RSP = (C <= 3 || LEAN) ? 12 : 16;       // floats of a record in memory (== grad_stride)
+    constexpr int RSP = (LEAN == 2 ? 8 : (C <= 3 || LEAN) ? 12 : 16);       // floats of a record in memory (== grad_stride)
     __shared__ float s_acc[WN * NV];
     __shared__ __attribute__((aligned(16))) float s_tab[kCells][16 * LN];
     __shared__ uint32_t s_pos[kCells], s_cnt[kCells];
@@ -1111,10 +1115,10 @@ int launch_n_contrib_tile_positions(void *geom, void *binning, void *image, int 
 // ---------------------------------------------------------------------------------------- launchers
 // One launch for both kinds of block: the first `wide_blocks` workgroups take the wide cells (they are dispatched
 // first and raise their issue priority: the launch's critical path), the rest the regular quadrants.
-template <int C, bool LEAN>
+template <int C, int LEAN>
 __global__ __launch_bounds__(64) void k_render_bwd(BatchDesc d, uint32_t wide_blocks)
 {
-    __shared__ BwdSmemV2<C, (C <= 3 || LEAN) ? 12 : 16> sm;
+    __shared__ BwdSmemV2<C, (LEAN == 2 ? 8 : (C <= 3 || LEAN) ? 12 : 16)> sm;
     if (blockIdx.x < wide_blocks) render_bwd_wide_cells<C, LEAN>(d, blockIdx.x, wide_blocks, sm);
     else render_bwd_cells<C, LEAN>(d, blockIdx.x - wide_blocks, sm);
 }
@@ -1162,18 +1166,20 @@ int launch_render_bwd(const BatchDesc &d, hipStream_t st)
     if (d.lean && d.C != 6) { set_error("lean backward records need 6 channels"); return DM4D_ERR_INVALID; }
     if (d.tile_records) {      // one workgroup per tile, (Gaussian, tile) records summed in LDS
         const dim3 tgrid((unsigned)T * (unsigned)d.B);
-        if (d.C <= 3) hipLaunchKernelGGL((k_render_bwd_tile<3, false, kTileWindow>), tgrid, dim3(256), 0, st, d);
-        else if (d.lean) hipLaunchKernelGGL((k_render_bwd_tile<6, true, kTileWindow>), tgrid, dim3(256), 0, st, d);
-        else hipLaunchKernelGGL((k_render_bwd_tile<6, false, kTileWindow>), tgrid, dim3(256), 0, st, d);
+        if (d.lean == 2) { set_error("tile records: no 32-byte variant (lean must be 0 or 1)"); return DM4D_ERR_INVALID; }
+        if (d.C <= 3) hipLaunchKernelGGL((k_render_bwd_tile<3, 0, kTileWindow>), tgrid, dim3(256), 0, st, d);
+        else if (d.lean) hipLaunchKernelGGL((k_render_bwd_tile<6, 1, kTileWindow>), tgrid, dim3(256), 0, st, d);
+        else hipLaunchKernelGGL((k_render_bwd_tile<6, 0, kTileWindow>), tgrid, dim3(256), 0, st, d);
         DM4D_HIP_CHECK(hipGetLastError());
         return DM4D_OK;
     }
     // the long cells' blocks first (multiple of 8 of them: the regular blocks keep their XCD), then the quadrants
     const uint32_t long_blocks = (uint32_t)(min(T * kCells, kWideWaves) * d.B);
     const dim3 grid(long_blocks + (uint32_t)blocks);
-    if (d.C <= 3) hipLaunchKernelGGL((k_render_bwd<3, false>), grid, dim3(64), 0, st, d, long_blocks);
-    else if (d.lean) hipLaunchKernelGGL((k_render_bwd<6, true>), grid, dim3(64), 0, st, d, long_blocks);
-    else hipLaunchKernelGGL((k_render_bwd<6, false>), grid, dim3(64), 0, st, d, long_blocks);
+    if (d.C <= 3) hipLaunchKernelGGL((k_render_bwd<3, 0>), grid, dim3(64), 0, st, d, long_blocks);
+    else if (d.lean == 2) hipLaunchKernelGGL((k_render_bwd<6, 2>), grid, dim3(64), 0, st, d, long_blocks);
+    else if (d.lean) hipLaunchKernelGGL((k_render_bwd<6, 1>), grid, dim3(64), 0, st, d, long_blocks);
+    else hipLaunchKernelGGL((k_render_bwd<6, 0>), grid, dim3(64), 0, st, d, long_blocks);
     DM4D_HIP_CHECK(hipGetLastError());
     return DM4D_OK;
 }

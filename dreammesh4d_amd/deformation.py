@@ -307,18 +307,23 @@ class DeformationNetwork(nn.Module):
 
             self.build_plan(nodes)
             d = self.deformation_net
-            lin0 = d.feature_out[0]
-            heads = [d.pos_deform] + ([] if d.no_ds else [d.scales_deform]) + ([] if d.no_dr else [d.rotations_deform]) + \
-                    ([] if d.no_do else [d.opacity_deform])
-            fused_mlp = lin0.out_features == 64 and lin0.in_features % 64 == 0 and lin0.in_features <= 256
-            params = [lin0.weight, lin0.bias]
-            for hd in heads:
-                params += [hd.feature_out[0].main_stream.weight, hd.feature_out[0].main_stream.bias,
-                           hd.feature_out[1].weight, hd.feature_out[1].bias]
+            # the module walk (ModuleList indexing, attribute lookups) costs ~0.1 ms per call: done once, the parameter OBJECTS
+            # are stable (an optimiser updates them in place; `.data` swaps keep the object)
+            cache = self.__dict__.get("_node_param_cache")
+            if cache is None:
+                lin0 = d.feature_out[0]
+                heads = [d.pos_deform] + ([] if d.no_ds else [d.scales_deform]) + ([] if d.no_dr else [d.rotations_deform]) + \
+                        ([] if d.no_do else [d.opacity_deform])
+                fused_mlp = lin0.out_features == 64 and lin0.in_features % 64 == 0 and lin0.in_features <= 256
+                params = [lin0.weight, lin0.bias]
+                for hd in heads:
+                    params += [hd.feature_out[0].main_stream.weight, hd.feature_out[0].main_stream.bias,
+                               hd.feature_out[1].weight, hd.feature_out[1].bias]
+                cache = self.__dict__["_node_param_cache"] = (heads, fused_mlp, params, [p for grid in d.grid.grids for p in grid])
+            heads, fused_mlp, params, planes = cache
             in_place = getattr(self, "grads_in_place", False)
             if fused_mlp and getattr(self, "fuse_node_network", True) and B <= 16:
                 # query + MLP as one operator (csrc/nodenet.hip), the 2 t - 1 of dynamic_sugar.py:431 inside
-                planes = [p for grid in d.grid.grids for p in grid]
                 outs = list(_NodeNetwork.apply(self._hex_plan, timestamps, in_place, len(heads), len(planes), *planes, *params))
                 feat = None
             else:

@@ -272,3 +272,40 @@ def test_fused_gather_and_face_backward_is_bit_identical(H, W, shared):
         for k in g:
             assert torch.equal(g[k], res[0][0][k]), k
     assert torch.equal(res[1][1], res[3][1]) and float(res[1][1].abs().max()) > 0
+
+
+@pytest.mark.parametrize("H,W", [(144, 176), (40, 48)])
+def test_no_depth_gradient_uses_32_byte_records_with_identical_gradients(H, W):
+    """The shipped dynamic configuration has no depth loss (configs/sugar_dynamic_dg.yaml:142-154: lambda_depth,
+    lambda_depth_rel, lambda_depth_tv = 0), so autograd hands the renderer NO gradient for the depth image: with the static
+    appearance frozen the blend backward then keeps 8 values per record (32 bytes, two 16-byte pieces instead of three).  Every
+    gradient must be bit-identical to the 48-byte records fed with an all-zero depth gradient (a zero adds nothing to any sum)."""
+    _need_gpu()
+    from dreammesh4d_amd import views
+
+    dev = torch.device("cuda:0")
+    B, M = 3, 100
+    sc, graph, topo, qs, scales, opac, rgb, raw, cams, vm, pm = _scene(2400, M, 4, B, H, W, dev, seed=2)
+    gen = torch.Generator().manual_seed(1)
+    gC = torch.randn(B, 6, H, W, generator=gen).to(dev)
+    gA = torch.randn(B, 1, H, W, generator=gen).to(dev)
+    res = {}
+    for mode in ("none", "zeros"):
+        r = views.ViewRenderer(graph, topo, H, W, cams[0].tanfov, method="hybrid")
+        leaves = {k: v.clone().requires_grad_(True) for k, v in raw.items()}
+        m2 = torch.zeros(B, r.N, 3, device=dev, requires_grad=True)
+        out = views.render_views(r, leaves["trans"], leaves["d_rot"], leaves["strain"], leaves["d_opacity"].squeeze(-1), qs,
+                                 scales, opac, rgb, vm, pm, torch.ones(6, device=dev), means2D=m2)
+        r.check()
+        if mode == "none":
+            torch.autograd.backward([out["color"], out["alpha"]], [gC, gA])
+        else:
+            torch.autograd.backward([out["color"], out["depth"], out["alpha"]], [gC, torch.zeros(B, 1, H, W, device=dev), gA])
+        res[mode] = {k: v.grad.clone() for k, v in leaves.items()}
+        res[mode]["m2"] = m2.grad.clone()
+        res[mode]["normal_grad"] = r.last_grads["col"][:, :, 3:].clone()
+        res[mode]["records"] = list(r.last_num_records)
+    assert res["none"]["records"] == res["zeros"]["records"]
+    for k in ("trans", "d_rot", "strain", "d_opacity", "m2", "normal_grad"):
+        assert float(res["none"][k].abs().max()) > 0, k
+        assert torch.equal(res["none"][k], res["zeros"][k]), k
