@@ -113,6 +113,7 @@ _SIGNATURES = {
     "dm4d_groupnorm_nhwc_backward": (C.c_int, [C.c_int32] * 5 + [vp, vp, C.c_int32, vp, vp, vp, C.c_int32, vp, vp, vp, C.c_int32, vp]),
     "dm4d_add_bias_nhwc": (C.c_int, [C.c_int64, C.c_int32, C.c_int32, vp, vp, vp, vp, vp]),
     "dm4d_geglu": (C.c_int, [C.c_int64, C.c_int32, C.c_int32, vp, vp, vp]),
+    "dm4d_add_layernorm_f16": (C.c_int, [C.c_int64, C.c_int32, C.c_int32, vp, vp, vp, vp, C.c_float, vp, vp, vp, vp]),
     "dm4d_dist2_knn3": (C.c_int, [C.c_int32, vp, vp, vp]),
     "dm4d_knn_scratch_bytes": (C.c_size_t, [C.c_int32]),
     "dm4d_dist2_knn3_ws": (C.c_int, [C.c_int32, vp, vp, vp, C.c_size_t, vp]),

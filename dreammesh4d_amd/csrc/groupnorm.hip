@@ -263,7 +263,7 @@ extern "C" int dm4d_groupnorm_nhwc_forward(int32_t N, int32_t HW, int32_t C, int
 {
     int rc = gn_check(N, HW, C, G, dtype, splits, x, gamma, beta, y, stats, scratch);
     if (rc != DM4D_OK || N == 0) return rc;
-    if (add && add_stride != 0 && add_stride != C) { set_error("groupnorm: add_stride must be 0 or C"); return DM4D_ERR_INVALID; }
+    if (add && add_stride != 0 && (add_stride < C || add_stride % 8 != 0)) { set_error("groupnorm: add_stride must be 0 or >= C and a multiple of 8"); return DM4D_ERR_INVALID; }
     GnArgs a{N, HW, C, G, splits, (HW + splits - 1) / splits, silu, add_stride, eps, x, add, gamma, beta, nullptr, y, stats, scratch};
     return dtype == DM4D_GN_F16 ? gn_launch<_Float16>(a, false, (hipStream_t)stream) : gn_launch<float>(a, false, (hipStream_t)stream);
 }
@@ -276,7 +276,7 @@ extern "C" int dm4d_groupnorm_nhwc_backward(int32_t N, int32_t HW, int32_t C, in
     int rc = gn_check(N, HW, C, G, dtype, splits, x, gamma, beta, dx, stats, scratch);
     if (rc != DM4D_OK || N == 0) return rc;
     if (!dy) { set_error("groupnorm: null pointer"); return DM4D_ERR_INVALID; }
-    if (add && add_stride != 0 && add_stride != C) { set_error("groupnorm: add_stride must be 0 or C"); return DM4D_ERR_INVALID; }
+    if (add && add_stride != 0 && (add_stride < C || add_stride % 8 != 0)) { set_error("groupnorm: add_stride must be 0 or >= C and a multiple of 8"); return DM4D_ERR_INVALID; }
     GnArgs a{N, HW, C, G, splits, (HW + splits - 1) / splits, silu, add_stride, 0.f, x, add, gamma, beta, dy, dx, const_cast<float *>(stats), scratch};
     return dtype == DM4D_GN_F16 ? gn_launch<_Float16>(a, true, (hipStream_t)stream) : gn_launch<float>(a, true, (hipStream_t)stream);
 }

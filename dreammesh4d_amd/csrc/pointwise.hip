@@ -52,6 +52,80 @@ __global__ __launch_bounds__(256) void k_geglu(size_t rows, int dv, const T *__r
     }
 }
 
+// s = x (+ tok[row / rows_per_sample]);  normed = LayerNorm(s) gamma + beta;  xb = s (+ bias2)      -- float16 rows of C <= 2048
+// One WAVE per row: a lane holds up to four 16-byte pieces of the row in registers (read once), mean and variance in float32
+// (two passes over the registers), wave sums by xor shuffles.  The transformer block of the UNet
+// (extern/ldm_zero123/modules/attention.py:196-213: x = attn1(norm1(x)) + x; x = attn2(norm2(x)) + x; x = ff(norm3(x)) + x)
+// evaluated without gradients uses it twice per block: LayerNorm of the running activation together with the residual operand
+// of the NEXT GEMM (the output bias already added, so that GEMM's epilogue is just "+ C"), and -- with the single-token
+// cross-attention's broadcast row -- the two residual adds and the LayerNorm between the self-attention and the feed-forward.
+__global__ __launch_bounds__(256) void k_add_layernorm_f16(size_t rows, int cv, int rows_per_sample, const _Float16 *__restrict__ x,
+                                                           const _Float16 *__restrict__ tok, const _Float16 *__restrict__ gamma,
+                                                           const _Float16 *__restrict__ beta, float eps, const _Float16 *__restrict__ bias2,
+                                                           _Float16 *__restrict__ normed, _Float16 *__restrict__ xb)
+{
+    typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+    const int lane = threadIdx.x & 63;
+    const size_t row = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const h8 *xr = reinterpret_cast<const h8 *>(x) + row * cv;
+    const h8 *tr = tok ? reinterpret_cast<const h8 *>(tok) + (row / (size_t)rows_per_sample) * cv : nullptr;
+    float v[4][8];
+    float sum = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int c = lane + 64 * k;
+        if (c < cv) {
+            const h8 a = xr[c];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[k][j] = (float)a[j];
+            if (tr) {
+                const h8 t = tr[c];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[k][j] = (float)(_Float16)(v[k][j] + (float)t[j]);      // (the separate add rounded to float16 too)
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) sum += v[k][j];
+        }
+    }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) sum += __shfl_xor(sum, m, 64);
+    const float n = (float)(cv * 8), mean = sum / n;
+    float sq = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        if (lane + 64 * k < cv) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { const float dlt = v[k][j] - mean; sq += dlt * dlt; }
+        }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) sq += __shfl_xor(sq, m, 64);
+    const float rstd = 1.0f / sqrtf(sq / n + eps);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int c = lane + 64 * k;
+        if (c < cv) {
+            const h8 g = reinterpret_cast<const h8 *>(gamma)[c], b = reinterpret_cast<const h8 *>(beta)[c];
+            h8 o;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] = (_Float16)((v[k][j] - mean) * rstd * (float)g[j] + (float)b[j]);
+            reinterpret_cast<h8 *>(normed)[row * cv + c] = o;
+            if (xb) {
+                h8 w;
+                if (bias2) {
+                    const h8 b2 = reinterpret_cast<const h8 *>(bias2)[c];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) w[j] = (_Float16)(v[k][j] + (float)b2[j]);
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) w[j] = (_Float16)v[k][j];
+                }
+                reinterpret_cast<h8 *>(xb)[row * cv + c] = w;
+            }
+        }
+    }
+}
+
 static unsigned pw_blocks(size_t n_vec)
 {
     const size_t b = (n_vec + 255) / 256;
@@ -89,6 +163,20 @@ extern "C" int dm4d_geglu(int64_t rows, int32_t D, int32_t dtype, const void *pr
         hipLaunchKernelGGL(k_geglu<_Float16>, dim3(pw_blocks(n_vec)), dim3(256), 0, (hipStream_t)stream, (size_t)rows, D / vec, (const _Float16 *)proj, (_Float16 *)y);
     else
         hipLaunchKernelGGL(k_geglu<float>, dim3(pw_blocks(n_vec)), dim3(256), 0, (hipStream_t)stream, (size_t)rows, D / vec, (const float *)proj, (float *)y);
+    DM4D_HIP_CHECK(hipGetLastError());
+    return DM4D_OK;
+}
+
+extern "C" int dm4d_add_layernorm_f16(int64_t rows, int32_t C, int32_t rows_per_sample, const void *x, const void *tok, const void *gamma,
+                                      const void *beta, float eps, const void *bias2, void *normed, void *xb, dm4d_stream_t stream)
+{
+    if (rows < 0 || C <= 0 || C % 8 || C > 2048 || rows_per_sample <= 0) { set_error("add_layernorm: rows %lld C %d (C %% 8 == 0, <= 2048)", (long long)rows, C); return DM4D_ERR_INVALID; }
+    if (rows == 0) return DM4D_OK;
+    if (!x || !gamma || !beta || !normed) { set_error("add_layernorm: null pointer"); return DM4D_ERR_INVALID; }
+    if ((((uintptr_t)x | (uintptr_t)tok | (uintptr_t)gamma | (uintptr_t)beta | (uintptr_t)bias2 | (uintptr_t)normed | (uintptr_t)xb) & 15) != 0) { set_error("add_layernorm: pointers must be 16-byte aligned"); return DM4D_ERR_INVALID; }
+    hipLaunchKernelGGL(k_add_layernorm_f16, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, (size_t)rows, C / 8, rows_per_sample,
+                       (const _Float16 *)x, (const _Float16 *)tok, (const _Float16 *)gamma, (const _Float16 *)beta, eps, (const _Float16 *)bias2,
+                       (_Float16 *)normed, (_Float16 *)xb);
     DM4D_HIP_CHECK(hipGetLastError());
     return DM4D_OK;
 }

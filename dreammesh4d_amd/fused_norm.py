@@ -80,7 +80,7 @@ class _GroupNormNHWC(torch.autograd.Function):
         S = _splits(H * W)
         stats = torch.empty(N, groups, 2, device=x.device, dtype=torch.float32)
         scratch = torch.empty(N, S, groups, 2, device=x.device, dtype=torch.float32)
-        add_stride = 0 if add is None or add.dim() == 1 else C                      # [C]: the same for every sample
+        add_stride = 0 if add is None or add.dim() == 1 else int(add.stride(0))     # [C]: the same for every sample; [N, C]: rows may be strided
         with torch.cuda.device(x.device):
             _lib.check(L.dm4d_groupnorm_nhwc_forward(N, H * W, C, groups, _DTYPES[x.dtype], x.data_ptr(),
                                                  0 if add is None else add.data_ptr(), add_stride, weight.data_ptr(), bias.data_ptr(),
@@ -130,7 +130,12 @@ def group_norm(module, x, silu=False, add=None, float32=False):
             if torch.is_grad_enabled() and add.requires_grad:        # the operator treats `add` as a constant
                 x, add = x + (add if add.dim() == 1 else add[:, :, None, None]).type(x.dtype).view(-1, x.shape[1], 1, 1), None
             else:
-                add = add.detach().to(x.dtype).contiguous()
+                add = add.detach().to(x.dtype)
+                # rows of a wider matrix are taken as they are (the UNet projects the timestep embedding for all its ResBlocks
+                # in one GEMM and hands each block a column slice): the C ABI takes the sample stride
+                if not (add.dim() == 2 and add.stride(1) == 1 and add.stride(0) >= add.shape[1] and add.stride(0) % 8 == 0
+                        and add.data_ptr() % 16 == 0) and not add.is_contiguous():
+                    add = add.contiguous()
         return _GroupNormNHWC.apply(x, module.weight, module.bias, add, module.num_groups, module.eps, silu)
     _fallback("group_norm", x, "layout" if not is_channels_last(x) else "dtype/channels/trainable affine")
     if add is not None:
@@ -182,3 +187,26 @@ def geglu(proj):
     _fallback("geglu", proj, "layout" if not proj.is_contiguous() else "dtype/width/requires_grad")
     x, gate = proj.chunk(2, dim=-1)
     return x * F.gelu(gate)
+
+
+def add_layer_norm(norm, x, tok=None, bias2=None, want_sum=True):
+    """(LayerNorm(s), s + bias2) for s = x + tok, x [B, L, C] float16 contiguous on a HIP device, tok [B, 1, C] or None (a row
+    per sample), ``norm`` an nn.LayerNorm over C with affine parameters, bias2 [C] or None -- ONE launch
+    (``dm4d_add_layernorm_f16``) for what the transformer block writes as up to two adds and a LayerNorm.  No autograd: the
+    caller (zero123.BasicTransformerBlock) uses it under no_grad with frozen parameters only."""
+    B, Lq, C = x.shape
+    if not (x.is_cuda and x.dtype == torch.float16 and x.is_contiguous() and C % 8 == 0 and C <= 2048
+            and norm.weight.dtype == torch.float16 and tuple(norm.normalized_shape) == (C,)):
+        raise ValueError("add_layer_norm: needs a contiguous float16 [B, L, C] HIP tensor, C % 8 == 0, C <= 2048")
+    if tok is not None:
+        tok = tok.reshape(B, C)
+        if not tok.is_contiguous() or tok.dtype != torch.float16:
+            tok = tok.to(torch.float16).contiguous()
+    n = torch.empty_like(x)
+    xb = torch.empty_like(x) if want_sum else None
+    with torch.cuda.device(x.device):
+        _lib.check(_lib.lib().dm4d_add_layernorm_f16(B * Lq, C, Lq, x.data_ptr(), 0 if tok is None else tok.data_ptr(), norm.weight.data_ptr(),
+                                                     norm.bias.data_ptr(), float(norm.eps), 0 if bias2 is None else bias2.data_ptr(), n.data_ptr(),
+                                                     0 if xb is None else xb.data_ptr(), torch.cuda.current_stream(x.device).cuda_stream),
+                   "add_layernorm")
+    return n, xb

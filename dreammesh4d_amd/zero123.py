@@ -31,7 +31,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from .fused_norm import add_bias, geglu, group_norm, is_channels_last
+from .fused_norm import add_bias, add_layer_norm, geglu, group_norm, is_channels_last
 
 
 # cross-attention over a one-token context evaluated in closed form (CrossAttention.single_token); False: the general path
@@ -63,6 +63,8 @@ def _conv_nobias(conv, x):
     return F.conv2d(x, conv.weight, None, conv.stride, conv.padding)
 
 
+FUSE_ADD_LAYERNORM = os.environ.get("DM4D_FUSE_ADD_LN", "1") != "0"                 # (A/B switch for BasicTransformerBlock._fused_no_grad)
+BATCH_SMALL_GEMMS = os.environ.get("DM4D_BATCH_SMALL_GEMMS", "1") != "0"      # (A/B switch for UNetModel._batched_small_gemms)
 _USE_MFMA_CONV = os.environ.get("DM4D_MFMA_CONV", "1") != "0"      # (A/B switch: "0" keeps every convolution on the library)
 
 
@@ -151,7 +153,10 @@ class ResBlock(nn.Module):
         skip = x if isinstance(self.skip_connection, nn.Identity) else _conv1x1(self.skip_connection, x)
         # h + emb[:, :, None, None], GroupNorm, SiLU (openaimodel.py:259-275) in one operator; Dropout(0) is the identity
         if _fold_bias(conv1, h):
-            h = group_norm(self.out_layers[0], _conv3x3(conv1, h, bias=False), silu=True, add=self.emb_layers(emb) + conv1.bias, float32=True)
+            add = self.__dict__.get("_emb_add")      # emb_layers(emb) + conv1.bias of ALL ResBlocks from one GEMM (UNetModel._batched_small_gemms)
+            if add is None:
+                add = self.emb_layers(emb) + conv1.bias
+            h = group_norm(self.out_layers[0], _conv3x3(conv1, h, bias=False), silu=True, add=add, float32=True)
             return _conv3x3(conv2, h, bias=True, residual=skip)        # skip + bias in the convolution's epilogue
         h = group_norm(self.out_layers[0], conv1(h), silu=True, add=self.emb_layers(emb), float32=True)
         return skip + conv2(h)
@@ -173,19 +178,25 @@ class CrossAttention(nn.Module):
         ddpm.py:1953-1956): the softmax over a single key is exactly 1, so every query's output is to_out(to_v(context)),
         whatever the queries are -- [B, 1, query_dim], to be broadcast over the positions.  The same numbers as the general
         path without its query projection, attention and output GEMM over all positions."""
-        return self.to_out(self.to_v(context))
+        v = self.__dict__.get("_v_token")          # to_v(context) of ALL cross-attentions from one GEMM (UNetModel._batched_small_gemms)
+        return self.to_out(self.to_v(context) if v is None else v)
 
     def forward(self, x, context=None):
         ctx = x if context is None else context
         B, L, _ = x.shape
         if context is not None and ctx.shape[1] == 1 and SINGLE_TOKEN_SHORTCUT:
             return self.single_token(ctx).expand(B, L, -1)
+        return self.to_out(self.attend(x, ctx))
+
+    def attend(self, x, ctx):
+        """softmax(q k^T / sqrt(d)) v with the heads merged again: everything of the layer before `to_out`."""
+        B, L, _ = x.shape
         h = self.heads
         q = self.to_q(x).view(B, L, h, -1).transpose(1, 2)
         k = self.to_k(ctx).view(B, ctx.shape[1], h, -1).transpose(1, 2)
         v = self.to_v(ctx).view(B, ctx.shape[1], h, -1).transpose(1, 2)
-        o = F.scaled_dot_product_attention(q, k, v)           # softmax(q k^T / sqrt(d)) v
-        return self.to_out(o.transpose(1, 2).reshape(B, L, -1))
+        o = F.scaled_dot_product_attention(q, k, v)
+        return o.transpose(1, 2).reshape(B, L, -1)
 
 
 class GEGLU(nn.Module):
@@ -214,7 +225,25 @@ class BasicTransformerBlock(nn.Module):
         self.attn2 = CrossAttention(dim, context_dim, heads, dim_head)
         self.norm1, self.norm2, self.norm3 = nn.LayerNorm(dim), nn.LayerNorm(dim), nn.LayerNorm(dim)
 
+    def _fused_no_grad(self, x, context):
+        """The block without gradients on a HIP device, float16, one context token: the same sums as `forward`, but the residual
+        adds ride in the GEMMs (`addmm`: C operand = residual + that GEMM's bias) and the LayerNorms come from the kernel that
+        also prepares that operand (fused_norm.add_layer_norm): per block 2 launches instead of 2 LayerNorms + 3 adds."""
+        B, L, Cc = x.shape
+        out1, ff2 = self.attn1.to_out[0], self.ff.net[2]
+        n1, xb = add_layer_norm(self.norm1, x, None, out1.bias)                           # norm1(x) | x + b_out
+        o = self.attn1.attend(n1, n1)
+        x1 = torch.addmm(xb.view(-1, Cc), o.view(B * L, -1), out1.weight.t()).view(B, L, Cc)      # attn1(norm1(x)) + x
+        tok = self.attn2.single_token(context)                                            # [B, 1, C]: the whole cross-attention
+        n3, x2b = add_layer_norm(self.norm3, x1, tok, ff2.bias)                           # norm3(x1 + tok) | x1 + tok + b_ff
+        g = self.ff.net[0](n3)
+        return torch.addmm(x2b.view(-1, Cc), g.view(B * L, -1), ff2.weight.t()).view(B, L, Cc)    # ff(norm3(x2)) + x2
+
     def forward(self, x, context):
+        if (FUSE_ADD_LAYERNORM and SINGLE_TOKEN_SHORTCUT and not torch.is_grad_enabled() and x.is_cuda and x.dtype == torch.float16
+                and x.is_contiguous() and context is not None and context.shape[1] == 1 and self.norm1.weight.dtype == torch.float16
+                and x.shape[-1] % 8 == 0 and x.shape[-1] <= 2048):
+            return self._fused_no_grad(x, context)
         x = self.attn1(self.norm1(x)) + x
         if context is not None and context.shape[1] == 1 and SINGLE_TOKEN_SHORTCUT:
             x = x + self.attn2.single_token(context)          # (norm2 only feeds the queries, which do not matter here)
@@ -298,15 +327,59 @@ class UNetModel(nn.Module):
         nn.init.zeros_(self.out[2].weight)
         nn.init.zeros_(self.out[2].bias)
 
+    def _batched_small_gemms(self, emb, context):
+        """The UNet's M = batch GEMMs that do not depend on the activations, as TWO launches instead of 22 + 16 (each a
+        7 us launch-bound kernel + its SiLU / bias add): the timestep projection of every ResBlock (`emb_layers` = SiLU,
+        Linear(emb) -- the same `emb` for all, openaimodel.py:259-266; the first convolution's bias, which this mirror folds
+        into the same per-(sample, channel) term, rides in the concatenated bias) and, when the context is ONE token, the
+        value projection of every cross-attention (CrossAttention.single_token).  The same products row by row; the blocks
+        get column slices (views) of the two results.  Frozen parameters on a HIP device only."""
+        cache = self.__dict__.get("_small_gemm_cache")
+        res = [m for m in self.modules() if isinstance(m, ResBlock)] if cache is None else cache["res"]
+        att = [m.attn2 for m in self.modules() if isinstance(m, BasicTransformerBlock)] if cache is None else cache["att"]
+        key = tuple((b.emb_layers[1].weight.data_ptr(), b.emb_layers[1].weight._version, b.in_layers[2].bias._version) for b in res) + \
+            tuple((a.to_v.weight.data_ptr(), a.to_v.weight._version) for a in att)
+        if cache is None or cache["key"] != key:
+            with torch.no_grad():
+                cache = dict(key=key, res=res, att=att,
+                             We=torch.cat([b.emb_layers[1].weight for b in res]).contiguous(),
+                             be=torch.cat([b.emb_layers[1].bias + b.in_layers[2].bias for b in res]).contiguous(),
+                             Wv=torch.cat([a.to_v.weight for a in att]).contiguous())
+            self.__dict__["_small_gemm_cache"] = cache
+        e_all = F.linear(F.silu(emb), cache["We"], cache["be"])                  # [B, sum C_out]
+        o = 0
+        for b in res:
+            c = b.emb_layers[1].out_features
+            b.__dict__["_emb_add"] = e_all[:, o:o + c]
+            o += c
+        if context is not None and context.shape[1] == 1 and SINGLE_TOKEN_SHORTCUT:
+            v_all = F.linear(context, cache["Wv"])                               # [B, 1, sum inner]
+            o = 0
+            for a in att:
+                c = a.to_v.out_features
+                a.__dict__["_v_token"] = v_all[:, :, o:o + c]
+                o += c
+        return res, att
+
     def forward(self, x, timesteps, context):
         emb = self.time_embed(timestep_embedding(timesteps, self.model_channels).type(x.dtype))
         hs, h = [], (_to_nhwc(x) if x.is_cuda and self.channels_last else x)
-        for m in self.input_blocks:
-            h = m(h, emb, context)
-            hs.append(h)
-        h = self.middle_block(h, emb, context)
-        for m in self.output_blocks:
-            h = m(torch.cat([h, hs.pop()], dim=1), emb, context)
+        frozen = not any(p.requires_grad for p in (self.time_embed[0].weight, self.out[2].weight))
+        touched = self._batched_small_gemms(emb, context) if (x.is_cuda and self.channels_last and frozen and BATCH_SMALL_GEMMS
+                                                              and not torch.is_grad_enabled()) else None
+        try:
+            for m in self.input_blocks:
+                h = m(h, emb, context)
+                hs.append(h)
+            h = self.middle_block(h, emb, context)
+            for m in self.output_blocks:
+                h = m(torch.cat([h, hs.pop()], dim=1), emb, context)
+        finally:
+            if touched is not None:
+                for b in touched[0]:
+                    b.__dict__.pop("_emb_add", None)
+                for a in touched[1]:
+                    a.__dict__.pop("_v_token", None)
         h = self.out[2](group_norm(self.out[0], h.type(x.dtype), silu=True, float32=True))
         return h.contiguous()
 

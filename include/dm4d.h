@@ -197,7 +197,7 @@ int dm4d_mark_visible(int32_t N, const float *means3D, const float *viewmatrix, 
 #define DM4D_GN_F32 1
 #define DM4D_GN_MAX_SPLITS 128
 int dm4d_groupnorm_nhwc_forward(int32_t N, int32_t HW, int32_t C, int32_t G, int32_t dtype, const void *x, const void *add,
-                                int32_t add_stride /* C: add is [N, C]; 0: add is [C], the same for every sample */,
+                                int32_t add_stride /* >= C (a multiple of 8): add is [N, C], rows add_stride elements apart; 0: add is [C], the same for every sample */,
                                 const void *gamma, const void *beta, float eps, int32_t silu, void *y, float *stats,
                                 float *scratch, int32_t splits, dm4d_stream_t stream);
 /* dL/dx of the above for frozen gamma / beta and a constant `add` (the guidance model is not trained): x, add as given to
@@ -213,6 +213,12 @@ int dm4d_add_bias_nhwc(int64_t rows, int32_t C, int32_t dtype, const void *a, co
 /* GEGLU (extern/ldm_zero123/modules/attention.py:48-56): y[r, d] = proj[r, d] * gelu(proj[r, D + d]), exact (erf) GELU;
  * proj [rows, 2 D], y [rows, D]. */
 int dm4d_geglu(int64_t rows, int32_t D, int32_t dtype, const void *proj, void *y, dm4d_stream_t stream);
+/* Residual add + LayerNorm of float16 rows (the UNet's transformer blocks, extern/ldm_zero123/modules/attention.py:196-213, without
+ * gradients):  s = x[r] (+ tok[r / rows_per_sample], a row per sample broadcast over its positions: the single-token
+ * cross-attention);  normed[r] = LayerNorm(s) gamma + beta (float32 statistics);  xb[r] = s (+ bias2) -- the residual operand of
+ * the next GEMM with that GEMM's output bias already added.  tok, bias2, xb may be NULL.  C % 8 == 0, C <= 2048. */
+int dm4d_add_layernorm_f16(int64_t rows, int32_t C, int32_t rows_per_sample, const void *x, const void *tok, const void *gamma,
+                           const void *beta, float eps, const void *bias2, void *normed, void *xb, dm4d_stream_t stream);
 
 /* ------------------------------------------------------------------ simple-knn */
 

@@ -195,3 +195,29 @@ def test_residual_bias_add_and_geglu(dtype):
         pr = p.clone().requires_grad_(True)                                               # gradient wanted: torch path
         fused_norm.geglu(pr).sum().backward()
         assert pr.grad is not None
+
+
+def test_add_layer_norm_matches_torch():
+    """dm4d_add_layernorm_f16: LayerNorm(x + tok) and x + tok + bias2 in one launch, against torch in float32."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a HIP device")
+    from dreammesh4d_amd.fused_norm import add_layer_norm
+
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(3)
+    for (B, L, C) in ((2, 64, 320), (3, 17, 640), (1, 5, 1280), (2, 9, 2048)):
+        x = torch.randn(B, L, C, generator=g).to(dev).half()
+        tok = torch.randn(B, 1, C, generator=g).to(dev).half()
+        b2 = torch.randn(C, generator=g).to(dev).half()
+        ln = torch.nn.LayerNorm(C).to(dev).half()
+        with torch.no_grad():
+            ln.weight.copy_(torch.randn(C, generator=g).to(dev)); ln.bias.copy_(torch.randn(C, generator=g).to(dev))
+        for t, b in ((None, None), (tok, None), (tok, b2), (None, b2)):
+            n, xb = add_layer_norm(ln, x, t, b)
+            s = x if t is None else (x + t)                                   # float16 sum, as the separate add would leave it
+            ref_n = torch.nn.functional.layer_norm(s.float(), (C,), ln.weight.float(), ln.bias.float(), ln.eps)
+            ref_xb = s.float() + (0 if b is None else b.float())
+            assert (n.float() - ref_n).abs().max() <= 2 ** -9 * max(1.0, ref_n.abs().max().item())
+            assert (xb.float() - ref_xb).abs().max() <= 2 ** -10 * max(1.0, ref_xb.abs().max().item())
+    with pytest.raises(ValueError):
+        add_layer_norm(torch.nn.LayerNorm(12).to(dev).half(), torch.zeros(1, 2, 12, device=dev, dtype=torch.float16))

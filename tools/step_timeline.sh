@@ -15,8 +15,8 @@ import csv, glob
 f = glob.glob('/tmp/stl/**/k_kernel_trace.csv', recursive=True)[0]
 rows = [r for r in csv.DictReader(open(f))]
 rows.sort(key=lambda r: int(r['Start_Timestamp']))
-# steps start at k_hex_fwd; take the 20th from the end
-starts = [i for i, r in enumerate(rows) if 'k_hex_fwd' in r['Kernel_Name']]
+# steps start at k_nodenet_fwd; take the 20th from the end
+starts = [i for i, r in enumerate(rows) if 'k_nodenet_fwd' in r['Kernel_Name']]
 i0, i1 = starts[-20], starts[-19]
 t0 = int(rows[i0]['Start_Timestamp'])
 for r in rows[i0:i1]:
