@@ -337,28 +337,28 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv3x3(ConvDesc d)
 //   (its patch pixel index is set to -2: the +-1 of the horizontal taps stays inside the 256 zero bytes); left / right image
 //   borders and rows past the tensor are zeros in the patch itself (the descriptor's range check).
 //   W a power of two >= 8 (conv_plan sends everything else to the implicit GEMM).
-constexpr int kDirPieces = 3;                                   // patch pieces per wave: 3 x 8 x 64 lanes / 4 = 384 pixels >= 34 x 10
-constexpr int kDirPatchSlots = kDirPieces * 512;
+constexpr int kDirPatchSlots = 1536;                            // patch: 384 pixels x 4 pieces >= 34 x 10
 constexpr int kDirZeroSlots = 16;                               // 256 bytes of zeros in front of each patch buffer
-constexpr int kDirBSlots = 512;
-constexpr int kDirRing = 9;                                     // filter ring: one stage per tap
-constexpr int kDirAhead = 4;                                    // filter tiles in flight ahead of the one being multiplied
-constexpr int kDirLdsSlots = 2 * (kDirZeroSlots + kDirPatchSlots) + kDirRing * kDirBSlots;
-
-// DMA instructions a wave issues in the iteration of tap `tap` (more: a chunk follows this one)
-constexpr int dir_issues(int tap, bool more) { return ((tap < kDirPieces && more) ? 1 : 0) + ((tap + kDirAhead < 9 || more) ? 1 : 0); }
+// NWN: wave columns (the tile is 256 pixels x 64 NWN filters, 4 NWN waves); RING: stages of the filter ring (stage = tap % RING:
+// 3 or 9, compile time in the unrolled tap loop); AHEAD: filter tiles in flight ahead of the one being multiplied (< RING)
+template <int NWN, int RING> constexpr int dir_lds_slots() { return 2 * (kDirZeroSlots + kDirPatchSlots) + RING * 256 * NWN; }
+// DMA instructions a wave issues in the iteration of tap `tap` (more: a chunk follows this one; PIECES patch pieces per wave)
+constexpr int dir_issues(int tap, bool more, int PIECES, int AHEAD) { return ((tap < PIECES && more) ? 1 : 0) + ((tap + AHEAD < 9 || more) ? 1 : 0); }
 // ... and how many it may leave in flight at the barrier of tap `tap`: everything issued after the filters of k-tile + 1, i.e. in the
-// previous kDirAhead - 2 iterations (those before tap 0 belong to the previous chunk, which had a successor)
-constexpr int dir_in_flight(int tap, bool more)
+// previous AHEAD - 2 iterations (those before tap 0 belong to the previous chunk, which had a successor)
+constexpr int dir_in_flight(int tap, bool more, int PIECES, int AHEAD)
 {
     int n = 0;
-    for (int k = 1; k <= kDirAhead - 2; ++k) n += tap - k >= 0 ? dir_issues(tap - k, more) : dir_issues(tap - k + 9, true);
+    for (int k = 1; k <= AHEAD - 2; ++k) n += tap - k >= 0 ? dir_issues(tap - k, more, PIECES, AHEAD) : dir_issues(tap - k + 9, true, PIECES, AHEAD);
     return n;
 }
 
+template <int NWN, int RING, int AHEAD>
 __device__ __forceinline__ void conv3x3_direct_tile(const ConvDesc &d, int chunks_per_split, int lgTW)
 {
-    constexpr int BM = 256, BN = 128, NW = 8;
+    constexpr int BM = 256, BN = 64 * NWN, NW = 4 * NWN;
+    constexpr int kDirPieces = kDirPatchSlots / (64 * NW), kDirBSlots = 256 * NWN, kDirRing = RING, kDirAhead = AHEAD;
+    static_assert(AHEAD >= 2 && AHEAD < RING && 9 % RING == 0 && kDirPieces <= 9, "ring");
     extern __shared__ __attribute__((aligned(1024))) uint4 smem[];
     [[maybe_unused]] const int cv_probe = d.probe;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -449,7 +449,7 @@ __device__ __forceinline__ void conv3x3_direct_tile(const ConvDesc &d, int chunk
         }
 #pragma unroll
         for (int j = 0; j < 2; ++j)
-            rb[ks][j] = *reinterpret_cast<const __attribute__((address_space(3))) f16x8 *>(fb[ks][j] + tap * (kDirBSlots * 16));
+            rb[ks][j] = *reinterpret_cast<const __attribute__((address_space(3))) f16x8 *>(fb[ks][j] + (tap % kDirRing) * (kDirBSlots * 16));
     };
     auto mma = [&](auto KS) {
         constexpr int ks = decltype(KS)::value;
@@ -468,7 +468,7 @@ __device__ __forceinline__ void conv3x3_direct_tile(const ConvDesc &d, int chunk
 #pragma unroll
         for (int i = 0; i < kDirPieces; ++i) issue_patch(i, 0, 0);
 #pragma unroll
-        for (int k = 0; k < kDirAhead; ++k) issue_b(k, k, 0);
+        for (int k = 0; k < kDirAhead; ++k) issue_b(k, k % kDirRing, 0);
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kDirAhead - 1) : "memory");
     }
     __syncthreads();                                        // (also publishes the zero regions)
@@ -481,12 +481,12 @@ __device__ __forceinline__ void conv3x3_direct_tile(const ConvDesc &d, int chunk
         __builtin_amdgcn_sched_barrier(0);      // reads first, THEN the MFMAs they overlap with (the scheduler otherwise sinks them to 1-2 MFMAs before their use)
         mma(K0{});
         // k-tile + 1's filters (and every patch piece issued before them) have landed
-        if (more) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(dir_in_flight(tap, true)) : "memory");
-        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(dir_in_flight(tap, false)) : "memory");
+        if (more) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(dir_in_flight(tap, true, kDirPieces, kDirAhead)) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(dir_in_flight(tap, false, kDirPieces, kDirAhead)) : "memory");
         __builtin_amdgcn_s_barrier();
         if (tap < kDirPieces && more) issue_patch(tap, (ch + 1) & 1, ch + 1);
-        if (tap + kDirAhead < 9) issue_b(tap + kDirAhead, tap + kDirAhead, ch);
-        else if (more) issue_b(tap + kDirAhead - 9, tap + kDirAhead - 9, ch + 1);
+        if (tap + kDirAhead < 9) issue_b(tap + kDirAhead, (tap + kDirAhead) % kDirRing, ch);
+        else if (more) issue_b(tap + kDirAhead - 9, (tap + kDirAhead - 9) % kDirRing, ch + 1);
         read(K0{}, std::integral_constant<int, (tap + 1) % 9>{}, tap == 8 ? pnext : pcur);
         __builtin_amdgcn_sched_barrier(0);
         mma(K1{});
@@ -511,16 +511,17 @@ __device__ __forceinline__ void conv3x3_direct_tile(const ConvDesc &d, int chunk
         }
     }
 #undef DM4D_TAP
-    static_assert((size_t)BM * (BN * 2 + 16) <= (size_t)kDirLdsSlots * 16, "epilogue staging does not fit");
+    static_assert((size_t)BM * (BN * 2 + 16) <= (size_t)dir_lds_slots<NWN, RING>() * 16, "epilogue staging does not fit");
     conv_epilogue<BM, BN, NW>(d, acc, row_of, 64 * wn, n0, reinterpret_cast<char *>(smem), tid, lane, cv_probe, [&](int row) {
         const int g = g0 + (row >> lgTW);
         return g < R ? g * W + x0 + (row & (TW - 1)) : -1;
     });
 }
 
-__global__ __launch_bounds__(512) void k_conv3x3_direct(ConvDesc d, int chunks_per_split, int lgTW)
+template <int NWN, int RING, int AHEAD>
+__global__ __launch_bounds__(256 * NWN) void k_conv3x3_direct(ConvDesc d, int chunks_per_split, int lgTW)
 {
-    conv3x3_direct_tile(d, chunks_per_split, lgTW);
+    conv3x3_direct_tile<NWN, RING, AHEAD>(d, chunks_per_split, lgTW);
 }
 
 // y = sum over splits of partial + bias (+ res), 8 outputs per thread
@@ -609,8 +610,8 @@ __global__ __launch_bounds__(256) void k_conv3x3_c128_small(int N, int H, int W,
 // 32 x 64 | 6: the same, 4-deep | 5: 256 x 128, 8 waves of 64 x 64, 3-deep | 8: the same, 4-deep | 7: the direct kernel (256 x 128)
 static void cfg_tile(int cfg, int &BM, int &BN)
 {
-    BM = (cfg == 1 || cfg == 5 || cfg == 7 || cfg == 8) ? 256 : 128;
-    BN = 128;
+    BM = (cfg == 1 || cfg == 5 || cfg == 7 || cfg == 8 || cfg == 9) ? 256 : 128;
+    BN = cfg == 9 ? 64 : 128;
 }
 static int conv_plan(int M, int W, int Cout, int kt_total, int &cfg, int &splits)
 {
@@ -618,7 +619,9 @@ static int conv_plan(int M, int W, int Cout, int kt_total, int &cfg, int &splits
     if (force) cfg = atoi(force);
     // measured per shape (tools/conv_shapes.py, profiles/r03_zero123.md): the direct kernel wins on the VAE encoder's wide images
     // (W >= 64: 1.3-1.5x), the 128 x 128 implicit GEMM with two 4-wave workgroups per CU is as fast or faster everywhere else
-    else if (W >= 64 && (W & (W - 1)) == 0) cfg = 7;
+    // (... and on the UNet's larger problems, >= 28 GFLOP: 640 -> 640 at 32^2 72 vs 97 us, 1280 -> 1280 at 16^2 75 vs 108 us; below that
+    // the implicit GEMM with split-K wins by up to 25 %)
+    else if (W >= 8 && (W & (W - 1)) == 0 && (W >= 64 || (double)M * Cout * kt_total * kCvBK * 2.0 >= 28e9)) cfg = 7;
     else cfg = 3;
     int BM, BN;
     cfg_tile(cfg, BM, BN);
@@ -700,18 +703,24 @@ int dm4d_conv3x3_nhwc_f16(int32_t N, int32_t H, int32_t W, int32_t Cin, int32_t 
     case 6: rc = conv_launch<4, 2, 1, 2, 4>(d, st); break;
     case 5: rc = conv_launch<4, 2, 2, 2, 3>(d, st); break;
     case 8: rc = conv_launch<4, 2, 2, 2, 4>(d, st); break;
-    case 7: {      // direct: 256 pixels x 128 filters, the input patch resident in LDS for the nine taps
+    case 7: case 9: {      // direct: 256 pixels x 128 (7) / 64 (9) filters, the input patch resident in LDS for the nine taps
         const int W_ = d.W;
         if (W_ < 8 || (W_ & (W_ - 1)) != 0) { set_error("conv3x3 direct: W must be a power of two >= 8"); return DM4D_ERR_UNSUPPORTED; }
         int lgTW = 3;
         while ((1 << lgTW) < W_ && lgTW < 5) ++lgTW;                       // TW = min(W, 32)
         const int TH = 256 >> lgTW, R = d.N * d.H, cpt = d.Cin / kCvBK;
-        const size_t lds = (size_t)kDirLdsSlots * 16;
         const int chunks_per_split = (cpt + d.splits - 1) / d.splits;
         d.splits = (cpt + chunks_per_split - 1) / chunks_per_split;
-        const dim3 grid((unsigned)(((R + TH - 1) / TH) * (W_ >> lgTW)), (d.Cout + 127) / 128, d.splits);
-        DM4D_HIP_CHECK(hipFuncSetAttribute((const void *)k_conv3x3_direct, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(k_conv3x3_direct, grid, dim3(512), lds, st, d, chunks_per_split, lgTW);
+        const unsigned tiles_m = (unsigned)(((R + TH - 1) / TH) * (W_ >> lgTW));
+        if (cfg == 7) {         // 8 waves, 256 x 128, one workgroup per CU
+            const size_t lds = (size_t)dir_lds_slots<2, 9>() * 16;
+            DM4D_HIP_CHECK(hipFuncSetAttribute((const void *)k_conv3x3_direct<2, 9, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL((k_conv3x3_direct<2, 9, 4>), dim3(tiles_m, (d.Cout + 127) / 128, d.splits), dim3(512), lds, st, d, chunks_per_split, lgTW);
+        } else {                // 4 waves, 256 x 64, two workgroups per CU (one fills the bubble around the other's barrier)
+            const size_t lds = (size_t)dir_lds_slots<1, 3>() * 16;
+            DM4D_HIP_CHECK(hipFuncSetAttribute((const void *)k_conv3x3_direct<1, 3, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL((k_conv3x3_direct<1, 3, 2>), dim3(tiles_m, (d.Cout + 63) / 64, d.splits), dim3(256), lds, st, d, chunks_per_split, lgTW);
+        }
         DM4D_HIP_CHECK(hipGetLastError());
         rc = DM4D_OK;
         break;

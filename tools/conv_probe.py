@@ -12,7 +12,7 @@ for (N,H,Ci,Co) in SH:
     w = (torch.randn(Co, Ci, 3, 3, device=dev, dtype=torch.float16) * 0.02)
     pw = conv_mfma.pack_weight(w)
     fl = 2.0*N*H*H*Ci*Co*9
-    for cfg in (3, 7):
+    for cfg in (3, 7, 9):
         os.environ["DM4D_CONV_CFG"] = str(cfg)
         row = []
         for probe in (0,):
