@@ -99,7 +99,45 @@ def _cg(L_, mat, B, x0, max_iter, tol, check_every, what):
     return x0, it
 
 
-def heat_geodesic_knn(verts, faces, node_xyz, K, device="cuda:0", chunk=2048, tol=1e-10, heat_tol=1e-13, stats=None):
+def _tri_inverse(Lc, nb=1024):
+    """Inverse of a lower-triangular matrix by block recursion: [[A, 0], [B, C]]^-1 = [[A^-1, 0], [-C^-1 B A^-1, C^-1]] -- all the
+    work is float64 GEMM (73 TFLOP/s on MI355X); only the <= nb diagonal blocks go through a triangular solve."""
+    n = int(Lc.shape[0])
+    if n <= nb:
+        return torch.linalg.solve_triangular(Lc, torch.eye(n, dtype=Lc.dtype, device=Lc.device), upper=False)
+    h = (n // 2 + 255) // 256 * 256
+    out = torch.zeros_like(Lc)
+    a = out[:h, :h] = _tri_inverse(Lc[:h, :h], nb)
+    c = out[h:, h:] = _tri_inverse(Lc[h:, h:], nb)
+    out[h:, :h] = -(c @ (Lc[h:, :h] @ a))
+    return out
+
+
+def _dense_from_csr(mat, dev):
+    """scipy CSR (float64) -> dense [V, V] float64 on the device."""
+    V = mat.shape[0]
+    T = lambda a, dt: torch.as_tensor(np.ascontiguousarray(a), dtype=dt, device=dev)
+    rows = torch.repeat_interleave(torch.arange(V, device=dev), T(np.diff(mat.indptr), torch.int64))
+    A = torch.zeros(V, V, dtype=torch.float64, device=dev)
+    A.index_put_((rows, T(mat.indices, torch.int64)), T(mat.data, torch.float64), accumulate=True)
+    return A
+
+
+# The DENSE solver: at the sizes the reference builds graphs for (16.7k vertices) a [V, V] float64 matrix is 2.2 GB of the 288 GB
+# and the chip multiplies float64 matrices at 73 TFLOP/s, so the V heat systems and the M Poisson systems are a Cholesky
+# factorisation (0.11 s), a blocked triangular inverse (0.05 s) and GEMMs -- 0.6 s for the whole graph where the batched conjugate
+# gradients (csrc/heat.hip, bandwidth bound at 5 TB/s) take 3.0 s.  And it is the ACCURATE one: the heat solution decays like
+# exp(-d / sqrt(t)) -- 1e-57 across the bench mesh -- and only its direction enters, so every far-field value needs RELATIVE
+# accuracy.  Factorising (A + t L), an M-matrix up to the obtuse triangles, and multiplying its non-negative inverse factors never
+# cancels, and keeps it (like the sparse direct solver of the reference); an iteration stopped at |r| / |b| = 1e-13 leaves
+# everything below 1e-13 arbitrary, and the Poisson step spreads that over the mesh.  Against the sparse-LU restatement at the
+# bench scale (tools/graph_check_large.py, 600 random vertices): dense 98.8 % identical neighbour sets (the rest exact ties), conjugate
+# gradients 73 %.  The conjugate gradients are therefore only what `solver="cg"` asks for explicitly (and what the small-mesh test
+# still checks); beyond DENSE_MAX_VERTICES (4 matrices of V^2 doubles = 137 GB at 65,536) `auto` refuses instead of degrading.
+DENSE_MAX_VERTICES = 65536
+
+
+def heat_geodesic_knn(verts, faces, node_xyz, K, device="cuda:0", chunk=2048, tol=1e-10, heat_tol=1e-13, stats=None, solver="auto"):
     """K nearest nodes of every vertex by HEAT-METHOD distance from the vertex + the reference's weights (module docstring).
     -> (idx [V,K] int64, weights [V,K] float32) on `device`."""
     dev = torch.device(device)
@@ -128,7 +166,22 @@ def heat_geodesic_knn(verts, faces, node_xyz, K, device="cuda:0", chunk=2048, to
     # ---- g_m = L^+ e_{t_m} for the M nodes (right-hand sides projected onto the range of L: zero mean)
     B = torch.full((V, M), -1.0 / V, **f64)
     B[node_vertex, torch.arange(M, device=dev)] += 1.0
-    g, it_p = _cg(L_, Lm, B, torch.zeros(V, M, **f64), max_iter=20000, tol=tol, check_every=50, what="Poisson")
+    if solver not in ("auto", "dense", "cg"):
+        raise ValueError("solver must be auto, dense or cg")
+    if solver == "auto" and V > DENSE_MAX_VERTICES:
+        raise _lib.Dm4dError(f"heat method: {V} vertices exceed the dense solver's limit ({DENSE_MAX_VERTICES}); pass solver='cg' to accept "
+                             "the conjugate gradients' far-field error, or geodesic='edgepath'")
+    dense = solver in ("dense", "auto")
+    if dense:
+        # L is singular (constants): L + (c / V) 1 1^T is positive definite and has the same solution for zero-mean right-hand sides
+        Ld = _dense_from_csr(Lm, dev)
+        Ld += float(Lm.diagonal().mean()) / V
+        Li = _tri_inverse(torch.linalg.cholesky(Ld))
+        del Ld
+        g, it_p = Li.mT @ (Li @ B), 0
+        del Li
+    else:
+        g, it_p = _cg(L_, Lm, B, torch.zeros(V, M, **f64), max_iter=20000, tol=tol, check_every=50, what="Poisson")
     # W[3 f + c][m] = -sum_k D[f, k, c] g[faces[f, k], m]:  phi_i(t_m) = X_i^T W[:, m]
     Dt = torch.as_tensor(D, **f64)
     W = torch.zeros(F_, 3, M, **f64)
@@ -142,17 +195,28 @@ def heat_geodesic_knn(verts, faces, node_xyz, K, device="cuda:0", chunk=2048, to
     idx = torch.empty(V, K, dtype=torch.int64, device=dev)
     w = torch.empty(V, K, dtype=torch.float32, device=dev)
     it_h = 0
+    Uall = None
+    if dense:          # (A + t L)^-1, all V columns at once (symmetric: column s is the heat solution of source s)
+        Li = _tri_inverse(torch.linalg.cholesky(_dense_from_csr(Hm, dev)))
+        Uall = Li.mT @ Li
+        del Li
+        _mark("heat_dense")
     for s0 in range(0, V, chunk):
         S = min(chunk, V - s0)
-        Bh = torch.zeros(V, S, **f64)
-        Bh[torch.arange(s0, s0 + S, device=dev), torch.arange(S, device=dev)] = 1.0
+        if dense:
+            U = Uall[:, s0:s0 + S].contiguous()
+        else:
+            Bh = torch.zeros(V, S, **f64)
+            Bh[torch.arange(s0, s0 + S, device=dev), torch.arange(S, device=dev)] = 1.0
         # The heat solution decays like exp(-d / sqrt(t)) and only its DIRECTION enters: a residual of 1e-10 leaves the far field
         # (u < 1e-10 max u) with arbitrary directions, and the Poisson solve spreads that over the sphere -- measured on the
         # 1.2k-vertex test mesh: 70 iterations (|r|/|b| = 1.5e-11) misrank a node pair 7e-4 apart, 80 iterations (7e-14) match
         # the sparse-LU oracle.  The well-conditioned heat system reaches 1e-13 in ~10 iterations more.
-        U, it = _cg(L_, Hm, Bh, torch.zeros(V, S, **f64), max_iter=2000, tol=heat_tol, check_every=10, what="heat")
-        it_h = max(it_h, it)
-        _mark("heat_cg")
+        if not dense:
+            U, it = _cg(L_, Hm, Bh, torch.zeros(V, S, **f64), max_iter=2000, tol=heat_tol, check_every=10, what="heat")
+            it_h = max(it_h, it)
+            del Bh
+            _mark("heat_cg")
         XT = torch.empty(3 * F_, S, **f64)
         with torch.cuda.device(dev):
             _lib.check(L_.dm4d_heat_face_directions(F_, S, faces_t.data_ptr(), Gt.data_ptr(), U.data_ptr(), XT.data_ptr(),
@@ -161,10 +225,10 @@ def heat_geodesic_knn(verts, faces, node_xyz, K, device="cuda:0", chunk=2048, to
         with torch.cuda.device(dev):
             _lib.check(L_.dm4d_graph_select_knn(S, M, K, score.data_ptr(), S, s0, vt.data_ptr(), nt.data_ptr(), idx.data_ptr(),
                                                 w.data_ptr(), torch.cuda.current_stream(dev).cuda_stream), "dm4d_graph_select_knn")
-        del Bh, U, XT, score
+        del U, XT, score
         _mark("gemm_select")
     if stats is not None:
-        stats.update(poisson_iterations=it_p, heat_iterations=it_h, t=float(t), V=V, M=M)
+        stats.update(poisson_iterations=it_p, heat_iterations=it_h, t=float(t), V=V, M=M, solver="dense" if dense else "cg")
     return idx, w
 
 
