@@ -63,6 +63,7 @@ def _conv_nobias(conv, x):
     return F.conv2d(x, conv.weight, None, conv.stride, conv.padding)
 
 
+VAE_ATTENTION_BMM = os.environ.get("DM4D_VAE_ATTN_BMM", "1") != "0"                  # (A/B switch: _VaeAttn as bmm + softmax + bmm)
 FUSE_ADD_LAYERNORM = os.environ.get("DM4D_FUSE_ADD_LN", "1") != "0"                 # (A/B switch for BasicTransformerBlock._fused_no_grad)
 BATCH_SMALL_GEMMS = os.environ.get("DM4D_BATCH_SMALL_GEMMS", "1") != "0"      # (A/B switch for UNetModel._batched_small_gemms)
 _USE_MFMA_CONV = os.environ.get("DM4D_MFMA_CONV", "1") != "0"      # (A/B switch: "0" keeps every convolution on the library)
@@ -415,8 +416,15 @@ class _VaeAttn(nn.Module):
     def forward(self, x):
         B, Cc, Hh, Ww = x.shape
         h = group_norm(self.norm, x)
-        q, k, v = (_conv1x1(f, h).flatten(2).transpose(1, 2)[:, None] for f in (self.q, self.k, self.v))   # b 1 (hw) c
-        o = F.scaled_dot_product_attention(q, k, v)[:, 0].transpose(1, 2).reshape(B, Cc, Hh, Ww)
+        q, k, v = (_conv1x1(f, h).flatten(2).transpose(1, 2) for f in (self.q, self.k, self.v))            # b (hw) c
+        if x.is_cuda and VAE_ATTENTION_BMM:
+            # ONE head of 512 channels over 1024 positions: as the reference writes it (model.py AttnBlock: bmm, softmax, bmm).
+            # The library's fused attention is built for head dimensions <= 256: its backward took 0.32 ms of the SDS step
+            # here, the three batched GEMMs and their gradients take 0.1 ms.
+            w_ = torch.softmax(torch.bmm(q, k.transpose(1, 2)) * (int(Cc) ** -0.5), dim=2)
+            o = torch.bmm(w_, v).transpose(1, 2).reshape(B, Cc, Hh, Ww)
+        else:
+            o = F.scaled_dot_product_attention(q[:, None], k[:, None], v[:, None])[:, 0].transpose(1, 2).reshape(B, Cc, Hh, Ww)
         return x + _conv1x1(self.proj_out, o)
 
 
@@ -528,7 +536,7 @@ class Zero123(nn.Module):
         mean, logvar = self.first_stage_model.encode_moments(x).chunk(2, dim=1)
         logvar = logvar.clamp(-30.0, 20.0)
         if noise is None:
-            noise = torch.randn(mean.shape).to(mean)      # the reference samples this on the CPU (distributions.py:37-41)
+            noise = torch.randn(mean.shape, pin_memory=mean.is_cuda).to(mean, non_blocking=True)      # the reference samples this on the CPU (distributions.py:37-41); pinned + non-blocking: see encode_images
         return self.scale_factor * (mean + torch.exp(0.5 * logvar) * noise)
 
 
@@ -591,7 +599,11 @@ class TemporalStableZero123Guidance(nn.Module):
     def encode_images(self, imgs, noise=None):
         """imgs [B,3,256,256] in [0,1] -> sampled latents [B,4,32,32] (imgs.dtype); differentiable w.r.t. imgs."""
         if noise is None:
-            noise = torch.randn(imgs.shape[0], 4, imgs.shape[2] // 8, imgs.shape[3] // 8).to(imgs.device, self.weights_dtype)
+            # drawn on the CPU like the reference's DiagonalGaussianDistribution.sample (distributions.py:37-41) -- but into PINNED
+            # memory and copied without blocking: a pageable host-to-device copy waits for everything queued on the stream, i.e.
+            # it stalled the host for the whole previous iteration (10 of its 14.4 ms) and nothing could be enqueued ahead
+            noise = torch.randn(imgs.shape[0], 4, imgs.shape[2] // 8, imgs.shape[3] // 8, pin_memory=imgs.is_cuda).to(
+                imgs.device, self.weights_dtype, non_blocking=True)
         if self.use_graphs and imgs.is_cuda and imgs.requires_grad and torch.is_grad_enabled() and self._graph_error is None:
             key = tuple(imgs.shape)
             try:
