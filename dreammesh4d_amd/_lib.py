@@ -120,6 +120,10 @@ _SIGNATURES = {
     "dm4d_skin_vertices_forward": (C.c_int, [C.c_int32] * 4 + [vp] * 10),
     "dm4d_skin_scratch_bytes": (C.c_size_t, [C.c_int32, C.c_int32]),
     "dm4d_skin_vertices_backward": (C.c_int, [C.c_int32] * 4 + [vp] * 17),
+    "dm4d_vertex_scales_forward": (C.c_int, [C.c_int32] * 5 + [vp] * 6),
+    "dm4d_vertex_scales_backward": (C.c_int, [C.c_int32] * 5 + [vp] * 10),
+    "dm4d_gaussian_scales_forward": (C.c_int, [C.c_int32] * 4 + [vp] * 6),
+    "dm4d_gaussian_scales_backward": (C.c_int, [C.c_int32] * 4 + [vp] * 10),
     "dm4d_face_gaussians_forward": (C.c_int, [C.c_int32] * 2 + [vp] * 8),
     "dm4d_face_scratch_bytes": (C.c_size_t, [C.c_int32]),
     "dm4d_face_gaussians_backward": (C.c_int, [C.c_int32] * 3 + [vp] * 13),

@@ -223,34 +223,93 @@ def strain_to_matrix(ds):
                         ds[..., 4], ds[..., 5], one + ds[..., 2]], dim=-1).reshape(ds.shape[:-1] + (3, 3))
 
 
+class _VertexScales(torch.autograd.Function):
+    """csrc/dscale.hip: dm4d_vertex_scales_forward / _backward (atomic-free gather over the node -> (vertex, k) adjacency)."""
+
+    @staticmethod
+    def forward(ctx, graph, m, ds, d_opacity):
+        L, g, dev = _lib.lib(), graph, graph.device
+        ds_, do_ = _f32(ds), (None if d_opacity is None else _f32(d_opacity))
+        NF = int(ds_.shape[0])
+        out = torch.empty(NF, g.V, 3, 3, dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            _lib.check(L.dm4d_vertex_scales_forward(m, NF, g.V, g.M, g.K, _p(g.nbr_idx), _p(g.nbr_w), _p(ds_), _p(do_), _p(out), _st(dev)),
+                       "dm4d_vertex_scales_forward")
+        ctx.graph, ctx.m = g, m
+        ctx.save_for_backward(ds_, do_)
+        return out
+
+    @staticmethod
+    def backward(ctx, g_out):
+        L, g, dev = _lib.lib(), ctx.graph, ctx.graph.device
+        ds_, do_ = ctx.saved_tensors
+        NF = int(ds_.shape[0])
+        go = _f32(g_out)
+        o_ds = torch.empty_like(ds_)
+        o_do = torch.empty_like(do_) if do_ is not None else None
+        with torch.cuda.device(dev):
+            _lib.check(L.dm4d_vertex_scales_backward(ctx.m, NF, g.V, g.M, g.K, _p(g.nbr_idx), _p(g.nbr_w), _p(ds_), _p(do_), _p(g.csr_off),
+                                                     _p(g.csr_items), _p(go), _p(o_ds), _p(o_do), _st(dev)), "dm4d_vertex_scales_backward")
+        return None, None, o_ds, o_do
+
+
 def vertex_scale_matrices(graph: DeformGraph, ds, d_opacity=None, method="hybrid"):
     """Per-vertex scale matrices [n_frames, V, 3, 3] of the `d_scale` branch (dynamic_sugar.py:593-611): lbs: the weighted
     sum of the neighbour nodes' strain matrices; hybrid: weighted by the nodes' opacities as well, plus (1 - lbs weight) I
     with the lbs weight clamp(sum_k w_k o_k + 0.4, max = 1) of the position blend (:572-578).  ds [n_frames, M, 6] raw strain
-    head outputs, d_opacity [n_frames, M] raw opacity logits."""
+    head outputs, d_opacity [n_frames, M] raw opacity logits.  HIP kernels (csrc/dscale.hip) on the graph's device."""
     if method not in ("lbs", "hybrid"):
         raise ValueError("d_scale needs skinning_method lbs or hybrid (the reference defines no vertex scale for dqs)")
-    idx = graph.nbr_idx.long()
-    S = strain_to_matrix(ds)[:, idx]                                   # [n_frames, V, K, 3, 3]
-    w = graph.nbr_w[None, :, :, None, None]
-    if method == "lbs":
-        return (w * S).sum(dim=2)
-    if d_opacity is None:
+    if method == "hybrid" and d_opacity is None:
         raise ValueError("hybrid skinning needs the opacity head output")
-    o = torch.sigmoid(d_opacity)[:, idx]                               # [n_frames, V, K]
-    lbs_w = torch.clamp((graph.nbr_w[None] * o).sum(dim=-1) + 0.4, max=1.0)
-    eye = torch.eye(3, dtype=S.dtype, device=S.device)
-    return (w * o[..., None, None] * S).sum(dim=2) + (1.0 - lbs_w)[..., None, None] * eye
+    if not ds.is_cuda:
+        raise _lib.Dm4dError("vertex_scale_matrices: the operator runs on the HIP device (no CPU fallback in the product)")
+    if tuple(ds.shape[1:]) != (graph.M, 6) or (method == "hybrid" and tuple(d_opacity.shape) != (ds.shape[0], graph.M)):
+        raise ValueError(f"vertex_scale_matrices: ds must be [n_frames, {graph.M}, 6] and d_opacity [n_frames, {graph.M}]")
+    return _VertexScales.apply(graph, METHODS[method], ds, d_opacity if method == "hybrid" else None)
+
+
+class _GaussianScales(torch.autograd.Function):
+    """csrc/dscale.hip: dm4d_gaussian_scales_forward / _backward (gather over the vertex -> (face, corner) adjacency)."""
+
+    @staticmethod
+    def forward(ctx, topo, bary, vertex_scales, scaling):
+        L, t, dev = _lib.lib(), topo, topo.device
+        sv, sc = _f32(vertex_scales), _f32(scaling).reshape(t.F * t.G, 3)
+        NF = int(sv.shape[0])
+        out = torch.empty(NF, t.F * t.G, 3, dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            _lib.check(L.dm4d_gaussian_scales_forward(NF, t.F, t.G, t.V, _p(t.faces), _p(bary), _p(sv), _p(sc), _p(out), _st(dev)),
+                       "dm4d_gaussian_scales_forward")
+        ctx.topo, ctx.bary, ctx.sc_shape = t, bary, scaling.shape
+        ctx.save_for_backward(sv, sc)
+        return out
+
+    @staticmethod
+    def backward(ctx, g_out):
+        L, t, dev = _lib.lib(), ctx.topo, ctx.topo.device
+        sv, sc = ctx.saved_tensors
+        NF = int(sv.shape[0])
+        go = _f32(g_out)
+        o_sv = torch.empty_like(sv) if ctx.needs_input_grad[2] else None
+        o_sc = torch.empty_like(sc) if ctx.needs_input_grad[3] else None
+        with torch.cuda.device(dev):
+            _lib.check(L.dm4d_gaussian_scales_backward(NF, t.F, t.G, t.V, _p(t.faces), _p(ctx.bary), _p(sv), _p(sc), _p(t.csr_off), _p(t.csr_items),
+                                                       _p(go), _p(o_sv), _p(o_sc), _st(dev)), "dm4d_gaussian_scales_backward")
+        return None, None, o_sv, None if o_sc is None else o_sc.reshape(ctx.sc_shape)
 
 
 def gaussian_scales(topo: MeshTopology, vertex_scales, scaling):
     """Scales [n_frames, N, 3] of the bound Gaussians under `d_scale` (dynamic_sugar.py:697-704): the barycentric blend of
-    the three corner vertices' scale matrices applied to the static scaling vector (thickness, s1, s2)."""
+    the three corner vertices' scale matrices applied to the static scaling vector (thickness, s1, s2).  HIP kernels
+    (csrc/dscale.hip)."""
     from . import geometry as geo
 
-    G = topo.G
-    bary = geo.bary_coords(G, vertex_scales.device, vertex_scales.dtype)[..., 0]      # [G, 3]
-    corner = vertex_scales[:, topo.faces.long()]                                      # [n_frames, F, 3, 3, 3]
-    D = torch.einsum("gc,tfcij->tfgij", bary, corner)                                 # [n_frames, F, G, 3, 3]
-    sc = scaling.reshape(topo.F, G, 3)
-    return torch.einsum("tfgij,fgj->tfgi", D, sc).reshape(vertex_scales.shape[0], topo.F * G, 3)
+    if not vertex_scales.is_cuda:
+        raise _lib.Dm4dError("gaussian_scales: the operator runs on the HIP device (no CPU fallback in the product)")
+    if tuple(vertex_scales.shape[1:]) != (topo.V, 3, 3) or scaling.numel() != topo.F * topo.G * 3:
+        raise ValueError(f"gaussian_scales: vertex_scales must be [n_frames, {topo.V}, 3, 3] and scaling [{topo.F * topo.G}, 3]")
+    bary = topo.__dict__.get("_bary_dev")
+    if bary is None:
+        bary = topo.__dict__["_bary_dev"] = geo.bary_coords(topo.G, topo.device, torch.float32)[..., 0].contiguous()       # [G, 3]
+    return _GaussianScales.apply(topo, bary, vertex_scales, scaling)

@@ -239,9 +239,9 @@ int dm4d_dist2_knn3_ws(int32_t N, const float *points, float *out, void *scratch
  * (dm4d_face_gaussians_backward) the rotation operations return what the reference's pypose LieTensor autograd returns
  * (SO3 Log / Act / Mul, so3 Exp: left-perturbation tangent gradients zero-padded into the quaternion storage,
  * C/geometry/dynamic_sugar.py:461,530-586,669-676,877-889) -- the gradient the reference actually trains its rotation
- * head with.  Restated from pypose 0.6.7's published rules (the package is not in the tree): parity unpinned.  The
- * dual-quaternion algebra of the DQS branch (C/utils/dual_quaternions.py:115-131,184-231, SO3 products of NON-unit
- * operands) stays Euclidean in both modes. */
+ * head with.  Restated from pypose 0.6.7's published rules (the package is not in the tree): parity unpinned.  The two
+ * SO3 products of the DQS branch's dual-quaternion algebra (C/utils/dual_quaternions.py:115-131,184-231, NON-unit
+ * operands) follow the same SO3_Mul rule in this mode (X: (g[:3], 0), Y: (g[:3] Adj(X), 0)). */
 #define DM4D_GRAD_PYPOSE 0x100
 
 /* Sparse-control skinning of the V mesh vertices by M deformation-graph nodes, K neighbours each
@@ -257,6 +257,23 @@ int dm4d_skin_vertices_forward(int32_t method, int32_t V, int32_t M, int32_t K, 
                                const float *ds, const float *d_opacity, float *out_xyz, float *out_rot,
                                dm4d_stream_t stream);
 size_t dm4d_skin_scratch_bytes(int32_t V, int32_t K);
+/* The `d_scale: true` branch (C/geometry/dynamic_sugar.py:593-611, 697-704; csrc/dscale.hip).  Vertex scale matrices
+ * out [n_frames, V, 9] (row-major 3x3) from the strain head ds [n_frames, M, 6] (and, hybrid, the opacity logits
+ * d_opacity [n_frames, M]); method 0 = lbs, 2 = hybrid (the reference defines no vertex scale for dqs).  Gaussian scales
+ * out [n_frames, F*G, 3] = (sum_c bary[g, c] vertex_scales[faces[f, c]]) scaling[f*G + g]; bary [G, 3]; G <= 6.
+ * Backward: node_csr_* as above (item = v*K + k), vert_csr_* the static inverse of faces (item = face*3 + corner);
+ * dL_ddo / dL_dvertex_scales / dL_dscaling may be NULL. */
+int dm4d_vertex_scales_forward(int32_t method, int32_t n_frames, int32_t V, int32_t M, int32_t K, const int32_t *nbr_idx, const float *nbr_w,
+                               const float *ds, const float *d_opacity, float *out, dm4d_stream_t stream);
+int dm4d_vertex_scales_backward(int32_t method, int32_t n_frames, int32_t V, int32_t M, int32_t K, const int32_t *nbr_idx, const float *nbr_w,
+                                const float *ds, const float *d_opacity, const int32_t *node_csr_offsets, const int32_t *node_csr_items,
+                                const float *dL_dout, float *dL_dds, float *dL_ddo, dm4d_stream_t stream);
+int dm4d_gaussian_scales_forward(int32_t n_frames, int32_t F, int32_t G, int32_t V, const int32_t *faces, const float *bary,
+                                 const float *vertex_scales, const float *scaling, float *out, dm4d_stream_t stream);
+int dm4d_gaussian_scales_backward(int32_t n_frames, int32_t F, int32_t G, int32_t V, const int32_t *faces, const float *bary,
+                                  const float *vertex_scales, const float *scaling, const int32_t *vert_csr_offsets,
+                                  const int32_t *vert_csr_items, const float *dL_dout, float *dL_dvertex_scales, float *dL_dscaling,
+                                  dm4d_stream_t stream);
 /* Backward.  node_csr_* is the static inverse of nbr_idx: node m is referenced by the items
  * node_csr_items[node_csr_offsets[m] .. node_csr_offsets[m+1]) where item = v*K + k.
  * dL_dxyz / dL_drot may be NULL (zero).  Output pointers may be NULL when not wanted.
