@@ -89,8 +89,9 @@ __global__ __launch_bounds__(kGnThreads) void k_groupnorm(GnArgs a)
             const float inv_m = 1.0f / ((float)cpg * (float)a.HW);
             float mean, rstd;
             if (MODE == kGnFwdApply) {
-                mean = s * inv_m;
-                const float var = fmaxf(q * inv_m - mean * mean, 0.f);
+                const float dm = s * inv_m;                                      // mean of the shifted values (see kGnFwdStats)
+                mean = (float)x[(size_t)t * cpg] + dm;
+                const float var = fmaxf(q * inv_m - dm * dm, 0.f);
                 rstd = 1.0f / sqrtf(var + a.eps);
                 if (split == 0) { a.stats[((size_t)n * G + t) * 2] = mean; a.stats[((size_t)n * G + t) * 2 + 1] = rstd; }
             } else {
@@ -119,7 +120,14 @@ __global__ __launch_bounds__(kGnThreads) void k_groupnorm(GnArgs a)
             for (int i = 0; i < VEC; ++i) {
                 acc1[i] = 0.f; acc2[i] = 0.f;
                 const float ad = (float)av[i];
-                if (MODE == kGnFwdStats) { k0[i] = ad; k1[i] = k2[i] = k3[i] = k4[i] = k5[i] = 0.f; continue; }
+                if (MODE == kGnFwdStats) {
+                    // SHIFTED sums: x + ad - K with K = the group's first element of the sample, so that the variance below is
+                    // sum d^2 / m - (sum d / m)^2 of values centred within ~a standard deviation of 0 -- the plain two-moment
+                    // form cancels catastrophically once |mean| >> std (float32: |mean| / std = 1e3 loses every digit)
+                    k0[i] = ad - (float)x[(size_t)((cb + i) / cpg) * cpg];
+                    k1[i] = k2[i] = k3[i] = k4[i] = k5[i] = 0.f;
+                    continue;
+                }
                 const int g = (cb + i) / cpg;
                 const float mean = g_a[g], rstd = g_b[g], gam = (float)gv[i], bet = (float)bv[i];
                 if (MODE == kGnFwdApply) {           // z = (x + ad) A + B

@@ -221,3 +221,26 @@ def test_add_layer_norm_matches_torch():
             assert (xb.float() - ref_xb).abs().max() <= 2 ** -10 * max(1.0, ref_xb.abs().max().item())
     with pytest.raises(ValueError):
         add_layer_norm(torch.nn.LayerNorm(12).to(dev).half(), torch.zeros(1, 2, 12, device=dev, dtype=torch.float16))
+
+
+def test_statistics_survive_a_large_mean():
+    """|mean| / std = 3000 in float32: the two-moment form E[x^2] - E[x]^2 loses every digit of the variance (1e-7 x 9e6); the
+    operator accumulates SHIFTED sums (csrc/groupnorm.hip) and must stay at the accuracy of a float64 reference."""
+    _need_gpu()
+    from dreammesh4d_amd import fused_norm
+
+    dev = torch.device("cuda:0")
+    N, C, H, W, G = 2, 64, 24, 20, 32
+    g = torch.Generator(device="cpu").manual_seed(11)
+    noise = 0.1 * torch.randn(N, C, H, W, generator=g, dtype=torch.float64)
+    offs = 300.0 + 2.0 * torch.randn(N, C, 1, 1, generator=g, dtype=torch.float64) * 0.01          # channels of a group differ a little
+    x64 = noise + offs
+    x = x64.float().to(dev).contiguous(memory_format=torch.channels_last)
+    m = torch.nn.GroupNorm(G, C, eps=1e-5).to(dev)
+    for p in m.parameters():
+        p.requires_grad_(False)
+    with torch.no_grad():
+        y = fused_norm.group_norm(m, x)
+    want = F.group_norm(x.double().cpu(), G, None, None, 1e-5)              # float64 statistics of the float32 data
+    err = float((y.double().cpu() - want).abs().max())
+    assert err < 5e-3, err                                                   # (the two-moment float32 form: errors of order 1)
