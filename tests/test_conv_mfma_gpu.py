@@ -13,6 +13,9 @@ SHAPES = [  # N, H, W, Cin, Cout       (a subset of the 22 shapes of one SDS ste
     (8, 32, 32, 320, 320), (8, 32, 32, 640, 320), (8, 16, 16, 640, 640), (8, 16, 16, 1280, 640), (8, 8, 8, 1280, 1280),
     (8, 8, 8, 2560, 1280), (8, 4, 4, 1280, 1280), (2, 128, 128, 128, 128), (2, 64, 64, 128, 256), (1, 32, 32, 512, 512),
     (3, 16, 16, 64, 96), (1, 5, 7, 32, 32),       # ragged: M not a multiple of any tile, W not a power of two
+    # the direct kernel (W >= 64) off its comfortable path: one channel chunk (no prefetch of a next patch), fewer filters than
+    # a tile, a row count that is no multiple of the tile's 8 rows, tiles that straddle two images, H != W
+    (1, 64, 64, 32, 64), (1, 20, 64, 64, 32), (3, 12, 64, 96, 160), (2, 8, 128, 64, 128),
 ]
 
 
