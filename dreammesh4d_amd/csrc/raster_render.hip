@@ -593,7 +593,7 @@ __device__ __forceinline__ void pixel_pair(const EntryRegs<C> &e, float (&acc)[1
             v = __builtin_fmaf(e.c[C > 3 ? 4 : 0], g[h][4], v);
             v = __builtin_fmaf(e.c[C > 3 ? 5 : 0], g[h][5], v);
         }
-        V[h] = __builtin_fmaf(e.dep, gD[h], v);
+        V[h] = LEAN == 2 ? v : __builtin_fmaf(e.dep, gD[h], v);      // (LEAN == 2: no depth gradient -- the product would be an exact 0)
     }
     const float R0 = __builtin_amdgcn_rcpf(Pinc[0]), R1 = __builtin_amdgcn_rcpf(Pinc[1]);
     Tb[0] = T[0] * R0; Tb[1] = T[1] * R1;                    // transmittance in front of the entry
