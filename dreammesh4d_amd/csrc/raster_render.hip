@@ -577,7 +577,9 @@ __device__ __forceinline__ void pixel_pair(const EntryRegs<C> &e, float (&acc)[1
     {
         const bool c0 = (e.k < last[0]) & pwok0 & (araw[0] >= kThr), c1 = (e.k < last[1]) & pwok1 & (araw[1] >= kThr);
         am[0] = c0 ? araw[0] : 0.f; am[1] = c1 ? araw[1] : 0.f;        // o G of the pairs that contribute (the straight-through factor of q)
-        a[0] = fminf(0.99f, am[0]); a[1] = fminf(0.99f, am[1]);
+        // min(0.99, am) for am >= 0 (never NaN: o G with finite o, G in [0, 1]) as ONE v_med3_f32: fminf costs a canonicalising v_max
+        // in front of its v_min, and this kernel's duration is its VALU instruction count (profiles/r03_pmc_sq.md)
+        a[0] = __builtin_amdgcn_fmed3f(am[0], 0.0f, 0.99f); a[1] = __builtin_amdgcn_fmed3f(am[1], 0.0f, 0.99f);
     }
     om[0] = 1.f - a[0]; om[1] = 1.f - a[1];
     Pinc[0] = om[0]; Pinc[1] = om[1];
