@@ -615,7 +615,7 @@ static void cfg_tile(int cfg, int &BM, int &BN)
 }
 static int conv_plan(int M, int W, int Cout, int kt_total, int &cfg, int &splits)
 {
-    const char *force = getenv("DM4D_CONV_CFG");
+    const char *force = getenv("DM4D_CONV_CFG");          // (A/B switches, read per call: tools/conv_probe.py flips them within a process)
     if (force) cfg = atoi(force);
     // measured per shape (tools/conv_shapes.py, profiles/r03_zero123.md): the direct kernel wins on the VAE encoder's wide images
     // (W >= 64: 1.3-1.5x), the 128 x 128 implicit GEMM with two 4-wave workgroups per CU is as fast or faster everywhere else
@@ -648,7 +648,11 @@ static int conv_launch(const ConvDesc &d, hipStream_t st)
     constexpr int A_INSTR = (BM * 4 + 64 * NW - 1) / (64 * NW), B_INSTR = (BN * 4 + 64 * NW - 1) / (64 * NW);
     const size_t lds = (size_t)kCvStages * (A_INSTR + B_INSTR) * 64 * NW * 16;
     const dim3 grid((d.M + BM - 1) / BM, (d.Cout + BN - 1) / BN, d.splits);
-    DM4D_HIP_CHECK(hipFuncSetAttribute((const void *)k_conv3x3<WM, WN, MB, NB, kCvStages>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    static bool attr_set = false;          // (per instantiation; a second thread repeating the call is harmless)
+    if (!attr_set) {
+        DM4D_HIP_CHECK(hipFuncSetAttribute((const void *)k_conv3x3<WM, WN, MB, NB, kCvStages>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set = true;
+    }
     hipLaunchKernelGGL((k_conv3x3<WM, WN, MB, NB, kCvStages>), grid, dim3(64 * NW), lds, st, d);
     DM4D_HIP_CHECK(hipGetLastError());
     return DM4D_OK;
@@ -714,11 +718,13 @@ int dm4d_conv3x3_nhwc_f16(int32_t N, int32_t H, int32_t W, int32_t Cin, int32_t 
         const unsigned tiles_m = (unsigned)(((R + TH - 1) / TH) * (W_ >> lgTW));
         if (cfg == 7) {         // 8 waves, 256 x 128, one workgroup per CU
             const size_t lds = (size_t)dir_lds_slots<2, 9>() * 16;
-            DM4D_HIP_CHECK(hipFuncSetAttribute((const void *)k_conv3x3_direct<2, 9, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            static bool attr_set = false;
+            if (!attr_set) { DM4D_HIP_CHECK(hipFuncSetAttribute((const void *)k_conv3x3_direct<2, 9, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr_set = true; }
             hipLaunchKernelGGL((k_conv3x3_direct<2, 9, 4>), dim3(tiles_m, (d.Cout + 127) / 128, d.splits), dim3(512), lds, st, d, chunks_per_split, lgTW);
         } else {                // 4 waves, 256 x 64, two workgroups per CU (one fills the bubble around the other's barrier)
             const size_t lds = (size_t)dir_lds_slots<1, 3>() * 16;
-            DM4D_HIP_CHECK(hipFuncSetAttribute((const void *)k_conv3x3_direct<1, 3, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            static bool attr_set = false;
+            if (!attr_set) { DM4D_HIP_CHECK(hipFuncSetAttribute((const void *)k_conv3x3_direct<1, 3, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr_set = true; }
             hipLaunchKernelGGL((k_conv3x3_direct<1, 3, 2>), dim3(tiles_m, (d.Cout + 63) / 64, d.splits), dim3(256), lds, st, d, chunks_per_split, lgTW);
         }
         DM4D_HIP_CHECK(hipGetLastError());

@@ -191,7 +191,8 @@ int dm4d_views_backward(const dm4d_views *v, const dm4d_views_grads *gr, dm4d_st
     // blend backward neither reduces nor records dL/dopacity and dL/d(rgb), 9 values per record instead of 13
     d.lean = gr->dL_dopacity ? 0 : 1;
     // ... and without a depth gradient (no depth loss in the shipped dynamic configuration) 8 values: 32-byte records
-    if (d.lean == 1 && !gr->dL_ddepth && !d.tile_records && !getenv("DM4D_NO_LEAN2")) d.lean = 2;
+    static const bool no_lean2 = getenv("DM4D_NO_LEAN2") != nullptr;          // (A/B switch)
+    if (d.lean == 1 && !gr->dL_ddepth && !d.tile_records && !no_lean2) d.lean = 2;
     // The blend backward writes one record per (Gaussian, cell) and the gather reads them back: in groups of views whose
     // records fit the 256 MB memory-side cache the round trip stays off HBM (8 views at once: 466 MB).
     static const int group_env = getenv("DM4D_BWD_GROUP") ? atoi(getenv("DM4D_BWD_GROUP")) : 0;
