@@ -251,17 +251,23 @@ __device__ __forceinline__ void conv3x3_tile(const ConvDesc &d)
 
     constexpr int S = kCvStages;
     constexpr int kPerStage = A_INSTR + B_INSTR;          // DMA instructions a wave has in flight per k-tile
-    static_assert(S >= 3 && S <= 4, "ring depth");
+    static_assert(S >= 3 && S <= 6, "ring depth");
     const int nk = CV_PROBE(16) ? 1 : kt1 - kt0;
+    // s_waitcnt vmcnt(tiles x kPerStage) for a run-time number of k-tiles allowed in flight (the immediate must be a constant)
+    auto wait_tiles = [&](int fly) {
+        switch (fly) {
+        case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+        case 1: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kPerStage) : "memory"); break;
+        case 2: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * kPerStage) : "memory"); break;
+        case 3: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * kPerStage) : "memory"); break;
+        default: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * kPerStage) : "memory"); break;
+        }
+    };
+    static_assert(4 * kPerStage < 64, "vmcnt is a 6-bit counter");
 #pragma unroll
     for (int p = 0; p < S - 1; ++p)
         if (p < nk) issue(p);
-    {   // tile 0 has landed; tiles 1 .. S - 2 may be in flight
-        const int fly = min(S - 2, nk - 1);
-        if (fly >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * kPerStage) : "memory");
-        else if (fly == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kPerStage) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
+    wait_tiles(min(S - 2, nk - 1));                   // tile 0 has landed; tiles 1 .. S - 2 may be in flight
     __builtin_amdgcn_s_barrier();
     if (nk > 0) read(K0{}, std::integral_constant<int, 0>{});
     // tile t (not the last) in ring stage U = t % S
@@ -270,8 +276,7 @@ __device__ __forceinline__ void conv3x3_tile(const ConvDesc &d)
         read(K1{}, U);
         __builtin_amdgcn_sched_barrier(0);      // reads first, THEN the MFMAs they overlap with (the scheduler otherwise sinks them to 1-2 MFMAs before their use)
         mma(K0{});
-        if (S == 4 && t + 2 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kPerStage) : "memory");     // tile t + 2 may be in flight
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        wait_tiles(min(S - 3, nk - 2 - t));     // tile t + 1 has landed; the tiles issued after it may be in flight
         if (!CV_PROBE(32)) __builtin_amdgcn_s_barrier();
         if (t + S - 1 < nk) issue((u + S - 1) % S);
         read(K0{}, std::integral_constant<int, (u + 1) % S>{});
@@ -284,30 +289,21 @@ __device__ __forceinline__ void conv3x3_tile(const ConvDesc &d)
         mma(K0{});
         mma(K1{});
     };
-    int t = 0;
-    for (; t + S < nk; t += S) {
-        body(std::integral_constant<int, 0>{}, t);
-        body(std::integral_constant<int, 1>{}, t + 1);
-        body(std::integral_constant<int, 2>{}, t + 2);
-        if constexpr (S == 4) body(std::integral_constant<int, 3>{}, t + 3);
-    }
-    // 1 .. S tiles left, starting in stage 0
-    if (nk > 0) {
-        const int left = nk - t;
-        if (left == 1) tail(std::integral_constant<int, 0>{});
-        else {
-            body(std::integral_constant<int, 0>{}, t);
-            if (left == 2) tail(std::integral_constant<int, 1>{});
-            else {
-                body(std::integral_constant<int, 1>{}, t + 1);
-                if (left == 3) tail(std::integral_constant<int, 2>{});
-                else if constexpr (S == 4) {
-                    body(std::integral_constant<int, 2>{}, t + 2);
-                    tail(std::integral_constant<int, 3>{});
-                }
-            }
+    // tiles t .. t + n - 1 (n <= S) starting in ring stage 0; the last of them is the launch's last tile iff `last`
+    auto run = [&](int t, int n, bool last) {
+#define DM4D_STEP(u)                                                                                  \
+        if constexpr ((u) < S) {                                                                      \
+            if (n > (u)) {                                                                            \
+                if (last && n == (u) + 1) tail(std::integral_constant<int, (u)>{});                  \
+                else body(std::integral_constant<int, (u)>{}, t + (u));                               \
+            }                                                                                         \
         }
-    }
+        DM4D_STEP(0) DM4D_STEP(1) DM4D_STEP(2) DM4D_STEP(3) DM4D_STEP(4) DM4D_STEP(5)
+#undef DM4D_STEP
+    };
+    int t = 0;
+    for (; t + S < nk; t += S) run(t, S, false);
+    if (nk > 0) run(t, nk - t, true);             // 1 .. S tiles left, starting in stage 0
 
     static_assert((size_t)BM * (BN * 2 + 16) <= (size_t)kCvStages * (A_SLOTS + B_SLOTS) * 16, "epilogue staging does not fit the ring");
     conv_epilogue<BM, BN, NW>(d, acc, a_row, 32 * NB * wn, n0, reinterpret_cast<char *>(smem), tid, lane, cv_probe,
@@ -703,6 +699,8 @@ int dm4d_conv3x3_nhwc_f16(int32_t N, int32_t H, int32_t W, int32_t Cin, int32_t 
     case 0: rc = conv_launch<2, 2, 2, 2, 3>(d, st); break;
     case 1: rc = conv_launch<2, 2, 4, 2, 3>(d, st); break;       // 256 x 128, 4 waves of 128 x 64, 3-deep (two workgroups per CU)
     case 3: rc = conv_launch<2, 2, 2, 2, 4>(d, st); break;
+    case 10: rc = conv_launch<2, 2, 2, 2, 5>(d, st); break;      // 128 x 128, 4 waves, 5-deep (80 KB: two workgroups per CU)
+    case 11: rc = conv_launch<2, 2, 2, 2, 6>(d, st); break;      // ... 6-deep (96 KB: one workgroup per CU)
     case 4: rc = conv_launch<4, 2, 1, 2, 3>(d, st); break;
     case 6: rc = conv_launch<4, 2, 1, 2, 4>(d, st); break;
     case 5: rc = conv_launch<4, 2, 2, 2, 3>(d, st); break;
