@@ -105,7 +105,9 @@ def _tri_inverse(Lc, nb=1024):
     n = int(Lc.shape[0])
     if n <= nb:
         return torch.linalg.solve_triangular(Lc, torch.eye(n, dtype=Lc.dtype, device=Lc.device), upper=False)
-    h = (n // 2 + 255) // 256 * 256
+    h = (n // 2 + 255) // 256 * 256          # (aligned split for the GEMMs; plain halves when that would leave nothing below)
+    if h >= n:
+        h = n // 2
     out = torch.zeros_like(Lc)
     a = out[:h, :h] = _tri_inverse(Lc[:h, :h], nb)
     c = out[h:, h:] = _tri_inverse(Lc[h:, h:], nb)

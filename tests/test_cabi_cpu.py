@@ -80,3 +80,36 @@ def test_argument_validation_is_host_side():
     assert L.dm4d_groupnorm_nhwc_backward(1, 4, 8, 4, 1, p, None, 0, p, p, p, 0, None, p, p, 1, None) == -1     # dy missing
     assert L.dm4d_add_bias_nhwc(4, 6, 1, p, p, p, p, None) == -1 and L.dm4d_geglu(4, 6, 0, p, p, None) == -1
     assert L.dm4d_add_bias_nhwc(0, 8, 1, None, None, None, None, None) == 0 and L.dm4d_geglu(0, 8, 1, None, None, None) == 0
+
+
+def test_conv_plan_scratch_sizes_follow_the_split_rule():
+    """dm4d_conv3x3_scratch_bytes is host-only: the float32 partial sums of the split-K launches.  The rule (csrc/conv_mfma.hip::
+    conv_plan): split only until every CU has one workgroup and never below 30 k-tiles per workgroup; no split for the direct
+    kernel's shapes at W >= 64 or for problems with >= 256 tiles."""
+    from dreammesh4d_amd import _lib
+
+    L = _lib.lib()
+    part = lambda splits, N, H, W, Co: splits * N * H * W * Co * 4 + 256
+    assert L.dm4d_conv3x3_scratch_bytes(8, 4, 4, 1280, 1280) == part(12, 8, 4, 4, 1280)       # 10 tiles, 360 k-tiles: 360 / 30
+    assert L.dm4d_conv3x3_scratch_bytes(8, 4, 4, 2560, 1280) == part(24, 8, 4, 4, 1280)
+    assert L.dm4d_conv3x3_scratch_bytes(8, 8, 8, 1280, 1280) == part(6, 8, 8, 8, 1280)        # 40 tiles: 256 / 40
+    assert L.dm4d_conv3x3_scratch_bytes(8, 16, 16, 640, 640) == part(3, 8, 16, 16, 640)
+    assert L.dm4d_conv3x3_scratch_bytes(8, 32, 32, 320, 320) == 256                            # 192 tiles: no split
+    assert L.dm4d_conv3x3_scratch_bytes(4, 256, 256, 128, 128) == 256                          # direct kernel, 2048 tiles
+    assert L.dm4d_conv3x3_scratch_bytes(0, 4, 4, 32, 32) == 256
+
+
+def test_blocked_triangular_inverse_of_the_dense_graph_solver():
+    """graph_build._tri_inverse (block recursion, all GEMM) against torch's inverse, on the CPU (pure torch): sizes below and
+    above the recursion's block size, not a multiple of its 256-row alignment."""
+    import torch
+
+    from dreammesh4d_amd.graph_build import _tri_inverse
+
+    g = torch.Generator().manual_seed(4)
+    for n, nb in ((37, 1024), (700, 128), (1030, 256)):
+        A = torch.randn(n, n, generator=g, dtype=torch.float64)
+        Lc = torch.linalg.cholesky(A @ A.T + n * torch.eye(n, dtype=torch.float64))
+        Li = _tri_inverse(Lc, nb=nb)
+        assert float((Li @ Lc - torch.eye(n, dtype=torch.float64)).abs().max()) < 1e-12
+        assert float(torch.triu(Li, 1).abs().max()) == 0.0
