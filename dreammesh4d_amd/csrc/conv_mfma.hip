@@ -602,11 +602,13 @@ __global__ __launch_bounds__(256) void k_conv3x3_c128_small(int N, int H, int W,
     }
 }
 
-// tile configurations (DM4D_CONV_CFG): 0: 128 x 128, 4 waves of 64 x 64, 3-deep ring | 3: the same, 4-deep | 4: 128 x 128, 8 waves of
-// 32 x 64 | 6: the same, 4-deep | 5: 256 x 128, 8 waves of 64 x 64, 3-deep | 8: the same, 4-deep | 7: the direct kernel (256 x 128)
+// tile configurations (DM4D_CONV_CFG; 3 and 7 are what conv_plan picks, the others are the measured alternatives of
+// profiles/r03_zero123.md): 3: 128 x 128, 4 waves of 64 x 64, 4-deep ring | 0 / 10 / 11: the same 3- / 5- / 6-deep | 4 / 6: 128 x 128,
+// 8 waves of 32 x 64, 3- / 4-deep | 7: the direct kernel, 256 x 128, 8 waves | 9: the direct kernel, 256 x 64, 4 waves, two per CU.
+// (256 x 128 implicit-GEMM tiles with 64 x 64 or 128 x 64 wave tiles were tried and removed: 256 VGPRs with spills.)
 static void cfg_tile(int cfg, int &BM, int &BN)
 {
-    BM = (cfg == 1 || cfg == 5 || cfg == 7 || cfg == 8 || cfg == 9) ? 256 : 128;
+    BM = (cfg == 7 || cfg == 9) ? 256 : 128;
     BN = cfg == 9 ? 64 : 128;
 }
 static int conv_plan(int M, int W, int Cout, int kt_total, int &cfg, int &splits)
@@ -697,14 +699,11 @@ int dm4d_conv3x3_nhwc_f16(int32_t N, int32_t H, int32_t W, int32_t Cin, int32_t 
     int rc;
     switch (cfg) {
     case 0: rc = conv_launch<2, 2, 2, 2, 3>(d, st); break;
-    case 1: rc = conv_launch<2, 2, 4, 2, 3>(d, st); break;       // 256 x 128, 4 waves of 128 x 64, 3-deep (two workgroups per CU)
     case 3: rc = conv_launch<2, 2, 2, 2, 4>(d, st); break;
     case 10: rc = conv_launch<2, 2, 2, 2, 5>(d, st); break;      // 128 x 128, 4 waves, 5-deep (80 KB: two workgroups per CU)
     case 11: rc = conv_launch<2, 2, 2, 2, 6>(d, st); break;      // ... 6-deep (96 KB: one workgroup per CU)
     case 4: rc = conv_launch<4, 2, 1, 2, 3>(d, st); break;
     case 6: rc = conv_launch<4, 2, 1, 2, 4>(d, st); break;
-    case 5: rc = conv_launch<4, 2, 2, 2, 3>(d, st); break;
-    case 8: rc = conv_launch<4, 2, 2, 2, 4>(d, st); break;
     case 7: case 9: {      // direct: 256 pixels x 128 (7) / 64 (9) filters, the input patch resident in LDS for the nine taps
         const int W_ = d.W;
         if (W_ < 8 || (W_ & (W_ - 1)) != 0) { set_error("conv3x3 direct: W must be a power of two >= 8"); return DM4D_ERR_UNSUPPORTED; }
