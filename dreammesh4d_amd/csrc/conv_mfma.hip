@@ -9,17 +9,25 @@
 // channels (NHWC) and a filter's taps x channels (torch's channels_last weight IS [C_out][3][3][C_in]) -- which is exactly the
 // fragment the f16 MFMA wants from a lane (v_mfma_f32_32x32x16_f16: lane l holds 8 consecutive k of row l & 31).  So:
 //   * a k-tile = one tap x 32 channels: 64 contiguous bytes per pixel / per filter, four 16-byte pieces;
-//   * global -> LDS by LDS-DMA (`global_load_lds_dwordx4`: no VGPR round trip, no ds_write -- the write path of the LDS is four
-//     times slower than its read path on this chip), the padding taps read a zero line;
+//   * global -> LDS by LDS-DMA (`buffer_load_dwordx4 ... lds`: no VGPR round trip, no ds_write -- the write path of the LDS is four
+//     times slower than its read path on this chip) through BUFFER DESCRIPTORS: a per-lane byte offset that never changes in the
+//     loop + a wave-uniform SGPR offset per k-tile; a padding tap carries an out-of-range offset and the hardware writes zeros.
+//     (The first version computed 64-bit addresses per tap: ~100 instructions per k-tile beside 8 MFMAs, and the loop was
+//     bound by instruction issue, not by anything it moved.)
 //   * the DMA lands 64 lanes x 16 B LINEARLY, but the per-lane SOURCE is free: lane -> (row, piece) is chosen so that piece c of row
 //     r sits at slot 4 r + (c ^ ((r >> 2) & 3)), which makes every ds_read_b128 of a fragment (16 lanes = 16 rows, one piece)
 //     hit 16 different 16-byte columns of the 256-byte LDS row: conflict-free (MI355X_MICROARCH.md, LDS lane groups);
-//   * a 3-deep ring of k-tiles, raw s_barrier + counted vmcnt: the DMA of tile k + 2 is in flight while tile k is multiplied;
-//   * workgroup = 4 waves, each a 64 x 64 block of the output tile (2 x 2 MFMA tiles: 4 ds_read_b128 feed 4 MFMAs);
-//   * small problems (the 8^2 and 4^2 levels: 512 / 128 pixels) split K over workgroups; partial sums in float32, reduced
-//     with the epilogue (bias, residual, conversion) by a second kernel.
-// Forward only: the UNet runs without gradients; the data gradient of a stride-1 convolution is the same operator on the
-// flipped / transposed filter.
+//   * a 4-deep ring of k-tiles, raw s_barrier + counted vmcnt, the fragments of the next half k-tile read while the MFMAs of the
+//     current one run (two register sets), ONE barrier per k-tile in its middle; the loop unrolled over the ring so that every
+//     LDS address is a register + an immediate;
+//   * workgroup = 4 waves, each a 64 x 64 block of the 128 x 128 output tile (2 x 2 MFMA tiles: 4 ds_read_b128 feed 4 MFMAs), two
+//     workgroups per CU; the filter fragment is the MFMA's A operand so that a lane ends with 4 consecutive output channels, and
+//     the epilogue goes through LDS to 16-byte stores (bias, residual there);
+//   * small problems (the 16^2 .. 4^2 levels) split K over workgroups -- only until every CU has one workgroup; partial sums in
+//     float32, reduced with the epilogue by a second kernel;
+//   * a DIRECT variant for wide images / large problems keeps the input patch of a 256-pixel tile resident in LDS for the nine taps.
+// The operator is the forward convolution; the data gradient of a stride-1 convolution is the same operator on the flipped,
+// transposed filter (conv_mfma.py), which is how the VAE encoder's backward runs here.
 #include <stdlib.h>
 #include <type_traits>
 #include "common.h"
@@ -51,9 +59,7 @@ struct ConvDesc {
 // slot (16-byte unit) of piece c of row r in a stage's operand tile
 __device__ __forceinline__ int cv_slot(int r, int c) { return 4 * r + (c ^ ((r >> 2) & 3)); }
 
-// WM x WN waves, each MB x NB MFMA tiles of 32 x 32: workgroup tile (32 MB WM) x (32 NB WN).  What decides the speed of these
-// shapes is the traffic between L2 and the CUs: a k-tile moves (BM + BN) x 64 bytes for BM x BN x 64 flops, i.e. 64 flop/B at
-// 128 x 128 -- 39 TB/s at the MFMA peak, which the L2 does not deliver -- 85 at 256 x 128 and 98 at 256 x 160.
+// WM x WN waves, each MB x NB MFMA tiles of 32 x 32: workgroup tile (32 MB WM) x (32 NB WN), kCvStages-deep ring.
 // ---- epilogue shared by both kernels.  The FILTER fragment is the MFMA's A operand, so D[row][col] has col = lane & 31 = the
 // wave's pixel row (tile row `row_of[i]`), row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5) = output channel: a lane holds 4 consecutive
 // channels of one pixel per register quad.  `pix(row)` maps a tile row to its output pixel (or -1).
