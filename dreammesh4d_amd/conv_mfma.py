@@ -26,13 +26,18 @@ def pack_weight(w):
     return w.detach().permute(0, 2, 3, 1).contiguous()
 
 
-def conv3x3(x, w_ohwi, bias=None, residual=None):
-    N, Ci, H, W = x.shape
+def conv3x3(x, w_ohwi, bias=None, residual=None, stride=1, pad=1):
+    """stride 1 / pad 1 (the default), or stride 2 with pad 1 (the UNet's Downsample) / pad 0 (the VAE encoder's Downsample:
+    F.pad(x, (0, 1, 0, 1)) + an unpadded convolution, without the padded copy): include/dm4d.h, dm4d_conv3x3_strided_nhwc_f16."""
+    N, Ci, Hin, Win = x.shape
     Co = int(w_ohwi.shape[0])
     if not (x.is_cuda and x.dtype == torch.float16 and x.is_contiguous(memory_format=torch.channels_last) and Ci % 32 == 0 and Co % 32 == 0):
         raise ValueError("conv3x3: x must be a channels_last float16 HIP tensor with C_in and C_out multiples of 32 (see supported())")
     if tuple(w_ohwi.shape) != (Co, 3, 3, Ci) or not w_ohwi.is_contiguous():
         raise ValueError(f"conv3x3: weight must be [C_out,3,3,{Ci}] contiguous (pack_weight), got {tuple(w_ohwi.shape)}")
+    if (stride, pad) not in ((1, 1), (2, 1), (2, 0)):
+        raise ValueError("conv3x3: stride 1 / pad 1, or stride 2 / pad 0 or 1")
+    H, W = (Hin, Win) if stride == 1 else (((Hin + 1) // 2, (Win + 1) // 2) if pad else (Hin // 2, Win // 2))
     if residual is not None and (tuple(residual.shape) != (N, Co, H, W) or not residual.is_contiguous(memory_format=torch.channels_last)
                                  or residual.dtype != torch.float16):
         raise ValueError("conv3x3: residual must be a channels_last float16 tensor of the output's shape")
@@ -41,11 +46,12 @@ def conv3x3(x, w_ohwi, bias=None, residual=None):
     y = torch.empty((N, Co, H, W), device=x.device, dtype=torch.float16, memory_format=torch.channels_last)
     # split-K partial sums of the small problems: from the caching allocator per call (stream-ordered, and a hipGraph capture
     # gets it from the graph's own pool)
-    buf = torch.empty(L.dm4d_conv3x3_scratch_bytes(N, H, W, Ci, Co), dtype=torch.uint8, device=x.device)
+    buf = torch.empty(L.dm4d_conv3x3_strided_scratch_bytes(N, Hin, Win, Ci, Co, stride), dtype=torch.uint8, device=x.device)
     with torch.cuda.device(x.device):
-        _lib.check(L.dm4d_conv3x3_nhwc_f16(N, H, W, Ci, Co, x.data_ptr(), w_ohwi.data_ptr(), 0 if bias is None else bias.data_ptr(),
-                                           0 if residual is None else residual.data_ptr(), y.data_ptr(), buf.data_ptr(),
-                                           torch.cuda.current_stream(x.device).cuda_stream), "dm4d_conv3x3_nhwc_f16")
+        _lib.check(L.dm4d_conv3x3_strided_nhwc_f16(N, Hin, Win, Ci, Co, stride, pad, x.data_ptr(), w_ohwi.data_ptr(),
+                                                   0 if bias is None else bias.data_ptr(), 0 if residual is None else residual.data_ptr(),
+                                                   y.data_ptr(), buf.data_ptr(), torch.cuda.current_stream(x.device).cuda_stream),
+                   "dm4d_conv3x3_strided_nhwc_f16")
     return y
 
 
@@ -113,3 +119,32 @@ def first_conv_supported(x, w):
 def conv3x3_first_frozen(x, w, b, w_t):
     """x [N, C<=4, H, W] -> [N, 128, H, W]; w_t = pack_weight_transposed(w) ([C, 3, 3, 128])."""
     return _ConvFirstFrozen.apply(x, w, b, w_t)
+
+
+class _Conv3x3Stride2Frozen(torch.autograd.Function):
+    """Stride-2 convolution with frozen parameters (the VAE encoder's Downsample: pad 0 + one zero behind each axis): forward on the
+    MFMA kernel without materialising the padded input; the data gradient on the library's transposed convolution of the PADDED
+    shape, cropped (a view) -- a strided data gradient visits every output pixel with a quarter of the taps and is no shape for the
+    implicit-GEMM kernel."""
+
+    @staticmethod
+    def forward(ctx, x, w, w_ohwi, bias, pad):
+        ctx.save_for_backward(w)
+        ctx.in_shape, ctx.pad = tuple(x.shape), pad
+        return conv3x3(x, w_ohwi, bias, None, stride=2, pad=pad)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (w,) = ctx.saved_tensors
+        if not ctx.needs_input_grad[0]:
+            return None, None, None, None, None
+        N, C, H, W = ctx.in_shape
+        if ctx.pad:
+            dx = torch.nn.grad.conv2d_input((N, C, H, W), w, dy, stride=2, padding=1)
+        else:
+            dx = torch.nn.grad.conv2d_input((N, C, H + 1, W + 1), w, dy, stride=2, padding=0)[:, :, :H, :W]
+        return dx, None, None, None, None
+
+
+def conv3x3_stride2_frozen(x, w, w_ohwi, bias=None, pad=0):
+    return _Conv3x3Stride2Frozen.apply(x, w, w_ohwi, bias, pad)

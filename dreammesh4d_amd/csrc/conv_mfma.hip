@@ -43,7 +43,8 @@ constexpr int kCvBK = 32;            // channels per k-tile (one tap)
 __device__ __attribute__((aligned(64))) uint4 g_conv_zero[4];     // the line the padding taps read (never written)
 
 struct ConvDesc {
-    int N, H, W, Cin, Cout, M;       // M = N H W
+    int N, H, W, Cin, Cout, M;       // H, W: OUTPUT size; M = N H W output pixels
+    int Hin, Win, stride, pad;       // input size; output (y, x), tap (ky, kx) reads input (stride y + ky - pad, stride x + kx - pad)
     const _Float16 *x, *w, *bias, *res;
     _Float16 *y;
     float *partial;                  // [splits][M][Cout] when splits > 1
@@ -148,11 +149,12 @@ __device__ __forceinline__ void conv3x3_tile(const ConvDesc &d)
     // ---- the DMA's addresses.  The loop must not spend VALU issue slots on them (measured: with MFMA, DMA and stores removed
     // the old loop still took a third of the kernel -- ~100 scalar / vector instructions per k-tile beside its 8 MFMAs), so:
     //   source = buffer descriptor (SGPRs) + per-lane byte offset (a VGPR that changes only when the TAP changes) + a
-    //   wave-uniform byte offset (an SGPR, + 64 per k-tile).  The input's descriptor starts (W + 1) pixels BEFORE the tensor so
+    //   wave-uniform byte offset (an SGPR, + 64 per k-tile).  The input's descriptor starts pad (W_in + 1) pixels BEFORE the tensor so
     //   that the uniform tap offset ((dy + 1) W + dx + 1) C_in is never negative; a lane whose tap falls outside the image (or
     //   whose row is past M / C_out) carries kOob and the hardware's range check fills its 16 bytes with zeros.
     const auto a_rs = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<_Float16 *>(d.x) - (size_t)(d.W + 1) * d.Cin, 0, (int)(((size_t)d.M + 2 * d.W + 2) * d.Cin * 2), 0x00020000);
+        const_cast<_Float16 *>(d.x) - (size_t)(d.pad * (d.Win + 1)) * d.Cin, 0,
+        (int)(((size_t)d.N * d.Hin * d.Win + 2 * d.Win + 2) * d.Cin * 2), 0x00020000);
     const auto b_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16 *>(d.w), 0, (int)((size_t)d.Cout * 9 * d.Cin * 2), 0x00020000);
     unsigned a_vo[A_INSTR], a_taps[A_INSTR], a_cur[A_INSTR], b_vo[B_INSTR];
 #pragma unroll
@@ -161,12 +163,12 @@ __device__ __forceinline__ void conv3x3_tile(const ConvDesc &d)
         const int p = m0 + r;
         const bool ok = r < BM && p < d.M;
         const int pp = ok ? p : 0, y = (pp % HW) / d.W, x = pp % d.W;
-        a_vo[i] = (unsigned)pp * (unsigned)(d.Cin * 2) + 16u * c;
+        a_vo[i] = (unsigned)(((pp / HW) * d.Hin + d.stride * y) * d.Win + d.stride * x) * (unsigned)(d.Cin * 2) + 16u * c;
         unsigned taps = 0;
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
-            const int yy = y + tap / 3 - 1, xx = x + tap % 3 - 1;
-            if (ok && (unsigned)yy < (unsigned)d.H && (unsigned)xx < (unsigned)d.W) taps |= 1u << tap;
+            const int yy = d.stride * y + tap / 3 - d.pad, xx = d.stride * x + tap % 3 - d.pad;
+            if (ok && (unsigned)yy < (unsigned)d.Hin && (unsigned)xx < (unsigned)d.Win) taps |= 1u << tap;
         }
         a_taps[i] = taps;
     }
@@ -178,7 +180,7 @@ __device__ __forceinline__ void conv3x3_tile(const ConvDesc &d)
     }
     // the issue stream's position: tap, chunk and the two uniform offsets
     int is_tap = kt0 / cpt, is_chunk = kt0 % cpt;
-    int is_a = ((is_tap / 3) * d.W + is_tap % 3) * d.Cin * 2 + is_chunk * (kCvBK * 2);
+    int is_a = ((is_tap / 3) * d.Win + is_tap % 3) * d.Cin * 2 + is_chunk * (kCvBK * 2);
     int is_b = (is_tap * d.Cin + is_chunk * kCvBK) * 2;
     auto set_tap = [&]() {
 #pragma unroll
@@ -201,7 +203,7 @@ __device__ __forceinline__ void conv3x3_tile(const ConvDesc &d)
         if (++is_chunk == cpt) {        // next tap: same channels from the start, the pixel one to the right (or a row down)
             is_chunk = 0;
             ++is_tap;
-            is_a = ((is_tap / 3) * d.W + is_tap % 3) * d.Cin * 2;
+            is_a = ((is_tap / 3) * d.Win + is_tap % 3) * d.Cin * 2;
             set_tap();
         }
     };
@@ -668,18 +670,45 @@ using namespace dm4d;
 
 extern "C" {
 
+// output size: stride 1 (pad 1): in;  stride 2, pad 1: floor((in + 2 - 3) / 2) + 1 = ceil(in / 2);  stride 2, pad 0 with ONE zero
+// behind (F.pad(x, (0, 1, 0, 1)) + an unpadded convolution): floor((in + 1 - 3) / 2) + 1 = floor(in / 2)
+static inline int conv_out(int in, int stride, int pad) { return stride == 1 ? in : (pad ? (in + 1) / 2 : in / 2); }
+// the plan never picks the direct kernel for a strided convolution (its patch is an un-strided block of the image)
+static int conv_plan_s(int M, int W, int Cout, int kt_total, int stride, int &cfg, int &splits)
+{
+    const int rc = conv_plan(M, stride == 1 ? W : 0, Cout, kt_total, cfg, splits);
+    if (stride != 1 && (cfg == 7 || cfg == 9)) cfg = 3;
+    return rc;
+}
+
 size_t dm4d_conv3x3_scratch_bytes(int32_t N, int32_t H, int32_t W, int32_t Cin, int32_t Cout)
 {
-    if (N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return 256;
+    return dm4d_conv3x3_strided_scratch_bytes(N, H, W, Cin, Cout, 1);
+}
+
+size_t dm4d_conv3x3_strided_scratch_bytes(int32_t N, int32_t Hin, int32_t Win, int32_t Cin, int32_t Cout, int32_t stride)
+{
+    if (N <= 0 || Hin <= 0 || Win <= 0 || Cin <= 0 || Cout <= 0 || stride < 1 || stride > 2) return 256;
+    const int H = conv_out(Hin, stride, 1), W = conv_out(Win, stride, 1);      // (pad 0 and 1 differ by at most one row: same plan)
     int cfg, splits;
-    conv_plan(N * H * W, W, Cout, 9 * Cin / kCvBK, cfg, splits);
+    conv_plan_s(N * H * W, W, Cout, 9 * Cin / kCvBK, stride, cfg, splits);
     return splits > 1 ? (size_t)splits * N * H * W * Cout * 4 + 256 : 256;
 }
 
 int dm4d_conv3x3_nhwc_f16(int32_t N, int32_t H, int32_t W, int32_t Cin, int32_t Cout, const void *x, const void *w, const void *bias,
                           const void *residual, void *y, void *scratch, dm4d_stream_t stream)
 {
-    if (N < 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) { set_error("conv3x3: bad shape"); return DM4D_ERR_INVALID; }
+    return dm4d_conv3x3_strided_nhwc_f16(N, H, W, Cin, Cout, 1, 1, x, w, bias, residual, y, scratch, stream);
+}
+
+int dm4d_conv3x3_strided_nhwc_f16(int32_t N, int32_t Hin, int32_t Win, int32_t Cin, int32_t Cout, int32_t stride, int32_t pad, const void *x,
+                                  const void *w, const void *bias, const void *residual, void *y, void *scratch, dm4d_stream_t stream)
+{
+    if (N < 0 || Hin <= 0 || Win <= 0 || Cin <= 0 || Cout <= 0) { set_error("conv3x3: bad shape"); return DM4D_ERR_INVALID; }
+    if (stride < 1 || stride > 2 || pad < 0 || pad > 1 || (stride == 1 && pad != 1)) { set_error("conv3x3: stride 1 / pad 1, or stride 2 / pad 0 or 1 (got %d, %d)", stride, pad); return DM4D_ERR_UNSUPPORTED; }
+    const int H = conv_out(Hin, stride, pad), W = conv_out(Win, stride, pad);
+    if (H <= 0 || W <= 0) { set_error("conv3x3: empty output"); return DM4D_ERR_INVALID; }
+    if (((int64_t)N * Hin * Win + 2 * Win + 2) * Cin * 2 >= 0x7FFF0000LL) { set_error("conv3x3: tensor too large for a 32-bit buffer descriptor"); return DM4D_ERR_UNSUPPORTED; }
     if (N == 0) return DM4D_OK;
     if (Cin % kCvBK != 0 || Cout % 32 != 0) { set_error("conv3x3: C_in and C_out must be multiples of %d (got %d, %d)", kCvBK, Cin, Cout); return DM4D_ERR_UNSUPPORTED; }
     if (((int64_t)N * H * W + 2 * W + 2) * Cin * 2 >= 0x7FFF0000LL || (int64_t)Cout * 9 * Cin * 2 >= 0x7FFF0000LL) { set_error("conv3x3: tensor too large for a 32-bit buffer descriptor"); return DM4D_ERR_UNSUPPORTED; }
@@ -688,6 +717,7 @@ int dm4d_conv3x3_nhwc_f16(int32_t N, int32_t H, int32_t W, int32_t Cin, int32_t 
     if ((((uintptr_t)x | (uintptr_t)w | (uintptr_t)y | (uintptr_t)bias | (uintptr_t)residual) & 15) != 0) { set_error("conv3x3: tensors must be 16-byte aligned"); return DM4D_ERR_INVALID; }
     ConvDesc d;
     d.N = N; d.H = H; d.W = W; d.Cin = Cin; d.Cout = Cout; d.M = N * H * W;
+    d.Hin = Hin; d.Win = Win; d.stride = stride; d.pad = pad;
     d.x = (const _Float16 *)x; d.w = (const _Float16 *)w; d.bias = (const _Float16 *)bias; d.res = (const _Float16 *)residual;
     d.y = (_Float16 *)y;
     d.kt_total = 9 * Cin / kCvBK;
@@ -696,7 +726,8 @@ int dm4d_conv3x3_nhwc_f16(int32_t N, int32_t H, int32_t W, int32_t Cin, int32_t 
     if (const char *pe = getenv("DM4D_CONV_PROBE")) d.probe = atoi(pe);
 #endif
     int cfg;
-    conv_plan(d.M, W, Cout, d.kt_total, cfg, d.splits);
+    conv_plan_s(d.M, W, Cout, d.kt_total, stride, cfg, d.splits);
+    if ((cfg == 7 || cfg == 9) && (stride != 1 || pad != 1)) { set_error("conv3x3: the direct kernel takes stride 1, pad 1 only"); return DM4D_ERR_UNSUPPORTED; }
     d.kt_per = (d.kt_total + d.splits - 1) / d.splits;
     d.splits = (d.kt_total + d.kt_per - 1) / d.kt_per;
     d.partial = (float *)scratch;

@@ -66,6 +66,7 @@ def _conv_nobias(conv, x):
 VAE_ATTENTION_BMM = os.environ.get("DM4D_VAE_ATTN_BMM", "1") != "0"                  # (A/B switch: _VaeAttn as bmm + softmax + bmm)
 FUSE_ADD_LAYERNORM = os.environ.get("DM4D_FUSE_ADD_LN", "1") != "0"                 # (A/B switch for BasicTransformerBlock._fused_no_grad)
 BATCH_SMALL_GEMMS = os.environ.get("DM4D_BATCH_SMALL_GEMMS", "1") != "0"      # (A/B switch for UNetModel._batched_small_gemms)
+_USE_MFMA_CONV_S2 = os.environ.get("DM4D_MFMA_CONV_S2", "1") != "0"            # (A/B switch: the stride-2 Downsample convolutions)
 _USE_MFMA_CONV = os.environ.get("DM4D_MFMA_CONV", "1") != "0"      # (A/B switch: "0" keeps every convolution on the library)
 
 
@@ -98,6 +99,26 @@ def _conv3x3(conv, x, bias=True, residual=None):
         return add_bias(residual, _conv_nobias(conv, x), conv.bias)      # (one fused kernel for skip + bias)
     y = F.conv2d(x, w, conv.bias if bias else None, conv.stride, conv.padding)
     return y if residual is None else residual + y
+
+
+def _conv3x3_stride2(conv, x, pad):
+    """The two Downsample convolutions (stride 2; pad 1: the UNet's, pad 0 + one zero behind each axis: the VAE encoder's) with
+    frozen parameters on a HIP device: the MFMA implicit-GEMM kernel reads the input with the stride and zero-fills what lies
+    outside, so the VAE's padded copy (a fill + a copy of up to 67 MB) is never made.  Anything else: the library path, as the
+    reference writes it."""
+    from . import conv_mfma
+
+    w = conv.weight
+    frozen = not (w.requires_grad or (conv.bias is not None and conv.bias.requires_grad))
+    if _USE_MFMA_CONV and _USE_MFMA_CONV_S2 and frozen and conv.groups == 1 and conv.dilation == (1, 1) and conv_mfma.supported(x, w):
+        key = (w.data_ptr(), w._version)
+        packed = getattr(conv, "_dm4d_ohwi", None)
+        if packed is None or packed[0] != key:
+            packed = conv._dm4d_ohwi = [key, conv_mfma.pack_weight(w), None]
+        if torch.is_grad_enabled() and x.requires_grad:
+            return conv_mfma.conv3x3_stride2_frozen(x, w, packed[1], conv.bias, pad)
+        return conv_mfma.conv3x3(x, packed[1], conv.bias, None, stride=2, pad=pad)
+    return conv(x) if pad else conv(F.pad(x, (0, 1, 0, 1)))
 
 
 def _conv1x1(conv, x):
@@ -134,7 +155,7 @@ class Downsample(nn.Module):
         self.op = nn.Conv2d(ch, ch, 3, stride=2, padding=1)
 
     def forward(self, x):
-        return self.op(x)
+        return _conv3x3_stride2(self.op, x, 1)
 
 
 class ResBlock(nn.Module):
@@ -434,7 +455,7 @@ class _VaeDown(nn.Module):
         self.conv = nn.Conv2d(ch, ch, 3, stride=2, padding=0)
 
     def forward(self, x):
-        return self.conv(F.pad(x, (0, 1, 0, 1)))
+        return _conv3x3_stride2(self.conv, x, 0)
 
 
 class _Level(nn.Module):

@@ -545,6 +545,14 @@ int dm4d_views_counters(const dm4d_views *v, int64_t *num_rendered, int64_t *num
 size_t dm4d_conv3x3_scratch_bytes(int32_t N, int32_t H, int32_t W, int32_t Cin, int32_t Cout);
 int dm4d_conv3x3_nhwc_f16(int32_t N, int32_t H, int32_t W, int32_t Cin, int32_t Cout, const void *x, const void *w, const void *bias,
                           const void *residual, void *y, void *scratch, dm4d_stream_t stream);
+/* The same operator with a stride and with the zero padding of the LOW side of each axis given (the high side gets what the last
+ * window needs).  stride 2, pad 1: the UNet's Downsample (openaimodel.py:123-156), output ceil(H_in / 2) x ceil(W_in / 2);
+ * stride 2, pad 0: the VAE encoder's Downsample, which pads (0, 1, 0, 1) and convolves without padding
+ * (diffusionmodules/model.py:85-100), output floor(H_in / 2) x floor(W_in / 2) -- the padded copy is never made.
+ * stride 1 needs pad 1.  Implicit-GEMM kernel only.  The scratch size is that of the pad-1 output (never smaller). */
+size_t dm4d_conv3x3_strided_scratch_bytes(int32_t N, int32_t Hin, int32_t Win, int32_t Cin, int32_t Cout, int32_t stride);
+int dm4d_conv3x3_strided_nhwc_f16(int32_t N, int32_t Hin, int32_t Win, int32_t Cin, int32_t Cout, int32_t stride, int32_t pad, const void *x,
+                                  const void *w, const void *bias, const void *residual, void *y, void *scratch, dm4d_stream_t stream);
 /* y = conv3x3(x, w) from exactly 128 channels to C_out <= 4 (stride 1, padding 1, float16, float32 accumulation, no bias):
  * x [N,H,W,128], w [C_out,3,3,128], y [N,H,W,C_out].  The data gradient of the VAE encoder's first convolution (image <-
  * 128 feature channels, ldm Encoder.conv_in, extern/ldm_zero123/modules/diffusionmodules/model.py:368-371): memory bound,

@@ -109,3 +109,31 @@ def test_first_convolution_data_gradient_on_the_small_cout_kernel():
         assert (y.float() - y32).abs().max() <= 2 ** -9 * y32.abs().max()
         assert x.grad.shape == x.shape and x.grad.is_contiguous(memory_format=torch.channels_last)
         assert (x.grad.float() - x32.grad).abs().max() <= 2 ** -10 * x32.grad.abs().max() + 1e-6
+
+
+@pytest.mark.parametrize("pad", [0, 1])
+@pytest.mark.parametrize("shape", [(2, 32, 32, 64, 64), (1, 64, 48, 128, 96), (3, 16, 16, 320, 320), (2, 9, 14, 32, 32)])
+def test_stride2_convolution_and_its_frozen_autograd_form(shape, pad):
+    """Stride 2 with pad 1 (the UNet's Downsample) and with pad 0 + one zero behind each axis (the VAE encoder's: F.pad(x, (0, 1, 0, 1))
+    + an unpadded convolution) against torch in float32; the data gradient of the autograd form against torch's."""
+    _need_gpu()
+    from dreammesh4d_amd import conv_mfma
+
+    N, H, W, Ci, Co = shape
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(H * 7 + pad)
+    x = torch.randn(N, Ci, H, W, generator=g).to(dev).half().contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    w = (torch.randn(Co, Ci, 3, 3, generator=g) * (9 * Ci) ** -0.5).to(dev).half()
+    b = torch.randn(Co, generator=g).to(dev).half()
+    ref_in = x.detach().float().requires_grad_(True)
+    ref = F.conv2d(ref_in, w.float(), b.float(), 2, 1) if pad else F.conv2d(F.pad(ref_in, (0, 1, 0, 1)), w.float(), b.float(), 2, 0)
+    y = conv_mfma.conv3x3_stride2_frozen(x, w, conv_mfma.pack_weight(w), b, pad)
+    assert y.shape == ref.shape and y.is_contiguous(memory_format=torch.channels_last)
+    assert (y.float() - ref).abs().max() <= 2 ** -10 * ref.abs().max() + 1e-6
+    with torch.no_grad():
+        assert torch.equal(y, conv_mfma.conv3x3(x.detach(), conv_mfma.pack_weight(w), b, None, stride=2, pad=pad))
+    gy = torch.randn(ref.shape, generator=g).to(dev).half().contiguous(memory_format=torch.channels_last)
+    y.backward(gy)
+    ref.backward(gy.float())
+    assert x.grad.shape == x.shape
+    assert (x.grad.float() - ref_in.grad).abs().max() <= 2 ** -9 * ref_in.grad.abs().max() + 1e-6
