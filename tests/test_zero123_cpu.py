@@ -154,3 +154,47 @@ def test_single_token_cross_attention_in_closed_form():
     finally:
         z.SINGLE_TOKEN_SHORTCUT = True
     assert torch.allclose(att(q, c), general, rtol=1e-6, atol=1e-7) and att(q, c).shape == (2, 5, att.to_q.in_features)
+
+
+def test_batched_small_gemms_hand_every_block_its_own_projection():
+    """UNetModel._batched_small_gemms: ONE GEMM for the timestep projections of all ResBlocks (emb_layers(emb) + the first
+    convolution's bias) and ONE for the value projections of all single-token cross-attentions; every block must get exactly the
+    column slice its own layers would compute (openaimodel.py:259-266, attention.py:196-213).  Host logic, run on the CPU."""
+    import torch
+
+    from dreammesh4d_amd import zero123 as z
+
+    torch.manual_seed(1)
+    unet = z.UNetModel(model_channels=32, context_dim=24, num_heads=4)
+    with torch.no_grad():
+        for m in unet.modules():
+            if isinstance(m, z.ResBlock):
+                torch.nn.init.normal_(m.in_layers[2].bias, std=0.3)
+    emb, ctx = torch.randn(3, unet.time_embed[2].out_features), torch.randn(3, 1, 24)
+    with torch.no_grad():
+        res, att = unet._batched_small_gemms(emb, ctx)
+        try:
+            assert len(res) == sum(isinstance(m, z.ResBlock) for m in unet.modules()) and len(att) == sum(isinstance(m, z.BasicTransformerBlock) for m in unet.modules())
+            for b in res:
+                want = b.emb_layers(emb) + b.in_layers[2].bias
+                got = b.__dict__["_emb_add"]
+                assert got.shape == want.shape and float((got - want).abs().max()) <= 1e-5 * float(want.abs().max())
+            for a in att:
+                want = a.to_v(ctx)
+                got = a.__dict__["_v_token"]
+                assert got.shape == want.shape and float((got - want).abs().max()) <= 1e-5 * float(want.abs().max())
+                assert float((a.single_token(ctx) - a.to_out(want)).abs().max()) <= 1e-5 * float(a.to_out(want).abs().max()) + 1e-7
+        finally:
+            for b in res:
+                b.__dict__.pop("_emb_add", None)
+            for a in att:
+                a.__dict__.pop("_v_token", None)
+    # the cache follows the parameters: an in-place update of a weight is picked up
+    with torch.no_grad():
+        res[0].emb_layers[1].weight.mul_(2.0)
+        unet._batched_small_gemms(emb, ctx)
+        assert float((res[0].__dict__["_emb_add"] - (res[0].emb_layers(emb) + res[0].in_layers[2].bias)).abs().max()) < 1e-4
+        for b in res:
+            b.__dict__.pop("_emb_add", None)
+        for a in att:
+            a.__dict__.pop("_v_token", None)
