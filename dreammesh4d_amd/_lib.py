@@ -142,6 +142,10 @@ _SIGNATURES = {
     "dm4d_conv3x3_c128_small_nhwc_f16": (C.c_int, [C.c_int32] * 4 + [vp] * 4),
     "dm4d_conv3x3_strided_scratch_bytes": (C.c_size_t, [C.c_int32] * 6),
     "dm4d_conv3x3_strided_nhwc_f16": (C.c_int, [C.c_int32] * 7 + [vp] * 7),
+    "dm4d_quat_to_matrix_forward": (C.c_int, [C.c_int64, vp, vp, vp]),
+    "dm4d_quat_to_matrix_backward_pypose": (C.c_int, [C.c_int64, vp, vp, vp, vp]),
+    "dm4d_linear_scratch_bytes": (C.c_size_t, [C.c_int64, C.c_int32, C.c_int32]),
+    "dm4d_linear_f16": (C.c_int, [C.c_int64, C.c_int32, C.c_int32] + [vp] * 5 + [C.c_int32, vp, vp]),
     "dm4d_cg_batched_scratch_bytes": (C.c_size_t, [C.c_int32] * 2),
     "dm4d_cg_batched_f64": (C.c_int, [C.c_int32] * 2 + [vp] * 7 + [C.c_int32, C.c_double, C.c_int32, C.POINTER(C.c_double), vp]),
     "dm4d_heat_face_directions": (C.c_int, [C.c_int32] * 2 + [vp] * 5),

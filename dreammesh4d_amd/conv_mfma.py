@@ -55,6 +55,48 @@ def conv3x3(x, w_ohwi, bias=None, residual=None, stride=1, pad=1):
     return y
 
 
+def pack_geglu(w, bias=None):
+    """Rows of a GEGLU projection ([2 D, K]: D value rows, then D gate rows; attention.py:48-56) interleaved in blocks of 64 --
+    rows 128 j .. 128 j + 63 = value rows 64 j .., rows 128 j + 64 .. = gate rows 64 j .. -- so that a 128-wide output tile of
+    `linear(..., act="geglu")` holds the values AND the gates of 64 output columns (include/dm4d.h, dm4d_linear_f16)."""
+    D = w.shape[0] // 2
+    if w.shape[0] != 2 * D or D % 64:
+        raise ValueError("pack_geglu: [2 D, K] with D a multiple of 64")
+    idx = torch.arange(2 * D, device=w.device).view(2, D // 64, 64).transpose(0, 1).reshape(-1)
+    return w.detach()[idx].contiguous(), (None if bias is None else bias.detach()[idx].contiguous())
+
+
+def linear_supported(x, w):
+    """float16 rows on a HIP device, K a multiple of 32, N of 8 (csrc/conv_mfma.hip: the one-tap implicit GEMM)."""
+    return (x.is_cuda and x.dtype == torch.float16 and w.dtype == torch.float16 and w.dim() == 2 and x.shape[-1] == w.shape[1]
+            and w.shape[1] % 32 == 0 and w.shape[0] % 8 == 0)
+
+
+def linear(x, w, bias=None, residual=None, act=None):
+    """act(x w^T + bias) (+ residual) on the MFMA kernel: x [..., K] float16 contiguous, w [N, K] contiguous (an nn.Linear weight as
+    it lies), residual [..., N]; act None or "geglu" (w / bias packed by pack_geglu; result [..., N / 2]).  No autograd (frozen
+    parameters under no_grad: zero123.py); include/dm4d.h, dm4d_linear_f16."""
+    K, N = int(x.shape[-1]), int(w.shape[0])
+    if not (linear_supported(x, w) and x.is_contiguous() and w.is_contiguous()):
+        raise ValueError("linear: x [..., K] / w [N, K] contiguous float16 HIP tensors, K % 32 == 0, N % 8 == 0 (see linear_supported())")
+    if act not in (None, "geglu"):
+        raise ValueError("linear: act is None or 'geglu'")
+    M = x.numel() // K
+    No = N // 2 if act else N
+    if residual is not None and (tuple(residual.shape) != tuple(x.shape[:-1]) + (No,) or not residual.is_contiguous() or residual.dtype != torch.float16):
+        raise ValueError("linear: residual must be a contiguous float16 tensor of the output's shape")
+    FLOPS[0] += 2 * M * K * N
+    L = _lib.lib()
+    y = torch.empty(tuple(x.shape[:-1]) + (No,), device=x.device, dtype=torch.float16)
+    nbytes = L.dm4d_linear_scratch_bytes(M, K, N)
+    buf = torch.empty(nbytes, dtype=torch.uint8, device=x.device) if nbytes > 256 and not act else None
+    with torch.cuda.device(x.device):
+        _lib.check(L.dm4d_linear_f16(M, K, N, x.data_ptr(), w.data_ptr(), 0 if bias is None else bias.data_ptr(),
+                                     0 if residual is None else residual.data_ptr(), y.data_ptr(), 1 if act else 0,
+                                     0 if buf is None else buf.data_ptr(), torch.cuda.current_stream(x.device).cuda_stream), "dm4d_linear_f16")
+    return y
+
+
 def pack_weight_transposed(w):
     """The filter of the DATA GRADIENT: dL/dx = conv3x3(dL/dy, w') with w'[ci][ky][kx][co] = w[co][2 - ky][2 - kx][ci]
     (stride 1, padding 1): [C_in, 3, 3, C_out] contiguous."""

@@ -48,7 +48,8 @@ struct ConvDesc {
     const _Float16 *x, *w, *bias, *res;
     _Float16 *y;
     float *partial;                  // [splits][M][Cout] when splits > 1
-    int splits, kt_total, kt_per;    // k-tiles (9 Cin / 32) in all / per split
+    int splits, kt_total, kt_per;    // k-tiles (taps x Cin / 32) in all / per split
+    int act;                         // epilogue: 0 none | 1 GEGLU: tile columns [0, 64) x gelu(columns [64, 128)), y is [M][Cout / 2] (dm4d_linear_f16)
     int probe;                       // timing experiments only (-DDM4D_CONV_PROBE, env DM4D_CONV_PROBE): 1 no stores, 2 no MFMA, 4 no DMA
 };
 #ifdef DM4D_CONV_PROBE
@@ -108,6 +109,28 @@ __device__ __forceinline__ void conv_epilogue(const ConvDesc &d, f32x16 (&acc)[M
                 *reinterpret_cast<f16x4 *>(stg + (size_t)row_of[i] * kRowB + 2 * cl) = h;
             }
     __syncthreads();
+    if constexpr (BN == 128) {
+        if (d.act == 1) {       // GEGLU on the float16-rounded projections (what the separate kernel read): value x gelu(gate), erf form
+            constexpr int kOutPieces = 8, kRows = 64 * NW / kOutPieces;
+            const int piece = tid % kOutPieces;
+            const size_t ldy = (size_t)(d.Cout >> 1);
+#pragma unroll 2
+            for (int row = tid / kOutPieces; row < BM; row += kRows) {
+                const int px = pix(row);
+                if (px < 0 || CV_PROBE(1)) continue;
+                const f16x8 v = *reinterpret_cast<const f16x8 *>(stg + (size_t)row * kRowB + 16 * piece);
+                const f16x8 g = *reinterpret_cast<const f16x8 *>(stg + (size_t)row * kRowB + 16 * (piece + 8));
+                f16x8 o;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const float gg = (float)g[k];
+                    o[k] = (_Float16)((float)v[k] * (0.5f * gg * (1.0f + erff(gg * 0.70710678118654752f))));
+                }
+                *reinterpret_cast<f16x8 *>(d.y + (size_t)px * ldy + (n0 >> 1) + 8 * piece) = o;
+            }
+            return;
+        }
+    }
     constexpr int kPieces = BN / 8;                         // 16-byte pieces per pixel row
     constexpr int kRowsPerPass = 64 * NW / kPieces;
     static_assert((64 * NW) % kPieces == 0, "tile width");
@@ -129,9 +152,11 @@ __device__ __forceinline__ void conv_epilogue(const ConvDesc &d, f32x16 (&acc)[M
 }
 
 // (the body is a __device__ function: the host pass cannot instantiate a __global__ template that uses the buffer builtins)
-template <int WM, int WN, int MB, int NB, int kCvStages>
+// KSZ: the filter is KSZ x KSZ (3; 1 = a GEMM y = x w^T over the [pixels][channels] view, dm4d_linear_f16)
+template <int WM, int WN, int MB, int NB, int kCvStages, int KSZ>
 __device__ __forceinline__ void conv3x3_tile(const ConvDesc &d)
 {
+    constexpr int TAPS = KSZ * KSZ;
     constexpr int NW = WM * WN, BM = 32 * MB * WM, BN = 32 * NB * WN;
     constexpr int A_INSTR = (BM * 4 + 64 * NW - 1) / (64 * NW), B_INSTR = (BN * 4 + 64 * NW - 1) / (64 * NW);   // DMA instructions per wave and stage
     constexpr int A_SLOTS = A_INSTR * 64 * NW, B_SLOTS = B_INSTR * 64 * NW;         // 16-byte slots per stage (rows past BM / BN: padding)
@@ -155,7 +180,7 @@ __device__ __forceinline__ void conv3x3_tile(const ConvDesc &d)
     const auto a_rs = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<_Float16 *>(d.x) - (size_t)(d.pad * (d.Win + 1)) * d.Cin, 0,
         (int)(((size_t)d.N * d.Hin * d.Win + 2 * d.Win + 2) * d.Cin * 2), 0x00020000);
-    const auto b_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16 *>(d.w), 0, (int)((size_t)d.Cout * 9 * d.Cin * 2), 0x00020000);
+    const auto b_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16 *>(d.w), 0, (int)((size_t)d.Cout * TAPS * d.Cin * 2), 0x00020000);
     unsigned a_vo[A_INSTR], a_taps[A_INSTR], a_cur[A_INSTR], b_vo[B_INSTR];
 #pragma unroll
     for (int i = 0; i < A_INSTR; ++i) {
@@ -166,8 +191,8 @@ __device__ __forceinline__ void conv3x3_tile(const ConvDesc &d)
         a_vo[i] = (unsigned)(((pp / HW) * d.Hin + d.stride * y) * d.Win + d.stride * x) * (unsigned)(d.Cin * 2) + 16u * c;
         unsigned taps = 0;
 #pragma unroll
-        for (int tap = 0; tap < 9; ++tap) {
-            const int yy = d.stride * y + tap / 3 - d.pad, xx = d.stride * x + tap % 3 - d.pad;
+        for (int tap = 0; tap < TAPS; ++tap) {
+            const int yy = d.stride * y + tap / KSZ - d.pad, xx = d.stride * x + tap % KSZ - d.pad;
             if (ok && (unsigned)yy < (unsigned)d.Hin && (unsigned)xx < (unsigned)d.Win) taps |= 1u << tap;
         }
         a_taps[i] = taps;
@@ -176,11 +201,11 @@ __device__ __forceinline__ void conv3x3_tile(const ConvDesc &d)
     for (int i = 0; i < B_INSTR; ++i) {
         const int s = 64 * (wave * B_INSTR + i) + lane, r = s >> 2, c = (s & 3) ^ ((r >> 2) & 3);
         const int co = n0 + r;
-        b_vo[i] = (r < BN && co < d.Cout) ? (unsigned)co * (unsigned)(9 * d.Cin * 2) + 16u * c : kOob;
+        b_vo[i] = (r < BN && co < d.Cout) ? (unsigned)co * (unsigned)(TAPS * d.Cin * 2) + 16u * c : kOob;
     }
     // the issue stream's position: tap, chunk and the two uniform offsets
     int is_tap = kt0 / cpt, is_chunk = kt0 % cpt;
-    int is_a = ((is_tap / 3) * d.Win + is_tap % 3) * d.Cin * 2 + is_chunk * (kCvBK * 2);
+    int is_a = ((is_tap / KSZ) * d.Win + is_tap % KSZ) * d.Cin * 2 + is_chunk * (kCvBK * 2);
     int is_b = (is_tap * d.Cin + is_chunk * kCvBK) * 2;
     auto set_tap = [&]() {
 #pragma unroll
@@ -203,7 +228,7 @@ __device__ __forceinline__ void conv3x3_tile(const ConvDesc &d)
         if (++is_chunk == cpt) {        // next tap: same channels from the start, the pixel one to the right (or a row down)
             is_chunk = 0;
             ++is_tap;
-            is_a = ((is_tap / 3) * d.Win + is_tap % 3) * d.Cin * 2;
+            is_a = ((is_tap / KSZ) * d.Win + is_tap % KSZ) * d.Cin * 2;
             set_tap();
         }
     };
@@ -318,10 +343,10 @@ __device__ __forceinline__ void conv3x3_tile(const ConvDesc &d)
                               [&](int row) { const int px = m0 + row; return px < d.M ? px : -1; });
 }
 
-template <int WM, int WN, int MB, int NB, int kCvStages>
+template <int WM, int WN, int MB, int NB, int kCvStages, int KS = 3>
 __global__ __launch_bounds__(64 * WM * WN) void k_conv3x3(ConvDesc d)
 {
-    conv3x3_tile<WM, WN, MB, NB, kCvStages>(d);
+    conv3x3_tile<WM, WN, MB, NB, kCvStages, KS>(d);
 }
 
 // ---------------------------------------------------------------------------------------- direct variant
@@ -647,7 +672,7 @@ static int conv_plan(int M, int W, int Cout, int kt_total, int &cfg, int &splits
     return 0;
 }
 
-template <int WM, int WN, int MB, int NB, int kCvStages>
+template <int WM, int WN, int MB, int NB, int kCvStages, int KS = 3>
 static int conv_launch(const ConvDesc &d, hipStream_t st)
 {
     constexpr int NW = WM * WN, BM = 32 * MB * WM, BN = 32 * NB * WN;
@@ -656,10 +681,10 @@ static int conv_launch(const ConvDesc &d, hipStream_t st)
     const dim3 grid((d.M + BM - 1) / BM, (d.Cout + BN - 1) / BN, d.splits);
     static bool attr_set = false;          // (per instantiation; a second thread repeating the call is harmless)
     if (!attr_set) {
-        DM4D_HIP_CHECK(hipFuncSetAttribute((const void *)k_conv3x3<WM, WN, MB, NB, kCvStages>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        DM4D_HIP_CHECK(hipFuncSetAttribute((const void *)k_conv3x3<WM, WN, MB, NB, kCvStages, KS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
-    hipLaunchKernelGGL((k_conv3x3<WM, WN, MB, NB, kCvStages>), grid, dim3(64 * NW), lds, st, d);
+    hipLaunchKernelGGL((k_conv3x3<WM, WN, MB, NB, kCvStages, KS>), grid, dim3(64 * NW), lds, st, d);
     DM4D_HIP_CHECK(hipGetLastError());
     return DM4D_OK;
 }
@@ -721,6 +746,7 @@ int dm4d_conv3x3_strided_nhwc_f16(int32_t N, int32_t Hin, int32_t Win, int32_t C
     d.x = (const _Float16 *)x; d.w = (const _Float16 *)w; d.bias = (const _Float16 *)bias; d.res = (const _Float16 *)residual;
     d.y = (_Float16 *)y;
     d.kt_total = 9 * Cin / kCvBK;
+    d.act = 0;
     d.probe = 0;
 #ifdef DM4D_CONV_PROBE
     if (const char *pe = getenv("DM4D_CONV_PROBE")) d.probe = atoi(pe);
@@ -770,6 +796,75 @@ int dm4d_conv3x3_strided_nhwc_f16(int32_t N, int32_t Hin, int32_t Win, int32_t C
     if (rc) return rc;
     if (d.splits > 1) {
         const size_t total = (size_t)d.M * Cout;
+        hipLaunchKernelGGL(k_conv_reduce, dim3((unsigned)((total / 8 + 255) / 256)), dim3(256), 0, st, d);
+        DM4D_HIP_CHECK(hipGetLastError());
+    }
+    return DM4D_OK;
+}
+
+// ---------------------------------------------------------------------------------------- linear layers (the same kernel, one tap)
+// y = act(x w^T + bias) (+ residual): x [M][K], w [N][K] (an nn.Linear weight / a 1x1 convolution's filter as it lies), float16,
+// float32 accumulation -- the transformer blocks' projections and the 1x1 convolutions of the Zero123 UNet (zero123.py), with
+// what the library GEMM leaves to extra launches in the epilogue: the residual add, and GEGLU (attention.py:48-56) for the
+// feed-forward's first projection.  Tiles: 128 x 128 (4 waves of 64 x 64) or, when that leaves most CUs idle, 64 x 64 (4 waves of
+// 32 x 32); split K by the convolution's rule.
+static void linear_plan(int64_t M, int N, int kt_total, int act, int &cfg, int &splits)
+{
+    const long tiles128 = (long)((M + 127) / 128) * ((N + 127) / 128);
+    cfg = (act == 1 || tiles128 >= 96) ? 3 : 13;
+    if (const char *force = getenv("DM4D_LIN_CFG")) { const int f = atoi(force); if (act != 1 || f == 3) cfg = f; }
+    const int B = cfg == 13 ? 64 : 128;
+    const long tiles = (long)((M + B - 1) / B) * ((N + B - 1) / B);
+    splits = (int)(256 / tiles);
+    if (splits > kt_total / 30) splits = kt_total / 30;
+    if (const char *fs = getenv("DM4D_LIN_SPLITS")) splits = atoi(fs);
+    if (splits < 1 || act == 1) splits = 1;             // (the reduction kernel has no GEGLU)
+    if (splits > 64) splits = 64;
+}
+
+size_t dm4d_linear_scratch_bytes(int64_t M, int32_t K, int32_t N)
+{
+    if (M <= 0 || K <= 0 || N <= 0) return 256;
+    int cfg, splits;
+    linear_plan(M, N, K / kCvBK, 0, cfg, splits);
+    return splits > 1 ? (size_t)splits * M * N * 4 + 256 : 256;
+}
+
+int dm4d_linear_f16(int64_t M, int32_t K, int32_t N, const void *x, const void *w, const void *bias, const void *residual, void *y,
+                    int32_t act, void *scratch, dm4d_stream_t stream)
+{
+    if (M < 0 || K <= 0 || N <= 0) { set_error("linear: bad shape"); return DM4D_ERR_INVALID; }
+    if (act != 0 && act != 1) { set_error("linear: act must be 0 (none) or 1 (GEGLU), got %d", act); return DM4D_ERR_INVALID; }
+    if (M == 0) return DM4D_OK;
+    if (K % kCvBK != 0 || N % 8 != 0) { set_error("linear: K must be a multiple of %d and N of 8 (got %d, %d)", kCvBK, K, N); return DM4D_ERR_UNSUPPORTED; }
+    if (act == 1 && (N % 128 != 0 || residual)) { set_error("linear: GEGLU needs N %% 128 == 0 (interleaved value / gate blocks of 64) and no residual"); return DM4D_ERR_UNSUPPORTED; }
+    if ((3 * M + 2) * K * 2 >= 0x7FFF0000LL || (int64_t)N * K * 2 >= 0x7FFF0000LL || M > 0x7FFFFFFF / 4) { set_error("linear: tensor too large for a 32-bit buffer descriptor"); return DM4D_ERR_UNSUPPORTED; }
+    if (!x || !w || !y) { set_error("linear: null tensor"); return DM4D_ERR_INVALID; }
+    if ((((uintptr_t)x | (uintptr_t)w | (uintptr_t)y | (uintptr_t)bias | (uintptr_t)residual) & 15) != 0) { set_error("linear: tensors must be 16-byte aligned"); return DM4D_ERR_INVALID; }
+    ConvDesc d;
+    d.N = 1; d.H = 1; d.W = (int)M; d.Cin = K; d.Cout = N; d.M = (int)M;
+    d.Hin = 1; d.Win = (int)M; d.stride = 1; d.pad = 0;
+    d.x = (const _Float16 *)x; d.w = (const _Float16 *)w; d.bias = (const _Float16 *)bias; d.res = (const _Float16 *)residual;
+    d.y = (_Float16 *)y;
+    d.kt_total = K / kCvBK;
+    d.act = act;
+    d.probe = 0;
+    int cfg;
+    linear_plan(M, N, d.kt_total, act, cfg, d.splits);
+    d.kt_per = (d.kt_total + d.splits - 1) / d.splits;
+    d.splits = (d.kt_total + d.kt_per - 1) / d.kt_per;
+    d.partial = (float *)scratch;
+    if (d.splits > 1 && !scratch) { set_error("linear: this shape needs the split-K scratch (dm4d_linear_scratch_bytes)"); return DM4D_ERR_INVALID; }
+    hipStream_t st = (hipStream_t)stream;
+    int rc;
+    switch (cfg) {
+    case 3: rc = conv_launch<2, 2, 2, 2, 4, 1>(d, st); break;
+    case 13: rc = conv_launch<2, 2, 1, 1, 4, 1>(d, st); break;
+    default: set_error("linear: bad configuration %d", cfg); return DM4D_ERR_INVALID;
+    }
+    if (rc) return rc;
+    if (d.splits > 1) {
+        const size_t total = (size_t)d.M * N;
         hipLaunchKernelGGL(k_conv_reduce, dim3((unsigned)((total / 8 + 255) / 256)), dim3(256), 0, st, d);
         DM4D_HIP_CHECK(hipGetLastError());
     }

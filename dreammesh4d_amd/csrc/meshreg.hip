@@ -29,12 +29,26 @@ __device__ __forceinline__ void edge_residual(const float *__restrict__ xi, cons
     for (int a = 0; a < 3; ++a) s[a] = (xi[a] - xj[a]) - ((R[3 * a] * e[0] + R[3 * a + 1] * e[1]) + R[3 * a + 2] * e[2]);
 }
 
+// A vertex is walked by a GROUP of kSub consecutive lanes (edge e0 + sub, + kSub, ...), their partial sums meet in a xor butterfly
+// inside the group: one thread per vertex made the kernel as long as its highest valence (the two poles of the bench's uv
+// sphere have ~360 edges against a mean of 6: 33 / 75 us forward / backward, and 343 us for the normal-consistency gather
+// below, whose poles touch ~700 pair roles).  The order of the sum is fixed by the lane assignment: deterministic.
+constexpr int kSub = 8;
+template <int N>
+__device__ __forceinline__ void group_sum(float (&v)[N])
+{
+#pragma unroll
+    for (int m = 1; m < kSub; m <<= 1)
+#pragma unroll
+        for (int k = 0; k < N; ++k) v[k] += __shfl_xor(v[k], m, kSub);
+}
+
 // per (timestamp, vertex): energy of its outgoing edges
 __global__ __launch_bounds__(256) void k_arap_fwd(ArapAdj a, const float *__restrict__ xyz, const float *__restrict__ rot,
                                                   float *__restrict__ energy /* [T][V] */)
 {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= a.V) return;
+    const int gid = blockIdx.x * 256 + threadIdx.x, i = gid / kSub, sub = gid % kSub;
+    if (i >= a.V) return;                      // (whole groups leave together: 256 % kSub == 0)
     const size_t t = blockIdx.y;
     xyz += t * a.V * 3;
     rot += t * a.V * 9;
@@ -43,14 +57,17 @@ __global__ __launch_bounds__(256) void k_arap_fwd(ArapAdj a, const float *__rest
     for (int k = 0; k < 9; ++k) R[k] = rot[9 * (size_t)i + k];
 #pragma unroll
     for (int k = 0; k < 3; ++k) xi[k] = xyz[3 * (size_t)i + k];
-    float acc = 0.f;
-    for (int eidx = a.off[i]; eidx < a.off[i + 1]; ++eidx) {
+    float acc[1] = {0.f};
+    const int e1 = a.off[i + 1];
+#pragma unroll 2
+    for (int eidx = a.off[i] + sub; eidx < e1; eidx += kSub) {
         const int j = a.nbr[eidx];
         float s[3];
         edge_residual(xi, xyz + 3 * (size_t)j, R, a.e + 3 * (size_t)eidx, s);
-        acc += a.w[eidx] * ((s[0] * s[0] + s[1] * s[1]) + s[2] * s[2]);
+        acc[0] += a.w[eidx] * ((s[0] * s[0] + s[1] * s[1]) + s[2] * s[2]);
     }
-    energy[t * a.V + i] = acc;
+    group_sum(acc);
+    if (sub == 0) energy[t * a.V + i] = acc[0];
 }
 
 // per (timestamp, vertex): dE/dx'_i and dE/dR_i, scaled by the upstream gradient of E_t
@@ -58,18 +75,20 @@ __global__ __launch_bounds__(256) void k_arap_bwd(ArapAdj a, const float *__rest
                                                   const float *__restrict__ g_energy /* [T] */, float *__restrict__ g_xyz,
                                                   float *__restrict__ g_rot)
 {
-    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int gid = blockIdx.x * 256 + threadIdx.x, i = gid / kSub, sub = gid % kSub;
     if (i >= a.V) return;
     const size_t t = blockIdx.y;
     xyz += t * a.V * 3;
     rot += t * a.V * 9;
     const float ge = 2.0f * g_energy[t];
-    float R[9], xi[3], gx[3] = {0.f, 0.f, 0.f}, gR[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    float R[9], xi[3], g[12] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};      // gx[3] | gR[9]
 #pragma unroll
     for (int k = 0; k < 9; ++k) R[k] = rot[9 * (size_t)i + k];
 #pragma unroll
     for (int k = 0; k < 3; ++k) xi[k] = xyz[3 * (size_t)i + k];
-    for (int eidx = a.off[i]; eidx < a.off[i + 1]; ++eidx) {
+    const int e1 = a.off[i + 1];
+#pragma unroll 2
+    for (int eidx = a.off[i] + sub; eidx < e1; eidx += kSub) {
         const int j = a.nbr[eidx], m = a.rev[eidx];
         const float *xj = xyz + 3 * (size_t)j;
         const float *e = a.e + 3 * (size_t)eidx;
@@ -79,20 +98,22 @@ __global__ __launch_bounds__(256) void k_arap_bwd(ArapAdj a, const float *__rest
         const float w = a.w[eidx], wr = a.w[m];
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-            gx[c] += w * s[c] - wr * sr[c];
+            g[c] += w * s[c] - wr * sr[c];
 #pragma unroll
-            for (int b = 0; b < 3; ++b) gR[3 * c + b] -= w * s[c] * e[b];
+            for (int b = 0; b < 3; ++b) g[3 + 3 * c + b] -= w * s[c] * e[b];
         }
     }
+    group_sum(g);
+    if (sub != 0) return;
     if (g_xyz) {
         float *o = g_xyz + (t * a.V + i) * 3;
 #pragma unroll
-        for (int c = 0; c < 3; ++c) o[c] = ge * gx[c];
+        for (int c = 0; c < 3; ++c) o[c] = ge * g[c];
     }
     if (g_rot) {
         float *o = g_rot + (t * a.V + i) * 9;
 #pragma unroll
-        for (int k = 0; k < 9; ++k) o[k] = ge * gR[k];
+        for (int k = 0; k < 9; ++k) o[k] = ge * g[3 + k];
     }
 }
 
@@ -137,17 +158,19 @@ __global__ __launch_bounds__(256) void k_nc_fwd(NcPairs pr, int V, const float *
     terms[t * pr.P + p] = 1.0f - c;
 }
 
-// items of vertex i: item = pair * 4 + role, CSR offsets [V+1]
+// items of vertex i: item = pair * 4 + role, CSR offsets [V+1]; a group of kSub lanes per (mesh, vertex), see k_arap_fwd
 __global__ __launch_bounds__(256) void k_nc_bwd(NcPairs pr, int V, const int32_t *__restrict__ off, const int32_t *__restrict__ items,
                                                 const float *__restrict__ xyz, const float *__restrict__ g_loss /* [T] */,
                                                 float *__restrict__ g_xyz)
 {
-    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int gid = blockIdx.x * 256 + threadIdx.x, i = gid / kSub, sub = gid % kSub;
     if (i >= V) return;
     const size_t t = blockIdx.y;
     const float *x = xyz + t * V * 3;
     float acc[3] = {0.f, 0.f, 0.f};
-    for (int k = off[i]; k < off[i + 1]; ++k) {
+    const int k1 = off[i + 1];
+#pragma unroll 2
+    for (int k = off[i] + sub; k < k1; k += kSub) {
         const int p = items[k] >> 2, role = items[k] & 3;
         float e[3], a[3], b[3], n0[3], m[3], l0, l1;
         const float c = nc_pair(x, pr.v + 4 * (size_t)p, e, a, b, n0, m, l0, l1);
@@ -170,9 +193,45 @@ __global__ __launch_bounds__(256) void k_nc_bwd(NcPairs pr, int V, const int32_t
             acc[d] += role == 0 ? -((dE + dA[d]) + dB[d]) : role == 1 ? dE : role == 2 ? dA[d] : dB[d];
         }
     }
+    group_sum(acc);
+    if (sub != 0) return;
     const float s = g_loss[t] / (float)pr.P;
 #pragma unroll
     for (int d = 0; d < 3; ++d) g_xyz[(t * V + i) * 3 + d] = acc[d] * s;
+}
+
+
+// ---------------------------------------------------------------------------------------- unit quaternion -> rotation matrix
+// get_timed_vertex_rotation(return_matrix=True) (dynamic_sugar.py:640-655: a pypose .matrix()) for the ARAP term: R [n][3][3] of
+// q [n][4] = (x, y, z, w), the arithmetic of the torch expression it replaces (ops.py::_MatrixPypose: ~45 elementwise launches
+// per iteration for 9 polynomials), and pypose's backward: dL/dq = (sum_i (R e_i) x G[:, i], 0).
+__global__ __launch_bounds__(256) void k_quat_matrix_fwd(size_t n, const float *__restrict__ q, float *__restrict__ R)
+{
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float4 v = reinterpret_cast<const float4 *>(q)[i];
+    const float x = v.x, y = v.y, z = v.z, w = v.w;
+    float *o = R + 9 * i;
+    o[0] = 1.0f - 2.0f * (y * y + z * z); o[1] = 2.0f * (x * y - z * w);        o[2] = 2.0f * (x * z + y * w);
+    o[3] = 2.0f * (x * y + z * w);        o[4] = 1.0f - 2.0f * (x * x + z * z); o[5] = 2.0f * (y * z - x * w);
+    o[6] = 2.0f * (x * z - y * w);        o[7] = 2.0f * (y * z + x * w);        o[8] = 1.0f - 2.0f * (x * x + y * y);
+}
+
+__global__ __launch_bounds__(256) void k_quat_matrix_bwd(size_t n, const float *__restrict__ R, const float *__restrict__ G, float *__restrict__ gq)
+{
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float *r = R + 9 * i, *g = G + 9 * i;
+    float t[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {          // column c of R x column c of G, summed over the columns in order
+        const float a[3] = {r[c], r[3 + c], r[6 + c]}, b[3] = {g[c], g[3 + c], g[6 + c]};
+        float o[3];
+        cross3(a, b, o);
+#pragma unroll
+        for (int d = 0; d < 3; ++d) t[d] = c == 0 ? o[d] : t[d] + o[d];
+    }
+    reinterpret_cast<float4 *>(gq)[i] = make_float4(t[0], t[1], t[2], 0.f);
 }
 
 
@@ -248,7 +307,7 @@ int dm4d_arap_energy_forward(int32_t T, int32_t V, const int32_t *csr_offsets, c
     if (T == 0 || V == 0) return DM4D_OK;
     if (!vertex_energy) { set_error("arap: null output"); return DM4D_ERR_INVALID; }
     ArapAdj a{V, csr_offsets, neighbors, reverse_edge, weights, rest_edges};
-    hipLaunchKernelGGL(k_arap_fwd, dim3((V + 255) / 256, T), dim3(256), 0, (hipStream_t)stream, a, xyz_prime, rotations, vertex_energy);
+    hipLaunchKernelGGL(k_arap_fwd, dim3((unsigned)(((size_t)V * kSub + 255) / 256), T), dim3(256), 0, (hipStream_t)stream, a, xyz_prime, rotations, vertex_energy);
     DM4D_HIP_CHECK(hipGetLastError());
     return DM4D_OK;
 }
@@ -263,7 +322,7 @@ int dm4d_arap_energy_backward(int32_t T, int32_t V, const int32_t *csr_offsets, 
     if (T == 0 || V == 0) return DM4D_OK;
     if (!g_energy) { set_error("arap: null upstream gradient"); return DM4D_ERR_INVALID; }
     ArapAdj a{V, csr_offsets, neighbors, reverse_edge, weights, rest_edges};
-    hipLaunchKernelGGL(k_arap_bwd, dim3((V + 255) / 256, T), dim3(256), 0, (hipStream_t)stream, a, xyz_prime, rotations, g_energy,
+    hipLaunchKernelGGL(k_arap_bwd, dim3((unsigned)(((size_t)V * kSub + 255) / 256), T), dim3(256), 0, (hipStream_t)stream, a, xyz_prime, rotations, g_energy,
                        g_xyz, g_rotations);
     DM4D_HIP_CHECK(hipGetLastError());
     return DM4D_OK;
@@ -289,8 +348,30 @@ int dm4d_normal_consistency_backward(int32_t T, int32_t V, int32_t P, const int3
     if (T == 0 || V == 0) return DM4D_OK;
     if (!pairs || !vert_offsets || !vert_items || !xyz || !g_loss || !g_xyz) { set_error("normal consistency: null tensor"); return DM4D_ERR_INVALID; }
     NcPairs pr{P > 0 ? P : 1, pairs};
-    hipLaunchKernelGGL(k_nc_bwd, dim3((V + 255) / 256, T), dim3(256), 0, (hipStream_t)stream, pr, V, vert_offsets, vert_items, xyz,
+    hipLaunchKernelGGL(k_nc_bwd, dim3((unsigned)(((size_t)V * kSub + 255) / 256), T), dim3(256), 0, (hipStream_t)stream, pr, V, vert_offsets, vert_items, xyz,
                        g_loss, g_xyz);
+    DM4D_HIP_CHECK(hipGetLastError());
+    return DM4D_OK;
+}
+
+int dm4d_quat_to_matrix_forward(int64_t n, const float *quat_xyzw, float *matrices, dm4d_stream_t stream)
+{
+    if (n < 0) { set_error("quat_to_matrix: negative size"); return DM4D_ERR_INVALID; }
+    if (n == 0) return DM4D_OK;
+    if (!quat_xyzw || !matrices) { set_error("quat_to_matrix: null tensor"); return DM4D_ERR_INVALID; }
+    if (((uintptr_t)quat_xyzw & 15) != 0) { set_error("quat_to_matrix: quaternions must be 16-byte aligned"); return DM4D_ERR_INVALID; }
+    hipLaunchKernelGGL(k_quat_matrix_fwd, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (size_t)n, quat_xyzw, matrices);
+    DM4D_HIP_CHECK(hipGetLastError());
+    return DM4D_OK;
+}
+
+int dm4d_quat_to_matrix_backward_pypose(int64_t n, const float *matrices, const float *g_matrices, float *g_quat, dm4d_stream_t stream)
+{
+    if (n < 0) { set_error("quat_to_matrix: negative size"); return DM4D_ERR_INVALID; }
+    if (n == 0) return DM4D_OK;
+    if (!matrices || !g_matrices || !g_quat) { set_error("quat_to_matrix: null tensor"); return DM4D_ERR_INVALID; }
+    if (((uintptr_t)g_quat & 15) != 0) { set_error("quat_to_matrix: the quaternion gradient must be 16-byte aligned"); return DM4D_ERR_INVALID; }
+    hipLaunchKernelGGL(k_quat_matrix_bwd, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (size_t)n, matrices, g_matrices, g_quat);
     DM4D_HIP_CHECK(hipGetLastError());
     return DM4D_OK;
 }

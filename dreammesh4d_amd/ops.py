@@ -185,16 +185,29 @@ class _MatrixPypose(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, q):
-        x, y, z, w = q.unbind(-1)
-        R = torch.stack([1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w),
-                         2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w),
-                         2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)], -1).reshape(*q.shape[:-1], 3, 3)
+        if q.is_cuda:          # one launch (csrc/meshreg.hip) instead of ~45 elementwise ones; the same arithmetic
+            qc = _f32(q)
+            R = torch.empty(qc.shape[:-1] + (3, 3), dtype=torch.float32, device=q.device)
+            with torch.cuda.device(q.device):
+                _lib.check(_lib.lib().dm4d_quat_to_matrix_forward(qc.numel() // 4, _p(qc), _p(R), _st(q.device)), "dm4d_quat_to_matrix_forward")
+        else:
+            x, y, z, w = q.unbind(-1)
+            R = torch.stack([1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w),
+                             2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w),
+                             2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)], -1).reshape(*q.shape[:-1], 3, 3)
         ctx.save_for_backward(R)
         return R
 
     @staticmethod
     def backward(ctx, G):
         (R,) = ctx.saved_tensors
+        if R.is_cuda:
+            Gc = _f32(G)
+            gq = torch.empty(R.shape[:-2] + (4,), dtype=torch.float32, device=R.device)
+            with torch.cuda.device(R.device):
+                _lib.check(_lib.lib().dm4d_quat_to_matrix_backward_pypose(R.numel() // 9, _p(R), _p(Gc), _p(gq), _st(R.device)),
+                           "dm4d_quat_to_matrix_backward_pypose")
+            return gq
         t = torch.linalg.cross(R.transpose(-1, -2), G.transpose(-1, -2), dim=-1).sum(dim=-2)     # sum over the columns i
         return torch.cat([t, torch.zeros_like(t[..., :1])], dim=-1)
 

@@ -64,6 +64,7 @@ def _conv_nobias(conv, x):
 
 
 VAE_ATTENTION_BMM = os.environ.get("DM4D_VAE_ATTN_BMM", "1") != "0"                  # (A/B switch: _VaeAttn as bmm + softmax + bmm)
+FUSE_QKV = os.environ.get("DM4D_FUSE_QKV", "1") != "0"                              # (A/B switch: CrossAttention's one-GEMM q, k, v)
 FUSE_ADD_LAYERNORM = os.environ.get("DM4D_FUSE_ADD_LN", "1") != "0"                 # (A/B switch for BasicTransformerBlock._fused_no_grad)
 BATCH_SMALL_GEMMS = os.environ.get("DM4D_BATCH_SMALL_GEMMS", "1") != "0"      # (A/B switch for UNetModel._batched_small_gemms)
 _USE_MFMA_CONV_S2 = os.environ.get("DM4D_MFMA_CONV_S2", "1") != "0"            # (A/B switch: the stride-2 Downsample convolutions)
@@ -130,9 +131,15 @@ def _conv1x1(conv, x):
     return conv(x)
 
 
+_FREQS = {}
+
+
 def timestep_embedding(t, dim, max_period=10000):
     half = dim // 2
-    freqs = torch.exp(-math.log(max_period) * torch.arange(half, dtype=torch.float32, device=t.device) / half)
+    key = (t.device, half, max_period)
+    freqs = _FREQS.get(key)          # a constant of (dim, max_period): four launches per step otherwise
+    if freqs is None:
+        freqs = _FREQS[key] = torch.exp(-math.log(max_period) * torch.arange(half, dtype=torch.float32, device=t.device) / half)
     args = t[:, None].float() * freqs[None]
     emb = torch.cat([torch.cos(args), torch.sin(args)], dim=-1)
     if dim % 2:
@@ -200,8 +207,23 @@ class CrossAttention(nn.Module):
         ddpm.py:1953-1956): the softmax over a single key is exactly 1, so every query's output is to_out(to_v(context)),
         whatever the queries are -- [B, 1, query_dim], to be broadcast over the positions.  The same numbers as the general
         path without its query projection, attention and output GEMM over all positions."""
-        v = self.__dict__.get("_v_token")          # to_v(context) of ALL cross-attentions from one GEMM (UNetModel._batched_small_gemms)
+        tok = self.__dict__.get("_tok")            # to_out(to_v(context)) of ALL cross-attentions from 1 + 3 GEMMs (UNetModel._batched_small_gemms)
+        if tok is not None:
+            return tok[:, None, :]
+        v = self.__dict__.get("_v_token")
         return self.to_out(self.to_v(context) if v is None else v)
+
+    def _qkv_weight(self):
+        """[to_q; to_k; to_v] as one matrix (self-attention under no_grad with frozen parameters: one GEMM instead of three
+        launch-bound ones at M = B x L, N = K = 320 .. 1280)."""
+        ws = (self.to_q.weight, self.to_k.weight, self.to_v.weight)
+        key = tuple((w.data_ptr(), w._version) for w in ws)
+        c = self.__dict__.get("_qkv_cache")
+        if c is None or c[0] != key:
+            with torch.no_grad():
+                c = (key, torch.cat(ws).contiguous())
+            self.__dict__["_qkv_cache"] = c
+        return c[1]
 
     def forward(self, x, context=None):
         ctx = x if context is None else context
@@ -214,6 +236,11 @@ class CrossAttention(nn.Module):
         """softmax(q k^T / sqrt(d)) v with the heads merged again: everything of the layer before `to_out`."""
         B, L, _ = x.shape
         h = self.heads
+        if (FUSE_QKV and x is ctx and x.is_cuda and not torch.is_grad_enabled() and self.to_q.weight.shape == self.to_k.weight.shape
+                and not any(w.requires_grad for w in (self.to_q.weight, self.to_k.weight, self.to_v.weight))):
+            qkv = F.linear(x, self._qkv_weight()).view(B, L, 3, h, -1)          # the same products; q, k, v are strided views
+            o = F.scaled_dot_product_attention(qkv[:, :, 0].transpose(1, 2), qkv[:, :, 1].transpose(1, 2), qkv[:, :, 2].transpose(1, 2))
+            return o.transpose(1, 2).reshape(B, L, -1)
         q = self.to_q(x).view(B, L, h, -1).transpose(1, 2)
         k = self.to_k(ctx).view(B, ctx.shape[1], h, -1).transpose(1, 2)
         v = self.to_v(ctx).view(B, ctx.shape[1], h, -1).transpose(1, 2)
@@ -255,11 +282,12 @@ class BasicTransformerBlock(nn.Module):
         out1, ff2 = self.attn1.to_out[0], self.ff.net[2]
         n1, xb = add_layer_norm(self.norm1, x, None, out1.bias)                           # norm1(x) | x + b_out
         o = self.attn1.attend(n1, n1)
-        x1 = torch.addmm(xb.view(-1, Cc), o.view(B * L, -1), out1.weight.t()).view(B, L, Cc)      # attn1(norm1(x)) + x
+        # (in place: xb / x2b are this function's own temporaries, and torch.addmm would first COPY its C operand to the result)
+        x1 = xb.view(-1, Cc).addmm_(o.view(B * L, -1), out1.weight.t()).view(B, L, Cc)            # attn1(norm1(x)) + x
         tok = self.attn2.single_token(context)                                            # [B, 1, C]: the whole cross-attention
         n3, x2b = add_layer_norm(self.norm3, x1, tok, ff2.bias)                           # norm3(x1 + tok) | x1 + tok + b_ff
         g = self.ff.net[0](n3)
-        return torch.addmm(x2b.view(-1, Cc), g.view(B * L, -1), ff2.weight.t()).view(B, L, Cc)    # ff(norm3(x2)) + x2
+        return x2b.view(-1, Cc).addmm_(g.view(B * L, -1), ff2.weight.t()).view(B, L, Cc)          # ff(norm3(x2)) + x2
 
     def forward(self, x, context):
         if (FUSE_ADD_LAYERNORM and SINGLE_TOKEN_SHORTCUT and not torch.is_grad_enabled() and x.is_cuda and x.dtype == torch.float16
@@ -350,20 +378,33 @@ class UNetModel(nn.Module):
         nn.init.zeros_(self.out[2].bias)
 
     def _batched_small_gemms(self, emb, context):
-        """The UNet's M = batch GEMMs that do not depend on the activations, as TWO launches instead of 22 + 16 (each a
+        """The UNet's M = batch GEMMs that do not depend on the activations, as 2 + 3 launches instead of 22 + 16 + 16 (each a
         7 us launch-bound kernel + its SiLU / bias add): the timestep projection of every ResBlock (`emb_layers` = SiLU,
         Linear(emb) -- the same `emb` for all, openaimodel.py:259-266; the first convolution's bias, which this mirror folds
         into the same per-(sample, channel) term, rides in the concatenated bias) and, when the context is ONE token, the
-        value projection of every cross-attention (CrossAttention.single_token).  The same products row by row; the blocks
-        get column slices (views) of the two results.  Frozen parameters on a HIP device only."""
+        value projection of every cross-attention (one GEMM) followed by its output projection (CrossAttention.single_token;
+        one batched GEMM per width: 320 / 640 / 1280).  The same products row by row; the blocks get slices (views) of the
+        results.  Frozen parameters on a HIP device only."""
         cache = self.__dict__.get("_small_gemm_cache")
         res = [m for m in self.modules() if isinstance(m, ResBlock)] if cache is None else cache["res"]
-        att = [m.attn2 for m in self.modules() if isinstance(m, BasicTransformerBlock)] if cache is None else cache["att"]
+        # (cross-attentions ordered by width: the tokens of one width are ONE batched GEMM over a contiguous column range)
+        att = sorted((m.attn2 for m in self.modules() if isinstance(m, BasicTransformerBlock)),
+                     key=lambda a: a.to_v.out_features) if cache is None else cache["att"]
         key = tuple((b.emb_layers[1].weight.data_ptr(), b.emb_layers[1].weight._version, b.in_layers[2].bias._version) for b in res) + \
-            tuple((a.to_v.weight.data_ptr(), a.to_v.weight._version) for a in att)
+            tuple((a.to_v.weight.data_ptr(), a.to_v.weight._version, a.to_out[0].weight.data_ptr(), a.to_out[0].weight._version,
+                   a.to_out[0].bias._version) for a in att)
         if cache is None or cache["key"] != key:
             with torch.no_grad():
-                cache = dict(key=key, res=res, att=att,
+                groups, o = [], 0          # (first column, modules, stacked to_out weights transposed [n, inner, C], biases [n, 1, C])
+                for a in att:
+                    if not groups or groups[-1][1][0].to_v.out_features != a.to_v.out_features or \
+                            groups[-1][1][0].to_out[0].out_features != a.to_out[0].out_features:
+                        groups.append([o, []])
+                    groups[-1][1].append(a)
+                    o += a.to_v.out_features
+                groups = [(o0, ms, torch.stack([a.to_out[0].weight.t() for a in ms]).contiguous(),
+                           torch.stack([a.to_out[0].bias for a in ms])[:, None, :].contiguous()) for o0, ms in groups]
+                cache = dict(key=key, res=res, att=att, groups=groups,
                              We=torch.cat([b.emb_layers[1].weight for b in res]).contiguous(),
                              be=torch.cat([b.emb_layers[1].bias + b.in_layers[2].bias for b in res]).contiguous(),
                              Wv=torch.cat([a.to_v.weight for a in att]).contiguous())
@@ -375,12 +416,14 @@ class UNetModel(nn.Module):
             b.__dict__["_emb_add"] = e_all[:, o:o + c]
             o += c
         if context is not None and context.shape[1] == 1 and SINGLE_TOKEN_SHORTCUT:
+            B = context.shape[0]
             v_all = F.linear(context, cache["Wv"])                               # [B, 1, sum inner]
-            o = 0
-            for a in att:
-                c = a.to_v.out_features
-                a.__dict__["_v_token"] = v_all[:, :, o:o + c]
-                o += c
+            for o0, ms, WoT, bo in cache["groups"]:
+                n, inner = len(ms), ms[0].to_v.out_features
+                v = v_all[:, 0, o0:o0 + n * inner].view(B, n, inner).transpose(0, 1)      # [n, B, inner]: a strided view
+                tok = torch.baddbmm(bo, v, WoT)                                  # to_out(to_v(context)) of the n blocks: [n, B, C]
+                for i, a in enumerate(ms):
+                    a.__dict__["_tok"] = tok[i]
         return res, att
 
     def forward(self, x, timesteps, context):
@@ -401,7 +444,7 @@ class UNetModel(nn.Module):
                 for b in touched[0]:
                     b.__dict__.pop("_emb_add", None)
                 for a in touched[1]:
-                    a.__dict__.pop("_v_token", None)
+                    a.__dict__.pop("_tok", None)
         h = self.out[2](group_norm(self.out[0], h.type(x.dtype), silu=True, float32=True))
         return h.contiguous()
 

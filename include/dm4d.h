@@ -390,6 +390,14 @@ int dm4d_arap_energy_backward(int32_t T, int32_t V, const int32_t *csr_offsets, 
                               const float *xyz_prime, const float *rotations, const float *g_energy, float *g_xyz,
                               float *g_rotations, dm4d_stream_t stream);
 
+/* R [n][3][3] (row-major) of n unit quaternions q [n][4] = (x, y, z, w): `get_timed_vertex_rotation(return_matrix=True)` of
+ * C/geometry/dynamic_sugar.py:640-655 (a pypose SO3.matrix()), which the dynamic stage feeds to the ARAP term
+ * (C/system/sugar_4dgen.py:304-311).  _backward_pypose: pypose's gradient with respect to the quaternion storage,
+ * g_quat [n][4] = (sum_i (R e_i) x G[:, i], 0), from the forward's matrices and dL/dR.  (The Euclidean convention differentiates
+ * the polynomial with torch autograd instead: ops.py::quat_xyzw_to_matrix.) */
+int dm4d_quat_to_matrix_forward(int64_t n, const float *quat_xyzw, float *matrices, dm4d_stream_t stream);
+int dm4d_quat_to_matrix_backward_pypose(int64_t n, const float *matrices, const float *g_matrices, float *g_quat, dm4d_stream_t stream);
+
 /* pytorch3d.loss.mesh_normal_consistency (pytorch3d@stable, un-vendored: C/requirements.txt:46) of T deformed meshes
  * of one topology, as C/system/sugar_4dgen.py:214-226 applies it to the step's surface meshes (lambda 100,
  * C/configs/sugar_dynamic_dg.yaml:146).  `pairs` [P,4] (device, static): for every pair of faces sharing an edge,
@@ -559,6 +567,21 @@ int dm4d_conv3x3_strided_nhwc_f16(int32_t N, int32_t Hin, int32_t Win, int32_t C
  * on the vector ALUs (v_dot2_f32_f16). */
 int dm4d_conv3x3_c128_small_nhwc_f16(int32_t N, int32_t H, int32_t W, int32_t Cout, const void *x, const void *w, void *y,
                                      dm4d_stream_t stream);
+/* y = act(x w^T + bias) (+ residual) for float16 x [M][K], w [N][K] (an nn.Linear weight, or the [C_out][1][1][C_in] filter of
+ * a 1x1 convolution over NHWC pixels), bias [N] or NULL, residual [M][N] or NULL, float32 accumulation: the linear layers of
+ * the Zero123 UNet's transformer blocks (extern/ldm_zero123/modules/attention.py:152-213: to_q / to_k / to_v / to_out, the
+ * feed-forward, proj_in / proj_out) and the ResBlocks' 1x1 skip convolutions (openaimodel.py:247-256) on the implicit-GEMM MFMA
+ * kernel of dm4d_conv3x3_nhwc_f16 with ONE tap.  The sum + bias is rounded to float16, the residual added after (rounded
+ * again), as the separate add it replaces.
+ *   act = 0: none, y [M][N].
+ *   act = 1: GEGLU (attention.py:48-56: value, gate = proj.chunk(2); value * gelu(gate), erf form), y [M][N / 2].  The rows of
+ *     w (and bias) must be INTERLEAVED in blocks of 64: rows 128 j .. 128 j + 63 = value rows 64 j .., rows 128 j + 64 .. 128 j + 127 =
+ *     gate rows 64 j .. (conv_mfma.pack_geglu); N % 128 == 0, no residual.
+ * K % 32 == 0, N % 8 == 0, 16-byte aligned pointers.  scratch: dm4d_linear_scratch_bytes (split-K partial sums; may be NULL
+ * when that returns <= 256).  Errors: DM4D_ERR_UNSUPPORTED for shapes outside this, DM4D_ERR_INVALID for null / misaligned. */
+size_t dm4d_linear_scratch_bytes(int64_t M, int32_t K, int32_t N);
+int dm4d_linear_f16(int64_t M, int32_t K, int32_t N, const void *x, const void *w, const void *bias, const void *residual, void *y,
+                    int32_t act, void *scratch, dm4d_stream_t stream);
 
 /* ------------------------------------------------------------------ heat-method geodesics of the deformation graph
  * The device pieces of build_deformation_graph(mode="geodisc") with the reference's own distance, the heat method

@@ -137,3 +137,68 @@ def test_stride2_convolution_and_its_frozen_autograd_form(shape, pad):
     ref.backward(gy.float())
     assert x.grad.shape == x.shape
     assert (x.grad.float() - ref_in.grad).abs().max() <= 2 ** -9 * ref_in.grad.abs().max() + 1e-6
+
+
+LINEAR_SHAPES = [      # (M, K, N): the UNet's token counts x widths, tails, a split-K shape, the 64 x 64 tiles
+    (8192, 320, 320), (8192, 320, 960), (8192, 1280, 320), (2048, 640, 1920), (512, 1280, 1280), (512, 5120, 1280), (128, 1280, 1280),
+    (200, 64, 72), (1, 32, 8), (333, 96, 200), (130, 3840, 64),
+]
+
+
+@pytest.mark.parametrize("M,K,N", LINEAR_SHAPES)
+@pytest.mark.parametrize("mode", ["plain", "bias_residual"])
+def test_linear_matches_float32_reference(M, K, N, mode):
+    """dm4d_linear_f16 against float32 matmul of the same float16 operands: the error is the float16 rounding of the result
+    (+ of the residual sum) and the float32 accumulation order, nothing that grows with K."""
+    _need_gpu()
+    dev = torch.device("cuda:0")
+    from dreammesh4d_amd import conv_mfma
+
+    g = torch.Generator().manual_seed(M + 7 * K + N)
+    x = torch.randn(M, K, generator=g).to(dev, torch.float16)
+    w = (torch.randn(N, K, generator=g) / K ** 0.5).to(dev, torch.float16)
+    b = torch.randn(N, generator=g).to(dev, torch.float16) if mode != "plain" else None
+    r = torch.randn(M, N, generator=g).to(dev, torch.float16) if mode != "plain" else None
+    y = conv_mfma.linear(x, w, b, r)
+    ref = x.float() @ w.float().t()
+    if b is not None:
+        ref = (ref + b.float()).half().float() + r.float()
+    assert y.shape == (M, N) and y.dtype == torch.float16
+    err = float((y.float() - ref).abs().max())
+    assert err <= 2e-3 * max(1.0, float(ref.abs().max())), err
+
+
+@pytest.mark.parametrize("M,K,D", [(8192, 320, 1280), (2048, 640, 2560), (512, 1280, 5120), (100, 64, 64)])
+def test_linear_geglu_matches_reference(M, K, D):
+    """GEGLU in the epilogue (attention.py:48-56: value, gate = proj(x).chunk(2); value * gelu(gate)) with the rows interleaved by
+    pack_geglu: the same as the float16 projection followed by the separate GEGLU."""
+    _need_gpu()
+    dev = torch.device("cuda:0")
+    from dreammesh4d_amd import conv_mfma
+
+    g = torch.Generator().manual_seed(M + K + D)
+    x = torch.randn(M, K, generator=g).to(dev, torch.float16)
+    w = (torch.randn(2 * D, K, generator=g) / K ** 0.5).to(dev, torch.float16)
+    b = torch.randn(2 * D, generator=g).to(dev, torch.float16)
+    wp, bp = conv_mfma.pack_geglu(w, b)
+    y = conv_mfma.linear(x, wp, bp, act="geglu")
+    proj = (x.float() @ w.float().t() + b.float()).half().float()
+    val, gate = proj.chunk(2, dim=-1)
+    ref = val * torch.nn.functional.gelu(gate)
+    assert y.shape == (M, D)
+    err = float((y.float() - ref).abs().max())
+    assert err <= 4e-3 * max(1.0, float(ref.abs().max())), err
+
+
+def test_linear_rejects_what_it_does_not_support():
+    _need_gpu()
+    dev = torch.device("cuda:0")
+    from dreammesh4d_amd import conv_mfma
+
+    x = torch.zeros(4, 48, device=dev, dtype=torch.float16)
+    with pytest.raises(ValueError):
+        conv_mfma.linear(x, torch.zeros(8, 48, device=dev, dtype=torch.float16))          # K % 32
+    with pytest.raises(ValueError):
+        conv_mfma.linear(torch.zeros(4, 64, device=dev, dtype=torch.float16), torch.zeros(12, 64, device=dev, dtype=torch.float16))   # N % 8
+    with pytest.raises(ValueError):
+        conv_mfma.linear(torch.zeros(4, 64, device=dev, dtype=torch.float16).t().contiguous().t(), torch.zeros(8, 64, device=dev, dtype=torch.float16))

@@ -152,3 +152,25 @@ def test_laplacian_smoothing_against_the_oracle():
     x2 = x.detach().clone().requires_grad_(True)
     ls(x2).backward()
     assert torch.equal(x.grad, x2.grad)
+
+
+def test_quat_to_matrix_hip_equals_the_torch_expression():
+    """ops.quat_xyzw_to_matrix (pypose convention) on the HIP device: csrc/meshreg.hip::k_quat_matrix_fwd / _bwd against the torch
+    expression the CPU path evaluates (dynamic_sugar.py:640-655: pypose SO3.matrix(); backward (sum_i R e_i x G[:, i], 0))."""
+    if not torch.cuda.is_available():
+        pytest.skip("no HIP device")
+    from dreammesh4d_amd import ops
+
+    g = torch.Generator().manual_seed(5)
+    q = torch.nn.functional.normalize(torch.randn(3, 1001, 4, generator=g), dim=-1)
+    G = torch.randn(3, 1001, 3, 3, generator=g)
+    qc = q.clone().requires_grad_(True)
+    Rc = ops.quat_xyzw_to_matrix(qc, "pypose")
+    Rc.backward(G)
+    qd = q.to("cuda:0").requires_grad_(True)
+    Rd = ops.quat_xyzw_to_matrix(qd, "pypose")
+    Rd.backward(G.to("cuda:0"))
+    assert Rd.shape == (3, 1001, 3, 3)
+    assert torch.equal(Rd.detach().cpu(), Rc.detach())                      # the same float32 operations in the same order
+    assert float((qd.grad.cpu() - qc.grad).abs().max()) <= 1e-6 * float(qc.grad.abs().max())
+    assert float(qd.grad[..., 3].abs().max()) == 0.0

@@ -158,8 +158,9 @@ def test_single_token_cross_attention_in_closed_form():
 
 def test_batched_small_gemms_hand_every_block_its_own_projection():
     """UNetModel._batched_small_gemms: ONE GEMM for the timestep projections of all ResBlocks (emb_layers(emb) + the first
-    convolution's bias) and ONE for the value projections of all single-token cross-attentions; every block must get exactly the
-    column slice its own layers would compute (openaimodel.py:259-266, attention.py:196-213).  Host logic, run on the CPU."""
+    convolution's bias), ONE for the value projections of all single-token cross-attentions and one batched GEMM per width for
+    their output projections; every block must get exactly what its own layers would compute (openaimodel.py:259-266,
+    attention.py:196-213).  Host logic, run on the CPU."""
     import torch
 
     from dreammesh4d_amd import zero123 as z
@@ -180,21 +181,24 @@ def test_batched_small_gemms_hand_every_block_its_own_projection():
                 got = b.__dict__["_emb_add"]
                 assert got.shape == want.shape and float((got - want).abs().max()) <= 1e-5 * float(want.abs().max())
             for a in att:
-                want = a.to_v(ctx)
-                got = a.__dict__["_v_token"]
-                assert got.shape == want.shape and float((got - want).abs().max()) <= 1e-5 * float(want.abs().max())
-                assert float((a.single_token(ctx) - a.to_out(want)).abs().max()) <= 1e-5 * float(a.to_out(want).abs().max()) + 1e-7
+                want = a.to_out(a.to_v(ctx))
+                got = a.__dict__["_tok"]
+                assert got.shape == (3, want.shape[-1]) and float((got[:, None] - want).abs().max()) <= 1e-5 * float(want.abs().max()) + 1e-7
+                assert a.single_token(ctx).shape == want.shape and float((a.single_token(ctx) - want).abs().max()) <= 1e-5 * float(want.abs().max()) + 1e-7
         finally:
             for b in res:
                 b.__dict__.pop("_emb_add", None)
             for a in att:
-                a.__dict__.pop("_v_token", None)
+                a.__dict__.pop("_tok", None)
     # the cache follows the parameters: an in-place update of a weight is picked up
     with torch.no_grad():
         res[0].emb_layers[1].weight.mul_(2.0)
         unet._batched_small_gemms(emb, ctx)
         assert float((res[0].__dict__["_emb_add"] - (res[0].emb_layers(emb) + res[0].in_layers[2].bias)).abs().max()) < 1e-4
+        att[0].to_out[0].weight.mul_(0.5)
+        unet._batched_small_gemms(emb, ctx)
+        assert float((att[0].__dict__["_tok"][:, None] - att[0].to_out(att[0].to_v(ctx))).abs().max()) < 1e-4
         for b in res:
             b.__dict__.pop("_emb_add", None)
         for a in att:
-            a.__dict__.pop("_v_token", None)
+            a.__dict__.pop("_tok", None)

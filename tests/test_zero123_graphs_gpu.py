@@ -42,3 +42,35 @@ def test_graphed_sds_step_equals_eager():
         assert float((a[1] - b[1]).abs().max()) <= 1e-5 * float(a[1].abs().max()), step
     assert graphed._graph_error is None, graphed._graph_error
     assert len(graphed._unet_graphs) == 1 and len(graphed._enc_graphed) == 1 and not eager._unet_graphs
+
+
+def test_fused_unet_path_equals_plain_forward(monkeypatch):
+    """The float16 / no_grad UNet on a HIP device takes shortcuts that must not change what it computes: q, k, v of a
+    self-attention from ONE GEMM (strided views into its result), the residual adds in the GEMMs' C operand written in place,
+    the timestep projections, single-token value and output projections of all blocks from batched GEMMs.  Against the same
+    module with every switch off (the reference's op-by-op forward, openaimodel.py / attention.py), on the same weights."""
+    if not torch.cuda.is_available():
+        pytest.skip("no HIP device")
+    from dreammesh4d_amd import zero123 as z
+
+    dev = torch.device("cuda:0")
+    torch.manual_seed(3)
+    unet = z.UNetModel(model_channels=64, context_dim=48, num_heads=4)
+    with torch.no_grad():
+        for m in unet.modules():            # (the zero-initialised projections would hide the transformer blocks)
+            if isinstance(m, z.SpatialTransformer):
+                torch.nn.init.normal_(m.proj_out.weight, std=0.05)
+        torch.nn.init.normal_(unet.out[2].weight, std=0.05)
+    unet = unet.to(dev, torch.float16).to(memory_format=torch.channels_last).requires_grad_(False)
+    x = torch.randn(4, 8, 32, 32, device=dev, dtype=torch.float16)
+    t = torch.tensor([10, 400, 700, 990], device=dev)
+    ctx = torch.randn(4, 1, 48, device=dev, dtype=torch.float16)
+    with torch.no_grad():
+        fused = unet(x, t, ctx).float()
+        for name in ("FUSE_QKV", "FUSE_ADD_LAYERNORM", "BATCH_SMALL_GEMMS"):
+            assert getattr(z, name)
+            monkeypatch.setattr(z, name, False)
+        plain = unet(x, t, ctx).float()
+    assert torch.isfinite(plain).all() and float(plain.abs().max()) > 1e-2
+    # float16 roundings in another order (one GEMM's accumulation against three, sums fused differently): ~1e-3 relative
+    assert float((fused - plain).abs().max()) <= 4e-3 * float(plain.abs().max()), float((fused - plain).abs().max()) / float(plain.abs().max())
