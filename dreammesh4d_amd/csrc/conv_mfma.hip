@@ -811,7 +811,9 @@ int dm4d_conv3x3_strided_nhwc_f16(int32_t N, int32_t Hin, int32_t Win, int32_t C
 static void linear_plan(int64_t M, int N, int kt_total, int act, int &cfg, int &splits)
 {
     const long tiles128 = (long)((M + 127) / 128) * ((N + 127) / 128);
-    cfg = (act == 1 || tiles128 >= 96) ? 3 : 13;
+    // (tools/linear_tune.py: the 64 x 64 tiles win while the 128 x 128 ones would leave CUs idle -- unless K is long, where the larger
+    // tile's fewer operand fetches matter more)
+    cfg = (act != 1 && tiles128 < 200 && (kt_total <= 24 || tiles128 < 96)) ? 13 : 3;
     if (const char *force = getenv("DM4D_LIN_CFG")) { const int f = atoi(force); if (act != 1 || f == 3) cfg = f; }
     const int B = cfg == 13 ? 64 : 128;
     const long tiles = (long)((M + B - 1) / B) * ((N + B - 1) / B);

@@ -22,6 +22,8 @@
 // dz = dy silu'(z),  s1 = sum_group dz gamma,  s2 = sum_group dz gamma xhat,  m = elements per group:
 //     dx = rstd (dz gamma - (s1 + xhat s2) / m)
 // -- the same two-pass structure.
+#include <stdlib.h>
+#include <type_traits>
 #include "common.h"
 #include "dm4d.h"
 
@@ -224,6 +226,137 @@ __global__ __launch_bounds__(kGnThreads) void k_groupnorm(GnArgs a)
     }
 }
 
+// ---------------------------------------------------------------------------------------- forward, slab-resident (ONE launch)
+// The UNet's activations at batch 8 are 0.3 .. 10 MB: both launches above are at the launch floor (5-8 us each, 61 GroupNorms per
+// forward = 0.9 ms of the 6.5 ms UNet).  Here a workgroup owns ALL pixels of one sample for a block of `gb` consecutive groups
+// (gb cpg channels = `ppp` 16-byte pieces per pixel; gb = the smallest count that makes the block a whole number of pieces), keeps
+// its slab in REGISTERS (<= kSlabPPT pieces per thread), and does statistics, normalisation, SiLU and the store from them: one
+// read, one write, one launch.  The slab's pieces are dealt piece-fastest (consecutive lanes read consecutive pieces of a pixel)
+// with a thread count that is a multiple of ppp, so a thread keeps ONE channel column and its constants for all its pixels.
+// Sums: shifted like the two-pass kernel's (x + add - K, K = the group's first element), per thread and channel, then through
+// LDS in a fixed order (deterministic).  Chosen by gn_slab_plan when the slab fits; everything else takes the two launches.
+constexpr int kSlabPPT = 24;
+constexpr int kSlabThreads = 256;
+__global__ __launch_bounds__(kSlabThreads) void k_groupnorm_slab_f16(GnArgs a, int gb, int ppp)
+{
+    typedef _Float16 V __attribute__((ext_vector_type(8)));
+    __shared__ float part[kSlabThreads][17];          // per thread: 8 channel sums, 8 channel sums of squares (+1: bank spread)
+    __shared__ float red[kSlabThreads][2];
+    __shared__ float gstat[16][2];                    // mean, rstd of the block's groups
+    const int n = blockIdx.y, t = threadIdx.x, nt = blockDim.x;
+    const int C = a.C, cpg = C / a.G, g0 = blockIdx.x * gb, c0 = g0 * cpg, nch = gb * cpg;
+    const int piece = t % ppp, R = nt / ppp;          // rows (pixels) in flight; this thread: pixels t / ppp, + R, ...
+    const size_t sample = (size_t)n * a.HW * C;
+    const _Float16 *__restrict__ x = (const _Float16 *)a.x + sample + c0 + 8 * piece;
+    const _Float16 *__restrict__ add = a.add ? (const _Float16 *)a.add + (size_t)n * a.add_stride + c0 + 8 * piece : nullptr;
+    V v[kSlabPPT];
+    const int p0 = t / ppp;
+    int cnt = 0;
+#pragma unroll
+    for (int k = 0; k < kSlabPPT; ++k) {
+        const int px = p0 + k * R;
+        if (px < a.HW) { v[k] = *reinterpret_cast<const V *>(x + (size_t)px * C); cnt = k + 1; }
+    }
+    float ad[8], sh[8];
+    {
+        V av = V{};
+        if (add) av = *reinterpret_cast<const V *>(add);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            ad[i] = (float)av[i];
+            const int g = (8 * piece + i) / cpg;                                   // group within the block
+            sh[i] = ad[i] - (float)((const _Float16 *)a.x)[sample + (size_t)(g0 + g) * cpg];
+        }
+    }
+    float s1[8], s2[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { s1[i] = 0.f; s2[i] = 0.f; }
+#pragma unroll
+    for (int k = 0; k < kSlabPPT; ++k) {
+        if (k < cnt) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const float w = (float)v[k][i] + sh[i];
+                s1[i] += w;
+                s2[i] = __builtin_fmaf(w, w, s2[i]);
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { part[t][i] = s1[i]; part[t][8 + i] = s2[i]; }
+    __syncthreads();
+    // channels -> J lanes per channel over the R threads of its piece column -> groups
+    const int J = nt / nch > 0 ? nt / nch : 1;
+    {
+        const int ch = t / J, j = t % J;
+        float s = 0.f, q = 0.f;
+        if (ch < nch) {
+            const int pc = ch >> 3, i = ch & 7;
+            for (int r = j; r < R; r += J) { s += part[pc + ppp * r][i]; q += part[pc + ppp * r][8 + i]; }
+        }
+        red[t][0] = s; red[t][1] = q;
+    }
+    __syncthreads();
+    if (t < gb) {
+        float s = 0.f, q = 0.f;
+        for (int e = 0; e < cpg * J; ++e) { s += red[t * cpg * J + e][0]; q += red[t * cpg * J + e][1]; }
+        const float inv_m = 1.0f / ((float)cpg * (float)a.HW);
+        const float dm = s * inv_m;
+        const float mean = (float)((const _Float16 *)a.x)[sample + (size_t)(g0 + t) * cpg] + dm;
+        const float var = fmaxf(q * inv_m - dm * dm, 0.f);
+        const float rstd = 1.0f / sqrtf(var + a.eps);
+        gstat[t][0] = mean; gstat[t][1] = rstd;
+        a.stats[((size_t)n * a.G + g0 + t) * 2] = mean;
+        a.stats[((size_t)n * a.G + g0 + t) * 2 + 1] = rstd;
+    }
+    __syncthreads();
+    float k0[8], k1[8];
+    {
+        const V gv = *reinterpret_cast<const V *>((const _Float16 *)a.gamma + c0 + 8 * piece);
+        const V bv = *reinterpret_cast<const V *>((const _Float16 *)a.beta + c0 + 8 * piece);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int g = (8 * piece + i) / cpg;
+            k0[i] = gstat[g][1] * (float)gv[i];
+            k1[i] = __builtin_fmaf(ad[i] - gstat[g][0], k0[i], (float)bv[i]);
+        }
+    }
+    _Float16 *__restrict__ out = (_Float16 *)a.out + sample + c0 + 8 * piece;
+#pragma unroll
+    for (int k = 0; k < kSlabPPT; ++k) {
+        if (k < cnt) {
+            V o;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                float z = __builtin_fmaf((float)v[k][i], k0[i], k1[i]);
+                if (a.silu) z = z * gn_sigmoid(z);
+                o[i] = (_Float16)z;
+            }
+            *reinterpret_cast<V *>(out + (size_t)(p0 + k * R) * C) = o;
+        }
+    }
+}
+
+// groups per workgroup, pieces per pixel and threads of the slab kernel for this shape; false: take the two-pass kernels
+static bool gn_slab_plan(const GnArgs &a, int &gb, int &ppp, int &threads)
+{
+    static const int off = [] { const char *e = getenv("DM4D_GN_SLAB"); return e && atoi(e) == 0 ? 1 : 0; }();      // (A/B switch)
+    if (off) return false;
+    const int cpg = a.C / a.G;
+    int g = 8, x = cpg;                 // gb = 8 / gcd(cpg, 8)
+    while (x % 2 == 0 && g > 1) { x /= 2; g /= 2; }
+    gb = g;
+    if (a.G % gb != 0 || gb > 16) return false;
+    ppp = gb * cpg / 8;
+    if (ppp < 1 || ppp > kSlabThreads / 2) return false;
+    threads = kSlabThreads / ppp * ppp;
+    if (gb * cpg > threads) return false;                                       // (the channel -> group stage has a lane per channel)
+    const int R = threads / ppp;
+    // measured per shape (tools/gn_shapes.py): 1.4-2.9x faster than the two launches at <= 16 x 16 pixels per sample (7-9 us against
+    // 10-23), 10 % slower at 32 x 32 (8 samples x 8 group blocks = 64 workgroups of 20 pieces per thread) and at the VAE's 64 x 64
+    return a.HW <= 256 && (a.HW + R - 1) / R <= kSlabPPT;
+}
+
 static size_t gn_lds_bytes(int C, int G, int vec, bool stats)
 {
     const int cv = C / vec, cw = cv < kGnThreads ? cv : kGnThreads, rpp = kGnThreads / cw;
@@ -238,6 +371,14 @@ static int gn_launch(GnArgs a, bool backward, hipStream_t st)
     const size_t lds_s = gn_lds_bytes(a.C, a.G, VEC, true), lds_a = gn_lds_bytes(a.C, a.G, VEC, false);
     if (lds_s > 64 * 1024) { set_error("groupnorm: C = %d needs %zu bytes of LDS", a.C, lds_s); return DM4D_ERR_INVALID; }
     if (!backward) {
+        if constexpr (std::is_same<T, _Float16>::value) {
+            int gb, ppp, threads;
+            if (gn_slab_plan(a, gb, ppp, threads)) {
+                hipLaunchKernelGGL(k_groupnorm_slab_f16, dim3(a.G / gb, a.N), dim3(threads), 0, st, a, gb, ppp);
+                DM4D_HIP_CHECK(hipGetLastError());
+                return DM4D_OK;
+            }
+        }
         hipLaunchKernelGGL((k_groupnorm<T, kGnFwdStats>), grid, block, lds_s, st, a);
         hipLaunchKernelGGL((k_groupnorm<T, kGnFwdApply>), grid, block, lds_a, st, a);
     } else {

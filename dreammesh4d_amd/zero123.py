@@ -31,6 +31,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from . import conv_mfma
 from .fused_norm import add_bias, add_layer_norm, geglu, group_norm, is_channels_last
 
 
@@ -64,6 +65,11 @@ def _conv_nobias(conv, x):
 
 
 VAE_ATTENTION_BMM = os.environ.get("DM4D_VAE_ATTN_BMM", "1") != "0"                  # (A/B switch: _VaeAttn as bmm + softmax + bmm)
+# The transformer blocks' linear layers on the hand-written MFMA kernel (conv_mfma.linear: the one-tap implicit GEMM with bias /
+# residual / GEGLU in its epilogue) where it beats the library GEMM + the extra launches: measured per shape (tools/linear_shapes.py),
+# that is the 32 x 32 level (M = 8192 rows: q/k/v 18.7 -> 14 us, attention output + residual 13.7 -> 10.3, GEGLU projection 52.5 ->
+# 39.5, proj_out + residual 13.7 -> ~9); at M <= 2048 hipBLASLt's kernels are as fast or faster and stay.
+MFMA_LINEAR_MIN_ROWS = int(os.environ.get("DM4D_MFMA_LINEAR_MIN_ROWS", "4096"))      # (A/B switch: a huge value = library everywhere)
 FUSE_QKV = os.environ.get("DM4D_FUSE_QKV", "1") != "0"                              # (A/B switch: CrossAttention's one-GEMM q, k, v)
 FUSE_ADD_LAYERNORM = os.environ.get("DM4D_FUSE_ADD_LN", "1") != "0"                 # (A/B switch for BasicTransformerBlock._fused_no_grad)
 BATCH_SMALL_GEMMS = os.environ.get("DM4D_BATCH_SMALL_GEMMS", "1") != "0"      # (A/B switch for UNetModel._batched_small_gemms)
@@ -238,7 +244,11 @@ class CrossAttention(nn.Module):
         h = self.heads
         if (FUSE_QKV and x is ctx and x.is_cuda and not torch.is_grad_enabled() and self.to_q.weight.shape == self.to_k.weight.shape
                 and not any(w.requires_grad for w in (self.to_q.weight, self.to_k.weight, self.to_v.weight))):
-            qkv = F.linear(x, self._qkv_weight()).view(B, L, 3, h, -1)          # the same products; q, k, v are strided views
+            wqkv = self._qkv_weight()
+            if B * L >= MFMA_LINEAR_MIN_ROWS and x.dtype == torch.float16 and x.is_contiguous() and conv_mfma.linear_supported(x, wqkv):
+                qkv = conv_mfma.linear(x, wqkv).view(B, L, 3, h, -1)
+            else:
+                qkv = F.linear(x, wqkv).view(B, L, 3, h, -1)                     # the same products; q, k, v are strided views
             o = F.scaled_dot_product_attention(qkv[:, :, 0].transpose(1, 2), qkv[:, :, 1].transpose(1, 2), qkv[:, :, 2].transpose(1, 2))
             return o.transpose(1, 2).reshape(B, L, -1)
         q = self.to_q(x).view(B, L, h, -1).transpose(1, 2)
@@ -279,12 +289,24 @@ class BasicTransformerBlock(nn.Module):
         adds ride in the GEMMs (`addmm`: C operand = residual + that GEMM's bias) and the LayerNorms come from the kernel that
         also prepares that operand (fused_norm.add_layer_norm): per block 2 launches instead of 2 LayerNorms + 3 adds."""
         B, L, Cc = x.shape
-        out1, ff2 = self.attn1.to_out[0], self.ff.net[2]
+        out1, ff1, ff2 = self.attn1.to_out[0], self.ff.net[0].proj, self.ff.net[2]
+        own = B * L >= MFMA_LINEAR_MIN_ROWS and conv_mfma.linear_supported(x, out1.weight) and ff1.out_features % 256 == 0
+        tok = self.attn2.single_token(context)                                            # [B, 1, C]: the whole cross-attention
+        if own:        # the MFMA kernel: bias and residual in the epilogue (no prepared C operand), GEGLU in the epilogue
+            n1, _ = add_layer_norm(self.norm1, x, None, None, want_sum=False)
+            o = self.attn1.attend(n1, n1)
+            x1 = conv_mfma.linear(o, out1.weight, out1.bias, residual=x)                  # attn1(norm1(x)) + x
+            n3, x2b = add_layer_norm(self.norm3, x1, tok, ff2.bias)                       # norm3(x1 + tok) | x1 + tok + b_ff
+            key = (ff1.weight.data_ptr(), ff1.weight._version, ff1.bias._version)
+            pk = self.__dict__.get("_geglu_packed")
+            if pk is None or pk[0] != key:
+                pk = self.__dict__["_geglu_packed"] = (key,) + conv_mfma.pack_geglu(ff1.weight, ff1.bias)
+            g = conv_mfma.linear(n3, pk[1], pk[2], act="geglu")
+            return x2b.view(-1, Cc).addmm_(g.view(B * L, -1), ff2.weight.t()).view(B, L, Cc)      # ff(norm3(x2)) + x2
         n1, xb = add_layer_norm(self.norm1, x, None, out1.bias)                           # norm1(x) | x + b_out
         o = self.attn1.attend(n1, n1)
         # (in place: xb / x2b are this function's own temporaries, and torch.addmm would first COPY its C operand to the result)
         x1 = xb.view(-1, Cc).addmm_(o.view(B * L, -1), out1.weight.t()).view(B, L, Cc)            # attn1(norm1(x)) + x
-        tok = self.attn2.single_token(context)                                            # [B, 1, C]: the whole cross-attention
         n3, x2b = add_layer_norm(self.norm3, x1, tok, ff2.bias)                           # norm3(x1 + tok) | x1 + tok + b_ff
         g = self.ff.net[0](n3)
         return x2b.view(-1, Cc).addmm_(g.view(B * L, -1), ff2.weight.t()).view(B, L, Cc)          # ff(norm3(x2)) + x2
@@ -320,6 +342,12 @@ class SpatialTransformer(nn.Module):
         h = h.flatten(2).transpose(1, 2)                      # b (h w) c  (a view of a channels-last tensor)
         for blk in self.transformer_blocks:
             h = blk(h, context)
+        w = self.proj_out.weight
+        if (h.is_cuda and B * Hh * Ww >= MFMA_LINEAR_MIN_ROWS and not torch.is_grad_enabled() and h.is_contiguous() and h.dtype == torch.float16
+                and is_channels_last(x) and x.dtype == torch.float16 and not w.requires_grad and conv_mfma.linear_supported(h, w.flatten(1))):
+            # proj_out + bias + the residual in one launch (tokens [B, HW, C] and NHWC pixels are the same memory)
+            y = conv_mfma.linear(h, w.flatten(1), self.proj_out.bias, residual=x.permute(0, 2, 3, 1).reshape(B, Hh * Ww, Cc))
+            return y.view(B, Hh, Ww, -1).permute(0, 3, 1, 2)
         h = h.transpose(1, 2).reshape(B, -1, Hh, Ww)
         return _conv1x1(self.proj_out, h) + x
 
