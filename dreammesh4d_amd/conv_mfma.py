@@ -8,6 +8,8 @@ memory), optional bias [C_out] and residual (same shape / format as the output; 
 epilogue).  `conv3x3` itself carries no autograd (the UNet runs under no_grad); `conv3x3_frozen` is the autograd form for
 frozen parameters (the VAE encoder the rendered image is differentiated through, stable_zero123_guidance.py:153-160): its data
 gradient is the same kernel on the flipped, transposed filter."""
+import ctypes
+
 import torch
 
 from . import _lib
@@ -163,30 +165,61 @@ def conv3x3_first_frozen(x, w, b, w_t):
     return _ConvFirstFrozen.apply(x, w, b, w_t)
 
 
+def pack_weight_s2_dgrad(w):
+    """The four filters of the stride-2 / pad-0 data gradient (include/dm4d.h, dm4d_conv3x3_s2_dgrad_nhwc_f16): for the input
+    pixels of parity (py, px) the taps (ky, kx) with ky in (2, 0) if py == 0 else (1,), kx likewise, as [C_in, KH, KW, C_out]."""
+    out = []
+    for py in (0, 1):
+        for px in (0, 1):
+            ky, kx = ([2, 0] if py == 0 else [1]), ([2, 0] if px == 0 else [1])
+            out.append(w.detach()[:, :, ky][:, :, :, kx].permute(1, 2, 3, 0).contiguous())
+    return out
+
+
+def conv3x3_s2_dgrad(dy, w_cls, in_shape):
+    """dL/dx [N, C_in, H, W] (channels_last) of the stride-2 / pad-0 Downsample convolution from dy [N, C_out, H/2, W/2]."""
+    N, Ci, H, W = in_shape
+    Co = int(dy.shape[1])
+    if not (dy.is_cuda and dy.dtype == torch.float16 and dy.is_contiguous(memory_format=torch.channels_last) and H % 2 == 0 and W % 2 == 0
+            and tuple(dy.shape) == (N, Co, H // 2, W // 2) and Ci % 32 == 0 and Co % 32 == 0):
+        raise ValueError("conv3x3_s2_dgrad: channels_last float16 dy of an even-sized input, C_in and C_out multiples of 32")
+    FLOPS[0] += 2 * N * (H // 2) * (W // 2) * Ci * Co * 9
+    dx = torch.empty((N, Ci, H, W), device=dy.device, dtype=torch.float16, memory_format=torch.channels_last)
+    ptrs = (ctypes.c_void_p * 4)(*[t.data_ptr() for t in w_cls])
+    with torch.cuda.device(dy.device):
+        _lib.check(_lib.lib().dm4d_conv3x3_s2_dgrad_nhwc_f16(N, H, W, Ci, Co, dy.data_ptr(), ptrs, dx.data_ptr(),
+                                                              torch.cuda.current_stream(dy.device).cuda_stream), "dm4d_conv3x3_s2_dgrad_nhwc_f16")
+    return dx
+
+
 class _Conv3x3Stride2Frozen(torch.autograd.Function):
     """Stride-2 convolution with frozen parameters (the VAE encoder's Downsample: pad 0 + one zero behind each axis): forward on the
-    MFMA kernel without materialising the padded input; the data gradient on the library's transposed convolution of the PADDED
-    shape, cropped (a view) -- a strided data gradient visits every output pixel with a quarter of the taps and is no shape for the
-    implicit-GEMM kernel."""
+    MFMA kernel without materialising the padded input; the data gradient as four stride-1 convolutions of dy, one per parity
+    class of the input pixels, on the same kernel (pad 0, even sizes, channel counts in multiples of 32); anything else on the
+    library's transposed convolution of the padded shape, cropped."""
 
     @staticmethod
-    def forward(ctx, x, w, w_ohwi, bias, pad):
+    def forward(ctx, x, w, w_ohwi, bias, pad, w_cls=None):
         ctx.save_for_backward(w)
-        ctx.in_shape, ctx.pad = tuple(x.shape), pad
+        ctx.in_shape, ctx.pad, ctx.w_cls = tuple(x.shape), pad, w_cls
         return conv3x3(x, w_ohwi, bias, None, stride=2, pad=pad)
 
     @staticmethod
     def backward(ctx, dy):
         (w,) = ctx.saved_tensors
         if not ctx.needs_input_grad[0]:
-            return None, None, None, None, None
+            return None, None, None, None, None, None
         N, C, H, W = ctx.in_shape
+        if (ctx.pad == 0 and ctx.w_cls is not None and H % 2 == 0 and W % 2 == 0 and C % 32 == 0 and dy.shape[1] % 32 == 0
+                and dy.dtype == torch.float16):
+            return conv3x3_s2_dgrad(dy.contiguous(memory_format=torch.channels_last), ctx.w_cls, ctx.in_shape), None, None, None, None, None
         if ctx.pad:
             dx = torch.nn.grad.conv2d_input((N, C, H, W), w, dy, stride=2, padding=1)
         else:
             dx = torch.nn.grad.conv2d_input((N, C, H + 1, W + 1), w, dy, stride=2, padding=0)[:, :, :H, :W]
-        return dx, None, None, None, None
+        return dx, None, None, None, None, None
 
 
-def conv3x3_stride2_frozen(x, w, w_ohwi, bias=None, pad=0):
-    return _Conv3x3Stride2Frozen.apply(x, w, w_ohwi, bias, pad)
+def conv3x3_stride2_frozen(x, w, w_ohwi, bias=None, pad=0, w_cls=None):
+    """w_cls: pack_weight_s2_dgrad(w) for the MFMA data gradient (None: the library's)."""
+    return _Conv3x3Stride2Frozen.apply(x, w, w_ohwi, bias, pad, w_cls)

@@ -44,7 +44,9 @@ __device__ __attribute__((aligned(64))) uint4 g_conv_zero[4];     // the line th
 
 struct ConvDesc {
     int N, H, W, Cin, Cout, M;       // H, W: OUTPUT size; M = N H W output pixels
-    int Hin, Win, stride, pad;       // input size; output (y, x), tap (ky, kx) reads input (stride y + ky - pad, stride x + kx - pad)
+    int Hin, Win, stride, pad;       // input size; output (y, x), tap (ky, kx) reads input (stride y + ky - pad, stride x + kx - pad_x)
+    int pad_x;                       // (= pad except for the 2 x 1 / 1 x 2 filters of the stride-2 data gradient)
+    int ostep, oy0, ox0;             // ostep > 0: output pixel (n, y, x) is WRITTEN at (n, ostep y + oy0, ostep x + ox0) of an [N][ostep H][ostep W] image
     const _Float16 *x, *w, *bias, *res;
     _Float16 *y;
     float *partial;                  // [splits][M][Cout] when splits > 1
@@ -152,11 +154,12 @@ __device__ __forceinline__ void conv_epilogue(const ConvDesc &d, f32x16 (&acc)[M
 }
 
 // (the body is a __device__ function: the host pass cannot instantiate a __global__ template that uses the buffer builtins)
-// KSZ: the filter is KSZ x KSZ (3; 1 = a GEMM y = x w^T over the [pixels][channels] view, dm4d_linear_f16)
-template <int WM, int WN, int MB, int NB, int kCvStages, int KSZ>
+// The filter is KH x KW: 3 x 3; 1 x 1 = a GEMM y = x w^T over the [pixels][channels] view (dm4d_linear_f16); 2 x 2, 2 x 1, 1 x 2, 1 x 1 with
+// a strided output = the four parity classes of the stride-2 data gradient (dm4d_conv3x3_s2_dgrad_nhwc_f16)
+template <int WM, int WN, int MB, int NB, int kCvStages, int KH, int KW>
 __device__ __forceinline__ void conv3x3_tile(const ConvDesc &d)
 {
-    constexpr int TAPS = KSZ * KSZ;
+    constexpr int TAPS = KH * KW;
     constexpr int NW = WM * WN, BM = 32 * MB * WM, BN = 32 * NB * WN;
     constexpr int A_INSTR = (BM * 4 + 64 * NW - 1) / (64 * NW), B_INSTR = (BN * 4 + 64 * NW - 1) / (64 * NW);   // DMA instructions per wave and stage
     constexpr int A_SLOTS = A_INSTR * 64 * NW, B_SLOTS = B_INSTR * 64 * NW;         // 16-byte slots per stage (rows past BM / BN: padding)
@@ -178,7 +181,7 @@ __device__ __forceinline__ void conv3x3_tile(const ConvDesc &d)
     //   that the uniform tap offset ((dy + 1) W + dx + 1) C_in is never negative; a lane whose tap falls outside the image (or
     //   whose row is past M / C_out) carries kOob and the hardware's range check fills its 16 bytes with zeros.
     const auto a_rs = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<_Float16 *>(d.x) - (size_t)(d.pad * (d.Win + 1)) * d.Cin, 0,
+        const_cast<_Float16 *>(d.x) - (size_t)(d.pad * d.Win + d.pad_x) * d.Cin, 0,
         (int)(((size_t)d.N * d.Hin * d.Win + 2 * d.Win + 2) * d.Cin * 2), 0x00020000);
     const auto b_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16 *>(d.w), 0, (int)((size_t)d.Cout * TAPS * d.Cin * 2), 0x00020000);
     unsigned a_vo[A_INSTR], a_taps[A_INSTR], a_cur[A_INSTR], b_vo[B_INSTR];
@@ -192,7 +195,7 @@ __device__ __forceinline__ void conv3x3_tile(const ConvDesc &d)
         unsigned taps = 0;
 #pragma unroll
         for (int tap = 0; tap < TAPS; ++tap) {
-            const int yy = d.stride * y + tap / KSZ - d.pad, xx = d.stride * x + tap % KSZ - d.pad;
+            const int yy = d.stride * y + tap / KW - d.pad, xx = d.stride * x + tap % KW - d.pad_x;
             if (ok && (unsigned)yy < (unsigned)d.Hin && (unsigned)xx < (unsigned)d.Win) taps |= 1u << tap;
         }
         a_taps[i] = taps;
@@ -205,7 +208,7 @@ __device__ __forceinline__ void conv3x3_tile(const ConvDesc &d)
     }
     // the issue stream's position: tap, chunk and the two uniform offsets
     int is_tap = kt0 / cpt, is_chunk = kt0 % cpt;
-    int is_a = ((is_tap / KSZ) * d.Win + is_tap % KSZ) * d.Cin * 2 + is_chunk * (kCvBK * 2);
+    int is_a = ((is_tap / KW) * d.Win + is_tap % KW) * d.Cin * 2 + is_chunk * (kCvBK * 2);
     int is_b = (is_tap * d.Cin + is_chunk * kCvBK) * 2;
     auto set_tap = [&]() {
 #pragma unroll
@@ -228,7 +231,7 @@ __device__ __forceinline__ void conv3x3_tile(const ConvDesc &d)
         if (++is_chunk == cpt) {        // next tap: same channels from the start, the pixel one to the right (or a row down)
             is_chunk = 0;
             ++is_tap;
-            is_a = ((is_tap / KSZ) * d.Win + is_tap % KSZ) * d.Cin * 2;
+            is_a = ((is_tap / KW) * d.Win + is_tap % KW) * d.Cin * 2;
             set_tap();
         }
     };
@@ -340,13 +343,19 @@ __device__ __forceinline__ void conv3x3_tile(const ConvDesc &d)
 
     static_assert((size_t)BM * (BN * 2 + 16) <= (size_t)kCvStages * (A_SLOTS + B_SLOTS) * 16, "epilogue staging does not fit the ring");
     conv_epilogue<BM, BN, NW>(d, acc, a_row, 32 * NB * wn, n0, reinterpret_cast<char *>(smem), tid, lane, cv_probe,
-                              [&](int row) { const int px = m0 + row; return px < d.M ? px : -1; });
+                              [&](int row) {
+                                  const int px = m0 + row;
+                                  if (px >= d.M) return -1;
+                                  if (d.ostep == 0) return px;
+                                  const int n = px / HW, r = px - n * HW, y = r / d.W, x = r - y * d.W;
+                                  return ((n * d.H + y) * d.ostep + d.oy0) * (d.W * d.ostep) + x * d.ostep + d.ox0;
+                              });
 }
 
-template <int WM, int WN, int MB, int NB, int kCvStages, int KS = 3>
+template <int WM, int WN, int MB, int NB, int kCvStages, int KH = 3, int KW = KH>
 __global__ __launch_bounds__(64 * WM * WN) void k_conv3x3(ConvDesc d)
 {
-    conv3x3_tile<WM, WN, MB, NB, kCvStages, KS>(d);
+    conv3x3_tile<WM, WN, MB, NB, kCvStages, KH, KW>(d);
 }
 
 // ---------------------------------------------------------------------------------------- direct variant
@@ -672,7 +681,7 @@ static int conv_plan(int M, int W, int Cout, int kt_total, int &cfg, int &splits
     return 0;
 }
 
-template <int WM, int WN, int MB, int NB, int kCvStages, int KS = 3>
+template <int WM, int WN, int MB, int NB, int kCvStages, int KH = 3, int KW = KH>
 static int conv_launch(const ConvDesc &d, hipStream_t st)
 {
     constexpr int NW = WM * WN, BM = 32 * MB * WM, BN = 32 * NB * WN;
@@ -681,10 +690,10 @@ static int conv_launch(const ConvDesc &d, hipStream_t st)
     const dim3 grid((d.M + BM - 1) / BM, (d.Cout + BN - 1) / BN, d.splits);
     static bool attr_set = false;          // (per instantiation; a second thread repeating the call is harmless)
     if (!attr_set) {
-        DM4D_HIP_CHECK(hipFuncSetAttribute((const void *)k_conv3x3<WM, WN, MB, NB, kCvStages, KS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        DM4D_HIP_CHECK(hipFuncSetAttribute((const void *)k_conv3x3<WM, WN, MB, NB, kCvStages, KH, KW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
-    hipLaunchKernelGGL((k_conv3x3<WM, WN, MB, NB, kCvStages, KS>), grid, dim3(64 * NW), lds, st, d);
+    hipLaunchKernelGGL((k_conv3x3<WM, WN, MB, NB, kCvStages, KH, KW>), grid, dim3(64 * NW), lds, st, d);
     DM4D_HIP_CHECK(hipGetLastError());
     return DM4D_OK;
 }
@@ -742,7 +751,8 @@ int dm4d_conv3x3_strided_nhwc_f16(int32_t N, int32_t Hin, int32_t Win, int32_t C
     if ((((uintptr_t)x | (uintptr_t)w | (uintptr_t)y | (uintptr_t)bias | (uintptr_t)residual) & 15) != 0) { set_error("conv3x3: tensors must be 16-byte aligned"); return DM4D_ERR_INVALID; }
     ConvDesc d;
     d.N = N; d.H = H; d.W = W; d.Cin = Cin; d.Cout = Cout; d.M = N * H * W;
-    d.Hin = Hin; d.Win = Win; d.stride = stride; d.pad = pad;
+    d.Hin = Hin; d.Win = Win; d.stride = stride; d.pad = pad; d.pad_x = pad;
+    d.ostep = 0; d.oy0 = 0; d.ox0 = 0;
     d.x = (const _Float16 *)x; d.w = (const _Float16 *)w; d.bias = (const _Float16 *)bias; d.res = (const _Float16 *)residual;
     d.y = (_Float16 *)y;
     d.kt_total = 9 * Cin / kCvBK;
@@ -845,7 +855,8 @@ int dm4d_linear_f16(int64_t M, int32_t K, int32_t N, const void *x, const void *
     if ((((uintptr_t)x | (uintptr_t)w | (uintptr_t)y | (uintptr_t)bias | (uintptr_t)residual) & 15) != 0) { set_error("linear: tensors must be 16-byte aligned"); return DM4D_ERR_INVALID; }
     ConvDesc d;
     d.N = 1; d.H = 1; d.W = (int)M; d.Cin = K; d.Cout = N; d.M = (int)M;
-    d.Hin = 1; d.Win = (int)M; d.stride = 1; d.pad = 0;
+    d.Hin = 1; d.Win = (int)M; d.stride = 1; d.pad = 0; d.pad_x = 0;
+    d.ostep = 0; d.oy0 = 0; d.ox0 = 0;
     d.x = (const _Float16 *)x; d.w = (const _Float16 *)w; d.bias = (const _Float16 *)bias; d.res = (const _Float16 *)residual;
     d.y = (_Float16 *)y;
     d.kt_total = K / kCvBK;
@@ -869,6 +880,46 @@ int dm4d_linear_f16(int64_t M, int32_t K, int32_t N, const void *x, const void *
         const size_t total = (size_t)d.M * N;
         hipLaunchKernelGGL(k_conv_reduce, dim3((unsigned)((total / 8 + 255) / 256)), dim3(256), 0, st, d);
         DM4D_HIP_CHECK(hipGetLastError());
+    }
+    return DM4D_OK;
+}
+
+// ---------------------------------------------------------------------------------------- data gradient of the stride-2 convolution
+// y[n][oy][ox] = sum_{ky, kx} x[n][2 oy + ky][2 ox + kx] w[ky][kx] (pad 0 + one zero behind each axis: the VAE encoder's Downsample,
+// model.py:85-100) -- dL/dx[iy][ix] gets, per axis, the taps k with (i - k) even: k in {0, 2} for an even coordinate (dy at i / 2 and
+// i / 2 - 1), k = 1 for an odd one.  So the four parity classes (iy & 1, ix & 1) of the input pixels are four STRIDE-1 convolutions
+// of dy with 2 x 2, 2 x 1, 1 x 2 and 1 x 1 filters (padding 1 on a 2-tap axis), each writing every second pixel of every second
+// row of dx: 4 + 2 + 2 + 1 = the forward's nine taps, on the implicit-GEMM kernel (the library's transposed convolution of the
+// padded shape took 100-170 us with its layout copies where the forward takes 36; profiles/r03_zero123.md).
+// w_cls[c]: class c = 2 (iy & 1) + (ix & 1), [C_in][KH][KW][C_out] float16 with tap (ty, tx) = w[:, :, 2 - 2 ty (KH = 2) or 1, 2 - 2 tx or 1]
+// transposed (conv_mfma.pack_weight_s2_dgrad).
+int dm4d_conv3x3_s2_dgrad_nhwc_f16(int32_t N, int32_t Hin, int32_t Win, int32_t Cin, int32_t Cout, const void *dy, const void *const *w_cls,
+                                   void *dx, dm4d_stream_t stream)
+{
+    if (N < 0 || Hin <= 0 || Win <= 0 || Cin <= 0 || Cout <= 0) { set_error("s2 dgrad: bad shape"); return DM4D_ERR_INVALID; }
+    if ((Hin | Win) & 1) { set_error("s2 dgrad: H_in and W_in must be even (got %d x %d)", Hin, Win); return DM4D_ERR_UNSUPPORTED; }
+    if (Cout % kCvBK != 0 || Cin % 32 != 0) { set_error("s2 dgrad: C_in and C_out must be multiples of 32 (got %d, %d)", Cin, Cout); return DM4D_ERR_UNSUPPORTED; }
+    if (N == 0) return DM4D_OK;
+    const int H = Hin / 2, W = Win / 2;
+    if (((int64_t)N * H * W + 2 * W + 2) * Cout * 2 >= 0x7FFF0000LL || (int64_t)Cin * 4 * Cout * 2 >= 0x7FFF0000LL || (int64_t)N * Hin * Win > 0x7FFFFFFF / 4) { set_error("s2 dgrad: tensor too large for a 32-bit buffer descriptor"); return DM4D_ERR_UNSUPPORTED; }
+    if (!dy || !w_cls || !dx || !w_cls[0] || !w_cls[1] || !w_cls[2] || !w_cls[3]) { set_error("s2 dgrad: null tensor"); return DM4D_ERR_INVALID; }
+    if ((((uintptr_t)dy | (uintptr_t)dx | (uintptr_t)w_cls[0] | (uintptr_t)w_cls[1] | (uintptr_t)w_cls[2] | (uintptr_t)w_cls[3]) & 15) != 0) { set_error("s2 dgrad: tensors must be 16-byte aligned"); return DM4D_ERR_INVALID; }
+    hipStream_t st = (hipStream_t)stream;
+    for (int cls = 0; cls < 4; ++cls) {
+        const int py = cls >> 1, px = cls & 1, kh = py ? 1 : 2, kw = px ? 1 : 2;
+        ConvDesc d;
+        d.N = N; d.H = H; d.W = W; d.Cin = Cout; d.Cout = Cin; d.M = N * H * W;       // (the operator's input is dy: its channels are the forward's C_out)
+        d.Hin = H; d.Win = W; d.stride = 1; d.pad = kh - 1; d.pad_x = kw - 1;
+        d.ostep = 2; d.oy0 = py; d.ox0 = px;
+        d.x = (const _Float16 *)dy; d.w = (const _Float16 *)w_cls[cls]; d.bias = nullptr; d.res = nullptr; d.y = (_Float16 *)dx;
+        d.partial = nullptr; d.splits = 1; d.kt_total = kh * kw * Cout / kCvBK; d.kt_per = d.kt_total;
+        d.act = 0; d.probe = 0;
+        int rc;
+        if (kh == 2 && kw == 2) rc = conv_launch<2, 2, 2, 2, 4, 2, 2>(d, st);
+        else if (kh == 2) rc = conv_launch<2, 2, 2, 2, 4, 2, 1>(d, st);
+        else if (kw == 2) rc = conv_launch<2, 2, 2, 2, 4, 1, 2>(d, st);
+        else rc = conv_launch<2, 2, 2, 2, 4, 1, 1>(d, st);
+        if (rc) return rc;
     }
     return DM4D_OK;
 }

@@ -73,6 +73,7 @@ MFMA_LINEAR_MIN_ROWS = int(os.environ.get("DM4D_MFMA_LINEAR_MIN_ROWS", "4096")) 
 FUSE_QKV = os.environ.get("DM4D_FUSE_QKV", "1") != "0"                              # (A/B switch: CrossAttention's one-GEMM q, k, v)
 FUSE_ADD_LAYERNORM = os.environ.get("DM4D_FUSE_ADD_LN", "1") != "0"                 # (A/B switch for BasicTransformerBlock._fused_no_grad)
 BATCH_SMALL_GEMMS = os.environ.get("DM4D_BATCH_SMALL_GEMMS", "1") != "0"      # (A/B switch for UNetModel._batched_small_gemms)
+_USE_MFMA_S2_DGRAD = os.environ.get("DM4D_MFMA_S2_DGRAD", "1") != "0"       # (A/B switch: the stride-2 data gradients of the VAE encoder)
 _USE_MFMA_CONV_S2 = os.environ.get("DM4D_MFMA_CONV_S2", "1") != "0"            # (A/B switch: the stride-2 Downsample convolutions)
 _USE_MFMA_CONV = os.environ.get("DM4D_MFMA_CONV", "1") != "0"      # (A/B switch: "0" keeps every convolution on the library)
 
@@ -123,7 +124,9 @@ def _conv3x3_stride2(conv, x, pad):
         if packed is None or packed[0] != key:
             packed = conv._dm4d_ohwi = [key, conv_mfma.pack_weight(w), None]
         if torch.is_grad_enabled() and x.requires_grad:
-            return conv_mfma.conv3x3_stride2_frozen(x, w, packed[1], conv.bias, pad)
+            if packed[2] is None and _USE_MFMA_S2_DGRAD and pad == 0:
+                packed[2] = conv_mfma.pack_weight_s2_dgrad(w)
+            return conv_mfma.conv3x3_stride2_frozen(x, w, packed[1], conv.bias, pad, packed[2] if pad == 0 else None)
         return conv_mfma.conv3x3(x, packed[1], conv.bias, None, stride=2, pad=pad)
     return conv(x) if pad else conv(F.pad(x, (0, 1, 0, 1)))
 

@@ -561,6 +561,14 @@ int dm4d_conv3x3_nhwc_f16(int32_t N, int32_t H, int32_t W, int32_t Cin, int32_t 
 size_t dm4d_conv3x3_strided_scratch_bytes(int32_t N, int32_t Hin, int32_t Win, int32_t Cin, int32_t Cout, int32_t stride);
 int dm4d_conv3x3_strided_nhwc_f16(int32_t N, int32_t Hin, int32_t Win, int32_t Cin, int32_t Cout, int32_t stride, int32_t pad, const void *x,
                                   const void *w, const void *bias, const void *residual, void *y, void *scratch, dm4d_stream_t stream);
+/* Data gradient of the stride-2 / pad-0 convolution whose input carries one zero row / column behind each axis (the VAE encoder's
+ * Downsample, extern/ldm_zero123/modules/diffusionmodules/model.py:85-100): dx [N,H_in,W_in,C_in] from dy [N,H_in/2,W_in/2,C_out],
+ * NHWC float16, float32 accumulation; H_in, W_in even, C_in and C_out multiples of 32.  The four parity classes of the input
+ * pixels are four stride-1 convolutions of dy (2x2, 2x1, 1x2, 1x1 taps) on the implicit-GEMM kernel, each writing every second
+ * pixel of every second row: w_cls[2 (iy & 1) + (ix & 1)] = [C_in][KH][KW][C_out] with tap (ty, tx) = the forward filter's tap
+ * (2 - 2 ty if KH == 2 else 1, 2 - 2 tx if KW == 2 else 1), transposed (conv_mfma.pack_weight_s2_dgrad). */
+int dm4d_conv3x3_s2_dgrad_nhwc_f16(int32_t N, int32_t Hin, int32_t Win, int32_t Cin, int32_t Cout, const void *dy, const void *const *w_cls,
+                                   void *dx, dm4d_stream_t stream);
 /* y = conv3x3(x, w) from exactly 128 channels to C_out <= 4 (stride 1, padding 1, float16, float32 accumulation, no bias):
  * x [N,H,W,128], w [C_out,3,3,128], y [N,H,W,C_out].  The data gradient of the VAE encoder's first convolution (image <-
  * 128 feature channels, ldm Encoder.conv_in, extern/ldm_zero123/modules/diffusionmodules/model.py:368-371): memory bound,

@@ -139,6 +139,34 @@ def test_stride2_convolution_and_its_frozen_autograd_form(shape, pad):
     assert (x.grad.float() - ref_in.grad).abs().max() <= 2 ** -9 * ref_in.grad.abs().max() + 1e-6
 
 
+@pytest.mark.parametrize("shape", [(2, 32, 32, 64, 64), (1, 64, 48, 128, 96), (3, 16, 16, 320, 320), (2, 10, 14, 32, 64), (4, 256, 256, 128, 128)])
+def test_stride2_data_gradient_on_the_mfma_kernel(shape):
+    """dm4d_conv3x3_s2_dgrad_nhwc_f16 (the VAE Downsample's data gradient as four stride-1 convolutions of dy, one per parity class
+    of the input pixels) against torch's gradient of F.conv2d(F.pad(x, (0, 1, 0, 1)), w, stride 2) in float32; and through the
+    autograd form, which must take this path when handed the packed filters."""
+    _need_gpu()
+    from dreammesh4d_amd import conv_mfma
+
+    N, H, W, Ci, Co = shape
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(H * 5 + Ci)
+    w = (torch.randn(Co, Ci, 3, 3, generator=g) * (9 * Ci) ** -0.5).to(dev).half()
+    gy = torch.randn(N, Co, H // 2, W // 2, generator=g).to(dev).half().contiguous(memory_format=torch.channels_last)
+    ref = torch.nn.grad.conv2d_input((N, Ci, H + 1, W + 1), w.float(), gy.float(), stride=2, padding=0)[:, :, :H, :W]
+    w_cls = conv_mfma.pack_weight_s2_dgrad(w)
+    assert [tuple(t.shape) for t in w_cls] == [(Ci, 2, 2, Co), (Ci, 2, 1, Co), (Ci, 1, 2, Co), (Ci, 1, 1, Co)]
+    dx = conv_mfma.conv3x3_s2_dgrad(gy, w_cls, (N, Ci, H, W))
+    assert dx.shape == (N, Ci, H, W) and dx.is_contiguous(memory_format=torch.channels_last)
+    assert (dx.float() - ref).abs().max() <= 2 ** -9 * ref.abs().max() + 1e-6
+    if N * H * W <= 1 << 16:
+        x = torch.randn(N, Ci, H, W, generator=g).to(dev).half().contiguous(memory_format=torch.channels_last).requires_grad_(True)
+        before = conv_mfma.FLOPS[0]
+        y = conv_mfma.conv3x3_stride2_frozen(x, w, conv_mfma.pack_weight(w), None, 0, w_cls)
+        y.backward(gy)
+        assert conv_mfma.FLOPS[0] - before == 2 * (2 * N * (H // 2) * (W // 2) * Ci * Co * 9)      # forward AND data gradient were tallied: both ran here
+        assert torch.equal(x.grad, dx)
+
+
 LINEAR_SHAPES = [      # (M, K, N): the UNet's token counts x widths, tails, a split-K shape, the 64 x 64 tiles
     (8192, 320, 320), (8192, 320, 960), (8192, 1280, 320), (2048, 640, 1920), (512, 1280, 1280), (512, 5120, 1280), (128, 1280, 1280),
     (200, 64, 72), (1, 32, 8), (333, 96, 200), (130, 3840, 64),
