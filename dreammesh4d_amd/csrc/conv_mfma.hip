@@ -170,7 +170,7 @@ __device__ __forceinline__ void conv3x3_tile(const ConvDesc &d)
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);            // (provably wave-uniform: LDS-DMA bases stay in SGPRs)
     const int wm = wave % WM, wn = wave / WM;
     const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
-    const int kt0 = blockIdx.z * d.kt_per, kt1 = min(d.kt_total, kt0 + d.kt_per);
+    const int kt0 = (d.splits > 1 ? (int)blockIdx.z : 0) * d.kt_per, kt1 = min(d.kt_total, kt0 + d.kt_per);   // (splits == 1: blockIdx.z is the caller's)
     const int HW = d.H * d.W, cpt = d.Cin / kCvBK;                        // k-tiles per tap
     constexpr unsigned kOob = 0x80000000u;                                // a voffset past every descriptor's range: the DMA writes zeros
 
@@ -356,6 +356,25 @@ template <int WM, int WN, int MB, int NB, int kCvStages, int KH = 3, int KW = KH
 __global__ __launch_bounds__(64 * WM * WN) void k_conv3x3(ConvDesc d)
 {
     conv3x3_tile<WM, WN, MB, NB, kCvStages, KH, KW>(d);
+}
+
+// the four parity classes of the stride-2 data gradient in ONE launch (blockIdx.z = class; dm4d_conv3x3_s2_dgrad_nhwc_f16)
+struct S2DgradDesc { ConvDesc d; const _Float16 *w[4]; };
+template <int kUnused>       // (a template like k_conv3x3: the host pass must not instantiate the tile, whose buffer builtins exist on the device only)
+__global__ __launch_bounds__(256) void k_conv_s2_dgrad(S2DgradDesc a)
+{
+    ConvDesc d = a.d;
+    const int cls = blockIdx.z, py = cls >> 1, px = cls & 1, kh = py ? 1 : 2, kw = px ? 1 : 2;
+    d.pad = kh - 1; d.pad_x = kw - 1; d.oy0 = py; d.ox0 = px;
+    d.w = a.w[cls];
+    d.kt_total = d.kt_per = kh * kw * d.Cin / kCvBK;
+    switch (cls) {
+    case 0: conv3x3_tile<2, 2, 2, 2, 4 + kUnused, 2, 2>(d); break;      // (+ kUnused: a DEPENDENT call, instantiated with the kernel)
+    case 1: conv3x3_tile<2, 2, 2, 2, 4 + kUnused, 2, 1>(d); break;
+    case 2: conv3x3_tile<2, 2, 2, 2, 4 + kUnused, 1, 2>(d); break;
+    default: conv3x3_tile<2, 2, 2, 2, 3 + kUnused, 1, 1>(d); break;      // (3-deep: <.., 4, 1, 1> is dm4d_linear_f16's, and the host pass
+                                                                           // rejects a second kernel instantiating the same device-only specialization)
+    }
 }
 
 // ---------------------------------------------------------------------------------------- direct variant
@@ -905,22 +924,20 @@ int dm4d_conv3x3_s2_dgrad_nhwc_f16(int32_t N, int32_t Hin, int32_t Win, int32_t 
     if (!dy || !w_cls || !dx || !w_cls[0] || !w_cls[1] || !w_cls[2] || !w_cls[3]) { set_error("s2 dgrad: null tensor"); return DM4D_ERR_INVALID; }
     if ((((uintptr_t)dy | (uintptr_t)dx | (uintptr_t)w_cls[0] | (uintptr_t)w_cls[1] | (uintptr_t)w_cls[2] | (uintptr_t)w_cls[3]) & 15) != 0) { set_error("s2 dgrad: tensors must be 16-byte aligned"); return DM4D_ERR_INVALID; }
     hipStream_t st = (hipStream_t)stream;
-    for (int cls = 0; cls < 4; ++cls) {
-        const int py = cls >> 1, px = cls & 1, kh = py ? 1 : 2, kw = px ? 1 : 2;
-        ConvDesc d;
-        d.N = N; d.H = H; d.W = W; d.Cin = Cout; d.Cout = Cin; d.M = N * H * W;       // (the operator's input is dy: its channels are the forward's C_out)
-        d.Hin = H; d.Win = W; d.stride = 1; d.pad = kh - 1; d.pad_x = kw - 1;
-        d.ostep = 2; d.oy0 = py; d.ox0 = px;
-        d.x = (const _Float16 *)dy; d.w = (const _Float16 *)w_cls[cls]; d.bias = nullptr; d.res = nullptr; d.y = (_Float16 *)dx;
-        d.partial = nullptr; d.splits = 1; d.kt_total = kh * kw * Cout / kCvBK; d.kt_per = d.kt_total;
-        d.act = 0; d.probe = 0;
-        int rc;
-        if (kh == 2 && kw == 2) rc = conv_launch<2, 2, 2, 2, 4, 2, 2>(d, st);
-        else if (kh == 2) rc = conv_launch<2, 2, 2, 2, 4, 2, 1>(d, st);
-        else if (kw == 2) rc = conv_launch<2, 2, 2, 2, 4, 1, 2>(d, st);
-        else rc = conv_launch<2, 2, 2, 2, 4, 1, 1>(d, st);
-        if (rc) return rc;
-    }
+    S2DgradDesc a;
+    ConvDesc &d = a.d;
+    d.N = N; d.H = H; d.W = W; d.Cin = Cout; d.Cout = Cin; d.M = N * H * W;       // (the operator's input is dy: its channels are the forward's C_out)
+    d.Hin = H; d.Win = W; d.stride = 1; d.pad = 1; d.pad_x = 1;                    // (pad, output offset, filter, k-tiles: per class, in the kernel)
+    d.ostep = 2; d.oy0 = 0; d.ox0 = 0;
+    d.x = (const _Float16 *)dy; d.w = nullptr; d.bias = nullptr; d.res = nullptr; d.y = (_Float16 *)dx;
+    d.partial = nullptr; d.splits = 1; d.kt_total = d.kt_per = 0;
+    d.act = 0; d.probe = 0;
+    for (int c = 0; c < 4; ++c) a.w[c] = (const _Float16 *)w_cls[c];
+    constexpr size_t lds = (size_t)4 * (2 + 2) * 256 * 16;                          // the 128 x 128 x 4-deep ring of conv_launch<2, 2, 2, 2, 4>
+    static bool attr_set = false;
+    if (!attr_set) { DM4D_HIP_CHECK(hipFuncSetAttribute((const void *)k_conv_s2_dgrad<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr_set = true; }
+    hipLaunchKernelGGL(k_conv_s2_dgrad<0>, dim3((d.M + 127) / 128, (Cin + 127) / 128, 4), dim3(256), lds, st, a);
+    DM4D_HIP_CHECK(hipGetLastError());
     return DM4D_OK;
 }
 
