@@ -70,6 +70,9 @@ VAE_ATTENTION_BMM = os.environ.get("DM4D_VAE_ATTN_BMM", "1") != "0"             
 # that is the 32 x 32 level (M = 8192 rows: q/k/v 18.7 -> 14 us, attention output + residual 13.7 -> 10.3, GEGLU projection 52.5 ->
 # 39.5, proj_out + residual 13.7 -> ~9); at M <= 2048 hipBLASLt's kernels are as fast or faster and stay.
 MFMA_LINEAR_MIN_ROWS = int(os.environ.get("DM4D_MFMA_LINEAR_MIN_ROWS", "4096"))      # (A/B switch: a huge value = library everywhere)
+# ... and the projections with a RESIDUAL (attention output, proj_out) from 512 rows on: the fused epilogue replaces the library GEMM + an
+# add launch (or its prepared C operand): 2048 x 640 -> 640: 7.9 us against 12.0, 512 x 1280 -> 1280: 10.5 against 11.4 + the add
+MFMA_LINEAR_RES_MIN_ROWS = int(os.environ.get("DM4D_MFMA_LINEAR_RES_MIN_ROWS", "512"))
 FUSE_QKV = os.environ.get("DM4D_FUSE_QKV", "1") != "0"                              # (A/B switch: CrossAttention's one-GEMM q, k, v)
 FUSE_ADD_LAYERNORM = os.environ.get("DM4D_FUSE_ADD_LN", "1") != "0"                 # (A/B switch for BasicTransformerBlock._fused_no_grad)
 BATCH_SMALL_GEMMS = os.environ.get("DM4D_BATCH_SMALL_GEMMS", "1") != "0"      # (A/B switch for UNetModel._batched_small_gemms)
@@ -289,22 +292,29 @@ class BasicTransformerBlock(nn.Module):
 
     def _fused_no_grad(self, x, context):
         """The block without gradients on a HIP device, float16, one context token: the same sums as `forward`, but the residual
-        adds ride in the GEMMs (`addmm`: C operand = residual + that GEMM's bias) and the LayerNorms come from the kernel that
-        also prepares that operand (fused_norm.add_layer_norm): per block 2 launches instead of 2 LayerNorms + 3 adds."""
+        adds ride in the GEMMs -- the epilogue of the MFMA kernel (conv_mfma.linear: bias + residual, GEGLU) where that is the
+        faster one (MFMA_LINEAR_*_MIN_ROWS), else the library's `addmm` with C operand = residual + that GEMM's bias -- and the
+        LayerNorms come from the kernel that also prepares that operand (fused_norm.add_layer_norm): per block 2 launches
+        instead of 2 LayerNorms + 3 adds."""
         B, L, Cc = x.shape
         out1, ff1, ff2 = self.attn1.to_out[0], self.ff.net[0].proj, self.ff.net[2]
-        own = B * L >= MFMA_LINEAR_MIN_ROWS and conv_mfma.linear_supported(x, out1.weight) and ff1.out_features % 256 == 0
+        ok = conv_mfma.linear_supported(x, out1.weight)
+        own_res = ok and B * L >= MFMA_LINEAR_RES_MIN_ROWS                                 # attention output + residual on the MFMA kernel
+        own_big = ok and B * L >= MFMA_LINEAR_MIN_ROWS and ff1.out_features % 256 == 0     # ... and the GEGLU projection (q/k/v: attend)
         tok = self.attn2.single_token(context)                                            # [B, 1, C]: the whole cross-attention
-        if own:        # the MFMA kernel: bias and residual in the epilogue (no prepared C operand), GEGLU in the epilogue
+        if own_res:    # the MFMA kernel: bias and residual in the epilogue (no prepared C operand)
             n1, _ = add_layer_norm(self.norm1, x, None, None, want_sum=False)
             o = self.attn1.attend(n1, n1)
             x1 = conv_mfma.linear(o, out1.weight, out1.bias, residual=x)                  # attn1(norm1(x)) + x
             n3, x2b = add_layer_norm(self.norm3, x1, tok, ff2.bias)                       # norm3(x1 + tok) | x1 + tok + b_ff
-            key = (ff1.weight.data_ptr(), ff1.weight._version, ff1.bias._version)
-            pk = self.__dict__.get("_geglu_packed")
-            if pk is None or pk[0] != key:
-                pk = self.__dict__["_geglu_packed"] = (key,) + conv_mfma.pack_geglu(ff1.weight, ff1.bias)
-            g = conv_mfma.linear(n3, pk[1], pk[2], act="geglu")
+            if own_big:                                                                   # GEGLU in the projection's epilogue
+                key = (ff1.weight.data_ptr(), ff1.weight._version, ff1.bias._version)
+                pk = self.__dict__.get("_geglu_packed")
+                if pk is None or pk[0] != key:
+                    pk = self.__dict__["_geglu_packed"] = (key,) + conv_mfma.pack_geglu(ff1.weight, ff1.bias)
+                g = conv_mfma.linear(n3, pk[1], pk[2], act="geglu")
+            else:
+                g = self.ff.net[0](n3)
             return x2b.view(-1, Cc).addmm_(g.view(B * L, -1), ff2.weight.t()).view(B, L, Cc)      # ff(norm3(x2)) + x2
         n1, xb = add_layer_norm(self.norm1, x, None, out1.bias)                           # norm1(x) | x + b_out
         o = self.attn1.attend(n1, n1)
@@ -346,7 +356,7 @@ class SpatialTransformer(nn.Module):
         for blk in self.transformer_blocks:
             h = blk(h, context)
         w = self.proj_out.weight
-        if (h.is_cuda and B * Hh * Ww >= MFMA_LINEAR_MIN_ROWS and not torch.is_grad_enabled() and h.is_contiguous() and h.dtype == torch.float16
+        if (h.is_cuda and B * Hh * Ww >= MFMA_LINEAR_RES_MIN_ROWS and not torch.is_grad_enabled() and h.is_contiguous() and h.dtype == torch.float16
                 and is_channels_last(x) and x.dtype == torch.float16 and not w.requires_grad and conv_mfma.linear_supported(h, w.flatten(1))):
             # proj_out + bias + the residual in one launch (tokens [B, HW, C] and NHWC pixels are the same memory)
             y = conv_mfma.linear(h, w.flatten(1), self.proj_out.bias, residual=x.permute(0, 2, 3, 1).reshape(B, Hh * Ww, Cc))
