@@ -99,6 +99,37 @@ def linear(x, w, bias=None, residual=None, act=None):
     return y
 
 
+def narrow_supported(x, w):
+    """A 3x3 convolution whose channel counts are NOT multiples of 32 (the ends of both networks: 8 -> 320 and 320 -> 4 in the UNet,
+    3 -> 128 and 512 -> 8 in the VAE encoder): run on the same kernel with the channels zero-padded to the next multiple of 32."""
+    return (x.is_cuda and x.dtype == torch.float16 and x.dim() == 4 and x.is_contiguous(memory_format=torch.channels_last)
+            and w.dim() == 4 and tuple(w.shape[2:]) == (3, 3) and w.dtype == torch.float16 and w.shape[1] == x.shape[1]
+            and (x.shape[1] % 32 != 0 or w.shape[0] % 32 != 0) and x.shape[0] > 0)
+
+
+def pad_weight(w, bias=None):
+    """(w [C_out', C_in', 3, 3] zero-padded to multiples of 32, bias [C_out'] or None): the padded taps / filters contribute exact
+    zeros, so conv(pad_channels(x), pad_weight(w))[:, :C_out] is the convolution."""
+    Co, Ci = int(w.shape[0]), int(w.shape[1])
+    Cop, Cip = -(-Co // 32) * 32, -(-Ci // 32) * 32
+    wp = torch.zeros((Cop, Cip, 3, 3), dtype=w.dtype, device=w.device)
+    wp[:Co, :Ci] = w.detach()
+    bp = None
+    if bias is not None:
+        bp = torch.zeros(Cop, dtype=bias.dtype, device=bias.device)
+        bp[:Co] = bias.detach()
+    return wp, bp
+
+
+def pad_channels(x, C):
+    """x [N, C', H, W] channels_last -> [N, C, H, W] channels_last with zeros in the new channels (differentiable: a slice assignment)."""
+    if x.shape[1] == C:
+        return x
+    y = torch.zeros((x.shape[0], C, x.shape[2], x.shape[3]), dtype=x.dtype, device=x.device).contiguous(memory_format=torch.channels_last)
+    y[:, :x.shape[1]] = x
+    return y
+
+
 def pack_weight_transposed(w):
     """The filter of the DATA GRADIENT: dL/dx = conv3x3(dL/dy, w') with w'[ci][ky][kx][co] = w[co][2 - ky][2 - kx][ci]
     (stride 1, padding 1): [C_in, 3, 3, C_out] contiguous."""
@@ -134,15 +165,17 @@ class _ConvFirstFrozen(torch.autograd.Function):
     filter: memory bound, where the library's grouped-convolution kernel took 0.5 ms of the 13 ms SDS step)."""
 
     @staticmethod
-    def forward(ctx, x, w, b, w_t):
+    def forward(ctx, x, w, b, w_t, w_pad=None, b_pad=None):
         ctx.save_for_backward(w_t)
+        if w_pad is not None:        # on the MFMA kernel with the image's channels zero-padded to 32 (pad_weight: [128, 3, 3, 32])
+            return conv3x3(pad_channels(x.detach(), int(w_pad.shape[3])), w_pad, b_pad)
         return torch.nn.functional.conv2d(x, w, b, 1, 1)
 
     @staticmethod
     def backward(ctx, dy):
         (w_t,) = ctx.saved_tensors
         if not ctx.needs_input_grad[0]:
-            return None, None, None, None
+            return None, None, None, None, None, None
         if not dy.is_contiguous(memory_format=torch.channels_last):
             dy = dy.contiguous(memory_format=torch.channels_last)
         N, C, H, W = dy.shape
@@ -152,7 +185,7 @@ class _ConvFirstFrozen(torch.autograd.Function):
         with torch.cuda.device(dy.device):
             _lib.check(_lib.lib().dm4d_conv3x3_c128_small_nhwc_f16(N, H, W, Ci, dy.data_ptr(), w_t.data_ptr(), dx.data_ptr(),
                                                                    torch.cuda.current_stream(dy.device).cuda_stream), "dm4d_conv3x3_c128_small_nhwc_f16")
-        return dx, None, None, None
+        return dx, None, None, None, None, None
 
 
 def first_conv_supported(x, w):
@@ -160,9 +193,10 @@ def first_conv_supported(x, w):
             and w.shape[0] == 128 and 1 <= w.shape[1] <= 4 and x.shape[1] == w.shape[1])
 
 
-def conv3x3_first_frozen(x, w, b, w_t):
-    """x [N, C<=4, H, W] -> [N, 128, H, W]; w_t = pack_weight_transposed(w) ([C, 3, 3, 128])."""
-    return _ConvFirstFrozen.apply(x, w, b, w_t)
+def conv3x3_first_frozen(x, w, b, w_t, w_pad=None, b_pad=None):
+    """x [N, C<=4, H, W] -> [N, 128, H, W]; w_t = pack_weight_transposed(w) ([C, 3, 3, 128]); w_pad / b_pad: pack_weight(pad_weight(w, b))
+    for the forward on the MFMA kernel (None: the library's)."""
+    return _ConvFirstFrozen.apply(x, w, b, w_t, w_pad, b_pad)
 
 
 def pack_weight_s2_dgrad(w):

@@ -76,6 +76,7 @@ MFMA_LINEAR_RES_MIN_ROWS = int(os.environ.get("DM4D_MFMA_LINEAR_RES_MIN_ROWS", "
 FUSE_QKV = os.environ.get("DM4D_FUSE_QKV", "1") != "0"                              # (A/B switch: CrossAttention's one-GEMM q, k, v)
 FUSE_ADD_LAYERNORM = os.environ.get("DM4D_FUSE_ADD_LN", "1") != "0"                 # (A/B switch for BasicTransformerBlock._fused_no_grad)
 BATCH_SMALL_GEMMS = os.environ.get("DM4D_BATCH_SMALL_GEMMS", "1") != "0"      # (A/B switch for UNetModel._batched_small_gemms)
+_USE_MFMA_CONV_NARROW = os.environ.get("DM4D_MFMA_CONV_NARROW", "1") != "0"  # (A/B switch: the 3- / 4- / 8-channel convolutions on zero-padded channels)
 _USE_MFMA_S2_DGRAD = os.environ.get("DM4D_MFMA_S2_DGRAD", "1") != "0"       # (A/B switch: the stride-2 data gradients of the VAE encoder)
 _USE_MFMA_CONV_S2 = os.environ.get("DM4D_MFMA_CONV_S2", "1") != "0"            # (A/B switch: the stride-2 Downsample convolutions)
 _USE_MFMA_CONV = os.environ.get("DM4D_MFMA_CONV", "1") != "0"      # (A/B switch: "0" keeps every convolution on the library)
@@ -91,6 +92,20 @@ def _conv3x3(conv, x, bias=True, residual=None):
 
     w = conv.weight
     frozen = not (w.requires_grad or (conv.bias is not None and conv.bias.requires_grad))
+    if (_USE_MFMA_CONV and _USE_MFMA_CONV_NARROW and frozen and residual is None and bias and conv.stride == (1, 1) and conv.padding == (1, 1)
+            and conv.dilation == (1, 1) and conv.groups == 1 and conv_mfma.narrow_supported(x, w)):
+        # 3 / 4 / 8 channels on one side (the ends of both networks): the same kernel on zero-padded channels
+        key = (w.data_ptr(), w._version, None if conv.bias is None else conv.bias._version)
+        packed = getattr(conv, "_dm4d_narrow", None)
+        if packed is None or packed[0] != key:
+            wp, bp = conv_mfma.pad_weight(w, conv.bias)
+            packed = conv._dm4d_narrow = (key, conv_mfma.pack_weight(wp), bp, conv_mfma.pack_weight_transposed(wp))
+        xp = conv_mfma.pad_channels(x, int(packed[1].shape[3]))
+        if torch.is_grad_enabled() and x.requires_grad:
+            y = conv_mfma.conv3x3_frozen(xp, packed[1], packed[3], packed[2], None)
+        else:
+            y = conv_mfma.conv3x3(xp, packed[1], packed[2])
+        return y[:, :w.shape[0]]
     if (_USE_MFMA_CONV and frozen and conv.stride == (1, 1) and conv.padding == (1, 1) and conv.dilation == (1, 1) and conv.groups == 1
             and conv_mfma.supported(x, w) and (residual is None or (residual.dtype == x.dtype and residual.shape[1] == w.shape[0]))):
         need_grad = torch.is_grad_enabled() and (x.requires_grad or (residual is not None and residual.requires_grad))
@@ -374,6 +389,8 @@ class _Seq(nn.Sequential):
                 x = layer(x, emb)
             elif isinstance(layer, SpatialTransformer):
                 x = layer(x, context)
+            elif isinstance(layer, nn.Conv2d) and layer.kernel_size == (3, 3) and layer.stride == (1, 1):
+                x = _conv3x3(layer, x)                    # (conv_in: 8 -> 320 channels)
             else:
                 x = layer(x)
         return x
@@ -486,7 +503,7 @@ class UNetModel(nn.Module):
                     b.__dict__.pop("_emb_add", None)
                 for a in touched[1]:
                     a.__dict__.pop("_tok", None)
-        h = self.out[2](group_norm(self.out[0], h.type(x.dtype), silu=True, float32=True))
+        h = _conv3x3(self.out[2], group_norm(self.out[0], h.type(x.dtype), silu=True, float32=True))
         return h.contiguous()
 
 
@@ -577,11 +594,12 @@ class VaeEncoder(nn.Module):
         c = self.conv_in
         if (_USE_MFMA_CONV and torch.is_grad_enabled() and x.requires_grad and not c.weight.requires_grad and not c.bias.requires_grad
                 and is_channels_last(x) and conv_mfma.first_conv_supported(x, c.weight)):
-            key = (c.weight.data_ptr(), c.weight._version)
+            key = (c.weight.data_ptr(), c.weight._version, c.bias._version)
             packed = getattr(c, "_dm4d_wt", None)
             if packed is None or packed[0] != key:
-                packed = c._dm4d_wt = (key, conv_mfma.pack_weight_transposed(c.weight))
-            return conv_mfma.conv3x3_first_frozen(x, c.weight, c.bias, packed[1])
+                wp, bp = conv_mfma.pad_weight(c.weight, c.bias) if _USE_MFMA_CONV_NARROW else (None, None)
+                packed = c._dm4d_wt = (key, conv_mfma.pack_weight_transposed(c.weight), None if wp is None else conv_mfma.pack_weight(wp), bp)
+            return conv_mfma.conv3x3_first_frozen(x, c.weight, c.bias, packed[1], packed[2], packed[3])
         return c(x)
 
     def forward(self, x):
@@ -592,7 +610,7 @@ class VaeEncoder(nn.Module):
             if hasattr(lvl, "downsample"):
                 h = lvl.downsample(h)
         h = self.mid.block_2(self.mid.attn_1(self.mid.block_1(h)))
-        return self.conv_out(group_norm(self.norm_out, h, silu=True)).contiguous()
+        return _conv3x3(self.conv_out, group_norm(self.norm_out, h, silu=True)).contiguous()
 
 
 class FirstStage(nn.Module):

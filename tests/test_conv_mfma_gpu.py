@@ -230,3 +230,33 @@ def test_linear_rejects_what_it_does_not_support():
         conv_mfma.linear(torch.zeros(4, 64, device=dev, dtype=torch.float16), torch.zeros(12, 64, device=dev, dtype=torch.float16))   # N % 8
     with pytest.raises(ValueError):
         conv_mfma.linear(torch.zeros(4, 64, device=dev, dtype=torch.float16).t().contiguous().t(), torch.zeros(8, 64, device=dev, dtype=torch.float16))
+
+
+@pytest.mark.parametrize("N,H,W,Ci,Co,grad", [(2, 32, 32, 8, 320, False), (2, 32, 32, 320, 4, False), (2, 16, 24, 512, 8, True), (1, 64, 64, 3, 128, False)])
+def test_narrow_convolutions_on_zero_padded_channels(N, H, W, Ci, Co, grad):
+    """The convolutions at the ends of the UNet (8 -> 320, 320 -> 4) and of the VAE encoder (3 -> 128, 512 -> 8) through
+    zero123._conv3x3: the MFMA kernel on channels zero-padded to 32, sliced back -- against torch in float32; with a frozen filter
+    and a gradient on the input, the data gradient too (the VAE's conv_out: the image is differentiated through it)."""
+    _need_gpu()
+    from dreammesh4d_amd import conv_mfma, zero123 as z
+
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(Ci * 3 + Co)
+    conv = torch.nn.Conv2d(Ci, Co, 3, padding=1).to(dev, torch.float16).requires_grad_(False)
+    with torch.no_grad():
+        conv.weight.copy_((torch.randn(Co, Ci, 3, 3, generator=g) * (9 * Ci) ** -0.5).to(dev))
+        conv.bias.copy_(torch.randn(Co, generator=g).to(dev))
+    x = torch.randn(N, Ci, H, W, generator=g).to(dev).half().contiguous(memory_format=torch.channels_last).requires_grad_(grad)
+    before = conv_mfma.FLOPS[0]
+    with torch.enable_grad() if grad else torch.no_grad():
+        y = z._conv3x3(conv, x)
+    assert conv_mfma.FLOPS[0] > before, "the convolution did not run on the MFMA kernel"
+    x32 = x.detach().float().requires_grad_(grad)
+    ref = F.conv2d(x32, conv.weight.float(), conv.bias.float(), 1, 1)
+    assert y.shape == ref.shape
+    assert (y.float() - ref).abs().max() <= 2 ** -9 * ref.abs().max() + 1e-6
+    if grad:
+        gy = torch.randn(ref.shape, generator=g).to(dev).half()
+        y.backward(gy)
+        ref.backward(gy.float())
+        assert (x.grad.float() - x32.grad).abs().max() <= 2 ** -9 * x32.grad.abs().max() + 1e-6
