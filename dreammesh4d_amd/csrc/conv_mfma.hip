@@ -498,6 +498,7 @@ __device__ __forceinline__ void conv3x3_direct_tile(const ConvDesc &d, int chunk
     // fragments of half step ks of tap TAP from patch buffer at byte address `pbase`, filter stage TAP % 3
     auto read = [&](auto KS, auto TAP, unsigned pbase) {
         constexpr int ks = decltype(KS)::value, tap = decltype(TAP)::value, dyi = tap / 3, dx = tap % 3 - 1;
+        if (CV_PROBE(64)) return;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int q = qa[i][dyi] + dx;
@@ -540,7 +541,7 @@ __device__ __forceinline__ void conv3x3_direct_tile(const ConvDesc &d, int chunk
         // k-tile + 1's filters (and every patch piece issued before them) have landed
         if (more) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(dir_in_flight(tap, true, kDirPieces, kDirAhead)) : "memory");
         else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(dir_in_flight(tap, false, kDirPieces, kDirAhead)) : "memory");
-        __builtin_amdgcn_s_barrier();
+        if (!CV_PROBE(32)) __builtin_amdgcn_s_barrier();
         if (tap < kDirPieces && more) issue_patch(tap, (ch + 1) & 1, ch + 1);
         if (tap + kDirAhead < 9) issue_b(tap + kDirAhead, (tap + kDirAhead) % kDirRing, ch);
         else if (more) issue_b(tap + kDirAhead - 9, (tap + kDirAhead - 9) % kDirRing, ch + 1);

@@ -12,10 +12,10 @@ for (N,H,Ci,Co) in SH:
     w = (torch.randn(Co, Ci, 3, 3, device=dev, dtype=torch.float16) * 0.02)
     pw = conv_mfma.pack_weight(w)
     fl = 2.0*N*H*H*Ci*Co*9
-    for cfg in (3, 7, 9):
+    for cfg in [int(c) for c in os.environ.get('CFGS', '3,7,9').split(',')]:
         os.environ["DM4D_CONV_CFG"] = str(cfg)
         row = []
-        for probe in (0,):
+        for probe in [int(c) for c in os.environ.get('PROBES', '0').split(',')]:
             os.environ["DM4D_CONV_PROBE"] = str(probe)
             for _ in range(3): conv_mfma.conv3x3(x, pw)
             torch.cuda.synchronize()
