@@ -113,3 +113,36 @@ def test_blocked_triangular_inverse_of_the_dense_graph_solver():
         Li = _tri_inverse(Lc, nb=nb)
         assert float((Li @ Lc - torch.eye(n, dtype=torch.float64)).abs().max()) < 1e-12
         assert float(torch.triu(Li, 1).abs().max()) == 0.0
+
+
+def test_round3_entry_points_validate_on_the_host():
+    """dm4d_linear_f16, dm4d_conv3x3_s2_dgrad_nhwc_f16, dm4d_quat_to_matrix_* reject what they do not take before any launch (no GPU
+    needed): the error codes of include/dm4d.h and a message in dm4d_last_error; an empty problem is DM4D_OK."""
+    import ctypes as C
+
+    L = _lib.lib()
+    buf = (C.c_float * 256)()
+    p = C.cast(buf, C.c_void_p)                                   # (16-byte aligned: ctypes arrays of this size are)
+    assert p.value % 16 == 0
+    # linear: K % 32, N % 8, GEGLU's N % 128 / no residual, act range, null, empty
+    assert L.dm4d_linear_f16(4, 48, 8, p, p, None, None, p, 0, None, None) == -4 and b"multiple of 32" in L.dm4d_last_error()
+    assert L.dm4d_linear_f16(4, 64, 12, p, p, None, None, p, 0, None, None) == -4
+    assert L.dm4d_linear_f16(4, 64, 64, p, p, None, None, p, 1, None, None) == -4 and b"GEGLU" in L.dm4d_last_error()
+    assert L.dm4d_linear_f16(4, 64, 128, p, p, None, p, p, 1, None, None) == -4
+    assert L.dm4d_linear_f16(4, 64, 64, p, p, None, None, p, 2, None, None) == -1
+    assert L.dm4d_linear_f16(4, 64, 64, None, p, None, None, p, 0, None, None) == -1
+    assert L.dm4d_linear_f16(4, 64, 64, C.c_void_p(p.value + 2), p, None, None, p, 0, None, None) == -1 and b"aligned" in L.dm4d_last_error()
+    assert L.dm4d_linear_f16(0, 64, 64, None, None, None, None, None, 0, None, None) == 0
+    assert L.dm4d_linear_scratch_bytes(8192, 320, 320) == 256                                   # 192 tiles of 128 x 128 / 768 of 64 x 64: no split
+    assert L.dm4d_linear_scratch_bytes(512, 5120, 1280) == 5 * 512 * 1280 * 4 + 256            # 40 tiles, 160 k-tiles: 160 / 30
+    # stride-2 data gradient: even sizes, channel multiples, the four filters
+    w4 = (C.c_void_p * 4)(p, p, p, p)
+    assert L.dm4d_conv3x3_s2_dgrad_nhwc_f16(1, 15, 16, 32, 32, p, w4, p, None) == -4 and b"even" in L.dm4d_last_error()
+    assert L.dm4d_conv3x3_s2_dgrad_nhwc_f16(1, 16, 16, 24, 32, p, w4, p, None) == -4
+    assert L.dm4d_conv3x3_s2_dgrad_nhwc_f16(1, 16, 16, 32, 32, p, (C.c_void_p * 4)(p, p, None, p), p, None) == -1
+    assert L.dm4d_conv3x3_s2_dgrad_nhwc_f16(0, 16, 16, 32, 32, None, None, None, None) == 0
+    # quaternion -> matrix
+    assert L.dm4d_quat_to_matrix_forward(-1, p, p, None) == -1
+    assert L.dm4d_quat_to_matrix_forward(4, None, p, None) == -1
+    assert L.dm4d_quat_to_matrix_backward_pypose(4, p, p, None, None) == -1
+    assert L.dm4d_quat_to_matrix_forward(0, None, None, None) == 0 and L.dm4d_quat_to_matrix_backward_pypose(0, None, None, None, None) == 0
