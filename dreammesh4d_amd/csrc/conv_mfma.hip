@@ -843,7 +843,7 @@ static void linear_plan(int64_t M, int N, int kt_total, int act, int &cfg, int &
     const long tiles128 = (long)((M + 127) / 128) * ((N + 127) / 128);
     // (tools/linear_tune.py: the 64 x 64 tiles win while the 128 x 128 ones would leave CUs idle -- unless K is long, where the larger
     // tile's fewer operand fetches matter more)
-    cfg = (act != 1 && tiles128 < 200 && (kt_total <= 24 || (tiles128 < 96 && kt_total < 80))) ? 13 : 3;      // (K >= 2560: 128 x 128 + split K)
+    cfg = (act != 1 && tiles128 < 200 && (kt_total <= 24 || (tiles128 < 96 && !(tiles128 >= 32 && kt_total >= 128)))) ? 13 : 3;      // (K >= 4096 on >= 32 tiles: 128 x 128 + split K)
     if (const char *force = getenv("DM4D_LIN_CFG")) { const int f = atoi(force); if (act != 1 || f == 3) cfg = f; }
     const int B = cfg == 13 ? 64 : 128;
     const long tiles = (long)((M + B - 1) / B) * ((N + B - 1) / B);
