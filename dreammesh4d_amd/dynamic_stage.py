@@ -122,7 +122,8 @@ class DynamicStage:
                 "ref_idx": T(ref_idx, torch.int64), "rnd_idx": T(rnd_idx, torch.int64), "n_ref": len(ref_idx), "n_rnd": len(rnd_idx),
                 "frames_t_idx": T(frames, torch.int64), "fidx_ref": T([fidx[i] for i in ref_idx], torch.int64),
                 "fidx_rnd": T([fidx[i] for i in rnd_idx], torch.int64),
-                "elev_rnd": T([elev[i] for i in rnd_idx], torch.float32), "azim_rnd": T([azim[i] for i in rnd_idx], torch.float32)}
+                "elev_rnd": torch.tensor([elev[i] for i in rnd_idx], dtype=torch.float32),        # (host tensors: see iteration())
+                "azim_rnd": torch.tensor([azim[i] for i in rnd_idx], dtype=torch.float32)}
 
     def inter_frame_arap(self):
         """ARAP energy at `num_inter_frames` timestamps of a random window of length `length_inter_frames`
@@ -162,15 +163,20 @@ class DynamicStage:
                            self.bg6, frame_index=u)
         rgb = out["color"][:, :3].clamp(0, 1).permute(0, 2, 3, 1)          # "render": clamp(0,1) (…temporal.py:229)
         mask = out["alpha"].permute(0, 2, 3, 1)
-        loss = rgb.sum() * 0.0
+        # (index_select, not `x[idx]`: the same rows, but a gather whose backward is ONE index_add launch -- advanced indexing
+        # differentiates through a sort-based index_put: six launches per use, three uses per iteration.  The loss starts as the
+        # number 0: `rgb.sum() * 0.0` was a full-resolution reduction forward and a full-resolution fill backward for nothing.)
+        loss = 0.0
         terms = {}
         if b["n_ref"]:
             ref = b["ref_idx"]
-            terms["rgb"] = F.mse_loss(self.ref_images[b["fidx_ref"]], rgb[ref])     # unmasked: colour outside the silhouette is penalised
-            terms["mask"] = F.mse_loss(mask[ref], self.ref_masks[b["fidx_ref"]])
+            terms["rgb"] = F.mse_loss(self.ref_images.index_select(0, b["fidx_ref"]), rgb.index_select(0, ref))     # unmasked: colour outside the silhouette is penalised
+            terms["mask"] = F.mse_loss(mask.index_select(0, ref), self.ref_masks.index_select(0, b["fidx_ref"]))
             loss = loss + self.lam["rgb"] * terms["rgb"] + C(self.lam["mask"], 0, it) * terms["mask"]
         if self.guidance is not None and b["n_rnd"]:
-            g = self.guidance(rgb[b["rnd_idx"]], b["elev_rnd"], b["azim_rnd"], torch.full_like(b["elev_rnd"], 3.8),
+            # elevation / azimuth stay on the HOST (they only feed the four-number camera embedding of get_cond: a dozen
+            # elementwise launches on 4-element device tensors otherwise)
+            g = self.guidance(rgb.index_select(0, b["rnd_idx"]), b["elev_rnd"], b["azim_rnd"], torch.full_like(b["elev_rnd"], 3.8),
                               frame_indices=b["fidx_rnd"])
             terms["sds"] = g["loss_sds"]
             loss = loss + C(self.lam["sds_zero123"], 0, it) * g["loss_sds"]
@@ -184,6 +190,8 @@ class DynamicStage:
             if self.inter_frame_reg > 0 and it % self.inter_frame_reg == 0:
                 terms["arap_reg_inter_frame"] = self.inter_frame_arap()
                 loss = loss + C(self.lam["arap_reg_inter_frame"], 0, it) * terms["arap_reg_inter_frame"]
+        if not torch.is_tensor(loss):                   # (no term applied: nothing to differentiate, but the step's contract is a backward)
+            loss = rgb.sum() * 0.0
         loss.backward()
         # A forward that overflowed its duplicate / record capacity rendered a wrong image: the optimiser step is skipped ON
         # THE DEVICE (found_inf, as a GradScaler would; no host sync), on EVERY rank (MAX over the ranks of the flag: the

@@ -774,7 +774,9 @@ class TemporalStableZero123Guidance(nn.Module):
                          torch.sin(torch.deg2rad(azimuth - self.cond_azimuth_deg)),
                          torch.cos(torch.deg2rad(azimuth - self.cond_azimuth_deg)),
                          torch.deg2rad(90 - torch.full_like(elevation, self.cond_elevation_deg))], dim=-1)[:, None, :]
-        T = T.to(dev, self.weights_dtype)
+        # (elevation / azimuth may be HOST tensors -- DynamicStage keeps them there: the four numbers are then computed on the host
+        # and uploaded once, without blocking: a pageable synchronous copy would wait for everything queued on the stream)
+        T = T.to(self.weights_dtype).to(dev, non_blocking=True) if T.device.type == "cpu" else T.to(dev, self.weights_dtype)
         idx = frame_indices if frame_indices is not None else torch.zeros(len(T), dtype=torch.long, device=dev)
         clip_emb = self.model.cc_projection(torch.cat([self.c_crossattn[idx], T], dim=-1))
         return {"c_crossattn": [torch.cat([torch.zeros_like(clip_emb), clip_emb], dim=0)],
