@@ -51,8 +51,8 @@ class DynamicStage:
         self.timestamps = timestamps                     # [L] in (0,1)
         # [L,H,W,3], [L,H,W,1]; the reference's gt image is composited on white outside the mask
         # (data/temporal_image.py:201-202) and the dynamic step compares it UNMASKED (system/sugar_4dgen.py:164-167)
-        self.ref_masks = ref_masks
-        self.ref_images = ref_images * ref_masks + (1.0 - ref_masks)
+        self.ref_masks = ref_masks.contiguous()
+        self.ref_images = (ref_images * ref_masks + (1.0 - ref_masks)).contiguous()
         self.ref_camera = ref_camera
         self.guidance = guidance
         self.normal_consistency = normal_consistency     # mesh_reg.MeshNormalConsistency of the surface mesh, or None
@@ -82,6 +82,7 @@ class DynamicStage:
         self.sharded = D.ShardedAdamW(self.opt.param_groups, self.reducer, betas=(0.9, 0.99), eps=1e-15) if self.sharded_optimizer else None
         self.overflow_skipped = 0        # iterations whose optimiser step was skipped on the device (reported by poll)
         self.global_step = 0
+        self.fused_image_head = True     # clamp + reference-view MSEs + the SDS views' resize as one operator (image_head.py); False: the torch composition
         self.poll_every = 8              # iterations between sync-free looks at the rasterizer's capacity counters
         self.bg6 = torch.ones(6, device=self.dev)      # training background is white (diff_sugar_rasterizer_temporal.py:96-101)
 
@@ -116,10 +117,16 @@ class DynamicStage:
         T = lambda a, dt=None: torch.as_tensor(np.asarray(a), dtype=dt).to(self.dev, non_blocking=True)
         ref_idx = [i for i, r in enumerate(is_ref) if r]
         rnd_idx = [i for i, r in enumerate(is_ref) if not r]
+        ref_pos, rnd_pos = [-1] * len(is_ref), [-1] * len(is_ref)          # the view's index among the reference / random views (image_head)
+        for k, i in enumerate(ref_idx):
+            ref_pos[i] = k
+        for k, i in enumerate(rnd_idx):
+            rnd_pos[i] = k
         fidx = [frames[u] for u in unit_frame]
         return {"frames": frames, "vm": T(np.stack([c.viewmatrix for c in cams]), torch.float32),
                 "pm": T(np.stack([c.projmatrix for c in cams]), torch.float32), "unit_frame": T(unit_frame, torch.int32),
                 "ref_idx": T(ref_idx, torch.int64), "rnd_idx": T(rnd_idx, torch.int64), "n_ref": len(ref_idx), "n_rnd": len(rnd_idx),
+                "ref_pos": T(ref_pos, torch.int32), "rnd_pos": T(rnd_pos, torch.int32),
                 "frames_t_idx": T(frames, torch.int64), "fidx_ref": T([fidx[i] for i in ref_idx], torch.int64),
                 "fidx_rnd": T([fidx[i] for i in rnd_idx], torch.int64),
                 "elev_rnd": torch.tensor([elev[i] for i in rnd_idx], dtype=torch.float32),        # (host tensors: see iteration())
@@ -161,23 +168,37 @@ class DynamicStage:
         # views of the same frame share its skinning / face transform (reference: cached per timestamp within a step)
         out = render_views(self.r, dx, dr, ds, do, st["q_static"], st["scales"], st["opacities"], st["rgb"], b["vm"], b["pm"],
                            self.bg6, frame_index=u)
-        rgb = out["color"][:, :3].clamp(0, 1).permute(0, 2, 3, 1)          # "render": clamp(0,1) (…temporal.py:229)
-        mask = out["alpha"].permute(0, 2, 3, 1)
+        # (the operator folds the guidance's resize to 256 x 256 in: only at the shipped 512 x 512, where that is a 2 x 2 mean)
+        fused_head = self.fused_image_head and out["color"].is_cuda and self.r.H == 512 and self.r.W == 512
+        if fused_head:
+            # clamp, the two reference-view MSEs and the random views at half the size (what the guidance's first step, a bilinear
+            # resize to 256 x 256, makes of them) as ONE operator each way (image_head.py, csrc/imagehead.hip)
+            from .image_head import image_head
+
+            mse_rgb, mse_mask, half = image_head(out["color"], out["alpha"], b["ref_pos"], b["rnd_pos"], self.ref_images, self.ref_masks,
+                                                 b["fidx_ref"], b["n_ref"], b["n_rnd"] if self.guidance is not None else 0)
+            rgb = mask = None
+        else:
+            rgb = out["color"][:, :3].clamp(0, 1).permute(0, 2, 3, 1)          # "render": clamp(0,1) (…temporal.py:229)
+            mask = out["alpha"].permute(0, 2, 3, 1)
         # (index_select, not `x[idx]`: the same rows, but a gather whose backward is ONE index_add launch -- advanced indexing
         # differentiates through a sort-based index_put: six launches per use, three uses per iteration.  The loss starts as the
         # number 0: `rgb.sum() * 0.0` was a full-resolution reduction forward and a full-resolution fill backward for nothing.)
         loss = 0.0
         terms = {}
         if b["n_ref"]:
-            ref = b["ref_idx"]
-            terms["rgb"] = F.mse_loss(self.ref_images.index_select(0, b["fidx_ref"]), rgb.index_select(0, ref))     # unmasked: colour outside the silhouette is penalised
-            terms["mask"] = F.mse_loss(mask.index_select(0, ref), self.ref_masks.index_select(0, b["fidx_ref"]))
+            if fused_head:
+                terms["rgb"], terms["mask"] = mse_rgb, mse_mask
+            else:
+                ref = b["ref_idx"]
+                terms["rgb"] = F.mse_loss(self.ref_images.index_select(0, b["fidx_ref"]), rgb.index_select(0, ref))     # unmasked: colour outside the silhouette is penalised
+                terms["mask"] = F.mse_loss(mask.index_select(0, ref), self.ref_masks.index_select(0, b["fidx_ref"]))
             loss = loss + self.lam["rgb"] * terms["rgb"] + C(self.lam["mask"], 0, it) * terms["mask"]
         if self.guidance is not None and b["n_rnd"]:
             # elevation / azimuth stay on the HOST (they only feed the four-number camera embedding of get_cond: a dozen
             # elementwise launches on 4-element device tensors otherwise)
-            g = self.guidance(rgb.index_select(0, b["rnd_idx"]), b["elev_rnd"], b["azim_rnd"], torch.full_like(b["elev_rnd"], 3.8),
-                              frame_indices=b["fidx_rnd"])
+            g = self.guidance(half if fused_head else rgb.index_select(0, b["rnd_idx"]), b["elev_rnd"], b["azim_rnd"],
+                              torch.full_like(b["elev_rnd"], 3.8), frame_indices=b["fidx_rnd"])
             terms["sds"] = g["loss_sds"]
             loss = loss + C(self.lam["sds_zero123"], 0, it) * g["loss_sds"]
         if self.normal_consistency is not None:
@@ -191,7 +212,7 @@ class DynamicStage:
                 terms["arap_reg_inter_frame"] = self.inter_frame_arap()
                 loss = loss + C(self.lam["arap_reg_inter_frame"], 0, it) * terms["arap_reg_inter_frame"]
         if not torch.is_tensor(loss):                   # (no term applied: nothing to differentiate, but the step's contract is a backward)
-            loss = rgb.sum() * 0.0
+            loss = out["color"].sum() * 0.0
         loss.backward()
         # A forward that overflowed its duplicate / record capacity rendered a wrong image: the optimiser step is skipped ON
         # THE DEVICE (found_inf, as a GradScaler would; no host sync), on EVERY rank (MAX over the ranks of the flag: the

@@ -390,6 +390,26 @@ int dm4d_arap_energy_backward(int32_t T, int32_t V, const int32_t *csr_offsets, 
                               const float *xyz_prime, const float *rotations, const float *g_energy, float *g_xyz,
                               float *g_rotations, dm4d_stream_t stream);
 
+/* The image-space head of a dynamic-stage iteration (C/system/sugar_4dgen.py:148-190: comp_rgb = clamp(render, 0, 1); on the
+ * reference views loss_rgb = mse(gt_rgb, comp_rgb), loss_mask = mse(gt_mask, opacity); the random views go to the Zero123
+ * guidance, whose first step is a bilinear resize to 256 x 256, C/guidance/temporal_stable_zero123_guidance.py:299-310 -- at half
+ * the size, the mean of each 2 x 2 block) in ONE launch each way instead of ~45 torch operators over 25 MB tensors.
+ *   color [B][C >= 3][H][W], alpha [B][1][H][W] float32 (the batched renderer's outputs); ref_pos / rnd_pos [B] int32: the view's
+ *   index among the reference / random views or -1; ref_images [L][H][W][3], ref_masks [L][H][W][1]; fidx_ref [n_ref] int64: the
+ *   frame of each reference view.  H, W even.
+ * forward: partial [B][dm4d_image_head_blocks(H, W)][2] = squared-error partial sums (rgb, mask) -- the caller adds them up (a
+ *   fixed order: deterministic) and divides by n_ref H W 3 / n_ref H W; half_rgb [n_rnd][H/2][W/2][3] = the resized clamped views.
+ * backward: g_rgb / g_mask = dL/d(mse_rgb), dL/d(mse_mask) (device scalars, NULL = 0), g_half = dL/d(half_rgb) or NULL; WRITES
+ *   g_color [B][C][H][W] (torch.clamp's pass-through mask 0 <= x <= 1 applied; zeros in channels >= 3) and g_alpha [B][1][H][W]. */
+int32_t dm4d_image_head_blocks(int32_t H, int32_t W);
+int dm4d_image_head_forward(int32_t B, int32_t H, int32_t W, int32_t C, const float *color, const float *alpha, const int32_t *ref_pos,
+                            const int32_t *rnd_pos, const float *ref_images, const float *ref_masks, const int64_t *fidx_ref, int32_t n_ref,
+                            int32_t n_rnd, float *partial, float *half_rgb, dm4d_stream_t stream);
+int dm4d_image_head_backward(int32_t B, int32_t H, int32_t W, int32_t C, const float *color, const float *alpha, const int32_t *ref_pos,
+                             const int32_t *rnd_pos, const float *ref_images, const float *ref_masks, const int64_t *fidx_ref, int32_t n_ref,
+                             int32_t n_rnd, const float *g_rgb, const float *g_mask, const float *g_half, float *g_color, float *g_alpha,
+                             dm4d_stream_t stream);
+
 /* R [n][3][3] (row-major) of n unit quaternions q [n][4] = (x, y, z, w): `get_timed_vertex_rotation(return_matrix=True)` of
  * C/geometry/dynamic_sugar.py:640-655 (a pypose SO3.matrix()), which the dynamic stage feeds to the ARAP term
  * (C/system/sugar_4dgen.py:304-311).  _backward_pypose: pypose's gradient with respect to the quaternion storage,

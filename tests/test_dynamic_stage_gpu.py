@@ -15,12 +15,12 @@ def _need_gpu():
         pytest.skip("no HIP device")
 
 
-def _build(dev, with_guidance, with_nc=False):
+def _build(dev, with_guidance, with_nc=False, size=128):
     from dreammesh4d_amd import geometry as geo, ops, synthetic as syn, views, zero123 as z
     from dreammesh4d_amd.deformation import DeformationNetwork
     from dreammesh4d_amd.dynamic_stage import DynamicStage
 
-    H = W = 128
+    H = W = size
     M, L = 100, 8
     sc = syn.mesh_bound_scene(2000, n_nodes=M, k=4, seed=0)
     T = lambda a: torch.tensor(a, device=dev)
@@ -133,3 +133,71 @@ def test_bench_rehearsal_two_ranks_over_gloo():
     line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert line["n_gpus"] == 2 and line["steps"] == 2 and "REHEARSAL" in line["data"]
     assert line["config"]["allreduce_bytes_per_step"] == line["config"]["allreduce_message_bytes"] < line["config"]["dense_gradient_bytes"] / 5
+
+
+@pytest.mark.parametrize("H,W,C", [(512, 512, 6), (64, 96, 3)])
+def test_image_head_equals_the_torch_composition(H, W, C):
+    """image_head (csrc/imagehead.hip) against what it replaces in DynamicStage.iteration: clamp(render, 0, 1); MSE against the
+    reference images / masks on the reference views (system/sugar_4dgen.py:164-172); the random views resized to half the size with
+    bilinear interpolation (the guidance's first step at 512 x 512) -- values, and the gradients on the renderer's colour and alpha
+    images including torch.clamp's pass-through at the bounds (pixels at exactly 0 and 1 are in the data)."""
+    _need_gpu()
+    import torch.nn.functional as F
+
+    from dreammesh4d_amd.image_head import image_head
+
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(H + C)
+    B, L = 6, 5
+    color = (torch.rand(B, C, H, W, generator=g) * 1.6 - 0.3)
+    color[:, :, ::7, ::5] = 0.0
+    color[:, :, 3::11, 1::4] = 1.0
+    alpha = torch.rand(B, 1, H, W, generator=g)
+    color, alpha = color.to(dev).requires_grad_(True), alpha.to(dev).requires_grad_(True)
+    ref_images, ref_masks = torch.rand(L, H, W, 3, generator=g).to(dev), (torch.rand(L, H, W, 1, generator=g) > 0.5).float().to(dev)
+    ref_idx, rnd_idx = [0, 3, 4], [1, 2, 5]
+    fidx_ref = torch.tensor([4, 0, 2], device=dev)
+    ref_pos = torch.tensor([0, -1, -1, 1, 2, -1], dtype=torch.int32, device=dev)
+    rnd_pos = torch.tensor([-1, 0, 1, -1, -1, 2], dtype=torch.int32, device=dev)
+    w_rgb, w_mask = 3.0, 0.7
+    gh = torch.randn(3, H // 2, W // 2, 3, generator=g).to(dev)
+    # the operator
+    m_rgb, m_mask, half = image_head(color, alpha, ref_pos, rnd_pos, ref_images, ref_masks, fidx_ref, 3, 3)
+    (w_rgb * m_rgb + w_mask * m_mask + (half * gh).sum()).backward()
+    got = (m_rgb.detach(), m_mask.detach(), half.detach(), color.grad.clone(), alpha.grad.clone())
+    color.grad = alpha.grad = None
+    # the composition
+    rgb = color[:, :3].clamp(0, 1).permute(0, 2, 3, 1)
+    mask = alpha.permute(0, 2, 3, 1)
+    ri, ni = torch.tensor(ref_idx, device=dev), torch.tensor(rnd_idx, device=dev)
+    r_rgb = F.mse_loss(ref_images.index_select(0, fidx_ref), rgb.index_select(0, ri))
+    r_mask = F.mse_loss(mask.index_select(0, ri), ref_masks.index_select(0, fidx_ref))
+    r_half = F.interpolate(rgb.index_select(0, ni).permute(0, 3, 1, 2), (H // 2, W // 2), mode="bilinear", align_corners=False).permute(0, 2, 3, 1)
+    (w_rgb * r_rgb + w_mask * r_mask + (r_half * gh).sum()).backward()
+    assert abs(float(got[0]) - float(r_rgb)) <= 2e-6 * float(r_rgb) and abs(float(got[1]) - float(r_mask)) <= 2e-6 * float(r_mask)
+    assert got[2].shape == r_half.shape and float((got[2] - r_half).abs().max()) <= 1e-7
+    assert float((got[3] - color.grad).abs().max()) <= 1e-6 * float(color.grad.abs().max())
+    assert float((got[4] - alpha.grad).abs().max()) <= 1e-6 * float(alpha.grad.abs().max())
+    if C > 3:
+        assert float(got[3][:, 3:].abs().max()) == 0.0
+
+
+def test_iteration_with_the_fused_image_head_equals_the_torch_composition():
+    """At the shipped 512 x 512 DynamicStage.iteration takes the fused image head: the same loss terms and the same parameter
+    update as the torch composition it replaces (same seeds, two copies of the stage)."""
+    _need_gpu()
+    dev = torch.device("cuda:0")
+    res = {}
+    for fused in (True, False):
+        torch.manual_seed(0)
+        stage = _build(dev, with_guidance=False, size=512)
+        stage.fused_image_head = fused
+        out = [stage.iteration() for _ in range(2)]
+        torch.cuda.synchronize()
+        res[fused] = ([{k: float(v) for k, v in o.items() if torch.is_tensor(v)} for o in out],
+                      torch.cat([p.detach().flatten() for p in stage.net.get_mlp_parameters()]).clone())
+    for a, b in zip(res[True][0], res[False][0]):
+        assert a.keys() == b.keys()
+        for k in a:
+            assert abs(a[k] - b[k]) <= 2e-5 * abs(b[k]) + 1e-9, (k, a[k], b[k])
+    assert float((res[True][1] - res[False][1]).abs().max()) <= 2e-4 * float(res[False][1].abs().max())
