@@ -799,7 +799,8 @@ class TemporalStableZero123Guidance(nn.Module):
         if rgb_as_latents:
             latents = F.interpolate(x, (32, 32), mode="bilinear", align_corners=False) * 2 - 1
         else:
-            latents = self.encode_images(F.interpolate(x, (256, 256), mode="bilinear", align_corners=False))
+            # (a bilinear resize to the size the image already has is the identity: DynamicStage hands over 256 x 256 views)
+            latents = self.encode_images(x if tuple(x.shape[-2:]) == (256, 256) else F.interpolate(x, (256, 256), mode="bilinear", align_corners=False))
         cond = self.get_cond(elevation, azimuth, camera_distances, frame_indices)
         if t is None:
             t = torch.randint(self.min_step, self.max_step + 1, [B], dtype=torch.long, device=latents.device)
