@@ -244,3 +244,28 @@ def test_statistics_survive_a_large_mean():
     want = F.group_norm(x.double().cpu(), G, None, None, 1e-5)              # float64 statistics of the float32 data
     err = float((y.double().cpu() - want).abs().max())
     assert err < 5e-3, err                                                   # (the two-moment float32 form: errors of order 1)
+
+
+@pytest.mark.parametrize("N,C,H,W", [(8, 320, 16, 16), (8, 640, 8, 8), (8, 1920, 16, 16), (8, 2560, 4, 4), (2, 512, 12, 16), (3, 64, 1, 1)])
+def test_slab_resident_single_launch_equals_the_two_pass_kernels(N, C, H, W, monkeypatch):
+    """csrc/groupnorm.hip::k_groupnorm_slab_f16 (samples of <= 16 x 16 pixels: one launch, the slab in registers) against a float64
+    GroupNorm (+ add, SiLU) of the same float16 data, with a large common offset in the data (|mean| / std = 60: shifted sums) --
+    and the statistics it leaves for the backward."""
+    _need_gpu()
+    from dreammesh4d_amd import fused_norm
+
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(C + H)
+    x = (6.0 + 0.1 * torch.randn(N, C, H, W, generator=g)).half().to(dev).contiguous(memory_format=torch.channels_last)
+    add = torch.randn(N, C, generator=g).half().to(dev) * 0.05
+    m = torch.nn.GroupNorm(32, C, eps=1e-6).to(dev).half()
+    with torch.no_grad():
+        m.weight.copy_(torch.randn(C, generator=g).to(dev)); m.bias.copy_(torch.randn(C, generator=g).to(dev))
+    for p in m.parameters():
+        p.requires_grad_(False)
+    with torch.no_grad():
+        y = fused_norm.group_norm(m, x, silu=True, add=add)
+    xin = x.double().cpu() + add.double().cpu()[:, :, None, None]
+    want = F.silu(F.group_norm(xin, 32, m.weight.double().cpu(), m.bias.double().cpu(), 1e-6))
+    err = float((y.double().cpu() - want).abs().max())
+    assert err <= 2 ** -9 * float(want.abs().max()) + 2e-3, err              # float16 rounding of the result
