@@ -143,6 +143,7 @@ _SIGNATURES = {
     "dm4d_conv3x3_strided_scratch_bytes": (C.c_size_t, [C.c_int32] * 6),
     "dm4d_conv3x3_strided_nhwc_f16": (C.c_int, [C.c_int32] * 7 + [vp] * 7),
     "dm4d_conv3x3_s2_dgrad_nhwc_f16": (C.c_int, [C.c_int32] * 5 + [vp, C.POINTER(C.c_void_p), vp, vp]),
+    "dm4d_attention_f16": (C.c_int, [C.c_int32] * 4 + [vp] * 3 + [C.c_int64, C.c_int64, vp, C.c_float, vp]),
     "dm4d_image_head_blocks": (C.c_int32, [C.c_int32, C.c_int32]),
     "dm4d_image_head_forward": (C.c_int, [C.c_int32] * 4 + [vp] * 7 + [C.c_int32, C.c_int32, vp, vp, vp]),
     "dm4d_image_head_backward": (C.c_int, [C.c_int32] * 4 + [vp] * 7 + [C.c_int32, C.c_int32] + [vp] * 6),

@@ -257,3 +257,25 @@ class _Conv3x3Stride2Frozen(torch.autograd.Function):
 def conv3x3_stride2_frozen(x, w, w_ohwi, bias=None, pad=0, w_cls=None):
     """w_cls: pack_weight_s2_dgrad(w) for the MFMA data gradient (None: the library's)."""
     return _Conv3x3Stride2Frozen.apply(x, w, w_ohwi, bias, pad, w_cls)
+
+
+def attention_supported(qkv):
+    """qkv [B, L, 3, heads, D] float16 on a HIP device (the fused q / k / v projection), D in (40, 64, 80, 160), L % 64 == 0."""
+    return (qkv.is_cuda and qkv.dtype == torch.float16 and qkv.dim() == 5 and qkv.shape[2] == 3 and qkv.is_contiguous()
+            and int(qkv.shape[4]) in (40, 64, 80, 160) and qkv.shape[1] % 64 == 0)
+
+
+def attention_qkv(qkv, scale=None):
+    """softmax(q k^T * scale) v for qkv [B, L, 3, heads, D] (q = qkv[:, :, 0] ...) -> [B, L, heads * D]: the UNet's self-attention on the
+    hand-written MFMA kernel (csrc/attention.hip, include/dm4d.h: dm4d_attention_f16).  No autograd."""
+    if not attention_supported(qkv):
+        raise ValueError("attention_qkv: contiguous float16 [B, L, 3, heads, D] on a HIP device, D in (40, 64, 80, 160), L % 64 == 0")
+    B, L, _, H, D = (int(v) for v in qkv.shape)
+    FLOPS[0] += 4 * B * H * L * L * D
+    out = torch.empty(B, L, H * D, dtype=torch.float16, device=qkv.device)
+    base, es = qkv.data_ptr(), 2
+    with torch.cuda.device(qkv.device):
+        _lib.check(_lib.lib().dm4d_attention_f16(B, L, H, D, base, base + H * D * es, base + 2 * H * D * es, L * 3 * H * D, 3 * H * D,
+                                                 out.data_ptr(), float(D ** -0.5 if scale is None else scale),
+                                                 torch.cuda.current_stream(qkv.device).cuda_stream), "dm4d_attention_f16")
+    return out

@@ -73,6 +73,7 @@ MFMA_LINEAR_MIN_ROWS = int(os.environ.get("DM4D_MFMA_LINEAR_MIN_ROWS", "4096")) 
 # ... and the projections with a RESIDUAL (attention output, proj_out) from 512 rows on: the fused epilogue replaces the library GEMM + an
 # add launch (or its prepared C operand): 2048 x 640 -> 640: 7.9 us against 12.0, 512 x 1280 -> 1280: 10.5 against 11.4 + the add
 MFMA_LINEAR_RES_MIN_ROWS = int(os.environ.get("DM4D_MFMA_LINEAR_RES_MIN_ROWS", "512"))
+MFMA_ATTENTION = os.environ.get("DM4D_MFMA_ATTENTION", "1") != "0"            # (A/B switch: the self-attention on csrc/attention.hip)
 FUSE_QKV = os.environ.get("DM4D_FUSE_QKV", "1") != "0"                              # (A/B switch: CrossAttention's one-GEMM q, k, v)
 FUSE_ADD_LAYERNORM = os.environ.get("DM4D_FUSE_ADD_LN", "1") != "0"                 # (A/B switch for BasicTransformerBlock._fused_no_grad)
 BATCH_SMALL_GEMMS = os.environ.get("DM4D_BATCH_SMALL_GEMMS", "1") != "0"      # (A/B switch for UNetModel._batched_small_gemms)
@@ -270,6 +271,8 @@ class CrossAttention(nn.Module):
                 qkv = conv_mfma.linear(x, wqkv).view(B, L, 3, h, -1)
             else:
                 qkv = F.linear(x, wqkv).view(B, L, 3, h, -1)                     # the same products; q, k, v are strided views
+            if MFMA_ATTENTION and conv_mfma.attention_supported(qkv):
+                return conv_mfma.attention_qkv(qkv)          # csrc/attention.hip: 78 -> 33 us at 1024 tokens, 18 -> 11 at 256, 8.5 -> 7 at 64
             o = F.scaled_dot_product_attention(qkv[:, :, 0].transpose(1, 2), qkv[:, :, 1].transpose(1, 2), qkv[:, :, 2].transpose(1, 2))
             return o.transpose(1, 2).reshape(B, L, -1)
         q = self.to_q(x).view(B, L, h, -1).transpose(1, 2)

@@ -390,6 +390,14 @@ int dm4d_arap_energy_backward(int32_t T, int32_t V, const int32_t *csr_offsets, 
                               const float *xyz_prime, const float *rotations, const float *g_energy, float *g_xyz,
                               float *g_rotations, dm4d_stream_t stream);
 
+/* out = softmax(q k^T * scale) v per (batch, head): the self-attentions of the Zero123 UNet's transformer blocks
+ * (extern/ldm_zero123/modules/attention.py:152-194) on the matrix cores.  float16 q, k, v with element (b, token, head, c) at
+ * base + b * batch_stride + token * tok_stride + head * D + c (elements; the three may be views into one fused projection), out
+ * [B][L][heads * D] float16; float32 statistics and accumulators, float16 probabilities.  D in {40, 64, 80, 160}, L a multiple of
+ * 64, 16-byte aligned bases and strides. */
+int dm4d_attention_f16(int32_t B, int32_t L, int32_t heads, int32_t D, const void *q, const void *k, const void *v, int64_t batch_stride,
+                       int64_t tok_stride, void *out, float scale, dm4d_stream_t stream);
+
 /* The image-space head of a dynamic-stage iteration (C/system/sugar_4dgen.py:148-190: comp_rgb = clamp(render, 0, 1); on the
  * reference views loss_rgb = mse(gt_rgb, comp_rgb), loss_mask = mse(gt_mask, opacity); the random views go to the Zero123
  * guidance, whose first step is a bilinear resize to 256 x 256, C/guidance/temporal_stable_zero123_guidance.py:299-310 -- at half
