@@ -153,10 +153,13 @@ __global__ __launch_bounds__(64 * NW) void k_attention(AttnArgs a)
                 pf[kt][r >> 3][r & 7] = (_Float16)p;
             }
         lrun = lrun * alpha + psum;
+        // (after the first few tiles a query's maximum rarely moves: alpha is exactly 1 in every lane, and the wave skips the rescale)
+        if (__builtin_amdgcn_ballot_w64(alpha != 1.0f) != 0ull) {
 #pragma unroll
-        for (int m = 0; m < MT; ++m)
+            for (int m = 0; m < MT; ++m)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) o[m][r] *= alpha;
+                for (int r = 0; r < 16; ++r) o[m][r] *= alpha;
+        }
         // O^T += V^T P^T: the keys of k-step (kt, u) in the order the P^T registers hold them
 #pragma unroll
         for (int m = 0; m < MT; ++m)
