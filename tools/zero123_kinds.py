@@ -11,7 +11,7 @@ def kind(n):
     if "Cijk" in n: return "GEMM (hipBLASLt; incl. the VAE attention's batched GEMMs)"
     if "groupnorm" in n: return "GroupNorm (+ SiLU + embedding / bias add), HIP `k_groupnorm*`"
     if "igemm" in n or "grouped_conv" in n or "naive_conv" in n or "SubTensorOp" in n: return "convolutions, library (conv_in / conv_out of both networks, the UNet's stride-2 Downsample pad 1 .. )"
-    if "attn_fwd" in n or "attn_bwd" in n: return "attention (UNet self-attention, library flash kernel)"
+    if "attn_fwd" in n or "attn_bwd" in n or "k_attention" in n: return "attention (UNet self-attention: HIP `k_attention`)"
     if "layernorm" in n or "layer_norm" in n: return "LayerNorm: HIP `k_add_layernorm_f16`"
     if "geglu" in n or "k_add_bias" in n: return "HIP `k_geglu`, `k_add_bias`"
     return "elementwise (residual adds, copies, casts, cat, softmax, rng ...)"
