@@ -681,7 +681,14 @@ static int conv_plan(int M, int W, int Cout, int kt_total, int &cfg, int &splits
     // (W >= 64: 1.3-1.5x), the 128 x 128 implicit GEMM with two 4-wave workgroups per CU is as fast or faster everywhere else
     // (... and on the UNet's larger problems, >= 28 GFLOP: 640 -> 640 at 32^2 72 vs 97 us, 1280 -> 1280 at 16^2 75 vs 108 us; below that
     // the implicit GEMM with split-K wins by up to 25 %)
-    else if (W >= 8 && (W & (W - 1)) == 0 && (W >= 64 || (double)M * Cout * kt_total * kCvBK * 2.0 >= 28e9)) cfg = 7;
+    // (... of its two tilings the 4-wave 256 x 64 one, two workgroups per CU, is as fast or up to 6 % faster than the 8-wave 256 x 128 one
+    // per shape IN ISOLATION (tools/conv_cfg_vae.py: 20 back-to-back calls on an L2-resident input) and 0.5 ms SLOWER in the SDS step
+    // (10.96 / 11.04 against 10.43 / 10.47 ms, tools/sds_ab.py with DM4D_CONV_DIRECT_CFG=9 / 7 alternating on one box): there the
+    // activations come from HBM, and the narrower filter tile fetches every input patch twice)
+    else if (W >= 8 && (W & (W - 1)) == 0 && (W >= 64 || (double)M * Cout * kt_total * kCvBK * 2.0 >= 28e9)) {
+        static const int dcfg = [] { const char *e = getenv("DM4D_CONV_DIRECT_CFG"); return e ? atoi(e) : 7; }();      // (A/B switch: 7 or 9)
+        cfg = dcfg == 9 ? 9 : 7;
+    }
     else cfg = 3;
     int BM, BN;
     cfg_tile(cfg, BM, BN);
