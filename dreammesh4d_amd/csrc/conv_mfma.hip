@@ -673,19 +673,18 @@ static void cfg_tile(int cfg, int &BM, int &BN)
     BM = (cfg == 7 || cfg == 9) ? 256 : 128;
     BN = cfg == 9 ? 64 : 128;
 }
+// (A/B switches, read once: the problem size from which the direct kernel takes the narrow images, the k-tiles a split must keep)
+static double direct_gflop() { static const double v = [] { const char *e = getenv("DM4D_CONV_DIRECT_GFLOP"); return e ? atof(e) : 14.0; }(); return v; }
+static int split_min_kt() { static const int v = [] { const char *e = getenv("DM4D_CONV_SPLIT_MIN_KT"); return e ? atoi(e) : 30; }(); return v; }
 static int conv_plan(int M, int W, int Cout, int kt_total, int &cfg, int &splits)
 {
     const char *force = getenv("DM4D_CONV_CFG");          // (A/B switches, read per call: tools/conv_probe.py flips them within a process)
     if (force) cfg = atoi(force);
-    // measured per shape (tools/conv_shapes.py, profiles/r03_zero123.md): the direct kernel wins on the VAE encoder's wide images
-    // (W >= 64: 1.3-1.5x), the 128 x 128 implicit GEMM with two 4-wave workgroups per CU is as fast or faster everywhere else
-    // (... and on the UNet's larger problems, >= 28 GFLOP: 640 -> 640 at 32^2 72 vs 97 us, 1280 -> 1280 at 16^2 75 vs 108 us; below that
-    // the implicit GEMM with split-K wins by up to 25 %)
-    // (... of its two tilings the 4-wave 256 x 64 one, two workgroups per CU, is as fast or up to 6 % faster than the 8-wave 256 x 128 one
-    // per shape IN ISOLATION (tools/conv_cfg_vae.py: 20 back-to-back calls on an L2-resident input) and 0.5 ms SLOWER in the SDS step
-    // (10.96 / 11.04 against 10.43 / 10.47 ms, tools/sds_ab.py with DM4D_CONV_DIRECT_CFG=9 / 7 alternating on one box): there the
-    // activations come from HBM, and the narrower filter tile fetches every input patch twice)
-    else if (W >= 8 && (W & (W - 1)) == 0 && (W >= 64 || (double)M * Cout * kt_total * kCvBK * 2.0 >= 28e9)) {
+    // the direct kernel takes the VAE encoder's wide images (W >= 64: 1.3-1.5x the implicit GEMM per shape) and, of the narrow ones, the
+    // problems of >= 14 GFLOP.  That threshold is set IN THE STEP (tools/sds_ab.py, DM4D_CONV_DIRECT_GFLOP = 0 / 3 / 7 / 14 / 28 / 1000 on one
+    // box: 10.60 / 10.51 / 10.59 / 10.42-10.49 / 10.83 / 10.78 ms per SDS step): timed alone (tools/conv_shapes.py) the split-K implicit GEMM
+    // wins up to 28 GFLOP by up to 25 %, but in the step its float32 partial sums and second launch cost more than on an idle, cache-warm chip
+    else if (W >= 8 && (W & (W - 1)) == 0 && (W >= 64 || (double)M * Cout * kt_total * kCvBK * 2.0 >= direct_gflop() * 1e9)) {
         static const int dcfg = [] { const char *e = getenv("DM4D_CONV_DIRECT_CFG"); return e ? atoi(e) : 7; }();      // (A/B switch: 7 or 9)
         cfg = dcfg == 9 ? 9 : 7;
     }
@@ -701,7 +700,7 @@ static int conv_plan(int M, int W, int Cout, int kt_total, int &cfg, int &splits
         // splits x M x C_out x 8 bytes of traffic and a second launch (measured optimum on the UNet's 4^2 .. 16^2 levels,
         // tools/scratch/conv_splits.py: 12 / 24 splits at 4^2, 6 at 8^2, 3 at 16^2, none at 32^2)
         splits = (int)(256 / tiles);
-        if (splits > kt_total / 30) splits = kt_total / 30;
+        if (splits > kt_total / split_min_kt()) splits = kt_total / split_min_kt();
     }
     if (splits < 1) splits = 1;
     if (splits > 64) splits = 64;

@@ -84,18 +84,20 @@ def test_argument_validation_is_host_side():
 
 def test_conv_plan_scratch_sizes_follow_the_split_rule():
     """dm4d_conv3x3_scratch_bytes is host-only: the float32 partial sums of the split-K launches.  The rule (csrc/conv_mfma.hip::
-    conv_plan): split only until every CU has one workgroup and never below 30 k-tiles per workgroup; no split for the direct
-    kernel's shapes at W >= 64 or for problems with >= 256 tiles."""
+    conv_plan): split only until every CU has one workgroup and never below 30 k-tiles per workgroup; tiles of 128 x 128 for the
+    implicit GEMM, of 256 x 128 for the direct kernel, which takes W >= 64 and the narrower power-of-two images from 14 GFLOP."""
     from dreammesh4d_amd import _lib
 
     L = _lib.lib()
     part = lambda splits, N, H, W, Co: splits * N * H * W * Co * 4 + 256
-    assert L.dm4d_conv3x3_scratch_bytes(8, 4, 4, 1280, 1280) == part(12, 8, 4, 4, 1280)       # 10 tiles, 360 k-tiles: 360 / 30
+    assert L.dm4d_conv3x3_scratch_bytes(8, 4, 4, 1280, 1280) == part(12, 8, 4, 4, 1280)       # implicit GEMM (W < 8): 10 tiles, 360 k-tiles: 360 / 30
     assert L.dm4d_conv3x3_scratch_bytes(8, 4, 4, 2560, 1280) == part(24, 8, 4, 4, 1280)
-    assert L.dm4d_conv3x3_scratch_bytes(8, 8, 8, 1280, 1280) == part(6, 8, 8, 8, 1280)        # 40 tiles: 256 / 40
-    assert L.dm4d_conv3x3_scratch_bytes(8, 16, 16, 640, 640) == part(3, 8, 16, 16, 640)
-    assert L.dm4d_conv3x3_scratch_bytes(8, 32, 32, 320, 320) == 256                            # 192 tiles: no split
-    assert L.dm4d_conv3x3_scratch_bytes(4, 256, 256, 128, 128) == 256                          # direct kernel, 2048 tiles
+    assert L.dm4d_conv3x3_scratch_bytes(8, 8, 8, 640, 1280) == part(6, 8, 8, 8, 1280)         # implicit GEMM (7.5 GFLOP): 40 tiles: 256 / 40
+    assert L.dm4d_conv3x3_scratch_bytes(8, 16, 16, 320, 640) == part(3, 8, 16, 16, 640)       # implicit GEMM: 80 tiles, 90 k-tiles
+    assert L.dm4d_conv3x3_scratch_bytes(8, 8, 8, 1280, 1280) == part(12, 8, 8, 8, 1280)       # direct (15.1 GFLOP): 20 tiles of 256 x 128, 360 / 30
+    assert L.dm4d_conv3x3_scratch_bytes(8, 16, 16, 640, 640) == part(6, 8, 16, 16, 640)       # direct: 40 tiles
+    assert L.dm4d_conv3x3_scratch_bytes(8, 32, 32, 320, 320) == part(2, 8, 32, 32, 320)       # direct: 96 tiles: 256 / 96
+    assert L.dm4d_conv3x3_scratch_bytes(4, 256, 256, 128, 128) == 256                          # direct, 1024 tiles: no split
     assert L.dm4d_conv3x3_scratch_bytes(0, 4, 4, 32, 32) == 256
 
 
