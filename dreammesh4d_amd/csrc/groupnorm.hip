@@ -354,7 +354,8 @@ static bool gn_slab_plan(const GnArgs &a, int &gb, int &ppp, int &threads)
     const int R = threads / ppp;
     // measured per shape (tools/gn_shapes.py): 1.4-2.9x faster than the two launches at <= 16 x 16 pixels per sample (7-9 us against
     // 10-23), 10 % slower at 32 x 32 (8 samples x 8 group blocks = 64 workgroups of 20 pieces per thread) and at the VAE's 64 x 64
-    return a.HW <= 256 && (a.HW + R - 1) / R <= kSlabPPT;
+    static const int max_hw = [] { const char *e = getenv("DM4D_GN_SLAB_MAX_HW"); return e ? atoi(e) : 256; }();      // (A/B switch)
+    return a.HW <= max_hw && (a.HW + R - 1) / R <= kSlabPPT;
 }
 
 static size_t gn_lds_bytes(int C, int G, int vec, bool stats)
