@@ -699,9 +699,12 @@ static int conv_plan(int M, int W, int Cout, int kt_total, int &cfg, int &splits
         // split K only until every CU has ONE workgroup, and never below 30 k-tiles per workgroup: the float32 partial sums cost
         // splits x M x C_out x 8 bytes of traffic and a second launch (measured optimum on the UNet's 4^2 .. 16^2 levels,
         // tools/scratch/conv_splits.py: 12 / 24 splits at 4^2, 6 at 8^2, 3 at 16^2, none at 32^2)
-        splits = (int)(256 / tiles);
+        static const int wgs = [] { const char *e = getenv("DM4D_CONV_SPLIT_WGS"); return e ? atoi(e) : 256; }();      // (A/B switch)
+        splits = (int)(wgs / tiles);
         if (splits > kt_total / split_min_kt()) splits = kt_total / split_min_kt();
     }
+    static const int max_splits = [] { const char *e = getenv("DM4D_CONV_MAX_SPLITS"); return e ? atoi(e) : 64; }();      // (A/B switch)
+    if (splits > max_splits) splits = max_splits;
     if (splits < 1) splits = 1;
     if (splits > 64) splits = 64;
     return 0;
