@@ -313,6 +313,12 @@ def main():
             except Exception as e:     # the headline line must not depend on it
                 out["config"]["dynamic_stage_iters_per_sec"] = None
                 out["config"]["dynamic_stage_error"] = repr(e)[:200]
+        if world == 1 and not args.no_iters:
+            try:
+                out["config"].update(static_stage_iterations(dev))
+            except Exception as e:
+                out["config"]["static_stage_iters_per_sec"] = None
+                out["config"]["static_stage_error"] = repr(e)[:200]
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(wl, args.cpu_baseline_views)
         print(json.dumps(out))
@@ -320,7 +326,7 @@ def main():
         dist.destroy_process_group()
 
 
-def dynamic_stage_iterations(wl, dev, n=10):
+def dynamic_stage_iterations(wl, dev, n=50):
     """dynamic-stage iterations/sec at the same scene: 4 frames x (1 reference + 1 SDS view) per iteration, HexPlane
     network, render, losses, full-size Zero123 SDS (SD-1.x UNet 860 M + VAE encoder, fp16, RANDOM weights: the
     checkpoint is not in the tree), backward, AdamW over the 35.76 M parameters
@@ -328,8 +334,7 @@ def dynamic_stage_iterations(wl, dev, n=10):
     from dreammesh4d_amd import synthetic as syn, zero123 as z
     from dreammesh4d_amd.dynamic_stage import DynamicStage
 
-    with torch.device(dev):
-        model = z.Zero123()
+    model = _zero123_model(dev)
     g = torch.Generator(device="cpu").manual_seed(0)
     guid = z.TemporalStableZero123Guidance(model, torch.randn(N_FRAMES, 1, 768, generator=g),
                                            torch.randn(N_FRAMES, 4, 32, 32, generator=g), cond_elevation_deg=5.0,
@@ -344,6 +349,14 @@ def dynamic_stage_iterations(wl, dev, n=10):
                          random_views_per_frame=VIEWS_PER_FRAME - 1,
                          normal_consistency=MeshNormalConsistency(wl.sc["faces"], len(wl.sc["verts"]), dev),
                          arap=ARAPCoach(wl.sc["verts"], wl.sc["faces"], dev), milestone_arap_reg=0)
+    # the first iteration runs STRICT: a 3x3 convolution, q/k/v projection, supported attention, GroupNorm / add / GEGLU of the
+    # guidance step that falls back to the library raises (zero123._library_fallback, fused_norm.expect_fused) instead of
+    # silently costing the step its hand-written kernels
+    os.environ["DM4D_STRICT_FUSED"] = "1"
+    try:
+        stage.iteration()
+    finally:
+        os.environ.pop("DM4D_STRICT_FUSED", None)
     for _ in range(3):
         stage.iteration()
     torch.cuda.synchronize(dev)
@@ -354,6 +367,54 @@ def dynamic_stage_iterations(wl, dev, n=10):
     dt = time.perf_counter() - t0
     return {"dynamic_stage_iters_per_sec": round(n / dt, 3), "dynamic_stage_ms_per_iteration": round(1e3 * dt / n, 2),
             "dynamic_stage_note": "8 views/iteration, full-size Zero123 fp16 with random weights, mesh normal consistency + key-frame ARAP, AdamW step included"}
+
+
+_ZERO123 = {}
+
+
+def _zero123_model(dev):
+    """The full-size random-weight Zero123 (860 M UNet + VAE encoder), built once and shared by both stage legs."""
+    from dreammesh4d_amd import zero123 as z
+
+    if "m" not in _ZERO123:
+        with torch.device(dev):
+            _ZERO123["m"] = z.Zero123()
+    return _ZERO123["m"]
+
+
+def static_stage_iterations(dev, n=50):
+    """static-stage iterations/sec at BASELINE configs[1] (sugar_static_refine: 50,004 mesh-bound Gaussians, 512 x 512): one
+    reference view + `random_camera.batch_size` = 4 random views per iteration (configs/sugar_static_refine.yaml:18-28), every
+    SuGaR parameter learnable -- the FULL blend backward, k_render_bwd<6, 0> -- rgb / mask MSE, full-size Zero123 SDS on the 4 random
+    views, mesh normal consistency + Laplacian smoothing, rgb / depth / normal total variation (so a gradient reaches the depth
+    image), AdamW over the six parameter groups (custom/threestudio-dreammesh4d/system/sugar_static.py:110-340)."""
+    from dreammesh4d_amd import renderer as R, sugar, synthetic as syn, zero123 as z
+    from dreammesh4d_amd.mesh_reg import MeshLaplacianSmoothing, MeshNormalConsistency
+    from dreammesh4d_amd.static_stage import StaticStage
+
+    sc = syn.mesh_bound_scene(8334, n_nodes=50, k=4, seed=0)
+    V = len(sc["verts"])
+    geo = sugar.SuGaR(sc["verts"], sc["faces"], vertex_colors=np.random.default_rng(0).random((V, 3)), device=dev, position_lr=0.00048,
+                      scaling_lr=0.005, feature_lr=0.001, opacity_lr=0.02, rotation_lr=0.001, spatial_lr_scale=1.0)
+    g = torch.Generator(device="cpu").manual_seed(0)
+    guid = z.StableZero123Guidance(_zero123_model(dev), torch.randn(1, 1, 768, generator=g), torch.randn(1, 4, 32, 32, generator=g),
+                                   cond_elevation_deg=5.0, half_precision_weights=True).to(dev)
+    ref_img = torch.rand(1, H, W, 3, generator=g).to(dev)
+    ref_mask = (torch.rand(1, H, W, 1, generator=g) > 0.5).float().to(dev)
+    stage = StaticStage(geo, R.DiffSuGaRNormal(geo), ref_img, ref_mask, H, W, guidance=guid, random_views=4,
+                        normal_consistency=MeshNormalConsistency(sc["faces"], V, dev), laplacian_smoothing=MeshLaplacianSmoothing(sc["faces"], V, dev))
+    for _ in range(4):
+        stage.iteration()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(n):
+        stage.iteration()
+    torch.cuda.synchronize(dev)
+    dt = time.perf_counter() - t0
+    return {"static_stage_iters_per_sec": round(n / dt, 3), "static_stage_ms_per_iteration": round(1e3 * dt / n, 2),
+            "static_stage_note": f"sugar_static_refine (configs[1]): {geo.n_gaussians} Gaussians, 1 reference + 4 random views of 512 x 512 per iteration, "
+                                 "every SuGaR parameter learnable (full blend backward), full-size Zero123 fp16 with random weights, normal consistency + "
+                                 "Laplacian + rgb / depth / normal TV, AdamW step included"}
 
 
 def cpu_baseline(wl, n_views):

@@ -752,10 +752,18 @@ size_t dm4d_conv3x3_scratch_bytes(int32_t N, int32_t H, int32_t W, int32_t Cin, 
 size_t dm4d_conv3x3_strided_scratch_bytes(int32_t N, int32_t Hin, int32_t Win, int32_t Cin, int32_t Cout, int32_t stride)
 {
     if (N <= 0 || Hin <= 0 || Win <= 0 || Cin <= 0 || Cout <= 0 || stride < 1 || stride > 2) return 256;
-    const int H = conv_out(Hin, stride, 1), W = conv_out(Win, stride, 1);      // (pad 0 and 1 differ by at most one row: same plan)
-    int cfg, splits;
-    conv_plan_s(N * H * W, W, Cout, 9 * Cin / kCvBK, stride, cfg, splits);
-    return splits > 1 ? (size_t)splits * N * H * W * Cout * 4 + 256 : 256;
+    // the launch plans from the REAL pad: for stride 2 with an odd H or W, pad 0 and pad 1 give different output sizes and
+    // possibly different split counts -- the scratch covers the larger of the two plans
+    size_t bytes = 256;
+    for (int pad = (stride == 1 ? 1 : 0); pad <= 1; ++pad) {
+        const int H = conv_out(Hin, stride, pad), W = conv_out(Win, stride, pad);
+        if (H <= 0 || W <= 0) continue;
+        int cfg, splits;
+        conv_plan_s(N * H * W, W, Cout, 9 * Cin / kCvBK, stride, cfg, splits);
+        const size_t b = splits > 1 ? (size_t)splits * N * H * W * Cout * 4 + 256 : 256;
+        if (b > bytes) bytes = b;
+    }
+    return bytes;
 }
 
 int dm4d_conv3x3_nhwc_f16(int32_t N, int32_t H, int32_t W, int32_t Cin, int32_t Cout, const void *x, const void *w, const void *bias,

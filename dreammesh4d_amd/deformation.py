@@ -223,7 +223,10 @@ class _NodeNetwork(torch.autograd.Function):
                                               optr, scratch.data_ptr(), torch.cuda.current_stream(dev).cuda_stream), "dm4d_nodenet_forward")
         ctx.plan, ctx.w, ctx.flags, ctx.n_heads = plan, w, flags, n_heads
         ctx.keep = (t, pl, ps, feat, samples, h, y, scratch)
-        ctx.plane_params = list(planes) if in_place and all(p.is_leaf for p in planes) else None
+        # (in-place gradient planes only when EVERY plane is a trainable leaf: a frozen plane must not receive a `.grad` an
+        # optimiser would then apply; DM4D_HEX_KEEP_SPATIAL also assumes that nothing else accumulates into these buffers --
+        # a plane TV / weight regulariser needs grads_in_place = False)
+        ctx.plane_params = list(planes) if in_place and all(p.is_leaf and p.requires_grad for p in planes) else None
         ctx.set_materialize_grads(False)
         return tuple(outs)
 

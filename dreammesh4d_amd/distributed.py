@@ -340,6 +340,9 @@ class ShardedAdamW:
         red = self.reducer
         sparse = {id(x) for x, ix in zip(red.params, red.index) if ix is not None}
         any_ = False
+        # the touched elements carry their own (exact) values: taken from the PARAMETERS as they are now (a load_state_dict
+        # since the last step must not be overwritten by the stale message buffer), decayed with the rest, written back
+        self._pack_params()
         for gi, g in enumerate(self.param_groups):
             tensors = [q.data for q in g["params"] if id(q) in sparse]
             if tensors:

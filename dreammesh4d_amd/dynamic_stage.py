@@ -51,6 +51,10 @@ class DynamicStage:
         self.timestamps = timestamps                     # [L] in (0,1)
         # [L,H,W,3], [L,H,W,1]; the reference's gt image is composited on white outside the mask
         # (data/temporal_image.py:201-202) and the dynamic step compares it UNMASKED (system/sugar_4dgen.py:164-167)
+        # (float32 on the stage's device whatever the data module delivered -- float64 from numpy, uint8-derived ...: the fused
+        # image head reads them through raw float32 pointers)
+        ref_masks = ref_masks.to(device=nodes.device, dtype=torch.float32)
+        ref_images = ref_images.to(device=nodes.device, dtype=torch.float32)
         self.ref_masks = ref_masks.contiguous()
         self.ref_images = (ref_images * ref_masks + (1.0 - ref_masks)).contiguous()
         self.ref_camera = ref_camera
@@ -80,6 +84,10 @@ class DynamicStage:
             self.reducer = D.GradAllReducer(net.parameters())
         self.sharded_optimizer = bool(sharded_optimizer)
         self.sharded = D.ShardedAdamW(self.opt.param_groups, self.reducer, betas=(0.9, 0.99), eps=1e-15) if self.sharded_optimizer else None
+        if self.sharded is not None and hasattr(net, "register_state_dict_pre_hook"):
+            # the sharded optimiser defers the weight decay of the texels no node touches: anything that reads the parameters as a
+            # whole through net.state_dict() (an exporter, a checkpoint callback) sees materialised values, not only state_for_checkpoint()
+            net.register_state_dict_pre_hook(lambda *_a, **_k: self.sharded.materialize())
         self.overflow_skipped = 0        # iterations whose optimiser step was skipped on the device (reported by poll)
         self.global_step = 0
         self.fused_image_head = True     # clamp + reference-view MSEs + the SDS views' resize as one operator (image_head.py); False: the torch composition
@@ -193,7 +201,7 @@ class DynamicStage:
                 ref = b["ref_idx"]
                 terms["rgb"] = F.mse_loss(self.ref_images.index_select(0, b["fidx_ref"]), rgb.index_select(0, ref))     # unmasked: colour outside the silhouette is penalised
                 terms["mask"] = F.mse_loss(mask.index_select(0, ref), self.ref_masks.index_select(0, b["fidx_ref"]))
-            loss = loss + self.lam["rgb"] * terms["rgb"] + C(self.lam["mask"], 0, it) * terms["mask"]
+            loss = loss + C(self.lam["rgb"], 0, it) * terms["rgb"] + C(self.lam["mask"], 0, it) * terms["mask"]
         if self.guidance is not None and b["n_rnd"]:
             # elevation / azimuth stay on the HOST (they only feed the four-number camera embedding of get_cond: a dozen
             # elementwise launches on 4-element device tensors otherwise)
@@ -241,8 +249,11 @@ class DynamicStage:
             try:
                 self.r.poll()
             except Dm4dError as e:
+                if not getattr(e, "overflow", False):      # anything else poll() may raise is a real error, not a skipped step
+                    raise
                 self.overflow_skipped += 1
-                terms["overflow_skipped"] = str(e)
+                self.last_overflow_message = str(e)
+                terms["overflow_skipped"] = torch.tensor(float(self.overflow_skipped))      # numeric like every other term
         return {"loss": loss.detach(), **terms}
 
     def state_for_checkpoint(self):

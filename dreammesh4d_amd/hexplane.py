@@ -119,7 +119,9 @@ class _HexPlaneFeatures(torch.autograd.Function):
                                                torch.cuda.current_stream(dev).cuda_stream), "dm4d_hexplane_forward")
         ctx.plan, ctx.t, ctx.planes, ctx.samples, ctx.cl = plan, t, pl, samples, cl
         # grads_in_place: the Parameters themselves (leaves, not outputs: no reference cycle), see backward()
-        ctx.params = list(planes) if in_place and all(p.is_leaf for p in planes) else None
+        # (only when EVERY plane is a trainable leaf: a frozen plane must never receive a `.grad`; the persistent buffers are
+        # overwritten at the touched texels only, so no other gradient source may accumulate into them in this mode)
+        ctx.params = list(planes) if in_place and all(p.is_leaf and p.requires_grad for p in planes) else None
         return feat
 
     @staticmethod

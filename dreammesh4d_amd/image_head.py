@@ -60,4 +60,14 @@ def image_head(color, alpha, ref_pos, rnd_pos, ref_images, ref_masks, fidx_ref, 
     if not (ref_images.is_contiguous() and ref_masks.is_contiguous() and ref_pos.dtype == torch.int32 and rnd_pos.dtype == torch.int32
             and fidx_ref.dtype == torch.int64):
         raise ValueError("image_head: contiguous reference images / masks, int32 positions, int64 frame indices")
+    # the kernel reads the references through raw float32 pointers: a float64 / uint8 frame stack (numpy / cv2 images) would be
+    # read as garbage where the torch composition this operator replaces would have promoted it
+    H, W = int(color.shape[2]), int(color.shape[3])
+    if not (ref_images.dtype == torch.float32 and ref_masks.dtype == torch.float32 and ref_images.device == color.device
+            and ref_masks.device == color.device and ref_images.dim() == 4 and tuple(ref_images.shape[1:]) == (H, W, 3)
+            and tuple(ref_masks.shape) == (ref_images.shape[0], H, W, 1)):
+        raise ValueError(f"image_head: ref_images [L,{H},{W},3] / ref_masks [L,{H},{W},1] must be float32 on {color.device}, got "
+                         f"{tuple(ref_images.shape)} {ref_images.dtype} {ref_images.device} / {tuple(ref_masks.shape)} {ref_masks.dtype}")
+    if alpha.device != color.device or any(t.device != color.device for t in (ref_pos, rnd_pos, fidx_ref)):
+        raise ValueError("image_head: every tensor on the colour image's device")
     return _ImageHead.apply(color, alpha, ref_pos, rnd_pos, ref_images, ref_masks, fidx_ref, int(n_ref), int(n_rnd))

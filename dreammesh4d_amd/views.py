@@ -128,9 +128,11 @@ class ViewRenderer:
         over = bool((done[:, 1] != 0).any() or (done[:, 3] != 0).any())
         self._grow(d, r_)
         if over:
-            raise _lib.Dm4dError(f"a forward overflowed its workspaces (num_rendered {d}, records {r_}); capacities raised to "
-                                 f"{self.capacity} / {self.record_capacity}; the optimiser step of that iteration was skipped "
-                                 "on the device if overflow_flag() was given to it")
+            e = _lib.Dm4dError(f"a forward overflowed its workspaces (num_rendered {d}, records {r_}); capacities raised to "
+                               f"{self.capacity} / {self.record_capacity}; the optimiser step of that iteration was skipped "
+                               "on the device if overflow_flag() was given to it")
+            e.overflow = True      # (callers that carry on after a skipped step tell it from other errors by this)
+            raise e
         return d, r_
 
     def _grow(self, d, r_):

@@ -83,6 +83,28 @@ _USE_MFMA_CONV_S2 = os.environ.get("DM4D_MFMA_CONV_S2", "1") != "0"            #
 _USE_MFMA_CONV = os.environ.get("DM4D_MFMA_CONV", "1") != "0"      # (A/B switch: "0" keeps every convolution on the library)
 
 
+def _library_fallback(op, x, reason):
+    """Count a call that took the library path although it ran on a device tensor (fused_norm.FALLBACKS: the same counter the
+    GroupNorm / add / GEGLU operators use; `fused_norm.expect_fused()` reports new entries when the guidance step ends and
+    raises under DM4D_STRICT_FUSED=1)."""
+    from . import fused_norm
+
+    fused_norm._fallback(op, x, reason)
+
+
+def _why_not_mfma_conv(conv, x, frozen):
+    w = conv.weight
+    if not _USE_MFMA_CONV:
+        return "DM4D_MFMA_CONV=0"
+    if not frozen:
+        return "trainable parameters"
+    if x.dtype != torch.float16 or w.dtype != torch.float16:
+        return f"dtype {x.dtype}"
+    if not is_channels_last(x):
+        return "not channels_last"
+    return f"shape C_in {x.shape[1]} C_out {w.shape[0]} groups {conv.groups}"
+
+
 def _conv3x3(conv, x, bias=True, residual=None):
     """A 3x3 / stride 1 / padding 1 convolution (+ bias, + residual) with FROZEN parameters (the guidance model is not
     trained).  On a HIP device with channels-last float16 activations: the hand-written MFMA implicit-GEMM kernel
@@ -122,6 +144,9 @@ def _conv3x3(conv, x, bias=True, residual=None):
             if packed[2] is None:
                 packed[2] = conv_mfma.pack_weight_transposed(w)
             return conv_mfma.conv3x3_frozen(x, packed[1], packed[2], b, res)
+    # the library branch: on a device tensor inside the guidance step this is a REGRESSION (4.4 ms of convolutions silently back
+    # on MIOpen): counted like the GroupNorm fallbacks, an error under fused_norm.expect_fused() + DM4D_STRICT_FUSED=1
+    _library_fallback("conv3x3", x, _why_not_mfma_conv(conv, x, frozen))
     if residual is not None and bias and _fold_bias(conv, x):
         return add_bias(residual, _conv_nobias(conv, x), conv.bias)      # (one fused kernel for skip + bias)
     y = F.conv2d(x, w, conv.bias if bias else None, conv.stride, conv.padding)
@@ -147,6 +172,7 @@ def _conv3x3_stride2(conv, x, pad):
                 packed[2] = conv_mfma.pack_weight_s2_dgrad(w)
             return conv_mfma.conv3x3_stride2_frozen(x, w, packed[1], conv.bias, pad, packed[2] if pad == 0 else None)
         return conv_mfma.conv3x3(x, packed[1], conv.bias, None, stride=2, pad=pad)
+    _library_fallback("conv3x3_stride2", x, _why_not_mfma_conv(conv, x, frozen))
     return conv(x) if pad else conv(F.pad(x, (0, 1, 0, 1)))
 
 
@@ -270,9 +296,15 @@ class CrossAttention(nn.Module):
             if B * L >= MFMA_LINEAR_MIN_ROWS and x.dtype == torch.float16 and x.is_contiguous() and conv_mfma.linear_supported(x, wqkv):
                 qkv = conv_mfma.linear(x, wqkv).view(B, L, 3, h, -1)
             else:
+                if B * L >= MFMA_LINEAR_MIN_ROWS and x.dtype == torch.float16:     # (below the threshold the library GEMM is the CHOICE)
+                    _library_fallback("linear_qkv", x, f"contiguous {x.is_contiguous()} K {x.shape[-1]} N {wqkv.shape[0]}")
                 qkv = F.linear(x, wqkv).view(B, L, 3, h, -1)                     # the same products; q, k, v are strided views
             if MFMA_ATTENTION and conv_mfma.attention_supported(qkv):
                 return conv_mfma.attention_qkv(qkv)          # csrc/attention.hip: 78 -> 33 us at 1024 tokens, 18 -> 11 at 256, 8.5 -> 7 at 64
+            # (other head sizes, or fewer than 64 tokens -- the UNet's 4 x 4 level -- are outside the kernel's domain: a property of
+            # the model, not a regression)
+            if x.dtype == torch.float16 and int(qkv.shape[4]) in (40, 64, 80, 160) and L >= 64:
+                _library_fallback("attention", x, f"MFMA_ATTENTION {MFMA_ATTENTION} qkv {tuple(qkv.shape)}")
             o = F.scaled_dot_product_attention(qkv[:, :, 0].transpose(1, 2), qkv[:, :, 1].transpose(1, 2), qkv[:, :, 2].transpose(1, 2))
             return o.transpose(1, 2).reshape(B, L, -1)
         q = self.to_q(x).view(B, L, h, -1).transpose(1, 2)

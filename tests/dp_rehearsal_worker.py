@@ -23,7 +23,7 @@ def main():
     dev = torch.device("cuda:0")
     torch.cuda.set_device(dev)
     H = W = 96
-    M, L = 200, 16
+    M, L = 200, int(os.environ.get("DM4D_REHEARSAL_FRAMES", "16"))      # (8 ranks: 32 frames = cfg 4's exact partition, 4 frames per rank)
     sc = syn.mesh_bound_scene(3000, n_nodes=M, k=4, seed=0)
     T = lambda a: torch.tensor(a, device=dev)
     graph = ops.DeformGraph(sc["verts"], sc["nbr_idx"], sc["nbr_w"], M, dev)
@@ -74,8 +74,8 @@ def main():
         both = [torch.empty_like(b) for _ in range(world)]
         dist.all_gather(both, b)
         if rank == 0:
-            assert torch.equal(both[0], both[1])
-            print(f"DP_REHEARSAL_OK mode=compare max_rel_diff={err:.2e} moment_elems_per_rank={st_s.sharded.exp_avg.numel()} "
+            assert all(torch.equal(both[0], x) for x in both[1:])
+            print(f"DP_REHEARSAL_OK mode=compare world={world} max_rel_diff={err:.2e} moment_elems_per_rank={st_s.sharded.exp_avg.numel()} "
                   f"message_elems={st_s.reducer.flat.numel()}", flush=True)
         dist.destroy_process_group()
         return
@@ -88,10 +88,17 @@ def main():
     other_frames = [None] * world
     dist.all_gather_object(other_frames, frames)
     if rank == 0:
-        assert torch.equal(both[0], both[1]), "replicas diverged: max |diff| %g" % float((both[0] - both[1]).abs().max())
-        assert set(other_frames[0][0]).isdisjoint(other_frames[1][0]), "ranks rendered the same frames"
+        for x in both[1:]:
+            assert torch.equal(both[0], x), "replicas diverged: max |diff| %g" % float((both[0] - x).abs().max())
+        for it in range(len(frames)):
+            seen = [f for r_ in range(world) for f in other_frames[r_][it]]
+            assert len(seen) == len(set(seen)), f"ranks rendered the same frames in iteration {it}: {other_frames}"
+            if L == 4 * world:          # cfg 4's partition: rank r owns frames 4r .. 4r + 3 (rotated per iteration): the timeline is covered
+                assert sorted(seen) == list(range(L)), seen
+        if L == 4 * world:
+            assert other_frames[0][0] == [0, 1, 2, 3] and other_frames[world - 1][0] == [L - 4, L - 3, L - 2, L - 1]
         moved = float((both[0] != 0).float().mean())
-        print(f"DP_REHEARSAL_OK mode={mode} message_bytes={stage.reducer.nbytes} dense_bytes={4 * stage.reducer.dense_elements} nonzero_params={moved:.3f}", flush=True)
+        print(f"DP_REHEARSAL_OK mode={mode} world={world} message_bytes={stage.reducer.nbytes} dense_bytes={4 * stage.reducer.dense_elements} nonzero_params={moved:.3f}", flush=True)
     dist.destroy_process_group()
 
 

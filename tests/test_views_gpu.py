@@ -309,3 +309,74 @@ def test_no_depth_gradient_uses_32_byte_records_with_identical_gradients(H, W):
     for k in ("trans", "d_rot", "strain", "d_opacity", "m2", "normal_grad"):
         assert float(res["none"][k].abs().max()) > 0, k
         assert torch.equal(res["none"][k], res["zeros"][k]), k
+
+
+@pytest.mark.parametrize("mode", ["lean32", "lean48", "full64"])
+def test_bench_scene_one_view_against_two_oracle_passes(mode):
+    """The TIMED kernel instantiations at the TIMED size: one (frame, view) unit of bench.py's scene (mesh-bound 199,980
+    Gaussians, 33,330 faces, 1000 nodes, hybrid skinning, 512 x 512, bench.py's own camera and node outputs) through
+    ``render_views`` in the three record modes the bench reports --
+        lean32: static appearance frozen, no depth gradient   k_render_bwd<6, 2>   (the headline step)
+        lean48: static appearance frozen, depth gradient       k_render_bwd<6, 1>   (`with_depth_gradient`)
+        full64: static appearance learnable, depth gradient    k_render_bwd<6, 0>   (`roofline_full`, sugar_static_refine)
+    -- against TWO oracle passes (RGB pass with dL/d(colour, depth, alpha), normal pass with dL/dcolour: the reference's
+    two rasterizer calls per view, renderer/diff_sugar_rasterizer_temporal.py:169-178,202-211) fed the HIP path's own
+    Gaussians: forward image bit-identical, every per-Gaussian gradient within tests/test_raster_gpu.py::_assert_grads' bars."""
+    _need_gpu()
+    import bench
+    from dreammesh4d_amd import ops, views
+    from oracle import raster as orc
+    from tests.test_raster_gpu import _assert_grads
+
+    dev = torch.device("cuda:0")
+    wl = bench.Workload(dev, 0, 1)
+    H, W, u = bench.H, bench.W, 3                      # unit 3: frame 1, its second camera
+    f = int(wl.fidx[u])
+    with torch.no_grad():
+        dx, dr, ds, do = (t[f:f + 1].contiguous() for t in wl.net.node_outputs(wl.nodes, wl.frame_t))
+    learn = mode == "full64"
+    st = [t.detach().clone().requires_grad_(learn) for t in (wl.scales, wl.opac, wl.rgb)]
+    leaves = [t.clone().requires_grad_(True) for t in (dx, dr, ds, do)]
+    r = views.ViewRenderer(wl.graph, wl.topo, H, W, wl.cams[0].tanfov, method="hybrid")
+    m2 = torch.zeros(1, r.N, 3, device=dev, requires_grad=True)
+    out = views.render_views(r, *leaves, wl.qs, st[0], st[1], st[2], wl.vm[u:u + 1], wl.pm[u:u + 1], wl.bg6, means2D=m2)
+    nr = r.check()
+    gC, gD, gA = wl.gC[u:u + 1], wl.gD[u:u + 1], wl.gA[u:u + 1]
+    if mode == "lean32":
+        torch.autograd.backward([out["color"], out["alpha"]], [gC, gA])
+    else:
+        torch.autograd.backward([out["color"], out["depth"], out["alpha"]], [gC, gD, gA])
+    torch.cuda.synchronize()
+    lg = r.last_grads
+    # the Gaussians the HIP path rendered (same kernels as inside render_views: bit-identical)
+    with torch.no_grad():
+        means, rots, normals = ops.face_gaussians(wl.topo, out["vxyz"][0], out["vrot"][0], wl.qs, grad_mode=r.grad_mode)
+    cam = wl.cams[u]
+    n = lambda t: t.detach().cpu().numpy()
+    ok = dict(image_height=H, image_width=W, tanfovx=cam.tanfov, tanfovy=cam.tanfov, bg=(1, 1, 1), scale_modifier=1.0,
+              viewmatrix=cam.viewmatrix, projmatrix=cam.projmatrix, campos=cam.campos)
+    o1, o2 = orc.RasterOracle(**ok), orc.RasterOracle(**ok)
+    o1.forward(n(means), n(st[1]).reshape(-1), colors_precomp=n(st[2]), scales=n(st[0]), rotations=n(rots))
+    o2.forward(n(means), n(st[1]).reshape(-1), colors_precomp=n(normals), scales=n(st[0]), rotations=n(rots))
+    assert o1.D == nr[0] == o2.D
+    assert np.array_equal(n(out["radii"][0]), o1.s["radii"])
+    col = n(out["color"][0])
+    assert np.array_equal(col[:3].view(np.uint32), o1.s["out_color"].view(np.uint32))
+    assert np.array_equal(col[3:].view(np.uint32), o2.s["out_color"].view(np.uint32))
+    assert np.array_equal(n(out["depth"][0, 0]).view(np.uint32), o1.s["out_depth"].view(np.uint32))
+    assert np.array_equal(n(out["alpha"][0, 0]).view(np.uint32), o1.s["out_alpha"].view(np.uint32))
+    g1 = o1.backward(n(gC[0, :3]), n(gD[0, 0]) if mode != "lean32" else None, n(gA[0, 0]))
+    g2 = o2.backward(n(gC[0, 3:]), None, None)
+    og = {k: g1[k] + g2[k] for k in ("dL_dmeans2D", "dL_dmeans3D", "dL_drots", "dL_dopacity", "dL_dscales")}
+    og["dL_dcolors"] = g2["dL_dcolors"] if not learn else np.concatenate([g1["dL_dcolors"], g2["dL_dcolors"]], axis=1)
+    g = {"dL_dmeans2D": n(m2.grad[0]), "dL_dmeans3D": n(lg["m3"][0]), "dL_drots": n(lg["rot"][0]),
+         "dL_dcolors": n(lg["col"][0]) if learn else n(lg["col"][0, :, 3:])}
+    keys = ["dL_dmeans2D", "dL_dcolors", "dL_dmeans3D", "dL_drots"]
+    if learn:
+        g["dL_dopacity"], g["dL_dscales"] = n(lg["op"][0]), n(lg["sc"][0])
+        keys += ["dL_dopacity", "dL_dscales"]
+    else:
+        assert lg["op"] is None and float(lg["col"][0, :, :3].abs().max()) == 0.0      # lean records: not reduced, not recorded
+    for k in keys:
+        assert float(np.abs(g[k]).max()) > 0, k
+    _assert_grads(g, og, keys=tuple(keys), o=[o1, o2])
