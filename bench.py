@@ -116,6 +116,14 @@ class Workload:
         # gradient is timed beside it (`with_depth_gradient`), and `roofline_full` always has one.
         self.depth_grad = os.environ.get("DM4D_BENCH_DEPTH_GRAD", "0") == "1"
         self._params = list(self.net.parameters())
+        # the step object (dreammesh4d_amd/step.py, csrc/step.hip): node network + render_views as one C call each way on
+        # persistent buffers -- the same kernels in the same order (tests/test_step_gpu.py: bit-identical), 0.2-0.3 ms of host
+        # time per step instead of 0.8.  DM4D_BENCH_STEP_OBJECT=0: the two-operator path (A/B).
+        from dreammesh4d_amd.step import DynamicStep
+        self.use_step_object = os.environ.get("DM4D_BENCH_STEP_OBJECT", "1") != "0"
+        self.dstep = DynamicStep(self.renderer, self.net, self.nodes, self.qs, self.scales, self.opac, self.rgb, self.bg6,
+                                 n_views=VIEWS_PER_STEP, n_frames=FRAMES_PER_STEP)
+        self.vm16, self.pm16 = self.vm.contiguous(), self.pm.contiguous()
 
     def set_static_learnable(self, flag):
         """False (the dynamic stage: static_learnable = False, dynamic_sugar.py:79-87): the blend backward neither reduces nor
@@ -130,9 +138,12 @@ class Workload:
             p.grad = None
         # node attributes once per distinct timestamp of the step (cached per step in the reference,
         # dynamic_sugar.py:367-405), then broadcast to the views of that frame
-        dx, dr, ds, do = self.net.node_outputs(self.nodes, self.frame_t)
-        out = self.render_views(self.renderer, dx, dr, ds, do, self.qs, self.scales, self.opac, self.rgb, self.vm, self.pm,
-                                self.bg6, frame_index=self.fidx)
+        if self.use_step_object and not self.scales.requires_grad:
+            out = self.dstep(self.frame_t, self.vm16, self.pm16, self.fidx)
+        else:       # (the full backward of `roofline_full`: static appearance learnable)
+            dx, dr, ds, do = self.net.node_outputs(self.nodes, self.frame_t)
+            out = self.render_views(self.renderer, dx, dr, ds, do, self.qs, self.scales, self.opac, self.rgb, self.vm, self.pm,
+                                    self.bg6, frame_index=self.fidx)
         if self.depth_grad:
             torch.autograd.backward([out["color"], out["depth"], out["alpha"]], [self.gC, self.gD, self.gA])
         else:

@@ -70,6 +70,16 @@ class MlpWeightsGrad(C.Structure):
     _fields_ = [("W0", vp), ("b0", vp), ("W1", vp * 4), ("b1", vp * 4), ("W2", vp * 4), ("b2", vp * 4)]
 
 
+class StepDesc(C.Structure):
+    """dm4d_step_desc (include/dm4d.h)."""
+    _fields_ = [("views", ViewsStruct), ("grads", ViewsGrads), ("S", C.c_int32), ("hex_flags", C.c_int32), ("hex_backward_flags", C.c_int32),
+                ("res", vp), ("aabb_host", vp), ("planes", vp), ("g_planes", vp), ("nodes", vp), ("times", vp),
+                ("w", MlpWeights), ("gw", MlpWeightsGrad), ("node_out", vp * 4), ("node_gout", vp * 4),
+                ("feat", vp), ("h_save", vp), ("y_save", vp), ("g_feat", vp), ("samples", vp), ("net_scratch", vp),
+                ("n_spatial", C.c_int32), ("n_time", C.c_int32)] + \
+               [(n, vp) for n in ("sp_scale", "sp_plane", "sp_texel", "sp_off", "sp_item", "tp_scale", "tp_plane", "tp_col", "tp_off", "tp_item")]
+
+
 MAX_GRAD_SEGMENTS = 64
 
 
@@ -177,6 +187,11 @@ _SIGNATURES = {
     "dm4d_views_backward": (C.c_int, [C.POINTER(ViewsStruct), C.POINTER(ViewsGrads), vp]),
     "dm4d_views_counters": (C.c_int, [C.POINTER(ViewsStruct), C.POINTER(C.c_int64), C.POINTER(C.c_int64),
                                       C.POINTER(C.c_int32), vp]),
+    "dm4d_step_create": (C.c_int, [C.POINTER(StepDesc), C.POINTER(vp)]),
+    "dm4d_step_destroy": (None, [vp]),
+    "dm4d_step_forward": (C.c_int, [vp] * 6),
+    "dm4d_step_backward": (C.c_int, [vp] * 7),
+    "dm4d_step_views": (vp, [vp]),
 }
 
 

@@ -661,6 +661,59 @@ int dm4d_nodenet_backward(int32_t S, int32_t M, int32_t B, const int32_t *res, c
                           const int32_t *tp_plane, const int32_t *tp_col, const int32_t *tp_off, const int32_t *tp_item,
                           float *g_feat, float *const *g_planes, const dm4d_mlp_weights_grad *gw, void *scratch, dm4d_stream_t stream);
 
+/* ------------------------------------------------------------------ step object
+ * One C call each way for the whole per-(frame, view) path of a dynamic-stage step on a FIXED problem:
+ *   dm4d_step_forward  = dm4d_nodenet_forward (deformation network of the graph nodes at the step's timestamps)
+ *                        -> dm4d_views_forward (skinning, face->Gaussian, fused RGB + normal rasterisation of every view)
+ *   dm4d_step_backward = dm4d_views_backward -> dm4d_nodenet_backward (parameter gradients WRITTEN into the descriptor's buffers)
+ * The object owns the structs, the pointer tables and the host arrays of the two operators (dm4d_step_create deep-copies the
+ * descriptor: nothing of it has to outlive the call); all device memory stays the caller's and must stay valid and unchanged in
+ * size until dm4d_step_destroy.  Per step the caller passes only what changes: timestamps, cameras, the view -> frame map, the
+ * upstream gradients.  Kernels, launch order and results are exactly those of the two operators called one after the other.
+ * Why it exists: the host side of a step (two autograd Functions, ~60 allocations, struct marshalling) took as long as the
+ * step's ~1 ms of GPU work (dreammesh4d_amd/step.py).  Host-side loop it replaces: C/renderer/gaussian_batch_renderer.py:21-76
+ * around C/geometry/dynamic_sugar.py:367-431.
+ *
+ * dm4d_step_desc.views: every field as for dm4d_views_forward EXCEPT viewmatrix / projmatrix / frame_index (arguments of
+ *   dm4d_step_forward; n_frames is read when frame_index is given); dx / dr / ds / d_opacity must be the buffers node_out[]
+ *   points at (ds / d_opacity NULL when the skinning method ignores them).
+ * dm4d_step_desc.grads: scratch + outputs as for dm4d_views_backward; dL_dcolor / dL_ddepth / dL_dalpha / dL_dv*_ext are arguments
+ *   of dm4d_step_backward; dL_dopacity / dL_dscales must be NULL (static appearance frozen: the dynamic stage,
+ *   C/geometry/dynamic_sugar.py:79-87); dL_ddx .. dL_ddo must be the buffers node_gout[] points at.
+ * node_out[k] / node_gout[k], k < w.n_heads: output of MLP head k [n_frames, M, out_dim[k]] and its upstream gradient (NULL = zero:
+ *   a head the skinning method does not read).
+ * hex_flags: the DM4D_HEX_* word of the forward; hex_backward_flags: OR-ed in for the backward (DM4D_HEX_KEEP_SPATIAL when g_planes
+ *   are persistent buffers whose untouched texels are already zero). */
+typedef struct dm4d_step dm4d_step;
+typedef struct dm4d_step_desc {
+    dm4d_views views;
+    dm4d_views_grads grads;
+    int32_t S, hex_flags, hex_backward_flags;
+    const int32_t *res;                 /* host [S,4] */
+    const float *aabb_host;             /* host [2,3] */
+    const float *const *planes;         /* host: S*6 device pointers */
+    float *const *g_planes;             /* host: S*6 device pointers (gradient planes) */
+    const float *nodes;                 /* [M,3] */
+    const float *times;                 /* (set by dm4d_step_forward) */
+    dm4d_mlp_weights w;
+    dm4d_mlp_weights_grad gw;
+    float *node_out[4];
+    const float *node_gout[4];
+    float *feat, *h_save, *y_save, *g_feat;      /* [n_frames*M, S*32] [.,64] [n_heads,.,64] [n_frames*M, S*32] */
+    void *samples, *net_scratch;                 /* dm4d_hexplane_scratch_bytes, dm4d_nodenet_scratch_bytes */
+    int32_t n_spatial, n_time;                   /* gather plan of the HexPlane backward, as dm4d_nodenet_backward */
+    const int32_t *sp_scale, *sp_plane, *sp_texel, *sp_off, *sp_item;
+    const int32_t *tp_scale, *tp_plane, *tp_col, *tp_off, *tp_item;
+} dm4d_step_desc;
+int dm4d_step_create(const dm4d_step_desc *desc, dm4d_step **out);
+void dm4d_step_destroy(dm4d_step *s);
+int dm4d_step_forward(dm4d_step *s, const float *times01, const float *viewmatrix, const float *projmatrix,
+                      const int32_t *frame_index, dm4d_stream_t stream);
+int dm4d_step_backward(dm4d_step *s, const float *dL_dcolor, const float *dL_ddepth, const float *dL_dalpha,
+                       const float *dL_dvxyz_ext, const float *dL_dvrot_ext, dm4d_stream_t stream);
+/* the object's dm4d_views as the last forward left it (for dm4d_views_counters); NULL if `s` is not a step object */
+const dm4d_views *dm4d_step_views(const dm4d_step *s);
+
 #ifdef __cplusplus
 }
 #endif

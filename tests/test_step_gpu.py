@@ -1,0 +1,140 @@
+"""-m gpu: the step object (dreammesh4d_amd/step.py, csrc/step.hip: dm4d_step_*) against the two operators it wraps --
+``DeformationNetwork.node_outputs`` + ``views.render_views`` -- on the same inputs: the same kernels in the same order, so images,
+node outputs and every parameter gradient must agree BIT FOR BIT; plus its contract (one step in flight, gradients dropped
+every step, rebuild when the capacities grow)."""
+import numpy as np
+import pytest
+import torch
+
+from dreammesh4d_amd import synthetic as syn
+
+pytestmark = pytest.mark.gpu
+
+
+def _setup(dev, method="hybrid", n_faces=2400, M=100, B=4, NF=2, H=144, W=176, seed=3):
+    from dreammesh4d_amd import geometry as geo, ops, views
+    from dreammesh4d_amd.deformation import DeformationNetwork
+
+    sc = syn.mesh_bound_scene(n_faces, n_nodes=M, k=4, seed=seed)
+    T = lambda a: torch.tensor(a, device=dev)
+    graph = ops.DeformGraph(sc["verts"], sc["nbr_idx"], sc["nbr_w"], M, dev)
+    topo = ops.MeshTopology(sc["faces"], len(sc["verts"]), 6, dev)
+    verts, faces = T(sc["verts"]), T(sc["faces"])
+    st = dict(qs=geo.quaternions(verts, faces, T(sc["complex"]), 6), sc=geo.scaling(T(sc["log_scales"]), syn.THICKNESS),
+              op=geo.strengths(T(sc["densities"])), rgb=geo.points_rgb(T(sc["sh_dc"])))
+    torch.manual_seed(0)
+    net = DeformationNetwork(resolution=(16, 16, 16, 9), multires=(1, 2), no_ds=False, no_dr=False, no_do=False).to(dev)
+    g0 = torch.Generator(device="cpu").manual_seed(5)
+    with torch.no_grad():
+        for name, p in net.named_parameters():
+            if "_deform" in name:
+                p.add_((0.02 * torch.randn(p.shape, generator=g0)).to(dev))
+    cams = [syn.make_camera(H, W, elev_deg=10 + 9 * b, azim_deg=-100 + 71 * b) for b in range(B)]
+    vm = torch.stack([T(c.viewmatrix) for c in cams])
+    pm = torch.stack([T(c.projmatrix) for c in cams])
+    fidx = torch.tensor([0, 1, 1, 0][:B], device=dev, dtype=torch.int32) if NF != B else None
+    t = torch.tensor([0.21, 0.67][:NF], device=dev)
+    r = lambda: views.ViewRenderer(graph, topo, H, W, cams[0].tanfov, method=method)
+    gen = torch.Generator().manual_seed(1)
+    gC, gD, gA = torch.randn(B, 6, H, W, generator=gen).to(dev), (0.1 * torch.randn(B, 1, H, W, generator=gen)).to(dev), torch.randn(B, 1, H, W, generator=gen).to(dev)
+    gV = (0.01 * torch.randn(NF, graph.V, 3, generator=gen)).to(dev)
+    return sc, net, T(sc["nodes"]), st, vm, pm, fidx, t, r, (gC, gD, gA, gV)
+
+
+@pytest.mark.parametrize("method,depth", [("hybrid", False), ("hybrid", True), ("lbs", False), ("dqs", True)])
+def test_step_object_is_bit_identical_to_node_outputs_plus_render_views(method, depth):
+    if not torch.cuda.is_available():
+        pytest.skip("no HIP device")
+    from dreammesh4d_amd import views
+    from dreammesh4d_amd.step import DynamicStep
+
+    dev = torch.device("cuda:0")
+    sc, net, nodes, st, vm, pm, fidx, t, mk, (gC, gD, gA, gV) = _setup(dev, method)
+    bg6 = torch.ones(6, device=dev)
+    params = [p for p in net.parameters() if p.requires_grad]
+
+    def backward(out):
+        outs, gs = [out["color"], out["alpha"], out["vxyz"]], [gC, gA, gV]
+        if depth:
+            outs.append(out["depth"]); gs.append(gD)
+        torch.autograd.backward(outs, gs)
+
+    # reference: the two operators
+    r1 = mk()
+    net.grads_in_place = False
+    dx, dr, ds, do = net.node_outputs(nodes, t)
+    o1 = views.render_views(r1, dx, dr, ds, do, st["qs"], st["sc"], st["op"], st["rgb"], vm, pm, bg6, frame_index=fidx)
+    backward(o1)
+    ref = {k: v.detach().clone() for k, v in o1.items()}
+    ref_nodes = [None if x is None else x.detach().clone() for x in (dx, dr, ds, do)]
+    ref_grads = [None if p.grad is None else p.grad.detach().clone() for p in params]
+    for p in params:
+        p.grad = None
+    # the step object (twice: the second call reuses every buffer)
+    r2 = mk()
+    step = DynamicStep(r2, net, nodes, st["qs"], st["sc"], st["op"], st["rgb"], bg6, n_views=vm.shape[0], n_frames=t.shape[0])
+    for rep in range(2):
+        o2 = step(t, vm, pm, fidx)
+        for k in ("color", "depth", "alpha", "radii", "vxyz", "vrot"):
+            assert torch.equal(o2[k], ref[k]), (k, rep)
+        no = step.node_outputs()
+        for name, want in zip(("dx", "dr", "ds", "do"), ref_nodes):
+            if want is not None:
+                assert torch.equal(no[name].view(want.shape), want), name
+        backward(o2)
+        n_checked = 0
+        for p, want in zip(params, ref_grads):
+            if want is None or not bool(want.any()):
+                continue              # (parameters the two-operator path leaves without gradient: the unused timenet)
+            assert p.grad is not None
+            assert torch.equal(p.grad, want), rep
+            n_checked += 1
+        assert n_checked >= 10
+        assert r2.check() == r1.check()
+        for p in params:
+            p.grad = None
+
+
+def test_step_object_contract():
+    if not torch.cuda.is_available():
+        pytest.skip("no HIP device")
+    from dreammesh4d_amd.step import DynamicStep
+
+    dev = torch.device("cuda:0")
+    sc, net, nodes, st, vm, pm, fidx, t, mk, (gC, gD, gA, gV) = _setup(dev)
+    bg6 = torch.ones(6, device=dev)
+    r = mk()
+    step = DynamicStep(r, net, nodes, st["qs"], st["sc"], st["op"], st["rgb"], bg6, n_views=4, n_frames=2)
+    o = step(t, vm, pm, fidx)
+    torch.autograd.backward([o["color"]], [gC])
+    g_first = [p.grad.clone() for p in step.params]
+    # a parameter that still holds a gradient: refused (no silent overwrite of an accumulated gradient)
+    o = step(t, vm, pm, fidx)
+    with pytest.raises(RuntimeError, match="still holds a gradient"):
+        torch.autograd.backward([o["color"]], [gC])
+    for p in step.params:
+        p.grad = None
+    # backward of a step whose buffers a later forward overwrote: refused
+    o_old = step(t, vm, pm, fidx)
+    o_new = step(t, vm, pm, fidx)
+    with pytest.raises(RuntimeError, match="already overwritten"):
+        torch.autograd.backward([o_old["color"]], [gC])
+    torch.autograd.backward([o_new["color"]], [gC])
+    for a, p in zip(g_first, step.params):
+        assert torch.equal(a, p.grad)              # deterministic: the same step gives the same bits
+    # grown capacities rebuild the object (new workspaces), same image
+    ref = o_new["color"].clone()
+    for p in step.params:
+        p.grad = None
+    r.capacity, r.record_capacity = 2 * r.capacity, 2 * r.record_capacity
+    o = step(t, vm, pm, fidx)
+    assert torch.equal(o["color"], ref) and step.key[0] == r.capacity
+    # wrong dtypes / shapes are rejected before the library sees a pointer
+    with pytest.raises(ValueError):
+        step(t.double(), vm, pm, fidx)
+    with pytest.raises(ValueError):
+        step(t, vm[:2], pm, fidx)
+    with pytest.raises(ValueError):
+        step(t, vm, pm, fidx.long())
+    with pytest.raises(ValueError):
+        DynamicStep(r, net, nodes, st["qs"], st["sc"].clone().requires_grad_(True), st["op"], st["rgb"], bg6, n_views=4, n_frames=2)
