@@ -13,6 +13,8 @@
 // written once (8 B).  Because (tile, depth bits, id) is a total order, the result is exactly
 // the order a stable radix sort of tile<<32|depth produces from the Gaussian-major duplicate
 // list -- the parity tests compare the (key, value) list bit-for-bit.
+#include <stdlib.h>
+
 #include "common.h"
 #include "raster.h"
 
@@ -91,10 +93,13 @@ __global__ __launch_bounds__(kColThreads) void k_colscan(BatchDesc d)
 // copy borrows the tile's cell-0 list segment, which is only written afterwards).
 // debug (dm4d_debug_trace): per-tile phase timestamps {start, loaded+binned, sorted, end} in 100 MHz ticks
 __device__ uint64_t *g_sort_trace = nullptr;
+__device__ int g_sort_trace_variant = 0;       // whose tiles are recorded: 0 the large (1024-thread) variant's, 1 the small one's
 int set_sort_trace_buffer(void *dev_ptr)
 {
     uint64_t *p = (uint64_t *)dev_ptr;
+    const int variant = getenv("DM4D_SORT_TRACE_VARIANT") ? atoi(getenv("DM4D_SORT_TRACE_VARIANT")) : 0;
     DM4D_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_sort_trace), &p, sizeof(p)));
+    DM4D_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_sort_trace_variant), &variant, sizeof(variant)));
     return DM4D_OK;
 }
 constexpr int kSortPerThread = 8;        // keys a thread holds in registers: LDS capacity = 8 x threads
@@ -114,7 +119,128 @@ constexpr int kBins = 1024;
 // 16-bit fields through ONE block scan, and each thread then walks its entries in order.  3 barriers per
 // chunk (the first version compacted 256 entries at a time with 16 ballots: 3 barriers and two
 // dependent gathers per 256 entries, 70 % of the kernel).
-constexpr int kFinE = 8;
+// ---- round 4: the split of a sorted tile list into its sixteen cell lists by BALLOT COMPACTION (finish_tile_lds) ----
+// The first version (finish_tile below, still used by the tiles whose lists do not fit the LDS) gives a thread kFinE consecutive
+// entries and lets it loop over the set bits of each entry's 16-cell mask: ~35 instructions per (entry, cell) pair in a loop
+// whose trip count is the LARGEST popcount of the wave's 64 entries (2.3 cells per entry on average, ~7 at the maximum) -- the
+// phase trace (tools/sort_trace.py) has it at 11 of the 17.6 us a tile's workgroup lives (62 % of the kernel).
+// Now: phase A, a thread per entry: gather cellinfo / cellmask, compute the entry's 16-bit cell mask and, per row of the tile's
+// 4 x 4 cell window, the record rank of the row's first reached cell (the ranks of the others follow from the mask: the cells a
+// row reaches are consecutive) -- 8 bytes per entry into LDS.  Phase B, a wave per four cells: 64 entries at a time, `ballot` of
+// "entry reaches cell k", position = cell base + the number of set bits below the lane: consecutive lanes write consecutive
+// words of the cell list, no loop over bits, no divergence, no block scan.
+constexpr uint32_t kCoarse = 256;              // level-1 depth buckets of the LDS sort (below)
+// the sixteen-cell mask of a tile-list entry (bit k = the Gaussian's alpha >= 1/255 support reaches cell k of tile (tx, ty); cell
+// ids as raster.h: 4 * quadrant + (cx & 1) + 2 * (cy & 1)) and, in `rowrank`, for each window row cy the record rank of its first
+// reached cell (8 bits each, saturated at kRankBig: ranks beyond are recomputed from cellinfo by the blend backward)
+__device__ __forceinline__ uint32_t tile_cell_mask(const uint4 ci, const uint64_t cm, const int tx, const int ty, uint32_t &rowrank)
+{
+    const int bx0 = (int)(ci.x & 0xFFFFu), by0 = (int)(ci.x >> 16);
+    const int nbx = (int)(ci.y & 0xFFFFu), nby = (int)(ci.y >> 16);
+    const int ox = 4 * tx - bx0, oy = 4 * ty - by0;
+    const bool dense = ci.w != 0u;
+    const int cx0 = max(bx0, 4 * tx) - 4 * tx, cx1 = min(bx0 + nbx, 4 * tx + 4) - 4 * tx;
+    const int cy0 = max(by0, 4 * ty) - 4 * ty, cy1 = min(by0 + nby, 4 * ty + 4) - 4 * ty;
+    const uint32_t xmask = cx1 > cx0 ? ((1u << (cx1 - cx0)) - 1u) << cx0 : 0u;   // (the block may miss the tile)
+    uint32_t mm = 0u;
+    rowrank = 0u;
+#pragma unroll
+    for (int cy = 0; cy < 4; ++cy) {
+        const int sh = (oy + cy) * nbx + ox;         // bit of the block mask that is cell (cx = 0, cy) of the window
+        uint32_t nib = dense ? xmask : (uint32_t)(sh >= 0 ? (cm >> (sh & 63)) : (cm << ((-sh) & 63))) & xmask;
+        nib = (cy >= cy0 && cy < cy1) ? nib : 0u;
+        mm |= ((nib & 3u) | ((nib & 12u) << 2)) << (8 * (cy >> 1) + 2 * (cy & 1));
+        // rank of the row's first reached cell: its index in a dense block, else the number of reached cells before it
+        const int first = sh + (nib ? __builtin_ctz(nib) : 0);
+        const uint32_t rk = dense ? (uint32_t)max(first, 0) : (uint32_t)__popcll(cm & ((1ull << (first & 63)) - 1ull));
+        rowrank |= min(rk, kRankBig) << (8 * cy);
+    }
+    return mm;
+}
+// ids[0 .. n): the tile's sorted Gaussian ids (LDS); rec[0 .. n): 8-byte scratch per entry (LDS); kSortThreads / 64 waves
+template <int kSortThreads>
+__device__ __forceinline__ void finish_tile_lds(const ViewCtx &c, const int tile, const uint32_t s, const uint32_t n,
+                                                const uint32_t *ids, uint2 *rec)
+{
+    constexpr int kWaves = kSortThreads / 64;
+    static_assert(kCells % kWaves == 0 || kWaves > kCells, "cells are dealt to the waves");
+    const GeomPtrs &g = c.g;
+    const BinPtrs &b = c.b;
+    const uint32_t cap = c.cap;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int tx = tile % c.vp.gx, ty = tile / c.vp.gx;
+    // ---- phase A: a thread per entry ----
+    for (uint32_t e = tid; e < n; e += kSortThreads) {
+        const uint32_t gid = ids[e];
+        const uint4 ci = g.cellinfo[gid];
+        const uint64_t cm = g.cellmask[gid];      // only meaningful when the block is not dense
+        uint32_t rr;
+        const uint32_t mm = tile_cell_mask(ci, cm, tx, ty, rr);
+        rec[e] = make_uint2(mm, rr);
+        b.point_list[s + e] = gid;
+    }
+    __syncthreads();
+    // ---- phase B: wave wv takes the cells k = wv, wv + kWaves, ...; 64 entries at a time, every one of the wave's cells per step
+    //      (one LDS read of the entry's record serves them all) ----
+    constexpr int kPer = (kCells + kWaves - 1) / kWaves;      // cells per wave: 4 (256 threads), 1 (1024 threads)
+    uint32_t base[kPer], below[kPer];
+    int ksh[kPer], cysh[kPer];
+#pragma unroll
+    for (int i = 0; i < kPer; ++i) {
+        const int k = min(wv + kWaves * i, kCells - 1);
+        const int qd = k >> 2, r4 = k & 3;
+        const int cx = 2 * (qd & 1) + (r4 & 1), cy = 2 * (qd >> 1) + (r4 >> 1);      // the cell's column / row in the tile's window
+        // bits of the mask that are the cells of row cy LEFT of column cx (the mask is in cell-id order: columns 0..3 of row cy sit at
+        // bit 8 (cy >> 1) + 2 (cy & 1) + {0, 1, 4, 5})
+        const uint32_t colbits = cx == 0 ? 0u : cx == 1 ? 1u : cx == 2 ? 3u : 0x13u;
+        below[i] = colbits << (8 * (cy >> 1) + 2 * (cy & 1));
+        base[i] = 0u;
+        ksh[i] = k;
+        cysh[i] = 8 * cy;
+    }
+    for (uint32_t e0 = 0; e0 < n; e0 += 64u) {
+        const uint32_t e = e0 + (uint32_t)lane;
+        const uint2 r = e < n ? rec[e] : make_uint2(0u, 0u);
+        const uint32_t id = e < n ? ids[e] : 0u;
+#pragma unroll
+        for (int i = 0; i < kPer; ++i) {
+            if (wv + kWaves * i >= kCells) continue;
+            const bool has = (r.x >> ksh[i]) & 1u;
+            const uint64_t bal = __builtin_amdgcn_ballot_w64(has);
+            if (has) {
+                const uint32_t pos = base[i] + mbcnt(bal);
+                if (s + pos < cap) {
+                    const uint32_t rank = min(((r.y >> cysh[i]) & 0xFFu) + (uint32_t)__builtin_popcount(r.x & below[i]), kRankBig);
+                    b.clist[(size_t)ksh[i] * b.cap + s + pos] = id | (rank << kGidBits);
+                    if (c.trec) b.cpos[(size_t)ksh[i] * b.cap + s + pos] = (uint16_t)min(e, 0xFFFFu);
+                }
+            }
+            base[i] += (uint32_t)__builtin_popcountll(bal);
+        }
+    }
+    if (lane == 0) {
+#pragma unroll
+        for (int i = 0; i < kPer; ++i) {
+            const int k = wv + kWaves * i;
+            if (k >= kCells) continue;
+            g.ccount[tile * kCells + k] = base[i];
+            // long cells are blended by their own kernels (raster.h, kLongCell); which slot a cell gets does not matter.
+            // The backward takes all of them (longlist); the forward only those of the tiles the LARGE variant sorts: it
+            // finishes long before the small variant, so their forward starts that much earlier.
+            const bool early = base[i] >= kLongCell && kSortThreads == 1024;
+            if (base[i] >= kWideBwd) g.longlist[atomicAdd(&g.counters[kCntLong], 1u)] = (uint32_t)(tile * kCells + k);
+            if (early) g.earlylist[atomicAdd(&g.counters[kCntLongEarly], 1u)] = (uint32_t)(tile * kCells + k);
+            g.cflag[tile * kCells + k] = early ? 1u : 0u;
+        }
+    }
+    if (c.trec && n > 0x10000u && tid == 0) g.counters[kCntRecOverflow] = 1u;   // cpos holds 16-bit tile-list positions
+}
+__device__ __forceinline__ uint32_t depth_bin(const uint32_t dz, const float zmin, const float scale, const int bins)
+{
+    return min((uint32_t)(bins - 1), (uint32_t)max(0, f2i_sat((__uint_as_float(dz) - zmin) * scale)));
+}
+
+constexpr int kFinE = 2;      // (round 4: only the HBM path -- tiles beyond the LDS capacity -- still takes this routine; 8 entries per thread cost the kernel 60 VGPRs)
 __device__ __forceinline__ uint64_t spread4(uint32_t x)   // bit i of x (< 16) -> 16-bit field i
 {
     // four copies of x at bit offsets 0, 15, 30, 45: bit i of copy i sits at 16 i
@@ -245,16 +371,17 @@ __device__ __forceinline__ void finish_tile(const ViewCtx &c, int tile, uint32_t
 }
 
 template <int kSortThreads>
-__global__ __launch_bounds__(kSortThreads, 4) void k_tile_sort(BatchDesc d)
+__global__ __launch_bounds__(kSortThreads, kSortThreads == 256 ? 6 : 4) void k_tile_sort(BatchDesc d)
 {
     constexpr int kSortLdsCap = kSortPerThread * kSortThreads;
     constexpr int kWaves = kSortThreads / 64;
     constexpr bool kIsLarge = kSortThreads == kSortLarge;
-    __shared__ uint32_t s_a[kSortLdsCap];      // sorted Gaussian ids
-    __shared__ uint64_t s_b[kSortLdsCap];      // bucket-major keys
-    __shared__ uint32_t s_bin[kBins + 1];      // histogram -> bucket ends
-    __shared__ uint32_t s_cur[kBins];          // bucket starts / scatter cursors
+    __shared__ uint64_t s_b[kSortLdsCap];          // bucket-major keys; afterwards the 8-byte per-entry records of finish_tile_lds
+    __shared__ uint32_t s_fine[kSortLdsCap + 1];   // fine histogram -> fine bucket starts / cursors -> ends; afterwards the sorted ids
+    __shared__ uint32_t s_cstart[kCoarse + 1];     // coarse histogram -> coarse bucket ends
     __shared__ uint32_t s_red[2 * kWaves];
+    uint32_t *s_bin = s_fine, *s_cur = s_fine + kBins + 1;      // HBM path (tiles beyond the LDS capacity): ONE level of linear buckets, as rounds 1-3
+    static_assert(kSortLdsCap + 1 >= 2 * kBins + 1, "the HBM path's histogram and cursors borrow s_fine");
     // block -> (view, tile) in the launch order of K3: the r-th longest tile of every view, views interleaved
     const int view = (int)(blockIdx.x % (uint32_t)d.B);
     const uint32_t rank = blockIdx.x / (uint32_t)d.B;
@@ -265,7 +392,7 @@ __global__ __launch_bounds__(kSortThreads, 4) void k_tile_sort(BatchDesc d)
     if (rank >= (uint32_t)c.T) return;
     const int t = (int)g.order[rank];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    uint64_t *tr = (g_sort_trace && kIsLarge) ? g_sort_trace + 5 * (size_t)blockIdx.x : nullptr;
+    uint64_t *tr = (g_sort_trace && (kIsLarge ? g_sort_trace_variant == 0 : g_sort_trace_variant == 1)) ? g_sort_trace + 5 * (size_t)blockIdx.x : nullptr;
     if (tr && tid == 0) tr[0] = wall_clock64();
     const uint32_t s = g.tile_start[t];
     uint32_t n = g.tile_count[t];
@@ -279,6 +406,14 @@ __global__ __launch_bounds__(kSortThreads, 4) void k_tile_sort(BatchDesc d)
         return;
     }
     if (n <= (uint32_t)kSortLdsCap) {
+        // TWO-LEVEL, histogram-equalised depth buckets (round 4).  A tile of a closed surface sees a front and a back layer, each a few
+        // percent of the tile's depth range: with ONE linear map depth -> 1024 buckets over [zmin, zmax] (rounds 1-3; still the HBM path
+        // below) most entries share a few dozen buckets, and the rank step is linear in the bucket size per entry (measured: the 695
+        // tiles of 1025 .. 2048 entries of the bench scene took 84 us by themselves, 46 us now; the large variant 45 -> 34 us).
+        // Level 1: kCoarse linear buckets, histogram + scan.  Level 2: coarse bucket c is split LINEARLY into as many fine buckets as it
+        // holds entries, so the fine buckets live in the index space of the output positions (fine = start[c] + floor(frac * count[c])),
+        // a second histogram + scan over n counters gives their starts, and a fine bucket holds ~1 entry wherever the depths are locally
+        // smooth.  Both maps are monotone in the depth: bucket order = depth order, the rank step resolves the rest by the full key.
         // ---- load, min / max depth ----
         uint64_t key[kSortPerThread];
         uint32_t dmin = 0xFFFFFFFFu, dmax = 0u;
@@ -296,67 +431,97 @@ __global__ __launch_bounds__(kSortThreads, 4) void k_tile_sort(BatchDesc d)
         dmin = wave_min_u32(dmin);
         dmax = wave_max_u32(dmax);
         if (lane == 0) { s_red[wv] = dmin; s_red[kWaves + wv] = dmax; }
-        for (int i = tid; i <= kBins; i += kSortThreads) s_bin[i] = 0u;
+        for (uint32_t i = tid; i <= kCoarse; i += kSortThreads) s_cstart[i] = 0u;
+        for (uint32_t i = tid; i <= n; i += kSortThreads) s_fine[i] = 0u;
         __syncthreads();
 #pragma unroll
         for (int w = 0; w < kWaves; ++w) { dmin = min(dmin, s_red[w]); dmax = max(dmax, s_red[kWaves + w]); }
         // depths are positive floats (> 0.2), so the bit patterns order like the values
         const float zmin = __uint_as_float(dmin), zspan = __uint_as_float(dmax) - zmin;
-        const float scale = (zspan > 0.f && zspan < 3.0e38f) ? (float)kBins / zspan : 0.f;
-        uint32_t bin[kSortPerThread];
+        const float scale = (zspan > 0.f && zspan < 3.0e38f) ? (float)kCoarse / zspan : 0.f;
+        // ---- level 1: coarse histogram ----
 #pragma unroll
-        for (int r = 0; r < kSortPerThread; ++r) {
-            const uint32_t e = r * kSortThreads + tid;
-            bin[r] = 0u;
-            if (e < n) {
-                const float z = __uint_as_float((uint32_t)(key[r] >> 32));
-                bin[r] = min((uint32_t)(kBins - 1), (uint32_t)max(0, f2i_sat((z - zmin) * scale)));
-                atomicAdd(&s_bin[bin[r] + 1], 1u);
+        for (int r = 0; r < kSortPerThread; ++r)
+            if ((uint32_t)(r * kSortThreads + tid) < n) atomicAdd(&s_cstart[depth_bin((uint32_t)(key[r] >> 32), zmin, scale, kCoarse) + 1], 1u);
+        __syncthreads();
+        if (tr && tid == 0) tr[1] = wall_clock64();
+        // inclusive scan by the first wave: cstart[1 + c] = end of coarse bucket c = start of c + 1, cstart[0] = 0
+        if (tid < 64) {
+            constexpr int per = kCoarse / 64;
+            uint32_t loc[per], sum = 0;
+#pragma unroll
+            for (int i = 0; i < per; ++i) { loc[i] = s_cstart[1 + tid * per + i]; sum += loc[i]; }
+            uint32_t run = wave_incl_scan_u32(sum, lane) - sum;
+#pragma unroll
+            for (int i = 0; i < per; ++i) {
+                run += loc[i];
+                s_cstart[1 + tid * per + i] = run;
             }
         }
         __syncthreads();
-        if (tr && tid == 0) tr[1] = wall_clock64();
-        // ---- exclusive scan of the kBins counts (kBins / 256 per thread) ----
-        {
-            constexpr int per = kBins / kSortThreads;
-            uint32_t loc[per], sum = 0;
+        // ---- level 2: fine bucket = start of the coarse bucket + linear position inside it, in units of (range / count) ----
+        uint32_t fb[kSortPerThread];
 #pragma unroll
-            for (int i = 0; i < per; ++i) { loc[i] = s_bin[1 + tid * per + i]; sum += loc[i]; }
+        for (int r = 0; r < kSortPerThread; ++r) {
+            fb[r] = 0u;
+            if ((uint32_t)(r * kSortThreads + tid) < n) {
+                const float q = fmaxf(0.f, (__uint_as_float((uint32_t)(key[r] >> 32)) - zmin) * scale);      // depth in coarse-bucket units
+                const uint32_t cb = min((uint32_t)(kCoarse - 1), (uint32_t)max(0, f2i_sat(q)));              // == depth_bin(...)
+                const uint32_t lo = s_cstart[cb], cnt = s_cstart[cb + 1] - lo;
+                const uint32_t sub = min(cnt - 1u, (uint32_t)max(0, f2i_sat((q - (float)cb) * (float)cnt)));
+                fb[r] = lo + sub;
+                atomicAdd(&s_fine[fb[r] + 1], 1u);
+            }
+        }
+        __syncthreads();
+        // exclusive scan of the n fine counters in place (<= kSortPerThread consecutive counters per thread): fine[1 + f] = start of f
+        {
+            const uint32_t per = (n + kSortThreads - 1) / kSortThreads;
+            uint32_t loc[kSortPerThread], sum = 0;
+#pragma unroll
+            for (int i = 0; i < kSortPerThread; ++i) {
+                const uint32_t f = (uint32_t)tid * per + (uint32_t)i;
+                loc[i] = ((uint32_t)i < per && f < n) ? s_fine[1 + f] : 0u;
+                sum += loc[i];
+            }
             const uint32_t incl = wave_incl_scan_u32(sum, lane);
-            __syncthreads();
             if (lane == 63) s_red[wv] = incl;
             __syncthreads();
             uint32_t run = incl - sum;
             for (int w = 0; w < wv; ++w) run += s_red[w];
 #pragma unroll
-            for (int i = 0; i < per; ++i) {
-                s_cur[tid * per + i] = run;      // start of bucket tid*per+i
+            for (int i = 0; i < kSortPerThread; ++i) {
+                const uint32_t f = (uint32_t)tid * per + (uint32_t)i;
+                if ((uint32_t)i < per && f < n) s_fine[1 + f] = run;
                 run += loc[i];
-                s_bin[1 + tid * per + i] = run;  // end of that bucket == start of the next
             }
         }
         __syncthreads();
-        // ---- bucket-major scatter ----
+        // ---- bucket-major scatter: cursor of fine bucket f = fine[1 + f] (its END afterwards; its start is fine[f], fine[0] = 0) ----
 #pragma unroll
-        for (int r = 0; r < kSortPerThread; ++r) {
-            const uint32_t e = r * kSortThreads + tid;
-            if (e < n) s_b[atomicAdd(&s_cur[bin[r]], 1u)] = key[r];
-        }
+        for (int r = 0; r < kSortPerThread; ++r)
+            if ((uint32_t)(r * kSortThreads + tid) < n) s_b[atomicAdd(&s_fine[1 + fb[r]], 1u)] = key[r];
         __syncthreads();
-        // ---- rank inside the bucket by the full key, write the sorted keys ----
+        // ---- rank inside the fine bucket by the full key ----
+        uint32_t pos[kSortPerThread];
 #pragma unroll
         for (int r = 0; r < kSortPerThread; ++r) {
-            const uint32_t e = r * kSortThreads + tid;
-            if (e < n) {
-                const uint32_t lo = s_bin[bin[r]], hi = s_bin[bin[r] + 1];
+            pos[r] = 0xFFFFFFFFu;
+            if ((uint32_t)(r * kSortThreads + tid) < n) {
+                const uint32_t lo = s_fine[fb[r]], hi = s_fine[fb[r] + 1];
                 uint32_t rank = 0;
                 for (uint32_t j = lo; j < hi; ++j) rank += (s_b[j] < key[r]) ? 1u : 0u;
-                s_a[lo + rank] = (uint32_t)key[r];       // the Gaussian id is all the later stages need
+                pos[r] = lo + rank;
             }
         }
+        __syncthreads();      // every read of the cursors and of the bucket-major keys is done: their memory is reused
+        uint32_t *s_ids = s_fine;                                   // the tile's sorted Gaussian ids (all the later stages need)
+#pragma unroll
+        for (int r = 0; r < kSortPerThread; ++r)
+            if (pos[r] != 0xFFFFFFFFu) s_ids[pos[r]] = (uint32_t)key[r];
         __syncthreads();
         if (tr && tid == 0) tr[2] = wall_clock64();
-        finish_tile<kSortThreads>(c, t, s, n, [&](uint32_t e) { return s_a[e]; });
+        finish_tile_lds<kSortThreads>(c, t, s, n, s_ids, reinterpret_cast<uint2 *>(s_b));
         if (tr && tid == 0) { tr[3] = wall_clock64(); tr[4] = n; }
     } else {
         // ---- large tile: the same bucket sort with the keys resident in HBM (L2) ----

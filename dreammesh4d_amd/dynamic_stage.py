@@ -93,6 +93,8 @@ class DynamicStage:
         self.fused_image_head = True     # clamp + reference-view MSEs + the SDS views' resize as one operator (image_head.py); False: the torch composition
         self.poll_every = 8              # iterations between sync-free looks at the rasterizer's capacity counters
         self.bg6 = torch.ones(6, device=self.dev)      # training background is white (diff_sugar_rasterizer_temporal.py:96-101)
+        self.use_step_object = True      # node network + render_views through dm4d_step_* (step.py) where it applies
+        self._step_objects = {}
 
     def sample_batch(self):
         """4 frames of L without replacement (this rank's share) + cameras: the fixed reference camera and
@@ -156,6 +158,25 @@ class DynamicStage:
             rot.append(q)
         return self.arap.compute_arap_energy(torch.stack(xyz), quat_xyzw_to_matrix(torch.stack(rot), self.r.grad_mode)).sum()
 
+    def _step_object(self, B, NF):
+        """The step object for this batch shape (step.DynamicStep), or None where it does not apply: CPU tensors, a learnable
+        static appearance, per-frame scales, a second gradient source on the network's parameters within the iteration (the
+        inter-frame ARAP term: the step object installs its persistent buffers as `.grad`, it does not accumulate)."""
+        if not self.use_step_object or self.dev.type != "cuda" or self.inter_frame_reg > 0:
+            return None
+        key = (B, NF)
+        if key not in self._step_objects:
+            from .step import DynamicStep
+
+            st = self.static
+            try:
+                self._step_objects[key] = DynamicStep(self.r, self.net, self.nodes, st["q_static"], st["scales"], st["opacities"], st["rgb"],
+                                                      self.bg6, n_views=B, n_frames=NF)
+            except ValueError as e:      # a configuration outside its domain: the two-operator host path (same kernels)
+                self._step_objects[key] = None
+                self.step_object_reason = str(e)
+        return self._step_objects[key]
+
     def update_learning_rate(self, it):
         for g in self.opt.param_groups:
             g["lr"] = C(self.sched[g["name"]], 0, it, interpolation="exp")      # spatial_lr_scale = 1 (yaml:81)
@@ -171,11 +192,16 @@ class DynamicStage:
         b = self.sample_batch()
         frames_t = self.timestamps[b["frames_t_idx"]]
         self.opt.zero_grad(set_to_none=True)
-        dx, dr, ds, do = self.net.node_outputs(self.nodes, frames_t)
         u = b["unit_frame"]
         # views of the same frame share its skinning / face transform (reference: cached per timestamp within a step)
-        out = render_views(self.r, dx, dr, ds, do, st["q_static"], st["scales"], st["opacities"], st["rgb"], b["vm"], b["pm"],
-                           self.bg6, frame_index=u)
+        step = self._step_object(int(b["vm"].shape[0]), len(b["frames"]))
+        if step is not None:
+            # node network + render_views as ONE C call each way on persistent buffers (step.py: the same kernels, bit-identical)
+            out = step(frames_t.to(torch.float32).contiguous(), b["vm"].contiguous(), b["pm"].contiguous(), u)
+        else:
+            dx, dr, ds, do = self.net.node_outputs(self.nodes, frames_t)
+            out = render_views(self.r, dx, dr, ds, do, st["q_static"], st["scales"], st["opacities"], st["rgb"], b["vm"], b["pm"],
+                               self.bg6, frame_index=u)
         # (the operator folds the guidance's resize to 256 x 256 in: only at the shipped 512 x 512, where that is a 2 x 2 mean)
         fused_head = self.fused_image_head and out["color"].is_cuda and self.r.H == 512 and self.r.W == 512
         if fused_head:

@@ -30,6 +30,11 @@ def _p(t):
     return None if t is None else t.data_ptr()
 
 
+def _on(t, dev):
+    """t lives on `dev` ("cuda" without an index = the current device's tensors pass)."""
+    return t.device.type == dev.type and (dev.index is None or t.device.index is None or t.device.index == dev.index)
+
+
 class _StepFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, st, anchor, times, vm, pm, fidx):
@@ -94,7 +99,7 @@ class DynamicStep:
             self.mlp += [hd.feature_out[0].main_stream.weight, hd.feature_out[0].main_stream.bias, hd.feature_out[1].weight, hd.feature_out[1].bias]
         self.planes = [p for grid in d.grid.grids for p in grid]
         for p in self.mlp:
-            if p.dtype != torch.float32 or not p.is_contiguous() or p.device != self.dev:
+            if p.dtype != torch.float32 or not p.is_contiguous() or not _on(p, self.dev):
                 raise ValueError("deformation MLP parameters must be contiguous float32 on the renderer's device")
         self.params = [p for p in self.planes + self.mlp if p.requires_grad]
         if not self.params:
@@ -219,15 +224,16 @@ class DynamicStep:
         if self.handle is None or self.key != self._ptr_state():
             self._build()
         dev, B, NF = self.dev, self.B, self.NF
-        if times.dtype != torch.float32 or not times.is_contiguous() or times.device != dev or times.numel() != NF:
+        if times.dtype != torch.float32 or not times.is_contiguous() or not _on(times, dev) or times.numel() != NF:
             raise ValueError(f"DynamicStep: timestamps must be a contiguous float32 [{NF}] tensor on {dev}")
         for name, t_ in (("viewmats", vm), ("projmats", pm)):
-            if t_.dtype != torch.float32 or not t_.is_contiguous() or t_.device != dev or t_.numel() != 16 * B:
-                raise ValueError(f"DynamicStep: {name} must be contiguous float32 [{B},4,4] on {dev}")
+            if t_.dtype != torch.float32 or not t_.is_contiguous() or not _on(t_, dev) or t_.numel() != 16 * B:
+                raise ValueError(f"DynamicStep: {name} must be contiguous float32 [{B},4,4] on {dev}, got {tuple(t_.shape)} {t_.dtype} "
+                                 f"{t_.device} contiguous={t_.is_contiguous()}")
         if fidx is None:
             if NF != B:
                 raise ValueError("DynamicStep: frame_index is required when n_frames != n_views")
-        elif fidx.dtype != torch.int32 or not fidx.is_contiguous() or fidx.device != dev or fidx.numel() != B:
+        elif fidx.dtype != torch.int32 or not fidx.is_contiguous() or not _on(fidx, dev) or fidx.numel() != B:
             raise ValueError(f"DynamicStep: frame_index must be a contiguous int32 [{B}] tensor on {dev}")
         self.serial += 1
         self._keep = (times, vm, pm, fidx)        # the library reads them again in the backward

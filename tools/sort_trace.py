@@ -1,6 +1,7 @@
 """Phase timing of k_tile_sort on the bench workload (dm4d_debug_sort_trace)."""
 import sys, numpy as np, torch
-sys.path.insert(0, '/root/repo')
+import os
+sys.path.insert(0, os.environ.get('GRAFT_REPO_ROOT', '/root/repo'))
 import bench
 from dreammesh4d_amd import _lib
 dev = torch.device('cuda:0')
@@ -24,6 +25,9 @@ for name, i, j in (("load+minmax+hist", 0, 1), ("scan+scatter+rank", 1, 2), ("fi
     print(f"  {name:20s} mean {d.mean():7.2f} us  p50 {np.percentile(d,50):7.2f}  p99 {np.percentile(d,99):7.2f}  max {d.max():7.2f}")
 n = a[:, 4]
 print("  n mean", n.mean(), "max", n.max(), " tiles > 2048:", (n > 2048).sum())
+for lo_, hi_ in ((1, 256), (256, 512), (512, 768), (768, 1024), (1024, 1536), (1536, 2049)):
+    m_ = (n >= lo_) & (n < hi_)
+    if m_.any(): print(f'  n in [{lo_},{hi_}): tiles {m_.sum()}  sort us {((a[m_,2]-a[m_,0])/100.0).mean():.1f}  finish us {((a[m_,3]-a[m_,2])/100.0).mean():.1f}')
 lg = a[n > 2048]
 if len(lg): print("  large tiles: sort us mean", ((lg[:,2]-lg[:,0])/100.0).mean(), "max", ((lg[:,2]-lg[:,0])/100.0).max(), " finish mean", ((lg[:,3]-lg[:,2])/100.0).mean(), " start us", ((lg[:,0]-t0)/100.0).round(0)[:12], " end us", ((lg[:,3]-t0)/100.0).round(0)[:12])
 big = a[np.argsort(-n)[:5]]

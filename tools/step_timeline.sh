@@ -2,7 +2,7 @@
 # Start / end of every kernel of ONE steady-state bench step relative to the step's first kernel (rocprofv3 --kernel-trace),
 # for several builds of libdm4d_hip.so on the same box:   tools/step_timeline.sh a.so b.so ...
 REPO=${GRAFT_REPO_ROOT:-/root/repo}
-cp $REPO/dreammesh4d_amd/libdm4d_hip.so /tmp/libdm4d_keep.so
+cp $REPO/dreammesh4d_amd/libdm4d_hip.so /tmp/libdm4d_keep.so; cp $REPO/dreammesh4d_amd/libdm4d_hip.so $REPO/build_cur.so 2>/dev/null
 cd /tmp && export TMPDIR=/tmp
 ALL=${ALL:-0}
 for v in "$@"; do
@@ -17,7 +17,10 @@ rows = [r for r in csv.DictReader(open(f))]
 rows.sort(key=lambda r: int(r['Start_Timestamp']))
 # steps start at k_nodenet_fwd; take the 20th from the end
 starts = [i for i, r in enumerate(rows) if 'k_nodenet_fwd' in r['Kernel_Name']]
-i0, i1 = starts[-20], starts[-19]
+# a HEADLINE step (32-byte records: k_render_bwd<6, 2>), the middle one (bench.py ends with the with-depth and full-backward legs)
+head = [k for k in range(len(starts) - 1) if any('k_render_bwd<6, 2>' in r['Kernel_Name'] for r in rows[starts[k]:starts[k + 1]])]
+k = head[len(head) // 2]
+i0, i1 = starts[k], starts[k + 1]
 t0 = int(rows[i0]['Start_Timestamp'])
 for r in rows[i0:i1]:
     n = r['Kernel_Name'].replace('void ', '').split('(')[0]
