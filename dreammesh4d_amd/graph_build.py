@@ -99,20 +99,60 @@ def _cg(L_, mat, B, x0, max_iter, tol, check_every, what):
     return x0, it
 
 
-def _tri_inverse(Lc, nb=1024):
+def _tri_inverse(Lc, nb=1024, out=None):
     """Inverse of a lower-triangular matrix by block recursion: [[A, 0], [B, C]]^-1 = [[A^-1, 0], [-C^-1 B A^-1, C^-1]] -- all the
-    work is float64 GEMM (73 TFLOP/s on MI355X); only the <= nb diagonal blocks go through a triangular solve."""
+    work is float64 GEMM (73 TFLOP/s on MI355X); only the <= nb diagonal blocks go through a triangular solve.  `out` (optional,
+    same shape, ZERO above the diagonal on entry or don't care: every element on and below the diagonal is written, the upper
+    triangle is zero-filled): the recursion writes into views of ONE result matrix instead of allocating one per level (2 V^2
+    doubles in all at the first version; at 83k vertices a V^2 matrix is 55.6 GB)."""
     n = int(Lc.shape[0])
+    if out is None:
+        out = torch.empty_like(Lc)
     if n <= nb:
-        return torch.linalg.solve_triangular(Lc, torch.eye(n, dtype=Lc.dtype, device=Lc.device), upper=False)
+        out.copy_(torch.linalg.solve_triangular(Lc, torch.eye(n, dtype=Lc.dtype, device=Lc.device), upper=False))
+        return out
     h = (n // 2 + 255) // 256 * 256          # (aligned split for the GEMMs; plain halves when that would leave nothing below)
     if h >= n:
         h = n // 2
-    out = torch.zeros_like(Lc)
-    a = out[:h, :h] = _tri_inverse(Lc[:h, :h], nb)
-    c = out[h:, h:] = _tri_inverse(Lc[h:, h:], nb)
-    out[h:, :h] = -(c @ (Lc[h:, :h] @ a))
+    out[:h, h:].zero_()
+    a = _tri_inverse(Lc[:h, :h], nb, out[:h, :h])
+    c = _tri_inverse(Lc[h:, h:], nb, out[h:, h:])
+    # -(C^-1 B A^-1) in row panels of C^-1, so that the temporaries stay at (rows x h) instead of (n - h) x h twice
+    BA = Lc[h:, :h] @ a                                       # [n - h, h]
+    rows = max(nb, (1 << 30) // max(h, 1))                    # ~8 GB of doubles per panel
+    for r0 in range(0, n - h, rows):
+        r1 = min(n - h, r0 + rows)
+        out[h + r0:h + r1, :h].copy_(c[r0:r1, :r1] @ BA[:r1])          # (C^-1 is lower triangular: columns beyond r1 are zero)
+    out[h:, :h].neg_()
     return out
+
+
+def _cholesky_lower_inplace(A, nb=4096, cb=8192):
+    """Blocked right-looking Cholesky factorisation IN PLACE: on return the lower triangle of the symmetric positive-definite
+    float64 matrix A holds L (A = L L^T), the strict upper triangle is zero.  Diagonal blocks through hipSOLVER (nb^3 / 3 each:
+    nothing), panels through a triangular solve, the trailing update -- all the flops, V^3 / 3 -- as float64 GEMMs on column blocks of
+    the LOWER part only.  torch.linalg.cholesky is out of place (a second V^2 matrix: 55.6 GB at 83k vertices) and ran at 14
+    TFLOP/s at 16.7k vertices; the GEMMs here run at ~70."""
+    n = int(A.shape[0])
+    for k in range(0, n, nb):
+        e = min(k + nb, n)
+        Lkk = torch.linalg.cholesky(A[k:e, k:e])
+        A[k:e, k:e] = Lkk
+        if e < n:
+            # panel below the diagonal block: P = A[e:, k:e] Lkk^-T
+            P = torch.linalg.solve_triangular(Lkk, A[e:, k:e].mT, upper=False).mT.contiguous()        # [n - e, nb]
+            A[e:, k:e] = P
+            for j in range(e, n, cb):                      # trailing update, lower part: A[j:, j:j+cb] -= P[j-e:] P[j-e:j-e+cb]^T
+                j1 = min(n, j + cb)
+                A[j:, j:j1].addmm_(P[j - e:], P[j - e:j1 - e].mT, alpha=-1.0)
+        del Lkk
+    # zero the strict upper triangle (it holds stale entries of A), block row by block row
+    for k in range(0, n, nb):
+        e = min(k + nb, n)
+        A[k:e, k:e].tril_()
+        if e < n:
+            A[k:e, e:].zero_()
+    return A
 
 
 def _dense_from_csr(mat, dev):
@@ -127,7 +167,7 @@ def _dense_from_csr(mat, dev):
 
 # The DENSE solver: at the sizes the reference builds graphs for (16.7k vertices) a [V, V] float64 matrix is 2.2 GB of the 288 GB
 # and the chip multiplies float64 matrices at 73 TFLOP/s, so the V heat systems and the M Poisson systems are a Cholesky
-# factorisation (0.11 s), a blocked triangular inverse (0.05 s) and GEMMs -- 0.6 s for the whole graph where the batched conjugate
+# factorisation, a blocked triangular inverse and GEMMs -- 0.6 s for the whole graph where the batched conjugate
 # gradients (csrc/heat.hip, bandwidth bound at 5 TB/s) take 3.0 s.  And it is the ACCURATE one: the heat solution decays like
 # exp(-d / sqrt(t)) -- 1e-57 across the bench mesh -- and only its direction enters, so every far-field value needs RELATIVE
 # accuracy.  Factorising (A + t L), an M-matrix up to the obtuse triangles, and multiplying its non-negative inverse factors never
@@ -135,8 +175,21 @@ def _dense_from_csr(mat, dev):
 # everything below 1e-13 arbitrary, and the Poisson step spreads that over the mesh.  Against the sparse-LU restatement at the
 # bench scale (tools/graph_check_large.py, 600 random vertices): dense 98.8 % identical neighbour sets (the rest exact ties), conjugate
 # gradients 73 %.  The conjugate gradients are therefore only what `solver="cg"` asks for explicitly (and what the small-mesh test
-# still checks); beyond DENSE_MAX_VERTICES (4 matrices of V^2 doubles = 137 GB at 65,536) `auto` refuses instead of degrading.
-DENSE_MAX_VERTICES = 65536
+# still checks).
+# Round 4: BASELINE cfg 5's mesh (166,667 faces, 83.3k vertices: 55.6 GB per V^2 matrix).  Round 3 held (A + t L)^-1 and three
+# more V^2 operators at once and refused above 65,536 vertices.  Now every factorisation is IN PLACE (_cholesky_lower_inplace), the
+# triangular inverse writes into one result matrix (_tri_inverse(out=...)), the factor is freed before the inverse is used, and the V
+# heat solutions are never held together: (A + t L)^-1[:, panel] = Li[s0:, :]^T Li[s0:, panel] (Li lower triangular: rows above the
+# panel do not contribute -- half the flops of the full product) for a panel of `chunk` sources at a time, reduced to its
+# [panel, M] scores before the next.  Peak: two V^2 matrices + panels (~125 GB at 83.3k vertices); the limit is what fits.
+DENSE_BYTES_BUDGET = 230e9           # of the 288 GB: two V^2 float64 matrices + ~15 % of panels / temporaries
+
+
+def dense_max_vertices(budget=DENSE_BYTES_BUDGET):
+    return int((budget / (2.3 * 8.0)) ** 0.5)
+
+
+DENSE_MAX_VERTICES = dense_max_vertices()       # ~111k
 
 
 def heat_geodesic_knn(verts, faces, node_xyz, K, device="cuda:0", chunk=2048, tol=1e-10, heat_tol=1e-13, stats=None, solver="auto"):
@@ -178,10 +231,9 @@ def heat_geodesic_knn(verts, faces, node_xyz, K, device="cuda:0", chunk=2048, to
         # L is singular (constants): L + (c / V) 1 1^T is positive definite and has the same solution for zero-mean right-hand sides
         Ld = _dense_from_csr(Lm, dev)
         Ld += float(Lm.diagonal().mean()) / V
-        Li = _tri_inverse(torch.linalg.cholesky(Ld))
+        _cholesky_lower_inplace(Ld)
+        g, it_p = torch.cholesky_solve(B, Ld, upper=False), 0           # M right-hand sides: two triangular solves, no inverse
         del Ld
-        g, it_p = Li.mT @ (Li @ B), 0
-        del Li
     else:
         g, it_p = _cg(L_, Lm, B, torch.zeros(V, M, **f64), max_iter=20000, tol=tol, check_every=50, what="Poisson")
     # W[3 f + c][m] = -sum_k D[f, k, c] g[faces[f, k], m]:  phi_i(t_m) = X_i^T W[:, m]
@@ -197,16 +249,20 @@ def heat_geodesic_knn(verts, faces, node_xyz, K, device="cuda:0", chunk=2048, to
     idx = torch.empty(V, K, dtype=torch.int64, device=dev)
     w = torch.empty(V, K, dtype=torch.float32, device=dev)
     it_h = 0
-    Uall = None
-    if dense:          # (A + t L)^-1, all V columns at once (symmetric: column s is the heat solution of source s)
-        Li = _tri_inverse(torch.linalg.cholesky(_dense_from_csr(Hm, dev)))
-        Uall = Li.mT @ Li
-        del Li
-        _mark("heat_dense")
+    Li = None
+    if dense:          # Li = L_H^-1 with (A + t L) = L_H L_H^T: (A + t L)^-1 = Li^T Li, taken a panel of columns at a time below
+        Hd = _dense_from_csr(Hm, dev)
+        _cholesky_lower_inplace(Hd)
+        _mark("heat_cholesky")
+        Li = _tri_inverse(Hd, out=torch.empty_like(Hd))
+        del Hd
+        _mark("heat_inverse")
     for s0 in range(0, V, chunk):
         S = min(chunk, V - s0)
         if dense:
-            U = Uall[:, s0:s0 + S].contiguous()
+            # column s of (A + t L)^-1 (symmetric) = the heat solution of source s; rows of Li above s0 vanish in these columns
+            U = torch.empty(V, S, **f64)
+            torch.matmul(Li[s0:, :].mT, Li[s0:, s0:s0 + S], out=U)
         else:
             Bh = torch.zeros(V, S, **f64)
             Bh[torch.arange(s0, s0 + S, device=dev), torch.arange(S, device=dev)] = 1.0
@@ -231,6 +287,7 @@ def heat_geodesic_knn(verts, faces, node_xyz, K, device="cuda:0", chunk=2048, to
         _mark("gemm_select")
     if stats is not None:
         stats.update(poisson_iterations=it_p, heat_iterations=it_h, t=float(t), V=V, M=M, solver="dense" if dense else "cg")
+    del Li
     return idx, w
 
 

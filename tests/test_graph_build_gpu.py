@@ -128,3 +128,44 @@ def test_dense_heat_solver_at_the_bench_scale_against_sparse_lu():
     assert same.mean() >= 0.97, same.mean()
     for i in np.nonzero(~same)[0]:           # the rest: ties in the oracle's own table
         assert abs(np.sort(d[i][idx[i]])[-1] - np.sort(d[i][o_idx[i]])[-1]) <= 1e-6 * max(1.0, np.abs(d[i]).max())
+
+
+def test_heat_graph_at_cfg5_scale_against_sparse_lu():
+    """BASELINE configs[4]'s mesh: 166,667 faces -> 83.3k vertices, 1000 nodes (custom/threestudio-dreammesh4d/geometry/
+    dynamic_sugar.py:745-861 solves per vertex at any size; round 3 refused above 65,536 vertices).  The blocked in-place dense
+    float64 solver (graph_build.py: ~125 GB at the peak) against the sparse-LU restatement of the heat method on 200 random source
+    vertices: >= 98 % identical neighbour sets, the rest ties in the oracle's own table; and within the time bar of 30 s + the
+    host-side assembly."""
+    _need_gpu()
+    import time
+
+    from dreammesh4d_amd.graph_build import DENSE_MAX_VERTICES, heat_geodesic_knn
+    from oracle import graph as G
+
+    if torch.cuda.get_device_properties(0).total_memory < 200e9:
+        pytest.skip("needs ~125 GB of device memory")
+    K = 4
+    sc = syn.mesh_bound_scene(166667, n_nodes=1000, k=K, seed=0)
+    v, f, n = np.asarray(sc["verts"], np.float64), np.asarray(sc["faces"]), np.asarray(sc["nodes"], np.float64)
+    assert 80_000 < len(v) < DENSE_MAX_VERTICES
+    stats = {}
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    idx, w = heat_geodesic_knn(sc["verts"], sc["faces"], sc["nodes"], K, "cuda:0", stats=stats)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    print(f"heat graph at V = {len(v)}: {dt:.1f} s, stages {({k: v_ for k, v_ in stats.items() if k.startswith('t_')})}, "
+          f"peak {torch.cuda.max_memory_allocated() / 1e9:.0f} GB")
+    assert stats["solver"] == "dense"
+    sub = np.sort(np.random.default_rng(0).choice(len(v), 200, replace=False))
+    node_vertex = np.array([np.argmin(np.linalg.norm(v - p, axis=1)) for p in n])
+    d = G.heat_method_distances(v, f, sub)[:, node_vertex]
+    o_idx = np.argsort(d, axis=1)[:, :K]
+    got = idx.cpu().numpy()[sub]
+    same = np.array([set(a) == set(b) for a, b in zip(got.tolist(), o_idx.tolist())])
+    assert same.mean() >= 0.98, same.mean()
+    for i in np.nonzero(~same)[0]:           # the rest: ties in the oracle's own table
+        assert abs(np.sort(d[i][got[i]])[-1] - np.sort(d[i][o_idx[i]])[-1]) <= 1e-6 * max(1.0, np.abs(d[i]).max())
+    wn = w.cpu().numpy()
+    assert np.isfinite(wn).all() and np.abs(wn.sum(1) - 1.0).max() < 1e-5 and all(len(set(r)) == K for r in got.tolist())
+    assert dt < 60.0, dt            # (the bar is 30 s of device work; the scipy assembly of the operators on the host is in dt too)

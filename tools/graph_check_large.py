@@ -10,8 +10,10 @@ from dreammesh4d_amd.graph_build import heat_geodesic_knn
 from oracle import graph as G
 
 n_sub = int(sys.argv[1]) if len(sys.argv) > 1 else 600
+n_faces = int(sys.argv[2]) if len(sys.argv) > 2 else 33334           # 166667: BASELINE cfg 5's mesh (83.3k vertices)
+solvers = sys.argv[3].split(",") if len(sys.argv) > 3 else ["dense", "cg"]
 K = 4
-sc = syn.mesh_bound_scene(33334, n_nodes=1000, k=K, seed=0)
+sc = syn.mesh_bound_scene(n_faces, n_nodes=1000, k=K, seed=0)
 v, f, n = np.asarray(sc["verts"], np.float64), np.asarray(sc["faces"]), np.asarray(sc["nodes"], np.float64)
 V = len(v)
 sub = np.sort(np.random.default_rng(0).choice(V, n_sub, replace=False))
@@ -20,8 +22,12 @@ t0 = time.perf_counter()
 d = G.heat_method_distances(v, f, sub)[:, node_vertex]                   # [n_sub, M]
 print(f"oracle: {n_sub} sources in {time.perf_counter() - t0:.1f} s")
 o_idx = np.argsort(d, axis=1)[:, :K]
-for solver in ("dense", "cg"):
-    idx, w = heat_geodesic_knn(sc["verts"], sc["faces"], sc["nodes"], K, "cuda:0", solver=solver)
+for solver in solvers:
+    stats = {}
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    idx, w = heat_geodesic_knn(sc["verts"], sc["faces"], sc["nodes"], K, "cuda:0", solver=solver, stats=stats)
+    torch.cuda.synchronize()
+    print(f"{solver}: V = {V}, {time.perf_counter() - t0:.2f} s, peak memory {torch.cuda.max_memory_allocated() / 1e9:.1f} GB, stages {({k: v for k, v in stats.items() if k.startswith('t_')})}")
     idx = idx.cpu().numpy()[sub]
     same = np.array([set(a) == set(b) for a, b in zip(idx.tolist(), o_idx.tolist())])
     # where they differ: how far apart (in the oracle's own distances) are the swapped nodes?
