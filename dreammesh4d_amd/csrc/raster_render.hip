@@ -531,8 +531,10 @@ struct EntryRegs {
 
 // Pixels P and P + 1 of the cell for the lane's entry (two independent chains side by side: the dependent DPP steps of
 // one hide behind the other).  acc: the lane's record.  tab: the row's (WIDE: wave's) pixel table.
+// running sums of the moments of q = dL/dG G over the cell's pixels (i, j in 0..3): the current row's and the cell's
+struct Moments { float r0, r1, r2, S0, Si, Sii, Sj, Sjj, Sij; };
 template <int C, int LEAN, bool WIDE, int P>
-__device__ __forceinline__ void pixel_pair(const EntryRegs<C> &e, float (&acc)[13], const bool front_lane, float *tab)
+__device__ __forceinline__ void pixel_pair(const EntryRegs<C> &e, float (&acc)[13], Moments &mo, const bool front_lane, float *tab)
 {
     constexpr int LN = PixTab<C>::kLine;
     float pw[2], G[2], araw[2], a[2], am[2], om[2], Pinc[2], Pexc[2], V[2], Tb[2], inv_om[2], w[2], Sinc[2], Sexc[2], Stot[2];
@@ -612,14 +614,18 @@ __device__ __forceinline__ void pixel_pair(const EntryRegs<C> &e, float (&acc)[1
     }
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
-        const int i = (P + h) & 3, j = (P + h) >> 2;
+        const int i = (P + h) & 3;
         const float dL_da = Tb[h] * V[h] - Stot[h] * inv_om[h];
         const float q = dL_da * am[h];                       // dL/dG G = (opacity dL/dalpha) G
-        const float qx = q * e.dx[i], qy = q * e.dy[j];
-        acc[0] += qx; acc[1] += qy;
-        acc[2] = __builtin_fmaf(qx, e.dx[i], acc[2]);
-        acc[3] = __builtin_fmaf(qx, e.dy[j], acc[3]);
-        acc[4] = __builtin_fmaf(qy, e.dy[j], acc[4]);
+        // Moments of q in the CELL's own pixel coordinates (i, j in 0..3), a row of four pixels at a time: r0 = sum q, r1 = sum i q,
+        // r2 = sum i^2 q (the factors are literals: 2.5 instructions per pixel), folded into S0, Si, Sii, Sj, Sjj, Sij when the row is
+        // complete (cell_pixels) and re-centred on the Gaussian once per chunk (finish_moments) -- 3.8 instructions per pixel where
+        // sum q (dx, dy, dx^2, dx dy, dy^2) with the entry's own offsets took 7 (round 4; this kernel's time is its VALU instruction count)
+        if (i == 0) mo.r0 = q;                               // (a row starts: no zero fill, no add)
+        else mo.r0 += q;
+        if (i == 1) { mo.r1 = q; mo.r2 = q; }
+        if (i == 2) { mo.r1 = __builtin_fmaf(2.f, q, mo.r1); mo.r2 = __builtin_fmaf(4.f, q, mo.r2); }
+        if (i == 3) { mo.r1 = __builtin_fmaf(3.f, q, mo.r1); mo.r2 = __builtin_fmaf(9.f, q, mo.r2); }
         if constexpr (LEAN == 2) {       // no depth gradient: 8 values
             acc[5] = __builtin_fmaf(w[h], g[h][3], acc[5]);
             acc[6] = __builtin_fmaf(w[h], g[h][4], acc[6]);
@@ -630,7 +636,7 @@ __device__ __forceinline__ void pixel_pair(const EntryRegs<C> &e, float (&acc)[1
             acc[7] = __builtin_fmaf(w[h], g[h][4], acc[7]);
             acc[8] = __builtin_fmaf(w[h], g[h][5], acc[8]);
         } else {
-            acc[5] += q;                                     // sum q = opacity * dL/dopacity: B2 divides by the opacity
+            // (sum q = opacity * dL/dopacity, B2 divides by the opacity: it is S0 of the moments, finish_moments)
             acc[6] = __builtin_fmaf(w[h], gD[h], acc[6]);
 #pragma unroll
             for (int ch = 0; ch < C; ++ch) acc[7 + ch] = __builtin_fmaf(w[h], g[h][ch], acc[7 + ch]);
@@ -639,23 +645,45 @@ __device__ __forceinline__ void pixel_pair(const EntryRegs<C> &e, float (&acc)[1
     // pin the pair's accumulations HERE: volatile asm statements keep their order, so without this the compiler sinks the
     // tails of all eight pairs below the last scan (they only feed `acc`) and keeps ~8 values per pair alive until then
     // (147 VGPRs instead of ~80)
-    asm volatile("" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]), "+v"(acc[4]), "+v"(acc[5]), "+v"(acc[6]), "+v"(acc[7]), "+v"(acc[8]));
+    asm volatile("" : "+v"(mo.r0), "+v"(mo.r1), "+v"(mo.r2), "+v"(acc[5]), "+v"(acc[6]), "+v"(acc[7]), "+v"(acc[8]));      // (pins the pair's tail here, see above)
     if (!LEAN) asm volatile("" : "+v"(acc[9]), "+v"(acc[C > 3 ? 10 : 9]), "+v"(acc[C > 3 ? 11 : 9]), "+v"(acc[C > 3 ? 12 : 9]));
+    if constexpr ((P & 3) == 2) {      // the row j = P >> 2 of the cell is complete
+        constexpr int j = P >> 2;
+        mo.S0 += mo.r0; mo.Si += mo.r1; mo.Sii += mo.r2;
+        if (j == 1) { mo.Sj += mo.r0; mo.Sjj += mo.r0; mo.Sij += mo.r1; }
+        if (j > 1) {
+            mo.Sj = __builtin_fmaf((float)j, mo.r0, mo.Sj);
+            mo.Sjj = __builtin_fmaf((float)(j * j), mo.r0, mo.Sjj);
+            mo.Sij = __builtin_fmaf((float)j, mo.r1, mo.Sij);
+        }
+        asm volatile("" : "+v"(mo.S0), "+v"(mo.Si), "+v"(mo.Sii), "+v"(mo.Sj), "+v"(mo.Sjj), "+v"(mo.Sij));
+    }
 }
 #undef DM4D_RM
 
-// the 16 pixels of the cell for the lane's entry
+// the 16 pixels of the cell for the lane's entry; acc[0..4] (and acc[5] of the full records) come out of the moments at the end:
+// with dx_i = X - i, dy_j = Y - j (X = e.dx[0], Y = e.dy[0]: the offsets of a cell's pixels differ by exact integers, load_entry)
+//   sum q dx = X S0 - Si,  sum q dy = Y S0 - Sj,  sum q dx^2 = X (X S0 - 2 Si) + Sii,  sum q dx dy = X (Y S0 - Sj) - Y Si + Sij,
+//   sum q dy^2 = Y (Y S0 - 2 Sj) + Sjj
 template <int C, int LEAN, bool WIDE>
 __device__ __forceinline__ void cell_pixels(const EntryRegs<C> &e, float (&acc)[13], const bool front_lane, float *tab)
 {
-    pixel_pair<C, LEAN, WIDE, 0>(e, acc, front_lane, tab);
-    pixel_pair<C, LEAN, WIDE, 2>(e, acc, front_lane, tab);
-    pixel_pair<C, LEAN, WIDE, 4>(e, acc, front_lane, tab);
-    pixel_pair<C, LEAN, WIDE, 6>(e, acc, front_lane, tab);
-    pixel_pair<C, LEAN, WIDE, 8>(e, acc, front_lane, tab);
-    pixel_pair<C, LEAN, WIDE, 10>(e, acc, front_lane, tab);
-    pixel_pair<C, LEAN, WIDE, 12>(e, acc, front_lane, tab);
-    pixel_pair<C, LEAN, WIDE, 14>(e, acc, front_lane, tab);
+    Moments mo = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    pixel_pair<C, LEAN, WIDE, 0>(e, acc, mo, front_lane, tab);
+    pixel_pair<C, LEAN, WIDE, 2>(e, acc, mo, front_lane, tab);
+    pixel_pair<C, LEAN, WIDE, 4>(e, acc, mo, front_lane, tab);
+    pixel_pair<C, LEAN, WIDE, 6>(e, acc, mo, front_lane, tab);
+    pixel_pair<C, LEAN, WIDE, 8>(e, acc, mo, front_lane, tab);
+    pixel_pair<C, LEAN, WIDE, 10>(e, acc, mo, front_lane, tab);
+    pixel_pair<C, LEAN, WIDE, 12>(e, acc, mo, front_lane, tab);
+    pixel_pair<C, LEAN, WIDE, 14>(e, acc, mo, front_lane, tab);
+    const float X = e.dx[0], Y = e.dy[0];
+    acc[0] = __builtin_fmaf(X, mo.S0, -mo.Si);
+    acc[1] = __builtin_fmaf(Y, mo.S0, -mo.Sj);
+    acc[2] = __builtin_fmaf(X, __builtin_fmaf(X, mo.S0, -2.f * mo.Si), mo.Sii);
+    acc[3] = __builtin_fmaf(X, __builtin_fmaf(Y, mo.S0, -mo.Sj), __builtin_fmaf(-Y, mo.Si, mo.Sij));
+    acc[4] = __builtin_fmaf(Y, __builtin_fmaf(Y, mo.S0, -2.f * mo.Sj), mo.Sjj);
+    if (!LEAN) acc[5] = mo.S0;
 }
 
 // backward record of a cell-list entry (raster.h, BinPtrs::clist): the Gaussian's first record + the rank K4 stored with the
