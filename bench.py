@@ -103,7 +103,9 @@ class Workload:
         # on gfx950 -- profiles/r03_tile_records.md); default: the bit-reproducible (Gaussian, cell) records
         self.renderer = views.ViewRenderer(self.graph, self.topo, H, W, self.cams[0].tanfov, method="hybrid",
                                            deterministic=os.environ.get("DM4D_TILE_RECORDS", "0") != "1")
-        self.renderer.fuse_face_backward = os.environ.get("DM4D_FUSE_FACE_BWD", "0") == "1"     # (A/B: gather + face backward as one kernel)
+        # record gather + face backward as ONE kernel with a thread per (view, Gaussian): nothing per view is materialised between the
+        # rasterizer and the mesh (round 4: -30 us per step; round 3's version looped over a frame's views per thread and lost).  A/B: =0
+        self.renderer.fuse_face_backward = os.environ.get("DM4D_FUSE_FACE_BWD", "1") == "1"
         g = torch.Generator(device="cpu").manual_seed(2)
         B = VIEWS_PER_STEP
         self.gC = torch.randn(B, 6, H, W, generator=g).to(dev)

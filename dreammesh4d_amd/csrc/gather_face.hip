@@ -2,10 +2,9 @@
 //
 // B2 (k_gather_bwd, raster_preprocess.hip) sums a Gaussian's backward records and runs the preprocess backward per (view,
 // Gaussian), writing dL/dmean3D, dL/drotation and dL/dcolour per VIEW (52 B x N x views: 83 MB per 8-view step on the bench
-// scene); k_face_bwd_face (skinning.hip) read them back, summed the views of a frame and reduced the six Gaussians of a face to
-// its corner records: 32 us of the step's serial chain.  Here a thread owns (frame, Gaussian), loops over the frame's views with
-// B2's body (same code: gather_gaussian), keeps the three gradients in registers and finishes the face (same code:
-// face_bwd_finish).  Results are bit-identical to the two-kernel path: the views are added in the same order.
+// scene); k_face_bwd_face (skinning.hip) reads them back, sums the views of a frame and reduces the six Gaussians of a face to
+// its corner records: 32 us of the step's serial chain.  Here B2's body (same code: gather_gaussian) keeps the three gradients in
+// registers and finishes the face (same code: face_bwd_finish) -- see the kernel for how the views of a frame meet.
 //
 // One translation unit with the two files whose device code it calls.
 #include "raster_preprocess.hip"
@@ -13,6 +12,11 @@
 
 namespace dm4d {
 
+// Round 4: a thread owns (VIEW, Gaussian) -- B2's own parallelism (round 3's version gave a thread a FRAME's views in a loop: half the
+// loads in flight of B2, which is bandwidth-bound: 214 us against 168 + 32 for the two kernels, and stayed off).  The face's corner
+// records are therefore per VIEW ([views][F][3][6]: 19 MB per 8-view step on the bench scene where the per-view Gaussian gradients
+// were 64 MB written and read back); the backward is linear, so k_face_bwd_vertex adds a frame's views when it sums a vertex's
+// corners.  Equal to the two-kernel path up to the order of those additions (tests/test_views_gpu.py).
 template <int PARTS>
 __global__ __launch_bounds__(kSkinThreads) void k_gather_face_bwd(BatchDesc d, int F, int G, int V, const int32_t *__restrict__ faces,
                                                                   const float *__restrict__ vxyz, const float *__restrict__ vrot,
@@ -25,24 +29,18 @@ __global__ __launch_bounds__(kSkinThreads) void k_gather_face_bwd(BatchDesc d, i
     const int fl = tid / G, sl = tid - fl * G;      // face in workgroup, slot
     const int f = blockIdx.x * faces_per_wg + fl;
     const bool live = fl < faces_per_wg && f < F;
-    const int frame = blockIdx.y;
+    const int bv = blockIdx.y;
+    const int frame = d.frame_index ? d.frame_index[bv] : bv;
     const int i = blockIdx.x * faces_per_wg * G + tid;      // == f * G + sl: the wave's Gaussians are consecutive
-    v3 gm = mk3(0, 0, 0), gn = mk3(0, 0, 0);
-    q4 go = q4{0.f, 0.f, 0.f, 0.f};
-    for (int bv = 0; bv < d.B; ++bv) {
-        if ((d.frame_index ? d.frame_index[bv] : bv) != frame) continue;       // (uniform)
-        const ViewCtx c = resolve(d, bv);
-        __syncthreads();
-        if (tid < 16) { sV[tid] = c.vp.view[tid]; sP[tid] = c.vp.proj[tid]; }
-        __syncthreads();
-        GatherOut res;
-        gather_gaussian<PARTS>(d, c, i, live, sV, sP, s_chunk[tid >> 6], res);
-        gm = gm + mk3(res.dmean[0], res.dmean[1], res.dmean[2]);
-        go = qadd(go, q4{res.drot[1], res.drot[2], res.drot[3], res.drot[0]});      // (w, x, y, z) -> (x, y, z, w)
-        gn = gn + mk3(res.dcol[3], res.dcol[4], res.dcol[5]);
-    }
+    const ViewCtx c = resolve(d, bv);
+    if (tid < 16) { sV[tid] = c.vp.view[tid]; sP[tid] = c.vp.proj[tid]; }
+    __syncthreads();
+    GatherOut res;
+    gather_gaussian<PARTS>(d, c, i, live, sV, sP, s_chunk[tid >> 6], res);
+    const v3 gm = mk3(res.dmean[0], res.dmean[1], res.dmean[2]), gn = mk3(res.dcol[3], res.dcol[4], res.dcol[5]);
+    const q4 go = q4{res.drot[1], res.drot[2], res.drot[3], res.drot[0]};      // (w, x, y, z) -> (x, y, z, w)
     face_bwd_finish(F, G, faces, vxyz + (size_t)frame * V * 3, vrot + (size_t)frame * V * 4, q_static, true, true, true, live, f, sl, fl * G,
-                    gm, go, gn, rec + (size_t)frame * F * 3 * kCornerRec, pypose);
+                    gm, go, gn, rec + (size_t)bv * F * 3 * kCornerRec, pypose);
 }
 
 // d: the backward's batch (per-view outputs dL_dmeans3D / dL_drotations / dL_dcolors NULL, dL_dmeans2D optional);
@@ -56,7 +54,8 @@ int launch_gather_face_bwd(const BatchDesc &d, int n_frames, int F, int G, int V
     if (d.C != 6) { set_error("the fused gather + face backward needs the 6-channel batch"); return DM4D_ERR_INVALID; }
     ProfScope prof_(kKGatherBwd, st);
     const int fpw = kSkinThreads / G;
-    const dim3 grid((F + fpw - 1) / fpw, n_frames);
+    (void)n_frames;
+    const dim3 grid((F + fpw - 1) / fpw, d.B);       // a workgroup row per VIEW
     if (grad_stride(d.C, d.lean) == 8)
         hipLaunchKernelGGL(k_gather_face_bwd<2>, grid, dim3(kSkinThreads), 0, st, d, F, G, V, faces, vxyz, vrot, qs, face_scratch, pypose);
     else if (grad_stride(d.C, d.lean) == 12)

@@ -724,27 +724,38 @@ __global__ __launch_bounds__(kSkinThreads) void k_face_bwd_vertex(int V, int F, 
                                                                   const float *__restrict__ rec,
                                                                   const float *__restrict__ ext_xyz,
                                                                   const float *__restrict__ ext_rot,
-                                                                  float *__restrict__ g_vxyz, float *__restrict__ g_vrot, int pypose)
+                                                                  float *__restrict__ g_vxyz, float *__restrict__ g_vrot, int pypose,
+                                                                  const int32_t *__restrict__ view_frame, int n_view_recs)
 {
+    // n_view_recs > 0 (round 4: the fused record gather + face kernel with a thread per (VIEW, Gaussian), gather_face.hip): `rec` holds
+    // one set of corner records per VIEW, [n_view_recs][F][3][6]; this frame's are those of the views b with view_frame[b] == frame
+    // (view_frame == NULL: view == frame), added in view order.  Otherwise one set per frame.
     const int gid = blockIdx.x * kSkinThreads + threadIdx.x;
     const int v = gid >> 3, c = gid & 7;
     const bool live = v < V;
+    const int frame = blockIdx.y;
     {
         const size_t bv = blockIdx.y;
         vrot += bv * V * 4;
-        rec += bv * F * 3 * kCornerRec;
+        if (n_view_recs <= 0) rec += bv * F * 3 * kCornerRec;
         g_vxyz += bv * V * 3;
         g_vrot += bv * V * 4;
         if (ext_xyz) ext_xyz += bv * V * 3;
         if (ext_rot) ext_rot += bv * V * 4;
     }
     float a[kCornerRec] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    if (live)
-        for (int e = csr_off[v] + c; e < csr_off[v + 1]; e += 8) {
-            const float2 *r = reinterpret_cast<const float2 *>(rec + (size_t)csr_item[e] * kCornerRec);
-            const float2 r0 = r[0], r1 = r[1], r2 = r[2];
-            a[0] += r0.x; a[1] += r0.y; a[2] += r1.x; a[3] += r1.y; a[4] += r2.x; a[5] += r2.y;
+    if (live) {
+        const int nb = n_view_recs > 0 ? n_view_recs : 1;
+        for (int b = 0; b < nb; ++b) {
+            if (n_view_recs > 0 && (view_frame ? view_frame[b] : b) != frame) continue;      // (uniform)
+            const float *__restrict__ rb = rec + (n_view_recs > 0 ? (size_t)b * F * 3 * kCornerRec : 0);
+            for (int e = csr_off[v] + c; e < csr_off[v + 1]; e += 8) {
+                const float2 *r = reinterpret_cast<const float2 *>(rb + (size_t)csr_item[e] * kCornerRec);
+                const float2 r0 = r[0], r1 = r[1], r2 = r[2];
+                a[0] += r0.x; a[1] += r0.y; a[2] += r1.x; a[3] += r1.y; a[4] += r2.x; a[5] += r2.y;
+            }
         }
+    }
 #pragma unroll
     for (int i = 0; i < kCornerRec; ++i) {
         a[i] = dpp_add<0xB1>(a[i]);     // lane ^ 1 (quad_perm [1,0,3,2])
@@ -829,15 +840,19 @@ int face_backward_launch(int B, int F, int G, int V, const int32_t *faces, const
     const int pypose = (G & kPypose) ? 1 : 0;
     G &= 0xff;
     ProfScope prof_(kKFaceBwd, st);
-    if (F > 0 && !(n_views < 0)) {         // n_views < 0: the corner records were already written (fused gather + face kernel)
+    // n_views < 0: the corner records were already written by the fused gather + face kernel -- -1: one set per frame; -(n + 1): one
+    // set per VIEW (n views), summed over a frame's views by the vertex kernel
+    if (F > 0 && !(n_views < 0)) {
         const int fpw = kSkinThreads / G;      // faces per workgroup (one thread per Gaussian)
         hipLaunchKernelGGL(k_face_bwd_face, dim3((F + fpw - 1) / fpw, B), dim3(kSkinThreads), 0, st, F, G,
                            V, faces, vxyz, vrot, qs, g_means, g_rots, g_normals, nstride, scratch, frame_index, n_views, pypose);
         DM4D_HIP_CHECK(hipGetLastError());
     }
     if (V > 0) {
+        const int n_view_recs = n_views < -1 ? -n_views - 1 : 0;
         hipLaunchKernelGGL(k_face_bwd_vertex, dim3((8 * V + kSkinThreads - 1) / kSkinThreads, B), dim3(kSkinThreads), 0, st, V,
-                           F, csr_off, csr_items, vrot, (const float *)scratch, ext_xyz, ext_rot, o_vxyz, o_vrot, pypose);
+                           F, csr_off, csr_items, vrot, (const float *)scratch, ext_xyz, ext_rot, o_vxyz, o_vrot, pypose,
+                           frame_index, n_view_recs);
         DM4D_HIP_CHECK(hipGetLastError());
     }
     return DM4D_OK;

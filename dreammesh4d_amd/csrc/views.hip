@@ -209,7 +209,7 @@ int dm4d_views_backward(const dm4d_views *v, const dm4d_views_grads *gr, dm4d_st
     rc = face_backward_launch(NF, v->F, v->G | (v->method & 0x100), v->V, v->faces, v->vxyz, v->vrot, v->q_static, gr->dL_dmeans3D,
                               gr->dL_drotations, fused_face ? nullptr : gr->dL_dcolors + 3, 6, gr->vert_csr_offsets, gr->vert_csr_items,
                               (float *)gr->face_scratch, gr->dL_dvxyz_ext, gr->dL_dvrot_ext, gr->dL_dvxyz, gr->dL_dvrot,
-                              v->frame_index, fused_face ? -1 : v->B, st);
+                              v->frame_index, fused_face ? -(v->B + 1) : v->B, st);      // (fused: per-VIEW corner records, face_backward_launch)
     if (rc) return rc;
     return skin_backward_launch(NF, v->method, v->V, v->M, v->K, v->verts, v->nbr_idx, v->nbr_w, v->dx, v->dr, v->ds,
                                 v->d_opacity, gr->dL_dvxyz, gr->dL_dvrot, gr->node_csr_offsets, gr->node_csr_items,

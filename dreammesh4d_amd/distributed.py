@@ -272,8 +272,13 @@ class ShardedAdamW:
         if w == 1:
             g_shard.copy_(self.padded)
         elif gloo:
-            host = self.padded.cpu() if self.padded.is_cuda else self.padded
-            dist.all_reduce(host)
+            # (functional rehearsal: the SAME all-reduce over the SAME n elements as the replicated path, then this rank's slice.  A
+            # ring's order of additions depends on the element's position in the message, and AdamW with eps = 1e-15 turns a last-bit
+            # difference of a gradient that is rounding noise into a full +-lr step: reducing the padded buffer instead made the
+            # 8-rank sharded / replicated comparison differ by 1e-4 of the parameter scale where 2 ranks, a + b = b + a, agree to 4e-6.
+            # Over RCCL reduce-scatter and all-reduce are different algorithms: there the two optimisers agree up to that noise.)
+            host = (self.padded.cpu() if self.padded.is_cuda else self.padded.clone())
+            dist.all_reduce(host[:n])
             g_shard.copy_(host[self.lo:self.hi])
         else:
             dist.reduce_scatter_tensor(g_shard, self.padded)

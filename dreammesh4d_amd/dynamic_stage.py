@@ -94,6 +94,9 @@ class DynamicStage:
         self.poll_every = 8              # iterations between sync-free looks at the rasterizer's capacity counters
         self.bg6 = torch.ones(6, device=self.dev)      # training background is white (diff_sugar_rasterizer_temporal.py:96-101)
         self.use_step_object = True      # node network + render_views through dm4d_step_* (step.py) where it applies
+        # nothing in this loop reads the per-view Gaussian gradients: record gather + face backward as one kernel (views.ViewRenderer)
+        if hasattr(renderer, "fuse_face_backward") and all(not t.requires_grad for t in (static["scales"], static["opacities"], static["rgb"])):
+            renderer.fuse_face_backward = True
         self._step_objects = {}
 
     def sample_batch(self):

@@ -112,7 +112,8 @@ class DynamicStep:
     # ------------------------------------------------------------------ construction of the C object
     def _ptr_state(self):
         """Everything the library holds pointers to that the caller may replace (a parameter's `.data` swap, grown capacities)."""
-        return (self.r.capacity, self.r.record_capacity) + tuple(p.data_ptr() for p in self.planes) + tuple(p.data_ptr() for p in self.mlp)
+        return (self.r.capacity, self.r.record_capacity, bool(self.r.fuse_face_backward)) + tuple(p.data_ptr() for p in self.planes) + \
+            tuple(p.data_ptr() for p in self.mlp)
 
     def _build(self):
         L = _lib.lib()
@@ -138,7 +139,8 @@ class DynamicStep:
             net_scratch=torch.empty(L.dm4d_nodenet_scratch_bytes(S, M, NF, n_heads), **u8))
         node = self.node = {k: torch.empty(NF, M, dims[k], **f) for k in self.head_names}
         gnode = self.gnode = {k: torch.empty(NF, M, dims[k], **f) for k in self.head_names}
-        bw = self.bw = dict(m2=torch.empty(B, N, 3, **f), m3=torch.empty(B, N, 3, **f), rot=torch.empty(B, N, 4, **f), col=torch.empty(B, N, 6, **f),
+        pv = (lambda *sh: None) if r.fuse_face_backward else (lambda *sh: torch.empty(*sh, **f))
+        bw = self.bw = dict(m2=pv(B, N, 3), m3=pv(B, N, 3), rot=pv(B, N, 4), col=pv(B, N, 6),
                             vx=torch.empty(NF, g.V, 3, **f), vr=torch.empty(NF, g.V, 4, **f))
         # parameter gradients: persistent (installed as .grad after every backward)
         pl = [p.detach() for p in self.planes]
@@ -170,7 +172,11 @@ class DynamicStep:
         gr = d.grads
         gr.node_csr_offsets, gr.node_csr_items, gr.vert_csr_offsets, gr.vert_csr_items = _p(g.csr_off), _p(g.csr_items), _p(t.csr_off), _p(t.csr_items)
         gr.grad_scratch, gr.skin_scratch, gr.face_scratch = _p(ws["grad"]), _p(ws["skin"]), _p(ws["face"])
-        gr.dL_dmeans2D, gr.dL_dmeans3D, gr.dL_drotations, gr.dL_dcolors = _p(bw["m2"]), _p(bw["m3"]), _p(bw["rot"]), _p(bw["col"])
+        # renderer.fuse_face_backward: the per-VIEW Gaussian gradients are not materialised (record gather + face backward as one
+        # kernel, csrc/gather_face.hip); r.last_grads then only holds the vertex / node gradients
+        self.fused_face = bool(r.fuse_face_backward)
+        if not self.fused_face:
+            gr.dL_dmeans2D, gr.dL_dmeans3D, gr.dL_drotations, gr.dL_dcolors = _p(bw["m2"]), _p(bw["m3"]), _p(bw["rot"]), _p(bw["col"])
         gr.dL_dvxyz, gr.dL_dvrot = _p(bw["vx"]), _p(bw["vr"])
         gr.dL_ddx, gr.dL_ddr = _p(gnode["dx"]), _p(gnode["dr"])
         gr.dL_dds = _p(gnode["ds"]) if v.ds else None

@@ -50,10 +50,10 @@ class ViewRenderer:
         # records, gradients equal up to the order of float additions (include/dm4d.h, dm4d_views.record_mode)
         self.deterministic = bool(deterministic)
         # True: the backward does not materialise the per-VIEW Gaussian gradients (dL/dmeans3D, dL/drotations, dL/dcolors):
-        # the record gather and the face backward run as ONE kernel (csrc/gather_face.hip; bit-identical node gradients).
-        # Measured on the bench scene (tools/env_bench_long.sh, one box, 400 steps): 214 us against 168 + 32 us for the two
-        # kernels, 1.157 against 1.136 ms per step -- a thread that loops over the frame's views has half the loads in flight
-        # of two threads that take one view each, and B2 is bandwidth-bound.  Hence off by default.
+        # the record gather and the face backward run as ONE kernel (csrc/gather_face.hip), a thread per (view, Gaussian) writing
+        # per-view corner records that the vertex kernel sums (round 4; the node gradients equal the two-kernel path's up to the
+        # order of the float additions over a frame's views).  The training loops (bench.py, DynamicStage) switch it on; off by
+        # default so that `last_grads` holds every per-view gradient for callers that look at them.
         self.fuse_face_backward = False
         self.N = topo.F * topo.G
         self.capacity = max(int(capacity_factor * self.N), 1 << 16)
