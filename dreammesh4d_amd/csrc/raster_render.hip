@@ -67,18 +67,22 @@ typedef float f4v __attribute__((ext_vector_type(4)));
 constexpr int kChunk = 16;   // list entries a row stages per step (one per lane of the row)
 constexpr int kFwdPairs = 2;   // PAIRS of entries per inner-loop step of the forward
 
-// LDS layout of a staged chunk: one 32-float block per PAIR of consecutive list entries (j even, j + 1),
-// geometry interleaved across the two entries so that a ds_read_b128 delivers register pairs the packed
-// FP32 instructions (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32: two lanes' worth of work per issue slot)
-// consume directly, colours kept per entry as channel pairs for the packed accumulators:
-//   [0..3]   x_j x_j1 y_j y_j1        [4..7]  A_j A_j1 B_j B_j1      [8..11] C_j C_j1 o_j o_j1   (conic A,B,C; opacity)
-//   [12..19] entry j  : c0 c1 c2 c3 | c4 c5 depth 1.0                 [20..27] entry j + 1, same
-//   [28..35] padding
-// Strides are chosen against LDS bank conflicts (measured: 64 % of the forward's LDS cycles were conflicts
-// with 32-float pairs and 1 KB rows): 36 floats per pair spreads the 8 pairs a row stages at once over all
-// banks, 292 floats per row puts the 4 rows' broadcast reads (4 distinct addresses per instruction) on
-// disjoint bank groups.
-constexpr int kPairFloats = 36;
+// LDS layout of a staged chunk (round 4): one 52-float block per PAIR of consecutive list entries (j even, j + 1).  The lane that
+// stages an entry evaluates, ONCE for the row's 4 x 4-pixel cell, what every pixel lane computed for itself before: the offsets of the
+// cell's four pixel columns / rows from the splat and the three terms of the quadratic form,
+//     Adx2_i = (A dx_i) dx_i,  Bdx_i = B dx_i   (dx_i = x - (cell x0 + i), i = 0..3)      Cdy2_j = (C dy_j) dy_j,  dy_j   (j = 0..3)
+// so that a pixel (i, j) of the cell gets its power from TWO 16-byte reads and three packed instructions for a pair of entries,
+//     power = -0.5 (Adx2_i + Cdy2_j) - Bdx_i dy_j,
+// bit-identical to -0.5f * ((A dx) dx + (C dy) dy) - (B dx) dy evaluated per pixel (the same products in the same association; the
+// column / row offsets are the same subtractions of the same integers) -- ten packed instructions per pair before: the forward's time is
+// its VALU instruction count (profiles/r03_pmc_sq.md: 98 % VALU-busy), and 16 pixel lanes no longer repeat what one staging lane can do.
+//   [4 i .. 4 i + 3]        Adx2_i(e0) Adx2_i(e1) Bdx_i(e0) Bdx_i(e1)          i = 0..3
+//   [16 + 4 j .. + 3]       Cdy2_j(e0) Cdy2_j(e1) dy_j(e0)  dy_j(e1)           j = 0..3
+//   [32 33]                 opacity(e0) opacity(e1)       [34 35] padding
+//   [36..43] entry e0: c0 c1 c2 c3 | c4 c5 depth 1.0      [44..51] entry e1, same
+// 16 lanes of a row read 4 distinct 16-byte pieces per instruction (the colours: one); 420 floats per row keep the four rows' reads on
+// different banks.
+constexpr int kPairFloats = 52;
 constexpr int kRowFloats = (kChunk / 2) * kPairFloats + 4;
 constexpr int kPair4 = kPairFloats / 4;   // float4 per pair block
 
@@ -113,33 +117,36 @@ __device__ __forceinline__ void zero_entry(float4 (&r)[4])
 #pragma unroll
     for (int v = 0; v < 4; ++v) r[v] = make_float4(0.f, 0.f, 0.f, 0.f);
 }
-// lane li of a row stores its gathered entry into the row's chunk (pair li >> 1, half li & 1)
-__device__ __forceinline__ void stage_entry(float *row_base, int li, const float4 (&r)[4])
+// lane li of a row stores its gathered entry into the row's chunk (pair li >> 1, half li & 1); (cx0, cy0): the pixel centre of
+// the row's cell that is its column 0 / row 0
+__device__ __forceinline__ void stage_entry(float *row_base, int li, const float4 (&r)[4], const float cx0, const float cy0)
 {
     float *pb = row_base + (li >> 1) * kPairFloats;
     const int h = li & 1;
-    pb[0 + h] = r[0].x; pb[2 + h] = r[0].y; pb[4 + h] = r[0].z; pb[6 + h] = r[0].w;
-    pb[8 + h] = r[1].x; pb[10 + h] = r[1].y;
-    *reinterpret_cast<float4 *>(pb + 12 + 8 * h) = r[2];
-    *reinterpret_cast<float4 *>(pb + 16 + 8 * h) = make_float4(r[3].x, r[3].y, r[1].z, 1.0f);
+    const float x = r[0].x, y = r[0].y, A = r[0].z, B = r[0].w, C = r[1].x;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const float dx = x - (cx0 + (float)k), dy = y - (cy0 + (float)k);      // == xy - (float)pixel: the sums are exact small integers
+        pb[4 * k + h] = (A * dx) * dx;
+        pb[4 * k + 2 + h] = B * dx;
+        pb[16 + 4 * k + h] = (C * dy) * dy;
+        pb[16 + 4 * k + 2 + h] = dy;
+    }
+    pb[32 + h] = r[1].y;
+    *reinterpret_cast<float4 *>(pb + 36 + 8 * h) = r[2];
+    *reinterpret_cast<float4 *>(pb + 40 + 8 * h) = make_float4(r[3].x, r[3].y, r[1].z, 1.0f);
 }
 
-// N pairs of alphas, written step-by-step across the pairs so that the instruction stream interleaves the
-// independent dependency chains (a lone wave on a long silhouette list issues dependent VALU ops slowly).
-// Per element bit-identical to:  power = -0.5f * ((A dx) dx + (C dy) dy) - (B dx) dy;  G = det_expf(power).
+// N pairs of Gaussians G = det_expf(power), written step-by-step across the pairs so that the instruction stream interleaves the
+// independent dependency chains (a lone wave on a long silhouette list issues dependent VALU ops slowly).  ga[j] / gc[j]: the pixel's
+// column / row pieces of pair j (stage_entry).  Per element bit-identical to
+//     power = -0.5f * ((A dx) dx + (C dy) dy) - (B dx) dy;  G = det_expf(power).
 template <int N>
-__device__ __forceinline__ void pair_gauss(const f4v (&g0)[N], const f4v (&g1)[N], const f4v (&g2)[N], f2v pxf, f2v pyf,
-                                           f2v (&dx)[N], f2v (&dy)[N], f2v (&pw)[N], f2v (&G)[N])
+__device__ __forceinline__ void pair_gauss(const f4v (&ga)[N], const f4v (&gc)[N], f2v (&pw)[N], f2v (&G)[N])
 {
-    f2v u[N], v[N], w[N];
+    f2v u[N], w[N];
 #pragma unroll
-    for (int j = 0; j < N; ++j) { dx[j] = g0[j].xy - pxf; dy[j] = g0[j].zw - pyf; }
-#pragma unroll
-    for (int j = 0; j < N; ++j) { u[j] = g1[j].xy * dx[j]; v[j] = g2[j].xy * dy[j]; w[j] = g1[j].zw * dx[j]; }
-#pragma unroll
-    for (int j = 0; j < N; ++j) { u[j] = u[j] * dx[j]; v[j] = v[j] * dy[j]; w[j] = w[j] * dy[j]; }
-#pragma unroll
-    for (int j = 0; j < N; ++j) u[j] = u[j] + v[j];
+    for (int j = 0; j < N; ++j) { u[j] = ga[j].xy + gc[j].xy; w[j] = ga[j].zw * gc[j].zw; }
 #pragma unroll
     for (int j = 0; j < N; ++j) pw[j] = (f2v)(-0.5f) * u[j] - w[j];
     // det_expf (common.h), two elements per instruction where the ISA has a packed form
@@ -231,7 +238,8 @@ __global__ __launch_bounds__(64) void k_render_fwd(BatchDesc d)
     const LanePixel lp = lane_pixel(lane, tx, ty, q);
     const int px = lp.px, py = lp.py, row = lp.row, li = lp.li;
     const bool inside = px < vp.W && py < vp.H;
-    const f2v pxf = (f2v)((float)px), pyf = (f2v)((float)py);
+    const float cx0 = (float)(px - (li & 3)), cy0 = (float)(py - (li >> 2));      // the row's cell: pixel centre of its column 0 / row 0
+    const int pi4 = li & 3, pj4 = 4 + (li >> 2);                                   // this pixel's column / row piece of a pair block (float4 index)
 
     const uint32_t s = g.tile_start[tile];
     uint32_t nr = (s < cap) ? g.ccount[tile * kCells + lp.cell] : 0u;   // this row's list length
@@ -258,7 +266,7 @@ __global__ __launch_bounds__(64) void k_render_fwd(BatchDesc d)
     for (uint32_t c0 = 0; c0 < nmax; c0 += kChunk) {
         const int cnt = (c0 < nr) ? (int)min((uint32_t)kChunk, nr - c0) : 0;
         __builtin_amdgcn_wave_barrier();
-        stage_entry(row_base, li, r);
+        stage_entry(row_base, li, r, cx0, cy0);
         zero_entry(r);
         const uint32_t wcur = wnext;
         if (c0 + 2 * kChunk + (uint32_t)li < nr) wnext = list[c0 + 2 * kChunk + li];
@@ -272,21 +280,26 @@ __global__ __launch_bounds__(64) void k_render_fwd(BatchDesc d)
             // lanes that do not take an entry blend with weight 0, which leaves their accumulators
             // bit-identical; padding entries are inert.
             const f4v *P = reinterpret_cast<const f4v *>(row_base + (t >> 1) * kPairFloats);
-            f4v g0[kFwdPairs], g1[kFwdPairs], g2[kFwdPairs];
-#pragma unroll
-            for (int j = 0; j < kFwdPairs; ++j) { g0[j] = P[kPair4 * j + 0]; g1[j] = P[kPair4 * j + 1]; g2[j] = P[kPair4 * j + 2]; }
-            f2v dx[kFwdPairs], dy[kFwdPairs], pw[kFwdPairs], G[kFwdPairs], al[kFwdPairs];
-            pair_gauss<kFwdPairs>(g0, g1, g2, pxf, pyf, dx, dy, pw, G);
+            f4v ga[kFwdPairs], gc[kFwdPairs];
+            f2v op[kFwdPairs];
 #pragma unroll
             for (int j = 0; j < kFwdPairs; ++j) {
-                const f2v oa = g2[j].zw * G[j];
+                ga[j] = P[kPair4 * j + pi4];
+                gc[j] = P[kPair4 * j + pj4];
+                op[j] = *reinterpret_cast<const f2v *>(reinterpret_cast<const float *>(P + kPair4 * j) + 32);
+            }
+            f2v pw[kFwdPairs], G[kFwdPairs], al[kFwdPairs];
+            pair_gauss<kFwdPairs>(ga, gc, pw, G);
+#pragma unroll
+            for (int j = 0; j < kFwdPairs; ++j) {
+                const f2v oa = op[j] * G[j];
                 al[j] = f2v{fminf(0.99f, oa.x), fminf(0.99f, oa.y)};
             }
 #pragma unroll
             for (int j = 0; j < kFwdPairs; ++j) {
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
-                    const f4v e0 = P[kPair4 * j + 3 + 2 * h], e1 = P[kPair4 * j + 4 + 2 * h];
+                    const f4v e0 = P[kPair4 * j + 9 + 2 * h], e1 = P[kPair4 * j + 10 + 2 * h];
                     const float alpha = h ? al[j].y : al[j].x, power = h ? pw[j].y : pw[j].x;
                     const float test_T = T_ * (1.0f - alpha);
                     const bool valid = (!done) & (power <= 0.0f) & (alpha >= 1.0f / 255.0f);
