@@ -30,6 +30,8 @@
 // extra depth and alpha channels) used at
 // custom/threestudio-dreammesh4d/renderer/diff_sugar_rasterizer_temporal.py:169-178,202-211.
 // C = 6 blends the RGB pass and the normal pass of one view together (same geometry, :202-211).
+#include <stdlib.h>
+
 #include "common.h"
 #include "raster.h"
 
@@ -1193,7 +1195,8 @@ int launch_render_fwd_long(const BatchDesc &d, hipStream_t st)
 {
     const int T = ((d.W + kTile - 1) / kTile) * ((d.H + kTile - 1) / kTile);
     if (T <= 0) return DM4D_OK;
-    const int long_blocks = (min(T * kCells, kLongWaves) * d.B + 3) / 4 * 4 / 4;   // 4 waves (cells) per workgroup, a multiple of B waves in all
+    static const int long_waves = getenv("DM4D_LONG_WAVES") ? atoi(getenv("DM4D_LONG_WAVES")) : kLongWaves;      // (A/B switch)
+    const int long_blocks = (min(T * kCells, long_waves) * d.B + 3) / 4 * 4 / 4;   // 4 waves (cells) per workgroup, a multiple of B waves in all
     if (d.C <= 3) hipLaunchKernelGGL(k_render_fwd_long<3>, dim3(long_blocks), dim3(256), 0, st, d);
     else hipLaunchKernelGGL(k_render_fwd_long<6>, dim3(long_blocks), dim3(256), 0, st, d);
     DM4D_HIP_CHECK(hipGetLastError());
