@@ -152,12 +152,14 @@ __device__ __forceinline__ void pair_gauss(const f4v (&ga)[N], const f4v (&gc)[N
 #pragma unroll
     for (int j = 0; j < N; ++j) pw[j] = (f2v)(-0.5f) * u[j] - w[j];
     // det_expf (common.h), two elements per instruction where the ISA has a packed form
-    const float L2E_HI = 0x1.715476p+0f, L2E_LO = 0x1.4ae0c0p-26f;
-    f2v x[N], n[N], f[N], p[N];
+    const float L2E_HI = 0x1.715476p+0f, L2E_LO = 0x1.4ae0c0p-26f, MAGIC = 12582912.0f;
+    f2v x[N], t[N], n[N], f[N], p[N];
 #pragma unroll
-    for (int j = 0; j < N; ++j) x[j] = f2v{fmaxf(pw[j].x, -87.0f), fmaxf(pw[j].y, -87.0f)};
+    for (int j = 0; j < N; ++j) x[j] = f2v{fmaxf(pw[j].x, -86.0f), fmaxf(pw[j].y, -86.0f)};
 #pragma unroll
-    for (int j = 0; j < N; ++j) n[j] = __builtin_elementwise_rint(x[j] * (f2v)(L2E_HI));
+    for (int j = 0; j < N; ++j) t[j] = __builtin_elementwise_fma(x[j], (f2v)(L2E_HI), (f2v)(MAGIC));
+#pragma unroll
+    for (int j = 0; j < N; ++j) n[j] = t[j] - (f2v)(MAGIC);
 #pragma unroll
     for (int j = 0; j < N; ++j) f[j] = __builtin_elementwise_fma(x[j], (f2v)(L2E_HI), -n[j]);
 #pragma unroll
@@ -175,7 +177,9 @@ __device__ __forceinline__ void pair_gauss(const f4v (&ga)[N], const f4v (&gc)[N
 #pragma unroll
     for (int j = 0; j < N; ++j) p[j] = __builtin_elementwise_fma(p[j], f[j], (f2v)(1.0f));
 #pragma unroll
-    for (int j = 0; j < N; ++j) G[j] = f2v{__builtin_ldexpf(p[j].x, (int)n[j].x), __builtin_ldexpf(p[j].y, (int)n[j].y)};
+    for (int j = 0; j < N; ++j)
+        G[j] = f2v{__uint_as_float(__float_as_uint(p[j].x) + (__float_as_uint(t[j].x) << 23)),
+                   __uint_as_float(__float_as_uint(p[j].y) + (__float_as_uint(t[j].y) << 23))};
 }
 
 // block -> (view, tile, quadrant): rank in the launch order of K3 (the r-th longest tile of every view, views

@@ -100,14 +100,29 @@ typedef struct {
 /* ------------------------------------------------------------------ */
 /* deterministic exp for x <= 0 : shared arithmetic contract            */
 /* 2^f minimax (degree 6) on [-0.5,0.5]; <= 1.4 ulp                     */
+/* Round 4: the same polynomial, with the two steps the GPU paid most   */
+/* for restated in operations it has as ONE instruction each (the       */
+/* forward blend kernel's time is its instruction count):               */
+/*   n = rint(x log2 e)   ->  t = fma(x, log2e_hi, 1.5 * 2^23);         */
+/*                            n = t - 1.5 * 2^23   (exact; t's low      */
+/*                            mantissa bits hold n in two's complement) */
+/*   ldexp(p, n)          ->  bits(p) + (bits(t) << 23): n added to p's */
+/*                            exponent field (p in [0.70, 1.42], n >=   */
+/*                            -124 after the clamp at -86: no underflow)*/
+/* n is now the rounding of the EXACT product (one rounding), where     */
+/* rint(float(x log2 e)) rounded twice: results differ from round 3's   */
+/* in the last bits for some x -- both sides of every comparison use    */
+/* this function.  exp(x) for x < -86 returns exp(-86) = 4.5e-38 (was   */
+/* -87): far below any alpha >= 1/255.                                  */
 /* ------------------------------------------------------------------ */
 static inline float dm4d_expf(float x)
 {
     const float L2E_HI = 0x1.715476p+0f;   /* float(log2 e) */
     const float L2E_LO = 0x1.4ae0c0p-26f;  /* log2 e - L2E_HI */
-    x = fmaxf(x, -87.0f);
-    float t = x * L2E_HI;
-    float n = rintf(t);
+    const float MAGIC = 12582912.0f;       /* 1.5 * 2^23 */
+    x = fmaxf(x, -86.0f);
+    float t = fmaf(x, L2E_HI, MAGIC);
+    float n = t - MAGIC;
     float f = fmaf(x, L2E_HI, -n);
     f = fmaf(x, L2E_LO, f);
     float p = 0x1.446c7ep-13f;
@@ -117,7 +132,12 @@ static inline float dm4d_expf(float x)
     p = fmaf(p, f, 0x1.ebfbe0p-3f);
     p = fmaf(p, f, 0x1.62e430p-1f);
     p = fmaf(p, f, 1.0f);
-    return ldexpf(p, (int)n);
+    uint32_t pb, tb;
+    memcpy(&pb, &p, 4);
+    memcpy(&tb, &t, 4);
+    pb += tb << 23;
+    memcpy(&p, &pb, 4);
+    return p;
 }
 
 float dm4d_oracle_expf(float x) { return dm4d_expf(x); }
