@@ -1224,7 +1224,8 @@ int launch_render_bwd(const BatchDesc &d, hipStream_t st)
         return DM4D_OK;
     }
     // the long cells' blocks first (multiple of 8 of them: the regular blocks keep their XCD), then the quadrants
-    const uint32_t long_blocks = (uint32_t)(min(T * kCells, kWideWaves) * d.B);
+    static const int wide_waves = getenv("DM4D_WIDE_WAVES") ? atoi(getenv("DM4D_WIDE_WAVES")) : kWideWaves;      // (A/B switch)
+    const uint32_t long_blocks = (uint32_t)(min(T * kCells, wide_waves) * d.B);
     const dim3 grid(long_blocks + (uint32_t)blocks);
     if (d.C <= 3) hipLaunchKernelGGL((k_render_bwd<3, 0>), grid, dim3(64), 0, st, d, long_blocks);
     else if (d.lean == 2) hipLaunchKernelGGL((k_render_bwd<6, 2>), grid, dim3(64), 0, st, d, long_blocks);
