@@ -44,6 +44,7 @@ struct GnArgs {
     void *out;          // y (forward apply) | dx (backward apply)
     float *stats;       // [N, G, 2] mean, rstd
     float *partial;     // [N, splits, G, 2]
+    const void *dx_add; // backward apply: dx += dx_add (the gradient that reaches x beside the norm: a residual connection), or NULL
 };
 
 __device__ __forceinline__ float gn_sigmoid(float z) { return 1.0f / (1.0f + __expf(-z)); }
@@ -69,6 +70,7 @@ __global__ __launch_bounds__(kGnThreads) void k_groupnorm(GnArgs a)
     const size_t sample = (size_t)n * a.HW * C;
     const T *__restrict__ x = (const T *)a.x + sample;
     const T *__restrict__ dy = kBwd ? (const T *)a.dy + sample : nullptr;
+    const T *__restrict__ dxa = (MODE == kGnBwdApply && a.dx_add) ? (const T *)a.dx_add + sample : nullptr;
     const T *__restrict__ add = a.add ? (const T *)a.add + (size_t)n * a.add_stride : nullptr;
 
     // ---- prologue: the sample's group statistics, from the slabs' partial sums.  J lanes per group sum every J-th slab, lane 0
@@ -142,7 +144,7 @@ __global__ __launch_bounds__(kGnThreads) void k_groupnorm(GnArgs a)
                     k5[i] = (MODE == kGnBwdApply) ? g_d[g] : 0.f;
                 }
             }
-            auto body = [&](const V xv, const V dv, T *o) {
+            auto body = [&](const V xv, const V dv, const V rv, T *o) {
                 V ov;
 #pragma unroll
                 for (int i = 0; i < VEC; ++i) {
@@ -168,7 +170,7 @@ __global__ __launch_bounds__(kGnThreads) void k_groupnorm(GnArgs a)
                             acc2[i] = __builtin_fmaf(dz, xh, acc2[i]);
                         } else {
                             const float corr = __builtin_fmaf(xh, k5[i], k4[i]);
-                            ov[i] = (T)(k0[i] * __builtin_fmaf(dz, k2[i], -corr));
+                            ov[i] = (T)(k0[i] * __builtin_fmaf(dz, k2[i], -corr) + (float)rv[i]);
                         }
                     }
                 }
@@ -177,20 +179,21 @@ __global__ __launch_bounds__(kGnThreads) void k_groupnorm(GnArgs a)
             T *out = kStats ? nullptr : (T *)a.out + sample;
             int r = row0 + tr;
             for (; r + (kGnUnroll - 1) * rpp < row1; r += kGnUnroll * rpp) {
-                V xv[kGnUnroll], dv[kGnUnroll];
+                V xv[kGnUnroll], dv[kGnUnroll], rv[kGnUnroll];
 #pragma unroll
                 for (int u = 0; u < kGnUnroll; ++u) {
                     const size_t off = (size_t)(r + u * rpp) * C + cb;
                     xv[u] = *reinterpret_cast<const V *>(x + off);
                     dv[u] = kBwd ? *reinterpret_cast<const V *>(dy + off) : V{};
+                    rv[u] = dxa ? *reinterpret_cast<const V *>(dxa + off) : V{};
                 }
 #pragma unroll
-                for (int u = 0; u < kGnUnroll; ++u) body(xv[u], dv[u], kStats ? nullptr : out + (size_t)(r + u * rpp) * C + cb);
+                for (int u = 0; u < kGnUnroll; ++u) body(xv[u], dv[u], rv[u], kStats ? nullptr : out + (size_t)(r + u * rpp) * C + cb);
             }
             for (; r < row1; r += rpp) {
                 const size_t off = (size_t)r * C + cb;
                 body(*reinterpret_cast<const V *>(x + off), kBwd ? *reinterpret_cast<const V *>(dy + off) : V{},
-                     kStats ? nullptr : out + off);
+                     dxa ? *reinterpret_cast<const V *>(dxa + off) : V{}, kStats ? nullptr : out + off);
             }
             if (kStats) {
 #pragma unroll
@@ -414,8 +417,21 @@ extern "C" int dm4d_groupnorm_nhwc_forward(int32_t N, int32_t HW, int32_t C, int
     int rc = gn_check(N, HW, C, G, dtype, splits, x, gamma, beta, y, stats, scratch);
     if (rc != DM4D_OK || N == 0) return rc;
     if (add && add_stride != 0 && (add_stride < C || add_stride % 8 != 0)) { set_error("groupnorm: add_stride must be 0 or >= C and a multiple of 8"); return DM4D_ERR_INVALID; }
-    GnArgs a{N, HW, C, G, splits, (HW + splits - 1) / splits, silu, add_stride, eps, x, add, gamma, beta, nullptr, y, stats, scratch};
+    GnArgs a{N, HW, C, G, splits, (HW + splits - 1) / splits, silu, add_stride, eps, x, add, gamma, beta, nullptr, y, stats, scratch, nullptr};
     return dtype == DM4D_GN_F16 ? gn_launch<_Float16>(a, false, (hipStream_t)stream) : gn_launch<float>(a, false, (hipStream_t)stream);
+}
+
+extern "C" int dm4d_groupnorm_nhwc_backward_add(int32_t N, int32_t HW, int32_t C, int32_t G, int32_t dtype, const void *x,
+                                                const void *add, int32_t add_stride, const void *gamma, const void *beta,
+                                                const float *stats, int32_t silu, const void *dy, const void *dx_add, void *dx,
+                                                float *scratch, int32_t splits, dm4d_stream_t stream)
+{
+    int rc = gn_check(N, HW, C, G, dtype, splits, x, gamma, beta, dx, stats, scratch);
+    if (rc != DM4D_OK || N == 0) return rc;
+    if (!dy) { set_error("groupnorm: null pointer"); return DM4D_ERR_INVALID; }
+    if (add && add_stride != 0 && (add_stride < C || add_stride % 8 != 0)) { set_error("groupnorm: add_stride must be 0 or >= C and a multiple of 8"); return DM4D_ERR_INVALID; }
+    GnArgs a{N, HW, C, G, splits, (HW + splits - 1) / splits, silu, add_stride, 0.f, x, add, gamma, beta, dy, dx, const_cast<float *>(stats), scratch, dx_add};
+    return dtype == DM4D_GN_F16 ? gn_launch<_Float16>(a, true, (hipStream_t)stream) : gn_launch<float>(a, true, (hipStream_t)stream);
 }
 
 extern "C" int dm4d_groupnorm_nhwc_backward(int32_t N, int32_t HW, int32_t C, int32_t G, int32_t dtype, const void *x,
@@ -423,10 +439,5 @@ extern "C" int dm4d_groupnorm_nhwc_backward(int32_t N, int32_t HW, int32_t C, in
                                             const float *stats, int32_t silu,
                                             const void *dy, void *dx, float *scratch, int32_t splits, dm4d_stream_t stream)
 {
-    int rc = gn_check(N, HW, C, G, dtype, splits, x, gamma, beta, dx, stats, scratch);
-    if (rc != DM4D_OK || N == 0) return rc;
-    if (!dy) { set_error("groupnorm: null pointer"); return DM4D_ERR_INVALID; }
-    if (add && add_stride != 0 && (add_stride < C || add_stride % 8 != 0)) { set_error("groupnorm: add_stride must be 0 or >= C and a multiple of 8"); return DM4D_ERR_INVALID; }
-    GnArgs a{N, HW, C, G, splits, (HW + splits - 1) / splits, silu, add_stride, 0.f, x, add, gamma, beta, dy, dx, const_cast<float *>(stats), scratch};
-    return dtype == DM4D_GN_F16 ? gn_launch<_Float16>(a, true, (hipStream_t)stream) : gn_launch<float>(a, true, (hipStream_t)stream);
+    return dm4d_groupnorm_nhwc_backward_add(N, HW, C, G, dtype, x, add, add_stride, gamma, beta, stats, silu, dy, nullptr, dx, scratch, splits, stream);
 }

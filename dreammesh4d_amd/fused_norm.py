@@ -73,7 +73,7 @@ def is_channels_last(x):
 
 class _GroupNormNHWC(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weight, bias, add, groups, eps, silu):
+    def forward(ctx, x, weight, bias, add, groups, eps, silu, skip=False):
         N, C, H, W = x.shape
         L = _lib.lib()
         y = torch.empty_like(x)                                    # same (channels-last) strides
@@ -88,24 +88,34 @@ class _GroupNormNHWC(torch.autograd.Function):
                                                  torch.cuda.current_stream(x.device).cuda_stream), "groupnorm forward")
         ctx.save_for_backward(x, weight, bias, stats, add)
         ctx.cfg = (groups, bool(silu), S, add_stride)
+        if skip:
+            # second output: x itself (a view), for the branch that goes AROUND the norm (a ResnetBlock's residual connection): the
+            # gradient it brings back is added where dx is written, not by autograd's accumulation launch
+            ctx.set_materialize_grads(False)
+            return y, x.view_as(x)
         return y
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, d_skip=None):
         x, weight, bias, stats, add = ctx.saved_tensors
         groups, silu, S, add_stride = ctx.cfg
         N, C, H, W = x.shape
+        if dy is None:                                             # only the branch around the norm was used
+            return d_skip, None, None, None, None, None, None, None
         if not is_channels_last(dy):
             dy = dy.contiguous(memory_format=torch.channels_last)
+        if d_skip is not None and not (is_channels_last(d_skip) and d_skip.dtype == x.dtype):
+            d_skip = d_skip.to(x.dtype).contiguous(memory_format=torch.channels_last)
         L = _lib.lib()
         dx = torch.empty_like(x)
         scratch = torch.empty(N, S, groups, 2, device=x.device, dtype=torch.float32)
         with torch.cuda.device(x.device):
-            _lib.check(L.dm4d_groupnorm_nhwc_backward(N, H * W, C, groups, _DTYPES[x.dtype], x.data_ptr(),
-                                                  0 if add is None else add.data_ptr(), add_stride, weight.data_ptr(), bias.data_ptr(),
-                                                  stats.data_ptr(), int(silu), dy.data_ptr(), dx.data_ptr(), scratch.data_ptr(), S,
-                                                  torch.cuda.current_stream(x.device).cuda_stream), "groupnorm backward")
-        return dx, None, None, None, None, None, None
+            _lib.check(L.dm4d_groupnorm_nhwc_backward_add(N, H * W, C, groups, _DTYPES[x.dtype], x.data_ptr(),
+                                                      0 if add is None else add.data_ptr(), add_stride, weight.data_ptr(), bias.data_ptr(),
+                                                      stats.data_ptr(), int(silu), dy.data_ptr(), 0 if d_skip is None else d_skip.data_ptr(),
+                                                      dx.data_ptr(), scratch.data_ptr(), S,
+                                                      torch.cuda.current_stream(x.device).cuda_stream), "groupnorm backward")
+        return dx, None, None, None, None, None, None, None
 
 
 def fused_ok(module, x):
@@ -115,10 +125,11 @@ def fused_ok(module, x):
             and not (torch.is_grad_enabled() and (w.requires_grad or module.bias.requires_grad)))
 
 
-def group_norm(module, x, silu=False, add=None, float32=False):
+def group_norm(module, x, silu=False, add=None, float32=False, skip=False):
     """act(GroupNorm(x + add)), add [N, C] (per sample and channel) or [C] (per channel).  `float32`: the reference's
     GroupNorm32 (statistics and affine map evaluated in float32 around half-precision storage) -- what the HIP kernels do
-    for every input."""
+    for every input.  `skip`: returns (y, x') with x' = x for the caller's branch AROUND the norm (a residual connection): on the
+    HIP operator the gradient x' brings back is added inside the backward kernel; elsewhere x' is x."""
     if add is not None:
         C = x.shape[1]
         if add.dim() == 2 and add.shape[0] == 1 and x.shape[0] != 1:
@@ -136,8 +147,12 @@ def group_norm(module, x, silu=False, add=None, float32=False):
                 if not (add.dim() == 2 and add.stride(1) == 1 and add.stride(0) >= add.shape[1] and add.stride(0) % 8 == 0
                         and add.data_ptr() % 16 == 0) and not add.is_contiguous():
                     add = add.contiguous()
-        return _GroupNormNHWC.apply(x, module.weight, module.bias, add, module.num_groups, module.eps, silu)
+        if skip and torch.is_grad_enabled() and x.requires_grad:
+            return _GroupNormNHWC.apply(x, module.weight, module.bias, add, module.num_groups, module.eps, silu, True)
+        y = _GroupNormNHWC.apply(x, module.weight, module.bias, add, module.num_groups, module.eps, silu)
+        return (y, x) if skip else y
     _fallback("group_norm", x, "layout" if not is_channels_last(x) else "dtype/channels/trainable affine")
+    x0 = x
     if add is not None:
         x = x + add.type(x.dtype).view(-1, x.shape[1], 1, 1)
     if float32 and not (x.is_cuda and x.dtype in (torch.float16, torch.bfloat16) and module.weight.dtype == x.dtype):
@@ -145,7 +160,8 @@ def group_norm(module, x, silu=False, add=None, float32=False):
     else:
         # (half tensors on a device: the library kernel already accumulates in float32 and rounds once)
         y = F.group_norm(x, module.num_groups, module.weight, module.bias, module.eps)
-    return F.silu(y) if silu else y
+    y = F.silu(y) if silu else y
+    return (y, x0) if skip else y
 
 
 # ----------------------------------------------------------------------------- a + b + bias[c], GEGLU

@@ -556,8 +556,10 @@ class _VaeRes(nn.Module):
             self.nin_shortcut = nn.Conv2d(cin, cout, 1)
 
     def forward(self, x):
-        skip = _conv1x1(self.nin_shortcut, x) if hasattr(self, "nin_shortcut") else x
-        h = group_norm(self.norm1, x, silu=True)
+        if hasattr(self, "nin_shortcut"):
+            skip, h = _conv1x1(self.nin_shortcut, x), group_norm(self.norm1, x, silu=True)
+        else:      # (x reaches the output around norm1: that branch's gradient is added inside the norm's backward kernel)
+            h, skip = group_norm(self.norm1, x, silu=True, skip=True)
         if _fold_bias(self.conv1, h):
             h = group_norm(self.norm2, _conv3x3(self.conv1, h, bias=False), silu=True, add=self.conv1.bias)
             return _conv3x3(self.conv2, h, bias=True, residual=skip)                  # (Dropout(0) is the identity)
@@ -573,7 +575,7 @@ class _VaeAttn(nn.Module):
 
     def forward(self, x):
         B, Cc, Hh, Ww = x.shape
-        h = group_norm(self.norm, x)
+        h, x = group_norm(self.norm, x, skip=True)
         q, k, v = (_conv1x1(f, h).flatten(2).transpose(1, 2) for f in (self.q, self.k, self.v))            # b (hw) c
         if x.is_cuda and VAE_ATTENTION_BMM:
             # ONE head of 512 channels over 1024 positions: as the reference writes it (model.py AttnBlock: bmm, softmax, bmm).
@@ -721,13 +723,34 @@ class _EncodeSample(nn.Module):
         return self.model.encode_first_stage_sample((imgs * 2.0 - 1.0).to(self.dtype), noise=noise.to(self.dtype)).to(imgs.dtype)
 
 
+class _SdsStep(torch.autograd.Function):
+    """The WHOLE SDS step as one hipGraph replay (TemporalStableZero123Guidance._sds_graph): images in, loss out; the image
+    gradient was computed inside the graph (for an upstream gradient of 1) and is scaled by the upstream gradient here."""
+
+    @staticmethod
+    def forward(ctx, imgs, st):
+        st.imgs.copy_(imgs)
+        st.graph.replay()
+        st.serial += 1
+        ctx.st, ctx.serial = st, st.serial
+        return st.loss.clone(), st.grad_norm.clone()
+
+    @staticmethod
+    def backward(ctx, g_loss, g_norm):
+        st = ctx.st
+        if ctx.serial != st.serial:
+            raise RuntimeError("the SDS step's graph was replayed again before this backward: its image gradient is gone "
+                               "(call backward before the next guidance step, or construct the guidance with one_graph=False)")
+        return st.d_imgs * g_loss, None
+
+
 class TemporalStableZero123Guidance(nn.Module):
     """`temporal-stable-zero123-guidance`.  `__call__(rgb[B,H,W,3], elevation, azimuth, camera_distances,
     frame_indices, rgb_as_latents=False) -> {"loss_sds", "grad_norm", "min_step", "max_step"}`."""
 
     def __init__(self, model: Zero123, c_crossattn, c_concat, cond_elevation_deg=0.0, cond_azimuth_deg=0.0,
                  guidance_scale=3.0, min_step_percent=0.02, max_step_percent=0.98, grad_clip=None,
-                 half_precision_weights=True, use_graphs=True, channels_last=True):
+                 half_precision_weights=True, use_graphs=True, channels_last=True, one_graph=None):
         super().__init__()
         # The SDS step is ~2000 small launches (UNet forward at 32x32 latents, VAE encoder forward + backward) whose
         # shapes never change: on a HIP device both halves are captured once per batch size as hipGraphs
@@ -735,6 +758,11 @@ class TemporalStableZero123Guidance(nn.Module):
         # 30 ms eager for ~2000 launches).  Same kernels, same results; eager is used if capture is not possible.
         self.use_graphs = use_graphs
         self._unet_graphs, self._enc_graphed, self._graph_error = {}, {}, None
+        # ONE graph for the whole step (encoder forward, conditioning, noise schedule, UNet, guidance arithmetic, loss, encoder
+        # backward to the images): `_sds_graph`.  Off: the encoder and the UNet as two / three graphs with ~80 eager launches
+        # between them (the round-3 arrangement; DM4D_SDS_ONE_GRAPH=0 for an A/B).
+        self.one_graph = (os.environ.get("DM4D_SDS_ONE_GRAPH", "1") != "0") if one_graph is None else bool(one_graph)
+        self._sds_graphs = {}
         self.weights_dtype = torch.float16 if half_precision_weights else torch.float32
         self.model = model.to(self.weights_dtype)
         # NHWC activations + filters on a HIP device (module docstring); `channels_last=False` keeps the NCHW library path
@@ -803,20 +831,112 @@ class TemporalStableZero123Guidance(nn.Module):
             self._graph_error = f"{type(e).__name__}: {e}"
             return self.model.apply_model(x, t, cond)
 
+    def _camera_T(self, elevation, azimuth):
+        """The four-number relative camera embedding [B,1,4] (float32, on the device of `elevation`)."""
+        return torch.stack([torch.deg2rad((90 - elevation) - (90 - self.cond_elevation_deg)),
+                            torch.sin(torch.deg2rad(azimuth - self.cond_azimuth_deg)),
+                            torch.cos(torch.deg2rad(azimuth - self.cond_azimuth_deg)),
+                            torch.deg2rad(90 - torch.full_like(elevation, self.cond_elevation_deg))], dim=-1)[:, None, :]
+
+    def _cond_from_T(self, T, idx):
+        """T [B,1,4] in the weights' dtype on the device, idx [B] frame indices."""
+        clip_emb = self.model.cc_projection(torch.cat([self.c_crossattn[idx], T], dim=-1))
+        return {"c_crossattn": [torch.cat([torch.zeros_like(clip_emb), clip_emb], dim=0)],
+                "c_concat": [torch.cat([torch.zeros_like(self.c_concat[idx]), self.c_concat[idx]], dim=0)]}
+
     @torch.no_grad()
     def get_cond(self, elevation, azimuth, camera_distances, frame_indices=None):
         dev = self.c_crossattn.device
-        T = torch.stack([torch.deg2rad((90 - elevation) - (90 - self.cond_elevation_deg)),
-                         torch.sin(torch.deg2rad(azimuth - self.cond_azimuth_deg)),
-                         torch.cos(torch.deg2rad(azimuth - self.cond_azimuth_deg)),
-                         torch.deg2rad(90 - torch.full_like(elevation, self.cond_elevation_deg))], dim=-1)[:, None, :]
+        T = self._camera_T(elevation, azimuth)
         # (elevation / azimuth may be HOST tensors -- DynamicStage keeps them there: the four numbers are then computed on the host
         # and uploaded once, without blocking: a pageable synchronous copy would wait for everything queued on the stream)
         T = T.to(self.weights_dtype).to(dev, non_blocking=True) if T.device.type == "cpu" else T.to(dev, self.weights_dtype)
         idx = frame_indices if frame_indices is not None else torch.zeros(len(T), dtype=torch.long, device=dev)
-        clip_emb = self.model.cc_projection(torch.cat([self.c_crossattn[idx], T], dim=-1))
-        return {"c_crossattn": [torch.cat([torch.zeros_like(clip_emb), clip_emb], dim=0)],
-                "c_concat": [torch.cat([torch.zeros_like(self.c_concat[idx]), self.c_concat[idx]], dim=0)]}
+        return self._cond_from_T(T, idx)
+
+    # ---- the step as ONE graph
+    def _sds_graph(self, B, dev, clipped):
+        """Static buffers + the captured step for a batch of B views: everything between the 256 x 256 images and (loss, dL/dimages)
+        -- what `_forward` does op by op, in the same order with the same kernels, so the replay returns what the eager step
+        returns; what changes from step to step (images, the two noises, timesteps, camera embedding, frame indices, the clip
+        value) lives in the static buffers, the guidance scale is a constant of the capture (part of the key)."""
+        import types
+
+        dt = self.weights_dtype
+        st = types.SimpleNamespace(serial=0)
+        st.imgs = torch.zeros(B, 3, 256, 256, device=dev, requires_grad=True)
+        st.post = torch.zeros(B, 4, 32, 32, device=dev, dtype=dt)
+        with torch.no_grad():
+            # the noise buffer with the STRIDES the latents have (a channel slice of the NHWC moments): `randn_like(latents)` deals its
+            # numbers in memory order, so only a buffer of the same layout receives the eager step's noise element for element
+            st.noise = torch.zeros_like(self.model.encode_first_stage_sample((st.imgs * 2.0 - 1.0).to(dt), noise=st.post).to(st.imgs.dtype))
+        st.t = torch.full((B,), self.min_step, dtype=torch.long, device=dev)
+        st.T = torch.zeros(B, 1, 4, device=dev, dtype=dt)
+        st.fidx = torch.zeros(B, dtype=torch.long, device=dev)
+        st.clip = torch.ones((), device=dev)
+        scale = self.guidance_scale
+
+        def run():
+            latents = self.model.encode_first_stage_sample((st.imgs * 2.0 - 1.0).to(dt), noise=st.post).to(st.imgs.dtype)
+            with torch.no_grad():
+                cond = self._cond_from_T(st.T, st.fidx)
+                ac = self.model.alphas_cumprod[st.t].view(-1, 1, 1, 1)
+                noisy = ac.sqrt() * latents + (1 - ac).sqrt() * st.noise
+                pred = self.model.apply_model(torch.cat([noisy] * 2).to(dt), torch.cat([st.t] * 2), cond)
+                unc, cnd = pred.float().chunk(2)
+                pred = unc + scale * (cnd - unc)
+                grad = torch.nan_to_num((1 - ac) * (pred - st.noise))
+                if clipped:
+                    grad = grad.clamp(-st.clip, st.clip)
+                target = latents - grad
+            loss = 0.5 * F.mse_loss(latents, target, reduction="sum") / B
+            (d_imgs,) = torch.autograd.grad(loss, st.imgs)
+            return loss.detach(), grad.norm(), d_imgs
+
+        cur, side = torch.cuda.current_stream(dev), torch.cuda.Stream(device=dev)
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):
+            for _ in range(2):          # library handles, algorithm choices, allocator warm-up
+                run()
+        cur.wait_stream(side)
+        st.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(st.graph):
+            st.loss, st.grad_norm, st.d_imgs = run()
+        return st
+
+    def _forward_one_graph(self, x, elevation, azimuth, frame_indices, noise, t):
+        """x [B,3,256,256] float32 in [0,1] (requires grad).  The random draws are the eager step's, in its order."""
+        B, dev = int(x.shape[0]), x.device
+        clip = self.grad_clip_val
+        # host -> device inputs through FRESH pinned tensors of the caching host allocator (it keeps a block until the copy that
+        # reads it has run; a buffer of our own would be overwritten by the next step while the host runs ahead), already in the
+        # device buffer's dtype: a converting cross-device copy stages through pageable memory and blocks
+        pinned = lambda v: torch.empty(v.shape, dtype=self.weights_dtype, pin_memory=True).copy_(v)
+        post = pinned(torch.randn(B, 4, 32, 32))                         # the posterior noise: on the CPU like the reference (encode_images)
+        T = self._camera_T(elevation, azimuth)
+        key = (B, float(self.guidance_scale), clip is not None)
+        if key not in self._sds_graphs:
+            self._sds_graphs[key] = self._sds_graph(B, dev, clip is not None)
+        st = self._sds_graphs[key]
+        with torch.no_grad():
+            st.post.copy_(post, non_blocking=True)
+            st.T.copy_(pinned(T) if T.device.type == "cpu" else T, non_blocking=True)
+            if frame_indices is None:
+                st.fidx.zero_()
+            else:
+                st.fidx.copy_(frame_indices, non_blocking=True)
+            if t is None:
+                st.t.random_(self.min_step, self.max_step + 1)
+            else:
+                st.t.copy_(t)
+            if noise is None:
+                st.noise.normal_()
+            else:
+                st.noise.copy_(noise)
+            if clip is not None:
+                st.clip.fill_(float(clip))
+        loss, grad_norm = _SdsStep.apply(x, st)
+        return {"loss_sds": loss, "grad_norm": grad_norm, "min_step": self.min_step, "max_step": self.max_step}
 
     def forward(self, rgb, elevation, azimuth, camera_distances, frame_indices=None, rgb_as_latents=False,
                 noise=None, t=None, **kwargs):
@@ -832,6 +952,16 @@ class TemporalStableZero123Guidance(nn.Module):
     def _forward(self, rgb, elevation, azimuth, camera_distances, frame_indices=None, rgb_as_latents=False, noise=None, t=None):
         B = rgb.shape[0]
         x = rgb.permute(0, 3, 1, 2)
+        if (self.one_graph and self.use_graphs and not rgb_as_latents and rgb.is_cuda and rgb.requires_grad and torch.is_grad_enabled()
+                and rgb.dtype == torch.float32 and self._graph_error is None):
+            x256 = x if tuple(x.shape[-2:]) == (256, 256) else F.interpolate(x, (256, 256), mode="bilinear", align_corners=False)
+            rng = (torch.get_rng_state(), torch.cuda.get_rng_state(rgb.device))
+            try:
+                return self._forward_one_graph(x256, elevation, azimuth, frame_indices, noise, t)
+            except Exception as e:      # noqa: BLE001  (capture is an optimisation: report once, take the multi-graph / eager step)
+                self._graph_error = f"{type(e).__name__}: {e}"
+                torch.set_rng_state(rng[0])
+                torch.cuda.set_rng_state(rng[1], rgb.device)
         if rgb_as_latents:
             latents = F.interpolate(x, (32, 32), mode="bilinear", align_corners=False) * 2 - 1
         else:

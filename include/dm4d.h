@@ -205,6 +205,13 @@ int dm4d_groupnorm_nhwc_forward(int32_t N, int32_t HW, int32_t C, int32_t G, int
 int dm4d_groupnorm_nhwc_backward(int32_t N, int32_t HW, int32_t C, int32_t G, int32_t dtype, const void *x, const void *add,
                                  int32_t add_stride, const void *gamma, const void *beta, const float *stats, int32_t silu,
                                  const void *dy, void *dx, float *scratch, int32_t splits, dm4d_stream_t stream);
+/* The same with dx += dx_add [N, HW, C] (NULL: nothing added): the gradient that reaches x beside the norm -- the residual
+ * connection of a ResnetBlock (diffusionmodules/model.py:121-145: x + h(norm1(x))) -- added where dx is written instead of by a
+ * launch of its own (autograd's accumulation: 13 adds of up to 67 MB per VAE encoder backward). */
+int dm4d_groupnorm_nhwc_backward_add(int32_t N, int32_t HW, int32_t C, int32_t G, int32_t dtype, const void *x, const void *add,
+                                     int32_t add_stride, const void *gamma, const void *beta, const float *stats, int32_t silu,
+                                     const void *dy, const void *dx_add, void *dx, float *scratch, int32_t splits,
+                                     dm4d_stream_t stream);
 
 /* y[r, c] = a[r, c] + b[r, c] + bias[c] over [rows, C] (the end of a ResBlock: skip + convolution output + that convolution's
  * bias -- openaimodel.py:259-275, diffusionmodules/model.py ResnetBlock); dtype as above, C % 8 == 0 (F16) / % 4 (F32). */

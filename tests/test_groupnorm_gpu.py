@@ -82,6 +82,55 @@ def test_forward_and_input_gradient_against_float32_torch(shape, dtype):
     assert torch.isfinite(xg.grad).all()
 
 
+@pytest.mark.parametrize("dtype", [torch.float16, torch.float32])
+def test_gradient_of_the_branch_around_the_norm_is_added_in_the_backward_kernel(dtype):
+    """group_norm(..., skip=True) -> (y, x'): out = f(y) + g(x') as a ResnetBlock uses it (x + h(norm(x))).  dL/dx must be the norm's
+    input gradient PLUS the branch's, from one backward launch pair (no accumulation launch), also when only one of the two
+    outputs is used."""
+    _need_gpu()
+    from dreammesh4d_amd import fused_norm
+
+    dev = torch.device("cuda:0")
+    for shape in ((2, 128, 64, 64), (3, 512, 9, 7), (1, 320, 32, 32)):
+        N, C, H, W = shape
+        g = torch.Generator(device="cpu").manual_seed(C + H)
+        x = (torch.randn(shape, generator=g) * 1.5 - 0.3).to(dev, dtype).contiguous(memory_format=torch.channels_last)
+        m = torch.nn.GroupNorm(32, C, eps=1e-6).to(dev, dtype).requires_grad_(False)
+        with torch.no_grad():
+            m.weight.copy_(1.0 + 0.3 * torch.randn(C, generator=g))
+            m.bias.copy_(0.2 * torch.randn(C, generator=g))
+        dy = torch.randn(shape, generator=g).to(dev, dtype).contiguous(memory_format=torch.channels_last)
+        ds = torch.randn(shape, generator=g).to(dev, dtype).contiguous(memory_format=torch.channels_last)
+        xr = x.float().clone().requires_grad_(True)
+        yr = F.silu(F.group_norm(xr, 32, m.weight.float(), m.bias.float(), m.eps))
+        (yr * dy.float()).sum().backward()
+        g_norm = xr.grad.clone()
+        tol = (4e-3 if dtype == torch.float16 else 3e-5) * max(float((g_norm + ds.float()).abs().max()), 1e-3)
+        # both outputs used
+        xg = x.clone().requires_grad_(True)
+        y, xs = fused_norm.group_norm(m, xg, silu=True, skip=True)
+        assert xs.data_ptr() == xg.data_ptr() and torch.equal(y, fused_norm.group_norm(m, x, silu=True))
+        ((y * dy).sum() + (xs * ds).sum()).backward()
+        assert float((xg.grad.float() - (g_norm + ds.float())).abs().max()) <= tol
+        # equal to autograd's own accumulation of the two-launch path up to one rounding of the sum
+        xa = x.clone().requires_grad_(True)
+        ((fused_norm.group_norm(m, xa, silu=True) * dy).sum() + (xa * ds).sum()).backward()
+        assert float((xg.grad.float() - xa.grad.float()).abs().max()) <= tol
+        # only the norm / only the branch
+        xg = x.clone().requires_grad_(True)
+        y, xs = fused_norm.group_norm(m, xg, silu=True, skip=True)
+        (y * dy).sum().backward()
+        assert float((xg.grad.float() - g_norm).abs().max()) <= tol
+        xg = x.clone().requires_grad_(True)
+        y, xs = fused_norm.group_norm(m, xg, silu=True, skip=True)
+        (xs * ds).sum().backward()
+        assert torch.equal(xg.grad, ds)
+        # no grad: (y, x)
+        with torch.no_grad():
+            y, xs = fused_norm.group_norm(m, x, silu=True, skip=True)
+        assert xs is x
+
+
 def test_what_falls_back_to_torch_and_what_is_rejected():
     _need_gpu()
     from dreammesh4d_amd import _lib, fused_norm

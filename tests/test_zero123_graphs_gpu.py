@@ -20,7 +20,8 @@ def test_graphed_sds_step_equals_eager():
     cc, cat = torch.randn(L, 1, 32), torch.randn(L, 4, 32, 32)
     kw = dict(cond_elevation_deg=5.0, half_precision_weights=False)
     eager = z.TemporalStableZero123Guidance(model, cc, cat, use_graphs=False, **kw).to(dev)
-    graphed = z.TemporalStableZero123Guidance(model, cc, cat, use_graphs=True, **kw).to(dev)     # shares the weights
+    graphed = z.TemporalStableZero123Guidance(model, cc, cat, use_graphs=True, one_graph=False, **kw).to(dev)     # shares the weights
+    whole = z.TemporalStableZero123Guidance(model, cc, cat, use_graphs=True, one_graph=True, **kw).to(dev)       # the whole step as ONE graph
     el = torch.tensor([10.0, 30.0, 60.0], device=dev)
     az = torch.tensor([-40.0, 90.0, 170.0], device=dev)
     fi = torch.tensor([0, 2, 5], device=dev)
@@ -30,18 +31,59 @@ def test_graphed_sds_step_equals_eager():
         rgb0 = torch.rand(B, 64, 64, 3, generator=g).to(dev)
         noise = torch.randn(B, 4, 32, 32, generator=g).to(dev)
         t = torch.randint(20, 980, (B,), generator=g).to(dev)
-        for name, guid in (("eager", eager), ("graphed", graphed)):
+        for name, guid in (("eager", eager), ("graphed", graphed), ("whole", whole)):
             rgb = rgb0.clone().requires_grad_(True)
             torch.manual_seed(7 + step)        # the VAE posterior noise (sampled on the CPU, like the reference)
             out = guid(rgb, el, az, torch.full_like(el, 3.8), frame_indices=fi, noise=noise, t=t)
             out["loss_sds"].backward()
             res[(name, step)] = (out["loss_sds"].detach().clone(), rgb.grad.clone())
-        a, b = res[("eager", step)], res[("graphed", step)]
+        a = res[("eager", step)]
         assert torch.isfinite(a[0]) and float(a[1].abs().max()) > 0
-        assert abs(float(a[0]) - float(b[0])) <= 1e-5 * abs(float(a[0])), (step, float(a[0]), float(b[0]))
-        assert float((a[1] - b[1]).abs().max()) <= 1e-5 * float(a[1].abs().max()), step
+        for other in ("graphed", "whole"):
+            b = res[(other, step)]
+            assert abs(float(a[0]) - float(b[0])) <= 1e-5 * abs(float(a[0])), (other, step, float(a[0]), float(b[0]))
+            assert float((a[1] - b[1]).abs().max()) <= 1e-5 * float(a[1].abs().max()), (other, step)
     assert graphed._graph_error is None, graphed._graph_error
-    assert len(graphed._unet_graphs) == 1 and len(graphed._enc_graphed) == 1 and not eager._unet_graphs
+    assert whole._graph_error is None, whole._graph_error
+    assert len(graphed._unet_graphs) == 1 and len(graphed._enc_graphed) == 1 and not eager._unet_graphs and not graphed._sds_graphs
+    assert len(whole._sds_graphs) == 1 and not whole._unet_graphs and not whole._enc_graphed
+
+
+def test_whole_step_graph_draws_the_eager_steps_random_numbers_and_scales_with_the_upstream_gradient():
+    """Without explicit noise / timesteps the one-graph step consumes the generators exactly like the eager step (posterior noise
+    on the CPU generator, then t, then the noise on the device generator): same seeds, same loss.  The image gradient inside the
+    graph is for an upstream gradient of 1; a weighted loss scales it."""
+    if not torch.cuda.is_available():
+        pytest.skip("no HIP device")
+    from dreammesh4d_amd import zero123 as z
+
+    dev = torch.device("cuda:0")
+    L, B = 4, 2
+    torch.manual_seed(1)
+    model = z.Zero123(unet_kwargs=dict(model_channels=32, context_dim=32, num_heads=4), vae_kwargs=dict(ch=32))
+    for p in model.model.diffusion_model.out.parameters():
+        torch.nn.init.normal_(p, std=0.05)
+    cc, cat = torch.randn(L, 1, 32), torch.randn(L, 4, 32, 32)
+    kw = dict(cond_elevation_deg=5.0, half_precision_weights=False, grad_clip=0.5)
+    eager = z.TemporalStableZero123Guidance(model, cc, cat, use_graphs=False, **kw).to(dev)
+    whole = z.TemporalStableZero123Guidance(model, cc, cat, use_graphs=True, one_graph=True, **kw).to(dev)
+    el, az = torch.tensor([10.0, 30.0]), torch.tensor([-40.0, 90.0])          # host tensors, as DynamicStage passes them
+    fi = torch.tensor([1, 3], device=dev)
+    rgb0 = torch.rand(B, 256, 256, 3, generator=torch.Generator().manual_seed(5)).to(dev)
+    for step in range(3):
+        got = {}
+        for name, guid in (("eager", eager), ("whole", whole)):
+            guid.update_step(0, step, grad_clip=0.5 - 0.1 * step)              # a scheduled clip value: a static buffer, not a re-capture
+            rgb = rgb0.clone().requires_grad_(True)
+            torch.manual_seed(11 + step)
+            torch.cuda.manual_seed(13 + step)
+            out = guid(rgb, el, az, torch.full_like(el, 3.8), frame_indices=fi)
+            (0.25 * out["loss_sds"]).backward()
+            got[name] = (float(out["loss_sds"]), float(out["grad_norm"]), rgb.grad.clone())
+        a, b = got["eager"], got["whole"]
+        assert abs(a[0] - b[0]) <= 1e-5 * abs(a[0]) and abs(a[1] - b[1]) <= 1e-5 * abs(a[1]), (step, a[:2], b[:2])
+        assert float(a[2].abs().max()) > 0 and float((a[2] - b[2]).abs().max()) <= 1e-5 * float(a[2].abs().max()), step
+    assert whole._graph_error is None and len(whole._sds_graphs) == 1
 
 
 def test_fused_unet_path_equals_plain_forward(monkeypatch):

@@ -41,7 +41,7 @@ if "--sync-debug" in sys.argv:      # every implicit host <-> device synchronisa
     stage.iteration()
     torch.cuda.set_sync_debug_mode("default")
     torch.cuda.synchronize()
-n = 10
+n = int(os.environ.get("DM4D_ITERS", "10"))
 host = 0.0
 t0 = time.perf_counter()
 for _ in range(n):
