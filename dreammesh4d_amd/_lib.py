@@ -121,6 +121,8 @@ _SIGNATURES = {
     "dm4d_mark_visible": (C.c_int, [C.c_int32, vp, vp, vp, vp]),
     "dm4d_groupnorm_nhwc_forward": (C.c_int, [C.c_int32] * 5 + [vp, vp, C.c_int32, vp, vp, C.c_float, C.c_int32, vp, vp, vp, C.c_int32, vp]),
     "dm4d_groupnorm_nhwc_backward": (C.c_int, [C.c_int32] * 5 + [vp, vp, C.c_int32, vp, vp, vp, C.c_int32, vp, vp, vp, C.c_int32, vp]),
+    "dm4d_sds_prepare": (C.c_int, [C.c_int32] * 3 + [C.c_float] + [vp] * 17),
+    "dm4d_sds_finish": (C.c_int, [C.c_int32] * 3 + [C.c_float, C.c_float] + [vp] * 18),
     "dm4d_groupnorm_nhwc_backward_add": (C.c_int, [C.c_int32] * 5 + [vp, vp, C.c_int32, vp, vp, vp, C.c_int32, vp, vp, vp, vp, C.c_int32, vp]),
     "dm4d_add_bias_nhwc": (C.c_int, [C.c_int64, C.c_int32, C.c_int32, vp, vp, vp, vp, vp]),
     "dm4d_geglu": (C.c_int, [C.c_int64, C.c_int32, C.c_int32, vp, vp, vp]),

@@ -556,10 +556,11 @@ class _VaeRes(nn.Module):
             self.nin_shortcut = nn.Conv2d(cin, cout, 1)
 
     def forward(self, x):
+        # (x reaches the output around norm1 -- as it is or through the 1 x 1 shortcut: that branch's gradient is added inside the
+        # norm's backward kernel, fused_norm.group_norm(skip=True))
+        h, skip = group_norm(self.norm1, x, silu=True, skip=True)
         if hasattr(self, "nin_shortcut"):
-            skip, h = _conv1x1(self.nin_shortcut, x), group_norm(self.norm1, x, silu=True)
-        else:      # (x reaches the output around norm1: that branch's gradient is added inside the norm's backward kernel)
-            h, skip = group_norm(self.norm1, x, silu=True, skip=True)
+            skip = _conv1x1(self.nin_shortcut, skip)
         if _fold_bias(self.conv1, h):
             h = group_norm(self.norm2, _conv3x3(self.conv1, h, bias=False), silu=True, add=self.conv1.bias)
             return _conv3x3(self.conv2, h, bias=True, residual=skip)                  # (Dropout(0) is the identity)
@@ -686,6 +687,9 @@ class Zero123(nn.Module):
         self.scale_factor = scale_factor
         betas = torch.linspace(linear_start ** 0.5, linear_end ** 0.5, timesteps, dtype=torch.float64) ** 2
         self.register_buffer("alphas_cumprod", torch.cumprod(1.0 - betas, dim=0).float(), persistent=False)
+        # (a float32 copy that `.to(float16)` of the module does not touch: the guidance reads the schedule from its scheduler in
+        # float32 whatever the weights' precision, temporal_stable_zero123_guidance.py:156)
+        self.__dict__["_alphas_f32"] = self.alphas_cumprod.detach().clone()
 
     def apply_model(self, x_noisy, t, cond):
         """hybrid conditioning (ddpm.py:1953-1956): concat c_concat on channels, cross-attend to c_crossattn."""
@@ -763,6 +767,9 @@ class TemporalStableZero123Guidance(nn.Module):
         # between them (the round-3 arrangement; DM4D_SDS_ONE_GRAPH=0 for an A/B).
         self.one_graph = (os.environ.get("DM4D_SDS_ONE_GRAPH", "1") != "0") if one_graph is None else bool(one_graph)
         self._sds_graphs = {}
+        # the arithmetic between the networks as two HIP launches inside that graph (float16 weights; csrc/sds_glue.hip) instead
+        # of ~70 torch operators on 16 K-element tensors (DM4D_SDS_FUSED_GLUE=0 for an A/B)
+        self.fused_glue = os.environ.get("DM4D_SDS_FUSED_GLUE", "1") != "0"
         self.weights_dtype = torch.float16 if half_precision_weights else torch.float32
         self.model = model.to(self.weights_dtype)
         # NHWC activations + filters on a HIP device (module docstring); `channels_last=False` keeps the NCHW library path
@@ -776,6 +783,7 @@ class TemporalStableZero123Guidance(nn.Module):
         self.cond_elevation_deg, self.cond_azimuth_deg = cond_elevation_deg, cond_azimuth_deg
         self.guidance_scale = guidance_scale
         self.num_train_timesteps = int(model.alphas_cumprod.shape[0])
+        self.register_buffer("alphas", model.__dict__["_alphas_f32"].detach().float().cpu().clone(), persistent=False)   # `self.alphas` (:156), float32
         self.grad_clip_val = grad_clip
         self.set_min_max_steps(min_step_percent, max_step_percent)
 
@@ -838,10 +846,13 @@ class TemporalStableZero123Guidance(nn.Module):
                             torch.cos(torch.deg2rad(azimuth - self.cond_azimuth_deg)),
                             torch.deg2rad(90 - torch.full_like(elevation, self.cond_elevation_deg))], dim=-1)[:, None, :]
 
+    def _crossattn_from_T(self, T, idx):
+        clip_emb = self.model.cc_projection(torch.cat([self.c_crossattn[idx], T], dim=-1))
+        return torch.cat([torch.zeros_like(clip_emb), clip_emb], dim=0)
+
     def _cond_from_T(self, T, idx):
         """T [B,1,4] in the weights' dtype on the device, idx [B] frame indices."""
-        clip_emb = self.model.cc_projection(torch.cat([self.c_crossattn[idx], T], dim=-1))
-        return {"c_crossattn": [torch.cat([torch.zeros_like(clip_emb), clip_emb], dim=0)],
+        return {"c_crossattn": [self._crossattn_from_T(T, idx)],
                 "c_concat": [torch.cat([torch.zeros_like(self.c_concat[idx]), self.c_concat[idx]], dim=0)]}
 
     @torch.no_grad()
@@ -875,12 +886,42 @@ class TemporalStableZero123Guidance(nn.Module):
         st.fidx = torch.zeros(B, dtype=torch.long, device=dev)
         st.clip = torch.ones((), device=dev)
         scale = self.guidance_scale
+        fused = self.fused_glue and dt == torch.float16
 
-        def run():
+        def run_fused():
+            # the arithmetic between the networks as two launches (csrc/sds_glue.hip: the same expressions with the same roundings)
+            import ctypes as C_
+
+            from . import _lib
+
+            L = _lib.lib()
+            ptr = lambda v: C_.c_void_p(v.data_ptr())
+            strides = lambda v: (C_.c_int64 * 4)(*v.stride())
+            stream = torch.cuda.current_stream(dev).cuda_stream
+            moments = self.model.first_stage_model.encode_moments((st.imgs * 2.0 - 1.0).to(dt))
+            with torch.no_grad():
+                x_in = torch.empty(2 * B, 8, 32, 32, device=dev, dtype=dt).contiguous(memory_format=torch.channels_last)
+                t2 = torch.empty(2 * B, dtype=torch.long, device=dev)
+                _lib.check(L.dm4d_sds_prepare(B, 32, 32, float(self.model.scale_factor), ptr(moments), strides(moments), ptr(st.post),
+                                              strides(st.post), ptr(st.noise), strides(st.noise), ptr(st.latents), strides(st.latents),
+                                              ptr(st.t), ptr(self.alphas), ptr(self.c_concat), strides(self.c_concat),
+                                              ptr(st.fidx), ptr(x_in), strides(x_in), ptr(t2), stream), "dm4d_sds_prepare")
+                pred = self.model.model.diffusion_model(x_in, t2, context=self._crossattn_from_T(st.T, st.fidx))
+                d_mom = torch.empty_like(moments)
+                loss, gnorm = torch.empty((), device=dev), torch.empty((), device=dev)
+                _lib.check(L.dm4d_sds_finish(B, 32, 32, float(self.model.scale_factor), float(scale), ptr(pred), strides(pred),
+                                             ptr(st.latents), strides(st.latents), ptr(st.noise), strides(st.noise), ptr(st.t),
+                                             ptr(self.alphas), ptr(st.clip) if clipped else None, ptr(moments),
+                                             strides(moments), ptr(st.post), strides(st.post), ptr(d_mom), strides(d_mom), ptr(loss),
+                                             ptr(gnorm), stream), "dm4d_sds_finish")
+            (d_imgs,) = torch.autograd.grad(moments, st.imgs, grad_outputs=d_mom)
+            return loss, gnorm, d_imgs
+
+        def run_ops():
             latents = self.model.encode_first_stage_sample((st.imgs * 2.0 - 1.0).to(dt), noise=st.post).to(st.imgs.dtype)
             with torch.no_grad():
                 cond = self._cond_from_T(st.T, st.fidx)
-                ac = self.model.alphas_cumprod[st.t].view(-1, 1, 1, 1)
+                ac = self.alphas[st.t].view(-1, 1, 1, 1)
                 noisy = ac.sqrt() * latents + (1 - ac).sqrt() * st.noise
                 pred = self.model.apply_model(torch.cat([noisy] * 2).to(dt), torch.cat([st.t] * 2), cond)
                 unc, cnd = pred.float().chunk(2)
@@ -892,6 +933,13 @@ class TemporalStableZero123Guidance(nn.Module):
             loss = 0.5 * F.mse_loss(latents, target, reduction="sum") / B
             (d_imgs,) = torch.autograd.grad(loss, st.imgs)
             return loss.detach(), grad.norm(), d_imgs
+
+        run = run_fused if fused else run_ops
+        st.fused_glue = fused
+        if fused:
+            st.latents = torch.zeros_like(st.noise)
+            if not (self.c_concat.is_contiguous() and self.alphas.dtype == torch.float32 and tuple(self.c_concat.shape[1:]) == (4, 32, 32)):
+                raise ValueError("fused SDS glue: c_concat must be a contiguous [L,4,32,32] tensor")
 
         cur, side = torch.cuda.current_stream(dev), torch.cuda.Stream(device=dev)
         side.wait_stream(cur)
@@ -973,7 +1021,7 @@ class TemporalStableZero123Guidance(nn.Module):
         with torch.no_grad():
             if noise is None:
                 noise = torch.randn_like(latents)
-            ac = self.model.alphas_cumprod.to(latents.device)[t].view(-1, 1, 1, 1)
+            ac = self.alphas.to(latents.device)[t].view(-1, 1, 1, 1)
             noisy = ac.sqrt() * latents + (1 - ac).sqrt() * noise                      # DDIMScheduler.add_noise
             pred = self._unet(torch.cat([noisy] * 2).to(self.weights_dtype), torch.cat([t] * 2), cond)
         unc, cnd = pred.float().chunk(2)

@@ -213,6 +213,26 @@ int dm4d_groupnorm_nhwc_backward_add(int32_t N, int32_t HW, int32_t C, int32_t G
                                      const void *dy, const void *dx_add, void *dx, float *scratch, int32_t splits,
                                      dm4d_stream_t stream);
 
+/* The arithmetic between the networks of a Zero123 SDS step (guidance/temporal_stable_zero123_guidance.py:299-374) as two launches;
+ * csrc/sds_glue.hip has the expressions.  Every tensor comes with its four element strides (batch, channel, row, column): the
+ * layouts are whatever the networks' last layers produce.  float16: moments [B,8,H,W], post (posterior noise) [B,4,H,W], c_concat
+ * [L,4,H,W], x_in [2B,8,H,W], pred [2B,4,H,W], d_moments [B,8,H,W]; float32: noise, latents [B,4,H,W], alphas_cumprod [T], clip
+ * (one number or NULL), loss, grad_norm; int64: t [B], frame_index [B], t2 [2B].
+ *   prepare: latents = scale_factor (mean + exp(0.5 clamp(logvar, -30, 20)) post); noisy = sqrt(ac[t]) latents + sqrt(1 - ac[t]) noise;
+ *            x_in = [noisy | 0] for the first B samples, [noisy | c_concat[frame_index]] for the second B; t2 = [t, t].
+ *   finish : pred = uncond + guidance_scale (cond - uncond); grad = clip(nan_to_num((1 - ac[t]) (pred - noise)));
+ *            loss = 0.5 sum (latents - (latents - grad))^2 / B; grad_norm = |grad|; d_moments = dloss/dmoments. */
+int dm4d_sds_prepare(int32_t B, int32_t H, int32_t W, float scale_factor, const void *moments, const int64_t *moments_strides,
+                     const void *post, const int64_t *post_strides, const float *noise, const int64_t *noise_strides, float *latents,
+                     const int64_t *latents_strides, const int64_t *t, const float *alphas_cumprod, const void *c_concat,
+                     const int64_t *c_concat_strides, const int64_t *frame_index, void *x_in, const int64_t *x_in_strides, int64_t *t2,
+                     dm4d_stream_t stream);
+int dm4d_sds_finish(int32_t B, int32_t H, int32_t W, float scale_factor, float guidance_scale, const void *pred,
+                    const int64_t *pred_strides, const float *latents, const int64_t *latents_strides, const float *noise,
+                    const int64_t *noise_strides, const int64_t *t, const float *alphas_cumprod, const float *clip, const void *moments,
+                    const int64_t *moments_strides, const void *post, const int64_t *post_strides, void *d_moments,
+                    const int64_t *d_moments_strides, float *loss, float *grad_norm, dm4d_stream_t stream);
+
 /* y[r, c] = a[r, c] + b[r, c] + bias[c] over [rows, C] (the end of a ResBlock: skip + convolution output + that convolution's
  * bias -- openaimodel.py:259-275, diffusionmodules/model.py ResnetBlock); dtype as above, C % 8 == 0 (F16) / % 4 (F32). */
 int dm4d_add_bias_nhwc(int64_t rows, int32_t C, int32_t dtype, const void *a, const void *b, const void *bias, void *y,

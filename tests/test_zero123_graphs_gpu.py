@@ -86,6 +86,57 @@ def test_whole_step_graph_draws_the_eager_steps_random_numbers_and_scales_with_t
     assert whole._graph_error is None and len(whole._sds_graphs) == 1
 
 
+@pytest.mark.parametrize("clip", [None, 0.3])
+def test_fused_glue_kernels_equal_the_torch_operators_between_the_networks(clip):
+    """csrc/sds_glue.hip (dm4d_sds_prepare / dm4d_sds_finish: posterior sample, noising, the UNet's input, guidance arithmetic,
+    loss, dL/dmoments -- two launches inside the step's graph) against the ~70 torch operators they replace, float16 weights:
+    the same expressions with the same roundings: loss and |grad| to 2e-6 (float32 sums in another order), the image gradient to
+    1e-4 of its range."""
+    if not torch.cuda.is_available():
+        pytest.skip("no HIP device")
+    from dreammesh4d_amd import zero123 as z
+
+    dev = torch.device("cuda:0")
+    L, B = 5, 3
+    torch.manual_seed(2)
+    model = z.Zero123(unet_kwargs=dict(model_channels=64, context_dim=32, num_heads=4), vae_kwargs=dict(ch=32))
+    for p in model.model.diffusion_model.out.parameters():
+        torch.nn.init.normal_(p, std=0.05)
+    with torch.no_grad():      # a posterior log-variance that reaches the lower clamp (random weights give ~0: the clamp's mask would go untested)
+        probe = model.first_stage_model.encode_moments(torch.rand(2, 3, 256, 256) * 2 - 1)[:, 4:]
+        model.first_stage_model.quant_conv.weight[4:] *= 8.0 / float(probe.std())
+        model.first_stage_model.quant_conv.bias[4:] = -20.0 - 8.0 / float(probe.std()) * (probe.mean() - model.first_stage_model.quant_conv.bias[4:])
+    cc, cat = torch.randn(L, 1, 32), torch.randn(L, 4, 32, 32)
+    kw = dict(cond_elevation_deg=5.0, half_precision_weights=True, grad_clip=clip, use_graphs=True, one_graph=True)
+    ops = z.TemporalStableZero123Guidance(model, cc, cat, **kw).to(dev)
+    ops.fused_glue = False
+    fused = z.TemporalStableZero123Guidance(model, cc, cat, **kw).to(dev)
+    assert fused.fused_glue
+    el, az = torch.tensor([10.0, 30.0, -5.0]), torch.tensor([-40.0, 90.0, 170.0])
+    fi = torch.tensor([1, 4, 0], device=dev)
+    for step in range(3):
+        rgb0 = torch.rand(B, 256, 256, 3, generator=torch.Generator().manual_seed(50 + step)).to(dev)
+        got = {}
+        for name, guid in (("ops", ops), ("fused", fused)):
+            rgb = rgb0.clone().requires_grad_(True)
+            torch.manual_seed(21 + step)
+            torch.cuda.manual_seed(23 + step)
+            out = guid(rgb, el, az, torch.full_like(el, 3.8), frame_indices=fi)
+            (0.5 * out["loss_sds"]).backward()
+            got[name] = (float(out["loss_sds"].detach()), float(out["grad_norm"].detach()), rgb.grad.clone())
+        a, b = got["ops"], got["fused"]
+        assert a[0] > 0 and a[1] > 0 and float(a[2].abs().max()) > 0
+        assert abs(a[0] - b[0]) <= 2e-6 * abs(a[0]) and abs(a[1] - b[1]) <= 2e-6 * abs(a[1]), (step, a[:2], b[:2])
+        # (dL/dmoments differs in the last float16 bit of a few elements -- the libraries' exp / rounding order; through the encoder's
+        # backward that is ~2e-5 of the image gradient's range)
+        assert float((a[2] - b[2]).abs().max()) <= 1e-4 * float(a[2].abs().max()), (step, float((a[2] - b[2]).abs().max()), float(a[2].abs().max()))
+    with torch.no_grad():
+        lv = model.first_stage_model.encode_moments((rgb0.permute(0, 3, 1, 2) * 2 - 1).to(torch.float16).contiguous(memory_format=torch.channels_last))[:, 4:].float()
+    assert float((lv < -30).float().mean()) > 0.02 and float((lv > -30).float().mean()) > 0.5          # both sides of the clamp were exercised
+    st_o, st_f = list(ops._sds_graphs.values())[0], list(fused._sds_graphs.values())[0]
+    assert ops._graph_error is None and fused._graph_error is None and st_f.fused_glue and not st_o.fused_glue
+
+
 def test_fused_unet_path_equals_plain_forward(monkeypatch):
     """The float16 / no_grad UNet on a HIP device takes shortcuts that must not change what it computes: q, k, v of a
     self-attention from ONE GEMM (strided views into its result), the residual adds in the GEMMs' C operand written in place,
