@@ -59,6 +59,20 @@ class ViewsGrads(C.Structure):
                                   "dL_ddx", "dL_ddr", "dL_dds", "dL_ddo")]
 
 
+class GViewsStruct(C.Structure):
+    """dm4d_gviews (include/dm4d.h)."""
+    _fields_ = [(n, C.c_int32) for n in ("B", "N", "image_height", "image_width")] + \
+               [(n, C.c_float) for n in ("tanfovx", "tanfovy", "scale_modifier")] + [("record_mode", C.c_int32), ("capacity", C.c_int64), ("record_capacity", C.c_int64)] + \
+               [(n, vp) for n in ("bg", "viewmatrix", "projmatrix", "means3D", "rotations", "scales", "opacities", "colors", "radii",
+                                  "out_color", "out_depth", "out_alpha", "geom", "binning", "image")]
+
+
+class GViewsGrads(C.Structure):
+    """dm4d_gviews_grads (include/dm4d.h)."""
+    _fields_ = [(n, vp) for n in ("dL_dcolor", "dL_ddepth", "dL_dalpha", "grad_scratch", "dL_dmeans2D", "dL_dmeans3D", "dL_drotations",
+                                  "dL_dscales", "dL_dopacity", "dL_dcolors")]
+
+
 class MlpWeights(C.Structure):
     """dm4d_mlp_weights (include/dm4d.h)."""
     _fields_ = [("in_dim", C.c_int32), ("width", C.c_int32), ("n_heads", C.c_int32), ("out_dim", C.c_int32 * 4),
@@ -187,6 +201,8 @@ _SIGNATURES = {
     "dm4d_views_skin_scratch_bytes": (C.c_size_t, [C.c_int32] * 3),
     "dm4d_views_face_scratch_bytes": (C.c_size_t, [C.c_int32] * 2),
     "dm4d_views_forward": (C.c_int, [C.POINTER(ViewsStruct), vp]),
+    "dm4d_gviews_forward": (C.c_int, [C.POINTER(GViewsStruct), vp]),
+    "dm4d_gviews_backward": (C.c_int, [C.POINTER(GViewsStruct), C.POINTER(GViewsGrads), vp]),
     "dm4d_views_backward": (C.c_int, [C.POINTER(ViewsStruct), C.POINTER(ViewsGrads), vp]),
     "dm4d_views_counters": (C.c_int, [C.POINTER(ViewsStruct), C.POINTER(C.c_int64), C.POINTER(C.c_int64),
                                       C.POINTER(C.c_int32), vp]),

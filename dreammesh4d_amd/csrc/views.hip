@@ -216,6 +216,81 @@ int dm4d_views_backward(const dm4d_views *v, const dm4d_views_grads *gr, dm4d_st
                                 (float *)gr->skin_scratch, gr->dL_ddx, gr->dL_ddr, gr->dL_dds, gr->dL_ddo, st);
 }
 
+// ---------------------------------------------------------------------------------- B views of one set of Gaussians
+static int gviews_check(const dm4d_gviews *v)
+{
+    if (!v) { set_error("null gviews"); return DM4D_ERR_INVALID; }
+    if (v->B <= 0 || v->B > 65535) { set_error("bad batch size %d", v->B); return DM4D_ERR_INVALID; }
+    if (v->N <= 0 || v->N > (1 << kGidBits)) { set_error("N = %d: 1 .. %d Gaussians per view", v->N, 1 << kGidBits); return DM4D_ERR_UNSUPPORTED; }
+    if (v->image_height <= 0 || v->image_width <= 0) { set_error("bad image size"); return DM4D_ERR_INVALID; }
+    if ((int64_t)((v->image_height + kTile - 1) / kTile) * ((v->image_width + kTile - 1) / kTile) > kMaxTiles) {
+        set_error("image has more than %d tiles", kMaxTiles);
+        return DM4D_ERR_UNSUPPORTED;
+    }
+    if (v->capacity <= 0 || v->capacity > 0xFFFFFFF0ll) { set_error("capacity out of range"); return DM4D_ERR_INVALID; }
+    if (v->record_capacity <= 0 || v->record_capacity > 0xFFFFFFF0ll) { set_error("record_capacity out of range"); return DM4D_ERR_INVALID; }
+    if (v->record_mode != DM4D_RECORDS_CELL && v->record_mode != DM4D_RECORDS_TILE) { set_error("bad record_mode %d", v->record_mode); return DM4D_ERR_INVALID; }
+    if (!v->bg || !v->viewmatrix || !v->projmatrix || !v->means3D || !v->rotations || !v->scales || !v->opacities || !v->colors ||
+        !v->radii || !v->geom || !v->binning || !v->image) {
+        set_error("null tensor in dm4d_gviews");
+        return DM4D_ERR_INVALID;
+    }
+    return DM4D_OK;
+}
+
+static BatchDesc gviews_batch(const dm4d_gviews *v)
+{
+    BatchDesc d;
+    memset(&d, 0, sizeof(d));
+    d.B = v->B; d.N = v->N; d.C = 6; d.W = v->image_width; d.H = v->image_height;
+    d.tanfovx = v->tanfovx; d.tanfovy = v->tanfovy; d.scale_modifier = v->scale_modifier;
+    d.bg = v->bg;
+    d.view = v->viewmatrix; d.proj = v->projmatrix; d.cam_stride = 16;
+    d.means3D = v->means3D; d.rotations = v->rotations; d.colors = v->colors; d.scales = v->scales; d.opacities = v->opacities;   // strides 0: shared
+    d.radii = v->radii; d.radii_stride = (size_t)v->N;
+    d.geom = (char *)v->geom; d.geom_stride = geom_layout(v->N, v->image_height, v->image_width).total;
+    d.binning = (char *)v->binning; d.bin_stride = binning_bytes(v->capacity); d.cap = (uint32_t)v->capacity;
+    d.rec_cap = (uint32_t)v->record_capacity;
+    d.tile_records = v->record_mode == DM4D_RECORDS_TILE ? 1 : 0;
+    d.image = (char *)v->image; d.img_stride = image_bytes(v->image_height, v->image_width);
+    d.out_color = v->out_color; d.out_depth = v->out_depth; d.out_alpha = v->out_alpha;
+    return d;
+}
+
+int dm4d_gviews_forward(const dm4d_gviews *v, dm4d_stream_t stream)
+{
+    int rc = gviews_check(v);
+    if (rc) return rc;
+    if (!v->out_color || !v->out_depth || !v->out_alpha) { set_error("null output image"); return DM4D_ERR_INVALID; }
+    hipStream_t st = (hipStream_t)stream;
+    const BatchDesc d = gviews_batch(v);
+    if ((rc = launch_zero_counters(d, st))) return rc;
+    if ((rc = launch_preprocess(d, st))) return rc;
+    if ((rc = launch_colscan(d, st))) return rc;
+    if ((rc = launch_scatter(d, st))) return rc;
+    if ((rc = launch_tile_sort(d, st))) return rc;
+    return launch_render_fwd(d, st);
+}
+
+int dm4d_gviews_backward(const dm4d_gviews *v, const dm4d_gviews_grads *gr, dm4d_stream_t stream)
+{
+    int rc = gviews_check(v);
+    if (rc) return rc;
+    if (!gr || !gr->dL_dcolor || !gr->grad_scratch || !gr->dL_dmeans2D || !gr->dL_dmeans3D || !gr->dL_drotations || !gr->dL_dscales ||
+        !gr->dL_dopacity || !gr->dL_dcolors) {
+        set_error("null tensor in dm4d_gviews_grads");
+        return DM4D_ERR_INVALID;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    BatchDesc d = gviews_batch(v);
+    d.dL_dcolor = gr->dL_dcolor; d.dL_ddepth = gr->dL_ddepth; d.dL_dalpha = gr->dL_dalpha;
+    d.dLq = (float *)gr->grad_scratch; d.dlq_stride = grad_bytes(v->record_capacity, 6) / 4;
+    d.o = BwdOutputs{gr->dL_dmeans2D, gr->dL_dmeans3D, gr->dL_dopacity, gr->dL_dcolors, nullptr, gr->dL_dscales, gr->dL_drotations, nullptr};
+    d.lean = 0;                                 // every appearance gradient: the static stage learns them all
+    if ((rc = launch_render_bwd(d, st))) return rc;
+    return launch_gather_bwd(d, st);
+}
+
 /* per view: num_rendered, num_records, overflow flags (synchronises the stream). */
 int dm4d_views_counters(const dm4d_views *v, int64_t *num_rendered, int64_t *num_records, int32_t *overflowed,
                         dm4d_stream_t stream)

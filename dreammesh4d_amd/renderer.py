@@ -13,6 +13,7 @@ plus the per-pixel epilogue below, written as batched tensor ops.  Output dict k
 follow the reference so its systems (``C/system/sugar_4dgen.py``) read it unchanged.
 """
 import math
+import os
 from typing import Dict, NamedTuple, Optional
 
 import torch
@@ -241,6 +242,8 @@ class DiffSuGaRNormal:
         """The geometry's per-Gaussian attributes, evaluated ONCE for all the views of a batch (the reference re-evaluates
         the properties for every view; the autograd graph is the same, shared)."""
         g = self.geometry
+        if hasattr(g, "render_attributes"):
+            return g.render_attributes()
         return dict(xyz=g.get_xyz, opacity=g.get_opacity, scaling=g.get_scaling, rotation=g.get_rotation, rgb=g.get_rendered_rgb(),
                     normals=g.get_gs_normals)
 
@@ -281,14 +284,61 @@ class DiffSuGaRNormal:
                 "depth": _where_detached(depth, mask), "viewspace_points": vsp, "visibility_filter": radii > 0, "radii": radii,
                 "raw_normal": n_raw, "raw_normal_from_dist": nd_raw}
 
+    # The views of a batch as ONE operator call (gviews.render_gaussian_views: same kernels, no host synchronisation, the images
+    # bit-identical to the per-view calls) where that applies: a HIP device, one field of view for the batch, no per-view
+    # background draw.  `batched = False` (or DM4D_STATIC_BATCHED=0) keeps the loop of per-view drop-in operator calls.
+    batched = os.environ.get("DM4D_STATIC_BATCHED", "1") != "0"
+
+    def _views_renderer(self, N, H, W, tanfov):
+        from . import gviews
+
+        key = (N, H, W, round(tanfov, 9))
+        cache = self.__dict__.setdefault("_gviews", {})
+        if key not in cache:
+            cache[key] = gviews.GaussianViews(N, H, W, tanfov, self.geometry.device)
+        self.views_renderer = cache[key]          # (the most recent one: overflow_flag() / poll() for the training loop)
+        return cache[key]
+
+    def _batch_forward_views(self, batch, w2c, full, fovy, B, H, W) -> Dict:
+        from . import gviews
+
+        g = self.geometry
+        ga = self.gaussians()
+        r = self._views_renderer(g.n_gaussians, H, W, math.tan(0.5 * float(fovy[0])))
+        bg = self.background_tensor
+        vsp = [torch.zeros(g.n_gaussians, 3, device=g.device, requires_grad=True) for _ in range(B)]
+        out = gviews.render_gaussian_views(r, ga["xyz"], ga["rotation"], ga["scaling"], ga["opacity"], torch.cat([ga["rgb"], ga["normals"]], dim=1),
+                                           w2c, full, torch.cat([bg, bg]), means2D=torch.stack(vsp))
+        color, depth, alpha = out["color"], out["depth"], out["alpha"]
+        mask = alpha > 0.99
+        mask3 = mask.expand(B, 3, H, W)
+        res = {}
+        if batch.get("rays_d") is not None:
+            xyz = batch["rays_o"].to(g.device) + depth.permute(0, 2, 3, 1) * batch["rays_d"].to(g.device)      # (before the detach, :162-163)
+            nd = F.normalize(depth_to_normal(xyz.permute(0, 3, 1, 2)), dim=1)
+            res["comp_normal_from_dist"] = _where_detached(nd * 0.5 * alpha + 0.5, mask3).permute(0, 2, 3, 1)
+        n = F.normalize(color[:, 3:], dim=1)
+        res["comp_normal"] = _where_detached(n * 0.5 * alpha + 0.5, mask3).permute(0, 2, 3, 1)
+        res["comp_rgb"] = color[:, :3].clamp(0, 1).permute(0, 2, 3, 1)
+        res["comp_depth"] = _where_detached(depth, mask).permute(0, 2, 3, 1)
+        res["comp_mask"] = alpha.permute(0, 2, 3, 1)
+        res["viewspace_points"] = vsp
+        res["visibility_filter"] = [out["radii"][b] > 0 for b in range(B)]
+        res["radii"] = [out["radii"][b] for b in range(B)]
+        return res
+
     def batch_forward(self, batch: Dict) -> Dict:
         """``GaussianBatchRenderer.batch_forward`` (renderer/gaussian_batch_renderer.py:9-122) for the static geometry."""
         g = self.geometry
         c2w = batch["c2w"].to(g.device)
         B = int(c2w.shape[0])
         H, W = int(batch["height"]), int(batch["width"])
-        fovy = torch.as_tensor(batch["fovy"], dtype=torch.float32, device=g.device).reshape(-1).expand(B)
+        fovy_in = torch.as_tensor(batch["fovy"], dtype=torch.float32).reshape(-1)      # (compared on the host when it arrives there: no synchronisation)
+        fovy = fovy_in.to(g.device).expand(B)
         w2c, full, center = cam_info_gaussian(c2w, fovy, fovy, 0.1, 100.0)
+        if (self.batched and g.device.type == "cuda" and not (self.training and self.invert_bg_prob < 1.0)
+                and bool((fovy_in == fovy_in[0]).all())):
+            return self._batch_forward_views(batch, w2c, full, fovy_in, B, H, W)
         outs = []
         ga = self.gaussians()
         for b in range(B):

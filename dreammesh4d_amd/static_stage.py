@@ -49,6 +49,7 @@ class StaticStage:
         self.reducer = D.GradAllReducer([p for p in geometry.parameters() if p.requires_grad and p.numel()])
         self.ref_cam = syn.make_camera(H, W, elev_deg=5.0, azim_deg=0.0)                # yaml:11-14
         self.global_step = 0
+        self.poll_every, self.overflow_skipped = 8, 0
 
     def _batch(self, cams):
         c2w = torch.stack([torch.tensor(c.c2w, dtype=torch.float32) for c in cams])
@@ -59,20 +60,24 @@ class StaticStage:
         g.update_learning_rate(it)
         self.opt.zero_grad(set_to_none=True)
         terms = {}
-        # ---- reference substep
-        out = self.r.batch_forward(self._batch([self.ref_cam]))
-        m = self.ref_mask.float()
-        terms["rgb"] = F.mse_loss(self.ref_image * m, out["comp_rgb"] * m)
-        terms["mask"] = F.mse_loss(m, out["comp_mask"])
-        loss = C(self.lam["rgb"], 0, it) * terms["rgb"] + C(self.lam["mask"], 0, it) * terms["mask"]
-        # ---- random substep
+        # ---- the reference view and the random views as ONE batch of the renderer (the reference renders the two substeps one
+        #      after the other from the same parameters and adds their losses, sugar_static.py:300-340: the same images and the same
+        #      sum; one operator call each way instead of two)
         u = torch.rand(self.rv, 2, generator=self.gen)
         elev, azim = -10.0 + 90.0 * u[:, 0], -180.0 + 360.0 * u[:, 1]
         cams = [syn.make_camera(self.H, self.W, elev_deg=float(e), azim_deg=float(a)) for e, a in zip(elev, azim)]
-        out = self.r.batch_forward(self._batch(cams))
+        both = self.r.batch_forward(self._batch([self.ref_cam] + cams))
+        # ---- reference substep
+        m = self.ref_mask.float()
+        terms["rgb"] = F.mse_loss(self.ref_image * m, both["comp_rgb"][:1] * m)
+        terms["mask"] = F.mse_loss(m, both["comp_mask"][:1])
+        loss = C(self.lam["rgb"], 0, it) * terms["rgb"] + C(self.lam["mask"], 0, it) * terms["mask"]
+        # ---- random substep
+        out = {k: v[1:] for k, v in both.items() if torch.is_tensor(v)}
         if self.guidance is not None:
             self.guidance.update_step(0, it)
-            go = self.guidance(out["comp_rgb"], elev.to(self.dev), azim.to(self.dev), torch.full((self.rv,), 3.8, device=self.dev))
+            # (elevation / azimuth stay on the host: they only feed the four-number camera embedding, as in DynamicStage)
+            go = self.guidance(out["comp_rgb"], elev, azim, torch.full((self.rv,), 3.8))
             terms["sds"] = go["loss_sds"]
             loss = loss + C(self.lam["sds"], 0, it) * terms["sds"]
         if self.nc is not None:
@@ -86,9 +91,29 @@ class StaticStage:
             loss = loss + C(self.lam[k], 0, it) * terms[k]
         loss.backward()
         self.reducer()
+        # the batched renderer sizes its duplicate / record lists without a host synchronisation: a forward that overflowed them
+        # rendered a wrong image, and the optimiser step is skipped ON THE DEVICE (found_inf, as in DynamicStage); poll() notices a
+        # step or two later and enlarges the capacities
+        vr = getattr(self.r, "views_renderer", None)
+        if vr is not None and vr.last is not None:
+            flag = vr.overflow_flag()
+            if D.world() > 1:
+                D.all_reduce_max(flag)
+            self.opt.found_inf, self.opt.grad_scale = flag, None
         self.opt.step()
         self.global_step += 1
-        return {"loss": loss.detach(), **{k: v.detach() for k, v in terms.items()}}
+        terms = {k: v.detach() for k, v in terms.items()}
+        if vr is not None and self.global_step % self.poll_every == 0:
+            from ._lib import Dm4dError
+
+            try:
+                vr.poll()
+            except Dm4dError as e:
+                if not getattr(e, "overflow", False):
+                    raise
+                self.overflow_skipped += 1
+                terms["overflow_skipped"] = torch.tensor(float(self.overflow_skipped))
+        return {"loss": loss.detach(), **terms}
 
     @classmethod
     def from_cfg(cls, system_cfg, geometry, renderer, ref_image, ref_mask, H, W, **kw):

@@ -388,6 +388,17 @@ class SuGaR(nn.Module):
     def get_gs_normals(self):
         return self.get_face_normals.repeat_interleave(self.cfg_n_gaussians_per_surface_triangle, dim=0)
 
+    def render_attributes(self):
+        """What a renderer call reads -- get_xyz, get_opacity, get_scaling, get_rotation, get_rendered_rgb(), get_gs_normals --
+        evaluated together: the same values, with the face vertices gathered and the face normals computed ONCE for the three
+        properties that need them (each property alone gathers its own)."""
+        G = self.cfg_n_gaussians_per_surface_triangle
+        fv = geo.face_verts(self._points, self._surface_mesh_faces)
+        fn = geo.face_normals(None, None, fv=fv)
+        return dict(xyz=geo.points(None, None, self._bary, fv=fv), opacity=self.get_opacity, scaling=self.get_scaling,
+                    rotation=geo.quaternions(None, self._surface_mesh_faces, self._quaternions, G, fv=fv, normals=fn),
+                    rgb=self.get_rendered_rgb(), normals=fn.repeat_interleave(G, dim=0))
+
     # ---- optimiser (sugar.py:329-416)
     def training_setup(self):
         ls = self._lr
@@ -411,9 +422,13 @@ class SuGaR(nn.Module):
         self.color_clip = C(self._color_clip_cfg, 0, iteration)                                   # sugar.py:404
 
     def merge_optimizer(self, net_optimizer):
-        groups = list(self.optimize_list) + ([{"params": g["params"], "lr": g["lr"]} for g in net_optimizer.param_groups]
-                                             if net_optimizer is not None else [])
-        self.optimizer = torch.optim.AdamW(groups, lr=0.0, betas=(0.9, 0.99), eps=1e-15)
+        # (fresh dicts: training_setup's Adam filled the ones of optimize_list with ITS defaults -- "fused": None among them -- in place)
+        groups = [{"params": g["params"], "lr": g["lr"], "name": g["name"]} for g in self.optimize_list] + \
+            ([{"params": g["params"], "lr": g["lr"]} for g in net_optimizer.param_groups] if net_optimizer is not None else [])
+        # (on a HIP device the fused implementation: one multi-tensor launch, and it honours `found_inf` -- the training loop skips
+        # the step on the device when the batched renderer overflowed a capacity, static_stage.StaticStage.iteration)
+        fused = {"fused": True} if all(p.is_cuda for g in groups for p in g["params"]) and len(groups) > 0 else {}
+        self.optimizer = torch.optim.AdamW(groups, lr=0.0, betas=(0.9, 0.99), eps=1e-15, **fused)
         return self.optimizer
 
 

@@ -597,6 +597,37 @@ int dm4d_views_backward(const dm4d_views *v, const dm4d_views_grads *g, dm4d_str
 int dm4d_views_counters(const dm4d_views *v, int64_t *num_rendered, int64_t *num_records, int32_t *overflowed,
                         dm4d_stream_t stream);
 
+/* ------------------------------------------------------------------ B views of ONE set of Gaussians (the static stage's batch)
+ * `GaussianBatchRenderer.batch_forward` (renderer/gaussian_batch_renderer.py:21-76) around `DiffGaussian.forward` of the static
+ * renderer (renderer/diff_sugar_rasterizer_normal.py:88-226): every view of a batch renders the SAME Gaussians (the SuGaR geometry
+ * evaluated once) from its own camera -- the reference loops over the views with one rasterizer call per pass and a host
+ * synchronisation in each.  Here: one call forward, one backward, no synchronisation (capacities as for dm4d_views: counters in the
+ * first 16 bytes of every view's geom workspace, dm4d_views_*_bytes for the workspace sizes).  colors = [N,6] (RGB | normal), as
+ * the fused 6-channel pass of the per-view operator.  Gradients come back per VIEW (the caller sums them over B). */
+typedef struct dm4d_gviews {
+    int32_t B, N, image_height, image_width;
+    float tanfovx, tanfovy, scale_modifier;
+    int32_t record_mode;                       /* DM4D_RECORDS_CELL / DM4D_RECORDS_TILE */
+    int64_t capacity, record_capacity;         /* duplicates / backward records per view */
+    const float *bg;                           /* [6] */
+    const float *viewmatrix, *projmatrix;      /* [B,16] each, row-vector convention */
+    const float *means3D, *rotations;          /* [N,3] [N,4] (w,x,y,z) */
+    const float *scales, *opacities, *colors;  /* [N,3] [N] [N,6] */
+    int32_t *radii;                            /* [B,N] */
+    float *out_color, *out_depth, *out_alpha;  /* [B,6,H,W] [B,H,W] [B,H,W] */
+    void *geom, *binning, *image;              /* dm4d_views_{geom,binning,image}_bytes(B, ...) */
+} dm4d_gviews;
+
+typedef struct dm4d_gviews_grads {
+    const float *dL_dcolor, *dL_ddepth, *dL_dalpha;     /* [B,6,H,W] [B,H,W] [B,H,W]; depth / alpha may be NULL */
+    void *grad_scratch;                                 /* dm4d_views_grad_bytes(B, record_capacity) */
+    float *dL_dmeans2D, *dL_dmeans3D, *dL_drotations;   /* [B,N,3] [B,N,3] [B,N,4] */
+    float *dL_dscales, *dL_dopacity, *dL_dcolors;       /* [B,N,3] [B,N] [B,N,6] */
+} dm4d_gviews_grads;
+
+int dm4d_gviews_forward(const dm4d_gviews *v, dm4d_stream_t stream);
+int dm4d_gviews_backward(const dm4d_gviews *v, const dm4d_gviews_grads *g, dm4d_stream_t stream);
+
 /* ------------------------------------------------------------------ 3x3 convolution on the matrix cores (Zero123 UNet)
  * y = conv3x3(x, w) + bias (+ residual): stride 1, padding 1, float16, float32 accumulation (v_mfma_f32_32x32x16_f16).
  * x [N,H,W,C_in], y / residual [N,H,W,C_out] (NHWC = torch.channels_last storage), w [C_out,3,3,C_in] (a channels_last
