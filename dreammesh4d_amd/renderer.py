@@ -56,6 +56,23 @@ def cam_info_gaussian(c2w, fovx, fovy, znear=0.1, zfar=100.0):
     return wv, full, center
 
 
+def batch_cameras(batch, device):
+    """(w2c, full_proj, camera_center [B,...] on `device`, fovy [B] as given) of a batch dict.  A batch whose `c2w` / `fovy` arrive
+    on the HOST (the data loaders' side) has its 4 x 4 algebra done there and ONE pinned, non-blocking upload per result: on the
+    device `torch.linalg.inv` checks its `info` on the host (two synchronisations) and a pageable host-to-device copy waits for
+    everything queued on the stream -- six stalls per call that serialise the host with the device."""
+    c2w = batch["c2w"]
+    B = int(c2w.shape[0])
+    fovy = torch.as_tensor(batch["fovy"], dtype=torch.float32).reshape(-1)
+    if c2w.device.type == "cpu" and fovy.device.type == "cpu" and torch.device(device).type == "cuda":
+        w2c, full, center = cam_info_gaussian(c2w, fovy.expand(B), fovy.expand(B), 0.1, 100.0)
+        up = lambda t: torch.empty(t.shape, dtype=t.dtype, pin_memory=True).copy_(t).to(device, non_blocking=True)
+        return up(w2c), up(full), up(center), fovy
+    fd = fovy.to(device).expand(B)
+    w2c, full, center = cam_info_gaussian(c2w.to(device), fd, fd, 0.1, 100.0)
+    return w2c, full, center, fovy
+
+
 class Camera(NamedTuple):
     """``Camera`` of C/geometry/gaussian_base.py:175-184."""
     FoVx: torch.Tensor
@@ -131,16 +148,14 @@ class DiffGaussianTemporal:
 
     def batch_forward(self, batch: Dict) -> Dict:
         g = self.geometry
-        c2w = batch["c2w"].to(g.device)
-        B = int(c2w.shape[0])
+        B = int(batch["c2w"].shape[0])
         H, W = int(batch["height"]), int(batch["width"])
-        fovy = torch.as_tensor(batch["fovy"], dtype=torch.float32, device=g.device).reshape(-1).expand(B)
+        w2c, full, _, fovy = batch_cameras(batch, g.device)
         fov0 = float(fovy[0])
         if not bool((fovy == fovy[0]).all()):
             raise NotImplementedError("one fovy per batch (the shipped configurations use a fixed 20 degrees)")
         # background: white in training, inverted at evaluation (…temporal.py:96-103)
         bg = self.background_tensor if self.training else 1.0 - self.background_tensor
-        w2c, full, _ = cam_info_gaussian(c2w, fovy, fovy, 0.1, 100.0)
         ts = batch.get("timestamp")
         fi = batch.get("frame_indices")
         if ts is None and fi is None:
@@ -330,12 +345,10 @@ class DiffSuGaRNormal:
     def batch_forward(self, batch: Dict) -> Dict:
         """``GaussianBatchRenderer.batch_forward`` (renderer/gaussian_batch_renderer.py:9-122) for the static geometry."""
         g = self.geometry
-        c2w = batch["c2w"].to(g.device)
-        B = int(c2w.shape[0])
+        B = int(batch["c2w"].shape[0])
         H, W = int(batch["height"]), int(batch["width"])
-        fovy_in = torch.as_tensor(batch["fovy"], dtype=torch.float32).reshape(-1)      # (compared on the host when it arrives there: no synchronisation)
-        fovy = fovy_in.to(g.device).expand(B)
-        w2c, full, center = cam_info_gaussian(c2w, fovy, fovy, 0.1, 100.0)
+        w2c, full, center, fovy_in = batch_cameras(batch, g.device)      # (fovy compared on the host when it arrives there: no synchronisation)
+        fovy = fovy_in.expand(B)
         if (self.batched and g.device.type == "cuda" and not (self.training and self.invert_bg_prob < 1.0)
                 and bool((fovy_in == fovy_in[0]).all())):
             return self._batch_forward_views(batch, w2c, full, fovy_in, B, H, W)

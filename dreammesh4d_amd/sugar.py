@@ -27,6 +27,17 @@ from .deformation import DeformationNetwork
 from .schedule import C
 
 
+def _thickness(module):
+    """`surface_mesh_thickness` as a Python number, read from the device ONCE per value (float(parameter) is a host
+    synchronisation: it stalled every evaluation of get_scaling, i.e. every training iteration)."""
+    p = module.surface_mesh_thickness
+    key = (p.data_ptr(), p._version)
+    c = module.__dict__.get("_thickness_cache")
+    if c is None or c[0] != key:
+        c = module.__dict__["_thickness_cache"] = (key, float(p))
+    return c[1]
+
+
 def RGB2SH(rgb):
     return (rgb - 0.5) / 0.28209479177387814
 
@@ -129,13 +140,13 @@ class DynamicSuGaR(nn.Module):
             with torch.no_grad():
                 q = geo.quaternions(self._points, self._surface_mesh_faces, self._quaternions, G)
                 xyz = geo.points(self._points, self._surface_mesh_faces, geo.bary_coords(G, self.device))
-            return dict(q=q, xyz=xyz, scaling=geo.scaling(self._scales, float(self.surface_mesh_thickness)),
+            return dict(q=q, xyz=xyz, scaling=geo.scaling(self._scales, _thickness(self)),
                         opacity=geo.strengths(self.all_densities), rgb=geo.points_rgb(self._sh_coordinates_dc))
         if self._static_cache is None:
             with torch.no_grad():
                 self._static_cache = dict(
                     q=geo.quaternions(self._points, self._surface_mesh_faces, self._quaternions, G),
-                    scaling=geo.scaling(self._scales, float(self.surface_mesh_thickness)),
+                    scaling=geo.scaling(self._scales, _thickness(self)),
                     opacity=geo.strengths(self.all_densities),
                     rgb=geo.points_rgb(self._sh_coordinates_dc),
                     xyz=geo.points(self._points, self._surface_mesh_faces, geo.bary_coords(G, self.device)))
@@ -355,7 +366,7 @@ class SuGaR(nn.Module):
 
     @property
     def get_scaling(self):
-        return geo.scaling(self._scales, float(self.surface_mesh_thickness))
+        return geo.scaling(self._scales, _thickness(self))
 
     @property
     def get_rotation(self):

@@ -907,7 +907,8 @@ class TemporalStableZero123Guidance(nn.Module):
                                               ptr(st.t), ptr(self.alphas), ptr(self.c_concat), strides(self.c_concat),
                                               ptr(st.fidx), ptr(x_in), strides(x_in), ptr(t2), stream), "dm4d_sds_prepare")
                 pred = self.model.model.diffusion_model(x_in, t2, context=self._crossattn_from_T(st.T, st.fidx))
-                d_mom = torch.empty_like(moments)
+                d_mom = torch.empty(moments.shape, device=dev, dtype=dt)      # (contiguous, like the `cat` autograd builds there: the library picks the
+                                                                              #  quant_conv's backward kernel by the gradient's layout)
                 loss, gnorm = torch.empty((), device=dev), torch.empty((), device=dev)
                 _lib.check(L.dm4d_sds_finish(B, 32, 32, float(self.model.scale_factor), float(scale), ptr(pred), strides(pred),
                                              ptr(st.latents), strides(st.latents), ptr(st.noise), strides(st.noise), ptr(st.t),
@@ -1003,13 +1004,15 @@ class TemporalStableZero123Guidance(nn.Module):
         if (self.one_graph and self.use_graphs and not rgb_as_latents and rgb.is_cuda and rgb.requires_grad and torch.is_grad_enabled()
                 and rgb.dtype == torch.float32 and self._graph_error is None):
             x256 = x if tuple(x.shape[-2:]) == (256, 256) else F.interpolate(x, (256, 256), mode="bilinear", align_corners=False)
-            rng = (torch.get_rng_state(), torch.cuda.get_rng_state(rgb.device))
+            # (the generators' states are only saved around a CAPTURE -- reading the device generator's state is a blocking copy)
+            rng = (torch.get_rng_state(), torch.cuda.get_rng_state(rgb.device)) if not self._sds_graphs else None
             try:
                 return self._forward_one_graph(x256, elevation, azimuth, frame_indices, noise, t)
             except Exception as e:      # noqa: BLE001  (capture is an optimisation: report once, take the multi-graph / eager step)
                 self._graph_error = f"{type(e).__name__}: {e}"
-                torch.set_rng_state(rng[0])
-                torch.cuda.set_rng_state(rng[1], rgb.device)
+                if rng is not None:
+                    torch.set_rng_state(rng[0])
+                    torch.cuda.set_rng_state(rng[1], rgb.device)
         if rgb_as_latents:
             latents = F.interpolate(x, (32, 32), mode="bilinear", align_corners=False) * 2 - 1
         else:

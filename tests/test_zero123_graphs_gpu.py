@@ -91,7 +91,7 @@ def test_fused_glue_kernels_equal_the_torch_operators_between_the_networks(clip)
     """csrc/sds_glue.hip (dm4d_sds_prepare / dm4d_sds_finish: posterior sample, noising, the UNet's input, guidance arithmetic,
     loss, dL/dmoments -- two launches inside the step's graph) against the ~70 torch operators they replace, float16 weights:
     the same expressions with the same roundings: loss and |grad| to 2e-6 (float32 sums in another order), the image gradient to
-    1e-4 of its range."""
+    float16 resolution (a last-bit difference of exp in a few elements of dL/dmoments)."""
     if not torch.cuda.is_available():
         pytest.skip("no HIP device")
     from dreammesh4d_amd import zero123 as z
@@ -105,7 +105,9 @@ def test_fused_glue_kernels_equal_the_torch_operators_between_the_networks(clip)
     with torch.no_grad():      # a posterior log-variance that reaches the lower clamp (random weights give ~0: the clamp's mask would go untested)
         probe = model.first_stage_model.encode_moments(torch.rand(2, 3, 256, 256) * 2 - 1)[:, 4:]
         model.first_stage_model.quant_conv.weight[4:] *= 8.0 / float(probe.std())
-        model.first_stage_model.quant_conv.bias[4:] = -20.0 - 8.0 / float(probe.std()) * (probe.mean() - model.first_stage_model.quant_conv.bias[4:])
+        # (mean -14: the typical standard deviation exp(-7) is still a NORMAL float16 number -- at -20 the whole chain runs in subnormals,
+        # where one last-bit difference of exp is a percent)
+        model.first_stage_model.quant_conv.bias[4:] = -14.0 - 8.0 / float(probe.std()) * (probe.mean() - model.first_stage_model.quant_conv.bias[4:])
     cc, cat = torch.randn(L, 1, 32), torch.randn(L, 4, 32, 32)
     kw = dict(cond_elevation_deg=5.0, half_precision_weights=True, grad_clip=clip, use_graphs=True, one_graph=True)
     ops = z.TemporalStableZero123Guidance(model, cc, cat, **kw).to(dev)
@@ -127,14 +129,87 @@ def test_fused_glue_kernels_equal_the_torch_operators_between_the_networks(clip)
         a, b = got["ops"], got["fused"]
         assert a[0] > 0 and a[1] > 0 and float(a[2].abs().max()) > 0
         assert abs(a[0] - b[0]) <= 2e-6 * abs(a[0]) and abs(a[1] - b[1]) <= 2e-6 * abs(a[1]), (step, a[:2], b[:2])
-        # (dL/dmoments differs in the last float16 bit of a few elements -- the libraries' exp / rounding order; through the encoder's
-        # backward that is ~2e-5 of the image gradient's range)
-        assert float((a[2] - b[2]).abs().max()) <= 1e-4 * float(a[2].abs().max()), (step, float((a[2] - b[2]).abs().max()), float(a[2].abs().max()))
+        # (dL/dmoments differs in the last float16 bit of a few elements -- exp of the two libraries; with this test's stretched
+        # log-variance that is up to ~1e-3 of the image gradient's range, 2e-5 at full size with the shipped statistics)
+        # (through the random-weight encoder's float16 backward a last-bit difference in an element of dL/dmoments is amplified
+        # locally: the kernels themselves are checked element by element in the next test)
+        assert float((a[2] - b[2]).abs().max()) <= 2e-2 * float(a[2].abs().max()), (step, float((a[2] - b[2]).abs().max()), float(a[2].abs().max()))
+        assert float((a[2] - b[2]).abs().mean()) <= 5e-3 * float(a[2].abs().mean()), step
     with torch.no_grad():
         lv = model.first_stage_model.encode_moments((rgb0.permute(0, 3, 1, 2) * 2 - 1).to(torch.float16).contiguous(memory_format=torch.channels_last))[:, 4:].float()
-    assert float((lv < -30).float().mean()) > 0.02 and float((lv > -30).float().mean()) > 0.5          # both sides of the clamp were exercised
+    assert float((lv < -30).float().mean()) > 0.005 and float((lv > -30).float().mean()) > 0.5          # both sides of the clamp were exercised
     st_o, st_f = list(ops._sds_graphs.values())[0], list(fused._sds_graphs.values())[0]
     assert ops._graph_error is None and fused._graph_error is None and st_f.fused_glue and not st_o.fused_glue
+
+
+def test_glue_kernels_element_by_element_against_torch_autograd():
+    """dm4d_sds_prepare / dm4d_sds_finish alone, on random float16 moments (log-variance on both sides of the lower clamp) and a
+    random "UNet prediction", against the torch operators with autograd: latents and the UNet's input bit-identical, loss and
+    |grad| to 1e-6, dL/dmoments identical except for isolated elements (<= 0.1 %) at most two float16 ulps apart."""
+    if not torch.cuda.is_available():
+        pytest.skip("no HIP device")
+    import ctypes as C_
+
+    import torch.nn.functional as F
+
+    from dreammesh4d_amd import _lib
+
+    dev = torch.device("cuda:0")
+    Lb = _lib.lib()
+    for B, clip in ((3, None), (4, 0.25), (1, None)):
+        g = torch.Generator().manual_seed(10 + B)
+        moments = torch.randn(B, 8, 32, 32, generator=g)
+        moments[:, 4:] = moments[:, 4:] * 8 - 14
+        moments = moments.to(dev, torch.float16).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+        post = torch.randn(B, 4, 32, 32, generator=g).to(dev, torch.float16)
+        noise = torch.randn(B, 4, 32, 32, generator=g).to(dev).contiguous(memory_format=torch.channels_last)
+        pred = torch.randn(2 * B, 4, 32, 32, generator=g).to(dev, torch.float16)
+        t = torch.randint(20, 980, (B,), generator=g).to(dev)
+        betas = torch.linspace(0.00085 ** 0.5, 0.0120 ** 0.5, 1000, dtype=torch.float64) ** 2
+        alphas = torch.cumprod(1.0 - betas, dim=0).float().to(dev)
+        cc = torch.randn(5, 4, 32, 32, generator=g).to(dev, torch.float16)
+        fidx = torch.randint(0, 5, (B,), generator=g).to(dev)
+        scale, gs = 0.18215, 3.0
+        mean, logvar = moments.chunk(2, dim=1)
+        latents = (scale * (mean + torch.exp(0.5 * logvar.clamp(-30.0, 20.0)) * post)).to(torch.float32)
+        with torch.no_grad():
+            ac = alphas[t].view(-1, 1, 1, 1)
+            noisy = ac.sqrt() * latents + (1 - ac).sqrt() * noise
+            unc, cnd = pred.float().chunk(2)
+            grad = torch.nan_to_num((1 - ac) * ((unc + gs * (cnd - unc)) - noise))
+            if clip is not None:
+                grad = grad.clamp(-clip, clip)
+            target = latents - grad
+        loss = 0.5 * F.mse_loss(latents, target, reduction="sum") / B
+        (dm_ref,) = torch.autograd.grad(loss, moments)
+        ptr = lambda v: C_.c_void_p(v.data_ptr())
+        st = lambda v: (C_.c_int64 * 4)(*v.stride())
+        md = moments.detach()
+        lat2 = torch.zeros_like(noise)
+        x_in = torch.empty(2 * B, 8, 32, 32, device=dev, dtype=torch.float16).contiguous(memory_format=torch.channels_last)
+        t2 = torch.empty(2 * B, dtype=torch.long, device=dev)
+        s = torch.cuda.current_stream().cuda_stream
+        _lib.check(Lb.dm4d_sds_prepare(B, 32, 32, scale, ptr(md), st(md), ptr(post), st(post), ptr(noise), st(noise), ptr(lat2), st(lat2), ptr(t),
+                                       ptr(alphas), ptr(cc), st(cc), ptr(fidx), ptr(x_in), st(x_in), ptr(t2), s), "dm4d_sds_prepare")
+        dm = torch.empty(md.shape, device=dev, dtype=torch.float16)
+        lo, gn = torch.empty((), device=dev), torch.empty((), device=dev)
+        cl = None if clip is None else torch.tensor(clip, device=dev)
+        _lib.check(Lb.dm4d_sds_finish(B, 32, 32, scale, gs, ptr(pred), st(pred), ptr(lat2), st(lat2), ptr(noise), st(noise), ptr(t), ptr(alphas),
+                                      None if cl is None else ptr(cl), ptr(md), st(md), ptr(post), st(post), ptr(dm), st(dm), ptr(lo), ptr(gn), s),
+                   "dm4d_sds_finish")
+        assert torch.equal(latents.detach(), lat2)
+        assert torch.equal(x_in[:B, :4], noisy.half()) and torch.equal(x_in[B:, :4], noisy.half())
+        assert torch.equal(x_in[:B, 4:], torch.zeros_like(x_in[:B, 4:])) and torch.equal(x_in[B:, 4:], cc[fidx])
+        assert torch.equal(t2, torch.cat([t, t]))
+        assert abs(float(lo) - float(loss)) <= 1e-6 * float(loss) and abs(float(gn) - float(grad.norm())) <= 1e-6 * float(grad.norm())
+        lv = md[:, 4:].float()
+        assert float((lv < -30).float().mean()) > 0.005 and bool((dm[:, 4:][lv < -30] == 0).all())            # the clamp's mask
+        off = dm != dm_ref
+        assert float(off.float().mean()) <= 1e-3, float(off.float().mean())
+        big = torch.maximum(dm.float().abs(), dm_ref.float().abs()).clamp_min(2.0 ** -14)                      # (subnormals: the spacing of 2^-14)
+        ulp = torch.exp2(torch.floor(torch.log2(big)) - 10)
+        worst = float(((dm.float() - dm_ref.float()).abs() / ulp).max())
+        assert worst <= 2.0, worst          # float16 ulps: a last-bit difference in dL/dmean (<= 0.1 % of the elements) carried through two more roundings
 
 
 def test_fused_unet_path_equals_plain_forward(monkeypatch):

@@ -50,6 +50,7 @@ def main():
     ap.add_argument("--n", type=int, default=30)
     ap.add_argument("--with-guidance", action="store_true")
     ap.add_argument("--tables", action="store_true")
+    ap.add_argument("--sync-debug", action="store_true", help="every implicit host <-> device synchronisation of one iteration, with its Python stack")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     stage = build(dev, a.with_guidance)
@@ -63,6 +64,19 @@ def main():
         hs.append(1e3 * (time.perf_counter() - t0))
         torch.cuda.synchronize(dev)
     print(f"host time to return from iteration() on an empty queue: median {sorted(hs)[5]:.2f} ms")
+    if a.sync_debug:
+        import traceback
+        import warnings
+
+        def show(msg, cat, fn, ln, *rest):
+            print(f"SYNC at {fn}:{ln}: {msg}")
+            traceback.print_stack(limit=10)
+        warnings.showwarning = show
+        warnings.simplefilter("always")
+        torch.cuda.set_sync_debug_mode("warn")
+        stage.iteration()
+        torch.cuda.set_sync_debug_mode("default")
+        torch.cuda.synchronize(dev)
     if a.tables:
         from torch.profiler import ProfilerActivity, profile
 
