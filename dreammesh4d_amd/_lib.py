@@ -103,6 +103,13 @@ class GradSegments(C.Structure):
                 ("count", C.c_int64 * MAX_GRAD_SEGMENTS), ("offset", C.c_int64 * MAX_GRAD_SEGMENTS)]
 
 
+class AdamwArgs(C.Structure):
+    """dm4d_adamw_args (include/dm4d.h)."""
+    _fields_ = [("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float), ("weight_decay", C.c_float), ("n_groups", C.c_int32),
+                ("lr", C.c_float * 8), ("group", C.c_int32 * MAX_GRAD_SEGMENTS), ("param", vp * MAX_GRAD_SEGMENTS), ("exp_avg", vp),
+                ("exp_avg_sq", vp), ("step", vp), ("pending_decay", vp), ("found_inf", vp), ("scratch", vp)]
+
+
 ALLOC_FN = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_int, C.c_size_t)
 
 _SIGNATURES = {
@@ -194,6 +201,7 @@ _SIGNATURES = {
     "dm4d_arap_energy_backward": (C.c_int, [C.c_int32, C.c_int32] + [vp] * 11),
     "dm4d_grad_pack": (C.c_int, [C.POINTER(GradSegments), vp, vp]),
     "dm4d_grad_unpack": (C.c_int, [C.POINTER(GradSegments), vp, C.c_float, vp]),
+    "dm4d_adamw_message": (C.c_int, [C.POINTER(GradSegments), C.POINTER(AdamwArgs), C.c_float, vp]),
     "dm4d_views_geom_bytes": (C.c_size_t, [C.c_int32] * 4),
     "dm4d_views_binning_bytes": (C.c_size_t, [C.c_int32, C.c_int64]),
     "dm4d_views_image_bytes": (C.c_size_t, [C.c_int32] * 3),

@@ -47,6 +47,70 @@ __global__ __launch_bounds__(256) void k_grad_unpack(PackDesc d, const float *__
     }
 }
 
+// ---------------------------------------------------------------------------------------- AdamW in message space
+// The optimiser step of the path (AdamW(betas (0.9, 0.99), eps 1e-15) over the deformation network,
+// geometry/sugar.py:406-416) for the elements that can RECEIVE gradient -- the message of the exchange step: the MLP, the time
+// planes, and of the 134 MB of spatial planes only the texels the static nodes touch (3.4 M of 35.76 M elements at the shipped
+// size).  Everything else has zero gradient and zero moments for ever: its whole update is the weight decay, which the caller
+// keeps as a pending factor per group (distributed.ShardedAdamW.materialize).  The dense step streams 35.76 M x (parameter,
+// gradient, two moments, three writes) = 1 GB per iteration (0.2 ms); this one 32 bytes x 3.4 M.
+//   k_adamw_scalars (one thread): the step counter (device: a step skipped by found_inf does not advance the bias corrections),
+//   the two bias corrections in float64, the pending decay factors.
+//   k_adamw_message: torch/optim/adamw.py::_single_tensor_adamw operation for operation per element, gathered from and scattered
+//   to the parameter / gradient STORAGE through the segment's index list.
+struct AdamDesc {
+    PackDesc seg;                       // grad[]: gradient storage of the segment (NULL: zeros)
+    float *param[kMaxSeg];
+    int group[kMaxSeg];
+    float lr[8];
+    int n_groups;
+    float beta1, beta2, eps, weight_decay, grad_scale;
+    float *exp_avg, *exp_avg_sq;
+    double *step, *pending_decay;
+    const float *found_inf;
+    float *scal;                        // [0] bias correction 1, [1] sqrt(bias correction 2), [2] 1 = apply / 0 = skip
+};
+
+__global__ void k_adamw_scalars(AdamDesc d)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const bool keep = !d.found_inf || *d.found_inf == 0.f;
+    const double step = *d.step + (keep ? 1.0 : 0.0);
+    *d.step = step;
+    d.scal[0] = (float)(1.0 - pow((double)d.beta1, step));
+    d.scal[1] = (float)sqrt(1.0 - pow((double)d.beta2, step));
+    d.scal[2] = keep ? 1.f : 0.f;
+    if (keep && d.pending_decay)
+        for (int g = 0; g < d.n_groups; ++g) d.pending_decay[g] *= 1.0 - (double)d.lr[g] * (double)d.weight_decay;
+}
+
+__global__ __launch_bounds__(256) void k_adamw_message(AdamDesc d)
+{
+    if (d.scal[2] == 0.f) return;
+    const int k = blockIdx.y;
+    const long long n = d.seg.count[k];
+    const float *__restrict__ grad = d.seg.grad[k];
+    const long long *__restrict__ ix = d.seg.index[k];
+    float *__restrict__ par = d.param[k];
+    float *__restrict__ m = d.exp_avg + d.seg.offset[k], *__restrict__ v = d.exp_avg_sq + d.seg.offset[k];
+    const float lr = d.lr[d.group[k]], bc1 = d.scal[0], bc2s = d.scal[1];
+    const float w1 = 1.0f - d.beta1, w2 = 1.0f - d.beta2, decay = 1.0f - lr * d.weight_decay, step_size = -(lr / bc1);
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const long long e = ix ? ix[i] : i;
+        const float g = (grad ? grad[e] : 0.f) * d.grad_scale;
+        const float p = par[e] * decay;
+        const float m0 = m[i];
+        const float m1 = w1 < 0.5f ? m0 + w1 * (g - m0) : g - (g - m0) * (1.0f - w1);       // torch.lerp(exp_avg, grad, 1 - beta1)
+        const float v1 = v[i] * d.beta2 + (w2 * g) * g;                                      // mul_(beta2).addcmul_(grad, grad, value = 1 - beta2)
+        const float denom = sqrtf(v1) / bc2s + d.eps;
+        par[e] = p + (m1 * step_size) / denom;
+        m[i] = m1;
+        v[i] = v1;
+    }
+}
+
+static int fill_pack(PackDesc &d, const dm4d_grad_segments *s, bool need_grad);
+
 static int fill_pack(PackDesc &d, const dm4d_grad_segments *s, bool need_grad)
 {
     if (!s || s->n_segments < 0 || s->n_segments > kMaxSeg) { set_error("grad segments: bad count"); return DM4D_ERR_INVALID; }
@@ -89,6 +153,32 @@ int dm4d_grad_unpack(const dm4d_grad_segments *segments, const float *flat, floa
     if (d.n_seg == 0) return DM4D_OK;
     if (!flat) { set_error("grad unpack: null message"); return DM4D_ERR_INVALID; }
     hipLaunchKernelGGL(k_grad_unpack, dim3(128, d.n_seg), dim3(256), 0, (hipStream_t)stream, d, flat, scale);
+    DM4D_HIP_CHECK(hipGetLastError());
+    return DM4D_OK;
+}
+
+int dm4d_adamw_message(const dm4d_grad_segments *segments, const dm4d_adamw_args *a, float grad_scale, dm4d_stream_t stream)
+{
+    AdamDesc d;
+    memset(&d, 0, sizeof(d));
+    int rc = fill_pack(d.seg, segments, false);
+    if (rc) return rc;
+    if (!a || !a->exp_avg || !a->exp_avg_sq || !a->step || !a->scratch) { set_error("adamw: null state"); return DM4D_ERR_INVALID; }
+    if (a->n_groups < 1 || a->n_groups > 8) { set_error("adamw: %d groups (1..8)", a->n_groups); return DM4D_ERR_INVALID; }
+    for (int k = 0; k < d.seg.n_seg; ++k) {
+        if (d.seg.count[k] > 0 && !a->param[k]) { set_error("adamw: null parameter storage (segment %d)", k); return DM4D_ERR_INVALID; }
+        if (a->group[k] < 0 || a->group[k] >= a->n_groups) { set_error("adamw: segment %d in group %d", k, a->group[k]); return DM4D_ERR_INVALID; }
+        d.param[k] = a->param[k];
+        d.group[k] = a->group[k];
+    }
+    for (int g = 0; g < a->n_groups; ++g) d.lr[g] = a->lr[g];
+    d.n_groups = a->n_groups;
+    d.beta1 = a->beta1; d.beta2 = a->beta2; d.eps = a->eps; d.weight_decay = a->weight_decay; d.grad_scale = grad_scale;
+    d.exp_avg = a->exp_avg; d.exp_avg_sq = a->exp_avg_sq; d.step = a->step; d.pending_decay = a->pending_decay;
+    d.found_inf = a->found_inf; d.scal = a->scratch;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(k_adamw_scalars, dim3(1), dim3(64), 0, st, d);
+    if (d.seg.n_seg > 0) hipLaunchKernelGGL(k_adamw_message, dim3(128, d.seg.n_seg), dim3(256), 0, st, d);
     DM4D_HIP_CHECK(hipGetLastError());
     return DM4D_OK;
 }

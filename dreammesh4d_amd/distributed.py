@@ -264,6 +264,8 @@ class ShardedAdamW:
         red, w = self.reducer, world()
         n = red.flat.numel()
         dev = self.padded.device
+        if w == 1 and dev.type == "cuda" and self.fused:
+            return self._step_fused(found_inf)
         keep = None if found_inf is None else (found_inf.reshape(()).to(dev) == 0)          # bool scalar: True = apply
         red.pack()
         self.padded[:n].copy_(red.flat)
@@ -325,6 +327,42 @@ class ShardedAdamW:
         #      materialize() (checkpointing, state_dict, tests) in one multi-tensor launch.
         self.pending_decay = decay_g if self.pending_decay is None else self.pending_decay * decay_g
         self._unpack_message()
+
+    fused = True      # single process on a HIP device: the step as two launches of csrc/gradpack.hip (dm4d_adamw_message)
+
+    def _step_fused(self, found_inf):
+        """One process, HIP device: gradients and parameters are read from / written to their storages through the message's index
+        lists, the moments live in message layout -- no pack, no unpack, the same per-element arithmetic (csrc/gradpack.hip)."""
+        import ctypes as C
+
+        from . import _lib
+
+        red, dev = self.reducer, self.padded.device
+        if self.step_t is None:
+            self.step_t = torch.zeros((), dtype=torch.float64, device=dev)
+        if self.pending_decay is None:
+            self.pending_decay = torch.ones(len(self.param_groups), dtype=torch.float64, device=dev)
+        if self.__dict__.get("_scal") is None:
+            self._scal = torch.zeros(4, dtype=torch.float32, device=dev)
+            gid_of = {id(p): gi for gi, g in enumerate(self.param_groups) for p in g["params"]}
+            self._seg_group = [gid_of[id(p)] for p in red.params]
+        seg = red._segments(False)
+        a = _lib.AdamwArgs()
+        a.beta1, a.beta2, a.eps, a.weight_decay = self.betas[0], self.betas[1], self.eps, self.weight_decay
+        a.n_groups = len(self.param_groups)
+        for gi, g in enumerate(self.param_groups):
+            a.lr[gi] = float(g["lr"])
+        for k, p in enumerate(red.params):
+            a.group[k] = self._seg_group[k]
+            a.param[k] = storage_flat(p.data).data_ptr()
+        a.exp_avg, a.exp_avg_sq = self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr()
+        a.step, a.pending_decay = self.step_t.data_ptr(), self.pending_decay.data_ptr()
+        fi = None if found_inf is None else found_inf.reshape(()).to(dev, torch.float32)
+        a.found_inf = None if fi is None else fi.data_ptr()
+        a.scratch = self._scal.data_ptr()
+        with torch.cuda.device(dev):
+            _lib.check(_lib.lib().dm4d_adamw_message(C.byref(seg), C.byref(a), 1.0, torch.cuda.current_stream(dev).cuda_stream), "dm4d_adamw_message")
+        self.step_count += 1
 
     def _unpack_message(self):
         red = self.reducer

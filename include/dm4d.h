@@ -510,6 +510,26 @@ typedef struct dm4d_grad_segments {
 int dm4d_grad_pack(const dm4d_grad_segments *segments, float *flat, dm4d_stream_t stream);
 int dm4d_grad_unpack(const dm4d_grad_segments *segments, const float *flat, float scale, dm4d_stream_t stream);
 
+/* AdamW (torch/optim/adamw.py::_single_tensor_adamw, operation for operation; the optimiser of C/geometry/sugar.py:406-416) over the
+ * elements of the message: segments->grad[k] = GRADIENT storage of segment k (NULL: zeros), param[k] = its PARAMETER storage (same
+ * layout; index[] addresses both), group[k] its learning-rate group.  exp_avg / exp_avg_sq: the moments in message layout (zeros
+ * before the first step); step: device scalar, steps APPLIED (advanced here unless *found_inf != 0, in which case nothing is
+ * written); pending_decay (optional, [n_groups] float64 on the device): multiplied by this step's (1 - lr weight_decay) per group --
+ * the whole update of the elements OUTSIDE the message (zero gradient, zero moments), which the caller applies when it needs them;
+ * scratch: 4 floats.  Two launches.  grad_scale multiplies every gradient (1 / world after a sum over ranks). */
+typedef struct dm4d_adamw_args {
+    float beta1, beta2, eps, weight_decay;
+    int32_t n_groups;
+    float lr[8];
+    int32_t group[DM4D_MAX_GRAD_SEGMENTS];
+    float *param[DM4D_MAX_GRAD_SEGMENTS];
+    float *exp_avg, *exp_avg_sq;
+    double *step, *pending_decay;
+    const float *found_inf;
+    float *scratch;
+} dm4d_adamw_args;
+int dm4d_adamw_message(const dm4d_grad_segments *segments, const dm4d_adamw_args *a, float grad_scale, dm4d_stream_t stream);
+
 /* ------------------------------------------------------------------ batched views (the fast path) */
 
 /* The whole per-view hot path for B (frame, view) units of one scene in 8 launches forward /
