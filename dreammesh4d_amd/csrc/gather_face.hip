@@ -23,7 +23,11 @@ __global__ __launch_bounds__(kSkinThreads) void k_gather_face_bwd(BatchDesc d, i
                                                                   const float *__restrict__ q_static, float *__restrict__ rec, int pypose)
 {
     __shared__ float sV[16], sP[16];
-    __shared__ __attribute__((aligned(16))) float s_chunk[kSkinThreads / 64][kGatherChunkFloats(PARTS)];
+    // ONE block of LDS for both phases: the waves' record chunks while the records are summed, then (after a barrier) the face part's
+    // exchange arrays -- 24.6 KB instead of 37 KB per workgroup: five workgroups per CU (what the 92 VGPRs allow) instead of four
+    constexpr int kChunk = kGatherChunkFloats(PARTS);
+    static_assert((kSkinThreads / 64) * kChunk >= kSkinThreads * 12, "the face part's arrays must fit the record chunks");
+    __shared__ __attribute__((aligned(16))) float s_mem[(kSkinThreads / 64) * kChunk];
     const int tid = threadIdx.x;
     const int faces_per_wg = kSkinThreads / G;
     const int fl = tid / G, sl = tid - fl * G;      // face in workgroup, slot
@@ -36,11 +40,13 @@ __global__ __launch_bounds__(kSkinThreads) void k_gather_face_bwd(BatchDesc d, i
     if (tid < 16) { sV[tid] = c.vp.view[tid]; sP[tid] = c.vp.proj[tid]; }
     __syncthreads();
     GatherOut res;
-    gather_gaussian<PARTS>(d, c, i, live, sV, sP, s_chunk[tid >> 6], res);
+    gather_gaussian<PARTS>(d, c, i, live, sV, sP, s_mem + (tid >> 6) * kChunk, res);
+    __syncthreads();              // every wave is done with its record chunk: the memory changes hands
     const v3 gm = mk3(res.dmean[0], res.dmean[1], res.dmean[2]), gn = mk3(res.dcol[3], res.dcol[4], res.dcol[5]);
     const q4 go = q4{res.drot[1], res.drot[2], res.drot[3], res.drot[0]};      // (w, x, y, z) -> (x, y, z, w)
     face_bwd_finish(F, G, faces, vxyz + (size_t)frame * V * 3, vrot + (size_t)frame * V * 4, q_static, true, true, true, live, f, sl, fl * G,
-                    gm, go, gn, rec + (size_t)bv * F * 3 * kCornerRec, pypose);
+                    gm, go, gn, rec + (size_t)bv * F * 3 * kCornerRec, pypose, reinterpret_cast<float (*)[3]>(s_mem),
+                    reinterpret_cast<float (*)[9]>(s_mem + kSkinThreads * 3));
 }
 
 // d: the backward's batch (per-view outputs dL_dmeans3D / dL_drotations / dL_dcolors NULL, dL_dmeans2D optional);

@@ -587,10 +587,10 @@ __device__ __forceinline__ void face_bwd_finish(const int F, const int G, const 
                                                 const float *__restrict__ vxyz, const float *__restrict__ vrot,
                                                 const float *__restrict__ q_static, const bool has_means, const bool has_rots,
                                                 const bool has_normals, const bool live, const int f, const int sl, const int base,
-                                                const v3 gm, const q4 go, const v3 gn_in, float *__restrict__ rec, const int pypose)
+                                                const v3 gm, const q4 go, const v3 gn_in, float *__restrict__ rec, const int pypose,
+                                                float (*s_log)[3] /* LDS [kSkinThreads][3]: per thread of a face's first three slots: Log of vertex (tid % G) */,
+                                                float (*s_val)[9] /* LDS [kSkinThreads][9]: per slot: gm (3), gr (3), gn (3) */)
 {
-    __shared__ float s_log[kSkinThreads][3];        // per thread of a face's first three slots: Log of vertex (tid % G)
-    __shared__ float s_val[kSkinThreads][9];        // per slot: gm (3), gr (3), gn (3)
     const int tid = threadIdx.x;
     // phase A: Log of the three vertex rotations, one per thread (G >= 3) or all by slot 0 (G == 1)
     if (live && has_rots) {
@@ -709,8 +709,10 @@ __global__ __launch_bounds__(kSkinThreads) void k_face_bwd_face(int F, int G, in
             }
         }
     }
+    __shared__ float s_log[kSkinThreads][3];
+    __shared__ float s_val[kSkinThreads][9];
     face_bwd_finish(F, G, faces, vxyz, vrot, q_static, g_means != nullptr, g_rots != nullptr, g_normals != nullptr, live, f, sl, fl * G,
-                    gm, go, gn, rec, pypose);
+                    gm, go, gn, rec, pypose, s_log, s_val);
 }
 
 // per vertex: fixed-order sum over incident face corners (static CSR), then Log backward
