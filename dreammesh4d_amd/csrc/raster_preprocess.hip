@@ -382,6 +382,9 @@ struct GatherOut { float dmean[3], drot[4], dcol[kMaxChannels]; };
 // PARTS: float4 per record: 2 (lean without depth gradient), 3 (12-float records: 3 channels, or lean 6-channel) or 4 (16 floats).
 // The body of B2 for Gaussian i of the view `c` (every lane of the wave calls it, for 64 CONSECUTIVE Gaussians of the SAME view:
 // the record streaming is wave-cooperative).  sV / sP: the view's matrices in LDS; chunk: this wave's staging window.
+// Records per LDS window of a wave: 128, and 96 for the 64-byte records of the full backward (4 x 7.7 KB per workgroup instead of
+// 4 x 10.2: four workgroups per CU -- what its ~100 VGPRs allow -- instead of three)
+constexpr int kGatherRecords(int parts) { return parts <= 3 ? DM4D_GREC : 96; }
 // Per-view outputs (c.o.*) are written where their pointer is set.
 template <int PARTS>
 __device__ __forceinline__ void gather_gaussian(const BatchDesc &d, const ViewCtx &c, const int i, const bool live, const float *sV,
@@ -393,7 +396,7 @@ __device__ __forceinline__ void gather_gaussian(const BatchDesc &d, const ViewCt
     const GeomPtrs &g = c.g;
     const float *__restrict__ dLt = c.dLq;
     const BwdOutputs &o = c.o;
-    constexpr int kGRec = DM4D_GREC, kGStride = PARTS <= 3 ? 12 : 20;
+    constexpr int kGRec = kGatherRecords(PARTS), kGStride = PARTS <= 3 ? 12 : 20;
     constexpr int NQ = kGRec * PARTS / 64;      // float4 a lane holds of a window in flight
     const int lane = threadIdx.x & 63;
     const size_t si = (size_t)i;
@@ -645,7 +648,7 @@ __device__ __forceinline__ void gather_gaussian(const BatchDesc &d, const ViewCt
         reinterpret_cast<float4 *>(o.dL_drotations)[i] = make_float4(drot[0], drot[1], drot[2], drot[3]);
 }
 
-constexpr int kGatherChunkFloats(int parts) { return DM4D_GREC * (parts <= 3 ? 12 : 20); }
+constexpr int kGatherChunkFloats(int parts) { return kGatherRecords(parts) * (parts <= 3 ? 12 : 20); }
 template <int PARTS>
 __global__ __launch_bounds__(kPreThreads) void k_gather_bwd(BatchDesc d)
 {
