@@ -314,16 +314,37 @@ class DiffSuGaRNormal:
         self.views_renderer = cache[key]          # (the most recent one: overflow_flag() / poll() for the training loop)
         return cache[key]
 
-    def _batch_forward_views(self, batch, w2c, full, fovy, B, H, W) -> Dict:
+    def _render_views(self, w2c, full, fovy, B, H, W, with_viewspace_points=True):
         from . import gviews
 
         g = self.geometry
         ga = self.gaussians()
         r = self._views_renderer(g.n_gaussians, H, W, math.tan(0.5 * float(fovy[0])))
         bg = self.background_tensor
-        vsp = [torch.zeros(g.n_gaussians, 3, device=g.device, requires_grad=True) for _ in range(B)]
+        vsp = [torch.zeros(g.n_gaussians, 3, device=g.device, requires_grad=True) for _ in range(B)] if with_viewspace_points else None
         out = gviews.render_gaussian_views(r, ga["xyz"], ga["rotation"], ga["scaling"], ga["opacity"], torch.cat([ga["rgb"], ga["normals"]], dim=1),
-                                           w2c, full, torch.cat([bg, bg]), means2D=torch.stack(vsp))
+                                           w2c, full, torch.cat([bg, bg]), means2D=None if vsp is None else torch.stack(vsp))
+        return out, vsp
+
+    def _batched_applies(self, fovy_in):
+        g = self.geometry
+        return (self.batched and g.device.type == "cuda" and not (self.training and self.invert_bg_prob < 1.0)
+                and bool((fovy_in == fovy_in[0]).all()))
+
+    def render_batch_raw(self, batch: Dict):
+        """The rasterizer's images of a batch WITHOUT the epilogue -- {"color" [B,6,H,W] (RGB | normal), "depth", "alpha" [B,1,H,W],
+        "radii"} -- for callers that evaluate the image-space terms themselves (static_head.static_head); None where the batched
+        operator does not apply (then batch_forward is the way)."""
+        g = self.geometry
+        B, H, W = int(batch["c2w"].shape[0]), int(batch["height"]), int(batch["width"])
+        w2c, full, _, fovy_in = batch_cameras(batch, g.device)
+        if not self._batched_applies(fovy_in):
+            return None
+        return self._render_views(w2c, full, fovy_in, B, H, W, with_viewspace_points=False)[0]
+
+    def _batch_forward_views(self, batch, w2c, full, fovy, B, H, W) -> Dict:
+        g = self.geometry
+        out, vsp = self._render_views(w2c, full, fovy, B, H, W)
         color, depth, alpha = out["color"], out["depth"], out["alpha"]
         mask = alpha > 0.99
         mask3 = mask.expand(B, 3, H, W)
@@ -349,8 +370,7 @@ class DiffSuGaRNormal:
         H, W = int(batch["height"]), int(batch["width"])
         w2c, full, center, fovy_in = batch_cameras(batch, g.device)      # (fovy compared on the host when it arrives there: no synchronisation)
         fovy = fovy_in.expand(B)
-        if (self.batched and g.device.type == "cuda" and not (self.training and self.invert_bg_prob < 1.0)
-                and bool((fovy_in == fovy_in[0]).all())):
+        if self._batched_applies(fovy_in):
             return self._batch_forward_views(batch, w2c, full, fovy_in, B, H, W)
         outs = []
         ga = self.gaussians()

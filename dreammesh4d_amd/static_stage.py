@@ -11,6 +11,8 @@ one fused RGB + normal call of the HIP rasterizer through ``renderer.DiffSuGaRNo
 torch ops (they are learnt here), the regularisers run on csrc/meshreg.hip.  Data-parallel training (static stage:
 ~1.7 MB of gradients) uses the same ``distributed.GradAllReducer``.
 """
+import os
+
 import torch
 import torch.nn.functional as F
 
@@ -50,6 +52,21 @@ class StaticStage:
         self.ref_cam = syn.make_camera(H, W, elev_deg=5.0, azim_deg=0.0)                # yaml:11-14
         self.global_step = 0
         self.poll_every, self.overflow_skipped = 8, 0
+        self.fused_head = os.environ.get("DM4D_STATIC_FUSED_HEAD", "1") != "0"      # the image-space terms as one operator (static_head.py)
+        self._head = None
+
+    def _head_positions(self):
+        """The operator's view tables for "one reference view, then `rv` random views" and the references as float32 [1,H,W,.]."""
+        if self._head is None:
+            dev = self.dev
+            B = 1 + self.rv
+            self._head = dict(ref_pos=torch.tensor([0] + [-1] * self.rv, dtype=torch.int32, device=dev),
+                              rnd_pos=torch.tensor([-1] + list(range(self.rv)), dtype=torch.int32, device=dev),
+                              fidx_ref=torch.zeros(1, dtype=torch.int64, device=dev))
+            self._ref_image_f = self.ref_image.to(dev, torch.float32).reshape(1, self.H, self.W, 3).contiguous()
+            self._ref_mask_f = self.ref_mask.to(dev, torch.float32).reshape(1, self.H, self.W, 1).contiguous()
+            assert B == len(self._head["ref_pos"])
+        return self._head
 
     def _batch(self, cams):
         c2w = torch.stack([torch.tensor(c.c2w, dtype=torch.float32) for c in cams])
@@ -66,18 +83,40 @@ class StaticStage:
         u = torch.rand(self.rv, 2, generator=self.gen)
         elev, azim = -10.0 + 90.0 * u[:, 0], -180.0 + 360.0 * u[:, 1]
         cams = [syn.make_camera(self.H, self.W, elev_deg=float(e), azim_deg=float(a)) for e, a in zip(elev, azim)]
-        both = self.r.batch_forward(self._batch([self.ref_cam] + cams))
-        # ---- reference substep
-        m = self.ref_mask.float()
-        terms["rgb"] = F.mse_loss(self.ref_image * m, both["comp_rgb"][:1] * m)
-        terms["mask"] = F.mse_loss(m, both["comp_mask"][:1])
+        batch = self._batch([self.ref_cam] + cams)
+        raw = None
+        if self.fused_head and self.dev.type == "cuda" and self.H % 2 == 0 and self.W % 2 == 0 and hasattr(self.r, "render_batch_raw"):
+            raw = self.r.render_batch_raw(batch)
+        if raw is not None:
+            # the image-space terms as ONE operator each way (static_head.py, csrc/statichead.hip): clamp, the normal map and the
+            # masked depth, the two masked MSEs of the reference view, the three total-variation terms and the random views at half
+            # the size (what the guidance's first step, a bilinear resize to 256 x 256, makes of 512 x 512 views)
+            from .static_head import static_head
+
+            hp = self._head_positions()
+            t5, half = static_head(raw["color"], raw["depth"], raw["alpha"], hp["ref_pos"], hp["rnd_pos"], self._ref_image_f, self._ref_mask_f,
+                                   hp["fidx_ref"], 1, self.rv)
+            terms["rgb"], terms["mask"], tv_rgb, tv_depth, tv_normal = t5.unbind(0)
+            out = {"half": half, "tv": {"rgb_tv": tv_rgb, "depth_tv": tv_depth, "normal_tv": tv_normal}}
+        else:
+            both = self.r.batch_forward(batch)
+            # ---- reference substep
+            m = self.ref_mask.float()
+            terms["rgb"] = F.mse_loss(self.ref_image * m, both["comp_rgb"][:1] * m)
+            terms["mask"] = F.mse_loss(m, both["comp_mask"][:1])
+            # ---- random substep
+            out = {k: v[1:] for k, v in both.items() if torch.is_tensor(v)}
         loss = C(self.lam["rgb"], 0, it) * terms["rgb"] + C(self.lam["mask"], 0, it) * terms["mask"]
-        # ---- random substep
-        out = {k: v[1:] for k, v in both.items() if torch.is_tensor(v)}
         if self.guidance is not None:
             self.guidance.update_step(0, it)
             # (elevation / azimuth stay on the host: they only feed the four-number camera embedding, as in DynamicStage)
-            go = self.guidance(out["comp_rgb"], elev, azim, torch.full((self.rv,), 3.8))
+            if raw is None:
+                views = out["comp_rgb"]
+            elif self.H == 512 and self.W == 512:
+                views = out["half"]                                                  # the guidance's own resize would produce exactly these
+            else:
+                views = raw["color"][1:, :3].clamp(0, 1).permute(0, 2, 3, 1)         # any other size: the guidance resizes
+            go = self.guidance(views, elev, azim, torch.full((self.rv,), 3.8))
             terms["sds"] = go["loss_sds"]
             loss = loss + C(self.lam["sds"], 0, it) * terms["sds"]
         if self.nc is not None:
@@ -87,7 +126,7 @@ class StaticStage:
             terms["laplacian_smoothing"] = self.lap(g.get_xyz_verts)
             loss = loss + C(self.lam["laplacian_smoothing"], 0, it) * terms["laplacian_smoothing"]
         for k, key in (("rgb_tv", "comp_rgb"), ("depth_tv", "comp_depth"), ("normal_tv", "comp_normal")):
-            terms[k] = tv_loss(out[key].permute(0, 3, 1, 2))
+            terms[k] = out["tv"][k] if raw is not None else tv_loss(out[key].permute(0, 3, 1, 2))
             loss = loss + C(self.lam[k], 0, it) * terms[k]
         loss.backward()
         self.reducer()

@@ -445,6 +445,24 @@ int dm4d_image_head_backward(int32_t B, int32_t H, int32_t W, int32_t C, const f
                              int32_t n_rnd, const float *g_rgb, const float *g_mask, const float *g_half, float *g_color, float *g_alpha,
                              dm4d_stream_t stream);
 
+/* The image-space terms of a STATIC-stage iteration (system/sugar_static.py:110-340 with the static renderer's epilogue,
+ * renderer/diff_sugar_rasterizer_normal.py:196-226) over the rendered batch color [B,6,H,W] (RGB | normal), depth, alpha [B,1,H,W]:
+ * on the reference views (ref_pos >= 0) the sums of squares of mse(gt m, clamp(rgb) m) and mse(m, alpha); on the random views
+ * (rnd_pos >= 0) the h / w total-variation sums of clamp(rgb), depth and the normal map normalize(normal) 0.5 alpha + 0.5, and the
+ * half-size clamp(rgb) images [n_rnd,H/2,W/2,3] (the guidance's input).  partial: [B, dm4d_static_head_blocks(H, W), 8] sums per
+ * workgroup {mse rgb, mse mask, tv rgb h, w, tv depth h, w, tv normal h, w} (the caller adds them and applies the normalisations of
+ * F.mse_loss / threestudio's tv_loss).  backward: g_terms = upstream gradients of (mse_rgb, mse_mask, tv_rgb, tv_depth, tv_normal)
+ * (5 floats on the device), g_half as half_rgb or NULL; writes dL/dcolor [B,6,H,W], dL/ddepth, dL/dalpha [B,1,H,W] (depth and
+ * the normal map receive gradient only where alpha > 0.99, as the renderer detaches them elsewhere).  H, W even. */
+int32_t dm4d_static_head_blocks(int32_t H, int32_t W);
+int dm4d_static_head_forward(int32_t B, int32_t H, int32_t W, const float *color, const float *depth, const float *alpha, const int32_t *ref_pos,
+                             const int32_t *rnd_pos, const float *ref_images, const float *ref_masks, const int64_t *fidx_ref, int32_t n_ref,
+                             int32_t n_rnd, float *partial, float *half_rgb, dm4d_stream_t stream);
+int dm4d_static_head_backward(int32_t B, int32_t H, int32_t W, const float *color, const float *depth, const float *alpha, const int32_t *ref_pos,
+                              const int32_t *rnd_pos, const float *ref_images, const float *ref_masks, const int64_t *fidx_ref, int32_t n_ref,
+                              int32_t n_rnd, const float *g_terms, const float *g_half, float *g_color, float *g_depth, float *g_alpha,
+                              dm4d_stream_t stream);
+
 /* R [n][3][3] (row-major) of n unit quaternions q [n][4] = (x, y, z, w): `get_timed_vertex_rotation(return_matrix=True)` of
  * C/geometry/dynamic_sugar.py:640-655 (a pypose SO3.matrix()), which the dynamic stage feeds to the ARAP term
  * (C/system/sugar_4dgen.py:304-311).  _backward_pypose: pypose's gradient with respect to the quaternion storage,

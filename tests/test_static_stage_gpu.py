@@ -168,3 +168,60 @@ def test_batched_views_equal_the_loop_of_per_view_operator_calls():
     # the capacity monitor of the batched path: no overflow on this scene, counters readable without a synchronisation
     vr = r.views_renderer
     assert float(vr.overflow_flag()) == 0.0 and vr.calibrated
+
+
+@pytest.mark.parametrize("shape", [(5, 64, 48), (3, 32, 32)])
+def test_static_head_equals_the_torch_composition(shape):
+    """static_head.static_head (csrc/statichead.hip: one launch each way) against the operators it replaces -- the static renderer's
+    epilogue (clamp, normal map, masks, detach rules) + StaticStage's masked MSEs, total-variation terms and the guidance's resize --
+    on random images whose opacity straddles 0.99 and whose colours leave [0, 1]: the five terms and the gradients of colour, depth
+    and opacity under random upstream weights."""
+    if not torch.cuda.is_available():
+        pytest.skip("no HIP device")
+    from dreammesh4d_amd.renderer import _where_detached
+    from dreammesh4d_amd.static_head import static_head
+    from dreammesh4d_amd.static_stage import tv_loss
+
+    dev = torch.device("cuda:0")
+    B, H, W = shape
+    n_ref, n_rnd = 1, B - 1
+    g = torch.Generator().manual_seed(B * 100 + H)
+    color = (torch.rand(B, 6, H, W, generator=g) * 1.6 - 0.3)
+    color[:, 3:] = torch.randn(B, 3, H, W, generator=g)
+    depth = torch.rand(B, 1, H, W, generator=g) * 3 + 1
+    alpha = torch.rand(B, 1, H, W, generator=g)
+    alpha[alpha > 0.5] = 0.992 + 0.008 * torch.rand(int((alpha > 0.5).sum()), generator=g)      # half the pixels solid
+    ref_img = torch.rand(1, H, W, 3, generator=g).to(dev)
+    ref_mask = (torch.rand(1, H, W, 1, generator=g) > 0.4).float().to(dev)
+    w5 = torch.rand(5, generator=g).to(dev) + 0.5
+    wh = torch.randn(n_rnd, H // 2, W // 2, 3, generator=g).to(dev)
+    ref_pos = torch.tensor([0] + [-1] * n_rnd, dtype=torch.int32, device=dev)
+    rnd_pos = torch.tensor([-1] + list(range(n_rnd)), dtype=torch.int32, device=dev)
+    fidx = torch.zeros(1, dtype=torch.int64, device=dev)
+    res = {}
+    for mode in ("torch", "hip"):
+        c, d, a = (t.clone().to(dev).requires_grad_(True) for t in (color, depth, alpha))
+        if mode == "hip":
+            t5, half = static_head(c, d, a, ref_pos, rnd_pos, ref_img, ref_mask, fidx, n_ref, n_rnd)
+        else:
+            mask = a > 0.99
+            rgb = c[:, :3].clamp(0, 1)
+            n = F.normalize(c[:, 3:], dim=1)
+            n_map = _where_detached(n * 0.5 * a + 0.5, mask.expand(B, 3, H, W))
+            dd = _where_detached(d, mask)
+            m = ref_mask
+            mse_rgb = F.mse_loss(ref_img * m, rgb[:1].permute(0, 2, 3, 1) * m)
+            mse_mask = F.mse_loss(m, a[:1].permute(0, 2, 3, 1))
+            t5 = torch.stack([mse_rgb, mse_mask, tv_loss(rgb[1:]), tv_loss(dd[1:]), tv_loss(n_map[1:])])
+            half = F.interpolate(rgb[1:], (H // 2, W // 2), mode="bilinear", align_corners=False).permute(0, 2, 3, 1)
+        ((t5 * w5).sum() + (half * wh).sum()).backward()
+        res[mode] = (t5.detach(), half.detach(), c.grad.clone(), d.grad.clone(), a.grad.clone())
+    ref, got = res["torch"], res["hip"]
+    assert float((ref[0] - got[0]).abs().max() / ref[0].abs().max()) <= 2e-6, (ref[0], got[0])
+    assert torch.equal(ref[1], got[1])                                  # the 2 x 2 mean in the library's order
+    for k, name in ((2, "color"), (3, "depth"), (4, "alpha")):
+        scale = float(ref[k].abs().max())
+        assert scale > 0 and float((ref[k] - got[k]).abs().max()) <= 2e-5 * scale, (name, float((ref[k] - got[k]).abs().max()), scale)
+    # where the opacity is below the threshold depth and the normal channels receive nothing
+    thin = (alpha <= 0.99).to(dev)
+    assert float(got[3][thin].abs().max()) == 0.0 and float(got[2][:, 3:][thin.expand(B, 3, H, W)].abs().max()) == 0.0
