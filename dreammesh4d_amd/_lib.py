@@ -184,6 +184,8 @@ _SIGNATURES = {
     "dm4d_static_head_blocks": (C.c_int32, [C.c_int32, C.c_int32]),
     "dm4d_static_head_forward": (C.c_int, [C.c_int32] * 3 + [vp] * 8 + [C.c_int32, C.c_int32, vp, vp, vp]),
     "dm4d_static_head_backward": (C.c_int, [C.c_int32] * 3 + [vp] * 8 + [C.c_int32, C.c_int32, vp, vp, vp, vp, vp, vp]),
+    "dm4d_sugar_attributes_forward": (C.c_int, [C.c_int32] * 3 + [vp] * 7 + [C.c_float, C.c_float] + [vp] * 6),
+    "dm4d_sugar_attributes_backward": (C.c_int, [C.c_int32] * 3 + [vp] * 7 + [C.c_float, C.c_float] + [vp] * 13),
     "dm4d_quat_to_matrix_forward": (C.c_int, [C.c_int64, vp, vp, vp]),
     "dm4d_quat_to_matrix_backward_pypose": (C.c_int, [C.c_int64, vp, vp, vp, vp]),
     "dm4d_linear_scratch_bytes": (C.c_size_t, [C.c_int64, C.c_int32, C.c_int32]),

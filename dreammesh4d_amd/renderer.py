@@ -322,7 +322,8 @@ class DiffSuGaRNormal:
         r = self._views_renderer(g.n_gaussians, H, W, math.tan(0.5 * float(fovy[0])))
         bg = self.background_tensor
         vsp = [torch.zeros(g.n_gaussians, 3, device=g.device, requires_grad=True) for _ in range(B)] if with_viewspace_points else None
-        out = gviews.render_gaussian_views(r, ga["xyz"], ga["rotation"], ga["scaling"], ga["opacity"], torch.cat([ga["rgb"], ga["normals"]], dim=1),
+        colors6 = ga["colors6"] if "colors6" in ga else torch.cat([ga["rgb"], ga["normals"]], dim=1)
+        out = gviews.render_gaussian_views(r, ga["xyz"], ga["rotation"], ga["scaling"], ga["opacity"], colors6,
                                            w2c, full, torch.cat([bg, bg]), means2D=None if vsp is None else torch.stack(vsp))
         return out, vsp
 

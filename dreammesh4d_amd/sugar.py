@@ -17,6 +17,7 @@ stage, dynamic_sugar.py:77-87).  What is NOT mirrored: building the deformation 
 weights per vertex) is an input here -- and the reference's ``discrete`` dynamic mode (per-frame tables).
 """
 import math
+import os
 
 import torch
 import torch.nn as nn
@@ -36,6 +37,53 @@ def _thickness(module):
     if c is None or c[0] != key:
         c = module.__dict__["_thickness_cache"] = (key, float(p))
     return c[1]
+
+
+class _SugarAttributes(torch.autograd.Function):
+    """(points, complex numbers, log scales, densities, sh_dc) -> (means, rotations, scales, opacities, colors6 = rgb | face normal):
+    ``dm4d_sugar_attributes_forward`` / ``_backward`` (csrc/sugar_attr.hip), the static SuGaR properties as one launch each way."""
+
+    @staticmethod
+    def forward(ctx, points, cx, log_scales, densities, sh_dc, faces, bary, thickness, clip):
+        from . import _lib
+
+        L = _lib.lib()
+        dev = points.device
+        Fn, G, V = int(faces.shape[0]), int(bary.shape[0]), int(points.shape[0])
+        N = Fn * G
+        f = dict(dtype=torch.float32, device=dev)
+        out = (torch.empty(N, 3, **f), torch.empty(N, 4, **f), torch.empty(N, 3, **f), torch.empty(N, **f), torch.empty(N, 6, **f))
+        b = bary.detach().reshape(G, 3).to(torch.float32).contiguous()
+        args = tuple(t.detach() for t in (points, cx, log_scales, densities, sh_dc))
+        with torch.cuda.device(dev):
+            _lib.check(L.dm4d_sugar_attributes_forward(Fn, G, V, args[0].data_ptr(), faces.data_ptr(), b.data_ptr(), args[1].data_ptr(),
+                                                       args[2].data_ptr(), args[3].data_ptr(), args[4].data_ptr(), float(thickness), float(clip),
+                                                       *[o.data_ptr() for o in out], torch.cuda.current_stream(dev).cuda_stream),
+                       "dm4d_sugar_attributes_forward")
+        ctx.save_for_backward(*args, faces, b, out[2], out[3])
+        ctx.consts = (Fn, G, V, float(thickness), float(clip))
+        ctx.set_materialize_grads(False)
+        return out
+
+    @staticmethod
+    def backward(ctx, g_m, g_q, g_s, g_o, g_c):
+        from . import _lib
+
+        L = _lib.lib()
+        points, cx, ls, den, sh, faces, b, scales, opac = ctx.saved_tensors
+        Fn, G, V, thickness, clip = ctx.consts
+        dev = points.device
+        need = ctx.needs_input_grad
+        p = lambda t: 0 if t is None else t.data_ptr()
+        c = lambda t: None if t is None else t.detach().to(torch.float32).contiguous()
+        g_m, g_q, g_s, g_o, g_c = c(g_m), c(g_q), c(g_s), c(g_o), c(g_c)
+        out = [torch.empty_like(t) if n else None for t, n in zip((points, cx, ls, den, sh), need[:5])]
+        with torch.cuda.device(dev):
+            _lib.check(L.dm4d_sugar_attributes_backward(Fn, G, V, points.data_ptr(), faces.data_ptr(), b.data_ptr(), cx.data_ptr(), ls.data_ptr(),
+                                                        den.data_ptr(), sh.data_ptr(), thickness, clip, scales.data_ptr(), opac.data_ptr(),
+                                                        p(g_m), p(g_q), p(g_s), p(g_o), p(g_c), *[p(o) for o in out],
+                                                        torch.cuda.current_stream(dev).cuda_stream), "dm4d_sugar_attributes_backward")
+        return (*out, None, None, None, None)
 
 
 def RGB2SH(rgb):
@@ -421,8 +469,15 @@ class SuGaR(nn.Module):
         backward from hipGraphs -- torch.cuda.make_graphed_callables -- was measured: host time per iteration 6.1 -> 4.6 ms, but the
         iteration with the Zero123 step, which is bound by the device, went from 13.9 to 14.4 ms: removed.)"""
         params = (self._points, self._quaternions, self._scales, self.all_densities, self._sh_coordinates_dc)
+        if self.fused_attributes and self._points.is_cuda and self.cfg_n_gaussians_per_surface_triangle in (1, 3, 4, 6) and \
+                all(p.dtype == torch.float32 and p.is_contiguous() for p in params):
+            # one launch each way (csrc/sugar_attr.hip; DM4D_FUSED_ATTRIBUTES=0 / `fused_attributes = False`: the torch operators)
+            m, q, sc, op, c6 = _SugarAttributes.apply(*params, self._surface_mesh_faces, self._bary, _thickness(self), float(self.color_clip))
+            return dict(xyz=m, opacity=op.reshape(-1, 1), scaling=sc, rotation=q, rgb=c6[:, :3], normals=c6[:, 3:], colors6=c6)
         clip = torch.as_tensor(float(self.color_clip), device=self.device)
         return dict(zip(self._ATTR_KEYS, self._attributes_fn(_thickness(self))(*params, clip)))
+
+    fused_attributes = os.environ.get("DM4D_FUSED_ATTRIBUTES", "1") != "0"
 
     # ---- optimiser (sugar.py:329-416)
     def training_setup(self):

@@ -463,6 +463,25 @@ int dm4d_static_head_backward(int32_t B, int32_t H, int32_t W, const float *colo
                               int32_t n_rnd, const float *g_terms, const float *g_half, float *g_color, float *g_depth, float *g_alpha,
                               dm4d_stream_t stream);
 
+/* The SuGaR geometry's per-Gaussian attributes from its parameters (geometry/sugar.py:471-570: get_xyz, get_scaling, get_rotation,
+ * get_opacity, the degree-0 SH colour, the face normals; csrc/sugar_attr.hip has the expressions), one launch each way -- the static
+ * stage learns every one of these parameters, and as torch operators the evaluation and its backward are ~300 launches on 50 k-element
+ * tensors.  points [V,3], faces [F,3] int64, bary [G,3] (G in 1, 3, 4, 6), complex_numbers / log_scales [N,2], densities [N], sh_dc
+ * [N,3], N = F G.  Outputs: the rasterizer's inputs means3D [N,3], rotations [N,4] (w,x,y,z), scales [N,3], opacities [N], colors6 [N,6]
+ * (rgb | face normal).  backward: `scales` / `opacities` as the forward returned them; any dL_d* input may be NULL (= zeros), any
+ * output NULL (= not wanted); dL_dpoints is zeroed and accumulated with float atomics (the order of a vertex's corner contributions is
+ * the hardware's, as with the index_add of the torch composition). */
+int dm4d_sugar_attributes_forward(int32_t F, int32_t G, int32_t V, const float *points, const int64_t *faces, const float *bary,
+                                  const float *complex_numbers, const float *log_scales, const float *densities, const float *sh_dc,
+                                  float thickness, float color_clip, float *means3D, float *rotations, float *scales, float *opacities,
+                                  float *colors6, dm4d_stream_t stream);
+int dm4d_sugar_attributes_backward(int32_t F, int32_t G, int32_t V, const float *points, const int64_t *faces, const float *bary,
+                                   const float *complex_numbers, const float *log_scales, const float *densities, const float *sh_dc,
+                                   float thickness, float color_clip, const float *scales, const float *opacities, const float *dL_dmeans3D,
+                                   const float *dL_drotations, const float *dL_dscales, const float *dL_dopacities, const float *dL_dcolors6,
+                                   float *dL_dpoints, float *dL_dcomplex, float *dL_dlog_scales, float *dL_ddensities, float *dL_dsh_dc,
+                                   dm4d_stream_t stream);
+
 /* R [n][3][3] (row-major) of n unit quaternions q [n][4] = (x, y, z, w): `get_timed_vertex_rotation(return_matrix=True)` of
  * C/geometry/dynamic_sugar.py:640-655 (a pypose SO3.matrix()), which the dynamic stage feeds to the ARAP term
  * (C/system/sugar_4dgen.py:304-311).  _backward_pypose: pypose's gradient with respect to the quaternion storage,

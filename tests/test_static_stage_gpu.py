@@ -21,6 +21,9 @@ def test_static_renderer_equals_the_two_pass_formulation():
     dev = torch.device("cuda:0")
     sc = syn.mesh_bound_scene(1200, n_nodes=20, k=4, seed=7)
     g = sugar.SuGaR(sc["verts"], sc["faces"], vertex_colors=np.random.default_rng(0).random((len(sc["verts"]), 3)), device=dev)
+    # (this test is about the RASTERIZER call: both sides read the attributes from the properties' torch operators; the fused
+    # attribute kernel agrees with them to 2e-6, test_fused_sugar_attributes..., which is not bit-identical planes)
+    g.fused_attributes = False
     with torch.no_grad():
         g._scales.add_(1.0)                                  # visible splats at 96^2
         g._scales[:, 1].add_(0.6)                            # anisotropic discs: the in-plane rotation (_quaternions) matters
@@ -225,3 +228,40 @@ def test_static_head_equals_the_torch_composition(shape):
     # where the opacity is below the threshold depth and the normal channels receive nothing
     thin = (alpha <= 0.99).to(dev)
     assert float(got[3][thin].abs().max()) == 0.0 and float(got[2][:, 3:][thin.expand(B, 3, H, W)].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("G", [6, 3, 1])
+def test_fused_sugar_attributes_equal_the_torch_properties(G):
+    """``SuGaR.render_attributes`` through csrc/sugar_attr.hip (one launch each way) against the properties' torch operators and
+    their autograd: every attribute the renderer reads, and the gradient of every learnt parameter under random upstream weights --
+    with rotated in-plane frames, colours on both sides of the SH clip and of the zero clamp."""
+    if not torch.cuda.is_available():
+        pytest.skip("no HIP device")
+    from dreammesh4d_amd import sugar, synthetic as syn
+
+    dev = torch.device("cuda:0")
+    sc = syn.mesh_bound_scene(900, n_nodes=10, k=4, seed=5)
+    res = {}
+    for mode in ("torch", "hip"):
+        g = sugar.SuGaR(sc["verts"], sc["faces"], n_gaussians_per_surface_triangle=G, vertex_colors=np.random.default_rng(3).random((len(sc["verts"]), 3)),
+                        device=dev, color_clip=1.2)
+        gen = torch.Generator().manual_seed(7)
+        with torch.no_grad():
+            g._quaternions.copy_(torch.randn(g._quaternions.shape, generator=gen).to(dev))
+            g._scales.add_(0.3 * torch.randn(g._scales.shape, generator=gen).to(dev))
+            g.all_densities.add_(torch.randn(g.all_densities.shape, generator=gen).to(dev))
+            g._sh_coordinates_dc.mul_(2.5)                                     # beyond the clip on both sides, below the zero clamp
+            g._points.add_(0.01 * torch.randn(g._points.shape, generator=gen).to(dev))
+        g.fused_attributes = mode == "hip"
+        a = g.render_attributes()
+        assert ("colors6" in a) == (mode == "hip")
+        w = {k: torch.randn(a[k].shape, generator=gen).to(dev) for k in ("xyz", "opacity", "scaling", "rotation", "rgb", "normals")}
+        sum((a[k] * w[k]).sum() for k in w).backward()
+        res[mode] = ({k: a[k].detach().clone() for k in w}, {n: p.grad.clone() for n, p in g.named_parameters() if p.requires_grad and p.numel()})
+    (va, ga), (vb, gb) = res["torch"], res["hip"]
+    for k in va:
+        assert float((va[k] - vb[k]).abs().max()) <= 2e-6 * max(float(va[k].abs().max()), 1.0), (k, float((va[k] - vb[k]).abs().max()))
+    assert set(ga) == set(gb) and len(ga) >= 5
+    for n in ga:
+        scale = float(ga[n].abs().max())
+        assert scale > 0 and float((ga[n] - gb[n]).abs().max()) <= 3e-5 * scale, (n, float((ga[n] - gb[n]).abs().max()), scale)
