@@ -364,6 +364,26 @@ class ShardedAdamW:
             _lib.check(_lib.lib().dm4d_adamw_message(C.byref(seg), C.byref(a), 1.0, torch.cuda.current_stream(dev).cuda_stream), "dm4d_adamw_message")
         self.step_count += 1
 
+    def state_dict(self):
+        """The optimiser's own state: this rank's slice of the two moments (message layout), the steps applied and the pending decay
+        factors.  (The message layout is a function of the reducer's parameters and touched-index sets: a checkpoint resumes into a
+        stage constructed the same way.)"""
+        return {"exp_avg": self.exp_avg.clone(), "exp_avg_sq": self.exp_avg_sq.clone(),
+                "step": None if self.step_t is None else self.step_t.clone(),
+                "pending_decay": None if self.pending_decay is None else self.pending_decay.clone(),
+                "lr": [float(g["lr"]) for g in self.param_groups], "world": world(), "elements": int(self.reducer.flat.numel())}
+
+    def load_state_dict(self, sd):
+        if int(sd["elements"]) != int(self.reducer.flat.numel()) or int(sd["world"]) != world() or tuple(sd["exp_avg"].shape) != tuple(self.exp_avg.shape):
+            raise ValueError("ShardedAdamW.load_state_dict: the state belongs to another message layout / world size")
+        dev = self.exp_avg.device
+        self.exp_avg.copy_(sd["exp_avg"].to(dev))
+        self.exp_avg_sq.copy_(sd["exp_avg_sq"].to(dev))
+        self.step_t = None if sd["step"] is None else sd["step"].to(dev, torch.float64).clone()
+        self.pending_decay = None if sd["pending_decay"] is None else sd["pending_decay"].to(dev, torch.float64).clone()
+        for g, lr in zip(self.param_groups, sd["lr"]):
+            g["lr"] = lr
+
     def _unpack_message(self):
         red = self.reducer
         for q, o, ix in zip(red.params, red.offsets, red.index):

@@ -74,3 +74,34 @@ def test_message_space_adamw_equals_the_dense_optimiser():
     # the parameters moved (the check above is not comparing initial values), also outside the message (weight decay)
     p0, _ = _setup(dev, 3)
     assert all(float((x - y).abs().max()) > 1e-4 for x, y in zip(p0, runs["fused"]))
+
+
+def test_optimiser_state_round_trip():
+    """state_dict / load_state_dict of the message-space optimiser: a second instance continued from the first one's state takes
+    the same steps bit for bit."""
+    if not torch.cuda.is_available():
+        pytest.skip("no HIP device")
+    from dreammesh4d_amd import distributed as D
+
+    dev = torch.device("cuda:0")
+    out = []
+    for resume in (False, True):
+        params, touched = _setup(dev, 4)
+        groups = [{"params": params[:2], "lr": 3.2e-3, "name": "deformation"}, {"params": params[2:], "lr": 3.2e-2, "name": "grid"}]
+        opt = D.ShardedAdamW(groups, D.GradAllReducer(params, touched=touched), betas=(0.9, 0.99), eps=1e-15)
+        for step in range(4):
+            if resume and step == 2:
+                sd, vals = opt.state_dict(), [p.detach().clone() for p in params]
+                params, touched = _setup(dev, 4)
+                with torch.no_grad():
+                    for p, v in zip(params, vals):
+                        p.copy_(v)
+                groups = [{"params": params[:2], "lr": 1.0, "name": "deformation"}, {"params": params[2:], "lr": 1.0, "name": "grid"}]
+                opt = D.ShardedAdamW(groups, D.GradAllReducer(params, touched=touched), betas=(0.9, 0.99), eps=1e-15)
+                opt.load_state_dict(sd)
+            for p, gr in zip(params, _grads(params, touched, step, dev)):
+                p.grad = gr
+            opt.step()
+        opt.materialize()
+        out.append([p.detach().clone() for p in params])
+    assert all(torch.equal(a, b) for a, b in zip(*out))
