@@ -582,6 +582,192 @@ __global__ __launch_bounds__(256 * NWN) void k_conv3x3_direct(ConvDesc d, int ch
     conv3x3_direct_tile<NWN, RING, AHEAD>(d, chunks_per_split, lgTW);
 }
 
+// ---------------------------------------------------------------------------------------- direct variant, rolled tap loop
+// The unrolled template above keeps every tap's swizzled fragment address in a register for the whole kernel (~130 of its 227 VGPRs):
+// two waves per SIMD, whose LDS reads, DMA issue and MFMAs then hardly overlap.  Here the SAME tile algebra for a 256-pixel x 64-filter
+// workgroup of 4 waves with the tap loop ROLLED over the three taps of a row (the row loop unrolled: which of a lane's three patch rows a
+// tap reads stays a compile-time register choice), the fragment addresses computed at each use (~6 VALU operations per 16-byte read, beside
+// 8 MFMAs per k-tile), a 3-stage filter ring (stage = column of the tap) fetched 2 ahead, and ONE patch buffer, re-fetched behind a
+// barrier at the chunk boundary: 37 KB of LDS and <= 128 registers -- FOUR workgroups per CU, which hide each other's boundaries and
+// whose LDS reads overlap with each other's MFMAs.
+template <int kRing, int kAhead>
+__device__ __forceinline__ void conv3x3_direct4_tile(const ConvDesc &d, int chunks_per_split, int lgTW)
+{
+    constexpr int BM = 256, BN = 64, NW = 4;
+    constexpr int kPieces = kDirPatchSlots / (64 * NW), kBSlots = 256;
+    static_assert(kAhead >= 2 && kAhead <= 9 && kRing >= kAhead + 1, "ring");
+    extern __shared__ __attribute__((aligned(1024))) uint4 smem[];
+    [[maybe_unused]] const int cv_probe = d.probe;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave;
+    const int W = d.W, TW = 1 << lgTW, PW = TW + 2, TH = BM >> lgTW, R = d.N * d.H;
+    const int ncb = W >> lgTW, rblk = blockIdx.x / ncb, cb = blockIdx.x - rblk * ncb;
+    const int g0 = rblk * TH, x0 = cb << lgTW, n0 = blockIdx.y * BN;
+    const int cpt = d.Cin / kCvBK;
+    const int ch0 = blockIdx.z * chunks_per_split, nch = min(cpt, ch0 + chunks_per_split) - ch0;
+    const int patch_px = (TH + 2) * PW;
+    constexpr unsigned kOob = 0x80000000u;
+    // LDS: [zeros | patch | filter ring]
+    uint4 *const s_patch = smem + kDirZeroSlots;
+    uint4 *const s_b = smem + kDirZeroSlots + kDirPatchSlots;             // [kRing][kBSlots]
+    if (tid < kDirZeroSlots) smem[tid] = make_uint4(0u, 0u, 0u, 0u);
+    const auto a_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16 *>(d.x) - (size_t)(W + 1) * d.Cin, 0,
+                                                        (int)(((size_t)d.M + 2 * W + 2) * d.Cin * 2), 0x00020000);
+    const auto b_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16 *>(d.w), 0, (int)((size_t)d.Cout * 9 * d.Cin * 2), 0x00020000);
+    unsigned p_vo[kPieces];
+#pragma unroll
+    for (int i = 0; i < kPieces; ++i) {
+        const int s = 64 * (wave * kPieces + i) + lane, q = s >> 2, c = (s & 3) ^ ((q >> 2) & 3);
+        const int pr = q / PW, pc = q - pr * PW;
+        const int g = g0 - 1 + pr, x = x0 - 1 + pc;
+        const bool ok = q < patch_px && (unsigned)x < (unsigned)W && (unsigned)g < (unsigned)R;
+        p_vo[i] = ok ? (unsigned)((g + 1) * W + x + 1) * (unsigned)(d.Cin * 2) + 16u * c : kOob;
+    }
+    unsigned b_vo;
+    {
+        const int s = 64 * wave + lane, r = s >> 2, c = (s & 3) ^ ((r >> 2) & 3);
+        const int co = n0 + r;
+        b_vo = co < d.Cout ? (unsigned)co * (unsigned)(9 * d.Cin * 2) + 16u * c : kOob;
+    }
+    const int cin2 = d.Cin * 2;
+    auto issue_patch = [&](int piece, int chunk) {
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rs, (__attribute__((address_space(3))) void *)(s_patch + 64 * (wave * kPieces + piece)), 16, p_vo[piece],
+                                                 (ch0 + chunk) * (kCvBK * 2), 0, 0);
+    };
+    auto issue_b = [&](int tap, int stage, int chunk) {
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(b_rs, (__attribute__((address_space(3))) void *)(s_b + stage * kBSlots + 64 * wave), 16, b_vo,
+                                                 tap * cin2 + (ch0 + chunk) * (kCvBK * 2), 0, 0);
+    };
+    int row_of[2], qa[2][3];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int r = 64 * wm + 32 * i + (lane & 31), tr = r >> lgTW, tc = r & (TW - 1);
+        const int g = g0 + tr, y = g % d.H;
+        const bool row_ok = g < R;
+        const int q = (tr + 1) * PW + tc + 1;
+        row_of[i] = r;
+        qa[i][0] = (row_ok && y > 0) ? q - PW : -2;
+        qa[i][1] = row_ok ? q : -2;
+        qa[i][2] = (row_ok && y < d.H - 1) ? q + PW : -2;
+    }
+    const int hi = lane >> 5;
+    unsigned fb[2][2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+            fb[ks][j] = (unsigned)(size_t)(__attribute__((address_space(3))) uint4 *)(s_b + cv_slot(32 * j + (lane & 31), 2 * ks + hi));
+    const unsigned pb0 = (unsigned)(size_t)(__attribute__((address_space(3))) uint4 *)s_patch;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    f16x8 ra[2][2] = {}, rb[2][2] = {};
+    // fragments of half step ks: patch pixels q0 / q1 (tap shift applied), filter ring stage `stage`
+    auto read = [&](auto KS, int q0, int q1, int stage) {
+        constexpr int ks = decltype(KS)::value;
+        const int qq[2] = {q0, q1};
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int q = qq[i];
+            const unsigned a = pb0 + 16u * (unsigned)(4 * q + ((2 * ks + hi) ^ ((q >> 2) & 3)));
+            ra[ks][i] = *reinterpret_cast<const __attribute__((address_space(3))) f16x8 *>(a);
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+            rb[ks][j] = *reinterpret_cast<const __attribute__((address_space(3))) f16x8 *>(fb[ks][j] + (unsigned)stage * (kBSlots * 16));
+    };
+    auto mma = [&](auto KS) {
+        constexpr int ks = decltype(KS)::value;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(rb[ks][j], ra[ks][i], acc[i][j], 0, 0, 0);
+    };
+    using K0 = std::integral_constant<int, 0>;
+    using K1 = std::integral_constant<int, 1>;
+
+    // k-tile t = (chunk t / 9, tap t % 9) lives in ring stage t % kRing; tiles t + 1 .. t + kAhead - 1 are in flight while t is multiplied
+    const int T = nch * 9;
+    if (nch > 0) {
+#pragma unroll
+        for (int i = 0; i < kPieces; ++i) issue_patch(i, 0);
+#pragma unroll
+        for (int k = 0; k < kAhead; ++k)
+            if (k < T) issue_b(k % 9, k % kRing, k / 9);
+        if (T >= kAhead) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kAhead - 1) : "memory");      // the patch and tile 0 have landed (in order)
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __syncthreads();                                                       // (also publishes the zero region)
+    if (nch > 0) read(K0{}, qa[0][0] - 1, qa[1][0] - 1, 0);
+    int t = 0, st_cur = 0, st_iss = kAhead % kRing, tap_iss = kAhead % 9, ch_iss = kAhead / 9;      // tile being multiplied; stage / (tap, chunk) of tile t + kAhead
+    for (int ch = 0; ch < nch; ++ch) {
+        const bool more = ch + 1 < nch;
+        // the three taps of patch row DY (compile time), rolled over the column dxi = 0, 1, 2 (tap = 3 DY + dxi, ring stage = dxi)
+        auto row = [&](auto DY) {
+            constexpr int dy = decltype(DY)::value;
+#pragma unroll 1
+            for (int dxi = 0; dxi < 3; ++dxi) {
+                const int tap = 3 * dy + dxi;
+                const bool final_tile = !more && tap == 8;
+                const int st_next = st_cur + 1 == kRing ? 0 : st_cur + 1;
+                read(K1{}, qa[0][dy] + dxi - 1, qa[1][dy] + dxi - 1, st_cur);
+                __builtin_amdgcn_sched_barrier(0);
+                mma(K0{});
+                if (!final_tile) {
+                    // k-tile + 1's filters have landed: of the kAhead - 1 tiles in flight the youngest kAhead - 2 may stay (the DMA retires in
+                    // order); near the end of the stream fewer are in flight and the count is no measure: wait for all
+                    if (t + kAhead - 1 < T) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kAhead - 2) : "memory");
+                    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_s_barrier();
+                    if (t + kAhead < T) issue_b(tap_iss, st_iss, ch_iss);            // k-tile + kAhead goes into a stage every wave has left
+                    if (tap != 8) {
+                        constexpr int dyn = dy < 2 ? dy + 1 : 2;
+                        const bool wrap = dxi == 2;
+                        read(K0{}, wrap ? qa[0][dyn] - 1 : qa[0][dy] + dxi, wrap ? qa[1][dyn] - 1 : qa[1][dy] + dxi, st_next);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                mma(K1{});
+                __builtin_amdgcn_sched_barrier(0);
+                ++t;
+                st_cur = st_next;
+                st_iss = st_iss + 1 == kRing ? 0 : st_iss + 1;
+                if (++tap_iss == 9) { tap_iss = 0; ++ch_iss; }
+            }
+        };
+        row(std::integral_constant<int, 0>{});
+        row(std::integral_constant<int, 1>{});
+        row(std::integral_constant<int, 2>{});
+        if (more) {
+            // every wave is done with the chunk's patch -> the next chunk's -> first fragments of its tap 0 (the CU's other workgroups
+            // run their taps meanwhile)
+            __builtin_amdgcn_s_barrier();
+#pragma unroll
+            for (int i = 0; i < kPieces; ++i) issue_patch(i, ch + 1);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            read(K0{}, qa[0][0] - 1, qa[1][0] - 1, st_cur);
+        }
+    }
+    static_assert((size_t)BM * (BN * 2 + 16) <= (size_t)(kDirZeroSlots + kDirPatchSlots + kRing * kBSlots) * 16, "epilogue staging does not fit");
+    conv_epilogue<BM, BN, NW>(d, acc, row_of, 0, n0, reinterpret_cast<char *>(smem), tid, lane, cv_probe, [&](int row) {
+        const int g = g0 + (row >> lgTW);
+        return g < R ? g * W + x0 + (row & (TW - 1)) : -1;
+    });
+}
+
+template <int kRing, int kAhead, int kOcc>
+__global__ __launch_bounds__(256, kOcc) void k_conv3x3_direct4(ConvDesc d, int chunks_per_split, int lgTW)
+{
+    conv3x3_direct4_tile<kRing, kAhead>(d, chunks_per_split, lgTW);
+}
+
 // y = sum over splits of partial + bias (+ res), 8 outputs per thread
 __global__ __launch_bounds__(256) void k_conv_reduce(ConvDesc d)
 {
@@ -670,8 +856,8 @@ __global__ __launch_bounds__(256) void k_conv3x3_c128_small(int N, int H, int W,
 // (256 x 128 implicit-GEMM tiles with 64 x 64 or 128 x 64 wave tiles were tried and removed: 256 VGPRs with spills.)
 static void cfg_tile(int cfg, int &BM, int &BN)
 {
-    BM = (cfg == 7 || cfg == 9) ? 256 : 128;
-    BN = cfg == 9 ? 64 : 128;
+    BM = (cfg == 7 || cfg == 9 || cfg == 12) ? 256 : 128;
+    BN = (cfg == 9 || cfg == 12) ? 64 : 128;
 }
 // (A/B switches, read once: the problem size from which the direct kernel takes the narrow images, the k-tiles a split must keep)
 static double direct_gflop() { static const double v = [] { const char *e = getenv("DM4D_CONV_DIRECT_GFLOP"); return e ? atof(e) : 14.0; }(); return v; }
@@ -686,7 +872,12 @@ static int conv_plan(int M, int W, int Cout, int kt_total, int &cfg, int &splits
     // wins up to 28 GFLOP by up to 25 %, but in the step its float32 partial sums and second launch cost more than on an idle, cache-warm chip
     else if (W >= 8 && (W & (W - 1)) == 0 && (W >= 64 || (double)M * Cout * kt_total * kCvBK * 2.0 >= direct_gflop() * 1e9)) {
         static const int dcfg = [] { const char *e = getenv("DM4D_CONV_DIRECT_CFG"); return e ? atoi(e) : 7; }();      // (A/B switch: 7 or 9)
-        cfg = dcfg == 9 ? 9 : 7;
+        cfg = (dcfg == 9 || dcfg == 12) ? dcfg : 7;
+        // the rolled-tap variant (four 4-wave workgroups per CU) where the grid gives every CU at least four 256 x 64 tiles: the VAE
+        // encoder's 256^2 and 128^2 levels (-12 / -10 / -4 % per call, tools/conv_cfg_vae.py); below that its chunk-boundary patch
+        // fetch is exposed and the 8-wave kernel wins (64^2: +6 ... +10 %)
+        static const long d4_min = [] { const char *e = getenv("DM4D_CONV_D4_MIN_WGS"); return e ? atol(e) : 1024L; }();      // (A/B switch; 0: never)
+        if (cfg == 7 && d4_min > 0 && (long)((M + 255) / 256) * ((Cout + 63) / 64) >= d4_min) cfg = 12;
     }
     else cfg = 3;
     int BM, BN;
@@ -740,7 +931,7 @@ static inline int conv_out(int in, int stride, int pad) { return stride == 1 ? i
 static int conv_plan_s(int M, int W, int Cout, int kt_total, int stride, int &cfg, int &splits)
 {
     const int rc = conv_plan(M, stride == 1 ? W : 0, Cout, kt_total, cfg, splits);
-    if (stride != 1 && (cfg == 7 || cfg == 9)) cfg = 3;
+    if (stride != 1 && (cfg == 7 || cfg == 9 || cfg == 12)) cfg = 3;
     return rc;
 }
 
@@ -800,7 +991,7 @@ int dm4d_conv3x3_strided_nhwc_f16(int32_t N, int32_t Hin, int32_t Win, int32_t C
 #endif
     int cfg;
     conv_plan_s(d.M, W, Cout, d.kt_total, stride, cfg, d.splits);
-    if ((cfg == 7 || cfg == 9) && (stride != 1 || pad != 1)) { set_error("conv3x3: the direct kernel takes stride 1, pad 1 only"); return DM4D_ERR_UNSUPPORTED; }
+    if ((cfg == 7 || cfg == 9 || cfg == 12) && (stride != 1 || pad != 1)) { set_error("conv3x3: the direct kernel takes stride 1, pad 1 only"); return DM4D_ERR_UNSUPPORTED; }
     d.kt_per = (d.kt_total + d.splits - 1) / d.splits;
     d.splits = (d.kt_total + d.kt_per - 1) / d.kt_per;
     d.partial = (float *)scratch;
@@ -814,7 +1005,7 @@ int dm4d_conv3x3_strided_nhwc_f16(int32_t N, int32_t Hin, int32_t Win, int32_t C
     case 11: rc = conv_launch<2, 2, 2, 2, 6>(d, st); break;      // ... 6-deep (96 KB: one workgroup per CU)
     case 4: rc = conv_launch<4, 2, 1, 2, 3>(d, st); break;
     case 6: rc = conv_launch<4, 2, 1, 2, 4>(d, st); break;
-    case 7: case 9: {      // direct: 256 pixels x 128 (7) / 64 (9) filters, the input patch resident in LDS for the nine taps
+    case 7: case 9: case 12: {      // direct: 256 pixels x 128 (7) / 64 (9) filters, the input patch resident in LDS for the nine taps
         const int W_ = d.W;
         if (W_ < 8 || (W_ & (W_ - 1)) != 0) { set_error("conv3x3 direct: W must be a power of two >= 8"); return DM4D_ERR_UNSUPPORTED; }
         int lgTW = 3;
@@ -828,6 +1019,11 @@ int dm4d_conv3x3_strided_nhwc_f16(int32_t N, int32_t Hin, int32_t Win, int32_t C
             static bool attr_set = false;
             if (!attr_set) { DM4D_HIP_CHECK(hipFuncSetAttribute((const void *)k_conv3x3_direct<2, 9, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr_set = true; }
             hipLaunchKernelGGL((k_conv3x3_direct<2, 9, 4>), dim3(tiles_m, (d.Cout + 127) / 128, d.splits), dim3(512), lds, st, d, chunks_per_split, lgTW);
+        } else if (cfg == 12) { // 4 waves, 256 x 64, rolled tap loop, one patch buffer: four workgroups per CU
+            const size_t lds = (size_t)(kDirZeroSlots + kDirPatchSlots + 3 * 256) * 16;
+            static bool attr_set = false;
+            if (!attr_set) { DM4D_HIP_CHECK(hipFuncSetAttribute((const void *)k_conv3x3_direct4<3, 2, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr_set = true; }
+            hipLaunchKernelGGL((k_conv3x3_direct4<3, 2, 4>), dim3(tiles_m, (d.Cout + 63) / 64, d.splits), dim3(256), lds, st, d, chunks_per_split, lgTW);
         } else {                // 4 waves, 256 x 64, two workgroups per CU (one fills the bubble around the other's barrier)
             const size_t lds = (size_t)dir_lds_slots<1, 3>() * 16;
             static bool attr_set = false;
