@@ -295,6 +295,8 @@ def main():
                                    f"({wl.topo.F} faces x 6), {N_NODES} graph nodes K={K_NBR} hybrid LBS/DQS skinning, "
                                    f"512x512; per view: skinning + face->Gaussian + RGB pass + normal pass, fwd+bwd"
                                    + ("" if wl.depth_grad else "; no gradient on the depth image, as in the shipped configuration (no depth loss)"),
+                       "comparability": "rounds 1-2 timed this step WITH a gradient on the depth image (48-byte records): their `value` compares with "
+                                        "`with_depth_gradient.views_per_s` below; from round 3 on `value` is the shipped configuration's step (no depth loss)",
                        "views_per_step_per_gpu": VIEWS_PER_STEP, "untimed_settle_steps": settle, "frames_per_step_per_gpu": FRAMES_PER_STEP,
                        "mean_duplicates_D": round(D_mean), "allreduce_bytes_per_step": reducer.nbytes if world > 1 else 0,
                        "allreduce_message_bytes": reducer.nbytes, "dense_gradient_bytes": 4 * reducer.dense_elements,
