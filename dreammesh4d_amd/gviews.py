@@ -24,6 +24,8 @@ class GaussianViews(ViewRenderer):
                  deterministic=True):
         self.graph = self.topo = None
         self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise _lib.Dm4dError("render_gaussian_views runs on the HIP device (there is no CPU fallback in the product)")
         self.H, self.W = int(image_height), int(image_width)
         self.tanfov = float(tanfov)
         self.scale_modifier = float(scale_modifier)

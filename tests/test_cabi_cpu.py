@@ -53,6 +53,37 @@ def test_product_has_no_cpu_fallback():
                                    scales=z + 1, rotations=torch.zeros(4, 4))
 
 
+def test_round4_operators_have_no_cpu_path_either():
+    """The batched static renderer, the static image head and the step object refuse CPU tensors (no fallback), and the new C entry
+    points reject bad arguments before touching a device."""
+    import ctypes as C
+
+    import torch
+
+    from dreammesh4d_amd import _lib, gviews, static_head
+
+    with pytest.raises(_lib.Dm4dError, match="no CPU fallback"):
+        gviews.GaussianViews(100, 64, 64, 0.2, "cpu")
+    z = torch.zeros(2, 6, 8, 8)
+    with pytest.raises(ValueError, match="float32 HIP tensors"):
+        static_head.static_head(z, z[:, :1], z[:, :1], torch.zeros(2, dtype=torch.int32), torch.zeros(2, dtype=torch.int32),
+                                torch.zeros(1, 8, 8, 3), torch.zeros(1, 8, 8, 1), torch.zeros(1, dtype=torch.int64), 1, 1)
+    L = _lib.lib()
+    dummy = (C.c_float * 64)()
+    p = C.cast(dummy, C.c_void_p)
+    assert L.dm4d_static_head_forward(2, 7, 8, p, p, p, p, p, p, p, p, 1, 1, p, p, None) == -4            # odd height: DM4D_ERR_UNSUPPORTED
+    assert b"H and W must be even" in L.dm4d_last_error()
+    assert L.dm4d_sugar_attributes_forward(10, 5, 30, p, p, p, p, p, p, p, 1e-6, 1.0, p, p, p, p, p, None) == -1      # G = 5
+    assert L.dm4d_sds_prepare(0, 32, 32, 0.18, p, p, p, p, p, p, p, p, p, p, p, p, p, p, p, p, None) == -1
+    gv = _lib.GViewsStruct()
+    gv.B, gv.N, gv.image_height, gv.image_width = 0, 10, 64, 64
+    assert L.dm4d_gviews_forward(C.byref(gv), None) == -1 and b"bad batch size" in L.dm4d_last_error()
+    assert L.dm4d_step_forward(None, p, p, p, None, None) == -1 and b"not a step object" in L.dm4d_last_error()
+    args = _lib.AdamwArgs()
+    seg = _lib.GradSegments()
+    assert L.dm4d_adamw_message(C.byref(seg), C.byref(args), 1.0, None) == -1 and b"null state" in L.dm4d_last_error()
+
+
 def test_argument_validation_is_host_side():
     """Entry points reject bad arguments before touching the device (so this runs without a GPU): the rasterizer's limits,
     the GroupNorm / pointwise operators' shape rules; the message is available through dm4d_last_error."""
