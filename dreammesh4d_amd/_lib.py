@@ -181,6 +181,9 @@ _SIGNATURES = {
     "dm4d_image_head_blocks": (C.c_int32, [C.c_int32, C.c_int32]),
     "dm4d_image_head_forward": (C.c_int, [C.c_int32] * 4 + [vp] * 7 + [C.c_int32, C.c_int32, vp, vp, vp]),
     "dm4d_image_head_backward": (C.c_int, [C.c_int32] * 4 + [vp] * 7 + [C.c_int32, C.c_int32] + [vp] * 6),
+    "dm4d_partial_sums": (C.c_int, [C.c_int64, C.c_int32, C.c_int32, vp, C.POINTER(C.c_float), vp, vp]),
+    "dm4d_weighted_sum": (C.c_int, [C.c_int32, C.POINTER(C.c_void_p), C.POINTER(C.c_float), vp, vp]),
+    "dm4d_weighted_sum_backward": (C.c_int, [C.c_int32, vp, C.POINTER(C.c_float), vp, vp]),
     "dm4d_static_head_blocks": (C.c_int32, [C.c_int32, C.c_int32]),
     "dm4d_static_head_forward": (C.c_int, [C.c_int32] * 3 + [vp] * 8 + [C.c_int32, C.c_int32, vp, vp, vp]),
     "dm4d_static_head_backward": (C.c_int, [C.c_int32] * 3 + [vp] * 8 + [C.c_int32, C.c_int32, vp, vp, vp, vp, vp, vp]),

@@ -114,6 +114,52 @@ __global__ __launch_bounds__(kHeadThreads) void k_head_bwd(HeadArgs a, const flo
 
 using namespace dm4d;
 
+// ---------------------------------------------------------------------------------------- the scalar arithmetic around the heads
+// What the systems do with a head's partial sums and with the loss terms (`loss = 0.0 + lambda_a * a + lambda_b * b + ...`,
+// system/sugar_4dgen.py:296-330, sugar_static.py:246-340) is a dozen 1-element torch operators forward and as many backward:
+// 5 us of launch each for one multiply.  Three one-workgroup kernels instead.
+constexpr int kGlueMax = 16;
+struct SumArgs { int64_t n; int k, m; float mat[8 * 8]; };
+// out[j] = sum_c mat[c][j] * (sum_i partial[i * k + c]); one workgroup, fixed order (deterministic)
+__global__ __launch_bounds__(256) void k_partial_sums(SumArgs a, const float *__restrict__ partial, float *__restrict__ out)
+{
+    __shared__ float s[8][256];
+    const int tid = threadIdx.x;
+    float acc[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) acc[c] = 0.f;
+    for (int64_t i = tid; i < a.n; i += 256)
+#pragma unroll
+        for (int c = 0; c < 8; ++c)
+            if (c < a.k) acc[c] += partial[i * a.k + c];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) s[c][tid] = acc[c];
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if (tid < w)
+#pragma unroll
+            for (int c = 0; c < 8; ++c) s[c][tid] += s[c][tid + w];
+        __syncthreads();
+    }
+    if (tid < a.m) {
+        float o = 0.f;
+        for (int c = 0; c < a.k; ++c) o += a.mat[c * a.m + tid] * s[c][0];
+        out[tid] = o;
+    }
+}
+struct WsumArgs { int n; const float *t[kGlueMax]; float w[kGlueMax]; };
+__global__ void k_weighted_sum(WsumArgs a, float *__restrict__ out)
+{
+    float acc = 0.0f;
+    for (int i = 0; i < a.n; ++i) acc = acc + a.w[i] * a.t[i][0];      // (the float32 roundings of the torch expression, left to right)
+    out[0] = acc;
+}
+__global__ void k_weighted_sum_bwd(WsumArgs a, const float *__restrict__ g, float *__restrict__ out)
+{
+    const int i = threadIdx.x;
+    if (i < a.n) out[i] = g[0] * a.w[i];
+}
+
 extern "C" {
 
 static int head_check(int B, int H, int W, int C, const void *color, const void *alpha, const void *ref_pos, const void *rnd_pos, int n_ref,
@@ -158,6 +204,54 @@ int dm4d_image_head_backward(int32_t B, int32_t H, int32_t W, int32_t C, const f
     HeadArgs a{B, H, W, C, color, alpha, ref_pos, rnd_pos, ref_images, ref_masks, fidx_ref, n_ref, n_rnd};
     hipLaunchKernelGGL(k_head_bwd, dim3(dm4d_image_head_blocks(H, W), B), dim3(kHeadThreads), 0, (hipStream_t)stream, a, g_rgb, g_mask, g_half, g_color,
                        g_alpha);
+    DM4D_HIP_CHECK(hipGetLastError());
+    return DM4D_OK;
+}
+
+int dm4d_partial_sums(int64_t n, int32_t k, int32_t m, const float *partial, const float *matrix, float *out, dm4d_stream_t stream)
+{
+    if (n < 0 || k < 1 || k > 8 || m < 1 || m > 8) { set_error("partial sums: n >= 0, 1 <= k, m <= 8 (got %lld, %d, %d)", (long long)n, k, m); return DM4D_ERR_INVALID; }
+    if ((n > 0 && !partial) || !matrix || !out) { set_error("partial sums: null pointer"); return DM4D_ERR_INVALID; }
+    SumArgs a;
+    a.n = n; a.k = k; a.m = m;
+    for (int i = 0; i < k * m; ++i) a.mat[i] = matrix[i];
+    hipLaunchKernelGGL(k_partial_sums, dim3(1), dim3(256), 0, (hipStream_t)stream, a, partial, out);
+    DM4D_HIP_CHECK(hipGetLastError());
+    return DM4D_OK;
+}
+
+static int wsum_args(WsumArgs &a, int32_t n, const float *const *terms, const float *weights)
+{
+    if (n < 1 || n > kGlueMax) { set_error("weighted sum: 1 <= n <= %d terms (got %d)", kGlueMax, n); return DM4D_ERR_INVALID; }
+    if (!weights) { set_error("weighted sum: null weights"); return DM4D_ERR_INVALID; }
+    a.n = n;
+    for (int i = 0; i < n; ++i) {
+        a.t[i] = terms ? terms[i] : nullptr;
+        a.w[i] = weights[i];
+    }
+    return DM4D_OK;
+}
+
+int dm4d_weighted_sum(int32_t n, const float *const *terms, const float *weights, float *out, dm4d_stream_t stream)
+{
+    WsumArgs a;
+    int rc = wsum_args(a, n, terms, weights);
+    if (rc != DM4D_OK) return rc;
+    if (!terms || !out) { set_error("weighted sum: null pointer"); return DM4D_ERR_INVALID; }
+    for (int i = 0; i < n; ++i)
+        if (!terms[i]) { set_error("weighted sum: term %d is null", i); return DM4D_ERR_INVALID; }
+    hipLaunchKernelGGL(k_weighted_sum, dim3(1), dim3(1), 0, (hipStream_t)stream, a, out);
+    DM4D_HIP_CHECK(hipGetLastError());
+    return DM4D_OK;
+}
+
+int dm4d_weighted_sum_backward(int32_t n, const float *g, const float *weights, float *out, dm4d_stream_t stream)
+{
+    WsumArgs a;
+    int rc = wsum_args(a, n, nullptr, weights);
+    if (rc != DM4D_OK) return rc;
+    if (!g || !out) { set_error("weighted sum: null pointer"); return DM4D_ERR_INVALID; }
+    hipLaunchKernelGGL(k_weighted_sum_bwd, dim3(1), dim3(64), 0, (hipStream_t)stream, a, g, out);
     DM4D_HIP_CHECK(hipGetLastError());
     return DM4D_OK;
 }

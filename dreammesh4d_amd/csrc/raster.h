@@ -276,8 +276,10 @@ __device__ __forceinline__ Bands cell_bands(float x, float y, float ca, float cb
     int bx1 = 4 * rc.x1, by1 = 4 * rc.y1;
     const float tau = __logf(255.0f * o) * 1.001f + 0.01f;
     const float det = ca * cc - cb * cb;
-    const float hx = sqrtf(2.0f * tau * cc / det) * 1.0001f + 0.02f;
-    const float hy = sqrtf(2.0f * tau * ca / det) * 1.0001f + 0.02f;
+    // (hardware sqrt / rcp, 1 ulp each: the 1e-4 margins are there for exactly this)
+    const float t2 = 2.0f * tau * __builtin_amdgcn_rcpf(det);
+    const float hx = __builtin_amdgcn_sqrtf(t2 * cc) * 1.0001f + 0.02f;
+    const float hy = __builtin_amdgcn_sqrtf(t2 * ca) * 1.0001f + 0.02f;
     if ((det > 0.f) && (hx == hx) && (hy == hy)) {
         // cell column b holds pixel centres 4b .. 4b+3: reached iff x + hx >= 4b and x - hx <= 4b + 3
         B.bx0 = max(B.bx0, f2i_sat(ceilf((x - hx - 3.0f) * 0.25f)));
@@ -298,15 +300,18 @@ __device__ __forceinline__ Bands cell_bands(float x, float y, float ca, float cb
 // where testing every cell against the four edges cost ~45 operations per CELL (36 of K1's 78 us).  Margins as in
 // cell_bands (they dwarf the rounding of the blend kernels' own power / exp): a culled cell holds no pixel with
 // alpha >= 1/255.
-struct EllipseRows { float L, det, ystar, yext, invA, B; };
+struct EllipseRows { float AL, det, ystar, yext, invA, B; };
 __device__ __forceinline__ EllipseRows ellipse_rows(float A, float B, float C, float tau)
 {
+    // hardware sqrt / rcp (1 ulp): the 1e-4 relative margins of row_span / yext cover them
     EllipseRows e;
-    e.L = 2.0f * tau * 1.0001f + 0.001f;
+    const float L = 2.0f * tau * 1.0001f + 0.001f;
     e.det = A * C - B * B;
-    e.ystar = B * sqrtf(e.L / (e.det * C));     // |ordinate| of the leftmost / rightmost point
-    e.yext = sqrtf(A * e.L / e.det) * 1.0001f;  // half extent in y
-    e.invA = 1.0f / A;
+    const float L_det = L * __builtin_amdgcn_rcpf(e.det);
+    e.ystar = B * __builtin_amdgcn_sqrtf(L_det * __builtin_amdgcn_rcpf(C));     // |ordinate| of the leftmost / rightmost point
+    e.yext = __builtin_amdgcn_sqrtf(A * L_det) * 1.0002f;  // half extent in y
+    e.invA = __builtin_amdgcn_rcpf(A);
+    e.AL = A * L;
     e.B = B;
     return e;
 }
@@ -318,9 +323,8 @@ __device__ __forceinline__ void row_span(const EllipseRows &e, float x, float y,
     b0 = 1; b1 = 0;
     if (!(ya <= yb)) return;
     const float yr = fminf(yb, fmaxf(ya, -e.ystar)), yl = fminf(yb, fmaxf(ya, e.ystar));
-    const float A_L = e.L / e.invA;
-    const float xhi = (-e.B * yr + sqrtf(fmaxf(0.f, A_L - e.det * yr * yr))) * e.invA;
-    const float xlo = (-e.B * yl - sqrtf(fmaxf(0.f, A_L - e.det * yl * yl))) * e.invA;
+    const float xhi = (-e.B * yr + __builtin_amdgcn_sqrtf(fmaxf(0.f, e.AL - e.det * yr * yr))) * e.invA;
+    const float xlo = (-e.B * yl - __builtin_amdgcn_sqrtf(fmaxf(0.f, e.AL - e.det * yl * yl))) * e.invA;
     const float m = 1.0e-4f * (fabsf(xhi) + fabsf(xlo)) + 0.02f;      // rounding of the two roots + the pixel margin
     b0 = f2i_sat(ceilf((x + xlo - m - 3.0f) * 0.25f));
     b1 = f2i_sat(floorf((x + xhi + m) * 0.25f));

@@ -29,6 +29,7 @@ import torch.nn.functional as F
 from . import distributed as D
 from . import synthetic as syn
 from .schedule import C
+from .loss_sum import weighted_sum
 from .views import render_views
 
 LAMBDA = {"sds_zero123": 0.1, "rgb": 5000.0, "mask": [200, 500.0, 5000.0, 1000],      # sugar_dynamic_dg.yaml:135-158
@@ -41,6 +42,31 @@ def quat_xyzw_to_matrix(q, grad_mode=None):
     return f(q, grad_mode)
 
 
+
+def upload_packed(arrays, device):
+    """{name: numpy array} -> {name: tensor on `device`}.  On a HIP device the arrays travel as ONE pinned, non-blocking copy (8-byte
+    aligned segments of one byte buffer, viewed with their dtypes): a dozen index lists of a few bytes each were a dozen copy
+    kernels in the stream (~5 us each at the head of every iteration) and, unpinned, a dozen staging copies on the host."""
+    import numpy as np
+
+    device = torch.device(device)
+    if device.type != "cuda":
+        return {k: torch.as_tensor(np.ascontiguousarray(v)).to(device) for k, v in arrays.items()}
+    offs, total = {}, 0
+    for k, v in arrays.items():
+        offs[k] = total
+        total += (v.nbytes + 7) // 8 * 8
+    host = torch.empty(max(total, 8), dtype=torch.uint8, pin_memory=True)      # (a fresh block of the caching host allocator: it is kept until the copy has run)
+    hv = host.numpy()
+    for k, v in arrays.items():
+        hv[offs[k]:offs[k] + v.nbytes] = np.ascontiguousarray(v).view(np.uint8).reshape(-1)
+    dev = host.to(device, non_blocking=True)
+    out = {}
+    for k, v in arrays.items():
+        out[k] = dev[offs[k]:offs[k] + v.nbytes].view(getattr(torch, str(v.dtype))).view(v.shape)
+    return out
+
+
 class DynamicStage:
     def __init__(self, renderer, net, nodes, static, timestamps, ref_images, ref_masks, ref_camera, guidance=None,
                  frames_per_step=4, random_views_per_frame=1, deformation_lr=0.00032, grid_lr=0.0032, seed=0,
@@ -51,6 +77,7 @@ class DynamicStage:
         self.lam = dict(LAMBDA)
         self.lam.update(lambdas or {})
         self.timestamps = timestamps                     # [L] in (0,1)
+        self._timestamps_host = None                     # (float32 copy on the host, sample_batch)
         # [L,H,W,3], [L,H,W,1]; the reference's gt image is composited on white outside the mask
         # (data/temporal_image.py:201-202) and the dynamic step compares it UNMASKED (system/sugar_4dgen.py:164-167)
         # (float32 on the stage's device whatever the data module delivered -- float64 from numpy, uint8-derived ...: the fused
@@ -133,7 +160,6 @@ class DynamicStage:
         # per array -- `x[mask]` / `mask.any()` on device tensors cost a host synchronisation each (six per iteration)
         import numpy as np
 
-        T = lambda a, dt=None: torch.as_tensor(np.asarray(a), dtype=dt).to(self.dev, non_blocking=True)
         ref_idx = [i for i, r in enumerate(is_ref) if r]
         rnd_idx = [i for i, r in enumerate(is_ref) if not r]
         ref_pos, rnd_pos = [-1] * len(is_ref), [-1] * len(is_ref)          # the view's index among the reference / random views (image_head)
@@ -142,12 +168,15 @@ class DynamicStage:
         for k, i in enumerate(rnd_idx):
             rnd_pos[i] = k
         fidx = [frames[u] for u in unit_frame]
-        return {"frames": frames, "vm": T(np.stack([c.viewmatrix for c in cams]), torch.float32),
-                "pm": T(np.stack([c.projmatrix for c in cams]), torch.float32), "unit_frame": T(unit_frame, torch.int32),
-                "ref_idx": T(ref_idx, torch.int64), "rnd_idx": T(rnd_idx, torch.int64), "n_ref": len(ref_idx), "n_rnd": len(rnd_idx),
-                "ref_pos": T(ref_pos, torch.int32), "rnd_pos": T(rnd_pos, torch.int32),
-                "frames_t_idx": T(frames, torch.int64), "fidx_ref": T([fidx[i] for i in ref_idx], torch.int64),
-                "fidx_rnd": T([fidx[i] for i in rnd_idx], torch.int64),
+        if self._timestamps_host is None or self._timestamps_host[1] is not self.timestamps:
+            self._timestamps_host = (self.timestamps.detach().to("cpu", torch.float32).numpy(), self.timestamps)      # (once: a host sync)
+        arrays = {"vm": np.stack([c.viewmatrix for c in cams]).astype(np.float32), "pm": np.stack([c.projmatrix for c in cams]).astype(np.float32),
+                  "frames_t": self._timestamps_host[0][frames], "unit_frame": np.asarray(unit_frame, np.int32),
+                  "ref_idx": np.asarray(ref_idx, np.int64), "rnd_idx": np.asarray(rnd_idx, np.int64),
+                  "ref_pos": np.asarray(ref_pos, np.int32), "rnd_pos": np.asarray(rnd_pos, np.int32),
+                  "frames_t_idx": np.asarray(frames, np.int64), "fidx_ref": np.asarray([fidx[i] for i in ref_idx], np.int64),
+                  "fidx_rnd": np.asarray([fidx[i] for i in rnd_idx], np.int64)}
+        return {"frames": frames, "n_ref": len(ref_idx), "n_rnd": len(rnd_idx), **upload_packed(arrays, self.dev),
                 "elev_rnd": torch.tensor([elev[i] for i in rnd_idx], dtype=torch.float32),        # (host tensors: see iteration())
                 "azim_rnd": torch.tensor([azim[i] for i in rnd_idx], dtype=torch.float32)}
 
@@ -199,7 +228,7 @@ class DynamicStage:
             else:                                   # yaml:115-116
                 self.guidance.update_step(0, it, min_step_percent=C(0.02, 0, it), max_step_percent=C(0.5, 0, it))
         b = self.sample_batch()
-        frames_t = self.timestamps[b["frames_t_idx"]]
+        frames_t = b["frames_t"]                 # = timestamps[frames], gathered on the host and uploaded with the cameras
         self.opt.zero_grad(set_to_none=True)
         u = b["unit_frame"]
         # views of the same frame share its skinning / face transform (reference: cached per timestamp within a step)
@@ -227,7 +256,9 @@ class DynamicStage:
         # (index_select, not `x[idx]`: the same rows, but a gather whose backward is ONE index_add launch -- advanced indexing
         # differentiates through a sort-based index_put: six launches per use, three uses per iteration.  The loss starts as the
         # number 0: `rgb.sum() * 0.0` was a full-resolution reduction forward and a full-resolution fill backward for nothing.)
-        loss = 0.0
+        # `loss = 0.0 + lambda_a * a + lambda_b * b + ...` is evaluated by ONE launch each way at the end (loss_sum.weighted_sum: the
+        # same float32 expression left to right; the torch operators -- two per term forward, two or three backward -- for CPU tensors)
+        pairs = []
         terms = {}
         if b["n_ref"]:
             if fused_head:
@@ -236,24 +267,25 @@ class DynamicStage:
                 ref = b["ref_idx"]
                 terms["rgb"] = F.mse_loss(self.ref_images.index_select(0, b["fidx_ref"]), rgb.index_select(0, ref))     # unmasked: colour outside the silhouette is penalised
                 terms["mask"] = F.mse_loss(mask.index_select(0, ref), self.ref_masks.index_select(0, b["fidx_ref"]))
-            loss = loss + C(self.lam["rgb"], 0, it) * terms["rgb"] + C(self.lam["mask"], 0, it) * terms["mask"]
+            pairs += [(C(self.lam["rgb"], 0, it), terms["rgb"]), (C(self.lam["mask"], 0, it), terms["mask"])]
         if self.guidance is not None and b["n_rnd"]:
             # elevation / azimuth stay on the HOST (they only feed the four-number camera embedding of get_cond: a dozen
             # elementwise launches on 4-element device tensors otherwise)
             g = self.guidance(half if fused_head else rgb.index_select(0, b["rnd_idx"]), b["elev_rnd"], b["azim_rnd"],
                               torch.full_like(b["elev_rnd"], 3.8), frame_indices=b["fidx_rnd"])
             terms["sds"] = g["loss_sds"]
-            loss = loss + C(self.lam["sds_zero123"], 0, it) * g["loss_sds"]
+            pairs.append((C(self.lam["sds_zero123"], 0, it), g["loss_sds"]))
         if self.normal_consistency is not None:
             # mesh_normal_consistency(get_timed_surface_mesh(batch timestamps)): the step's deformed meshes, one per frame
             terms["normal_consistency"] = self.normal_consistency(out["vxyz"])
-            loss = loss + C(self.lam["normal_consistency"], 0, it) * terms["normal_consistency"]
+            pairs.append((C(self.lam["normal_consistency"], 0, it), terms["normal_consistency"]))
         if self.arap is not None and it >= self.milestone_arap_reg:
             terms["arap_reg_key_frame"] = self.arap.compute_arap_energy(out["vxyz"], quat_xyzw_to_matrix(out["vrot"], self.r.grad_mode)).sum()
-            loss = loss + C(self.lam["arap_reg_key_frame"], 0, it) * terms["arap_reg_key_frame"]
+            pairs.append((C(self.lam["arap_reg_key_frame"], 0, it), terms["arap_reg_key_frame"]))
             if self.inter_frame_reg > 0 and it % self.inter_frame_reg == 0:
                 terms["arap_reg_inter_frame"] = self.inter_frame_arap()
-                loss = loss + C(self.lam["arap_reg_inter_frame"], 0, it) * terms["arap_reg_inter_frame"]
+                pairs.append((C(self.lam["arap_reg_inter_frame"], 0, it), terms["arap_reg_inter_frame"]))
+        loss = weighted_sum(pairs)
         if not torch.is_tensor(loss):                   # (no term applied: nothing to differentiate, but the step's contract is a backward)
             loss = out["color"].sum() * 0.0
         loss.backward()

@@ -27,9 +27,11 @@ class _ImageHead(torch.autograd.Function):
                                                  torch.cuda.current_stream(dev).cuda_stream), "dm4d_image_head_forward")
         ctx.save_for_backward(c, a, ref_pos, rnd_pos, ref_images, ref_masks, fidx_ref)
         ctx.n = (n_ref, n_rnd)
-        s = partial.view(-1, 2).sum(0)
+        from .loss_sum import partial_sums
+
         d = float(max(n_ref, 1) * H * W)
-        return s[0] / (3.0 * d), s[1] / d, half
+        s = partial_sums(partial.view(-1, 2), [[1.0 / (3.0 * d), 0.0], [0.0, 1.0 / d]])      # (one launch: sum + F.mse_loss's normalisation)
+        return s[0], s[1], half
 
     @staticmethod
     def backward(ctx, g_rgb, g_mask, g_half):

@@ -29,7 +29,9 @@ class _StaticHead(torch.autograd.Function):
                                                   torch.cuda.current_stream(dev).cuda_stream), "dm4d_static_head_forward")
         ctx.save_for_backward(c, d, a, ref_pos, rnd_pos, ref_images, ref_masks, fidx_ref)
         ctx.n = (n_ref, n_rnd)
-        return partial.sum(0) @ norm, half            # [8] sums -> the five terms (F.mse_loss's / tv_loss's normalisations: `norm` [8, 5])
+        from .loss_sum import partial_sums
+
+        return partial_sums(partial, norm), half      # [8] sums -> the five terms (F.mse_loss's / tv_loss's normalisations: `norm` [8][5]), one launch
 
     @staticmethod
     def backward(ctx, g_terms, g_half):
@@ -62,7 +64,7 @@ def _norm_matrix(H, W, n_ref, n_rnd, dev):
         for t, c in ((0, 3), (1, 1), (2, 3)):          # threestudio/utils/loss.py:8-16: 2 (h_tv / (c (h - 1) w) + w_tv / (c h (w - 1))) / b
             m[2 + 2 * t, 2 + t] = 2.0 / (c * (H - 1) * W * max(n_rnd, 1))
             m[3 + 2 * t, 2 + t] = 2.0 / (c * H * (W - 1) * max(n_rnd, 1))
-        _NORM[key] = m.to(torch.float32).to(dev)
+        _NORM[key] = m.tolist()          # host numbers: the sum kernel takes the matrix by value
     return _NORM[key]
 
 

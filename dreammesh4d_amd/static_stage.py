@@ -18,6 +18,7 @@ import torch.nn.functional as F
 
 from . import distributed as D
 from . import synthetic as syn
+from .loss_sum import weighted_sum
 from .schedule import C
 
 # sugar_static_refine.yaml:105-133 (terms with lambda 0 and the stage-"gaussian" SuGaR regularisers, which start at
@@ -96,7 +97,8 @@ class StaticStage:
             hp = self._head_positions()
             t5, half = static_head(raw["color"], raw["depth"], raw["alpha"], hp["ref_pos"], hp["rnd_pos"], self._ref_image_f, self._ref_mask_f,
                                    hp["fidx_ref"], 1, self.rv)
-            terms["rgb"], terms["mask"], tv_rgb, tv_depth, tv_normal = t5.unbind(0)
+            # (the five terms enter the loss as ONE vector, loss_sum.weighted_sum: unbinding them costs a stack of five gradients backward)
+            terms["rgb"], terms["mask"], tv_rgb, tv_depth, tv_normal = t5.detach().unbind(0)
             out = {"half": half, "tv": {"rgb_tv": tv_rgb, "depth_tv": tv_depth, "normal_tv": tv_normal}}
         else:
             both = self.r.batch_forward(batch)
@@ -106,7 +108,11 @@ class StaticStage:
             terms["mask"] = F.mse_loss(m, both["comp_mask"][:1])
             # ---- random substep
             out = {k: v[1:] for k, v in both.items() if torch.is_tensor(v)}
-        loss = C(self.lam["rgb"], 0, it) * terms["rgb"] + C(self.lam["mask"], 0, it) * terms["mask"]
+        # `loss = lambda_rgb * rgb + lambda_mask * mask + ...` as ONE launch each way (loss_sum.weighted_sum), evaluated left to right
+        if raw is not None:
+            pairs = [(tuple(C(self.lam[k], 0, it) for k in ("rgb", "mask", "rgb_tv", "depth_tv", "normal_tv")), t5)]
+        else:
+            pairs = [(C(self.lam["rgb"], 0, it), terms["rgb"]), (C(self.lam["mask"], 0, it), terms["mask"])]
         if self.guidance is not None:
             self.guidance.update_step(0, it)
             # (elevation / azimuth stay on the host: they only feed the four-number camera embedding, as in DynamicStage)
@@ -118,16 +124,18 @@ class StaticStage:
                 views = raw["color"][1:, :3].clamp(0, 1).permute(0, 2, 3, 1)         # any other size: the guidance resizes
             go = self.guidance(views, elev, azim, torch.full((self.rv,), 3.8))
             terms["sds"] = go["loss_sds"]
-            loss = loss + C(self.lam["sds"], 0, it) * terms["sds"]
+            pairs.append((C(self.lam["sds"], 0, it), terms["sds"]))
         if self.nc is not None:
             terms["normal_consistency"] = self.nc(g.get_xyz_verts)
-            loss = loss + C(self.lam["normal_consistency"], 0, it) * terms["normal_consistency"]
+            pairs.append((C(self.lam["normal_consistency"], 0, it), terms["normal_consistency"]))
         if self.lap is not None:
             terms["laplacian_smoothing"] = self.lap(g.get_xyz_verts)
-            loss = loss + C(self.lam["laplacian_smoothing"], 0, it) * terms["laplacian_smoothing"]
+            pairs.append((C(self.lam["laplacian_smoothing"], 0, it), terms["laplacian_smoothing"]))
         for k, key in (("rgb_tv", "comp_rgb"), ("depth_tv", "comp_depth"), ("normal_tv", "comp_normal")):
             terms[k] = out["tv"][k] if raw is not None else tv_loss(out[key].permute(0, 3, 1, 2))
-            loss = loss + C(self.lam[k], 0, it) * terms[k]
+            if raw is None:
+                pairs.append((C(self.lam[k], 0, it), terms[k]))
+        loss = weighted_sum(pairs)
         loss.backward()
         self.reducer()
         # the batched renderer sizes its duplicate / record lists without a host synchronisation: a forward that overflowed them

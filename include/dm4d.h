@@ -445,6 +445,19 @@ int dm4d_image_head_backward(int32_t B, int32_t H, int32_t W, int32_t C, const f
                              int32_t n_rnd, const float *g_rgb, const float *g_mask, const float *g_half, float *g_color, float *g_alpha,
                              dm4d_stream_t stream);
 
+/* The scalar arithmetic around the two heads (system/sugar_4dgen.py:296-330, sugar_static.py:246-340: `loss = lambda_rgb *
+ * loss_rgb + lambda_mask * loss_mask + lambda_sds * loss_sds + ...` on 0-dim tensors, and the sum + normalisation of a head's
+ * partial sums) as one launch each instead of one torch operator per multiply / add (5 us of launch for one flop, ~25 of them
+ * per iteration forward + backward).
+ *   dm4d_partial_sums: out[j] = sum_c matrix[c * m + j] * (sum_{i < n} partial[i * k + c]), 1 <= k, m <= 8; `matrix` is a HOST
+ *     array (passed by value); one workgroup, fixed order.
+ *   dm4d_weighted_sum: out[0] = ((0 + w[0] * *terms[0]) + w[1] * *terms[1]) + ... in float32, the torch expression's roundings;
+ *     `terms` (an array of n <= 16 device pointers) and `weights` are HOST arrays.
+ *   dm4d_weighted_sum_backward: out[i] = *g * w[i]. */
+int dm4d_partial_sums(int64_t n, int32_t k, int32_t m, const float *partial, const float *matrix, float *out, dm4d_stream_t stream);
+int dm4d_weighted_sum(int32_t n, const float *const *terms, const float *weights, float *out, dm4d_stream_t stream);
+int dm4d_weighted_sum_backward(int32_t n, const float *g, const float *weights, float *out, dm4d_stream_t stream);
+
 /* The image-space terms of a STATIC-stage iteration (system/sugar_static.py:110-340 with the static renderer's epilogue,
  * renderer/diff_sugar_rasterizer_normal.py:196-226) over the rendered batch color [B,6,H,W] (RGB | normal), depth, alpha [B,1,H,W]:
  * on the reference views (ref_pos >= 0) the sums of squares of mse(gt m, clamp(rgb) m) and mse(m, alpha); on the random views

@@ -1,0 +1,59 @@
+"""loss_sum (csrc/imagehead.hip: dm4d_weighted_sum*, dm4d_partial_sums) against the torch expressions it replaces
+(system/sugar_4dgen.py:296-330, sugar_static.py:246-340: `loss = lambda_a * a + lambda_b * b + ...` on 0-dim tensors)."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def test_weighted_sum_is_the_torch_expression_bit_for_bit():
+    from dreammesh4d_amd.loss_sum import weighted_sum
+
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(3)
+    ws = [5000.0, 500.0, 0.1, 1.0, 10.0, 0.37, 1e-3]
+    vals = (torch.randn(7, generator=g) * torch.tensor([1e-3, 1e-2, 1e3, 1.0, 1e-4, 7.0, 1e5])).tolist()
+    a = [torch.tensor(v, device=dev, requires_grad=True) for v in vals]
+    b = [torch.tensor(v, device=dev, requires_grad=True) for v in vals]
+    ref = 0.0
+    for w, t in zip(ws, a):
+        ref = ref + w * t
+    # scalars, and the middle five as ONE vector term
+    vec = torch.stack([t.detach() for t in b[1:6]]).requires_grad_(True)
+    got = weighted_sum([(ws[0], b[0]), (tuple(ws[1:6]), vec), (ws[6], b[6])])
+    assert got.dtype == torch.float32 and got.dim() == 0
+    assert torch.equal(got.detach(), ref.detach())
+    up = torch.tensor(0.731, device=dev)
+    (ref * up).backward()
+    (got * up).backward()
+    assert torch.equal(b[0].grad, a[0].grad) and torch.equal(b[6].grad, a[6].grad)
+    assert torch.equal(vec.grad, torch.stack([t.grad for t in a[1:6]]))
+
+
+def test_weighted_sum_takes_the_torch_expression_for_anything_else():
+    from dreammesh4d_amd.loss_sum import weighted_sum
+
+    a, b = torch.tensor(2.0, requires_grad=True), torch.tensor(3.0, dtype=torch.float64)
+    out = weighted_sum([(0.5, a), (2.0, b)])           # CPU / float64: not the kernel's domain
+    assert float(out) == 7.0
+    out.backward()
+    assert float(a.grad) == 0.5
+    assert weighted_sum([]) == 0.0
+
+
+def test_partial_sums_and_limits():
+    from dreammesh4d_amd import _lib
+    from dreammesh4d_amd.loss_sum import partial_sums
+
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(5)
+    for n, k, m in ((2048, 2, 2), (1280, 8, 5), (1, 3, 8), (0, 4, 1)):
+        p = torch.rand(n, k, generator=g).to(dev)
+        mat = torch.rand(k, m, generator=g, dtype=torch.float64)
+        got = partial_sums(p, mat.tolist())
+        ref = (p.double().sum(0) @ mat.to(dev)).float()
+        assert torch.allclose(got, ref, rtol=2e-6, atol=1e-7), (n, k, m)
+    with pytest.raises(_lib.Dm4dError):
+        partial_sums(torch.zeros(4, 9, device=dev), [[1.0]] * 9)
+    with pytest.raises(ValueError):
+        partial_sums(torch.zeros(4, 2, device=dev, dtype=torch.float64), [[1.0], [1.0]])

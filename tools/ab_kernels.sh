@@ -12,7 +12,7 @@ for v in "$@"; do
   python - <<PY
 import csv, glob
 f = glob.glob('/tmp/abk/**/k_kernel_stats.csv', recursive=True)[0]
-for r in list(csv.DictReader(open(f)))[:9]:
+for r in list(csv.DictReader(open(f)))[:12]:
     print(f"  {float(r['AverageNs'])/1e3:8.1f} us x {r['Calls']:>5s}  {r['Name'][:70]}")
 PY
 done
