@@ -57,3 +57,19 @@ def test_partial_sums_and_limits():
         partial_sums(torch.zeros(4, 9, device=dev), [[1.0]] * 9)
     with pytest.raises(ValueError):
         partial_sums(torch.zeros(4, 2, device=dev, dtype=torch.float64), [[1.0], [1.0]])
+
+
+def test_upload_packed_is_one_copy_with_the_arrays_dtypes():
+    import numpy as np
+
+    from dreammesh4d_amd.dynamic_stage import upload_packed
+
+    arrays = {"vm": np.arange(128, dtype=np.float32).reshape(8, 4, 4), "t": np.asarray([0.1, 0.7, 0.3], np.float32), "idx": np.asarray([3, 1, 0, 2, 5], np.int64),
+              "pos": np.asarray([-1, 0, 1], np.int32), "empty": np.zeros((0,), np.int64)}
+    out = upload_packed(arrays, torch.device("cuda:0"))
+    base = {t.untyped_storage().data_ptr() for t in out.values()}
+    assert len(base) == 1                                   # views of ONE device buffer
+    for k, v in arrays.items():
+        assert out[k].is_cuda and tuple(out[k].shape) == v.shape and str(out[k].dtype) == "torch." + str(v.dtype)
+        assert np.array_equal(out[k].cpu().numpy(), v)
+        assert out[k].data_ptr() % 8 == 0
