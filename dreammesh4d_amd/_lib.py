@@ -166,7 +166,7 @@ _SIGNATURES = {
     "dm4d_laplacian_smoothing_forward": (C.c_int, [C.c_int32] * 2 + [vp] * 6),
     "dm4d_laplacian_smoothing_backward": (C.c_int, [C.c_int32] * 2 + [vp] * 6),
     "dm4d_normal_consistency_forward": (C.c_int, [C.c_int32] * 3 + [vp] * 4),
-    "dm4d_normal_consistency_backward": (C.c_int, [C.c_int32] * 3 + [vp] * 7),
+    "dm4d_normal_consistency_backward": (C.c_int, [C.c_int32] * 3 + [vp] * 8),
     "dm4d_hexplane_forward": (C.c_int, [C.c_int32] * 3 + [vp] * 2 + [C.c_int32] + [vp] * 6),
     "dm4d_hexplane_axis_index": (C.c_int, [C.c_int32] * 2 + [vp] * 5),
     "dm4d_hexplane_scratch_bytes": (C.c_size_t, [C.c_int32] * 3),

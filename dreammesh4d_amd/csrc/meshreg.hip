@@ -158,40 +158,60 @@ __global__ __launch_bounds__(256) void k_nc_fwd(NcPairs pr, int V, const float *
     terms[t * pr.P + p] = 1.0f - c;
 }
 
+// Backward in two launches: the four vertices' gradient vectors of every pair (one thread per pair: the pair's normals, norms
+// and cosine are evaluated ONCE, not once per vertex that gathers them -- with their correctly rounded divisions and square roots
+// they were a 48-64 us kernel beside a 5 us forward), then the gather below.
+__global__ __launch_bounds__(256) void k_nc_bwd_pairs(NcPairs pr, int V, const float *__restrict__ xyz, float *__restrict__ roles /* [T][P][4][3] */)
+{
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= pr.P) return;
+    const size_t t = blockIdx.y;
+    float e[3], a[3], b[3], n0[3], m[3], l0, l1;
+    const float c = nc_pair(xyz + t * V * 3, pr.v + 4 * (size_t)p, e, a, b, n0, m, l0, l1);
+    // d(1 - c)/dn0 = -(m / (l0 l1) - c n0 / l0^2),  d(1 - c)/dm = -(n0 / (l0 l1) - c m / l1^2)
+    float g0[3], g1[3];
+    const float r01 = 1.0f / (l0 * l1), c00 = c / (l0 * l0), c11 = c / (l1 * l1);
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        g0[d] = -(m[d] * r01 - c00 * n0[d]);
+        g1[d] = -(n0[d] * r01 - c11 * m[d]);
+    }
+    // n0 = e x a: d/de = a x g0, d/da = g0 x e;   m = b x e: d/db = e x g1, d/de = g1 x b
+    float dE0[3], dE1[3], dA[3], dB[3];
+    cross3(a, g0, dE0);
+    cross3(g1, b, dE1);
+    cross3(g0, e, dA);
+    cross3(e, g1, dB);
+    float4 *o = reinterpret_cast<float4 *>(roles + (t * pr.P + p) * 12);
+    float r[12];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        const float dE = dE0[d] + dE1[d];
+        r[d] = -((dE + dA[d]) + dB[d]);      // role 0: v0
+        r[3 + d] = dE;                        // role 1: v1
+        r[6 + d] = dA[d];                     // role 2: a
+        r[9 + d] = dB[d];                     // role 3: b
+    }
+    o[0] = make_float4(r[0], r[1], r[2], r[3]);
+    o[1] = make_float4(r[4], r[5], r[6], r[7]);
+    o[2] = make_float4(r[8], r[9], r[10], r[11]);
+}
+
 // items of vertex i: item = pair * 4 + role, CSR offsets [V+1]; a group of kSub lanes per (mesh, vertex), see k_arap_fwd
 __global__ __launch_bounds__(256) void k_nc_bwd(NcPairs pr, int V, const int32_t *__restrict__ off, const int32_t *__restrict__ items,
-                                                const float *__restrict__ xyz, const float *__restrict__ g_loss /* [T] */,
+                                                const float *__restrict__ roles, const float *__restrict__ g_loss /* [T] */,
                                                 float *__restrict__ g_xyz)
 {
     const int gid = blockIdx.x * 256 + threadIdx.x, i = gid / kSub, sub = gid % kSub;
     if (i >= V) return;
     const size_t t = blockIdx.y;
-    const float *x = xyz + t * V * 3;
+    const float *rt = roles + t * pr.P * 12;
     float acc[3] = {0.f, 0.f, 0.f};
     const int k1 = off[i + 1];
 #pragma unroll 2
     for (int k = off[i] + sub; k < k1; k += kSub) {
-        const int p = items[k] >> 2, role = items[k] & 3;
-        float e[3], a[3], b[3], n0[3], m[3], l0, l1;
-        const float c = nc_pair(x, pr.v + 4 * (size_t)p, e, a, b, n0, m, l0, l1);
-        // d(1 - c)/dn0 = -(m / (l0 l1) - c n0 / l0^2),  d(1 - c)/dm = -(n0 / (l0 l1) - c m / l1^2)
-        float g0[3], g1[3];
-#pragma unroll
-        for (int d = 0; d < 3; ++d) {
-            g0[d] = -(m[d] / (l0 * l1) - c * n0[d] / (l0 * l0));
-            g1[d] = -(n0[d] / (l0 * l1) - c * m[d] / (l1 * l1));
-        }
-        // n0 = e x a: d/de = a x g0, d/da = g0 x e;   m = b x e: d/db = e x g1, d/de = g1 x b
-        float dE0[3], dE1[3], dA[3], dB[3];
-        cross3(a, g0, dE0);
-        cross3(g1, b, dE1);
-        cross3(g0, e, dA);
-        cross3(e, g1, dB);
-#pragma unroll
-        for (int d = 0; d < 3; ++d) {
-            const float dE = dE0[d] + dE1[d];
-            acc[d] += role == 0 ? -((dE + dA[d]) + dB[d]) : role == 1 ? dE : role == 2 ? dA[d] : dB[d];
-        }
+        const float *r = rt + 3 * (size_t)items[k];      // (item = pair * 4 + role: the role's vector of the pair)
+        acc[0] += r[0]; acc[1] += r[1]; acc[2] += r[2];
     }
     group_sum(acc);
     if (sub != 0) return;
@@ -342,13 +362,18 @@ int dm4d_normal_consistency_forward(int32_t T, int32_t V, int32_t P, const int32
 
 int dm4d_normal_consistency_backward(int32_t T, int32_t V, int32_t P, const int32_t *pairs, const int32_t *vert_offsets,
                                      const int32_t *vert_items, const float *xyz, const float *g_loss, float *g_xyz,
-                                     dm4d_stream_t stream)
+                                     float *scratch, dm4d_stream_t stream)
 {
     if (T < 0 || V < 0 || P < 0) { set_error("normal consistency: negative size"); return DM4D_ERR_INVALID; }
     if (T == 0 || V == 0) return DM4D_OK;
     if (!pairs || !vert_offsets || !vert_items || !xyz || !g_loss || !g_xyz) { set_error("normal consistency: null tensor"); return DM4D_ERR_INVALID; }
+    if (P > 0 && (!scratch || ((uintptr_t)scratch & 15) != 0)) { set_error("normal consistency: the backward needs a 16-byte aligned scratch of T P 12 floats"); return DM4D_ERR_INVALID; }
     NcPairs pr{P > 0 ? P : 1, pairs};
-    hipLaunchKernelGGL(k_nc_bwd, dim3((unsigned)(((size_t)V * kSub + 255) / 256), T), dim3(256), 0, (hipStream_t)stream, pr, V, vert_offsets, vert_items, xyz,
+    if (P > 0) {
+        hipLaunchKernelGGL(k_nc_bwd_pairs, dim3((P + 255) / 256, T), dim3(256), 0, (hipStream_t)stream, pr, V, xyz, scratch);
+        DM4D_HIP_CHECK(hipGetLastError());
+    }
+    hipLaunchKernelGGL(k_nc_bwd, dim3((unsigned)(((size_t)V * kSub + 255) / 256), T), dim3(256), 0, (hipStream_t)stream, pr, V, vert_offsets, vert_items, scratch,
                        g_loss, g_xyz);
     DM4D_HIP_CHECK(hipGetLastError());
     return DM4D_OK;

@@ -510,12 +510,13 @@ int dm4d_quat_to_matrix_backward_pypose(int64_t n, const float *matrices, const 
  * incidences of an edge in face order, all i < j combinations).  terms [T,P] = 1 - cos((v1-v0)x(a-v0), -(v1-v0)x(b-v0));
  * the loss of mesh t is the mean of its terms and pytorch3d returns the mean over the meshes (host side).
  * Backward: vert_offsets [V+1] / vert_items (item = pair * 4 + role, role = 0..3 for v0, v1, a, b) list the pairs that
- * touch every vertex; g_loss [T] = dL/d(loss_t); g_xyz [T,V,3] is WRITTEN (gather, no atomics, deterministic). */
+ * touch every vertex; g_loss [T] = dL/d(loss_t); g_xyz [T,V,3] is WRITTEN (gather, no atomics, deterministic); scratch: T P 12
+ * floats, 16-byte aligned (the four vertices' gradient vectors of every pair, evaluated once per pair, then gathered). */
 int dm4d_normal_consistency_forward(int32_t T, int32_t V, int32_t P, const int32_t *pairs, const float *xyz, float *terms,
                                     dm4d_stream_t stream);
 int dm4d_normal_consistency_backward(int32_t T, int32_t V, int32_t P, const int32_t *pairs, const int32_t *vert_offsets,
                                      const int32_t *vert_items, const float *xyz, const float *g_loss, float *g_xyz,
-                                     dm4d_stream_t stream);
+                                     float *scratch, dm4d_stream_t stream);
 
 /* pytorch3d.loss.mesh_laplacian_smoothing(meshes, method="uniform") of T meshes of one topology (static stage lambda 1,
  * C/configs/sugar_static_refine.yaml:122, C/system/sugar_static.py:246-254; dynamic stage C/system/sugar_4dgen.py:227-230):
