@@ -208,7 +208,7 @@ __global__ __launch_bounds__(256) void k_nc_bwd(NcPairs pr, int V, const int32_t
     const float *rt = roles + t * pr.P * 12;
     float acc[3] = {0.f, 0.f, 0.f};
     const int k1 = off[i + 1];
-#pragma unroll 2
+#pragma unroll 4
     for (int k = off[i] + sub; k < k1; k += kSub) {
         const float *r = rt + 3 * (size_t)items[k];      // (item = pair * 4 + role: the role's vector of the pair)
         acc[0] += r[0]; acc[1] += r[1]; acc[2] += r[2];
@@ -264,16 +264,21 @@ __global__ __launch_bounds__(256) void k_quat_matrix_bwd(size_t n, const float *
 __global__ __launch_bounds__(256) void k_lap_fwd(int V, const int32_t *__restrict__ off, const int32_t *__restrict__ nbr,
                                                  const float *__restrict__ xyz, float *__restrict__ terms, float *__restrict__ unit)
 {
-    const int i = blockIdx.x * 256 + threadIdx.x;
+    // a group of kSub lanes per (mesh, vertex), as in k_arap_fwd (one thread per vertex: 63 / 84 us forward / backward at 8.3k
+    // vertices -- the kernel was as long as the highest valence's chain of dependent loads)
+    const int gid = blockIdx.x * 256 + threadIdx.x, i = gid / kSub, sub = gid % kSub;
     if (i >= V) return;
     const size_t t = blockIdx.y;
     const float *x = xyz + t * V * 3;
     float s[3] = {0.f, 0.f, 0.f};
     const int e0 = off[i], e1 = off[i + 1];
-    for (int e = e0; e < e1; ++e) {
+#pragma unroll 4
+    for (int e = e0 + sub; e < e1; e += kSub) {
         const float *xj = x + 3 * (size_t)nbr[e];
         s[0] += xj[0]; s[1] += xj[1]; s[2] += xj[2];
     }
+    group_sum(s);
+    if (sub != 0) return;
     const float inv = e1 > e0 ? 1.0f / (float)(e1 - e0) : 0.f;
     float d[3];
 #pragma unroll
@@ -288,19 +293,23 @@ __global__ __launch_bounds__(256) void k_lap_fwd(int V, const int32_t *__restric
 __global__ __launch_bounds__(256) void k_lap_bwd(int V, const int32_t *__restrict__ off, const int32_t *__restrict__ nbr,
                                                  const float *__restrict__ unit, const float *__restrict__ g_loss, float *__restrict__ g_xyz)
 {
-    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int gid = blockIdx.x * 256 + threadIdx.x, i = gid / kSub, sub = gid % kSub;
     if (i >= V) return;
     const size_t t = blockIdx.y;
     const float *u = unit + t * V * 3;
-    float a[3] = {-u[3 * (size_t)i], -u[3 * (size_t)i + 1], -u[3 * (size_t)i + 2]};
-    for (int e = off[i]; e < off[i + 1]; ++e) {
+    float a[3] = {0.f, 0.f, 0.f};
+    const int e1 = off[i + 1];
+#pragma unroll 4
+    for (int e = off[i] + sub; e < e1; e += kSub) {
         const int j = nbr[e];
         const float w = 1.0f / (float)(off[j + 1] - off[j]);
         a[0] += u[3 * (size_t)j] * w; a[1] += u[3 * (size_t)j + 1] * w; a[2] += u[3 * (size_t)j + 2] * w;
     }
+    group_sum(a);
+    if (sub != 0) return;
     const float s = g_loss[t] / (float)V;
 #pragma unroll
-    for (int k = 0; k < 3; ++k) g_xyz[(t * V + i) * 3 + k] = a[k] * s;
+    for (int k = 0; k < 3; ++k) g_xyz[(t * V + i) * 3 + k] = (a[k] - u[3 * (size_t)i + k]) * s;
 }
 
 static int arap_check(int T, int V, const void *off, const void *nbr, const void *rev, const void *w, const void *e,
@@ -407,7 +416,7 @@ int dm4d_laplacian_smoothing_forward(int32_t T, int32_t V, const int32_t *csr_of
     if (T < 0 || V < 0) { set_error("laplacian smoothing: negative size"); return DM4D_ERR_INVALID; }
     if (T == 0 || V == 0) return DM4D_OK;
     if (!csr_offsets || !neighbors || !xyz || !terms || !unit) { set_error("laplacian smoothing: null tensor"); return DM4D_ERR_INVALID; }
-    hipLaunchKernelGGL(k_lap_fwd, dim3((V + 255) / 256, T), dim3(256), 0, (hipStream_t)stream, V, csr_offsets, neighbors, xyz, terms, unit);
+    hipLaunchKernelGGL(k_lap_fwd, dim3((unsigned)(((size_t)V * kSub + 255) / 256), T), dim3(256), 0, (hipStream_t)stream, V, csr_offsets, neighbors, xyz, terms, unit);
     DM4D_HIP_CHECK(hipGetLastError());
     return DM4D_OK;
 }
@@ -418,7 +427,7 @@ int dm4d_laplacian_smoothing_backward(int32_t T, int32_t V, const int32_t *csr_o
     if (T < 0 || V < 0) { set_error("laplacian smoothing: negative size"); return DM4D_ERR_INVALID; }
     if (T == 0 || V == 0) return DM4D_OK;
     if (!csr_offsets || !neighbors || !unit || !g_loss || !g_xyz) { set_error("laplacian smoothing: null tensor"); return DM4D_ERR_INVALID; }
-    hipLaunchKernelGGL(k_lap_bwd, dim3((V + 255) / 256, T), dim3(256), 0, (hipStream_t)stream, V, csr_offsets, neighbors, unit, g_loss, g_xyz);
+    hipLaunchKernelGGL(k_lap_bwd, dim3((unsigned)(((size_t)V * kSub + 255) / 256), T), dim3(256), 0, (hipStream_t)stream, V, csr_offsets, neighbors, unit, g_loss, g_xyz);
     DM4D_HIP_CHECK(hipGetLastError());
     return DM4D_OK;
 }
