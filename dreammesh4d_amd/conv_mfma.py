@@ -125,7 +125,9 @@ def pad_channels(x, C):
     """x [N, C', H, W] channels_last -> [N, C, H, W] channels_last with zeros in the new channels (differentiable: a slice assignment)."""
     if x.shape[1] == C:
         return x
-    y = torch.zeros((x.shape[0], C, x.shape[2], x.shape[3]), dtype=x.dtype, device=x.device).contiguous(memory_format=torch.channels_last)
+    # (allocated channels-last and zeroed in place: `zeros(...).contiguous(channels_last)` was a fill AND a copy of the padded tensor --
+    # 21 us for the VAE encoder's 4 x 256^2 x 32 input)
+    y = torch.empty((x.shape[0], C, x.shape[2], x.shape[3]), dtype=x.dtype, device=x.device, memory_format=torch.channels_last).zero_()
     y[:, :x.shape[1]] = x
     return y
 

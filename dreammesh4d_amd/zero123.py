@@ -875,7 +875,9 @@ class TemporalStableZero123Guidance(nn.Module):
 
         dt = self.weights_dtype
         st = types.SimpleNamespace(serial=0)
-        st.imgs = torch.zeros(B, 3, 256, 256, device=dev, requires_grad=True)
+        # (channels-last like the views the image heads hand over ([B, H, W, 3] permuted) and like the encoder wants them: the copy in,
+        # the cast and the image gradient on its way back stay plain contiguous passes)
+        st.imgs = torch.zeros(B, 3, 256, 256, device=dev).contiguous(memory_format=torch.channels_last).requires_grad_(True)
         st.post = torch.zeros(B, 4, 32, 32, device=dev, dtype=dt)
         with torch.no_grad():
             # the noise buffer with the STRIDES the latents have (a channel slice of the NHWC moments): `randn_like(latents)` deals its
@@ -900,7 +902,7 @@ class TemporalStableZero123Guidance(nn.Module):
             stream = torch.cuda.current_stream(dev).cuda_stream
             moments = self.model.first_stage_model.encode_moments((st.imgs * 2.0 - 1.0).to(dt))
             with torch.no_grad():
-                x_in = torch.empty(2 * B, 8, 32, 32, device=dev, dtype=dt).contiguous(memory_format=torch.channels_last)
+                x_in = torch.empty(2 * B, 8, 32, 32, device=dev, dtype=dt, memory_format=torch.channels_last)
                 t2 = torch.empty(2 * B, dtype=torch.long, device=dev)
                 _lib.check(L.dm4d_sds_prepare(B, 32, 32, float(self.model.scale_factor), ptr(moments), strides(moments), ptr(st.post),
                                               strides(st.post), ptr(st.noise), strides(st.noise), ptr(st.latents), strides(st.latents),
