@@ -73,3 +73,29 @@ def test_upload_packed_is_one_copy_with_the_arrays_dtypes():
         assert out[k].is_cuda and tuple(out[k].shape) == v.shape and str(out[k].dtype) == "torch." + str(v.dtype)
         assert np.array_equal(out[k].cpu().numpy(), v)
         assert out[k].data_ptr() % 8 == 0
+
+
+def test_weighted_sum_beyond_the_kernel_domain_and_c_abi_limits():
+    import ctypes as C
+
+    from dreammesh4d_amd import _lib
+    from dreammesh4d_amd.loss_sum import weighted_sum
+
+    dev = torch.device("cuda:0")
+    ts = [torch.tensor(float(i + 1), device=dev, requires_grad=True) for i in range(17)]      # 17 terms: more than one launch takes
+    out = weighted_sum([(0.5, t) for t in ts])
+    assert float(out) == 0.5 * sum(range(1, 18))
+    out.backward()
+    assert all(float(t.grad) == 0.5 for t in ts)
+    L = _lib.lib()
+    w = (C.c_float * 17)(*([1.0] * 17))
+    p = (C.c_void_p * 17)(*[t.data_ptr() for t in ts])
+    o = torch.zeros((), device=dev)
+    assert L.dm4d_weighted_sum(17, p, w, o.data_ptr(), 0) != 0          # n > 16: refused, with a message
+    assert b"16" in L.dm4d_last_error()
+    assert L.dm4d_weighted_sum(0, p, w, o.data_ptr(), 0) != 0
+    assert L.dm4d_weighted_sum_backward(3, None, w, o.data_ptr(), 0) != 0
+    big = torch.rand(200_000, 8, device=dev)
+    from dreammesh4d_amd.loss_sum import partial_sums
+    eye = [[1.0 if i == j else 0.0 for j in range(8)] for i in range(8)]
+    assert torch.allclose(partial_sums(big, eye), big.double().sum(0).float(), rtol=3e-6)
