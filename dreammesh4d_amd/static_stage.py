@@ -37,7 +37,7 @@ def tv_loss(x):
 
 class StaticStage:
     def __init__(self, geometry, renderer, ref_image, ref_mask, H, W, guidance=None, random_views=4, normal_consistency=None,
-                 laplacian_smoothing=None, seed=0, lambdas=None):
+                 laplacian_smoothing=None, seed=0, lambdas=None, message_adamw=None):
         self.g, self.r = geometry, renderer
         self.lam = dict(LAMBDA)            # `system.loss` of the configuration (from_cfg); defaults: sugar_static_refine.yaml
         self.lam.update(lambdas or {})
@@ -50,6 +50,13 @@ class StaticStage:
         self.gen = torch.Generator(device="cpu").manual_seed(seed + 977 * D.rank())
         self.opt = geometry.merge_optimizer(None)
         self.reducer = D.GradAllReducer([p for p in geometry.parameters() if p.requires_grad and p.numel()])
+        # One process on a HIP device: the AdamW step as the dynamic stage's fused kernel over the reducer's (here dense) message --
+        # distributed.ShardedAdamW._step_fused, two launches -- instead of torch's multi-tensor kernel, which runs one launch per
+        # parameter group with a handful of workgroups each: 5 x 35 us for these six small tensors, 11.21 -> 11.05 ms per iteration
+        # (same per-element arithmetic, tests/test_adamw_gpu.py; message_adamw=False / DM4D_MESSAGE_ADAMW=0: torch's)
+        if message_adamw is None:
+            message_adamw = self.dev.type == "cuda" and D.world() == 1 and os.environ.get("DM4D_MESSAGE_ADAMW", "1") != "0"
+        self.sharded = D.ShardedAdamW(self.opt.param_groups, self.reducer, betas=(0.9, 0.99), eps=1e-15) if message_adamw else None
         self.ref_cam = syn.make_camera(H, W, elev_deg=5.0, azim_deg=0.0)                # yaml:11-14
         self.global_step = 0
         self.poll_every, self.overflow_skipped = 8, 0
@@ -147,7 +154,12 @@ class StaticStage:
             if D.world() > 1:
                 D.all_reduce_max(flag)
             self.opt.found_inf, self.opt.grad_scale = flag, None
-        self.opt.step()
+        if self.sharded is not None:
+            for gs, go in zip(self.sharded.param_groups, self.opt.param_groups):
+                gs["lr"] = go["lr"]
+            self.sharded.step(found_inf=flag if (vr is not None and vr.last is not None) else None)
+        else:
+            self.opt.step()
         self.global_step += 1
         terms = {k: v.detach() for k, v in terms.items()}
         if vr is not None and self.global_step % self.poll_every == 0:
