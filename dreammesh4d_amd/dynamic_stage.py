@@ -178,7 +178,10 @@ class DynamicStage:
                   "fidx_rnd": np.asarray([fidx[i] for i in rnd_idx], np.int64)}
         return {"frames": frames, "n_ref": len(ref_idx), "n_rnd": len(rnd_idx), **upload_packed(arrays, self.dev),
                 "elev_rnd": torch.tensor([elev[i] for i in rnd_idx], dtype=torch.float32),        # (host tensors: see iteration())
-                "azim_rnd": torch.tensor([azim[i] for i in rnd_idx], dtype=torch.float32)}
+                "azim_rnd": torch.tensor([azim[i] for i in rnd_idx], dtype=torch.float32),
+                # (a host copy for the guidance: with all of its conditioning inputs on the host the conditioning graph does not wait
+                #  for the caller's stream, zero123._forward_one_graph)
+                "fidx_rnd_host": torch.from_numpy(arrays["fidx_rnd"].copy())}
 
     def inter_frame_arap(self):
         """ARAP energy at `num_inter_frames` timestamps of a random window of length `length_inter_frames`
@@ -272,7 +275,8 @@ class DynamicStage:
             # elevation / azimuth stay on the HOST (they only feed the four-number camera embedding of get_cond: a dozen
             # elementwise launches on 4-element device tensors otherwise)
             g = self.guidance(half if fused_head else rgb.index_select(0, b["rnd_idx"]), b["elev_rnd"], b["azim_rnd"],
-                              torch.full_like(b["elev_rnd"], 3.8), frame_indices=b["fidx_rnd"])
+                              torch.full_like(b["elev_rnd"], 3.8),
+                              frame_indices=b["fidx_rnd_host"] if getattr(self.guidance, "host_frame_indices", False) else b["fidx_rnd"])
             terms["sds"] = g["loss_sds"]
             pairs.append((C(self.lam["sds_zero123"], 0, it), g["loss_sds"]))
         if self.normal_consistency is not None:

@@ -24,6 +24,7 @@ Module and parameter names follow the LDM checkpoint layout (`model.diffusion_mo
 load/zero123/download.sh).  Architecture parity is pinned by tests/golden/zero123_small.npz: a
 reduced-width UNet and encoder of the REFERENCE code, filled by a name-seeded recipe both sides share.
 """
+import contextlib
 import math
 import os
 
@@ -520,12 +521,21 @@ class UNetModel(nn.Module):
                     a.__dict__["_tok"] = tok[i]
         return res, att
 
-    def forward(self, x, timesteps, context):
-        emb = self.time_embed(timestep_embedding(timesteps, self.model_channels).type(x.dtype))
-        hs, h = [], (_to_nhwc(x) if x.is_cuda and self.channels_last else x)
+    def precompute(self, timesteps, context, dtype):
+        """Everything of `forward` that does not depend on the activations: the timestep embedding and -- frozen parameters,
+        channels-last, no autograd, on a device -- the batched small GEMMs (`_batched_small_gemms`).  The guidance's one-graph step
+        replays this as its own small graph on a side stream, ahead of the step (TemporalStableZero123Guidance._sds_graph); the
+        result goes to `forward(..., pre=...)`."""
+        emb = self.time_embed(timestep_embedding(timesteps, self.model_channels).type(dtype))
         frozen = not any(p.requires_grad for p in (self.time_embed[0].weight, self.out[2].weight))
-        touched = self._batched_small_gemms(emb, context) if (x.is_cuda and self.channels_last and frozen and BATCH_SMALL_GEMMS
+        touched = self._batched_small_gemms(emb, context) if (emb.is_cuda and self.channels_last and frozen and BATCH_SMALL_GEMMS
                                                               and not torch.is_grad_enabled()) else None
+        return emb, touched
+
+    def forward(self, x, timesteps, context, pre=None):
+        """`pre`: the result of `precompute` for the same (timesteps, context), computed here when absent."""
+        emb, touched = self.precompute(timesteps, context, x.dtype) if pre is None else pre
+        hs, h = [], (_to_nhwc(x) if x.is_cuda and self.channels_last else x)
         try:
             for m in self.input_blocks:
                 h = m(h, emb, context)
@@ -752,6 +762,8 @@ class TemporalStableZero123Guidance(nn.Module):
     """`temporal-stable-zero123-guidance`.  `__call__(rgb[B,H,W,3], elevation, azimuth, camera_distances,
     frame_indices, rgb_as_latents=False) -> {"loss_sds", "grad_norm", "min_step", "max_step"}`."""
 
+    host_frame_indices = True      # `frame_indices` (and elevation / azimuth) may be HOST tensors: the one-graph step prefers them
+
     def __init__(self, model: Zero123, c_crossattn, c_concat, cond_elevation_deg=0.0, cond_azimuth_deg=0.0,
                  guidance_scale=3.0, min_step_percent=0.02, max_step_percent=0.98, grad_clip=None,
                  half_precision_weights=True, use_graphs=True, channels_last=True, one_graph=None):
@@ -900,6 +912,8 @@ class TemporalStableZero123Guidance(nn.Module):
             ptr = lambda v: C_.c_void_p(v.data_ptr())
             strides = lambda v: (C_.c_int64 * 4)(*v.stride())
             stream = torch.cuda.current_stream(dev).cuda_stream
+            unet = self.model.model.diffusion_model
+            pre, ctx = (None, None) if st.pre is None else st.pre       # (the conditioning graph's static results, run_pre)
             moments = self.model.first_stage_model.encode_moments((st.imgs * 2.0 - 1.0).to(dt))
             with torch.no_grad():
                 x_in = torch.empty(2 * B, 8, 32, 32, device=dev, dtype=dt, memory_format=torch.channels_last)
@@ -908,7 +922,7 @@ class TemporalStableZero123Guidance(nn.Module):
                                               strides(st.post), ptr(st.noise), strides(st.noise), ptr(st.latents), strides(st.latents),
                                               ptr(st.t), ptr(self.alphas), ptr(self.c_concat), strides(self.c_concat),
                                               ptr(st.fidx), ptr(x_in), strides(x_in), ptr(t2), stream), "dm4d_sds_prepare")
-                pred = self.model.model.diffusion_model(x_in, t2, context=self._crossattn_from_T(st.T, st.fidx))
+                pred = unet(x_in, t2, context=self._crossattn_from_T(st.T, st.fidx) if ctx is None else ctx, pre=pre)
                 d_mom = torch.empty(moments.shape, device=dev, dtype=dt)      # (contiguous, like the `cat` autograd builds there: the library picks the
                                                                               #  quant_conv's backward kernel by the gradient's layout)
                 loss, gnorm = torch.empty((), device=dev), torch.empty((), device=dev)
@@ -944,14 +958,37 @@ class TemporalStableZero123Guidance(nn.Module):
             if not (self.c_concat.is_contiguous() and self.alphas.dtype == torch.float32 and tuple(self.c_concat.shape[1:]) == (4, 32, 32)):
                 raise ValueError("fused SDS glue: c_concat must be a contiguous [L,4,32,32] tensor")
 
+        # The part of the UNet that does not depend on the latents -- camera embedding -> cc_projection, timestep embedding, the batched
+        # M = batch GEMMs of every ResBlock / cross-attention (UNetModel.precompute): ~25 launch-bound kernels, ~0.2 ms -- as its OWN small
+        # graph, replayed on a side stream as soon as the previous step's graph is done: the host enqueues a guidance call while the
+        # device is still rasterising, so these kernels run beside the render kernels instead of at the head of the UNet.  (As a side
+        # BRANCH of one graph they cost more than they hid: DESIGN.md section 3 "Round 4".)  DM4D_SDS_PRE_GRAPH=0: one graph, as before.
+        st.pre, st.pre_graph = None, None
+        split = fused and os.environ.get("DM4D_SDS_PRE_GRAPH", "1") != "0"
+
+        def run_pre():
+            with torch.no_grad():
+                ctx = self._crossattn_from_T(st.T, st.fidx)
+                return self.model.model.diffusion_model.precompute(torch.cat([st.t, st.t]), ctx, dt), ctx
+
         cur, side = torch.cuda.current_stream(dev), torch.cuda.Stream(device=dev)
         side.wait_stream(cur)
         with torch.cuda.stream(side):
             for _ in range(2):          # library handles, algorithm choices, allocator warm-up
+                if split:
+                    st.pre = run_pre()
                 run()
+                st.pre = None
         cur.wait_stream(side)
+        if split:
+            st.pre_graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(st.pre_graph):
+                st.pre = run_pre()      # (static tensors of the graphs' shared pool, referenced from here for the graphs' lifetime)
+            st.side = torch.cuda.Stream(device=dev)
+            st.pre_done, st.main_done = torch.cuda.Event(), torch.cuda.Event()
+            st.main_done.record(cur)
         st.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(st.graph):
+        with torch.cuda.graph(st.graph, **({"pool": st.pre_graph.pool()} if split else {})):
             st.loss, st.grad_norm, st.d_imgs = run()
         return st
 
@@ -969,24 +1006,45 @@ class TemporalStableZero123Guidance(nn.Module):
         if key not in self._sds_graphs:
             self._sds_graphs[key] = self._sds_graph(B, dev, clip is not None)
         st = self._sds_graphs[key]
+        cur = torch.cuda.current_stream(dev)
         with torch.no_grad():
-            st.post.copy_(post, non_blocking=True)
-            st.T.copy_(pinned(T) if T.device.type == "cpu" else T, non_blocking=True)
-            if frame_indices is None:
-                st.fidx.zero_()
-            else:
-                st.fidx.copy_(frame_indices, non_blocking=True)
-            if t is None:
-                st.t.random_(self.min_step, self.max_step + 1)
-            else:
-                st.t.copy_(t)
-            if noise is None:
-                st.noise.normal_()
-            else:
-                st.noise.copy_(noise)
-            if clip is not None:
-                st.clip.fill_(float(clip))
+            # Everything the step needs besides the images -- posterior noise, camera embedding, frame indices, timesteps, noise, the
+            # clip value -- and the conditioning graph go to the SIDE stream when every input comes from the host (or is drawn here):
+            # there is nothing to wait for but the previous step's graph, which reads the same buffers.  A device input orders the
+            # side stream behind the caller's, i.e. where the one-graph step had this work.
+            on_side = st.pre_graph is not None
+            if on_side:
+                on_host = lambda v: v is None or v.device.type == "cpu"
+                st.side.wait_event(st.main_done)
+                if not (T.device.type == "cpu" and on_host(frame_indices) and on_host(t) and on_host(noise)):
+                    st.side.wait_stream(cur)
+            pinned_long = lambda v: torch.empty(v.shape, dtype=torch.long, pin_memory=True).copy_(v)
+            with torch.cuda.stream(st.side) if on_side else contextlib.nullcontext():
+                st.post.copy_(post, non_blocking=True)
+                st.T.copy_(pinned(T) if T.device.type == "cpu" else T, non_blocking=True)
+                if frame_indices is None:
+                    st.fidx.zero_()
+                else:
+                    st.fidx.copy_(pinned_long(frame_indices) if frame_indices.device.type == "cpu" else frame_indices, non_blocking=True)
+                if t is None:
+                    st.t.random_(self.min_step, self.max_step + 1)
+                else:
+                    st.t.copy_(pinned_long(t) if t.device.type == "cpu" else t, non_blocking=True)
+                if on_side:
+                    st.pre_graph.replay()
+                if noise is None:
+                    st.noise.normal_()
+                else:
+                    st.noise.copy_(noise, non_blocking=True)
+                if clip is not None:
+                    st.clip.fill_(float(clip))
+                if on_side:
+                    st.pre_done.record(st.side)
+            if on_side:
+                cur.wait_event(st.pre_done)
         loss, grad_norm = _SdsStep.apply(x, st)
+        if st.pre_graph is not None:
+            st.main_done.record(cur)
         return {"loss_sds": loss, "grad_norm": grad_norm, "min_step": self.min_step, "max_step": self.max_step}
 
     def forward(self, rgb, elevation, azimuth, camera_distances, frame_indices=None, rgb_as_latents=False,
