@@ -74,6 +74,13 @@ MFMA_LINEAR_MIN_ROWS = int(os.environ.get("DM4D_MFMA_LINEAR_MIN_ROWS", "4096")) 
 # ... and the projections with a RESIDUAL (attention output, proj_out) from 512 rows on: the fused epilogue replaces the library GEMM + an
 # add launch (or its prepared C operand): 2048 x 640 -> 640: 7.9 us against 12.0, 512 x 1280 -> 1280: 10.5 against 11.4 + the add
 MFMA_LINEAR_RES_MIN_ROWS = int(os.environ.get("DM4D_MFMA_LINEAR_RES_MIN_ROWS", "512"))
+# ... the feed-forward's second projection (+ the residual the LayerNorm kernel prepared) and the 1x1 convolutions (proj_in, a ResBlock's
+# skip connection) at the 32 x 32 level too: in the step (tools/sds_ab.py, two alternating rounds) 9.94 / 9.95 ms with the library, 9.95 /
+# 9.97 and 9.92 / 9.94 with these two on the MFMA kernel from 8192 rows on (13 library launches fewer, the same loss to the last
+# digit), but 10.02-10.03 and 9.98-10.00 from 512 rows on (like q/k/v + GEGLU from 512 rows on: 10.02-10.03): at M <= 2048 hipBLASLt's
+# small tiles stay the faster choice
+MFMA_FF2_MIN_ROWS = int(os.environ.get("DM4D_MFMA_FF2_MIN_ROWS", "4096"))                 # (A/B switches)
+MFMA_CONV1X1_MIN_ROWS = int(os.environ.get("DM4D_MFMA_CONV1X1_MIN_ROWS", "4096"))
 MFMA_ATTENTION = os.environ.get("DM4D_MFMA_ATTENTION", "1") != "0"            # (A/B switch: the self-attention on csrc/attention.hip)
 FUSE_QKV = os.environ.get("DM4D_FUSE_QKV", "1") != "0"                              # (A/B switch: CrossAttention's one-GEMM q, k, v)
 FUSE_ADD_LAYERNORM = os.environ.get("DM4D_FUSE_ADD_LN", "1") != "0"                 # (A/B switch for BasicTransformerBlock._fused_no_grad)
@@ -181,8 +188,15 @@ def _conv3x3_stride2(conv, x, pad):
 def _conv1x1(conv, x):
     """A 1x1 convolution; on a channels-last tensor a GEMM over the [B, H*W, C] token view of the same memory."""
     if x.is_cuda and is_channels_last(x):
+        from . import conv_mfma
+
         B, Cc, Hh, Ww = x.shape
-        y = F.linear(x.permute(0, 2, 3, 1).reshape(B, Hh * Ww, Cc), conv.weight.flatten(1), conv.bias)
+        tok, w = x.permute(0, 2, 3, 1).reshape(B, Hh * Ww, Cc), conv.weight.flatten(1)
+        if (B * Hh * Ww >= MFMA_CONV1X1_MIN_ROWS and not torch.is_grad_enabled() and not conv.weight.requires_grad and tok.is_contiguous()
+                and w.is_contiguous() and conv_mfma.linear_supported(tok, w)):
+            y = conv_mfma.linear(tok, w, conv.bias)
+        else:
+            y = F.linear(tok, w, conv.bias)
         return y.view(B, Hh, Ww, -1).permute(0, 3, 1, 2)
     return conv(x)
 
@@ -367,6 +381,8 @@ class BasicTransformerBlock(nn.Module):
                 g = conv_mfma.linear(n3, pk[1], pk[2], act="geglu")
             else:
                 g = self.ff.net[0](n3)
+            if B * L >= MFMA_FF2_MIN_ROWS and g.is_contiguous() and conv_mfma.linear_supported(g, ff2.weight):
+                return conv_mfma.linear(g, ff2.weight, None, residual=x2b)                    # (x2b already carries ff2's bias)
             return x2b.view(-1, Cc).addmm_(g.view(B * L, -1), ff2.weight.t()).view(B, L, Cc)      # ff(norm3(x2)) + x2
         n1, xb = add_layer_norm(self.norm1, x, None, out1.bias)                           # norm1(x) | x + b_out
         o = self.attn1.attend(n1, n1)
