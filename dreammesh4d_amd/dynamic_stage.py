@@ -231,6 +231,9 @@ class DynamicStage:
             else:                                   # yaml:115-116
                 self.guidance.update_step(0, it, min_step_percent=C(0.02, 0, it), max_step_percent=C(0.5, 0, it))
         b = self.sample_batch()
+        if self.guidance is not None and b["n_rnd"] and getattr(self.guidance, "host_frame_indices", False):
+            # the guidance's conditioning (a function of the cameras, the frame indices and the timesteps it draws) ahead of the render
+            self.guidance.prefetch(b["elev_rnd"], b["azim_rnd"], frame_indices=b["fidx_rnd_host"])
         frames_t = b["frames_t"]                 # = timestamps[frames], gathered on the host and uploaded with the cameras
         self.opt.zero_grad(set_to_none=True)
         u = b["unit_frame"]

@@ -92,6 +92,9 @@ class StaticStage:
         elev, azim = -10.0 + 90.0 * u[:, 0], -180.0 + 360.0 * u[:, 1]
         cams = [syn.make_camera(self.H, self.W, elev_deg=float(e), azim_deg=float(a)) for e, a in zip(elev, azim)]
         batch = self._batch([self.ref_cam] + cams)
+        if self.guidance is not None and hasattr(self.guidance, "prefetch"):
+            self.guidance.update_step(0, it)
+            self.guidance.prefetch(elev, azim)          # the conditioning of this iteration's guidance call, ahead of the render
         raw = None
         if self.fused_head and self.dev.type == "cuda" and self.H % 2 == 0 and self.W % 2 == 0 and hasattr(self.r, "render_batch_raw"):
             raw = self.r.render_batch_raw(batch)

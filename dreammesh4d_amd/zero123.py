@@ -1008,14 +1008,17 @@ class TemporalStableZero123Guidance(nn.Module):
             st.loss, st.grad_norm, st.d_imgs = run()
         return st
 
-    def _forward_one_graph(self, x, elevation, azimuth, frame_indices, noise, t):
-        """x [B,3,256,256] float32 in [0,1] (requires grad).  The random draws are the eager step's, in its order."""
-        B, dev = int(x.shape[0]), x.device
+    def _stage_inputs(self, B, dev, elevation, azimuth, frame_indices, noise, t):
+        """Everything a one-graph step needs besides the images, written into the step's static buffers; with the conditioning graph
+        (`_sds_graph`) on the SIDE stream, followed by that graph, when every input comes from the host (or is drawn here): there is
+        nothing to wait for but the previous step's graph, which reads the same buffers.  A device input orders the side stream
+        behind the caller's, i.e. where the one-graph step had this work.  The random draws are the eager step's, in its order."""
         clip = self.grad_clip_val
         # host -> device inputs through FRESH pinned tensors of the caching host allocator (it keeps a block until the copy that
         # reads it has run; a buffer of our own would be overwritten by the next step while the host runs ahead), already in the
         # device buffer's dtype: a converting cross-device copy stages through pageable memory and blocks
         pinned = lambda v: torch.empty(v.shape, dtype=self.weights_dtype, pin_memory=True).copy_(v)
+        pinned_long = lambda v: torch.empty(v.shape, dtype=torch.long, pin_memory=True).copy_(v)
         post = pinned(torch.randn(B, 4, 32, 32))                         # the posterior noise: on the CPU like the reference (encode_images)
         T = self._camera_T(elevation, azimuth)
         key = (B, float(self.guidance_scale), clip is not None)
@@ -1024,17 +1027,12 @@ class TemporalStableZero123Guidance(nn.Module):
         st = self._sds_graphs[key]
         cur = torch.cuda.current_stream(dev)
         with torch.no_grad():
-            # Everything the step needs besides the images -- posterior noise, camera embedding, frame indices, timesteps, noise, the
-            # clip value -- and the conditioning graph go to the SIDE stream when every input comes from the host (or is drawn here):
-            # there is nothing to wait for but the previous step's graph, which reads the same buffers.  A device input orders the
-            # side stream behind the caller's, i.e. where the one-graph step had this work.
             on_side = st.pre_graph is not None
             if on_side:
                 on_host = lambda v: v is None or v.device.type == "cpu"
                 st.side.wait_event(st.main_done)
                 if not (T.device.type == "cpu" and on_host(frame_indices) and on_host(t) and on_host(noise)):
                     st.side.wait_stream(cur)
-            pinned_long = lambda v: torch.empty(v.shape, dtype=torch.long, pin_memory=True).copy_(v)
             with torch.cuda.stream(st.side) if on_side else contextlib.nullcontext():
                 st.post.copy_(post, non_blocking=True)
                 st.T.copy_(pinned(T) if T.device.type == "cpu" else T, non_blocking=True)
@@ -1056,8 +1054,39 @@ class TemporalStableZero123Guidance(nn.Module):
                     st.clip.fill_(float(clip))
                 if on_side:
                     st.pre_done.record(st.side)
-            if on_side:
-                cur.wait_event(st.pre_done)
+        return st
+
+    def prefetch(self, elevation, azimuth, frame_indices=None):
+        """Stage the NEXT guidance call's conditioning ahead of it -- before the caller enqueues its render: the conditioning graph and
+        the step's small inputs then run on the side stream beside the render kernels whatever the host's lead over the device.  Host
+        tensors only (elevation / azimuth / frame_indices as the call will pass them; timesteps and noise are drawn here); a no-op
+        returning False until the step's graphs exist (the first call captures them) or when the step is not the two-graph one.  The
+        call that follows must pass the same tensors (checked) and no `noise` / `t` of its own, else the staging is redone."""
+        self._prefetched = None
+        B = int(elevation.shape[0])
+        st = self._sds_graphs.get((B, float(self.guidance_scale), self.grad_clip_val is not None))
+        host = lambda v: v is None or (torch.is_tensor(v) and v.device.type == "cpu")
+        if (st is None or st.pre_graph is None or not (host(elevation) and host(azimuth) and host(frame_indices))
+                or os.environ.get("DM4D_SDS_PREFETCH", "1") == "0"):      # (A/B switch)
+            return False
+        self._stage_inputs(B, st.imgs.device, elevation, azimuth, frame_indices, None, None)
+        self._prefetched = (st, elevation.clone(), azimuth.clone(), None if frame_indices is None else frame_indices.clone())
+        return True
+
+    def _forward_one_graph(self, x, elevation, azimuth, frame_indices, noise, t):
+        """x [B,3,256,256] float32 in [0,1] (requires grad)."""
+        B, dev = int(x.shape[0]), x.device
+        pf, self._prefetched = self.__dict__.get("_prefetched"), None
+        same = lambda a, b: (a is None and b is None) or (a is not None and b is not None and a.device == b.device
+                                                          and a.shape == b.shape and torch.equal(a, b))
+        if (pf is not None and noise is None and t is None and int(pf[0].imgs.shape[0]) == B and same(pf[1], elevation)
+                and same(pf[2], azimuth) and same(pf[3], frame_indices)):
+            st = pf[0]                                   # staged by prefetch(): nothing left to do but wait for it
+        else:
+            st = self._stage_inputs(B, dev, elevation, azimuth, frame_indices, noise, t)
+        cur = torch.cuda.current_stream(dev)
+        if st.pre_graph is not None:
+            cur.wait_event(st.pre_done)
         loss, grad_norm = _SdsStep.apply(x, st)
         if st.pre_graph is not None:
             st.main_done.record(cur)
