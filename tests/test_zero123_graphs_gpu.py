@@ -242,3 +242,55 @@ def test_fused_unet_path_equals_plain_forward(monkeypatch):
     assert torch.isfinite(plain).all() and float(plain.abs().max()) > 1e-2
     # float16 roundings in another order (one GEMM's accumulation against three, sums fused differently): ~1e-3 relative
     assert float((fused - plain).abs().max()) <= 4e-3 * float(plain.abs().max()), float((fused - plain).abs().max()) / float(plain.abs().max())
+
+
+def test_conditioning_graph_on_the_side_stream_and_prefetch_equal_the_one_graph_step(monkeypatch):
+    """float16 weights: the step is the conditioning graph on a side stream + the main graph (zero123._sds_graph).  With the same
+    seeds it returns what the one-graph step returns (DM4D_SDS_PRE_GRAPH=0), whether the conditioning is staged by the call itself
+    or ahead of it by prefetch(); a call whose tensors differ from the prefetched ones stages again."""
+    if not torch.cuda.is_available():
+        pytest.skip("no HIP device")
+    from dreammesh4d_amd import zero123 as z
+
+    dev = torch.device("cuda:0")
+    L, B = 5, 2
+    torch.manual_seed(3)
+    model = z.Zero123(unet_kwargs=dict(model_channels=32, context_dim=32, num_heads=4), vae_kwargs=dict(ch=32))
+    for p in model.model.diffusion_model.out.parameters():
+        torch.nn.init.normal_(p, std=0.05)
+    cc, cat = torch.randn(L, 1, 32), torch.randn(L, 4, 32, 32)
+    kw = dict(cond_elevation_deg=5.0, half_precision_weights=True)
+    one = z.TemporalStableZero123Guidance(model, cc, cat, **kw).to(dev)
+    two = z.TemporalStableZero123Guidance(model, cc, cat, **kw).to(dev)          # shares the weights
+    assert two.prefetch(torch.tensor([10.0, 30.0]), torch.tensor([-40.0, 90.0])) is False      # no graphs yet: nothing to replay ahead
+    el, az, fi = torch.tensor([10.0, 30.0]), torch.tensor([-40.0, 90.0]), torch.tensor([1, 4])      # host tensors
+    rgb0 = torch.rand(B, 256, 256, 3, generator=torch.Generator().manual_seed(5)).to(dev)
+
+    def run(guid, step, prefetch):
+        rgb = rgb0.clone().requires_grad_(True)
+        torch.manual_seed(11 + step)
+        torch.cuda.manual_seed(13 + step)
+        staged = guid.prefetch(el, az, frame_indices=fi) if prefetch else None
+        out = guid(rgb, el, az, torch.full_like(el, 3.8), frame_indices=fi)
+        out["loss_sds"].backward()
+        torch.cuda.synchronize()
+        return float(out["loss_sds"]), float(out["grad_norm"]), rgb.grad.clone(), staged
+
+    for step in range(3):
+        monkeypatch.setenv("DM4D_SDS_PRE_GRAPH", "0")
+        a = run(one, step, False)
+        monkeypatch.delenv("DM4D_SDS_PRE_GRAPH")
+        b = run(two, step, False)
+        c = run(two, step, True)
+        assert c[3] is True                     # (the call before has captured the graphs: there is something to replay ahead)
+        for other in (b, c):
+            assert a[0] == other[0] and a[1] == other[1], (step, a[:2], other[:2])
+            assert float(a[2].abs().max()) > 0 and torch.equal(a[2], other[2]), step
+    assert one._graph_error is None and two._graph_error is None
+    st1, st2 = next(iter(one._sds_graphs.values())), next(iter(two._sds_graphs.values()))
+    assert st1.pre_graph is None and st2.pre_graph is not None
+    # a prefetch for OTHER cameras than the call's: the call stages its own
+    assert two.prefetch(el + 1.0, az, frame_indices=fi)
+    d = run(two, 2, False)
+    assert two.__dict__.get("_prefetched") is None
+    assert torch.isfinite(torch.tensor(d[0])) and float(d[2].abs().max()) > 0
