@@ -1,6 +1,10 @@
 """Time of one Zero123 SDS step (full-size UNet + VAE encoder, fp16, random weights, hipGraph replay) and its loss: run with
 DM4D_MFMA_CONV=0 / 1 for the A/B of the hand-written convolutions (profiles/r03_zero123.md)."""
 import sys, os, time, torch
+import os
+# the ISOLATED step: no render to run the conditioning graph beside, so the two-graph arrangement only adds its second launch and
+# the join (DESIGN.md section 3 "Round 4"); the iteration-level tools (iters_per_sec.py, bench.py) measure it where it pays
+os.environ.setdefault("DM4D_SDS_PRE_GRAPH", "0")
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 from dreammesh4d_amd import zero123 as z
 dev = torch.device('cuda:0'); L = 32

@@ -4,6 +4,10 @@ step, its split, FLOPs (torch.utils.flop_counter) and achieved TFLOP/s against t
   python tools/zero123_profile.py            -> one JSON line
   python tools/zero123_profile.py --steps-only N   -> just N steady-state steps (the command rocprofv3 wraps)"""
 import json, sys, time, torch
+import os
+# the ISOLATED step: no render to run the conditioning graph beside, so the two-graph arrangement only adds its second launch and
+# the join (DESIGN.md section 3 "Round 4"); the iteration-level tools (iters_per_sec.py, bench.py) measure it where it pays
+os.environ.setdefault("DM4D_SDS_PRE_GRAPH", "0")
 sys.path.insert(0, '.'); sys.path.insert(0, '/root/repo')
 from dreammesh4d_amd import zero123 as z
 dev = torch.device('cuda:0'); L = 32
