@@ -58,8 +58,10 @@ constexpr uint32_t kRankBig = 127u;    // rank field: index of the cell's record
 constexpr uint32_t kGidMask = (1u << kGidBits) - 1u;
 // The entry-parallel backward gives cells with at least this many entries a whole wave (64 entries per step) instead
 // of a DPP row (16 per step): `longlist` holds them.
+// (160: same-box A/B of 128 / 160 / 176 / 192 / 224 / 256 / 384 by bench.py's step, tools/ab_many.sh -- 64 and 96 double the kernel: a wide
+// block's six-step scans and one-cell table cost more per entry than a row's)
 #ifndef DM4D_WIDE_BWD
-#define DM4D_WIDE_BWD 128
+#define DM4D_WIDE_BWD 160
 #endif
 constexpr uint32_t kWideBwd = DM4D_WIDE_BWD;
 // tile-record mode: (Gaussian, tile) accumulators a workgroup of k_render_bwd_tile holds in LDS at a time (a window of the

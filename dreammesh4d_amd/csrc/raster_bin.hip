@@ -219,17 +219,30 @@ __device__ __forceinline__ void finish_tile_lds(const ViewCtx &c, const int tile
         }
     }
     if (lane == 0) {
+        // long cells are blended by their own kernels (raster.h, kLongCell); which slot a cell gets does not matter.
+        // The backward takes all of them (longlist); the forward only those of the tiles the LARGE variant sorts: it
+        // finishes long before the small variant, so their forward starts that much earlier.
+        // ONE returning atomic per wave and list for the wave's cells together (round 4, second half: one per cell was up to four
+        // DEPENDENT round trips to one L2 address at the end of every workgroup's life -- the small variant 91 -> 75 us when fewer cells
+        // took them, tools/prof_two_libs.sh)
+        uint32_t nw = 0, ne = 0;
+#pragma unroll
+        for (int i = 0; i < kPer; ++i) {
+            const int k = wv + kWaves * i;
+            if (k >= kCells) continue;
+            nw += base[i] >= kWideBwd ? 1u : 0u;
+            ne += (base[i] >= kLongCell && kSortThreads == 1024) ? 1u : 0u;
+        }
+        uint32_t sw = nw ? atomicAdd(&g.counters[kCntLong], nw) : 0u;
+        uint32_t se = ne ? atomicAdd(&g.counters[kCntLongEarly], ne) : 0u;
 #pragma unroll
         for (int i = 0; i < kPer; ++i) {
             const int k = wv + kWaves * i;
             if (k >= kCells) continue;
             g.ccount[tile * kCells + k] = base[i];
-            // long cells are blended by their own kernels (raster.h, kLongCell); which slot a cell gets does not matter.
-            // The backward takes all of them (longlist); the forward only those of the tiles the LARGE variant sorts: it
-            // finishes long before the small variant, so their forward starts that much earlier.
             const bool early = base[i] >= kLongCell && kSortThreads == 1024;
-            if (base[i] >= kWideBwd) g.longlist[atomicAdd(&g.counters[kCntLong], 1u)] = (uint32_t)(tile * kCells + k);
-            if (early) g.earlylist[atomicAdd(&g.counters[kCntLongEarly], 1u)] = (uint32_t)(tile * kCells + k);
+            if (base[i] >= kWideBwd) g.longlist[sw++] = (uint32_t)(tile * kCells + k);
+            if (early) g.earlylist[se++] = (uint32_t)(tile * kCells + k);
             g.cflag[tile * kCells + k] = early ? 1u : 0u;
         }
     }
@@ -364,8 +377,16 @@ __device__ __forceinline__ void finish_tile(const ViewCtx &c, int tile, uint32_t
         // The backward takes all of them (longlist); the forward only those of the tiles THIS, the large, variant
         // sorts: it finishes long before the small variant, so their forward starts that much earlier.
         const bool is_long = s_cbase[tid] >= kLongCell, early = is_long && kSortThreads == kSortLarge;
-        if (s_cbase[tid] >= kWideBwd) g.longlist[atomicAdd(&g.counters[kCntLong], 1u)] = (uint32_t)(tile * kCells + tid);
-        if (early) g.earlylist[atomicAdd(&g.counters[kCntLongEarly], 1u)] = (uint32_t)(tile * kCells + tid);
+        const bool wide = s_cbase[tid] >= kWideBwd;
+        // (one returning atomic per list for the tile's sixteen cells: the lanes of this branch are lanes 0..15 of wave 0)
+        const uint64_t bw = __builtin_amdgcn_ballot_w64(wide), be = __builtin_amdgcn_ballot_w64(early);
+        uint32_t sw = 0, se = 0;
+        if (tid == 0 && bw) sw = atomicAdd(&g.counters[kCntLong], (uint32_t)__builtin_popcountll(bw));
+        if (tid == 0 && be) se = atomicAdd(&g.counters[kCntLongEarly], (uint32_t)__builtin_popcountll(be));
+        sw = (uint32_t)__builtin_amdgcn_readfirstlane((int)sw);
+        se = (uint32_t)__builtin_amdgcn_readfirstlane((int)se);
+        if (wide) g.longlist[sw + mbcnt(bw)] = (uint32_t)(tile * kCells + tid);
+        if (early) g.earlylist[se + mbcnt(be)] = (uint32_t)(tile * kCells + tid);
         g.cflag[tile * kCells + tid] = early ? 1u : 0u;
     }
 }
