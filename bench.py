@@ -153,8 +153,40 @@ class Workload:
         return out
 
 
+def _free_port():
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _spawn_ranks(n):
+    """`python bench.py --gpus N` (N > 1) outside a launcher: start the N ranks here, one process per GPU, the way the
+    reference's own launcher does (launch.py:114,166,228-235 hands `devices = N` to the trainer, which spawns them).  The
+    children are this same command under torch.distributed.run (rendezvous on 127.0.0.1); rank 0 prints the JSON line."""
+    import subprocess
+    backend = os.environ.get("DM4D_BENCH_BACKEND", "nccl")
+    have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if backend == "nccl" and have < n:
+        raise SystemExit(f"bench.py --gpus {n}: only {have} HIP device(s) visible (DM4D_BENCH_BACKEND=gloo rehearses the "
+                         f"control flow with ranks sharing devices; never a performance number)")
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or n) // n)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    raise SystemExit(subprocess.call(cmd, env=env))
+
+
 def main():
     args = parse()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ:
+        if args.gpus > 1:
+            _spawn_ranks(args.gpus)          # does not return
+    elif int(os.environ["WORLD_SIZE"]) != args.gpus and "--gpus" in " ".join(sys.argv[1:]):
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={os.environ['WORLD_SIZE']} ranks")
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))

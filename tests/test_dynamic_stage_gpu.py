@@ -149,6 +149,27 @@ def test_bench_rehearsal_two_ranks_over_gloo():
     assert line["config"]["allreduce_bytes_per_step"] == line["config"]["allreduce_message_bytes"] < line["config"]["dense_gradient_bytes"] / 5
 
 
+def test_bench_spawns_its_own_ranks_from_gpus_flag():
+    """`python bench.py --gpus 2 ...` with NO launcher in the command (the driver's command shape): bench.py starts the two
+    ranks itself (reference: launch.py:114,166,228-235 -- the launcher owns the per-GPU processes) and rank 0's line says
+    n_gpus = 2.  Rehearsal mode (gloo, ranks share the one GPU); with the RCCL backend and fewer devices than ranks it
+    refuses loudly instead of rendering on one GPU and printing n_gpus = 1 (round 4's behaviour)."""
+    if not torch.cuda.is_available():
+        pytest.skip("no HIP device")
+    import json, os, subprocess, sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    cmd = [sys.executable, "bench.py", "--gpus", "2", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-iters"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=dict(env, DM4D_BENCH_BACKEND="gloo"), cwd=root)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and "REHEARSAL" in line["data"]
+    if torch.cuda.device_count() < 2:
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=env, cwd=root)
+        assert r.returncode != 0 and "HIP device" in (r.stdout + r.stderr)
+
+
 @pytest.mark.parametrize("H,W,C", [(512, 512, 6), (64, 96, 3)])
 def test_image_head_equals_the_torch_composition(H, W, C):
     """image_head (csrc/imagehead.hip) against what it replaces in DynamicStage.iteration: clamp(render, 0, 1); MSE against the
