@@ -110,6 +110,14 @@ class AdamwArgs(C.Structure):
                 ("exp_avg_sq", vp), ("step", vp), ("pending_decay", vp), ("found_inf", vp), ("scratch", vp)]
 
 
+class AdamwStepArgs(C.Structure):
+    """dm4d_adamw_step_args (include/dm4d.h)."""
+    _fields_ = [("n_groups", C.c_int32), ("lr", C.c_float * 8), ("beta1", C.c_float * 8), ("beta2", C.c_float * 8), ("eps", C.c_float * 8),
+                ("weight_decay", C.c_float * 8), ("group", C.c_int32 * MAX_GRAD_SEGMENTS), ("param", vp * MAX_GRAD_SEGMENTS),
+                ("param_out", vp * MAX_GRAD_SEGMENTS), ("grad_in_message", C.c_uint8 * MAX_GRAD_SEGMENTS), ("skip", C.c_uint8 * MAX_GRAD_SEGMENTS),
+                ("exp_avg", vp), ("exp_avg_sq", vp), ("step", vp), ("pending_decay", vp), ("found_inf", vp), ("scratch", vp)]
+
+
 ALLOC_FN = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_int, C.c_size_t)
 
 _SIGNATURES = {
@@ -166,7 +174,8 @@ _SIGNATURES = {
     "dm4d_laplacian_smoothing_forward": (C.c_int, [C.c_int32] * 2 + [vp] * 6),
     "dm4d_laplacian_smoothing_backward": (C.c_int, [C.c_int32] * 2 + [vp] * 6),
     "dm4d_normal_consistency_forward": (C.c_int, [C.c_int32] * 3 + [vp] * 4),
-    "dm4d_normal_consistency_backward": (C.c_int, [C.c_int32] * 3 + [vp] * 8),
+    "dm4d_normal_consistency_backward": (C.c_int, [C.c_int32] * 3 + [vp] * 7),
+    "dm4d_normal_consistency_backward_scratch": (C.c_int, [C.c_int32] * 3 + [vp] * 8),
     "dm4d_hexplane_forward": (C.c_int, [C.c_int32] * 3 + [vp] * 2 + [C.c_int32] + [vp] * 6),
     "dm4d_hexplane_axis_index": (C.c_int, [C.c_int32] * 2 + [vp] * 5),
     "dm4d_hexplane_scratch_bytes": (C.c_size_t, [C.c_int32] * 3),
@@ -210,6 +219,7 @@ _SIGNATURES = {
     "dm4d_grad_pack": (C.c_int, [C.POINTER(GradSegments), vp, vp]),
     "dm4d_grad_unpack": (C.c_int, [C.POINTER(GradSegments), vp, C.c_float, vp]),
     "dm4d_adamw_message": (C.c_int, [C.POINTER(GradSegments), C.POINTER(AdamwArgs), C.c_float, vp]),
+    "dm4d_adamw_step": (C.c_int, [C.POINTER(GradSegments), C.POINTER(AdamwStepArgs), C.c_float, vp]),
     "dm4d_views_geom_bytes": (C.c_size_t, [C.c_int32] * 4),
     "dm4d_views_binning_bytes": (C.c_size_t, [C.c_int32, C.c_int64]),
     "dm4d_views_image_bytes": (C.c_size_t, [C.c_int32] * 3),
@@ -262,8 +272,20 @@ def lib() -> C.CDLL:
             fn = getattr(L, name)
             fn.restype = res
             fn.argtypes = args
+        want = abi_version()
+        if L.dm4d_version() != want:
+            raise ImportError(f"{SO_PATH} has ABI version {L.dm4d_version()}, include/dm4d.h declares {want}: rebuild it "
+                              "(`python -c 'import __graft_entry__ as g; g.build()'`)")
         _LIB = L
     return _LIB
+
+
+def abi_version() -> int:
+    """DM4D_ABI_VERSION of include/dm4d.h (the header this table of signatures was written against)."""
+    import re
+
+    hdr = os.path.join(os.path.dirname(_HERE), "include", "dm4d.h")
+    return int(re.search(r"#define\s+DM4D_ABI_VERSION\s+(\d+)", open(hdr).read()).group(1))
 
 
 def check(rc, what=""):

@@ -110,7 +110,7 @@ using namespace dm4d;
 
 extern "C" {
 
-int dm4d_version(void) { return 100; }
+int dm4d_version(void) { return DM4D_ABI_VERSION; }
 const char *dm4d_last_error(void) { return g_err; }
 
 void dm4d_profile_enable(unsigned kernel_mask) { g_prof_mask = kernel_mask; }

@@ -371,7 +371,23 @@ int dm4d_normal_consistency_forward(int32_t T, int32_t V, int32_t P, const int32
 
 int dm4d_normal_consistency_backward(int32_t T, int32_t V, int32_t P, const int32_t *pairs, const int32_t *vert_offsets,
                                      const int32_t *vert_items, const float *xyz, const float *g_loss, float *g_xyz,
-                                     float *scratch, dm4d_stream_t stream)
+                                     dm4d_stream_t stream)
+{
+    // rounds 1-3's signature: the scratch is the library's (see include/dm4d.h)
+    static float *own = nullptr;
+    static size_t own_floats = 0;
+    const size_t need = (T > 0 && P > 0) ? (size_t)T * (size_t)P * 12 : 0;
+    if (need > own_floats) {
+        if (own) { DM4D_HIP_CHECK(hipDeviceSynchronize()); DM4D_HIP_CHECK(hipFree(own)); own = nullptr; own_floats = 0; }
+        DM4D_HIP_CHECK(hipMalloc((void **)&own, need * sizeof(float)));
+        own_floats = need;
+    }
+    return dm4d_normal_consistency_backward_scratch(T, V, P, pairs, vert_offsets, vert_items, xyz, g_loss, g_xyz, own, stream);
+}
+
+int dm4d_normal_consistency_backward_scratch(int32_t T, int32_t V, int32_t P, const int32_t *pairs, const int32_t *vert_offsets,
+                                             const int32_t *vert_items, const float *xyz, const float *g_loss, float *g_xyz,
+                                             float *scratch, dm4d_stream_t stream)
 {
     if (T < 0 || V < 0 || P < 0) { set_error("normal consistency: negative size"); return DM4D_ERR_INVALID; }
     if (T == 0 || V == 0) return DM4D_OK;

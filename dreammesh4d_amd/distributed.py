@@ -198,12 +198,21 @@ def all_reduce_max(t):
     return t
 
 
+# The reference's EFFECTIVE hyperparameters (verified with torch: `Adam(l, lr=0, eps=1e-15)` fills the dicts of `l` in place,
+# `AdamW(l, betas=[0.9, 0.99], eps=1e-15)` afterwards only setdefault()s): the groups training_setup / training_setup_dynamic
+# create -- points, f_dc, f_rest, all_densities, scales, quaternions, deformation, grid -- run betas (0.9, 0.999) and NO weight decay;
+# groups appended by merge_optimizer from `net_optimizer` run AdamW's (0.9, 0.99) / 0.01
+# (C/geometry/sugar.py:382,406-416, C/geometry/dynamic_sugar.py:231-235).
+REFERENCE_GEOMETRY_GROUP = {"betas": (0.9, 0.999), "eps": 1e-15, "weight_decay": 0.0}
+REFERENCE_MERGED_GROUP = {"betas": (0.9, 0.99), "eps": 1e-15, "weight_decay": 0.01}
+
+
 class ShardedAdamW:
     """The AdamW step of the data-parallel loop with the optimiser state SHARDED over the ranks (SURVEY.md section 8e:
     "reduce-scatter -> sharded AdamW -> all-gather params"), in the MESSAGE space of a ``GradAllReducer``:
 
         gradients --pack--> flat message --reduce-scatter (sum, x 1/world)--> this rank's 1/world slice
-        slice: AdamW (moments live only here) on the slice of the packed PARAMETER values
+        slice: AdamW (moments live only here); the parameters are read and written IN their storages through the message's index lists
         updated slices --all-gather--> flat message --unpack--> parameters
 
     Every rank ends with the same parameters as the replicated ``torch.optim.AdamW`` step after an all-reduce (same
@@ -211,62 +220,192 @@ class ShardedAdamW:
     1/world of the two moment buffers: at the shipped dynamic-stage configuration the replicated step streams
     35.76 M x (param + grad + 2 moments) = 572 MB per rank per iteration, the sharded one 1/world of the 13.5 MB message.
     Elements outside the message (HexPlane texels no node touches) have zero gradient on every rank, hence zero moments:
-    their update is the weight decay alone, applied locally.
+    their update is the weight decay alone, applied locally (and lazily: ``materialize``).
 
-    ``groups``: [{"params": [...], "lr": float, "name": ...}] like an optimiser's param_groups (lr may be changed
-    between steps through ``param_groups``).  Works over RCCL (reduce_scatter_tensor / all_gather_into_tensor) and over
-    gloo (all_reduce + slice / all_gather) for the CPU tests."""
+    ``groups``: an optimiser's ``param_groups`` -- [{"params": [...], "lr": float, "betas": (b1, b2), "eps": e, "weight_decay": w,
+    "name": ...}]; lr / betas / eps / weight_decay are read PER GROUP at every step (so schedules and the reference's mixed
+    hyperparameters work: ``REFERENCE_GEOMETRY_GROUP``), the constructor's values are the defaults of groups that lack a key.
+    On a HIP device the step is the kernel pair of csrc/gradpack.hip (``dm4d_adamw_step``) for ANY world size (round 5; round 4
+    ran the slice through torch operators when world > 1); on CPU tensors -- the gloo tests -- the same arithmetic in torch
+    operators.  Works over RCCL (reduce_scatter_tensor / all_gather_into_tensor) and over gloo (all_reduce + slice / all_gather).
+    A parameter whose ``.grad`` is None on a single process is skipped like torch.optim skips it (no decay, no moment decay, its
+    step counter not advanced); with world > 1 a missing gradient is this rank's zeros in the sum, as in ``GradAllReducer``."""
 
     def __init__(self, groups, reducer: GradAllReducer, betas=(0.9, 0.99), eps=1e-15, weight_decay=0.01):
         self.param_groups = [dict(g) for g in groups]
-        self.reducer, self.betas, self.eps, self.weight_decay = reducer, betas, eps, weight_decay
+        if not 1 <= len(self.param_groups) <= 8:
+            raise ValueError("ShardedAdamW: 1..8 parameter groups")
+        self.reducer, self.betas, self.eps, self.weight_decay = reducer, tuple(betas), eps, weight_decay
+        for g in self.param_groups:
+            if g.get("amsgrad") or g.get("maximize"):
+                raise NotImplementedError("ShardedAdamW: amsgrad / maximize groups")
         w, r = world(), rank()
         n = reducer.flat.numel()
         self.chunk = (n + w - 1) // w
-        self.padded = torch.zeros(self.chunk * w, dtype=torch.float32, device=reducer.flat.device)
-        self.lo, self.hi = r * self.chunk, (r + 1) * self.chunk
         dev = reducer.flat.device
+        self.padded = torch.zeros(self.chunk * w, dtype=torch.float32, device=dev)
+        self.lo, self.hi = r * self.chunk, (r + 1) * self.chunk
         self.exp_avg = torch.zeros(self.chunk, dtype=torch.float32, device=dev)
         self.exp_avg_sq = torch.zeros(self.chunk, dtype=torch.float32, device=dev)
         self.step_count = 0
-        self.step_t = None               # steps APPLIED (device scalar: a step masked by found_inf does not count)
-        self.pending_decay = None        # per group: product of the decay factors not yet applied to the untouched elements
-        # group id of every message element of the local slice (learning rates are per group)
-        gid_of = {}
-        for gi, g in enumerate(self.param_groups):
-            for p in g["params"]:
-                gid_of[id(p)] = gi
-        gid = torch.zeros(self.chunk * w, dtype=torch.long, device=dev)
-        for p, o, ix in zip(reducer.params, reducer.offsets, reducer.index):
-            cnt = p.numel() if ix is None else ix.numel()
+        nseg = len(reducer.params)
+        self.step_t = torch.zeros(nseg, dtype=torch.float64, device=dev)          # steps APPLIED per segment (a step masked by found_inf, or a segment without a gradient, does not count)
+        self.pending_decay = torch.ones(nseg, dtype=torch.float64, device=dev)    # per segment: product of the decay factors not yet applied to its elements OUTSIDE the message
+        self._decay_pending = False                                               # (host: False while every step so far had weight_decay == 0 everywhere)
+        gid_of = {id(p): gi for gi, g in enumerate(self.param_groups) for p in g["params"]}
+        for p in reducer.params:
             if id(p) not in gid_of:
                 raise ValueError("every reduced parameter must belong to a group")
-            gid[o:o + cnt] = gid_of[id(p)]
-        self.gid = gid[self.lo:self.hi].clone()
+        self._seg_group = [gid_of[id(p)] for p in reducer.params]
+        # segment id of every message element of the local slice (the torch-operator path gathers its per-element scalars with it)
+        sid = torch.zeros(self.chunk * w, dtype=torch.long, device=dev)
+        for k, (p, o, ix) in enumerate(zip(reducer.params, reducer.offsets, reducer.index)):
+            sid[o:o + (p.numel() if ix is None else ix.numel())] = k
+        self.sid = sid[self.lo:self.hi].clone()
+        self._scal = None
+
+    fused = True      # HIP device: the step as two launches of csrc/gradpack.hip (dm4d_adamw_step); False: the torch-operator form (tests)
 
     def zero_grad(self, set_to_none=True):
         for p in self.reducer.params:
             p.grad = None if set_to_none else (p.grad.zero_() if p.grad is not None else None)
 
+    def _hyper(self):
+        """Per group (lr, beta1, beta2, eps, weight_decay) as the groups hold them NOW."""
+        out = []
+        for g in self.param_groups:
+            b = g.get("betas", self.betas)
+            out.append((float(g["lr"]), float(b[0]), float(b[1]), float(g.get("eps", self.eps)), float(g.get("weight_decay", self.weight_decay))))
+        return out
+
     def _pack_params(self):
         """parameter VALUES in message layout (the reducer's pack, applied to .data instead of .grad)."""
         red, flat = self.reducer, self.padded
+        if flat.is_cuda:
+            self._kernel_pack("dm4d_grad_pack")
+            return
         for p, o, ix in zip(red.params, red.offsets, red.index):
             cnt = p.numel() if ix is None else ix.numel()
             src = storage_flat(p.data)
             flat[o:o + cnt].copy_(src if ix is None else src.index_select(0, ix))
 
+    def _kernel_pack(self, fn):
+        """dm4d_grad_pack / dm4d_grad_unpack between `padded` and the PARAMETER storages (one launch)."""
+        import ctypes as C
+
+        from . import _lib
+
+        red, dev = self.reducer, self.padded.device
+        seg = _lib.GradSegments()
+        seg.n_segments = len(red.params)
+        for k, (p, o, ix) in enumerate(zip(red.params, red.offsets, red.index)):
+            seg.grad[k] = storage_flat(p.data).data_ptr()
+            seg.index[k] = None if ix is None else ix.data_ptr()
+            seg.count[k] = p.numel() if ix is None else ix.numel()
+            seg.offset[k] = o
+        st = torch.cuda.current_stream(dev).cuda_stream
+        with torch.cuda.device(dev):
+            if fn == "dm4d_grad_pack":
+                _lib.check(_lib.lib().dm4d_grad_pack(C.byref(seg), self.padded.data_ptr(), st), fn)
+            else:
+                _lib.check(_lib.lib().dm4d_grad_unpack(C.byref(seg), self.padded.data_ptr(), 1.0, st), fn)
+
     @torch.no_grad()
     def step(self, found_inf=None):
         """found_inf (optional, scalar float tensor on the device, 1.0 = skip): the step is then masked ON THE DEVICE the way a
-        fused torch optimiser skips on `found_inf` (no host sync): parameters, both moments and the step counter keep
+        fused torch optimiser skips on `found_inf` (no host sync): parameters, both moments and the step counters keep
         their values.  The collectives still run, so the ranks stay in lockstep; every rank must pass the same flag."""
+        dev = self.padded.device
+        hyper = self._hyper()
+        self._decay_pending = self._decay_pending or any(h[4] != 0.0 for h in hyper)
+        self.step_count += 1            # steps ATTEMPTED (host-side bookkeeping only)
+        if dev.type == "cuda" and self.fused:
+            return self._step_kernel(found_inf, hyper)
+        return self._step_ops(found_inf, hyper)
+
+    # ------------------------------------------------------------------ HIP: csrc/gradpack.hip
+    def _step_kernel(self, found_inf, hyper):
+        import ctypes as C
+
+        from . import _lib
+
+        red, dev, w = self.reducer, self.padded.device, world()
+        n = red.flat.numel()
+        if self._scal is None:
+            self._scal = torch.zeros(1 + 2 * _lib.MAX_GRAD_SEGMENTS, dtype=torch.float32, device=dev)
+            self._p_slice = torch.zeros(self.chunk, dtype=torch.float32, device=dev) if w > 1 else None
+            self._g_slice = torch.zeros(self.chunk, dtype=torch.float32, device=dev) if w > 1 else None
+        a = _lib.AdamwStepArgs()
+        a.n_groups = len(hyper)
+        for gi, (lr, b1, b2, eps, wd) in enumerate(hyper):
+            a.lr[gi], a.beta1[gi], a.beta2[gi], a.eps[gi], a.weight_decay[gi] = lr, b1, b2, eps, wd
+        a.exp_avg, a.exp_avg_sq = self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr()
+        a.step, a.pending_decay = self.step_t.data_ptr(), self.pending_decay.data_ptr()
+        fi = None if found_inf is None else found_inf.reshape(()).to(dev, torch.float32)
+        a.found_inf = None if fi is None else fi.data_ptr()
+        a.scratch = self._scal.data_ptr()
+        if w == 1:
+            # one process: gradients and parameters are read from / written to their storages through the message's index lists,
+            # the moments live in message layout -- no pack, no unpack
+            seg = red._segments(False)
+            for k, p in enumerate(red.params):
+                a.group[k] = self._seg_group[k]
+                a.param[k] = storage_flat(p.data).data_ptr()
+                a.skip[k] = 1 if p.grad is None else 0
+            scale = 1.0
+        else:
+            # pack -> reduce-scatter -> the kernel on this rank's slice -> all-gather -> unpack into the parameters
+            seg0 = red._segments(False)
+            with torch.cuda.device(dev):
+                _lib.check(_lib.lib().dm4d_grad_pack(C.byref(seg0), self.padded.data_ptr(), torch.cuda.current_stream(dev).cuda_stream), "dm4d_grad_pack")
+            g_slice = self._g_slice
+            if dist.get_backend() == "gloo":
+                # (functional rehearsal on a shared device: the SAME all-reduce over the SAME n elements as the replicated path, then this
+                #  rank's slice -- a ring's order of additions depends on the element's position in the message, and AdamW with eps = 1e-15
+                #  turns a last-bit difference of a gradient that is rounding noise into a full +-lr step)
+                host = self.padded.cpu()
+                dist.all_reduce(host[:n])
+                g_slice.copy_(host[self.lo:self.hi])
+            else:
+                dist.reduce_scatter_tensor(g_slice, self.padded)
+            seg = _lib.GradSegments()
+            seg.n_segments = len(red.params)
+            for k, (p, o, ix) in enumerate(zip(red.params, red.offsets, red.index)):
+                cnt = p.numel() if ix is None else ix.numel()
+                lo, hi = max(o, self.lo), min(o + cnt, self.hi)
+                a.group[k] = self._seg_group[k]
+                base = storage_flat(p.data).data_ptr()
+                if hi <= lo:
+                    seg.count[k], seg.offset[k], seg.grad[k], seg.index[k], a.param[k] = 0, 0, None, None, base
+                    continue
+                seg.count[k], seg.offset[k] = hi - lo, lo - self.lo
+                seg.grad[k] = g_slice.data_ptr() + 4 * (lo - self.lo)
+                a.grad_in_message[k] = 1
+                a.param_out[k] = self._p_slice.data_ptr() + 4 * (lo - self.lo)
+                if ix is None:
+                    seg.index[k], a.param[k] = None, base + 4 * (lo - o)
+                else:
+                    seg.index[k], a.param[k] = ix.data_ptr() + 8 * (lo - o), base
+            scale = 1.0 / w
+            # (a step skipped by found_inf still fills the send slice: the kernel copies the CURRENT parameter values into param_out)
+        with torch.cuda.device(dev):
+            _lib.check(_lib.lib().dm4d_adamw_step(C.byref(seg), C.byref(a), scale, torch.cuda.current_stream(dev).cuda_stream), "dm4d_adamw_step")
+        if w > 1:
+            if dist.get_backend() == "gloo":
+                parts = [torch.empty(self.chunk, dtype=torch.float32) for _ in range(w)]
+                dist.all_gather(parts, self._p_slice.cpu())
+                self.padded.copy_(torch.cat(parts))
+            else:
+                dist.all_gather_into_tensor(self.padded, self._p_slice)
+            self._kernel_pack("dm4d_grad_unpack")
+
+    # ------------------------------------------------------------------ torch operators (CPU tensors: the gloo tests; `fused = False`)
+    def _step_ops(self, found_inf, hyper):
         red, w = self.reducer, world()
         n = red.flat.numel()
         dev = self.padded.device
-        if w == 1 and dev.type == "cuda" and self.fused:
-            return self._step_fused(found_inf)
         keep = None if found_inf is None else (found_inf.reshape(()).to(dev) == 0)          # bool scalar: True = apply
+        has_grad = torch.tensor([1.0 if (p.grad is not None or w > 1) else 0.0 for p in red.params], dtype=torch.float64, device=dev)
         red.pack()
         self.padded[:n].copy_(red.flat)
         g_shard = torch.empty(self.chunk, dtype=torch.float32, device=dev)
@@ -274,43 +413,38 @@ class ShardedAdamW:
         if w == 1:
             g_shard.copy_(self.padded)
         elif gloo:
-            # (functional rehearsal: the SAME all-reduce over the SAME n elements as the replicated path, then this rank's slice.  A
-            # ring's order of additions depends on the element's position in the message, and AdamW with eps = 1e-15 turns a last-bit
-            # difference of a gradient that is rounding noise into a full +-lr step: reducing the padded buffer instead made the
-            # 8-rank sharded / replicated comparison differ by 1e-4 of the parameter scale where 2 ranks, a + b = b + a, agree to 4e-6.
-            # Over RCCL reduce-scatter and all-reduce are different algorithms: there the two optimisers agree up to that noise.)
             host = (self.padded.cpu() if self.padded.is_cuda else self.padded.clone())
             dist.all_reduce(host[:n])
             g_shard.copy_(host[self.lo:self.hi])
         else:
             dist.reduce_scatter_tensor(g_shard, self.padded)
         g_shard.mul_(1.0 / w)
-        # ---- AdamW on the slice: torch/optim/adamw.py::_single_tensor_adamw, operation for operation (the step count lives
+        # ---- AdamW on the slice: torch/optim/adamw.py::_single_tensor_adamw, operation for operation (the step counts live
         #      on the device so that a skipped step does not advance the bias corrections)
         self._pack_params()
         p_old = self.padded[self.lo:self.hi].clone()
-        if self.step_t is None:
-            self.step_t = torch.zeros((), dtype=torch.float64, device=dev)
-        step_new = self.step_t + 1.0
-        b1, b2 = self.betas
-        lr_g = torch.tensor([float(g["lr"]) for g in self.param_groups], dtype=torch.float32, device=dev)
-        lr = lr_g[self.gid]
-        p = p_old * (1.0 - lr * self.weight_decay)
-        exp_avg = torch.lerp(self.exp_avg, g_shard, 1.0 - b1)
-        exp_avg_sq = (self.exp_avg_sq * b2).addcmul_(g_shard, g_shard, value=1.0 - b2)
-        bc1 = (1.0 - torch.pow(torch.tensor(b1, dtype=torch.float64, device=dev), step_new)).to(torch.float32)
-        bc2_sqrt = torch.sqrt(1.0 - torch.pow(torch.tensor(b2, dtype=torch.float64, device=dev), step_new)).to(torch.float32)
-        denom = (exp_avg_sq.sqrt() / bc2_sqrt).add_(self.eps)
-        p.addcdiv_(exp_avg * (-(lr / bc1)), denom)
-        decay_g = (1.0 - lr_g.double() * self.weight_decay)             # this step's decay factor per group
-        if keep is not None:
-            p = torch.where(keep, p, p_old)
-            exp_avg = torch.where(keep, exp_avg, self.exp_avg)
-            exp_avg_sq = torch.where(keep, exp_avg_sq, self.exp_avg_sq)
-            step_new = torch.where(keep, step_new, self.step_t)
-            decay_g = torch.where(keep, decay_g, torch.ones_like(decay_g))
+        apply_seg = has_grad if keep is None else has_grad * keep.to(torch.float64)          # [n_seg] 1 = this segment steps
+        step_new = self.step_t + apply_seg
+        sg = torch.tensor(self._seg_group, dtype=torch.long, device=dev)
+        col = lambda j, dt: torch.tensor([h[j] for h in hyper], dtype=dt, device=dev)[sg]   # per SEGMENT
+        lr_s, b1_s, b2_s, eps_s, wd_s = (col(j, torch.float32) for j in range(5))
+        bc1_s = (1.0 - torch.pow(col(1, torch.float64), step_new)).to(torch.float32)
+        bc2s_s = torch.sqrt(1.0 - torch.pow(col(2, torch.float64), step_new)).to(torch.float32)
+        sid = self.sid
+        lr, b2 = lr_s[sid], b2_s[sid]
+        w1, w2 = (1.0 - b1_s)[sid], (1.0 - b2_s)[sid]
+        p = p_old * (1.0 - lr * wd_s[sid])
+        exp_avg = self.exp_avg + w1 * (g_shard - self.exp_avg)                   # torch.lerp(exp_avg, grad, 1 - beta1), weight < 0.5
+        exp_avg_sq = self.exp_avg_sq * b2 + (w2 * g_shard) * g_shard
+        denom = (exp_avg_sq.sqrt() / bc2s_s[sid]).add_(eps_s[sid])
+        p = p + (exp_avg * (-(lr / bc1_s[sid]))) / denom
+        decay_s = (1.0 - lr_s.double() * wd_s.double())                          # this step's decay factor per segment
+        on = apply_seg[sid] != 0
+        p = torch.where(on, p, p_old)
+        exp_avg = torch.where(on, exp_avg, self.exp_avg)
+        exp_avg_sq = torch.where(on, exp_avg_sq, self.exp_avg_sq)
+        decay_s = torch.where(apply_seg != 0, decay_s, torch.ones_like(decay_s))
         self.exp_avg, self.exp_avg_sq, self.step_t = exp_avg, exp_avg_sq, step_new
-        self.step_count += 1            # steps ATTEMPTED (host-side bookkeeping only)
         # ---- everyone gets every slice
         if w == 1:
             self.padded.copy_(p)
@@ -322,70 +456,38 @@ class ShardedAdamW:
             dist.all_gather_into_tensor(self.padded, p)
         # ---- back into the parameters.  Elements outside the message (HexPlane texels no node touches) have zero gradient
         #      and zero moments on every rank: their whole update is the weight decay -- and no forward ever READS them (the
-        #      nodes are static).  Multiplying 134 MB of grids by the decay every step (round 2: a torch op per tensor) is
-        #      therefore deferred: the product of the steps' decay factors is kept per group on the device and applied by
-        #      materialize() (checkpointing, state_dict, tests) in one multi-tensor launch.
-        self.pending_decay = decay_g if self.pending_decay is None else self.pending_decay * decay_g
+        #      nodes are static).  Multiplying 134 MB of grids by the decay every step is therefore deferred: the product of the
+        #      steps' decay factors is kept per segment on the device and applied by materialize() (checkpointing, state_dict, tests).
+        self.pending_decay = self.pending_decay * decay_s
         self._unpack_message()
-
-    fused = True      # single process on a HIP device: the step as two launches of csrc/gradpack.hip (dm4d_adamw_message)
-
-    def _step_fused(self, found_inf):
-        """One process, HIP device: gradients and parameters are read from / written to their storages through the message's index
-        lists, the moments live in message layout -- no pack, no unpack, the same per-element arithmetic (csrc/gradpack.hip)."""
-        import ctypes as C
-
-        from . import _lib
-
-        red, dev = self.reducer, self.padded.device
-        if self.step_t is None:
-            self.step_t = torch.zeros((), dtype=torch.float64, device=dev)
-        if self.pending_decay is None:
-            self.pending_decay = torch.ones(len(self.param_groups), dtype=torch.float64, device=dev)
-        if self.__dict__.get("_scal") is None:
-            self._scal = torch.zeros(4, dtype=torch.float32, device=dev)
-            gid_of = {id(p): gi for gi, g in enumerate(self.param_groups) for p in g["params"]}
-            self._seg_group = [gid_of[id(p)] for p in red.params]
-        seg = red._segments(False)
-        a = _lib.AdamwArgs()
-        a.beta1, a.beta2, a.eps, a.weight_decay = self.betas[0], self.betas[1], self.eps, self.weight_decay
-        a.n_groups = len(self.param_groups)
-        for gi, g in enumerate(self.param_groups):
-            a.lr[gi] = float(g["lr"])
-        for k, p in enumerate(red.params):
-            a.group[k] = self._seg_group[k]
-            a.param[k] = storage_flat(p.data).data_ptr()
-        a.exp_avg, a.exp_avg_sq = self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr()
-        a.step, a.pending_decay = self.step_t.data_ptr(), self.pending_decay.data_ptr()
-        fi = None if found_inf is None else found_inf.reshape(()).to(dev, torch.float32)
-        a.found_inf = None if fi is None else fi.data_ptr()
-        a.scratch = self._scal.data_ptr()
-        with torch.cuda.device(dev):
-            _lib.check(_lib.lib().dm4d_adamw_message(C.byref(seg), C.byref(a), 1.0, torch.cuda.current_stream(dev).cuda_stream), "dm4d_adamw_message")
-        self.step_count += 1
 
     def state_dict(self):
         """The optimiser's own state: this rank's slice of the two moments (message layout), the steps applied and the pending decay
-        factors.  (The message layout is a function of the reducer's parameters and touched-index sets: a checkpoint resumes into a
-        stage constructed the same way.)"""
-        return {"exp_avg": self.exp_avg.clone(), "exp_avg_sq": self.exp_avg_sq.clone(),
-                "step": None if self.step_t is None else self.step_t.clone(),
-                "pending_decay": None if self.pending_decay is None else self.pending_decay.clone(),
-                "lr": [float(g["lr"]) for g in self.param_groups], "world": world(), "elements": int(self.reducer.flat.numel())}
+        factors per segment, the groups' hyperparameters.  (The message layout is a function of the reducer's parameters and
+        touched-index sets: a checkpoint resumes into a stage constructed the same way.)"""
+        return {"exp_avg": self.exp_avg.clone(), "exp_avg_sq": self.exp_avg_sq.clone(), "step": self.step_t.clone(),
+                "pending_decay": self.pending_decay.clone(), "decay_pending": bool(self._decay_pending), "step_count": int(self.step_count),
+                "hyper": self._hyper(), "world": world(), "elements": int(self.reducer.flat.numel()), "segments": len(self.reducer.params)}
 
     def load_state_dict(self, sd):
-        if int(sd["elements"]) != int(self.reducer.flat.numel()) or int(sd["world"]) != world() or tuple(sd["exp_avg"].shape) != tuple(self.exp_avg.shape):
+        if int(sd["elements"]) != int(self.reducer.flat.numel()) or int(sd["world"]) != world() or tuple(sd["exp_avg"].shape) != tuple(self.exp_avg.shape) \
+                or int(sd.get("segments", -1)) != len(self.reducer.params):
             raise ValueError("ShardedAdamW.load_state_dict: the state belongs to another message layout / world size")
         dev = self.exp_avg.device
-        self.exp_avg.copy_(sd["exp_avg"].to(dev))
-        self.exp_avg_sq.copy_(sd["exp_avg_sq"].to(dev))
-        self.step_t = None if sd["step"] is None else sd["step"].to(dev, torch.float64).clone()
-        self.pending_decay = None if sd["pending_decay"] is None else sd["pending_decay"].to(dev, torch.float64).clone()
-        for g, lr in zip(self.param_groups, sd["lr"]):
-            g["lr"] = lr
+        self.exp_avg = sd["exp_avg"].to(dev, torch.float32).clone()
+        self.exp_avg_sq = sd["exp_avg_sq"].to(dev, torch.float32).clone()
+        self.step_t = sd["step"].to(dev, torch.float64).clone()
+        self.pending_decay = sd["pending_decay"].to(dev, torch.float64).clone()
+        self._decay_pending = bool(sd.get("decay_pending", True))
+        self.step_count = int(sd.get("step_count", 0))
+        for g, (lr, b1, b2, eps, wd) in zip(self.param_groups, sd["hyper"]):
+            g["lr"], g["betas"], g["eps"], g["weight_decay"] = lr, (b1, b2), eps, wd
 
     def _unpack_message(self):
         red = self.reducer
+        if self.padded.is_cuda:
+            self._kernel_pack("dm4d_grad_unpack")
+            return
         for q, o, ix in zip(red.params, red.offsets, red.index):
             cnt = q.numel() if ix is None else ix.numel()
             seg = self.padded[o:o + cnt]
@@ -397,20 +499,18 @@ class ShardedAdamW:
     @torch.no_grad()
     def materialize(self):
         """Apply the deferred weight decay of the elements outside the message (see step()); afterwards every parameter
-        element equals what the replicated AdamW would hold.  Call before reading the parameters as a whole (checkpoints)."""
-        if self.pending_decay is None:
+        element equals what the replicated AdamW would hold.  Call before reading the parameters as a whole (checkpoints).
+        Nothing to do while no group has a weight decay (the reference's effective configuration of the geometry groups)."""
+        if not self._decay_pending:
             return
         red = self.reducer
-        sparse = {id(x) for x, ix in zip(red.params, red.index) if ix is not None}
-        any_ = False
-        # the touched elements carry their own (exact) values: taken from the PARAMETERS as they are now (a load_state_dict
-        # since the last step must not be overwritten by the stale message buffer), decayed with the rest, written back
-        self._pack_params()
-        for gi, g in enumerate(self.param_groups):
-            tensors = [q.data for q in g["params"] if id(q) in sparse]
-            if tensors:
-                torch._foreach_mul_(tensors, self.pending_decay[gi].to(torch.float32))      # one multi-tensor launch per group
-                any_ = True
-        if any_:
-            self._unpack_message()                     # the touched elements carry their own (exact) values
-        self.pending_decay = None
+        ks = [k for k, ix in enumerate(red.index) if ix is not None]
+        if ks:
+            # the touched elements carry their own (exact) values: taken from the PARAMETERS as they are now (a load_state_dict
+            # since the last step must not be overwritten by the stale message buffer), decayed with the rest, written back
+            self._pack_params()
+            factors = self.pending_decay.to(torch.float32)
+            torch._foreach_mul_([red.params[k].data for k in ks], [factors[k] for k in ks])       # one multi-tensor launch
+            self._unpack_message()
+        self.pending_decay = torch.ones_like(self.pending_decay)
+        self._decay_pending = False

@@ -5,7 +5,10 @@ Host-side restatement of the loop body of `SuGaR4DGen.training_step`
 per iteration), its batch (custom/threestudio-dreammesh4d/data/temporal_image.py:291-324: 4 of L frames,
 one reference view + `random_camera.batch_size` random views per frame), its loss weights
 (configs/sugar_dynamic_dg.yaml:135-158) and its optimiser (geometry/dynamic_sugar.py:167-235,
-geometry/sugar.py:406-416: AdamW, betas (0.9, 0.99), eps 1e-15, groups `deformation` 3.2e-4 / `grid` 3.2e-3).
+geometry/sugar.py:406-416: groups `deformation` 3.2e-4 / `grid` 3.2e-3 in an AdamW constructed with betas [0.9, 0.99],
+eps 1e-15 -- whose two groups EFFECTIVELY run betas (0.9, 0.999) and weight_decay 0, because training_setup_dynamic's
+Adam(l, lr=0, eps=1e-15) filled their dicts in place first and AdamW only fills what is missing:
+distributed.REFERENCE_GEOMETRY_GROUP; `optimizer_hyper=` overrides).
 
 What runs per iteration on each GPU:
   HexPlane+MLP at the step's 4 timestamps (1 fused launch) -> render_views for the 8 (frame, view) units
@@ -71,7 +74,7 @@ class DynamicStage:
     def __init__(self, renderer, net, nodes, static, timestamps, ref_images, ref_masks, ref_camera, guidance=None,
                  frames_per_step=4, random_views_per_frame=1, deformation_lr=0.00032, grid_lr=0.0032, seed=0,
                  normal_consistency=None, arap=None, milestone_arap_reg=100, inter_frame_reg=0, num_inter_frames=10,
-                 length_inter_frames=0.1, sharded_optimizer=None, lambdas=None):
+                 length_inter_frames=0.1, sharded_optimizer=None, lambdas=None, optimizer_hyper=None):
         self.r, self.net, self.nodes, self.static = renderer, net, nodes, static
         # loss weights: `system.loss` of the configuration (from_cfg), defaulting to the shipped sugar_dynamic_dg.yaml values
         self.lam = dict(LAMBDA)
@@ -95,9 +98,11 @@ class DynamicStage:
         self.frames_per_step, self.rv = frames_per_step, random_views_per_frame
         self.dev = nodes.device
         self.gen = torch.Generator(device="cpu").manual_seed(seed + 977 * D.rank())   # per-rank seed (launch.py:166)
+        hyper = dict(D.REFERENCE_GEOMETRY_GROUP)         # what the reference's two groups effectively run (module docstring)
+        hyper.update(optimizer_hyper or {})
         self.opt = torch.optim.AdamW([
-            {"params": net.get_mlp_parameters(), "lr": C(deformation_lr, 0, 0, interpolation="exp"), "name": "deformation"},
-            {"params": net.get_grid_parameters(), "lr": C(grid_lr, 0, 0, interpolation="exp"), "name": "grid"}],
+            {"params": net.get_mlp_parameters(), "lr": C(deformation_lr, 0, 0, interpolation="exp"), "name": "deformation", **hyper},
+            {"params": net.get_grid_parameters(), "lr": C(grid_lr, 0, 0, interpolation="exp"), "name": "grid", **hyper}],
             lr=0.0, betas=(0.9, 0.99), eps=1e-15, **({"fused": True} if self.dev.type == "cuda" else {}))   # one multi-tensor launch
         self.sched = {"deformation": deformation_lr, "grid": grid_lr}
         # The exchange: the structured-sparse message (touched texels + time planes + MLP: 13.5 MB instead of 143 MB at the
@@ -111,10 +116,12 @@ class DynamicStage:
             net.grads_in_place = True     # persistent HexPlane gradient planes: this loop drops its gradients every step
         else:
             self.reducer = D.GradAllReducer(net.parameters())
-        # (default: on for ONE process on a HIP device -- there the message-space step is two launches over the 3.4 M elements that can
-        # receive gradient, distributed.ShardedAdamW._step_fused, against 0.2 ms of dense AdamW over 35.76 M; off otherwise)
+        # (default: on for a HIP device, whatever the world size -- the message-space step is two launches over the 3.4 M elements
+        # that can receive gradient (csrc/gradpack.hip: dm4d_adamw_step) against 0.2 ms of dense AdamW over 35.76 M; with world > 1:
+        # pack -> reduce-scatter -> the same kernel on this rank's 1 / world slice -> all-gather -> unpack, SURVEY.md section 8e.
+        # Round 4 fell back to all-reduce + torch's dense fused AdamW when world > 1.  Off on CPU tensors; DM4D_MESSAGE_ADAMW=0.)
         if sharded_optimizer is None:
-            sharded_optimizer = self.dev.type == "cuda" and D.world() == 1 and os.environ.get("DM4D_MESSAGE_ADAMW", "1") != "0"
+            sharded_optimizer = self.dev.type == "cuda" and os.environ.get("DM4D_MESSAGE_ADAMW", "1") != "0"
         self.sharded_optimizer = bool(sharded_optimizer)
         self.sharded = D.ShardedAdamW(self.opt.param_groups, self.reducer, betas=(0.9, 0.99), eps=1e-15) if self.sharded_optimizer else None
         if self.sharded is not None and hasattr(net, "register_state_dict_pre_hook"):
@@ -240,7 +247,7 @@ class DynamicStage:
         # views of the same frame share its skinning / face transform (reference: cached per timestamp within a step)
         step = self._step_object(int(b["vm"].shape[0]), len(b["frames"]))
         if step is not None:
-            # node network + render_views as ONE C call each way on persistent buffers (step.py: the same kernels, bit-identical)
+            # node network + render_views as ONE C call each way on persistent buffers (step.py: the same kernels; bit-identical for the same fuse_face_backward setting)
             out = step(frames_t.to(torch.float32).contiguous(), b["vm"].contiguous(), b["pm"].contiguous(), u)
         else:
             dx, dr, ds, do = self.net.node_outputs(self.nodes, frames_t)
@@ -306,7 +313,7 @@ class DynamicStage:
                 D.all_reduce_max(flag)
         if self.sharded_optimizer:
             for gs, go in zip(self.sharded.param_groups, self.opt.param_groups):
-                gs["lr"] = go["lr"]
+                gs.update({k: go[k] for k in ("lr", "betas", "eps", "weight_decay") if k in go})
             self.sharded.step(found_inf=flag)         # the exchange (reduce-scatter / all-gather) is inside
         else:
             self.reducer()                  # the one exchange step (no-op for a single process)
@@ -336,6 +343,24 @@ class DynamicStage:
         if self.sharded is not None:
             self.sharded.materialize()
         return self.net.state_dict()
+
+    def optimizer_state_dict(self):
+        """What a checkpoint's ``optimizer_states`` entry holds for this stage: the optimiser that actually STEPS.  With the
+        message-space optimiser that is ``ShardedAdamW.state_dict()`` (this rank's slice of the moments, the per-segment step counters
+        and pending decay) -- ``self.opt``, the torch AdamW a host would save by default, never steps then and its state is empty."""
+        if self.sharded is not None:
+            return {"kind": "dm4d.ShardedAdamW", "state": self.sharded.state_dict(), "global_step": int(self.global_step), "rng_state": self.gen.get_state()}
+        return {"kind": "torch.optim.AdamW", "state": self.opt.state_dict(), "global_step": int(self.global_step), "rng_state": self.gen.get_state()}
+
+    def load_optimizer_state_dict(self, sd):
+        """Resume: the moments, step counters (bias corrections) and the iteration count continue where the checkpoint left them."""
+        kind = "dm4d.ShardedAdamW" if self.sharded is not None else "torch.optim.AdamW"
+        if sd.get("kind") != kind:
+            raise ValueError(f"the checkpoint's optimiser state is a {sd.get('kind')}, this stage steps a {kind}")
+        (self.sharded if self.sharded is not None else self.opt).load_state_dict(sd["state"])
+        self.global_step = int(sd.get("global_step", self.global_step))
+        if sd.get("rng_state") is not None:          # the batch sampler's generator: the resumed run draws the frames / cameras the uninterrupted one would
+            self.gen.set_state(sd["rng_state"].cpu())
 
     @classmethod
     def from_cfg(cls, system_cfg, renderer, net, nodes, static, timestamps, ref_images, ref_masks, ref_camera, **kw):

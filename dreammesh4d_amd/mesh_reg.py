@@ -149,10 +149,10 @@ class _NormalConsistency(torch.autograd.Function):
         gx = torch.empty_like(x)
         roles = torch.empty(T, max(nc.n_pairs, 1), 12, dtype=torch.float32, device=dev)      # the pairs' per-vertex gradient vectors
         with torch.cuda.device(dev):
-            _lib.check(L.dm4d_normal_consistency_backward(T, nc.n_verts, nc.n_pairs, nc._pairs.data_ptr(), nc._off.data_ptr(),
+            _lib.check(L.dm4d_normal_consistency_backward_scratch(T, nc.n_verts, nc.n_pairs, nc._pairs.data_ptr(), nc._off.data_ptr(),
                                                           nc._items.data_ptr(), x.data_ptr(), g.data_ptr(), gx.data_ptr(),
                                                           roles.data_ptr(), torch.cuda.current_stream(dev).cuda_stream),
-                       "dm4d_normal_consistency_backward")
+                       "dm4d_normal_consistency_backward_scratch")
         return None, gx
 
 

@@ -1,7 +1,8 @@
 """One static-stage (SuGaR refinement) training iteration: host-side restatement of ``SuGaRStatic.training_step``
 (custom/threestudio-dreammesh4d/system/sugar_static.py:110-340, stage "sugar") with the loss weights of
-configs/sugar_static_refine.yaml:105-133 and the optimiser of geometry/sugar.py:329-416 (AdamW, betas (0.9, 0.99),
-eps 1e-15; groups points / f_dc / f_rest / all_densities / scales / quaternions).
+configs/sugar_static_refine.yaml:105-133 and the optimiser of geometry/sugar.py:329-416 (an AdamW constructed with betas
+[0.9, 0.99], eps 1e-15 whose groups points / f_dc / f_rest / all_densities / scales / quaternions effectively run betas
+(0.9, 0.999) without weight decay: sugar.SuGaR.merge_optimizer).
 
 Per iteration: a reference substep -- the reference view, rgb and mask MSE against the input image (:151-160) -- and a
 random substep -- `random_camera.batch_size` views (elev U[-10,80], azim U[-180,180], dist 3.8, fovy 20 deg; yaml:21-28):
@@ -56,6 +57,8 @@ class StaticStage:
         # (same per-element arithmetic, tests/test_adamw_gpu.py; message_adamw=False / DM4D_MESSAGE_ADAMW=0: torch's)
         if message_adamw is None:
             message_adamw = self.dev.type == "cuda" and D.world() == 1 and os.environ.get("DM4D_MESSAGE_ADAMW", "1") != "0"
+        # (betas / eps / weight_decay PER GROUP, from the optimiser's own groups: geometry.merge_optimizer keeps the reference's effective
+        #  mix -- geometry groups (0.9, 0.999) / no decay, appended groups (0.9, 0.99) / 0.01)
         self.sharded = D.ShardedAdamW(self.opt.param_groups, self.reducer, betas=(0.9, 0.99), eps=1e-15) if message_adamw else None
         self.ref_cam = syn.make_camera(H, W, elev_deg=5.0, azim_deg=0.0)                # yaml:11-14
         self.global_step = 0
@@ -159,7 +162,7 @@ class StaticStage:
             self.opt.found_inf, self.opt.grad_scale = flag, None
         if self.sharded is not None:
             for gs, go in zip(self.sharded.param_groups, self.opt.param_groups):
-                gs["lr"] = go["lr"]
+                gs.update({k: go[k] for k in ("lr", "betas", "eps", "weight_decay") if k in go})
             self.sharded.step(found_inf=flag if (vr is not None and vr.last is not None) else None)
         else:
             self.opt.step()
@@ -176,6 +179,28 @@ class StaticStage:
                 self.overflow_skipped += 1
                 terms["overflow_skipped"] = torch.tensor(float(self.overflow_skipped))
         return {"loss": loss.detach(), **terms}
+
+    def state_for_checkpoint(self):
+        """The geometry's parameters as a replicated optimiser would hold them (any deferred weight decay applied)."""
+        if self.sharded is not None:
+            self.sharded.materialize()
+        return self.g.state_dict()
+
+    def optimizer_state_dict(self):
+        """The state of the optimiser that actually steps (DynamicStage.optimizer_state_dict: with the message-space optimiser
+        ``self.opt`` never steps and a host saving ITS state would save nothing)."""
+        if self.sharded is not None:
+            return {"kind": "dm4d.ShardedAdamW", "state": self.sharded.state_dict(), "global_step": int(self.global_step), "rng_state": self.gen.get_state()}
+        return {"kind": "torch.optim.AdamW", "state": self.opt.state_dict(), "global_step": int(self.global_step), "rng_state": self.gen.get_state()}
+
+    def load_optimizer_state_dict(self, sd):
+        kind = "dm4d.ShardedAdamW" if self.sharded is not None else "torch.optim.AdamW"
+        if sd.get("kind") != kind:
+            raise ValueError(f"the checkpoint's optimiser state is a {sd.get('kind')}, this stage steps a {kind}")
+        (self.sharded if self.sharded is not None else self.opt).load_state_dict(sd["state"])
+        self.global_step = int(sd.get("global_step", self.global_step))
+        if sd.get("rng_state") is not None:          # the batch sampler's generator: the resumed run draws the frames / cameras the uninterrupted one would
+            self.gen.set_state(sd["rng_state"].cpu())
 
     @classmethod
     def from_cfg(cls, system_cfg, geometry, renderer, ref_image, ref_mask, H, W, **kw):

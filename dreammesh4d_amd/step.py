@@ -17,7 +17,11 @@ host needs 0.76-0.88 ms to ENQUEUE that (two autograd Functions, ~60 tensor allo
 
 It covers the dynamic stage as shipped: static appearance frozen (``static_learnable: false``, dynamic_sugar.py:79-87), the fused
 64-wide deformation MLP, deterministic (Gaussian, cell) records.  Results are bit-identical to ``node_outputs`` +
-``render_views`` (the same kernels in the same order; tests/test_step_gpu.py)."""
+``render_views`` FOR THE SAME ``renderer.fuse_face_backward`` SETTING (the same kernels in the same order; tests/test_step_gpu.py).
+With ``fuse_face_backward`` on (``DynamicStage`` and ``bench.py`` switch it on) BOTH paths run csrc/gather_face.hip, whose per-view
+corner records are summed by the vertex kernel in another order than the two-kernel path adds the per-view Gaussian gradients: the
+images are still bit-identical, the parameter gradients equal the two-kernel path's up to the order of those additions (2e-6 of
+the tensor's scale, tests/test_views_gpu.py, tests/test_step_gpu.py)."""
 import ctypes as C
 
 import torch

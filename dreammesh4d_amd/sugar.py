@@ -249,9 +249,20 @@ class DynamicSuGaR(nn.Module):
         self.optimizer = torch.optim.Adam(self.optimize_list, lr=0.0, eps=1e-15)
 
     def merge_optimizer(self, net_optimizer):
-        """AdamW over the geometry's groups + the system's groups (sugar.py:406-416)."""
-        groups = list(self.optimize_list) + (list(net_optimizer.param_groups) if net_optimizer is not None else [])
-        self.optimizer = torch.optim.AdamW(groups, lr=0.0, betas=(0.9, 0.99), eps=1e-15)
+        """sugar.py:406-416.  The reference appends the other modules' groups to ``optimize_list`` and builds
+        ``AdamW(l, lr=0.0, betas=[0.9, 0.99], eps=1e-15)`` -- but ``training_setup``'s ``Adam(l, lr=0.0, eps=1e-15)`` (:382) has already
+        filled the dicts of ``optimize_list`` IN PLACE with Adam's defaults, and AdamW only fills what is missing: the geometry groups
+        effectively run betas (0.9, 0.999) and weight_decay 0, only the appended groups get (0.9, 0.99) / 0.01.  That effective
+        behaviour is kept: betas / eps / weight_decay / amsgrad / maximize are carried over from the Adam-filled dicts; the
+        implementation switches Adam left there (fused / foreach / capturable / differentiable: None / False, which would pin the
+        slow path) are not."""
+        keep = ("lr", "name", "betas", "eps", "weight_decay", "amsgrad", "maximize")
+        groups = [{"params": g["params"], **{k: g[k] for k in keep if k in g}} for g in self.optimize_list] + \
+            ([{"params": g["params"], "lr": g["lr"]} for g in net_optimizer.param_groups] if net_optimizer is not None else [])
+        # (on a HIP device the fused implementation: one multi-tensor launch, and it honours `found_inf` -- the training loop skips
+        # the step on the device when the batched renderer overflowed a capacity, static_stage.StaticStage.iteration)
+        fused = {"fused": True} if all(p.is_cuda for g in groups for p in g["params"]) and len(groups) > 0 else {}
+        self.optimizer = torch.optim.AdamW(groups, lr=0.0, betas=(0.9, 0.99), eps=1e-15, **fused)
         return self.optimizer
 
     def update_learning_rate(self, iteration):
@@ -502,8 +513,10 @@ class SuGaR(nn.Module):
         self.color_clip = C(self._color_clip_cfg, 0, iteration)                                   # sugar.py:404
 
     def merge_optimizer(self, net_optimizer):
-        # (fresh dicts: training_setup's Adam filled the ones of optimize_list with ITS defaults -- "fused": None among them -- in place)
-        groups = [{"params": g["params"], "lr": g["lr"], "name": g["name"]} for g in self.optimize_list] + \
+        """sugar.py:406-416 with the reference's EFFECTIVE per-group hyperparameters (see DynamicSuGaR.merge_optimizer: training_setup's
+        Adam fills the dicts of optimize_list in place -- betas (0.9, 0.999), weight_decay 0 -- and AdamW only fills what is missing)."""
+        keep = ("lr", "name", "betas", "eps", "weight_decay", "amsgrad", "maximize")
+        groups = [{"params": g["params"], **{k: g[k] for k in keep if k in g}} for g in self.optimize_list] + \
             ([{"params": g["params"], "lr": g["lr"]} for g in net_optimizer.param_groups] if net_optimizer is not None else [])
         # (on a HIP device the fused implementation: one multi-tensor launch, and it honours `found_inf` -- the training loop skips
         # the step on the device when the batched renderer overflowed a capacity, static_stage.StaticStage.iteration)

@@ -191,16 +191,30 @@ def load_module_weights(path, module_name=None, ignore_modules=None, map_locatio
     return sd, ckpt["epoch"], ckpt["global_step"]
 
 
-def save_checkpoint(path, modules, epoch=0, global_step=0):
+def save_checkpoint(path, modules, epoch=0, global_step=0, optimizer_states=None):
     """The inverse: ``{"state_dict": {"<name>.<key>": tensor}, "epoch", "global_step"}`` for ``modules`` =
-    {"geometry": nn.Module, ...}, so the reference's ``system.weights`` can load what this package trained."""
+    {"geometry": nn.Module, ...}, so the reference's ``system.weights`` can load what this package trained.
+    ``optimizer_states`` (optional): a list like Lightning's checkpoint key of that name -- here the stages'
+    ``optimizer_state_dict()`` (the state of the optimiser that actually steps), restored by ``load_optimizer_states``."""
     import torch
 
     sd = {}
     for name, m in modules.items():
         for k, v in m.state_dict().items():
             sd[f"{name}.{k}"] = v.detach().cpu().contiguous()      # plain contiguous tensors (the planes are channels_last here)
-    torch.save({"state_dict": sd, "epoch": int(epoch), "global_step": int(global_step)}, path)
+    ckpt = {"state_dict": sd, "epoch": int(epoch), "global_step": int(global_step)}
+    if optimizer_states is not None:
+        to_cpu = lambda o: o.detach().cpu() if torch.is_tensor(o) else ({k: to_cpu(v) for k, v in o.items()} if isinstance(o, dict) else
+                                                                      ([to_cpu(v) for v in o] if isinstance(o, (list, tuple)) else o))
+        ckpt["optimizer_states"] = [to_cpu(o) for o in optimizer_states]
+    torch.save(ckpt, path)
+
+
+def load_optimizer_states(path, map_location="cpu"):
+    """The ``optimizer_states`` list of a checkpoint written by ``save_checkpoint`` ([] when it has none)."""
+    import torch
+
+    return list(torch.load(path, map_location=map_location, weights_only=False).get("optimizer_states", []))
 
 
 def load_geometry(geometry, path, strict=False):

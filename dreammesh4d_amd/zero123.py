@@ -973,6 +973,15 @@ class TemporalStableZero123Guidance(nn.Module):
             st.latents = torch.zeros_like(st.noise)
             if not (self.c_concat.is_contiguous() and self.alphas.dtype == torch.float32 and tuple(self.c_concat.shape[1:]) == (4, 32, 32)):
                 raise ValueError("fused SDS glue: c_concat must be a contiguous [L,4,32,32] tensor")
+            # the two glue kernels read c_concat[fidx] and alphas[t] through raw pointers inside a captured graph, where an out-of-range
+            # index or a buffer left on the host is a silent out-of-bounds read or a GPU fault (the torch indexing they replace would
+            # raise): the buffers are pinned to the step's device here, the indices are validated on the host in _stage_inputs
+            for name, buf in (("alphas", self.alphas), ("c_concat", self.c_concat)):
+                if buf.device != torch.device(dev) or not buf.is_contiguous():
+                    raise ValueError(f"fused SDS glue: `{name}` must be a contiguous tensor on {dev} (it is on {buf.device}); move the guidance with .to(device)")
+            if self.alphas.numel() < self.max_step + 1:
+                raise ValueError(f"fused SDS glue: the noise schedule has {self.alphas.numel()} entries, max_step is {self.max_step}")
+            st.glue_ptrs = (self.alphas.data_ptr(), self.c_concat.data_ptr(), int(self.c_concat.shape[0]), int(self.alphas.numel()))
 
         # The part of the UNet that does not depend on the latents -- camera embedding -> cc_projection, timestep embedding, the batched
         # M = batch GEMMs of every ResBlock / cross-attention (UNetModel.precompute): ~25 launch-bound kernels, ~0.2 ms -- as its OWN small
@@ -1025,6 +1034,22 @@ class TemporalStableZero123Guidance(nn.Module):
         if key not in self._sds_graphs:
             self._sds_graphs[key] = self._sds_graph(B, dev, clip is not None)
         st = self._sds_graphs[key]
+        if st.fused_glue:
+            # what the captured glue kernels will index with, checked where torch's indexing would have raised: host inputs by value,
+            # the schedule bounds always (device-resident indices cannot be checked without a synchronisation: the caller's contract)
+            n_frames, n_alpha = int(self.c_concat.shape[0]), int(self.alphas.numel())
+            if (self.alphas.data_ptr(), self.c_concat.data_ptr(), n_frames, n_alpha) != st.glue_ptrs:
+                raise RuntimeError("the guidance's `alphas` / `c_concat` buffers were replaced after the SDS step was captured (their "
+                                   "addresses are constants of the graph): clear `_sds_graphs` after moving or reloading the guidance")
+            if not (0 <= self.min_step <= self.max_step < n_alpha):
+                raise ValueError(f"timestep range [{self.min_step}, {self.max_step}] outside the noise schedule's {n_alpha} entries")
+            if frame_indices is not None and frame_indices.device.type == "cpu" and frame_indices.numel() and \
+                    not (0 <= int(frame_indices.min()) and int(frame_indices.max()) < n_frames):
+                raise IndexError(f"frame_indices {frame_indices.tolist()} outside the {n_frames} conditioning frames")
+            if frame_indices is not None and int(frame_indices.numel()) != B:
+                raise ValueError(f"{int(frame_indices.numel())} frame indices for {B} views")
+            if t is not None and t.device.type == "cpu" and t.numel() and not (0 <= int(t.min()) and int(t.max()) < n_alpha):
+                raise IndexError(f"timesteps {t.tolist()} outside the noise schedule's {n_alpha} entries")
         cur = torch.cuda.current_stream(dev)
         with torch.no_grad():
             on_side = st.pre_graph is not None

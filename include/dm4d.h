@@ -42,6 +42,10 @@ extern "C" {
 
 typedef void *dm4d_stream_t;   /* hipStream_t */
 
+/* ABI version = 100 * major + round.  A binding built against this header checks dm4d_version() == DM4D_ABI_VERSION when it loads the
+ * library (dreammesh4d_amd/_lib.py does).  Entry points are never changed in place from round 5 on: a new argument is a new symbol
+ * (dm4d_adamw_step beside dm4d_adamw_message, dm4d_normal_consistency_backward_scratch beside dm4d_normal_consistency_backward). */
+#define DM4D_ABI_VERSION 105
 int dm4d_version(void);
 const char *dm4d_last_error(void);
 /* Number of HIP devices visible / name of device `dev` (host helpers for the loader). */
@@ -514,9 +518,15 @@ int dm4d_quat_to_matrix_backward_pypose(int64_t n, const float *matrices, const 
  * floats, 16-byte aligned (the four vertices' gradient vectors of every pair, evaluated once per pair, then gathered). */
 int dm4d_normal_consistency_forward(int32_t T, int32_t V, int32_t P, const int32_t *pairs, const float *xyz, float *terms,
                                     dm4d_stream_t stream);
+int dm4d_normal_consistency_backward_scratch(int32_t T, int32_t V, int32_t P, const int32_t *pairs, const int32_t *vert_offsets,
+                                             const int32_t *vert_items, const float *xyz, const float *g_loss, float *g_xyz,
+                                             float *scratch, dm4d_stream_t stream);
+/* The signature of rounds 1-3 (no scratch argument), kept for callers built against it: the same two kernels on a scratch the
+ * LIBRARY owns (grown with hipMalloc when a larger T P is seen, one per process, calls serialised on it by stream order only --
+ * callers with several streams use the _scratch form).  Round 4 had inserted `scratch` before `stream` in place. */
 int dm4d_normal_consistency_backward(int32_t T, int32_t V, int32_t P, const int32_t *pairs, const int32_t *vert_offsets,
                                      const int32_t *vert_items, const float *xyz, const float *g_loss, float *g_xyz,
-                                     float *scratch, dm4d_stream_t stream);
+                                     dm4d_stream_t stream);
 
 /* pytorch3d.loss.mesh_laplacian_smoothing(meshes, method="uniform") of T meshes of one topology (static stage lambda 1,
  * C/configs/sugar_static_refine.yaml:122, C/system/sugar_static.py:246-254; dynamic stage C/system/sugar_4dgen.py:227-230):
@@ -580,6 +590,33 @@ typedef struct dm4d_adamw_args {
     float *scratch;
 } dm4d_adamw_args;
 int dm4d_adamw_message(const dm4d_grad_segments *segments, const dm4d_adamw_args *a, float grad_scale, dm4d_stream_t stream);
+
+/* Round 5: the same step with the hyperparameters PER GROUP and the optimiser's bookkeeping PER SEGMENT (dm4d_adamw_message stays
+ * as it is for callers built against it).  Why per group: the reference's optimiser does not run one set of hyperparameters --
+ * training_setup's Adam(l, lr=0, eps=1e-15) fills the group dicts of optimize_list in place (betas (0.9, 0.999), weight_decay 0) and
+ * merge_optimizer's AdamW(l, betas=[0.9, 0.99], eps=1e-15) only fills what is missing, so the geometry / deformation groups run
+ * beta2 = 0.999 without decay and only groups appended later get (0.9, 0.99) / 0.01 (C/geometry/sugar.py:382,406-416,
+ * C/geometry/dynamic_sugar.py:231-235).
+ *   skip[k] != 0: no gradient reached segment k -- torch.optim skips such a parameter entirely (nothing written, step[k] kept);
+ *   step, pending_decay: [n_segments] float64 on the device (zeros / ones before the first step);
+ *   grad_in_message[k] != 0: segments->grad[k] is already in MESSAGE layout (this rank's reduce-scattered slice: read at [i]) and
+ *     index[k] addresses only the parameter; param_out[k] (optional): the updated values also in message layout (the all-gather's
+ *     send slice) -- the sharded data-parallel step as pack, reduce-scatter, THIS, all-gather, unpack;
+ *   scratch: 1 + 2 * DM4D_MAX_GRAD_SEGMENTS floats.  Two launches. */
+typedef struct dm4d_adamw_step_args {
+    int32_t n_groups;
+    float lr[8], beta1[8], beta2[8], eps[8], weight_decay[8];
+    int32_t group[DM4D_MAX_GRAD_SEGMENTS];
+    float *param[DM4D_MAX_GRAD_SEGMENTS];
+    float *param_out[DM4D_MAX_GRAD_SEGMENTS];
+    uint8_t grad_in_message[DM4D_MAX_GRAD_SEGMENTS];
+    uint8_t skip[DM4D_MAX_GRAD_SEGMENTS];
+    float *exp_avg, *exp_avg_sq;
+    double *step, *pending_decay;
+    const float *found_inf;
+    float *scratch;
+} dm4d_adamw_step_args;
+int dm4d_adamw_step(const dm4d_grad_segments *segments, const dm4d_adamw_step_args *a, float grad_scale, dm4d_stream_t stream);
 
 /* ------------------------------------------------------------------ batched views (the fast path) */
 

@@ -152,3 +152,97 @@ def test_sharded_adamw_matches_the_replicated_step_world2():
         assert torch.allclose(ps, pr, rtol=1e-6, atol=1e-7), (ps - pr).abs().max()
     assert not torch.equal(a["replicated"][-1], torch.zeros_like(a["replicated"][-1]))
     assert a["state_elems"] == (a["message"] + 1) // 2                        # each rank holds half of the moments
+
+
+def _worker_sharded_mixed(rank, world, port, out):
+    """As _worker_sharded, with the reference's EFFECTIVE mix of hyperparameters: the group training_setup created runs betas
+    (0.9, 0.999) without decay (distributed.REFERENCE_GEOMETRY_GROUP), the appended group AdamW's (0.9, 0.99) / 0.01."""
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    idx = torch.tensor([3, 17, 18, 64, 119])
+    results = {}
+    for mode in ("replicated", "sharded"):
+        torch.manual_seed(0)
+        grid = torch.nn.Parameter(torch.randn(1, 4, 5, 6))
+        mlp = torch.nn.Linear(6, 3)
+        groups = [{"params": list(mlp.parameters()), "lr": 3.2e-4, "name": "deformation", **D.REFERENCE_GEOMETRY_GROUP},
+                  {"params": [grid], "lr": 3.2e-3, "name": "appended", "weight_decay": 0.05, "eps": 1e-8}]
+        params = list(mlp.parameters()) + [grid]
+        red = D.GradAllReducer(params, touched={grid: idx})
+        opt = torch.optim.AdamW(groups, lr=0.0, betas=(0.9, 0.99), eps=1e-15, foreach=False) if mode == "replicated" else \
+            D.ShardedAdamW(groups, red, betas=(0.9, 0.99), eps=1e-15)
+        for it in range(5):
+            opt.zero_grad(set_to_none=True)
+            x = torch.full((2, 6), float(rank + 1 + it))
+            (mlp(x).pow(2).sum() + (grid.view(-1)[idx] * float(rank + 2)).pow(2).sum()).backward()
+            if mode == "replicated":
+                red()
+            opt.step()
+        if mode == "sharded":
+            assert opt.param_groups[0]["betas"] == (0.9, 0.999) and opt.param_groups[0]["weight_decay"] == 0.0
+            opt.materialize()
+        results[mode] = [p.detach().clone() for p in params]
+    out[rank] = results
+    dist.destroy_process_group()
+
+
+def test_sharded_adamw_per_group_hyperparameters_world2():
+    world = 2
+    out = mp.Manager().dict()
+    mp.spawn(_worker_sharded_mixed, args=(world, _free_port(), out), nprocs=world, join=True)
+    a, b = out[0], out[1]
+    for pa, pb in zip(a["sharded"], b["sharded"]):
+        assert torch.equal(pa, pb)
+    for ps, pr in zip(a["sharded"], a["replicated"]):
+        assert torch.allclose(ps, pr, rtol=1e-6, atol=1e-7), (ps - pr).abs().max()
+
+
+def test_parameter_without_gradient_is_skipped_like_torch_skips_it():
+    """One process: a parameter whose .grad is None takes NO step in torch.optim (no weight decay, no moment decay, its step counter
+    stays) -- round 4's message-space step treated it as a zero gradient.  Three steps, the second without a gradient on `b`."""
+    runs = {}
+    for mode in ("torch", "message"):
+        torch.manual_seed(1)
+        a, b = torch.nn.Parameter(torch.randn(7)), torch.nn.Parameter(torch.randn(5))
+        groups = [{"params": [a], "lr": 1e-2, **D.REFERENCE_GEOMETRY_GROUP}, {"params": [b], "lr": 2e-2, "weight_decay": 0.1}]
+        opt = torch.optim.AdamW(groups, lr=0.0, betas=(0.9, 0.99), eps=1e-15, foreach=False) if mode == "torch" else \
+            D.ShardedAdamW(groups, D.GradAllReducer([a, b]), betas=(0.9, 0.99), eps=1e-15)
+        g = torch.Generator().manual_seed(5)
+        for it in range(3):
+            a.grad = torch.randn(7, generator=g)
+            gb = torch.randn(5, generator=g)
+            b.grad = None if it == 1 else gb
+            opt.step()
+        if mode == "message":
+            assert opt.step_t.tolist() == [3.0, 2.0]
+            opt.materialize()
+        runs[mode] = (a.detach().clone(), b.detach().clone())
+    for x, y in zip(runs["torch"], runs["message"]):
+        assert torch.allclose(x, y, rtol=1e-6, atol=1e-7), (x - y).abs().max()
+
+
+def test_merge_optimizer_keeps_the_reference_effective_hyperparameters():
+    """geometry/sugar.py:382,406-416: Adam(l, lr=0, eps=1e-15) fills the group dicts in place, AdamW(l, betas=[0.9, 0.99], eps=1e-15) only
+    fills what is missing -- the geometry groups run betas (0.9, 0.999) WITHOUT weight decay, appended groups (0.9, 0.99) / 0.01.
+    (Round 4 built fresh dicts and so trained the geometry with beta2 = 0.99 and weight_decay = 0.01.)"""
+    import numpy as np
+
+    from dreammesh4d_amd import sugar, synthetic as syn
+
+    sc = syn.mesh_bound_scene(60, n_nodes=8, k=4, seed=0)
+    g = sugar.SuGaR(sc["verts"], sc["faces"], vertex_colors=np.random.default_rng(0).random((len(sc["verts"]), 3)), device=torch.device("cpu"))
+    extra = torch.nn.Linear(3, 3)
+    opt = g.merge_optimizer(torch.optim.SGD([{"params": list(extra.parameters()), "lr": 0.01}], lr=0.0))
+    named = [q for q in opt.param_groups if "name" in q]
+    assert {q["name"] for q in named} >= {"points", "f_dc", "all_densities", "scales", "quaternions"}
+    for q in named:
+        assert tuple(q["betas"]) == (0.9, 0.999) and q["weight_decay"] == 0 and q["eps"] == 1e-15, q["name"]
+    tail = [q for q in opt.param_groups if "name" not in q]
+    assert len(tail) == 1 and tuple(tail[0]["betas"]) == (0.9, 0.99) and tail[0]["weight_decay"] == 0.01 and tail[0]["eps"] == 1e-15
+    # the in-place behaviour itself, as torch has it (what the reference relies on without saying so)
+    p = torch.nn.Parameter(torch.zeros(2))
+    l = [{"params": [p], "lr": 0.1, "name": "x"}]
+    torch.optim.Adam(l, lr=0.0, eps=1e-15)
+    o = torch.optim.AdamW(l, lr=0.0, betas=[0.9, 0.99], eps=1e-15)
+    assert tuple(o.param_groups[0]["betas"]) == (0.9, 0.999) and o.param_groups[0]["weight_decay"] == 0
+    assert D.REFERENCE_GEOMETRY_GROUP == {"betas": (0.9, 0.999), "eps": 1e-15, "weight_decay": 0.0}

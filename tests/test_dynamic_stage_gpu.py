@@ -77,6 +77,9 @@ def test_iteration_fits_reference_frames():
     stage.r.check()
     assert stage.global_step == 40
     assert {g["name"] for g in stage.opt.param_groups} == {"deformation", "grid"}
+    # the reference's EFFECTIVE hyperparameters of these two groups (training_setup_dynamic's Adam fills the dicts in place)
+    assert all(tuple(g["betas"]) == (0.9, 0.999) and g["weight_decay"] == 0.0 and g["eps"] == 1e-15 for g in stage.opt.param_groups)
+    assert all(tuple(g["betas"]) == (0.9, 0.999) and g["weight_decay"] == 0.0 for g in stage.sharded.param_groups)
 
 
 def test_iteration_with_zero123_sds_runs_and_updates_the_network():
@@ -96,6 +99,47 @@ def test_iteration_with_zero123_sds_runs_and_updates_the_network():
     after = stage.net.get_mlp_parameters()
     assert any(not torch.equal(a, b) for a, b in zip(after, before))
     assert stage.guidance.max_step == 500 and stage.guidance.min_step == 20      # yaml:118-119 (0.02 / 0.5)
+
+
+def test_checkpoint_resume_continues_the_optimiser(tmp_path):
+    """the optimiser that STEPS on a HIP device is the message-space one; `stage.opt` (what a host would save by default)
+    never steps.  save_checkpoint(..., optimizer_states=[stage.optimizer_state_dict()]) + load into a freshly built stage: the third
+    iteration of the resumed run is bit-identical to the uninterrupted run's (moments, per-segment step counters = bias corrections,
+    iteration count = schedules, sampler state); without the optimiser state it is not."""
+    _need_gpu()
+    from dreammesh4d_amd import wire_formats as wf
+
+    dev = torch.device("cuda:0")
+    a = _build(dev, with_guidance=False)
+    assert a.sharded is not None and len(a.opt.state_dict()["state"]) == 0
+    for _ in range(3):
+        a.iteration()
+    want = [p.detach().clone() for p in a.net.parameters()]
+    b = _build(dev, with_guidance=False)
+    for _ in range(2):
+        b.iteration()
+    b.state_for_checkpoint()
+    path = str(tmp_path / "dyn.ckpt")
+    wf.save_checkpoint(path, {"geometry._deformation": b.net}, global_step=b.global_step, optimizer_states=[b.optimizer_state_dict()])
+    assert len(b.opt.state_dict()["state"]) == 0          # the torch optimiser indeed holds nothing
+    got = {}
+    for with_state in (True, False):
+        c = _build(dev, with_guidance=False)
+        sd, _, step = wf.load_module_weights(path, module_name="geometry._deformation")
+        c.net.load_state_dict(sd, strict=True)
+        if with_state:
+            (osd,) = wf.load_optimizer_states(path)
+            c.load_optimizer_state_dict(osd)
+            assert c.global_step == 2 and c.sharded.step_t.tolist() == b.sharded.step_t.tolist()
+        else:
+            c.global_step = step
+            c.gen.set_state(b.gen.get_state())
+        c.iteration()
+        got[with_state] = [p.detach().clone() for p in c.net.parameters()]
+    assert all(torch.equal(x, y) for x, y in zip(want, got[True]))
+    assert not all(torch.equal(x, y) for x, y in zip(want, got[False]))
+    with pytest.raises(ValueError):
+        c.load_optimizer_state_dict({"kind": "torch.optim.AdamW", "state": {}})
 
 
 def _torchrun(args, env=None, timeout=600, nproc=2):
