@@ -230,12 +230,14 @@ _SIGNATURES = {
     "dm4d_gviews_forward": (C.c_int, [C.POINTER(GViewsStruct), vp]),
     "dm4d_gviews_backward": (C.c_int, [C.POINTER(GViewsStruct), C.POINTER(GViewsGrads), vp]),
     "dm4d_views_backward": (C.c_int, [C.POINTER(ViewsStruct), C.POINTER(ViewsGrads), vp]),
+    "dm4d_views_backward_rgb": (C.c_int, [C.POINTER(ViewsStruct), C.POINTER(ViewsGrads), vp]),
     "dm4d_views_counters": (C.c_int, [C.POINTER(ViewsStruct), C.POINTER(C.c_int64), C.POINTER(C.c_int64),
                                       C.POINTER(C.c_int32), vp]),
     "dm4d_step_create": (C.c_int, [C.POINTER(StepDesc), C.POINTER(vp)]),
     "dm4d_step_destroy": (None, [vp]),
     "dm4d_step_forward": (C.c_int, [vp] * 6),
     "dm4d_step_backward": (C.c_int, [vp] * 7),
+    "dm4d_step_backward_rgb": (C.c_int, [vp] * 6),
     "dm4d_step_views": (vp, [vp]),
 }
 

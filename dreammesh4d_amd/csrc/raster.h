@@ -40,7 +40,7 @@ constexpr int kCells = 16;       // 4x4-pixel cells per 16x16 tile; cell id = 4 
 // (mean2D 2 | conic 3 | depth | colour channels 3..5) instead of 13 (+ opacity, colour channels 0..2); lean = 2: the same
 // WITHOUT a depth gradient (dL_ddepth == NULL: the shipped dynamic configuration has no depth loss,
 // configs/sugar_dynamic_dg.yaml:142-154) -- 8 values = 32 bytes, two 16-byte pieces per record instead of three.
-DM4D_HD static inline int grad_stride(int C, int lean = 0) { return lean == 2 ? 8 : (C <= 3 || lean) ? 12 : 16; }
+DM4D_HD static inline int grad_stride(int C, int lean = 0) { return lean >= 2 ? 8 : (C <= 3 || lean) ? 12 : 16; }
 
 // counters[]: duplicates, duplicate-capacity overflow, records (sum of the Gaussians' cells), record-capacity overflow
 // kCntLong: number of LONG cells (cell lists of >= kLongCell entries, K4 appends them to `longlist`)
@@ -364,7 +364,7 @@ struct BatchDesc {
     float *out_color, *out_depth, *out_alpha;
     const float *dL_dcolor, *dL_ddepth, *dL_dalpha;
     float *dLq; size_t dlq_stride; uint32_t rec_cap;   // backward records: capacity (records) per view
-    int lean;              // backward: 0 full | 1 lean | 2 lean without depth gradient (see grad_stride); lean requires C == 6
+    int lean;              // backward: 0 full | 1 lean | 2 lean without depth gradient | 3 = 2 and no gradient on colour channels 3..5 (see grad_stride); lean requires C == 6
     int tile_records;      // 1: ONE backward record per (Gaussian, tile) instead of per (Gaussian, cell): K1 counts tiles, K4
                            // also writes cpos, the blend backward is k_render_bwd_tile (a workgroup per tile sums its
                            // sixteen cells' records in LDS with ds_add_f32: the order of the additions, and so the last

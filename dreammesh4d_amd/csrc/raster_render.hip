@@ -536,7 +536,10 @@ __device__ __forceinline__ void scan2_add(float &a, float &b, float &ea, float &
 // the values arrive in plain VGPRs and feed full-rate VALU instructions -- as DPP row_newbcast operands (the values
 // kept in "lane p of the row") every consumer ran at the DPP half rate (measured: tools/ubench/valu.hip, 4.2 against
 // 2.4 cycles per wave instruction).
-template <int C> struct PixTab { static constexpr int kLine = C > 3 ? 12 : 8; };
+// LEAN == 3 (round 5): a 6-channel FORWARD whose channels 3..5 (the normal pass) receive no gradient -- the shipped dynamic
+// configuration has every normal weight at 0 (C/configs/sugar_dynamic_dg.yaml:145-157), so in the reference autograd never enters
+// the normal pass's backward: the table line is the 3-channel one, V carries three colour terms, a record five moments.
+template <int C, int LEAN = 0> struct PixTab { static constexpr int kLine = (C > 3 && LEAN != 3) ? 12 : 8; };
 
 // one list entry, held by the lane that owns it
 template <int C>
@@ -555,14 +558,15 @@ struct Moments { float r0, r1, r2, S0, Si, Sii, Sj, Sjj, Sij; };
 template <int C, int LEAN, bool WIDE, int P>
 __device__ __forceinline__ void pixel_pair(const EntryRegs<C> &e, float (&acc)[13], Moments &mo, const bool front_lane, float *tab)
 {
-    constexpr int LN = PixTab<C>::kLine;
+    constexpr int LN = PixTab<C, LEAN>::kLine;
+    constexpr bool kSix = C > 3 && LEAN != 3;         // gradients on six colour channels
     float pw[2], G[2], araw[2], a[2], am[2], om[2], Pinc[2], Pexc[2], V[2], Tb[2], inv_om[2], w[2], Sinc[2], Sexc[2], Stot[2];
     float g[2][6], gD[2], gA[2], T[2], S[2];
     uint32_t last[2];
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
         const float4 *ln = reinterpret_cast<const float4 *>(tab + (P + h) * LN);
-        if constexpr (C > 3) {
+        if constexpr (kSix) {
             const float4 q2 = ln[2], q0 = ln[0], q1 = ln[1];
             g[h][0] = q0.x; g[h][1] = q0.y; g[h][2] = q0.z; g[h][3] = q0.w; g[h][4] = q1.x; g[h][5] = q1.y; gD[h] = q1.z; gA[h] = q1.w;
             T[h] = q2.x; S[h] = q2.y; last[h] = __float_as_uint(q2.z);
@@ -611,12 +615,12 @@ __device__ __forceinline__ void pixel_pair(const EntryRegs<C> &e, float (&acc)[1
         float v = __builtin_fmaf(e.c[0], g[h][0], gA[h]);
         v = __builtin_fmaf(e.c[1], g[h][1], v);
         v = __builtin_fmaf(e.c[2], g[h][2], v);
-        if (C > 3) {
+        if (kSix) {
             v = __builtin_fmaf(e.c[C > 3 ? 3 : 0], g[h][3], v);
             v = __builtin_fmaf(e.c[C > 3 ? 4 : 0], g[h][4], v);
             v = __builtin_fmaf(e.c[C > 3 ? 5 : 0], g[h][5], v);
         }
-        V[h] = LEAN == 2 ? v : __builtin_fmaf(e.dep, gD[h], v);      // (LEAN == 2: no depth gradient -- the product would be an exact 0)
+        V[h] = LEAN >= 2 ? v : __builtin_fmaf(e.dep, gD[h], v);      // (LEAN == 2: no depth gradient -- the product would be an exact 0)
     }
     const float R0 = __builtin_amdgcn_rcpf(Pinc[0]), R1 = __builtin_amdgcn_rcpf(Pinc[1]);
     Tb[0] = T[0] * R0; Tb[1] = T[1] * R1;                    // transmittance in front of the entry
@@ -627,7 +631,7 @@ __device__ __forceinline__ void pixel_pair(const EntryRegs<C> &e, float (&acc)[1
     scan2_add<WIDE>(Sinc[0], Sinc[1], Sexc[0], Sexc[1]);
     Stot[0] = S[0] + Sexc[0]; Stot[1] = S[1] + Sexc[1];      // everything behind the entry
     if (front_lane) {      // the chunk in front starts from (T before, S from) this chunk's front entry
-        float *t0 = tab + P * LN + (C > 3 ? 8 : 5), *t1 = t0 + LN;
+        float *t0 = tab + P * LN + (kSix ? 8 : 5), *t1 = t0 + LN;
         *reinterpret_cast<float2 *>(t0) = make_float2(Tb[0], S[0] + Sinc[0]);
         *reinterpret_cast<float2 *>(t1) = make_float2(Tb[1], S[1] + Sinc[1]);
     }
@@ -645,7 +649,8 @@ __device__ __forceinline__ void pixel_pair(const EntryRegs<C> &e, float (&acc)[1
         if (i == 1) { mo.r1 = q; mo.r2 = q; }
         if (i == 2) { mo.r1 = __builtin_fmaf(2.f, q, mo.r1); mo.r2 = __builtin_fmaf(4.f, q, mo.r2); }
         if (i == 3) { mo.r1 = __builtin_fmaf(3.f, q, mo.r1); mo.r2 = __builtin_fmaf(9.f, q, mo.r2); }
-        if constexpr (LEAN == 2) {       // no depth gradient: 8 values
+        if constexpr (LEAN == 3) {       // no depth gradient, no gradient on the normal channels: the five moments are the record
+        } else if constexpr (LEAN == 2) {       // no depth gradient: 8 values
             acc[5] = __builtin_fmaf(w[h], g[h][3], acc[5]);
             acc[6] = __builtin_fmaf(w[h], g[h][4], acc[6]);
             acc[7] = __builtin_fmaf(w[h], g[h][5], acc[7]);
@@ -761,9 +766,10 @@ __device__ __forceinline__ void load_entry(EntryRegs<C> &e, uint32_t &slot, cons
 }
 
 // table line of one pixel (written by the lane that "owns" it: lane p of the row); outside the image: nothing contributes
-template <int C>
+template <int C, int LEAN = 0>
 __device__ __forceinline__ void load_pixel(float *line, const ViewCtx &c, const int pxi, const int pyi)
 {
+    constexpr int CG = LEAN == 3 ? 3 : C;           // channels that carry a gradient
     const ViewParams &vp = c.vp;
     const bool inside = pxi < vp.W && pyi < vp.H;
     const size_t P = (size_t)vp.H * vp.W, pid = (size_t)pyi * vp.W + pxi;
@@ -773,15 +779,15 @@ __device__ __forceinline__ void load_pixel(float *line, const ViewCtx &c, const 
         T_final = c.im.final_T[pid];
         last = c.im.n_contrib[pid];
 #pragma unroll
-        for (int ch = 0; ch < C; ++ch) g[ch] = c.dL_dcolor[ch * P + pid];
-        if (c.dL_ddepth) gD = c.dL_ddepth[pid];
+        for (int ch = 0; ch < CG; ++ch) g[ch] = c.dL_dcolor[ch * P + pid];
+        if (LEAN < 2 && c.dL_ddepth) gD = c.dL_ddepth[pid];
         if (c.dL_dalpha) gA = c.dL_dalpha[pid];
     }
     float bgdot = 0.f;
 #pragma unroll
-    for (int ch = 0; ch < C; ++ch) bgdot += vp.bg[ch] * g[ch];
+    for (int ch = 0; ch < CG; ++ch) bgdot += vp.bg[ch] * g[ch];
     float4 *ln = reinterpret_cast<float4 *>(line);
-    if constexpr (C > 3) {
+    if constexpr (CG > 3) {
         ln[0] = make_float4(g[0], g[1], g[2], g[3]);
         ln[1] = make_float4(g[4], g[5], gD, gA);
         ln[2] = make_float4(T_final, T_final * bgdot, __uint_as_float(last), 0.f);
@@ -821,13 +827,13 @@ __device__ __forceinline__ void store_records(float *__restrict__ rec, const uin
 }
 
 // LDS of one wave of the backward kernel: the pixel tables of its rows
-template <int C, int RSP> struct BwdSmemV2 { __attribute__((aligned(16))) float tab[4][16 * PixTab<C>::kLine]; RecStage<RSP> stage; };
+template <int C, int RSP> struct BwdSmemV2 { __attribute__((aligned(16))) float tab[4][16 * PixTab<C>::kLine]; RecStage<RSP> stage; };      // (LEAN == 3 uses 8 of a line's 12 floats)
 
 // regular blocks: wave = quadrant, row = cell
 template <int C, int LEAN>
-__device__ __forceinline__ void render_bwd_cells(const BatchDesc &d, const uint32_t bid, BwdSmemV2<C, (LEAN == 2 ? 8 : (C <= 3 || LEAN) ? 12 : 16)> &sm)
+__device__ __forceinline__ void render_bwd_cells(const BatchDesc &d, const uint32_t bid, BwdSmemV2<C, (LEAN >= 2 ? 8 : (C <= 3 || LEAN) ? 12 : 16)> &sm)
 {
-    constexpr int RSP = (LEAN == 2 ? 8 : (C <= 3 || LEAN) ? 12 : 16);   // == grad_stride(C, LEAN)
+    constexpr int RSP = (LEAN >= 2 ? 8 : (C <= 3 || LEAN) ? 12 : 16);   // == grad_stride(C, LEAN)
     const WaveTrace trace;
     int view, tile, q;
     if (!block_to_quadrant(d, bid, view, tile, q)) { trace.done(0); return; }
@@ -862,7 +868,7 @@ __device__ __forceinline__ void render_bwd_cells(const BatchDesc &d, const uint3
     if (ndmax == 0 || ndmax < g_min_work) { trace.done(0); return; }
     set_priority_by_length(ndmax);
     float *tab = sm.tab[row];
-    load_pixel<C>(tab + li * PixTab<C>::kLine, c, lp.px, lp.py);
+    load_pixel<C, LEAN>(tab + li * PixTab<C, LEAN>::kLine, c, lp.px, lp.py);
     __builtin_amdgcn_wave_barrier();
     const float cx0 = (float)(lp.px - (li & 3)), cy0 = (float)(lp.py - (li >> 2));
     const bool front_lane = li == 15;
@@ -883,9 +889,9 @@ __device__ __forceinline__ void render_bwd_cells(const BatchDesc &d, const uint3
 
 // wide blocks: wave = one long cell
 template <int C, int LEAN>
-__device__ __forceinline__ void render_bwd_wide_cells(const BatchDesc &d, const uint32_t bid, const uint32_t nblocks, BwdSmemV2<C, (LEAN == 2 ? 8 : (C <= 3 || LEAN) ? 12 : 16)> &sm)
+__device__ __forceinline__ void render_bwd_wide_cells(const BatchDesc &d, const uint32_t bid, const uint32_t nblocks, BwdSmemV2<C, (LEAN >= 2 ? 8 : (C <= 3 || LEAN) ? 12 : 16)> &sm)
 {
-    constexpr int RSP = (LEAN == 2 ? 8 : (C <= 3 || LEAN) ? 12 : 16);
+    constexpr int RSP = (LEAN >= 2 ? 8 : (C <= 3 || LEAN) ? 12 : 16);
     const WaveTrace trace;
     uint32_t traced = 0;
     const int view = (int)(bid % (uint32_t)d.B);
@@ -921,7 +927,7 @@ __device__ __forceinline__ void render_bwd_wide_cells(const BatchDesc &d, const 
         if (nd == 0u) continue;
         traced += nd;
         __builtin_amdgcn_wave_barrier();
-        if (lane < 16) load_pixel<C>(tab + p * PixTab<C>::kLine, c, cxi + (p & 3), cyi + (p >> 2));
+        if (lane < 16) load_pixel<C, LEAN>(tab + p * PixTab<C, LEAN>::kLine, c, cxi + (p & 3), cyi + (p >> 2));
         __builtin_amdgcn_wave_barrier();
         const float cx0 = (float)cxi, cy0 = (float)cyi;
         for (uint32_t c0 = ((nd - 1u) / 64u) * 64u;; c0 -= 64u) {
@@ -967,7 +973,7 @@ __global__ __launch_bounds__(256, DM4D_TILE_WAVES) void k_render_bwd_tile(BatchD
 {
     constexpr int LN = PixTab<C>::kLine;
     constexpr int NV = LEAN ? 9 : (C > 3 ? 13 : 10);      // values of a record
-    constexpr int RSP = (LEAN == 2 ? 8 : (C <= 3 || LEAN) ? 12 : 16);       // floats of a record in memory (== grad_stride)
+    constexpr int RSP = (LEAN >= 2 ? 8 : (C <= 3 || LEAN) ? 12 : 16);       // floats of a record in memory (== grad_stride)
     __shared__ float s_acc[WN * NV];
     __shared__ __attribute__((aligned(16))) float s_tab[kCells][16 * LN];
     __shared__ uint32_t s_pos[kCells], s_cnt[kCells];
@@ -1167,7 +1173,7 @@ int launch_n_contrib_tile_positions(void *geom, void *binning, void *image, int 
 template <int C, int LEAN>
 __global__ __launch_bounds__(64) void k_render_bwd(BatchDesc d, uint32_t wide_blocks)
 {
-    __shared__ BwdSmemV2<C, (LEAN == 2 ? 8 : (C <= 3 || LEAN) ? 12 : 16)> sm;
+    __shared__ BwdSmemV2<C, (LEAN >= 2 ? 8 : (C <= 3 || LEAN) ? 12 : 16)> sm;
     if (blockIdx.x < wide_blocks) render_bwd_wide_cells<C, LEAN>(d, blockIdx.x, wide_blocks, sm);
     else render_bwd_cells<C, LEAN>(d, blockIdx.x - wide_blocks, sm);
 }
@@ -1216,7 +1222,7 @@ int launch_render_bwd(const BatchDesc &d, hipStream_t st)
     if (d.lean && d.C != 6) { set_error("lean backward records need 6 channels"); return DM4D_ERR_INVALID; }
     if (d.tile_records) {      // one workgroup per tile, (Gaussian, tile) records summed in LDS
         const dim3 tgrid((unsigned)T * (unsigned)d.B);
-        if (d.lean == 2) { set_error("tile records: no 32-byte variant (lean must be 0 or 1)"); return DM4D_ERR_INVALID; }
+        if (d.lean >= 2) { set_error("tile records: no 32-byte variant (lean must be 0 or 1)"); return DM4D_ERR_INVALID; }
         if (d.C <= 3) hipLaunchKernelGGL((k_render_bwd_tile<3, 0, kTileWindow>), tgrid, dim3(256), 0, st, d);
         else if (d.lean) hipLaunchKernelGGL((k_render_bwd_tile<6, 1, kTileWindow>), tgrid, dim3(256), 0, st, d);
         else hipLaunchKernelGGL((k_render_bwd_tile<6, 0, kTileWindow>), tgrid, dim3(256), 0, st, d);
@@ -1228,6 +1234,7 @@ int launch_render_bwd(const BatchDesc &d, hipStream_t st)
     const uint32_t long_blocks = (uint32_t)(min(T * kCells, wide_waves) * d.B);
     const dim3 grid(long_blocks + (uint32_t)blocks);
     if (d.C <= 3) hipLaunchKernelGGL((k_render_bwd<3, 0>), grid, dim3(64), 0, st, d, long_blocks);
+    else if (d.lean == 3) hipLaunchKernelGGL((k_render_bwd<6, 3>), grid, dim3(64), 0, st, d, long_blocks);
     else if (d.lean == 2) hipLaunchKernelGGL((k_render_bwd<6, 2>), grid, dim3(64), 0, st, d, long_blocks);
     else if (d.lean) hipLaunchKernelGGL((k_render_bwd<6, 1>), grid, dim3(64), 0, st, d, long_blocks);
     else hipLaunchKernelGGL((k_render_bwd<6, 0>), grid, dim3(64), 0, st, d, long_blocks);

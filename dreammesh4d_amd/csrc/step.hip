@@ -103,8 +103,23 @@ int dm4d_step_forward(dm4d_step *s, const float *times01, const float *viewmatri
     return dm4d_views_forward(&v, stream);
 }
 
+static int step_backward_impl(dm4d_step *s, const float *dL_dcolor, const float *dL_ddepth, const float *dL_dalpha,
+                              const float *dL_dvxyz_ext, const float *dL_dvrot_ext, dm4d_stream_t stream, bool rgb_only);
+
 int dm4d_step_backward(dm4d_step *s, const float *dL_dcolor, const float *dL_ddepth, const float *dL_dalpha,
                        const float *dL_dvxyz_ext, const float *dL_dvrot_ext, dm4d_stream_t stream)
+{
+    return step_backward_impl(s, dL_dcolor, dL_ddepth, dL_dalpha, dL_dvxyz_ext, dL_dvrot_ext, stream, false);
+}
+
+int dm4d_step_backward_rgb(dm4d_step *s, const float *dL_dcolor, const float *dL_dalpha, const float *dL_dvxyz_ext,
+                           const float *dL_dvrot_ext, dm4d_stream_t stream)
+{
+    return step_backward_impl(s, dL_dcolor, nullptr, dL_dalpha, dL_dvxyz_ext, dL_dvrot_ext, stream, true);
+}
+
+static int step_backward_impl(dm4d_step *s, const float *dL_dcolor, const float *dL_ddepth, const float *dL_dalpha,
+                              const float *dL_dvxyz_ext, const float *dL_dvrot_ext, dm4d_stream_t stream, bool rgb_only)
 {
     using namespace dm4d;
     if (!s || s->magic != kStepMagic) { set_error("step: not a step object"); return DM4D_ERR_INVALID; }
@@ -113,7 +128,7 @@ int dm4d_step_backward(dm4d_step *s, const float *dL_dcolor, const float *dL_dde
     dm4d_views_grads &g = d.grads;
     g.dL_dcolor = dL_dcolor; g.dL_ddepth = dL_ddepth; g.dL_dalpha = dL_dalpha;
     g.dL_dvxyz_ext = dL_dvxyz_ext; g.dL_dvrot_ext = dL_dvrot_ext;
-    int rc = dm4d_views_backward(&d.views, &g, stream);
+    int rc = rgb_only ? dm4d_views_backward_rgb(&d.views, &g, stream) : dm4d_views_backward(&d.views, &g, stream);
     if (rc) return rc;
     const dm4d_views &v = d.views;
     const int NF = v.frame_index ? v.n_frames : v.B;

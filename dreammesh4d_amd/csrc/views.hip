@@ -164,7 +164,20 @@ int dm4d_views_forward(const dm4d_views *v, dm4d_stream_t stream)
     return launch_render_fwd(d, st);
 }
 
+static int views_backward_impl(const dm4d_views *v, const dm4d_views_grads *gr, dm4d_stream_t stream, bool rgb_only);
+
 int dm4d_views_backward(const dm4d_views *v, const dm4d_views_grads *gr, dm4d_stream_t stream)
+{
+    return views_backward_impl(v, gr, stream, false);
+}
+
+/* dL_dcolor's channels 3..5 (the normal pass) are declared zero and not read: dm4d.h */
+int dm4d_views_backward_rgb(const dm4d_views *v, const dm4d_views_grads *gr, dm4d_stream_t stream)
+{
+    return views_backward_impl(v, gr, stream, true);
+}
+
+static int views_backward_impl(const dm4d_views *v, const dm4d_views_grads *gr, dm4d_stream_t stream, bool rgb_only)
 {
     int rc = views_check(v);
     if (rc) return rc;
@@ -193,6 +206,15 @@ int dm4d_views_backward(const dm4d_views *v, const dm4d_views_grads *gr, dm4d_st
     // ... and without a depth gradient (no depth loss in the shipped dynamic configuration) 8 values: 32-byte records
     static const bool no_lean2 = getenv("DM4D_NO_LEAN2") != nullptr;          // (A/B switch)
     if (d.lean == 1 && !gr->dL_ddepth && !d.tile_records && !no_lean2) d.lean = 2;
+    if (rgb_only) {
+        // no loss reads the normal image (every normal weight 0 in C/configs/sugar_dynamic_dg.yaml:145-157; in the reference autograd
+        // then never enters the normal pass's backward, C/renderer/diff_sugar_rasterizer_temporal.py:202-211): 5 per-entry sums, not 8
+        if (d.lean != 2) {
+            set_error("dm4d_views_backward_rgb: needs the static appearance frozen (dL_dopacity NULL), no depth gradient and cell records");
+            return DM4D_ERR_UNSUPPORTED;
+        }
+        d.lean = 3;
+    }
     // The blend backward writes one record per (Gaussian, cell) and the gather reads them back: in groups of views whose
     // records fit the 256 MB memory-side cache the round trip stays off HBM (8 views at once: 466 MB).
     static const int group_env = getenv("DM4D_BWD_GROUP") ? atoi(getenv("DM4D_BWD_GROUP")) : 0;

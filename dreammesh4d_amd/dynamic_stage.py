@@ -39,6 +39,10 @@ LAMBDA = {"sds_zero123": 0.1, "rgb": 5000.0, "mask": [200, 500.0, 5000.0, 1000],
           "normal_consistency": 100.0, "arap_reg_key_frame": 10.0, "arap_reg_inter_frame": 10.0}
 
 
+# the terms of system/sugar_4dgen.py that read comp_normal (:201-207 normal / normal_smooth, :236-275 normal_tv, normal_depth_consistency)
+NORMAL_TERMS = ("normal", "normal_smooth", "normal_tv", "normal_depth_consistency", "3d_normal_smooth")
+
+
 def quat_xyzw_to_matrix(q, grad_mode=None):
     from .ops import quat_xyzw_to_matrix as f
 
@@ -137,7 +141,21 @@ class DynamicStage:
         # nothing in this loop reads the per-view Gaussian gradients: record gather + face backward as one kernel (views.ViewRenderer)
         if hasattr(renderer, "fuse_face_backward") and all(not t.requires_grad for t in (static["scales"], static["opacities"], static["rgb"])):
             renderer.fuse_face_backward = True
+        # ... and nothing in it reads the normal image unless one of the normal terms has a weight: then the backward of the normal
+        # pass is skipped, as autograd skips it in the reference (system/sugar_4dgen.py:201-207,236-275 only touch comp_normal under
+        # lambda_normal*, lambda_normal_depth_consistency; all 0 in sugar_dynamic_dg.yaml:145-157)
+        if hasattr(renderer, "rgb_gradient_only"):
+            renderer.rgb_gradient_only = not any(self._weight_is_set(k) for k in NORMAL_TERMS) and os.environ.get("DM4D_RGB_GRADIENT_ONLY", "1") != "0"
         self._step_objects = {}
+
+    def _weight_is_set(self, name):
+        """A loss weight of the configuration that is not identically zero (numbers, or C() schedules: [start, v0, v1, end])."""
+        v = self.lam.get(name, 0)
+        if v is None:
+            return False
+        if isinstance(v, (list, tuple)):
+            return any(float(x) != 0.0 for x in v[1:3]) if len(v) >= 3 else any(float(x) != 0.0 for x in v)
+        return float(v) != 0.0
 
     def sample_batch(self):
         """4 frames of L without replacement (this rank's share) + cameras: the fixed reference camera and

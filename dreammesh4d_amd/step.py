@@ -263,8 +263,13 @@ class DynamicStep:
         if gc is None:
             gc = torch.zeros_like(self.out["color"])
         with torch.cuda.device(dev):
-            _lib.check(_lib.lib().dm4d_step_backward(self.handle, gc.data_ptr(), _p(gd), _p(ga), _p(gx), _p(gr_),
-                                                     torch.cuda.current_stream(dev).cuda_stream), "dm4d_step_backward")
+            if bool(getattr(self.r, "rgb_gradient_only", False)) and gd is None and self.r.deterministic:
+                # no loss reads the normal image: channels 3..5 of the upstream gradient are not read (views.py, dm4d_views_backward_rgb)
+                _lib.check(_lib.lib().dm4d_step_backward_rgb(self.handle, gc.data_ptr(), _p(ga), _p(gx), _p(gr_),
+                                                             torch.cuda.current_stream(dev).cuda_stream), "dm4d_step_backward_rgb")
+            else:
+                _lib.check(_lib.lib().dm4d_step_backward(self.handle, gc.data_ptr(), _p(gd), _p(ga), _p(gx), _p(gr_),
+                                                         torch.cuda.current_stream(dev).cuda_stream), "dm4d_step_backward")
         for p, gb in zip(self.planes, self.g_planes):
             if p.requires_grad:
                 p.grad = gb

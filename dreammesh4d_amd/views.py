@@ -55,6 +55,11 @@ class ViewRenderer:
         # order of the float additions over a frame's views).  The training loops (bench.py, DynamicStage) switch it on; off by
         # default so that `last_grads` holds every per-view gradient for callers that look at them.
         self.fuse_face_backward = False
+        # True: the caller declares that NO loss reads channels 3..5 of `color` (the normal image): their upstream gradient is not read
+        # and nothing flows through the normals (dm4d_views_backward_rgb; the reference's autograd does the same when every normal
+        # weight is 0, configs/sugar_dynamic_dg.yaml:145-157).  DynamicStage sets it from its loss weights; bench.py's headline step
+        # keeps both passes' backward (SURVEY.md section 8d credits them).
+        self.rgb_gradient_only = False
         self.N = topo.F * topo.G
         self.capacity = max(int(capacity_factor * self.N), 1 << 16)
         # backward records = (Gaussian, 4x4-pixel cell) pairs; ~2 per duplicate for mesh-bound splats
@@ -253,9 +258,14 @@ class _RenderViews(torch.autograd.Function):
                         _p(t.csr_items), _p(scr["grad"]), _p(scr["skin"]), _p(scr["face"]), _p(o["m2"]), _p(o["m3"]),
                         _p(o["rot"]), _p(o["col"]), _p(o["op"]), _p(o["sc"]), _p(o["vx"]), _p(o["vr"]), _p(o["dx"]),
                         _p(o["dr"]), _p(o["ds"]), _p(o["do"]))
+        # renderer.rgb_gradient_only: the caller declares that no loss reads the normal image (channels 3..5 of `color`): their upstream
+        # gradient is not read and the blend backward carries 5 per-entry sums instead of 8 (dm4d_views_backward_rgb) -- where the lean
+        # configuration it needs applies (static appearance frozen, no depth gradient, cell records); otherwise the full call
+        rgb = bool(getattr(r, "rgb_gradient_only", False)) and not ctx.need_static and gd is None and r.deterministic
+        fn = L.dm4d_views_backward_rgb if rgb else L.dm4d_views_backward
         with torch.cuda.device(dev):
-            _lib.check(L.dm4d_views_backward(C.byref(vs), C.byref(gs), torch.cuda.current_stream(dev).cuda_stream),
-                       "dm4d_views_backward")
+            _lib.check(fn(C.byref(vs), C.byref(gs), torch.cuda.current_stream(dev).cuda_stream),
+                       "dm4d_views_backward_rgb" if rgb else "dm4d_views_backward")
         s = ctx.shapes
         r._give_ws(ctx.ws)   # stream-ordered reuse by the next forward is safe
         ctx.ws = ctx.internal = None

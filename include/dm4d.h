@@ -700,6 +700,12 @@ size_t dm4d_views_skin_scratch_bytes(int32_t B, int32_t V, int32_t K);
 size_t dm4d_views_face_scratch_bytes(int32_t B, int32_t F);
 int dm4d_views_forward(const dm4d_views *v, dm4d_stream_t stream);
 int dm4d_views_backward(const dm4d_views *v, const dm4d_views_grads *g, dm4d_stream_t stream);
+/* Round 5: the same backward when NO loss reads the normal image -- dL_dcolor's channels 3..5 are DECLARED zero and not read (the
+ * tensor keeps its [B,6,H,W] shape), the blend backward carries 5 per-entry sums instead of 8 and no gradient flows through the
+ * normals.  That is what autograd does in the reference when every normal weight is 0 (C/configs/sugar_dynamic_dg.yaml:145-157: the
+ * normal pass's backward, C/renderer/diff_sugar_rasterizer_temporal.py:202-211, is never entered).  Requires the lean configuration:
+ * dL_dopacity == NULL, dL_ddepth == NULL, cell records.  Results equal dm4d_views_backward fed zeros on channels 3..5. */
+int dm4d_views_backward_rgb(const dm4d_views *v, const dm4d_views_grads *g, dm4d_stream_t stream);
 /* num_rendered[b], num_records[b], overflowed[b] (bit 0: duplicates > capacity, bit 1: records >
  * record_capacity) of the last forward (host arrays of B, any may be NULL; synchronises the stream). */
 int dm4d_views_counters(const dm4d_views *v, int64_t *num_rendered, int64_t *num_records, int32_t *overflowed,
@@ -877,6 +883,9 @@ int dm4d_step_forward(dm4d_step *s, const float *times01, const float *viewmatri
                       const int32_t *frame_index, dm4d_stream_t stream);
 int dm4d_step_backward(dm4d_step *s, const float *dL_dcolor, const float *dL_ddepth, const float *dL_dalpha,
                        const float *dL_dvxyz_ext, const float *dL_dvrot_ext, dm4d_stream_t stream);
+/* dm4d_views_backward_rgb inside the step object (no depth gradient by construction). */
+int dm4d_step_backward_rgb(dm4d_step *s, const float *dL_dcolor, const float *dL_dalpha, const float *dL_dvxyz_ext,
+                           const float *dL_dvrot_ext, dm4d_stream_t stream);
 /* the object's dm4d_views as the last forward left it (for dm4d_views_counters); NULL if `s` is not a step object */
 const dm4d_views *dm4d_step_views(const dm4d_step *s);
 

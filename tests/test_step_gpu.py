@@ -133,6 +133,40 @@ def test_fused_face_backward_equals_two_kernels_within_rounding():
     assert n >= 10
 
 
+def test_step_object_rgb_gradient_only():
+    """dm4d_step_backward_rgb (what DynamicStage runs with the shipped loss weights: nothing reads the normal image): every parameter
+    gradient bit-identical to dm4d_step_backward fed exact zeros on channels 3..5; the upstream gradient's normal channels hold NaN."""
+    if not torch.cuda.is_available():
+        pytest.skip("no HIP device")
+    from dreammesh4d_amd.step import DynamicStep
+
+    dev = torch.device("cuda:0")
+    sc, net, nodes, st, vm, pm, fidx, t, mk, (gC, gD, gA, gV) = _setup(dev, "hybrid")
+    bg6 = torch.ones(6, device=dev)
+    params = [p for p in net.parameters() if p.requires_grad]
+    gz, gj = gC.clone(), gC.clone()
+    gz[:, 3:] = 0.0
+    gj[:, 3:] = float("nan")
+    res = {}
+    for rgb in (False, True):
+        r = mk()
+        r.fuse_face_backward = True
+        r.rgb_gradient_only = rgb
+        step = DynamicStep(r, net, nodes, st["qs"], st["sc"], st["op"], st["rgb"], bg6, n_views=vm.shape[0], n_frames=t.shape[0])
+        o = step(t, vm, pm, fidx)
+        torch.autograd.backward([o["color"], o["alpha"], o["vxyz"]], [gj if rgb else gz, gA, gV])
+        res[rgb] = [None if p.grad is None else p.grad.detach().clone() for p in params]
+        for p in params:
+            p.grad = None
+    n = 0
+    for a, b in zip(res[False], res[True]):
+        if a is None or not bool(a.any()):
+            continue
+        assert torch.isfinite(b).all() and torch.equal(a, b)
+        n += 1
+    assert n >= 10
+
+
 def test_step_object_contract():
     if not torch.cuda.is_available():
         pytest.skip("no HIP device")

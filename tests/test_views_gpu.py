@@ -320,6 +320,54 @@ def test_no_depth_gradient_uses_32_byte_records_with_identical_gradients(H, W):
         assert torch.equal(res["none"][k], res["zeros"][k]), k
 
 
+@pytest.mark.parametrize("fuse", [False, True])
+@pytest.mark.parametrize("H,W", [(144, 176), (40, 48)])
+def test_rgb_gradient_only_equals_the_full_backward_fed_zeros_on_the_normal_channels(H, W, fuse):
+    """`renderer.rgb_gradient_only` (dm4d_views_backward_rgb, k_render_bwd<6, 3>): no loss reads the normal image, so channels 3..5
+    of the upstream gradient are not read (here they hold GARBAGE, NaN included) and the blend backward carries 5 per-entry sums
+    instead of 8.  Every gradient must be bit-identical to the 32-byte-record backward fed exact zeros on those channels (a zero
+    adds nothing to any sum; the normals then receive no gradient), which is what autograd does in the reference when every
+    normal weight of the configuration is 0 (configs/sugar_dynamic_dg.yaml:145-157).  With a depth gradient present the flag
+    falls back to the full call (the lean configuration it needs does not apply)."""
+    _need_gpu()
+    from dreammesh4d_amd import views
+
+    dev = torch.device("cuda:0")
+    B, M = 4, 100
+    sc, graph, topo, qs, scales, opac, rgb, raw, cams, vm, pm = _scene(2400, M, 4, B, H, W, dev, seed=7)
+    fidx = torch.tensor([0, 1, 1, 0], device=dev, dtype=torch.int32)
+    gen = torch.Generator().manual_seed(4)
+    gC = torch.randn(B, 6, H, W, generator=gen).to(dev)
+    gA = torch.randn(B, 1, H, W, generator=gen).to(dev)
+    gD = (0.1 * torch.randn(B, 1, H, W, generator=gen)).to(dev)
+    gC_zero = gC.clone()
+    gC_zero[:, 3:] = 0.0
+    gC_junk = gC.clone()
+    gC_junk[:, 3:] = float("nan")
+    gC_junk[:, 4, ::3] = 1.0e30
+    res = {}
+    for mode in ("zeros", "rgb", "rgb_with_depth", "zeros_with_depth"):
+        r = views.ViewRenderer(graph, topo, H, W, cams[0].tanfov, method="hybrid")
+        r.fuse_face_backward = fuse
+        r.rgb_gradient_only = mode.startswith("rgb")
+        leaves = {k: v[:2].clone().requires_grad_(True) for k, v in raw.items()}
+        m2 = torch.zeros(B, r.N, 3, device=dev, requires_grad=True)
+        out = views.render_views(r, leaves["trans"], leaves["d_rot"], leaves["strain"], leaves["d_opacity"].squeeze(-1), qs,
+                                 scales, opac, rgb, vm, pm, torch.ones(6, device=dev), frame_index=fidx, means2D=m2)
+        if mode.endswith("with_depth"):
+            # (the flag does not apply: the full call reads all six channels, so it gets the zeros)
+            torch.autograd.backward([out["color"], out["depth"], out["alpha"]], [gC_zero, gD, gA])
+        else:
+            torch.autograd.backward([out["color"], out["alpha"]], [gC_junk if mode == "rgb" else gC_zero, gA])
+        res[mode] = {k: v.grad.clone() for k, v in leaves.items()}
+        res[mode]["m2"] = m2.grad.clone()
+    for a, b in (("zeros", "rgb"), ("zeros_with_depth", "rgb_with_depth")):
+        for k in ("trans", "d_rot", "strain", "d_opacity", "m2"):
+            assert torch.isfinite(res[b][k]).all() and float(res[a][k].abs().max()) > 0, (a, k)
+            assert torch.equal(res[a][k], res[b][k]), (a, b, k, float((res[a][k] - res[b][k]).abs().max()))
+    assert not torch.equal(res["zeros"]["trans"], res["zeros_with_depth"]["trans"])
+
+
 @pytest.mark.parametrize("mode", ["lean32", "lean48", "full64"])
 def test_bench_scene_one_view_against_two_oracle_passes(mode):
     """The TIMED kernel instantiations at the TIMED size: one (frame, view) unit of bench.py's scene (mesh-bound 199,980
