@@ -20,13 +20,13 @@ into its nested ``Config`` dataclass, sets ``self.device``, calls ``self.configu
     ``solid-color-background``, ``no-material``
 * ``parse_optimizer(config, model)``           -- threestudio/systems/utils.py:55-89 for the optimisers torch ships
 
-What it does NOT contain: the launcher, the systems, the data modules, the exporters.  Two
-set-up steps of the reference need packages that are not in the tree and are therefore inputs here, as extra ``cfg``
-keys the reference's dataclasses do not have: the CLIP image embeddings of the conditioning frames
-(``cond_embeddings_path``: a torch file {"c_crossattn" [L,1,768], "c_concat" [L,4,32,32]}; the reference computes them
-with the checkpoint's CLIP encoder in ``prepare_embeddings``, guidance :141-199), and the deformation graph's node
-samples when reproducibility across runs is wanted (``dg_node_seed``; the reference draws them with open3d's
-``sample_points_uniformly``, dynamic_sugar.py:752-753).
+What it does NOT contain: the launcher, the systems, the data modules, the exporters.  The guidances'
+``prepare_embeddings`` (guidance :174-226: the conditioning frames through the checkpoint's CLIP ViT-L/14 image tower and the VAE
+encoder's posterior mean) runs from the configuration's own keys -- ``cond_video_dir`` / ``cond_image_path`` + the checkpoint -- through
+``clip_vit.py`` (round 5; parity unpinned: `clip`, `kornia`, `cv2` are absent from the image); two extra ``cfg`` keys the reference's
+dataclasses do not have remain as OPTIONS: ``cond_embeddings_path`` (a torch file {"c_crossattn" [L,1,768], "c_concat" [L,4,32,32]}
+computed elsewhere, e.g. by the reference itself) and the deformation graph's node samples when reproducibility across runs is
+wanted (``dg_node_seed``; the reference draws them with open3d's ``sample_points_uniformly``, dynamic_sugar.py:752-753).
 """
 import dataclasses
 import math
@@ -515,9 +515,13 @@ def _zero123_from_config(pretrained_config, pretrained_model_name_or_path, devic
     if not os.path.exists(pretrained_model_name_or_path):
         raise FileNotFoundError(f"{pretrained_model_name_or_path}: the Zero123 checkpoint (load/zero123/download.sh) is not there")
     sd = torch.load(pretrained_model_name_or_path, map_location="cpu")
-    missing = _z.load_zero123_state_dict(model, sd.get("state_dict", sd))
+    sd = sd.get("state_dict", sd)
+    missing = _z.load_zero123_state_dict(model, sd)
     if missing:
         raise KeyError(f"checkpoint lacks {len(missing)} tensors of the UNet / VAE encoder / cc_projection, e.g. {missing[:3]}")
+    # the checkpoint's CLIP image tower (`cond_stage_model.model.visual.*`): only `prepare_embeddings` needs it, once, at set-up time --
+    # kept as the plain tensors until then (and dropped afterwards), never moved to the device with the model
+    model.__dict__["_clip_visual_sd"] = {k: v for k, v in sd.items() if k.startswith("cond_stage_model.model.visual.")}
     return model
 
 
@@ -540,10 +544,40 @@ class _TemporalZero123Config:                         # TemporalStableZero123Gui
     cond_embeddings_path: Optional[str] = None        # (not a reference key, see the module docstring)
 
 
-def _load_embeddings(c, n):
+def _load_embeddings(c, n, model=None, device=None, clip_tower=None):
+    """The conditioning embeddings of the guidance: ``prepare_embeddings_video(cfg.cond_video_dir)`` / ``prepare_embeddings(
+    cfg.cond_image_path)`` as the reference computes them at ``configure`` time (guidance :166,174-226) from the configuration's OWN keys
+    -- the frames through the checkpoint's CLIP ViT-L/14 image tower and the VAE encoder's posterior mean (clip_vit.py; parity
+    unpinned: `clip` / `kornia` / `cv2` are absent) -- or, when the non-reference key ``cond_embeddings_path`` is set, from that file."""
     if not c.cond_embeddings_path:
-        raise NotImplementedError("the CLIP image encoder of `prepare_embeddings` is not part of this package: pass the "
-                                  "conditioning embeddings as cond_embeddings_path (a torch file with c_crossattn, c_concat)")
+        from . import clip_vit
+
+        if hasattr(c, "cond_video_dir"):
+            paths = [clip_vit.video_frame_path(c.cond_video_dir, i) for i in range(n)]
+        else:
+            paths = [c.cond_image_path]
+        lost = [p for p in paths if not os.path.exists(p)]
+        if lost:
+            raise FileNotFoundError(f"conditioning frame(s) not found: {lost[:3]} (cond_video_dir / cond_image_path of the configuration; "
+                                    "or pass precomputed embeddings as cond_embeddings_path)")
+        if clip_tower is None:
+            vis = getattr(model, "_clip_visual_sd", None)
+            if not vis:
+                raise KeyError("the Zero123 model carries no CLIP image tower (`cond_stage_model.model.visual.*` of the checkpoint): pass "
+                               "`clip_tower=` or the conditioning embeddings as cond_embeddings_path")
+            clip_tower = clip_vit.CLIPVisionTower.from_state_dict(vis)
+        wd = torch.float16 if c.half_precision_weights else torch.float32
+        clip_tower = clip_tower.to(device=device, dtype=wd).eval()      # (its LayerNorms compute in float32 whatever their storage, guidance :117-134)
+        p0 = next(model.first_stage_model.parameters())
+        vae_back = None
+        if p0.device != torch.device(device) or p0.dtype != wd:
+            vae_back = (p0.device, p0.dtype)
+            model.first_stage_model.to(device=device, dtype=wd)
+        _, cc, ct = clip_vit.prepare_embeddings(model, clip_tower, paths, device, wd)
+        if vae_back is not None:
+            model.first_stage_model.to(device=vae_back[0], dtype=vae_back[1])
+        model.__dict__.pop("_clip_visual_sd", None)
+        return cc.cpu(), ct.cpu()
     e = torch.load(c.cond_embeddings_path, map_location="cpu")
     cc, ct = e["c_crossattn"], e["c_concat"]
     if cc.shape[0] < n or ct.shape[0] < n:
@@ -556,13 +590,14 @@ class TemporalStableZero123Guidance(_z.TemporalStableZero123Guidance, Updateable
     Config = _TemporalZero123Config
     _frames_key = "num_frames"
 
-    def __init__(self, cfg=None, model=None):
-        """``model``: an already built ``zero123.Zero123`` (tests, random weights); otherwise the checkpoint is loaded."""
+    def __init__(self, cfg=None, model=None, clip_tower=None):
+        """``model``: an already built ``zero123.Zero123`` (tests, random weights); otherwise the checkpoint is loaded.  ``clip_tower``:
+        a ``clip_vit.CLIPVisionTower`` for ``prepare_embeddings`` when ``model`` was not loaded from a checkpoint that carries one."""
         c = parse_structured(self.Config, cfg)
         dev = get_device()
         if model is None:
             model = _zero123_from_config(c.pretrained_config, c.pretrained_model_name_or_path, dev)
-        cc, ct = _load_embeddings(c, getattr(c, self._frames_key) if self._frames_key else 1)
+        cc, ct = _load_embeddings(c, getattr(c, self._frames_key) if self._frames_key else 1, model=model, device=dev, clip_tower=clip_tower)
         grad_clip = c.grad_clip
         _z.TemporalStableZero123Guidance.__init__(
             self, model, cc, ct, cond_elevation_deg=c.cond_elevation_deg, cond_azimuth_deg=c.cond_azimuth_deg,
