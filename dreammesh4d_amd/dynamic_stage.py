@@ -39,6 +39,13 @@ LAMBDA = {"sds_zero123": 0.1, "rgb": 5000.0, "mask": [200, 500.0, 5000.0, 1000],
           "normal_consistency": 100.0, "arap_reg_key_frame": 10.0, "arap_reg_inter_frame": 10.0}
 
 
+# Loss terms of system/sugar_4dgen.py:181-207,236-300 whose weight is 0 in the shipped configuration (sugar_dynamic_dg.yaml:135-158): computed by
+# DynamicStage._optional_terms -- the reference's torch expressions on the reference's images (renderer.compose_outputs) -- when a
+# configuration gives them a weight.  (ref) = reference substep only, (both) = once per substep, each over its own views.
+OPTIONAL_TERMS = ("depth", "depth_rel", "normal",                                                    # (ref), need ref_depths / ref_normals
+                  "normal_smooth", "rgb_tv", "depth_tv", "normal_tv", "normal_depth_consistency",      # (both)
+                  "ref_xyz", "laplacian_smoothing",                                                   # (ref)
+                  "obj_centric")                                                                      # (both)
 # the terms of system/sugar_4dgen.py that read comp_normal (:201-207 normal / normal_smooth, :236-275 normal_tv, normal_depth_consistency)
 NORMAL_TERMS = ("normal", "normal_smooth", "normal_tv", "normal_depth_consistency", "3d_normal_smooth")
 
@@ -78,7 +85,8 @@ class DynamicStage:
     def __init__(self, renderer, net, nodes, static, timestamps, ref_images, ref_masks, ref_camera, guidance=None,
                  frames_per_step=4, random_views_per_frame=1, deformation_lr=0.00032, grid_lr=0.0032, seed=0,
                  normal_consistency=None, arap=None, milestone_arap_reg=100, inter_frame_reg=0, num_inter_frames=10,
-                 length_inter_frames=0.1, sharded_optimizer=None, lambdas=None, optimizer_hyper=None):
+                 length_inter_frames=0.1, sharded_optimizer=None, lambdas=None, optimizer_hyper=None, ref_depths=None, ref_normals=None,
+                 laplacian_smoothing=None):
         self.r, self.net, self.nodes, self.static = renderer, net, nodes, static
         # loss weights: `system.loss` of the configuration (from_cfg), defaulting to the shipped sugar_dynamic_dg.yaml values
         self.lam = dict(LAMBDA)
@@ -94,6 +102,15 @@ class DynamicStage:
         self.ref_masks = ref_masks.contiguous()
         self.ref_images = (ref_images * ref_masks + (1.0 - ref_masks)).contiguous()
         self.ref_camera = ref_camera
+        # optional inputs of optional terms: the data module's `ref_depth` [L,H,W,1] / `ref_normal` [L,H,W,3] (lambda_depth, lambda_depth_rel,
+        # lambda_normal: system/sugar_4dgen.py:181-213), a mesh_reg.MeshLaplacianSmoothing (lambda_laplacian_smoothing, :227-230)
+        self.ref_depths = None if ref_depths is None else ref_depths.to(device=nodes.device, dtype=torch.float32).contiguous()
+        self.ref_normals = None if ref_normals is None else ref_normals.to(device=nodes.device, dtype=torch.float32).contiguous()
+        self.laplacian_smoothing = laplacian_smoothing
+        for k, need in (("depth", self.ref_depths), ("depth_rel", self.ref_depths), ("normal", self.ref_normals), ("laplacian_smoothing", laplacian_smoothing)):
+            if self._weight_is_set(k) and need is None:
+                raise ValueError(f"lambda_{k} is set but the stage was not given what the term reads "
+                                 f"({'ref_depths' if 'depth' in k else 'ref_normals' if k == 'normal' else 'laplacian_smoothing'}=...)")
         self.guidance = guidance
         self.normal_consistency = normal_consistency     # mesh_reg.MeshNormalConsistency of the surface mesh, or None
         self.arap = arap                                  # mesh_reg.ARAPCoach of the surface mesh, or None
@@ -196,6 +213,7 @@ class DynamicStage:
         if self._timestamps_host is None or self._timestamps_host[1] is not self.timestamps:
             self._timestamps_host = (self.timestamps.detach().to("cpu", torch.float32).numpy(), self.timestamps)      # (once: a host sync)
         arrays = {"vm": np.stack([c.viewmatrix for c in cams]).astype(np.float32), "pm": np.stack([c.projmatrix for c in cams]).astype(np.float32),
+                  "c2w": np.stack([c.c2w for c in cams]).astype(np.float32),          # (threestudio convention: the rays of normal_depth_consistency)
                   "frames_t": self._timestamps_host[0][frames], "unit_frame": np.asarray(unit_frame, np.int32),
                   "ref_idx": np.asarray(ref_idx, np.int64), "rnd_idx": np.asarray(rnd_idx, np.int64),
                   "ref_pos": np.asarray(ref_pos, np.int32), "rnd_pos": np.asarray(rnd_pos, np.int32),
@@ -317,6 +335,10 @@ class DynamicStage:
             if self.inter_frame_reg > 0 and it % self.inter_frame_reg == 0:
                 terms["arap_reg_inter_frame"] = self.inter_frame_arap()
                 pairs.append((C(self.lam["arap_reg_inter_frame"], 0, it), terms["arap_reg_inter_frame"]))
+        if any(self._weight_is_set(k) for k in OPTIONAL_TERMS):
+            for k, v in self._optional_terms(out, b, it).items():
+                terms[k] = v if k not in terms else terms[k] + v
+                pairs.append((C(self.lam[k.split("/")[0]], 0, it), v))
         loss = weighted_sum(pairs)
         if not torch.is_tensor(loss):                   # (no term applied: nothing to differentiate, but the step's contract is a backward)
             loss = out["color"].sum() * 0.0
@@ -355,6 +377,72 @@ class DynamicStage:
                 terms["overflow_skipped"] = torch.tensor(float(self.overflow_skipped))      # numeric like every other term
         return {"loss": loss.detach(), **terms}
 
+    def _optional_terms(self, out, b, it):
+        """The terms of OPTIONAL_TERMS that have a weight, as the reference writes them (system/sugar_4dgen.py:181-300), on the reference
+        renderer's images of this step's views (renderer.compose_outputs).  Plain torch operators (boolean-mask gathers synchronise): these
+        terms are off in the shipped configuration and are not part of the measured path.  Keys: "<term>/ref", "<term>/zero123" -- the
+        reference evaluates the regularisers once per substep over that substep's views and adds the substeps' losses."""
+        import torch.nn.functional as F_
+
+        from . import renderer as R
+        from .static_stage import tv_loss
+
+        on = self._weight_is_set
+        H, W = self.r.H, self.r.W
+        rays_o = rays_d = None
+        if on("normal_depth_consistency"):
+            dirs = R.ray_directions(H, W, 0.5 * H / self.ref_camera.tanfov, device=self.dev)      # data/temporal_image.py: get_ray_directions + get_rays
+            rays_o, rays_d = R.rays(dirs, b["c2w"])
+        img = R.compose_outputs(out["color"], out["depth"], out["alpha"], rays_o, rays_d)
+        res = {}
+        groups = [("ref", b["ref_idx"]), ("zero123", b["rnd_idx"])]
+        for name, idx in groups:
+            if idx.numel() == 0:
+                continue
+            sel = {k: v.index_select(0, idx) for k, v in img.items()}
+            if on("normal_smooth"):                                              # :236-246
+                n = sel["comp_normal"]
+                res[f"normal_smooth/{name}"] = (n[:, 1:] - n[:, :-1]).square().mean() + (n[:, :, 1:] - n[:, :, :-1]).square().mean()
+            for k, key in (("rgb_tv", "comp_rgb"), ("depth_tv", "comp_depth"), ("normal_tv", "comp_normal")):    # :248-266
+                if on(k):
+                    res[f"{k}/{name}"] = tv_loss(sel[key].permute(0, 3, 1, 2))
+            if on("normal_depth_consistency"):                                   # :268-282
+                rn, rd = sel["comp_normal"] * 2 - 1, sel["comp_normal_from_dist"] * 2 - 1
+                res[f"normal_depth_consistency/{name}"] = (1 - (rn.unsqueeze(-2) @ rd.unsqueeze(-1))).mean()
+            if on("obj_centric"):                                                # :292-300 (the step's deformed meshes)
+                vx = out["vxyz"]
+                res[f"obj_centric/{name}"] = vx[..., 0].mean().abs() + vx[..., 1].mean().abs()
+        if b["n_ref"]:
+            sel = {k: v.index_select(0, b["ref_idx"]) for k, v in img.items()}
+            gt_mask = self.ref_masks.index_select(0, b["fidx_ref"]) > 0.5                    # [n,H,W,1] bool
+            if on("depth") or on("depth_rel"):
+                gt = self.ref_depths.index_select(0, b["fidx_ref"])
+                valid_gt, valid_pred = gt[gt_mask], sel["comp_depth"][gt_mask]
+                if on("depth"):                                                  # :181-192: least-squares scale / shift of the ground truth
+                    with torch.no_grad():
+                        A = torch.stack([valid_gt, torch.ones_like(valid_gt)], dim=-1)
+                        X = torch.linalg.lstsq(A, valid_pred.unsqueeze(1)).solution
+                        fit = (A @ X)
+                    res["depth/ref"] = F_.mse_loss(fit, valid_pred.unsqueeze(1))
+                if on("depth_rel"):                                              # :194-200: 1 - Pearson correlation (torchmetrics.PearsonCorrCoef)
+                    x, y = valid_pred - valid_pred.mean(), valid_gt - valid_gt.mean()
+                    res["depth_rel/ref"] = 1 - (x * y).sum() / (x.square().sum().sqrt() * y.square().sum().sqrt())
+            if on("normal"):                                                     # :202-213
+                m = gt_mask.squeeze(-1)
+                gt_n = 1 - 2 * self.ref_normals.index_select(0, b["fidx_ref"])[m]
+                pr_n = 2 * sel["comp_normal"][m] - 1
+                res["normal/ref"] = 1 - F_.cosine_similarity(pr_n, gt_n).mean()
+            if on("laplacian_smoothing"):                                        # :227-230
+                res["laplacian_smoothing/ref"] = self.laplacian_smoothing(out["vxyz"])
+            if on("ref_xyz"):                                                    # :286-290: the mesh at t = 0 against the rest mesh
+                from . import ops
+
+                dx, dr, ds, do = self.net.node_outputs(self.nodes, torch.zeros(1, device=self.dev))
+                x0, _ = ops.skin_vertices(self.r.graph, dx[0], dr[0], None if ds is None else ds[0], None if do is None else do[0],
+                                          self.r.method_name, grad_mode=self.r.grad_mode)
+                res["ref_xyz/ref"] = (x0 - self.r.graph.verts).abs().mean()
+        return res
+
     def state_for_checkpoint(self):
         """Parameters as a replicated AdamW would hold them (the sharded optimiser defers the weight decay of the HexPlane
         texels no node touches: distributed.ShardedAdamW.materialize)."""
@@ -389,11 +477,11 @@ class DynamicStage:
         not part of this loop."""
         loss = dict(system_cfg.get("loss", {}))
         lam = {k[len("lambda_"):]: v for k, v in loss.items() if k.startswith("lambda_")}
-        unknown = {k for k, v in lam.items() if k not in LAMBDA and v not in (0, 0.0, None)}
+        unknown = {k for k, v in lam.items() if k not in LAMBDA and k not in OPTIONAL_TERMS and v not in (0, 0.0, None)}
         if unknown:
             raise NotImplementedError(f"loss terms with a non-zero weight that this loop does not compute: {sorted(unknown)}")
         freq, geo = system_cfg.get("freq", {}), system_cfg.get("geometry", {})
-        args = dict(lambdas={k: v for k, v in lam.items() if k in LAMBDA},
+        args = dict(lambdas={k: v for k, v in lam.items() if k in LAMBDA or (k in OPTIONAL_TERMS and v not in (0, 0.0, None))},
                     milestone_arap_reg=int(freq.get("milestone_arap_reg", 100)), inter_frame_reg=int(freq.get("inter_frame_reg", 0)),
                     num_inter_frames=int(system_cfg.get("num_inter_frames", 10)),
                     length_inter_frames=float(system_cfg.get("length_inter_frames", 0.1)),

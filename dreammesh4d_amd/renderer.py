@@ -117,6 +117,27 @@ def _where_detached(x, mask):
     return torch.where(mask, x, x.detach())
 
 
+def compose_outputs(color, depth, alpha, rays_o=None, rays_d=None):
+    """The reference renderer's image-space epilogue (…temporal.py:180-229) on the raw rasterizer images color [B,6,H,W] (rgb | blended
+    normals), depth, alpha [B,1,H,W]: ``comp_rgb``, ``comp_normal``, ``comp_depth``, ``comp_mask`` and, with rays, ``comp_normal_from_dist``
+    ([B,H,W,.]); gradients of depth / normals only where alpha > 0.99 (``x[~mask] = x[~mask].detach()``)."""
+    B, _, H, W = color.shape
+    mask = alpha > 0.99
+    depth = _where_detached(depth, mask)                          # …temporal.py:180-181
+    mask3 = mask.expand(B, 3, H, W)
+    res = {}
+    if rays_d is not None:
+        xyz = rays_o + depth.permute(0, 2, 3, 1) * rays_d          # :187
+        nd = F.normalize(depth_to_normal(xyz.permute(0, 3, 1, 2)), dim=1)
+        res["comp_normal_from_dist"] = _where_detached(nd * 0.5 * alpha + 0.5, mask3).permute(0, 2, 3, 1)
+    n = F.normalize(color[:, 3:], dim=1)                          # :212-217
+    res["comp_normal"] = _where_detached(n * 0.5 * alpha + 0.5, mask3).permute(0, 2, 3, 1)
+    res["comp_rgb"] = color[:, :3].clamp(0, 1).permute(0, 2, 3, 1)
+    res["comp_depth"] = depth.permute(0, 2, 3, 1)
+    res["comp_mask"] = alpha.permute(0, 2, 3, 1)
+    return res
+
+
 class DiffGaussianTemporal:
     """The reference's ``diff-sugar-rasterizer-temporal`` renderer over a ``sugar.DynamicSuGaR`` geometry.
 
@@ -170,20 +191,9 @@ class DiffGaussianTemporal:
                                  g.get_points_rgb(), w2c, full, torch.cat([bg, bg]), frame_index=frame_index,
                                  means2D=torch.stack(vsp))
         g._deformed_vert_positions = out["vxyz"]                      # read by the mesh regularisers of the system
-        color, depth, alpha = out["color"], out["depth"], out["alpha"]
-        mask = alpha > 0.99
-        depth = _where_detached(depth, mask)                          # …temporal.py:180-181
-        mask3 = mask.expand(B, 3, H, W)
-        res = {}
-        if batch.get("rays_d") is not None:
-            xyz = batch["rays_o"].to(g.device) + depth.permute(0, 2, 3, 1) * batch["rays_d"].to(g.device)   # :187
-            nd = F.normalize(depth_to_normal(xyz.permute(0, 3, 1, 2)), dim=1)
-            res["comp_normal_from_dist"] = _where_detached(nd * 0.5 * alpha + 0.5, mask3).permute(0, 2, 3, 1)
-        n = F.normalize(color[:, 3:], dim=1)                          # :212-217
-        res["comp_normal"] = _where_detached(n * 0.5 * alpha + 0.5, mask3).permute(0, 2, 3, 1)
-        res["comp_rgb"] = color[:, :3].clamp(0, 1).permute(0, 2, 3, 1)
-        res["comp_depth"] = depth.permute(0, 2, 3, 1)
-        res["comp_mask"] = alpha.permute(0, 2, 3, 1)
+        has_rays = batch.get("rays_d") is not None
+        res = compose_outputs(out["color"], out["depth"], out["alpha"], batch["rays_o"].to(g.device) if has_rays else None,
+                              batch["rays_d"].to(g.device) if has_rays else None)
         res["viewspace_points"] = vsp
         res["visibility_filter"] = [out["radii"][b] > 0 for b in range(B)]
         res["radii"] = [out["radii"][b] for b in range(B)]
