@@ -246,8 +246,8 @@ class DynamicStage:
         """The step object for this batch shape (step.DynamicStep), or None where it does not apply: CPU tensors, a learnable
         static appearance, per-frame scales, a second gradient source on the network's parameters within the iteration (the
         inter-frame ARAP term: the step object installs its persistent buffers as `.grad`, it does not accumulate)."""
-        if not self.use_step_object or self.dev.type != "cuda" or self.inter_frame_reg > 0:
-            return None
+        if not self.use_step_object or self.dev.type != "cuda" or self.inter_frame_reg > 0 or self._weight_is_set("ref_xyz"):
+            return None            # (ref_xyz queries the network a second time, at t = 0: a second gradient source like the inter-frame ARAP term)
         key = (B, NF)
         if key not in self._step_objects:
             from .step import DynamicStep
