@@ -15,6 +15,13 @@
 #include "hexplane.hip"
 #include "deform_mlp.hip"
 
+// Probe builds (tools/build_variant.sh <name> "-DDM4D_PROBE_NODENET=n" nodenet.hip; never the product): 1 = no plane sampling (constant
+// features), 2 = no MLP, 3 = no [in][out] weight copies, 4 / 5 / 6 = bwd3 without its time columns / spatial texels / split-K reduction,
+// 7 / 8 / 9 = bwd2 without its parameter-gradient tiles / per-point products / zero fill: what each phase of the four launches costs.
+#ifndef DM4D_PROBE_NODENET
+#define DM4D_PROBE_NODENET 0
+#endif
+
 namespace dm4d {
 
 // 1024 threads: the query is a chain of dependent gathers (node -> 24 texels per feature), so the 2048 features of the tile are
@@ -22,20 +29,24 @@ namespace dm4d {
 // operators it replaces); the MLP is the 4-wave code of deform_mlp.hip, waves 4..15 leave after the barrier that publishes
 // the tile (a wave that has ended no longer counts at s_barrier).
 constexpr int kNodeFwdThreads = 1024;
-__global__ __launch_bounds__(kNodeFwdThreads) void k_nodenet_fwd(HexDesc hd, MlpDesc d, const float *__restrict__ nodes, const float *__restrict__ times,
+__global__ __launch_bounds__(kNodeFwdThreads) void k_nodenet_fwd(HexDesc hd, MlpDesc d_, const float *__restrict__ nodes, const float *__restrict__ times,
                                                                  float *__restrict__ feat, float *__restrict__ samples, float *__restrict__ Hs,
                                                                  float *__restrict__ Ys, float *out0, float *out1, float *out2, float *out3)
 {
     __shared__ float4 s_f[(kMaxIn / 4) * kXs];          // feat tile   [feature quad][row]
+    MlpDesc d = d_;
     const int tid = threadIdx.x, row0 = blockIdx.x * kRT, IN = d.IN;     // IN == hd.S * 32
     float *sf = reinterpret_cast<float *>(s_f);
     // 32 consecutive lanes = the 32 channels of one (row, scale) query: one 128-byte line per texel (channels-last planes)
     for (int e = tid; e < kRT * IN; e += kNodeFwdThreads) {
         const int r = e / IN, col = e % IN, row = row0 + r;
         float v = 0.f;
-        if (row < d.P) v = hex_feature(hd, nodes, times, row / hd.M, row % hd.M, col / kHexCh, col % kHexCh, feat, samples);
+        if (DM4D_PROBE_NODENET == 1) v = 1.0f + 1e-3f * (float)col;
+        else if (row < d.P) v = hex_feature(hd, nodes, times, row / hd.M, row % hd.M, col / kHexCh, col % kHexCh, feat, samples);
         sf[((col >> 2) * kXs + r) * 4 + (col & 3)] = v;
     }
+    if (DM4D_PROBE_NODENET == 2) return;
+    if (DM4D_PROBE_NODENET == 3) d.W0T = nullptr;
     if (tid >= 256) { __syncthreads(); return; }        // (their share of the barrier inside mlp_fwd_block that publishes s_f)
     mlp_fwd_block(d, (int)blockIdx.x, (int)gridDim.x, s_f, Hs, Ys, out0, out1, out2, out3);
 }
@@ -48,10 +59,10 @@ __global__ __launch_bounds__(256) void k_nodenet_bwd2(HexDesc hd, MlpDesc d, Nod
                                                       const float *g3)
 {
     unsigned b = blockIdx.x;
-    if (b < jb.wgrad_blocks) { mlp_wgrad_block(d, (int)(b % jb.wgrad_tiles), (int)(b / jb.wgrad_tiles), feat, Hs, Ys, g0, g1, g2, g3); return; }
+    if (b < jb.wgrad_blocks) { if (DM4D_PROBE_NODENET != 7) mlp_wgrad_block(d, (int)(b % jb.wgrad_tiles), (int)(b / jb.wgrad_tiles), feat, Hs, Ys, g0, g1, g2, g3); return; }
     b -= jb.wgrad_blocks;
-    if (b < jb.point_blocks) { hex_bwd_point(hd, b, g_feat, G); return; }
-    hex_zero(hg, b - jb.point_blocks);
+    if (b < jb.point_blocks) { if (DM4D_PROBE_NODENET != 8) hex_bwd_point(hd, b, g_feat, G); return; }
+    if (DM4D_PROBE_NODENET != 9) hex_zero(hg, b - jb.point_blocks);
 }
 
 __global__ __launch_bounds__(256) void k_nodenet_bwd3(HexDesc hd, MlpDesc d, NodeBwdJobs jb, const float *__restrict__ nodes,
@@ -60,15 +71,15 @@ __global__ __launch_bounds__(256) void k_nodenet_bwd3(HexDesc hd, MlpDesc d, Nod
 {
     unsigned b = blockIdx.x;
     if (b < (unsigned)pl.n_time) {
-        hex_bwd_time(hd, b, nodes, times, pl.n_time, pl.tp_scale, pl.tp_plane, pl.tp_col, pl.tp_off, pl.tp_item, G, hg);
+        if (DM4D_PROBE_NODENET != 4) hex_bwd_time(hd, b, nodes, times, pl.n_time, pl.tp_scale, pl.tp_plane, pl.tp_col, pl.tp_off, pl.tp_item, G, hg);
         return;
     }
     b -= (unsigned)pl.n_time;
     if (b < jb.plane_blocks) {
-        hex_bwd_spatial(hd, b, nodes, pl.n_spatial, pl.sp_scale, pl.sp_plane, pl.sp_texel, pl.sp_off, pl.sp_item, G, hg);
+        if (DM4D_PROBE_NODENET != 5) hex_bwd_spatial(hd, b, nodes, pl.n_spatial, pl.sp_scale, pl.sp_plane, pl.sp_texel, pl.sp_off, pl.sp_item, G, hg);
         return;
     }
-    mlp_reduce_block(d, mg, kKSplit, b - jb.plane_blocks);
+    if (DM4D_PROBE_NODENET != 6) mlp_reduce_block(d, mg, kKSplit, b - jb.plane_blocks);
 }
 
 }  // namespace dm4d

@@ -294,11 +294,20 @@ def test_systems_and_datamodules_by_name_drive_an_iteration_from_the_config_bloc
     assert {"rgb", "mask", "sds", "normal_consistency"} <= set(t0) and "arap_reg_key_frame" in t1
     assert all(torch.isfinite(v).all() for v in t1.values() if torch.is_tensor(v)) and st.global_step == 2
     assert any(not torch.equal(a, b) for a, b in zip(before, system.geometry._deformation.get_mlp_parameters()))
-    # a term the loop does not compute must not be silently dropped
+    # a term the loop cannot compute must not be silently dropped: lambda_depth needs the data module's ref_depth (round 5: the optional
+    # terms of system/sugar_4dgen.py:181-300 are computed when they have a weight AND their inputs), an unknown name is refused
     bad = copy.deepcopy(cfg)
     bad["loss"]["lambda_depth"] = 0.05
+    with pytest.raises(ValueError):
+        ts.find("sugar-4dgen-system")(bad, data, model=None)
+    bad = copy.deepcopy(cfg)
+    bad["loss"]["lambda_not_a_term_of_the_reference"] = 0.05
     with pytest.raises(NotImplementedError):
         ts.find("sugar-4dgen-system")(bad, data, model=None)
+    tv = copy.deepcopy(cfg)
+    tv["loss"]["lambda_rgb_tv"] = 1.0
+    tvs = ts.find("sugar-4dgen-system")(tv, data, model=None)
+    assert "rgb_tv/ref" in tvs.training_step()
     # ---- static stage by name
     scfg = copy.deepcopy(ts.resolve({"data": DATA, "system": STATIC_SYSTEM})["system"])
     scfg["geometry"]["surface_mesh_to_bind_path"] = mesh
