@@ -39,6 +39,7 @@ constexpr int kMaxOut = 8;
 constexpr int kMaxIn = 256;
 constexpr int kXs = 17;       // float4 stride of a feature quad in the LDS exchange tiles (16 rows + pad)
 constexpr int kKSplit = 8;    // row slices of the parameter-gradient products
+constexpr int kMaxTickets = 4 * (kMaxIn / 16 + 1) + 25 * kMaxHeads + 4;      // parameter-gradient tiles (rounded up to a multiple of 4)
 
 struct MlpDesc {
     int P, IN, n_heads;
@@ -50,6 +51,7 @@ struct MlpDesc {
     float *DY;                  // [n_heads][P][64]  dL/dy_k   (backward)
     float *DH;                  // [P][64]           dL/dh     (backward)
     float *partial;             // [kKSplit][partial_floats]
+    unsigned *tickets;          // [kMaxTickets]
 };
 
 struct MlpGrads {
@@ -180,13 +182,24 @@ __global__ __launch_bounds__(256) void k_mlp_fwd(MlpDesc d, const float *__restr
 }
 
 // ------------------------------------------------------------------------------------------ backward (activations)
-__global__ __launch_bounds__(256) void k_mlp_bwd(MlpDesc d, const float *__restrict__ Hs, const float *g0, const float *g1,
-                                                 const float *g2, const float *g3, float *__restrict__ g_feat)
+// `feat_sink(row, first feature, d feat of the lane's 4 consecutive features)`: what happens to a tile of dL/dfeat -- k_mlp_bwd stores
+// it; the fused node network (nodenet.hip, round 5) turns it into the HexPlane's per-point plane-product gradients on the spot
+struct StoreFeatGrad {
+    float *g_feat;
+    int IN;
+    __device__ __forceinline__ void operator()(const int row, const int col, const float4 v) const
+    {
+        *reinterpret_cast<float4 *>(g_feat + (size_t)row * IN + col) = v;
+    }
+};
+template <typename FeatSink>
+__device__ __forceinline__ void mlp_bwd_block(const MlpDesc &d, const int bx, const float *__restrict__ Hs, const float *g0, const float *g1,
+                                              const float *g2, const float *g3, const bool want_feat, const FeatSink &feat_sink)
 {
     __shared__ float4 s_dy[(kW / 4) * kXs];
     __shared__ float4 s_dh[(kW / 4) * kXs];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, i = lane & 15, kq = lane >> 4;
-    const int row0 = blockIdx.x * kRT, IN = d.IN;
+    const int row0 = bx * kRT, IN = d.IN;
     const int row = row0 + i;
     const int fo = 16 * w + 4 * kq;
     const float *gs[kMaxHeads] = {g0, g1, g2, g3};
@@ -233,7 +246,7 @@ __global__ __launch_bounds__(256) void k_mlp_bwd(MlpDesc d, const float *__restr
     s_dh[(4 * w + kq) * kXs + i] = to4(dh);
     __syncthreads();
     // d feat[r][in] = sum_o W0[o][in] dh[r][o]   (M tiles of 16 inputs, wave w takes tiles w, w + 4, ...)
-    if (g_feat) {
+    if (want_feat) {
         for (int mt = w; mt < IN / 16; mt += 4) {
             const float *__restrict__ Wrow = d.W0T + (size_t)(16 * mt + i) * kW + 4 * kq;   // A[m = i][k = o] = W0[o][16 mt + i]
             float4 wc[4];
@@ -244,20 +257,36 @@ __global__ __launch_bounds__(256) void k_mlp_bwd(MlpDesc d, const float *__restr
             a1 = mfma4(wc[1], s_dh[(4 + kq) * kXs + i], a1);
             a0 = mfma4(wc[2], s_dh[(8 + kq) * kXs + i], a0);
             a1 = mfma4(wc[3], s_dh[(12 + kq) * kXs + i], a1);
-            if (row < d.P) *reinterpret_cast<float4 *>(g_feat + (size_t)row * IN + 16 * mt + 4 * kq) = to4(a0 + a1);
+            if (row < d.P) feat_sink(row, 16 * mt + 4 * kq, to4(a0 + a1));
         }
     }
+}
+
+__global__ __launch_bounds__(256) void k_mlp_bwd(MlpDesc d, const float *__restrict__ Hs, const float *g0, const float *g1,
+                                                 const float *g2, const float *g3, float *__restrict__ g_feat)
+{
+    mlp_bwd_block(d, (int)blockIdx.x, Hs, g0, g1, g2, g3, g_feat != nullptr, StoreFeatGrad{g_feat, d.IN});
 }
 
 // ------------------------------------------------------------------------------------------ backward (parameters)
 // out[m][n] = sum_rows L[row][m] R[row][n] for one 16x16 tile of one parameter and one row slice.  Tiles, in
 // blockIdx.x order:  dW0 (L = dh, R = feat) 4 x (IN/16 + 1)  |  per head: dW1 (L = dy_k, R = relu(h)) 4 x 5,
 // dW2 (L = g_k, R = y_k) 1 x 5.  The last column tile of every group is the bias: R = 1.
+// `last` (optional, round 5): the reduction over the row slices inside this launch -- every slice block publishes its partial tile
+// (agent-scope release), draws a ticket of its tile, and the block that draws the last one sums the kKSplit partials of the tile IN
+// SLICE ORDER (the additions of mlp_reduce_block: bit-identical) straight into the gradient tensors.  8 KB of partials per tile: the
+// case cdna_hip_programming.md's split-K recipe calls worth it; it removes the reduce launch from the end of the step's chain.
+// DM4D_WGRAD_FINISH: 2 = write-through (sc1) partial stores + sc1 loads, no fence (the recipe's cheaper form); 1 = plain stores + one
+// agent-scope release per slice block and one acquire in the last arriver; 0 = no in-launch reduction (the caller launches k_mlp_reduce)
+#ifndef DM4D_WGRAD_FINISH
+#define DM4D_WGRAD_FINISH 2
+#endif
+struct WgradFinish { unsigned *tickets; const MlpGrads *g; };      // tickets[tile]: zeroed by an EARLIER launch of the stream
 __device__ __forceinline__ void mlp_wgrad_block(const MlpDesc &d, const int bx, const int by, const float *__restrict__ feat,
                                                 const float *__restrict__ Hs, const float *__restrict__ Ys, const float *g0,
-                                                const float *g1, const float *g2, const float *g3)
+                                                const float *g1, const float *g2, const float *g3, const WgradFinish *last = nullptr)
 {
-    __shared__ float s_part[3][64][5];
+    __shared__ float s_part[3][64][5];      // ([0][0][4]: the "this block reduces" flag of the in-launch reduction -- one LDS object, not two)
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, i = lane & 15, kq = lane >> 4;
     const float *gs[kMaxHeads] = {g0, g1, g2, g3};
     const int IN = d.IN, P = d.P;
@@ -322,11 +351,59 @@ __device__ __forceinline__ void mlp_wgrad_block(const MlpDesc &d, const int bx, 
             const float v = ((acc[j] + s_part[0][lane][j]) + s_part[1][lane][j]) + s_part[2][lane][j];
             const int m = 16 * mt + 4 * kq + j;     // D: row = 4 (lane >> 4) + j, column = lane & 15
             if (m >= Mdim) continue;
-            if (bias) {
-                if (i == 0) part[b_off + m] = v;
-            } else {
-                part[w_off + (size_t)m * Ndim + ncol] = v;
+            // (in-launch reduction: the partial leaves as a WRITE-THROUGH store -- an agent-scope relaxed atomic store lowers to
+            //  `global_store_dword ... sc1` -- so that no release fence is needed before the ticket)
+            float *dst = bias ? part + b_off + m : part + w_off + (size_t)m * Ndim + ncol;
+            if (bias && i != 0) continue;
+            if (last && DM4D_WGRAD_FINISH == 2) __hip_atomic_store(dst, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            else *dst = v;
+        }
+    }
+    if (!last) return;
+    // ---- in-launch reduction: publish, ticket, the last arriver sums (cdna_hip_programming.md, split-K recipe / Guideline 16) ----
+    if (w == 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (lane == 0) {
+            if (DM4D_WGRAD_FINISH == 1) {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             }
+            const unsigned ticket = __hip_atomic_fetch_add(last->tickets + bx, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const bool is_last = ticket == (unsigned)(kKSplit - 1);
+            if (is_last && DM4D_WGRAD_FINISH == 1) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            s_part[0][0][4] = is_last ? 1.f : 0.f;
+        }
+    }
+    __syncthreads();
+    if (s_part[0][0][4] == 0.f || w != 0) return;
+    {
+        const MlpGrads &g = *last->g;
+        const size_t n = partial_floats(d);
+        // the tile's parameter: the decode above, as pointers
+        float *Wg = nullptr, *Bg = nullptr;
+        if (bx < n0) { Wg = g.W0; Bg = g.b0; }
+        else {
+            const int k = (bx - n0) / 25, u = (bx - n0) % 25;
+            if (u < 20) { Wg = g.W1[k]; Bg = g.b1[k]; }
+            else { Wg = g.W2[k]; Bg = g.b2[k]; }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int m = 16 * mt + 4 * kq + j;
+            if (m >= Mdim || (bias && i != 0)) continue;
+            const size_t e = bias ? b_off + m : w_off + (size_t)m * Ndim + ncol;
+            float a = 0.f;
+            if (DM4D_WGRAD_FINISH == 2) {      // write-through partials are read back with sc1 loads (agent-scope relaxed atomic loads): past the L1
+                float pv[kKSplit];
+#pragma unroll
+                for (int sl = 0; sl < kKSplit; ++sl) pv[sl] = __hip_atomic_load(d.partial + (size_t)sl * n + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+                for (int sl = 0; sl < kKSplit; ++sl) a += pv[sl];
+            } else {
+                for (int sl = 0; sl < kKSplit; ++sl) a += d.partial[(size_t)sl * n + e];
+            }
+            if (bias) { if (Bg) Bg[m] = a; }
+            else if (Wg) Wg[(size_t)m * Ndim + ncol] = a;
         }
     }
 }
@@ -377,6 +454,7 @@ static size_t scratch_floats(int P, int in_dim, int n_heads, size_t *dy_off, siz
     n += (size_t)P * kW;
     if (part_off) *part_off = n;
     n += (size_t)kKSplit * ((size_t)kW * in_dim + kW + (size_t)n_heads * (kW * kW + kW + kMaxOut * kW + kMaxOut));
+    n += kMaxTickets;        // the tiles' arrival tickets of the in-launch reduction (uint32; behind the partials' upper bound)
     return n;
 }
 
@@ -408,6 +486,7 @@ static int fill_mlp(MlpDesc &d, int P, const dm4d_mlp_weights *w, void *scratch)
     d.DY = s ? s + dy_off : nullptr;
     d.DH = s ? s + dh_off : nullptr;
     d.partial = s ? s + part_off : nullptr;
+    d.tickets = s ? reinterpret_cast<unsigned *>(s + scratch_floats(P, d.IN, d.n_heads, nullptr, nullptr, nullptr) - kMaxTickets) : nullptr;
     return DM4D_OK;
 }
 

@@ -12,6 +12,8 @@
 // chain"): what this buys is four launches and two dependent round trips, not bandwidth.
 //
 // Reference: C/geometry/deformation.py:88-305,430-436 queried by C/geometry/dynamic_sugar.py:420-431.
+#include <stdlib.h>
+
 #include "hexplane.hip"
 #include "deform_mlp.hip"
 
@@ -51,7 +53,75 @@ __global__ __launch_bounds__(kNodeFwdThreads) void k_nodenet_fwd(HexDesc hd, Mlp
     mlp_fwd_block(d, (int)blockIdx.x, (int)gridDim.x, s_f, Hs, Ys, out0, out1, out2, out3);
 }
 
-struct NodeBwdJobs { unsigned point_blocks, wgrad_tiles, wgrad_blocks, zero_blocks, plane_blocks, reduce_blocks; };
+struct NodeBwdJobs { unsigned point_blocks, wgrad_tiles, wgrad_blocks, zero_blocks, plane_blocks, reduce_blocks, mlp_blocks; };
+
+// ---- round 5: the backward as TWO launches (the three below stay: DM4D_NODENET_BWD3=1, the A/B switch) ----
+//   k_nodenet_bwdA   MLP backward of 16 rows (dy_k, dx, dh) whose dL/dfeat tile goes straight on to the HexPlane's per-point
+//                    plane-product gradients G (the lane that holds four consecutive channels of a row reads its six saved samples as
+//                    float4s and rewrites them in place: hex_bwd_point's products in its order) | zero fill of the time planes | the
+//                    parameter-gradient tiles' arrival tickets cleared
+//   k_nodenet_bwdB   parameter-gradient tiles with the row-slice reduction inside the launch (mlp_wgrad_block's last-arriving slice) |
+//                    time-plane columns | spatial texels
+// Measured on the bench scene (tools/build_variant.sh probes, profiles/r05_nodenet_probe.txt): of the 67 us of k_mlp_bwd (12) ->
+// bwd2 (21) -> bwd3 (34) the per-point products and the split-K reduction cost ~4 and ~0 us of kernel time but each holds a launch
+// boundary and a dependent round trip on the step's serial chain; bwd3's 34 us are its two gathers (9 + 11) on a ~14 us floor.
+struct PointGrad {
+    float *G;           // [B][M][S][6][32]: the forward's samples, rewritten in place
+    int S;
+    __device__ __forceinline__ void operator()(const int row, const int col, const float4 g) const
+    {
+        const int s = col / kHexCh, c = col % kHexCh;
+        float *o = G + (((size_t)row * S + s) * kHexPlanes) * kHexCh + c;
+        float4 v[kHexPlanes], pre[kHexPlanes], suf[kHexPlanes];
+#pragma unroll
+        for (int p = 0; p < kHexPlanes; ++p) v[p] = *reinterpret_cast<const float4 *>(o + (size_t)p * kHexCh);
+        pre[0] = make_float4(1.f, 1.f, 1.f, 1.f);
+#pragma unroll
+        for (int p = 1; p < kHexPlanes; ++p)
+            pre[p] = make_float4(pre[p - 1].x * v[p - 1].x, pre[p - 1].y * v[p - 1].y, pre[p - 1].z * v[p - 1].z, pre[p - 1].w * v[p - 1].w);
+        suf[kHexPlanes - 1] = make_float4(1.f, 1.f, 1.f, 1.f);
+#pragma unroll
+        for (int p = kHexPlanes - 2; p >= 0; --p)
+            suf[p] = make_float4(suf[p + 1].x * v[p + 1].x, suf[p + 1].y * v[p + 1].y, suf[p + 1].z * v[p + 1].z, suf[p + 1].w * v[p + 1].w);
+#pragma unroll
+        for (int p = 0; p < kHexPlanes; ++p)
+            *reinterpret_cast<float4 *>(o + (size_t)p * kHexCh) =
+                make_float4(g.x * (pre[p].x * suf[p].x), g.y * (pre[p].y * suf[p].y), g.z * (pre[p].z * suf[p].z), g.w * (pre[p].w * suf[p].w));
+    }
+};
+
+__global__ __launch_bounds__(256) void k_nodenet_bwdA(HexDesc hd, MlpDesc d, NodeBwdJobs jb, float *__restrict__ G, HexGrads hg,
+                                                      const float *__restrict__ Hs, const float *g0, const float *g1, const float *g2,
+                                                      const float *g3)
+{
+    unsigned b = blockIdx.x;
+    if (b < jb.mlp_blocks) { mlp_bwd_block(d, (int)b, Hs, g0, g1, g2, g3, true, PointGrad{G, hd.S}); return; }
+    b -= jb.mlp_blocks;
+    if (b < jb.zero_blocks) { hex_zero(hg, b); return; }
+    for (int t = threadIdx.x; t < kMaxTickets; t += 256) d.tickets[t] = 0u;
+}
+
+__global__ __launch_bounds__(256) void k_nodenet_bwdB(HexDesc hd, MlpDesc d, NodeBwdJobs jb, const float *__restrict__ nodes,
+                                                      const float *__restrict__ times, HexPlan pl, const float *__restrict__ G, HexGrads hg,
+                                                      MlpGrads mg, const float *__restrict__ feat, const float *__restrict__ Hs,
+                                                      const float *__restrict__ Ys, const float *g0, const float *g1, const float *g2,
+                                                      const float *g3)
+{
+    unsigned b = blockIdx.x;
+    if (b < jb.wgrad_blocks) {
+        // slice-major: the eight slices of a tile are eight blocks apart in launch order only by the tile count, i.e. they start together
+        const WgradFinish fin = {d.tickets, &mg};
+        mlp_wgrad_block(d, (int)(b % jb.wgrad_tiles), (int)(b / jb.wgrad_tiles), feat, Hs, Ys, g0, g1, g2, g3, DM4D_WGRAD_FINISH ? &fin : nullptr);
+        return;
+    }
+    b -= jb.wgrad_blocks;
+    if (b < (unsigned)pl.n_time) {
+        hex_bwd_time(hd, b, nodes, times, pl.n_time, pl.tp_scale, pl.tp_plane, pl.tp_col, pl.tp_off, pl.tp_item, G, hg);
+        return;
+    }
+    b -= (unsigned)pl.n_time;
+    hex_bwd_spatial(hd, b, nodes, pl.n_spatial, pl.sp_scale, pl.sp_plane, pl.sp_texel, pl.sp_off, pl.sp_item, G, hg);
+}
 
 __global__ __launch_bounds__(256) void k_nodenet_bwd2(HexDesc hd, MlpDesc d, NodeBwdJobs jb, const float *__restrict__ g_feat, float *__restrict__ G,
                                                       HexGrads hg, const float *__restrict__ feat, const float *__restrict__ Hs,
@@ -165,6 +235,30 @@ int dm4d_nodenet_backward(int32_t S, int32_t M, int32_t B, const int32_t *res, c
     if (flags & DM4D_HEX_KEEP_SPATIAL)
         for (int s = 0; s < S; ++s)
             for (int p : {0, 1, 3}) hg.keep_mask |= 1ull << (s * kHexPlanes + p);
+    static const bool three_launches = getenv("DM4D_NODENET_BWD3") && atoi(getenv("DM4D_NODENET_BWD3")) != 0;      // (A/B switch: rounds 3-4's chain)
+    if (!three_launches) {
+        NodeBwdJobs jb;
+        memset(&jb, 0, sizeof(jb));
+        jb.mlp_blocks = (unsigned)((P + kRT - 1) / kRT);
+        jb.zero_blocks = kHexZeroBlocks * (unsigned)hg.n;
+        jb.wgrad_tiles = (unsigned)(4 * (d.IN / 16 + 1) + 25 * d.n_heads);
+        jb.wgrad_blocks = jb.wgrad_tiles * kKSplit;
+        jb.plane_blocks = (unsigned)(((size_t)(n_spatial > 0 ? n_spatial : 0) * kHexCh + 255) / 256);
+        if ((int)jb.wgrad_tiles > kMaxTickets) { set_error("nodenet: %u parameter-gradient tiles", jb.wgrad_tiles); return DM4D_ERR_UNSUPPORTED; }
+        hipLaunchKernelGGL(k_nodenet_bwdA, dim3(jb.mlp_blocks + jb.zero_blocks + 1), dim3(256), 0, st, hd, d, jb, (float *)samples, hg, h_save,
+                           g[0], g[1], g[2], g[3]);
+        DM4D_HIP_CHECK(hipGetLastError());
+        HexPlan pl = {n_spatial, n_time < 0 ? 0 : n_time, sp_scale, sp_plane, sp_texel, sp_off, sp_item, tp_scale, tp_plane, tp_col, tp_off, tp_item};
+        hipLaunchKernelGGL(k_nodenet_bwdB, dim3(jb.wgrad_blocks + (unsigned)pl.n_time + jb.plane_blocks), dim3(256), 0, st, hd, d, jb, nodes, times,
+                           pl, (const float *)samples, hg, mg, feat, h_save, y_save, g[0], g[1], g[2], g[3]);
+        DM4D_HIP_CHECK(hipGetLastError());
+        if (!DM4D_WGRAD_FINISH) {
+            const size_t np = partial_floats(d);
+            hipLaunchKernelGGL(k_mlp_reduce, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, st, d, mg, kKSplit);
+            DM4D_HIP_CHECK(hipGetLastError());
+        }
+        return DM4D_OK;
+    }
     // 1: dL/dy_k, dL/dh, dL/dfeat
     hipLaunchKernelGGL(k_mlp_bwd, dim3((P + kRT - 1) / kRT), dim3(256), 0, st, d, h_save, g[0], g[1], g[2], g[3], g_feat);
     DM4D_HIP_CHECK(hipGetLastError());
