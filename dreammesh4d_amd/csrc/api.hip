@@ -233,9 +233,7 @@ int dm4d_rasterize_render(const dm4d_raster_settings *s, const dm4d_raster_input
     d.out_alpha = out_alpha;
     rc = launch_scatter(d, st);
     if (rc) return rc;
-    rc = launch_tile_sort(d, st);
-    if (rc) return rc;
-    return launch_render_fwd(d, st);
+    return launch_sort_and_forward(d, st);
 }
 
 int dm4d_rasterize_backward(const dm4d_raster_settings *s, const dm4d_raster_inputs *in, const int32_t *radii,

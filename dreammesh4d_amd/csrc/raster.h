@@ -442,6 +442,12 @@ DM4D_HD static inline ViewCtx resolve(const BatchDesc &d, int b)
     return c;
 }
 
+// division of labour of the tile sort's two variants (raster_bin.hip) -- the forward blend needs it too (raster_render.hip): the
+// 256-thread variant sorts every tile of <= kSortSmallCap entries in LDS (and, fused, blends it), the 1024-thread variant the larger
+// ones among the first kLargeRanks ranks of a view's longest-first tile order
+constexpr int kSortSmallCap = 2048;
+constexpr int kLargeRanks = 64;
+
 // ---- launchers (defined in the .hip files); every launch covers the d.B views of the batch ----
 int launch_preprocess(const BatchDesc &d, hipStream_t st);
 int launch_colscan(const BatchDesc &d, hipStream_t st);
@@ -452,6 +458,7 @@ int launch_tile_sort(const BatchDesc &d, hipStream_t st);
 struct AuxStream { hipStream_t st, st2; hipEvent_t fork, join, fork2, join2; bool ok; bool pending2; };
 AuxStream *aux_stream();
 int launch_render_fwd(const BatchDesc &d, hipStream_t st);
+int launch_sort_and_forward(const BatchDesc &d, hipStream_t st);      // K4 + K5 of a forward (every caller runs them back to back)
 int launch_render_fwd_long(const BatchDesc &d, hipStream_t st);   // the long cells of the large tiles (earlylist)
 int launch_render_bwd(const BatchDesc &d, hipStream_t st);
 int launch_gather_bwd(const BatchDesc &d, hipStream_t st);

@@ -104,7 +104,8 @@ int set_sort_trace_buffer(void *dev_ptr)
 }
 constexpr int kSortPerThread = 8;        // keys a thread holds in registers: LDS capacity = 8 x threads
 constexpr int kSortSmall = 256, kSortLarge = 1024;   // threads of the two variants (tiles <= 2048 / <= 8192 entries)
-constexpr int kLargeRanks = 64;          // tiles per view (the first ranks of K3's longest-first order) the large variant covers
+static_assert(kSortPerThread * kSortSmall == kSortSmallCap, "raster.h: the small variant's LDS capacity");
+// (kLargeRanks, raster.h: tiles per view -- the first ranks of K3's longest-first order -- the large variant covers)
 constexpr int kBins = 1024;
 
 // Split the sorted tile list into the sixteen cell lists (stable compaction by the Gaussian's cell block,
@@ -391,6 +392,12 @@ __device__ __forceinline__ void finish_tile(const ViewCtx &c, int tile, uint32_t
     }
 }
 
+// (Round 5, measured and removed: the 256-thread variant going straight on to the FORWARD BLEND of its tile -- wave w = quadrant w, the
+// code of k_render_fwd (raster_fwd.h), in the LDS the sort no longer needs.  Bit-identical images, one launch and one cross-stream
+// hand-over less -- and the fused kernel takes exactly as long as sort + hand-over + forward (255 us against 71 + 12 + 170,
+// profiles/r05_timeline_fused_sort_forward.txt): both halves are VALU-bound (74 % / 96 % busy), so there is nothing for them to hide in
+// each other, a four-wave workgroup holds its slots until its slowest quadrant is done, and the large tiles' quadrants, launched on
+// their own behind the large variant, delay the long cells' kernel: the backward starts 28 us LATER.)
 template <int kSortThreads>
 __global__ __launch_bounds__(kSortThreads, kSortThreads == 256 ? 6 : 4) void k_tile_sort(BatchDesc d)
 {
@@ -677,6 +684,14 @@ int launch_tile_sort(const BatchDesc &d, hipStream_t st)
         DM4D_HIP_CHECK(hipStreamWaitEvent(st, a->join, 0));
     }
     return DM4D_OK;
+}
+
+// K4 + K5 of a forward (every caller runs them back to back)
+int launch_sort_and_forward(const BatchDesc &d, hipStream_t st)
+{
+    int rc = launch_tile_sort(d, st);
+    if (rc) return rc;
+    return launch_render_fwd(d, st);
 }
 
 }  // namespace dm4d

@@ -160,8 +160,7 @@ int dm4d_views_forward(const dm4d_views *v, dm4d_stream_t stream)
     if ((rc = launch_preprocess(d, st))) return rc;
     if ((rc = launch_colscan(d, st))) return rc;
     if ((rc = launch_scatter(d, st))) return rc;
-    if ((rc = launch_tile_sort(d, st))) return rc;
-    return launch_render_fwd(d, st);
+    return launch_sort_and_forward(d, st);
 }
 
 static int views_backward_impl(const dm4d_views *v, const dm4d_views_grads *gr, dm4d_stream_t stream, bool rgb_only);
@@ -290,8 +289,7 @@ int dm4d_gviews_forward(const dm4d_gviews *v, dm4d_stream_t stream)
     if ((rc = launch_preprocess(d, st))) return rc;
     if ((rc = launch_colscan(d, st))) return rc;
     if ((rc = launch_scatter(d, st))) return rc;
-    if ((rc = launch_tile_sort(d, st))) return rc;
-    return launch_render_fwd(d, st);
+    return launch_sort_and_forward(d, st);
 }
 
 int dm4d_gviews_backward(const dm4d_gviews *v, const dm4d_gviews_grads *gr, dm4d_stream_t stream)

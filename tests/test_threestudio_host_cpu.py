@@ -163,8 +163,14 @@ def test_stage_loss_weights_come_from_the_config_block():
         assert seen["lambdas"] == {"rgb": 1.5, "mask": [0, 1.0, 2.0, 10], "sds_zero123": 0.3}
         assert (seen["milestone_arap_reg"], seen["inter_frame_reg"], seen["num_inter_frames"], seen["length_inter_frames"]) == (7, 2, 5, 0.25)
         assert seen["deformation_lr"] == 1e-3 and seen["grid_lr"] == [0, 1e-2, 1e-3, 100]
+        # round 5: the reference's optional terms (OPTIONAL_TERMS) are handed to the stage when they have a weight; a name the reference
+        # does not have is still refused
+        seen.clear()
+        with pytest.raises(_Stop):
+            DynamicStage.from_cfg({"loss": {"lambda_depth": 0.05, "lambda_rgb_tv": 0.0}}, *[None] * 8)
+        assert seen["lambdas"] == {"depth": 0.05}
         with pytest.raises(NotImplementedError):
-            DynamicStage.from_cfg({"loss": {"lambda_depth": 0.05}}, *[None] * 8)
+            DynamicStage.from_cfg({"loss": {"lambda_not_a_reference_term": 0.05}}, *[None] * 8)
     finally:
         DynamicStage.__init__ = real
     assert set(LAMBDA) == {"sds_zero123", "rgb", "mask", "normal_consistency", "arap_reg_key_frame", "arap_reg_inter_frame"}
