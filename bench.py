@@ -306,11 +306,11 @@ def main():
         V = len(wl.sc["verts"])
         b_view = 2 * ((104 * N + 84 * D_mean + 28 * H * W) + (228 * N + 48 * D_mean + 40 * H * W)) + 40 * V + 28 * N + 12288 * N_NODES
         # HBM traffic of the dominant kernel per launch from the committed PMC passes of this same workload
-        # (profiles/r04_pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs, FETCH_SIZE x2
+        # (profiles/r05_pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs, FETCH_SIZE x2
         # per MI355X_MICROARCH.md's gfx950 correction).  The workload is seeded, so it is launch-invariant.
         traffic = None
         try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r04_pmc_traffic.json")))
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r05_pmc_traffic.json")))
             # the timed kernel: the lean variant (one launch takes the wide blocks and the quadrants).  (Until r02's last
             # refresh this summed every k_render_bwd* entry of the file -- the non-lean variant of the roofline_full leg
             # included -- and so reported twice the kernel's traffic.)
@@ -413,7 +413,9 @@ def dynamic_stage_iterations(wl, dev, n=50):
     torch.cuda.synchronize(dev)
     dt = time.perf_counter() - t0
     return {"dynamic_stage_iters_per_sec": round(n / dt, 3), "dynamic_stage_ms_per_iteration": round(1e3 * dt / n, 2),
-            "dynamic_stage_note": "8 views/iteration, full-size Zero123 fp16 with random weights, mesh normal consistency + key-frame ARAP, AdamW step included"}
+            "dynamic_stage_note": "8 views/iteration, full-size Zero123 fp16 with random weights, mesh normal consistency + key-frame ARAP, AdamW step "
+                                  "(the reference's effective betas (0.9, 0.999), no decay) included; no backward of the normal pass: no loss of the shipped "
+                                  "configuration reads the normal image (the headline step above keeps both passes' backward)"}
 
 
 _ZERO123 = {}
