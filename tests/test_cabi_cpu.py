@@ -179,3 +179,23 @@ def test_round3_entry_points_validate_on_the_host():
     assert L.dm4d_quat_to_matrix_forward(4, None, p, None) == -1
     assert L.dm4d_quat_to_matrix_backward_pypose(4, p, p, None, None) == -1
     assert L.dm4d_quat_to_matrix_forward(0, None, None, None) == 0 and L.dm4d_quat_to_matrix_backward_pypose(0, None, None, None, None) == 0
+
+
+def test_bench_gpus_flag_is_honoured_or_refused():
+    """`python bench.py --gpus N` with N > 1 and no launcher starts its own ranks (tests/test_dynamic_stage_gpu.py); where fewer HIP
+    devices than ranks are visible -- here: none -- it must refuse loudly instead of rendering on one device and printing n_gpus = 1
+    (round 4's behaviour: `--gpus` was parsed and never read)."""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "DM4D_BENCH_BACKEND")}
+    import torch
+
+    if torch.cuda.is_available() and torch.cuda.device_count() >= 2:
+        return
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--steps", "1"], capture_output=True, text=True, timeout=300, env=env, cwd=root)
+    assert r.returncode != 0 and "HIP device" in (r.stdout + r.stderr)
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", "0"], capture_output=True, text=True, timeout=300, env=env, cwd=root)
+    assert r.returncode != 0
