@@ -24,6 +24,7 @@ namespace dm4d {
 constexpr int kHexCh = 32;        // output_coordinate_dim (deformation.py:64)
 constexpr int kHexPlanes = 6;     // (x,y) (x,z) (x,t) (y,z) (y,t) (z,t)
 constexpr int kHexMaxScales = 8;
+constexpr int kHexMaxFrames = 16;   // frames (distinct timestamps) per call
 __constant__ int c_axis0[6] = {0, 0, 0, 1, 1, 2};
 __constant__ int c_axis1[6] = {1, 2, 3, 2, 3, 3};
 static const int c_axis0_host[6] = {0, 0, 0, 1, 1, 2}, c_axis1_host[6] = {1, 2, 3, 2, 3, 3};
@@ -178,9 +179,17 @@ __device__ __forceinline__ void hex_bwd_spatial(const HexDesc &d, const unsigned
         xn[3] = 0.f;
         const Sample q = plane_sample(d, s, p, xn);
         const float w = corner == 0 ? q.w00 : corner == 1 ? q.w01 : corner == 2 ? q.w10 : q.w11;
+        // the frames' values are REQUESTED together and added in frame order afterwards: as a loop with a run-time trip count this
+        // was one global round trip per frame, one after the other (the compiler issues a load, waits, adds) -- the whole cost of
+        // this job (profiles/r05_nodenet_probe.txt: 11 us with the gathers, 0 without)
+        float gv[kHexMaxFrames];
+#pragma unroll
+        for (int f = 0; f < kHexMaxFrames; ++f)
+            gv[f] = f < d.B ? G[((((size_t)f * d.M + m) * d.S + s) * kHexPlanes + p) * kHexCh + c] : 0.f;
         float gs = 0.f;
-        for (int f = 0; f < d.B; ++f)
-            gs += G[((((size_t)f * d.M + m) * d.S + s) * kHexPlanes + p) * kHexCh + c];
+#pragma unroll
+        for (int f = 0; f < kHexMaxFrames; ++f)
+            if (f < d.B) gs += gv[f];
         acc += w * gs;
     }
     const size_t HW = (size_t)d.res[s][c_axis0[p]] * d.res[s][c_axis1[p]];
@@ -194,7 +203,6 @@ __device__ __forceinline__ void hex_bwd_spatial(const HexDesc &d, const unsigned
 // order, and the column's distinct time rows (<= 2 B: the two time texels of every frame, merged in a fixed
 // order) are then combined from the per-frame sums.  Deterministic.
 //   tp_scale[u], tp_plane[u], tp_col[u]; tp_off[U+1], tp_item[] = node * 2 + corner (column corner)
-constexpr int kHexMaxFrames = 16;
 __device__ __forceinline__ void hex_bwd_time(const HexDesc &d, const unsigned bid, const float *__restrict__ nodes,
                                              const float *__restrict__ times, int U,
                                              const int32_t *__restrict__ tp_scale,
