@@ -162,3 +162,80 @@ def test_abi_of_round_4_still_steps():
     _lib.check(_lib.lib().dm4d_adamw_message(C.byref(seg), C.byref(a), 1.0, torch.cuda.current_stream(dev).cuda_stream), "dm4d_adamw_message")
     torch.cuda.synchronize()
     assert float(st) == 1.0 and float((p - ref.detach()).abs().max()) <= 2e-6 * float(p.abs().max())
+
+
+def test_slice_form_equals_the_whole_message_step():
+    """dm4d_adamw_step's data-parallel SLICE form on one device, without a process group: the message is cut into three slices as three
+    ranks would hold them (gradient = the slice of the packed, reduced message: `grad_in_message`; parameters addressed in their storages
+    through the index lists; updated values also into the all-gather's send slice: `param_out`), each slice stepped by its own call with
+    its own slice of the moments -- parameters, moments and send slices must equal ONE call over the whole message bit for bit, a step
+    masked by found_inf must leave everything alone and still fill the send slices."""
+    if not torch.cuda.is_available():
+        pytest.skip("no HIP device")
+    import ctypes as C
+
+    from dreammesh4d_amd import _lib, distributed as D
+    from dreammesh4d_amd.distributed import storage_flat
+
+    dev = torch.device("cuda:0")
+    L = _lib.lib()
+    st = torch.cuda.current_stream(dev).cuda_stream
+    hyper = [(3.2e-3, 0.9, 0.999, 1e-15, 0.0), (3.2e-2, 0.8, 0.95, 1e-10, 0.03)]
+
+    def fill(a, n_seg):
+        a.n_groups = 2
+        for gi, (lr, b1, b2, eps, wd) in enumerate(hyper):
+            a.lr[gi], a.beta1[gi], a.beta2[gi], a.eps[gi], a.weight_decay[gi] = lr, b1, b2, eps, wd
+        for k in range(n_seg):
+            a.group[k] = 0 if k < 2 else 1
+
+    results = {}
+    for mode in ("whole", "slices"):
+        params, touched = _setup(dev, 9)
+        red = D.GradAllReducer(params, touched=touched)
+        n = red.flat.numel()
+        W = 3
+        chunk = (n + W - 1) // W
+        m, v = torch.zeros(chunk * W, device=dev), torch.zeros(chunk * W, device=dev)
+        send = torch.full((chunk * W,), float("nan"), device=dev)
+        steps = [torch.zeros(len(params), dtype=torch.float64, device=dev) for _ in range(W if mode == "slices" else 1)]
+        scal = torch.zeros(1 + 2 * _lib.MAX_GRAD_SEGMENTS, device=dev)
+        for it in range(3):
+            for p, gr in zip(params, _grads(params, touched, it, dev)):
+                p.grad = gr
+            red.pack()                                              # the "reduced" message (world 1: the gradients themselves)
+            msg = red.flat.clone()
+            flag = torch.tensor(1.0 if it == 1 else 0.0, device=dev)
+            for r in range(W if mode == "slices" else 1):
+                lo, hi = (r * chunk, (r + 1) * chunk) if mode == "slices" else (0, chunk * W)
+                seg, a = _lib.GradSegments(), _lib.AdamwStepArgs()
+                seg.n_segments = len(params)
+                fill(a, len(params))
+                for k, (p, o, ix) in enumerate(zip(red.params, red.offsets, red.index)):
+                    cnt = p.numel() if ix is None else ix.numel()
+                    s0, s1 = max(o, lo), min(o + cnt, hi)
+                    base = storage_flat(p.data).data_ptr()
+                    if s1 <= s0:
+                        seg.count[k], seg.offset[k], seg.grad[k], seg.index[k], a.param[k] = 0, 0, None, None, base
+                        continue
+                    seg.count[k], seg.offset[k] = s1 - s0, s0 - lo
+                    seg.grad[k] = msg.data_ptr() + 4 * s0
+                    a.grad_in_message[k] = 1
+                    a.param_out[k] = send.data_ptr() + 4 * s0
+                    if ix is None:
+                        seg.index[k], a.param[k] = None, base + 4 * (s0 - o)
+                    else:
+                        seg.index[k], a.param[k] = ix.data_ptr() + 8 * (s0 - o), base
+                a.exp_avg, a.exp_avg_sq = m.data_ptr() + 4 * lo, v.data_ptr() + 4 * lo
+                a.step, a.pending_decay, a.found_inf, a.scratch = steps[r].data_ptr(), None, flag.data_ptr(), scal.data_ptr()
+                _lib.check(L.dm4d_adamw_step(C.byref(seg), C.byref(a), 1.0, st), "dm4d_adamw_step")
+            if it == 1:                                             # masked step: the send slices hold the CURRENT parameter values
+                cur = D.ShardedAdamW([{"params": params, "lr": 0.0}], red)
+                cur._pack_params()
+                assert torch.equal(send[:n], cur.padded[:n])
+        torch.cuda.synchronize()
+        results[mode] = ([p.detach().clone() for p in params], m[:n].clone(), v[:n].clone(), send[:n].clone(), [s.clone() for s in steps])
+    (pw, mw, vw, sw, stw), (ps, ms, vs, ss, sts) = results["whole"], results["slices"]
+    assert all(torch.equal(a, b) for a, b in zip(pw, ps)) and torch.equal(mw, ms) and torch.equal(vw, vs) and torch.equal(sw, ss)
+    assert stw[0].tolist() == [2.0] * 4 and all(s.tolist() == [2.0] * 4 for s in sts)      # the masked step does not count
+    assert torch.isfinite(sw).all() and float(mw.abs().max()) > 0
