@@ -345,3 +345,32 @@ def test_static_learnable_dynamic_geometry_gets_appearance_gradients(tmp_path):
     (out["comp_rgb"].mean() + out["comp_mask"].mean()).backward()
     for p in (geometry._scales, geometry.all_densities, geometry._sh_coordinates_dc):
         assert p.grad is not None and torch.isfinite(p.grad).all() and p.grad.abs().sum() > 0
+
+
+def test_guidance_constructs_on_the_device_from_the_shipped_keys_in_half_precision(tmp_path):
+    """`temporal-stable-zero123-guidance` from its YAML block's OWN keys on the HIP device with `half_precision_weights: true` (the
+    shipped default): frames from cond_video_dir, CLIP tower + VAE encoder from the checkpoint, no cond_embeddings_path -- the float16
+    embeddings agree with the float32 ones computed on the CPU to float16 accuracy, and a guidance call runs on them."""
+    if not torch.cuda.is_available():
+        pytest.skip("no HIP device")
+    from tests.test_prepare_embeddings_cpu import _tiny_checkpoint, _write_frames
+
+    from dreammesh4d_amd import clip_vit, threestudio_host as ts
+
+    dev = torch.device("cuda:0")
+    ckpt, yml, model, tower = _tiny_checkpoint(tmp_path)
+    vdir = str(tmp_path / "video")
+    _write_frames(vdir, 2)
+    cfg = {"num_frames": 2, "pretrained_config": yml, "pretrained_model_name_or_path": ckpt, "vram_O": True, "cond_video_dir": vdir,
+           "cond_elevation_deg": 5.0, "cond_azimuth_deg": 0.0, "cond_camera_distance": 3.8, "guidance_scale": 3.0, "min_step_percent": 0.02,
+           "max_step_percent": 0.5, "chunk_size": None, "half_precision_weights": True}
+    g = ts.find("temporal-stable-zero123-guidance")(cfg)
+    assert g.c_crossattn.is_cuda and g.c_crossattn.dtype == torch.float16 and tuple(g.c_concat.shape) == (2, 4, 32, 32)
+    paths = [clip_vit.video_frame_path(vdir, i) for i in range(2)]
+    _, cc, ct = clip_vit.prepare_embeddings(model, tower.eval(), paths, torch.device("cpu"), torch.float32)
+    for got, want in ((g.c_crossattn, cc), (g.c_concat, ct)):
+        err = float((got.float().cpu() - want).abs().max()) / max(float(want.abs().max()), 1e-6)
+        assert err < 3e-2, err
+    rgb = torch.rand(2, 64, 64, 3, device=dev, requires_grad=True)
+    out = g(rgb, torch.tensor([10.0, 20.0]), torch.tensor([30.0, -40.0]), torch.full((2,), 3.8), frame_indices=torch.tensor([0, 1]))
+    assert torch.isfinite(out["loss_sds"])
