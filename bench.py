@@ -249,7 +249,8 @@ def main():
             L.dm4d_profile_enable(0)
             tot = ctypes.c_double(0.0)
             nl = L.dm4d_profile_collect(K_RENDER_BWD, ctypes.byref(tot))
-            return el, tot.value / max(nl, 1) * 1e-3, int(nl)
+            # seconds of the dominant kernel per STEP (a step's views may go through several launches of it: the pipelined backward)
+            return el, tot.value / n * 1e-3, int(nl)
 
         for _ in range(warmup):
             step()
@@ -317,7 +318,10 @@ def main():
                                           + ("48-byte lean records)" if wl.depth_grad else "32-byte lean records: no depth gradient)"),
                 "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
                 "traffic": pmc_traffic(kern, B), "alg_bytes_per_launch": round(alg_bytes), "avg_launch_us": round(leg["avg_s"] * 1e6, 2),
-                "launches_timed": leg["n_launch"]}
+                "launches_timed": leg["n_launch"], "launches_per_step": round(leg["n_launch"] / leg["steps"], 2),
+                "per": "step: `alg_bytes_per_launch` / `avg_launch_us` / `traffic` are the SUMS over the launches of one step (the views of a step go through "
+                       "`launches_per_step` launches of this kernel, each timed with HIP events on its stream; from round 6 the record gather of one group "
+                       "of views runs on a helper stream BESIDE the next group's launch, so the durations include what that costs this kernel)"}
         out = {"value": round(value, 3), "ms_per_step": round(leg["elapsed"] / leg["steps"] * 1e3, 4), "views_per_step_per_gpu": B,
                "mean_duplicates_D": round(D_mean), "whole_view_frac_of_hbm_roofline": round(value / world * b_view / (HBM_PEAK_GBS * 1e9), 5),
                "roofline": roof}

@@ -399,7 +399,7 @@ __device__ __forceinline__ void finish_tile(const ViewCtx &c, int tile, uint32_t
 // each other, a four-wave workgroup holds its slots until its slowest quadrant is done, and the large tiles' quadrants, launched on
 // their own behind the large variant, delay the long cells' kernel: the backward starts 28 us LATER.)
 template <int kSortThreads>
-__global__ __launch_bounds__(kSortThreads, kSortThreads == 256 ? 6 : 4) void k_tile_sort(BatchDesc d)
+__device__ __forceinline__ void tile_sort_block(const BatchDesc &d, const uint32_t blk)
 {
     constexpr int kSortLdsCap = kSortPerThread * kSortThreads;
     constexpr int kWaves = kSortThreads / 64;
@@ -411,8 +411,8 @@ __global__ __launch_bounds__(kSortThreads, kSortThreads == 256 ? 6 : 4) void k_t
     uint32_t *s_bin = s_fine, *s_cur = s_fine + kBins + 1;      // HBM path (tiles beyond the LDS capacity): ONE level of linear buckets, as rounds 1-3
     static_assert(kSortLdsCap + 1 >= 2 * kBins + 1, "the HBM path's histogram and cursors borrow s_fine");
     // block -> (view, tile) in the launch order of K3: the r-th longest tile of every view, views interleaved
-    const int view = (int)(blockIdx.x % (uint32_t)d.B);
-    const uint32_t rank = blockIdx.x / (uint32_t)d.B;
+    const int view = (int)(blk % (uint32_t)d.B);
+    const uint32_t rank = blk / (uint32_t)d.B;
     const ViewCtx c = resolve(d, view);
     const GeomPtrs &g = c.g;
     const BinPtrs &b = c.b;
@@ -420,7 +420,7 @@ __global__ __launch_bounds__(kSortThreads, kSortThreads == 256 ? 6 : 4) void k_t
     if (rank >= (uint32_t)c.T) return;
     const int t = (int)g.order[rank];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    uint64_t *tr = (g_sort_trace && (kIsLarge ? g_sort_trace_variant == 0 : g_sort_trace_variant == 1)) ? g_sort_trace + 5 * (size_t)blockIdx.x : nullptr;
+    uint64_t *tr = (g_sort_trace && (kIsLarge ? g_sort_trace_variant == 0 : g_sort_trace_variant == 1)) ? g_sort_trace + 5 * (size_t)blk : nullptr;
     if (tr && tid == 0) tr[0] = wall_clock64();
     const uint32_t s = g.tile_start[t];
     uint32_t n = g.tile_count[t];
@@ -619,6 +619,22 @@ __global__ __launch_bounds__(kSortThreads, kSortThreads == 256 ? 6 : 4) void k_t
     }
 }
 
+// The kernel: workgroup -> blocks `blockIdx.x + k gridDim.x` of the (rank, view) order.  The small variant is launched with one
+// workgroup per block; the LARGE variant with at most one workgroup per CU (round 6): its workgroups need a whole CU each (1024
+// threads, 104 KB of LDS), and every one beyond the first round used to wait for a CU to drain of the small variant's workgroups that
+// run beside it -- with 20 views per step (64 ranks x 20 = 1280 workgroups, ~220 of them with a tile to sort) the launch took 200 us
+// against 33 us at 8 views, and the long cells' forward behind it ended after the regular forward.  The blocks of the first round are
+// ranks 0 .. 256 / B - 1 of every view: the longest tiles, i.e. the ones this variant exists for; a block without such a tile costs its
+// workgroup two dependent loads.
+template <int kSortThreads>
+__global__ __launch_bounds__(kSortThreads, kSortThreads == 256 ? 6 : 4) void k_tile_sort(BatchDesc d, const uint32_t n_blocks)
+{
+    for (uint32_t blk = blockIdx.x; blk < n_blocks; blk += gridDim.x) {
+        tile_sort_block<kSortThreads>(d, blk);
+        if (blk + gridDim.x < n_blocks) __syncthreads();      // the next block reuses the LDS
+    }
+}
+
 int launch_colscan(const BatchDesc &d, hipStream_t st)
 {
     const int T = ((d.W + kTile - 1) / kTile) * ((d.H + kTile - 1) / kTile);
@@ -650,6 +666,18 @@ AuxStream *aux_stream()
     return &a;
 }
 
+// workgroups of the large variant's launch: one per CU (DM4D_SORT_LARGE_GRID overrides: the A/B switch; 0 = one per block, as rounds 1-5)
+static unsigned large_grid_cap()
+{
+    static const unsigned cap = [] {
+        if (const char *e = getenv("DM4D_SORT_LARGE_GRID")) { const long v = atol(e); return v <= 0 ? 0xFFFFFFFFu : (unsigned)v; }
+        int dev = 0, cus = 256;
+        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        return (unsigned)max(cus, 1);
+    }();
+    return cap;
+}
+
 int launch_tile_sort(const BatchDesc &d, hipStream_t st)
 {
     const int T = ((d.W + kTile - 1) / kTile) * ((d.H + kTile - 1) / kTile);
@@ -665,7 +693,7 @@ int launch_tile_sort(const BatchDesc &d, hipStream_t st)
         DM4D_HIP_CHECK(hipEventRecord(a->fork, st));
         DM4D_HIP_CHECK(hipStreamWaitEvent(a->st, a->fork, 0));
     }
-    hipLaunchKernelGGL(k_tile_sort<kSortLarge>, dim3(large_blocks), dim3(kSortLarge), 0, st, d);
+    hipLaunchKernelGGL(k_tile_sort<kSortLarge>, dim3(min(large_blocks, large_grid_cap())), dim3(kSortLarge), 0, st, d, large_blocks);
     DM4D_HIP_CHECK(hipGetLastError());
     if (a) {
         // the forward of the large tiles' long cells starts as soon as THEIR sort is done, on a second helper stream,
@@ -677,7 +705,7 @@ int launch_tile_sort(const BatchDesc &d, hipStream_t st)
         DM4D_HIP_CHECK(hipEventRecord(a->join2, a->st2));
         a->pending2 = true;
     }
-    hipLaunchKernelGGL(k_tile_sort<kSortSmall>, dim3((unsigned)T * (unsigned)d.B), dim3(kSortSmall), 0, sst, d);
+    hipLaunchKernelGGL(k_tile_sort<kSortSmall>, dim3((unsigned)T * (unsigned)d.B), dim3(kSortSmall), 0, sst, d, (unsigned)T * (unsigned)d.B);
     DM4D_HIP_CHECK(hipGetLastError());
     if (a) {
         DM4D_HIP_CHECK(hipEventRecord(a->join, a->st));

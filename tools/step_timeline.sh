@@ -8,7 +8,7 @@ ALL=${ALL:-0}
 for v in "$@"; do
   cp $REPO/$v $REPO/dreammesh4d_amd/libdm4d_hip.so
   rm -rf /tmp/stl
-  rocprofv3 --kernel-trace --output-format csv -d /tmp/stl -o k -- python $REPO/bench.py --no-cpu-baseline --no-iters --steps 30 --warmup 5 > /dev/null 2>&1
+  rocprofv3 --kernel-trace --output-format csv -d /tmp/stl -o k -- python $REPO/bench.py --no-cpu-baseline --no-iters --no-step8 --no-variants --steps 30 --warmup 5 $BENCH_ARGS > /dev/null 2>&1
   echo "== $v"
   python - <<PY
 import csv, glob
