@@ -281,6 +281,13 @@ __global__ __launch_bounds__(256) void k_mlp_bwd(MlpDesc d, const float *__restr
 #ifndef DM4D_WGRAD_FINISH
 #define DM4D_WGRAD_FINISH 2
 #endif
+// Variant 2 is NOT a HIP-memory-model program: it relies on gfx942 / gfx950 hardware rules -- an sc1 store is written through to the
+// agent-coherent L2 before `s_waitcnt vmcnt(0)` retires it (vmcnt covers stores on gfx9), the ticket atomic executes at the L2 behind
+// it, and sc1 loads by the last arriver bypass its L1 (cdna_hip_programming.md, split-K recipe, "write-through" form).  Any other
+// target must build the fenced form.
+#if DM4D_WGRAD_FINISH == 2 && defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__) && !defined(__gfx942__)
+#error "DM4D_WGRAD_FINISH=2 (write-through split-K partials without a fence) is only valid on gfx942 / gfx950: build with -DDM4D_WGRAD_FINISH=1"
+#endif
 struct WgradFinish { unsigned *tickets; const MlpGrads *g; };      // tickets[tile]: zeroed by an EARLIER launch of the stream
 __device__ __forceinline__ void mlp_wgrad_block(const MlpDesc &d, const int bx, const int by, const float *__restrict__ feat,
                                                 const float *__restrict__ Hs, const float *__restrict__ Ys, const float *g0,

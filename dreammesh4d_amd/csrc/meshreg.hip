@@ -11,6 +11,7 @@
 // loop; here one launch covers all T timestamps over a static CSR adjacency (weights and rest edges precomputed
 // once).  The backward gathers: vertex i adds the terms of its own edges and, through the reverse-edge index,
 // of the edges that point at it -- no atomics, deterministic.
+#include <mutex>
 #include "common.h"
 #include "../../include/dm4d.h"
 
@@ -373,11 +374,27 @@ int dm4d_normal_consistency_backward(int32_t T, int32_t V, int32_t P, const int3
                                      const int32_t *vert_items, const float *xyz, const float *g_loss, float *g_xyz,
                                      dm4d_stream_t stream)
 {
-    // rounds 1-3's signature: the scratch is the library's (see include/dm4d.h)
-    static float *own = nullptr;
-    static size_t own_floats = 0;
+    // rounds 1-3's signature: the scratch is the library's (see include/dm4d.h) -- one per DEVICE (a pointer of another device is not
+    // addressable), guarded by a mutex (two host threads), never grown while the stream is capturing (hipFree / hipMalloc are illegal
+    // there; callers that capture use the _scratch form), and grown only after the device has drained (another stream may still
+    // read the old block)
+    static std::mutex mu;
+    static float *own_dev[64] = {};
+    static size_t own_floats_dev[64] = {};
+    int dev = 0;
+    DM4D_HIP_CHECK(hipGetDevice(&dev));
+    if (dev < 0 || dev >= 64) { set_error("normal consistency: device index %d", dev); return DM4D_ERR_UNSUPPORTED; }
     const size_t need = (T > 0 && P > 0) ? (size_t)T * (size_t)P * 12 : 0;
+    std::lock_guard<std::mutex> lock(mu);
+    float *&own = own_dev[dev];
+    size_t &own_floats = own_floats_dev[dev];
     if (need > own_floats) {
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing((hipStream_t)stream, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone) {
+            set_error("normal consistency backward: the library-owned scratch cannot grow during stream capture; call "
+                      "dm4d_normal_consistency_backward_scratch with a caller-owned scratch");
+            return DM4D_ERR_UNSUPPORTED;
+        }
         if (own) { DM4D_HIP_CHECK(hipDeviceSynchronize()); DM4D_HIP_CHECK(hipFree(own)); own = nullptr; own_floats = 0; }
         DM4D_HIP_CHECK(hipMalloc((void **)&own, need * sizeof(float)));
         own_floats = need;

@@ -204,7 +204,9 @@ static int views_backward_impl(const dm4d_views *v, const dm4d_views_grads *gr, 
     d.lean = gr->dL_dopacity ? 0 : 1;
     // ... and without a depth gradient (no depth loss in the shipped dynamic configuration) 8 values: 32-byte records
     static const bool no_lean2 = getenv("DM4D_NO_LEAN2") != nullptr;          // (A/B switch)
-    if (d.lean == 1 && !gr->dL_ddepth && !d.tile_records && !no_lean2) d.lean = 2;
+    // (the switch never applies to the rgb-only call: that call IS the 32-byte-record path, and a caller that selected it from the
+    //  conditions above -- views.py, step.py -- must not get DM4D_ERR_UNSUPPORTED from a probe switch)
+    if (d.lean == 1 && !gr->dL_ddepth && !d.tile_records && (!no_lean2 || rgb_only)) d.lean = 2;
     if (rgb_only) {
         // no loss reads the normal image (every normal weight 0 in C/configs/sugar_dynamic_dg.yaml:145-157; in the reference autograd
         // then never enters the normal pass's backward, C/renderer/diff_sugar_rasterizer_temporal.py:202-211): 5 per-entry sums, not 8

@@ -207,6 +207,43 @@ REFERENCE_GEOMETRY_GROUP = {"betas": (0.9, 0.999), "eps": 1e-15, "weight_decay":
 REFERENCE_MERGED_GROUP = {"betas": (0.9, 0.99), "eps": 1e-15, "weight_decay": 0.01}
 
 
+def stage_optimizer_state(sharded, opt, global_step, gen):
+    """The ``optimizer_states`` entry of a checkpoint for a training stage (DynamicStage / StaticStage ``optimizer_state_dict``): the
+    optimiser that actually STEPS.  With the message-space optimiser and world > 1 this is COLLECTIVE -- every rank calls it; the
+    moments are all-gathered into ``ShardedAdamW.full_state_dict()`` and the batch samplers' generator states (seeded per rank: the
+    ranks draw different frames and cameras) are gathered into ``rng_states`` -- so the one file rank 0 writes resumes every rank with
+    ITS moments slice and ITS generator (round 5 saved rank 0's shard and rank 0's generator: loaded on every rank without an error)."""
+    if sharded is None:
+        return {"kind": "torch.optim.AdamW", "state": opt.state_dict(), "global_step": int(global_step), "rng_state": gen.get_state()}
+    w = world()
+    sd = {"kind": "dm4d.ShardedAdamW", "state": sharded.full_state_dict() if w > 1 else sharded.state_dict(), "global_step": int(global_step),
+          "rng_state": gen.get_state()}
+    if w > 1:
+        states = [None] * w
+        dist.all_gather_object(states, gen.get_state())
+        sd["rng_states"], sd["world"] = states, w
+    return sd
+
+
+def load_stage_optimizer_state(sd, sharded, opt, gen):
+    """Inverse of ``stage_optimizer_state``; returns the checkpoint's global step (None if it has none)."""
+    kind = "dm4d.ShardedAdamW" if sharded is not None else "torch.optim.AdamW"
+    if sd.get("kind") != kind:
+        raise ValueError(f"the checkpoint's optimiser state is a {sd.get('kind')}, this stage steps a {kind}")
+    (sharded if sharded is not None else opt).load_state_dict(sd["state"])
+    rs = sd.get("rng_states")
+    if rs is not None and len(rs) == world():
+        gen.set_state(rs[rank()].cpu())          # this rank's own sampler: the resumed run draws the frames / cameras the uninterrupted one would
+    elif rs is not None:
+        raise ValueError(f"the checkpoint holds the sampler states of {len(rs)} ranks, this run has {world()}: the frames / cameras drawn after "
+                         "the resume cannot continue the saved run's")
+    elif sd.get("rng_state") is not None:
+        if world() > 1:
+            raise ValueError("a single-process checkpoint's sampler state would make every rank draw the same frames and cameras")
+        gen.set_state(sd["rng_state"].cpu())
+    return sd.get("global_step")
+
+
 class ShardedAdamW:
     """The AdamW step of the data-parallel loop with the optimiser state SHARDED over the ranks (SURVEY.md section 8e:
     "reduce-scatter -> sharded AdamW -> all-gather params"), in the MESSAGE space of a ``GradAllReducer``:
@@ -462,20 +499,61 @@ class ShardedAdamW:
         self._unpack_message()
 
     def state_dict(self):
-        """The optimiser's own state: this rank's slice of the two moments (message layout), the steps applied and the pending decay
-        factors per segment, the groups' hyperparameters.  (The message layout is a function of the reducer's parameters and
+        """This RANK's shard of the optimiser state: its slice [lo, hi) of the two moments (message layout), the steps applied and the
+        pending decay factors per segment, the groups' hyperparameters -- and whose slice it is (rank, lo, hi): ``load_state_dict``
+        refuses another rank's shard.  With world > 1 a checkpoint therefore holds either one shard PER RANK or ``full_state_dict()``
+        (what the stages' ``optimizer_state_dict()`` write).  (The message layout is a function of the reducer's parameters and
         touched-index sets: a checkpoint resumes into a stage constructed the same way.)"""
-        return {"exp_avg": self.exp_avg.clone(), "exp_avg_sq": self.exp_avg_sq.clone(), "step": self.step_t.clone(),
+        return {"layout": "shard", "exp_avg": self.exp_avg.clone(), "exp_avg_sq": self.exp_avg_sq.clone(), "step": self.step_t.clone(),
                 "pending_decay": self.pending_decay.clone(), "decay_pending": bool(self._decay_pending), "step_count": int(self.step_count),
-                "hyper": self._hyper(), "world": world(), "elements": int(self.reducer.flat.numel()), "segments": len(self.reducer.params)}
+                "hyper": self._hyper(), "world": world(), "rank": rank(), "lo": int(self.lo), "hi": int(self.hi),
+                "elements": int(self.reducer.flat.numel()), "segments": len(self.reducer.params)}
+
+    def full_state_dict(self):
+        """COLLECTIVE (every rank calls it, every rank gets the result): the moments of the WHOLE message, all-gathered from the ranks'
+        slices -- a state any rank of any world size can load (``load_state_dict`` takes its own slice), so one file written by
+        rank 0 resumes every rank.  13.5 MB x 2 at the shipped dynamic-stage configuration."""
+        sd = self.state_dict()
+        w, n = world(), int(self.reducer.flat.numel())
+        for k in ("exp_avg", "exp_avg_sq"):
+            mine = getattr(self, k)
+            if w == 1:
+                full = mine
+            elif dist.get_backend() == "gloo" or not mine.is_cuda:
+                parts = [torch.empty(self.chunk, dtype=torch.float32) for _ in range(w)]
+                dist.all_gather(parts, mine.detach().cpu().contiguous())
+                full = torch.cat(parts).to(mine.device)
+            else:
+                full = torch.empty(self.chunk * w, dtype=torch.float32, device=mine.device)
+                dist.all_gather_into_tensor(full, mine.contiguous())
+            sd[k] = full[:n].clone()
+        sd["layout"] = "full"
+        for k in ("rank", "lo", "hi"):
+            sd.pop(k)
+        return sd
 
     def load_state_dict(self, sd):
-        if int(sd["elements"]) != int(self.reducer.flat.numel()) or int(sd["world"]) != world() or tuple(sd["exp_avg"].shape) != tuple(self.exp_avg.shape) \
-                or int(sd.get("segments", -1)) != len(self.reducer.params):
-            raise ValueError("ShardedAdamW.load_state_dict: the state belongs to another message layout / world size")
+        """A state of ``full_state_dict()`` (any writer world size: this rank takes its slice) or this rank's own shard of
+        ``state_dict()`` -- another rank's shard, another world size's shard or another message layout raises."""
+        n = int(self.reducer.flat.numel())
+        if int(sd["elements"]) != n or int(sd.get("segments", -1)) != len(self.reducer.params):
+            raise ValueError("ShardedAdamW.load_state_dict: the state belongs to another message layout")
         dev = self.exp_avg.device
-        self.exp_avg = sd["exp_avg"].to(dev, torch.float32).clone()
-        self.exp_avg_sq = sd["exp_avg_sq"].to(dev, torch.float32).clone()
+        # (a state without "layout" was written by round 5: a shard that did not say whose -- only a single-process run can trust it)
+        layout = sd.get("layout", "shard")
+        if layout == "full":
+            if tuple(sd["exp_avg"].shape) != (n,) or tuple(sd["exp_avg_sq"].shape) != (n,):
+                raise ValueError("ShardedAdamW.load_state_dict: a full state holds the moments of the whole message")
+            take = lambda t: torch.nn.functional.pad(t.to(dev, torch.float32), (0, self.padded.numel() - n))[self.lo:self.hi].clone()
+            ea, es = take(sd["exp_avg"]), take(sd["exp_avg_sq"])
+        else:
+            mine = (int(sd.get("rank", 0 if world() == 1 else -1)), int(sd.get("lo", self.lo if world() == 1 else -1)), int(sd.get("hi", self.hi if world() == 1 else -1)))
+            if int(sd["world"]) != world() or tuple(sd["exp_avg"].shape) != tuple(self.exp_avg.shape) or mine != (rank(), int(self.lo), int(self.hi)):
+                raise ValueError(f"ShardedAdamW.load_state_dict: this is the shard of rank {sd.get('rank', '?')} of {sd['world']} (elements "
+                                 f"[{sd.get('lo', '?')}, {sd.get('hi', '?')})), not of rank {rank()} of {world()} ([{self.lo}, {self.hi})): save "
+                                 "full_state_dict() (collective) or one state_dict() per rank")
+            ea, es = sd["exp_avg"].to(dev, torch.float32).clone(), sd["exp_avg_sq"].to(dev, torch.float32).clone()
+        self.exp_avg, self.exp_avg_sq = ea, es
         self.step_t = sd["step"].to(dev, torch.float64).clone()
         self.pending_decay = sd["pending_decay"].to(dev, torch.float64).clone()
         self._decay_pending = bool(sd.get("decay_pending", True))

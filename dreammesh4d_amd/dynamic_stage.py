@@ -166,12 +166,26 @@ class DynamicStage:
         self._step_objects = {}
 
     def _weight_is_set(self, name):
-        """A loss weight of the configuration that is not identically zero (numbers, or C() schedules: [start, v0, v1, end])."""
+        """A loss weight of the configuration that is not identically zero: a number, or a C() schedule normalised the way schedule.C
+        reads it -- [v0, v1, end] (start 0), [start, v0, v1, end], or piecewise [s0, v0, v1, s1, v2, s2, ...] -- of which EVERY value
+        entry counts (a weight that starts at 0 and is switched on later is set); a shape C() would not accept counts as set."""
         v = self.lam.get(name, 0)
         if v is None:
             return False
         if isinstance(v, (list, tuple)):
-            return any(float(x) != 0.0 for x in v[1:3]) if len(v) >= 3 else any(float(x) != 0.0 for x in v)
+            v = list(v)
+            if len(v) == 3:
+                v = [0] + v
+            if len(v) == 4:
+                vals = v[1:3]
+            elif len(v) >= 6:
+                vals = [v[1], v[2]] + v[4::2]           # v0, v1, then the value of every further (value, step) pair
+            else:
+                return True
+            try:
+                return any(float(x) != 0.0 for x in vals)
+            except (TypeError, ValueError):
+                return True
         return float(v) != 0.0
 
     def sample_batch(self):
@@ -454,19 +468,18 @@ class DynamicStage:
         """What a checkpoint's ``optimizer_states`` entry holds for this stage: the optimiser that actually STEPS.  With the
         message-space optimiser that is ``ShardedAdamW.state_dict()`` (this rank's slice of the moments, the per-segment step counters
         and pending decay) -- ``self.opt``, the torch AdamW a host would save by default, never steps then and its state is empty."""
-        if self.sharded is not None:
-            return {"kind": "dm4d.ShardedAdamW", "state": self.sharded.state_dict(), "global_step": int(self.global_step), "rng_state": self.gen.get_state()}
-        return {"kind": "torch.optim.AdamW", "state": self.opt.state_dict(), "global_step": int(self.global_step), "rng_state": self.gen.get_state()}
+        from .distributed import stage_optimizer_state
+
+        return stage_optimizer_state(self.sharded, self.opt, self.global_step, self.gen)      # (COLLECTIVE when world > 1: every rank calls it)
 
     def load_optimizer_state_dict(self, sd):
-        """Resume: the moments, step counters (bias corrections) and the iteration count continue where the checkpoint left them."""
-        kind = "dm4d.ShardedAdamW" if self.sharded is not None else "torch.optim.AdamW"
-        if sd.get("kind") != kind:
-            raise ValueError(f"the checkpoint's optimiser state is a {sd.get('kind')}, this stage steps a {kind}")
-        (self.sharded if self.sharded is not None else self.opt).load_state_dict(sd["state"])
-        self.global_step = int(sd.get("global_step", self.global_step))
-        if sd.get("rng_state") is not None:          # the batch sampler's generator: the resumed run draws the frames / cameras the uninterrupted one would
-            self.gen.set_state(sd["rng_state"].cpu())
+        """Resume: the moments, step counters (bias corrections), the iteration count and this rank's batch sampler continue where the
+        checkpoint left them."""
+        from .distributed import load_stage_optimizer_state
+
+        gs = load_stage_optimizer_state(sd, self.sharded, self.opt, self.gen)
+        if gs is not None:
+            self.global_step = int(gs)
 
     @classmethod
     def from_cfg(cls, system_cfg, renderer, net, nodes, static, timestamps, ref_images, ref_masks, ref_camera, **kw):

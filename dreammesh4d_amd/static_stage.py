@@ -189,18 +189,18 @@ class StaticStage:
     def optimizer_state_dict(self):
         """The state of the optimiser that actually steps (DynamicStage.optimizer_state_dict: with the message-space optimiser
         ``self.opt`` never steps and a host saving ITS state would save nothing)."""
-        if self.sharded is not None:
-            return {"kind": "dm4d.ShardedAdamW", "state": self.sharded.state_dict(), "global_step": int(self.global_step), "rng_state": self.gen.get_state()}
-        return {"kind": "torch.optim.AdamW", "state": self.opt.state_dict(), "global_step": int(self.global_step), "rng_state": self.gen.get_state()}
+        from .distributed import stage_optimizer_state
+
+        return stage_optimizer_state(self.sharded, self.opt, self.global_step, self.gen)      # (COLLECTIVE when world > 1: every rank calls it)
 
     def load_optimizer_state_dict(self, sd):
-        kind = "dm4d.ShardedAdamW" if self.sharded is not None else "torch.optim.AdamW"
-        if sd.get("kind") != kind:
-            raise ValueError(f"the checkpoint's optimiser state is a {sd.get('kind')}, this stage steps a {kind}")
-        (self.sharded if self.sharded is not None else self.opt).load_state_dict(sd["state"])
-        self.global_step = int(sd.get("global_step", self.global_step))
-        if sd.get("rng_state") is not None:          # the batch sampler's generator: the resumed run draws the frames / cameras the uninterrupted one would
-            self.gen.set_state(sd["rng_state"].cpu())
+        """Resume: the moments, step counters (bias corrections), the iteration count and this rank's batch sampler continue where the
+        checkpoint left them."""
+        from .distributed import load_stage_optimizer_state
+
+        gs = load_stage_optimizer_state(sd, self.sharded, self.opt, self.gen)
+        if gs is not None:
+            self.global_step = int(gs)
 
     @classmethod
     def from_cfg(cls, system_cfg, geometry, renderer, ref_image, ref_mask, H, W, **kw):

@@ -246,3 +246,81 @@ def test_merge_optimizer_keeps_the_reference_effective_hyperparameters():
     o = torch.optim.AdamW(l, lr=0.0, betas=[0.9, 0.99], eps=1e-15)
     assert tuple(o.param_groups[0]["betas"]) == (0.9, 0.999) and o.param_groups[0]["weight_decay"] == 0
     assert D.REFERENCE_GEOMETRY_GROUP == {"betas": (0.9, 0.999), "eps": 1e-15, "weight_decay": 0.0}
+
+
+def _worker_resume(rank, world, port, out):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    idx = torch.tensor([3, 17, 18, 64, 119])
+
+    def build():
+        torch.manual_seed(0)
+        grid = torch.nn.Parameter(torch.randn(1, 4, 5, 6))
+        mlp = torch.nn.Linear(6, 3)
+        unused = torch.nn.Parameter(torch.ones(5))
+        groups = [{"params": list(mlp.parameters()) + [unused], "lr": 3.2e-4, "name": "deformation"}, {"params": [grid], "lr": 3.2e-3, "name": "grid"}]
+        params = list(mlp.parameters()) + [unused, grid]
+        red = D.GradAllReducer(params, touched={grid: idx})
+        return grid, mlp, params, D.ShardedAdamW(groups, red, betas=(0.9, 0.99), eps=1e-15), torch.Generator().manual_seed(100 + rank)
+
+    def iterate(grid, mlp, opt, gen, n):
+        for _ in range(n):
+            opt.zero_grad(set_to_none=True)
+            x = torch.rand(2, 6, generator=gen) + float(rank)           # this rank's own batch: drawn from ITS generator
+            (mlp(x).pow(2).sum() + (grid.view(-1)[idx] * float(rank + 2)).pow(2).sum()).backward()
+            opt.step()
+
+    # the uninterrupted run: 3 iterations, checkpoint, 2 more
+    grid, mlp, params, opt, gen = build()
+    iterate(grid, mlp, opt, gen, 3)
+    saved_params = [p.detach().clone() for p in params]
+    sd = D.stage_optimizer_state(opt, None, 3, gen)                      # collective; the "file" is what RANK 0 holds
+    shard0 = [opt.state_dict()]
+    box = [sd]
+    dist.broadcast_object_list(box, src=0)
+    dist.broadcast_object_list(shard0, src=0)
+    sd0 = box[0]
+    iterate(grid, mlp, opt, gen, 2)
+    want = [p.detach().clone() for p in params]
+    # the resumed run: a fresh stage, the checkpoint's parameters, RANK 0's optimiser entry on every rank
+    grid2, mlp2, params2, opt2, gen2 = build()
+    with torch.no_grad():
+        for p, v in zip(params2, saved_params):
+            p.copy_(v)
+    res = {"full_moments": int(sd0["state"]["exp_avg"].numel()), "message": int(opt2.reducer.flat.numel()), "layout": sd0["state"]["layout"]}
+    try:
+        opt2.load_state_dict(shard0[0])                                 # rank 0's SHARD: fine on rank 0, refused on rank 1
+        res["shard_of_rank0"] = "loaded"
+    except ValueError:
+        res["shard_of_rank0"] = "refused"
+    step = D.load_stage_optimizer_state(sd0, opt2, None, gen2)
+    res["step"] = step
+    res["gen_is_mine"] = bool(torch.equal(gen2.get_state(), sd0["rng_states"][rank]))
+    res["gens_differ"] = not torch.equal(sd0["rng_states"][0], sd0["rng_states"][1])
+    iterate(grid2, mlp2, opt2, gen2, 2)
+    res["equal"] = all(torch.equal(a.detach(), b) for a, b in zip(params2, want))
+    res["moved"] = any(not torch.equal(a, b) for a, b in zip(saved_params, want))
+    try:            # a single-process checkpoint's sampler state must not make every rank draw the same batches
+        D.load_stage_optimizer_state({"kind": "dm4d.ShardedAdamW", "state": sd0["state"], "rng_state": gen.get_state()}, opt2, None, gen2)
+        res["single_rng"] = "loaded"
+    except ValueError:
+        res["single_rng"] = "refused"
+    out[rank] = res
+    dist.destroy_process_group()
+
+
+def test_sharded_adamw_checkpoint_resumes_every_rank_world2():
+    """a checkpoint written by rank 0 must resume EVERY rank -- the optimiser entry of a stage holds the moments of the
+    whole message (all-gathered: each rank loads its own slice) and every rank's sampler state; the resumed 2-rank run is bit-identical to
+    the uninterrupted one; another rank's shard is refused instead of silently applied to the wrong slice."""
+    world = 2
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker_resume, args=(world, _free_port(), out), nprocs=world, join=True)
+    for r in range(world):
+        o = out[r]
+        assert o["layout"] == "full" and o["full_moments"] == o["message"]
+        assert o["equal"] and o["moved"] and o["step"] == 3
+        assert o["gen_is_mine"] and o["gens_differ"]
+        assert o["single_rng"] == "refused"
+    assert out[0]["shard_of_rank0"] == "loaded" and out[1]["shard_of_rank0"] == "refused"

@@ -210,3 +210,80 @@ def test_step_object_contract():
         step(t, vm, pm, fidx.long())
     with pytest.raises(ValueError):
         DynamicStep(r, net, nodes, st["qs"], st["sc"].clone().requires_grad_(True), st["op"], st["rgb"], bg6, n_views=4, n_frames=2)
+
+
+def test_twenty_unit_step_equals_per_view_and_per_frame_composition():
+    """The partition BASELINE.json configs[3] / SURVEY.md 8(e) name, at its size: bench.py's step object over 4 frames x (4 SDS views + 1
+    reference view) = 20 (frame, view) units of the 199,980-Gaussian scene at 512 x 512, against the composition of the same work from
+    smaller calls --
+      * every unit ALONE through ``views.render_views`` (B = 1, the frame's node outputs): image, depth, alpha, radii and the duplicate
+        count bit for bit (a unit of the batch is the unit on its own: tile order, sort, blend do not see the other 19);
+      * every FRAME alone (its 5 views, one ``render_views`` call with the backward): the node-output gradients of the frame bit for bit
+        (the vertex kernel adds a frame's views in view order whatever else is in the batch), and from those, through
+        ``DeformationNetwork.node_outputs``' backward, every parameter gradient bit for bit.
+    One unit against two oracle passes: tests/test_views_gpu.py::test_bench_scene_one_view_against_two_oracle_passes."""
+    if not torch.cuda.is_available():
+        pytest.skip("no HIP device")
+    import bench
+    from dreammesh4d_amd import views
+
+    dev = torch.device("cuda:0")
+    wl = bench.Workload(dev, 0, 1)
+    assert wl.views_per_step == 20 and wl.views_per_frame == 5 and bench.FRAMES_PER_STEP == 4
+    st = wl.dstep
+    out = st(wl.frame_t, wl.vm16, wl.pm16, wl.fidx)
+    torch.autograd.backward([out["color"], out["alpha"]], [wl.gC, wl.gA])
+    D = wl.renderer.check()
+    ref = {k: out[k].detach().clone() for k in ("color", "depth", "alpha", "radii", "vxyz", "vrot")}
+    names = st.head_names
+    ref_gnode = {k: st.gnode[k].detach().clone() for k in names}
+    params = st.params
+    ref_grads = [p.grad.detach().clone() for p in params]
+    assert all(bool(g.any()) for g in ref_grads[-4:])
+    for p in wl.net.parameters():
+        p.grad = None
+
+    # ---- composition
+    wl.net.grads_in_place = False
+    dx, dr, ds, do = wl.net.node_outputs(wl.nodes, wl.frame_t)
+    raw = {"dx": dx, "dr": dr, "ds": ds, "do": do}
+    for k in names:
+        assert torch.equal(st.node_outputs()[k].view(raw[k].shape), raw[k]), k
+    def renderer():
+        r = views.ViewRenderer(wl.graph, wl.topo, bench.H, bench.W, wl.cams[0].tanfov, method="hybrid")
+        r.fuse_face_backward = True
+        return r
+    # every unit alone, forward only
+    r1 = renderer()
+    with torch.no_grad():
+        for u in range(20):
+            f = int(wl.fidx[u])
+            o = views.render_views(r1, dx[f:f + 1], dr[f:f + 1], ds[f:f + 1], do[f:f + 1], wl.qs, wl.scales, wl.opac, wl.rgb,
+                                   wl.vm[u:u + 1], wl.pm[u:u + 1], wl.bg6)
+            for k in ("color", "depth", "alpha", "radii"):
+                assert torch.equal(o[k][0], ref[k][u]), (k, u)
+            assert torch.equal(o["vxyz"][0], ref["vxyz"][f]) and torch.equal(o["vrot"][0], ref["vrot"][f])
+            assert r1.check()[0] == D[u], u
+    # every frame alone, with the backward
+    g_frames = {k: [] for k in names}
+    for f in range(4):
+        leaves = {k: raw[k][f:f + 1].detach().clone().requires_grad_(True) for k in names}
+        r5 = renderer()
+        v = slice(5 * f, 5 * f + 5)
+        assert [int(x) for x in wl.fidx[v]] == [f] * 5
+        o = views.render_views(r5, leaves["dx"], leaves["dr"], leaves["ds"], leaves["do"], wl.qs, wl.scales, wl.opac, wl.rgb, wl.vm[v], wl.pm[v],
+                               wl.bg6, frame_index=torch.zeros(5, dtype=torch.int32, device=dev))
+        for k in ("color", "depth", "alpha"):
+            assert torch.equal(o[k], ref[k][v]), (k, f)
+        torch.autograd.backward([o["color"], o["alpha"]], [wl.gC[v], wl.gA[v]])
+        for k in names:
+            g_frames[k].append(leaves[k].grad)
+    g_nodes = {k: torch.cat(g_frames[k], 0) for k in names}
+    for k in names:
+        assert torch.equal(g_nodes[k].reshape(ref_gnode[k].shape), ref_gnode[k]), k
+    torch.autograd.backward([raw[k] for k in names], [g_nodes[k] for k in names])
+    n = 0
+    for p, want in zip(params, ref_grads):
+        assert p.grad is not None and torch.equal(p.grad, want), n
+        n += 1
+    assert n >= 30

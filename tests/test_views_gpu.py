@@ -370,7 +370,7 @@ def test_rgb_gradient_only_equals_the_full_backward_fed_zeros_on_the_normal_chan
 
 @pytest.mark.parametrize("mode", ["lean32", "lean48", "full64"])
 def test_bench_scene_one_view_against_two_oracle_passes(mode):
-    """The TIMED kernel instantiations at the TIMED size: one (frame, view) unit of bench.py's scene (mesh-bound 199,980
+    """The TIMED kernel instantiations at the TIMED size: one (frame, view) unit of bench.py's 20-unit step (mesh-bound 199,980
     Gaussians, 33,330 faces, 1000 nodes, hybrid skinning, 512 x 512, bench.py's own camera and node outputs) through
     ``render_views`` in the three record modes the bench reports --
         lean32: static appearance frozen, no depth gradient   k_render_bwd<6, 2>   (the headline step)
@@ -387,7 +387,9 @@ def test_bench_scene_one_view_against_two_oracle_passes(mode):
 
     dev = torch.device("cuda:0")
     wl = bench.Workload(dev, 0, 1)
-    H, W, u = bench.H, bench.W, 3                      # unit 3: frame 1, its second camera
+    # (bench.Workload is the 20-unit step of BASELINE configs[3]: 4 frames x (4 SDS views + 1 reference view))
+    H, W, u = bench.H, bench.W, 9                      # unit 9: frame 1, its fifth camera
+    assert wl.views_per_step == 20 and int(wl.fidx[u]) == 1
     f = int(wl.fidx[u])
     with torch.no_grad():
         dx, dr, ds, do = (t[f:f + 1].contiguous() for t in wl.net.node_outputs(wl.nodes, wl.frame_t))

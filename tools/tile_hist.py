@@ -16,15 +16,18 @@ geom = ws["geom"].cpu().numpy()
 T = 1024
 al = lambda x: (x + 255) // 256 * 256
 off = 256; tc = off; off = al(off + T * 4); off = al(off + (T + 1) * 4); cc = off; off = al(off + T * 64); cd = off
-n, work, wide = [], [], []
+n, work, wide, tot = [], [], [], []
 for b in range(B):
     g = geom[b * stride:(b + 1) * stride]
     n.append(g[tc:tc + T * 4].view(np.uint32).copy())
     c = g[cc:cc + T * 64].view(np.uint32).reshape(T, 16)
     d = g[cd:cd + T * 64].view(np.uint32).reshape(T, 16)
     work.append(np.minimum(c, d).sum(1))
+    tot.append(c.sum(1))
     wide.append((c >= 128).sum(1))
 n, work, wide = np.concatenate(n), np.concatenate(work), np.concatenate(wide)
+tot = np.concatenate(tot)
+print("cell-list entries (= backward records)", tot.sum(), "consumed by the forward", work.sum(), "=", work.sum() / tot.sum())
 print("tiles", n.size, "duplicates", n.sum(), "consumed cell entries", work.sum(), "max tile", n.max())
 edges = [0, 1, 128, 256, 384, 496, 768, 1024, 1536, 2048, 4096, 1 << 30]
 for lo, hi in zip(edges[:-1], edges[1:]):
