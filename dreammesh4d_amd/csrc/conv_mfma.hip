@@ -582,6 +582,203 @@ __global__ __launch_bounds__(256 * NWN) void k_conv3x3_direct(ConvDesc d, int ch
     conv3x3_direct_tile<NWN, RING, AHEAD>(d, chunks_per_split, lgTW);
 }
 
+// ---------------------------------------------------------------------------------------- direct variant, PING-PONG waves (round 6)
+// The 8-wave direct kernel above keeps both waves of a SIMD in step from barrier to barrier: both read fragments, then both want the
+// SIMD's matrix pipe -- the three phases of a k-tile (fragment reads, operand DMA, 8 MFMAs) hardly overlap (1380 cycles per k-tile
+// against 512 of MFMA per SIMD; profiles/r03_zero123.md).  Here the two waves of a SIMD (wave w and w + 4: the dispatcher deals a
+// workgroup's waves to the SIMDs cyclically) run the SAME stream half a period apart (MI355X_MICROARCH.md, "Two waves per SIMD"):
+//     LOAD(t):    issue the DMA of k-tile t + AHEAD (and a piece of the next chunk's patch), read the 8 fragments of k-tile t into
+//                 registers, wait for them and for this wave's DMA pieces of k-tile t + 1, s_barrier
+//     COMPUTE(t): the 8 MFMAs of k-tile t, s_barrier
+// with waves 4-7 one barrier behind waves 0-3, so that every interval between two barriers pairs one wave's 8 MFMAs (256 cycles of the
+// SIMD's matrix pipe) with its partner's LDS reads and DMA issue -- matrix beside memory.  One register set of fragments (a wave never
+// reads while it multiplies), two barriers per k-tile.  Same tile algebra, LDS layout, DMA order and epilogue as conv3x3_direct_tile<2, 9, 4>:
+// a k-tile's tiles are waited for by every wave at the end of its LOAD of the k-tile before and published by the barrier behind it.
+template <int AHEAD>
+__device__ __forceinline__ void conv3x3_direct_pp_tile(const ConvDesc &d, int chunks_per_split, int lgTW)
+{
+    constexpr int NWN = 2, RING = 9;
+    constexpr int BM = 256, BN = 64 * NWN, NW = 4 * NWN;
+    constexpr int kDirPieces = kDirPatchSlots / (64 * NW), kDirBSlots = 256 * NWN, kDirRing = RING, kDirAhead = AHEAD;
+    static_assert(AHEAD >= 2 && AHEAD < RING && kDirPieces <= 9, "ring");
+    extern __shared__ __attribute__((aligned(1024))) uint4 smem[];
+    [[maybe_unused]] const int cv_probe = d.probe;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave & 3, wn = wave >> 2;
+    const int W = d.W, TW = 1 << lgTW, PW = TW + 2, TH = BM >> lgTW, R = d.N * d.H;
+    const int ncb = W >> lgTW, rblk = blockIdx.x / ncb, cb = blockIdx.x - rblk * ncb;
+    const int g0 = rblk * TH, x0 = cb << lgTW, n0 = blockIdx.y * BN;
+    const int cpt = d.Cin / kCvBK;
+    const int ch0 = blockIdx.z * chunks_per_split, nch = min(cpt, ch0 + chunks_per_split) - ch0;
+    const int patch_px = (TH + 2) * PW;
+    constexpr unsigned kOob = 0x80000000u;
+    uint4 *const s_patch0 = smem + kDirZeroSlots;
+    constexpr int kPatchStride = kDirZeroSlots + kDirPatchSlots;
+    uint4 *const s_b = smem + 2 * kPatchStride;
+    if (tid < kDirZeroSlots) { smem[tid] = make_uint4(0u, 0u, 0u, 0u); smem[kPatchStride + tid] = make_uint4(0u, 0u, 0u, 0u); }
+
+    const auto a_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16 *>(d.x) - (size_t)(W + 1) * d.Cin, 0,
+                                                        (int)(((size_t)d.M + 2 * W + 2) * d.Cin * 2), 0x00020000);
+    const auto b_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16 *>(d.w), 0, (int)((size_t)d.Cout * 9 * d.Cin * 2), 0x00020000);
+    unsigned p_vo[kDirPieces];
+#pragma unroll
+    for (int i = 0; i < kDirPieces; ++i) {
+        const int s = 64 * (wave * kDirPieces + i) + lane, q = s >> 2, c = (s & 3) ^ ((q >> 2) & 3);
+        const int pr = q / PW, pc = q - pr * PW;
+        const int g = g0 - 1 + pr, x = x0 - 1 + pc;
+        const bool ok = q < patch_px && (unsigned)x < (unsigned)W && (unsigned)g < (unsigned)R;
+        p_vo[i] = ok ? (unsigned)((g + 1) * W + x + 1) * (unsigned)(d.Cin * 2) + 16u * c : kOob;
+    }
+    unsigned b_vo;
+    {
+        const int s = 64 * wave + lane, r = s >> 2, c = (s & 3) ^ ((r >> 2) & 3);
+        const int co = n0 + r;
+        b_vo = co < d.Cout ? (unsigned)co * (unsigned)(9 * d.Cin * 2) + 16u * c : kOob;
+    }
+    const int cin2 = d.Cin * 2;
+    auto issue_patch = [&](int piece, int buf, int chunk) {
+        if (CV_PROBE(4)) return;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rs, (__attribute__((address_space(3))) void *)(s_patch0 + buf * kPatchStride + 64 * (wave * kDirPieces + piece)),
+                                                 16, p_vo[piece], (ch0 + chunk) * (kCvBK * 2), 0, 0);
+    };
+    auto issue_b = [&](int tap, int stage, int chunk) {
+        if (CV_PROBE(4)) return;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(b_rs, (__attribute__((address_space(3))) void *)(s_b + stage * kDirBSlots + 64 * wave), 16, b_vo,
+                                                 tap * cin2 + (ch0 + chunk) * (kCvBK * 2), 0, 0);
+    };
+    int row_of[2], qa[2][3];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int r = 64 * wm + 32 * i + (lane & 31), tr = r >> lgTW, tc = r & (TW - 1);
+        const int g = g0 + tr, y = g % d.H;
+        const bool row_ok = g < R;
+        const int q = (tr + 1) * PW + tc + 1;
+        row_of[i] = r;
+        qa[i][0] = (row_ok && y > 0) ? q - PW : -2;
+        qa[i][1] = row_ok ? q : -2;
+        qa[i][2] = (row_ok && y < d.H - 1) ? q + PW : -2;
+    }
+    const int hi = lane >> 5;
+    unsigned fb[2][2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+            fb[ks][j] = (unsigned)(size_t)(__attribute__((address_space(3))) uint4 *)(s_b + cv_slot(64 * wn + 32 * j + (lane & 31), 2 * ks + hi));
+    const unsigned pb0 = (unsigned)(size_t)(__attribute__((address_space(3))) uint4 *)s_patch0;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    f16x8 ra[2][2] = {}, rb[2][2] = {};
+    // byte offset (from a patch buffer's start) of the ks = 0 fragment of tile row i for each of the nine taps; ks = 1 is the same slot
+    // with piece ^ 2, i.e. offset ^ 32 (the buffers are 256-byte aligned): 18 registers instead of ~6 VALU operations per read -- a
+    // LOAD interval is as long as its instruction stream (DMA issue, addresses, 8 reads, their latency), not as its bytes
+    unsigned po[2][9];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int q = qa[i][tap / 3] + (tap % 3 - 1);
+            po[i][tap] = 16u * (unsigned)(4 * q + (hi ^ ((q >> 2) & 3)));
+        }
+    // every fragment of k-tile (tap TAP) from the patch buffer at byte address `pbase`, filter stage TAP % RING
+    auto read_all = [&](auto TAP, unsigned pbase) {
+        constexpr int tap = decltype(TAP)::value;
+        if (CV_PROBE(64)) return;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const unsigned a = pbase + (po[i][tap] ^ (ks ? 32u : 0u));
+                ra[ks][i] = *reinterpret_cast<const __attribute__((address_space(3))) f16x8 *>(a);
+            }
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+                rb[ks][j] = *reinterpret_cast<const __attribute__((address_space(3))) f16x8 *>(fb[ks][j] + (tap % kDirRing) * (kDirBSlots * 16));
+        }
+    };
+#define DM4D_TAP(n) std::integral_constant<int, n>{}
+    // prologue: the first patch, the first AHEAD filter tiles; k-tile 0's operands have landed behind the barrier
+    if (nch > 0) {
+#pragma unroll
+        for (int i = 0; i < kDirPieces; ++i) issue_patch(i, 0, 0);
+#pragma unroll
+        for (int k = 0; k < kDirAhead; ++k) issue_b(k, k % kDirRing, 0);
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kDirAhead - 1) : "memory");
+    }
+    __syncthreads();                                        // (also publishes the zero regions)
+    if (wn == 1) __builtin_amdgcn_s_barrier();              // the second half starts one interval late: its LOAD beside the first half's COMPUTE
+    // Measured alternatives (4 x 64^2, 512 -> 512, us per call; the lock-step kernel 78.7-81): the DMA issued in the LOAD interval 71.3; ONE
+    // barrier per k-tile with the second half multiplying k-tile t - 1 BEFORE it loads k-tile t (an interval = one wave's LOAD + COMPUTE)
+    // 73.5; this form 68.3.  The matrix stream alone (no reads, no DMA) takes 54 us of the lock-step kernel's 87 in the probe build: the
+    // chip does not sustain the nominal 2.4 GHz x 1024 flop per SIMD cycle under it, so the ceiling is nearer 1.6 than 2.5 PFLOP/s.
+    auto step = [&](auto TAP, int ch, unsigned pcur, bool more) {
+        constexpr int tap = decltype(TAP)::value;
+        // ---- LOAD: the fragments of this k-tile; this wave's pieces of k-tile + 1 (its filters and every patch piece issued before
+        //      them) have landed -- what may stay in flight was issued behind them, in the AHEAD - 2 COMPUTE intervals before this one
+        read_all(TAP, pcur);
+        if (more) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(dir_in_flight(tap, true, kDirPieces, kDirAhead)) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(dir_in_flight(tap, false, kDirPieces, kDirAhead)) : "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        if (!CV_PROBE(32)) __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- COMPUTE: 8 MFMAs; the DMA of k-tile + AHEAD (and a piece of the next chunk's patch, BEFORE it: the DMA retires in order) is
+        //      issued between them
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    if (CV_PROBE(2)) acc[0][0][0] += (float)ra[ks][i][0] + (float)rb[ks][j][0];
+                    else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(rb[ks][j], ra[ks][i], acc[i][j], 0, 0, 0);
+                    if (ks == 0 && i == 0 && j == 0) {
+                        if (tap < kDirPieces && more) issue_patch(tap, (ch + 1) & 1, ch + 1);
+                    }
+                    if (ks == 0 && i == 0 && j == 1) {
+                        if (tap + kDirAhead < 9) issue_b(tap + kDirAhead, (tap + kDirAhead) % kDirRing, ch);
+                        else if (more) issue_b(tap + kDirAhead - 9, (tap + kDirAhead - 9) % kDirRing, ch + 1);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+        if (!CV_PROBE(32)) __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    for (int ch = 0; ch < nch; ++ch) {
+        const unsigned pcur = pb0 + (unsigned)(ch & 1) * (kPatchStride * 16);
+        const bool more = ch + 1 < nch;
+        step(DM4D_TAP(0), ch, pcur, more);
+        step(DM4D_TAP(1), ch, pcur, more);
+        step(DM4D_TAP(2), ch, pcur, more);
+        step(DM4D_TAP(3), ch, pcur, more);
+        step(DM4D_TAP(4), ch, pcur, more);
+        step(DM4D_TAP(5), ch, pcur, more);
+        step(DM4D_TAP(6), ch, pcur, more);
+        step(DM4D_TAP(7), ch, pcur, more);
+        step(DM4D_TAP(8), ch, pcur, more);
+    }
+#undef DM4D_TAP
+    if (wn == 0) __builtin_amdgcn_s_barrier();              // (the second half's last COMPUTE)
+    static_assert((size_t)BM * (BN * 2 + 16) <= (size_t)dir_lds_slots<NWN, RING>() * 16, "epilogue staging does not fit");
+    conv_epilogue<BM, BN, NW>(d, acc, row_of, 64 * wn, n0, reinterpret_cast<char *>(smem), tid, lane, cv_probe, [&](int row) {
+        const int g = g0 + (row >> lgTW);
+        return g < R ? g * W + x0 + (row & (TW - 1)) : -1;
+    });
+}
+
+template <int AHEAD>
+__global__ __launch_bounds__(512) void k_conv3x3_direct_pp(ConvDesc d, int chunks_per_split, int lgTW)
+{
+    conv3x3_direct_pp_tile<AHEAD>(d, chunks_per_split, lgTW);
+}
+
 // ---------------------------------------------------------------------------------------- direct variant, rolled tap loop
 // The unrolled template above keeps every tap's swizzled fragment address in a register for the whole kernel (~130 of its 227 VGPRs):
 // two waves per SIMD, whose LDS reads, DMA issue and MFMAs then hardly overlap.  Here the SAME tile algebra for a 256-pixel x 64-filter
@@ -852,11 +1049,12 @@ __global__ __launch_bounds__(256) void k_conv3x3_c128_small(int N, int H, int W,
 
 // tile configurations (DM4D_CONV_CFG; 3 and 7 are what conv_plan picks, the others are the measured alternatives of
 // profiles/r03_zero123.md): 3: 128 x 128, 4 waves of 64 x 64, 4-deep ring | 0 / 10 / 11: the same 3- / 5- / 6-deep | 4 / 6: 128 x 128,
-// 8 waves of 32 x 64, 3- / 4-deep | 7: the direct kernel, 256 x 128, 8 waves | 9: the direct kernel, 256 x 64, 4 waves, two per CU.
+// 8 waves of 32 x 64, 3- / 4-deep | 7: the direct kernel, 256 x 128, 8 waves | 9: the direct kernel, 256 x 64, 4 waves, two per CU |
+// 12: the rolled-tap direct kernel, 256 x 64, four per CU | 13 (round 6, the default direct kernel): 7's tile with the two waves of a SIMD half a period apart.
 // (256 x 128 implicit-GEMM tiles with 64 x 64 or 128 x 64 wave tiles were tried and removed: 256 VGPRs with spills.)
 static void cfg_tile(int cfg, int &BM, int &BN)
 {
-    BM = (cfg == 7 || cfg == 9 || cfg == 12) ? 256 : 128;
+    BM = (cfg == 7 || cfg == 9 || cfg == 12 || cfg == 13) ? 256 : 128;
     BN = (cfg == 9 || cfg == 12) ? 64 : 128;
 }
 // (A/B switches, read once: the problem size from which the direct kernel takes the narrow images, the k-tiles a split must keep)
@@ -871,8 +1069,11 @@ static int conv_plan(int M, int W, int Cout, int kt_total, int &cfg, int &splits
     // box: 10.60 / 10.51 / 10.59 / 10.42-10.49 / 10.83 / 10.78 ms per SDS step): timed alone (tools/conv_shapes.py) the split-K implicit GEMM
     // wins up to 28 GFLOP by up to 25 %, but in the step its float32 partial sums and second launch cost more than on an idle, cache-warm chip
     else if (W >= 8 && (W & (W - 1)) == 0 && (W >= 64 || (double)M * Cout * kt_total * kCvBK * 2.0 >= direct_gflop() * 1e9)) {
-        static const int dcfg = [] { const char *e = getenv("DM4D_CONV_DIRECT_CFG"); return e ? atoi(e) : 7; }();      // (A/B switch: 7 or 9)
-        cfg = (dcfg == 9 || dcfg == 12) ? dcfg : 7;
+        // round 6: the ping-pong kernel (13) on every direct shape -- per call -4 ... -17 % against the lock-step 8-wave kernel (7) and
+        // -7 / +1 / -6 % against the rolled 4-wave one (12) on its three shapes (tools/conv_cfg_vae.py); in the step 67.1 -> 63.6 ms of direct
+        // convolutions per 21 steps under rocprofv3, 9.87 -> 9.78 ms per SDS step (tools/sds_ab.py, two alternating rounds)
+        static const int dcfg = [] { const char *e = getenv("DM4D_CONV_DIRECT_CFG"); return e ? atoi(e) : 13; }();      // (A/B switch: 7, 9, 12 or 13)
+        cfg = (dcfg == 7 || dcfg == 9 || dcfg == 12) ? dcfg : 13;
         // the rolled-tap variant (four 4-wave workgroups per CU) where the grid gives every CU at least four 256 x 64 tiles: the VAE
         // encoder's 256^2 and 128^2 levels (-12 / -10 / -4 % per call, tools/conv_cfg_vae.py); below that its chunk-boundary patch
         // fetch is exposed and the 8-wave kernel wins (64^2: +6 ... +10 %)
@@ -931,7 +1132,7 @@ static inline int conv_out(int in, int stride, int pad) { return stride == 1 ? i
 static int conv_plan_s(int M, int W, int Cout, int kt_total, int stride, int &cfg, int &splits)
 {
     const int rc = conv_plan(M, stride == 1 ? W : 0, Cout, kt_total, cfg, splits);
-    if (stride != 1 && (cfg == 7 || cfg == 9 || cfg == 12)) cfg = 3;
+    if (stride != 1 && (cfg == 7 || cfg == 9 || cfg == 12 || cfg == 13)) cfg = 3;
     return rc;
 }
 
@@ -991,7 +1192,7 @@ int dm4d_conv3x3_strided_nhwc_f16(int32_t N, int32_t Hin, int32_t Win, int32_t C
 #endif
     int cfg;
     conv_plan_s(d.M, W, Cout, d.kt_total, stride, cfg, d.splits);
-    if ((cfg == 7 || cfg == 9 || cfg == 12) && (stride != 1 || pad != 1)) { set_error("conv3x3: the direct kernel takes stride 1, pad 1 only"); return DM4D_ERR_UNSUPPORTED; }
+    if ((cfg == 7 || cfg == 9 || cfg == 12 || cfg == 13) && (stride != 1 || pad != 1)) { set_error("conv3x3: the direct kernel takes stride 1, pad 1 only"); return DM4D_ERR_UNSUPPORTED; }
     d.kt_per = (d.kt_total + d.splits - 1) / d.splits;
     d.splits = (d.kt_total + d.kt_per - 1) / d.kt_per;
     d.partial = (float *)scratch;
@@ -1005,7 +1206,7 @@ int dm4d_conv3x3_strided_nhwc_f16(int32_t N, int32_t Hin, int32_t Win, int32_t C
     case 11: rc = conv_launch<2, 2, 2, 2, 6>(d, st); break;      // ... 6-deep (96 KB: one workgroup per CU)
     case 4: rc = conv_launch<4, 2, 1, 2, 3>(d, st); break;
     case 6: rc = conv_launch<4, 2, 1, 2, 4>(d, st); break;
-    case 7: case 9: case 12: {      // direct: 256 pixels x 128 (7) / 64 (9) filters, the input patch resident in LDS for the nine taps
+    case 7: case 9: case 12: case 13: {      // direct: 256 pixels x 128 (7) / 64 (9) filters, the input patch resident in LDS for the nine taps
         const int W_ = d.W;
         if (W_ < 8 || (W_ & (W_ - 1)) != 0) { set_error("conv3x3 direct: W must be a power of two >= 8"); return DM4D_ERR_UNSUPPORTED; }
         int lgTW = 3;
@@ -1014,7 +1215,12 @@ int dm4d_conv3x3_strided_nhwc_f16(int32_t N, int32_t Hin, int32_t Win, int32_t C
         const int chunks_per_split = (cpt + d.splits - 1) / d.splits;
         d.splits = (cpt + chunks_per_split - 1) / chunks_per_split;
         const unsigned tiles_m = (unsigned)(((R + TH - 1) / TH) * (W_ >> lgTW));
-        if (cfg == 7) {         // 8 waves, 256 x 128, one workgroup per CU
+        if (cfg == 13) {        // 8 waves, 256 x 128, the two waves of a SIMD half a period apart (ping-pong)
+            const size_t lds = (size_t)dir_lds_slots<2, 9>() * 16;
+            static bool attr_set = false;
+            if (!attr_set) { DM4D_HIP_CHECK(hipFuncSetAttribute((const void *)k_conv3x3_direct_pp<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr_set = true; }
+            hipLaunchKernelGGL((k_conv3x3_direct_pp<4>), dim3(tiles_m, (d.Cout + 127) / 128, d.splits), dim3(512), lds, st, d, chunks_per_split, lgTW);
+        } else if (cfg == 7) {         // 8 waves, 256 x 128, one workgroup per CU
             const size_t lds = (size_t)dir_lds_slots<2, 9>() * 16;
             static bool attr_set = false;
             if (!attr_set) { DM4D_HIP_CHECK(hipFuncSetAttribute((const void *)k_conv3x3_direct<2, 9, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr_set = true; }

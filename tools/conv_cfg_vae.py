@@ -15,7 +15,7 @@ def bench(fn, n=20):
     for _ in range(5): g.replay()
     torch.cuda.synchronize()
     return (time.perf_counter() - t0) / (5 * n) * 1e6
-for (N,H,Ci,Co) in [(4,256,128,128),(4,128,128,256),(4,128,256,256),(4,64,256,512),(4,64,512,512),(8,32,640,640),(1,32,64,128),(2,64,96,160)]:
+for (N,H,Ci,Co) in [(4,256,128,128),(4,128,128,256),(4,128,256,256),(4,64,256,512),(4,64,512,512),(4,32,512,512),(8,32,320,320),(8,32,640,320),(8,32,960,320),(8,32,640,640),(1,32,64,128),(2,64,96,160)]:
     x = torch.randn(N, Ci, H, H, device=dev, dtype=torch.float16).contiguous(memory_format=torch.channels_last)
     w = (torch.randn(Co, Ci, 3, 3, device=dev, dtype=torch.float16) * (9*Ci)**-0.5)
     b = torch.randn(Co, device=dev, dtype=torch.float16)
