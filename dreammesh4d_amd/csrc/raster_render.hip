@@ -301,6 +301,15 @@ __device__ __forceinline__ void pixel_pair(const EntryRegs<C> &e, float (&acc)[1
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
         const float4 *ln = reinterpret_cast<const float4 *>(tab + (P + h) * LN);
+#if defined(DM4D_BWD_PROBE) && (DM4D_BWD_PROBE & 2)      // TIMING PROBE: no table reads (values from registers)
+        if constexpr (kSix) {
+            const float f_ = e.o + (float)(P + h);
+            g[h][0] = f_; g[h][1] = e.dep; g[h][2] = f_ + 1.f; g[h][3] = f_ * 0.5f; g[h][4] = e.dep + 2.f; g[h][5] = f_ - 1.f; gD[h] = 0.f; gA[h] = f_;
+            T[h] = 0.5f; S[h] = e.dep; last[h] = 0xFFFFu;
+            (void)ln;
+            continue;
+        }
+#endif
         if constexpr (kSix) {
             const float4 q2 = ln[2], q0 = ln[0], q1 = ln[1];
             g[h][0] = q0.x; g[h][1] = q0.y; g[h][2] = q0.z; g[h][3] = q0.w; g[h][4] = q1.x; g[h][5] = q1.y; gD[h] = q1.z; gA[h] = q1.w;
@@ -321,6 +330,17 @@ __device__ __forceinline__ void pixel_pair(const EntryRegs<C> &e, float (&acc)[1
     // alpha: the hardware exp2 (1 ulp) instead of the contract's det_expf (12 instructions) -- but the DECISIONS of the
     // forward (power <= 0, alpha >= 1/255) must be reproduced exactly, so a pair within 5e-6 (relative) of the alpha
     // threshold or 1e-6 of power == 0 sends the wave through det_expf (rare: a wave-uniform branch)
+#ifdef DM4D_BWD_MASKPROBE
+    // TIMING PROBE ONLY (tools/build_variant.sh): what the backward would cost if the forward handed it a 16-bit contributor mask per
+    // list entry -- one bit test per pixel instead of the two compares, the select chain and the exp guard (results are NOT the reference's)
+    G[0] = __builtin_amdgcn_exp2f(pw[0] * 0x1.715476p+0f);
+    G[1] = __builtin_amdgcn_exp2f(pw[1] * 0x1.715476p+0f);
+    araw[0] = e.o * G[0]; araw[1] = e.o * G[1];
+    am[0] = __uint_as_float(__float_as_uint(araw[0]) & (uint32_t)__builtin_amdgcn_sbfe((int)e.k, P, 1));
+    am[1] = __uint_as_float(__float_as_uint(araw[1]) & (uint32_t)__builtin_amdgcn_sbfe((int)e.k, P + 1, 1));
+    a[0] = __builtin_amdgcn_fmed3f(am[0], 0.0f, 0.99f); a[1] = __builtin_amdgcn_fmed3f(am[1], 0.0f, 0.99f);
+    (void)last;
+#else
     constexpr float kThr = 1.0f / 255.0f;
     G[0] = __builtin_amdgcn_exp2f(pw[0] * 0x1.715476p+0f);
     G[1] = __builtin_amdgcn_exp2f(pw[1] * 0x1.715476p+0f);
@@ -341,10 +361,15 @@ __device__ __forceinline__ void pixel_pair(const EntryRegs<C> &e, float (&acc)[1
         // in front of its v_min, and this kernel's duration is its VALU instruction count (profiles/r03_pmc_sq.md)
         a[0] = __builtin_amdgcn_fmed3f(am[0], 0.0f, 0.99f); a[1] = __builtin_amdgcn_fmed3f(am[1], 0.0f, 0.99f);
     }
+#endif
     om[0] = 1.f - a[0]; om[1] = 1.f - a[1];
     Pinc[0] = om[0]; Pinc[1] = om[1];
     Pexc[0] = Pexc[1] = 1.0f;
+#if defined(DM4D_BWD_PROBE) && (DM4D_BWD_PROBE & 4)      // TIMING PROBE: no scans
+    Pexc[0] = Pinc[0] * 0.5f; Pexc[1] = Pinc[1] * 0.5f;
+#else
     scan2_mul<WIDE>(Pinc[0], Pinc[1], Pexc[0], Pexc[1]);     // product over the entries behind, this one included / excluded
+#endif
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
         float v = __builtin_fmaf(e.c[0], g[h][0], gA[h]);
@@ -357,15 +382,27 @@ __device__ __forceinline__ void pixel_pair(const EntryRegs<C> &e, float (&acc)[1
         }
         V[h] = LEAN >= 2 ? v : __builtin_fmaf(e.dep, gD[h], v);      // (LEAN == 2: no depth gradient -- the product would be an exact 0)
     }
+#if defined(DM4D_BWD_PROBE) && (DM4D_BWD_PROBE & 8)      // TIMING PROBE: no rcp
+    const float R0 = Pinc[0] + 1.f, R1 = Pinc[1] + 1.f;
+#else
     const float R0 = __builtin_amdgcn_rcpf(Pinc[0]), R1 = __builtin_amdgcn_rcpf(Pinc[1]);
+#endif
     Tb[0] = T[0] * R0; Tb[1] = T[1] * R1;                    // transmittance in front of the entry
     inv_om[0] = Pexc[0] * R0; inv_om[1] = Pexc[1] * R1;      // 1 / (1 - alpha)
     w[0] = a[0] * Tb[0]; w[1] = a[1] * Tb[1];
     Sinc[0] = V[0] * w[0]; Sinc[1] = V[1] * w[1];
     Sexc[0] = Sexc[1] = 0.0f;
+#if defined(DM4D_BWD_PROBE) && (DM4D_BWD_PROBE & 4)
+    Sexc[0] = Sinc[0] * 0.5f; Sexc[1] = Sinc[1] * 0.5f;
+#else
     scan2_add<WIDE>(Sinc[0], Sinc[1], Sexc[0], Sexc[1]);
+#endif
     Stot[0] = S[0] + Sexc[0]; Stot[1] = S[1] + Sexc[1];      // everything behind the entry
+#if defined(DM4D_BWD_PROBE) && (DM4D_BWD_PROBE & 16)     // TIMING PROBE: no carry write
+    if (false) {
+#else
     if (front_lane) {      // the chunk in front starts from (T before, S from) this chunk's front entry
+#endif
         float *t0 = tab + P * LN + (kSix ? 8 : 5), *t1 = t0 + LN;
         *reinterpret_cast<float2 *>(t0) = make_float2(Tb[0], S[0] + Sinc[0]);
         *reinterpret_cast<float2 *>(t1) = make_float2(Tb[1], S[1] + Sinc[1]);
@@ -428,6 +465,11 @@ template <int C, int LEAN, bool WIDE>
 __device__ __forceinline__ void cell_pixels(const EntryRegs<C> &e, float (&acc)[13], const bool front_lane, float *tab)
 {
     Moments mo = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#if defined(DM4D_BWD_PROBE) && (DM4D_BWD_PROBE & 128)    // TIMING PROBE: no pixel work at all (gathers, zero fills and record stores only)
+    acc[0] = e.o; acc[1] = e.dep; acc[2] = e.dx[0]; acc[3] = e.dy[1]; acc[4] = e.Bdx[2]; acc[5] = e.c[0]; acc[6] = e.c[C > 3 ? 3 : 1]; acc[7] = e.Adx2[3] + e.Cdy2[2];
+    (void)front_lane; (void)tab;
+    return;
+#endif
     pixel_pair<C, LEAN, WIDE, 0>(e, acc, mo, front_lane, tab);
     pixel_pair<C, LEAN, WIDE, 2>(e, acc, mo, front_lane, tab);
     pixel_pair<C, LEAN, WIDE, 4>(e, acc, mo, front_lane, tab);
@@ -473,6 +515,15 @@ __device__ __forceinline__ void load_entry(EntryRegs<C> &e, uint32_t &slot, cons
     e.o = 0.f; e.dep = 0.f; e.k = 0xFFFFFFFFu; slot = 0xFFFFFFFFu;
 #pragma unroll
     for (int ch = 0; ch < C; ++ch) e.c[ch] = 0.f;
+#if defined(DM4D_BWD_PROBE) && (DM4D_BWD_PROBE & 64)     // TIMING PROBE: no gathers of the entry's attributes
+    if (live) {
+        const uint32_t word = list[j];
+        if (SLOT) slot = (word & kGidMask) * 3u + (word >> kGidBits);
+        e.k = j;
+        x = cx0 + (float)(word & 3u); y = cy0 + (float)((word >> 2) & 3u); cA = 0.3f; cB = 0.01f; cC = 0.2f; e.o = 0.8f; e.dep = 3.f;
+        for (int ch = 0; ch < C; ++ch) e.c[ch] = 0.1f * (float)ch;
+    } else
+#endif
     if (live) {
         const uint32_t word = list[j];
         if (SLOT) slot = entry_slot(word, g, gx, gy);
@@ -551,12 +602,39 @@ __device__ __forceinline__ void store_records(float *__restrict__ rec, const uin
     if (RSP > 12) mine[3] = make_float4(acc[12], 0.f, 0.f, 0.f);
     st.slot[lane] = slot;
     __builtin_amdgcn_wave_barrier();
+    if constexpr (RSP == 8) {      // 32-byte records: two lanes per record, every lane of both store instructions active
+#if !defined(DM4D_BWD_STORE4)
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            const int entry = 32 * p + (lane >> 1), part = lane & 1;
+            const uint32_t sl = st.slot[entry];
+#if defined(DM4D_BWD_PROBE) && (DM4D_BWD_PROBE & 32)
+            if (sl == 0xFFFFFFF0u)
+#else
+            if (sl < rec_cap)
+#endif
+            {
+#if defined(DM4D_BWD_NT)
+                typedef float f4v __attribute__((ext_vector_type(4)));
+                __builtin_nontemporal_store(*reinterpret_cast<const f4v *>(&st.rec[entry][4 * part]), reinterpret_cast<f4v *>(rec + (size_t)sl * RSP) + part);
+#else
+                reinterpret_cast<float4 *>(rec + (size_t)sl * RSP)[part] = reinterpret_cast<const float4 *>(st.rec[entry])[part];
+#endif
+            }
+        }
+        return;
+#endif
+    }
     const int part = lane & 3;
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
         const int entry = 16 * p + (lane >> 2);
         const uint32_t sl = st.slot[entry];
+#if defined(DM4D_BWD_PROBE) && (DM4D_BWD_PROBE & 32)     // TIMING PROBE: no record stores
+        if (part < RSP / 4 && sl == 0xFFFFFFF0u)
+#else
         if (part < RSP / 4 && sl < rec_cap)
+#endif
             reinterpret_cast<float4 *>(rec + (size_t)sl * RSP)[part] = reinterpret_cast<const float4 *>(st.rec[entry])[part];
     }
 }
