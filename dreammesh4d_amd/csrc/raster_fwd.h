@@ -95,6 +95,11 @@ __device__ __forceinline__ void pair_gauss(const f4v (&ga)[N], const f4v (&gc)[N
     for (int j = 0; j < N; ++j) { u[j] = ga[j].xy + gc[j].xy; w[j] = ga[j].zw * gc[j].zw; }
 #pragma unroll
     for (int j = 0; j < N; ++j) pw[j] = (f2v)(-0.5f) * u[j] - w[j];
+#if defined(DM4D_FWD_PROBE) && (DM4D_FWD_PROBE & 1)      // TIMING PROBE (tools/build_variant.sh): the hardware exp2 instead of the contract's polynomial
+#pragma unroll
+    for (int j = 0; j < N; ++j) G[j] = f2v{__builtin_amdgcn_exp2f(pw[j].x * 0x1.715476p+0f), __builtin_amdgcn_exp2f(pw[j].y * 0x1.715476p+0f)};
+    return;
+#endif
     // det_expf (common.h), two elements per instruction where the ISA has a packed form
     const float L2E_HI = 0x1.715476p+0f, L2E_LO = 0x1.4ae0c0p-26f, MAGIC = 12582912.0f;
     f2v x[N], t[N], n[N], f[N], p[N];

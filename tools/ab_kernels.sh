@@ -7,7 +7,7 @@ cd /tmp && export TMPDIR=/tmp
 for v in "$@"; do
   cp $REPO/$v $REPO/dreammesh4d_amd/libdm4d_hip.so
   rm -rf /tmp/abk
-  rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/abk -o k -- python $REPO/bench.py --no-cpu-baseline --no-iters --steps 30 --warmup 5 > /dev/null 2>&1
+  rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/abk -o k -- python $REPO/bench.py --no-cpu-baseline --no-iters --no-step8 --no-variants --steps 30 --warmup 5 $BENCH_ARGS > /dev/null 2>&1
   echo "== $v"
   python - <<PY
 import csv, glob
