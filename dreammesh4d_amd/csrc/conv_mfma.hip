@@ -594,11 +594,17 @@ __global__ __launch_bounds__(256 * NWN) void k_conv3x3_direct(ConvDesc d, int ch
 // SIMD's matrix pipe) with its partner's LDS reads and DMA issue -- matrix beside memory.  One register set of fragments (a wave never
 // reads while it multiplies), two barriers per k-tile.  Same tile algebra, LDS layout, DMA order and epilogue as conv3x3_direct_tile<2, 9, 4>:
 // a k-tile's tiles are waited for by every wave at the end of its LOAD of the k-tile before and published by the barrier behind it.
-template <int AHEAD>
+// MB: 32-row MFMA tiles of pixels per wave -- 2: the 256 x 128 workgroup tile; 4 (round 6): 512 x 128, for the wide levels whose grid still fills the machine:
+// a filter piece then feeds 16 MFMAs per wave instead of 8 (0.83 instead of 1.33 LDS-DMA instructions per 8 MFMAs: the DMA issue, ~130 cycles
+// an instruction, is what an interval of this kernel is as long as), the DMA is issued in the LOAD interval (12 fragment reads + 1.6 DMA beside 16 MFMAs).
+template <int MB> constexpr int pp_patch_slots() { return MB == 2 ? kDirPatchSlots : 2560; }      // 4: (16 + 2) x 34 = 612 patch pixels x 4 pieces, in whole pieces per wave
+template <int MB> constexpr int pp_lds_slots() { return 2 * (kDirZeroSlots + pp_patch_slots<MB>()) + 9 * 512; }
+template <int AHEAD, int MB>
 __device__ __forceinline__ void conv3x3_direct_pp_tile(const ConvDesc &d, int chunks_per_split, int lgTW)
 {
     constexpr int NWN = 2, RING = 9;
-    constexpr int BM = 256, BN = 64 * NWN, NW = 4 * NWN;
+    constexpr int BM = 128 * MB, BN = 64 * NWN, NW = 4 * NWN;
+    constexpr int kDirPatchSlots = pp_patch_slots<MB>();      // (shadows the 256-pixel tile's constant)
     constexpr int kDirPieces = kDirPatchSlots / (64 * NW), kDirBSlots = 256 * NWN, kDirRing = RING, kDirAhead = AHEAD;
     static_assert(AHEAD >= 2 && AHEAD < RING && kDirPieces <= 9, "ring");
     extern __shared__ __attribute__((aligned(1024))) uint4 smem[];
@@ -647,10 +653,10 @@ __device__ __forceinline__ void conv3x3_direct_pp_tile(const ConvDesc &d, int ch
         __builtin_amdgcn_raw_ptr_buffer_load_lds(b_rs, (__attribute__((address_space(3))) void *)(s_b + stage * kDirBSlots + 64 * wave), 16, b_vo,
                                                  tap * cin2 + (ch0 + chunk) * (kCvBK * 2), 0, 0);
     };
-    int row_of[2], qa[2][3];
+    int row_of[MB], qa[MB][3];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int r = 64 * wm + 32 * i + (lane & 31), tr = r >> lgTW, tc = r & (TW - 1);
+    for (int i = 0; i < MB; ++i) {
+        const int r = 32 * MB * wm + 32 * i + (lane & 31), tr = r >> lgTW, tc = r & (TW - 1);
         const int g = g0 + tr, y = g % d.H;
         const bool row_ok = g < R;
         const int q = (tr + 1) * PW + tc + 1;
@@ -668,34 +674,50 @@ __device__ __forceinline__ void conv3x3_direct_pp_tile(const ConvDesc &d, int ch
             fb[ks][j] = (unsigned)(size_t)(__attribute__((address_space(3))) uint4 *)(s_b + cv_slot(64 * wn + 32 * j + (lane & 31), 2 * ks + hi));
     const unsigned pb0 = (unsigned)(size_t)(__attribute__((address_space(3))) uint4 *)s_patch0;
 
-    f32x16 acc[2][2];
+    f32x16 acc[MB][2];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < MB; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    f16x8 ra[2][2] = {}, rb[2][2] = {};
+    f16x8 ra[2][MB] = {}, rb[2][2] = {};
     // byte offset (from a patch buffer's start) of the ks = 0 fragment of tile row i for each of the nine taps; ks = 1 is the same slot
     // with piece ^ 2, i.e. offset ^ 32 (the buffers are 256-byte aligned): 18 registers instead of ~6 VALU operations per read -- a
     // LOAD interval is as long as its instruction stream (DMA issue, addresses, 8 reads, their latency), not as its bytes
-    unsigned po[2][9];
+    // (MB = 4: 36 of them do not fit beside 128 accumulator registers -- 256 VGPRs + 10 spilled; its LOAD interval lies beside 16 MFMAs and has
+    //  the issue slots to compute the four addresses of a k-tile from qa[][], ~5 VALU operations each)
+    constexpr int kPo = MB == 2 ? 9 : 1;
+    unsigned po[MB][kPo];
+    if constexpr (MB == 2) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < MB; ++i)
 #pragma unroll
-        for (int tap = 0; tap < 9; ++tap) {
-            const int q = qa[i][tap / 3] + (tap % 3 - 1);
-            po[i][tap] = 16u * (unsigned)(4 * q + (hi ^ ((q >> 2) & 3)));
-        }
+            for (int tap = 0; tap < 9; ++tap) {
+                const int q = qa[i][tap / 3] + (tap % 3 - 1);
+                po[i][tap] = 16u * (unsigned)(4 * q + (hi ^ ((q >> 2) & 3)));
+            }
+    }
     // every fragment of k-tile (tap TAP) from the patch buffer at byte address `pbase`, filter stage TAP % RING
     auto read_all = [&](auto TAP, unsigned pbase) {
         constexpr int tap = decltype(TAP)::value;
         if (CV_PROBE(64)) return;
+        unsigned pa[MB];
+#pragma unroll
+        for (int i = 0; i < MB; ++i) {
+            if constexpr (MB == 2) pa[i] = po[i][tap];
+            else {
+                int q = qa[i][tap / 3];
+                asm volatile("" : "+v"(q));          // (computed HERE: the loop-invariant code motion would keep all 36 addresses in registers again)
+                q += tap % 3 - 1;
+                pa[i] = 16u * (unsigned)(4 * q + (hi ^ ((q >> 2) & 3)));
+            }
+        }
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const unsigned a = pbase + (po[i][tap] ^ (ks ? 32u : 0u));
+            for (int i = 0; i < MB; ++i) {
+                const unsigned a = pbase + (pa[i] ^ (ks ? 32u : 0u));
                 ra[ks][i] = *reinterpret_cast<const __attribute__((address_space(3))) f16x8 *>(a);
             }
 #pragma unroll
@@ -721,30 +743,39 @@ __device__ __forceinline__ void conv3x3_direct_pp_tile(const ConvDesc &d, int ch
     auto step = [&](auto TAP, int ch, unsigned pcur, bool more) {
         constexpr int tap = decltype(TAP)::value;
         // ---- LOAD: the fragments of this k-tile; this wave's pieces of k-tile + 1 (its filters and every patch piece issued before
-        //      them) have landed -- what may stay in flight was issued behind them, in the AHEAD - 2 COMPUTE intervals before this one
+        //      them) have landed -- what may stay in flight was issued behind them, in the AHEAD - 2 intervals before this one (and, MB = 4,
+        //      in this one: the DMA of k-tile + AHEAD -- a piece of the next chunk's patch BEFORE it, the DMA retires in order -- leads the interval)
+        constexpr bool kDmaInLoad = MB == 4;
+        if constexpr (kDmaInLoad) {
+            if (tap < kDirPieces && more) issue_patch(tap, (ch + 1) & 1, ch + 1);
+            if (tap + kDirAhead < 9) issue_b(tap + kDirAhead, (tap + kDirAhead) % kDirRing, ch);
+            else if (more) issue_b(tap + kDirAhead - 9, (tap + kDirAhead - 9) % kDirRing, ch + 1);
+        }
         read_all(TAP, pcur);
-        if (more) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(dir_in_flight(tap, true, kDirPieces, kDirAhead)) : "memory");
-        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(dir_in_flight(tap, false, kDirPieces, kDirAhead)) : "memory");
+        constexpr int kMine1 = kDmaInLoad ? dir_issues(tap, true, kDirPieces, kDirAhead) : 0, kMine0 = kDmaInLoad ? dir_issues(tap, false, kDirPieces, kDirAhead) : 0;
+        if (more) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(dir_in_flight(tap, true, kDirPieces, kDirAhead) + kMine1) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(dir_in_flight(tap, false, kDirPieces, kDirAhead) + kMine0) : "memory");
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
         if (!CV_PROBE(32)) __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
-        // ---- COMPUTE: 8 MFMAs; the DMA of k-tile + AHEAD (and a piece of the next chunk's patch, BEFORE it: the DMA retires in order) is
-        //      issued between them
+        // ---- COMPUTE: 4 MB MFMAs; MB = 2: the DMA of k-tile + AHEAD is issued between them
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < MB; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
                     if (CV_PROBE(2)) acc[0][0][0] += (float)ra[ks][i][0] + (float)rb[ks][j][0];
                     else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(rb[ks][j], ra[ks][i], acc[i][j], 0, 0, 0);
-                    if (ks == 0 && i == 0 && j == 0) {
-                        if (tap < kDirPieces && more) issue_patch(tap, (ch + 1) & 1, ch + 1);
-                    }
-                    if (ks == 0 && i == 0 && j == 1) {
-                        if (tap + kDirAhead < 9) issue_b(tap + kDirAhead, (tap + kDirAhead) % kDirRing, ch);
-                        else if (more) issue_b(tap + kDirAhead - 9, (tap + kDirAhead - 9) % kDirRing, ch + 1);
+                    if constexpr (!kDmaInLoad) {
+                        if (ks == 0 && i == 0 && j == 0) {
+                            if (tap < kDirPieces && more) issue_patch(tap, (ch + 1) & 1, ch + 1);
+                        }
+                        if (ks == 0 && i == 0 && j == 1) {
+                            if (tap + kDirAhead < 9) issue_b(tap + kDirAhead, (tap + kDirAhead) % kDirRing, ch);
+                            else if (more) issue_b(tap + kDirAhead - 9, (tap + kDirAhead - 9) % kDirRing, ch + 1);
+                        }
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 }
@@ -766,17 +797,17 @@ __device__ __forceinline__ void conv3x3_direct_pp_tile(const ConvDesc &d, int ch
     }
 #undef DM4D_TAP
     if (wn == 0) __builtin_amdgcn_s_barrier();              // (the second half's last COMPUTE)
-    static_assert((size_t)BM * (BN * 2 + 16) <= (size_t)dir_lds_slots<NWN, RING>() * 16, "epilogue staging does not fit");
+    static_assert((size_t)BM * (BN * 2 + 16) <= (size_t)pp_lds_slots<MB>() * 16, "epilogue staging does not fit");
     conv_epilogue<BM, BN, NW>(d, acc, row_of, 64 * wn, n0, reinterpret_cast<char *>(smem), tid, lane, cv_probe, [&](int row) {
         const int g = g0 + (row >> lgTW);
         return g < R ? g * W + x0 + (row & (TW - 1)) : -1;
     });
 }
 
-template <int AHEAD>
+template <int AHEAD, int MB>
 __global__ __launch_bounds__(512) void k_conv3x3_direct_pp(ConvDesc d, int chunks_per_split, int lgTW)
 {
-    conv3x3_direct_pp_tile<AHEAD>(d, chunks_per_split, lgTW);
+    conv3x3_direct_pp_tile<AHEAD, MB>(d, chunks_per_split, lgTW);
 }
 
 // ---------------------------------------------------------------------------------------- direct variant, rolled tap loop
@@ -1050,11 +1081,12 @@ __global__ __launch_bounds__(256) void k_conv3x3_c128_small(int N, int H, int W,
 // tile configurations (DM4D_CONV_CFG; 3 and 7 are what conv_plan picks, the others are the measured alternatives of
 // profiles/r03_zero123.md): 3: 128 x 128, 4 waves of 64 x 64, 4-deep ring | 0 / 10 / 11: the same 3- / 5- / 6-deep | 4 / 6: 128 x 128,
 // 8 waves of 32 x 64, 3- / 4-deep | 7: the direct kernel, 256 x 128, 8 waves | 9: the direct kernel, 256 x 64, 4 waves, two per CU |
-// 12: the rolled-tap direct kernel, 256 x 64, four per CU | 13 (round 6, the default direct kernel): 7's tile with the two waves of a SIMD half a period apart.
+// 12: the rolled-tap direct kernel, 256 x 64, four per CU | 13 (round 6, the default direct kernel): 7's tile with the two waves of a SIMD half a period apart |
+// 14: the same with a 512 x 128 tile (the plan's choice where its grid fills the machine).
 // (256 x 128 implicit-GEMM tiles with 64 x 64 or 128 x 64 wave tiles were tried and removed: 256 VGPRs with spills.)
 static void cfg_tile(int cfg, int &BM, int &BN)
 {
-    BM = (cfg == 7 || cfg == 9 || cfg == 12 || cfg == 13) ? 256 : 128;
+    BM = cfg == 14 ? 512 : (cfg == 7 || cfg == 9 || cfg == 12 || cfg == 13) ? 256 : 128;
     BN = (cfg == 9 || cfg == 12) ? 64 : 128;
 }
 // (A/B switches, read once: the problem size from which the direct kernel takes the narrow images, the k-tiles a split must keep)
@@ -1079,6 +1111,10 @@ static int conv_plan(int M, int W, int Cout, int kt_total, int &cfg, int &splits
         // fetch is exposed and the 8-wave kernel wins (64^2: +6 ... +10 %)
         static const long d4_min = [] { const char *e = getenv("DM4D_CONV_D4_MIN_WGS"); return e ? atol(e) : 1024L; }();      // (A/B switch; 0: never)
         if (cfg == 7 && d4_min > 0 && (long)((M + 255) / 256) * ((Cout + 63) / 64) >= d4_min) cfg = 12;
+        // the 512-pixel ping-pong tile where its grid still gives every CU a workgroup (the VAE encoder's 256^2 and 128^2 levels: -8 ... -12 % per call
+        // against the 256-pixel one; with half the machine filled, 64^2: +20 ... +40 %)
+        static const long p14_min = [] { const char *e = getenv("DM4D_CONV_PP512_MIN_WGS"); return e ? atol(e) : 256L; }();      // (A/B switch; 0: never)
+        if (cfg == 13 && p14_min > 0 && W >= 32 && (long)((M + 511) / 512) * ((Cout + 127) / 128) >= p14_min) cfg = 14;
     }
     else cfg = 3;
     int BM, BN;
@@ -1132,7 +1168,7 @@ static inline int conv_out(int in, int stride, int pad) { return stride == 1 ? i
 static int conv_plan_s(int M, int W, int Cout, int kt_total, int stride, int &cfg, int &splits)
 {
     const int rc = conv_plan(M, stride == 1 ? W : 0, Cout, kt_total, cfg, splits);
-    if (stride != 1 && (cfg == 7 || cfg == 9 || cfg == 12 || cfg == 13)) cfg = 3;
+    if (stride != 1 && (cfg == 7 || cfg == 9 || cfg == 12 || cfg == 13 || cfg == 14)) cfg = 3;
     return rc;
 }
 
@@ -1192,7 +1228,7 @@ int dm4d_conv3x3_strided_nhwc_f16(int32_t N, int32_t Hin, int32_t Win, int32_t C
 #endif
     int cfg;
     conv_plan_s(d.M, W, Cout, d.kt_total, stride, cfg, d.splits);
-    if ((cfg == 7 || cfg == 9 || cfg == 12 || cfg == 13) && (stride != 1 || pad != 1)) { set_error("conv3x3: the direct kernel takes stride 1, pad 1 only"); return DM4D_ERR_UNSUPPORTED; }
+    if ((cfg == 7 || cfg == 9 || cfg == 12 || cfg == 13 || cfg == 14) && (stride != 1 || pad != 1)) { set_error("conv3x3: the direct kernel takes stride 1, pad 1 only"); return DM4D_ERR_UNSUPPORTED; }
     d.kt_per = (d.kt_total + d.splits - 1) / d.splits;
     d.splits = (d.kt_total + d.kt_per - 1) / d.kt_per;
     d.partial = (float *)scratch;
@@ -1206,20 +1242,26 @@ int dm4d_conv3x3_strided_nhwc_f16(int32_t N, int32_t Hin, int32_t Win, int32_t C
     case 11: rc = conv_launch<2, 2, 2, 2, 6>(d, st); break;      // ... 6-deep (96 KB: one workgroup per CU)
     case 4: rc = conv_launch<4, 2, 1, 2, 3>(d, st); break;
     case 6: rc = conv_launch<4, 2, 1, 2, 4>(d, st); break;
-    case 7: case 9: case 12: case 13: {      // direct: 256 pixels x 128 (7) / 64 (9) filters, the input patch resident in LDS for the nine taps
+    case 7: case 9: case 12: case 13: case 14: {      // direct: 256 pixels x 128 (7) / 64 (9) filters, the input patch resident in LDS for the nine taps
         const int W_ = d.W;
         if (W_ < 8 || (W_ & (W_ - 1)) != 0) { set_error("conv3x3 direct: W must be a power of two >= 8"); return DM4D_ERR_UNSUPPORTED; }
         int lgTW = 3;
         while ((1 << lgTW) < W_ && lgTW < 5) ++lgTW;                       // TW = min(W, 32)
-        const int TH = 256 >> lgTW, R = d.N * d.H, cpt = d.Cin / kCvBK;
+        if (cfg == 14 && W_ < 32) { set_error("conv3x3 direct (512-pixel tile): W must be a power of two >= 32"); return DM4D_ERR_UNSUPPORTED; }
+        const int TH = (cfg == 14 ? 512 : 256) >> lgTW, R = d.N * d.H, cpt = d.Cin / kCvBK;
         const int chunks_per_split = (cpt + d.splits - 1) / d.splits;
         d.splits = (cpt + chunks_per_split - 1) / chunks_per_split;
         const unsigned tiles_m = (unsigned)(((R + TH - 1) / TH) * (W_ >> lgTW));
-        if (cfg == 13) {        // 8 waves, 256 x 128, the two waves of a SIMD half a period apart (ping-pong)
-            const size_t lds = (size_t)dir_lds_slots<2, 9>() * 16;
+        if (cfg == 14) {        // 8 waves, 512 x 128, ping-pong
+            const size_t lds = (size_t)pp_lds_slots<4>() * 16;
             static bool attr_set = false;
-            if (!attr_set) { DM4D_HIP_CHECK(hipFuncSetAttribute((const void *)k_conv3x3_direct_pp<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr_set = true; }
-            hipLaunchKernelGGL((k_conv3x3_direct_pp<4>), dim3(tiles_m, (d.Cout + 127) / 128, d.splits), dim3(512), lds, st, d, chunks_per_split, lgTW);
+            if (!attr_set) { DM4D_HIP_CHECK(hipFuncSetAttribute((const void *)k_conv3x3_direct_pp<4, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr_set = true; }
+            hipLaunchKernelGGL((k_conv3x3_direct_pp<4, 4>), dim3(tiles_m, (d.Cout + 127) / 128, d.splits), dim3(512), lds, st, d, chunks_per_split, lgTW);
+        } else if (cfg == 13) {        // 8 waves, 256 x 128, the two waves of a SIMD half a period apart (ping-pong)
+            const size_t lds = (size_t)pp_lds_slots<2>() * 16;
+            static bool attr_set = false;
+            if (!attr_set) { DM4D_HIP_CHECK(hipFuncSetAttribute((const void *)k_conv3x3_direct_pp<4, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr_set = true; }
+            hipLaunchKernelGGL((k_conv3x3_direct_pp<4, 2>), dim3(tiles_m, (d.Cout + 127) / 128, d.splits), dim3(512), lds, st, d, chunks_per_split, lgTW);
         } else if (cfg == 7) {         // 8 waves, 256 x 128, one workgroup per CU
             const size_t lds = (size_t)dir_lds_slots<2, 9>() * 16;
             static bool attr_set = false;

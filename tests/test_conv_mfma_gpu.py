@@ -16,6 +16,9 @@ SHAPES = [  # N, H, W, Cin, Cout       (a subset of the 22 shapes of one SDS ste
     # the direct kernel (W >= 64) off its comfortable path: one channel chunk (no prefetch of a next patch), fewer filters than
     # a tile, a row count that is no multiple of the tile's 8 rows, tiles that straddle two images, H != W
     (1, 64, 64, 32, 64), (1, 20, 64, 64, 32), (3, 12, 64, 96, 160), (2, 8, 128, 64, 128),
+    # round 6: grids that fill the machine with 512 x 128 tiles (the plan's ping-pong kernel with the 512-pixel tile): the VAE encoder's 256^2 level,
+    # and a ragged one (1000 image rows: no multiple of the tile's 16, tiles straddle images, a partial filter tile, H != W)
+    (4, 256, 256, 128, 128), (5, 200, 128, 64, 160),
 ]
 
 
@@ -51,6 +54,32 @@ def test_conv3x3_matches_float32_accumulated_reference(shape, epilogue):
     err = (y.float() - ref).abs().max().item()
     assert err <= 2 ** -10 * ref.abs().max().item() + 1e-6, (err, ref.abs().max().item())
     assert torch.equal(y, conv_mfma.conv3x3(x, conv_mfma.pack_weight(w), bias, res))       # fixed reduction order
+
+
+@pytest.mark.parametrize("cfg", [13, 14])
+@pytest.mark.parametrize("shape", [(1, 20, 64, 64, 32), (3, 12, 64, 96, 160), (2, 8, 128, 64, 128), (1, 32, 32, 512, 512), (2, 40, 32, 32, 64)])
+def test_conv3x3_ping_pong_tiles_forced(shape, cfg, monkeypatch):
+    """The two ping-pong direct kernels (256- and 512-pixel tiles, csrc/conv_mfma.hip cfg 13 / 14) FORCED onto small and ragged shapes the plan
+    would give to other kernels: one channel chunk, fewer filters than a tile, rows that are no multiple of the tile's, tiles that straddle
+    images, most of a 512-pixel tile past the tensor's end."""
+    _need_gpu()
+    from dreammesh4d_amd import conv_mfma
+
+    N, H, W, Ci, Co = shape
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(Ci + Co + H + cfg)
+    x = torch.randn(N, Ci, H, W, generator=g).to(dev).half().contiguous(memory_format=torch.channels_last)
+    w = (torch.randn(Co, Ci, 3, 3, generator=g) * (9 * Ci) ** -0.5).to(dev).half()
+    bias = torch.randn(Co, generator=g).to(dev).half()
+    res = torch.randn(N, Co, H, W, generator=g).to(dev).half().contiguous(memory_format=torch.channels_last)
+    monkeypatch.setenv("DM4D_CONV_CFG", str(cfg))
+    monkeypatch.setenv("DM4D_CONV_SPLITS", "1")
+    y = conv_mfma.conv3x3(x, conv_mfma.pack_weight(w), bias, res)
+    ref = _ref(x, w, bias, res)
+    err = (y.float() - ref).abs().max().item()
+    assert err <= 2 ** -10 * ref.abs().max().item() + 1e-6, (err, ref.abs().max().item())
+    monkeypatch.setenv("DM4D_CONV_CFG", "7")          # the lock-step direct kernel: the same tile algebra and k order -> the same bits
+    assert torch.equal(y, conv_mfma.conv3x3(x, conv_mfma.pack_weight(w), bias, res))
 
 
 def test_frozen_conv_data_gradient_and_residual_gradient():
