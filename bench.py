@@ -319,9 +319,8 @@ def main():
                 "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
                 "traffic": pmc_traffic(kern, B), "alg_bytes_per_launch": round(alg_bytes), "avg_launch_us": round(leg["avg_s"] * 1e6, 2),
                 "launches_timed": leg["n_launch"], "launches_per_step": round(leg["n_launch"] / leg["steps"], 2),
-                "per": "step: `alg_bytes_per_launch` / `avg_launch_us` / `traffic` are the SUMS over the launches of one step (the views of a step go through "
-                       "`launches_per_step` launches of this kernel, each timed with HIP events on its stream; from round 6 the record gather of one group "
-                       "of views runs on a helper stream BESIDE the next group's launch, so the durations include what that costs this kernel)"}
+                "per": "step: `alg_bytes_per_launch` / `avg_launch_us` / `traffic` are per STEP = per launch (ONE launch of this kernel covers the step's views; "
+                       "timed with HIP events on its stream inside the library)"}
         out = {"value": round(value, 3), "ms_per_step": round(leg["elapsed"] / leg["steps"] * 1e3, 4), "views_per_step_per_gpu": B,
                "mean_duplicates_D": round(D_mean), "whole_view_frac_of_hbm_roofline": round(value / world * b_view / (HBM_PEAK_GBS * 1e9), 5),
                "roofline": roof}
@@ -392,6 +391,13 @@ def main():
             except Exception as e:     # the headline line must not depend on it
                 out["config"]["dynamic_stage_iters_per_sec"] = None
                 out["config"]["dynamic_stage_error"] = repr(e)[:200]
+            # ... and at the partition of the headline step (BASELINE configs[3]: 4 SDS views + the reference view per frame = 20 views per
+            # iteration, UNet batch 32 / VAE encoder batch 16)
+            try:
+                out["config"].update(dynamic_stage_iterations(wl, dev, n=20, sds_views_per_frame=VIEWS_PER_FRAME - 1, key="dynamic_stage_20_units"))
+            except Exception as e:
+                out["config"]["dynamic_stage_20_units_iters_per_sec"] = None
+                out["config"]["dynamic_stage_20_units_error"] = repr(e)[:200]
         if world == 1 and not args.no_iters:
             try:
                 out["config"].update(static_stage_iterations(dev))
@@ -405,8 +411,8 @@ def main():
         dist.destroy_process_group()
 
 
-def dynamic_stage_iterations(wl, dev, n=50):
-    """dynamic-stage iterations/sec at the same scene: 4 frames x (1 reference + 1 SDS view) per iteration, HexPlane
+def dynamic_stage_iterations(wl, dev, n=50, sds_views_per_frame=VIEWS_PER_FRAME_YAML - 1, key="dynamic_stage"):
+    """dynamic-stage iterations/sec at the same scene: 4 frames x (1 reference + `sds_views_per_frame` SDS views) per iteration, HexPlane
     network, render, losses, full-size Zero123 SDS (SD-1.x UNet 860 M + VAE encoder, fp16, RANDOM weights: the
     checkpoint is not in the tree), backward, AdamW over the 35.76 M parameters
     (custom/threestudio-dreammesh4d/system/sugar_4dgen.py:397-429)."""
@@ -425,7 +431,7 @@ def dynamic_stage_iterations(wl, dev, n=50):
 
     stage = DynamicStage(wl.renderer, wl.net, wl.nodes, static, wl.timestamps, ref_img, ref_mask,
                          syn.make_camera(H, W, elev_deg=5.0, azim_deg=0.0), guidance=guid, frames_per_step=FRAMES_PER_STEP,
-                         random_views_per_frame=VIEWS_PER_FRAME_YAML - 1,
+                         random_views_per_frame=sds_views_per_frame,
                          normal_consistency=MeshNormalConsistency(wl.sc["faces"], len(wl.sc["verts"]), dev),
                          arap=ARAPCoach(wl.sc["verts"], wl.sc["faces"], dev), milestone_arap_reg=0)
     # the first iteration runs STRICT: a 3x3 convolution, q/k/v projection, supported attention, GroupNorm / add / GEGLU of the
@@ -444,8 +450,8 @@ def dynamic_stage_iterations(wl, dev, n=50):
         stage.iteration()
     torch.cuda.synchronize(dev)
     dt = time.perf_counter() - t0
-    return {"dynamic_stage_iters_per_sec": round(n / dt, 3), "dynamic_stage_ms_per_iteration": round(1e3 * dt / n, 2),
-            "dynamic_stage_note": "8 views/iteration, full-size Zero123 fp16 with random weights, mesh normal consistency + key-frame ARAP, AdamW step "
+    return {f"{key}_iters_per_sec": round(n / dt, 3), f"{key}_ms_per_iteration": round(1e3 * dt / n, 2),
+            f"{key}_note": f"{FRAMES_PER_STEP * (1 + sds_views_per_frame)} views/iteration (4 frames x (1 reference + {sds_views_per_frame} SDS views)), full-size Zero123 fp16 with random weights, mesh normal consistency + key-frame ARAP, AdamW step "
                                   "(the reference's effective betas (0.9, 0.999), no decay) included; no backward of the normal pass: no loss of the shipped "
                                   "configuration reads the normal image (the headline step above keeps both passes' backward)"}
 

@@ -27,7 +27,7 @@ if "--reg" in sys.argv or os.environ.get("DM4D_ITER_REG"):      # + the regulari
     kw = dict(normal_consistency=MeshNormalConsistency(wl.sc["faces"], len(wl.sc["verts"]), dev), arap=ARAPCoach(wl.sc["verts"], wl.sc["faces"], dev),
               milestone_arap_reg=0)
 stage = DynamicStage(wl.renderer, wl.net, wl.nodes, static, wl.timestamps, ref_img, ref_mask, cam, guidance=guid,
-                     frames_per_step=4, random_views_per_frame=1, **kw)
+                     frames_per_step=4, random_views_per_frame=int(os.environ.get("DM4D_ITER_RND_VIEWS", "1")), **kw)
 for i in range(3):
     out = stage.iteration()
     torch.cuda.synchronize()
@@ -58,4 +58,4 @@ if "--host" in sys.argv:            # time the host spends enqueueing an iterati
     pr.disable(); torch.cuda.synchronize()
     pstats.Stats(pr).sort_stats("tottime").print_stats(28)
 print(json.dumps({"dynamic_stage_iters_per_sec": round(n / dt, 3), "ms_per_iteration": round(1e3 * dt / n, 2),
-                  "views_per_iteration": 8, "zero123": "full size, fp16, random weights"}))
+                  "views_per_iteration": 4 * (1 + int(os.environ.get("DM4D_ITER_RND_VIEWS", "1"))), "zero123": "full size, fp16, random weights"}))
