@@ -439,3 +439,45 @@ def test_bench_scene_one_view_against_two_oracle_passes(mode):
     for k in keys:
         assert float(np.abs(g[k]).max()) > 0, k
     _assert_grads(g, og, keys=tuple(keys), o=[o1, o2])
+
+
+def test_bench_step_every_unit_forward_against_two_oracle_passes():
+    """The headline step of bench.py (BASELINE configs[3]'s per-GPU share: 4 frames x (4 SDS + 1 reference view) = 20 units, 199,980 Gaussians,
+    512 x 512) through the STEP OBJECT, every one of its 20 units against two oracle passes fed the HIP path's own Gaussians: RGB image, normal
+    image, depth, alpha bit-identical, radii and duplicate counts equal.  (Gradients of a unit against the oracle:
+    test_bench_scene_one_view_against_two_oracle_passes; units of the batch against units alone, bit for bit, with their gradients:
+    tests/test_step_gpu.py::test_twenty_unit_step_equals_per_view_and_per_frame_composition.)"""
+    _need_gpu()
+    import bench
+    from dreammesh4d_amd import ops
+    from oracle import raster as orc
+
+    dev = torch.device("cuda:0")
+    wl = bench.Workload(dev, 0, 1)
+    assert wl.views_per_step == 20
+    H, W = bench.H, bench.W
+    out = wl.dstep(wl.frame_t, wl.vm16, wl.pm16, wl.fidx)
+    D = wl.renderer.check()
+    torch.cuda.synchronize()
+    n = lambda t: t.detach().cpu().numpy()
+    col, dep, alp, rad = n(out["color"]), n(out["depth"]), n(out["alpha"]), n(out["radii"])
+    gaussians = {}
+    for u in range(20):
+        f = int(wl.fidx[u])
+        if f not in gaussians:
+            with torch.no_grad():
+                means, rots, normals = ops.face_gaussians(wl.topo, out["vxyz"][f], out["vrot"][f], wl.qs, grad_mode=wl.renderer.grad_mode)
+            gaussians[f] = (n(means), n(rots), n(normals))
+        means, rots, normals = gaussians[f]
+        cam = wl.cams[u]
+        ok = dict(image_height=H, image_width=W, tanfovx=cam.tanfov, tanfovy=cam.tanfov, bg=(1, 1, 1), scale_modifier=1.0,
+                  viewmatrix=cam.viewmatrix, projmatrix=cam.projmatrix, campos=cam.campos)
+        o1, o2 = orc.RasterOracle(**ok), orc.RasterOracle(**ok)
+        o1.forward(means, n(wl.opac).reshape(-1), colors_precomp=n(wl.rgb), scales=n(wl.scales), rotations=rots)
+        o2.forward(means, n(wl.opac).reshape(-1), colors_precomp=normals, scales=n(wl.scales), rotations=rots)
+        assert o1.D == D[u] == o2.D, u
+        assert np.array_equal(rad[u], o1.s["radii"]), u
+        assert np.array_equal(col[u, :3].view(np.uint32), o1.s["out_color"].view(np.uint32)), u
+        assert np.array_equal(col[u, 3:].view(np.uint32), o2.s["out_color"].view(np.uint32)), u
+        assert np.array_equal(dep[u, 0].view(np.uint32), o1.s["out_depth"].view(np.uint32)), u
+        assert np.array_equal(alp[u, 0].view(np.uint32), o1.s["out_alpha"].view(np.uint32)), u
