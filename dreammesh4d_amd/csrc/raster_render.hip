@@ -670,7 +670,11 @@ __device__ __forceinline__ void render_bwd_cells(const BatchDesc &d, const uint3
     const int gx = lp.px >> 2, gy = lp.py >> 2;      // the row's cell, in cells from the image origin (as cellinfo counts)
     // entries the forward never reached get all-zero records, so that B2 can sum every Gaussian's contiguous record
     // block without looking anything up
+#if defined(DM4D_BWD_PROBE) && (DM4D_BWD_PROBE & 256)    // TIMING PROBE: no zero records for the entries the forward never reached
+    for (uint32_t j = nr; j < nr; j += 16u) {
+#else
     for (uint32_t j = nd + (uint32_t)li; j < nr; j += 16u) {
+#endif
         const uint32_t slot = entry_slot(list[j], g, gx, gy);
         if (slot < rec_cap) {
             float4 *dst = reinterpret_cast<float4 *>(rec + (size_t)slot * RSP);
@@ -729,7 +733,11 @@ __device__ __forceinline__ void render_bwd_wide_cells(const BatchDesc &d, const 
         const uint32_t nr = g.ccount[cellid], nd = min(g.cdone[cellid], nr);
         const uint32_t *__restrict__ list = b.clist + (size_t)cell * b.cap + s;
         const int gx = cxi >> 2, gy = cyi >> 2;
+#if defined(DM4D_BWD_PROBE) && (DM4D_BWD_PROBE & 256)
+        for (uint32_t j = nr; j < nr; j += 64u) {
+#else
         for (uint32_t j = nd + (uint32_t)lane; j < nr; j += 64u) {     // zero records for the unconsumed entries
+#endif
             const uint32_t slot = entry_slot(list[j], g, gx, gy);
             if (slot < rec_cap) {
                 float4 *dst = reinterpret_cast<float4 *>(rec + (size_t)slot * RSP);
