@@ -176,3 +176,22 @@ def test_stage_loss_weights_come_from_the_config_block():
     assert set(LAMBDA) == {"sds_zero123", "rgb", "mask", "normal_consistency", "arap_reg_key_frame", "arap_reg_inter_frame"}
     with pytest.raises(NotImplementedError):
         StaticStage.from_cfg({"loss": {"lambda_normal_smooth": 1.0}}, None, None, None, None, 8, 8)
+
+
+def test_bench_partition_is_the_one_baseline_configs_3_names():
+    """bench.py's headline step = BASELINE.json configs[3]'s per-GPU share (rank r takes frames {4r .. 4r+3} x 4 views plus their 4
+    reference views = 20 units); the shipped YAML's own iteration (4 frames x (1 SDS + 1 reference view), configs/sugar_dynamic_dg.yaml:9-11,24) is
+    the step timed beside it."""
+    import json
+    import os
+
+    import bench
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cfg3 = json.load(open(os.path.join(root, "BASELINE.json")))["configs"][3]
+    assert "32 frames" in cfg3 and "4 views" in cfg3 and "8 MI355X" in cfg3 and "200k" in cfg3
+    assert bench.N_FRAMES == 32 and bench.FRAMES_PER_STEP == 32 // 8
+    assert bench.VIEWS_PER_FRAME == 4 + 1 and bench.FRAMES_PER_STEP * bench.VIEWS_PER_FRAME == 20
+    assert bench.VIEWS_PER_FRAME_YAML == 2 and bench.N_FACES * 6 == 200_004
+    a = bench.parse.__wrapped__() if hasattr(bench.parse, "__wrapped__") else None      # (argparse reads sys.argv: defaults only)
+    assert a is None or a.views_per_frame == 5
