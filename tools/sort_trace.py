@@ -5,7 +5,7 @@ sys.path.insert(0, os.environ.get('GRAFT_REPO_ROOT', '/root/repo'))
 import bench
 from dreammesh4d_amd import _lib
 dev = torch.device('cuda:0')
-wl = bench.Workload(dev, 0, 1)
+wl = bench.Workload(dev, 0, 1, views_per_frame=2)
 for _ in range(3):
     wl.step()
 torch.cuda.synchronize()
